@@ -1,0 +1,33 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'oracle')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def golden():
+    import torch
+
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            cache[name] = torch.load(os.path.join(GOLDEN, name), weights_only=False)
+        return cache[name]
+
+    return load
+
+
+def sd_f32(sd):
+    return {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()}

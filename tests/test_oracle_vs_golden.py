@@ -1,0 +1,104 @@
+"""CPU: pins oracle/muse_oracle.py (the restatement) against golden vectors produced by the
+UNMODIFIED reference (oracle/make_golden.py).  Integer outputs bit-exact; fp32 outputs to 2e-5
+relative-to-scale (same math, different op grouping)."""
+import torch
+
+import muse_oracle as O
+from conftest import sd_f32
+
+
+def close(a, b, tol=2e-5):
+    scale = max(1.0, b.abs().max().item())
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale, f'max err {err} scale {scale}'
+
+
+def test_ops_match_reference(golden):
+    g = golden('transformer_tiny.pt')
+    sd, op = sd_f32(g['sd']), g['op']
+    p = 'transformer_blocks.layers.0.'
+    close(O.layer_norm(op['x'], sd[p + '0.norm.gamma'], sd[p + '0.norm.beta']), op['ln'])
+    close(O.attention(op['x'], sd, p + '0.', 8), op['self_attn'])
+    close(O.attention(op['x'], sd, p + '1.', 8, context=op['ctx'], context_mask=op['cmask']), op['cross_attn'])
+    close(O.feed_forward(op['x'], sd, p + '2.'), op['ff'])
+
+
+def test_attend_math_equals_flash_branch(golden):
+    op = golden('transformer_tiny.pt')['op']
+    out = O.attend(op['q'], op['k'], op['v'], mask=op['m4'])
+    close(out, op['attend_math'], 1e-6)
+    # the default flash=True branch (third-party tiled softmax, restated) agrees with the in-tree math branch
+    close(op['attend_flash'], op['attend_math'], 1e-5)
+
+
+def test_transformer_forward_matches_reference(golden):
+    g = golden('transformer_tiny.pt')
+    sd = sd_f32(g['sd'])
+    cfg = dict(depth=g['cfg']['depth'], heads=g['cfg']['heads'])
+    lc, emb = O.transformer_forward(sd, cfg, g['ids'], g['text_embeds'], 0., return_embed=True)
+    ln = O.transformer_forward(sd, cfg, g['ids'], g['text_embeds'], 1.)
+    close(lc, g['logits_cond']); close(emb, g['embed']); close(ln, g['logits_null'])
+    close(O.forward_with_cond_scale(sd, cfg, g['ids'], g['text_embeds'], 3.), g['logits_scaled'])
+
+
+def test_schedule_matches_reference(golden):
+    for (T, n), cnt in golden('schedule.pt').items():
+        assert O.mask_counts(T, n) == cnt
+    assert O.mask_counts(18, 256) == [256, 254, 251, 246, 238, 229, 217, 204, 189, 172, 154, 134, 114, 92, 70, 47, 23, 1]
+
+
+def test_sampling_helpers_match_reference(golden):
+    g = golden('sampling_v8192.pt')
+    lg = g['logits']
+    assert not O.threshold_ties(lg).any()
+    filt = O.top_k_filter(lg, 0.9)
+    assert torch.equal(torch.isinf(filt), g['filtered_isinf'])
+    u05, u0 = g['uniform']
+    assert torch.equal(O.gumbel_sample(filt, O.gumbel_from_uniform(u05), 0.5), g['pred_T05'])
+    assert torch.equal(O.gumbel_sample(filt, O.gumbel_from_uniform(u0), 0.), g['pred_T0'])
+
+
+def _replay(golden, name):
+    g, t = golden(name), golden('transformer_tiny.pt')
+    T = g['timesteps']
+    logits_by_step = g['step_logits']
+    sd = sd_f32(t['sd'])
+    cfg = dict(depth=t['cfg']['depth'], heads=t['cfg']['heads'])
+
+    def demask(ids, step):
+        if logits_by_step is not None:
+            # the re-mask scatter must have produced the ids the reference fed its transformer
+            assert torch.equal(ids, g['step_ids'][step]), f'masked ids differ at step {step}'
+            return logits_by_step[step]
+        return O.forward_with_cond_scale(sd, cfg, ids, t['text_embeds'], 3.)
+
+    trace = []
+    ids = O.generate_ids(demask, 2, 64, t['mask_id'], lambda s, shp: O.gumbel_from_uniform(g['uniform'][s]),
+                         timesteps=T, trace=trace)
+    return g, ids, trace
+
+
+def test_generate_replay_T4_bit_exact(golden):
+    g, ids, trace = _replay(golden, 'generate_tiny_T4.pt')
+    assert not any(tr['tie'].any() for tr in trace), 'golden has a boundary tie; regenerate with another seed'
+    assert torch.equal(ids.reshape(2, 8, 8), g['final_ids'])
+
+
+def test_generate_replay_T18_end_to_end(golden):
+    """No recorded logits: the restated transformer drives the loop; ids must still be bit-exact
+    (peaky golden weights keep every argmax / top-k margin far above fp32 reassociation noise)."""
+    g, ids, trace = _replay(golden, 'generate_tiny_T18.pt')
+    for tr_, ref_ids in zip(trace, g['step_ids']):
+        assert torch.equal(tr_['masked_ids'], ref_ids), f"step {tr_['step']}"
+    assert torch.equal(ids.reshape(2, 8, 8), g['final_ids'])
+
+
+def test_vae_matches_reference(golden):
+    g = golden('vae_tiny.pt')
+    sd = sd_f32(g['sd'])
+    close(O.vae_decode_from_ids(sd, g['ids']), g['decoded'])
+    fmap, ids = O.vae_encode(sd, g['image'])
+    assert torch.equal(ids, g['enc_ids'])
+    close(fmap, g['enc_fmap'])
+    gt = golden('generate_tiny_T4.pt')
+    close(O.vae_decode_from_ids(sd, gt['final_ids']), gt['images'])
