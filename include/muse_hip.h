@@ -1,0 +1,232 @@
+/* muse_hip.h -- C ABI of libmuse_hip.so: the MI355X (gfx950) hot path of lucidrains/muse-maskgit-pytorch.
+ *
+ * The reference has no FFI / plugin seam of its own (it is pure PyTorch); the drop-in boundary is its Python
+ * class surface (muse_maskgit_pytorch/__init__.py:1-4) and, one level down, the Attend(q, k, v, mask) operator
+ * (attend.py:109).  Each entry point below names the reference code it replaces (file:line relative to
+ * /root/reference/muse_maskgit_pytorch/).  The reference-side binding is a ctypes stub: see INTEGRATION.md.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++ / torch types.  Every function returns int: MM_OK (0) or a
+ *     negative MM_ERR_* code; mm_last_error() returns the calling thread's last message.  Nothing throws or
+ *     aborts across the ABI.
+ *   - All tensor pointers are CALLER-OWNED DEVICE pointers (the host framework allocates; this library never
+ *     frees them).  Scratch memory is a caller-provided workspace sized by the matching *_workspace_bytes().
+ *   - Every launch goes to the explicit `stream` (a hipStream_t); no hidden synchronisation, no default-stream
+ *     use.  Handles are immutable after create: share them across threads, one in-flight call per
+ *     (handle, workspace).
+ *   - dtypes: token ids / mask indices int64 (torch.long, mmp.py:519); scores / logits fp32; activations and
+ *     Linear / conv / embedding weights bf16 (raw uint16 bits); norm gains, biases, scales, null_kv fp32;
+ *     masks uint8 (1 = keep).
+ */
+#ifndef MUSE_HIP_H
+#define MUSE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MM_ABI_VERSION 1
+
+#define MM_OK 0
+#define MM_ERR_SHAPE (-1)
+#define MM_ERR_DTYPE (-2)
+#define MM_ERR_ALIGN (-3)
+#define MM_ERR_ARCH (-4)
+#define MM_ERR_HIP (-5)
+#define MM_ERR_WORKSPACE (-6)
+#define MM_ERR_UNSUPPORTED (-7)
+
+#define MM_NOISE_NONE 0     /* plain argmax of logits / temperature                                        */
+#define MM_NOISE_GUMBEL 1   /* caller supplies -log(-log(u)) per (token, vocab) -- bit-exact parity mode     */
+#define MM_NOISE_UNIFORM 2  /* caller supplies u; the kernel applies mmp.py:403-408                          */
+#define MM_NOISE_PHILOX 3   /* on-device Philox4x32-10 keyed by (seed, global token row, step, vocab/4)      */
+
+typedef void* mm_stream_t;  /* hipStream_t */
+
+int mm_abi_version(void);
+const char* mm_last_error(void);
+/* MM_OK iff the current HIP device is gfx950; MM_ERR_ARCH otherwise (product path refuses to run elsewhere). */
+int mm_device_check(void);
+
+/* ------------------------------------------------------------------------------------------------ operators */
+
+/* nn.Linear(bias=False): out[m][n] = sum_k x[m][k] * w[n][k]            (mmp.py:85,88,118-124,225,233)
+ * x bf16 [M][ldx], w bf16 [N][ldw], K % 64 == 0 (zero-pad), ldx/ldw % 8 == 0.
+ * out_f32 != 0: out is fp32 [M][ldc] else bf16.  resid_f32 (optional, fp32 [M][ldc], may alias out when
+ * out_f32) is added in the epilogue: the residual adds of TransformerBlocks.forward (mmp.py:189-193). */
+int mm_gemm_bf16(mm_stream_t stream, const void* x, int64_t ldx, const void* w, int64_t ldw, int M, int N, int K,
+                 void* out, int64_t ldc, int out_f32, const float* resid_f32);
+
+/* to_logits + classifier-free guidance in one pass:
+ *   out[m][n] = null + (cond - null) * cond_scale,  cond = x_cond[m].w[n], null = x_null[m].w[n]
+ * (mmp.py:250-254 + 332).  out fp32 [M][ldc]. */
+int mm_gemm_cfg_logits(mm_stream_t stream, const void* x_cond, const void* x_null, int64_t ldx, const void* w,
+                       int64_t ldw, int M, int N, int K, float* out, int64_t ldc, float cond_scale);
+
+/* x[row] = token_emb[ids[row]] + pos_emb[row % n]  (mmp.py:322-323); tables bf16, x fp32 [rows][dim]. */
+int mm_embed(mm_stream_t stream, const int64_t* ids, int rows, int n, const void* token_emb, int vocab_rows,
+             const void* pos_emb, int dim, float* x);
+
+/* LayerNorm (mmp.py:63-70): fp32 in, bf16 out, eps 1e-5; beta may be NULL (it is a zero buffer in the reference).
+ * row_index (optional int32 [rows]) gathers source rows. */
+int mm_layernorm(mm_stream_t stream, const float* x, int64_t ldx, int rows, int dim, const float* gamma,
+                 const float* beta, const int32_t* row_index, void* out, int64_t ldo);
+
+/* GEGLU + LayerNorm(inner) (mmp.py:72-77, 86-87): h bf16 [rows][2*Fp] = [x half | gate half]; out bf16 [rows][Fp]
+ * with columns >= F zero. */
+int mm_geglu_ln(mm_stream_t stream, const void* h, int64_t ldh, int rows, int F, int Fp, const float* gamma,
+                const float* beta, void* out, int64_t ldo);
+
+/* The Attend seam (attend.py:109-140): softmax(scale * q k^T, key mask) v.  dim_head must be 64.
+ * Element strides (batch, head, token) per operand, d contiguous.  nk = number of keys.
+ * normalize != 0 additionally fuses mmp.py:145-153: q,k are L2-normalised and scaled by q_scale/k_scale [64]
+ * in-kernel and a learned null key/value (null_k/null_v fp32 [heads][64], raw parameters) is prepended.
+ * key_mask: optional uint8 [B][nk] (1 = keep), row stride km_sb. */
+int mm_attend(mm_stream_t stream, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const void* k,
+              int64_t k_sb, int64_t k_sh, int64_t k_sn, const void* v, int64_t v_sb, int64_t v_sh, int64_t v_sn,
+              void* out, int64_t o_sb, int64_t o_sh, int64_t o_sn, int B, int H, int nq, int nk,
+              const uint8_t* key_mask, int64_t km_sb, int normalize, const float* q_scale, const float* k_scale,
+              const float* null_k, const float* null_v, float scale);
+
+/* Re-mask step (mmp.py:558-563): per sample the k highest scores (ties: lower index) get ids = mask_id; every
+ * other slot's score becomes -1e5 (what mmp.py:609 leaves there).  rows_out (optional int32 [B*k]) receives the
+ * flat positions b*n + pos of the masked tokens, ascending per sample. */
+int mm_mask_step(mm_stream_t stream, float* scores, int64_t* ids, int B, int n, int k, int64_t mask_id,
+                 int32_t* rows_out);
+
+/* top-k filter + Gumbel argmax + confidence (mmp.py:576-580, 603-606, 403-418) on R rows of CFG-combined fp32
+ * logits [R][ld].  rows (optional) gives each row's flat token position (default: r).  Results are scattered:
+ * ids[pos] = pred, scores[pos] = 1 - softmax(logits)[pred]; pred_out / score_out (optional) are compact [R].
+ * temperature must already be max(T, 1e-10) (mmp.py:411).  Noise (GUMBEL/UNIFORM) is indexed by flat token
+ * position: noise[pos * noise_ld + v]. */
+int mm_sample_rows(mm_stream_t stream, const float* logits, int64_t ld, int R, int V, int k_keep,
+                   const int32_t* rows, float temperature, int noise_kind, const float* noise, int64_t noise_ld,
+                   uint64_t seed, uint64_t row_offset, uint32_t step, int64_t* ids, float* scores,
+                   int64_t* pred_out, float* score_out);
+
+/* The uniforms MM_NOISE_PHILOX draws for rows [row_offset, row_offset + rows) at `step`: out fp32 [rows][V]. */
+int mm_philox_uniform(mm_stream_t stream, uint64_t seed, uint64_t row_offset, uint32_t step, int rows, int V,
+                      float* out);
+
+/* ---- VQGanVAE operators, activations NHWC bf16 (vqgan_vae.py:223-281, 422-441) */
+
+/* Implicit-GEMM convolution.  in bf16 [B][Hin][Win][Cin] (Cin % 8 == 0); w bf16 [Cout][Kp], k = (ty*TW+tx)*Cin+ci,
+ * Kp = TH*TW*Cin rounded up to 64 (zero padded).  Virtual output grid Hv x Wv per image; input pixel of tap
+ * (ty,tx) = (y*stride + ty + off_y, x*stride + tx + off_x), zero outside.  Output pixel (y*os+py, x*os+px) of an
+ * Hout x Wout image -> ConvTranspose2d(4,2,1) is four calls with os=2.  Epilogue: + bias[Cout],
+ * LeakyReLU(0.1) if act, + resid (bf16, same shape as out).  out_nchw_f32 != 0 writes fp32 [B][Cout][Hout][Wout]. */
+int mm_conv2d_nhwc(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
+                   int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
+                   int Hout, int Wout, const float* bias, int act, const void* resid, void* out, int out_nchw_f32);
+
+int mm_glu_nhwc(mm_stream_t stream, const void* x, int64_t rows, int C, void* out);            /* nn.GLU(dim=1)    */
+int mm_groupnorm_nhwc(mm_stream_t stream, const void* x, int B, int HW, int C, int groups, const float* gamma,
+                      const float* beta, int act, float* stats_ws /* [B*groups*2] */, void* out); /* nn.GroupNorm */
+/* LFQ.indices_to_codes + project_out (vqgan_vae.py:430-432): ids int64 [count] -> bf16 [count][C];
+ * w fp32 [C][bits], b fp32 [C]; w == NULL means no projection (C == bits). */
+int mm_lfq_decode(mm_stream_t stream, const int64_t* ids, int64_t count, int bits, int C, const float* w,
+                  const float* b, void* out);
+/* LFQ.forward in eval mode (vqgan_vae.py:424): x bf16 [count][C] -> ids int64 [count], out bf16 [count][C]. */
+int mm_lfq_encode(mm_stream_t stream, const void* x, int64_t count, int C, int bits, const float* w_in,
+                  const float* b_in, const float* w_out, const float* b_out, int64_t* ids, void* out);
+int mm_nchw_f32_to_nhwc8_bf16(mm_stream_t stream, const float* img, int B, int C, int H, int W, void* out);
+int mm_nhwc_bf16_to_nchw_f32(mm_stream_t stream, const void* x, int B, int C, int H, int W, float* out);
+
+/* ------------------------------------------------------------------------------------------------ transformer */
+
+typedef struct mm_attn_weights {
+    const float* ln_gamma;   /* norm.gamma [D]                                                            */
+    const float* ln_beta;    /* norm.beta  [D] (zero buffer; may be NULL)                                  */
+    const void* w_q;         /* bf16 [I][D]   to_q.weight                                                  */
+    const void* w_kv;        /* bf16 [2I][D]  to_kv.weight; self-attn: pack q|kv contiguously (w_kv == w_q + I*D) */
+    const void* w_out;       /* bf16 [D][I]   to_out.weight                                                */
+    const float* null_k;     /* fp32 [H][64]  null_kv[0]                                                   */
+    const float* null_v;     /* fp32 [H][64]  null_kv[1]                                                   */
+    const float* q_scale;    /* fp32 [64]                                                                  */
+    const float* k_scale;    /* fp32 [64]                                                                  */
+} mm_attn_weights;
+
+typedef struct mm_ff_weights {
+    const float* ln1_gamma;  /* [D]   */
+    const float* ln1_beta;
+    const void* w1;          /* bf16 [2*Fp][D]: rows [0,F) gelu half, rows [Fp,Fp+F) gate half, other rows zero */
+    const float* ln2_gamma;  /* [F]   */
+    const float* ln2_beta;
+    const void* w2;          /* bf16 [D][Fp], columns >= F zero                                            */
+} mm_ff_weights;
+
+typedef struct mm_layer_weights {
+    mm_attn_weights self_attn;
+    mm_attn_weights cross_attn;
+    mm_ff_weights ff;
+} mm_layer_weights;
+
+typedef struct mm_transformer_desc {
+    int32_t dim, depth, heads, dim_head, ff_inner, ff_inner_padded;
+    int32_t seq_len, num_tokens, vocab_rows, dim_out, text_dim, self_cond;
+    const void* token_emb;          /* bf16 [vocab_rows][D]  (vocab_rows = num_tokens + 1 with the mask id)  */
+    const void* pos_emb;            /* bf16 [seq_len][D]                                                     */
+    const void* text_proj;          /* bf16 [D][text_dim] or NULL = nn.Identity (mmp.py:233)                 */
+    const mm_layer_weights* layers; /* host array [depth]                                                    */
+    const float* final_gamma;       /* transformer_blocks.norm                                               */
+    const float* final_beta;
+    const void* to_logits;          /* bf16 [dim_out][D]                                                     */
+    mm_ff_weights self_cond_ff;     /* self_cond_to_init_embed (used only when self_cond != 0)               */
+} mm_transformer_desc;
+
+typedef struct mm_transformer mm_transformer_t;
+
+int mm_transformer_create(const mm_transformer_desc* desc, mm_transformer_t** out);
+void mm_transformer_destroy(mm_transformer_t* model);
+
+/* Context of Transformer.forward (mmp.py:302-318): ctx bf16 [B][m][D] (m = L + nc), key_mask uint8 [B][m].
+ * text_embeds fp32 [B][L][text_dim] zero-padded (t5.py:93); cond_ids (optional) int64 [B][nc].
+ * drop_text != 0 builds the classifier-free "null" mask (text keys off, cond-id keys on). */
+size_t mm_context_workspace_bytes(const mm_transformer_t* model, int B, int L);
+int mm_transformer_context(const mm_transformer_t* model, mm_stream_t stream, const float* text_embeds, int B,
+                           int L, const int64_t* cond_ids, int nc, int drop_text, void* ctx, uint8_t* key_mask,
+                           void* workspace, size_t workspace_bytes);
+
+/* Transformer.forward without the loss branch (mmp.py:322-335): ids int64 [B][n]; ctx / key_mask as above;
+ * self_cond_embed optional fp32 [B*n][D].  Outputs (each optional): embed bf16 [B*n][D] (the final LayerNorm
+ * output), logits fp32 [B*n][dim_out]. */
+size_t mm_transformer_workspace_bytes(const mm_transformer_t* model, int B, int n, int m);
+int mm_transformer_forward(const mm_transformer_t* model, mm_stream_t stream, const int64_t* ids, int B, int n,
+                           const void* ctx, const uint8_t* key_mask, int m, const float* self_cond_embed,
+                           void* embed_out, float* logits_out, void* workspace, size_t workspace_bytes);
+
+/* MaskGit.generate's decode loop (mmp.py:519-615), whole loop on `stream` with no host synchronisation:
+ * CFG double pass batched as 2B sequences, cross-attention K/V of the context computed once, logits and
+ * sampling only at the currently masked rows.  Host supplies the per-step schedule computed with the
+ * reference's own arithmetic (mask_counts[t] = max(int(cos(t*pi/2)*n), 1), temperatures[t] = max(T0*(steps
+ * left)/T, 1e-10)).  noise (GUMBEL/UNIFORM modes): fp32 [timesteps][B][n][V].  Outputs: ids int64 [B][n],
+ * scores fp32 [B][n].  Optional traces [timesteps][B][n]: trace_masked_ids (ids after the re-mask scatter),
+ * trace_ids / trace_scores (state after each step). */
+typedef struct mm_generate_params {
+    int32_t batch, n, timesteps, k_keep, noise_kind, nc, L, reserved;
+    float cond_scale;
+    float pad0;
+    uint64_t seed, row_offset;
+    const int32_t* mask_counts;     /* host [timesteps] */
+    const float* temperatures;      /* host [timesteps] */
+    const float* text_embeds;       /* device fp32 [B][L][text_dim] */
+    const int64_t* cond_ids;        /* device int64 [B][nc] or NULL */
+    const float* noise;             /* device or NULL */
+    int64_t* ids;                   /* device out */
+    float* scores;                  /* device out */
+    int64_t* trace_masked_ids;
+    int64_t* trace_ids;
+    float* trace_scores;
+} mm_generate_params;
+
+size_t mm_generate_workspace_bytes(const mm_transformer_t* model, int B, int n, int L, int nc);
+int mm_generate(const mm_transformer_t* model, mm_stream_t stream, const mm_generate_params* params,
+                void* workspace, size_t workspace_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUSE_HIP_H */

@@ -1,0 +1,139 @@
+"""ctypes binding of libmuse_hip.so (C ABI: include/muse_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, this raises.
+torch is used only for device memory (tensor.data_ptr()) and the current HIP stream.
+"""
+import ctypes as C
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libmuse_hip.so')
+HEADER_PATH = os.path.join(HERE, '..', 'include', 'muse_hip.h')
+
+MM_OK = 0
+MM_NOISE_NONE, MM_NOISE_GUMBEL, MM_NOISE_UNIFORM, MM_NOISE_PHILOX = 0, 1, 2, 3
+
+c_i64, c_int, c_f32, c_vp, c_u64, c_u32, c_sz = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_uint64, C.c_uint32, C.c_size_t
+
+
+class MuseHipError(RuntimeError):
+    pass
+
+
+class AttnWeights(C.Structure):
+    _fields_ = [(n, c_vp) for n in ('ln_gamma', 'ln_beta', 'w_q', 'w_kv', 'w_out', 'null_k', 'null_v', 'q_scale', 'k_scale')]
+
+
+class FFWeights(C.Structure):
+    _fields_ = [(n, c_vp) for n in ('ln1_gamma', 'ln1_beta', 'w1', 'ln2_gamma', 'ln2_beta', 'w2')]
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [('self_attn', AttnWeights), ('cross_attn', AttnWeights), ('ff', FFWeights)]
+
+
+class TransformerDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('dim', 'depth', 'heads', 'dim_head', 'ff_inner', 'ff_inner_padded', 'seq_len',
+                                         'num_tokens', 'vocab_rows', 'dim_out', 'text_dim', 'self_cond')] + \
+               [('token_emb', c_vp), ('pos_emb', c_vp), ('text_proj', c_vp), ('layers', C.POINTER(LayerWeights)),
+                ('final_gamma', c_vp), ('final_beta', c_vp), ('to_logits', c_vp), ('self_cond_ff', FFWeights)]
+
+
+class GenerateParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('batch', 'n', 'timesteps', 'k_keep', 'noise_kind', 'nc', 'L', 'reserved')] + \
+               [('cond_scale', c_f32), ('pad0', c_f32), ('seed', c_u64), ('row_offset', c_u64),
+                ('mask_counts', C.POINTER(C.c_int32)), ('temperatures', C.POINTER(c_f32)),
+                ('text_embeds', c_vp), ('cond_ids', c_vp), ('noise', c_vp), ('ids', c_vp), ('scores', c_vp),
+                ('trace_masked_ids', c_vp), ('trace_ids', c_vp), ('trace_scores', c_vp)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/muse_hip.h must appear here (tests check both ways)
+SIGNATURES = {
+    'mm_abi_version': (c_int, []),
+    'mm_last_error': (C.c_char_p, []),
+    'mm_device_check': (c_int, []),
+    'mm_gemm_bf16': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_int, c_vp]),
+    'mm_gemm_cfg_logits': (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_f32]),
+    'mm_embed': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp]),
+    'mm_layernorm': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_i64]),
+    'mm_geglu_ln': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_i64]),
+    'mm_attend': (c_int, [c_vp] + [c_vp, c_i64, c_i64, c_i64] * 4 + [c_int, c_int, c_int, c_int, c_vp, c_i64, c_int,
+                                                                  c_vp, c_vp, c_vp, c_vp, c_f32]),
+    'mm_mask_step': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_i64, c_vp]),
+    'mm_sample_rows': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_f32, c_int, c_vp, c_i64, c_u64, c_u64,
+                               c_u32, c_vp, c_vp, c_vp, c_vp]),
+    'mm_philox_uniform': (c_int, [c_vp, c_u64, c_u64, c_u32, c_int, c_int, c_vp]),
+    'mm_conv2d_nhwc': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int] + [c_int] * 12 + [c_vp, c_int, c_vp, c_vp, c_int]),
+    'mm_glu_nhwc': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp]),
+    'mm_groupnorm_nhwc': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
+    'mm_lfq_decode': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
+    'mm_lfq_encode': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'mm_nchw_f32_to_nhwc8_bf16': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    'mm_nhwc_bf16_to_nchw_f32': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    'mm_transformer_create': (c_int, [C.POINTER(TransformerDesc), C.POINTER(c_vp)]),
+    'mm_transformer_destroy': (None, [c_vp]),
+    'mm_context_workspace_bytes': (c_sz, [c_vp, c_int, c_int]),
+    'mm_transformer_context': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_sz]),
+    'mm_transformer_workspace_bytes': (c_sz, [c_vp, c_int, c_int, c_int]),
+    'mm_transformer_forward': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_sz]),
+    'mm_generate_workspace_bytes': (c_sz, [c_vp, c_int, c_int, c_int, c_int]),
+    'mm_generate': (c_int, [c_vp, c_vp, C.POINTER(GenerateParams), c_vp, c_sz]),
+}
+
+_lib = None
+
+
+def header_symbols():
+    """Function names declared in include/muse_hip.h."""
+    with open(HEADER_PATH) as f:
+        text = re.sub(r'/\*.*?\*/', '', f.read(), flags=re.S)
+    return sorted(set(re.findall(r'\b(mm_[a-z0-9_]+)\s*\(', text)))
+
+
+def lib():
+    """Loads libmuse_hip.so (once).  No fallback: a missing library is an error."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MuseHipError(f'{LIB_PATH} not found: build it with `python -m muse_maskgit_pytorch_amd.build` '
+                               '(hipcc, gfx950).  There is no CPU / eager fallback in this package.')
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        if l.mm_abi_version() != 1:
+            raise MuseHipError('libmuse_hip ABI version mismatch')
+        _lib = l
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != MM_OK:
+        msg = lib().mm_last_error()
+        raise MuseHipError(f'{what} failed ({rc}): {msg.decode() if msg else ""}')
+
+
+def stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+_device_ok = False
+
+
+def require_device():
+    """Fail loudly unless a gfx950 device is current."""
+    global _device_ok
+    if not _device_ok:
+        import torch
+        if not torch.cuda.is_available():
+            raise MuseHipError('no HIP device visible: the muse_maskgit_pytorch_amd hot path only runs on MI355X (gfx950)')
+        check(lib().mm_device_check(), 'mm_device_check')
+        _device_ok = True

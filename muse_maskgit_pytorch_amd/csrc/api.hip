@@ -1,0 +1,219 @@
+// C-ABI layer: argument validation + error plumbing around the kernel launchers.  See include/muse_hip.h.
+#include <stdio.h>
+#include <string.h>
+
+#include "muse_hip_internal.h"
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+int mm_set_error(int code, const char* msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg ? msg : "");
+    return code;
+}
+
+int mm_set_hip_error(hipError_t e, const char* where) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", where ? where : "hip", hipGetErrorString(e));
+    return MM_ERR_HIP;
+}
+
+int mm_check_launch(const char* kernel) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return mm_set_hip_error(e, kernel);
+    return MM_OK;
+}
+
+#define CHK_PTR(p, name) \
+    if (!(p)) return mm_set_error(MM_ERR_SHAPE, name " is NULL")
+#define CHK_ALIGN16(p, name) \
+    if (((uintptr_t)(p)) & 15) return mm_set_error(MM_ERR_ALIGN, name " must be 16-byte aligned")
+
+extern "C" {
+
+int mm_abi_version(void) { return MM_ABI_VERSION; }
+const char* mm_last_error(void) { return g_err; }
+
+int mm_device_check(void) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return mm_set_hip_error(e, "hipGetDevice");
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return mm_set_hip_error(e, "hipGetDeviceProperties");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        snprintf(g_err, sizeof(g_err), "libmuse_hip is built for gfx950 (MI355X); current device is %s", prop.gcnArchName);
+        return MM_ERR_ARCH;
+    }
+    return MM_OK;
+}
+
+int mm_gemm_bf16(mm_stream_t stream, const void* x, int64_t ldx, const void* w, int64_t ldw, int M, int N, int K,
+                 void* out, int64_t ldc, int out_f32, const float* resid_f32) {
+    if (M == 0 || N == 0) return MM_OK;
+    CHK_PTR(x, "x"); CHK_PTR(w, "w"); CHK_PTR(out, "out");
+    CHK_ALIGN16(x, "x"); CHK_ALIGN16(w, "w"); CHK_ALIGN16(out, "out");
+    if (M < 0 || N < 0) return mm_set_error(MM_ERR_SHAPE, "gemm: negative size");
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mode = MODE_DENSE;
+    a.W = (const bf16_t*)w; a.N = N; a.ldw = (int)ldw; a.K = K;
+    a.M = M; a.X = (const bf16_t*)x; a.ldx = (int)ldx;
+    a.out = out; a.ldc = ldc; a.out_kind = out_f32 ? OUT_F32 : OUT_BF16;
+    a.resid_f32 = resid_f32; a.ldr = ldc;
+    return mm_gemm_launch(a, (hipStream_t)stream);
+}
+
+int mm_gemm_cfg_logits(mm_stream_t stream, const void* x_cond, const void* x_null, int64_t ldx, const void* w,
+                       int64_t ldw, int M, int N, int K, float* out, int64_t ldc, float cond_scale) {
+    if (M == 0 || N == 0) return MM_OK;
+    CHK_PTR(x_cond, "x_cond"); CHK_PTR(x_null, "x_null"); CHK_PTR(w, "w"); CHK_PTR(out, "out");
+    CHK_ALIGN16(x_cond, "x_cond"); CHK_ALIGN16(x_null, "x_null"); CHK_ALIGN16(w, "w"); CHK_ALIGN16(out, "out");
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mode = MODE_CFG;
+    a.W = (const bf16_t*)w; a.N = N; a.ldw = (int)ldw; a.K = K;
+    a.M = M; a.X = (const bf16_t*)x_cond; a.X2 = (const bf16_t*)x_null; a.ldx = (int)ldx;
+    a.out = out; a.ldc = ldc; a.out_kind = OUT_F32; a.cfg_scale = cond_scale;
+    return mm_gemm_launch(a, (hipStream_t)stream);
+}
+
+int mm_embed(mm_stream_t stream, const int64_t* ids, int rows, int n, const void* token_emb, int vocab_rows,
+             const void* pos_emb, int dim, float* x) {
+    if (rows == 0) return MM_OK;
+    CHK_PTR(ids, "ids"); CHK_PTR(token_emb, "token_emb"); CHK_PTR(pos_emb, "pos_emb"); CHK_PTR(x, "x");
+    CHK_ALIGN16(token_emb, "token_emb"); CHK_ALIGN16(pos_emb, "pos_emb"); CHK_ALIGN16(x, "x");
+    if (n <= 0) return mm_set_error(MM_ERR_SHAPE, "embed: n <= 0");
+    return k_embed((hipStream_t)stream, ids, rows, n, 0, (const bf16_t*)token_emb, vocab_rows, (const bf16_t*)pos_emb, dim, x);
+}
+
+int mm_layernorm(mm_stream_t stream, const float* x, int64_t ldx, int rows, int dim, const float* gamma,
+                 const float* beta, const int32_t* row_index, void* out, int64_t ldo) {
+    if (rows == 0) return MM_OK;
+    CHK_PTR(x, "x"); CHK_PTR(gamma, "gamma"); CHK_PTR(out, "out");
+    CHK_ALIGN16(x, "x"); CHK_ALIGN16(gamma, "gamma");
+    return k_layernorm((hipStream_t)stream, x, ldx, rows, dim, gamma, beta, row_index, (bf16_t*)out, ldo);
+}
+
+int mm_geglu_ln(mm_stream_t stream, const void* h, int64_t ldh, int rows, int F, int Fp, const float* gamma,
+                const float* beta, void* out, int64_t ldo) {
+    if (rows == 0) return MM_OK;
+    CHK_PTR(h, "h"); CHK_PTR(gamma, "gamma"); CHK_PTR(out, "out");
+    CHK_ALIGN16(h, "h"); CHK_ALIGN16(out, "out");
+    return k_geglu_ln((hipStream_t)stream, (const bf16_t*)h, ldh, rows, F, Fp, gamma, beta, (bf16_t*)out, ldo);
+}
+
+int mm_attend(mm_stream_t stream, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const void* k,
+              int64_t k_sb, int64_t k_sh, int64_t k_sn, const void* v, int64_t v_sb, int64_t v_sh, int64_t v_sn,
+              void* out, int64_t o_sb, int64_t o_sh, int64_t o_sn, int B, int H, int nq, int nk,
+              const uint8_t* key_mask, int64_t km_sb, int normalize, const float* q_scale, const float* k_scale,
+              const float* null_k, const float* null_v, float scale) {
+    CHK_PTR(q, "q"); CHK_PTR(k, "k"); CHK_PTR(v, "v"); CHK_PTR(out, "out");
+    CHK_ALIGN16(q, "q"); CHK_ALIGN16(k, "k"); CHK_ALIGN16(v, "v");
+    if ((null_k == nullptr) != (null_v == nullptr)) return mm_set_error(MM_ERR_SHAPE, "attend: null_k and null_v go together");
+    AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = (const bf16_t*)q; a.q_sb = q_sb; a.q_sh = q_sh; a.q_sn = q_sn;
+    a.k = (const bf16_t*)k; a.k_sb = k_sb; a.k_sh = k_sh; a.k_sn = k_sn;
+    a.v = (const bf16_t*)v; a.v_sb = v_sb; a.v_sh = v_sh; a.v_sn = v_sn;
+    a.out = (bf16_t*)out; a.o_sb = o_sb; a.o_sh = o_sh; a.o_sn = o_sn;
+    a.B = B; a.H = H; a.nq = nq; a.nk = nk;
+    a.key_mask = key_mask; a.km_sb = km_sb;
+    a.normalize = normalize; a.q_scale = q_scale; a.k_scale = k_scale;
+    a.null_k = null_k; a.null_v = null_v; a.scale = scale; a.kv_batch_mod = 0;
+    return k_attention((hipStream_t)stream, a);
+}
+
+int mm_mask_step(mm_stream_t stream, float* scores, int64_t* ids, int B, int n, int k, int64_t mask_id,
+                 int32_t* rows_out) {
+    if (B == 0) return MM_OK;
+    CHK_PTR(scores, "scores"); CHK_PTR(ids, "ids");
+    return k_mask_step((hipStream_t)stream, scores, ids, B, n, k, mask_id, rows_out);
+}
+
+int mm_sample_rows(mm_stream_t stream, const float* logits, int64_t ld, int R, int V, int k_keep,
+                   const int32_t* rows, float temperature, int noise_kind, const float* noise, int64_t noise_ld,
+                   uint64_t seed, uint64_t row_offset, uint32_t step, int64_t* ids, float* scores,
+                   int64_t* pred_out, float* score_out) {
+    if (R == 0) return MM_OK;
+    CHK_PTR(logits, "logits"); CHK_ALIGN16(logits, "logits");
+    if (noise) CHK_ALIGN16(noise, "noise");
+    if (noise_kind < MM_NOISE_NONE || noise_kind > MM_NOISE_PHILOX) return mm_set_error(MM_ERR_SHAPE, "sample_rows: bad noise_kind");
+    SampleArgs a;
+    memset(&a, 0, sizeof(a));
+    a.logits = logits; a.ld = ld; a.R = R; a.V = V; a.k_keep = k_keep; a.rows = rows;
+    a.temperature = temperature; a.noise_kind = noise_kind; a.noise = noise; a.noise_ld = noise_ld;
+    a.seed = seed; a.row_offset = row_offset; a.step = step;
+    a.ids = ids; a.scores = scores; a.pred_out = pred_out; a.score_out = score_out;
+    return k_sample_rows((hipStream_t)stream, a);
+}
+
+int mm_philox_uniform(mm_stream_t stream, uint64_t seed, uint64_t row_offset, uint32_t step, int rows, int V, float* out) {
+    if (rows == 0) return MM_OK;
+    CHK_PTR(out, "out"); CHK_ALIGN16(out, "out");
+    return k_philox_fill((hipStream_t)stream, seed, row_offset, step, rows, V, out);
+}
+
+int mm_conv2d_nhwc(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
+                   int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
+                   int Hout, int Wout, const float* bias, int act, const void* resid, void* out, int out_nchw_f32) {
+    if (B == 0) return MM_OK;
+    CHK_PTR(in, "in"); CHK_PTR(w, "w"); CHK_PTR(out, "out");
+    CHK_ALIGN16(in, "in"); CHK_ALIGN16(w, "w"); CHK_ALIGN16(out, "out");
+    if (TH <= 0 || TW <= 0 || Cin <= 0 || Cout <= 0 || Hv <= 0 || Wv <= 0) return mm_set_error(MM_ERR_SHAPE, "conv: bad geometry");
+    if (!out_nchw_f32 && (Cout % 4)) return mm_set_error(MM_ERR_SHAPE, "conv: NHWC bf16 output needs Cout % 4 == 0");
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mode = MODE_CONV;
+    a.Ktrue = TH * TW * Cin;
+    a.K = (a.Ktrue + 63) / 64 * 64;
+    a.W = (const bf16_t*)w; a.N = Cout; a.ldw = a.K;
+    a.M = B * Hv * Wv; a.X = (const bf16_t*)in; a.ldx = Cin;
+    a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.TW = TW; a.stride = stride; a.off_y = off_y; a.off_x = off_x;
+    a.Hv = Hv; a.Wv = Wv; a.os = os; a.py = py; a.px = px; a.Hout = Hout; a.Wout = Wout;
+    a.out = out; a.ldc = Cout; a.out_kind = out_nchw_f32 ? OUT_NCHW_F32 : OUT_BF16;
+    a.bias = bias; a.act = act ? ACT_LEAKY : ACT_NONE;
+    a.resid_bf16 = (const bf16_t*)resid; a.ldr = Cout;
+    return mm_gemm_launch(a, (hipStream_t)stream);
+}
+
+int mm_glu_nhwc(mm_stream_t stream, const void* x, int64_t rows, int C, void* out) {
+    if (rows == 0) return MM_OK;
+    CHK_PTR(x, "x"); CHK_PTR(out, "out"); CHK_ALIGN16(x, "x"); CHK_ALIGN16(out, "out");
+    return k_glu((hipStream_t)stream, (const bf16_t*)x, rows, C, (bf16_t*)out);
+}
+
+int mm_groupnorm_nhwc(mm_stream_t stream, const void* x, int B, int HW, int C, int groups, const float* gamma,
+                      const float* beta, int act, float* stats_ws, void* out) {
+    if (B == 0) return MM_OK;
+    CHK_PTR(x, "x"); CHK_PTR(out, "out"); CHK_PTR(gamma, "gamma"); CHK_PTR(beta, "beta"); CHK_PTR(stats_ws, "stats_ws");
+    CHK_ALIGN16(x, "x"); CHK_ALIGN16(out, "out");
+    return k_groupnorm((hipStream_t)stream, (const bf16_t*)x, B, HW, C, groups, gamma, beta, act ? ACT_LEAKY : ACT_NONE, stats_ws, (bf16_t*)out);
+}
+
+int mm_lfq_decode(mm_stream_t stream, const int64_t* ids, int64_t count, int bits, int C, const float* w,
+                  const float* b, void* out) {
+    if (count == 0) return MM_OK;
+    CHK_PTR(ids, "ids"); CHK_PTR(out, "out");
+    if (w && !b) return mm_set_error(MM_ERR_SHAPE, "lfq_decode: project_out needs its bias");
+    return k_lfq_decode((hipStream_t)stream, ids, count, bits, C, w, b, (bf16_t*)out);
+}
+
+int mm_lfq_encode(mm_stream_t stream, const void* x, int64_t count, int C, int bits, const float* w_in,
+                  const float* b_in, const float* w_out, const float* b_out, int64_t* ids, void* out) {
+    if (count == 0) return MM_OK;
+    CHK_PTR(x, "x"); CHK_PTR(ids, "ids");
+    return k_lfq_encode((hipStream_t)stream, (const bf16_t*)x, count, C, bits, w_in, b_in, w_out, b_out, ids, (bf16_t*)out);
+}
+
+int mm_nchw_f32_to_nhwc8_bf16(mm_stream_t stream, const float* img, int B, int C, int H, int W, void* out) {
+    CHK_PTR(img, "img"); CHK_PTR(out, "out"); CHK_ALIGN16(out, "out");
+    return k_nchw_to_nhwc8((hipStream_t)stream, img, B, C, H, W, (bf16_t*)out);
+}
+
+int mm_nhwc_bf16_to_nchw_f32(mm_stream_t stream, const void* x, int B, int C, int H, int W, float* out) {
+    CHK_PTR(x, "x"); CHK_PTR(out, "out");
+    return k_nhwc_to_nchw_f32((hipStream_t)stream, (const bf16_t*)x, B, C, H, W, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,253 @@
+// Muse attention for gfx950:   softmax(8 * q^ . k^ + key mask) @ v   with a learned null key/value
+// (muse_maskgit_pytorch.py:143-159 + attend.py:123-140; the default flash branch attend.py:66-107 computes the
+// same function).  dim_head is 64 (the reference default and every BASELINE config).
+//
+// One 256-thread workgroup = 4 waves = 64 queries of one (batch, head); each wave owns 16 queries.
+//   * optional prologue fusion (normalize=1): q / k rows come straight out of the projection GEMMs
+//     ([tokens][heads*64] bf16); F.normalize + the learned per-dim scales are applied while staging, so
+//     the reference's rearrange / cat / l2norm / scale passes (mmp.py:143-153) never touch HBM.
+//   * the null key/value (mmp.py:145-149) is not a 257th key: it INITIALISES the online-softmax state
+//     (m = s_null, l = 1, O = v_null), so the key loop runs over exactly nk real keys in tiles of 64.
+//   * S^T = K Q^T on MFMA (16x16x32 bf16): a lane then owns 4 consecutive keys of ONE query, so the
+//     row max / row sum need two cross-lane steps and P packs into 8-byte LDS writes.
+//   * O = P V on MFMA; V is transposed while it is staged into LDS (keys become the contiguous axis).
+//   LDS: K tile 8 KiB + V^T tile 8 KiB + 4 x 2 KiB P, all in 128-byte rows with the 16-byte chunk index
+//   XOR (row & 7)  -> conflict-free ds_read_b128 fragment reads.
+#include "common.h"
+#include "muse_hip_internal.h"
+
+namespace {
+
+constexpr int DH = 64;
+constexpr int KT = 64;       // keys per tile
+constexpr float NEG_BIG = -3.0e38f;
+
+__device__ __forceinline__ int sw_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+__global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[8192 + 8192 + 4 * 2048];
+    unsigned char* Ks = smem;
+    unsigned char* Vt = smem + 8192;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    unsigned char* Ps = smem + 16384 + w * 2048;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q_wave0 = blockIdx.x * 64 + w * 16;
+
+    // ---- Q fragment (B operand of S^T): query = q_wave0 + fr, d = ks*32 + 8*fg .. +7
+    const int qi = q_wave0 + fr;
+    const bool q_ok = qi < p.nq;
+    uint4 qf[2];
+    float qv0[8], qv1[8];     // the (bf16-rounded) q^ values this lane holds, for the null-key score
+    {
+        const bf16_t* qp = p.q + (size_t)b * p.q_sb + (size_t)h * p.q_sh + (size_t)(q_ok ? qi : 0) * p.q_sn;
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        const uint4 l0 = *reinterpret_cast<const uint4*>(qp + 8 * fg);        // row index clamped: always in bounds
+        const uint4 l1 = *reinterpret_cast<const uint4*>(qp + 32 + 8 * fg);
+        qf[0] = q_ok ? l0 : z;
+        qf[1] = q_ok ? l1 : z;
+        unpack8(qf[0], qv0);
+        unpack8(qf[1], qv1);
+        if (p.normalize) {
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += qv0[j] * qv0[j] + qv1[j] * qv1[j];
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);      // F.normalize eps (mmp.py:41-42)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                qv0[j] = qv0[j] * inv * p.q_scale[8 * fg + j];
+                qv1[j] = qv1[j] * inv * p.q_scale[32 + 8 * fg + j];
+            }
+            qf[0] = pack8(qv0);
+            qf[1] = pack8(qv1);
+            unpack8(qf[0], qv0);   // what the MFMA sees
+            unpack8(qf[1], qv1);
+        }
+    }
+
+    // ---- online-softmax state.  Scores are per query = per lane column fr (replicated over fg);
+    //      acc_o[dt][r] holds query 4*fg + r, d = dt*16 + fr.
+    float m_run = -1.0e30f, l_run = 0.f;
+    f32x4_t acc_o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) acc_o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (p.null_k) {
+        const float* nk = p.null_k + h * DH;
+        const float* nv = p.null_v + h * DH;
+        float nss = 0.f;
+        for (int d = 0; d < DH; ++d) nss += nk[d] * nk[d];
+        const float ninv = p.normalize ? 1.f / fmaxf(sqrtf(nss), 1e-12f) : 1.f;
+        float part = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d0 = 8 * fg + j, d1 = 32 + 8 * fg + j;
+            const float ks0 = p.normalize ? p.k_scale[d0] : 1.f, ks1 = p.normalize ? p.k_scale[d1] : 1.f;
+            const float k0 = bf16_to_f32(f32_to_bf16(nk[d0] * ninv * ks0));
+            const float k1 = bf16_to_f32(f32_to_bf16(nk[d1] * ninv * ks1));
+            part += qv0[j] * k0 + qv1[j] * k1;
+        }
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);
+        m_run = part * p.scale;
+        l_run = 1.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const float v0 = bf16_to_f32(f32_to_bf16(nv[dt * 16 + fr]));
+            acc_o[dt] = f32x4_t{v0, v0, v0, v0};
+        }
+    }
+
+    const int kb = p.kv_batch_mod > 0 ? b % p.kv_batch_mod : b;
+    const bf16_t* kbase = p.k + (size_t)kb * p.k_sb + (size_t)h * p.k_sh;
+    const bf16_t* vbase = p.v + (size_t)kb * p.v_sb + (size_t)h * p.v_sh;
+    const uint8_t* kmask = p.key_mask ? p.key_mask + (size_t)b * p.km_sb : nullptr;
+
+    for (int kt0 = 0; kt0 < p.nk; kt0 += KT) {
+        // ---- stage K tile: thread -> key t>>2, 16 d values at (t&3)*16
+        {
+            const int key = t >> 2, dpart = (t & 3) * 16;
+            const int kg = kt0 + key;
+            const bool ok = kg < p.nk;
+            const bf16_t* kp = kbase + (size_t)(ok ? kg : 0) * p.k_sn + dpart;
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            const uint4 l0 = *reinterpret_cast<const uint4*>(kp);
+            const uint4 l1 = *reinterpret_cast<const uint4*>(kp + 8);
+            uint4 r0 = ok ? l0 : z;
+            uint4 r1 = ok ? l1 : z;
+            if (p.normalize) {
+                float f0[8], f1[8];
+                unpack8(r0, f0); unpack8(r1, f1);
+                float ss = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ss += f0[j] * f0[j] + f1[j] * f1[j];
+                ss += __shfl_xor(ss, 1, 64);
+                ss += __shfl_xor(ss, 2, 64);
+                const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    f0[j] = f0[j] * inv * p.k_scale[dpart + j];
+                    f1[j] = f1[j] * inv * p.k_scale[dpart + 8 + j];
+                }
+                r0 = pack8(f0); r1 = pack8(f1);
+            }
+            *reinterpret_cast<uint4*>(Ks + sw_off(key, dpart >> 3)) = r0;
+            *reinterpret_cast<uint4*>(Ks + sw_off(key, (dpart >> 3) + 1)) = r1;
+        }
+        // ---- stage V tile transposed: thread -> key pair t&31, d chunk t>>5; Vt[d][key]
+        {
+            const int kp2 = t & 31, dc = t >> 5;
+            const int kg = kt0 + 2 * kp2;
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            const bool ok0 = kg < p.nk, ok1 = kg + 1 < p.nk;
+            const uint4 l0 = *reinterpret_cast<const uint4*>(vbase + (size_t)(ok0 ? kg : 0) * p.v_sn + dc * 8);
+            const uint4 l1 = *reinterpret_cast<const uint4*>(vbase + (size_t)(ok1 ? kg + 1 : 0) * p.v_sn + dc * 8);
+            const uint4 a0 = ok0 ? l0 : z;
+            const uint4 a1 = ok1 ? l1 : z;
+            const uint32_t w0[4] = {a0.x, a0.y, a0.z, a0.w};
+            const uint32_t w1[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t lo = (i & 1) ? (w0[i >> 1] >> 16) : (w0[i >> 1] & 0xFFFFu);
+                const uint32_t hi = (i & 1) ? (w1[i >> 1] >> 16) : (w1[i >> 1] & 0xFFFFu);
+                const int d = dc * 8 + i;
+                *reinterpret_cast<uint32_t*>(Vt + sw_off(d, kp2 >> 2) + (kp2 & 3) * 4) = lo | (hi << 16);
+            }
+        }
+        __syncthreads();
+
+        // ---- S^T = K Q^T : acc_s[kt4][r] -> key kt0 + kt4*16 + 4*fg + r, query fr
+        f32x4_t acc_s[4];
+#pragma unroll
+        for (int kt4 = 0; kt4 < 4; ++kt4) {
+            acc_s[kt4] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint4 kf = *reinterpret_cast<const uint4*>(Ks + sw_off(kt4 * 16 + fr, ks * 4 + fg));
+                acc_s[kt4] = mfma16(kf, qf[ks], acc_s[kt4]);
+            }
+        }
+        float tmax = NEG_BIG;
+#pragma unroll
+        for (int kt4 = 0; kt4 < 4; ++kt4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kg = kt0 + kt4 * 16 + 4 * fg + r;
+                bool ok = kg < p.nk;
+                if (ok && kmask) ok = kmask[kg] != 0;
+                const float s = ok ? acc_s[kt4][r] * p.scale : NEG_BIG;
+                acc_s[kt4][r] = s;
+                tmax = fmaxf(tmax, s);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int kt4 = 0; kt4 < 4; ++kt4) {
+            float pv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pv[r] = expf(acc_s[kt4][r] - m_new);
+                psum += pv[r];
+            }
+            // P[query fr][keys kt4*16 + 4fg .. +3] -> 8-byte LDS write
+            const int chunk = kt4 * 2 + (fg >> 1);
+            *reinterpret_cast<uint2*>(Ps + sw_off(fr, chunk) + (fg & 1) * 8) =
+                make_uint2(pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]));
+        }
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        // rescale O: row 4*fg + r needs that query's alpha (held by lane 4*fg + r)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ar = __shfl(alpha, 4 * fg + r, 64);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) acc_o[dt][r] *= ar;
+        }
+        __builtin_amdgcn_wave_barrier();   // P writes (this wave) before P reads (this wave)
+        // ---- O += P V
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint4 pf = *reinterpret_cast<const uint4*>(Ps + sw_off(fr, ks * 4 + fg));
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const uint4 vf = *reinterpret_cast<const uint4*>(Vt + sw_off(dt * 16 + fr, ks * 4 + fg));
+                acc_o[dt] = mfma16(pf, vf, acc_o[dt]);
+            }
+        }
+        __syncthreads();   // all waves done with Ks / Vt before the next tile is staged
+    }
+
+    // ---- epilogue: O / l  -> bf16
+    const float linv = 1.f / l_run;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float lr = __shfl(linv, 4 * fg + r, 64);
+        const int qo = q_wave0 + 4 * fg + r;
+        if (qo < p.nq) {
+            bf16_t* op = p.out + (size_t)b * p.o_sb + (size_t)h * p.o_sh + (size_t)qo * p.o_sn;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) op[dt * 16 + fr] = f32_to_bf16(acc_o[dt][r] * lr);
+        }
+    }
+}
+
+}  // namespace
+
+int k_attention(hipStream_t s, const AttnArgs& a) {
+    if (a.B <= 0 || a.H <= 0 || a.nq <= 0) return MM_OK;
+    if (a.nk < 0) return mm_set_error(MM_ERR_SHAPE, "attention: nk < 0");
+    if (a.nk == 0 && !a.null_k) return mm_set_error(MM_ERR_SHAPE, "attention: no keys at all");
+    if ((a.q_sn % 8) || (a.k_sn % 8) || (a.v_sn % 8) || (a.q_sh % 8) || (a.k_sh % 8) || (a.v_sh % 8) ||
+        (a.q_sb % 8) || (a.k_sb % 8) || (a.v_sb % 8))
+        return mm_set_error(MM_ERR_ALIGN, "attention: q/k/v strides must be multiples of 8 elements");
+    if (a.normalize && (!a.q_scale || !a.k_scale)) return mm_set_error(MM_ERR_SHAPE, "attention: normalize needs q_scale/k_scale");
+    dim3 grid((a.nq + 63) / 64, a.H, a.B);
+    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, s, a);
+    return mm_check_launch("attention_kernel");
+}

@@ -1,0 +1,85 @@
+// Device-side helpers shared by every gfx950 kernel in this library.
+// Written for CDNA4 only: wave = 64 lanes, MFMA 16x16x32 bf16, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits; all HBM activations/weights use this
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;  // one MFMA A/B operand (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // one 16x16 accumulator fragment
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;  // 16 raw bytes in registers (native vector: HIP's uint4 class
+                                                                  // defeats SROA in conditionally-filled staging arrays)
+
+#define MM_WAVE 64
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// round-to-nearest-even, the same rounding torch's .to(bfloat16) applies (NaN not expected here)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+__device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
+
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+    f[0] = bf16lo(v.x); f[1] = bf16hi(v.x); f[2] = bf16lo(v.y); f[3] = bf16hi(v.y);
+    f[4] = bf16lo(v.z); f[5] = bf16hi(v.z); f[6] = bf16lo(v.w); f[7] = bf16hi(v.w);
+}
+
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    uint4 v;
+    v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
+    v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
+    return v;
+}
+
+__device__ __forceinline__ f32x4_t mfma16(const uint4& a, const uint4& b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                   __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4_t mfma16(u32x4_t a, u32x4_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                   __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+// full-wave (64-lane) butterfly reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// XCD-aware tile order: block b is dispatched to XCD b % 8 (observed, used for speed only), so give
+// every XCD one contiguous run of the linear tile index (bijective for any tile count), then walk
+// that run in groups of GROUP_M row-tiles so a group's activation tiles stay in the XCD's 4 MiB L2
+// while the weight tiles stream past.
+__device__ __forceinline__ void xcd_grouped_tile(int bid, int tiles_m, int tiles_n, int group_m, int& tm, int& tn) {
+    const int total = tiles_m * tiles_n;
+    const int q = total >> 3, r = total & 7;
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int gsz = group_m * tiles_n;
+    const int g = lin / gsz;
+    const int first_m = g * group_m;
+    const int gm = min(tiles_m - first_m, group_m);
+    const int in_g = lin - g * gsz;
+    tm = first_m + in_g % gm;
+    tn = in_g / gm;
+}

@@ -1,0 +1,452 @@
+// Host-side orchestration of the transformer forward and the MaskGit decode loop on one HIP stream.
+// Pure launch sequencing: no allocation, no synchronisation, no host<->device copies inside the timed path
+// (so the whole of mm_generate is hipGraph-capturable).  Reference: muse_maskgit_pytorch.py:187-195 (blocks),
+// :279-335 (forward), :491-615 (generate).
+#include <new>
+#include <string.h>
+#include <vector>
+
+#include "common.h"
+#include "muse_hip_internal.h"
+
+struct mm_transformer {
+    mm_transformer_desc d;
+    std::vector<mm_layer_weights> layers;
+    int I;    // heads * dim_head
+    int Fp;
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ small kernels
+// text_embeds fp32 [B][L][text_dim] -> bf16 rows + key mask  (mmp.py:304: mask = (text_embeds != 0).any(-1))
+__global__ __launch_bounds__(256) void text_context_kernel(const float* __restrict__ text, int B, int L, int text_dim,
+                                                           bf16_t* __restrict__ out, int out_rows_per_batch, long ldo,
+                                                           uint8_t* __restrict__ mask, int m, int drop_text) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * L) return;
+    const int b = row / L, j = row - b * L;
+    const float* tr = text + (size_t)row * text_dim;
+    bf16_t* orow = out + ((size_t)b * out_rows_per_batch + j) * ldo;
+    bool nz = false;
+    for (int c = lane; c < text_dim; c += 64) {
+        const float v = tr[c];
+        nz |= (v != 0.f);
+        orow[c] = f32_to_bf16(v);
+    }
+    const bool any = __ballot(nz) != 0ull;
+    if (lane == 0 && mask) mask[(size_t)b * m + j] = (any && !drop_text) ? 1 : 0;
+}
+
+// ctx[b][L + c][:] = token_emb[cond_ids[b][c]][:]; mask = 1   (mmp.py:314-318)
+__global__ __launch_bounds__(256) void gather_cond_kernel(const bf16_t* __restrict__ table, int D, const int64_t* __restrict__ idx,
+                                                          int B, int nc, int vocab_rows, bf16_t* __restrict__ ctx,
+                                                          uint8_t* __restrict__ mask, int m, int L) {
+    const int chunks = D >> 3;
+    const long total = (long)B * nc * chunks;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / chunks;
+        const int c = (int)(i - r * chunks);
+        const int b = (int)(r / nc), j = (int)(r - (long)b * nc);
+        long id = idx[r];
+        id = id < 0 ? 0 : (id >= vocab_rows ? vocab_rows - 1 : id);
+        *reinterpret_cast<uint4*>(ctx + ((size_t)b * m + L + j) * D + c * 8) =
+            *reinterpret_cast<const uint4*>(table + id * D + c * 8);
+        if (c == 0 && mask) mask[(size_t)b * m + L + j] = 1;
+    }
+}
+
+__global__ void fill_i64_kernel(int64_t* p, long n, int64_t v) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------ workspace carving
+struct Carver {
+    unsigned char* base;
+    size_t off;
+    explicit Carver(void* p) : base((unsigned char*)p), off(0) {}
+    template <typename T>
+    T* take(size_t count) {
+        off = (off + 255) & ~(size_t)255;
+        T* r = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += count * sizeof(T);
+        return r;
+    }
+    size_t used() const { return (off + 255) & ~(size_t)255; }
+};
+
+#define RC(x)                \
+    do {                     \
+        int _rc = (x);       \
+        if (_rc) return _rc; \
+    } while (0)
+
+int gemm_dense(hipStream_t s, const bf16_t* X, int ldx, const bf16_t* W, int ldw, int M, int N, int K, void* out, long ldc,
+               int out_kind, const float* resid) {
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mode = MODE_DENSE;
+    a.W = W; a.N = N; a.ldw = ldw; a.K = K; a.M = M; a.X = X; a.ldx = ldx;
+    a.out = out; a.ldc = ldc; a.out_kind = out_kind; a.resid_f32 = resid; a.ldr = ldc;
+    return mm_gemm_launch(a, s);
+}
+
+struct Bufs {       // activation scratch for `rows` token rows
+    float* x;       // [rows][D] residual stream fp32
+    bf16_t* xn;     // [rows][D]
+    bf16_t* qkv;    // [rows][3I]
+    bf16_t* att;    // [rows][I]
+    bf16_t* h;      // [rows][2Fp]
+    bf16_t* a;      // [rows][Fp]
+};
+
+void carve_bufs(Carver& c, const mm_transformer* t, size_t rows, Bufs& b) {
+    const int D = t->d.dim, I = t->I, Fp = t->Fp;
+    b.x = c.take<float>(rows * D);
+    b.xn = c.take<bf16_t>(rows * D);
+    b.qkv = c.take<bf16_t>(rows * 3 * I);
+    b.att = c.take<bf16_t>(rows * I);
+    b.h = c.take<bf16_t>(rows * 2 * Fp);
+    b.a = c.take<bf16_t>(rows * Fp);
+}
+
+// dst += FF(src)   (mmp.py:79-89 with the residual of :193 / the self-cond add of :328)
+int ff_block(const mm_transformer* t, hipStream_t s, const mm_ff_weights& w, const float* src, float* dst, int rows, Bufs& b) {
+    const int D = t->d.dim, F = t->d.ff_inner, Fp = t->Fp;
+    RC(k_layernorm(s, src, D, rows, D, w.ln1_gamma, w.ln1_beta, nullptr, b.xn, D));
+    RC(gemm_dense(s, b.xn, D, (const bf16_t*)w.w1, D, rows, 2 * Fp, D, b.h, 2 * Fp, OUT_BF16, nullptr));
+    RC(k_geglu_ln(s, b.h, 2 * Fp, rows, F, Fp, w.ln2_gamma, w.ln2_beta, b.a, Fp));
+    RC(gemm_dense(s, b.a, Fp, (const bf16_t*)w.w2, Fp, rows, D, Fp, dst, D, OUT_F32, dst));
+    return MM_OK;
+}
+
+// x += SelfAttention(x) over `seqs` sequences of n tokens  (mmp.py:126-162 with context = None, :189)
+int self_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weights& w, int seqs, int n, Bufs& b) {
+    const int D = t->d.dim, I = t->I, H = t->d.heads;
+    const int rows = seqs * n;
+    RC(k_layernorm(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, b.xn, D));
+    const bf16_t* wq = (const bf16_t*)w.w_q;
+    const bf16_t* wkv = (const bf16_t*)w.w_kv;
+    if (wkv == wq + (size_t)I * D) {
+        RC(gemm_dense(s, b.xn, D, wq, D, rows, 3 * I, D, b.qkv, 3 * I, OUT_BF16, nullptr));
+    } else {
+        RC(gemm_dense(s, b.xn, D, wq, D, rows, I, D, b.qkv, 3 * I, OUT_BF16, nullptr));
+        RC(gemm_dense(s, b.xn, D, wkv, D, rows, 2 * I, D, b.qkv + I, 3 * I, OUT_BF16, nullptr));
+    }
+    AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = b.qkv; a.q_sb = (long)n * 3 * I; a.q_sh = 64; a.q_sn = 3 * I;
+    a.k = b.qkv + I; a.k_sb = a.q_sb; a.k_sh = 64; a.k_sn = 3 * I;
+    a.v = b.qkv + 2 * I; a.v_sb = a.q_sb; a.v_sh = 64; a.v_sn = 3 * I;
+    a.out = b.att; a.o_sb = (long)n * I; a.o_sh = 64; a.o_sn = I;
+    a.B = seqs; a.H = H; a.nq = n; a.nk = n;
+    a.normalize = 1; a.q_scale = w.q_scale; a.k_scale = w.k_scale; a.null_k = w.null_k; a.null_v = w.null_v;
+    a.scale = 8.f;
+    RC(k_attention(s, a));
+    RC(gemm_dense(s, b.att, I, (const bf16_t*)w.w_out, I, rows, D, I, b.x, D, OUT_F32, b.x));
+    return MM_OK;
+}
+
+// x += CrossAttention(x, ctx) for `seqs` sequences; ckv = ctx @ to_kv^T given as [kv_seqs*m][2I]  (mmp.py:191)
+int cross_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weights& w, int seqs, int n, const bf16_t* ckv,
+                     int m, int kv_batch_mod, const uint8_t* key_mask, Bufs& b) {
+    const int D = t->d.dim, I = t->I, H = t->d.heads;
+    const int rows = seqs * n;
+    RC(k_layernorm(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, b.xn, D));
+    RC(gemm_dense(s, b.xn, D, (const bf16_t*)w.w_q, D, rows, I, D, b.qkv, I, OUT_BF16, nullptr));
+    AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = b.qkv; a.q_sb = (long)n * I; a.q_sh = 64; a.q_sn = I;
+    a.k = ckv; a.k_sb = (long)m * 2 * I; a.k_sh = 64; a.k_sn = 2 * I;
+    a.v = ckv + I; a.v_sb = a.k_sb; a.v_sh = 64; a.v_sn = 2 * I;
+    a.out = b.att; a.o_sb = (long)n * I; a.o_sh = 64; a.o_sn = I;
+    a.B = seqs; a.H = H; a.nq = n; a.nk = m;
+    a.key_mask = key_mask; a.km_sb = m;
+    a.normalize = 1; a.q_scale = w.q_scale; a.k_scale = w.k_scale; a.null_k = w.null_k; a.null_v = w.null_v;
+    a.scale = 8.f; a.kv_batch_mod = kv_batch_mod;
+    RC(k_attention(s, a));
+    RC(gemm_dense(s, b.att, I, (const bf16_t*)w.w_out, I, rows, D, I, b.x, D, OUT_F32, b.x));
+    return MM_OK;
+}
+
+int check_model(const mm_transformer* t) {
+    if (!t) return mm_set_error(MM_ERR_SHAPE, "model handle is NULL");
+    return MM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mm_transformer_create(const mm_transformer_desc* desc, mm_transformer_t** out) {
+    if (!desc || !out) return mm_set_error(MM_ERR_SHAPE, "transformer_create: NULL argument");
+    const mm_transformer_desc& d = *desc;
+    if (d.dim_head != 64) return mm_set_error(MM_ERR_UNSUPPORTED, "transformer: dim_head must be 64");
+    if (d.dim <= 0 || d.dim % 64 || d.dim > 2048) return mm_set_error(MM_ERR_SHAPE, "transformer: dim must be a multiple of 64, <= 2048");
+    if (d.depth <= 0 || d.heads <= 0 || !d.layers) return mm_set_error(MM_ERR_SHAPE, "transformer: depth/heads/layers");
+    if (d.ff_inner_padded % 64 || d.ff_inner_padded < d.ff_inner) return mm_set_error(MM_ERR_SHAPE, "transformer: ff_inner_padded must be a multiple of 64 >= ff_inner");
+    if (d.text_proj && (d.text_dim % 64)) return mm_set_error(MM_ERR_SHAPE, "transformer: text_dim must be a multiple of 64 when projected");
+    if (!d.text_proj && d.text_dim != d.dim) return mm_set_error(MM_ERR_SHAPE, "transformer: text_proj is NULL but text_dim != dim");
+    if (!d.token_emb || !d.pos_emb || !d.to_logits || !d.final_gamma) return mm_set_error(MM_ERR_SHAPE, "transformer: missing weight pointer");
+    mm_transformer* t = new (std::nothrow) mm_transformer();
+    if (!t) return mm_set_error(MM_ERR_HIP, "out of host memory");
+    t->d = d;
+    t->layers.assign(d.layers, d.layers + d.depth);
+    t->d.layers = t->layers.data();
+    t->I = d.heads * d.dim_head;
+    t->Fp = d.ff_inner_padded;
+    *out = t;
+    return MM_OK;
+}
+
+void mm_transformer_destroy(mm_transformer_t* model) { delete model; }
+
+size_t mm_context_workspace_bytes(const mm_transformer_t* t, int B, int L) {
+    if (!t) return 0;
+    Carver c(nullptr);
+    if (t->d.text_proj) {
+        c.take<bf16_t>((size_t)B * L * t->d.text_dim);
+        c.take<bf16_t>((size_t)B * L * t->d.dim);
+    }
+    return c.used() + 256;
+}
+
+int mm_transformer_context(const mm_transformer_t* t, mm_stream_t stream, const float* text_embeds, int B, int L,
+                           const int64_t* cond_ids, int nc, int drop_text, void* ctx, uint8_t* key_mask,
+                           void* workspace, size_t workspace_bytes) {
+    RC(check_model(t));
+    hipStream_t s = (hipStream_t)stream;
+    const int D = t->d.dim, m = L + nc;
+    if (B <= 0 || L < 0 || nc < 0 || m <= 0) return mm_set_error(MM_ERR_SHAPE, "context: bad sizes");
+    if (L > 0 && !text_embeds) return mm_set_error(MM_ERR_SHAPE, "context: text_embeds is NULL");
+    if (nc > 0 && !cond_ids) return mm_set_error(MM_ERR_SHAPE, "context: cond_ids is NULL");
+    if (workspace_bytes < mm_context_workspace_bytes(t, B, L)) return mm_set_error(MM_ERR_WORKSPACE, "context: workspace too small");
+    bf16_t* ctxp = (bf16_t*)ctx;
+    if (L > 0) {
+        if (!t->d.text_proj) {
+            hipLaunchKernelGGL(text_context_kernel, dim3((B * L + 3) / 4), dim3(256), 0, s, text_embeds, B, L, t->d.text_dim, ctxp,
+                               m, (long)D, key_mask, m, drop_text);
+            RC(mm_check_launch("text_context_kernel"));
+        } else {
+            Carver c(workspace);
+            bf16_t* tb = c.take<bf16_t>((size_t)B * L * t->d.text_dim);
+            bf16_t* proj = c.take<bf16_t>((size_t)B * L * D);
+            hipLaunchKernelGGL(text_context_kernel, dim3((B * L + 3) / 4), dim3(256), 0, s, text_embeds, B, L, t->d.text_dim, tb,
+                               L, (long)t->d.text_dim, key_mask, m, drop_text);
+            RC(mm_check_launch("text_context_kernel"));
+            RC(gemm_dense(s, tb, t->d.text_dim, (const bf16_t*)t->d.text_proj, t->d.text_dim, B * L, D, t->d.text_dim, proj, D,
+                          OUT_BF16, nullptr));
+            const hipError_t e = hipMemcpy2DAsync(ctxp, (size_t)m * D * 2, proj, (size_t)L * D * 2, (size_t)L * D * 2, B,
+                                                  hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) return mm_set_hip_error(e, "context: hipMemcpy2DAsync");
+        }
+    }
+    if (nc > 0) {
+        long chunks = (long)B * nc * (D / 8);
+        int blocks = (int)((chunks + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(gather_cond_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)t->d.token_emb, D, cond_ids, B, nc,
+                           t->d.vocab_rows, ctxp, key_mask, m, L);
+        RC(mm_check_launch("gather_cond_kernel"));
+    }
+    return MM_OK;
+}
+
+size_t mm_transformer_workspace_bytes(const mm_transformer_t* t, int B, int n, int m) {
+    if (!t) return 0;
+    Carver c(nullptr);
+    Bufs b;
+    carve_bufs(c, t, (size_t)B * n, b);
+    c.take<bf16_t>((size_t)B * m * 2 * t->I);    // cross K/V of one layer
+    c.take<bf16_t>((size_t)B * n * t->d.dim);    // embed when the caller does not want it
+    return c.used() + 256;
+}
+
+int mm_transformer_forward(const mm_transformer_t* t, mm_stream_t stream, const int64_t* ids, int B, int n,
+                           const void* ctx, const uint8_t* key_mask, int m, const float* self_cond_embed,
+                           void* embed_out, float* logits_out, void* workspace, size_t workspace_bytes) {
+    RC(check_model(t));
+    hipStream_t s = (hipStream_t)stream;
+    const int D = t->d.dim, I = t->I;
+    if (B <= 0 || n <= 0 || n > t->d.seq_len) return mm_set_error(MM_ERR_SHAPE, "forward: need 0 < n <= seq_len");   // mmp.py:293
+    if (m <= 0 || !ctx || !key_mask || !ids) return mm_set_error(MM_ERR_SHAPE, "forward: ids/ctx/key_mask required");
+    if (workspace_bytes < mm_transformer_workspace_bytes(t, B, n, m)) return mm_set_error(MM_ERR_WORKSPACE, "forward: workspace too small");
+    const int rows = B * n;
+    Carver c(workspace);
+    Bufs b;
+    carve_bufs(c, t, (size_t)rows, b);
+    bf16_t* ckv = c.take<bf16_t>((size_t)B * m * 2 * I);
+    bf16_t* emb = c.take<bf16_t>((size_t)rows * D);
+    if (embed_out) emb = (bf16_t*)embed_out;
+
+    RC(k_embed(s, ids, rows, n, 0, (const bf16_t*)t->d.token_emb, t->d.vocab_rows, (const bf16_t*)t->d.pos_emb, D, b.x));
+    if (t->d.self_cond && self_cond_embed)       // mmp.py:325-328 (zeros when absent: FF(0) still adds LN-beta terms = 0)
+        RC(ff_block(t, s, t->d.self_cond_ff, self_cond_embed, b.x, rows, b));
+    for (int l = 0; l < t->d.depth; ++l) {
+        const mm_layer_weights& w = t->layers[l];
+        RC(self_attn_block(t, s, w.self_attn, B, n, b));
+        RC(gemm_dense(s, (const bf16_t*)ctx, D, (const bf16_t*)w.cross_attn.w_kv, D, B * m, 2 * I, D, ckv, 2 * I, OUT_BF16, nullptr));
+        RC(cross_attn_block(t, s, w.cross_attn, B, n, ckv, m, 0, key_mask, b));
+        RC(ff_block(t, s, w.ff, b.x, b.x, rows, b));
+    }
+    RC(k_layernorm(s, b.x, D, rows, D, t->d.final_gamma, t->d.final_beta, nullptr, emb, D));
+    if (logits_out)
+        RC(gemm_dense(s, emb, D, (const bf16_t*)t->d.to_logits, D, rows, t->d.dim_out, D, logits_out, t->d.dim_out, OUT_F32, nullptr));
+    return MM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ generate
+namespace {
+struct GenBufs {
+    Bufs b;                 // 2B sequences
+    bf16_t* ctx;            // [B][m][D]
+    uint8_t* masks;         // [2B][m]: cond masks then null masks
+    bf16_t* ckv;            // [depth][B*m][2I]
+    float* cvec;            // [depth][D]: to_out(null_v) of each cross-attention (base model null pass)
+    bf16_t* nullv;          // [I] scratch
+    int32_t* rows;          // [B*n]
+    bf16_t* embc;           // [B*n][D]
+    bf16_t* embn;           // [B*n][D]
+    float* logits;          // [B*n][V]
+    void* ctx_ws; size_t ctx_ws_bytes;
+};
+void carve_gen(Carver& c, const mm_transformer* t, int B, int n, int L, int nc, GenBufs& g) {
+    const int D = t->d.dim, I = t->I, m = L + nc;
+    carve_bufs(c, t, (size_t)2 * B * n, g.b);
+    g.ctx = c.take<bf16_t>((size_t)B * m * D);
+    g.masks = c.take<uint8_t>((size_t)2 * B * m);
+    g.ckv = c.take<bf16_t>((size_t)t->d.depth * B * m * 2 * I);
+    g.cvec = c.take<float>((size_t)t->d.depth * D);
+    g.nullv = c.take<bf16_t>((size_t)I + 64);
+    g.rows = c.take<int32_t>((size_t)B * n);
+    g.embc = c.take<bf16_t>((size_t)B * n * D);
+    g.embn = c.take<bf16_t>((size_t)B * n * D);
+    g.logits = c.take<float>((size_t)B * n * t->d.dim_out);
+    g.ctx_ws_bytes = mm_context_workspace_bytes(t, B, L);
+    g.ctx_ws = c.take<unsigned char>(g.ctx_ws_bytes);
+}
+}  // namespace
+
+size_t mm_generate_workspace_bytes(const mm_transformer_t* t, int B, int n, int L, int nc) {
+    if (!t) return 0;
+    Carver c(nullptr);
+    GenBufs g;
+    carve_gen(c, t, B, n, L, nc, g);
+    return c.used() + 256;
+}
+
+int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate_params* p, void* workspace, size_t workspace_bytes) {
+    RC(check_model(t));
+    if (!p) return mm_set_error(MM_ERR_SHAPE, "generate: params is NULL");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = p->batch, n = p->n, T = p->timesteps, L = p->L, nc = p->nc, m = L + nc;
+    const int D = t->d.dim, I = t->I, V = t->d.dim_out;
+    if (B <= 0 || n <= 0 || n > t->d.seq_len || T <= 0) return mm_set_error(MM_ERR_SHAPE, "generate: bad batch/n/timesteps");
+    if (t->d.vocab_rows != t->d.num_tokens + 1) return mm_set_error(MM_ERR_SHAPE, "generate: transformer has no mask id (MaskGitTransformer required)");
+    if (t->d.self_cond) return mm_set_error(MM_ERR_UNSUPPORTED, "generate: self-conditioning transformers use the stepwise path");
+    if (!p->mask_counts || !p->temperatures || !p->ids || !p->scores) return mm_set_error(MM_ERR_SHAPE, "generate: schedule / outputs required");
+    if (m <= 0) return mm_set_error(MM_ERR_SHAPE, "generate: empty context");
+    if (p->cond_scale == 1.f) return mm_set_error(MM_ERR_UNSUPPORTED, "generate: cond_scale == 1 (single pass) uses the stepwise path");
+    if ((p->noise_kind == MM_NOISE_GUMBEL || p->noise_kind == MM_NOISE_UNIFORM) && !p->noise)
+        return mm_set_error(MM_ERR_SHAPE, "generate: noise tensor required for this noise_kind");
+    if (workspace_bytes < mm_generate_workspace_bytes(t, B, n, L, nc)) return mm_set_error(MM_ERR_WORKSPACE, "generate: workspace too small");
+    for (int i = 0; i < T; ++i)
+        if (p->mask_counts[i] < 1 || p->mask_counts[i] > n || (i > 0 && p->mask_counts[i] > p->mask_counts[i - 1]))
+            return mm_set_error(MM_ERR_SHAPE, "generate: mask_counts must be non-increasing within [1, n]");
+    if (p->mask_counts[0] != n) return mm_set_error(MM_ERR_SHAPE, "generate: the first step must mask every token (mmp.py:519-563)");
+
+    Carver c(workspace);
+    GenBufs g;
+    carve_gen(c, t, B, n, L, nc, g);
+    const int M = B * n;            // rows of one CFG half
+    const int64_t mask_id = t->d.num_tokens;
+
+    // ---- step-invariant work: context, masks, cross-attention K/V of every layer, null-pass constants
+    RC(mm_transformer_context(t, stream, p->text_embeds, B, L, p->cond_ids, nc, 0, g.ctx, g.masks, g.ctx_ws, g.ctx_ws_bytes));
+    {   // null masks: text keys off, cond-id keys on (mmp.py:308-310, 318)
+        hipError_t e = hipMemsetAsync(g.masks + (size_t)B * m, 0, (size_t)B * m, s);
+        if (e != hipSuccess) return mm_set_hip_error(e, "generate: memset masks");
+        if (nc > 0) {
+            e = hipMemset2DAsync(g.masks + (size_t)B * m + L, m, 1, nc, B, s);
+            if (e != hipSuccess) return mm_set_hip_error(e, "generate: memset2d masks");
+        }
+    }
+    for (int l = 0; l < t->d.depth; ++l) {
+        const mm_attn_weights& w = t->layers[l].cross_attn;
+        bf16_t* ckv_l = g.ckv + (size_t)l * B * m * 2 * I;
+        RC(gemm_dense(s, g.ctx, D, (const bf16_t*)w.w_kv, D, B * m, 2 * I, D, ckv_l, 2 * I, OUT_BF16, nullptr));
+        if (nc == 0) {
+            // softmax over the single unmasked (null) key is exactly 1 -> attention out = bf16(null_v) for every
+            // query, so the null pass's cross-attention is the constant row to_out(null_v)
+            RC(k_f32_to_bf16(s, w.null_v, g.nullv, I));
+            RC(gemm_dense(s, g.nullv, I, (const bf16_t*)w.w_out, I, 1, D, I, g.cvec + (size_t)l * D, D, OUT_F32, nullptr));
+        }
+    }
+    {
+        hipLaunchKernelGGL(fill_i64_kernel, dim3(64), dim3(256), 0, s, p->ids, (long)M, mask_id);   // mmp.py:519
+        RC(mm_check_launch("fill_i64_kernel"));
+        const hipError_t e = hipMemsetAsync(p->scores, 0, (size_t)M * 4, s);                          // mmp.py:520
+        if (e != hipSuccess) return mm_set_hip_error(e, "generate: memset scores");
+    }
+
+    Bufs& b = g.b;
+    for (int step = 0; step < T; ++step) {
+        const int k = p->mask_counts[step];
+        const int R = B * k;
+        RC(k_mask_step(s, p->scores, p->ids, B, n, k, mask_id, g.rows));                            // mmp.py:558-563
+        if (p->trace_masked_ids) {
+            const hipError_t e = hipMemcpyAsync(p->trace_masked_ids + (size_t)step * M, p->ids, (size_t)M * 8, hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) return mm_set_hip_error(e, "generate: trace copy");
+        }
+        // both CFG halves see the same ids: rows [0, M) = cond pass, [M, 2M) = null pass (mmp.py:250-252)
+        RC(k_embed(s, p->ids, M, n, 0, (const bf16_t*)t->d.token_emb, t->d.vocab_rows, (const bf16_t*)t->d.pos_emb, D, b.x));
+        {
+            const hipError_t e = hipMemcpyAsync(b.x + (size_t)M * D, b.x, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) return mm_set_hip_error(e, "generate: x copy");
+        }
+        for (int l = 0; l < t->d.depth; ++l) {
+            const mm_layer_weights& w = t->layers[l];
+            RC(self_attn_block(t, s, w.self_attn, 2 * B, n, b));
+            const bf16_t* ckv_l = g.ckv + (size_t)l * B * m * 2 * I;
+            if (nc == 0) {
+                RC(cross_attn_block(t, s, w.cross_attn, B, n, ckv_l, m, 0, g.masks, b));
+                RC(k_add_rowvec(s, b.x + (size_t)M * D, D, M, D, g.cvec + (size_t)l * D));
+            } else {
+                RC(cross_attn_block(t, s, w.cross_attn, 2 * B, n, ckv_l, m, B, g.masks, b));
+            }
+            RC(ff_block(t, s, w.ff, b.x, b.x, 2 * M, b));
+        }
+        // final norm + to_logits + CFG only at the rows that are sampled this step
+        RC(k_layernorm(s, b.x, D, R, D, t->d.final_gamma, t->d.final_beta, g.rows, g.embc, D));
+        RC(k_layernorm(s, b.x + (size_t)M * D, D, R, D, t->d.final_gamma, t->d.final_beta, g.rows, g.embn, D));
+        {
+            GemmArgs a;
+            memset(&a, 0, sizeof(a));
+            a.mode = MODE_CFG;
+            a.W = (const bf16_t*)t->d.to_logits; a.N = V; a.ldw = D; a.K = D;
+            a.M = R; a.X = g.embc; a.X2 = g.embn; a.ldx = D;
+            a.out = g.logits; a.ldc = V; a.out_kind = OUT_F32; a.cfg_scale = p->cond_scale;
+            RC(mm_gemm_launch(a, s));
+        }
+        SampleArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.logits = g.logits; sa.ld = V; sa.R = R; sa.V = V; sa.k_keep = p->k_keep; sa.rows = g.rows;
+        sa.temperature = p->temperatures[step]; sa.noise_kind = p->noise_kind;
+        sa.noise = p->noise ? p->noise + (size_t)step * M * V : nullptr; sa.noise_ld = V;
+        sa.seed = p->seed; sa.row_offset = p->row_offset * (uint64_t)n; sa.step = (uint32_t)step;
+        sa.ids = p->ids; sa.scores = p->scores;
+        RC(k_sample_rows(s, sa));                                                                    // mmp.py:576-609
+        if (p->trace_ids) {
+            const hipError_t e = hipMemcpyAsync(p->trace_ids + (size_t)step * M, p->ids, (size_t)M * 8, hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) return mm_set_hip_error(e, "generate: trace copy");
+        }
+        if (p->trace_scores) {
+            const hipError_t e = hipMemcpyAsync(p->trace_scores + (size_t)step * M, p->scores, (size_t)M * 4, hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) return mm_set_hip_error(e, "generate: trace copy");
+        }
+    }
+    return MM_OK;
+}
+
+}  // extern "C"

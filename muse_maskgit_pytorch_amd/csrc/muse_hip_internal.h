@@ -1,0 +1,91 @@
+// Internal (C++) declarations shared between the kernel translation units and the C-ABI layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/muse_hip.h"
+
+typedef uint16_t bf16_t;
+
+enum { MODE_DENSE = 0, MODE_CFG = 1, MODE_CONV = 2 };
+enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_NCHW_F32 = 2 };
+enum { ACT_NONE = 0, ACT_LEAKY = 1 };
+
+struct GemmArgs {
+    int mode;
+    // weight operand W[N][ldw], K contiguous (zero padded to a multiple of 64)
+    const bf16_t* W; int N; int ldw; int K;
+    // activation operand: M rows
+    int M;
+    const bf16_t* X; int ldx;     // dense / cfg-cond / conv input (NHWC)
+    const bf16_t* X2;             // cfg-null rows
+    // conv geometry (MODE_CONV): virtual output grid Hv x Wv per image, taps TH x TW
+    int Hin, Win, Cin, TW, stride, off_y, off_x, Hv, Wv, Ktrue;
+    int os, py, px, Hout, Wout;   // output pixel = (y*os+py, x*os+px) in an Hout x Wout image
+    // epilogue
+    void* out; long ldc; int out_kind;
+    const float* bias; const float* resid_f32; const bf16_t* resid_bf16; long ldr;
+    int act; float cfg_scale;
+    int tiles_m, tiles_n;         // filled by mm_gemm_launch
+};
+
+int mm_gemm_launch(GemmArgs a, hipStream_t stream);
+
+// error plumbing (thread-local message, never throws across the ABI)
+int mm_set_error(int code, const char* msg);
+int mm_set_hip_error(hipError_t e, const char* where);
+int mm_check_launch(const char* kernel);
+
+// ---- kernel launchers implemented in the other .hip files (all asynchronous on `stream`)
+int k_embed(hipStream_t s, const int64_t* ids, int rows, int n, int pos_offset, const bf16_t* tok, int vocab_rows,
+            const bf16_t* pos, int D, float* x);
+int k_layernorm(hipStream_t s, const float* x, long ldx, int rows, int D, const float* gamma, const float* beta,
+                const int32_t* row_index, bf16_t* out, long ldo);
+int k_geglu_ln(hipStream_t s, const bf16_t* h, long ldh, int rows, int F, int Fp, const float* gamma, const float* beta,
+               bf16_t* out, long ldo);
+int k_add_rowvec(hipStream_t s, float* x, long ldx, int rows, int D, const float* vec);
+int k_f32_to_bf16(hipStream_t s, const float* x, bf16_t* out, long count);
+
+struct AttnArgs {
+    const bf16_t* q; long q_sb, q_sh, q_sn;      // element strides: batch, head, token (d contiguous, dh = 64)
+    const bf16_t* k; long k_sb, k_sh, k_sn;
+    const bf16_t* v; long v_sb, v_sh, v_sn;
+    bf16_t* out; long o_sb, o_sh, o_sn;
+    int B, H, nq, nk;                            // nk real keys (null key excluded)
+    const uint8_t* key_mask; long km_sb;         // optional (B, nk) 1 = keep
+    int normalize;                               // 1: l2norm(q)*q_scale, l2norm(k)*k_scale in-kernel
+    const float* q_scale; const float* k_scale;  // [64]
+    const float* null_k; const float* null_v;    // optional [H][64] fp32 (raw parameter values)
+    float scale;                                 // 8
+    int kv_batch_mod;                            // > 0: k/v batch index = b % kv_batch_mod (CFG halves share one context)
+};
+int k_attention(hipStream_t s, const AttnArgs& a);
+
+int k_mask_step(hipStream_t s, float* scores, int64_t* ids, int B, int n, int k, int64_t mask_id, int32_t* rows_out);
+struct SampleArgs {
+    const float* logits; long ld;                // [R][V] CFG-combined logits of the gathered rows
+    int R, V, k_keep;                            // keep the k largest per row
+    const int32_t* rows;                         // [R] flat position b*n + pos of each gathered row
+    float inv_temperature_divisor;               // unused placeholder (division is IEEE, see sampling.hip)
+    float temperature;                           // already clamped to >= 1e-10
+    int noise_kind;                              // MM_NOISE_*
+    const float* noise; long noise_ld;           // indexed by flat position: noise[(b*n+pos)*noise_ld + v]
+    uint64_t seed; uint64_t row_offset; uint32_t step;
+    int64_t* ids; float* scores;                 // scattered outputs, indexed by flat position
+    int64_t* pred_out; float* score_out;         // optional compact outputs [R]
+};
+int k_sample_rows(hipStream_t s, const SampleArgs& a);
+int k_philox_fill(hipStream_t s, uint64_t seed, uint64_t row_offset, uint32_t step, int rows, int V, float* out);
+int k_text_context(hipStream_t s, const float* text, int rows, int text_dim, int L, int m, bf16_t* out_bf16, long ldo,
+                   uint8_t* mask, int drop_text);
+int k_gather_rows_bf16(hipStream_t s, const bf16_t* table, int D, const int64_t* idx, int B, int nc, int vocab_rows,
+                       bf16_t* out, long out_batch_stride, long out_row_offset, uint8_t* mask, int m, int L);
+
+// vae kernels
+int k_lfq_decode(hipStream_t s, const int64_t* ids, long count, int bits, int C, const float* w, const float* b, bf16_t* out);
+int k_lfq_encode(hipStream_t s, const bf16_t* x, long count, int C, int bits, const float* w, const float* b,
+                 const float* wo, const float* bo, int64_t* ids, bf16_t* out);
+int k_glu(hipStream_t s, const bf16_t* x, long rows, int C, bf16_t* out);
+int k_groupnorm(hipStream_t s, const bf16_t* x, int B, int HW, int C, int groups, const float* gamma, const float* beta,
+                int act, float* stats_ws, bf16_t* out);
+int k_nchw_to_nhwc8(hipStream_t s, const float* img, int B, int C, int H, int W, bf16_t* out);
+int k_nhwc_to_nchw_f32(hipStream_t s, const bf16_t* x, int B, int C, int H, int W, float* out);

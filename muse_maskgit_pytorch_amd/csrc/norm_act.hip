@@ -1,0 +1,198 @@
+// HBM-bound row kernels of the transformer (gfx950): token+position embedding, LayerNorm, GEGLU+LayerNorm,
+// row-vector add.  One 64-lane wave per row, 16-byte vector accesses, fp32 statistics via wave butterflies.
+#include "common.h"
+#include "muse_hip_internal.h"
+
+namespace {
+
+// x[row][:] = token_emb[ids[row]] + pos_emb[row % n]           (muse_maskgit_pytorch.py:322-323)
+__global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ ids, int rows, int n, int pos_offset,
+                                                    const bf16_t* __restrict__ tok, int vocab_rows,
+                                                    const bf16_t* __restrict__ pos, int D, float* __restrict__ x) {
+    const int chunks = D >> 3;
+    const long total = (long)rows * chunks;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / chunks), c = (int)(i - (long)row * chunks);
+        long id = ids[row];
+        id = id < 0 ? 0 : (id >= vocab_rows ? vocab_rows - 1 : id);
+        const uint4 tv = *reinterpret_cast<const uint4*>(tok + id * D + c * 8);
+        const uint4 pv = *reinterpret_cast<const uint4*>(pos + (long)(row % n + pos_offset) * D + c * 8);
+        float a[8], b[8];
+        unpack8(tv, a); unpack8(pv, b);
+        float* xo = x + (long)row * D + c * 8;
+        *reinterpret_cast<float4*>(xo) = make_float4(a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]);
+        *reinterpret_cast<float4*>(xo + 4) = make_float4(a[4] + b[4], a[5] + b[5], a[6] + b[6], a[7] + b[7]);
+    }
+}
+
+// F.layer_norm(x, (D,), gamma, beta), eps 1e-5 (muse_maskgit_pytorch.py:63-70); fp32 in, bf16 out.
+// Optional row gather (row_index) so the final norm only touches the rows that are sampled.
+constexpr int LN_MAX_IT = 8;   // D <= 64 lanes * 4 * 8 = 2048
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long ldx, int rows, int D,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const int32_t* __restrict__ row_index, bf16_t* __restrict__ out, long ldo) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long src = row_index ? (long)row_index[row] : (long)row;
+    const float* xr = x + src * ldx;
+    const int nvec = D >> 2;
+    float4 v[LN_MAX_IT];
+    float sum = 0.f;
+#pragma unroll
+    for (int it = 0; it < LN_MAX_IT; ++it) {
+        const int c = it * 64 + lane;
+        if (c < nvec) {
+            v[it] = *reinterpret_cast<const float4*>(xr + c * 4);
+            sum += (v[it].x + v[it].y) + (v[it].z + v[it].w);
+        }
+    }
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int it = 0; it < LN_MAX_IT; ++it) {
+        const int c = it * 64 + lane;
+        if (c < nvec) {
+            const float a = v[it].x - mean, b = v[it].y - mean, cc = v[it].z - mean, d = v[it].w - mean;
+            sq += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float rstd = 1.f / sqrtf(wave_sum(sq) / (float)D + 1e-5f);
+    bf16_t* orow = out + (long)row * ldo;
+#pragma unroll
+    for (int it = 0; it < LN_MAX_IT; ++it) {
+        const int c = it * 64 + lane;
+        if (c < nvec) {
+            const float4 g = *reinterpret_cast<const float4*>(gamma + c * 4);
+            float4 bt = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (beta) bt = *reinterpret_cast<const float4*>(beta + c * 4);
+            const float o0 = (v[it].x - mean) * rstd * g.x + bt.x, o1 = (v[it].y - mean) * rstd * g.y + bt.y;
+            const float o2 = (v[it].z - mean) * rstd * g.z + bt.z, o3 = (v[it].w - mean) * rstd * g.w + bt.w;
+            *reinterpret_cast<uint2*>(orow + c * 4) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+        }
+    }
+}
+
+// GEGLU + LayerNorm(inner)  (muse_maskgit_pytorch.py:72-77, 86-87): h = [x | gate] (each Fp wide, F valid),
+// a = gate * gelu_erf(x); out = LN(a) over the F valid columns; columns F..Fp-1 are written as zeros so the
+// following GEMM can run on the padded K.
+constexpr int GG_MAX_IT = 12;  // Fp <= 64 * 8 * 12 = 6144
+__global__ __launch_bounds__(256) void geglu_ln_kernel(const bf16_t* __restrict__ h, long ldh, int rows, int F, int Fp,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       bf16_t* __restrict__ out, long ldo) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16_t* hr = h + (long)row * ldh;
+    const int nch = Fp >> 3;
+    float a[GG_MAX_IT][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int it = 0; it < GG_MAX_IT; ++it) {
+        const int c = it * 64 + lane;
+        if (c < nch) {
+            float xv[8], gv[8];
+            unpack8(*reinterpret_cast<const uint4*>(hr + c * 8), xv);
+            unpack8(*reinterpret_cast<const uint4*>(hr + Fp + c * 8), gv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float ge = 0.5f * xv[j] * (1.f + erff(xv[j] * 0.70710678118654752440f));
+                const float val = (c * 8 + j < F) ? gv[j] * ge : 0.f;
+                a[it][j] = val;
+                sum += val;
+            }
+        }
+    }
+    const float mean = wave_sum(sum) / (float)F;
+    float sq = 0.f;
+#pragma unroll
+    for (int it = 0; it < GG_MAX_IT; ++it) {
+        const int c = it * 64 + lane;
+        if (c < nch) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (c * 8 + j < F) { const float d = a[it][j] - mean; sq += d * d; }
+        }
+    }
+    const float rstd = 1.f / sqrtf(wave_sum(sq) / (float)F + 1e-5f);
+    bf16_t* orow = out + (long)row * ldo;
+#pragma unroll
+    for (int it = 0; it < GG_MAX_IT; ++it) {
+        const int c = it * 64 + lane;
+        if (c < nch) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int col = c * 8 + j;
+                o[j] = (col < F) ? (a[it][j] - mean) * rstd * gamma[col] + (beta ? beta[col] : 0.f) : 0.f;
+            }
+            *reinterpret_cast<uint4*>(orow + c * 8) = pack8(o);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void add_rowvec_kernel(float* __restrict__ x, long ldx, int rows, int D, const float* __restrict__ vec) {
+    const int nvec = D >> 2;
+    const long total = (long)rows * nvec;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / nvec), c = (int)(i - (long)row * nvec);
+        float4* px = reinterpret_cast<float4*>(x + (long)row * ldx + c * 4);
+        const float4 v = *reinterpret_cast<const float4*>(vec + c * 4);
+        float4 a = *px;
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        *px = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, long count) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+        out[i] = f32_to_bf16(x[i]);
+}
+
+inline int grid_for(long items, int per_block = 256, int cap = 256 * 8) {
+    long b = (items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    return (int)(b > cap ? cap : b);
+}
+
+}  // namespace
+
+int k_embed(hipStream_t s, const int64_t* ids, int rows, int n, int pos_offset, const bf16_t* tok, int vocab_rows,
+            const bf16_t* pos, int D, float* x) {
+    if (rows <= 0) return MM_OK;
+    if (D % 8) return mm_set_error(MM_ERR_SHAPE, "embed: dim must be a multiple of 8");
+    hipLaunchKernelGGL(embed_kernel, dim3(grid_for((long)rows * (D / 8))), dim3(256), 0, s, ids, rows, n, pos_offset, tok,
+                       vocab_rows, pos, D, x);
+    return mm_check_launch("embed_kernel");
+}
+
+int k_layernorm(hipStream_t s, const float* x, long ldx, int rows, int D, const float* gamma, const float* beta,
+                const int32_t* row_index, bf16_t* out, long ldo) {
+    if (rows <= 0) return MM_OK;
+    if (D % 4 || D > 64 * 4 * LN_MAX_IT) return mm_set_error(MM_ERR_SHAPE, "layernorm: dim must be a multiple of 4 and <= 2048");
+    if (ldx % 4 || ldo % 4) return mm_set_error(MM_ERR_ALIGN, "layernorm: strides must be multiples of 4 elements");
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, D, gamma, beta, row_index, out, ldo);
+    return mm_check_launch("layernorm_kernel");
+}
+
+int k_geglu_ln(hipStream_t s, const bf16_t* h, long ldh, int rows, int F, int Fp, const float* gamma, const float* beta,
+               bf16_t* out, long ldo) {
+    if (rows <= 0) return MM_OK;
+    if (Fp % 8 || Fp < F || Fp > 64 * 8 * GG_MAX_IT) return mm_set_error(MM_ERR_SHAPE, "geglu_ln: padded inner dim must be a multiple of 8, >= F and <= 6144");
+    if (ldh % 8 || ldo % 8) return mm_set_error(MM_ERR_ALIGN, "geglu_ln: strides must be multiples of 8 elements");
+    hipLaunchKernelGGL(geglu_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, h, ldh, rows, F, Fp, gamma, beta, out, ldo);
+    return mm_check_launch("geglu_ln_kernel");
+}
+
+int k_add_rowvec(hipStream_t s, float* x, long ldx, int rows, int D, const float* vec) {
+    if (rows <= 0) return MM_OK;
+    if (D % 4 || ldx % 4) return mm_set_error(MM_ERR_ALIGN, "add_rowvec: dim/stride must be multiples of 4");
+    hipLaunchKernelGGL(add_rowvec_kernel, dim3(grid_for((long)rows * (D / 4))), dim3(256), 0, s, x, ldx, rows, D, vec);
+    return mm_check_launch("add_rowvec_kernel");
+}
+
+int k_f32_to_bf16(hipStream_t s, const float* x, bf16_t* out, long count) {
+    if (count <= 0) return MM_OK;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(count)), dim3(256), 0, s, x, out, count);
+    return mm_check_launch("f32_to_bf16_kernel");
+}

@@ -1,0 +1,481 @@
+"""Transformer / MaskGitTransformer / TokenCritic / MaskGit / Muse drop-ins for MI355X.
+
+Same constructor + method signatures and the same state_dict key names as the reference
+(muse_maskgit_pytorch.py:63-791), so reference checkpoints load unchanged.  The nn.Modules hold fp32 parameters
+only; all arithmetic of `Transformer.forward`, `forward_with_cond_scale` and `MaskGit.generate` runs in
+libmuse_hip.so (bf16 MFMA kernels, fp32 residual stream / logits / sampling) through the C ABI in
+include/muse_hip.h.  There is no eager fallback: without the library or without a gfx950 device these raise.
+"""
+import ctypes as C
+import math
+from functools import partial
+from pathlib import Path
+from typing import Callable, List, Optional
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import ops
+from .attend import Attend
+from .t5 import DEFAULT_T5_NAME, get_encoded_dim, t5_encode_text
+from .vqgan_vae import VQGanVAE
+
+bf16 = torch.bfloat16
+
+
+def exists(v):
+    return v is not None
+
+
+def default(v, d):
+    return v if exists(v) else d
+
+
+def eval_decorator(fn):
+    def inner(model, *args, **kwargs):
+        was_training = model.training
+        model.eval()
+        out = fn(model, *args, **kwargs)
+        model.train(was_training)
+        return out
+    return inner
+
+
+def cosine_schedule(t):
+    return torch.cos(t * math.pi * 0.5)
+
+
+# ------------------------------------------------------------------------------------------------ parameter containers
+
+class LayerNorm(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.gamma = nn.Parameter(torch.ones(dim))
+        self.register_buffer('beta', torch.zeros(dim))
+
+    def forward(self, x):
+        shp = x.shape
+        out = ops.layernorm(x.reshape(-1, shp[-1]).float().contiguous(), self.gamma.detach().float(), self.beta.float())
+        return out.reshape(shp).to(x.dtype)
+
+
+class GEGLU(nn.Module):
+    def forward(self, x):
+        raise NotImplementedError('GEGLU is fused with the following LayerNorm on MI355X (mm_geglu_ln); call the Transformer')
+
+
+def FeedForward(dim, mult=4):
+    inner_dim = int(dim * mult * 2 / 3)
+    return nn.Sequential(LayerNorm(dim), nn.Linear(dim, inner_dim * 2, bias=False), GEGLU(), LayerNorm(inner_dim),
+                         nn.Linear(inner_dim, dim, bias=False))
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, dim_head=64, heads=8, cross_attend=False, scale=8, flash=True, dropout=0.):
+        super().__init__()
+        self.scale = scale
+        self.heads = heads
+        inner_dim = dim_head * heads
+        self.cross_attend = cross_attend
+        self.norm = LayerNorm(dim)
+        self.attend = Attend(flash=flash, dropout=dropout, scale=scale)
+        self.null_kv = nn.Parameter(torch.randn(2, heads, 1, dim_head))
+        self.to_q = nn.Linear(dim, inner_dim, bias=False)
+        self.to_kv = nn.Linear(dim, inner_dim * 2, bias=False)
+        self.q_scale = nn.Parameter(torch.ones(dim_head))
+        self.k_scale = nn.Parameter(torch.ones(dim_head))
+        self.to_out = nn.Linear(inner_dim, dim, bias=False)
+
+
+class TransformerBlocks(nn.Module):
+    def __init__(self, *, dim, depth, dim_head=64, heads=8, ff_mult=4, flash=True):
+        super().__init__()
+        self.layers = nn.ModuleList([])
+        for _ in range(depth):
+            self.layers.append(nn.ModuleList([
+                Attention(dim=dim, dim_head=dim_head, heads=heads, flash=flash),
+                Attention(dim=dim, dim_head=dim_head, heads=heads, cross_attend=True, flash=flash),
+                FeedForward(dim=dim, mult=ff_mult)]))
+        self.norm = LayerNorm(dim)
+        self.cfg = dict(dim=dim, depth=depth, dim_head=dim_head, heads=heads, ff_mult=ff_mult)
+
+
+# ------------------------------------------------------------------------------------------------ Transformer
+
+class _Handle:
+    """Owns the packed device weights (torch tensors) and the C model handle built from them."""
+
+    def __init__(self):
+        self.keep = []
+        self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                L.lib().mm_transformer_destroy(self.ptr)
+        except Exception:
+            pass
+
+
+class Transformer(nn.Module):
+    def __init__(self, *, num_tokens, dim, seq_len, dim_out=None, t5_name=DEFAULT_T5_NAME, self_cond=False,
+                 add_mask_id=False, **kwargs):
+        super().__init__()
+        self.dim = dim
+        self.mask_id = num_tokens if add_mask_id else None
+        self.num_tokens = num_tokens
+        self.token_emb = nn.Embedding(num_tokens + int(add_mask_id), dim)
+        self.pos_emb = nn.Embedding(seq_len, dim)
+        self.seq_len = seq_len
+        self.transformer_blocks = TransformerBlocks(dim=dim, **kwargs)
+        self.norm = LayerNorm(dim)            # allocated but never applied, as in the reference (mmp.py:222)
+        self.dim_out = default(dim_out, num_tokens)
+        self.to_logits = nn.Linear(dim, self.dim_out, bias=False)
+        self.encode_text = partial(t5_encode_text, name=t5_name)
+        text_embed_dim = get_encoded_dim(t5_name)
+        self.text_embed_dim = text_embed_dim
+        self.text_embed_proj = nn.Linear(text_embed_dim, dim, bias=False) if text_embed_dim != dim else nn.Identity()
+        self.self_cond = self_cond
+        self.self_cond_to_init_embed = FeedForward(dim)
+        self._handle = None
+        self._handle_key = None
+        self._ws = None
+
+    # ---- packing (once per parameter version / device)
+    def _pack_ff(self, ff, keep):
+        w1, w2 = ff[1].weight.detach(), ff[4].weight.detach()
+        F = w2.shape[1]
+        Fp = (F + 63) // 64 * 64
+        D = w1.shape[1]
+        w1p = torch.zeros(2 * Fp, D, dtype=bf16, device=w1.device)
+        w1p[:F] = w1[:F].to(bf16)
+        w1p[Fp:Fp + F] = w1[F:].to(bf16)
+        w2p = ops.pad_cols(w2.to(bf16), 64)
+        assert w2p.shape[1] == Fp
+        t = dict(g1=ff[0].gamma.detach().float().contiguous(), b1=ff[0].beta.float().contiguous(), w1=w1p,
+                 g2=ff[3].gamma.detach().float().contiguous(), b2=ff[3].beta.float().contiguous(), w2=w2p)
+        keep.append(t)
+        fw = L.FFWeights(L.ptr(t['g1']), L.ptr(t['b1']), L.ptr(t['w1']), L.ptr(t['g2']), L.ptr(t['b2']), L.ptr(t['w2']))
+        return fw, F, Fp
+
+    def _pack_attn(self, a, keep, fused):
+        f32c = lambda x: x.detach().float().contiguous()
+        I = a.to_q.weight.shape[0]
+        D = a.to_q.weight.shape[1]
+        if fused:
+            wqkv = torch.cat([a.to_q.weight.detach(), a.to_kv.weight.detach()], dim=0).to(bf16).contiguous()
+            wq_ptr = wqkv.data_ptr()
+            wkv_ptr = wq_ptr + I * D * 2
+            wkeep = wqkv
+        else:
+            wq = a.to_q.weight.detach().to(bf16).contiguous()
+            wkv = a.to_kv.weight.detach().to(bf16).contiguous()
+            wq_ptr, wkv_ptr, wkeep = wq.data_ptr(), wkv.data_ptr(), (wq, wkv)
+        t = dict(g=f32c(a.norm.gamma), b=f32c(a.norm.beta), w=wkeep, wo=a.to_out.weight.detach().to(bf16).contiguous(),
+                 nk=f32c(a.null_kv[0, :, 0, :]), nv=f32c(a.null_kv[1, :, 0, :]), qs=f32c(a.q_scale), ks=f32c(a.k_scale))
+        keep.append(t)
+        return L.AttnWeights(L.ptr(t['g']), L.ptr(t['b']), C.c_void_p(wq_ptr), C.c_void_p(wkv_ptr), L.ptr(t['wo']),
+                             L.ptr(t['nk']), L.ptr(t['nv']), L.ptr(t['qs']), L.ptr(t['ks']))
+
+    def _model(self):
+        L.require_device()
+        dev = self.token_emb.weight.device
+        if dev.type != 'cuda':
+            raise L.MuseHipError('Transformer parameters are not on the GPU; the MI355X path has no CPU fallback')
+        key = (str(dev),) + tuple(p._version for p in self.parameters())
+        if self._handle is not None and self._handle_key == key:
+            return self._handle
+        h = _Handle()
+        tb = self.transformer_blocks
+        cfg = tb.cfg
+        layers = (L.LayerWeights * cfg['depth'])()
+        F = Fp = 0
+        for i, (sa, ca, ff) in enumerate(tb.layers):
+            layers[i].self_attn = self._pack_attn(sa, h.keep, fused=True)
+            layers[i].cross_attn = self._pack_attn(ca, h.keep, fused=False)
+            layers[i].ff, F, Fp = self._pack_ff(ff, h.keep)
+        sc_ff, _, _ = self._pack_ff(self.self_cond_to_init_embed, h.keep)
+        f32c = lambda x: x.detach().float().contiguous()
+        t = dict(tok=self.token_emb.weight.detach().to(bf16).contiguous(), pos=self.pos_emb.weight.detach().to(bf16).contiguous(),
+                 fg=f32c(tb.norm.gamma), fb=f32c(tb.norm.beta), wl=self.to_logits.weight.detach().to(bf16).contiguous(),
+                 tp=self.text_embed_proj.weight.detach().to(bf16).contiguous() if isinstance(self.text_embed_proj, nn.Linear) else None)
+        h.keep.append(t)
+        h.keep.append(layers)
+        d = L.TransformerDesc()
+        d.dim, d.depth, d.heads, d.dim_head = self.dim, cfg['depth'], cfg['heads'], cfg['dim_head']
+        d.ff_inner, d.ff_inner_padded = F, Fp
+        d.seq_len, d.num_tokens, d.vocab_rows, d.dim_out = self.seq_len, self.num_tokens, self.token_emb.weight.shape[0], self.dim_out
+        d.text_dim, d.self_cond = self.text_embed_dim, int(bool(self.self_cond))
+        d.token_emb, d.pos_emb, d.text_proj = L.ptr(t['tok']), L.ptr(t['pos']), L.ptr(t['tp'])
+        d.layers = C.cast(layers, C.POINTER(L.LayerWeights))
+        d.final_gamma, d.final_beta, d.to_logits = L.ptr(t['fg']), L.ptr(t['fb']), L.ptr(t['wl'])
+        d.self_cond_ff = sc_ff
+        L.check(L.lib().mm_transformer_create(C.byref(d), C.byref(h.ptr)), 'mm_transformer_create')
+        h.packed = t
+        self._handle, self._handle_key = h, key
+        return h
+
+    def _workspace(self, nbytes, device):
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return self._ws
+
+    # ---- context (mmp.py:302-318)
+    def _context(self, text_embeds, conditioning_token_ids, cond_drop_prob):
+        h = self._model()
+        dev = self.token_emb.weight.device
+        te = text_embeds.to(device=dev, dtype=torch.float32).contiguous()
+        b, Lt, td = te.shape
+        assert td == self.text_embed_dim, f'text embeds have dim {td}, transformer expects {self.text_embed_dim}'
+        cids, nc = None, 0
+        if exists(conditioning_token_ids):
+            cids = conditioning_token_ids.reshape(b, -1).to(device=dev, dtype=torch.long).contiguous()
+            nc = cids.shape[1]
+        m = Lt + nc
+        ctx = torch.empty(b, m, self.dim, dtype=bf16, device=dev)
+        mask = torch.empty(b, m, dtype=torch.uint8, device=dev)
+        wsb = L.lib().mm_context_workspace_bytes(h.ptr, b, Lt)
+        ws = torch.empty(int(wsb), dtype=torch.uint8, device=dev)
+        L.check(L.lib().mm_transformer_context(h.ptr, L.stream(), L.ptr(te), b, Lt, L.ptr(cids), nc, int(cond_drop_prob == 1),
+                                               L.ptr(ctx), L.ptr(mask), L.ptr(ws), wsb), 'mm_transformer_context')
+        if 0. < cond_drop_prob < 1.:       # per-sample text drop for training-time CFG (mmp.py:308-310, 393-399)
+            keep = (torch.rand((b, 1), device=dev) < (1. - cond_drop_prob)).to(torch.uint8)
+            mask[:, :Lt] *= keep
+        return ctx, mask
+
+    def _run(self, ids, ctx, mask, self_cond_embed=None, want_embed=True, want_logits=True):
+        h = self._model()
+        dev = self.token_emb.weight.device
+        ids = ids.to(device=dev, dtype=torch.long).contiguous()
+        b, n = ids.shape
+        assert n <= self.seq_len                                              # mmp.py:293
+        m = ctx.shape[1]
+        embed = torch.empty(b * n, self.dim, dtype=bf16, device=dev) if want_embed else None
+        logits = torch.empty(b * n, self.dim_out, dtype=torch.float32, device=dev) if want_logits else None
+        sce = None
+        if self.self_cond and exists(self_cond_embed):
+            sce = self_cond_embed.to(device=dev, dtype=torch.float32).reshape(b * n, self.dim).contiguous()
+        wsb = L.lib().mm_transformer_workspace_bytes(h.ptr, b, n, m)
+        ws = self._workspace(wsb, dev)
+        L.check(L.lib().mm_transformer_forward(h.ptr, L.stream(), L.ptr(ids), b, n, L.ptr(ctx), L.ptr(mask), m, L.ptr(sce),
+                                               L.ptr(embed), L.ptr(logits), L.ptr(ws), ws.numel()), 'mm_transformer_forward')
+        return embed, logits
+
+    # ---- reference surface
+    def forward_with_cond_scale(self, *args, cond_scale=3., return_embed=False, **kwargs):
+        """mmp.py:240-259.  Both passes run to the final LayerNorm; to_logits and the guidance combine
+        null + (cond - null) * cond_scale are one fused MFMA GEMM (mm_gemm_cfg_logits)."""
+        if cond_scale == 1:
+            return self.forward(*args, return_embed=return_embed, cond_drop_prob=0., **kwargs)
+        x = args[0] if args else kwargs.pop('x')
+        b, n = x.shape
+        emb_c = self.forward(x, *args[1:], _embed_only=True, cond_drop_prob=0., **kwargs)
+        emb_n = self.forward(x, *args[1:], _embed_only=True, cond_drop_prob=1., **kwargs)
+        h = self._model()
+        scaled = ops.gemm_cfg_logits(emb_c, emb_n, h.packed['wl'], cond_scale).reshape(b, n, self.dim_out)
+        if return_embed:
+            return scaled, emb_c.float().reshape(b, n, self.dim)
+        return scaled
+
+    def forward_with_neg_prompt(self, text_embed: torch.Tensor, neg_text_embed: torch.Tensor, cond_scale=3., return_embed=False, **kwargs):
+        # the reference implementation of this method cannot run (mmp.py:261-277 uses undefined names)
+        raise NotImplementedError('forward_with_neg_prompt is broken in the reference (undefined *args / scaled_logits); no parity target')
+
+    @torch.no_grad()
+    def forward(self, x, return_embed=False, return_logits=False, labels=None, ignore_index=0, self_cond_embed=None,
+                cond_drop_prob=0., conditioning_token_ids: Optional[torch.Tensor] = None, texts: Optional[List[str]] = None,
+                text_embeds: Optional[torch.Tensor] = None, _embed_only=False):
+        """mmp.py:279-348, inference branches.  Returns fp32 logits (b, n, dim_out) [and the fp32 view of the
+        bf16 embed]; `_embed_only` (internal) returns the bf16 [b*n, dim] embed for the fused CFG GEMM."""
+        b, n = x.shape
+        assert n <= self.seq_len
+        assert exists(texts) ^ exists(text_embeds)
+        if exists(texts):
+            text_embeds = self.encode_text(texts)
+        ctx, mask = self._context(text_embeds, conditioning_token_ids, cond_drop_prob)
+        if _embed_only:
+            embed, _ = self._run(x, ctx, mask, self_cond_embed, want_embed=True, want_logits=False)
+            return embed
+        if exists(labels):
+            raise NotImplementedError('training losses (mmp.py:337-348) are the next scope row (SURVEY 8f-1); this build is the '
+                                      'inference hot path')
+        embed, logits = self._run(x, ctx, mask, self_cond_embed)
+        logits = logits.reshape(b, n, self.dim_out)
+        if return_embed:
+            return logits, embed.float().reshape(b, n, self.dim)
+        return logits
+
+
+class SelfCritic(nn.Module):
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+        self.to_pred = nn.Linear(net.dim, 1)
+
+    def forward(self, *a, **k):
+        raise NotImplementedError('token-critic scoring is a later scope row (SURVEY 8f-2)')
+
+
+class MaskGitTransformer(Transformer):
+    def __init__(self, *args, **kwargs):
+        assert 'add_mask_id' not in kwargs
+        super().__init__(*args, add_mask_id=True, **kwargs)
+
+
+class TokenCritic(Transformer):
+    def __init__(self, *args, **kwargs):
+        assert 'dim_out' not in kwargs
+        super().__init__(*args, dim_out=1, **kwargs)
+
+
+# ------------------------------------------------------------------------------------------------ MaskGit
+
+class MaskGit(nn.Module):
+    def __init__(self, image_size, transformer: MaskGitTransformer, noise_schedule: Callable = cosine_schedule,
+                 token_critic: Optional[TokenCritic] = None, self_token_critic=False, vae: Optional[VQGanVAE] = None,
+                 cond_vae: Optional[VQGanVAE] = None, cond_image_size=None, cond_drop_prob=0.5, self_cond_prob=0.9,
+                 no_mask_token_prob=0., critic_loss_weight=1.):
+        super().__init__()
+        if not isinstance(transformer, MaskGitTransformer):
+            raise TypeError('transformer must be a MaskGitTransformer')        # what @beartype enforces (mmp.py:427-432)
+        if exists(vae) and not isinstance(vae, VQGanVAE):
+            raise TypeError('vae must be a VQGanVAE')
+        self.vae = vae.copy_for_eval() if exists(vae) else None
+        self.cond_vae = cond_vae.eval() if exists(cond_vae) else self.vae
+        assert not (exists(cond_vae) and not exists(cond_image_size)), 'cond_image_size must be specified if conditioning'
+        self.image_size = image_size
+        self.cond_image_size = cond_image_size
+        self.resize_image_for_cond_image = exists(cond_image_size)
+        self.cond_drop_prob = cond_drop_prob
+        self.transformer = transformer
+        self.self_cond = transformer.self_cond
+        if exists(self.vae):
+            assert self.vae.codebook_size == self.cond_vae.codebook_size == transformer.num_tokens, \
+                'transformer num_tokens must be set to be equal to the vae codebook size'
+        self.mask_id = transformer.mask_id
+        self.noise_schedule = noise_schedule
+        assert not (self_token_critic and exists(token_critic))
+        self.token_critic = token_critic
+        if self_token_critic:
+            self.token_critic = SelfCritic(transformer)
+        self.critic_loss_weight = critic_loss_weight
+        self.self_cond_prob = self_cond_prob
+        self.no_mask_token_prob = no_mask_token_prob
+        self._gen_ws = None
+
+    def save(self, path):
+        torch.save(self.state_dict(), path)
+
+    def load(self, path):
+        path = Path(path)
+        assert path.exists()
+        self.load_state_dict(torch.load(str(path)))
+
+    def _mask_counts(self, timesteps, seq_len, device='cpu'):
+        """mmp.py:556-559 with the user's noise_schedule, evaluated up front instead of one host sync per step."""
+        out = []
+        for t in torch.linspace(0, 1, timesteps):
+            out.append(max(int((self.noise_schedule(t) * seq_len).item()), 1))
+        return out
+
+    @torch.no_grad()
+    @eval_decorator
+    def generate(self, texts: List[str], negative_texts: Optional[List[str]] = None, cond_images: Optional[torch.Tensor] = None,
+                 fmap_size=None, temperature=1., topk_filter_thres=0.9, can_remask_prev_masked=False,
+                 force_not_use_token_critic=False, timesteps=18, cond_scale=3, critic_noise_scale=1,
+                 *, text_embeds: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None, noise_kind: str = 'philox',
+                 seed: Optional[int] = None, row_offset: int = 0, return_ids: bool = False, trace: Optional[dict] = None):
+        """mmp.py:491-621.  Keyword-only extras (not in the reference): `text_embeds` bypasses the T5 call,
+        `noise` (+ `noise_kind` 'gumbel' | 'uniform') injects the per-step noise tensor [T,B,n,V] for parity runs,
+        `seed` / `row_offset` key the on-device Philox stream (row_offset = global index of this shard's first
+        sample, so sharded runs reproduce the unsharded ids), `trace` receives per-step states."""
+        tr = self.transformer
+        use_token_critic = exists(self.token_critic) and not force_not_use_token_critic
+        if use_token_critic or exists(negative_texts) or can_remask_prev_masked or self.self_cond or cond_scale == 1:
+            raise NotImplementedError('token critic / negative prompts / remasking / self-conditioning / cond_scale=1 decode '
+                                      'variants are later scope rows (SURVEY 8f-2); the fused MI355X loop covers the default path')
+        if exists(fmap_size):
+            fmap = fmap_size
+        else:
+            fmap = self.vae.get_encoded_fmap_size(self.image_size)
+        dev = tr.token_emb.weight.device
+        seq_len = fmap ** 2
+        if not exists(text_embeds):
+            text_embeds = tr.encode_text(texts)
+        te = text_embeds.to(device=dev, dtype=torch.float32).contiguous()
+        B, Lt, _ = te.shape
+        cond_ids, nc = None, 0
+        if self.resize_image_for_cond_image:
+            assert exists(cond_images), 'conditioning image must be passed in to generate for super res maskgit'
+            _, cond_ids, _ = self.cond_vae.encode(cond_images)
+            cond_ids = cond_ids.reshape(B, -1).contiguous()
+            nc = cond_ids.shape[1]
+        h = tr._model()
+        counts = self._mask_counts(timesteps, seq_len)
+        temps = ops.step_temperatures(timesteps, temperature)
+        V = tr.dim_out
+        k_keep = math.ceil((1 - topk_filter_thres) * V)                       # mmp.py:414
+        p = L.GenerateParams()
+        p.batch, p.n, p.timesteps, p.k_keep, p.nc, p.L = B, seq_len, timesteps, k_keep, nc, Lt
+        p.cond_scale = float(cond_scale)
+        kinds = dict(none=L.MM_NOISE_NONE, gumbel=L.MM_NOISE_GUMBEL, uniform=L.MM_NOISE_UNIFORM, philox=L.MM_NOISE_PHILOX)
+        p.noise_kind = kinds[noise_kind] if not exists(noise) or noise_kind != 'philox' else L.MM_NOISE_UNIFORM
+        if exists(noise):
+            noise = noise.to(device=dev, dtype=torch.float32).contiguous()
+            assert noise.shape == (timesteps, B, seq_len, V), f'noise must be [T,B,n,V], got {tuple(noise.shape)}'
+            assert p.noise_kind in (L.MM_NOISE_GUMBEL, L.MM_NOISE_UNIFORM)
+        if not exists(seed):
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())                # follows torch.manual_seed
+        p.seed, p.row_offset = seed, row_offset
+        cnt_arr = (C.c_int32 * timesteps)(*counts)
+        tmp_arr = (C.c_float * timesteps)(*temps)
+        p.mask_counts, p.temperatures = cnt_arr, tmp_arr
+        ids = torch.empty(B, seq_len, dtype=torch.long, device=dev)
+        scores = torch.empty(B, seq_len, dtype=torch.float32, device=dev)
+        p.text_embeds, p.cond_ids, p.noise, p.ids, p.scores = L.ptr(te), L.ptr(cond_ids), L.ptr(noise), L.ptr(ids), L.ptr(scores)
+        if trace is not None:
+            trace['masked_ids'] = torch.empty(timesteps, B, seq_len, dtype=torch.long, device=dev)
+            trace['ids'] = torch.empty(timesteps, B, seq_len, dtype=torch.long, device=dev)
+            trace['scores'] = torch.empty(timesteps, B, seq_len, dtype=torch.float32, device=dev)
+            trace['counts'], trace['temperatures'] = counts, temps
+            p.trace_masked_ids, p.trace_ids, p.trace_scores = L.ptr(trace['masked_ids']), L.ptr(trace['ids']), L.ptr(trace['scores'])
+        wsb = L.lib().mm_generate_workspace_bytes(h.ptr, B, seq_len, Lt, nc)
+        if self._gen_ws is None or self._gen_ws.numel() < wsb or self._gen_ws.device != dev:
+            self._gen_ws = torch.empty(int(wsb), dtype=torch.uint8, device=dev)
+        L.check(L.lib().mm_generate(h.ptr, L.stream(), C.byref(p), L.ptr(self._gen_ws), self._gen_ws.numel()), 'mm_generate')
+        ids = ids.reshape(B, fmap, fmap)                                       # mmp.py:615
+        if return_ids or not exists(self.vae):
+            return ids
+        return self.vae.decode_from_ids(ids)                                   # mmp.py:620
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError('MaskGit training loss (mmp.py:623-741) is the next scope row (SURVEY 8f-1)')
+
+
+class Muse(nn.Module):
+    def __init__(self, base: MaskGit, superres: MaskGit):
+        super().__init__()
+        if not isinstance(base, MaskGit) or not isinstance(superres, MaskGit):
+            raise TypeError('base and superres must be MaskGit instances')
+        self.base_maskgit = base.eval()
+        assert superres.resize_image_for_cond_image
+        self.superres_maskgit = superres.eval()
+
+    @torch.no_grad()
+    def forward(self, texts: List[str], cond_scale=3., temperature=1., timesteps=18, superres_timesteps=None,
+                return_lowres=False, return_pil_images=True):
+        """mmp.py:758-791."""
+        lowres_image = self.base_maskgit.generate(texts=texts, cond_scale=cond_scale, temperature=temperature, timesteps=timesteps)
+        superres_image = self.superres_maskgit.generate(texts=texts, cond_scale=cond_scale, cond_images=lowres_image,
+                                                        temperature=temperature, timesteps=default(superres_timesteps, timesteps))
+        if return_pil_images:
+            try:
+                import torchvision.transforms as T
+            except ImportError as e:
+                raise RuntimeError('return_pil_images=True needs torchvision (absent here); pass return_pil_images=False') from e
+            lowres_image = list(map(T.ToPILImage(), lowres_image))
+            superres_image = list(map(T.ToPILImage(), superres_image))
+        if not return_lowres:
+            return superres_image
+        return superres_image, lowres_image

@@ -1,0 +1,256 @@
+"""Tensor-level wrappers over the C ABI (include/muse_hip.h).  torch supplies device memory and the stream only;
+every computation below happens inside libmuse_hip.so.  All tensors must live on the current gfx950 device."""
+import math
+
+import torch
+
+from . import _lib as L
+
+bf16 = torch.bfloat16
+
+
+def _chk_cuda(*ts):
+    L.require_device()
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.MuseHipError('tensor is not on the GPU: the muse_maskgit_pytorch_amd ops have no CPU path')
+
+
+def pad_cols(t, mult):
+    """zero-pad the last dim to a multiple of `mult` (contiguous copy)."""
+    k = t.shape[-1]
+    kp = (k + mult - 1) // mult * mult
+    if kp == k:
+        return t.contiguous()
+    out = torch.zeros(*t.shape[:-1], kp, dtype=t.dtype, device=t.device)
+    out[..., :k] = t
+    return out
+
+
+def gemm(x, w, out_f32=False, resid=None, out=None):
+    """x bf16 [M,K] @ w bf16 [N,K]^T -> [M,N] (bf16 or fp32); resid fp32 [M,N] added in the epilogue."""
+    _chk_cuda(x, w, resid)
+    assert x.dtype == bf16 and w.dtype == bf16 and x.stride(-1) == 1 and w.stride(-1) == 1
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32 if out_f32 else bf16, device=x.device)
+    L.check(L.lib().mm_gemm_bf16(L.stream(), L.ptr(x), x.stride(0), L.ptr(w), w.stride(0), M, N, K, L.ptr(out),
+                                 out.stride(0), int(out_f32), L.ptr(resid)), 'mm_gemm_bf16')
+    return out
+
+
+def gemm_cfg_logits(x_cond, x_null, w, cond_scale, out=None):
+    _chk_cuda(x_cond, x_null, w)
+    M, K = x_cond.shape
+    N = w.shape[0]
+    assert x_null.shape == x_cond.shape and x_cond.stride(0) == x_null.stride(0)
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=w.device)
+    L.check(L.lib().mm_gemm_cfg_logits(L.stream(), L.ptr(x_cond), L.ptr(x_null), x_cond.stride(0), L.ptr(w), w.stride(0),
+                                       M, N, K, L.ptr(out), out.stride(0), float(cond_scale)), 'mm_gemm_cfg_logits')
+    return out
+
+
+def embed(ids, token_emb, pos_emb):
+    _chk_cuda(ids, token_emb, pos_emb)
+    b, n = ids.shape
+    D = token_emb.shape[1]
+    x = torch.empty(b * n, D, dtype=torch.float32, device=ids.device)
+    L.check(L.lib().mm_embed(L.stream(), L.ptr(ids.contiguous()), b * n, n, L.ptr(token_emb), token_emb.shape[0],
+                             L.ptr(pos_emb), D, L.ptr(x)), 'mm_embed')
+    return x
+
+
+def layernorm(x, gamma, beta=None, row_index=None):
+    _chk_cuda(x, gamma, beta, row_index)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    rows = x.shape[0] if row_index is None else row_index.numel()
+    D = x.shape[1]
+    out = torch.empty(rows, D, dtype=bf16, device=x.device)
+    L.check(L.lib().mm_layernorm(L.stream(), L.ptr(x), x.stride(0), rows, D, L.ptr(gamma), L.ptr(beta), L.ptr(row_index),
+                                 L.ptr(out), D), 'mm_layernorm')
+    return out
+
+
+def geglu_ln(h, F, gamma, beta=None):
+    _chk_cuda(h, gamma, beta)
+    rows, two_fp = h.shape
+    Fp = two_fp // 2
+    out = torch.empty(rows, Fp, dtype=bf16, device=h.device)
+    L.check(L.lib().mm_geglu_ln(L.stream(), L.ptr(h), h.stride(0), rows, F, Fp, L.ptr(gamma), L.ptr(beta), L.ptr(out), Fp),
+            'mm_geglu_ln')
+    return out
+
+
+def attend(q, k, v, key_mask=None, scale=8.0, normalize=False, q_scale=None, k_scale=None, null_k=None, null_v=None):
+    """q (b,h,n,64), k/v (b,h,j,64) bf16 with arbitrary batch/head/token strides (d contiguous); key_mask (b,j) bool/uint8."""
+    _chk_cuda(q, k, v, key_mask)
+    assert q.dtype == bf16 and k.dtype == bf16 and v.dtype == bf16
+    b, h, n, d = q.shape
+    j = k.shape[2]
+    assert d == 64 and q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1
+    out = torch.empty(b, h, n, d, dtype=bf16, device=q.device)
+    km = None
+    if key_mask is not None:
+        km = key_mask.to(torch.uint8).contiguous()
+        assert km.shape == (b, j)
+    L.check(L.lib().mm_attend(L.stream(), L.ptr(q), q.stride(0), q.stride(1), q.stride(2), L.ptr(k), k.stride(0), k.stride(1),
+                              k.stride(2), L.ptr(v), v.stride(0), v.stride(1), v.stride(2), L.ptr(out), out.stride(0),
+                              out.stride(1), out.stride(2), b, h, n, j, L.ptr(km), j, int(normalize), L.ptr(q_scale),
+                              L.ptr(k_scale), L.ptr(null_k), L.ptr(null_v), float(scale)), 'mm_attend')
+    return out
+
+
+def mask_step(scores, ids, k, mask_id, want_rows=True):
+    """in place on scores / ids; returns int32 [B*k] flat positions of the masked tokens."""
+    _chk_cuda(scores, ids)
+    B, n = scores.shape
+    assert scores.is_contiguous() and ids.is_contiguous() and ids.dtype == torch.long and scores.dtype == torch.float32
+    rows = torch.empty(B * k, dtype=torch.int32, device=scores.device) if want_rows else None
+    L.check(L.lib().mm_mask_step(L.stream(), L.ptr(scores), L.ptr(ids), B, n, k, int(mask_id), L.ptr(rows)), 'mm_mask_step')
+    return rows
+
+
+def sample_rows(logits, k_keep, temperature, rows=None, noise_kind=L.MM_NOISE_NONE, noise=None, seed=0, row_offset=0,
+                step=0, ids=None, scores=None):
+    """logits fp32 [R,V]; returns (pred int64 [R], score fp32 [R]) and scatters into ids/scores when given."""
+    _chk_cuda(logits, rows, noise, ids, scores)
+    R, V = logits.shape
+    pred = torch.empty(R, dtype=torch.long, device=logits.device)
+    sc = torch.empty(R, dtype=torch.float32, device=logits.device)
+    noise_ld = 0
+    if noise is not None:
+        assert noise.dtype == torch.float32 and noise.stride(-1) == 1
+        noise_ld = noise.shape[-1]
+    L.check(L.lib().mm_sample_rows(L.stream(), L.ptr(logits), logits.stride(0), R, V, int(k_keep), L.ptr(rows),
+                                   float(temperature), int(noise_kind), L.ptr(noise), noise_ld, int(seed), int(row_offset),
+                                   int(step), L.ptr(ids), L.ptr(scores), L.ptr(pred), L.ptr(sc)), 'mm_sample_rows')
+    return pred, sc
+
+
+def philox_uniform(seed, row_offset, step, rows, V, device):
+    L.require_device()
+    out = torch.empty(rows, V, dtype=torch.float32, device=device)
+    L.check(L.lib().mm_philox_uniform(L.stream(), int(seed), int(row_offset), int(step), rows, V, L.ptr(out)), 'mm_philox_uniform')
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ VAE ops (NHWC bf16)
+
+def conv2d_nhwc(x, w_packed, cout, th, tw, stride=1, off=(0, 0), out_hw=None, os_=1, parity=(0, 0), full_hw=None, bias=None,
+                act=False, resid=None, out=None, out_nchw_f32=False):
+    """x bf16 [B,H,W,Cin]; w_packed bf16 [Cout, Kp] (see pack_conv_weight).  Returns NHWC bf16 (or NCHW fp32)."""
+    _chk_cuda(x, w_packed, bias, resid, out)
+    B, H, W, Cin = x.shape
+    Hv, Wv = out_hw if out_hw is not None else (H, W)
+    Hout, Wout = full_hw if full_hw is not None else (Hv * os_, Wv * os_)
+    if out is None:
+        if out_nchw_f32:
+            out = torch.empty(B, cout, Hout, Wout, dtype=torch.float32, device=x.device)
+        else:
+            out = torch.empty(B, Hout, Wout, cout, dtype=bf16, device=x.device)
+    L.check(L.lib().mm_conv2d_nhwc(L.stream(), L.ptr(x), B, H, W, Cin, L.ptr(w_packed), cout, th, tw, stride, off[0], off[1],
+                                   Hv, Wv, os_, parity[0], parity[1], Hout, Wout, L.ptr(bias), int(act), L.ptr(resid),
+                                   L.ptr(out), int(out_nchw_f32)), 'mm_conv2d_nhwc')
+    return out
+
+
+def glu_nhwc(x):
+    _chk_cuda(x)
+    C2 = x.shape[-1]
+    rows = x.numel() // C2
+    out = torch.empty(*x.shape[:-1], C2 // 2, dtype=bf16, device=x.device)
+    L.check(L.lib().mm_glu_nhwc(L.stream(), L.ptr(x), rows, C2 // 2, L.ptr(out)), 'mm_glu_nhwc')
+    return out
+
+
+def groupnorm_nhwc(x, groups, gamma, beta, act=False):
+    _chk_cuda(x, gamma, beta)
+    B, H, W, Cc = x.shape
+    out = torch.empty_like(x)
+    ws = torch.empty(B * groups * 2, dtype=torch.float32, device=x.device)
+    L.check(L.lib().mm_groupnorm_nhwc(L.stream(), L.ptr(x), B, H * W, Cc, groups, L.ptr(gamma), L.ptr(beta), int(act), L.ptr(ws),
+                                      L.ptr(out)), 'mm_groupnorm_nhwc')
+    return out
+
+
+def lfq_decode(ids, bits, C, w=None, b=None):
+    _chk_cuda(ids, w, b)
+    ids = ids.contiguous()
+    out = torch.empty(*ids.shape, C, dtype=bf16, device=ids.device)
+    L.check(L.lib().mm_lfq_decode(L.stream(), L.ptr(ids), ids.numel(), bits, C, L.ptr(w), L.ptr(b), L.ptr(out)), 'mm_lfq_decode')
+    return out
+
+
+def lfq_encode(x, bits, w_in=None, b_in=None, w_out=None, b_out=None):
+    """x bf16 [..., C] -> (ids int64 [...], quantized bf16 [..., C])."""
+    _chk_cuda(x)
+    C = x.shape[-1]
+    count = x.numel() // C
+    ids = torch.empty(x.shape[:-1], dtype=torch.long, device=x.device)
+    out = torch.empty_like(x)
+    L.check(L.lib().mm_lfq_encode(L.stream(), L.ptr(x), count, C, bits, L.ptr(w_in), L.ptr(b_in), L.ptr(w_out), L.ptr(b_out),
+                                  L.ptr(ids), L.ptr(out)), 'mm_lfq_encode')
+    return ids, out
+
+
+def nchw_to_nhwc8(img):
+    _chk_cuda(img)
+    B, Cc, H, W = img.shape
+    out = torch.empty(B, H, W, 8, dtype=bf16, device=img.device)
+    L.check(L.lib().mm_nchw_f32_to_nhwc8_bf16(L.stream(), L.ptr(img.contiguous().float()), B, Cc, H, W, L.ptr(out)), 'nchw_to_nhwc8')
+    return out
+
+
+def nhwc_to_nchw_f32(x):
+    _chk_cuda(x)
+    B, H, W, Cc = x.shape
+    out = torch.empty(B, Cc, H, W, dtype=torch.float32, device=x.device)
+    L.check(L.lib().mm_nhwc_bf16_to_nchw_f32(L.stream(), L.ptr(x), B, Cc, H, W, L.ptr(out)), 'nhwc_to_nchw')
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ weight packing (host side, once)
+
+def pack_conv_weight(w):
+    """Conv2d weight [Cout, Cin, TH, TW] -> bf16 [Cout, Kp], k = (ty*TW + tx)*Cin + ci, Kp = ceil64(TH*TW*Cin)."""
+    cout = w.shape[0]
+    return pad_cols(w.permute(0, 2, 3, 1).reshape(cout, -1).to(bf16), 64)
+
+
+def pack_conv_weight_cin8(w):
+    """first conv (Cin = image channels <= 8): pad Cin to 8 to match the NHWC8 image layout."""
+    cout, cin, th, tw = w.shape
+    wp = torch.zeros(cout, 8, th, tw, dtype=w.dtype, device=w.device)
+    wp[:, :cin] = w
+    return pack_conv_weight(wp)
+
+
+def pack_convT_weight(w):
+    """ConvTranspose2d(4,2,1) weight [Cin, Cout, 4, 4] -> four bf16 [Cout, Kp] matrices, one per output parity (py,px):
+    out[2y+py, 2x+px] = sum_{ty,tx in 0..1} in[y+ty-1+py, x+tx-1+px] . w[:, :, 3-py-2ty, 3-px-2tx]."""
+    packs = {}
+    for py in range(2):
+        for px in range(2):
+            taps = []
+            for ty in range(2):
+                for tx in range(2):
+                    taps.append(w[:, :, 3 - py - 2 * ty, 3 - px - 2 * tx].t())      # [Cout, Cin]
+            packs[(py, px)] = pad_cols(torch.cat(taps, dim=1).to(bf16), 64)
+    return packs
+
+
+def mask_counts(timesteps, seq_len):
+    """muse_maskgit_pytorch.py:556-559 evaluated on the host once (the reference syncs the device every step for this):
+    same fp32 linspace / cos, python int() truncation, max(., 1)."""
+    out = []
+    for t in torch.linspace(0, 1, timesteps):
+        out.append(max(int((torch.cos(t * math.pi * 0.5) * seq_len).item()), 1))
+    return out
+
+
+def step_temperatures(timesteps, temperature):
+    """muse_maskgit_pytorch.py:578 + the clamp of :411."""
+    return [max(temperature * (s / timesteps), 1e-10) for s in reversed(range(timesteps))]

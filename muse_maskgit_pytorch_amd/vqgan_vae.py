@@ -1,0 +1,263 @@
+"""VQGanVAE drop-in (inference path) for MI355X.
+
+Mirrors the reference's class surface and checkpoint key names (vqgan_vae.py:185-441): `encode`, `decode`,
+`decode_from_ids`, `get_encoded_fmap_size`, `copy_for_eval`, `codebook_size`, `save` / `load`.  The nn modules
+below are parameter containers only (fp32, reference key names); all arithmetic runs through libmuse_hip.so on
+NHWC bf16 activations: implicit-GEMM MFMA convolutions, ConvTranspose2d(4,2,1) as four parity 2x2 convolutions,
+GLU / GroupNorm / LFQ kernels.  Training (`forward(return_loss=...)`, discriminator, VGG) is out of scope
+ and raises.
+"""
+import copy
+import math
+from pathlib import Path
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+def leaky_relu(p=0.1):
+    return nn.LeakyReLU(0.1)      # the reference ignores p (vqgan_vae.py:103-104)
+
+
+class GLUResBlock(nn.Module):
+    def __init__(self, chan, groups=16):
+        super().__init__()
+        self.net = nn.Sequential(nn.Conv2d(chan, chan * 2, 3, padding=1), nn.GLU(dim=1), nn.GroupNorm(groups, chan),
+                                 nn.Conv2d(chan, chan * 2, 3, padding=1), nn.GLU(dim=1), nn.GroupNorm(groups, chan),
+                                 nn.Conv2d(chan, chan, 1))
+        self.groups = groups
+
+
+class ResBlock(nn.Module):
+    def __init__(self, chan, groups=16):
+        super().__init__()
+        self.net = nn.Sequential(nn.Conv2d(chan, chan, 3, padding=1), nn.GroupNorm(groups, chan), leaky_relu(),
+                                 nn.Conv2d(chan, chan, 3, padding=1), nn.GroupNorm(groups, chan), leaky_relu(),
+                                 nn.Conv2d(chan, chan, 1))
+        self.groups = groups
+
+
+class Discriminator(nn.Module):
+    """Parameter container so that reference training checkpoints load with strict key matching
+    (vqgan_vae.py:150-181).  Not on the hot path: no forward."""
+
+    def __init__(self, dims, channels=3, groups=16, init_kernel_size=5):
+        super().__init__()
+        self.layers = nn.ModuleList([nn.Sequential(nn.Conv2d(channels, dims[0], init_kernel_size, padding=init_kernel_size // 2), leaky_relu())])
+        for dim_in, dim_out in zip(dims[:-1], dims[1:]):
+            self.layers.append(nn.Sequential(nn.Conv2d(dim_in, dim_out, 4, stride=2, padding=1), nn.GroupNorm(groups, dim_out), leaky_relu()))
+        dim = dims[-1]
+        self.to_logits = nn.Sequential(nn.Conv2d(dim, dim, 1), leaky_relu(), nn.Conv2d(dim, 1, 4))
+
+    def forward(self, x):
+        raise NotImplementedError('VQGAN training (discriminator) is outside the MI355X hot path')
+
+
+class ResnetEncDec(nn.Module):
+    """Same layer list / key names as the reference (vqgan_vae.py:185-249)."""
+
+    def __init__(self, dim, *, channels=3, layers=4, layer_mults=None, num_resnet_blocks=1, resnet_groups=16,
+                 first_conv_kernel_size=5):
+        super().__init__()
+        assert dim % resnet_groups == 0, f'dimension {dim} must be divisible by {resnet_groups} (groups for the groupnorm)'
+        self.layers = layers
+        self.encoders = nn.ModuleList([])
+        self.decoders = nn.ModuleList([])
+        layer_mults = layer_mults if layer_mults is not None else [2 ** t for t in range(layers)]
+        assert len(layer_mults) == layers, 'layer multipliers must be equal to designated number of layers'
+        dims = (dim, *[dim * m for m in layer_mults])
+        self.encoded_dim = dims[-1]
+        if not isinstance(num_resnet_blocks, tuple):
+            num_resnet_blocks = (*((0,) * (layers - 1)), num_resnet_blocks)
+        assert len(num_resnet_blocks) == layers, 'number of resnet blocks config must be equal to number of layers'
+        for (dim_in, dim_out), nblocks in zip(zip(dims[:-1], dims[1:]), num_resnet_blocks):
+            self.encoders.append(nn.Sequential(nn.Conv2d(dim_in, dim_out, 4, stride=2, padding=1), leaky_relu()))
+            self.decoders.insert(0, nn.Sequential(nn.ConvTranspose2d(dim_out, dim_in, 4, 2, 1), leaky_relu()))
+            for _ in range(nblocks):
+                self.encoders.append(ResBlock(dim_out, groups=resnet_groups))
+                self.decoders.insert(0, GLUResBlock(dim_out, groups=resnet_groups))
+        self.encoders.insert(0, nn.Conv2d(channels, dim, first_conv_kernel_size, padding=first_conv_kernel_size // 2))
+        self.decoders.append(nn.Conv2d(dim, channels, 1))
+
+    def get_encoded_fmap_size(self, image_size):
+        return image_size // (2 ** self.layers)
+
+    @property
+    def last_dec_layer(self):
+        return self.decoders[-1].weight
+
+
+class LFQ(nn.Module):
+    """Parameter container for the lookup-free quantizer the reference takes from vector-quantize-pytorch
+    (vqgan_vae.py:331-335): project_in / project_out Linear (+bias) and the bit-weight buffer `mask`."""
+
+    def __init__(self, *, dim, codebook_size, **_):
+        super().__init__()
+        assert codebook_size & (codebook_size - 1) == 0, 'LFQ codebook size must be a power of two'
+        self.codebook_dim = int(math.log2(codebook_size))
+        self.dim = dim
+        has_proj = dim != self.codebook_dim
+        self.project_in = nn.Linear(dim, self.codebook_dim) if has_proj else nn.Identity()
+        self.project_out = nn.Linear(self.codebook_dim, dim) if has_proj else nn.Identity()
+        self.register_buffer('mask', 2 ** torch.arange(self.codebook_dim - 1, -1, -1))
+
+
+class VQGanVAE(nn.Module):
+    def __init__(self, *, dim, channels=3, layers=4, l2_recon_loss=False, use_hinge_loss=True, vgg=None,
+                 lookup_free_quantization=True, codebook_size=65536,
+                 vq_kwargs: dict = dict(codebook_dim=256, decay=0.8, commitment_weight=1., kmeans_init=True, use_cosine_sim=True),
+                 lfq_kwargs: dict = dict(diversity_gamma=4.), use_vgg_and_gan=True, discr_layers=4, **kwargs):
+        super().__init__()
+        encdec_kwargs = {k[len('encdec_'):]: v for k, v in kwargs.items() if k.startswith('encdec_')}
+        self.channels = channels
+        self.codebook_size = codebook_size
+        self.dim_divisor = 2 ** layers
+        self.enc_dec = ResnetEncDec(dim=dim, channels=channels, layers=layers, **encdec_kwargs)
+        self.lookup_free_quantization = lookup_free_quantization
+        if not lookup_free_quantization:
+            # the reference's VectorQuantize branch cannot be constructed (vqgan_vae.py:337-342 is a TypeError)
+            raise NotImplementedError('only lookup_free_quantization=True is executable in the reference')
+        self.quantizer = LFQ(dim=self.enc_dec.encoded_dim, codebook_size=codebook_size, **lfq_kwargs)
+        self._vgg = None
+        self.discr = None
+        self.use_vgg_and_gan = use_vgg_and_gan
+        if use_vgg_and_gan:
+            dims = (dim, *[dim * 2 ** t for t in range(discr_layers)])
+            self.discr = Discriminator(dims=dims, channels=channels)
+        self._packed = None
+
+    # ---- reference surface
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @property
+    def encoded_dim(self):
+        return self.enc_dec.encoded_dim
+
+    def get_encoded_fmap_size(self, image_size):
+        return self.enc_dec.get_encoded_fmap_size(image_size)
+
+    def copy_for_eval(self):
+        """vqgan_vae.py:394-403 (including its side effect of moving the caller's VAE to CPU)."""
+        device = next(self.parameters()).device
+        self._packed = None
+        vae_copy = copy.deepcopy(self.cpu())
+        if vae_copy.use_vgg_and_gan:
+            del vae_copy.discr
+            del vae_copy._vgg
+        vae_copy.eval()
+        return vae_copy.to(device)
+
+    def save(self, path):
+        torch.save(self.state_dict(), path)
+
+    def load(self, path):
+        path = Path(path)
+        assert path.exists()
+        self.load_state_dict(torch.load(str(path)))
+
+    # ---- packed (bf16, kernel layout) weights, rebuilt when parameters change
+    def _pack(self):
+        key = (str(self.device),) + tuple(p._version for p in self.parameters())
+        if self._packed is not None and self._packed['key'] == key:
+            return self._packed
+        ed = self.enc_dec
+        f32 = lambda t: t.detach().float().contiguous()
+        P = dict(key=key, enc=[], dec=[])
+        enc0 = ed.encoders[0]
+        P['stem'] = dict(w=ops.pack_conv_weight_cin8(enc0.weight.detach()), b=f32(enc0.bias), k=enc0.kernel_size[0], cout=enc0.out_channels)
+        for i in range(1, ed.layers + 1):
+            c = ed.encoders[i][0]
+            P['enc'].append(dict(w=ops.pack_conv_weight(c.weight.detach()), b=f32(c.bias), cout=c.out_channels))
+
+        def pack_block(net, idx_convs, idx_gns):
+            out = dict(convs=[], gns=[])
+            for i in idx_convs:
+                out['convs'].append(dict(w=ops.pack_conv_weight(net[i].weight.detach()), b=f32(net[i].bias), cout=net[i].out_channels,
+                                         k=net[i].kernel_size[0]))
+            for i in idx_gns:
+                out['gns'].append(dict(g=f32(net[i].weight), b=f32(net[i].bias), groups=net[i].num_groups))
+            return out
+
+        P['enc_res'] = [pack_block(m.net, (0, 3, 6), (1, 4)) for m in ed.encoders[ed.layers + 1:]]
+        n_glu = len(ed.decoders) - ed.layers - 1
+        P['dec_res'] = [pack_block(m.net, (0, 3, 6), (2, 5)) for m in ed.decoders[:n_glu]]
+        for m in ed.decoders[n_glu:n_glu + ed.layers]:
+            ct = m[0]
+            P['dec'].append(dict(w=ops.pack_convT_weight(ct.weight.detach()), b=f32(ct.bias), cout=ct.out_channels))
+        last = ed.decoders[-1]
+        P['head'] = dict(w=ops.pack_conv_weight(last.weight.detach()), b=f32(last.bias), cout=last.out_channels)
+        q = self.quantizer
+        P['bits'] = q.codebook_dim
+        if isinstance(q.project_in, nn.Linear):
+            P['lfq'] = dict(wi=f32(q.project_in.weight), bi=f32(q.project_in.bias), wo=f32(q.project_out.weight), bo=f32(q.project_out.bias))
+        else:
+            P['lfq'] = dict(wi=None, bi=None, wo=None, bo=None)
+        self._packed = P
+        return P
+
+    # ---- hot path
+    @torch.no_grad()
+    def encode(self, fmap):
+        """vqgan_vae.py:422-425: image (B,C,H,W) fp32 -> (quantized fmap (B,C',h,w) fp32, ids (B,h,w) int64, aux loss 0)."""
+        P = self._pack()
+        x = ops.nchw_to_nhwc8(fmap)
+        st = P['stem']
+        x = ops.conv2d_nhwc(x, st['w'], st['cout'], st['k'], st['k'], 1, (-(st['k'] // 2), -(st['k'] // 2)), bias=st['b'])
+        for e in P['enc']:                                        # Conv2d(4, stride 2, pad 1) + LeakyReLU(0.1)
+            B, H, W, _ = x.shape
+            x = ops.conv2d_nhwc(x, e['w'], e['cout'], 4, 4, 2, (-1, -1), out_hw=(H // 2, W // 2), bias=e['b'], act=True)
+        for r in P['enc_res']:                                    # ResBlock (vqgan_vae.py:267-281)
+            c0, c1, c2 = r['convs']
+            g0, g1 = r['gns']
+            h = ops.conv2d_nhwc(x, c0['w'], c0['cout'], 3, 3, 1, (-1, -1), bias=c0['b'])
+            h = ops.groupnorm_nhwc(h, g0['groups'], g0['g'], g0['b'], act=True)
+            h = ops.conv2d_nhwc(h, c1['w'], c1['cout'], 3, 3, 1, (-1, -1), bias=c1['b'])
+            h = ops.groupnorm_nhwc(h, g1['groups'], g1['g'], g1['b'], act=True)
+            x = ops.conv2d_nhwc(h, c2['w'], c2['cout'], 1, 1, 1, (0, 0), bias=c2['b'], resid=x)
+        lf = P['lfq']
+        ids, q = ops.lfq_encode(x, P['bits'], lf['wi'], lf['bi'], lf['wo'], lf['bo'])
+        return ops.nhwc_to_nchw_f32(q), ids, torch.zeros((), device=fmap.device)
+
+    @torch.no_grad()
+    def _decode_nhwc(self, x):
+        """ResnetEncDec.decode (vqgan_vae.py:246-249) on NHWC bf16 -> NCHW fp32 image."""
+        P = self._pack()
+        for r in P['dec_res']:                                    # GLUResBlock (vqgan_vae.py:251-265)
+            c0, c1, c2 = r['convs']
+            g0, g1 = r['gns']
+            h = ops.conv2d_nhwc(x, c0['w'], c0['cout'], 3, 3, 1, (-1, -1), bias=c0['b'])
+            h = ops.groupnorm_nhwc(ops.glu_nhwc(h), g0['groups'], g0['g'], g0['b'])
+            h = ops.conv2d_nhwc(h, c1['w'], c1['cout'], 3, 3, 1, (-1, -1), bias=c1['b'])
+            h = ops.groupnorm_nhwc(ops.glu_nhwc(h), g1['groups'], g1['g'], g1['b'])
+            x = ops.conv2d_nhwc(h, c2['w'], c2['cout'], 1, 1, 1, (0, 0), bias=c2['b'], resid=x)
+        for d in P['dec']:                                        # ConvTranspose2d(4,2,1) + LeakyReLU as 4 parity convs
+            B, H, W, _ = x.shape
+            out = torch.empty(B, 2 * H, 2 * W, d['cout'], dtype=torch.bfloat16, device=x.device)
+            for (py, px), w in d['w'].items():
+                ops.conv2d_nhwc(x, w, d['cout'], 2, 2, 1, (py - 1, px - 1), out_hw=(H, W), os_=2, parity=(py, px),
+                                full_hw=(2 * H, 2 * W), bias=d['b'], act=True, out=out)
+            x = out
+        hd = P['head']
+        return ops.conv2d_nhwc(x, hd['w'], hd['cout'], 1, 1, 1, (0, 0), bias=hd['b'], out_nchw_f32=True)
+
+    @torch.no_grad()
+    def decode_from_ids(self, ids):
+        """vqgan_vae.py:427-438: ids (B,h,w) int64 -> image (B,C,H,W) fp32 (unclamped)."""
+        P = self._pack()
+        lf = P['lfq']
+        x = ops.lfq_decode(ids, P['bits'], self.enc_dec.encoded_dim, lf['wo'], lf['bo'])     # (B,h,w,C) NHWC bf16
+        return self._decode_nhwc(x)
+
+    @torch.no_grad()
+    def decode(self, fmap):
+        """vqgan_vae.py:440-441: fmap (B,C,h,w) fp32 -> image."""
+        x = fmap.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+        return self._decode_nhwc(x)
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError('VQGAN training losses (vqgan_vae.py:443-534) are outside the MI355X hot path; '
+                                  'use encode / decode / decode_from_ids')

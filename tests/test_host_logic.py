@@ -1,0 +1,150 @@
+"""CPU tests of the host-side logic: C-ABI library surface, checkpoint compatibility, weight packing, conv
+geometry, schedule.  No kernel is launched here (there is no GPU in the build container)."""
+import ctypes as C
+import math
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import emu
+import muse_oracle as O
+from conftest import ROOT, sd_f32
+
+import muse_maskgit_pytorch_amd as mm
+from muse_maskgit_pytorch_amd import _lib, ops
+
+
+# ------------------------------------------------------------------------------------------------ C ABI surface
+def test_library_loads_and_exports_every_header_symbol():
+    lib = _lib.lib()
+    declared = _lib.header_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in include/muse_hip.h but not exported'
+    assert set(declared) == set(_lib.SIGNATURES), 'ctypes signature table out of sync with the header'
+    assert lib.mm_abi_version() == 1
+
+
+def test_abi_reports_errors_without_touching_the_gpu():
+    lib = _lib.lib()
+    # empty problems are no-ops
+    assert lib.mm_gemm_bf16(None, None, 0, None, 0, 0, 0, 64, None, 0, 0, None) == 0
+    # NULL operands -> MM_ERR_SHAPE with a message, no crash
+    rc = lib.mm_gemm_bf16(None, None, 64, None, 64, 4, 4, 64, None, 4, 0, None)
+    assert rc == -1 and b'NULL' in lib.mm_last_error()
+    rc = lib.mm_transformer_create(None, None)
+    assert rc == -1
+    assert lib.mm_transformer_workspace_bytes(None, 1, 1, 1) == 0
+
+
+def test_no_fallback_when_there_is_no_gpu():
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(_lib.MuseHipError):
+        ops.gemm(torch.zeros(4, 64, dtype=torch.bfloat16), torch.zeros(4, 64, dtype=torch.bfloat16))
+    t = mm.MaskGitTransformer(num_tokens=512, seq_len=64, dim=128, depth=1, t5_name='t5-small')
+    with pytest.raises(_lib.MuseHipError):
+        t(torch.zeros(1, 4, dtype=torch.long), text_embeds=torch.randn(1, 3, 512))
+
+
+def test_product_package_does_not_import_the_oracle():
+    src = os.path.join(ROOT, 'muse_maskgit_pytorch_amd')
+    for f in os.listdir(src):
+        if f.endswith('.py'):
+            text = open(os.path.join(src, f)).read()
+            assert 'muse_oracle' not in text and 'oracle/' not in text and 'reference_harness' not in text, f
+
+
+# ------------------------------------------------------------------------------------------------ checkpoints
+def test_state_dict_keys_match_reference(golden):
+    g, gv = golden('transformer_tiny.pt'), golden('vae_tiny.pt')
+    t = mm.MaskGitTransformer(t5_name='t5-small', **g['cfg'])
+    assert list(t.state_dict().keys()) == list(g['sd'].keys())
+    for k, v in t.state_dict().items():
+        assert v.shape == g['sd'][k].shape, k
+    v = mm.VQGanVAE(**gv['cfg'])
+    ve = v.copy_for_eval()
+    assert list(ve.state_dict().keys()) == list(gv['sd'].keys())
+    assert any(k.startswith('discr.') for k in v.state_dict())        # training checkpoints carry the discriminator
+    mg = mm.MaskGit(vae=v, transformer=t, image_size=128)
+    assert len(mg.state_dict()) == 45 + 45 + 58                       # vae.* + cond_vae.* (same object) + transformer.*
+    assert mg.mask_id == 512
+
+
+def test_maskgit_type_checks_like_beartype():
+    t = mm.Transformer(num_tokens=512, seq_len=64, dim=128, depth=1, t5_name='t5-small')
+    with pytest.raises(TypeError):
+        mm.MaskGit(image_size=128, transformer=t, vae=mm.VQGanVAE(dim=16, codebook_size=512))
+
+
+# ------------------------------------------------------------------------------------------------ schedule
+def test_schedule_matches_oracle_and_reference(golden):
+    for (T, n), cnt in golden('schedule.pt').items():
+        assert ops.mask_counts(T, n) == cnt == O.mask_counts(T, n)
+    assert ops.step_temperatures(18, 1.)[-1] == 1e-10
+    assert ops.step_temperatures(4, 2.) == O.step_temperatures(4, 2.)
+    t = mm.MaskGitTransformer(num_tokens=512, seq_len=64, dim=128, depth=1, t5_name='t5-small')
+    mg = mm.MaskGit(image_size=128, transformer=t, vae=mm.VQGanVAE(dim=16, codebook_size=512))
+    assert mg._mask_counts(18, 256) == O.mask_counts(18, 256)
+
+
+# ------------------------------------------------------------------------------------------------ conv packing / geometry
+def test_conv_packing_matches_torch_convs():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 16, 6, 6, generator=g)
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    # 3x3 pad 1
+    w, b = torch.randn(24, 16, 3, 3, generator=g), torch.randn(24, generator=g)
+    y = emu.conv2d_nhwc(xn, ops.pack_conv_weight(w).float(), 24, 3, 3, 1, (-1, -1), bias=b)
+    assert torch.allclose(y.permute(0, 3, 1, 2), F.conv2d(x, w.bfloat16().float(), b, padding=1), atol=1e-4)
+    # 4x4 stride 2 pad 1
+    w = torch.randn(8, 16, 4, 4, generator=g)
+    y = emu.conv2d_nhwc(xn, ops.pack_conv_weight(w).float(), 8, 4, 4, 2, (-1, -1), out_hw=(3, 3))
+    assert torch.allclose(y.permute(0, 3, 1, 2), F.conv2d(x, w.bfloat16().float(), None, stride=2, padding=1), atol=1e-4)
+    # ConvTranspose2d(4, 2, 1) as four parity 2x2 convolutions
+    wt, bt = torch.randn(16, 8, 4, 4, generator=g), torch.randn(8, generator=g)
+    out = torch.zeros(2, 12, 12, 8)
+    for (py, px), wp in ops.pack_convT_weight(wt).items():
+        emu.conv2d_nhwc(xn, wp.float(), 8, 2, 2, 1, (py - 1, px - 1), out_hw=(6, 6), os_=2, parity=(py, px), full_hw=(12, 12),
+                        bias=bt, out=out)
+    ref = F.conv_transpose2d(x, wt.bfloat16().float(), bt, stride=2, padding=1)
+    assert torch.allclose(out.permute(0, 3, 1, 2), ref, atol=1e-4)
+    # 5x5 stem on the NHWC8 image layout
+    img = torch.randn(2, 3, 6, 6, generator=g)
+    ws = torch.randn(8, 3, 5, 5, generator=g)
+    y = emu.conv2d_nhwc(emu.nchw_to_nhwc8(img), ops.pack_conv_weight_cin8(ws).float(), 8, 5, 5, 1, (-2, -2))
+    assert torch.allclose(y.permute(0, 3, 1, 2), F.conv2d(img, ws.bfloat16().float(), None, padding=2), atol=1e-4)
+
+
+def test_vae_host_orchestration_against_reference_golden(golden, monkeypatch):
+    """VQGanVAE.encode / decode_from_ids with every C-ABI op replaced by its CPU emulation must reproduce the
+    reference's outputs: validates layer order, conv geometry and weight packing of the host code."""
+    gv = golden('vae_tiny.pt')
+    emu.install(monkeypatch, ops)
+    v = mm.VQGanVAE(**gv['cfg']).copy_for_eval()
+    v.load_state_dict(sd_f32(gv['sd']))
+    dec = v.decode_from_ids(gv['ids'])
+    assert dec.shape == gv['decoded'].shape
+    assert (dec - gv['decoded']).abs().max() < 2e-4 * gv['decoded'].abs().max().clamp(min=1)
+    fmap, ids, aux = v.encode(gv['image'])
+    assert torch.equal(ids, gv['enc_ids'])
+    assert (fmap - gv['enc_fmap']).abs().max() < 1e-4
+    assert v.get_encoded_fmap_size(128) == gv['fmap_size'] == 8
+
+
+def test_ff_packing_layout():
+    t = mm.MaskGitTransformer(num_tokens=512, seq_len=64, dim=128, depth=1, t5_name='t5-small')
+    ff = t.transformer_blocks.layers[0][2]
+    keep = []
+    fw, F_, Fp = t._pack_ff(ff, keep)
+    assert (F_, Fp) == (341, 384)
+    w1p, w2p = keep[0]['w1'].float(), keep[0]['w2'].float()
+    w1 = ff[1].weight.detach().bfloat16().float()
+    assert torch.equal(w1p[:341], w1[:341]) and torch.equal(w1p[384:384 + 341], w1[341:])
+    assert w1p[341:384].abs().sum() == 0 and w1p[384 + 341:].abs().sum() == 0
+    assert w2p.shape == (128, 384) and w2p[:, 341:].abs().sum() == 0
+    assert int(128 * 4 * 2 / 3) == 341 and int(512 * 4 * 2 / 3) == 1365
