@@ -226,6 +226,14 @@ size_t mm_generate_workspace_bytes(const mm_transformer_t* model, int B, int n, 
 int mm_generate(const mm_transformer_t* model, mm_stream_t stream, const mm_generate_params* params,
                 void* workspace, size_t workspace_bytes);
 
+/* ---- in-library kernel timing (bench.py's roofline leg).  When enabled, mm_generate brackets its two dominant
+ * kernels with HIP events on the launch stream: slot 0 = the CFG to_logits GEMM (MFMA-bound), slot 1 = sample_rows
+ * (HBM-bound).  mm_profile_read synchronises those events and returns, per slot, the launch count, the summed
+ * duration in milliseconds and the summed algorithmic work (flops for slot 0, bytes for slot 1), then resets. */
+#define MM_PROF_SLOTS 2
+int mm_profile_enable(int enable);
+int mm_profile_read(int slot, int64_t* launches, double* total_ms, double* total_work);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,6 +9,23 @@
 #include "common.h"
 #include "muse_hip_internal.h"
 
+// ---- optional event timing of the two dominant kernels of mm_generate (see mm_profile_* in muse_hip.h)
+namespace prof {
+struct Rec { hipEvent_t a, b; double work; };
+bool enabled = false;
+std::vector<Rec> recs[MM_PROF_SLOTS];
+std::vector<Rec> pool;
+inline Rec begin(hipStream_t s, double work) {
+    Rec r;
+    if (!pool.empty()) { r = pool.back(); pool.pop_back(); }
+    else { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); }
+    r.work = work;
+    (void)hipEventRecord(r.a, s);
+    return r;
+}
+inline void end(hipStream_t s, int slot, Rec& r) { (void)hipEventRecord(r.b, s); recs[slot].push_back(r); }
+}  // namespace prof
+
 struct mm_transformer {
     mm_transformer_desc d;
     std::vector<mm_layer_weights> layers;
@@ -328,6 +345,31 @@ void carve_gen(Carver& c, const mm_transformer* t, int B, int n, int L, int nc, 
 }
 }  // namespace
 
+int mm_profile_enable(int enable) {
+    prof::enabled = enable != 0;
+    return MM_OK;
+}
+
+int mm_profile_read(int slot, int64_t* launches, double* total_ms, double* total_work) {
+    if (slot < 0 || slot >= MM_PROF_SLOTS) return mm_set_error(MM_ERR_SHAPE, "profile_read: bad slot");
+    double ms = 0.0, work = 0.0;
+    int64_t n = 0;
+    for (prof::Rec& r : prof::recs[slot]) {
+        hipError_t e = hipEventSynchronize(r.b);
+        if (e != hipSuccess) return mm_set_hip_error(e, "profile_read: hipEventSynchronize");
+        float t = 0.f;
+        e = hipEventElapsedTime(&t, r.a, r.b);
+        if (e != hipSuccess) return mm_set_hip_error(e, "profile_read: hipEventElapsedTime");
+        ms += t; work += r.work; ++n;
+        prof::pool.push_back(r);
+    }
+    prof::recs[slot].clear();
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = ms;
+    if (total_work) *total_work = work;
+    return MM_OK;
+}
+
 size_t mm_generate_workspace_bytes(const mm_transformer_t* t, int B, int n, int L, int nc) {
     if (!t) return 0;
     Carver c(nullptr);
@@ -427,7 +469,10 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
             a.W = (const bf16_t*)t->d.to_logits; a.N = V; a.ldw = D; a.K = D;
             a.M = R; a.X = g.embc; a.X2 = g.embn; a.ldx = D;
             a.out = g.logits; a.ldc = V; a.out_kind = OUT_F32; a.cfg_scale = p->cond_scale;
+            prof::Rec pr;
+            if (prof::enabled) pr = prof::begin(s, 2.0 * 2.0 * (double)R * (double)V * (double)D);   // cond + null rows
             RC(mm_gemm_launch(a, s));
+            if (prof::enabled) prof::end(s, 0, pr);
         }
         SampleArgs sa;
         memset(&sa, 0, sizeof(sa));
@@ -436,7 +481,12 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
         sa.noise = p->noise ? p->noise + (size_t)step * M * V : nullptr; sa.noise_ld = V;
         sa.seed = p->seed; sa.row_offset = p->row_offset * (uint64_t)n; sa.step = (uint32_t)step;
         sa.ids = p->ids; sa.scores = p->scores;
-        RC(k_sample_rows(s, sa));                                                                    // mmp.py:576-609
+        {
+            prof::Rec pr;
+            if (prof::enabled) pr = prof::begin(s, 4.0 * (double)R * (double)V);      // one fp32 read of each row
+            RC(k_sample_rows(s, sa));                                                                // mmp.py:576-609
+            if (prof::enabled) prof::end(s, 1, pr);
+        }
         if (p->trace_ids) {
             const hipError_t e = hipMemcpyAsync(p->trace_ids + (size_t)step * M, p->ids, (size_t)M * 8, hipMemcpyDeviceToDevice, s);
             if (e != hipSuccess) return mm_set_hip_error(e, "generate: trace copy");

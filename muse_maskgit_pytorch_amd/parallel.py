@@ -1,0 +1,34 @@
+"""Multi-GPU path: one process per GPU, the batch is sharded, the decode loop needs no communication (every reduction
+in MaskGit.generate is over the vocabulary or token axis of ONE sample, muse_maskgit_pytorch.py:561,576,580,603), and the
+generated token grids are exchanged with a single all-gather (RCCL over xGMI when the backend is 'nccl').  The
+reference has no distributed inference code; this is the north star's requirement."""
+import torch
+
+
+def shard_bounds(total, rank, world):
+    """contiguous batch shard of `rank`: the first total % world ranks get one extra sample."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def allgather_ids(ids, dist, group=None):
+    """ids int64 (b, f, f), same b on every rank -> (world*b, f, f).  Final ids are < codebook_size <= 65536 (the last
+    decode step leaves no mask id, mmp.py:584-588), so they travel as int32: 4 bytes/token, 32 KiB per rank at C2."""
+    world = dist.get_world_size(group)
+    send = ids.to(torch.int32).contiguous()
+    out = torch.empty((world * send.shape[0],) + tuple(send.shape[1:]), dtype=torch.int32, device=send.device)
+    dist.all_gather_into_tensor(out, send, group=group)      # concatenated along dim 0 in rank order
+    return out.to(torch.long)
+
+
+def generate_sharded(maskgit, text_embeds, dist, seed, **kw):
+    """Every rank passes the GLOBAL text_embeds (B_total, L, d); it decodes its contiguous shard with the Philox stream
+    keyed by the GLOBAL sample index (row_offset), so the gathered ids equal the single-GPU result for the same seed.
+    Requires B_total % world == 0 (all_gather_into_tensor needs equal shards).  Returns (all ids, local ids)."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    total = text_embeds.shape[0]
+    assert total % world == 0, 'global batch must divide evenly across ranks'
+    lo, hi = shard_bounds(total, rank, world)
+    local = maskgit.generate([''] * (hi - lo), text_embeds=text_embeds[lo:hi], seed=seed, row_offset=lo, return_ids=True, **kw)
+    return allgather_ids(local, dist), local
