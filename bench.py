@@ -54,17 +54,17 @@ def synth_text(total, L, dim, seed=0):
     return te
 
 
-def cpu_baseline(mg, te_one, timesteps, cond_scale, sample_steps=2):
+def cpu_baseline(mg, te_one, timesteps, cond_scale, sample_steps=1, max_threads=32):
     """The reference algorithm (oracle port, fp32 torch on the host cores) on a bounded sample of the same workload:
     batch 1, `sample_steps` of the 18 decode steps (every reference step costs the same: it always runs the full
     2-pass transformer and the full-vocabulary tail) + one VAE decode, extrapolated to a full generate."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import muse_oracle as O
-    cores = os.cpu_count()
+    cores = min(os.cpu_count(), max_threads)   # torch's intra-op pool stops scaling (and regresses) far below 256 threads
     torch.set_num_threads(cores)
     tr = mg.transformer
-    sd = {k: v.detach().float().cpu() for k, v in tr.state_dict().items()}
-    vsd = {k: v.detach().float().cpu() for k, v in mg.vae.state_dict().items()}
+    sd = {k: (v.detach().float().cpu() if v.is_floating_point() else v.detach().cpu()) for k, v in tr.state_dict().items()}
+    vsd = {k: (v.detach().float().cpu() if v.is_floating_point() else v.detach().cpu()) for k, v in mg.vae.state_dict().items()}
     cfg = dict(depth=tr.transformer_blocks.cfg['depth'], heads=tr.transformer_blocks.cfg['heads'])
     n, V = tr.seq_len, tr.num_tokens
     counts = O.mask_counts(timesteps, n)

@@ -231,6 +231,8 @@ int mm_generate(const mm_transformer_t* model, mm_stream_t stream, const mm_gene
  * (HBM-bound).  mm_profile_read synchronises those events and returns, per slot, the launch count, the summed
  * duration in milliseconds and the summed algorithmic work (flops for slot 0, bytes for slot 1), then resets. */
 #define MM_PROF_SLOTS 2
+/* kernel ablation switches for tools/ (0 = product behaviour) */
+int mm_debug_set(int flags);
 int mm_profile_enable(int enable);
 int mm_profile_read(int slot, int64_t* launches, double* total_ms, double* total_work);
 

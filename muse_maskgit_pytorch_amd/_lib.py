@@ -79,6 +79,7 @@ SIGNATURES = {
     'mm_transformer_forward': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_sz]),
     'mm_generate_workspace_bytes': (c_sz, [c_vp, c_int, c_int, c_int, c_int]),
     'mm_generate': (c_int, [c_vp, c_vp, C.POINTER(GenerateParams), c_vp, c_sz]),
+    'mm_debug_set': (c_int, [c_int]),
     'mm_profile_enable': (c_int, [c_int]),
     'mm_profile_read': (c_int, [c_int, C.POINTER(c_i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }

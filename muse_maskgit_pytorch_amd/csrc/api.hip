@@ -32,6 +32,7 @@ int mm_check_launch(const char* kernel) {
 extern "C" {
 
 int mm_abi_version(void) { return MM_ABI_VERSION; }
+int mm_debug_set(int flags) { g_mm_debug = flags; return MM_OK; }
 const char* mm_last_error(void) { return g_err; }
 
 int mm_device_check(void) {

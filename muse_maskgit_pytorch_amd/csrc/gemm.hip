@@ -11,8 +11,11 @@
 // activation tile the B operand, so one accumulator fragment holds 4 CONSECUTIVE output features of one
 // token: the epilogue stores 16 B (fp32) / 8 B (bf16) per lane instead of 4 scalars.
 // LDS: two 32 KiB stages (W tile + X tile, row = 128 B = 8 chunks of 16 B, chunk index XOR (row & 7) so
-// every ds_read_b128 lane group hits 16 distinct slots); global->register->LDS staging with the next
-// tile's loads issued before the current tile's MFMAs; one barrier per K-tile.
+// every ds_read_b128 lane group hits 16 distinct slots).  Staging is LDS-DMA (global_load_lds_dwordx4, 1 KiB =
+// 8 tile rows per wave instruction): no VGPR round trip and -- what matters on CDNA4 -- no ds_write_b128, which at
+// ~13 LDS cycles each made the register-staged first version of this kernel LDS-bound.  The DMA writes lane-linear,
+// so the XOR swizzle is applied to each lane's SOURCE address.  The next tile's DMA is issued before the current
+// tile's MFMAs; one __syncthreads (vmcnt(0) + barrier) per K-tile.
 // Grid: 1-D, XCD-aware grouped tile order (common.h).
 #include "common.h"
 #include "muse_hip_internal.h"
@@ -22,8 +25,12 @@ namespace {
 constexpr int BT = 128;   // tile edge (both n and m)
 constexpr int BK = 64;    // k per stage
 constexpr int STAGE_BYTES = 2 * BT * BK * 2;   // W tile + X tile
+constexpr int SMEM_BYTES = BT * (BT + 4) * 4;  // max(2 stages = 64 KiB, fp32 output tile with padded rows = 66 KiB)
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+// source of the implicit-GEMM loader for taps that fall into the zero padding
+__device__ __attribute__((aligned(16))) const unsigned int g_zero_page[64] = {0};
 
 template <int MODE>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
@@ -36,19 +43,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     const int n0 = tile_n * BT;
     const int m0 = tile_m * (MODE == MODE_CFG ? 64 : BT);   // CFG: 64 tokens x {cond, null} per tile
 
-    // ---- per-thread staging geometry: chunk column t&7, rows (t>>3) + 32*i
-    const int chunk = t & 7;
-    const int row0 = t >> 3;
+    // ---- per-lane DMA geometry.  Wave w stages tile rows [32w, 32w+32) with 4 instructions of 8 rows each; within an
+    //      instruction lane l lands on (row l>>3, physical chunk l&7), which must hold logical chunk (l&7) ^ (row & 7).
+    const int chunk = (lane & 7) ^ (lane >> 3);
+    const int row0 = 32 * wid + (lane >> 3);          // rows row0 + 8*i
     const bf16_t* wptr[4];
     const bf16_t* xptr[4];
-    bool wok[4], xok[4];
+    bool xok[4];
     int cb[4], cy[4], cx[4];   // conv: batch / output y / output x of the staged rows
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int r = row0 + 32 * i;
+        const int r = row0 + 8 * i;
         const int n = n0 + r;
-        wok[i] = n < p.N;
-        wptr[i] = p.W + (size_t)(wok[i] ? n : 0) * p.ldw + chunk * 8;
+        // out-of-range rows are clamped to row 0: they only feed outputs the epilogue never stores
+        wptr[i] = p.W + (size_t)(n < p.N ? n : 0) * p.ldw + chunk * 8;
         if constexpr (MODE == MODE_DENSE) {
             const int m = m0 + r;
             xok[i] = m < p.M;
@@ -71,19 +79,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         }
     }
 
-    u32x4_t wreg[4], xreg[4];
-
-#define LOAD_TILE(kt_)                                                                                             \
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#define ISSUE_TILE(kt_, stage_)                                                                                    \
     {                                                                                                              \
         const int k0_ = (kt_) * BK;                                                                                \
+        unsigned char* ws_ = smem + (stage_) * STAGE_BYTES + wid * 4096;   /* this wave's 32 rows of the W tile */ \
+        unsigned char* xs_ = ws_ + BT * BK * 2;                                                                    \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
-            wreg[i] = *reinterpret_cast<const u32x4_t*>(wptr[i] + k0_); /* out-of-range rows are clamped to row 0: */ \
-        /* they only feed output rows/columns the epilogue never stores, so no zero fill is needed */              \
+            __builtin_amdgcn_global_load_lds(wptr[i] + k0_, (lds_ptr_t)(ws_ + i * 1024), 16, 0, 0);                \
         if constexpr (MODE != MODE_CONV) {                                                                         \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
-                xreg[i] = *reinterpret_cast<const u32x4_t*>(xptr[i] + k0_);                                       \
+                __builtin_amdgcn_global_load_lds(xptr[i] + k0_, (lds_ptr_t)(xs_ + i * 1024), 16, 0, 0);            \
         } else {                                                                                                   \
-            /* im2col on the fly: this thread's 8 channels of K-index k belong to tap k / Cin */                   \
+            /* im2col on the fly: this lane's 8 channels of K-index k belong to tap k / Cin; taps that fall in the */ \
+            /* zero padding (or k >= Ktrue) are fetched from a zero page instead */                                \
             const int k_ = k0_ + chunk * 8;                                                                        \
             const int tap_ = k_ / p.Cin;                                                                           \
             const int c_ = k_ - tap_ * p.Cin;                                                                      \
@@ -92,22 +101,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                        \
                 const int iy_ = cy[i] * p.stride + ty_ + p.off_y;                                                  \
                 const int ix_ = cx[i] * p.stride + tx_ + p.off_x;                                                  \
-                const bool ok_ = xok[i] && kok_ && iy_ >= 0 && iy_ < p.Hin && ix_ >= 0 && ix_ < p.Win;             \
-                const size_t off_ = (((size_t)cb[i] * p.Hin + (ok_ ? iy_ : 0)) * p.Win + (ok_ ? ix_ : 0)) * p.Cin + c_; \
-                const u32x4_t ld_ = *reinterpret_cast<const u32x4_t*>(p.X + off_);                                  \
-                const unsigned int keep_ = ok_ ? 0xFFFFFFFFu : 0u;            /* zero the padding taps */             \
-                xreg[i] = ld_ & keep_;                                                                             \
+                const bool ok_ = kok_ && iy_ >= 0 && iy_ < p.Hin && ix_ >= 0 && ix_ < p.Win;                       \
+                const size_t off_ = (((size_t)cb[i] * p.Hin + iy_) * p.Win + ix_) * p.Cin + c_;                    \
+                const bf16_t* src_ = ok_ ? p.X + off_ : reinterpret_cast<const bf16_t*>(g_zero_page);              \
+                __builtin_amdgcn_global_load_lds(src_, (lds_ptr_t)(xs_ + i * 1024), 16, 0, 0);                     \
             }                                                                                                      \
-        }                                                                                                          \
-    }
-#define STORE_TILE(stage_)                                                                                         \
-    {                                                                                                              \
-        unsigned char* ws_ = smem + (stage_) * STAGE_BYTES;                                                        \
-        unsigned char* xs_ = ws_ + BT * BK * 2;                                                                    \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
-            const int r_ = row0 + 32 * i;                                                                          \
-            *reinterpret_cast<u32x4_t*>(ws_ + lds_off(r_, chunk)) = wreg[i];                                         \
-            *reinterpret_cast<u32x4_t*>(xs_ + lds_off(r_, chunk)) = xreg[i];                                         \
         }                                                                                                          \
     }
 
@@ -118,9 +116,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int KT = p.K / BK;
-    LOAD_TILE(0);
-    STORE_TILE(0);
-    __syncthreads();
+    ISSUE_TILE(0, 0);
+    __syncthreads();        // with an LDS-DMA in flight this is vmcnt(0) + s_barrier
 
     const int fr = lane & 15, fg = lane >> 4;
 #define COMPUTE_TILE(stage_)                                                                                       \
@@ -133,99 +130,161 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                 af[i] = *reinterpret_cast<const u32x4_t*>(ws_ + lds_off(wave_n * 64 + i * 16 + fr, ks * 4 + fg));  \
                 bfm[i] = *reinterpret_cast<const u32x4_t*>(xs_ + lds_off(wave_m * 64 + i * 16 + fr, ks * 4 + fg)); \
             }                                                                                                      \
+            if (!(p.debug & 4)) {                                                                                  \
             _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                          \
                 _Pragma("unroll") for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(af[a], bfm[b], acc[a][b]);        \
+            } else { _Pragma("unroll") for (int a = 0; a < 4; ++a) { acc[a][0][0] += __uint_as_float(af[a][0] ^ bfm[a][1]); } } \
         }                                                                                                          \
     }
-    // steady state: next tile's global loads are in flight while this tile's MFMAs run; one barrier per tile
+    // steady state: the next tile's DMA is in flight while this tile's MFMAs run; one barrier per tile
     for (int kt = 0; kt < KT - 1; ++kt) {
-        LOAD_TILE(kt + 1);
-        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch issue ahead of the MFMA block (hipcc sinks it otherwise)
+        if (!(p.debug & 2)) ISSUE_TILE(kt + 1, (kt + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);   // keep the DMA issue ahead of the MFMA block
         COMPUTE_TILE(kt & 1);
-        __builtin_amdgcn_sched_barrier(0);
-        STORE_TILE((kt + 1) & 1);
         __syncthreads();
     }
     COMPUTE_TILE((KT - 1) & 1);
 
-    // ---- epilogue: lane holds out[m][n..n+3] per fragment; n = 4 consecutive output features
+    // ---- epilogue.  A lane holds out[m][n..n+3] per fragment (16 rows x 64 B per store instruction): storing that
+    //      directly touches half cache lines and was measured at 35-45 % of the kernel.  Instead the tile goes
+    //      through LDS (fp32, row stride 132 floats: conflict-free ds_write_b128) and is written out row-contiguously,
+    //      16 B per lane, 512 B (fp32) / 256 B (bf16) of one row per quarter wave; the residual is read the same way.
+    if ((p.debug & 1) && acc[0][0][0] != 12345.678f) return;
     constexpr int MT = (MODE == MODE_CFG) ? 2 : 4;
+    constexpr int TROWS = (MODE == MODE_CFG) ? 64 : BT;
+
+    if (p.out_kind == OUT_NCHW_F32) {
+        // narrow conv head (Cout = image channels): direct scalar stores, out[b][n][y][x]
+        float* op = reinterpret_cast<float*>(p.out);
+#pragma unroll
+        for (int b = 0; b < MT; ++b) {
+            const int m = m0 + wave_m * 64 + b * 16 + fr;
+            if (m >= p.M) continue;
+            const int hw = p.Hv * p.Wv;
+            const int ob = m / hw;
+            const int rem = m - ob * hw;
+            const int oy = (rem / p.Wv) * p.os + p.py, ox = (rem % p.Wv) * p.os + p.px;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int n = n0 + wave_n * 64 + a * 16 + fg * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < p.N) {
+                        float v = acc[a][b][r] + (p.bias ? p.bias[n + r] : 0.f);
+                        if (p.act == ACT_LEAKY) v = v > 0.f ? v : 0.1f * v;
+                        op[(((size_t)ob * p.N + n + r) * p.Hout + oy) * p.Wout + ox] = v;
+                    }
+            }
+        }
+        return;
+    }
+
+    __syncthreads();                       // every wave is done reading the last stage
+    float* ct = reinterpret_cast<float*>(smem);
+    constexpr int CT_LD = BT + 4;          // floats per tile row (528 B)
 #pragma unroll
     for (int b = 0; b < MT; ++b) {
-        int m;
-        if constexpr (MODE == MODE_CFG) m = m0 + wave_m * 32 + b * 16 + fr;
-        else m = m0 + wave_m * 64 + b * 16 + fr;
-        if (m >= p.M) continue;
-        size_t orow;        // row index into out / resid
-        int ob = 0, oy = 0, ox = 0;
-        if constexpr (MODE == MODE_CONV) {
-            const int hw = p.Hv * p.Wv;
-            ob = m / hw;
-            const int rem = m - ob * hw;
-            oy = (rem / p.Wv) * p.os + p.py;
-            ox = (rem % p.Wv) * p.os + p.px;
-            orow = ((size_t)ob * p.Hout + oy) * p.Wout + ox;
-        } else {
-            orow = (size_t)m;
-        }
+        const int ml = (MODE == MODE_CFG) ? (wave_m * 32 + b * 16 + fr) : (wave_m * 64 + b * 16 + fr);
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            const int n = n0 + wave_n * 64 + a * 16 + fg * 4;
-            if (n >= p.N) continue;
+            const int nl = wave_n * 64 + a * 16 + fg * 4;
             float v[4];
             if constexpr (MODE == MODE_CFG) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float c = acc[a][b][r], nl = acc[a][(b + 2) & 3][r];
-                    v[r] = nl + (c - nl) * p.cfg_scale;      // muse_maskgit_pytorch.py:254
+                    const float c = acc[a][b][r], nlv = acc[a][(b + 2) & 3][r];
+                    v[r] = nlv + (c - nlv) * p.cfg_scale;      // muse_maskgit_pytorch.py:254
                 }
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r];
             }
-            const bool full = n + 3 < p.N;
             if (p.bias) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += p.bias[n + r];
+                for (int r = 0; r < 4; ++r) v[r] += (n0 + nl + r < p.N) ? p.bias[n0 + nl + r] : 0.f;
             }
             if (p.act == ACT_LEAKY) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.1f * v[r];   // vqgan_vae.py:103-104
             }
+            *reinterpret_cast<float4*>(ct + ml * CT_LD + nl) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    __syncthreads();
+
+    // row-contiguous write-out, 16 B per lane, consecutive lanes on consecutive addresses
+    auto out_row = [&](int m) -> size_t {
+        if constexpr (MODE == MODE_CONV) {
+            const int hw = p.Hv * p.Wv;
+            const int ob = m / hw;
+            const int rem = m - ob * hw;
+            const int oy = (rem / p.Wv) * p.os + p.py, ox = (rem % p.Wv) * p.os + p.px;
+            return ((size_t)ob * p.Hout + oy) * p.Wout + ox;
+        } else {
+            return (size_t)m;
+        }
+    };
+    if (p.out_kind == OUT_F32) {
+        // 4 columns per lane: 32 lanes cover one 512-byte tile row, 8 rows per pass
+        const int c4 = (t & 31) * 4;
+        const int n = n0 + c4;
+#pragma unroll 4
+        for (int pass = 0; pass < TROWS / 8; ++pass) {
+            const int ml = pass * 8 + (t >> 5);
+            const int m = m0 + ml;
+            if (m >= p.M || n >= p.N) continue;
+            const size_t orow = out_row(m);
+            const float4 cv = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c4);
+            float v[4] = {cv.x, cv.y, cv.z, cv.w};
+            const bool full = n + 3 < p.N;
             if (p.resid_f32) {
                 const float* rp = p.resid_f32 + orow * p.ldr + n;
                 if (full) {
-                    const float4 rv = *reinterpret_cast<const float4*>(rp);
-                    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                    const float4 r0 = *reinterpret_cast<const float4*>(rp);
+                    v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += rp[r];
                 }
             }
+            float* op = reinterpret_cast<float*>(p.out) + orow * p.ldc + n;
+            if (full) *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < p.N) op[r] = v[r];
+            }
+        }
+    } else {
+        // bf16: 8 columns per lane: 16 lanes cover one 256-byte tile row, 16 rows per pass
+        const int c8 = (t & 15) * 8;
+        const int n = n0 + c8;
+#pragma unroll 4
+        for (int pass = 0; pass < TROWS / 16; ++pass) {
+            const int ml = pass * 16 + (t >> 4);
+            const int m = m0 + ml;
+            if (m >= p.M || n >= p.N) continue;
+            const size_t orow = out_row(m);
+            const float4 lo = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c8);
+            const float4 hi = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c8 + 4);
+            float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            const bool full = n + 7 < p.N;
             if (p.resid_bf16) {
                 const bf16_t* rp = p.resid_bf16 + orow * p.ldr + n;
+                if (full) {
+                    float rv[8];
+                    unpack8(*reinterpret_cast<const uint4*>(rp), rv);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += bf16_to_f32(rp[r]);
+                    for (int r = 0; r < 8; ++r) v[r] += rv[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) if (n + r < p.N) v[r] += bf16_to_f32(rp[r]);
+                }
             }
-            if (p.out_kind == OUT_F32) {
-                float* op = reinterpret_cast<float*>(p.out) + orow * p.ldc + n;
-                if (full) *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
-                else {
+            bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + orow * p.ldc + n;
+            if (full) *reinterpret_cast<uint4*>(op) = pack8(v);
+            else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) if (n + r < p.N) op[r] = v[r];
-                }
-            } else if (p.out_kind == OUT_BF16) {
-                bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + orow * p.ldc + n;
-                if (full) *reinterpret_cast<uint2*>(op) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (n + r < p.N) op[r] = f32_to_bf16(v[r]);
-                }
-            } else {   // OUT_NCHW_F32: out[b][n][y][x]
-                float* op = reinterpret_cast<float*>(p.out);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < p.N) op[(((size_t)ob * p.N + n + r) * p.Hout + oy) * p.Wout + ox] = v[r];
+                for (int r = 0; r < 8; ++r) if (n + r < p.N) op[r] = f32_to_bf16(v[r]);
             }
         }
     }
@@ -236,23 +295,30 @@ int launch(const GemmArgs& a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<MODE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
         if (e != hipSuccess) return mm_set_hip_error(e, "gemm hipFuncSetAttribute");
         attr_set = true;
     }
     const int blocks = a.tiles_m * a.tiles_n;
     if (blocks <= 0) return MM_OK;
-    hipLaunchKernelGGL(gemm_kernel<MODE>, dim3(blocks), dim3(256), 2 * STAGE_BYTES, stream, a);
+    hipLaunchKernelGGL(gemm_kernel<MODE>, dim3(blocks), dim3(256), SMEM_BYTES, stream, a);
     return mm_check_launch("gemm_kernel");
 }
 
 }  // namespace
 
+int g_mm_debug = 0;
+
 int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
+    a.debug = g_mm_debug;
     if (a.K <= 0 || (a.K % BK) != 0) return mm_set_error(MM_ERR_SHAPE, "gemm: K must be a positive multiple of 64 (pad at pack time)");
     if ((a.ldw % 8) != 0 || (a.mode != MODE_CONV && (a.ldx % 8) != 0)) return mm_set_error(MM_ERR_ALIGN, "gemm: row strides must be multiples of 8 elements (16 B)");
     if (a.mode == MODE_CONV && (a.Cin % 8) != 0) return mm_set_error(MM_ERR_SHAPE, "conv: Cin must be a multiple of 8");
-    if ((a.ldc % 4) != 0 && a.out_kind != OUT_NCHW_F32 && a.N >= 4) return mm_set_error(MM_ERR_ALIGN, "gemm: ldc must be a multiple of 4");
+    if (a.out_kind != OUT_NCHW_F32 && a.N >= 8 && ((a.out_kind == OUT_F32 && (a.ldc % 4)) || (a.out_kind == OUT_BF16 && (a.ldc % 8))))
+        return mm_set_error(MM_ERR_ALIGN, "gemm: ldc must be a multiple of 4 (fp32 out) / 8 (bf16 out) elements");
+    if ((a.resid_f32 && (a.ldr % 4)) || (a.resid_bf16 && (a.ldr % 8))) return mm_set_error(MM_ERR_ALIGN, "gemm: residual stride alignment");
+    if ((a.resid_f32 && a.out_kind != OUT_F32) || (a.resid_bf16 && a.out_kind != OUT_BF16))
+        return mm_set_error(MM_ERR_DTYPE, "gemm: the residual must have the output's dtype");
     a.tiles_n = (a.N + BT - 1) / BT;
     const int tm = a.mode == MODE_CFG ? 64 : BT;
     a.tiles_m = (a.M + tm - 1) / tm;

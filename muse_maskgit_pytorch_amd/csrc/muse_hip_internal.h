@@ -26,7 +26,9 @@ struct GemmArgs {
     const float* bias; const float* resid_f32; const bf16_t* resid_bf16; long ldr;
     int act; float cfg_scale;
     int tiles_m, tiles_n;         // filled by mm_gemm_launch
+    int debug;                    // ablation bits (mm_debug_set): 1 = no epilogue stores, 2 = no DMA after tile 0, 4 = no MFMA
 };
+extern int g_mm_debug;
 
 int mm_gemm_launch(GemmArgs a, hipStream_t stream);
 

@@ -28,6 +28,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
 // F.layer_norm(x, (D,), gamma, beta), eps 1e-5 (muse_maskgit_pytorch.py:63-70); fp32 in, bf16 out.
 // Optional row gather (row_index) so the final norm only touches the rows that are sampled.
 constexpr int LN_MAX_IT = 8;   // D <= 64 lanes * 4 * 8 = 2048
+template <int NIT>             // float4 iterations per lane: instantiated for 2 / 4 / 8 so small dims keep registers (and occupancy)
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long ldx, int rows, int D,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const int32_t* __restrict__ row_index, bf16_t* __restrict__ out, long ldo) {
@@ -37,10 +38,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const long src = row_index ? (long)row_index[row] : (long)row;
     const float* xr = x + src * ldx;
     const int nvec = D >> 2;
-    float4 v[LN_MAX_IT];
+    float4 v[NIT];
     float sum = 0.f;
 #pragma unroll
-    for (int it = 0; it < LN_MAX_IT; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int c = it * 64 + lane;
         if (c < nvec) {
             v[it] = *reinterpret_cast<const float4*>(xr + c * 4);
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const float mean = wave_sum(sum) / (float)D;
     float sq = 0.f;
 #pragma unroll
-    for (int it = 0; it < LN_MAX_IT; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int c = it * 64 + lane;
         if (c < nvec) {
             const float a = v[it].x - mean, b = v[it].y - mean, cc = v[it].z - mean, d = v[it].w - mean;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const float rstd = 1.f / sqrtf(wave_sum(sq) / (float)D + 1e-5f);
     bf16_t* orow = out + (long)row * ldo;
 #pragma unroll
-    for (int it = 0; it < LN_MAX_IT; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int c = it * 64 + lane;
         if (c < nvec) {
             const float4 g = *reinterpret_cast<const float4*>(gamma + c * 4);
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // a = gate * gelu_erf(x); out = LN(a) over the F valid columns; columns F..Fp-1 are written as zeros so the
 // following GEMM can run on the padded K.
 constexpr int GG_MAX_IT = 12;  // Fp <= 64 * 8 * 12 = 6144
+template <int NIT>             // 16-byte iterations per lane: 3 (F <= 1536) / 6 / 12
 __global__ __launch_bounds__(256) void geglu_ln_kernel(const bf16_t* __restrict__ h, long ldh, int rows, int F, int Fp,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        bf16_t* __restrict__ out, long ldo) {
@@ -85,10 +87,10 @@ __global__ __launch_bounds__(256) void geglu_ln_kernel(const bf16_t* __restrict_
     if (row >= rows) return;
     const bf16_t* hr = h + (long)row * ldh;
     const int nch = Fp >> 3;
-    float a[GG_MAX_IT][8];
+    float a[NIT][8];
     float sum = 0.f;
 #pragma unroll
-    for (int it = 0; it < GG_MAX_IT; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int c = it * 64 + lane;
         if (c < nch) {
             float xv[8], gv[8];
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256) void geglu_ln_kernel(const bf16_t* __restrict_
     const float mean = wave_sum(sum) / (float)F;
     float sq = 0.f;
 #pragma unroll
-    for (int it = 0; it < GG_MAX_IT; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int c = it * 64 + lane;
         if (c < nch) {
 #pragma unroll
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void geglu_ln_kernel(const bf16_t* __restrict_
     const float rstd = 1.f / sqrtf(wave_sum(sq) / (float)F + 1e-5f);
     bf16_t* orow = out + (long)row * ldo;
 #pragma unroll
-    for (int it = 0; it < GG_MAX_IT; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int c = it * 64 + lane;
         if (c < nch) {
             float o[8];
@@ -171,7 +173,10 @@ int k_layernorm(hipStream_t s, const float* x, long ldx, int rows, int D, const 
     if (rows <= 0) return MM_OK;
     if (D % 4 || D > 64 * 4 * LN_MAX_IT) return mm_set_error(MM_ERR_SHAPE, "layernorm: dim must be a multiple of 4 and <= 2048");
     if (ldx % 4 || ldo % 4) return mm_set_error(MM_ERR_ALIGN, "layernorm: strides must be multiples of 4 elements");
-    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, D, gamma, beta, row_index, out, ldo);
+    const int nit = (D / 4 + 63) / 64;
+    if (nit <= 2) hipLaunchKernelGGL(layernorm_kernel<2>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, D, gamma, beta, row_index, out, ldo);
+    else if (nit <= 4) hipLaunchKernelGGL(layernorm_kernel<4>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, D, gamma, beta, row_index, out, ldo);
+    else hipLaunchKernelGGL(layernorm_kernel<8>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, D, gamma, beta, row_index, out, ldo);
     return mm_check_launch("layernorm_kernel");
 }
 
@@ -180,7 +185,10 @@ int k_geglu_ln(hipStream_t s, const bf16_t* h, long ldh, int rows, int F, int Fp
     if (rows <= 0) return MM_OK;
     if (Fp % 8 || Fp < F || Fp > 64 * 8 * GG_MAX_IT) return mm_set_error(MM_ERR_SHAPE, "geglu_ln: padded inner dim must be a multiple of 8, >= F and <= 6144");
     if (ldh % 8 || ldo % 8) return mm_set_error(MM_ERR_ALIGN, "geglu_ln: strides must be multiples of 8 elements");
-    hipLaunchKernelGGL(geglu_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, h, ldh, rows, F, Fp, gamma, beta, out, ldo);
+    const int nit = (Fp / 8 + 63) / 64;
+    if (nit <= 3) hipLaunchKernelGGL(geglu_ln_kernel<3>, dim3((rows + 3) / 4), dim3(256), 0, s, h, ldh, rows, F, Fp, gamma, beta, out, ldo);
+    else if (nit <= 6) hipLaunchKernelGGL(geglu_ln_kernel<6>, dim3((rows + 3) / 4), dim3(256), 0, s, h, ldh, rows, F, Fp, gamma, beta, out, ldo);
+    else hipLaunchKernelGGL(geglu_ln_kernel<12>, dim3((rows + 3) / 4), dim3(256), 0, s, h, ldh, rows, F, Fp, gamma, beta, out, ldo);
     return mm_check_launch("geglu_ln_kernel");
 }
 

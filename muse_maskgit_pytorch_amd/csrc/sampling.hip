@@ -94,43 +94,86 @@ __global__ __launch_bounds__(256) void philox_fill_kernel(uint64_t seed, uint64_
 }
 
 // ------------------------------------------------------------------------------------------------ sample rows
-constexpr int ST = 512;         // threads per row: 8 waves = 2 per SIMD -> 256 VGPRs each, the row (<= 128 values/lane) stays in registers
+// Structure (one 512-thread workgroup per row, the row lives in registers, 128 values per lane at V = 65536):
+//   A  max / min of the row                                     (2 VALU per value)
+//   B  sum exp(x - max)                                         (softmax denominator of mmp.py:603)
+//   C  2048-bin value-linear histogram in LDS                   (non-returning LDS atomics)
+//      -> one wave scans it: bin t that holds the k-th largest value, and how many values lie above t
+//   D  every value with bin >= t is appended (value, index) to this WAVE's private slice of an LDS list --
+//      slot = running wave count + lane prefix of the ballot, so no atomics and no waits
+//   then short loops over the ~k listed entries only: exact k-th largest inside bin t (rank counting), Gumbel
+//   noise + argmax over the entries >= that threshold.
+// Passes A-D are the only fully unrolled code (the register file cannot be indexed dynamically); keeping them to a few
+// instructions per value matters: the first version of this kernel spent its time fetching ~50k instructions per row.
+// Rows the fast path cannot take (span 0 / non-finite, > 2048 values inside bin t, a wave slice overflowing -- i.e.
+// massive ties) go through slow_row(): bisection on the integer keys, re-reading the row from L2.
+constexpr int ST = 512;          // threads per row: 8 waves = 2 per SIMD -> up to 256 VGPRs each
 constexpr int NW = ST / 64;
-constexpr int NB = 2048;        // histogram bins
-constexpr int CAND_CAP = 2048;  // exact-select capacity
-constexpr int KEPT_CAP = 8192;  // kept-entry list (k = ceil(0.1*65536) = 6554; only threshold TIES can exceed k)
+constexpr int NB = 2048;         // histogram bins
+constexpr int CAND_CAP = 2048;   // exact-select capacity (values inside the threshold bin)
+constexpr int WSLICE = 1280;     // per-wave list capacity; k/8 = 820 at V = 65536, sigma ~ 27
 
-// order-preserving map float -> uint32 (larger float <=> larger key); -0.0 < +0.0 is harmless here
+// order-preserving map float -> uint32 (larger float <=> larger key)
 __device__ __forceinline__ uint32_t fkey(float f) {
     const uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-struct SampleShared {
-    float redf[16];
-    float redf2[16];
-    uint32_t redu[16];
-    uint32_t redu2[16];
-    int redi[16];
-    float bval[16];
-    float bx[16];
-    uint32_t hist[NB];
-    uint32_t cand[CAND_CAP];
-    uint32_t lane_sums[64];
-    float kx[KEPT_CAP];
-    int ki[KEPT_CAP];
-    int nkept;
-    int ncand;
-    int tbin, above, cnt;
-    uint32_t thr;
-    uint32_t kmin, kmax;
-};
-
-// opaque read: stops the compiler from keeping per-element derived values (keys, bins) alive across the passes,
-// which is what pushes a 128-values-per-lane kernel into scratch
+// opaque read: stops the compiler from keeping per-value derived quantities alive across the passes
 __device__ __forceinline__ float opaque(float x) {
     asm volatile("" : "+v"(x));
     return x;
+}
+
+struct SampleShared {
+    float redf[NW];
+    float redf2[NW];
+    int redi[NW];
+    float bval[NW];
+    float bx[NW];
+    int wcount[NW];
+    uint32_t hist[NB];
+    uint32_t lane_sums[64];
+    uint32_t cand[CAND_CAP];
+    float kx[NW * WSLICE];
+    int ki[NW * WSLICE];
+    int ncand;
+    int tbin, above, cnt;
+    int slow;
+    uint32_t thr;
+    int scount;
+};
+
+// exact k-th largest key of the row by bisection over the 32 key bits, reading the row from memory each round
+__device__ uint32_t slow_threshold(const float* lr, int V, int k, SampleShared& S) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    uint32_t prefix = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t trial = prefix | (1u << bit);
+        int c = 0;
+        for (int i = tid; i < V; i += ST) c += fkey(lr[i]) >= trial;
+        c = wave_sum_i(c);
+        __syncthreads();
+        if (lane == 0) S.redi[wid] = c;
+        __syncthreads();
+        int tot = 0;
+        for (int w = 0; w < NW; ++w) tot += S.redi[w];
+        if (tot >= k) prefix = trial;      // at least k keys >= trial: the k-th largest has this bit set
+    }
+    __syncthreads();
+    return prefix;
+}
+
+__device__ __forceinline__ float noise_gumbel(const SampleArgs& p, long pos_flat, int idx) {
+    if (p.noise_kind == MM_NOISE_GUMBEL) return p.noise[(size_t)pos_flat * p.noise_ld + idx];
+    if (p.noise_kind == MM_NOISE_UNIFORM) return gumbel_of(p.noise[(size_t)pos_flat * p.noise_ld + idx]);
+    if (p.noise_kind == MM_NOISE_PHILOX) {
+        float u[4];
+        philox_uniform4(p.seed, p.row_offset + (uint64_t)pos_flat, p.step, (uint32_t)(idx >> 2), u);
+        const int sel = idx & 3;
+        return gumbel_of(sel == 0 ? u[0] : sel == 1 ? u[1] : sel == 2 ? u[2] : u[3]);
+    }
+    return 0.f;
 }
 
 template <int VEC_IT, bool FULL>
@@ -147,174 +190,156 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
 #pragma unroll
     for (int it = 0; it < VEC_IT; ++it) {
         const int e = (it * ST + tid) * 4;
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 x = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         if (FULL || e < V) x = *reinterpret_cast<const float4*>(lr + e);
         v[it * 4 + 0] = x.x; v[it * 4 + 1] = x.y; v[it * 4 + 2] = x.z; v[it * 4 + 3] = x.w;
     }
-    auto valid = [&](int it) { return FULL || (it * ST + tid) * 4 < V; };   // V % 4 == 0: a float4 is all-valid or all-pad
+    // padding (e >= V) is -inf: neutral for the max and for exp(); min / histogram / list passes skip it by index
 
-    // ---- phase A: row max / min
+    // ---- A: row max / min
     float vmax = -INFINITY, vmin = INFINITY;
 #pragma unroll
-    for (int it = 0; it < VEC_IT; ++it)
-        if (valid(it)) {
+    for (int it = 0; it < VEC_IT; ++it) {
+        const bool ok = FULL || (it * ST + tid) * 4 < V;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { vmax = fmaxf(vmax, v[it * 4 + c]); vmin = fminf(vmin, v[it * 4 + c]); }
+        for (int c = 0; c < 4; ++c) {
+            vmax = fmaxf(vmax, v[it * 4 + c]);
+            vmin = fminf(vmin, ok ? v[it * 4 + c] : INFINITY);
         }
+    }
     vmax = wave_max(vmax);
     vmin = -wave_max(-vmin);
     if (lane == 0) { S.redf[wid] = vmax; S.redf2[wid] = vmin; }
+    if (tid == 0) { S.ncand = 0; S.slow = 0; S.scount = 0; }
+    for (int i = tid; i < NB; i += ST) S.hist[i] = 0;
     __syncthreads();
     vmax = S.redf[0]; vmin = S.redf2[0];
 #pragma unroll
     for (int i = 1; i < NW; ++i) { vmax = fmaxf(vmax, S.redf[i]); vmin = fminf(vmin, S.redf2[i]); }
-    __syncthreads();
 
-    // ---- softmax denominator on the unfiltered logits (mmp.py:603)
+    // ---- B: softmax denominator on the unfiltered logits (fast exp: v_exp_f32, ~1e-6 relative per term)
     float se = 0.f;
 #pragma unroll
-    for (int it = 0; it < VEC_IT; ++it)
-        if (valid(it)) {
+    for (int i = 0; i < VEC_IT * 4; ++i) se += __expf(opaque(v[i]) - vmax);
+
+    // ---- C: value-linear histogram (bin 0 = smallest).  Not usable when the span is 0 / inf / NaN -> slow path
+    const float span = vmax - vmin;
+    const bool fast = (span >= 1e-30f) && (span < 3.0e38f);
+    const float inv_w = fast ? (float)NB / span : 0.f;
+    if (fast) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) se += expf(opaque(v[it * 4 + c]) - vmax);
+        for (int it = 0; it < VEC_IT; ++it) {
+            if (FULL || (it * ST + tid) * 4 < V) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int b = min(NB - 1, (int)((opaque(v[it * 4 + c]) - vmin) * inv_w));
+                    atomicAdd(&S.hist[b], 1u);
+                }
+            }
         }
+    }
     se = wave_sum(se);
+    __syncthreads();                      // histogram complete; redf reads above are done
     if (lane == 0) S.redf[wid] = se;
+    // one wave finds the bin holding the k-th largest: each lane owns 32 consecutive bins
+    const int need = p.k_keep;
+    if (wid == 0 && fast) {
+        uint32_t mine = 0;
+        for (int j = 0; j < NB / 64; ++j) mine += S.hist[lane * (NB / 64) + j];
+        S.lane_sums[lane] = mine;
+        __builtin_amdgcn_wave_barrier();
+        uint32_t above = 0;
+        for (int l2 = lane + 1; l2 < 64; ++l2) above += S.lane_sums[l2];
+        if (above < (uint32_t)need && (uint32_t)need <= above + mine) {
+            uint32_t acc = above;
+            for (int j = NB / 64 - 1; j >= 0; --j) {
+                const uint32_t hc = S.hist[lane * (NB / 64) + j];
+                if ((uint32_t)need <= acc + hc) { S.tbin = lane * (NB / 64) + j; S.above = (int)acc; S.cnt = (int)hc; break; }
+                acc += hc;
+            }
+        }
+    }
     __syncthreads();
     float sumexp = 0.f;
 #pragma unroll
     for (int i = 0; i < NW; ++i) sumexp += S.redf[i];
-    __syncthreads();
+    const int tbin = S.tbin;
+    bool slow = !fast || S.cnt > CAND_CAP;
 
-    // ---- phase B: exact k-th largest key by iterated histogram select
-    uint32_t klo = fkey(vmin), khi = fkey(vmax);
-    int need = p.k_keep;             // rank (1-based, from the top) inside [klo, khi]
-    uint32_t thr = klo;
-    const float span = vmax - vmin;
-    bool fbins = (span >= 1e-30f) && (span < 3.0e38f);   // level 0: value-linear bins spread a bell curve evenly
-    const float inv_w = fbins ? (float)NB / span : 0.f;
-    for (int level = 0; level < 8; ++level) {
-        if (klo == khi) { thr = klo; break; }
-        const uint32_t range = khi - klo;
-        const int sh = max(0, 32 - __clz((int)range) - 11);    // (range >> sh) < 2048
-        auto bin_of = [&](float x, uint32_t key) -> int {
-            if (fbins) {
-                const int bb = (int)((x - vmin) * inv_w);
-                return min(NB - 1, max(0, bb));
-            }
-            return (int)((key - klo) >> sh);
-        };
-        for (int i = tid; i < NB; i += ST) S.hist[i] = 0;
-        if (tid == 0) { S.ncand = 0; S.kmin = 0xFFFFFFFFu; S.kmax = 0u; }
-        __syncthreads();
+    // ---- D: append every value with bin >= tbin to this wave's slice (no atomics: ballot prefix + running count)
+    int wcount = 0;                       // wave-uniform
+    if (!slow) {
+        float* mykx = S.kx + wid * WSLICE;
+        int* myki = S.ki + wid * WSLICE;
 #pragma unroll
-        for (int it = 0; it < VEC_IT; ++it)
-            if (valid(it)) {
+        for (int it = 0; it < VEC_IT; ++it) {
+            const int e = (it * ST + tid) * 4;
+            const bool ok = FULL || e < V;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float x = opaque(v[it * 4 + c]);
-                    const uint32_t key = fkey(x);
-                    if (key >= klo && key <= khi) atomicAdd(&S.hist[bin_of(x, key)], 1u);
-                }
-            }
-        __syncthreads();
-        // one wave finds the bin holding the need-th largest: each lane owns 32 consecutive bins
-        if (wid == 0) {
-            uint32_t mine = 0;
-            for (int j = 0; j < NB / 64; ++j) mine += S.hist[lane * (NB / 64) + j];
-            S.lane_sums[lane] = mine;
-            __builtin_amdgcn_wave_barrier();
-            uint32_t above = 0;                      // elements in lanes above this one
-            for (int l2 = lane + 1; l2 < 64; ++l2) above += S.lane_sums[l2];
-            if (above < (uint32_t)need && (uint32_t)need <= above + mine) {
-                uint32_t acc = above;
-                for (int j = NB / 64 - 1; j >= 0; --j) {
-                    const uint32_t hcount = S.hist[lane * (NB / 64) + j];
-                    if ((uint32_t)need <= acc + hcount) { S.tbin = lane * (NB / 64) + j; S.above = (int)acc; S.cnt = (int)hcount; break; }
-                    acc += hcount;
+            for (int c = 0; c < 4; ++c) {
+                const float x = opaque(v[it * 4 + c]);
+                const bool kp = ok && min(NB - 1, (int)((x - vmin) * inv_w)) >= tbin;
+                const unsigned long long bal = __ballot(kp);
+                if (bal != 0ull) {
+                    const int slot = wcount + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (kp && slot < WSLICE) { mykx[slot] = x; myki[slot] = e + c; }
+                    wcount += __popcll(bal);
                 }
             }
         }
-        __syncthreads();
-        const int tbin = S.tbin, cnt = S.cnt;
-        need -= S.above;
-        const bool small = cnt <= CAND_CAP;
-        // gather the target bin's members (exact select) or their key range (refine)
-#pragma unroll
-        for (int it = 0; it < VEC_IT; ++it)
-            if (valid(it)) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float x = opaque(v[it * 4 + c]);
-                    const uint32_t key = fkey(x);
-                    if (key >= klo && key <= khi && bin_of(x, key) == tbin) {
-                        if (small) { const int slot = atomicAdd(&S.ncand, 1); S.cand[slot] = key; }
-                        else { atomicMin(&S.kmin, key); atomicMax(&S.kmax, key); }
-                    }
-                }
-            }
-        __syncthreads();
-        if (small) {
-            // value t with  #{> t} < need <= #{>= t}  among the candidates
-            for (int i = tid; i < cnt; i += ST) {
-                const uint32_t ki = S.cand[i];
-                int gt = 0, ge = 0;
-                for (int j = 0; j < cnt; ++j) { const uint32_t kj = S.cand[j]; gt += kj > ki; ge += kj >= ki; }
-                if (gt < need && need <= ge) S.thr = ki;
-            }
-            __syncthreads();
-            thr = S.thr;
-            break;
-        }
-        klo = S.kmin; khi = S.kmax;
-        fbins = false;
-        __syncthreads();
-    }
-
-    // ---- compact the kept entries (key >= threshold) into LDS: one LDS atomic per wave-instruction
-    if (tid == 0) S.nkept = 0;
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < VEC_IT; ++it) {
-        const int e = (it * ST + tid) * 4;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float x = opaque(v[it * 4 + c]);
-            const bool kp = valid(it) && fkey(x) >= thr;
-            const unsigned long long bal = __ballot(kp);
-            if (bal != 0ull) {
-                const int leader = __ffsll((long long)bal) - 1;
-                int base = 0;
-                if (lane == leader) base = atomicAdd(&S.nkept, __popcll(bal));
-                base = __shfl(base, leader, 64);
-                const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
-                if (kp && slot < KEPT_CAP) { S.kx[slot] = x; S.ki[slot] = e + c; }
-            }
-        }
+        if (wcount > WSLICE && lane == 0) S.slow = 1;
+        if (lane == 0) S.wcount[wid] = wcount;
     }
     __syncthreads();
-    const int nkept = min(S.nkept, KEPT_CAP);
+    slow = slow || S.slow != 0;
+
+    uint32_t thr;
+    if (!slow) {
+        // ---- exact threshold: the (need - above)-th largest among the members of bin tbin
+        const int need_in = need - S.above;
+        for (int w = 0; w < NW; ++w) {
+            const int cw = S.wcount[w];
+            for (int i = tid; i < cw; i += ST) {
+                const float x = S.kx[w * WSLICE + i];
+                if (min(NB - 1, (int)((x - vmin) * inv_w)) == tbin) { const int sl = atomicAdd(&S.ncand, 1); if (sl < CAND_CAP) S.cand[sl] = fkey(x); }
+            }
+        }
+        __syncthreads();
+        const int cnt = min(S.ncand, CAND_CAP);
+        for (int i = tid; i < cnt; i += ST) {
+            const uint32_t ki = S.cand[i];
+            int gt = 0, ge = 0;
+            for (int j = 0; j < cnt; ++j) { const uint32_t kj = S.cand[j]; gt += kj > ki; ge += kj >= ki; }
+            if (gt < need_in && need_in <= ge) S.thr = ki;      // every thread that satisfies this holds the same key
+        }
+        __syncthreads();
+        thr = S.thr;
+    } else {
+        thr = slow_threshold(lr, V, need, S);
+    }
 
     // ---- Gumbel argmax over the kept entries (mmp.py:410-411); ties -> lower index like torch.argmax
     const float T = p.temperature;
     float best = -INFINITY, best_x = 0.f;
     int best_i = 0x7FFFFFFF;
-    for (int i = tid; i < nkept; i += ST) {
-        const float x = S.kx[i];
-        const int idx = S.ki[i];
-        float g = 0.f;
-        if (p.noise_kind == MM_NOISE_GUMBEL) {
-            g = p.noise[(size_t)pos_flat * p.noise_ld + idx];
-        } else if (p.noise_kind == MM_NOISE_UNIFORM) {
-            g = gumbel_of(p.noise[(size_t)pos_flat * p.noise_ld + idx]);
-        } else if (p.noise_kind == MM_NOISE_PHILOX) {
-            float u[4];
-            philox_uniform4(p.seed, p.row_offset + (uint64_t)pos_flat, p.step, (uint32_t)(idx >> 2), u);
-            const int sel = idx & 3;
-            g = gumbel_of(sel == 0 ? u[0] : sel == 1 ? u[1] : sel == 2 ? u[2] : u[3]);
+    if (!slow) {
+        for (int w = 0; w < NW; ++w) {
+            const int cw = S.wcount[w];
+            for (int i = tid; i < cw; i += ST) {
+                const float x = S.kx[w * WSLICE + i];
+                if (fkey(x) < thr) continue;
+                const int idx = S.ki[w * WSLICE + i];
+                const float y = x / T + noise_gumbel(p, pos_flat, idx);      // IEEE division: same bits as torch's CPU kernel
+                if (y > best || (y == best && idx < best_i)) { best = y; best_i = idx; best_x = x; }
+            }
         }
-        const float y = x / T + g;          // IEEE division: same bits as torch's CPU kernel
-        if (y > best || (y == best && idx < best_i)) { best = y; best_i = idx; best_x = x; }
+    } else {
+        for (int idx = tid; idx < V; idx += ST) {
+            const float x = lr[idx];
+            if (fkey(x) < thr) continue;
+            const float y = x / T + noise_gumbel(p, pos_flat, idx);
+            if (y > best || (y == best && idx < best_i)) { best = y; best_i = idx; best_x = x; }
+        }
     }
     // wave reduce (value desc, index asc)
 #pragma unroll

@@ -35,7 +35,8 @@ def gemm(x, w, out_f32=False, resid=None, out=None):
     N = w.shape[0]
     assert w.shape[1] == K
     if out is None:
-        out = torch.empty(M, N, dtype=torch.float32 if out_f32 else bf16, device=x.device)
+        ldc = (N + 7) // 8 * 8                 # 16-byte aligned rows for the vectorised write-out
+        out = torch.empty(M, ldc, dtype=torch.float32 if out_f32 else bf16, device=x.device)[:, :N]
     L.check(L.lib().mm_gemm_bf16(L.stream(), L.ptr(x), x.stride(0), L.ptr(w), w.stride(0), M, N, K, L.ptr(out),
                                  out.stride(0), int(out_f32), L.ptr(resid)), 'mm_gemm_bf16')
     return out

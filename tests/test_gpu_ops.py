@@ -136,7 +136,8 @@ def test_gemm_dense(M, N, K):
     if N % 4 == 0:
         check_close(ops.gemm(xd, wd, out_f32=True), ref, atol=tol, what=f'gemm f32 {M}x{N}x{K}')
         resid = rnd(M, N, gen=g)
-        check_close(ops.gemm(xd, wd, out_f32=True, resid=resid.to(DEV)), ref + resid, atol=tol + 1e-6, what='gemm f32 + resid')
+        out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+        check_close(ops.gemm(xd, wd, out_f32=True, resid=resid.to(DEV), out=out), ref + resid, atol=tol + 1e-6, what='gemm f32 + resid')
         check_close(ops.gemm(xd, wd), ref, atol=1e-3, rtol=ULP, what='gemm bf16 out')
     else:
         out = torch.empty(M, 4, dtype=torch.float32, device=DEV)     # N=1: ldc padded to 4

@@ -1,0 +1,45 @@
+"""GPU microbenchmark of the MFMA GEMM family on the shapes of the C2 base config (tools only, not a test)."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from muse_maskgit_pytorch_amd import _lib, ops
+
+SHAPES = [('qkv', 16384, 1536, 512), ('out', 16384, 512, 512), ('w1', 16384, 2816, 512), ('w2', 16384, 512, 1408),
+          ('xq', 8192, 512, 512), ('big', 8192, 8192, 8192), ('logits', 8192, 65536, 512)]
+
+
+def timeit(fn, iters=20):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def main():
+    dev = 'cuda'
+    flags = [int(f) for f in (sys.argv[1:] or ['0'])]
+    for name, M, N, K in SHAPES:
+        x = torch.randn(M, K, device=dev).bfloat16()
+        w = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+        out_bf = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        line = f'{name:7s} M={M:6d} N={N:6d} K={K:5d}'
+        for fl in flags:
+            _lib.lib().mm_debug_set(fl)
+            if name == 'logits':
+                o32 = torch.empty(M // 2, N, device=dev, dtype=torch.float32)
+                t = timeit(lambda: ops.gemm_cfg_logits(x[:M // 2], x[M // 2:], w, 3.0, out=o32), 5)
+            else:
+                t = timeit(lambda: ops.gemm(x, w, out=out_bf))
+            line += f' | dbg{fl}: {t * 1e6:8.1f} us {2 * M * N * K / t / 1e12:7.1f} TF'
+        _lib.lib().mm_debug_set(0)
+        print(line, flush=True)
+
+
+if __name__ == '__main__':
+    main()
