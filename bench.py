@@ -54,7 +54,7 @@ def synth_text(total, L, dim, seed=0):
     return te
 
 
-def cpu_baseline(mg, te_one, timesteps, cond_scale, sample_steps=1, max_threads=32):
+def cpu_baseline(mg, te_one, timesteps, cond_scale, sample_steps=18, max_threads=32):
     """The reference algorithm (oracle port, fp32 torch on the host cores) on a bounded sample of the same workload:
     batch 1, `sample_steps` of the 18 decode steps (every reference step costs the same: it always runs the full
     2-pass transformer and the full-vocabulary tail) + one VAE decode, extrapolated to a full generate."""
@@ -67,6 +67,7 @@ def cpu_baseline(mg, te_one, timesteps, cond_scale, sample_steps=1, max_threads=
     vsd = {k: (v.detach().float().cpu() if v.is_floating_point() else v.detach().cpu()) for k, v in mg.vae.state_dict().items()}
     cfg = dict(depth=tr.transformer_blocks.cfg['depth'], heads=tr.transformer_blocks.cfg['heads'])
     n, V = tr.seq_len, tr.num_tokens
+    sample_steps = min(sample_steps, timesteps)
     counts = O.mask_counts(timesteps, n)
     temps = O.step_temperatures(timesteps, 1.)
     ids = torch.full((1, n), tr.mask_id, dtype=torch.long)

@@ -42,7 +42,7 @@ extern "C" {
 #define MM_NOISE_NONE 0     /* plain argmax of logits / temperature                                        */
 #define MM_NOISE_GUMBEL 1   /* caller supplies -log(-log(u)) per (token, vocab) -- bit-exact parity mode     */
 #define MM_NOISE_UNIFORM 2  /* caller supplies u; the kernel applies mmp.py:403-408                          */
-#define MM_NOISE_PHILOX 3   /* on-device Philox4x32-10 keyed by (seed, global token row, step, vocab/4)      */
+#define MM_NOISE_PHILOX 3   /* on-device Philox2x32-10, counter = (global token row, step, vocab/2), key = seed */
 
 typedef void* mm_stream_t;  /* hipStream_t */
 
@@ -76,9 +76,16 @@ int mm_layernorm(mm_stream_t stream, const float* x, int64_t ldx, int rows, int 
                  const float* beta, const int32_t* row_index, void* out, int64_t ldo);
 
 /* GEGLU + LayerNorm(inner) (mmp.py:72-77, 86-87): h bf16 [rows][2*Fp] = [x half | gate half]; out bf16 [rows][Fp]
- * with columns >= F zero. */
+ * with columns >= F zero.  gamma / beta: fp32 [Fp] (zero-padded past F; read with 16-byte loads). */
 int mm_geglu_ln(mm_stream_t stream, const void* h, int64_t ldh, int rows, int F, int Fp, const float* gamma,
                 const float* beta, void* out, int64_t ldo);
+
+/* Linear(D, 2F) + GEGLU in one pass (mmp.py:85 + :72-77): w1 GEGLU-interleaved as in mm_ff_weights; out bf16 [M][Fp] =
+ * gate * gelu_erf(x), columns >= F come out as zero.  Then LayerNorm(inner) (mmp.py:87) on that: mm_layernorm_inner. */
+int mm_gemm_geglu(mm_stream_t stream, const void* x, int64_t ldx, const void* w1, int64_t ldw, int M, int Fp, int K,
+                  void* out, int64_t ldc);
+int mm_layernorm_inner(mm_stream_t stream, const void* a, int64_t lda, int rows, int F, int Fp, const float* gamma,
+                       const float* beta, void* out, int64_t ldo);
 
 /* The Attend seam (attend.py:109-140): softmax(scale * q k^T, key mask) v.  dim_head must be 64.
  * Element strides (batch, head, token) per operand, d contiguous.  nk = number of keys.
@@ -152,8 +159,10 @@ typedef struct mm_attn_weights {
 typedef struct mm_ff_weights {
     const float* ln1_gamma;  /* [D]   */
     const float* ln1_beta;
-    const void* w1;          /* bf16 [2*Fp][D]: rows [0,F) gelu half, rows [Fp,Fp+F) gate half, other rows zero */
-    const float* ln2_gamma;  /* [F]   */
+    const void* w1;          /* bf16 [2*Fp][D], GEGLU-interleaved: per 128-row tile t and half-tile w (0,1), rows
+                              * [128t+64w, +32) = gelu-half features 64t+32w.., rows [128t+64w+32, +32) = the gate-half
+                              * features of the same 32 output columns (features >= F are zero rows)            */
+    const float* ln2_gamma;  /* [Fp]: F gains, zero padded */
     const float* ln2_beta;
     const void* w2;          /* bf16 [D][Fp], columns >= F zero                                            */
 } mm_ff_weights;

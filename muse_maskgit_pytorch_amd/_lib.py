@@ -58,6 +58,8 @@ SIGNATURES = {
     'mm_embed': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp]),
     'mm_layernorm': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_i64]),
     'mm_geglu_ln': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_i64]),
+    'mm_gemm_geglu': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_i64]),
+    'mm_layernorm_inner': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_i64]),
     'mm_attend': (c_int, [c_vp] + [c_vp, c_i64, c_i64, c_i64] * 4 + [c_int, c_int, c_int, c_int, c_vp, c_i64, c_int,
                                                                   c_vp, c_vp, c_vp, c_vp, c_f32]),
     'mm_mask_step': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_i64, c_vp]),

@@ -104,6 +104,29 @@ int mm_geglu_ln(mm_stream_t stream, const void* h, int64_t ldh, int rows, int F,
     return k_geglu_ln((hipStream_t)stream, (const bf16_t*)h, ldh, rows, F, Fp, gamma, beta, (bf16_t*)out, ldo);
 }
 
+int mm_gemm_geglu(mm_stream_t stream, const void* x, int64_t ldx, const void* w1, int64_t ldw, int M, int Fp, int K,
+                  void* out, int64_t ldc) {
+    if (M == 0) return MM_OK;
+    CHK_PTR(x, "x"); CHK_PTR(w1, "w1"); CHK_PTR(out, "out");
+    CHK_ALIGN16(x, "x"); CHK_ALIGN16(w1, "w1"); CHK_ALIGN16(out, "out");
+    if (Fp <= 0 || Fp % 64) return mm_set_error(MM_ERR_SHAPE, "gemm_geglu: Fp must be a positive multiple of 64");
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mode = MODE_DENSE; a.epi = EPI_GEGLU;
+    a.W = (const bf16_t*)w1; a.N = 2 * Fp; a.ldw = (int)ldw; a.K = K;
+    a.M = M; a.X = (const bf16_t*)x; a.ldx = (int)ldx;
+    a.out = out; a.ldc = ldc; a.out_kind = OUT_BF16;
+    return mm_gemm_launch(a, (hipStream_t)stream);
+}
+
+int mm_layernorm_inner(mm_stream_t stream, const void* a, int64_t lda, int rows, int F, int Fp, const float* gamma,
+                       const float* beta, void* out, int64_t ldo) {
+    if (rows == 0) return MM_OK;
+    CHK_PTR(a, "a"); CHK_PTR(gamma, "gamma"); CHK_PTR(out, "out");
+    CHK_ALIGN16(a, "a"); CHK_ALIGN16(out, "out");
+    return k_ln_bf16((hipStream_t)stream, (const bf16_t*)a, lda, rows, F, Fp, gamma, beta, (bf16_t*)out, ldo);
+}
+
 int mm_attend(mm_stream_t stream, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const void* k,
               int64_t k_sb, int64_t k_sh, int64_t k_sn, const void* v, int64_t v_sb, int64_t v_sh, int64_t v_sn,
               void* out, int64_t o_sb, int64_t o_sh, int64_t o_sn, int B, int H, int nq, int nk,
@@ -162,7 +185,7 @@ int mm_conv2d_nhwc(mm_stream_t stream, const void* in, int B, int Hin, int Win, 
     CHK_PTR(in, "in"); CHK_PTR(w, "w"); CHK_PTR(out, "out");
     CHK_ALIGN16(in, "in"); CHK_ALIGN16(w, "w"); CHK_ALIGN16(out, "out");
     if (TH <= 0 || TW <= 0 || Cin <= 0 || Cout <= 0 || Hv <= 0 || Wv <= 0) return mm_set_error(MM_ERR_SHAPE, "conv: bad geometry");
-    if (!out_nchw_f32 && (Cout % 4)) return mm_set_error(MM_ERR_SHAPE, "conv: NHWC bf16 output needs Cout % 4 == 0");
+    if (!out_nchw_f32 && (Cout % 8)) return mm_set_error(MM_ERR_SHAPE, "conv: NHWC bf16 output needs Cout % 8 == 0");
     GemmArgs a;
     memset(&a, 0, sizeof(a));
     a.mode = MODE_CONV;

@@ -104,18 +104,32 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p) {
     const bf16_t* vbase = p.v + (size_t)kb * p.v_sb + (size_t)h * p.v_sh;
     const uint8_t* kmask = p.key_mask ? p.key_mask + (size_t)b * p.km_sb : nullptr;
 
+    // ---- K/V staging is split (issue the global loads early, write LDS late): the next tile's loads are in flight while
+    //      the current tile's MFMAs and softmax run
+    const int s_key = t >> 2, s_dpart = (t & 3) * 16;      // K: thread -> key t>>2, 16 d values at (t&3)*16
+    const int s_kp2 = t & 31, s_dc = t >> 5;               // V: thread -> key pair t&31, d chunk t>>5 (written transposed)
+    uint4 kr0, kr1, vr0, vr1;
+    bool kok, vok0, vok1;
+#define LOAD_KV(kt0_)                                                                                              \
+    {                                                                                                              \
+        const int kg_ = (kt0_) + s_key;                                                                            \
+        kok = kg_ < p.nk;                                                                                          \
+        const bf16_t* kp_ = kbase + (size_t)(kok ? kg_ : 0) * p.k_sn + s_dpart;                                    \
+        kr0 = *reinterpret_cast<const uint4*>(kp_);                                                                \
+        kr1 = *reinterpret_cast<const uint4*>(kp_ + 8);                                                            \
+        const int vg_ = (kt0_) + 2 * s_kp2;                                                                        \
+        vok0 = vg_ < p.nk; vok1 = vg_ + 1 < p.nk;                                                                  \
+        vr0 = *reinterpret_cast<const uint4*>(vbase + (size_t)(vok0 ? vg_ : 0) * p.v_sn + s_dc * 8);               \
+        vr1 = *reinterpret_cast<const uint4*>(vbase + (size_t)(vok1 ? vg_ + 1 : 0) * p.v_sn + s_dc * 8);           \
+    }
+    if (p.nk > 0) LOAD_KV(0);
+
     for (int kt0 = 0; kt0 < p.nk; kt0 += KT) {
-        // ---- stage K tile: thread -> key t>>2, 16 d values at (t&3)*16
+        // ---- write the staged K tile (normalised) and V tile (transposed) to LDS
         {
-            const int key = t >> 2, dpart = (t & 3) * 16;
-            const int kg = kt0 + key;
-            const bool ok = kg < p.nk;
-            const bf16_t* kp = kbase + (size_t)(ok ? kg : 0) * p.k_sn + dpart;
             const uint4 z = make_uint4(0, 0, 0, 0);
-            const uint4 l0 = *reinterpret_cast<const uint4*>(kp);
-            const uint4 l1 = *reinterpret_cast<const uint4*>(kp + 8);
-            uint4 r0 = ok ? l0 : z;
-            uint4 r1 = ok ? l1 : z;
+            uint4 r0 = kok ? kr0 : z;
+            uint4 r1 = kok ? kr1 : z;
             if (p.normalize) {
                 float f0[8], f1[8];
                 unpack8(r0, f0); unpack8(r1, f1);
@@ -127,35 +141,27 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p) {
                 const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    f0[j] = f0[j] * inv * p.k_scale[dpart + j];
-                    f1[j] = f1[j] * inv * p.k_scale[dpart + 8 + j];
+                    f0[j] = f0[j] * inv * p.k_scale[s_dpart + j];
+                    f1[j] = f1[j] * inv * p.k_scale[s_dpart + 8 + j];
                 }
                 r0 = pack8(f0); r1 = pack8(f1);
             }
-            *reinterpret_cast<uint4*>(Ks + sw_off(key, dpart >> 3)) = r0;
-            *reinterpret_cast<uint4*>(Ks + sw_off(key, (dpart >> 3) + 1)) = r1;
-        }
-        // ---- stage V tile transposed: thread -> key pair t&31, d chunk t>>5; Vt[d][key]
-        {
-            const int kp2 = t & 31, dc = t >> 5;
-            const int kg = kt0 + 2 * kp2;
-            const uint4 z = make_uint4(0, 0, 0, 0);
-            const bool ok0 = kg < p.nk, ok1 = kg + 1 < p.nk;
-            const uint4 l0 = *reinterpret_cast<const uint4*>(vbase + (size_t)(ok0 ? kg : 0) * p.v_sn + dc * 8);
-            const uint4 l1 = *reinterpret_cast<const uint4*>(vbase + (size_t)(ok1 ? kg + 1 : 0) * p.v_sn + dc * 8);
-            const uint4 a0 = ok0 ? l0 : z;
-            const uint4 a1 = ok1 ? l1 : z;
+            *reinterpret_cast<uint4*>(Ks + sw_off(s_key, s_dpart >> 3)) = r0;
+            *reinterpret_cast<uint4*>(Ks + sw_off(s_key, (s_dpart >> 3) + 1)) = r1;
+            const uint4 a0 = vok0 ? vr0 : z;
+            const uint4 a1 = vok1 ? vr1 : z;
             const uint32_t w0[4] = {a0.x, a0.y, a0.z, a0.w};
             const uint32_t w1[4] = {a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const uint32_t lo = (i & 1) ? (w0[i >> 1] >> 16) : (w0[i >> 1] & 0xFFFFu);
                 const uint32_t hi = (i & 1) ? (w1[i >> 1] >> 16) : (w1[i >> 1] & 0xFFFFu);
-                const int d = dc * 8 + i;
-                *reinterpret_cast<uint32_t*>(Vt + sw_off(d, kp2 >> 2) + (kp2 & 3) * 4) = lo | (hi << 16);
+                const int d = s_dc * 8 + i;
+                *reinterpret_cast<uint32_t*>(Vt + sw_off(d, s_kp2 >> 2) + (s_kp2 & 3) * 4) = lo | (hi << 16);
             }
         }
         __syncthreads();
+        if (kt0 + KT < p.nk) LOAD_KV(kt0 + KT);      // in flight during this tile's compute
 
         // ---- S^T = K Q^T : acc_s[kt4][r] -> key kt0 + kt4*16 + 4*fg + r, query fr
         f32x4_t acc_s[4];

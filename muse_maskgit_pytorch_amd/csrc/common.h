@@ -49,6 +49,11 @@ __device__ __forceinline__ f32x4_t mfma16(u32x4_t a, u32x4_t b, f32x4_t c) {
                                                    __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
+// exact (erf) GELU of the first GEGLU half times the gate half (muse_maskgit_pytorch.py:72-77)
+__device__ __forceinline__ float geglu_f(float x, float gate) {
+    return gate * (0.5f * x * (1.f + erff(x * 0.70710678118654752440f)));
+}
+
 // full-wave (64-lane) butterfly reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

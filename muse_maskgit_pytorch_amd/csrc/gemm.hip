@@ -182,9 +182,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     __syncthreads();                       // every wave is done reading the last stage
     float* ct = reinterpret_cast<float*>(smem);
     constexpr int CT_LD = BT + 4;          // floats per tile row (528 B)
+    const bool geglu = (MODE == MODE_DENSE) && p.epi == EPI_GEGLU;
 #pragma unroll
     for (int b = 0; b < MT; ++b) {
         const int ml = (MODE == MODE_CFG) ? (wave_m * 32 + b * 16 + fr) : (wave_m * 64 + b * 16 + fr);
+        if (geglu) {
+            // W rows are interleaved per wave: fragments a = 0,1 hold the gelu half, a = 2,3 the gate half of the SAME
+            // 32 output columns -> gate * gelu(x) is lane-local; the tile emits 64 columns
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int nl = wave_n * 32 + a * 16 + fg * 4;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = geglu_f(acc[a][b][r], acc[a + 2][b][r]);
+                *reinterpret_cast<float4*>(ct + ml * CT_LD + nl) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            continue;
+        }
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const int nl = wave_n * 64 + a * 16 + fg * 4;
@@ -211,6 +225,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         }
     }
     __syncthreads();
+
+    if (geglu) {
+        // 64 output columns per tile row (128 B bf16): 8 lanes x 8 columns per row, 32 rows per pass
+        const int c8 = (t & 7) * 8;
+        const int no = tile_n * 64 + c8;           // output column; the output has N/2 columns
+#pragma unroll 4
+        for (int pass = 0; pass < BT / 32; ++pass) {
+            const int ml = pass * 32 + (t >> 3);
+            const int m = m0 + ml;
+            if (m >= p.M || no >= p.N / 2) continue;
+            const float4 lo = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c8);
+            const float4 hi = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c8 + 4);
+            float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + no) = pack8(v);
+        }
+        return;
+    }
 
     // row-contiguous write-out, 16 B per lane, consecutive lanes on consecutive addresses
     auto out_row = [&](int m) -> size_t {
@@ -319,6 +350,9 @@ int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
     if ((a.resid_f32 && (a.ldr % 4)) || (a.resid_bf16 && (a.ldr % 8))) return mm_set_error(MM_ERR_ALIGN, "gemm: residual stride alignment");
     if ((a.resid_f32 && a.out_kind != OUT_F32) || (a.resid_bf16 && a.out_kind != OUT_BF16))
         return mm_set_error(MM_ERR_DTYPE, "gemm: the residual must have the output's dtype");
+    if (a.epi == EPI_GEGLU && (a.mode != MODE_DENSE || (a.N % 128) || a.out_kind != OUT_BF16 || a.bias || a.resid_f32 || a.resid_bf16))
+        return mm_set_error(MM_ERR_SHAPE, "gemm: GEGLU epilogue needs a dense bf16 GEMM with N % 128 == 0");
+    if (!(a.debug & 8) && mm_gemm_big_eligible(a)) return mm_gemm_big_launch(a, stream);
     a.tiles_n = (a.N + BT - 1) / BT;
     const int tm = a.mode == MODE_CFG ? 64 : BT;
     a.tiles_m = (a.M + tm - 1) / tm;

@@ -1,0 +1,255 @@
+// Large-tile variant of the bf16 MFMA GEMM (gemm.hip) for the token-parallel GEMMs of the transformer
+// (M = tokens >= 256):  256 (m) x 128 (n) x 64 (k) per 512-thread workgroup = 8 waves as 4(m) x 2(n), each wave the same
+// 64x64 = 4x4 fragment patch as the small kernel (so each output element sees the identical MFMA sequence: results are
+// bit-identical between the two kernels).
+//
+// Why: at K = 512 the 128x128 kernel is latency-bound, not MFMA-bound (ablation in tools/gemm_bench.py: loop skeleton +
+// exposed DMA latency ~ 2/3 of the time).  Here
+//   * THREE 48 KiB stages with the LDS-DMA issued TWO tiles ahead and a COUNTED s_waitcnt vmcnt(6) (6 DMA instructions per
+//     wave per tile), raw s_barrier -- a __syncthreads() would drain the queue with vmcnt(0);
+//   * one workgroup per CU (144 KiB LDS), 2 waves per SIMD;
+//   * 85 flop per LDS-DMA byte instead of 64, and half as many prologues / epilogues per output element.
+// Same XOR-swizzled 128-byte rows, same LDS-staged row-contiguous epilogue as gemm.hip.
+#include "common.h"
+#include "muse_hip_internal.h"
+
+namespace {
+
+constexpr int BMB = 256;    // m rows per tile (tokens; CFG: 128 tokens x {cond, null})
+constexpr int BNB = 128;    // n rows of W per tile
+constexpr int BK = 64;
+constexpr int W_BYTES = BNB * BK * 2;              // 16 KiB
+constexpr int X_BYTES = BMB * BK * 2;              // 32 KiB
+constexpr int STAGE_B = W_BYTES + X_BYTES;         // 48 KiB
+constexpr int NSTAGE = 3;
+constexpr int CT_LD = BNB + 4;                     // fp32 output tile row stride (floats)
+constexpr int SMEM_B = NSTAGE * STAGE_B;           // 144 KiB >= 256 * 132 * 4 = 132 KiB
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+template <int MODE>
+__global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wave_m = wid >> 1, wave_n = wid & 1;
+    int tile_m, tile_n;
+    xcd_grouped_tile(blockIdx.x, p.tiles_m, p.tiles_n, 8, tile_m, tile_n);
+    const int n0 = tile_n * BNB;
+    const int m0 = tile_m * (MODE == MODE_CFG ? 128 : BMB);
+
+    // ---- per-lane DMA geometry: one instruction = 8 tile rows; lane l -> (row l>>3, physical chunk l&7) holding logical
+    //      chunk (l&7) ^ (row&7).  Wave w stages W rows [16w, 16w+16) (2 instr) and X rows [32w, 32w+32) (4 instr).
+    const int chunk = (lane & 7) ^ (lane >> 3);
+    const bf16_t* wptr[2];
+    const bf16_t* xptr[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int n = n0 + 16 * wid + 8 * i + (lane >> 3);
+        wptr[i] = p.W + (size_t)(n < p.N ? n : 0) * p.ldw + chunk * 8;      // clamped rows feed only unstored outputs
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 32 * wid + 8 * i + (lane >> 3);
+        if constexpr (MODE == MODE_CFG) {
+            const int wm = r >> 6, jj = r & 63;
+            const int tok = m0 + wm * 32 + (jj & 31);
+            xptr[i] = ((jj >> 5) ? p.X2 : p.X) + (size_t)(tok < p.M ? tok : 0) * p.ldx + chunk * 8;
+        } else {
+            const int m = m0 + r;
+            xptr[i] = p.X + (size_t)(m < p.M ? m : 0) * p.ldx + chunk * 8;
+        }
+    }
+
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#define ISSUE_TILE(kt_, stage_)                                                                              \
+    {                                                                                                        \
+        const int k0_ = (kt_) * BK;                                                                          \
+        unsigned char* ws_ = smem + (stage_) * STAGE_B + wid * 2048;                                         \
+        unsigned char* xs_ = smem + (stage_) * STAGE_B + W_BYTES + wid * 4096;                               \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                        \
+            __builtin_amdgcn_global_load_lds(wptr[i] + k0_, (lds_ptr_t)(ws_ + i * 1024), 16, 0, 0);          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                        \
+            __builtin_amdgcn_global_load_lds(xptr[i] + k0_, (lds_ptr_t)(xs_ + i * 1024), 16, 0, 0);          \
+    }
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int KT = p.K / BK;
+    ISSUE_TILE(0, 0);
+    if (KT > 1) ISSUE_TILE(1, 1);
+
+    for (int kt = 0; kt < KT; ++kt) {
+        // tile kt has landed once at most the NEXT tile's 6 DMA instructions of this wave are still outstanding
+        if (kt + 1 < KT && !(p.debug & 2)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my ds_reads of the previous tile are complete
+        __builtin_amdgcn_s_barrier();                          // everybody's DMA of tile kt landed; stage (kt+2)%3 is free
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < KT && !(p.debug & 2)) ISSUE_TILE(kt + 2, (kt + 2) % NSTAGE);
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* ws = smem + (kt % NSTAGE) * STAGE_B;
+        const unsigned char* xs = ws + W_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4_t af[4], bfm[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const u32x4_t*>(ws + lds_off(wave_n * 64 + i * 16 + fr, ks * 4 + fg));
+                bfm[i] = *reinterpret_cast<const u32x4_t*>(xs + lds_off(wave_m * 64 + i * 16 + fr, ks * 4 + fg));
+            }
+            if (!(p.debug & 4)) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(af[a], bfm[b], acc[a][b]);
+            } else {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a][0][0] += __uint_as_float(af[a][0] ^ bfm[a][1]);
+            }
+        }
+    }
+    if ((p.debug & 1) && acc[0][0][0] != 12345.678f) return;
+
+    // ---- epilogue: fp32 tile through LDS, row-contiguous 16-byte write-out (see gemm.hip)
+    constexpr int MT = (MODE == MODE_CFG) ? 2 : 4;
+    constexpr int TROWS = (MODE == MODE_CFG) ? 128 : BMB;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    float* ct = reinterpret_cast<float*>(smem);
+    const bool geglu = (MODE == MODE_DENSE) && p.epi == EPI_GEGLU;
+#pragma unroll
+    for (int b = 0; b < MT; ++b) {
+        const int ml = (MODE == MODE_CFG) ? (wave_m * 32 + b * 16 + fr) : (wave_m * 64 + b * 16 + fr);
+        if (geglu) {      // see gemm.hip: fragments 0,1 = gelu half, 2,3 = gate half of the same 32 output columns
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int nl = wave_n * 32 + a * 16 + fg * 4;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = geglu_f(acc[a][b][r], acc[a + 2][b][r]);
+                *reinterpret_cast<float4*>(ct + ml * CT_LD + nl) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            continue;
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int nl = wave_n * 64 + a * 16 + fg * 4;
+            float v[4];
+            if constexpr (MODE == MODE_CFG) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float c = acc[a][b][r], nlv = acc[a][(b + 2) & 3][r];
+                    v[r] = nlv + (c - nlv) * p.cfg_scale;      // muse_maskgit_pytorch.py:254
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r];
+            }
+            *reinterpret_cast<float4*>(ct + ml * CT_LD + nl) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    __syncthreads();
+
+    if (geglu) {
+        const int c8 = (t & 7) * 8;
+        const int no = tile_n * 64 + c8;
+#pragma unroll 4
+        for (int pass = 0; pass < BMB / 64; ++pass) {
+            const int ml = pass * 64 + (t >> 3);
+            const int m = m0 + ml;
+            if (m >= p.M || no >= p.N / 2) continue;
+            const float4 lo = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c8);
+            const float4 hi = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c8 + 4);
+            float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + no) = pack8(v);
+        }
+        return;
+    }
+
+    if (p.out_kind == OUT_F32) {
+        const int c4 = (t & 31) * 4;
+        const int n = n0 + c4;
+#pragma unroll 4
+        for (int pass = 0; pass < TROWS / 16; ++pass) {
+            const int ml = pass * 16 + (t >> 5);
+            const int m = m0 + ml;
+            if (m >= p.M || n >= p.N) continue;
+            const float4 cv = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c4);
+            float v[4] = {cv.x, cv.y, cv.z, cv.w};
+            const bool full = n + 3 < p.N;
+            if (p.resid_f32) {
+                const float* rp = p.resid_f32 + (size_t)m * p.ldr + n;
+                if (full) {
+                    const float4 r0 = *reinterpret_cast<const float4*>(rp);
+                    v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += rp[r];
+                }
+            }
+            float* op = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n;
+            if (full) *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < p.N) op[r] = v[r];
+            }
+        }
+    } else {
+        const int c8 = (t & 15) * 8;
+        const int n = n0 + c8;
+#pragma unroll 4
+        for (int pass = 0; pass < TROWS / 32; ++pass) {
+            const int ml = pass * 32 + (t >> 4);
+            const int m = m0 + ml;
+            if (m >= p.M || n >= p.N) continue;
+            const float4 lo = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c8);
+            const float4 hi = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c8 + 4);
+            float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + n;
+            if (n + 7 < p.N) *reinterpret_cast<uint4*>(op) = pack8(v);
+            else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) if (n + r < p.N) op[r] = f32_to_bf16(v[r]);
+            }
+        }
+    }
+}
+
+template <int MODE>
+int launch_big(const GemmArgs& a, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<MODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
+        if (e != hipSuccess) return mm_set_hip_error(e, "gemm_big hipFuncSetAttribute");
+        attr_set = true;
+    }
+    const int blocks = a.tiles_m * a.tiles_n;
+    hipLaunchKernelGGL(gemm_big_kernel<MODE>, dim3(blocks), dim3(512), SMEM_B, stream, a);
+    return mm_check_launch("gemm_big_kernel");
+}
+
+}  // namespace
+
+// dense / CFG GEMMs without bias / activation / bf16 residual, large enough to fill 256-row tiles
+bool mm_gemm_big_eligible(const GemmArgs& a) {
+    if (a.mode == MODE_CONV || a.bias || a.act != ACT_NONE || a.resid_bf16 || a.out_kind == OUT_NCHW_F32) return false;
+    const int tok = a.mode == MODE_CFG ? 128 : BMB;
+    const long tiles = (long)((a.M + tok - 1) / tok) * ((a.N + BNB - 1) / BNB);
+    return a.M >= 2 * tok && a.N >= BNB && tiles >= 256;      // one workgroup per CU: fewer tiles than CUs idles the chip
+}
+
+int mm_gemm_big_launch(GemmArgs a, hipStream_t stream) {
+    a.tiles_n = (a.N + BNB - 1) / BNB;
+    const int tm = a.mode == MODE_CFG ? 128 : BMB;
+    a.tiles_m = (a.M + tm - 1) / tm;
+    if (a.mode == MODE_CFG) return launch_big<MODE_CFG>(a, stream);
+    return launch_big<MODE_DENSE>(a, stream);
+}

@@ -132,8 +132,15 @@ void carve_bufs(Carver& c, const mm_transformer* t, size_t rows, Bufs& b) {
 int ff_block(const mm_transformer* t, hipStream_t s, const mm_ff_weights& w, const float* src, float* dst, int rows, Bufs& b) {
     const int D = t->d.dim, F = t->d.ff_inner, Fp = t->Fp;
     RC(k_layernorm(s, src, D, rows, D, w.ln1_gamma, w.ln1_beta, nullptr, b.xn, D));
-    RC(gemm_dense(s, b.xn, D, (const bf16_t*)w.w1, D, rows, 2 * Fp, D, b.h, 2 * Fp, OUT_BF16, nullptr));
-    RC(k_geglu_ln(s, b.h, 2 * Fp, rows, F, Fp, w.ln2_gamma, w.ln2_beta, b.a, Fp));
+    {   // Linear(D, 2F) with the GEGLU fused into the epilogue: w1 is packed GEGLU-interleaved, the GEMM emits gate*gelu(x)
+        GemmArgs a;
+        memset(&a, 0, sizeof(a));
+        a.mode = MODE_DENSE; a.epi = EPI_GEGLU;
+        a.W = (const bf16_t*)w.w1; a.N = 2 * Fp; a.ldw = D; a.K = D; a.M = rows; a.X = b.xn; a.ldx = D;
+        a.out = b.h; a.ldc = Fp; a.out_kind = OUT_BF16;
+        RC(mm_gemm_launch(a, s));
+    }
+    RC(k_ln_bf16(s, b.h, Fp, rows, F, Fp, w.ln2_gamma, w.ln2_beta, b.a, Fp));
     RC(gemm_dense(s, b.a, Fp, (const bf16_t*)w.w2, Fp, rows, D, Fp, dst, D, OUT_F32, dst));
     return MM_OK;
 }

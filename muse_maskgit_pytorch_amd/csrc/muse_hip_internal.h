@@ -9,6 +9,7 @@ typedef uint16_t bf16_t;
 enum { MODE_DENSE = 0, MODE_CFG = 1, MODE_CONV = 2 };
 enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_NCHW_F32 = 2 };
 enum { ACT_NONE = 0, ACT_LEAKY = 1 };
+enum { EPI_NONE = 0, EPI_GEGLU = 1 };
 
 struct GemmArgs {
     int mode;
@@ -25,12 +26,15 @@ struct GemmArgs {
     void* out; long ldc; int out_kind;
     const float* bias; const float* resid_f32; const bf16_t* resid_bf16; long ldr;
     int act; float cfg_scale;
+    int epi;                      // EPI_GEGLU: W rows are GEGLU-interleaved, the tile emits N/2 columns of gate*gelu(x)
     int tiles_m, tiles_n;         // filled by mm_gemm_launch
-    int debug;                    // ablation bits (mm_debug_set): 1 = no epilogue stores, 2 = no DMA after tile 0, 4 = no MFMA
+    int debug;                    // ablation bits (mm_debug_set): 1 = no epilogue stores, 2 = no DMA after tile 0, 4 = no MFMA, 8 = force the 128x128 kernel
 };
 extern int g_mm_debug;
 
 int mm_gemm_launch(GemmArgs a, hipStream_t stream);
+bool mm_gemm_big_eligible(const GemmArgs& a);      // gemm_big.hip: 256x128 tile, 3-stage counted-vmcnt pipeline
+int mm_gemm_big_launch(GemmArgs a, hipStream_t stream);
 
 // error plumbing (thread-local message, never throws across the ABI)
 int mm_set_error(int code, const char* msg);
@@ -45,6 +49,8 @@ int k_layernorm(hipStream_t s, const float* x, long ldx, int rows, int D, const 
 int k_geglu_ln(hipStream_t s, const bf16_t* h, long ldh, int rows, int F, int Fp, const float* gamma, const float* beta,
                bf16_t* out, long ldo);
 int k_add_rowvec(hipStream_t s, float* x, long ldx, int rows, int D, const float* vec);
+int k_ln_bf16(hipStream_t s, const bf16_t* a, long lda, int rows, int F, int Fp, const float* gamma, const float* beta,
+              bf16_t* out, long ldo);
 int k_f32_to_bf16(hipStream_t s, const float* x, bf16_t* out, long count);
 
 struct AttnArgs {
@@ -74,6 +80,8 @@ struct SampleArgs {
     uint64_t seed; uint64_t row_offset; uint32_t step;
     int64_t* ids; float* scores;                 // scattered outputs, indexed by flat position
     int64_t* pred_out; float* score_out;         // optional compact outputs [R]
+    int debug;                                   // ablation bits 16 / 32 / 64 / 128 (tools/sample_bench.py)
+    float z_lo;                                  // histogram lower bound in sigmas above the row mean (set by k_sample_rows)
 };
 int k_sample_rows(hipStream_t s, const SampleArgs& a);
 int k_philox_fill(hipStream_t s, uint64_t seed, uint64_t row_offset, uint32_t step, int rows, int V, float* out);

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // a = gate * gelu_erf(x); out = LN(a) over the F valid columns; columns F..Fp-1 are written as zeros so the
 // following GEMM can run on the padded K.
 constexpr int GG_MAX_IT = 12;  // Fp <= 64 * 8 * 12 = 6144
-template <int NIT>             // 16-byte iterations per lane: 3 (F <= 1536) / 6 / 12
+template <int NIT, bool FUSED_IN>   // 16-byte iterations per lane: 3 (F <= 1536) / 6 / 12; FUSED_IN: h already holds gate*gelu(x) [rows][Fp]
 __global__ __launch_bounds__(256) void geglu_ln_kernel(const bf16_t* __restrict__ h, long ldh, int rows, int F, int Fp,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        bf16_t* __restrict__ out, long ldo) {
@@ -95,11 +95,11 @@ __global__ __launch_bounds__(256) void geglu_ln_kernel(const bf16_t* __restrict_
         if (c < nch) {
             float xv[8], gv[8];
             unpack8(*reinterpret_cast<const uint4*>(hr + c * 8), xv);
-            unpack8(*reinterpret_cast<const uint4*>(hr + Fp + c * 8), gv);
+            if (!FUSED_IN) unpack8(*reinterpret_cast<const uint4*>(hr + Fp + c * 8), gv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float ge = 0.5f * xv[j] * (1.f + erff(xv[j] * 0.70710678118654752440f));
-                const float val = (c * 8 + j < F) ? gv[j] * ge : 0.f;
+                const float act = FUSED_IN ? xv[j] : geglu_f(xv[j], gv[j]);
+                const float val = (c * 8 + j < F) ? act : 0.f;
                 a[it][j] = val;
                 sum += val;
             }
@@ -122,11 +122,18 @@ __global__ __launch_bounds__(256) void geglu_ln_kernel(const bf16_t* __restrict_
     for (int it = 0; it < NIT; ++it) {
         const int c = it * 64 + lane;
         if (c < nch) {
+            // gamma / beta are padded to Fp floats by the caller: two 16-byte loads instead of 16 scalar ones (the scalar
+            // form made this kernel issue-bound at ~1 TB/s)
+            const float4 g0 = *reinterpret_cast<const float4*>(gamma + c * 8), g1 = *reinterpret_cast<const float4*>(gamma + c * 8 + 4);
+            float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+            if (beta) { b0 = *reinterpret_cast<const float4*>(beta + c * 8); b1 = *reinterpret_cast<const float4*>(beta + c * 8 + 4); }
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
             float o[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int col = c * 8 + j;
-                o[j] = (col < F) ? (a[it][j] - mean) * rstd * gamma[col] + (beta ? beta[col] : 0.f) : 0.f;
+                o[j] = (col < F) ? (a[it][j] - mean) * rstd * gg[j] + bb[j] : 0.f;
             }
             *reinterpret_cast<uint4*>(orow + c * 8) = pack8(o);
         }
@@ -186,10 +193,23 @@ int k_geglu_ln(hipStream_t s, const bf16_t* h, long ldh, int rows, int F, int Fp
     if (Fp % 8 || Fp < F || Fp > 64 * 8 * GG_MAX_IT) return mm_set_error(MM_ERR_SHAPE, "geglu_ln: padded inner dim must be a multiple of 8, >= F and <= 6144");
     if (ldh % 8 || ldo % 8) return mm_set_error(MM_ERR_ALIGN, "geglu_ln: strides must be multiples of 8 elements");
     const int nit = (Fp / 8 + 63) / 64;
-    if (nit <= 3) hipLaunchKernelGGL(geglu_ln_kernel<3>, dim3((rows + 3) / 4), dim3(256), 0, s, h, ldh, rows, F, Fp, gamma, beta, out, ldo);
-    else if (nit <= 6) hipLaunchKernelGGL(geglu_ln_kernel<6>, dim3((rows + 3) / 4), dim3(256), 0, s, h, ldh, rows, F, Fp, gamma, beta, out, ldo);
-    else hipLaunchKernelGGL(geglu_ln_kernel<12>, dim3((rows + 3) / 4), dim3(256), 0, s, h, ldh, rows, F, Fp, gamma, beta, out, ldo);
+    if (nit <= 3) hipLaunchKernelGGL((geglu_ln_kernel<3, false>), dim3((rows + 3) / 4), dim3(256), 0, s, h, ldh, rows, F, Fp, gamma, beta, out, ldo);
+    else if (nit <= 6) hipLaunchKernelGGL((geglu_ln_kernel<6, false>), dim3((rows + 3) / 4), dim3(256), 0, s, h, ldh, rows, F, Fp, gamma, beta, out, ldo);
+    else hipLaunchKernelGGL((geglu_ln_kernel<12, false>), dim3((rows + 3) / 4), dim3(256), 0, s, h, ldh, rows, F, Fp, gamma, beta, out, ldo);
     return mm_check_launch("geglu_ln_kernel");
+}
+
+// LayerNorm(inner) on the already-activated GEGLU output a [rows][Fp] bf16 (columns >= F are zero / ignored)
+int k_ln_bf16(hipStream_t s, const bf16_t* a, long lda, int rows, int F, int Fp, const float* gamma, const float* beta,
+              bf16_t* out, long ldo) {
+    if (rows <= 0) return MM_OK;
+    if (Fp % 8 || Fp < F || Fp > 64 * 8 * GG_MAX_IT) return mm_set_error(MM_ERR_SHAPE, "ln_bf16: padded width must be a multiple of 8, >= F and <= 6144");
+    if (lda % 8 || ldo % 8) return mm_set_error(MM_ERR_ALIGN, "ln_bf16: strides must be multiples of 8 elements");
+    const int nit = (Fp / 8 + 63) / 64;
+    if (nit <= 3) hipLaunchKernelGGL((geglu_ln_kernel<3, true>), dim3((rows + 3) / 4), dim3(256), 0, s, a, lda, rows, F, Fp, gamma, beta, out, ldo);
+    else if (nit <= 6) hipLaunchKernelGGL((geglu_ln_kernel<6, true>), dim3((rows + 3) / 4), dim3(256), 0, s, a, lda, rows, F, Fp, gamma, beta, out, ldo);
+    else hipLaunchKernelGGL((geglu_ln_kernel<12, true>), dim3((rows + 3) / 4), dim3(256), 0, s, a, lda, rows, F, Fp, gamma, beta, out, ldo);
+    return mm_check_launch("ln_bf16_kernel");
 }
 
 int k_add_rowvec(hipStream_t s, float* x, long ldx, int rows, int D, const float* vec) {

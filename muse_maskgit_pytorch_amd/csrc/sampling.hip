@@ -13,6 +13,8 @@
 //                512-thread workgroup (128 values per lane) -- the reference sweeps this tensor ~14 times.
 //                This is the HBM-bound kernel of the path: algorithmic bytes = 4*V per row (+ 4*V noise in
 //                parity mode).
+#include <math.h>
+
 #include "common.h"
 #include "muse_hip_internal.h"
 
@@ -52,28 +54,29 @@ __global__ __launch_bounds__(256) void mask_step_kernel(float* __restrict__ scor
     }
 }
 
-// ------------------------------------------------------------------------------------------------ philox4x32-10
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
-                                              uint32_t (&out)[4]) {
+// ------------------------------------------------------------------------------------------------ Philox2x32-10
+// Counter-based: the uniform for (seed, global token row, decode step, vocabulary index v) is output (v & 1) of
+// Philox2x32-10 with the 64-bit counter  row << 24 | (step & 0xFF) << 16 | (v >> 1)  and a 32-bit key mixed from the seed.
+// One call serves two adjacent vocabulary entries; the kernel only evaluates it for the ~10 % kept entries.
+__device__ __forceinline__ void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t k, uint32_t (&out)[2]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-        const uint32_t n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        const uint64_t p = (uint64_t)0xD256D193u * c0;
+        const uint32_t n0 = (uint32_t)(p >> 32) ^ k ^ c1;
+        c1 = (uint32_t)p;
+        c0 = n0;
+        k += 0x9E3779B9u;
     }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+    out[0] = c0; out[1] = c1;
 }
 
-__device__ __forceinline__ void philox_uniform4(uint64_t seed, uint64_t row_global, uint32_t step, uint32_t col4, float (&u)[4]) {
-    uint32_t o[4];
-    philox4x32_10(col4, step, (uint32_t)row_global, (uint32_t)(row_global >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), o);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) u[i] = (float)(o[i] >> 8) * (1.0f / 16777216.0f);   // 24-bit, [0, 1)
+__device__ __forceinline__ void philox_uniform2(uint64_t seed, uint64_t row_global, uint32_t step, uint32_t col2, float (&u)[2]) {
+    const uint64_t ctr = (row_global << 24) | ((uint64_t)(step & 0xFFu) << 16) | (uint64_t)(col2 & 0xFFFFu);
+    const uint32_t key = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x85EBCA6Bu) ^ ((step >> 8) * 0xC2B2AE35u);
+    uint32_t o[2];
+    philox2x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), key, o);
+    u[0] = (float)(o[0] >> 8) * (1.0f / 16777216.0f);   // 24-bit, [0, 1)
+    u[1] = (float)(o[1] >> 8) * (1.0f / 16777216.0f);
 }
 
 __device__ __forceinline__ float gumbel_of(float u) {
@@ -87,9 +90,10 @@ __global__ __launch_bounds__(256) void philox_fill_kernel(uint64_t seed, uint64_
     const long total = (long)rows * nv;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int row = (int)(i / nv), c = (int)(i - (long)row * nv);
-        float u[4];
-        philox_uniform4(seed, row_offset + (uint64_t)row, step, (uint32_t)c, u);
-        *reinterpret_cast<float4*>(out + (long)row * V + c * 4) = make_float4(u[0], u[1], u[2], u[3]);
+        float u0[2], u1[2];
+        philox_uniform2(seed, row_offset + (uint64_t)row, step, (uint32_t)(2 * c), u0);
+        philox_uniform2(seed, row_offset + (uint64_t)row, step, (uint32_t)(2 * c + 1), u1);
+        *reinterpret_cast<float4*>(out + (long)row * V + c * 4) = make_float4(u0[0], u0[1], u1[0], u1[1]);
     }
 }
 
@@ -168,10 +172,9 @@ __device__ __forceinline__ float noise_gumbel(const SampleArgs& p, long pos_flat
     if (p.noise_kind == MM_NOISE_GUMBEL) return p.noise[(size_t)pos_flat * p.noise_ld + idx];
     if (p.noise_kind == MM_NOISE_UNIFORM) return gumbel_of(p.noise[(size_t)pos_flat * p.noise_ld + idx]);
     if (p.noise_kind == MM_NOISE_PHILOX) {
-        float u[4];
-        philox_uniform4(p.seed, p.row_offset + (uint64_t)pos_flat, p.step, (uint32_t)(idx >> 2), u);
-        const int sel = idx & 3;
-        return gumbel_of(sel == 0 ? u[0] : sel == 1 ? u[1] : sel == 2 ? u[2] : u[3]);
+        float u[2];
+        philox_uniform2(p.seed, p.row_offset + (uint64_t)pos_flat, p.step, (uint32_t)(idx >> 1), u);
+        return gumbel_of((idx & 1) ? u[1] : u[0]);
     }
     return 0.f;
 }
@@ -197,43 +200,56 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
     // padding (e >= V) is -inf: neutral for the max and for exp(); min / histogram / list passes skip it by index
 
     // ---- A: row max / min
-    float vmax = -INFINITY, vmin = INFINITY;
+    float vmax = -INFINITY, vmin = INFINITY, s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int it = 0; it < VEC_IT; ++it) {
         const bool ok = FULL || (it * ST + tid) * 4 < V;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            vmax = fmaxf(vmax, v[it * 4 + c]);
-            vmin = fminf(vmin, ok ? v[it * 4 + c] : INFINITY);
+            const float x = v[it * 4 + c];
+            vmax = fmaxf(vmax, x);
+            vmin = fminf(vmin, ok ? x : INFINITY);
+            s1 += ok ? x : 0.f;
+            s2 += ok ? x * x : 0.f;
         }
     }
     vmax = wave_max(vmax);
     vmin = -wave_max(-vmin);
-    if (lane == 0) { S.redf[wid] = vmax; S.redf2[wid] = vmin; }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) { S.redf[wid] = vmax; S.redf2[wid] = vmin; S.bval[wid] = s1; S.bx[wid] = s2; }
     if (tid == 0) { S.ncand = 0; S.slow = 0; S.scount = 0; }
     for (int i = tid; i < NB; i += ST) S.hist[i] = 0;
     __syncthreads();
-    vmax = S.redf[0]; vmin = S.redf2[0];
+    vmax = S.redf[0]; vmin = S.redf2[0]; s1 = S.bval[0]; s2 = S.bx[0];
 #pragma unroll
-    for (int i = 1; i < NW; ++i) { vmax = fmaxf(vmax, S.redf[i]); vmin = fminf(vmin, S.redf2[i]); }
+    for (int i = 1; i < NW; ++i) { vmax = fmaxf(vmax, S.redf[i]); vmin = fminf(vmin, S.redf2[i]); s1 += S.bval[i]; s2 += S.bx[i]; }
 
     // ---- B: softmax denominator on the unfiltered logits (fast exp: v_exp_f32, ~1e-6 relative per term)
     float se = 0.f;
+    if (!(p.debug & 128)) {
 #pragma unroll
-    for (int i = 0; i < VEC_IT * 4; ++i) se += __expf(opaque(v[i]) - vmax);
+        for (int i = 0; i < VEC_IT * 4; ++i) se += __expf(opaque(v[i]) - vmax);
+    }
 
     // ---- C: value-linear histogram (bin 0 = smallest).  Not usable when the span is 0 / inf / NaN -> slow path
-    const float span = vmax - vmin;
+    //      Only the upper tail is binned: values below lo = mean + z_lo * std cannot hold the k-th largest of a bell-shaped
+    //      row (z_lo = normal quantile of 1 - k/V minus a 0.8 sigma margin, from the host); if fewer than k values turn out to
+    //      be >= lo the row takes the slow path.  This cuts the LDS atomics ~3x and makes the bins 3x finer.
+    const float mean = s1 / (float)V;
+    const float var = fmaxf(s2 / (float)V - mean * mean, 0.f);
+    const float lo = fmaxf(vmin, mean + p.z_lo * sqrtf(var));
+    const float span = vmax - lo;
     const bool fast = (span >= 1e-30f) && (span < 3.0e38f);
     const float inv_w = fast ? (float)NB / span : 0.f;
-    if (fast) {
+    if (fast && !(p.debug & 16)) {
 #pragma unroll
         for (int it = 0; it < VEC_IT; ++it) {
             if (FULL || (it * ST + tid) * 4 < V) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const int b = min(NB - 1, (int)((opaque(v[it * 4 + c]) - vmin) * inv_w));
-                    atomicAdd(&S.hist[b], 1u);
+                    const float x = opaque(v[it * 4 + c]);
+                    if (x >= lo) atomicAdd(&S.hist[min(NB - 1, (int)((x - lo) * inv_w))], 1u);
                 }
             }
         }
@@ -250,6 +266,7 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
         __builtin_amdgcn_wave_barrier();
         uint32_t above = 0;
         for (int l2 = lane + 1; l2 < 64; ++l2) above += S.lane_sums[l2];
+        if (lane == 0 && above + mine < (uint32_t)need) S.slow = 1;      // the tail estimate missed: fewer than k values >= lo
         if (above < (uint32_t)need && (uint32_t)need <= above + mine) {
             uint32_t acc = above;
             for (int j = NB / 64 - 1; j >= 0; --j) {
@@ -264,13 +281,16 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
 #pragma unroll
     for (int i = 0; i < NW; ++i) sumexp += S.redf[i];
     const int tbin = S.tbin;
-    bool slow = !fast || S.cnt > CAND_CAP;
+    bool slow = !fast || S.slow != 0 || S.cnt > CAND_CAP;
 
     // ---- D: append every value with bin >= tbin to this wave's slice (no atomics: ballot prefix + running count)
     int wcount = 0;                       // wave-uniform
-    if (!slow) {
+    if (!slow && !(p.debug & 32)) {
         float* mykx = S.kx + wid * WSLICE;
         int* myki = S.ki + wid * WSLICE;
+        // lower edge of bin tbin, lowered by a relative 1e-6 so that rounding can only ADD a few values of bin tbin-1
+        // (harmless: they are neither candidates nor >= the final threshold)
+        const float edge = lo + (float)tbin / inv_w - (fabsf(lo) + span) * 1e-6f;
 #pragma unroll
         for (int it = 0; it < VEC_IT; ++it) {
             const int e = (it * ST + tid) * 4;
@@ -278,7 +298,7 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float x = opaque(v[it * 4 + c]);
-                const bool kp = ok && min(NB - 1, (int)((x - vmin) * inv_w)) >= tbin;
+                const bool kp = ok && x >= edge;
                 const unsigned long long bal = __ballot(kp);
                 if (bal != 0ull) {
                     const int slot = wcount + __popcll(bal & ((1ull << lane) - 1ull));
@@ -294,6 +314,7 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
     slow = slow || S.slow != 0;
 
     uint32_t thr;
+    if (p.debug & 64) { thr = 0xFFFFFFFFu; } else
     if (!slow) {
         // ---- exact threshold: the (need - above)-th largest among the members of bin tbin
         const int need_in = need - S.above;
@@ -301,7 +322,7 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
             const int cw = S.wcount[w];
             for (int i = tid; i < cw; i += ST) {
                 const float x = S.kx[w * WSLICE + i];
-                if (min(NB - 1, (int)((x - vmin) * inv_w)) == tbin) { const int sl = atomicAdd(&S.ncand, 1); if (sl < CAND_CAP) S.cand[sl] = fkey(x); }
+                if (x >= lo && min(NB - 1, (int)((x - lo) * inv_w)) == tbin) { const int sl = atomicAdd(&S.ncand, 1); if (sl < CAND_CAP) S.cand[sl] = fkey(x); }
             }
         }
         __syncthreads();
@@ -372,7 +393,25 @@ int k_mask_step(hipStream_t s, float* scores, int64_t* ids, int B, int n, int k,
     return mm_check_launch("mask_step_kernel");
 }
 
-int k_sample_rows(hipStream_t s, const SampleArgs& a) {
+// normal quantile (Acklam's rational approximation, |error| < 1.2e-9 in the central region): used only to place the
+// histogram's lower bound, never for a result
+static double norm_quantile(double p) {
+    static const double a[] = {-3.969683028665376e+01, 2.209460984245205e+02, -2.759285104469687e+02, 1.383577518672690e+02, -3.066479806614716e+01, 2.506628277459239e+00};
+    static const double b[] = {-5.447609879822406e+01, 1.615858368580409e+02, -1.556989798598866e+02, 6.680131188771972e+01, -1.328068155288572e+01};
+    static const double c[] = {-7.784894002430293e-03, -3.223964580411365e-01, -2.400758277161838e+00, -2.549732539343734e+00, 4.374664141464968e+00, 2.938163982698783e+00};
+    static const double d[] = {7.784695709041462e-03, 3.224671290700398e-01, 2.445134137142996e+00, 3.754408661907416e+00};
+    if (p <= 0.0) return -1e9;
+    if (p >= 1.0) return 1e9;
+    if (p < 0.02425) { const double q = sqrt(-2 * log(p)); return (((((c[0]*q+c[1])*q+c[2])*q+c[3])*q+c[4])*q+c[5]) / ((((d[0]*q+d[1])*q+d[2])*q+d[3])*q+1); }
+    if (p > 1 - 0.02425) { const double q = sqrt(-2 * log(1 - p)); return -(((((c[0]*q+c[1])*q+c[2])*q+c[3])*q+c[4])*q+c[5]) / ((((d[0]*q+d[1])*q+d[2])*q+d[3])*q+1); }
+    const double q = p - 0.5, r = q * q;
+    return (((((a[0]*r+a[1])*r+a[2])*r+a[3])*r+a[4])*r+a[5])*q / (((((b[0]*r+b[1])*r+b[2])*r+b[3])*r+b[4])*r+1);
+}
+
+int k_sample_rows(hipStream_t s, const SampleArgs& a_in) {
+    SampleArgs a = a_in;
+    a.debug = g_mm_debug;
+    a.z_lo = (float)(norm_quantile(1.0 - (double)a.k_keep / (double)a.V) - 0.8);
     if (a.R <= 0) return MM_OK;
     if (a.V <= 0 || (a.V % 4) || a.V > 65536) return mm_set_error(MM_ERR_SHAPE, "sample_rows: V must be a multiple of 4 and <= 65536");
     if (a.k_keep < 1 || a.k_keep > a.V) return mm_set_error(MM_ERR_SHAPE, "sample_rows: k_keep out of range");

@@ -148,13 +148,11 @@ class Transformer(nn.Module):
         F = w2.shape[1]
         Fp = (F + 63) // 64 * 64
         D = w1.shape[1]
-        w1p = torch.zeros(2 * Fp, D, dtype=bf16, device=w1.device)
-        w1p[:F] = w1[:F].to(bf16)
-        w1p[Fp:Fp + F] = w1[F:].to(bf16)
+        w1p = ops.pack_w1_geglu(w1, Fp)          # GEGLU-interleaved tile order (the GEMM epilogue emits gate*gelu(x))
         w2p = ops.pad_cols(w2.to(bf16), 64)
         assert w2p.shape[1] == Fp
         t = dict(g1=ff[0].gamma.detach().float().contiguous(), b1=ff[0].beta.float().contiguous(), w1=w1p,
-                 g2=ff[3].gamma.detach().float().contiguous(), b2=ff[3].beta.float().contiguous(), w2=w2p)
+                 g2=ops.pad_cols(ff[3].gamma.detach().float(), Fp), b2=ops.pad_cols(ff[3].beta.float(), Fp), w2=w2p)
         keep.append(t)
         fw = L.FFWeights(L.ptr(t['g1']), L.ptr(t['b1']), L.ptr(t['w1']), L.ptr(t['g2']), L.ptr(t['b2']), L.ptr(t['w2']))
         return fw, F, Fp

@@ -80,8 +80,50 @@ def geglu_ln(h, F, gamma, beta=None):
     rows, two_fp = h.shape
     Fp = two_fp // 2
     out = torch.empty(rows, Fp, dtype=bf16, device=h.device)
+    gamma, beta = pad_cols(gamma.float(), Fp), (pad_cols(beta.float(), Fp) if beta is not None else None)
     L.check(L.lib().mm_geglu_ln(L.stream(), L.ptr(h), h.stride(0), rows, F, Fp, L.ptr(gamma), L.ptr(beta), L.ptr(out), Fp),
             'mm_geglu_ln')
+    return out
+
+
+def pack_w1_geglu(w1, Fp):
+    """FeedForward's first Linear weight [2F, D] (rows [0,F) = gelu half, [F,2F) = gate half, mmp.py:72-77,85) -> bf16
+    [2*Fp, D] in the tile order the GEGLU-fused GEMM epilogue expects: per 128-row tile t and wave half w, 32 gelu-half
+    rows (output columns 64t+32w .. +31) followed by the 32 gate-half rows of the same columns; columns >= F are zero."""
+    F2, D = w1.shape
+    F = F2 // 2
+    out = torch.zeros(2 * Fp, D, dtype=bf16, device=w1.device)
+    r = torch.arange(2 * Fp, device=w1.device)
+    t, rem = r // 128, r % 128
+    w, rem2 = rem // 64, rem % 64
+    is_gate = rem2 >= 32
+    col = 64 * t + 32 * w + (rem2 % 32)                 # output column of this packed row
+    src = torch.where(is_gate, col + F, col)
+    valid = col < F
+    out[valid] = w1[src[valid]].to(bf16)
+    return out
+
+
+def gemm_geglu(x, w1_packed, out=None):
+    """x bf16 [M, K] @ GEGLU-interleaved w1 [2Fp, K] -> bf16 [M, Fp] = gate * gelu(x-half)."""
+    _chk_cuda(x, w1_packed)
+    M, K = x.shape
+    Fp = w1_packed.shape[0] // 2
+    if out is None:
+        out = torch.empty(M, Fp, dtype=bf16, device=x.device)
+    L.check(L.lib().mm_gemm_geglu(L.stream(), L.ptr(x), x.stride(0), L.ptr(w1_packed), w1_packed.stride(0), M, Fp, K, L.ptr(out),
+                                  out.stride(0)), 'mm_gemm_geglu')
+    return out
+
+
+def layernorm_inner(a, F, gamma, beta=None):
+    """LayerNorm over the first F of Fp columns of a bf16 [rows, Fp]; padding columns are written as zero."""
+    _chk_cuda(a, gamma, beta)
+    rows, Fp = a.shape
+    out = torch.empty(rows, Fp, dtype=bf16, device=a.device)
+    gamma, beta = pad_cols(gamma.float(), Fp), (pad_cols(beta.float(), Fp) if beta is not None else None)
+    L.check(L.lib().mm_layernorm_inner(L.stream(), L.ptr(a), a.stride(0), rows, F, Fp, L.ptr(gamma), L.ptr(beta), L.ptr(out), Fp),
+            'mm_layernorm_inner')
     return out
 
 

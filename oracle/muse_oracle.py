@@ -55,8 +55,8 @@ def geglu(x):
 def feed_forward(x, sd, prefix, rp=None):
     """muse_maskgit_pytorch.py:79-89 -- LN(D) -> Linear(D,2F) -> GEGLU -> LN(F) -> Linear(F,D), no bias."""
     h = _rp(rp, layer_norm(x, sd[prefix + '0.gamma'], sd[prefix + '0.beta']))
-    h = _rp(rp, h @ sd[prefix + '1.weight'].t())
-    h = geglu(h)
+    h = h @ sd[prefix + '1.weight'].t()
+    h = _rp(rp, geglu(h))          # HIP path: GEGLU runs on the fp32 accumulators in the GEMM epilogue, its result is stored bf16
     h = _rp(rp, layer_norm(h, sd[prefix + '3.gamma'], sd[prefix + '3.beta']))
     return h @ sd[prefix + '4.weight'].t()
 

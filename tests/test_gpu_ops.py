@@ -156,6 +156,30 @@ def test_gemm_is_transpose_sensitive_and_row_independent():
     assert torch.equal(full[100:177], part)
 
 
+@pytest.mark.parametrize('M,N,K', [(2048, 1536, 512), (700, 2816, 512), (1030, 512, 1408), (512, 128, 64)])
+def test_gemm_large_tile_kernel_is_bit_identical_to_small(M, N, K):
+    """M >= 512 takes the 256x128 / 3-stage kernel (gemm_big.hip); debug bit 8 forces the 128x128 kernel.  Same MFMA
+    sequence per output element -> identical bits, repeated to shake out pipeline races."""
+    if DRY:
+        pytest.skip('kernel-structure test')
+    g = torch.Generator().manual_seed(M + N)
+    x, w = r16(rnd(M, K, gen=g)).to(DEV, bf16), r16(rnd(N, K, gen=g, scale=0.1)).to(DEV, bf16)
+    resid = rnd(M, N, gen=g).to(DEV)
+    lib = _lib.lib()
+    lib.mm_debug_set(8)
+    small_f32 = ops.gemm(x, w, out_f32=True, resid=resid, out=torch.empty(M, N, device=DEV))
+    small_bf = ops.gemm(x, w)
+    xc, xn = x[: M // 2].contiguous(), x[M // 2: 2 * (M // 2)].contiguous()
+    small_cfg = ops.gemm_cfg_logits(xc, xn, w, 3.0)
+    lib.mm_debug_set(0)
+    ref = x.double().cpu() @ w.double().cpu().t()
+    check_close(small_bf, ref, atol=1e-3, rtol=ULP, what='small kernel')
+    for rep in range(5):
+        assert torch.equal(ops.gemm(x, w, out_f32=True, resid=resid, out=torch.empty(M, N, device=DEV)), small_f32), f'f32 rep {rep}'
+        assert torch.equal(ops.gemm(x, w), small_bf), f'bf16 rep {rep}'
+        assert torch.equal(ops.gemm_cfg_logits(xc, xn, w, 3.0), small_cfg), f'cfg rep {rep}'
+
+
 @pytest.mark.parametrize('M,N,K', [(64, 512, 128), (100, 8192, 512), (2, 65536, 512), (257, 640, 64)])
 def test_gemm_cfg_logits(M, N, K):
     g = torch.Generator().manual_seed(11 + M)
@@ -208,6 +232,26 @@ def test_geglu_ln(F_):
     ref[:, :F_] = O.layer_norm(a, gamma, beta)
     got = ops.geglu_ln(h.to(DEV, bf16), F_, gamma.to(DEV), beta.to(DEV))
     check_close(got, ref, atol=1e-3, rtol=ULP, what='geglu_ln')
+    assert (got[:, F_:].float() == 0).all()
+
+
+@pytest.mark.parametrize('M,D,F_', [(256, 128, 341), (1000, 512, 1365), (64, 512, 1365)])
+def test_gemm_geglu_fused_and_layernorm_inner(M, D, F_):
+    if DRY:
+        pytest.skip('kernel-structure test')
+    Fp = (F_ + 63) // 64 * 64
+    g = torch.Generator().manual_seed(M + F_)
+    x = r16(rnd(M, D, gen=g))
+    w1 = r16(rnd(2 * F_, D, gen=g, scale=0.1))
+    h = x.double() @ w1.double().t()
+    ref = (h[:, F_:] * F.gelu(h[:, :F_])).float()
+    a = ops.gemm_geglu(x.to(DEV, bf16), ops.pack_w1_geglu(w1.to(DEV), Fp))
+    assert a.shape == (M, Fp) and (a[:, F_:].float() == 0).all()
+    check_close(a[:, :F_], ref, atol=1e-3, rtol=ULP, what='fused GEGLU GEMM')
+    gamma, beta = 1 + 0.2 * rnd(F_, gen=g), 0.1 * rnd(F_, gen=g)
+    got = ops.layernorm_inner(a, F_, gamma.to(DEV), beta.to(DEV))
+    exp = O.layer_norm(a[:, :F_].float().cpu(), gamma, beta)
+    check_close(got[:, :F_], exp, atol=1e-3, rtol=ULP, what='layernorm_inner')
     assert (got[:, F_:].float() == 0).all()
 
 

@@ -144,7 +144,21 @@ def test_ff_packing_layout():
     assert (F_, Fp) == (341, 384)
     w1p, w2p = keep[0]['w1'].float(), keep[0]['w2'].float()
     w1 = ff[1].weight.detach().bfloat16().float()
-    assert torch.equal(w1p[:341], w1[:341]) and torch.equal(w1p[384:384 + 341], w1[341:])
-    assert w1p[341:384].abs().sum() == 0 and w1p[384 + 341:].abs().sum() == 0
+    assert w1p.shape == (768, 128)
+    # GEGLU-interleaved order: tile t, half w: 32 gelu-half rows then the 32 gate-half rows of the same output columns
+    for t_, w_, j in [(0, 0, 0), (0, 1, 5), (2, 1, 31), (5, 0, 20)]:
+        col = 64 * t_ + 32 * w_ + j
+        gelu_row, gate_row = w1p[128 * t_ + 64 * w_ + j], w1p[128 * t_ + 64 * w_ + 32 + j]
+        if col < 341:
+            assert torch.equal(gelu_row, w1[col]) and torch.equal(gate_row, w1[341 + col])
+        else:
+            assert gelu_row.abs().sum() == 0 and gate_row.abs().sum() == 0
+    # emulating the fused epilogue on the packed matrix reproduces GEGLU(x @ w1^T) in the first F columns, zeros after
+    x = torch.randn(3, 128)
+    y = (x @ w1p.t()).reshape(3, 6, 2, 2, 32)                    # [row][tile][half][gelu|gate][32]
+    fused = (y[..., 1, :] * torch.nn.functional.gelu(y[..., 0, :])).reshape(3, 384)
+    h = x @ w1.t()
+    ref = h[:, 341:] * torch.nn.functional.gelu(h[:, :341])
+    assert torch.allclose(fused[:, :341], ref, atol=1e-5) and fused[:, 341:].abs().sum() == 0
     assert w2p.shape == (128, 384) and w2p[:, 341:].abs().sum() == 0
     assert int(128 * 4 * 2 / 3) == 341 and int(512 * 4 * 2 / 3) == 1365
