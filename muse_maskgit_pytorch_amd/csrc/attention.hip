@@ -24,15 +24,46 @@ constexpr float NEG_BIG = -3.0e38f;
 
 __device__ __forceinline__ int sw_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
-__global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[8192 + 8192 + 4 * 2048];
+template <int NWV>      // waves per workgroup: 4 (64 queries) or 8 (128 queries: K/V staging amortised over twice the queries)
+__global__ __launch_bounds__(NWV * 64) void attention_kernel(const AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[8192 + 8192 + NWV * 2048];
     unsigned char* Ks = smem;
     unsigned char* Vt = smem + 8192;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     unsigned char* Ps = smem + 16384 + w * 2048;
     const int fr = lane & 15, fg = lane >> 4;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int q_wave0 = blockIdx.x * 64 + w * 16;
+    const int q_wave0 = blockIdx.x * (NWV * 16) + w * 16;
+
+    // (the first K/V tile's loads are issued here, ahead of the Q / null-key prologue, so the latencies overlap)
+    const int kb = p.kv_batch_mod > 0 ? b % p.kv_batch_mod : b;
+    const bf16_t* kbase = p.k + (size_t)kb * p.k_sb + (size_t)h * p.k_sh;
+    const bf16_t* vbase = p.v + (size_t)kb * p.v_sb + (size_t)h * p.v_sh;
+    const uint8_t* kmask = p.key_mask ? p.key_mask + (size_t)b * p.km_sb : nullptr;
+
+    // ---- K/V staging is split (issue the global loads early, write LDS late): the next tile's loads are in flight while
+    //      the current tile's MFMAs and softmax run
+    // K: 512 16-byte chunks per tile: NWV=4 -> 2 adjacent chunks per thread, NWV=8 -> 1 chunk per thread
+    constexpr int KCH = 512 / (NWV * 64);                   // chunks per thread (2 or 1)
+    const int s_key = t / (8 / KCH), s_dpart = (t % (8 / KCH)) * (8 * KCH);
+    const int s_kp2 = t & 31, s_dc = (t >> 5) & 7;         // V: threads 0..255 -> key pair t&31, d chunk t>>5 (written transposed)
+    const bool v_thread = t < 256;
+    uint4 kr0, kr1, vr0, vr1;
+    bool kok, vok0, vok1;
+#define LOAD_KV(kt0_)                                                                                              \
+    {                                                                                                              \
+        const int kg_ = (kt0_) + s_key;                                                                            \
+        kok = kg_ < p.nk;                                                                                          \
+        const bf16_t* kp_ = kbase + (size_t)(kok ? kg_ : 0) * p.k_sn + s_dpart;                                    \
+        kr0 = *reinterpret_cast<const uint4*>(kp_);                                                                \
+        if (KCH == 2) kr1 = *reinterpret_cast<const uint4*>(kp_ + 8);                                              \
+        const int vg_ = (kt0_) + 2 * s_kp2;                                                                        \
+        vok0 = vg_ < p.nk; vok1 = vg_ + 1 < p.nk;                                                                  \
+        vr0 = *reinterpret_cast<const uint4*>(vbase + (size_t)(vok0 ? vg_ : 0) * p.v_sn + s_dc * 8);               \
+        vr1 = *reinterpret_cast<const uint4*>(vbase + (size_t)(vok1 ? vg_ + 1 : 0) * p.v_sn + s_dc * 8);           \
+    }
+    if (p.nk > 0) LOAD_KV(0);
+
 
     // ---- Q fragment (B operand of S^T): query = q_wave0 + fr, d = ks*32 + 8*fg .. +7
     const int qi = q_wave0 + fr;
@@ -99,37 +130,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p) {
         }
     }
 
-    const int kb = p.kv_batch_mod > 0 ? b % p.kv_batch_mod : b;
-    const bf16_t* kbase = p.k + (size_t)kb * p.k_sb + (size_t)h * p.k_sh;
-    const bf16_t* vbase = p.v + (size_t)kb * p.v_sb + (size_t)h * p.v_sh;
-    const uint8_t* kmask = p.key_mask ? p.key_mask + (size_t)b * p.km_sb : nullptr;
-
-    // ---- K/V staging is split (issue the global loads early, write LDS late): the next tile's loads are in flight while
-    //      the current tile's MFMAs and softmax run
-    const int s_key = t >> 2, s_dpart = (t & 3) * 16;      // K: thread -> key t>>2, 16 d values at (t&3)*16
-    const int s_kp2 = t & 31, s_dc = t >> 5;               // V: thread -> key pair t&31, d chunk t>>5 (written transposed)
-    uint4 kr0, kr1, vr0, vr1;
-    bool kok, vok0, vok1;
-#define LOAD_KV(kt0_)                                                                                              \
-    {                                                                                                              \
-        const int kg_ = (kt0_) + s_key;                                                                            \
-        kok = kg_ < p.nk;                                                                                          \
-        const bf16_t* kp_ = kbase + (size_t)(kok ? kg_ : 0) * p.k_sn + s_dpart;                                    \
-        kr0 = *reinterpret_cast<const uint4*>(kp_);                                                                \
-        kr1 = *reinterpret_cast<const uint4*>(kp_ + 8);                                                            \
-        const int vg_ = (kt0_) + 2 * s_kp2;                                                                        \
-        vok0 = vg_ < p.nk; vok1 = vg_ + 1 < p.nk;                                                                  \
-        vr0 = *reinterpret_cast<const uint4*>(vbase + (size_t)(vok0 ? vg_ : 0) * p.v_sn + s_dc * 8);               \
-        vr1 = *reinterpret_cast<const uint4*>(vbase + (size_t)(vok1 ? vg_ + 1 : 0) * p.v_sn + s_dc * 8);           \
-    }
-    if (p.nk > 0) LOAD_KV(0);
-
     for (int kt0 = 0; kt0 < p.nk; kt0 += KT) {
         // ---- write the staged K tile (normalised) and V tile (transposed) to LDS
-        {
+        if (!(p.debug & 512)) {
             const uint4 z = make_uint4(0, 0, 0, 0);
             uint4 r0 = kok ? kr0 : z;
-            uint4 r1 = kok ? kr1 : z;
+            uint4 r1 = (KCH == 2 && kok) ? kr1 : z;
             if (p.normalize) {
                 float f0[8], f1[8];
                 unpack8(r0, f0); unpack8(r1, f1);
@@ -138,16 +144,18 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p) {
                 for (int j = 0; j < 8; ++j) ss += f0[j] * f0[j] + f1[j] * f1[j];
                 ss += __shfl_xor(ss, 1, 64);
                 ss += __shfl_xor(ss, 2, 64);
+                if (KCH == 1) ss += __shfl_xor(ss, 4, 64);
                 const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     f0[j] = f0[j] * inv * p.k_scale[s_dpart + j];
-                    f1[j] = f1[j] * inv * p.k_scale[s_dpart + 8 + j];
+                    if (KCH == 2) f1[j] = f1[j] * inv * p.k_scale[s_dpart + 8 + j];
                 }
                 r0 = pack8(f0); r1 = pack8(f1);
             }
             *reinterpret_cast<uint4*>(Ks + sw_off(s_key, s_dpart >> 3)) = r0;
-            *reinterpret_cast<uint4*>(Ks + sw_off(s_key, (s_dpart >> 3) + 1)) = r1;
+            if (KCH == 2) *reinterpret_cast<uint4*>(Ks + sw_off(s_key, (s_dpart >> 3) + 1)) = r1;
+            if (v_thread) {
             const uint4 a0 = vok0 ? vr0 : z;
             const uint4 a1 = vok1 ? vr1 : z;
             const uint32_t w0[4] = {a0.x, a0.y, a0.z, a0.w};
@@ -159,10 +167,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p) {
                 const int d = s_dc * 8 + i;
                 *reinterpret_cast<uint32_t*>(Vt + sw_off(d, s_kp2 >> 2) + (s_kp2 & 3) * 4) = lo | (hi << 16);
             }
+            }
         }
         __syncthreads();
         if (kt0 + KT < p.nk) LOAD_KV(kt0 + KT);      // in flight during this tile's compute
 
+        if (p.debug & 256) { __syncthreads(); continue; }
         // ---- S^T = K Q^T : acc_s[kt4][r] -> key kt0 + kt4*16 + 4*fg + r, query fr
         f32x4_t acc_s[4];
 #pragma unroll
@@ -175,28 +185,42 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p) {
             }
         }
         float tmax = NEG_BIG;
+        // interior tiles without a key mask need no per-score validity test (wave-uniform branch)
+        const bool edge_tile = (kt0 + KT > p.nk) || (kmask != nullptr);
+        if (!edge_tile) {
 #pragma unroll
-        for (int kt4 = 0; kt4 < 4; ++kt4)
+            for (int kt4 = 0; kt4 < 4; ++kt4)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int kg = kt0 + kt4 * 16 + 4 * fg + r;
-                bool ok = kg < p.nk;
-                if (ok && kmask) ok = kmask[kg] != 0;
-                const float s = ok ? acc_s[kt4][r] * p.scale : NEG_BIG;
-                acc_s[kt4][r] = s;
-                tmax = fmaxf(tmax, s);
-            }
+                for (int r = 0; r < 4; ++r) {
+                    const float s = acc_s[kt4][r] * p.scale;
+                    acc_s[kt4][r] = s;
+                    tmax = fmaxf(tmax, s);
+                }
+        } else {
+#pragma unroll
+            for (int kt4 = 0; kt4 < 4; ++kt4)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kg = kt0 + kt4 * 16 + 4 * fg + r;
+                    bool ok = kg < p.nk;
+                    if (ok && kmask) ok = kmask[kg] != 0;
+                    const float s = ok ? acc_s[kt4][r] * p.scale : NEG_BIG;
+                    acc_s[kt4][r] = s;
+                    tmax = fmaxf(tmax, s);
+                }
+        }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);
-        const float alpha = expf(m_run - m_new);
+        // the weights are rounded to bf16 for the PV MFMA, so the hardware exp2 path (~1e-6 relative) is exact enough
+        const float alpha = __expf(m_run - m_new);
         float psum = 0.f;
 #pragma unroll
         for (int kt4 = 0; kt4 < 4; ++kt4) {
             float pv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                pv[r] = expf(acc_s[kt4][r] - m_new);
+                pv[r] = (p.debug & 1024) ? acc_s[kt4][r] - m_new : __expf(acc_s[kt4][r] - m_new);
                 psum += pv[r];
             }
             // P[query fr][keys kt4*16 + 4fg .. +3] -> 8-byte LDS write
@@ -229,31 +253,51 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p) {
         __syncthreads();   // all waves done with Ks / Vt before the next tile is staged
     }
 
-    // ---- epilogue: O / l  -> bf16
+    // ---- epilogue: O / l -> bf16, transposed through this wave's P buffer (16 queries x 64 d = 2 KiB) so that each lane
+    //      stores 2 x 16 B of one 128-byte output row instead of 16 scattered 2-byte values
     const float linv = 1.f / l_run;
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float lr = __shfl(linv, 4 * fg + r, 64);
-        const int qo = q_wave0 + 4 * fg + r;
-        if (qo < p.nq) {
-            bf16_t* op = p.out + (size_t)b * p.o_sb + (size_t)h * p.o_sh + (size_t)qo * p.o_sn;
+        const int row = 4 * fg + r;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) op[dt * 16 + fr] = f32_to_bf16(acc_o[dt][r] * lr);
+        for (int dt = 0; dt < 4; ++dt)
+            *reinterpret_cast<bf16_t*>(Ps + row * 128 + (dt * 16 + fr) * 2) = f32_to_bf16(acc_o[dt][r] * lr);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = i * 64 + lane;            // 128 chunks of 16 B: row c>>3, chunk c&7
+        const int qo = q_wave0 + (c >> 3);
+        if (qo < p.nq) {
+            const uint4 val = *reinterpret_cast<const uint4*>(Ps + (c >> 3) * 128 + (c & 7) * 16);
+            *reinterpret_cast<uint4*>(p.out + (size_t)b * p.o_sb + (size_t)h * p.o_sh + (size_t)qo * p.o_sn + (c & 7) * 8) = val;
         }
     }
 }
 
 }  // namespace
 
-int k_attention(hipStream_t s, const AttnArgs& a) {
+int k_attention(hipStream_t s, const AttnArgs& a_in) {
+    AttnArgs a = a_in;
+    a.debug = g_mm_debug;
     if (a.B <= 0 || a.H <= 0 || a.nq <= 0) return MM_OK;
     if (a.nk < 0) return mm_set_error(MM_ERR_SHAPE, "attention: nk < 0");
     if (a.nk == 0 && !a.null_k) return mm_set_error(MM_ERR_SHAPE, "attention: no keys at all");
     if ((a.q_sn % 8) || (a.k_sn % 8) || (a.v_sn % 8) || (a.q_sh % 8) || (a.k_sh % 8) || (a.v_sh % 8) ||
-        (a.q_sb % 8) || (a.k_sb % 8) || (a.v_sb % 8))
+        (a.q_sb % 8) || (a.k_sb % 8) || (a.v_sb % 8) || (a.o_sn % 8) || (a.o_sh % 8) || (a.o_sb % 8))
         return mm_set_error(MM_ERR_ALIGN, "attention: q/k/v strides must be multiples of 8 elements");
     if (a.normalize && (!a.q_scale || !a.k_scale)) return mm_set_error(MM_ERR_SHAPE, "attention: normalize needs q_scale/k_scale");
-    dim3 grid((a.nq + 63) / 64, a.H, a.B);
-    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, s, a);
+    const int reps = 1 + ((g_mm_debug >> 16) & 0xFF);      // tools/attn_bench.py: back-to-back launches from C
+    for (int r = 0; r < reps; ++r) {
+        if (a.nq >= 128 && a.nk >= 128 && !(g_mm_debug & 2048)) {
+            dim3 grid((a.nq + 127) / 128, a.H, a.B);
+            hipLaunchKernelGGL(attention_kernel<8>, grid, dim3(512), 0, s, a);
+        } else {
+            dim3 grid((a.nq + 63) / 64, a.H, a.B);
+            hipLaunchKernelGGL(attention_kernel<4>, grid, dim3(256), 0, s, a);
+        }
+    }
     return mm_check_launch("attention_kernel");
 }

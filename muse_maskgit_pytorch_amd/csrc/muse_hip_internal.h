@@ -65,6 +65,7 @@ struct AttnArgs {
     const float* null_k; const float* null_v;    // optional [H][64] fp32 (raw parameter values)
     float scale;                                 // 8
     int kv_batch_mod;                            // > 0: k/v batch index = b % kv_batch_mod (CFG halves share one context)
+    int debug;                                   // ablation bits 256 (no compute) / 512 (no staging) / 1024 (no softmax exp)
 };
 int k_attention(hipStream_t s, const AttnArgs& a);
 

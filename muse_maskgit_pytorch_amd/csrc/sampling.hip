@@ -318,10 +318,11 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
     if (!slow) {
         // ---- exact threshold: the (need - above)-th largest among the members of bin tbin
         const int need_in = need - S.above;
-        for (int w = 0; w < NW; ++w) {
-            const int cw = S.wcount[w];
-            for (int i = tid; i < cw; i += ST) {
-                const float x = S.kx[w * WSLICE + i];
+        {   // each wave scans its own slice for the members of bin tbin (a few dozen per row)
+            const float* mykx = S.kx + wid * WSLICE;
+            const int cw = min(wcount, WSLICE);
+            for (int i = lane; i < cw; i += 64) {
+                const float x = mykx[i];
                 if (x >= lo && min(NB - 1, (int)((x - lo) * inv_w)) == tbin) { const int sl = atomicAdd(&S.ncand, 1); if (sl < CAND_CAP) S.cand[sl] = fkey(x); }
             }
         }
@@ -344,14 +345,22 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
     float best = -INFINITY, best_x = 0.f;
     int best_i = 0x7FFFFFFF;
     if (!slow) {
-        for (int w = 0; w < NW; ++w) {
-            const int cw = S.wcount[w];
-            for (int i = tid; i < cw; i += ST) {
-                const float x = S.kx[w * WSLICE + i];
-                if (fkey(x) < thr) continue;
-                const int idx = S.ki[w * WSLICE + i];
-                const float y = x / T + noise_gumbel(p, pos_flat, idx);      // IEEE division: same bits as torch's CPU kernel
-                if (y > best || (y == best && idx < best_i)) { best = y; best_i = idx; best_x = x; }
+        // each wave walks its own slice, 4 independent entries per lane per trip so the RNG's multiply chains overlap
+        const float* mykx = S.kx + wid * WSLICE;
+        const int* myki = S.ki + wid * WSLICE;
+        const int cw = min(wcount, WSLICE);
+        for (int base = 0; base < cw; base += 256) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * 64 + lane;
+                if (i < cw) {
+                    const float x = mykx[i];
+                    if (fkey(x) >= thr) {
+                        const int idx = myki[i];
+                        const float y = x / T + noise_gumbel(p, pos_flat, idx);      // IEEE division: same bits as torch's CPU kernel
+                        if (y > best || (y == best && idx < best_i)) { best = y; best_i = idx; best_x = x; }
+                    }
+                }
             }
         }
     } else {

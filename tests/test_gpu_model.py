@@ -226,3 +226,36 @@ def test_superres_context_with_cond_ids(golden):
     mg = mm.MaskGit(image_size=128, transformer=t, vae=vae, cond_vae=vae.copy_for_eval(), cond_image_size=64).to(DEV)
     out = mg.generate(['a', 'b'], timesteps=3, text_embeds=te, cond_images=torch.randn(2, 3, 64, 64, device=DEV), seed=3, return_ids=True)
     assert out.shape == (2, 8, 8) and (out < 512).all()
+
+
+@pytest.mark.parametrize('name,kw,B,n,L,nc', [
+    ('super-res shapes (C4): 1024 tokens, 256 cond ids in the context', dict(num_tokens=512, seq_len=1024, dim=128, depth=1, heads=8), 2, 1024, 9, 256),
+    ('paper-scale widths (C5): dim 1024, 16 heads, vocabulary 8192', dict(num_tokens=8192, seq_len=64, dim=1024, depth=2, heads=16), 2, 64, 12, 0),
+    ('base widths (C2): dim 512, FF inner 1365', dict(num_tokens=1024, seq_len=256, dim=512, depth=2, heads=8), 3, 256, 20, 0),
+])
+def test_transformer_other_configs_vs_oracle(name, kw, B, n, L, nc):
+    """random-init models at the shapes of the other BASELINE configs (reduced depth so the CPU oracle stays fast)."""
+    torch.manual_seed(5)
+    t = mm.MaskGitTransformer(t5_name='t5-small', dim_head=64, **kw)
+    with torch.no_grad():
+        for p_ in t.parameters():
+            p_.copy_(p_.to(torch.bfloat16).float())
+    sd = {k: v.detach().clone() for k, v in t.state_dict().items()}
+    t = t.to(DEV).eval()
+    gen = torch.Generator().manual_seed(1)
+    ids = torch.randint(0, kw['num_tokens'] + 1, (B, n), generator=gen)
+    te = torch.randn(B, L, 512, generator=gen)
+    te[-1, L // 2:] = 0
+    cids = torch.randint(0, kw['num_tokens'], (B, nc), generator=gen) if nc else None
+    cfg = dict(depth=kw['depth'], heads=kw['heads'])
+    for drop in (0., 1.):
+        got = t(ids.to(DEV), text_embeds=te.to(DEV), cond_drop_prob=drop, conditioning_token_ids=cids.to(DEV) if nc else None)
+        ref = O.transformer_forward(sd, cfg, ids, te, drop, conditioning_token_ids=cids, rp=O.bf16_round)
+        e = _report(f'{name} drop={drop}', got, ref)
+        scale = ref.abs().max().item()
+        assert e.max() < 0.03 * scale and e.mean() < 3e-3 * scale
+    # the fused decode loop runs at these shapes too (ids only)
+    if n <= 256:
+        mg = mm.MaskGit(image_size=16 * int(n ** 0.5), transformer=t, vae=None)
+        out = mg.generate(['x'] * B, timesteps=3, text_embeds=te, seed=2, fmap_size=int(n ** 0.5))
+        assert out.shape == (B, int(n ** 0.5), int(n ** 0.5)) and (out < kw['num_tokens']).all() and (out >= 0).all()
