@@ -28,13 +28,15 @@ struct GemmArgs {
     int act; float cfg_scale;
     int epi;                      // EPI_GEGLU: W rows are GEGLU-interleaved, the tile emits N/2 columns of gate*gelu(x)
     int tiles_m, tiles_n;         // filled by mm_gemm_launch
-    int debug;                    // ablation bits (mm_debug_set): 1 = no epilogue stores, 2 = no DMA after tile 0, 4 = no MFMA, 8 = force the 128x128 kernel
+    int debug;                    // ablation bits (mm_debug_set): 1 = no epilogue stores, 2 = no DMA after tile 0, 4 = no MFMA, 8 = force the 128x128 kernel, 4096 = no persistent kernel
 };
 extern int g_mm_debug;
 
 int mm_gemm_launch(GemmArgs a, hipStream_t stream);
 bool mm_gemm_big_eligible(const GemmArgs& a);      // gemm_big.hip: 256x128 tile, 3-stage counted-vmcnt pipeline
 int mm_gemm_big_launch(GemmArgs a, hipStream_t stream);
+bool mm_gemm_pers_eligible(const GemmArgs& a);     // gemm_pers.hip: persistent 256x128, stores overlapped with the next tile
+int mm_gemm_pers_launch(GemmArgs a, hipStream_t stream);
 
 // error plumbing (thread-local message, never throws across the ABI)
 int mm_set_error(int code, const char* msg);

@@ -180,6 +180,38 @@ def test_gemm_large_tile_kernel_is_bit_identical_to_small(M, N, K):
         assert torch.equal(ops.gemm_cfg_logits(xc, xn, w, 3.0), small_cfg), f'cfg rep {rep}'
 
 
+@pytest.mark.parametrize('kind,M,N,K', [('dense', 16384, 1536, 512), ('dense', 8192, 2048, 1024), ('dense', 9000, 4096, 512),
+                                         ('geglu', 16384, 2816, 512), ('cfg', 8128, 8192, 512), ('cfg', 4096, 65536, 512)])
+def test_gemm_persistent_kernel_is_bit_identical(kind, M, N, K):
+    """>= 256 tiles of 256x128 with a pure-store epilogue take the persistent kernel (gemm_pers.hip: cross-tile DMA
+    prefetch, stores overlapped with the next tile, counted vmcnt); debug bit 4096 disables it.  Identical MFMA
+    sequence -> identical bits; repeated runs to shake out pipeline races (ragged M included)."""
+    if DRY:
+        pytest.skip('kernel-structure test')
+    g = torch.Generator().manual_seed(M + N + K)
+    lib = _lib.lib()
+    w = r16(rnd(N, K, gen=g, scale=0.1)).to(DEV, bf16)
+    if kind == 'cfg':
+        xc, xn = r16(rnd(M, K, gen=g)).to(DEV, bf16), r16(rnd(M, K, gen=g)).to(DEV, bf16)
+        run = lambda: ops.gemm_cfg_logits(xc, xn, w, 3.0)
+    elif kind == 'geglu':
+        x = r16(rnd(M, K, gen=g)).to(DEV, bf16)
+        run = lambda: ops.gemm_geglu(x, w)
+    else:
+        x = r16(rnd(M, K, gen=g)).to(DEV, bf16)
+        run = lambda: ops.gemm(x, w)
+    lib.mm_debug_set(4096)
+    ref = run()
+    lib.mm_debug_set(0)
+    for rep in range(6):
+        got = run()
+        assert torch.equal(got, ref), f'{kind} rep {rep}: {(got != ref).sum().item()} of {got.numel()} elements differ'
+    if kind == 'dense':
+        sub = slice(0, 512)
+        exact = x[sub].double().cpu() @ w.double().cpu().t()
+        check_close(ref[sub], exact, atol=1e-3, rtol=ULP, what='non-persistent reference itself')
+
+
 @pytest.mark.parametrize('M,N,K', [(64, 512, 128), (100, 8192, 512), (2, 65536, 512), (257, 640, 64)])
 def test_gemm_cfg_logits(M, N, K):
     g = torch.Generator().manual_seed(11 + M)

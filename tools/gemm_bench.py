@@ -23,7 +23,7 @@ def timeit(fn, iters=20):
 
 def main():
     dev = 'cuda'
-    flags = [int(f) for f in (sys.argv[1:] or ['0', '8'])]
+    flags = [int(f) for f in (sys.argv[1:] or ['0', '4096', '8'])]
     for name, M, N, K in SHAPES:
         x = torch.randn(M, K, device=dev).bfloat16()
         w = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
