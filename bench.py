@@ -170,6 +170,21 @@ def main():
     loop_ms = sum(a.elapsed_time(b) for a, b in marks)
 
     if rank == 0:
+        # HBM traffic per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+        # (separate runs: counters cannot be collected inside the timed region); null when no summary is committed
+        pmc = {}
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r01_bench_b32_pmc_summary.json')) as f:
+                for name, v in json.load(f).items():
+                    pmc[name] = v
+        except OSError:
+            pass
+
+        def traffic_of(substr):
+            for name, v in pmc.items():
+                if substr in name:
+                    return v['hbm_bytes_per_launch']
+            return None
         total_images = world * B * args.steps
         value = total_images / elapsed
         passes = 2 * T
@@ -188,14 +203,18 @@ def main():
                        'weights': 'random init (module defaults, torch.manual_seed(0))'},
             'transformer_tok_per_s_per_gpu': tok_s_gpu,
             'decode_loop_ms_per_step': loop_ms / args.steps,
-            'roofline': {'kernel': 'gemm_kernel<MODE_CFG> (to_logits + classifier-free guidance)', 'bound': 'mfma',
+            'roofline': {'kernel': 'gemm_pers_kernel<MODE_CFG> (to_logits + classifier-free guidance, persistent 256x128 MFMA GEMM)', 'bound': 'mfma',
                          'achieved': g_flops / (g_ms * 1e-3) / 1e12 if g_ms else None, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': (g_flops / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if g_ms else None, 'traffic': None,
+                         'frac': (g_flops / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if g_ms else None,
+                         'traffic': traffic_of('gemm_pers_kernel<1>') if not args.tiny and B == 32 else None,
+                         'traffic_source': 'profiles/r01_bench_b32_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch, FETCH x2 gfx950 correction)',
                          'launches': g_cnt, 'avg_launch_ms': g_ms / g_cnt if g_cnt else None,
                          'algorithmic_flops_per_launch': g_flops / g_cnt if g_cnt else None},
             'roofline_hbm': {'kernel': 'sample_kernel (top-k + Gumbel argmax + confidence)', 'bound': 'hbm',
                              'achieved': s_bytes / (s_ms * 1e-3) / 1e9 if s_ms else None, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                             'frac': (s_bytes / (s_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if s_ms else None, 'traffic': None,
+                             'frac': (s_bytes / (s_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if s_ms else None,
+                             'traffic': traffic_of('sample_kernel') if not args.tiny and B == 32 else None,
+                             'algorithmic_bytes_per_launch': s_bytes / s_cnt if s_cnt else None,
                              'launches': s_cnt, 'avg_launch_ms': s_ms / s_cnt if s_cnt else None},
         }
         if world == 1 and not args.no_cpu_baseline:
