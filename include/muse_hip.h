@@ -114,6 +114,14 @@ int mm_sample_rows(mm_stream_t stream, const float* logits, int64_t ld, int R, i
                    uint64_t seed, uint64_t row_offset, uint32_t step, int64_t* ids, float* scores,
                    int64_t* pred_out, float* score_out);
 
+/* Training-forward losses of Transformer.forward (mmp.py:337-348), forward only:
+ *   mm_ce_loss : F.cross_entropy over the vocabulary with ignore_index, mean over the non-ignored rows; logits fp32 [R][ld],
+ *                labels int64 [R], row_loss_ws fp32 [R] scratch, out fp32 [1] (NaN when every row is ignored, like torch).
+ *   mm_bce_loss: F.binary_cross_entropy_with_logits(x, y), mean; x, y fp32 [n] (TokenCritic, dim_out == 1). */
+int mm_ce_loss(mm_stream_t stream, const float* logits, int64_t ld, int R, int V, const int64_t* labels, int64_t ignore_index,
+               float* row_loss_ws, float* out);
+int mm_bce_loss(mm_stream_t stream, const float* x, const float* y, int n, float* out);
+
 /* The uniforms MM_NOISE_PHILOX draws for rows [row_offset, row_offset + rows) at `step`: out fp32 [rows][V]. */
 int mm_philox_uniform(mm_stream_t stream, uint64_t seed, uint64_t row_offset, uint32_t step, int rows, int V,
                       float* out);

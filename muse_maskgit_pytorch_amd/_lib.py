@@ -65,6 +65,8 @@ SIGNATURES = {
     'mm_mask_step': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_i64, c_vp]),
     'mm_sample_rows': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_f32, c_int, c_vp, c_i64, c_u64, c_u64,
                                c_u32, c_vp, c_vp, c_vp, c_vp]),
+    'mm_ce_loss': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_i64, c_vp, c_vp]),
+    'mm_bce_loss': (c_int, [c_vp, c_vp, c_vp, c_int, c_vp]),
     'mm_philox_uniform': (c_int, [c_vp, c_u64, c_u64, c_u32, c_int, c_int, c_vp]),
     'mm_conv2d_nhwc': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int] + [c_int] * 12 + [c_vp, c_int, c_vp, c_vp, c_int]),
     'mm_glu_nhwc': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp]),

@@ -172,6 +172,18 @@ int mm_sample_rows(mm_stream_t stream, const float* logits, int64_t ld, int R, i
     return k_sample_rows((hipStream_t)stream, a);
 }
 
+int mm_ce_loss(mm_stream_t stream, const float* logits, int64_t ld, int R, int V, const int64_t* labels, int64_t ignore_index,
+               float* row_loss_ws, float* out) {
+    CHK_PTR(logits, "logits"); CHK_PTR(labels, "labels"); CHK_PTR(row_loss_ws, "row_loss_ws"); CHK_PTR(out, "out");
+    CHK_ALIGN16(logits, "logits");
+    return k_ce_loss((hipStream_t)stream, logits, ld, R, V, labels, ignore_index, row_loss_ws, out);
+}
+
+int mm_bce_loss(mm_stream_t stream, const float* x, const float* y, int n, float* out) {
+    CHK_PTR(x, "x"); CHK_PTR(y, "y"); CHK_PTR(out, "out");
+    return k_bce_loss((hipStream_t)stream, x, y, n, out);
+}
+
 int mm_philox_uniform(mm_stream_t stream, uint64_t seed, uint64_t row_offset, uint32_t step, int rows, int V, float* out) {
     if (rows == 0) return MM_OK;
     CHK_PTR(out, "out"); CHK_ALIGN16(out, "out");

@@ -93,6 +93,10 @@ int k_text_context(hipStream_t s, const float* text, int rows, int text_dim, int
 int k_gather_rows_bf16(hipStream_t s, const bf16_t* table, int D, const int64_t* idx, int B, int nc, int vocab_rows,
                        bf16_t* out, long out_batch_stride, long out_row_offset, uint8_t* mask, int m, int L);
 
+int k_ce_loss(hipStream_t s, const float* logits, long ld, int R, int V, const int64_t* labels, int64_t ignore_index,
+              float* row_loss_ws, float* out);
+int k_bce_loss(hipStream_t s, const float* x, const float* y, int n, float* out);
+
 // vae kernels
 int k_lfq_decode(hipStream_t s, const int64_t* ids, long count, int bits, int C, const float* w, const float* b, bf16_t* out);
 int k_lfq_encode(hipStream_t s, const bf16_t* x, long count, int C, int bits, const float* w, const float* b,

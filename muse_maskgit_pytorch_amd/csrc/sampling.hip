@@ -452,3 +452,98 @@ int k_philox_fill(hipStream_t s, uint64_t seed, uint64_t row_offset, uint32_t st
     hipLaunchKernelGGL(philox_fill_kernel, dim3((int)blocks), dim3(256), 0, s, seed, row_offset, step, rows, V, out);
     return mm_check_launch("philox_fill_kernel");
 }
+
+// ------------------------------------------------------------------------------------------------ training-forward losses
+// F.cross_entropy(logits (b n c -> b c n), labels, ignore_index) (muse_maskgit_pytorch.py:343): per row
+// loss = logsumexp(logits) - logits[label], rows with label == ignore_index contribute nothing; the mean over the other rows
+// is taken by ce_finish_kernel.  One 256-thread workgroup streams a row once (online max / sum): HBM-bound, 4*V bytes per row.
+namespace {
+
+__global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, long ld, int V, const int64_t* __restrict__ labels,
+                                                      int64_t ignore_index, float* __restrict__ row_loss) {
+    __shared__ float sm[4], ss[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t lab = labels[row];
+    if (lab == ignore_index) { if (tid == 0) row_loss[row] = -1.f; return; }      // marker: losses are >= 0
+    const float* lr = logits + (size_t)row * ld;
+    float m = -INFINITY, s = 0.f;
+    for (int i = tid * 4; i < V; i += 256 * 4) {
+        const float4 x = *reinterpret_cast<const float4*>(lr + i);
+        const float mx = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
+        if (mx > m) { s *= expf(m - mx); m = mx; }
+        s += expf(x.x - m) + expf(x.y - m) + expf(x.z - m) + expf(x.w - m);
+    }
+    // combine (m, s) pairs: wave butterfly then across the 4 waves
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o, 64), os = __shfl_xor(s, o, 64);
+        const float nm = fmaxf(m, om);
+        s = (nm == -INFINITY) ? 0.f : s * expf(m - nm) + os * expf(om - nm);
+        m = nm;
+    }
+    if (lane == 0) { sm[wid] = m; ss[wid] = s; }
+    __syncthreads();
+    if (tid == 0) {
+        float M = sm[0], S = ss[0];
+        for (int w = 1; w < 4; ++w) {
+            const float nm = fmaxf(M, sm[w]);
+            S = S * expf(M - nm) + ss[w] * expf(sm[w] - nm);
+            M = nm;
+        }
+        const bool ok = lab >= 0 && lab < V;
+        row_loss[row] = ok ? (M + logf(S)) - lr[lab] : -1.f;
+    }
+}
+
+// mean over the rows that are not ignored (row_loss >= 0); a single workgroup: R is a few thousand
+__global__ __launch_bounds__(256) void ce_finish_kernel(const float* __restrict__ row_loss, int R, float* __restrict__ out) {
+    __shared__ float ssum[4];
+    __shared__ int scnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    float s = 0.f;
+    int c = 0;
+    for (int i = tid; i < R; i += 256) { const float v = row_loss[i]; if (v >= 0.f) { s += v; ++c; } }
+    s = wave_sum(s);
+    c = wave_sum_i(c);
+    if (lane == 0) { ssum[wid] = s; scnt[wid] = c; }
+    __syncthreads();
+    if (tid == 0) {
+        const float S = ssum[0] + ssum[1] + ssum[2] + ssum[3];
+        const int Cn = scnt[0] + scnt[1] + scnt[2] + scnt[3];
+        out[0] = Cn > 0 ? S / (float)Cn : NAN;          // torch returns nan when every target is ignored
+    }
+}
+
+// F.binary_cross_entropy_with_logits(x, y) (muse_maskgit_pytorch.py:341, 374): mean(max(x,0) - x*y + log1p(exp(-|x|)))
+__global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ x, const float* __restrict__ y, int n, float* __restrict__ out) {
+    __shared__ float ssum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    float s = 0.f;
+    for (int i = tid; i < n; i += 256) {
+        const float v = x[i];
+        s += fmaxf(v, 0.f) - v * y[i] + log1pf(expf(-fabsf(v)));
+    }
+    s = wave_sum(s);
+    if (lane == 0) ssum[wid] = s;
+    __syncthreads();
+    if (tid == 0) out[0] = (ssum[0] + ssum[1] + ssum[2] + ssum[3]) / (float)n;
+}
+
+}  // namespace
+
+int k_ce_loss(hipStream_t s, const float* logits, long ld, int R, int V, const int64_t* labels, int64_t ignore_index,
+              float* row_loss_ws, float* out) {
+    if (R <= 0) return mm_set_error(MM_ERR_SHAPE, "ce_loss: no rows");
+    if (V % 4 || ld % 4) return mm_set_error(MM_ERR_ALIGN, "ce_loss: V and the row stride must be multiples of 4");
+    hipLaunchKernelGGL(ce_rows_kernel, dim3(R), dim3(256), 0, s, logits, ld, V, labels, ignore_index, row_loss_ws);
+    int rc = mm_check_launch("ce_rows_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, s, row_loss_ws, R, out);
+    return mm_check_launch("ce_finish_kernel");
+}
+
+int k_bce_loss(hipStream_t s, const float* x, const float* y, int n, float* out) {
+    if (n <= 0) return mm_set_error(MM_ERR_SHAPE, "bce_loss: no elements");
+    hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(256), 0, s, x, y, n, out);
+    return mm_check_launch("bce_kernel");
+}

@@ -46,6 +46,18 @@ def cosine_schedule(t):
     return torch.cos(t * math.pi * 0.5)
 
 
+def _get_mask_subset_prob(mask, prob, min_mask=0):
+    """mmp.py:46-59 (BERT-style: a random subset of the masked positions keeps its token)."""
+    batch, seq = mask.shape
+    num_to_mask = (mask.sum(dim=-1, keepdim=True) * prob).clamp(min=min_mask)
+    logits = torch.rand((batch, seq), device=mask.device).masked_fill(~mask, -1)
+    randperm = logits.argsort(dim=-1).argsort(dim=-1).float()
+    randperm -= (~mask).sum(dim=-1, keepdim=True)
+    subset_mask = randperm < num_to_mask
+    subset_mask.masked_fill_(~mask, False)
+    return subset_mask
+
+
 # ------------------------------------------------------------------------------------------------ parameter containers
 
 class LayerNorm(nn.Module):
@@ -295,14 +307,20 @@ class Transformer(nn.Module):
         if _embed_only:
             embed, _ = self._run(x, ctx, mask, self_cond_embed, want_embed=True, want_logits=False)
             return embed
-        if exists(labels):
-            raise NotImplementedError('training losses (mmp.py:337-348) are the next scope row (SURVEY 8f-1); this build is the '
-                                      'inference hot path')
         embed, logits = self._run(x, ctx, mask, self_cond_embed)
-        logits = logits.reshape(b, n, self.dim_out)
         if return_embed:
-            return logits, embed.float().reshape(b, n, self.dim)
-        return logits
+            return logits.reshape(b, n, self.dim_out), embed.float().reshape(b, n, self.dim)
+        if not exists(labels):
+            return logits.reshape(b, n, self.dim_out)
+        # training-forward losses (mmp.py:340-348), forward only: no autograd graph is built on this path
+        dev = logits.device
+        if self.dim_out == 1:
+            loss = ops.bce_loss(logits.reshape(-1), labels.to(dev))
+        else:
+            loss = ops.ce_loss(logits, labels.to(device=dev, dtype=torch.long).reshape(-1).contiguous(), ignore_index)
+        if not return_logits:
+            return loss
+        return loss, logits.reshape(b, n, self.dim_out)
 
 
 class SelfCritic(nn.Module):
@@ -447,8 +465,49 @@ class MaskGit(nn.Module):
             return ids
         return self.vae.decode_from_ids(ids)                                   # mmp.py:620
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError('MaskGit training loss (mmp.py:623-741) is the next scope row (SURVEY 8f-1)')
+    @torch.no_grad()
+    def forward(self, images_or_ids: torch.Tensor, ignore_index=-1, cond_images: Optional[torch.Tensor] = None,
+                cond_token_ids: Optional[torch.Tensor] = None, texts: Optional[List[str]] = None,
+                text_embeds: Optional[torch.Tensor] = None, cond_drop_prob=None, train_only_generator=False,
+                sample_temperature=None):
+        """Training loss of mmp.py:623-741, FORWARD ONLY (no autograd through the HIP path yet: SURVEY 8f-1).  The random
+        masking uses torch's device generator exactly like the reference does on a GPU."""
+        dev = self.transformer.token_emb.weight.device
+        if images_or_ids.dtype == torch.float:
+            assert exists(self.vae), 'vqgan vae must be passed in if training from raw images'
+            assert all(hw == self.image_size for hw in images_or_ids.shape[-2:]), 'the image you passed in is not of the correct dimensions'
+            _, ids, _ = self.vae.encode(images_or_ids.to(dev))
+        else:
+            assert not self.resize_image_for_cond_image, 'you cannot pass in raw image token ids if you want the framework to autoresize image for conditioning super res transformer'
+            ids = images_or_ids.to(dev)
+        ids = ids.reshape(ids.shape[0], -1)
+        batch, seq_len = ids.shape
+        cond_drop_prob = default(cond_drop_prob, self.cond_drop_prob)
+        assert not (exists(cond_images) and exists(cond_token_ids)), 'if conditioning on low resolution, cannot pass in both images and token ids'
+        if exists(cond_images):
+            assert exists(self.cond_vae), 'cond vqgan vae must be passed in'
+            assert all(hw == self.cond_image_size for hw in cond_images.shape[-2:])
+            _, cond_token_ids, _ = self.cond_vae.encode(cond_images.to(dev))
+        # prepare mask (mmp.py:671-686); `uniform` ignores its bounds in the reference, plain U(0,1)
+        rand_time = torch.zeros((batch,), device=dev).float().uniform_(0, 1)
+        rand_mask_probs = self.noise_schedule(rand_time)
+        num_token_masked = (seq_len * rand_mask_probs).round().clamp(min=1)
+        batch_randperm = torch.rand((batch, seq_len), device=dev).argsort(dim=-1)
+        mask = batch_randperm < num_token_masked[:, None]
+        mask_id = self.transformer.mask_id
+        labels = torch.where(mask, ids, torch.full_like(ids, ignore_index))
+        if self.no_mask_token_prob > 0.:
+            mask &= ~_get_mask_subset_prob(mask, self.no_mask_token_prob)
+        x = torch.where(mask, torch.full_like(ids, mask_id), ids)
+        if exists(texts):
+            text_embeds = self.transformer.encode_text(texts)
+        if self.transformer.self_cond:
+            raise NotImplementedError('self-conditioning is a later scope row (SURVEY 8f-2)')
+        ce_loss = self.transformer(x, text_embeds=text_embeds, conditioning_token_ids=cond_token_ids, labels=labels,
+                                   cond_drop_prob=cond_drop_prob, ignore_index=ignore_index)
+        if not exists(self.token_critic) or train_only_generator:
+            return ce_loss
+        raise NotImplementedError('token-critic loss (mmp.py:726-741) is a later scope row (SURVEY 8f-2)')
 
 
 class Muse(nn.Module):

@@ -173,6 +173,26 @@ def sample_rows(logits, k_keep, temperature, rows=None, noise_kind=L.MM_NOISE_NO
     return pred, sc
 
 
+def ce_loss(logits, labels, ignore_index):
+    """logits fp32 [R, V], labels int64 [R] -> scalar fp32 tensor: F.cross_entropy(..., ignore_index), mean reduction."""
+    _chk_cuda(logits, labels)
+    R, V = logits.shape
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1 and labels.dtype == torch.long and labels.is_contiguous()
+    ws = torch.empty(R, dtype=torch.float32, device=logits.device)
+    out = torch.empty(1, dtype=torch.float32, device=logits.device)
+    L.check(L.lib().mm_ce_loss(L.stream(), L.ptr(logits), logits.stride(0), R, V, L.ptr(labels), int(ignore_index), L.ptr(ws), L.ptr(out)),
+            'mm_ce_loss')
+    return out[0]
+
+
+def bce_loss(x, y):
+    _chk_cuda(x, y)
+    x, y = x.float().contiguous().reshape(-1), y.float().contiguous().reshape(-1)
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    L.check(L.lib().mm_bce_loss(L.stream(), L.ptr(x), L.ptr(y), x.numel(), L.ptr(out)), 'mm_bce_loss')
+    return out[0]
+
+
 def philox_uniform(seed, row_offset, step, rows, V, device):
     L.require_device()
     out = torch.empty(rows, V, dtype=torch.float32, device=device)

@@ -152,6 +152,21 @@ def main():
             cnt.append(max(int((mmp.cosine_schedule(timestep) * nseq).item()), 1))
         sched[(T, nseq)] = cnt
     torch.save(sched, os.path.join(OUT, 'schedule.pt'))
+    # ------------------------------------------------------------------ training-forward losses (mmp.py:337-348, 383-386)
+    gen2 = torch.Generator().manual_seed(99)
+    lids = torch.randint(0, 512, (2, 64), generator=gen2)
+    lmask = torch.rand(2, 64, generator=gen2) < 0.6
+    labels = torch.where(lmask, lids, torch.full_like(lids, -1))
+    lx = torch.where(lmask, torch.full_like(lids, tr.mask_id), lids)
+    with torch.no_grad():
+        loss, llogits = tr(lx, text_embeds=te, labels=labels, ignore_index=-1, return_logits=True)
+        loss_drop = tr(lx, text_embeds=te, labels=labels, ignore_index=-1, cond_drop_prob=1.)
+        critic = pkg.TokenCritic(num_tokens=512, seq_len=64, dim=128, depth=1, dim_head=64, heads=8, t5_name='t5-small')
+        round_module_to_bf16_(critic).eval()
+        y = (torch.rand(2, 64, generator=gen2) < 0.5).float()
+        bce = critic(lx.clamp(max=511), text_embeds=te, labels=y)
+    torch.save(dict(x=lx, labels=labels, loss=loss, logits=llogits, loss_drop=loss_drop, critic_sd=sd_bf16(critic.state_dict()),
+                    critic_labels=y, critic_bce=bce), os.path.join(OUT, 'loss_tiny.pt'))
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -158,6 +158,14 @@ def forward_with_cond_scale(sd, cfg, ids, text_embeds, cond_scale=3., rp=None, r
     return scaled
 
 
+def transformer_loss(sd, cfg, ids, text_embeds, labels, ignore_index=0, cond_drop_prob=0., rp=None, **kw):
+    """muse_maskgit_pytorch.py:337-348: CE over the vocabulary with ignore_index, or BCE-with-logits when dim_out == 1."""
+    logits = transformer_forward(sd, cfg, ids, text_embeds, cond_drop_prob, rp=rp, **kw)
+    if logits.shape[-1] == 1:
+        return F.binary_cross_entropy_with_logits(logits[..., 0], labels)
+    return F.cross_entropy(logits.permute(0, 2, 1), labels, ignore_index=ignore_index)
+
+
 # ----------------------------------------------------------------------------- sampling tail
 
 def cosine_schedule(t):

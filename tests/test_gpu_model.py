@@ -259,3 +259,31 @@ def test_transformer_other_configs_vs_oracle(name, kw, B, n, L, nc):
         mg = mm.MaskGit(image_size=16 * int(n ** 0.5), transformer=t, vae=None)
         out = mg.generate(['x'] * B, timesteps=3, text_embeds=te, seed=2, fmap_size=int(n ** 0.5))
         assert out.shape == (B, int(n ** 0.5), int(n ** 0.5)) and (out < kw['num_tokens']).all() and (out >= 0).all()
+
+
+def test_training_forward_loss_vs_reference(golden):
+    """Transformer.forward(labels=...) / TokenCritic BCE / MaskGit.forward: forward-only losses (mmp.py:337-348, 623-724)."""
+    g, t = _tiny_transformer(golden)
+    l = golden('loss_tiny.pt')
+    te = g['text_embeds'].to(DEV)
+    loss, logits = t(l['x'].to(DEV), text_embeds=te, labels=l['labels'].to(DEV), ignore_index=-1, return_logits=True)
+    # the kernel against torch's own cross_entropy on the SAME (HIP) logits: fp32 summation order only
+    ref_same = torch.nn.functional.cross_entropy(logits.permute(0, 2, 1).cpu(), l['labels'], ignore_index=-1)
+    assert abs(loss.item() - ref_same.item()) < 2e-5 * max(1.0, ref_same.item())
+    print(f'[parity] CE loss HIP {loss.item():.5f} vs reference fp32 {l["loss"].item():.5f}')
+    assert abs(loss.item() - l['loss'].item()) < 0.02 * l['loss'].item()
+    loss_drop = t(l['x'].to(DEV), text_embeds=te, labels=l['labels'].to(DEV), ignore_index=-1, cond_drop_prob=1.)
+    assert abs(loss_drop.item() - l['loss_drop'].item()) < 0.02 * l['loss_drop'].item()
+    all_ignored = t(l['x'].to(DEV), text_embeds=te, labels=torch.full_like(l['labels'], -1).to(DEV), ignore_index=-1)
+    assert torch.isnan(all_ignored)
+    critic = mm.TokenCritic(num_tokens=512, seq_len=64, dim=128, depth=1, dim_head=64, heads=8, t5_name='t5-small')
+    critic.load_state_dict(sd_f32(l['critic_sd']))
+    bce = critic.to(DEV).eval()(l['x'].clamp(max=511).to(DEV), text_embeds=te, labels=l['critic_labels'].to(DEV))
+    print(f'[parity] critic BCE HIP {bce.item():.5f} vs reference {l["critic_bce"].item():.5f}')
+    assert abs(bce.item() - l['critic_bce'].item()) < 5e-3
+    # MaskGit.forward: random masking with the device generator, then the same CE; reproducible under a seed
+    mg = mm.MaskGit(image_size=128, transformer=t, vae=None, cond_drop_prob=0.)
+    ids = torch.randint(0, 512, (2, 8, 8), device=DEV)
+    torch.manual_seed(3); a = mg(ids, text_embeds=te)
+    torch.manual_seed(3); b = mg(ids, text_embeds=te)
+    assert torch.isfinite(a) and a.item() > 0 and torch.equal(a, b)

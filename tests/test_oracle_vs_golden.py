@@ -102,3 +102,13 @@ def test_vae_matches_reference(golden):
     close(fmap, g['enc_fmap'])
     gt = golden('generate_tiny_T4.pt')
     close(O.vae_decode_from_ids(sd, gt['final_ids']), gt['images'])
+
+
+def test_training_forward_losses_match_reference(golden):
+    g, l = golden('transformer_tiny.pt'), golden('loss_tiny.pt')
+    sd = sd_f32(g['sd'])
+    cfg = dict(depth=g['cfg']['depth'], heads=g['cfg']['heads'])
+    assert abs(O.transformer_loss(sd, cfg, l['x'], g['text_embeds'], l['labels'], ignore_index=-1).item() - l['loss'].item()) < 1e-4
+    assert abs(O.transformer_loss(sd, cfg, l['x'], g['text_embeds'], l['labels'], ignore_index=-1, cond_drop_prob=1.).item() - l['loss_drop'].item()) < 1e-4
+    bce = O.transformer_loss(sd_f32(l['critic_sd']), dict(depth=1, heads=8), l['x'].clamp(max=511), g['text_embeds'], l['critic_labels'])
+    assert abs(bce.item() - l['critic_bce'].item()) < 1e-5
