@@ -15,27 +15,30 @@ inline int grid_for(long items, int per_block = 256, int cap = 256 * 16) {
     return (int)(b > cap ? cap : b);
 }
 
-// out[p][c] = bias[c] + sum_j (bit_j(id_p) ? +1 : -1) * w[c][j],  bit_j = (id >> (bits-1-j)) & 1  (MSB = code dim 0)
+// out[p][c] = bias[c] + sum_j (bit_j(id_p) ? +1 : -1) * w[c][j],  bit_j = (id >> (bits-1-j)) & 1  (MSB = code dim 0).
+// One thread produces 8 consecutive channels of one pixel (one 16-byte store).
 __global__ __launch_bounds__(256) void lfq_decode_kernel(const int64_t* __restrict__ ids, long count, int bits, int C,
                                                          const float* __restrict__ w, const float* __restrict__ bias,
                                                          bf16_t* __restrict__ out) {
-    const long total = count * C;
+    const int nch = C >> 3;
+    const long total = count * nch;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long pix = i / C;
-        const int c = (int)(i - pix * C);
+        const long pix = i / nch;
+        const int c0 = (int)(i - pix * nch) * 8;
         const int64_t id = ids[pix];
-        float acc;
-        if (w) {
-            acc = 0.f;
-            for (int j = 0; j < bits; ++j) {
-                const float sgn = ((id >> (bits - 1 - j)) & 1) ? 1.f : -1.f;
-                acc += sgn * w[c * bits + j];
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = c0 + k;
+            if (w) {
+                float a = bias[c];
+                for (int j = 0; j < bits; ++j) a += ((id >> (bits - 1 - j)) & 1) ? w[c * bits + j] : -w[c * bits + j];
+                acc[k] = a;
+            } else {
+                acc[k] = ((id >> (bits - 1 - c)) & 1) ? 1.f : -1.f;
             }
-            acc += bias[c];
-        } else {
-            acc = ((id >> (bits - 1 - c)) & 1) ? 1.f : -1.f;
         }
-        out[i] = f32_to_bf16(acc);
+        *reinterpret_cast<uint4*>(out + pix * C + c0) = pack8(acc);
     }
 }
 
@@ -191,7 +194,8 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_f32_kernel(const bf16_t* __r
 int k_lfq_decode(hipStream_t s, const int64_t* ids, long count, int bits, int C, const float* w, const float* b, bf16_t* out) {
     if (count <= 0) return MM_OK;
     if (!w && C != bits) return mm_set_error(MM_ERR_SHAPE, "lfq_decode: no projection requires C == bits");
-    hipLaunchKernelGGL(lfq_decode_kernel, dim3(grid_for(count * C)), dim3(256), 0, s, ids, count, bits, C, w, b, out);
+    if (C % 8) return mm_set_error(MM_ERR_SHAPE, "lfq_decode: C must be a multiple of 8");
+    hipLaunchKernelGGL(lfq_decode_kernel, dim3(grid_for(count * (C / 8))), dim3(256), 0, s, ids, count, bits, C, w, b, out);
     return mm_check_launch("lfq_decode_kernel");
 }
 

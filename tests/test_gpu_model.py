@@ -254,11 +254,16 @@ def test_transformer_other_configs_vs_oracle(name, kw, B, n, L, nc):
         e = _report(f'{name} drop={drop}', got, ref)
         scale = ref.abs().max().item()
         assert e.max() < 0.03 * scale and e.mean() < 3e-3 * scale
-    # the fused decode loop runs at these shapes too (ids only)
-    if n <= 256:
-        mg = mm.MaskGit(image_size=16 * int(n ** 0.5), transformer=t, vae=None)
-        out = mg.generate(['x'] * B, timesteps=3, text_embeds=te, seed=2, fmap_size=int(n ** 0.5))
-        assert out.shape == (B, int(n ** 0.5), int(n ** 0.5)) and (out < kw['num_tokens']).all() and (out >= 0).all()
+    # the fused decode loop runs at these shapes too (ids only; super-res: with 256 conditioning ids from a real tiny VAE)
+    f = int(n ** 0.5)
+    if nc:
+        vae = mm.VQGanVAE(dim=16, codebook_size=kw['num_tokens'])
+        mg = mm.MaskGit(image_size=16 * f, transformer=t, vae=vae, cond_vae=vae.copy_for_eval(), cond_image_size=256).to(DEV)
+        out = mg.generate(['x'] * B, timesteps=3, text_embeds=te, seed=2, cond_images=torch.randn(B, 3, 256, 256, device=DEV), return_ids=True)
+    else:
+        mg = mm.MaskGit(image_size=16 * f, transformer=t, vae=None)
+        out = mg.generate(['x'] * B, timesteps=3, text_embeds=te, seed=2, fmap_size=f)
+    assert out.shape == (B, f, f) and (out < kw['num_tokens']).all() and (out >= 0).all()
 
 
 def test_training_forward_loss_vs_reference(golden):
@@ -287,3 +292,25 @@ def test_training_forward_loss_vs_reference(golden):
     torch.manual_seed(3); a = mg(ids, text_embeds=te)
     torch.manual_seed(3); b = mg(ids, text_embeds=te)
     assert torch.isfinite(a) and a.item() > 0 and torch.equal(a, b)
+
+
+def test_generate_is_hip_graph_capturable(golden):
+    """mm_generate issues only kernels / async memsets / async copies on the given stream (no allocation, no sync, no host
+    copy), so the whole 18-step decode can be captured into a HIP graph and replayed."""
+    g, t = _tiny_transformer(golden)
+    te = g['text_embeds'].to(DEV)
+    mg = mm.MaskGit(image_size=128, transformer=t, vae=None)
+    eager = mg.generate(['a', 'b'], timesteps=6, text_embeds=te, seed=11, fmap_size=8)      # also warms the workspace / packing
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            captured = mg.generate(['a', 'b'], timesteps=6, text_embeds=te, seed=11, fmap_size=8)
+    captured.fill_(-1)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(captured, eager)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(captured, eager)
