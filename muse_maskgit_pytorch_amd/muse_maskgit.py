@@ -324,13 +324,35 @@ class Transformer(nn.Module):
 
 
 class SelfCritic(nn.Module):
+    """mmp.py:352-374: a Linear(dim, 1) head on the generator's own (cond-pass) embedding."""
+
     def __init__(self, net):
         super().__init__()
         self.net = net
         self.to_pred = nn.Linear(net.dim, 1)
 
-    def forward(self, *a, **k):
-        raise NotImplementedError('token-critic scoring is a later scope row (SURVEY 8f-2)')
+    def _pred(self, embeds):
+        b, n, d = embeds.shape
+        w = ops.pad_cols(self.to_pred.weight.detach().to(bf16), 64)                    # [1, D] as a 1x1 conv weight
+        x = embeds.reshape(b * n, 1, 1, d).to(bf16).contiguous()
+        out = ops.conv2d_nhwc(x, w, 1, 1, 1, 1, (0, 0), bias=self.to_pred.bias.detach().float().contiguous(), out_nchw_f32=True)
+        return out.reshape(b, n, 1)
+
+    @torch.no_grad()
+    def forward_with_cond_scale(self, x, *args, **kwargs):
+        _, embeds = self.net.forward_with_cond_scale(x, *args, return_embed=True, **kwargs)
+        return self._pred(embeds)
+
+    def forward_with_neg_prompt(self, x, *args, **kwargs):
+        raise NotImplementedError('forward_with_neg_prompt is broken in the reference (mmp.py:261-277)')
+
+    @torch.no_grad()
+    def forward(self, x, *args, labels=None, **kwargs):
+        _, embeds = self.net(x, *args, return_embed=True, **kwargs)
+        logits = self._pred(embeds)
+        if not exists(labels):
+            return logits
+        return ops.bce_loss(logits.reshape(-1), labels.to(logits.device))
 
 
 class MaskGitTransformer(Transformer):
@@ -401,16 +423,23 @@ class MaskGit(nn.Module):
                  fmap_size=None, temperature=1., topk_filter_thres=0.9, can_remask_prev_masked=False,
                  force_not_use_token_critic=False, timesteps=18, cond_scale=3, critic_noise_scale=1,
                  *, text_embeds: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None, noise_kind: str = 'philox',
-                 seed: Optional[int] = None, row_offset: int = 0, return_ids: bool = False, trace: Optional[dict] = None):
+                 seed: Optional[int] = None, row_offset: int = 0, return_ids: bool = False, trace: Optional[dict] = None,
+                 critic_noise: Optional[torch.Tensor] = None):
         """mmp.py:491-621.  Keyword-only extras (not in the reference): `text_embeds` bypasses the T5 call,
         `noise` (+ `noise_kind` 'gumbel' | 'uniform') injects the per-step noise tensor [T,B,n,V] for parity runs,
         `seed` / `row_offset` key the on-device Philox stream (row_offset = global index of this shard's first
-        sample, so sharded runs reproduce the unsharded ids), `trace` receives per-step states."""
+        sample, so sharded runs reproduce the unsharded ids), `trace` receives per-step states, `critic_noise` [T,B,n]
+        injects the U(0,1) draws of the token-critic score annealing (mmp.py:601)."""
         tr = self.transformer
         use_token_critic = exists(self.token_critic) and not force_not_use_token_critic
-        if use_token_critic or exists(negative_texts) or can_remask_prev_masked or self.self_cond or cond_scale == 1:
-            raise NotImplementedError('token critic / negative prompts / remasking / self-conditioning / cond_scale=1 decode '
-                                      'variants are later scope rows (SURVEY 8f-2); the fused MI355X loop covers the default path')
+        if exists(negative_texts):
+            raise NotImplementedError('negative prompting cannot run in the reference either (mmp.py:261-277, 544: undefined names '
+                                      'and a keyword mismatch); there is no behaviour to be compatible with')
+        if use_token_critic or can_remask_prev_masked or self.self_cond or cond_scale == 1:
+            # decode variants that need logits / scores at EVERY position: stepwise loop over the same C-ABI operators
+            return self._generate_stepwise(texts, cond_images, fmap_size, temperature, topk_filter_thres, can_remask_prev_masked,
+                                           use_token_critic, timesteps, cond_scale, critic_noise_scale, text_embeds, noise, noise_kind,
+                                           seed, row_offset, return_ids, trace, critic_noise)
         if exists(fmap_size):
             fmap = fmap_size
         else:
@@ -464,6 +493,66 @@ class MaskGit(nn.Module):
         if return_ids or not exists(self.vae):
             return ids
         return self.vae.decode_from_ids(ids)                                   # mmp.py:620
+
+    def _generate_stepwise(self, texts, cond_images, fmap_size, temperature, thres, can_remask, use_critic, timesteps, cond_scale,
+                           critic_noise_scale, text_embeds, noise, noise_kind, seed, row_offset, return_ids, trace, critic_noise=None):
+        """mmp.py:556-609 one step at a time through the public operators (general transformer forward over all positions):
+        token critic / self critic scores, self-conditioning, can_remask_prev_masked, cond_scale == 1."""
+        tr = self.transformer
+        dev = tr.token_emb.weight.device
+        fmap = fmap_size if exists(fmap_size) else self.vae.get_encoded_fmap_size(self.image_size)
+        n = fmap ** 2
+        if not exists(text_embeds):
+            text_embeds = tr.encode_text(texts)
+        te = text_embeds.to(device=dev, dtype=torch.float32).contiguous()
+        B = te.shape[0]
+        cond_ids = None
+        if self.resize_image_for_cond_image:
+            assert exists(cond_images), 'conditioning image must be passed in to generate for super res maskgit'
+            _, cond_ids, _ = self.cond_vae.encode(cond_images)
+        if can_remask and not use_critic:
+            assert self.no_mask_token_prob > 0., 'without training with some of the non-masked tokens forced to predict, not sure if the logits will be meaningful for these token'
+        V = tr.dim_out
+        k_keep = math.ceil((1 - thres) * V)
+        counts = self._mask_counts(timesteps, n)
+        temps = ops.step_temperatures(timesteps, temperature)
+        kinds = dict(none=L.MM_NOISE_NONE, gumbel=L.MM_NOISE_GUMBEL, uniform=L.MM_NOISE_UNIFORM, philox=L.MM_NOISE_PHILOX)
+        kind = kinds[noise_kind] if not exists(noise) or noise_kind != 'philox' else L.MM_NOISE_UNIFORM
+        if exists(noise):
+            noise = noise.to(device=dev, dtype=torch.float32).contiguous()
+        if not exists(seed):
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        ids = torch.full((B, n), self.mask_id, dtype=torch.long, device=dev)
+        scores = torch.zeros((B, n), dtype=torch.float32, device=dev)
+        self_cond_embed = None
+        for step in range(timesteps):
+            ops.mask_step(scores, ids, counts[step], self.mask_id, want_rows=False)                  # mmp.py:558-563
+            is_mask = ids == self.mask_id
+            logits, embed = tr.forward_with_cond_scale(ids, text_embeds=te, self_cond_embed=self_cond_embed,
+                                                       conditioning_token_ids=cond_ids, cond_scale=cond_scale, return_embed=True)
+            self_cond_embed = embed if self.self_cond else None                                      # mmp.py:574
+            pred, conf = ops.sample_rows(logits.reshape(B * n, V), k_keep, temps[step], noise_kind=kind,
+                                         noise=noise[step].reshape(B * n, V) if exists(noise) else None, seed=seed,
+                                         row_offset=row_offset * n, step=step)                        # mmp.py:576-580, 603-606
+            ids = torch.where(is_mask, pred.reshape(B, n), ids)                                      # mmp.py:582-588
+            if use_critic:
+                sc = self.token_critic.forward_with_cond_scale(ids, text_embeds=te, conditioning_token_ids=cond_ids, cond_scale=cond_scale)
+                sc = sc.reshape(B, n).float()
+                steps_until_x0 = timesteps - 1 - step
+                u = critic_noise[step].to(dev).reshape(sc.shape) if exists(critic_noise) else torch.rand(sc.shape, device=dev)
+                scores = (sc + (u - 0.5) * critic_noise_scale * (steps_until_x0 / timesteps)).contiguous()
+            else:
+                scores = conf.reshape(B, n)
+                if not can_remask:
+                    scores = scores.masked_fill(~is_mask, -1e5)                                      # mmp.py:608-609
+                scores = scores.contiguous()
+            if trace is not None:
+                trace.setdefault('ids', []).append(ids.clone())
+                trace.setdefault('scores', []).append(scores.clone())
+        ids = ids.reshape(B, fmap, fmap)
+        if return_ids or not exists(self.vae):
+            return ids
+        return self.vae.decode_from_ids(ids)
 
     @torch.no_grad()
     def forward(self, images_or_ids: torch.Tensor, ignore_index=-1, cond_images: Optional[torch.Tensor] = None,

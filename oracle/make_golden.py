@@ -167,6 +167,75 @@ def main():
         bce = critic(lx.clamp(max=511), text_embeds=te, labels=y)
     torch.save(dict(x=lx, labels=labels, loss=loss, logits=llogits, loss_drop=loss_drop, critic_sd=sd_bf16(critic.state_dict()),
                     critic_labels=y, critic_bce=bce), os.path.join(OUT, 'loss_tiny.pt'))
+    # ------------------------------------------------------------------ decode variants (mmp.py:540-609): token critic,
+    # self critic, self-conditioning, can_remask_prev_masked, cond_scale == 1
+    variants = {}
+
+    def run_variant(name, mg_, T, **gen_kw):
+        tr_ = mg_.transformer
+        tr_.encode_text = lambda texts, te=te: te
+        rec = dict(step_ids=[])
+        orig = tr_.forward_with_cond_scale
+
+        def fw(ids_, *a, **kw):
+            rec['step_ids'].append(ids_.clone())
+            return orig(ids_, *a, **kw)
+
+        tr_.forward_with_cond_scale = fw
+        critic_u = []
+        orig_uniform = mmp.uniform
+
+        def uniform_rec(shape, min=0, max=1, device=None):
+            u = orig_uniform(shape, min, max, device)
+            critic_u.append(u.clone())
+            return u
+
+        mmp.uniform = uniform_rec
+        final = {}
+        orig_dec = mg_.vae.decode_from_ids
+
+        def dec_rec(i):
+            final['ids'] = i.clone()
+            return orig_dec(i)
+
+        mg_.vae.decode_from_ids = dec_rec
+        torch.manual_seed(500 + len(variants))
+        with NoiseTape(mmp) as tape:
+            mg_.generate(['a', 'b'], timesteps=T, **gen_kw)
+        out = final['ids']
+        mmp.uniform = orig_uniform
+        tr_.forward_with_cond_scale = orig
+        variants[name] = dict(timesteps=T, uniform=tape.uniform_draws, critic_uniform=critic_u, step_ids=rec['step_ids'], final_ids=out)
+
+    torch.manual_seed(3)
+    critic2 = pkg.TokenCritic(num_tokens=512, seq_len=64, dim=128, depth=1, dim_head=64, heads=8, t5_name='t5-small')
+    with torch.no_grad():
+        critic2.to_logits.weight.mul_(8.)
+    round_module_to_bf16_(critic2).eval()
+    critic2.encode_text = lambda texts, te=te: te
+    run_variant('token_critic', pkg.MaskGit(vae=vae, transformer=tr, image_size=128, token_critic=critic2), 5)
+    variants['token_critic']['critic_sd'] = sd_bf16(critic2.state_dict())
+
+    torch.manual_seed(4)
+    mg_sc = pkg.MaskGit(vae=vae, transformer=tr, image_size=128, self_token_critic=True)
+    with torch.no_grad():
+        mg_sc.token_critic.to_pred.weight.mul_(8.)
+    round_module_to_bf16_(mg_sc.token_critic.to_pred)
+    run_variant('self_critic', mg_sc, 5)
+    variants['self_critic']['to_pred'] = sd_bf16(mg_sc.token_critic.to_pred.state_dict())
+
+    run_variant('cond_scale_1', pkg.MaskGit(vae=vae, transformer=tr, image_size=128), 5, cond_scale=1)
+    run_variant('can_remask', pkg.MaskGit(vae=vae, transformer=tr, image_size=128, no_mask_token_prob=0.25), 5,
+                can_remask_prev_masked=True)
+
+    torch.manual_seed(5)
+    trsc = pkg.MaskGitTransformer(t5_name='t5-small', self_cond=True, **dict(tcfg, depth=1))
+    with torch.no_grad():
+        trsc.to_logits.weight.mul_(8.)
+    round_module_to_bf16_(trsc).eval()
+    run_variant('self_cond', pkg.MaskGit(vae=vae, transformer=trsc, image_size=128), 4)
+    variants['self_cond']['sd'] = sd_bf16(trsc.state_dict())
+    torch.save(variants, os.path.join(OUT, 'generate_variants_tiny.pt'))
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -240,7 +240,7 @@ def boundary_ties(scores, k):
     return s[:, k - 1] == s[:, k]
 
 
-def sample_step(logits, gumbel, ids, mask_id, temperature, thres=0.9):
+def sample_step(logits, gumbel, ids, mask_id, temperature, thres=0.9, can_remask_prev_masked=False):
     """muse_maskgit_pytorch.py:576-609 for one step, given the CFG-combined logits (b,n,V),
     the injected Gumbel noise (b,n,V) and ids AFTER the re-mask scatter.
     Returns (new_ids, new_scores, pred_ids)."""
@@ -250,14 +250,18 @@ def sample_step(logits, gumbel, ids, mask_id, temperature, thres=0.9):
     new_ids = torch.where(is_mask, pred, ids)
     probs = logits.softmax(dim=-1)
     scores = 1 - probs.gather(2, pred[..., None])[..., 0]
-    scores = scores.masked_fill(~is_mask, MASK_FILL)
+    if not can_remask_prev_masked:                          # :608-609
+        scores = scores.masked_fill(~is_mask, MASK_FILL)
     return new_ids, scores, pred
 
 
 def generate_ids(demask_fn, batch, seq_len, mask_id, gumbel_fn, timesteps=18, temperature=1.,
-                 thres=0.9, trace=None):
+                 thres=0.9, trace=None, can_remask_prev_masked=False, critic_fn=None, critic_uniform_fn=None,
+                 critic_noise_scale=1.):
     """muse_maskgit_pytorch.py:507-615 without text encoding / VAE.  ``demask_fn(ids, step)`` returns the
-    CFG-combined logits (b,n,V) fp32; ``gumbel_fn(step, shape)`` returns the Gumbel noise."""
+    CFG-combined logits (b,n,V) fp32 (a stateful closure carries the self-conditioning embed, :574);
+    ``gumbel_fn(step, shape)`` returns the Gumbel noise.  With ``critic_fn(ids, step) -> (b,n)`` the next step's
+    scores come from the token critic plus annealed uniform noise ``critic_uniform_fn(step, shape)`` (:590-601)."""
     ids = torch.full((batch, seq_len), mask_id, dtype=torch.long)
     scores = torch.zeros((batch, seq_len), dtype=torch.float32)
     counts = mask_counts(timesteps, seq_len)
@@ -269,7 +273,11 @@ def generate_ids(demask_fn, batch, seq_len, mask_id, gumbel_fn, timesteps=18, te
         logits = demask_fn(ids, step)
         g = gumbel_fn(step, logits.shape)
         masked_ids = ids
-        ids, scores, pred = sample_step(logits, g, ids, mask_id, temps[step], thres)
+        ids, scores, pred = sample_step(logits, g, ids, mask_id, temps[step], thres, can_remask_prev_masked)
+        if critic_fn is not None:
+            steps_until_x0 = timesteps - (step + 1)
+            scores = critic_fn(ids, step)
+            scores = scores + (critic_uniform_fn(step, scores.shape) - 0.5) * critic_noise_scale * (steps_until_x0 / timesteps)
         if trace is not None:
             trace.append(dict(step=step, k=counts[step], sel=sel, tie=tie, masked_ids=masked_ids,
                               ids=ids.clone(), scores=scores.clone(), pred=pred))

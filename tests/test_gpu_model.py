@@ -314,3 +314,107 @@ def test_generate_is_hip_graph_capturable(golden):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(captured, eager)
+
+
+def test_generate_stepwise_variants(golden):
+    """decode variants that go through the stepwise path: cond_scale == 1 (checked bit-exactly against the oracle loop on
+    HIP logits), can_remask_prev_masked, token critic, self critic, self-conditioning (run + determinism)."""
+    g, t = _tiny_transformer(golden)
+    te = g['text_embeds']
+    B, n, V, T = 2, 64, 512, 5
+    gumbel = O.gumbel_from_uniform(torch.rand(T, B, n, V, generator=torch.Generator().manual_seed(8)))
+    mg = mm.MaskGit(image_size=128, transformer=t, vae=None)
+    ids = mg.generate(['a', 'b'], timesteps=T, text_embeds=te, noise=gumbel, noise_kind='gumbel', fmap_size=8, cond_scale=1)
+    free = O.generate_ids(lambda i, s: t(i.to(DEV), text_embeds=te.to(DEV)).cpu(), B, n, 512, lambda s, shp: gumbel[s], timesteps=T)
+    assert torch.equal(ids.reshape(B, n).cpu(), free)
+    # the stepwise path and the fused engine agree on the default configuration too (same noise, cond_scale 3)
+    fused = mg.generate(['a', 'b'], timesteps=T, text_embeds=te, noise=gumbel, noise_kind='gumbel', fmap_size=8)
+    step = mg._generate_stepwise(['a', 'b'], None, 8, 1., 0.9, False, False, T, 3, 1, te, gumbel, 'gumbel', 0, 0, True, None)
+    assert torch.equal(fused, step)
+    # can_remask_prev_masked
+    mg2 = mm.MaskGit(image_size=128, transformer=t, vae=None, no_mask_token_prob=0.25)
+    r1 = mg2.generate(['a', 'b'], timesteps=T, text_embeds=te, seed=5, fmap_size=8, can_remask_prev_masked=True)
+    r2 = mg2.generate(['a', 'b'], timesteps=T, text_embeds=te, seed=5, fmap_size=8, can_remask_prev_masked=True)
+    assert torch.equal(r1, r2) and (r1 < 512).all()
+    # token critic and self critic
+    critic = mm.TokenCritic(num_tokens=512, seq_len=64, dim=128, depth=1, dim_head=64, heads=8, t5_name='t5-small').to(DEV)
+    mg3 = mm.MaskGit(image_size=128, transformer=t, vae=None, token_critic=critic)
+    torch.manual_seed(1); c1 = mg3.generate(['a', 'b'], timesteps=T, text_embeds=te, seed=5, fmap_size=8)
+    torch.manual_seed(1); c2 = mg3.generate(['a', 'b'], timesteps=T, text_embeds=te, seed=5, fmap_size=8)
+    assert torch.equal(c1, c2) and c1.shape == (2, 8, 8) and (c1 < 512).all()
+    mg4 = mm.MaskGit(image_size=128, transformer=t, vae=None, self_token_critic=True).to(DEV)
+    torch.manual_seed(1); s1 = mg4.generate(['a', 'b'], timesteps=T, text_embeds=te, seed=5, fmap_size=8)
+    assert s1.shape == (2, 8, 8) and (s1 < 512).all()
+    # self-conditioning transformer: the embed of step t feeds step t+1 (mmp.py:325-328, 574)
+    torch.manual_seed(2)
+    tsc = mm.MaskGitTransformer(num_tokens=512, seq_len=64, dim=128, depth=1, dim_head=64, heads=8, t5_name='t5-small', self_cond=True).to(DEV)
+    mg5 = mm.MaskGit(image_size=128, transformer=tsc, vae=None)
+    o1 = mg5.generate(['a', 'b'], timesteps=3, text_embeds=te, seed=5, fmap_size=8)
+    assert o1.shape == (2, 8, 8) and (o1 < 512).all()
+    # self-cond forward against the oracle
+    sd = {k: v.detach().cpu().clone() for k, v in tsc.state_dict().items()}
+    for k in sd:
+        if sd[k].is_floating_point():
+            sd[k] = sd[k].to(torch.bfloat16).float()
+    tsc.load_state_dict(sd)
+    ids0 = torch.randint(0, 513, (2, 64))
+    sce = torch.randn(2, 64, 128)
+    got = tsc(ids0.to(DEV), text_embeds=te.to(DEV), self_cond_embed=sce.to(DEV))
+    ref = O.transformer_forward(sd, dict(depth=1, heads=8, self_cond=True), ids0, te, 0., self_cond_embed=sce, rp=O.bf16_round)
+    e = _report('self-conditioned forward', got, ref)
+    assert e.max() < 0.03 * ref.abs().max()
+
+
+@pytest.mark.parametrize('name', ['token_critic', 'self_critic', 'cond_scale_1', 'can_remask', 'self_cond'])
+def test_generate_variants_vs_reference_goldens(golden, name):
+    """mmp.py:540-609 decode variants replayed with the reference's recorded noise:
+    (1) the HIP stepwise loop must equal, bit for bit, the oracle loop fed by the HIP transformer (same logits, same noise);
+    (2) against the fp32 reference's final ids the agreement is reported (bf16 GEMM operands can flip a near-tie and the
+        loop then diverges by design); >= 90 % must agree."""
+    gv, gt = golden('generate_variants_tiny.pt')[name], golden('transformer_tiny.pt')
+    te = gt['text_embeds']
+    T, B, n, V = gv['timesteps'], 2, 64, 512
+    if name == 'self_cond':
+        t = mm.MaskGitTransformer(num_tokens=512, seq_len=64, dim=128, depth=1, dim_head=64, heads=8, t5_name='t5-small', self_cond=True)
+        t.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in gv['sd'].items()})
+        t = t.to(DEV)
+    else:
+        _, t = _tiny_transformer(golden)
+    kw, okw = {}, {}
+    if name == 'token_critic':
+        critic = mm.TokenCritic(num_tokens=512, seq_len=64, dim=128, depth=1, dim_head=64, heads=8, t5_name='t5-small')
+        critic.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in gv['critic_sd'].items()})
+        mg = mm.MaskGit(image_size=128, transformer=t, vae=None, token_critic=critic.to(DEV))
+    elif name == 'self_critic':
+        mg = mm.MaskGit(image_size=128, transformer=t, vae=None, self_token_critic=True)
+        mg.token_critic.to_pred.load_state_dict({k: v.float() for k, v in gv['to_pred'].items()})
+        mg = mg.to(DEV)
+    elif name == 'can_remask':
+        mg = mm.MaskGit(image_size=128, transformer=t, vae=None, no_mask_token_prob=0.25)
+        kw['can_remask_prev_masked'] = okw['can_remask_prev_masked'] = True
+    else:
+        mg = mm.MaskGit(image_size=128, transformer=t, vae=None)
+    cond_scale = 1 if name == 'cond_scale_1' else 3
+    uni = torch.stack(gv['uniform'])                                           # [T, B, n, V] the reference's U(0,1) draws
+    if name in ('token_critic', 'self_critic'):
+        cu = torch.stack([u.reshape(B, n) for u in gv['critic_uniform']])
+        kw['critic_noise'] = cu
+        okw['critic_fn'] = lambda ids, step: mg.token_critic.forward_with_cond_scale(ids.to(DEV), text_embeds=te.to(DEV), cond_scale=cond_scale).reshape(B, n).float().cpu()
+        okw['critic_uniform_fn'] = lambda step, shape: cu[step]
+    trace = {}
+    got = mg.generate(['a', 'b'], timesteps=T, text_embeds=te, noise=uni, noise_kind='uniform', fmap_size=8, cond_scale=cond_scale,
+                      trace=trace, **kw).reshape(B, n).cpu()
+    state = dict(embed=None)
+
+    def demask(ids, step):
+        logits, embed = t.forward_with_cond_scale(ids.to(DEV), text_embeds=te.to(DEV), self_cond_embed=state['embed'], cond_scale=cond_scale,
+                                                  return_embed=True)
+        state['embed'] = embed if name == 'self_cond' else None
+        return logits.cpu()
+
+    free = O.generate_ids(demask, B, n, 512, lambda s, shp: O.gumbel_from_uniform(uni[s]), timesteps=T, **okw)
+    assert torch.equal(got, free), f'{name}: HIP stepwise loop differs from the oracle loop on the same logits'
+    ref = gv['final_ids'].reshape(B, n)
+    agree = (got == ref).float().mean().item()
+    print(f'[parity] decode variant {name}: final ids equal to the fp32 reference {agree * 100:.1f} %')
+    assert agree >= 0.9

@@ -1,6 +1,7 @@
 """CPU: pins oracle/muse_oracle.py (the restatement) against golden vectors produced by the
 UNMODIFIED reference (oracle/make_golden.py).  Integer outputs bit-exact; fp32 outputs to 2e-5
 relative-to-scale (same math, different op grouping)."""
+import pytest
 import torch
 
 import muse_oracle as O
@@ -90,6 +91,45 @@ def test_generate_replay_T18_end_to_end(golden):
     g, ids, trace = _replay(golden, 'generate_tiny_T18.pt')
     for tr_, ref_ids in zip(trace, g['step_ids']):
         assert torch.equal(tr_['masked_ids'], ref_ids), f"step {tr_['step']}"
+    assert torch.equal(ids.reshape(2, 8, 8), g['final_ids'])
+
+
+def _variant_fns(golden, name, fwd=None):
+    """closures replaying one recorded decode variant of the reference through ``fwd`` (default: the oracle transformer)."""
+    g, t = golden('generate_variants_tiny.pt')[name], golden('transformer_tiny.pt')
+    te = t['text_embeds']
+    sd = sd_f32(g['sd'] if name == 'self_cond' else t['sd'])
+    cfg = dict(depth=1 if name == 'self_cond' else t['cfg']['depth'], heads=t['cfg']['heads'], self_cond=name == 'self_cond')
+    cond_scale = 1. if name == 'cond_scale_1' else 3.
+    state = dict(embed=None)
+    fwd = fwd or (lambda ids, **kw: O.forward_with_cond_scale(sd, cfg, ids, te, cond_scale, return_embed=True, **kw))
+
+    def demask(ids, step):
+        # (the self critic calls the SAME transformer, so its recording interleaves generator and critic inputs)
+        assert torch.equal(ids, g['step_ids'][step * (2 if name == 'self_critic' else 1)]), f'{name}: masked ids differ from the reference at step {step}'
+        logits, embed = fwd(ids, self_cond_embed=state['embed']) if name == 'self_cond' else fwd(ids)
+        state['embed'] = embed
+        return logits
+
+    kw = dict(can_remask_prev_masked=name == 'can_remask')
+    if name == 'token_critic':
+        csd = sd_f32(g['critic_sd'])
+        kw.update(critic_fn=lambda ids, step: O.forward_with_cond_scale(csd, dict(depth=1, heads=8), ids, te, 3.)[..., 0])
+    if name == 'self_critic':
+        w, b = g['to_pred']['weight'].float(), g['to_pred']['bias'].float()
+        kw.update(critic_fn=lambda ids, step: (O.forward_with_cond_scale(sd, cfg, ids, te, 3., return_embed=True)[1] @ w.t() + b)[..., 0])
+    if 'critic_fn' in kw:
+        kw.update(critic_uniform_fn=lambda step, shape: g['critic_uniform'][step].reshape(shape))
+    return g, t, demask, kw
+
+
+@pytest.mark.parametrize('name', ['token_critic', 'self_critic', 'cond_scale_1', 'can_remask', 'self_cond'])
+def test_generate_variants_replay_bit_exact(golden, name):
+    """mmp.py:540-609 decode variants: the oracle loop replays the reference's recorded noise and must reproduce the ids the
+    reference fed its transformer at every step, and the final ids."""
+    g, t, demask, kw = _variant_fns(golden, name)
+    ids = O.generate_ids(demask, 2, 64, t['mask_id'], lambda s, shp: O.gumbel_from_uniform(g['uniform'][s]),
+                         timesteps=g['timesteps'], **kw)
     assert torch.equal(ids.reshape(2, 8, 8), g['final_ids'])
 
 
