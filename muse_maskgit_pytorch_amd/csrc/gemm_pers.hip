@@ -177,7 +177,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(const GemmArgs p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                   \
         __builtin_amdgcn_s_barrier();                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                                   \
-        DMA_STMT;                                                                                                            \
+        if (!(p.debug & 2)) { DMA_STMT; }                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                                   \
         const unsigned char* ws = smem + (g & 1) * STAGE_B;                                                                  \
         const unsigned char* xs = ws + W_BYTES;                                                                              \
@@ -187,11 +187,13 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(const GemmArgs p) {
                 af[i] = *reinterpret_cast<const u32x4_t*>(ws + lds_off(wave_n * 64 + i * 16 + fr, ks * 4 + fg));             \
                 bfm[i] = *reinterpret_cast<const u32x4_t*>(xs + lds_off(wave_m * 64 + i * 16 + fr, ks * 4 + fg));            \
             }                                                                                                                \
+            if (!(p.debug & 4)) {                                                                                            \
             _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                                    \
                 _Pragma("unroll") for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(af[a], bfm[b], acc[a][b]);                  \
+            } else { _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(af[i]), "v"(bfm[i])); }           \
         }                                                                                                                    \
         st_prev = 0;                                                                                                         \
-        if ((PIECE) >= 0 && (PIECE) < npieces && have_prev) {                                                                \
+        if ((PIECE) >= 0 && (PIECE) < npieces && have_prev && !(p.debug & 1)) {                                              \
             store_piece<MODE>(p, ct, (PIECE) < 0 ? 0 : (PIECE), t, prv_m0, prv_n0, prv_tile_n);                              \
             st_prev = (prv_m0 + tile_rows <= p.M) ? 1 : 0;                                                                   \
         }                                                                                                                    \
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(const GemmArgs p) {
         // tile boundary: everyone is done with the stages' last reads and with reading the previous ct -> overwrite ct
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        acc_to_ct<MODE>(p, acc, ct, wave_m, wave_n, fr, fg);
+        if (!(p.debug & 16)) acc_to_ct<MODE>(p, acc, ct, wave_m, wave_n, fr, fg);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         prv_m0 = cur_m0; prv_n0 = cur_n0; prv_tile_n = cur_tile_n; have_prev = true;
@@ -223,7 +225,8 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(const GemmArgs p) {
         has_next = vb + G < total;
     }
     // drain the last tile
-    for (int q = 0; q < npieces; ++q) store_piece<MODE>(p, ct, q, t, prv_m0, prv_n0, prv_tile_n);
+    if (!(p.debug & 1))
+        for (int q = 0; q < npieces; ++q) store_piece<MODE>(p, ct, q, t, prv_m0, prv_n0, prv_tile_n);
 }
 
 template <int MODE>

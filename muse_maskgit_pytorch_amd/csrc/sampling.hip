@@ -129,24 +129,34 @@ __device__ __forceinline__ float opaque(float x) {
     return x;
 }
 
+static_assert(NB == 64 * 32, "the histogram scan assumes 32 bins per lane");
+
 struct SampleShared {
     float redf[NW];
     float redf2[NW];
-    int redi[NW];
     float bval[NW];
     float bx[NW];
-    int wcount[NW];
-    uint32_t hist[NB];
-    uint32_t lane_sums[64];
+    float redse[NW];
+    int redi[NW];
+    uint32_t hist[NB];            // TRANSPOSED: bin b lives at hslot(b), so lane l's 32 consecutive bins form a conflict-free column
     uint32_t cand[CAND_CAP];
-    float kx[NW * WSLICE];
-    int ki[NW * WSLICE];
+    uint2 kv[NW * WSLICE];        // (value bits, vocabulary index), one slice per wave
     int ncand;
-    int tbin, above, cnt;
     int slow;
     uint32_t thr;
-    int scount;
 };
+
+__device__ __forceinline__ int hslot(int b) { return ((b & 31) << 6) | (b >> 5); }
+
+// inclusive suffix sum over the wave: result[l] = sum of x over lanes >= l
+__device__ __forceinline__ uint32_t wave_suffix_sum(uint32_t x, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_down((int)x, o, 64);
+        if (lane + o < 64) x += t;
+    }
+    return x;
+}
 
 // exact k-th largest key of the row by bisection over the 32 key bits, reading the row from memory each round
 __device__ uint32_t slow_threshold(const float* lr, int V, int k, SampleShared& S) {
@@ -198,8 +208,16 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
         v[it * 4 + 0] = x.x; v[it * 4 + 1] = x.y; v[it * 4 + 2] = x.z; v[it * 4 + 3] = x.w;
     }
     // padding (e >= V) is -inf: neutral for the max and for exp(); min / histogram / list passes skip it by index
+    const int stop = (p.debug >> 8) & 7;      // ablation only: leave after phase `stop` (tools/sample_bench.py)
+    if (stop == 1) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VEC_IT * 4; ++i) s += v[i];
+        if (s == 12345.678f) p.score_out[row] = s;
+        return;
+    }
 
-    // ---- A: row max / min
+    // ---- A: row max / min / mean / variance
     float vmax = -INFINITY, vmin = INFINITY, s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int it = 0; it < VEC_IT; ++it) {
@@ -218,12 +236,13 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
     if (lane == 0) { S.redf[wid] = vmax; S.redf2[wid] = vmin; S.bval[wid] = s1; S.bx[wid] = s2; }
-    if (tid == 0) { S.ncand = 0; S.slow = 0; S.scount = 0; }
+    if (tid == 0) { S.ncand = 0; S.slow = 0; }
     for (int i = tid; i < NB; i += ST) S.hist[i] = 0;
     __syncthreads();
     vmax = S.redf[0]; vmin = S.redf2[0]; s1 = S.bval[0]; s2 = S.bx[0];
 #pragma unroll
     for (int i = 1; i < NW; ++i) { vmax = fmaxf(vmax, S.redf[i]); vmin = fminf(vmin, S.redf2[i]); s1 += S.bval[i]; s2 += S.bx[i]; }
+    if (stop == 2) { if (vmax + s1 == 12345.678f) p.score_out[row] = s2; return; }
 
     // ---- B: softmax denominator on the unfiltered logits (fast exp: v_exp_f32, ~1e-6 relative per term)
     float se = 0.f;
@@ -231,63 +250,80 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
 #pragma unroll
         for (int i = 0; i < VEC_IT * 4; ++i) se += __expf(opaque(v[i]) - vmax);
     }
+    se = wave_sum(se);
+    if (lane == 0) S.redse[wid] = se;        // published by the barrier that closes the histogram pass
 
-    // ---- C: value-linear histogram (bin 0 = smallest).  Not usable when the span is 0 / inf / NaN -> slow path
-    //      Only the upper tail is binned: values below lo = mean + z_lo * std cannot hold the k-th largest of a bell-shaped
-    //      row (z_lo = normal quantile of 1 - k/V minus a 0.8 sigma margin, from the host); if fewer than k values turn out to
-    //      be >= lo the row takes the slow path.  This cuts the LDS atomics ~3x and makes the bins 3x finer.
+    // ---- C: value-linear histogram of the row's UPPER TAIL (bin 0 = smallest), then every wave scans it (redundantly: no
+    //      broadcast, no extra barrier) for the bin t holding the k-th largest value.
+    //      Attempt 0 bins only values >= lo = mean + z_lo * std (z_lo = normal quantile of 1 - k/V minus a margin, from the
+    //      host): a bell-shaped row has its k-th largest well above lo, and this cuts the LDS atomics ~5x and makes the bins
+    //      finer.  If fewer than k values turn out to be >= lo (heavy-tailed row) attempt 1 repeats the pass over the full
+    //      range [min, max] -- the row is still in registers, so a miss costs one more register pass, not a re-read.
+    //      Span 0 / inf / NaN or > CAND_CAP values inside bin t (massive ties) -> slow path.
     const float mean = s1 / (float)V;
     const float var = fmaxf(s2 / (float)V - mean * mean, 0.f);
-    const float lo = fmaxf(vmin, mean + p.z_lo * sqrtf(var));
-    const float span = vmax - lo;
-    const bool fast = (span >= 1e-30f) && (span < 3.0e38f);
-    const float inv_w = fast ? (float)NB / span : 0.f;
-    if (fast && !(p.debug & 16)) {
+    const int need = p.k_keep;
+    float lo = fmaxf(vmin, mean + p.z_lo * sqrtf(var));
+    float span, inv_w;
+    bool fast, found = false;
+    int tbin = 0, above = 0, cnt = 0;
+#pragma unroll 1
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        span = vmax - lo;
+        fast = (span >= 1e-30f) && (span < 3.0e38f);
+        inv_w = fast ? (float)NB / span : 0.f;
+        if (fast && !(p.debug & 16)) {
 #pragma unroll
-        for (int it = 0; it < VEC_IT; ++it) {
-            if (FULL || (it * ST + tid) * 4 < V) {
+            for (int it = 0; it < VEC_IT; ++it) {
+                if (FULL || (it * ST + tid) * 4 < V) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float x = opaque(v[it * 4 + c]);
-                    if (x >= lo) atomicAdd(&S.hist[min(NB - 1, (int)((x - lo) * inv_w))], 1u);
+                    for (int c = 0; c < 4; ++c) {
+                        const float x = opaque(v[it * 4 + c]);
+                        if (x >= lo) atomicAdd(&S.hist[hslot(min(NB - 1, (int)((x - lo) * inv_w)))], 1u);
+                    }
                 }
             }
         }
-    }
-    se = wave_sum(se);
-    __syncthreads();                      // histogram complete; redf reads above are done
-    if (lane == 0) S.redf[wid] = se;
-    // one wave finds the bin holding the k-th largest: each lane owns 32 consecutive bins
-    const int need = p.k_keep;
-    if (wid == 0 && fast) {
-        uint32_t mine = 0;
-        for (int j = 0; j < NB / 64; ++j) mine += S.hist[lane * (NB / 64) + j];
-        S.lane_sums[lane] = mine;
-        __builtin_amdgcn_wave_barrier();
-        uint32_t above = 0;
-        for (int l2 = lane + 1; l2 < 64; ++l2) above += S.lane_sums[l2];
-        if (lane == 0 && above + mine < (uint32_t)need) S.slow = 1;      // the tail estimate missed: fewer than k values >= lo
-        if (above < (uint32_t)need && (uint32_t)need <= above + mine) {
-            uint32_t acc = above;
-            for (int j = NB / 64 - 1; j >= 0; --j) {
-                const uint32_t hc = S.hist[lane * (NB / 64) + j];
-                if ((uint32_t)need <= acc + hc) { S.tbin = lane * (NB / 64) + j; S.above = (int)acc; S.cnt = (int)hc; break; }
-                acc += hc;
+        __syncthreads();                      // histogram complete
+        if (fast) {
+            uint32_t mine = 0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) mine += S.hist[j * 64 + lane];      // bins 32*lane .. 32*lane+31
+            const uint32_t suf = wave_suffix_sum(mine, lane);
+            const uint32_t ab = suf - mine;                                  // values in bins above this lane's range
+            if ((uint32_t)__shfl((int)suf, 0, 64) >= (uint32_t)need) {       // else: the tail estimate missed
+                const unsigned long long own = __ballot(ab < (uint32_t)need && (uint32_t)need <= suf);
+                const int L = __ffsll((long long)own) - 1;
+                const uint32_t abL = (uint32_t)__shfl((int)ab, L, 64);
+                const uint32_t h = lane < 32 ? S.hist[lane * 64 + L] : 0u;   // bin 32*L + lane
+                const uint32_t suf2 = wave_suffix_sum(h, lane);
+                const uint32_t ab2 = abL + suf2 - h;
+                const unsigned long long own2 = __ballot(lane < 32 && ab2 < (uint32_t)need && (uint32_t)need <= ab2 + h);
+                const int J = __ffsll((long long)own2) - 1;
+                tbin = L * 32 + J;
+                above = __shfl((int)ab2, J, 64);
+                cnt = __shfl((int)h, J, 64);
+                found = true;
             }
         }
+        if (!fast || found || attempt == 1 || !(lo > vmin)) break;
+        lo = vmin;                            // retry over the full range
+        __syncthreads();                      // every wave is done reading the histogram
+        for (int i = tid; i < NB; i += ST) S.hist[i] = 0;
+        __syncthreads();
     }
-    __syncthreads();
+    if (stop == 3) { if (se == 12345.678f) p.score_out[row] = (float)tbin; return; }
     float sumexp = 0.f;
 #pragma unroll
-    for (int i = 0; i < NW; ++i) sumexp += S.redf[i];
-    const int tbin = S.tbin;
-    bool slow = !fast || S.slow != 0 || S.cnt > CAND_CAP;
+    for (int i = 0; i < NW; ++i) sumexp += S.redse[i];
+    bool slow = !fast || !found || cnt > CAND_CAP;
+    if (stop == 4) { if (sumexp == 12345.678f) p.score_out[row] = (float)tbin; return; }
 
-    // ---- D: append every value with bin >= tbin to this wave's slice (no atomics: ballot prefix + running count)
+    // ---- D: append every value with bin >= tbin to this wave's slice (no atomics: ballot prefix + running count).
+    //      Straight-line: with ~10 % kept a ballot is practically never empty, so no branch around the bookkeeping.
     int wcount = 0;                       // wave-uniform
+    uint2* mykv = S.kv + wid * WSLICE;
     if (!slow && !(p.debug & 32)) {
-        float* mykx = S.kx + wid * WSLICE;
-        int* myki = S.ki + wid * WSLICE;
         // lower edge of bin tbin, lowered by a relative 1e-6 so that rounding can only ADD a few values of bin tbin-1
         // (harmless: they are neither candidates nor >= the final threshold)
         const float edge = lo + (float)tbin / inv_w - (fabsf(lo) + span) * 1e-6f;
@@ -300,15 +336,22 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
                 const float x = opaque(v[it * 4 + c]);
                 const bool kp = ok && x >= edge;
                 const unsigned long long bal = __ballot(kp);
-                if (bal != 0ull) {
-                    const int slot = wcount + __popcll(bal & ((1ull << lane) - 1ull));
-                    if (kp && slot < WSLICE) { mykx[slot] = x; myki[slot] = e + c; }
-                    wcount += __popcll(bal);
-                }
+                const int slot = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, (uint32_t)wcount));
+                if (kp) mykv[min(slot, WSLICE - 1)] = make_uint2(__float_as_uint(x), (uint32_t)(e + c));
+                wcount += __popcll(bal);
             }
         }
         if (wcount > WSLICE && lane == 0) S.slow = 1;
-        if (lane == 0) S.wcount[wid] = wcount;
+    }
+    if (stop == 5) { if (sumexp == 12345.678f) p.score_out[row] = (float)wcount; return; }
+    const int cw = min(wcount, WSLICE);
+    if (!slow) {
+        // members of bin tbin in this wave's own slice (a few per wave) -> the shared candidate list
+#pragma unroll 2
+        for (int i = lane; i < cw; i += 64) {
+            const float x = __uint_as_float(mykv[i].x);
+            if (x >= lo && min(NB - 1, (int)((x - lo) * inv_w)) == tbin) { const int sl = atomicAdd(&S.ncand, 1); if (sl < CAND_CAP) S.cand[sl] = fkey(x); }
+        }
     }
     __syncthreads();
     slow = slow || S.slow != 0;
@@ -316,22 +359,14 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
     uint32_t thr;
     if (p.debug & 64) { thr = 0xFFFFFFFFu; } else
     if (!slow) {
-        // ---- exact threshold: the (need - above)-th largest among the members of bin tbin
-        const int need_in = need - S.above;
-        {   // each wave scans its own slice for the members of bin tbin (a few dozen per row)
-            const float* mykx = S.kx + wid * WSLICE;
-            const int cw = min(wcount, WSLICE);
-            for (int i = lane; i < cw; i += 64) {
-                const float x = mykx[i];
-                if (x >= lo && min(NB - 1, (int)((x - lo) * inv_w)) == tbin) { const int sl = atomicAdd(&S.ncand, 1); if (sl < CAND_CAP) S.cand[sl] = fkey(x); }
-            }
-        }
-        __syncthreads();
-        const int cnt = min(S.ncand, CAND_CAP);
-        for (int i = tid; i < cnt; i += ST) {
+        // ---- exact threshold: the (need - above)-th largest among the members of bin tbin (rank counting)
+        const int need_in = need - above;
+        const int n_c = min(S.ncand, CAND_CAP);
+        for (int i = tid; i < n_c; i += ST) {
             const uint32_t ki = S.cand[i];
             int gt = 0, ge = 0;
-            for (int j = 0; j < cnt; ++j) { const uint32_t kj = S.cand[j]; gt += kj > ki; ge += kj >= ki; }
+#pragma unroll 4
+            for (int j = 0; j < n_c; ++j) { const uint32_t kj = S.cand[j]; gt += kj > ki; ge += kj >= ki; }
             if (gt < need_in && need_in <= ge) S.thr = ki;      // every thread that satisfies this holds the same key
         }
         __syncthreads();
@@ -339,6 +374,7 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
     } else {
         thr = slow_threshold(lr, V, need, S);
     }
+    if (stop == 6) { if (sumexp == 12345.678f) p.score_out[row] = (float)thr; return; }
 
     // ---- Gumbel argmax over the kept entries (mmp.py:410-411); ties -> lower index like torch.argmax
     const float T = p.temperature;
@@ -346,17 +382,15 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
     int best_i = 0x7FFFFFFF;
     if (!slow) {
         // each wave walks its own slice, 4 independent entries per lane per trip so the RNG's multiply chains overlap
-        const float* mykx = S.kx + wid * WSLICE;
-        const int* myki = S.ki + wid * WSLICE;
-        const int cw = min(wcount, WSLICE);
         for (int base = 0; base < cw; base += 256) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i = base + u * 64 + lane;
                 if (i < cw) {
-                    const float x = mykx[i];
+                    const uint2 ent = mykv[i];
+                    const float x = __uint_as_float(ent.x);
                     if (fkey(x) >= thr) {
-                        const int idx = myki[i];
+                        const int idx = (int)ent.y;
                         const float y = x / T + noise_gumbel(p, pos_flat, idx);      // IEEE division: same bits as torch's CPU kernel
                         if (y > best || (y == best && idx < best_i)) { best = y; best_i = idx; best_x = x; }
                     }
@@ -420,7 +454,7 @@ static double norm_quantile(double p) {
 int k_sample_rows(hipStream_t s, const SampleArgs& a_in) {
     SampleArgs a = a_in;
     a.debug = g_mm_debug;
-    a.z_lo = (float)(norm_quantile(1.0 - (double)a.k_keep / (double)a.V) - 0.8);
+    a.z_lo = (float)(norm_quantile(1.0 - (double)a.k_keep / (double)a.V) - 0.35);
     if (a.R <= 0) return MM_OK;
     if (a.V <= 0 || (a.V % 4) || a.V > 65536) return mm_set_error(MM_ERR_SHAPE, "sample_rows: V must be a multiple of 4 and <= 65536");
     if (a.k_keep < 1 || a.k_keep > a.V) return mm_set_error(MM_ERR_SHAPE, "sample_rows: k_keep out of range");

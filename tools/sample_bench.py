@@ -13,9 +13,23 @@ def timeit(fn, iters=10):
     return (time.perf_counter() - t0) / iters
 
 R, V = 8192, 65536
-logits = torch.randn(R, V, device='cuda') * 0.6
+args = sys.argv[1:]
+if args and args[0] == 'insitu':
+    # the logits the C2 bench model actually produces at step 0 (all positions masked), not a synthetic Gaussian
+    args = args[1:]
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    mg, _ = bench.build_models('cuda')
+    te = bench.synth_text(32, 16, 512).cuda()
+    ids = torch.full((32, 256), mg.transformer.mask_id, device='cuda', dtype=torch.long)
+    logits = mg.transformer.forward_with_cond_scale(ids, text_embeds=te, cond_scale=3.).reshape(R, V).contiguous()
+    print('in-situ logits: mean %.3f std %.3f min %.3f max %.3f' % (logits.mean().item(), logits.std().item(), logits.min().item(), logits.max().item()))
+    r0 = logits[0]
+    print('row0 std %.3f skew %.3f kurt %.3f' % (r0.std().item(), (((r0 - r0.mean()) / r0.std()) ** 3).mean().item(), (((r0 - r0.mean()) / r0.std()) ** 4).mean().item()))
+else:
+    logits = torch.randn(R, V, device='cuda') * 0.6
 k = math.ceil(0.1 * V)
-for fl in [int(a) for a in (sys.argv[1:] or ['0'])]:
+for fl in [int(a) for a in (args or ['0'])]:
     _lib.lib().mm_debug_set(fl)
     t = timeit(lambda: ops.sample_rows(logits, k, 0.7, noise_kind=_lib.MM_NOISE_PHILOX, seed=1))
     print(f'dbg{fl:4d}: {t*1e6:8.1f} us  {R*V*4/t/1e9:7.1f} GB/s', flush=True)
