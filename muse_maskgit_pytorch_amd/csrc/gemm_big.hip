@@ -10,6 +10,9 @@
 //   * one workgroup per CU (144 KiB LDS), 2 waves per SIMD;
 //   * 85 flop per LDS-DMA byte instead of 64, and half as many prologues / epilogues per output element.
 // Same XOR-swizzled 128-byte rows, same LDS-staged row-contiguous epilogue as gemm.hip.
+// MODE_CONV (implicit-GEMM NHWC convolution, vqgan_vae.py:224-232,255-261,271-277) is served when Cin % 64 == 0: a 64-wide
+// k-tile then lies inside ONE filter tap, so the tap walk (ty, tx, channel offset) is wave-uniform running state and the
+// per-lane im2col work per k-tile is a bounds test and one 64-bit multiply-add per staged row.
 #include "common.h"
 #include "muse_hip_internal.h"
 
@@ -26,6 +29,9 @@ constexpr int CT_LD = BNB + 4;                     // fp32 output tile row strid
 constexpr int SMEM_B = NSTAGE * STAGE_B;           // 144 KiB >= 256 * 132 * 4 = 132 KiB
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+// source of the implicit-GEMM loader for taps that fall into the zero padding
+__device__ __attribute__((aligned(16))) const unsigned int g_zero_page_big[64] = {0};
 
 template <int MODE>
 __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
@@ -49,6 +55,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
         const int n = n0 + 16 * wid + 8 * i + (lane >> 3);
         wptr[i] = p.W + (size_t)(n < p.N ? n : 0) * p.ldw + chunk * 8;      // clamped rows feed only unstored outputs
     }
+    int ciy[4], cix[4], cpix[4];      // conv: input y / x of tap (0,0) and the flat pixel index of that position, per staged row
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = 32 * wid + 8 * i + (lane >> 3);
@@ -56,11 +63,23 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
             const int wm = r >> 6, jj = r & 63;
             const int tok = m0 + wm * 32 + (jj & 31);
             xptr[i] = ((jj >> 5) ? p.X2 : p.X) + (size_t)(tok < p.M ? tok : 0) * p.ldx + chunk * 8;
+        } else if constexpr (MODE == MODE_CONV) {
+            const int m = m0 + r;
+            const int mm = m < p.M ? m : 0;
+            const int hw = p.Hv * p.Wv;
+            const int cb = mm / hw;
+            const int rem = mm - cb * hw;
+            const int cy = rem / p.Wv, cx = rem - cy * p.Wv;
+            ciy[i] = cy * p.stride + p.off_y;
+            cix[i] = cx * p.stride + p.off_x;
+            cpix[i] = (cb * p.Hin + ciy[i]) * p.Win + cix[i];
+            xptr[i] = p.X + chunk * 8;
         } else {
             const int m = m0 + r;
             xptr[i] = p.X + (size_t)(m < p.M ? m : 0) * p.ldx + chunk * 8;
         }
     }
+    int tap_y = 0, tap_x = 0, tap_c = 0;      // conv: filter tap and channel offset of the NEXT k-tile to issue (wave-uniform)
 
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define ISSUE_TILE(kt_, stage_)                                                                              \
@@ -70,8 +89,20 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
         unsigned char* xs_ = smem + (stage_) * STAGE_B + W_BYTES + wid * 4096;                               \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                        \
             __builtin_amdgcn_global_load_lds(wptr[i] + k0_, (lds_ptr_t)(ws_ + i * 1024), 16, 0, 0);          \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                        \
-            __builtin_amdgcn_global_load_lds(xptr[i] + k0_, (lds_ptr_t)(xs_ + i * 1024), 16, 0, 0);          \
+        if constexpr (MODE != MODE_CONV) {                                                                   \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                    \
+                __builtin_amdgcn_global_load_lds(xptr[i] + k0_, (lds_ptr_t)(xs_ + i * 1024), 16, 0, 0);      \
+        } else {                                                                                             \
+            const int dpix_ = tap_y * p.Win + tap_x;                                                         \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
+                const bool ok_ = (unsigned)(ciy[i] + tap_y) < (unsigned)p.Hin && (unsigned)(cix[i] + tap_x) < (unsigned)p.Win; \
+                const bf16_t* src_ = xptr[i] + ((size_t)(cpix[i] + dpix_) * p.Cin + tap_c);                  \
+                if (!ok_) src_ = reinterpret_cast<const bf16_t*>(g_zero_page_big);                           \
+                __builtin_amdgcn_global_load_lds(src_, (lds_ptr_t)(xs_ + i * 1024), 16, 0, 0);               \
+            }                                                                                                \
+            tap_c += BK;                                                                                     \
+            if (tap_c >= p.Cin) { tap_c = 0; if (++tap_x == p.TW) { tap_x = 0; ++tap_y; } }                  \
+        }                                                                                                    \
     }
 
     f32x4_t acc[4][4];
@@ -152,10 +183,29 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r];
             }
+            if (p.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (n0 + nl + r < p.N) ? p.bias[n0 + nl + r] : 0.f;
+            }
+            if (p.act == ACT_LEAKY) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.1f * v[r];   // vqgan_vae.py:103-104
+            }
             *reinterpret_cast<float4*>(ct + ml * CT_LD + nl) = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
     __syncthreads();
+    auto out_row = [&](int m) -> size_t {
+        if constexpr (MODE == MODE_CONV) {
+            const int hw = p.Hv * p.Wv;
+            const int ob = m / hw;
+            const int rem = m - ob * hw;
+            const int oy = (rem / p.Wv) * p.os + p.py, ox = (rem % p.Wv) * p.os + p.px;
+            return ((size_t)ob * p.Hout + oy) * p.Wout + ox;
+        } else {
+            return (size_t)m;
+        }
+    };
 
     if (geglu) {
         const int c8 = (t & 7) * 8;
@@ -184,8 +234,9 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
             const float4 cv = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c4);
             float v[4] = {cv.x, cv.y, cv.z, cv.w};
             const bool full = n + 3 < p.N;
+            const size_t orow = out_row(m);
             if (p.resid_f32) {
-                const float* rp = p.resid_f32 + (size_t)m * p.ldr + n;
+                const float* rp = p.resid_f32 + orow * p.ldr + n;
                 if (full) {
                     const float4 r0 = *reinterpret_cast<const float4*>(rp);
                     v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
@@ -194,7 +245,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
                     for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += rp[r];
                 }
             }
-            float* op = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n;
+            float* op = reinterpret_cast<float*>(p.out) + orow * p.ldc + n;
             if (full) *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
             else {
 #pragma unroll
@@ -212,7 +263,20 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
             const float4 lo = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c8);
             const float4 hi = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c8 + 4);
             float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-            bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + n;
+            const size_t orow = out_row(m);
+            if (p.resid_bf16) {
+                const bf16_t* rp = p.resid_bf16 + orow * p.ldr + n;
+                if (n + 7 < p.N) {
+                    float rv[8];
+                    unpack8(*reinterpret_cast<const uint4*>(rp), rv);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += rv[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) if (n + r < p.N) v[r] += bf16_to_f32(rp[r]);
+                }
+            }
+            bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + orow * p.ldc + n;
             if (n + 7 < p.N) *reinterpret_cast<uint4*>(op) = pack8(v);
             else {
 #pragma unroll
@@ -238,9 +302,10 @@ int launch_big(const GemmArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-// dense / CFG GEMMs without bias / activation / bf16 residual, large enough to fill 256-row tiles
+// GEMMs large enough to fill 256-row tiles; convolutions only when a k-tile stays inside one filter tap
 bool mm_gemm_big_eligible(const GemmArgs& a) {
-    if (a.mode == MODE_CONV || a.bias || a.act != ACT_NONE || a.resid_bf16 || a.out_kind == OUT_NCHW_F32) return false;
+    if (a.out_kind == OUT_NCHW_F32) return false;
+    if (a.mode == MODE_CONV && ((a.Cin % BK) != 0 || a.K != a.Ktrue)) return false;
     const int tok = a.mode == MODE_CFG ? 128 : BMB;
     const long tiles = (long)((a.M + tok - 1) / tok) * ((a.N + BNB - 1) / BNB);
     return a.M >= 2 * tok && a.N >= BNB && tiles >= 256;      // one workgroup per CU: fewer tiles than CUs idles the chip
@@ -251,5 +316,6 @@ int mm_gemm_big_launch(GemmArgs a, hipStream_t stream) {
     const int tm = a.mode == MODE_CFG ? 128 : BMB;
     a.tiles_m = (a.M + tm - 1) / tm;
     if (a.mode == MODE_CFG) return launch_big<MODE_CFG>(a, stream);
+    if (a.mode == MODE_CONV) return launch_big<MODE_CONV>(a, stream);
     return launch_big<MODE_DENSE>(a, stream);
 }

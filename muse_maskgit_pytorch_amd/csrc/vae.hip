@@ -16,7 +16,43 @@ inline int grid_for(long items, int per_block = 256, int cap = 256 * 16) {
 }
 
 // out[p][c] = bias[c] + sum_j (bit_j(id_p) ? +1 : -1) * w[c][j],  bit_j = (id >> (bits-1-j)) & 1  (MSB = code dim 0).
-// One thread produces 8 consecutive channels of one pixel (one 16-byte store).
+// A thread owns 8 consecutive channels: their bits x 8 projection weights stay in registers while it walks a strip of pixels
+// (one 16-byte store per pixel); the sum runs j = 0..bits-1 from the bias like the reference's Linear.
+template <int BITS>
+__global__ __launch_bounds__(256) void lfq_decode_proj_kernel(const int64_t* __restrict__ ids, long count, int C, int strip,
+                                                              const float* __restrict__ w, const float* __restrict__ bias,
+                                                              bf16_t* __restrict__ out) {
+    const int nch = C >> 3;
+    const int cg = blockIdx.x * blockDim.x + threadIdx.x;      // channel group
+    if (cg >= nch) return;
+    const int c0 = cg * 8;
+    float wr[8][BITS], br[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        br[k] = bias[c0 + k];
+#pragma unroll
+        for (int j = 0; j < BITS; ++j) wr[k][j] = w[(c0 + k) * BITS + j];
+    }
+    const long p0 = (long)blockIdx.y * strip;
+    const long p1 = p0 + strip < count ? p0 + strip : count;
+    for (long pix = p0; pix < p1; ++pix) {
+        const int64_t id = ids[pix];
+        float sg[BITS];
+#pragma unroll
+        for (int j = 0; j < BITS; ++j) sg[j] = ((id >> (BITS - 1 - j)) & 1) ? 1.f : -1.f;
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float a = br[k];
+#pragma unroll
+            for (int j = 0; j < BITS; ++j) a += sg[j] * wr[k][j];      // exact product: same bits as a +/- w
+            acc[k] = a;
+        }
+        *reinterpret_cast<uint4*>(out + pix * C + c0) = pack8(acc);
+    }
+}
+
+// general / projection-free form: one thread produces 8 consecutive channels of one pixel
 __global__ __launch_bounds__(256) void lfq_decode_kernel(const int64_t* __restrict__ ids, long count, int bits, int C,
                                                          const float* __restrict__ w, const float* __restrict__ bias,
                                                          bf16_t* __restrict__ out) {
@@ -195,6 +231,18 @@ int k_lfq_decode(hipStream_t s, const int64_t* ids, long count, int bits, int C,
     if (count <= 0) return MM_OK;
     if (!w && C != bits) return mm_set_error(MM_ERR_SHAPE, "lfq_decode: no projection requires C == bits");
     if (C % 8) return mm_set_error(MM_ERR_SHAPE, "lfq_decode: C must be a multiple of 8");
+    if (w && (bits == 16 || bits == 13) && C >= 512) {
+        // wide projection (the 65536- / 8192-entry codebooks): register-resident weights, strips of pixels
+        const int nch = C / 8;
+        const int bx = (nch + 255) / 256;
+        long strips = 2048 / bx;
+        if (strips > count) strips = count;
+        const int strip = (int)((count + strips - 1) / strips);
+        const dim3 grid(bx, (unsigned)((count + strip - 1) / strip));
+        if (bits == 16) hipLaunchKernelGGL((lfq_decode_proj_kernel<16>), grid, dim3(256), 0, s, ids, count, C, strip, w, b, out);
+        else hipLaunchKernelGGL((lfq_decode_proj_kernel<13>), grid, dim3(256), 0, s, ids, count, C, strip, w, b, out);
+        return mm_check_launch("lfq_decode_proj_kernel");
+    }
     hipLaunchKernelGGL(lfq_decode_kernel, dim3(grid_for(count * (C / 8))), dim3(256), 0, s, ids, count, bits, C, w, b, out);
     return mm_check_launch("lfq_decode_kernel");
 }

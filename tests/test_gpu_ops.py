@@ -461,6 +461,43 @@ def test_conv_variants_match_emulation(cin, cout, hw, kind):
     check_close(got, ref, atol=2e-3, rtol=ULP, what=f'conv {kind}')
 
 
+@pytest.mark.parametrize('kind', ['c3', 'c1', 'c4s2', 'ct'])
+def test_conv_large_tile_kernel_is_bit_identical_to_small(kind):
+    """Cin % 64 == 0 convolutions with >= 256 tiles run on the 256x128 three-stage kernel (gemm_big.hip: wave-uniform tap walk);
+    same MFMA order as the 128x128 kernel that test_conv_variants_match_emulation pins -> bit-identical outputs."""
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(11)
+    B, hw, cin, cout = 8, 64, 64, 256
+    x = rnd(B, hw, hw, cin, gen=g).to(DEV, bf16)
+    bias = (0.1 * rnd(cout, gen=g)).to(DEV)
+    if kind in ('c3', 'c1'):
+        k = 3 if kind == 'c3' else 1
+        w = ops.pack_conv_weight(rnd(cout, cin, k, k, gen=g, scale=0.05)).to(DEV)
+        resid = rnd(B, hw, hw, cout, gen=g).to(DEV, bf16) if k == 1 else None
+        run = lambda: ops.conv2d_nhwc(x, w, cout, k, k, 1, (-(k // 2), -(k // 2)), bias=bias, act=(k == 3), resid=resid)
+    elif kind == 'c4s2':
+        x = rnd(B, 2 * hw, 2 * hw, cin, gen=g).to(DEV, bf16)
+        w = ops.pack_conv_weight(rnd(cout, cin, 4, 4, gen=g, scale=0.05)).to(DEV)
+        run = lambda: ops.conv2d_nhwc(x, w, cout, 4, 4, 2, (-1, -1), out_hw=(hw, hw), bias=bias, act=True)
+    else:
+        packs = {k_: v.to(DEV) for k_, v in ops.pack_convT_weight(rnd(cin, cout, 4, 4, gen=g, scale=0.05)).items()}
+
+        def run():
+            out = torch.zeros(B, 2 * hw, 2 * hw, cout, dtype=bf16, device=DEV)
+            for (py, px), wp in packs.items():
+                ops.conv2d_nhwc(x, wp, cout, 2, 2, 1, (py - 1, px - 1), out_hw=(hw, hw), os_=2, parity=(py, px), full_hw=(2 * hw, 2 * hw),
+                                bias=bias, act=True, out=out)
+            return out
+    big = run()
+    lib.mm_debug_set(8)
+    try:
+        small = run()
+    finally:
+        lib.mm_debug_set(0)
+    assert torch.equal(big, small)
+    assert big.float().abs().max() > 0.05
+
+
 def test_glu_groupnorm_lfq_layout():
     g = torch.Generator().manual_seed(2)
     x = r16(rnd(2, 4, 4, 256, gen=g))
@@ -473,6 +510,12 @@ def test_glu_groupnorm_lfq_layout():
     ids = torch.randint(0, 512, (2, 8, 8), generator=g)
     wo, bo = rnd(128, 9, gen=g), rnd(128, gen=g)
     check_close(ops.lfq_decode(ids.to(DEV), 9, 128, wo.to(DEV), bo.to(DEV)), emu.lfq_decode(ids, 9, 128, wo, bo), atol=1e-3, rtol=ULP, what='lfq decode')
+    # the wide-projection kernel (16-bit / 13-bit codebooks, register-resident weights, pixel strips)
+    for bits, C in ((16, 2048), (13, 512)):
+        ids_w = torch.randint(0, 2 ** bits, (3, 7, 5), generator=g)
+        wo_w, bo_w = rnd(C, bits, gen=g), rnd(C, gen=g)
+        check_close(ops.lfq_decode(ids_w.to(DEV), bits, C, wo_w.to(DEV), bo_w.to(DEV)), emu.lfq_decode(ids_w, bits, C, wo_w, bo_w),
+                    atol=1e-3, rtol=ULP, what=f'lfq decode {bits} bit')
     wi, bi = rnd(9, 128, gen=g), rnd(9, gen=g)
     xe = r16(rnd(2, 8, 8, 128, gen=g))
     ids_ref, q_ref = emu.lfq_encode(xe, 9, wi, bi, wo, bo)
