@@ -203,10 +203,10 @@ def main():
                        'weights': 'random init (module defaults, torch.manual_seed(0))'},
             'transformer_tok_per_s_per_gpu': tok_s_gpu,
             'decode_loop_ms_per_step': loop_ms / args.steps,
-            'roofline': {'kernel': 'gemm_pers_kernel<MODE_CFG> (to_logits + classifier-free guidance, persistent 256x128 MFMA GEMM)', 'bound': 'mfma',
+            'roofline': {'kernel': 'gemm_cfg2_kernel (to_logits + classifier-free guidance, persistent 128-token x 256-column MFMA GEMM)', 'bound': 'mfma',
                          'achieved': g_flops / (g_ms * 1e-3) / 1e12 if g_ms else None, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': (g_flops / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if g_ms else None,
-                         'traffic': traffic_of('gemm_pers_kernel<1>') if not args.tiny and B == 32 else None,
+                         'traffic': traffic_of('gemm_cfg2_kernel') if not args.tiny and B == 32 else None,
                          'traffic_source': 'profiles/r01_bench_b32_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch, FETCH x2 gfx950 correction)',
                          'launches': g_cnt, 'avg_launch_ms': g_ms / g_cnt if g_cnt else None,
                          'algorithmic_flops_per_launch': g_flops / g_cnt if g_cnt else None},

@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libmuse_hip.so')
-SOURCES = ['gemm.hip', 'gemm_big.hip', 'gemm_pers.hip', 'attention.hip', 'norm_act.hip', 'sampling.hip', 'vae.hip', 'model.hip', 'api.hip']
+SOURCES = ['gemm.hip', 'gemm_big.hip', 'gemm_pers.hip', 'gemm_cfg.hip', 'attention.hip', 'norm_act.hip', 'sampling.hip', 'vae.hip', 'model.hip', 'api.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
          '-fno-fast-math', '-ffp-contract=off']
 
@@ -25,13 +25,16 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    flags = list(FLAGS)
+    if os.environ.get('MM_GEMM_ABLATE'):      # tools/gemm_bench.py ablations only: run-time skip-stores / -DMA / -MFMA switches in the k-loops
+        flags.append('-DMM_GEMM_ABLATE')
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
     for src in SOURCES:
         obj = os.path.join(HERE, 'build', src.replace('.hip', '.o'))
         objs.append(obj)
-        cmd = [hipcc, *FLAGS, '-c', os.path.join(CSRC, src), '-o', obj]
+        cmd = [hipcc, *flags, '-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -352,6 +352,7 @@ int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
         return mm_set_error(MM_ERR_DTYPE, "gemm: the residual must have the output's dtype");
     if (a.epi == EPI_GEGLU && (a.mode != MODE_DENSE || (a.N % 128) || a.out_kind != OUT_BF16 || a.bias || a.resid_f32 || a.resid_bf16))
         return mm_set_error(MM_ERR_SHAPE, "gemm: GEGLU epilogue needs a dense bf16 GEMM with N % 128 == 0");
+    if (!(a.debug & (8 | 4096 | 8192)) && mm_gemm_cfg2_eligible(a)) return mm_gemm_cfg2_launch(a, stream);
     if (!(a.debug & (8 | 4096)) && mm_gemm_pers_eligible(a)) return mm_gemm_pers_launch(a, stream);
     if (!(a.debug & 8) && mm_gemm_big_eligible(a)) return mm_gemm_big_launch(a, stream);
     a.tiles_n = (a.N + BT - 1) / BT;

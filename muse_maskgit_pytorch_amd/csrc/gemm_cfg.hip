@@ -1,0 +1,306 @@
+// to_logits + classifier-free guidance, second generation (muse_maskgit_pytorch.py:250-254, 332): persistent MFMA GEMM with a
+// 128-token x 256-vocabulary tile.
+//
+// Why another kernel: the 256x128 kernels of this family all plateau where their LDS-DMA operand stream reaches ~45 GB/s per
+// CU (tools/gemm_bench.py ablations: removing the MFMAs changes nothing, removing the DMA gives +40..50 %; 48 KiB per
+// 4.2 MFLOP k-step / 45 GB/s = 1.03 PFLOP/s chip-wide, which is what they measure).  Doubling the vocabulary width of the tile
+// cuts the operand bytes per flop by a third (32 KiB per 4.2 MFLOP) and the ds_read traffic per MFMA by a quarter.
+//
+// Shape of the pipeline (one 512-thread workgroup per CU, 8 waves = 2 token halves x 4 vocabulary quarters, each wave
+// 64 tokens x {cond, null} x 64 columns = 4 x 8 accumulator fragments):
+//   * K is walked in steps of 32 (one v_mfma_f32_16x16x32_bf16 per fragment pair); three 32 KiB LDS stages, the LDS-DMA runs
+//     TWO k-steps ahead of the MFMAs across tile boundaries (its own tile cursor), one barrier per k-step;
+//   * LDS rows are 64 B; a 16-row block is stored row-major with the 16-byte chunk index XORed by (-(row >> 2)) & 3, which
+//     makes every ds_read_b128 lane group hit 16 distinct slots (MI355X_MICROARCH.md, LDS table) while 4 consecutive DMA
+//     lanes still fetch one contiguous 64-byte row segment; the swizzle is applied to the DMA's SOURCE address;
+//   * the fp32 output tile (128 KiB) does not fit beside the stages, so it leaves in two halves through a 64 KiB staging
+//     tile `ct`: at the end of a tile every wave combines cond / null, writes the first 32 of its 64 tokens to ct and keeps the
+//     other 32 (32 VGPRs) until the middle of the NEXT tile; ct drains row-contiguously (1 KiB per wave instruction), one
+//     8 KiB piece per k-step, inside the next tile's MFMA stream;
+//   * a piece is read from ct right after a step's barrier (raw ds_read: see lds_read_b128_raw) and stored at the end of the
+//     step, after the DMA issue; a piece is one token row per wave, so whether a wave issues the store is wave-uniform and the
+//     counted s_waitcnt vmcnt(N) at the top of a step knows exactly what may still be in flight behind the stage it is about
+//     to read (the stores of the last two steps + the DMA one step ahead; VMEM retires in order and vmcnt counts stores).
+// All waits are builtins, not inline asm, so that the compiler's own waitcnt pass sees them -- otherwise it assumes the LDS-DMA
+// may still be writing and drains vmcnt(0) in front of ds_reads.
+// The accumulation order per output element (k ascending in chunks of 32, one MFMA each) equals gemm.hip / gemm_big.hip /
+// gemm_pers.hip: results are bit-identical to those kernels.
+#include "common.h"
+#include "muse_hip_internal.h"
+
+#ifdef MM_GEMM_ABLATE
+#define ABL(p_, bit_) ((p_).debug & (bit_))
+#else
+#define ABL(p_, bit_) 0
+#endif
+
+namespace {
+
+constexpr int TOK = 128, BN = 256, BK = 32, NST = 3;
+constexpr int XT_B = 2 * TOK * BK * 2;      // 16 KiB: 256 activation rows (128 tokens x {cond, null}) x 64 B
+constexpr int WT_B = BN * BK * 2;           // 16 KiB
+constexpr int STG_B = XT_B + WT_B;          // 32 KiB
+constexpr int CT_OFF = NST * STG_B;         // 96 KiB
+constexpr int SMEM_B = CT_OFF + 65536;      // 160 KiB
+
+#define WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
+
+__device__ __forceinline__ void wait_vmcnt(int n) {      // n is wave-uniform
+    switch (n) {
+        case 0: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+        case 1: __builtin_amdgcn_s_waitcnt(0x0F71); break;
+        case 2: __builtin_amdgcn_s_waitcnt(0x0F72); break;
+        case 4: __builtin_amdgcn_s_waitcnt(0x0F74); break;
+        case 5: __builtin_amdgcn_s_waitcnt(0x0F75); break;
+        case 6: __builtin_amdgcn_s_waitcnt(0x0F76); break;
+        default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+    }
+}
+
+// raw LDS read the compiler's waitcnt pass cannot see (it would put an s_waitcnt vmcnt(0) in front: it cannot tell ct from the
+// DMA stages); the caller waits lgkmcnt(0) before using the value
+__device__ __forceinline__ uint4 lds_read_b128_raw(const unsigned char* ptr) {
+    typedef __attribute__((address_space(3))) const unsigned char* lds_cptr_t;
+    const unsigned addr = (unsigned)(size_t)(lds_cptr_t)ptr;
+    u32x4_t v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+struct LoadCur {
+    const bf16_t* x[2];
+    const bf16_t* w[2];
+};
+
+__device__ __forceinline__ void cfg_tile_setup(const GemmArgs& p, int vb, int wid, int lane, LoadCur& lc) {
+    int tile_m, tile_n;
+    xcd_grouped_tile(vb, p.tiles_m, p.tiles_n, 8, tile_m, tile_n);
+    const int m0 = tile_m * TOK, n0 = tile_n * BN;
+    const int c = (lane & 3) ^ ((-(lane >> 4)) & 3);      // logical 16-byte chunk this lane fetches into physical chunk lane & 3
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        // activation block xb of the tile: wave row wm = xb >> 3, pass h = (xb >> 2) & 1 (0 cond, 1 null), token block tb = xb & 3
+        const int xb = 2 * wid + i;
+        const int tok = m0 + (xb >> 3) * 64 + (xb & 3) * 16 + (lane >> 2);
+        lc.x[i] = (((xb >> 2) & 1) ? p.X2 : p.X) + (size_t)(tok < p.M ? tok : 0) * p.ldx + c * 8;   // clamped rows: never stored
+        lc.w[i] = p.W + (size_t)(n0 + xb * 16 + (lane >> 2)) * p.ldw + c * 8;
+    }
+}
+
+__global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* ct = smem + CT_OFF;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int total = p.tiles_m * p.tiles_n;
+    const int G = gridDim.x;
+    const int KT = p.K / BK;
+    const int KH = KT >> 1;
+    const int rd = fr * 64 + ((fg ^ ((-(fr >> 2)) & 3)) << 4);      // this lane's fragment offset inside a 16-row block
+
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    int vb = blockIdx.x;
+    if (vb >= total) return;
+    const int steps_total = ((total - 1 - vb) / G + 1) * KT;
+
+    // ---- load cursor: runs two k-steps ahead of the compute cursor, across tile boundaries; step s lands in stage s % 3
+    LoadCur lc;
+    int l_vb = vb, l_k = 0;
+    bool l_live = true;
+    cfg_tile_setup(p, l_vb, wid, lane, lc);
+#define LOAD_NEXT(st_)                                                                                         \
+    if (l_live) {                                                                                              \
+        if (!ABL(p, 2)) {                                                                                      \
+            unsigned char* xs_ = smem + (st_) * STG_B + wid * 2048;                                            \
+            const int k0_ = l_k * BK;                                                                          \
+            __builtin_amdgcn_global_load_lds(lc.x[0] + k0_, (lds_ptr_t)(xs_), 16, 0, 0);                       \
+            __builtin_amdgcn_global_load_lds(lc.x[1] + k0_, (lds_ptr_t)(xs_ + 1024), 16, 0, 0);                \
+            __builtin_amdgcn_global_load_lds(lc.w[0] + k0_, (lds_ptr_t)(xs_ + XT_B), 16, 0, 0);                \
+            __builtin_amdgcn_global_load_lds(lc.w[1] + k0_, (lds_ptr_t)(xs_ + XT_B + 1024), 16, 0, 0);         \
+        }                                                                                                      \
+        if (++l_k == KT) {                                                                                     \
+            l_k = 0;                                                                                           \
+            l_vb += G;                                                                                         \
+            l_live = l_vb < total;                                                                             \
+            if (l_live) cfg_tile_setup(p, l_vb, wid, lane, lc);                                                \
+        }                                                                                                      \
+    }
+    LOAD_NEXT(0);
+    LOAD_NEXT(1);
+
+    f32x4_t acc[4][8];
+    f32x4_t held[2][4];             // second half of the previous tile's output (tokens 32..63 of this wave), combined
+    bool have_prev = false;
+    int pm0 = 0, pn0 = 0;
+    int g = 0;                      // global k-step counter of the compute cursor
+    int st1 = 0, st2 = 0;           // did this wave issue a store in the previous / second-previous k-step (wave-uniform)
+
+#define HELD_TO_CT()                                                                                           \
+    {                                                                                                          \
+        _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                        \
+            const int hrow_ = wm * 32 + b * 16 + fr;                                                           \
+            _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                                    \
+                const int c_ = wn * 16 + a * 4 + fg;                                                           \
+                *reinterpret_cast<f32x4_t*>(ct + hrow_ * 1024 + ((c_ ^ (hrow_ & 7)) << 4)) = held[b][a];       \
+            }                                                                                                  \
+        }                                                                                                      \
+    }
+    // one 8 KiB piece of ct = 8 token rows x 1 KiB: this wave handles row q*8 + wid, lane = 16-byte chunk
+#define PIECE_ROW(q_) ((q_) * 8 + wid)
+#define PIECE_TOKEN(hrow_, half_) (pm0 + ((hrow_) >> 5) * 64 + (half_) * 32 + ((hrow_) & 31))
+
+    while (true) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 8; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < KT; ++kt) {
+            // stage g % 3 has landed once only what this wave issued AFTER its DMA of step g can still be in flight: the store of
+            // step g-2, the 4 DMA instructions of step g+1, the store of step g-1
+            wait_vmcnt(((g + 1 < steps_total && !ABL(p, 2)) ? 4 : 0) + st1 + st2);
+            WAIT_LGKM0();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt == KH && have_prev) {
+                // every wave has read the last piece of the first half (step KH-1 at the latest): second half -> ct
+                HELD_TO_CT();
+                WAIT_LGKM0();
+                __builtin_amdgcn_s_barrier();
+            }
+            // this step's piece of the previous tile: first half during steps 0..7, second half during steps KH..KH+7
+            const int half = kt >= KH ? 1 : 0;
+            const int q = kt - (half ? KH : 0);
+            const int hrow = PIECE_ROW(q);
+            const int ptok = PIECE_TOKEN(hrow, half);
+            const bool piece = have_prev && q < 8 && ptok < p.M && !ABL(p, 1);      // wave-uniform
+            uint4 pv = make_uint4(0, 0, 0, 0);
+            if (piece) pv = lds_read_b128_raw(ct + hrow * 1024 + ((lane ^ (hrow & 7)) << 4));
+            float* pv_ptr = reinterpret_cast<float*>(p.out) + (size_t)ptok * p.ldc + pn0 + lane * 4;
+            __builtin_amdgcn_sched_barrier(0);
+            LOAD_NEXT((g + 2) % NST);                                   // step g+2: its stage was last read in step g-1
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned char* xs = smem + (g % NST) * STG_B + wm * 8192 + rd;
+            const unsigned char* ws = smem + (g % NST) * STG_B + XT_B + wn * 4096 + rd;
+            // fragment reads run one token-block PAIR ahead of the MFMAs that consume them (two 2-fragment buffers): the LDS pipe
+            // and the matrix pipe overlap inside the wave, and the register cost stays at 16 + 16 VGPRs
+            u32x4_t af[4], p0[2], p1[2];
+#define READ_PAIR(dst_, j_)                                                                                    \
+            dst_[0] = *reinterpret_cast<const u32x4_t*>(xs + (2 * (j_)) * 1024);                               \
+            dst_[1] = *reinterpret_cast<const u32x4_t*>(xs + (2 * (j_) + 1) * 1024);
+#define MFMA_PAIR(src_, j_)                                                                                    \
+            if (!ABL(p, 4)) {                                                                                  \
+                __builtin_amdgcn_s_setprio(1);                                                                 \
+                _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                  \
+                    _Pragma("unroll") for (int a = 0; a < 4; ++a)                                              \
+                        acc[a][2 * (j_) + h] = mfma16(af[a], src_[h], acc[a][2 * (j_) + h]);                   \
+                __builtin_amdgcn_s_setprio(0);                                                                 \
+            } else { asm volatile("" ::"v"(af[0]), "v"(af[1]), "v"(af[2]), "v"(af[3]), "v"(src_[0]), "v"(src_[1])); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const u32x4_t*>(ws + i * 1024);
+            READ_PAIR(p0, 0)
+            READ_PAIR(p1, 1)
+            __builtin_amdgcn_sched_barrier(0);
+            MFMA_PAIR(p0, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            READ_PAIR(p0, 2)
+            __builtin_amdgcn_sched_barrier(0);
+            MFMA_PAIR(p1, 1)
+            __builtin_amdgcn_sched_barrier(0);
+            READ_PAIR(p1, 3)
+            __builtin_amdgcn_sched_barrier(0);
+            MFMA_PAIR(p0, 2)
+            __builtin_amdgcn_sched_barrier(0);
+            MFMA_PAIR(p1, 3)
+            __builtin_amdgcn_sched_barrier(0);
+            st2 = st1;
+            st1 = 0;
+            if (piece) {
+                WAIT_LGKM0();                                           // the raw read of pv
+                __builtin_amdgcn_sched_barrier(0);
+                *reinterpret_cast<uint4*>(pv_ptr) = pv;
+                st1 = 1;
+            }
+            ++g;
+        }
+        // ---- tile end: all pieces of the previous tile have been read; combine this tile and park it
+        int tile_m, tile_n;
+        xcd_grouped_tile(vb, p.tiles_m, p.tiles_n, 8, tile_m, tile_n);
+        WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                f32x4_t v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float cv = acc[a][b][r], nl = acc[a][b + 4][r];
+                    v[r] = nl + (cv - nl) * p.cfg_scale;      // muse_maskgit_pytorch.py:254
+                }
+                if (b < 2) {
+                    if (!ABL(p, 16)) {
+                        const int hrow = wm * 32 + b * 16 + fr;
+                        const int c = wn * 16 + a * 4 + fg;
+                        *reinterpret_cast<f32x4_t*>(ct + hrow * 1024 + ((c ^ (hrow & 7)) << 4)) = v;
+                    }
+                } else {
+                    held[b - 2][a] = v;
+                }
+            }
+        }
+        pm0 = tile_m * TOK; pn0 = tile_n * BN;
+        have_prev = true;
+        vb += G;
+        if (vb >= total) break;
+    }
+    // ---- drain the last tile
+    WAIT_LGKM0();
+    __builtin_amdgcn_s_barrier();
+    for (int half = 0; half < 2; ++half) {
+        if (half) {
+            HELD_TO_CT();
+            WAIT_LGKM0();
+            __builtin_amdgcn_s_barrier();
+        }
+        for (int q = 0; q < 8; ++q) {
+            const int hrow = PIECE_ROW(q);
+            const int ptok = PIECE_TOKEN(hrow, half);
+            if (ptok < p.M && !ABL(p, 1)) {
+                const uint4 pv = *reinterpret_cast<const uint4*>(ct + hrow * 1024 + ((lane ^ (hrow & 7)) << 4));
+                *reinterpret_cast<uint4*>(reinterpret_cast<float*>(p.out) + (size_t)ptok * p.ldc + pn0 + lane * 4) = pv;
+            }
+        }
+        WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+}  // namespace
+
+// K a multiple of 32 with at least 16 k-steps (the 16 store pieces of a tile ride on the next tile's k-loop), N a multiple of
+// the 256-column tile, fp32 output with 16-byte aligned rows, enough tiles for one workgroup per CU
+bool mm_gemm_cfg2_eligible(const GemmArgs& a) {
+    if (a.mode != MODE_CFG || a.out_kind != OUT_F32 || a.bias || a.act != ACT_NONE || a.resid_bf16 || a.resid_f32) return false;
+    if ((a.K % BK) != 0 || a.K < 16 * BK || (a.N % BN) != 0) return false;
+    if ((a.ldc % 4) || (((uintptr_t)a.out) & 15)) return false;
+    const long tiles = (long)((a.M + TOK - 1) / TOK) * (a.N / BN);
+    return tiles >= 256;
+}
+
+int mm_gemm_cfg2_launch(GemmArgs a, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cfg2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
+        if (e != hipSuccess) return mm_set_hip_error(e, "gemm_cfg2 hipFuncSetAttribute");
+        attr_set = true;
+    }
+    a.tiles_n = a.N / BN;
+    a.tiles_m = (a.M + TOK - 1) / TOK;
+    const int total = a.tiles_m * a.tiles_n;
+    const int grid = total < 256 ? total : 256;
+    hipLaunchKernelGGL(gemm_cfg2_kernel, dim3(grid), dim3(512), SMEM_B, stream, a);
+    return mm_check_launch("gemm_cfg2_kernel");
+}

@@ -15,6 +15,15 @@
 #include "common.h"
 #include "muse_hip_internal.h"
 
+// Ablation hooks (skip stores / DMA / MFMA / the ct transpose via mm_debug_set bits 1 / 2 / 4 / 16, tools/gemm_bench.py) are compiled
+// in only with -DMM_GEMM_ABLATE: as run-time branches they split the k-loop into a dozen basic blocks, which stops the
+// scheduler from overlapping ds_reads, DMA issue and MFMAs.
+#ifdef MM_GEMM_ABLATE
+#define ABL(p_, bit_) ((p_).debug & (bit_))
+#else
+#define ABL(p_, bit_) 0
+#endif
+
 namespace {
 
 constexpr int BMB = 256, BNB = 128, BK = 64;
@@ -106,7 +115,50 @@ __device__ __forceinline__ void acc_to_ct(const GemmArgs& p, const f32x4_t (&acc
     }
 }
 
-// one 8 KiB piece of ct -> global, 16 B per lane, consecutive lanes on consecutive addresses of one output row
+// one 8 KiB piece of ct, 16 B per lane, consecutive lanes on consecutive addresses of one output row: the LDS read ...
+// (inline asm on purpose: a ds_read the compiler can see gets an s_waitcnt vmcnt(0) in front of it -- its waitcnt pass
+//  cannot tell ct from the DMA stages and assumes the LDS-DMA in flight may write what is being read.  The caller waits
+//  lgkmcnt(0) itself before using the value.)
+__device__ __forceinline__ uint4 lds_read_b128_raw(const unsigned char* ptr) {
+    typedef __attribute__((address_space(3))) const unsigned char* lds_cptr_t;
+    const unsigned addr = (unsigned)(size_t)(lds_cptr_t)ptr;
+    u32x4_t v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+template <int MODE>
+__device__ __forceinline__ uint4 read_piece(const GemmArgs& p, const unsigned char* ct, int piece, int t) {
+    if constexpr (MODE == MODE_CFG) {
+        const int row = piece * 16 + (t >> 5), c = t & 31;
+        return lds_read_b128_raw(ct + row * 512 + ((c ^ (row & 7)) << 4));
+    } else if (p.epi == EPI_GEGLU) {
+        const int row = piece * 64 + (t >> 3), c = t & 7;
+        return lds_read_b128_raw(ct + row * 128 + ((c ^ (row & 7)) << 4));
+    } else {
+        const int row = piece * 32 + (t >> 4), c = t & 15;
+        return lds_read_b128_raw(ct + row * 256 + ((c ^ (row & 15)) << 4));
+    }
+}
+
+// ... and the global store of what read_piece returned
+template <int MODE>
+__device__ __forceinline__ void write_piece(const GemmArgs& p, const uint4 v, int piece, int t, int m0, int n0, int tile_n) {
+    if constexpr (MODE == MODE_CFG) {
+        const int row = piece * 16 + (t >> 5), c = t & 31;
+        const int m = m0 + row;
+        if (m < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n0 + c * 4) = v;
+    } else if (p.epi == EPI_GEGLU) {
+        const int row = piece * 64 + (t >> 3), c = t & 7;
+        const int m = m0 + row;
+        if (m < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + tile_n * 64 + c * 8) = v;
+    } else {
+        const int row = piece * 32 + (t >> 4), c = t & 15;
+        const int m = m0 + row;
+        if (m < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + n0 + c * 8) = v;
+    }
+}
+
 template <int MODE>
 __device__ __forceinline__ void store_piece(const GemmArgs& p, const unsigned char* ct, int piece, int t, int m0, int n0, int tile_n) {
     if constexpr (MODE == MODE_CFG) {
@@ -143,89 +195,126 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(const GemmArgs p) {
     const int npieces = (MODE == MODE_DENSE && p.epi == EPI_GEGLU) ? 4 : 8;
 
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
-#define ISSUE_TILE(tp_, kt_, g_)                                                                              \
+#define ISSUE_TILE(tp_, kt_, st_)                                                                             \
     {                                                                                                         \
         const int k0_ = (kt_) * BK;                                                                           \
-        const int st_ = (g_) & 1;                                                                             \
-        unsigned char* ws_ = smem + st_ * STAGE_B + wid * 2048;                                               \
-        unsigned char* xs_ = smem + st_ * STAGE_B + W_BYTES + wid * 4096;                                     \
+        unsigned char* ws_ = smem + (st_) * STAGE_B + wid * 2048;                                             \
+        unsigned char* xs_ = smem + (st_) * STAGE_B + W_BYTES + wid * 4096;                                   \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
             __builtin_amdgcn_global_load_lds((tp_).w[i] + k0_, (lds_ptr_t)(ws_ + i * 1024), 16, 0, 0);        \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
             __builtin_amdgcn_global_load_lds((tp_).x[i] + k0_, (lds_ptr_t)(xs_ + i * 1024), 16, 0, 0);        \
     }
 
-    f32x4_t acc[4][4];
-    TilePtrs cur;
-    int prv_m0 = 0, prv_n0 = 0, prv_tile_n = 0;
     int vb = blockIdx.x;
     if (vb >= total) return;
-    tile_setup<MODE>(p, vb, wid, lane, cur);
-    bool has_next = vb + G < total;
-    bool have_prev = false;
-    int g = 0;                  // flattened (tile, k-tile) iteration counter: selects the DMA stage
-    int st_prev = 0;            // VMEM stores this wave issued in the previous iteration (they sit behind the DMA we wait for)
-    ISSUE_TILE(cur, 0, 0);
+    const int steps_total = ((total - 1 - vb) / G + 1) * KT;      // k-steps this workgroup runs over all its tiles
 
-    // one pipeline iteration: wait for this iteration's operands; DMA_STMT issues the NEXT iteration's; 32 MFMAs per wave;
-    // then (PIECE >= 0) one 8 KiB piece of the previous tile's output goes from ct to HBM.
-    // A ragged tile may skip a whole store instruction (all lanes predicated off): then count 0 -- under-counting only makes
-    // the wait conservative, over-counting would let the DMA we need slip.
-#define ITER(PIECE, DMA_STMT)                                                                                                \
-    {                                                                                                                        \
-        if (st_prev) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                   \
-        __builtin_amdgcn_s_barrier();                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                                   \
-        if (!(p.debug & 2)) { DMA_STMT; }                                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                                                   \
-        const unsigned char* ws = smem + (g & 1) * STAGE_B;                                                                  \
-        const unsigned char* xs = ws + W_BYTES;                                                                              \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                                   \
-            u32x4_t af[4], bfm[4];                                                                                           \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                  \
-                af[i] = *reinterpret_cast<const u32x4_t*>(ws + lds_off(wave_n * 64 + i * 16 + fr, ks * 4 + fg));             \
-                bfm[i] = *reinterpret_cast<const u32x4_t*>(xs + lds_off(wave_m * 64 + i * 16 + fr, ks * 4 + fg));            \
-            }                                                                                                                \
-            if (!(p.debug & 4)) {                                                                                            \
-            _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                                    \
-                _Pragma("unroll") for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(af[a], bfm[b], acc[a][b]);                  \
-            } else { _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(af[i]), "v"(bfm[i])); }           \
-        }                                                                                                                    \
-        st_prev = 0;                                                                                                         \
-        if ((PIECE) >= 0 && (PIECE) < npieces && have_prev && !(p.debug & 1)) {                                              \
-            store_piece<MODE>(p, ct, (PIECE) < 0 ? 0 : (PIECE), t, prv_m0, prv_n0, prv_tile_n);                              \
-            st_prev = (prv_m0 + tile_rows <= p.M) ? 1 : 0;                                                                   \
-        }                                                                                                                    \
-        ++g;                                                                                                                 \
+    // ---- load cursor: the DMA runs ahead of the MFMAs across tile boundaries (step s lands in stage s & 1)
+    TilePtrs lc;
+    int l_vb = vb, l_k = 0;
+    bool l_live = true;
+    tile_setup<MODE>(p, l_vb, wid, lane, lc);
+#define LOAD_NEXT(st_)                                                                                        \
+    if (l_live) {                                                                                             \
+        if (!ABL(p, 2)) ISSUE_TILE(lc, l_k, st_);                                                         \
+        if (++l_k == KT) {                                                                                    \
+            l_k = 0;                                                                                          \
+            l_vb += G;                                                                                        \
+            l_live = l_vb < total;                                                                            \
+            if (l_live) tile_setup<MODE>(p, l_vb, wid, lane, lc);                                             \
+        }                                                                                                     \
     }
+    LOAD_NEXT(0);
+    LOAD_NEXT(1);
+
+    // fragment registers, double-buffered over the two 32-wide k-halves of a stage: while the MFMAs of one half run, the
+    // ds_reads of the next half (after the barrier: of the NEXT stage) are in flight -- the LDS pipe and the matrix pipe
+    // overlap instead of alternating (the single-buffered loop idled the MFMAs ~45 % of the time even without any DMA)
+    u32x4_t a0[4], b0[4], a1[4], b1[4];
+#define READ_FRAGS(af_, bf_, st_, ks_)                                                                        \
+    {                                                                                                         \
+        const unsigned char* ws_ = smem + (st_) * STAGE_B;                                                    \
+        const unsigned char* xs_ = ws_ + W_BYTES;                                                             \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
+            af_[i] = *reinterpret_cast<const u32x4_t*>(ws_ + lds_off(wave_n * 64 + i * 16 + fr, (ks_) * 4 + fg)); \
+            bf_[i] = *reinterpret_cast<const u32x4_t*>(xs_ + lds_off(wave_m * 64 + i * 16 + fr, (ks_) * 4 + fg)); \
+        }                                                                                                     \
+    }
+#define MFMA_HALF(af_, bf_)                                                                                   \
+    if (!ABL(p, 4)) {                                                                                         \
+        __builtin_amdgcn_s_setprio(1);                                                                        \
+        _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                         \
+            _Pragma("unroll") for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(af_[a], bf_[b], acc[a][b]);      \
+        __builtin_amdgcn_s_setprio(0);                                                                        \
+    } else { _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(af_[i]), "v"(bf_[i])); }
+
+    // step 0 has landed once only step 1's six DMA instructions are still in flight
+    if (steps_total > 1 && !ABL(p, 2)) __builtin_amdgcn_s_waitcnt(0x0F76);      // vmcnt(6)
+    else __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_s_barrier();
+    READ_FRAGS(a0, b0, 0, 0);
+
+    f32x4_t acc[4][4];
+    int prv_m0 = 0, prv_n0 = 0, prv_tile_n = 0;
+    bool have_prev = false;
+    int g = 0;                  // global k-step counter: the stage of step g is g & 1
+    int st_prev = 0;            // VMEM stores this wave issued in the previous step (they sit behind the DMA we wait for)
 
     while (true) {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        // head: 7 iterations, pieces 0..6 of the previous tile; middle: K > 512 only; tail: last k-tile, piece 7, and the DMA of
-        // the NEXT tile's first k-tile (its pointers are computed here, after this tile's last use of `cur`)
-#pragma unroll
-        for (int u = 0; u < 7; ++u) ITER(u, ISSUE_TILE(cur, u + 1, g + 1))
-        for (int kt = 7; kt < KT - 1; ++kt) ITER(-1, ISSUE_TILE(cur, kt + 1, g + 1))
-        const int cur_m0 = cur.m0, cur_n0 = cur.n0, cur_tile_n = cur.tile_n;
-        if (has_next) tile_setup<MODE>(p, vb + G, wid, lane, cur);
-        ITER(7, if (has_next) ISSUE_TILE(cur, 0, g + 1))
-        // tile boundary: everyone is done with the stages' last reads and with reading the previous ct -> overwrite ct
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int kt = 0; kt < KT; ++kt) {
+            const int st = g & 1;
+            // a0/b0 were requested 16 MFMAs ago: retiring them HERE (a wait the compiler's scoreboard sees) keeps it from placing
+            // an lgkmcnt(0) behind the a1/b1 reads below, which would serialise those reads with the first MFMA half
+            __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0)
+            READ_FRAGS(a1, b1, st, 1);
+            MFMA_HALF(a0, b0);
+            // step g+1 (issued after the previous barrier) has landed once at most the store of the previous step is in flight.
+            // A ragged tile may skip a whole store instruction (all lanes predicated off): then st_prev = 0 -- under-counting
+            // only makes the wait conservative, over-counting would let the DMA we need slip.
+            // (waits as builtins, not inline asm: the compiler's own waitcnt pass must SEE them, or it assumes the LDS-DMA may still
+            //  be in flight and drains vmcnt(0) in front of later ds_reads)
+            if (st_prev) __builtin_amdgcn_s_waitcnt(0x0F71); else __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(1) / vmcnt(0)
+            __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): my reads of stage st are complete
+            __builtin_amdgcn_s_barrier();                           // everybody's are: stage st is free, step g+1 is visible
+            __builtin_amdgcn_sched_barrier(0);
+            // one 8 KiB piece of the previous tile's output goes from ct to HBM inside this tile's MFMA stream: read it BEFORE
+            // the DMA issue (nothing but the previous store is in flight here), store it after the MFMAs
+            const bool piece = kt < npieces && have_prev && !ABL(p, 1);
+            uint4 pv = make_uint4(0, 0, 0, 0);
+            if (piece) pv = read_piece<MODE>(p, ct, kt, t);
+            __builtin_amdgcn_sched_barrier(0);
+            LOAD_NEXT(st);                                          // step g+2
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < steps_total) READ_FRAGS(a0, b0, st ^ 1, 0);
+            MFMA_HALF(a1, b1);
+            st_prev = 0;
+            if (piece) {
+                __builtin_amdgcn_s_waitcnt(0xC07F);                 // the raw ds_read of pv (and, long done, a0/b0)
+                __builtin_amdgcn_sched_barrier(0);
+                write_piece<MODE>(p, pv, kt, t, prv_m0, prv_n0, prv_tile_n);
+                st_prev = (prv_m0 + tile_rows <= p.M) ? 1 : 0;
+            }
+            ++g;
+        }
+        // tile boundary: everyone is done reading the previous ct -> overwrite it with this tile's output
+        int tile_m, tile_n;
+        xcd_grouped_tile(vb, p.tiles_m, p.tiles_n, 8, tile_m, tile_n);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
-        if (!(p.debug & 16)) acc_to_ct<MODE>(p, acc, ct, wave_m, wave_n, fr, fg);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!ABL(p, 16)) acc_to_ct<MODE>(p, acc, ct, wave_m, wave_n, fr, fg);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
-        prv_m0 = cur_m0; prv_n0 = cur_n0; prv_tile_n = cur_tile_n; have_prev = true;
+        prv_m0 = tile_m * tile_rows; prv_n0 = tile_n * BNB; prv_tile_n = tile_n; have_prev = true;
         vb += G;
         if (vb >= total) break;
-        has_next = vb + G < total;
     }
     // drain the last tile
-    if (!(p.debug & 1))
+    if (!ABL(p, 1))
         for (int q = 0; q < npieces; ++q) store_piece<MODE>(p, ct, q, t, prv_m0, prv_n0, prv_tile_n);
 }
 

@@ -35,7 +35,10 @@ extern int g_mm_debug;
 int mm_gemm_launch(GemmArgs a, hipStream_t stream);
 bool mm_gemm_big_eligible(const GemmArgs& a);      // gemm_big.hip: 256x128 tile, 3-stage counted-vmcnt pipeline
 int mm_gemm_big_launch(GemmArgs a, hipStream_t stream);
-bool mm_gemm_pers_eligible(const GemmArgs& a);     // gemm_pers.hip: persistent 256x128, stores overlapped with the next tile
+bool mm_gemm_pers_eligible(const GemmArgs& a);
+bool mm_gemm_cfg2_eligible(const GemmArgs& a);     // gemm_cfg.hip: persistent 128 tokens x 256 columns, guidance logits
+int mm_gemm_cfg2_launch(GemmArgs a, hipStream_t stream);
+// gemm_pers.hip: persistent 256x128, stores overlapped with the next tile
 int mm_gemm_pers_launch(GemmArgs a, hipStream_t stream);
 
 // error plumbing (thread-local message, never throws across the ABI)

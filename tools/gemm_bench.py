@@ -23,10 +23,14 @@ def timeit(fn, iters=20):
 
 def main():
     dev = 'cuda'
-    flags = [int(f) for f in (sys.argv[1:] or ['0', '4096', '8'])]
+    args = sys.argv[1:]
+    pad = 0
+    if args and args[0].startswith('pad'):      # operand row stride = K + pad elements (de-aligns the power-of-two row pitch)
+        pad = int(args[0][3:]); args = args[1:]
+    flags = [int(f) for f in (args or ['0', '4096', '8'])]
     for name, M, N, K in SHAPES:
-        x = torch.randn(M, K, device=dev).bfloat16()
-        w = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+        x = torch.randn(M, K + pad, device=dev).bfloat16()[:, :K]
+        w = (torch.randn(N, K + pad, device=dev) * 0.05).bfloat16()[:, :K]
         out_bf = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         line = f'{name:7s} M={M:6d} N={N:6d} K={K:5d}'
         for fl in flags:
