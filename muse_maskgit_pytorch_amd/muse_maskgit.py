@@ -288,9 +288,19 @@ class Transformer(nn.Module):
             return scaled, emb_c.float().reshape(b, n, self.dim)
         return scaled
 
-    def forward_with_neg_prompt(self, text_embed: torch.Tensor, neg_text_embed: torch.Tensor, cond_scale=3., return_embed=False, **kwargs):
-        # the reference implementation of this method cannot run (mmp.py:261-277 uses undefined names)
-        raise NotImplementedError('forward_with_neg_prompt is broken in the reference (undefined *args / scaled_logits); no parity target')
+    def forward_with_neg_prompt(self, x, text_embed: torch.Tensor, neg_text_embed: torch.Tensor, cond_scale=3., return_embed=False, **kwargs):
+        """EXTENSION, no reference parity possible: mmp.py:261-277 cannot run (undefined `*args` / `scaled_logits`, and generate
+        passes `neg_text_embeds` where the signature says `neg_text_embed`, mmp.py:544).  This is its evident intent: guidance
+        away from the negative prompt, neg + (pos - neg) * cond_scale, returning the POSITIVE pass's embed; both passes run with
+        their text attended (cond_drop_prob 0) and share the fused to_logits + combine GEMM.  `x` (the token ids) is an added
+        first argument -- the broken original never received them."""
+        b, n = x.shape
+        emb_p = self.forward(x, _embed_only=True, cond_drop_prob=0., text_embeds=text_embed, **kwargs)
+        emb_n = self.forward(x, _embed_only=True, cond_drop_prob=0., text_embeds=neg_text_embed, **kwargs)
+        scaled = ops.gemm_cfg_logits(emb_p, emb_n, self._model().packed['wl'], cond_scale).reshape(b, n, self.dim_out)
+        if return_embed:
+            return scaled, emb_p.float().reshape(b, n, self.dim)
+        return scaled
 
     @torch.no_grad()
     def forward(self, x, return_embed=False, return_logits=False, labels=None, ignore_index=0, self_cond_embed=None,
@@ -343,8 +353,11 @@ class SelfCritic(nn.Module):
         _, embeds = self.net.forward_with_cond_scale(x, *args, return_embed=True, **kwargs)
         return self._pred(embeds)
 
+    @torch.no_grad()
     def forward_with_neg_prompt(self, x, *args, **kwargs):
-        raise NotImplementedError('forward_with_neg_prompt is broken in the reference (mmp.py:261-277)')
+        """EXTENSION (see Transformer.forward_with_neg_prompt): the critic head on the negative-prompt-guided generator embed."""
+        _, embeds = self.net.forward_with_neg_prompt(x, *args, return_embed=True, **kwargs)
+        return self._pred(embeds)
 
     @torch.no_grad()
     def forward(self, x, *args, labels=None, **kwargs):
@@ -424,22 +437,22 @@ class MaskGit(nn.Module):
                  force_not_use_token_critic=False, timesteps=18, cond_scale=3, critic_noise_scale=1,
                  *, text_embeds: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None, noise_kind: str = 'philox',
                  seed: Optional[int] = None, row_offset: int = 0, return_ids: bool = False, trace: Optional[dict] = None,
-                 critic_noise: Optional[torch.Tensor] = None):
+                 critic_noise: Optional[torch.Tensor] = None, neg_text_embeds: Optional[torch.Tensor] = None):
         """mmp.py:491-621.  Keyword-only extras (not in the reference): `text_embeds` bypasses the T5 call,
         `noise` (+ `noise_kind` 'gumbel' | 'uniform') injects the per-step noise tensor [T,B,n,V] for parity runs,
         `seed` / `row_offset` key the on-device Philox stream (row_offset = global index of this shard's first
         sample, so sharded runs reproduce the unsharded ids), `trace` receives per-step states, `critic_noise` [T,B,n]
-        injects the U(0,1) draws of the token-critic score annealing (mmp.py:601)."""
+        injects the U(0,1) draws of the token-critic score annealing (mmp.py:601).  `negative_texts` (or `neg_text_embeds`) is an
+        EXTENSION: the reference's negative-prompt path cannot run (see Transformer.forward_with_neg_prompt)."""
         tr = self.transformer
         use_token_critic = exists(self.token_critic) and not force_not_use_token_critic
-        if exists(negative_texts):
-            raise NotImplementedError('negative prompting cannot run in the reference either (mmp.py:261-277, 544: undefined names '
-                                      'and a keyword mismatch); there is no behaviour to be compatible with')
-        if use_token_critic or can_remask_prev_masked or self.self_cond or cond_scale == 1:
+        if exists(negative_texts) or exists(neg_text_embeds):
+            assert exists(neg_text_embeds) or len(texts) == len(negative_texts)       # mmp.py:541
+        if exists(negative_texts) or exists(neg_text_embeds) or use_token_critic or can_remask_prev_masked or self.self_cond or cond_scale == 1:
             # decode variants that need logits / scores at EVERY position: stepwise loop over the same C-ABI operators
             return self._generate_stepwise(texts, cond_images, fmap_size, temperature, topk_filter_thres, can_remask_prev_masked,
                                            use_token_critic, timesteps, cond_scale, critic_noise_scale, text_embeds, noise, noise_kind,
-                                           seed, row_offset, return_ids, trace, critic_noise)
+                                           seed, row_offset, return_ids, trace, critic_noise, negative_texts, neg_text_embeds)
         if exists(fmap_size):
             fmap = fmap_size
         else:
@@ -495,7 +508,8 @@ class MaskGit(nn.Module):
         return self.vae.decode_from_ids(ids)                                   # mmp.py:620
 
     def _generate_stepwise(self, texts, cond_images, fmap_size, temperature, thres, can_remask, use_critic, timesteps, cond_scale,
-                           critic_noise_scale, text_embeds, noise, noise_kind, seed, row_offset, return_ids, trace, critic_noise=None):
+                           critic_noise_scale, text_embeds, noise, noise_kind, seed, row_offset, return_ids, trace, critic_noise=None,
+                           negative_texts=None, neg_text_embeds=None):
         """mmp.py:556-609 one step at a time through the public operators (general transformer forward over all positions):
         token critic / self critic scores, self-conditioning, can_remask_prev_masked, cond_scale == 1."""
         tr = self.transformer
@@ -506,6 +520,9 @@ class MaskGit(nn.Module):
             text_embeds = tr.encode_text(texts)
         te = text_embeds.to(device=dev, dtype=torch.float32).contiguous()
         B = te.shape[0]
+        if exists(negative_texts) and not exists(neg_text_embeds):
+            neg_text_embeds = tr.encode_text(negative_texts)                                         # mmp.py:543
+        nte = neg_text_embeds.to(device=dev, dtype=torch.float32).contiguous() if exists(neg_text_embeds) else None
         cond_ids = None
         if self.resize_image_for_cond_image:
             assert exists(cond_images), 'conditioning image must be passed in to generate for super res maskgit'
@@ -528,15 +545,22 @@ class MaskGit(nn.Module):
         for step in range(timesteps):
             ops.mask_step(scores, ids, counts[step], self.mask_id, want_rows=False)                  # mmp.py:558-563
             is_mask = ids == self.mask_id
-            logits, embed = tr.forward_with_cond_scale(ids, text_embeds=te, self_cond_embed=self_cond_embed,
-                                                       conditioning_token_ids=cond_ids, cond_scale=cond_scale, return_embed=True)
+            if exists(nte):
+                logits, embed = tr.forward_with_neg_prompt(ids, te, nte, cond_scale=cond_scale, return_embed=True, self_cond_embed=self_cond_embed,
+                                                           conditioning_token_ids=cond_ids)
+            else:
+                logits, embed = tr.forward_with_cond_scale(ids, text_embeds=te, self_cond_embed=self_cond_embed,
+                                                           conditioning_token_ids=cond_ids, cond_scale=cond_scale, return_embed=True)
             self_cond_embed = embed if self.self_cond else None                                      # mmp.py:574
             pred, conf = ops.sample_rows(logits.reshape(B * n, V), k_keep, temps[step], noise_kind=kind,
                                          noise=noise[step].reshape(B * n, V) if exists(noise) else None, seed=seed,
                                          row_offset=row_offset * n, step=step)                        # mmp.py:576-580, 603-606
             ids = torch.where(is_mask, pred.reshape(B, n), ids)                                      # mmp.py:582-588
             if use_critic:
-                sc = self.token_critic.forward_with_cond_scale(ids, text_embeds=te, conditioning_token_ids=cond_ids, cond_scale=cond_scale)
+                if exists(nte):
+                    sc = self.token_critic.forward_with_neg_prompt(ids, te, nte, cond_scale=cond_scale, conditioning_token_ids=cond_ids)
+                else:
+                    sc = self.token_critic.forward_with_cond_scale(ids, text_embeds=te, conditioning_token_ids=cond_ids, cond_scale=cond_scale)
                 sc = sc.reshape(B, n).float()
                 steps_until_x0 = timesteps - 1 - step
                 u = critic_noise[step].to(dev).reshape(sc.shape) if exists(critic_noise) else torch.rand(sc.shape, device=dev)

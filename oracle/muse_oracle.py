@@ -158,6 +158,16 @@ def forward_with_cond_scale(sd, cfg, ids, text_embeds, cond_scale=3., rp=None, r
     return scaled
 
 
+def forward_with_neg_prompt(sd, cfg, ids, text_embed, neg_text_embed, cond_scale=3., rp=None, return_embed=False, **kw):
+    """SELF-DEFINED, PARITY UNPINNED: muse_maskgit_pytorch.py:261-277 cannot execute (undefined `*args` / `scaled_logits`; the
+    caller at :544 passes a keyword the signature does not have).  This restates its evident intent -- the classifier-free
+    formula of :254 with the negative prompt's pass in the place of the null pass, both passes with cond_drop_prob 0."""
+    neg = transformer_forward(sd, cfg, ids, neg_text_embed, 0., rp=rp, **kw)
+    pos, embed = transformer_forward(sd, cfg, ids, text_embed, 0., rp=rp, return_embed=True, **kw)
+    out = neg + (pos - neg) * cond_scale
+    return (out, embed) if return_embed else out
+
+
 def transformer_loss(sd, cfg, ids, text_embeds, labels, ignore_index=0, cond_drop_prob=0., rp=None, **kw):
     """muse_maskgit_pytorch.py:337-348: CE over the vocabulary with ignore_index, or BCE-with-logits when dim_out == 1."""
     logits = transformer_forward(sd, cfg, ids, text_embeds, cond_drop_prob, rp=rp, **kw)

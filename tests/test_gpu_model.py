@@ -418,3 +418,23 @@ def test_generate_variants_vs_reference_goldens(golden, name):
     agree = (got == ref).float().mean().item()
     print(f'[parity] decode variant {name}: final ids equal to the fp32 reference {agree * 100:.1f} %')
     assert agree >= 0.9
+
+
+def test_negative_prompt_extension(golden):
+    """EXTENSION without a reference parity target (mmp.py:261-277 cannot run): negative-prompt guidance neg + (pos - neg) * s.
+    Checked against the oracle's restatement of that intent, and end to end through generate."""
+    g, t = _tiny_transformer(golden)
+    te = g['text_embeds']
+    nte = torch.randn(2, 5, 512, generator=torch.Generator().manual_seed(3))
+    sd = {k: v.float() if v.is_floating_point() else v for k, v in g['sd'].items()}
+    cfg = dict(depth=g['cfg']['depth'], heads=g['cfg']['heads'])
+    got, emb = t.forward_with_neg_prompt(g['ids'].to(DEV), te.to(DEV), nte.to(DEV), cond_scale=3., return_embed=True)
+    ref, ref_emb = O.forward_with_neg_prompt(sd, cfg, g['ids'], te, nte, 3., rp=O.bf16_round, return_embed=True)
+    e = _report('negative-prompt logits', got, ref)
+    assert e.max() < 0.03 * ref.abs().max()
+    assert _report('negative-prompt embed', emb, ref_emb).max() < 0.05
+    mg = mm.MaskGit(image_size=128, transformer=t, vae=None)
+    a = mg.generate(['a', 'b'], timesteps=4, text_embeds=te, neg_text_embeds=nte, seed=3, fmap_size=8)
+    b = mg.generate(['a', 'b'], timesteps=4, text_embeds=te, neg_text_embeds=nte, seed=3, fmap_size=8)
+    c = mg.generate(['a', 'b'], timesteps=4, text_embeds=te, seed=3, fmap_size=8)
+    assert torch.equal(a, b) and a.shape == (2, 8, 8) and not torch.equal(a, c)
