@@ -122,6 +122,64 @@ int mm_ce_loss(mm_stream_t stream, const float* logits, int64_t ld, int R, int V
                float* row_loss_ws, float* out);
 int mm_bce_loss(mm_stream_t stream, const float* x, const float* y, int n, float* out);
 
+/* ---- backward operators of the transformer training step (MaskGit.forward, mmp.py:623-741, which the reference
+ *      differentiates with torch autograd).  Activation gradients are bf16, the residual-stream gradient and every parameter
+ *      gradient fp32.  Linear layers: dX = dY * W and dW = dY^T * X are mm_gemm_bf16 calls on transposed copies
+ *      (mm_transpose_bf16).  INTEGRATION.md lists the per-layer call sequence. */
+
+/* out[c][r] = in[r][c]; bf16, strides in elements (multiples of 8). */
+int mm_transpose_bf16(mm_stream_t stream, const void* in, int64_t rows, int64_t cols, int64_t ld_in, void* out, int64_t ld_out);
+/* out[i] = bf16(x[i]). */
+int mm_f32_to_bf16(mm_stream_t stream, const float* x, void* out, int64_t count);
+/* out[c] = sum_p part[p][c] in index order (deterministic reduction of per-workgroup partials). */
+int mm_colsum_f32(mm_stream_t stream, const float* part, int nparts, int D, float* out);
+
+/* LayerNorm (mmp.py:63-70) backward.  x fp32 [.][ldx] (the forward input), dy bf16 [rows][lddy], gamma fp32 [D]; row_index
+ * (optional int32 [rows]): dy row r belongs to x row row_index[r] (the forward normalised a gathered subset) and dx row
+ * row_index[r] receives its gradient.  dx fp32: accumulate != 0 adds into it (residual stream), else overwrites those rows.
+ * dgamma fp32 [D] is overwritten; ws: mm_ln_bwd_workspace_floats(rows, D) floats of scratch. */
+int64_t mm_ln_bwd_workspace_floats(int rows, int D);
+int mm_layernorm_bwd(mm_stream_t stream, const float* x, int64_t ldx, const void* dy, int64_t lddy, const float* gamma,
+                     const int32_t* row_index, int rows, int D, float* dx, int64_t lddx, int accumulate, float* dgamma, float* ws);
+
+/* Backward of mm_geglu_ln (GEGLU mmp.py:72-77 + the FeedForward's inner LayerNorm mmp.py:86): h bf16 [rows][ldh] = [x | gate]
+ * (each Fp wide, F valid), dz bf16 [rows][lddz] gradient of the normalised output, gamma fp32 [Fp] (padded); dh bf16
+ * [rows][lddh] = gradient w.r.t. h (padding columns zero), dgamma fp32 [Fp]; ws: mm_ln_bwd_workspace_floats(rows, Fp). */
+int mm_geglu_ln_bwd(mm_stream_t stream, const void* h, int64_t ldh, const void* dz, int64_t lddz, const float* gamma, int rows,
+                    int F, int Fp, void* dh, int64_t lddh, float* dgamma, float* ws);
+
+/* d(mean cross-entropy over R rows)/d(logits) (mmp.py:343): dl bf16 [R][ldd] = (softmax(logits[r]) - onehot(labels[r])) * scale,
+ * scale = 1 / (number of rows in the mean); every row must carry a valid label (gather the non-ignored rows first). */
+int mm_ce_bwd(mm_stream_t stream, const float* logits, int64_t ld, int R, int V, const int64_t* labels, float scale, void* dl,
+              int64_t ldd);
+
+/* Embedding backward (mmp.py:322-323): dx fp32 [B*n][D]; dpos fp32 [n][D] is overwritten, dtoken fp32 [rows of the table][D]
+ * must be zeroed by the caller and is accumulated with fp32 atomics (the one non-deterministic sum of the backward pass). */
+int mm_embed_bwd(mm_stream_t stream, const int64_t* ids, int B, int n, int D, const float* dx, float* dtoken, float* dpos);
+/* dst[row_index[r]][:] = src[r][:] for r < R; bf16, D % 8 == 0 (gradient of a row gather; dst zeroed by the caller). */
+int mm_scatter_rows_bf16(mm_stream_t stream, const void* src, const int32_t* row_index, int R, int D, void* dst);
+
+/* Backward of mm_attend in its Muse form (normalize = 1, null key/value, scale 8; mmp.py:137-162, attend.py:109-140).
+ * q/k/v: the forward inputs (raw projections), o: the forward output, dout: its gradient (all bf16, strided like mm_attend).
+ * Outputs: dqn / dkn = gradients w.r.t. the NORMALISED, scaled q / k (feed mm_qk_norm_bwd), dv; dnk / dnv fp32 [B*H][64] =
+ * gradients of the normalised null key / the null value per (batch, head).  nq in {64, 128, 256}. */
+int mm_attention_bwd(mm_stream_t stream, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const void* k, int64_t k_sb,
+                     int64_t k_sh, int64_t k_sn, const void* v, int64_t v_sb, int64_t v_sh, int64_t v_sn, const void* o,
+                     int64_t o_sb, int64_t o_sh, int64_t o_sn, const void* dout, int64_t do_sb, int64_t do_sh, int64_t do_sn,
+                     void* dqn, int64_t dq_sb, int64_t dq_sh, int64_t dq_sn, void* dkn, int64_t dk_sb, int64_t dk_sh, int64_t dk_sn,
+                     void* dv, int64_t dv_sb, int64_t dv_sh, int64_t dv_sn, float* dnk, float* dnv, int B, int H, int nq, int nk,
+                     const uint8_t* key_mask, int64_t km_sb, const float* q_scale, const float* k_scale, const float* null_k,
+                     const float* null_v, float scale);
+
+/* y = l2norm(x) * scale per head of 64 (mmp.py:151-153) backward: dx = (g - xh (xh . g)) / |x|, g = dy * scale; dscale partials.
+ * rows x heads_per_row vectors of 64.  x: bf16 [rows][ldx] (head hh at column hh*64), or x_f32 fp32 [H][64] broadcast (vector i
+ * uses row i % H: the null key).  dy: bf16 [rows][lddy] or dy_f32 fp32 [rows*heads_per_row][64].  dx likewise (bf16 / fp32).
+ * dscale_part fp32 [mm_qk_norm_bwd_blocks(rows*heads_per_row)][64]: reduce with mm_colsum_f32. */
+int64_t mm_qk_norm_bwd_blocks(int64_t nvec);
+int mm_qk_norm_bwd(mm_stream_t stream, const void* x, int64_t ldx, const float* x_f32, int H, const void* dy, int64_t lddy,
+                   const float* dy_f32, const float* scale, int64_t rows, int heads_per_row, void* dx, int64_t lddx,
+                   float* dx_f32, float* dscale_part);
+
 /* The uniforms MM_NOISE_PHILOX draws for rows [row_offset, row_offset + rows) at `step`: out fp32 [rows][V]. */
 int mm_philox_uniform(mm_stream_t stream, uint64_t seed, uint64_t row_offset, uint32_t step, int rows, int V,
                       float* out);

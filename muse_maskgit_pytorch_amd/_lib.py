@@ -67,6 +67,18 @@ SIGNATURES = {
                                c_u32, c_vp, c_vp, c_vp, c_vp]),
     'mm_ce_loss': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_i64, c_vp, c_vp]),
     'mm_bce_loss': (c_int, [c_vp, c_vp, c_vp, c_int, c_vp]),
+    'mm_transpose_bf16': (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64]),
+    'mm_f32_to_bf16': (c_int, [c_vp, c_vp, c_vp, c_i64]),
+    'mm_colsum_f32': (c_int, [c_vp, c_vp, c_int, c_int, c_vp]),
+    'mm_ln_bwd_workspace_floats': (c_i64, [c_int, c_int]),
+    'mm_layernorm_bwd': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_vp, c_i64, c_int, c_vp, c_vp]),
+    'mm_geglu_ln_bwd': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp]),
+    'mm_ce_bwd': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_f32, c_vp, c_i64]),
+    'mm_embed_bwd': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    'mm_scatter_rows_bf16': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
+    'mm_attention_bwd': (c_int, [c_vp] + [c_vp, c_i64, c_i64, c_i64] * 8 + [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32]),
+    'mm_qk_norm_bwd_blocks': (c_i64, [c_i64]),
+    'mm_qk_norm_bwd': (c_int, [c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_vp]),
     'mm_philox_uniform': (c_int, [c_vp, c_u64, c_u64, c_u32, c_int, c_int, c_vp]),
     'mm_conv2d_nhwc': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int] + [c_int] * 12 + [c_vp, c_int, c_vp, c_vp, c_int]),
     'mm_glu_nhwc': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp]),

@@ -184,6 +184,90 @@ int mm_bce_loss(mm_stream_t stream, const float* x, const float* y, int n, float
     return k_bce_loss((hipStream_t)stream, x, y, n, out);
 }
 
+int mm_transpose_bf16(mm_stream_t stream, const void* in, int64_t rows, int64_t cols, int64_t ld_in, void* out, int64_t ld_out) {
+    if (rows == 0 || cols == 0) return MM_OK;
+    CHK_PTR(in, "in"); CHK_PTR(out, "out"); CHK_ALIGN16(in, "in"); CHK_ALIGN16(out, "out");
+    return k_transpose_bf16((hipStream_t)stream, (const bf16_t*)in, rows, cols, ld_in, (bf16_t*)out, ld_out);
+}
+
+int mm_f32_to_bf16(mm_stream_t stream, const float* x, void* out, int64_t count) {
+    if (count == 0) return MM_OK;
+    CHK_PTR(x, "x"); CHK_PTR(out, "out");
+    return k_f32_to_bf16((hipStream_t)stream, x, (bf16_t*)out, count);
+}
+
+int mm_colsum_f32(mm_stream_t stream, const float* part, int nparts, int D, float* out) {
+    CHK_PTR(part, "part"); CHK_PTR(out, "out");
+    return k_colsum((hipStream_t)stream, part, nparts, D, out);
+}
+
+int64_t mm_ln_bwd_workspace_floats(int rows, int D) { return k_ln_bwd_workspace_floats(rows, D); }
+
+int mm_layernorm_bwd(mm_stream_t stream, const float* x, int64_t ldx, const void* dy, int64_t lddy, const float* gamma,
+                     const int32_t* row_index, int rows, int D, float* dx, int64_t lddx, int accumulate, float* dgamma, float* ws) {
+    if (rows == 0) return MM_OK;
+    CHK_PTR(x, "x"); CHK_PTR(dy, "dy"); CHK_PTR(gamma, "gamma"); CHK_PTR(dx, "dx"); CHK_PTR(dgamma, "dgamma"); CHK_PTR(ws, "ws");
+    CHK_ALIGN16(x, "x"); CHK_ALIGN16(dx, "dx");
+    return k_layernorm_bwd((hipStream_t)stream, x, ldx, (const bf16_t*)dy, lddy, gamma, row_index, rows, D, dx, lddx, accumulate, dgamma, ws);
+}
+
+int mm_geglu_ln_bwd(mm_stream_t stream, const void* h, int64_t ldh, const void* dz, int64_t lddz, const float* gamma, int rows,
+                    int F, int Fp, void* dh, int64_t lddh, float* dgamma, float* ws) {
+    if (rows == 0) return MM_OK;
+    CHK_PTR(h, "h"); CHK_PTR(dz, "dz"); CHK_PTR(gamma, "gamma"); CHK_PTR(dh, "dh"); CHK_PTR(dgamma, "dgamma"); CHK_PTR(ws, "ws");
+    CHK_ALIGN16(h, "h"); CHK_ALIGN16(dz, "dz"); CHK_ALIGN16(dh, "dh");
+    return k_geglu_ln_bwd((hipStream_t)stream, (const bf16_t*)h, ldh, (const bf16_t*)dz, lddz, gamma, rows, F, Fp, (bf16_t*)dh, lddh, dgamma, ws);
+}
+
+int mm_ce_bwd(mm_stream_t stream, const float* logits, int64_t ld, int R, int V, const int64_t* labels, float scale, void* dl,
+              int64_t ldd) {
+    if (R == 0) return MM_OK;
+    CHK_PTR(logits, "logits"); CHK_PTR(labels, "labels"); CHK_PTR(dl, "dl"); CHK_ALIGN16(logits, "logits");
+    return k_ce_bwd((hipStream_t)stream, logits, ld, R, V, labels, scale, (bf16_t*)dl, ldd);
+}
+
+int mm_embed_bwd(mm_stream_t stream, const int64_t* ids, int B, int n, int D, const float* dx, float* dtoken, float* dpos) {
+    if (B == 0) return MM_OK;
+    CHK_PTR(ids, "ids"); CHK_PTR(dx, "dx"); CHK_PTR(dtoken, "dtoken"); CHK_PTR(dpos, "dpos");
+    return k_embed_bwd((hipStream_t)stream, ids, B, n, D, dx, dtoken, dpos);
+}
+
+int mm_scatter_rows_bf16(mm_stream_t stream, const void* src, const int32_t* row_index, int R, int D, void* dst) {
+    if (R == 0) return MM_OK;
+    CHK_PTR(src, "src"); CHK_PTR(row_index, "row_index"); CHK_PTR(dst, "dst"); CHK_ALIGN16(src, "src"); CHK_ALIGN16(dst, "dst");
+    return k_scatter_rows_bf16((hipStream_t)stream, (const bf16_t*)src, row_index, R, D, (bf16_t*)dst);
+}
+
+int mm_attention_bwd(mm_stream_t stream, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const void* k, int64_t k_sb,
+                     int64_t k_sh, int64_t k_sn, const void* v, int64_t v_sb, int64_t v_sh, int64_t v_sn, const void* o,
+                     int64_t o_sb, int64_t o_sh, int64_t o_sn, const void* dout, int64_t do_sb, int64_t do_sh, int64_t do_sn,
+                     void* dqn, int64_t dq_sb, int64_t dq_sh, int64_t dq_sn, void* dkn, int64_t dk_sb, int64_t dk_sh, int64_t dk_sn,
+                     void* dv, int64_t dv_sb, int64_t dv_sh, int64_t dv_sn, float* dnk, float* dnv, int B, int H, int nq, int nk,
+                     const uint8_t* key_mask, int64_t km_sb, const float* q_scale, const float* k_scale, const float* null_k,
+                     const float* null_v, float scale) {
+    CHK_PTR(q, "q"); CHK_PTR(o, "o"); CHK_PTR(dout, "dout"); CHK_PTR(dqn, "dqn"); CHK_PTR(dnk, "dnk"); CHK_PTR(dnv, "dnv");
+    if (nk > 0) { CHK_PTR(k, "k"); CHK_PTR(v, "v"); CHK_PTR(dkn, "dkn"); CHK_PTR(dv, "dv"); }
+    CHK_ALIGN16(q, "q"); CHK_ALIGN16(k, "k"); CHK_ALIGN16(v, "v"); CHK_ALIGN16(o, "o"); CHK_ALIGN16(dout, "dout");
+    return k_attention_bwd((hipStream_t)stream, (const bf16_t*)q, q_sb, q_sh, q_sn, (const bf16_t*)k, k_sb, k_sh, k_sn, (const bf16_t*)v, v_sb,
+                           v_sh, v_sn, (const bf16_t*)o, o_sb, o_sh, o_sn, (const bf16_t*)dout, do_sb, do_sh, do_sn, (bf16_t*)dqn, dq_sb, dq_sh,
+                           dq_sn, (bf16_t*)dkn, dk_sb, dk_sh, dk_sn, (bf16_t*)dv, dv_sb, dv_sh, dv_sn, dnk, dnv, B, H, nq, nk, key_mask, km_sb,
+                           q_scale, k_scale, null_k, null_v, scale);
+}
+
+int64_t mm_qk_norm_bwd_blocks(int64_t nvec) { return k_qk_norm_bwd_blocks(nvec); }
+
+int mm_qk_norm_bwd(mm_stream_t stream, const void* x, int64_t ldx, const float* x_f32, int H, const void* dy, int64_t lddy,
+                   const float* dy_f32, const float* scale, int64_t rows, int heads_per_row, void* dx, int64_t lddx,
+                   float* dx_f32, float* dscale_part) {
+    if (rows == 0) return MM_OK;
+    if (!x && !x_f32) return mm_set_error(MM_ERR_SHAPE, "qk_norm_bwd: x or x_f32 is required");
+    if (!dy && !dy_f32) return mm_set_error(MM_ERR_SHAPE, "qk_norm_bwd: dy or dy_f32 is required");
+    if (!dx && !dx_f32) return mm_set_error(MM_ERR_SHAPE, "qk_norm_bwd: dx or dx_f32 is required");
+    CHK_PTR(scale, "scale"); CHK_PTR(dscale_part, "dscale_part");
+    return k_qk_norm_bwd((hipStream_t)stream, (const bf16_t*)x, ldx, x_f32, H, (const bf16_t*)dy, lddy, dy_f32, scale, rows, heads_per_row,
+                         (bf16_t*)dx, lddx, dx_f32, dscale_part);
+}
+
 int mm_philox_uniform(mm_stream_t stream, uint64_t seed, uint64_t row_offset, uint32_t step, int rows, int V, float* out) {
     if (rows == 0) return MM_OK;
     CHK_PTR(out, "out"); CHK_ALIGN16(out, "out");

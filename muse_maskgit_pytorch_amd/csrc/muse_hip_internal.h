@@ -74,6 +74,27 @@ struct AttnArgs {
 };
 int k_attention(hipStream_t s, const AttnArgs& a);
 
+// train.hip / attention_bwd.hip: backward operators
+int k_transpose_bf16(hipStream_t s, const bf16_t* in, long rows, long cols, long ldi, bf16_t* out, long ldo);
+int k_colsum(hipStream_t s, const float* part, int nparts, int D, float* out);
+long k_ln_bwd_workspace_floats(int rows, int D);
+int k_layernorm_bwd(hipStream_t s, const float* x, long ldx, const bf16_t* dy, long lddy, const float* gamma, const int32_t* row_index,
+                    int rows, int D, float* dx, long lddx, int accumulate, float* dgamma, float* ws);
+int k_geglu_ln_bwd(hipStream_t s, const bf16_t* h, long ldh, const bf16_t* dz, long lddz, const float* gamma, int rows, int F, int Fp,
+                   bf16_t* dh, long lddh, float* dgamma, float* ws);
+int k_ce_bwd(hipStream_t s, const float* logits, long ld, int R, int V, const int64_t* labels, float scale, bf16_t* dl, long ldd);
+int k_embed_bwd(hipStream_t s, const int64_t* ids, int B, int n, int D, const float* dx, float* dtoken, float* dpos);
+int k_scatter_rows_bf16(hipStream_t s, const bf16_t* src, const int32_t* row_index, int R, int D, bf16_t* dst);
+int k_attention_bwd(hipStream_t s, const bf16_t* q, long q_sb, long q_sh, long q_sn, const bf16_t* k, long k_sb, long k_sh, long k_sn,
+                    const bf16_t* v, long v_sb, long v_sh, long v_sn, const bf16_t* o, long o_sb, long o_sh, long o_sn,
+                    const bf16_t* dout, long do_sb, long do_sh, long do_sn, bf16_t* dqn, long dq_sb, long dq_sh, long dq_sn,
+                    bf16_t* dkn, long dk_sb, long dk_sh, long dk_sn, bf16_t* dv, long dv_sb, long dv_sh, long dv_sn, float* dnk, float* dnv,
+                    int B, int H, int nq, int nk, const uint8_t* key_mask, long km_sb, const float* q_scale, const float* k_scale,
+                    const float* null_k, const float* null_v, float scale);
+long k_qk_norm_bwd_blocks(long nvec);
+int k_qk_norm_bwd(hipStream_t s, const bf16_t* x, long ldx, const float* x_f32, int H, const bf16_t* dy, long lddy, const float* dy_f32,
+                  const float* scale, long rows, int heads_per_row, bf16_t* dx, long lddx, float* dx_f32, float* dscale_part);
+
 int k_mask_step(hipStream_t s, float* scores, int64_t* ids, int B, int n, int k, int64_t mask_id, int32_t* rows_out);
 struct SampleArgs {
     const float* logits; long ld;                // [R][V] CFG-combined logits of the gathered rows

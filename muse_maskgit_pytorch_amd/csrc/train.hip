@@ -1,0 +1,432 @@
+// Backward kernels of the transformer training step (muse_maskgit_pytorch.py:623-741 runs `loss.backward()` through autograd; here
+// every operator of Transformer.forward has a hand-written gradient kernel), gfx950.
+//
+//   transpose_bf16      : [R][C] -> [C][R]; the NT MFMA GEMM (gemm*.hip) then serves dX = dY * W and dW = dY^T * X
+//   layernorm_bwd       : LayerNorm(x; gamma) with fp32 x (mmp.py:63-70); dx is ACCUMULATED into the residual-stream gradient
+//   geglu_ln_bwd        : gradient of LayerNorm_inner(gate * gelu(x)) w.r.t. the w1 output h = [x | gate] (mmp.py:72-77, 86)
+//   ce_bwd              : d(mean cross-entropy)/d(logits) in bf16 (mmp.py:343)
+//   embed_bwd           : token / position embedding gradients (mmp.py:322-323)
+//   colsum partial sums : gamma gradients are reduced deterministically (per-workgroup partials, then one pass over them)
+// All row kernels keep a row in registers: one wave per row, a lane owns fixed columns, so the gamma partial of a workgroup is a
+// plain per-lane accumulation over its rows.
+#include <math.h>
+
+#include "common.h"
+#include "muse_hip_internal.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ transpose
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, long rows, long cols, long ldi,
+                                                             bf16_t* __restrict__ out, long ldo) {
+    __shared__ bf16_t tile[64][72];          // row pitch 144 B
+    const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = t + i * 256;         // 512 chunks of 8 elements
+        const int r = idx >> 3, c = (idx & 7) * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r0 + r < rows) {
+            if (c0 + c + 8 <= cols) v = *reinterpret_cast<const uint4*>(in + (r0 + r) * ldi + c0 + c);
+            else {
+                bf16_t tmp[8];
+                for (int j = 0; j < 8; ++j) tmp[j] = (c0 + c + j < cols) ? in[(r0 + r) * ldi + c0 + c + j] : (bf16_t)0;
+                v = *reinterpret_cast<const uint4*>(tmp);
+            }
+        }
+        *reinterpret_cast<uint4*>(&tile[r][c]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = t + i * 256;
+        const int c = idx >> 3, r = (idx & 7) * 8;       // output row c0 + c, output columns r0 + r .. +7
+        if (c0 + c >= cols) continue;
+        bf16_t tmp[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tmp[j] = tile[r + j][c];
+        bf16_t* op = out + (c0 + c) * ldo + r0 + r;
+        if (r0 + r + 8 <= rows) *reinterpret_cast<uint4*>(op) = *reinterpret_cast<const uint4*>(tmp);
+        else
+            for (int j = 0; j < 8; ++j)
+                if (r0 + r + j < rows) op[j] = tmp[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm backward (fp32 x)
+// y = (x - mean) * rstd * gamma + beta.  With xhat = (x - mean) * rstd and g = dy * gamma:
+//   dx = rstd * (g - mean_D(g) - xhat * mean_D(g * xhat)),   dgamma = sum_rows dy * xhat      (beta is a buffer: no gradient)
+constexpr int LNB_ROWS = 16;       // rows per wave -> 64 rows per workgroup
+template <int NIT>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, long ldx, const bf16_t* __restrict__ dy, long lddy,
+                                                            const float* __restrict__ gamma, const int32_t* __restrict__ row_index,
+                                                            int rows, int D, float* __restrict__ dx, long lddx, int accumulate,
+                                                            float* __restrict__ dgamma_part) {
+    __shared__ float red[4][64 * 4 * NIT];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nvec = D >> 2;
+    float4 gm[NIT], dg[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int c = it * 64 + lane;
+        gm[it] = c < nvec ? *reinterpret_cast<const float4*>(gamma + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int row0 = (blockIdx.x * 4 + wid) * LNB_ROWS;
+    for (int rr = 0; rr < LNB_ROWS; ++rr) {
+        const int row = row0 + rr;
+        if (row >= rows) break;
+        // row_index: the forward normalised a GATHERED subset of rows (final norm before to_logits); dy row `row` belongs to x row
+        // row_index[row], and dx goes there
+        const long src = row_index ? (long)row_index[row] : (long)row;
+        const float* xr = x + src * ldx;
+        const bf16_t* dyr = dy + (long)row * lddy;
+        float4 v[NIT], gy[NIT];
+        float sum = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = it * 64 + lane;
+            v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            gy[it] = v[it];
+            if (c < nvec) {
+                v[it] = *reinterpret_cast<const float4*>(xr + c * 4);
+                const uint2 d2 = *reinterpret_cast<const uint2*>(dyr + c * 4);
+                gy[it] = make_float4(bf16lo(d2.x), bf16hi(d2.x), bf16lo(d2.y), bf16hi(d2.y));
+                sum += (v[it].x + v[it].y) + (v[it].z + v[it].w);
+            }
+        }
+        const float mean = wave_sum(sum) / (float)D;
+        float sq = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = it * 64 + lane;
+            if (c < nvec) {
+                const float a = v[it].x - mean, b = v[it].y - mean, cc = v[it].z - mean, d = v[it].w - mean;
+                sq += (a * a + b * b) + (cc * cc + d * d);
+            }
+        }
+        const float rstd = 1.f / sqrtf(wave_sum(sq) / (float)D + 1e-5f);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = it * 64 + lane;
+            if (c < nvec) {
+                // v <- xhat, gy stays dy; accumulate the two row means and the gamma partial
+                v[it].x = (v[it].x - mean) * rstd; v[it].y = (v[it].y - mean) * rstd;
+                v[it].z = (v[it].z - mean) * rstd; v[it].w = (v[it].w - mean) * rstd;
+                dg[it].x += gy[it].x * v[it].x; dg[it].y += gy[it].y * v[it].y;
+                dg[it].z += gy[it].z * v[it].z; dg[it].w += gy[it].w * v[it].w;
+                const float g0 = gy[it].x * gm[it].x, g1 = gy[it].y * gm[it].y, g2 = gy[it].z * gm[it].z, g3 = gy[it].w * gm[it].w;
+                s1 += (g0 + g1) + (g2 + g3);
+                s2 += (g0 * v[it].x + g1 * v[it].y) + (g2 * v[it].z + g3 * v[it].w);
+            }
+        }
+        const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+        float* dxr = dx + src * lddx;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = it * 64 + lane;
+            if (c < nvec) {
+                float4 o;
+                o.x = rstd * (gy[it].x * gm[it].x - c1 - v[it].x * c2);
+                o.y = rstd * (gy[it].y * gm[it].y - c1 - v[it].y * c2);
+                o.z = rstd * (gy[it].z * gm[it].z - c1 - v[it].z * c2);
+                o.w = rstd * (gy[it].w * gm[it].w - c1 - v[it].w * c2);
+                if (accumulate) {
+                    const float4 old = *reinterpret_cast<const float4*>(dxr + c * 4);
+                    o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+                }
+                *reinterpret_cast<float4*>(dxr + c * 4) = o;
+            }
+        }
+    }
+    // workgroup partial of dgamma: waves 1..3 -> LDS, wave 0 adds in fixed order and writes
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) *reinterpret_cast<float4*>(&red[wid][(it * 64 + lane) * 4]) = dg[it];
+    __syncthreads();
+    if (wid == 0) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = it * 64 + lane;
+            if (c < nvec) {
+                float4 a = *reinterpret_cast<const float4*>(&red[0][c * 4]);
+                for (int w = 1; w < 4; ++w) {
+                    const float4 b = *reinterpret_cast<const float4*>(&red[w][c * 4]);
+                    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+                }
+                *reinterpret_cast<float4*>(dgamma_part + (long)blockIdx.x * D + c * 4) = a;
+            }
+        }
+    }
+}
+
+// out[c] = sum over p of part[p][c], partials added in index order (deterministic)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int nparts, int D, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= D) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(long)p * D + c];
+    out[c] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ GEGLU + inner LayerNorm backward
+// forward (norm_act.hip geglu_ln_kernel): a = gate * gelu_erf(x) over the F valid of Fp columns, z = LN(a; gamma).
+// gelu'(x) = Phi(x) + x * phi(x)
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}
+
+template <int NIT>      // 16-byte iterations per lane: 3 (Fp <= 1536) / 6 / 12
+__global__ __launch_bounds__(256) void geglu_ln_bwd_kernel(const bf16_t* __restrict__ h, long ldh, const bf16_t* __restrict__ dz, long lddz,
+                                                           const float* __restrict__ gamma, int rows, int F, int Fp,
+                                                           bf16_t* __restrict__ dh, long lddh, float* __restrict__ dgamma_part) {
+    __shared__ float red[4][64 * 8 * NIT];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nch = Fp >> 3;
+    float dg[NIT][8];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dg[it][j] = 0.f;
+    const int row0 = (blockIdx.x * 4 + wid) * LNB_ROWS;
+    for (int rr = 0; rr < LNB_ROWS; ++rr) {
+        const int row = row0 + rr;
+        if (row >= rows) break;
+        const bf16_t* hr = h + (long)row * ldh;
+        const bf16_t* dzr = dz + (long)row * lddz;
+        float a[NIT][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = it * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[it][j] = 0.f;
+            if (c < nch) {
+                float xv[8], gv[8];
+                unpack8(*reinterpret_cast<const uint4*>(hr + c * 8), xv);
+                unpack8(*reinterpret_cast<const uint4*>(hr + Fp + c * 8), gv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float val = (c * 8 + j < F) ? gv[j] * gelu_f(xv[j]) : 0.f;
+                    a[it][j] = val;
+                    sum += val;
+                }
+            }
+        }
+        const float mean = wave_sum(sum) / (float)F;
+        float sq = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = it * 64 + lane;
+            if (c < nch) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (c * 8 + j < F) { const float d = a[it][j] - mean; sq += d * d; }
+            }
+        }
+        const float rstd = 1.f / sqrtf(wave_sum(sq) / (float)F + 1e-5f);
+        float s1 = 0.f, s2 = 0.f;
+        float g[NIT][8];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = it * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[it][j] = 0.f;
+            if (c < nch) {
+                float dv[8];
+                unpack8(*reinterpret_cast<const uint4*>(dzr + c * 8), dv);
+                const float4 g0 = *reinterpret_cast<const float4*>(gamma + c * 8), g1 = *reinterpret_cast<const float4*>(gamma + c * 8 + 4);
+                const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (c * 8 + j < F) {
+                        const float xh = (a[it][j] - mean) * rstd;
+                        a[it][j] = xh;                         // a <- xhat
+                        dg[it][j] += dv[j] * xh;
+                        const float gj = dv[j] * gg[j];
+                        g[it][j] = gj;
+                        s1 += gj;
+                        s2 += gj * xh;
+                    }
+                }
+            }
+        }
+        const float c1 = wave_sum(s1) / (float)F, c2 = wave_sum(s2) / (float)F;
+        bf16_t* dhr = dh + (long)row * lddh;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = it * 64 + lane;
+            if (c < nch) {
+                float xv[8], gv[8], ox[8], og[8];
+                unpack8(*reinterpret_cast<const uint4*>(hr + c * 8), xv);
+                unpack8(*reinterpret_cast<const uint4*>(hr + Fp + c * 8), gv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float da = 0.f;
+                    if (c * 8 + j < F) da = rstd * (g[it][j] - c1 - a[it][j] * c2);
+                    og[j] = da * gelu_f(xv[j]);                        // d gate
+                    ox[j] = da * gv[j] * gelu_grad_f(xv[j]);           // d x
+                }
+                *reinterpret_cast<uint4*>(dhr + c * 8) = pack8(ox);
+                *reinterpret_cast<uint4*>(dhr + Fp + c * 8) = pack8(og);
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[wid][(it * 64 + lane) * 8 + j] = dg[it][j];
+    __syncthreads();
+    if (wid == 0) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = it * 64 + lane;
+            if (c < nch) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float s = red[0][c * 8 + j];
+                    for (int w = 1; w < 4; ++w) s += red[w][c * 8 + j];
+                    dgamma_part[(long)blockIdx.x * Fp + c * 8 + j] = s;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ cross-entropy backward
+// loss = mean over R rows of (logsumexp(l_r) - l_r[label_r]);  dl[r][v] = (softmax(l_r)[v] - [v == label_r]) / R, written in bf16.
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, long ld, int V, const int64_t* __restrict__ labels,
+                                                     float scale, bf16_t* __restrict__ dl, long ldd) {
+    __shared__ float sm[4], ss[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float* lr = logits + (size_t)row * ld;
+    float m = -INFINITY, s = 0.f;
+    for (int i = tid * 4; i < V; i += 256 * 4) {
+        const float4 x = *reinterpret_cast<const float4*>(lr + i);
+        const float mx = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
+        if (mx > m) { s *= expf(m - mx); m = mx; }
+        s += expf(x.x - m) + expf(x.y - m) + expf(x.z - m) + expf(x.w - m);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o, 64), os = __shfl_xor(s, o, 64);
+        const float nm = fmaxf(m, om);
+        s = (nm == -INFINITY) ? 0.f : s * expf(m - nm) + os * expf(om - nm);
+        m = nm;
+    }
+    if (lane == 0) { sm[wid] = m; ss[wid] = s; }
+    __syncthreads();
+    float M = sm[0], S = ss[0];
+    for (int w = 1; w < 4; ++w) {
+        const float nm = fmaxf(M, sm[w]);
+        S = S * expf(M - nm) + ss[w] * expf(sm[w] - nm);
+        M = nm;
+    }
+    const float inv = scale / S;
+    const int lab = (int)labels[row];
+    bf16_t* dr = dl + (size_t)row * ldd;
+    for (int i = tid * 4; i < V; i += 256 * 4) {      // second sweep: the row (<= 256 KiB) is L2-resident
+        const float4 x = *reinterpret_cast<const float4*>(lr + i);
+        float p0 = expf(x.x - M) * inv, p1 = expf(x.y - M) * inv, p2 = expf(x.z - M) * inv, p3 = expf(x.w - M) * inv;
+        if (lab == i) p0 -= scale; else if (lab == i + 1) p1 -= scale; else if (lab == i + 2) p2 -= scale; else if (lab == i + 3) p3 -= scale;
+        *reinterpret_cast<uint2*>(dr + i) = make_uint2(pack_bf16x2(p0, p1), pack_bf16x2(p2, p3));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ embedding backward
+// x[b*n + p] = token_emb[ids] + pos_emb[p]  ->  dpos[p] = sum_b dx[b*n + p] (fixed order), dtoken[id] += dx (fp32 atomics: many
+// rows share the mask id, and the order of those additions is not fixed -- the only non-deterministic sum of the backward pass)
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, int B, int n, int D, const float* __restrict__ dx,
+                                                        float* __restrict__ dtoken, float* __restrict__ dpos) {
+    const int p = blockIdx.x;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float v = dx[((long)b * n + p) * D + d];
+            s += v;
+            atomicAdd(dtoken + ids[(long)b * n + p] * D + d, v);
+        }
+        dpos[(long)p * D + d] = s;
+    }
+}
+
+// bf16 rows scattered into a zero-initialised [M][D] bf16 buffer (gradient of a row gather)
+__global__ __launch_bounds__(256) void scatter_rows_bf16_kernel(const bf16_t* __restrict__ src, const int32_t* __restrict__ row_index, int R, int D,
+                                                                bf16_t* __restrict__ dst) {
+    const long total = (long)R * (D >> 3);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / (D >> 3)), c = (int)(i % (D >> 3)) * 8;
+        *reinterpret_cast<uint4*>(dst + (long)row_index[r] * D + c) = *reinterpret_cast<const uint4*>(src + (long)r * D + c);
+    }
+}
+
+}  // namespace
+
+int k_transpose_bf16(hipStream_t s, const bf16_t* in, long rows, long cols, long ldi, bf16_t* out, long ldo) {
+    if (rows <= 0 || cols <= 0) return MM_OK;
+    if ((ldi % 8) || (ldo % 8)) return mm_set_error(MM_ERR_ALIGN, "transpose: strides must be multiples of 8 elements");
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64)), dim3(256), 0, s, in, rows, cols, ldi, out, ldo);
+    return mm_check_launch("transpose_bf16_kernel");
+}
+
+int k_colsum(hipStream_t s, const float* part, int nparts, int D, float* out) {
+    if (D <= 0) return MM_OK;
+    hipLaunchKernelGGL(colsum_kernel, dim3((D + 255) / 256), dim3(256), 0, s, part, nparts, D, out);
+    return mm_check_launch("colsum_kernel");
+}
+
+long k_ln_bwd_workspace_floats(int rows, int D) { return (long)((rows + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS)) * D; }
+
+int k_layernorm_bwd(hipStream_t s, const float* x, long ldx, const bf16_t* dy, long lddy, const float* gamma, const int32_t* row_index,
+                    int rows, int D, float* dx, long lddx, int accumulate, float* dgamma, float* ws) {
+    if (rows <= 0) return MM_OK;
+    if (D % 4 || D > 2048 || (ldx % 4) || (lddy % 4) || (lddx % 4)) return mm_set_error(MM_ERR_SHAPE, "layernorm_bwd: dim multiple of 4, <= 2048; strides multiples of 4");
+    const int blocks = (rows + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS);
+    const int nit = (D / 4 + 63) / 64;
+    if (nit <= 2) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(256), 0, s, x, ldx, dy, lddy, gamma, row_index, rows, D, dx, lddx, accumulate, ws);
+    else if (nit <= 4) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(blocks), dim3(256), 0, s, x, ldx, dy, lddy, gamma, row_index, rows, D, dx, lddx, accumulate, ws);
+    else hipLaunchKernelGGL(layernorm_bwd_kernel<8>, dim3(blocks), dim3(256), 0, s, x, ldx, dy, lddy, gamma, row_index, rows, D, dx, lddx, accumulate, ws);
+    int rc = mm_check_launch("layernorm_bwd_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_kernel, dim3((D + 255) / 256), dim3(256), 0, s, ws, blocks, D, dgamma);
+    return mm_check_launch("colsum_kernel");
+}
+
+int k_geglu_ln_bwd(hipStream_t s, const bf16_t* h, long ldh, const bf16_t* dz, long lddz, const float* gamma, int rows, int F, int Fp,
+                   bf16_t* dh, long lddh, float* dgamma, float* ws) {
+    if (rows <= 0) return MM_OK;
+    if (Fp % 8 || Fp < F || Fp > 6144 || (ldh % 8) || (lddz % 8) || (lddh % 8)) return mm_set_error(MM_ERR_SHAPE, "geglu_ln_bwd: bad padded width / strides");
+    const int blocks = (rows + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS);
+    const int nit = (Fp / 8 + 63) / 64;
+    if (nit <= 3) hipLaunchKernelGGL(geglu_ln_bwd_kernel<3>, dim3(blocks), dim3(256), 0, s, h, ldh, dz, lddz, gamma, rows, F, Fp, dh, lddh, ws);
+    else if (nit <= 6) hipLaunchKernelGGL(geglu_ln_bwd_kernel<6>, dim3(blocks), dim3(256), 0, s, h, ldh, dz, lddz, gamma, rows, F, Fp, dh, lddh, ws);
+    else return mm_set_error(MM_ERR_SHAPE, "geglu_ln_bwd: padded inner width above 3072 is not built");
+    int rc = mm_check_launch("geglu_ln_bwd_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_kernel, dim3((Fp + 255) / 256), dim3(256), 0, s, ws, blocks, Fp, dgamma);
+    return mm_check_launch("colsum_kernel");
+}
+
+int k_ce_bwd(hipStream_t s, const float* logits, long ld, int R, int V, const int64_t* labels, float scale, bf16_t* dl, long ldd) {
+    if (R <= 0) return MM_OK;
+    if (V % 4 || (ld % 4) || (ldd % 4)) return mm_set_error(MM_ERR_SHAPE, "ce_bwd: V and strides must be multiples of 4");
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3(R), dim3(256), 0, s, logits, ld, V, labels, scale, dl, ldd);
+    return mm_check_launch("ce_bwd_kernel");
+}
+
+int k_embed_bwd(hipStream_t s, const int64_t* ids, int B, int n, int D, const float* dx, float* dtoken, float* dpos) {
+    if (B <= 0) return MM_OK;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(n), dim3(256), 0, s, ids, B, n, D, dx, dtoken, dpos);
+    return mm_check_launch("embed_bwd_kernel");
+}
+
+int k_scatter_rows_bf16(hipStream_t s, const bf16_t* src, const int32_t* row_index, int R, int D, bf16_t* dst) {
+    if (R <= 0) return MM_OK;
+    if (D % 8) return mm_set_error(MM_ERR_SHAPE, "scatter_rows: D must be a multiple of 8");
+    long blocks = ((long)R * (D / 8) + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(scatter_rows_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, row_index, R, D, dst);
+    return mm_check_launch("scatter_rows_bf16_kernel");
+}

@@ -317,3 +317,137 @@ def mask_counts(timesteps, seq_len):
 def step_temperatures(timesteps, temperature):
     """muse_maskgit_pytorch.py:578 + the clamp of :411."""
     return [max(temperature * (s / timesteps), 1e-10) for s in reversed(range(timesteps))]
+
+
+# ------------------------------------------------------------------------------------------------ backward operators (training)
+def transpose(x):
+    """bf16 [R,C] (row stride % 8 == 0) -> contiguous [C,Rp] view [:, :R] with Rp = R rounded up to 8."""
+    _chk_cuda(x)
+    assert x.dtype == bf16 and x.dim() == 2 and x.stride(1) == 1
+    R, C = x.shape
+    Rp = (R + 7) // 8 * 8
+    out = torch.empty(C, Rp, dtype=bf16, device=x.device)
+    if Rp != R:
+        out.zero_()
+    L.check(L.lib().mm_transpose_bf16(L.stream(), L.ptr(x), R, C, x.stride(0), L.ptr(out), Rp), 'mm_transpose_bf16')
+    return out[:, :R]
+
+
+def to_bf16(x):
+    _chk_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty(x.shape, dtype=bf16, device=x.device)
+    L.check(L.lib().mm_f32_to_bf16(L.stream(), L.ptr(x), L.ptr(out), x.numel()), 'mm_f32_to_bf16')
+    return out
+
+
+def colsum(part):
+    """fp32 [P, D] -> [D], rows added in index order."""
+    _chk_cuda(part)
+    assert part.dtype == torch.float32 and part.is_contiguous()
+    P, D = part.shape
+    out = torch.empty(D, dtype=torch.float32, device=part.device)
+    L.check(L.lib().mm_colsum_f32(L.stream(), L.ptr(part), P, D, L.ptr(out)), 'mm_colsum_f32')
+    return out
+
+
+def layernorm_bwd(x, dy, gamma, dx, accumulate=True, row_index=None):
+    """dx (fp32 [M,D], in place) += / = LayerNorm backward; returns dgamma fp32 [D]."""
+    _chk_cuda(x, dy, gamma, dx, row_index)
+    rows, D = dy.shape
+    assert x.dtype == torch.float32 and dy.dtype == bf16 and dx.dtype == torch.float32 and x.stride(1) == 1 and dy.stride(1) == 1
+    ws = torch.empty(L.lib().mm_ln_bwd_workspace_floats(rows, D), dtype=torch.float32, device=x.device)
+    dg = torch.empty(D, dtype=torch.float32, device=x.device)
+    L.check(L.lib().mm_layernorm_bwd(L.stream(), L.ptr(x), x.stride(0), L.ptr(dy), dy.stride(0), L.ptr(gamma), L.ptr(row_index), rows, D,
+                                     L.ptr(dx), dx.stride(0), int(accumulate), L.ptr(dg), L.ptr(ws)), 'mm_layernorm_bwd')
+    return dg
+
+
+def geglu_ln_bwd(h, dz, F, gamma):
+    """h bf16 [rows, 2Fp] = [x | gate], dz bf16 [rows, Fp]; returns (dh bf16 [rows, 2Fp], dgamma fp32 [F])."""
+    _chk_cuda(h, dz, gamma)
+    rows, two_fp = h.shape
+    Fp = two_fp // 2
+    gp = pad_cols(gamma.float(), Fp)
+    dh = torch.empty(rows, two_fp, dtype=bf16, device=h.device)
+    ws = torch.empty(L.lib().mm_ln_bwd_workspace_floats(rows, Fp), dtype=torch.float32, device=h.device)
+    dg = torch.empty(Fp, dtype=torch.float32, device=h.device)
+    L.check(L.lib().mm_geglu_ln_bwd(L.stream(), L.ptr(h), h.stride(0), L.ptr(dz), dz.stride(0), L.ptr(gp), rows, F, Fp, L.ptr(dh), two_fp,
+                                    L.ptr(dg), L.ptr(ws)), 'mm_geglu_ln_bwd')
+    return dh, dg[:F]
+
+
+def ce_bwd(logits, labels, scale):
+    _chk_cuda(logits, labels)
+    R, V = logits.shape
+    assert logits.dtype == torch.float32 and labels.dtype == torch.long and logits.stride(1) == 1
+    dl = torch.empty(R, V, dtype=bf16, device=logits.device)
+    L.check(L.lib().mm_ce_bwd(L.stream(), L.ptr(logits), logits.stride(0), R, V, L.ptr(labels.contiguous()), float(scale), L.ptr(dl), V), 'mm_ce_bwd')
+    return dl
+
+
+def embed_bwd(ids, dx, table_rows):
+    """ids int64 [B,n], dx fp32 [B*n, D] -> (dtoken fp32 [table_rows, D], dpos fp32 [n, D])."""
+    _chk_cuda(ids, dx)
+    B, n = ids.shape
+    D = dx.shape[1]
+    assert dx.is_contiguous() and dx.dtype == torch.float32
+    dtok = torch.zeros(table_rows, D, dtype=torch.float32, device=dx.device)
+    dpos = torch.empty(n, D, dtype=torch.float32, device=dx.device)
+    L.check(L.lib().mm_embed_bwd(L.stream(), L.ptr(ids.contiguous()), B, n, D, L.ptr(dx), L.ptr(dtok), L.ptr(dpos)), 'mm_embed_bwd')
+    return dtok, dpos
+
+
+def scatter_rows(src, row_index, M):
+    _chk_cuda(src, row_index)
+    R, D = src.shape
+    dst = torch.zeros(M, D, dtype=bf16, device=src.device)
+    L.check(L.lib().mm_scatter_rows_bf16(L.stream(), L.ptr(src.contiguous()), L.ptr(row_index), R, D, L.ptr(dst)), 'mm_scatter_rows_bf16')
+    return dst
+
+
+def attention_bwd(q, k, v, o, dout, q_scale, k_scale, null_k, null_v, key_mask=None, scale=8.0):
+    """Muse attention backward.  q/o/dout (b,h,n,64), k/v (b,h,j,64) bf16 strided views.  Returns dqn (b,n,h*64), dkn, dv (b,j,h*64)
+    bf16 -- gradients w.r.t. the normalised q / k and v -- and dnk, dnv fp32 (b*h, 64) for the null key / value."""
+    _chk_cuda(q, k, v, o, dout, key_mask)
+    b, h, n, d = q.shape
+    j = k.shape[2]
+    dev = q.device
+    dqn = torch.empty(b, n, h * 64, dtype=bf16, device=dev)
+    dkn = torch.empty(b, max(j, 1), h * 64, dtype=bf16, device=dev)
+    dv = torch.empty(b, max(j, 1), h * 64, dtype=bf16, device=dev)
+    dnk = torch.empty(b * h, 64, dtype=torch.float32, device=dev)
+    dnv = torch.empty(b * h, 64, dtype=torch.float32, device=dev)
+    km = key_mask.to(torch.uint8).contiguous() if key_mask is not None else None
+
+    def st(t):
+        return (L.ptr(t), t.stride(0), t.stride(1), t.stride(2))
+
+    def st_bnh(t, rows):
+        return (L.ptr(t), rows * h * 64, 64, h * 64)
+    L.check(L.lib().mm_attention_bwd(L.stream(), *st(q), *st(k), *st(v), *st(o), *st(dout), *st_bnh(dqn, n), *st_bnh(dkn, max(j, 1)),
+                                     *st_bnh(dv, max(j, 1)), L.ptr(dnk), L.ptr(dnv), b, h, n, j, L.ptr(km), j, L.ptr(q_scale), L.ptr(k_scale),
+                                     L.ptr(null_k), L.ptr(null_v), float(scale)), 'mm_attention_bwd')
+    return dqn, dkn[:, :j], dv[:, :j], dnk, dnv
+
+
+def qk_norm_bwd(x, dy, scale, heads, x_f32=None, dy_f32=None):
+    """l2norm * scale backward on `heads` vectors of 64 per row.  bf16 form: x, dy [rows, >= heads*64] -> (dx bf16 [rows, heads*64],
+    dscale fp32 [64]).  fp32 form (null key): x_f32 [H, 64] broadcast over dy_f32 [rows*H, 64] -> (dx fp32 [rows*H, 64], dscale)."""
+    lib = L.lib()
+    if x_f32 is not None:
+        _chk_cuda(x_f32, dy_f32, scale)
+        nvec = dy_f32.shape[0]
+        H = x_f32.shape[0]
+        dx = torch.empty(nvec, 64, dtype=torch.float32, device=dy_f32.device)
+        part = torch.empty(lib.mm_qk_norm_bwd_blocks(nvec), 64, dtype=torch.float32, device=dy_f32.device)
+        L.check(lib.mm_qk_norm_bwd(L.stream(), None, 0, L.ptr(x_f32.contiguous()), H, None, 0, L.ptr(dy_f32), L.ptr(scale), nvec, 1, None, 0,
+                                   L.ptr(dx), L.ptr(part)), 'mm_qk_norm_bwd')
+        return dx, colsum(part)
+    _chk_cuda(x, dy, scale)
+    rows = x.shape[0]
+    dx = torch.empty(rows, heads * 64, dtype=bf16, device=x.device)
+    part = torch.empty(lib.mm_qk_norm_bwd_blocks(rows * heads), 64, dtype=torch.float32, device=x.device)
+    L.check(lib.mm_qk_norm_bwd(L.stream(), L.ptr(x), x.stride(0), None, heads, L.ptr(dy), dy.stride(0), None, L.ptr(scale), rows, heads,
+                               L.ptr(dx), heads * 64, None, L.ptr(part)), 'mm_qk_norm_bwd')
+    return dx, colsum(part)
