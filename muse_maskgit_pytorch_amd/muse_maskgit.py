@@ -302,12 +302,28 @@ class Transformer(nn.Module):
             return scaled, emb_p.float().reshape(b, n, self.dim)
         return scaled
 
-    @torch.no_grad()
     def forward(self, x, return_embed=False, return_logits=False, labels=None, ignore_index=0, self_cond_embed=None,
                 cond_drop_prob=0., conditioning_token_ids: Optional[torch.Tensor] = None, texts: Optional[List[str]] = None,
                 text_embeds: Optional[torch.Tensor] = None, _embed_only=False):
-        """mmp.py:279-348, inference branches.  Returns fp32 logits (b, n, dim_out) [and the fp32 view of the
-        bf16 embed]; `_embed_only` (internal) returns the bf16 [b*n, dim] embed for the fused CFG GEMM."""
+        """mmp.py:279-348.  Returns fp32 logits (b, n, dim_out) [and the fp32 view of the bf16 embed]; `_embed_only` (internal)
+        returns the bf16 [b*n, dim] embed for the fused CFG GEMM.  With `labels`, autograd enabled and trainable parameters the
+        cross-entropy comes from the differentiable MI355X training path (training.py: hand-written backward); otherwise the loss
+        is computed forward-only."""
+        if (exists(labels) and not return_logits and self.dim_out != 1 and torch.is_grad_enabled() and self.to_logits.weight.requires_grad
+                and bool((labels != ignore_index).any())):      # all rows ignored: NaN like F.cross_entropy, nothing to differentiate
+            assert exists(texts) ^ exists(text_embeds)
+            if exists(texts):
+                text_embeds = self.encode_text(texts)
+            if exists(conditioning_token_ids):
+                raise NotImplementedError('training with conditioning token ids (super-res) is a later scope row (SURVEY 8f-1)')
+            from .training import transformer_loss
+            return transformer_loss(self, x, text_embeds, labels, ignore_index, cond_drop_prob)
+        with torch.no_grad():
+            return self._forward_no_grad(x, return_embed, return_logits, labels, ignore_index, self_cond_embed, cond_drop_prob,
+                                         conditioning_token_ids, texts, text_embeds, _embed_only)
+
+    def _forward_no_grad(self, x, return_embed, return_logits, labels, ignore_index, self_cond_embed, cond_drop_prob,
+                         conditioning_token_ids, texts, text_embeds, _embed_only):
         b, n = x.shape
         assert n <= self.seq_len
         assert exists(texts) ^ exists(text_embeds)
@@ -578,13 +594,23 @@ class MaskGit(nn.Module):
             return ids
         return self.vae.decode_from_ids(ids)
 
-    @torch.no_grad()
     def forward(self, images_or_ids: torch.Tensor, ignore_index=-1, cond_images: Optional[torch.Tensor] = None,
                 cond_token_ids: Optional[torch.Tensor] = None, texts: Optional[List[str]] = None,
                 text_embeds: Optional[torch.Tensor] = None, cond_drop_prob=None, train_only_generator=False,
                 sample_temperature=None):
-        """Training loss of mmp.py:623-741, FORWARD ONLY (no autograd through the HIP path yet: SURVEY 8f-1).  The random
-        masking uses torch's device generator exactly like the reference does on a GPU."""
+        """Training loss of mmp.py:623-741.  With autograd enabled the generator's cross-entropy is differentiable (training.py:
+        hand-written MI355X backward; `loss.backward()` fills the transformer's .grad), under torch.no_grad() it is forward only.
+        The random masking uses torch's device generator exactly like the reference does on a GPU."""
+        with torch.no_grad():
+            x, labels, text_embeds, cond_token_ids, cond_drop_prob = self._training_inputs(images_or_ids, ignore_index, cond_images,
+                                                                                         cond_token_ids, texts, text_embeds, cond_drop_prob)
+        ce_loss = self.transformer(x, text_embeds=text_embeds, conditioning_token_ids=cond_token_ids, labels=labels,
+                                   cond_drop_prob=cond_drop_prob, ignore_index=ignore_index)
+        if not exists(self.token_critic) or train_only_generator:
+            return ce_loss
+        raise NotImplementedError('token-critic loss (mmp.py:726-741) is a later scope row (SURVEY 8f-2)')
+
+    def _training_inputs(self, images_or_ids, ignore_index, cond_images, cond_token_ids, texts, text_embeds, cond_drop_prob):
         dev = self.transformer.token_emb.weight.device
         if images_or_ids.dtype == torch.float:
             assert exists(self.vae), 'vqgan vae must be passed in if training from raw images'
@@ -616,11 +642,7 @@ class MaskGit(nn.Module):
             text_embeds = self.transformer.encode_text(texts)
         if self.transformer.self_cond:
             raise NotImplementedError('self-conditioning is a later scope row (SURVEY 8f-2)')
-        ce_loss = self.transformer(x, text_embeds=text_embeds, conditioning_token_ids=cond_token_ids, labels=labels,
-                                   cond_drop_prob=cond_drop_prob, ignore_index=ignore_index)
-        if not exists(self.token_critic) or train_only_generator:
-            return ce_loss
-        raise NotImplementedError('token-critic loss (mmp.py:726-741) is a later scope row (SURVEY 8f-2)')
+        return x, labels, text_embeds, cond_token_ids, cond_drop_prob
 
 
 class Muse(nn.Module):

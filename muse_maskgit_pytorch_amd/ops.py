@@ -127,21 +127,27 @@ def layernorm_inner(a, F, gamma, beta=None):
     return out
 
 
-def attend(q, k, v, key_mask=None, scale=8.0, normalize=False, q_scale=None, k_scale=None, null_k=None, null_v=None):
-    """q (b,h,n,64), k/v (b,h,j,64) bf16 with arbitrary batch/head/token strides (d contiguous); key_mask (b,j) bool/uint8."""
+def attend(q, k, v, key_mask=None, scale=8.0, normalize=False, q_scale=None, k_scale=None, null_k=None, null_v=None, out_rows=False):
+    """q (b,h,n,64), k/v (b,h,j,64) bf16 with arbitrary batch/head/token strides (d contiguous); key_mask (b,j) bool/uint8.
+    out_rows: return the output as [b*n, h*64] rows (heads merged, 'b h n d -> b n (h d)', mmp.py:161) instead of (b,h,n,64)."""
     _chk_cuda(q, k, v, key_mask)
     assert q.dtype == bf16 and k.dtype == bf16 and v.dtype == bf16
     b, h, n, d = q.shape
     j = k.shape[2]
     assert d == 64 and q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1
-    out = torch.empty(b, h, n, d, dtype=bf16, device=q.device)
+    if out_rows:
+        out = torch.empty(b * n, h * d, dtype=bf16, device=q.device)
+        ost = (n * h * d, d, h * d)
+    else:
+        out = torch.empty(b, h, n, d, dtype=bf16, device=q.device)
+        ost = (out.stride(0), out.stride(1), out.stride(2))
     km = None
     if key_mask is not None:
         km = key_mask.to(torch.uint8).contiguous()
         assert km.shape == (b, j)
     L.check(L.lib().mm_attend(L.stream(), L.ptr(q), q.stride(0), q.stride(1), q.stride(2), L.ptr(k), k.stride(0), k.stride(1),
-                              k.stride(2), L.ptr(v), v.stride(0), v.stride(1), v.stride(2), L.ptr(out), out.stride(0),
-                              out.stride(1), out.stride(2), b, h, n, j, L.ptr(km), j, int(normalize), L.ptr(q_scale),
+                              k.stride(2), L.ptr(v), v.stride(0), v.stride(1), v.stride(2), L.ptr(out), ost[0], ost[1], ost[2],
+                              b, h, n, j, L.ptr(km), j, int(normalize), L.ptr(q_scale),
                               L.ptr(k_scale), L.ptr(null_k), L.ptr(null_v), float(scale)), 'mm_attend')
     return out
 
@@ -320,17 +326,19 @@ def step_temperatures(timesteps, temperature):
 
 
 # ------------------------------------------------------------------------------------------------ backward operators (training)
-def transpose(x):
-    """bf16 [R,C] (row stride % 8 == 0) -> contiguous [C,Rp] view [:, :R] with Rp = R rounded up to 8."""
+def transpose(x, pad_to=None):
+    """bf16 [R,C] (row stride % 8 == 0) -> [C,R].  pad_to: return the contiguous [C, Rp] buffer instead, Rp = R rounded up to
+    `pad_to`, padding columns zero (a GEMM contraction dimension)."""
     _chk_cuda(x)
     assert x.dtype == bf16 and x.dim() == 2 and x.stride(1) == 1
     R, C = x.shape
-    Rp = (R + 7) // 8 * 8
+    mult = pad_to or 8
+    Rp = (R + mult - 1) // mult * mult
     out = torch.empty(C, Rp, dtype=bf16, device=x.device)
     if Rp != R:
         out.zero_()
     L.check(L.lib().mm_transpose_bf16(L.stream(), L.ptr(x), R, C, x.stride(0), L.ptr(out), Rp), 'mm_transpose_bf16')
-    return out[:, :R]
+    return out if pad_to else out[:, :R]
 
 
 def to_bf16(x):

@@ -1,0 +1,268 @@
+"""Training step of the transformer on MI355X: forward WITH saved activations and a hand-written backward, as one
+torch.autograd.Function, so that `loss = maskgit(images_or_ids, ...); loss.backward()` works as with the reference
+(muse_maskgit_pytorch.py:623-741, which differentiates Transformer.forward mmp.py:279-348 with autograd).
+
+Every arithmetic step is a C-ABI operator of libmuse_hip.so (include/muse_hip.h): bf16 MFMA GEMMs (activation gradients
+bf16, parameter gradients fp32), the MFMA attention backward, LayerNorm / GEGLU / cross-entropy / embedding gradient kernels.
+torch supplies memory, the autograd tape and the optimizer; parameters stay fp32 nn.Parameters (bf16 copies are packed per
+step), gradients land in .grad like with the reference.  First scope: the base model -- no self-conditioning, no
+super-res conditioning ids (those raise).  Linear layers:  dX = dY W  and  dW = dY^T X  are NT GEMMs on transposed copies.
+"""
+import torch
+
+from . import ops
+
+bf16 = torch.bfloat16
+
+
+def _pad64(n):
+    return (n + 63) // 64 * 64
+
+
+def _t(x):
+    """bf16 [R, C] -> contiguous [C, R64] transposed copy whose padding columns are zero (a GEMM contraction dim)."""
+    return ops.transpose(x, pad_to=64)
+
+
+def _wgrad(dy, x):
+    """dW [N, K] = dY^T X for dY [M, N], X [M, K] (bf16) -> fp32."""
+    return ops.gemm(_t(dy), _t(x), out_f32=True)
+
+
+def _dgrad(dy, w):
+    """dX [M, K] = dY W for dY [M, N], W [N, K] (bf16) -> bf16."""
+    return ops.gemm(dy, _t(w))
+
+
+def _heads(t, b, n, h, col0=0):
+    """[b*n, >= col0 + h*64] row tensor -> (b, h, n, 64) strided view."""
+    return t[:, col0:col0 + h * 64].unflatten(0, (b, n)).unflatten(2, (h, 64)).permute(0, 2, 1, 3)
+
+
+class _Params:
+    """fixed order of the parameters that receive gradients"""
+
+    def __init__(self, tr):
+        self.names, self.tensors = [], []
+        tb = tr.transformer_blocks
+
+        def add(name, p):
+            self.names.append(name)
+            self.tensors.append(p)
+        add('token_emb', tr.token_emb.weight)
+        add('pos_emb', tr.pos_emb.weight)
+        self.has_proj = isinstance(tr.text_embed_proj, torch.nn.Linear)
+        if self.has_proj:
+            add('text_proj', tr.text_embed_proj.weight)
+        for i, (sa, ca, ff) in enumerate(tb.layers):
+            for tag, a in (('sa', sa), ('ca', ca)):
+                for nm in ('norm.gamma', 'to_q.weight', 'to_kv.weight', 'q_scale', 'k_scale', 'null_kv', 'to_out.weight'):
+                    obj = a
+                    for part in nm.split('.'):
+                        obj = getattr(obj, part)
+                    add(f'{i}.{tag}.{nm}', obj)
+            add(f'{i}.ff.g1', ff[0].gamma)
+            add(f'{i}.ff.w1', ff[1].weight)
+            add(f'{i}.ff.g2', ff[3].gamma)
+            add(f'{i}.ff.w2', ff[4].weight)
+        add('final.gamma', tb.norm.gamma)
+        add('to_logits', tr.to_logits.weight)
+
+
+class TransformerTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cfg, ids, te, ctx_mask, labels_rows, row_index, *params):
+        """cfg: dict(depth, heads, dim, F, names, betas ...); ids int64 [b, n]; te fp32 [b, L, td]; ctx_mask uint8 [b, L];
+        row_index int32 [R] = flat positions with a label, labels_rows int64 [R]."""
+        P = dict(zip(cfg['names'], params))
+        dev = ids.device
+        b, n = ids.shape
+        D, H, F = cfg['dim'], cfg['heads'], cfg['F']
+        I = H * 64
+        Fp = _pad64(F)
+        M = b * n
+        Lt = te.shape[1]
+        W = {}           # bf16 operand copies of this step
+        sv = dict(b=b, n=n, Lt=Lt, layers=[])
+        f32 = lambda t: t.detach().float().contiguous()
+
+        x = ops.embed(ids, P['token_emb'].detach().to(bf16).contiguous(), P['pos_emb'].detach().to(bf16).contiguous())       # mmp.py:322-323
+        te_b = ops.to_bf16(te.reshape(b * Lt, -1).contiguous())
+        if cfg['has_proj']:
+            W['tp'] = P['text_proj'].detach().to(bf16).contiguous()
+            cx = ops.gemm(te_b, W['tp'])                                                                             # mmp.py:302
+        else:
+            cx = te_b
+        sv['te_b'], sv['cx'] = te_b, cx
+        for i in range(cfg['depth']):
+            lw, ls = {}, {}
+            # ---- self attention (mmp.py:137-162, 186)
+            a = f'{i}.sa.'
+            lw['wqkv'] = torch.cat([P[a + 'to_q.weight'].detach(), P[a + 'to_kv.weight'].detach()], 0).to(bf16).contiguous()
+            lw['wo'] = P[a + 'to_out.weight'].detach().to(bf16).contiguous()
+            ls['x0'] = x
+            u = ops.layernorm(x, f32(P[a + 'norm.gamma']), cfg['betas'][a])
+            qkv = ops.gemm(u, lw['wqkv'])
+            nk, nv = f32(P[a + 'null_kv'][0, :, 0]), f32(P[a + 'null_kv'][1, :, 0])
+            o = ops.attend(_heads(qkv, b, n, H), _heads(qkv, b, n, H, I), _heads(qkv, b, n, H, 2 * I), normalize=True,
+                           q_scale=f32(P[a + 'q_scale']), k_scale=f32(P[a + 'k_scale']), null_k=nk, null_v=nv, out_rows=True)
+            x = ops.gemm(o, lw['wo'], out_f32=True, resid=x)
+            ls.update(u=u, qkv=qkv, o=o)
+            # ---- cross attention (mmp.py:139-141, 155-157, 187)
+            c = f'{i}.ca.'
+            lw['wq2'] = P[c + 'to_q.weight'].detach().to(bf16).contiguous()
+            lw['wkv2'] = P[c + 'to_kv.weight'].detach().to(bf16).contiguous()
+            lw['wo2'] = P[c + 'to_out.weight'].detach().to(bf16).contiguous()
+            ls['x1'] = x
+            u2 = ops.layernorm(x, f32(P[c + 'norm.gamma']), cfg['betas'][c])
+            q2 = ops.gemm(u2, lw['wq2'])
+            kv2 = ops.gemm(cx, lw['wkv2'])
+            o2 = ops.attend(_heads(q2, b, n, H), _heads(kv2, b, Lt, H), _heads(kv2, b, Lt, H, I), key_mask=ctx_mask, normalize=True,
+                            q_scale=f32(P[c + 'q_scale']), k_scale=f32(P[c + 'k_scale']), null_k=f32(P[c + 'null_kv'][0, :, 0]),
+                            null_v=f32(P[c + 'null_kv'][1, :, 0]), out_rows=True)
+            x = ops.gemm(o2, lw['wo2'], out_f32=True, resid=x)
+            ls.update(u2=u2, q2=q2, kv2=kv2, o2=o2)
+            # ---- feed forward (mmp.py:79-89, 188)
+            w1 = P[f'{i}.ff.w1'].detach()
+            w1p = torch.zeros(2 * Fp, D, dtype=bf16, device=dev)
+            w1p[:F] = w1[:F]
+            w1p[Fp:Fp + F] = w1[F:]
+            lw['w1p'] = w1p
+            lw['w2p'] = ops.pad_cols(P[f'{i}.ff.w2'].detach().to(bf16), 64)
+            ls['x2'] = x
+            u3 = ops.layernorm(x, f32(P[f'{i}.ff.g1']), cfg['betas'][f'{i}.ff.b1'])
+            hh = ops.gemm(u3, w1p)
+            z = ops.geglu_ln(hh, F, f32(P[f'{i}.ff.g2']), cfg['betas'][f'{i}.ff.b2'])
+            x = ops.gemm(z, lw['w2p'], out_f32=True, resid=x)
+            ls.update(u3=u3, h=hh, z=z)
+            sv['layers'].append((lw, ls))
+        # ---- head on the rows that carry a label (mmp.py:330-343): rows with ignore_index contribute nothing to the loss
+        W['wl'] = P['to_logits'].detach().to(bf16).contiguous()
+        e = ops.layernorm(x, f32(P['final.gamma']), cfg['betas']['final'], row_index=row_index)
+        logits = ops.gemm(e, W['wl'], out_f32=True)
+        loss = ops.ce_loss(logits, labels_rows, -100)
+        sv.update(xL=x, e=e, logits=logits, W=W)
+        ctx.sv, ctx.cfg = sv, cfg
+        ctx.P = {k: v.detach() for k, v in P.items()}
+        ctx.ids, ctx.labels_rows, ctx.row_index, ctx.ctx_mask = ids, labels_rows, row_index, ctx_mask
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, gloss):
+        sv, cfg, P = ctx.sv, ctx.cfg, ctx.P
+        b, n, Lt = sv['b'], sv['n'], sv['Lt']
+        D, H, F = cfg['dim'], cfg['heads'], cfg['F']
+        I = H * 64
+        Fp = _pad64(F)
+        M = b * n
+        dev = ctx.ids.device
+        G = {}
+        f32 = lambda t: t.float().contiguous()
+        R = ctx.row_index.numel()
+        # ---- head
+        dl = ops.ce_bwd(sv['logits'], ctx.labels_rows, 1.0 / R)
+        G['to_logits'] = _wgrad(dl, sv['e'])
+        de = _dgrad(dl, sv['W']['wl'])
+        dres = torch.zeros(M, D, dtype=torch.float32, device=dev)
+        G['final.gamma'] = ops.layernorm_bwd(sv['xL'], de, f32(P['final.gamma']), dres, accumulate=False, row_index=ctx.row_index)
+        dcx = None
+        for i in reversed(range(cfg['depth'])):
+            lw, ls = sv['layers'][i]
+            # ---- feed forward
+            dy = ops.to_bf16(dres)
+            dz = _dgrad(dy, lw['w2p'])
+            G[f'{i}.ff.w2'] = _wgrad(dy, ls['z'])[:, :F]
+            dh, G[f'{i}.ff.g2'] = ops.geglu_ln_bwd(ls['h'], dz, F, f32(P[f'{i}.ff.g2']))
+            du3 = _dgrad(dh, lw['w1p'])
+            dw1p = _wgrad(dh, ls['u3'])
+            G[f'{i}.ff.w1'] = torch.cat([dw1p[:F], dw1p[Fp:Fp + F]], 0)
+            G[f'{i}.ff.g1'] = ops.layernorm_bwd(ls['x2'], du3, f32(P[f'{i}.ff.g1']), dres)
+            # ---- cross attention
+            c = f'{i}.ca.'
+            dy = ops.to_bf16(dres)
+            do2 = _dgrad(dy, lw['wo2'])
+            G[c + 'to_out.weight'] = _wgrad(dy, ls['o2'])
+            qs, ks = f32(P[c + 'q_scale']), f32(P[c + 'k_scale'])
+            nk, nv = f32(P[c + 'null_kv'][0, :, 0]), f32(P[c + 'null_kv'][1, :, 0])
+            dqn, dkn, dv, dnk, dnv = ops.attention_bwd(_heads(ls['q2'], b, n, H), _heads(ls['kv2'], b, Lt, H), _heads(ls['kv2'], b, Lt, H, I),
+                                                       _heads(ls['o2'], b, n, H), _heads(do2, b, n, H), qs, ks, nk, nv, key_mask=ctx.ctx_mask)
+            dq2, dqs = ops.qk_norm_bwd(ls['q2'], dqn.reshape(M, I), qs, H)
+            dk2, dks = ops.qk_norm_bwd(ls['kv2'], dkn.reshape(b * Lt, I), ks, H)
+            dnull, dks_n = ops.qk_norm_bwd(None, None, ks, H, x_f32=nk, dy_f32=dnk)
+            G[c + 'q_scale'], G[c + 'k_scale'] = dqs, dks + dks_n
+            G[c + 'null_kv'] = torch.stack([ops.colsum(dnull.reshape(b, H * 64)), ops.colsum(dnv.reshape(b, H * 64))], 0).reshape(2, H, 1, 64)
+            dkv2 = torch.cat([dk2, dv.reshape(b * Lt, I)], 1)
+            du2 = _dgrad(dq2, lw['wq2'])
+            G[c + 'to_q.weight'] = _wgrad(dq2, ls['u2'])
+            G[c + 'to_kv.weight'] = _wgrad(dkv2, sv['cx'])
+            if cfg['has_proj']:
+                d1 = ops.gemm(dkv2, _t(lw['wkv2']), out_f32=True, resid=dcx)
+                dcx = d1
+            G[c + 'norm.gamma'] = ops.layernorm_bwd(ls['x1'], du2, f32(P[c + 'norm.gamma']), dres)
+            # ---- self attention
+            a = f'{i}.sa.'
+            dy = ops.to_bf16(dres)
+            do = _dgrad(dy, lw['wo'])
+            G[a + 'to_out.weight'] = _wgrad(dy, ls['o'])
+            qs, ks = f32(P[a + 'q_scale']), f32(P[a + 'k_scale'])
+            nk, nv = f32(P[a + 'null_kv'][0, :, 0]), f32(P[a + 'null_kv'][1, :, 0])
+            qkv = ls['qkv']
+            dqn, dkn, dv, dnk, dnv = ops.attention_bwd(_heads(qkv, b, n, H), _heads(qkv, b, n, H, I), _heads(qkv, b, n, H, 2 * I),
+                                                       _heads(ls['o'], b, n, H), _heads(do, b, n, H), qs, ks, nk, nv)
+            dq, dqs = ops.qk_norm_bwd(qkv, dqn.reshape(M, I), qs, H)
+            dk, dks = ops.qk_norm_bwd(qkv[:, I:], dkn.reshape(M, I), ks, H)
+            dnull, dks_n = ops.qk_norm_bwd(None, None, ks, H, x_f32=nk, dy_f32=dnk)
+            G[a + 'q_scale'], G[a + 'k_scale'] = dqs, dks + dks_n
+            G[a + 'null_kv'] = torch.stack([ops.colsum(dnull.reshape(b, H * 64)), ops.colsum(dnv.reshape(b, H * 64))], 0).reshape(2, H, 1, 64)
+            dqkv = torch.cat([dq, dk, dv.reshape(M, I)], 1)
+            du = _dgrad(dqkv, lw['wqkv'])
+            dwqkv = _wgrad(dqkv, ls['u'])
+            G[a + 'to_q.weight'], G[a + 'to_kv.weight'] = dwqkv[:I], dwqkv[I:]
+            G[a + 'norm.gamma'] = ops.layernorm_bwd(ls['x0'], du, f32(P[a + 'norm.gamma']), dres)
+        # ---- embeddings / text projection
+        G['token_emb'], G['pos_emb'] = ops.embed_bwd(ctx.ids, dres, P['token_emb'].shape[0])
+        if n < P['pos_emb'].shape[0]:
+            full = torch.zeros_like(P['pos_emb'], dtype=torch.float32)
+            full[:n] = G['pos_emb']
+            G['pos_emb'] = full
+        if cfg['has_proj']:
+            G['text_proj'] = _wgrad(ops.to_bf16(dcx), sv['te_b'])
+        grads = []
+        for name in cfg['names']:
+            g = G[name].to(P[name].dtype).reshape(P[name].shape)
+            grads.append(g * gloss if gloss.numel() == 1 and float(gloss) != 1.0 else g)
+        ctx.sv = None
+        return (None, None, None, None, None, None, *grads)
+
+
+def transformer_loss(tr, ids, text_embeds, labels, ignore_index, cond_drop_prob):
+    """Differentiable CE loss of Transformer.forward(labels=...) (mmp.py:337-346) on the MI355X training path."""
+    if tr.self_cond:
+        raise NotImplementedError('training with self-conditioning is a later scope row (SURVEY 8f-2)')
+    if tr.dim_out == 1:
+        raise NotImplementedError('critic (BCE) training is a later scope row (SURVEY 8f-2)')
+    dev = tr.token_emb.weight.device
+    ids = ids.to(device=dev, dtype=torch.long).contiguous()
+    b, n = ids.shape
+    assert (b * n) % 64 == 0, 'the training path needs batch * seq_len to be a multiple of 64'
+    te = text_embeds.to(device=dev, dtype=torch.float32).contiguous()
+    ctx_mask = (te != 0).any(dim=-1)                                                   # mmp.py:304
+    if cond_drop_prob >= 1.:
+        ctx_mask = torch.zeros_like(ctx_mask)
+    elif cond_drop_prob > 0.:                                                          # mmp.py:308-310, 393-399
+        ctx_mask = ctx_mask & (torch.rand((b, 1), device=dev) < (1. - cond_drop_prob))
+    labels = labels.to(device=dev, dtype=torch.long).reshape(-1)
+    row_index = torch.nonzero(labels != ignore_index).reshape(-1).to(torch.int32).contiguous()
+    assert row_index.numel() > 0, 'no position carries a label'
+    labels_rows = labels[row_index.long()].contiguous()
+    pr = _Params(tr)
+    tb = tr.transformer_blocks
+    betas = {'final': tb.norm.beta.float().contiguous()}
+    for i, (sa, ca, ff) in enumerate(tb.layers):
+        betas[f'{i}.sa.'] = sa.norm.beta.float().contiguous()
+        betas[f'{i}.ca.'] = ca.norm.beta.float().contiguous()
+        betas[f'{i}.ff.b1'] = ff[0].beta.float().contiguous()
+        betas[f'{i}.ff.b2'] = ff[3].beta.float().contiguous()
+    cfg = dict(depth=tb.cfg['depth'], heads=tb.cfg['heads'], dim=tr.dim, F=tb.layers[0][2][4].weight.shape[1], names=pr.names,
+               has_proj=pr.has_proj, betas=betas)
+    return TransformerTrainFn.apply(cfg, ids, te, ctx_mask.to(torch.uint8).contiguous(), labels_rows, row_index, *pr.tensors)
