@@ -127,6 +127,12 @@ int mm_bce_loss(mm_stream_t stream, const float* x, const float* y, int n, float
  *      gradient fp32.  Linear layers: dX = dY * W and dW = dY^T * X are mm_gemm_bf16 calls on transposed copies
  *      (mm_transpose_bf16).  INTEGRATION.md lists the per-layer call sequence. */
 
+/* Weight-gradient GEMM out[M][N] = x[M][K] * w[N][K]^T (fp32) with a LONG contraction K (= the token count) and a small
+ * output: the K loop is split over `splits` workgroups per tile (partial slabs in ws, splits*M*N floats), then reduced in a fixed
+ * order.  mm_gemm_wgrad_splits(M, N, K) proposes a split count (1 = use mm_gemm_bf16). */
+int mm_gemm_wgrad_splits(int M, int N, int K);
+int mm_gemm_wgrad(mm_stream_t stream, const void* x, int64_t ldx, const void* w, int64_t ldw, int M, int N, int K, int splits,
+                  float* ws, float* out);
 /* out[c][r] = in[r][c]; bf16, strides in elements (multiples of 8). */
 int mm_transpose_bf16(mm_stream_t stream, const void* in, int64_t rows, int64_t cols, int64_t ld_in, void* out, int64_t ld_out);
 /* out[i] = bf16(x[i]). */

@@ -184,6 +184,33 @@ int mm_bce_loss(mm_stream_t stream, const float* x, const float* y, int n, float
     return k_bce_loss((hipStream_t)stream, x, y, n, out);
 }
 
+int mm_gemm_wgrad_splits(int M, int N, int K) {
+    const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+    const int kt = K / 64;
+    int s = 1;
+    while (tiles * s < 384 && (kt % (s * 2)) == 0 && kt / (s * 2) >= 8) s *= 2;      // fill the 256 CUs, keep >= 512 of K per workgroup
+    return s;
+}
+
+int mm_gemm_wgrad(mm_stream_t stream, const void* x, int64_t ldx, const void* w, int64_t ldw, int M, int N, int K, int splits,
+                  float* ws, float* out) {
+    if (M == 0 || N == 0) return MM_OK;
+    CHK_PTR(x, "x"); CHK_PTR(w, "w"); CHK_PTR(out, "out"); CHK_ALIGN16(x, "x"); CHK_ALIGN16(w, "w"); CHK_ALIGN16(out, "out");
+    if (N % 4) return mm_set_error(MM_ERR_SHAPE, "gemm_wgrad: N must be a multiple of 4");
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mode = MODE_DENSE;
+    a.W = (const bf16_t*)w; a.N = N; a.ldw = (int)ldw; a.K = K;
+    a.M = M; a.X = (const bf16_t*)x; a.ldx = (int)ldx;
+    a.ldc = N; a.out_kind = OUT_F32; a.ldr = N;
+    if (splits <= 1) { a.out = out; return mm_gemm_launch(a, (hipStream_t)stream); }
+    CHK_PTR(ws, "ws"); CHK_ALIGN16(ws, "ws");
+    a.out = ws; a.splits = splits; a.split_stride = (long)M * N;
+    int rc = mm_gemm_launch(a, (hipStream_t)stream);
+    if (rc) return rc;
+    return k_colsum((hipStream_t)stream, ws, splits, (long)M * N, out);
+}
+
 int mm_transpose_bf16(mm_stream_t stream, const void* in, int64_t rows, int64_t cols, int64_t ld_in, void* out, int64_t ld_out) {
     if (rows == 0 || cols == 0) return MM_OK;
     CHK_PTR(in, "in"); CHK_PTR(out, "out"); CHK_ALIGN16(in, "in"); CHK_ALIGN16(out, "out");

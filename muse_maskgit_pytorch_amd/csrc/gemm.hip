@@ -115,8 +115,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int KT = p.K / BK;
-    ISSUE_TILE(0, 0);
+    // split-K: this workgroup covers k-tiles [kt0, kt0 + KT) and writes its partial sums to slab blockIdx.y of `out`
+    const int nsplit = p.splits > 1 ? p.splits : 1;
+    const int KT = p.K / BK / nsplit;
+    const int kt0 = (int)blockIdx.y * KT;
+    void* const outp = p.splits > 1 ? static_cast<void*>(reinterpret_cast<float*>(p.out) + (size_t)blockIdx.y * p.split_stride) : p.out;
+    ISSUE_TILE(kt0, 0);
     __syncthreads();        // with an LDS-DMA in flight this is vmcnt(0) + s_barrier
 
     const int fr = lane & 15, fg = lane >> 4;
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     }
     // steady state: the next tile's DMA is in flight while this tile's MFMAs run; one barrier per tile
     for (int kt = 0; kt < KT - 1; ++kt) {
-        if (!(p.debug & 2)) ISSUE_TILE(kt + 1, (kt + 1) & 1);
+        if (!(p.debug & 2)) ISSUE_TILE(kt0 + kt + 1, (kt + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);   // keep the DMA issue ahead of the MFMA block
         COMPUTE_TILE(kt & 1);
         __syncthreads();
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 
     if (p.out_kind == OUT_NCHW_F32) {
         // narrow conv head (Cout = image channels): direct scalar stores, out[b][n][y][x]
-        float* op = reinterpret_cast<float*>(p.out);
+        float* op = reinterpret_cast<float*>(outp);
 #pragma unroll
         for (int b = 0; b < MT; ++b) {
             const int m = m0 + wave_m * 64 + b * 16 + fr;
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             const float4 lo = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c8);
             const float4 hi = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c8 + 4);
             float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + no) = pack8(v);
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(outp) + (size_t)m * p.ldc + no) = pack8(v);
         }
         return;
     }
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                     for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += rp[r];
                 }
             }
-            float* op = reinterpret_cast<float*>(p.out) + orow * p.ldc + n;
+            float* op = reinterpret_cast<float*>(outp) + orow * p.ldc + n;
             if (full) *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
             else {
 #pragma unroll
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                     for (int r = 0; r < 8; ++r) if (n + r < p.N) v[r] += bf16_to_f32(rp[r]);
                 }
             }
-            bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + orow * p.ldc + n;
+            bf16_t* op = reinterpret_cast<bf16_t*>(outp) + orow * p.ldc + n;
             if (full) *reinterpret_cast<uint4*>(op) = pack8(v);
             else {
 #pragma unroll
@@ -332,7 +336,7 @@ int launch(const GemmArgs& a, hipStream_t stream) {
     }
     const int blocks = a.tiles_m * a.tiles_n;
     if (blocks <= 0) return MM_OK;
-    hipLaunchKernelGGL(gemm_kernel<MODE>, dim3(blocks), dim3(256), SMEM_BYTES, stream, a);
+    hipLaunchKernelGGL(gemm_kernel<MODE>, dim3(blocks, a.splits > 1 ? a.splits : 1), dim3(256), SMEM_BYTES, stream, a);
     return mm_check_launch("gemm_kernel");
 }
 
@@ -352,6 +356,13 @@ int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
         return mm_set_error(MM_ERR_DTYPE, "gemm: the residual must have the output's dtype");
     if (a.epi == EPI_GEGLU && (a.mode != MODE_DENSE || (a.N % 128) || a.out_kind != OUT_BF16 || a.bias || a.resid_f32 || a.resid_bf16))
         return mm_set_error(MM_ERR_SHAPE, "gemm: GEGLU epilogue needs a dense bf16 GEMM with N % 128 == 0");
+    if (a.splits > 1) {
+        if (a.mode != MODE_DENSE || a.out_kind != OUT_F32 || a.resid_f32 || a.bias || a.epi != EPI_NONE || (a.K / BK) % a.splits)
+            return mm_set_error(MM_ERR_SHAPE, "gemm: split-K needs a plain dense fp32-output GEMM with K/64 divisible by the split count");
+        a.tiles_n = (a.N + BT - 1) / BT;
+        a.tiles_m = (a.M + BT - 1) / BT;
+        return launch<MODE_DENSE>(a, stream);
+    }
     if (!(a.debug & (8 | 4096 | 8192)) && mm_gemm_cfg2_eligible(a)) return mm_gemm_cfg2_launch(a, stream);
     if (!(a.debug & (8 | 4096)) && mm_gemm_pers_eligible(a)) return mm_gemm_pers_launch(a, stream);
     if (!(a.debug & 8) && mm_gemm_big_eligible(a)) return mm_gemm_big_launch(a, stream);

@@ -28,6 +28,7 @@ struct GemmArgs {
     int act; float cfg_scale;
     int epi;                      // EPI_GEGLU: W rows are GEGLU-interleaved, the tile emits N/2 columns of gate*gelu(x)
     int tiles_m, tiles_n;         // filled by mm_gemm_launch
+    int splits; long split_stride; // split-K (weight gradients): gridDim.y = splits, split s sums k-tiles [s*K/splits, (s+1)*K/splits) into out + s*split_stride floats
     int debug;                    // ablation bits (mm_debug_set): 1 = no epilogue stores, 2 = no DMA after tile 0, 4 = no MFMA, 8 = force the 128x128 kernel, 4096 = no persistent kernel
 };
 extern int g_mm_debug;
@@ -76,7 +77,7 @@ int k_attention(hipStream_t s, const AttnArgs& a);
 
 // train.hip / attention_bwd.hip: backward operators
 int k_transpose_bf16(hipStream_t s, const bf16_t* in, long rows, long cols, long ldi, bf16_t* out, long ldo);
-int k_colsum(hipStream_t s, const float* part, int nparts, int D, float* out);
+int k_colsum(hipStream_t s, const float* part, int nparts, long D, float* out);
 long k_ln_bwd_workspace_floats(int rows, int D);
 int k_layernorm_bwd(hipStream_t s, const float* x, long ldx, const bf16_t* dy, long lddy, const float* gamma, const int32_t* row_index,
                     int rows, int D, float* dx, long lddx, int accumulate, float* dgamma, float* ws);

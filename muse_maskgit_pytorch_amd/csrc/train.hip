@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
 // ------------------------------------------------------------------------------------------------ LayerNorm backward (fp32 x)
 // y = (x - mean) * rstd * gamma + beta.  With xhat = (x - mean) * rstd and g = dy * gamma:
 //   dx = rstd * (g - mean_D(g) - xhat * mean_D(g * xhat)),   dgamma = sum_rows dy * xhat      (beta is a buffer: no gradient)
-constexpr int LNB_ROWS = 16;       // rows per wave -> 64 rows per workgroup
+constexpr int LNB_ROWS = 4;        // rows per wave -> 16 rows per workgroup (512 workgroups at 8192 rows)
 template <int NIT>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, long ldx, const bf16_t* __restrict__ dy, long lddy,
                                                             const float* __restrict__ gamma, const int32_t* __restrict__ row_index,
@@ -161,13 +161,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
-// out[c] = sum over p of part[p][c], partials added in index order (deterministic)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int nparts, int D, float* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= D) return;
-    float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += part[(long)p * D + c];
-    out[c] = s;
+// out[c] = sum over p of part[p][c] in a fixed order (deterministic): 64 columns per workgroup, 4 interleaved partial streams
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int nparts, long D, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const long c = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rg = threadIdx.x >> 6;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < D) {
+        int p = rg;
+        for (; p + 4 < nparts; p += 8) { s0 += part[(long)p * D + c]; s1 += part[(long)(p + 4) * D + c]; }
+        if (p < nparts) s0 += part[(long)p * D + c];
+    }
+    red[rg][threadIdx.x & 63] = s0 + s1;
+    __syncthreads();
+    if (rg == 0 && c < D) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------ GEGLU + inner LayerNorm backward
@@ -196,20 +203,22 @@ __global__ __launch_bounds__(256) void geglu_ln_bwd_kernel(const bf16_t* __restr
         if (row >= rows) break;
         const bf16_t* hr = h + (long)row * ldh;
         const bf16_t* dzr = dz + (long)row * lddz;
-        float a[NIT][8];
+        float a[NIT][8], ph[NIT][8];
         float sum = 0.f;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int c = it * 64 + lane;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a[it][j] = 0.f;
+            for (int j = 0; j < 8; ++j) { a[it][j] = 0.f; ph[it][j] = 0.f; }
             if (c < nch) {
                 float xv[8], gv[8];
                 unpack8(*reinterpret_cast<const uint4*>(hr + c * 8), xv);
                 unpack8(*reinterpret_cast<const uint4*>(hr + Fp + c * 8), gv);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float val = (c * 8 + j < F) ? gv[j] * gelu_f(xv[j]) : 0.f;
+                    const float cdf = 0.5f * (1.f + erff(xv[j] * 0.70710678118654752440f));      // Phi(x): gelu = x Phi, gelu' = Phi + x phi
+                    ph[it][j] = cdf;
+                    const float val = (c * 8 + j < F) ? gv[j] * (xv[j] * cdf) : 0.f;
                     a[it][j] = val;
                     sum += val;
                 }
@@ -266,8 +275,8 @@ __global__ __launch_bounds__(256) void geglu_ln_bwd_kernel(const bf16_t* __restr
                 for (int j = 0; j < 8; ++j) {
                     float da = 0.f;
                     if (c * 8 + j < F) da = rstd * (g[it][j] - c1 - a[it][j] * c2);
-                    og[j] = da * gelu_f(xv[j]);                        // d gate
-                    ox[j] = da * gv[j] * gelu_grad_f(xv[j]);           // d x
+                    og[j] = da * (xv[j] * ph[it][j]);                                                                      // d gate
+                    ox[j] = da * gv[j] * (ph[it][j] + xv[j] * 0.39894228040143267794f * __expf(-0.5f * xv[j] * xv[j]));     // d x
                 }
                 *reinterpret_cast<uint4*>(dhr + c * 8) = pack8(ox);
                 *reinterpret_cast<uint4*>(dhr + Fp + c * 8) = pack8(og);
@@ -371,9 +380,9 @@ int k_transpose_bf16(hipStream_t s, const bf16_t* in, long rows, long cols, long
     return mm_check_launch("transpose_bf16_kernel");
 }
 
-int k_colsum(hipStream_t s, const float* part, int nparts, int D, float* out) {
+int k_colsum(hipStream_t s, const float* part, int nparts, long D, float* out) {
     if (D <= 0) return MM_OK;
-    hipLaunchKernelGGL(colsum_kernel, dim3((D + 255) / 256), dim3(256), 0, s, part, nparts, D, out);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((D + 63) / 64)), dim3(256), 0, s, part, nparts, D, out);
     return mm_check_launch("colsum_kernel");
 }
 
@@ -390,7 +399,7 @@ int k_layernorm_bwd(hipStream_t s, const float* x, long ldx, const bf16_t* dy, l
     else hipLaunchKernelGGL(layernorm_bwd_kernel<8>, dim3(blocks), dim3(256), 0, s, x, ldx, dy, lddy, gamma, row_index, rows, D, dx, lddx, accumulate, ws);
     int rc = mm_check_launch("layernorm_bwd_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(colsum_kernel, dim3((D + 255) / 256), dim3(256), 0, s, ws, blocks, D, dgamma);
+    hipLaunchKernelGGL(colsum_kernel, dim3((D + 63) / 64), dim3(256), 0, s, ws, blocks, (long)D, dgamma);
     return mm_check_launch("colsum_kernel");
 }
 
@@ -405,7 +414,7 @@ int k_geglu_ln_bwd(hipStream_t s, const bf16_t* h, long ldh, const bf16_t* dz, l
     else return mm_set_error(MM_ERR_SHAPE, "geglu_ln_bwd: padded inner width above 3072 is not built");
     int rc = mm_check_launch("geglu_ln_bwd_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(colsum_kernel, dim3((Fp + 255) / 256), dim3(256), 0, s, ws, blocks, Fp, dgamma);
+    hipLaunchKernelGGL(colsum_kernel, dim3((Fp + 63) / 64), dim3(256), 0, s, ws, blocks, (long)Fp, dgamma);
     return mm_check_launch("colsum_kernel");
 }
 

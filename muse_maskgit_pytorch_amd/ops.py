@@ -341,6 +341,22 @@ def transpose(x, pad_to=None):
     return out if pad_to else out[:, :R]
 
 
+def gemm_wgrad(xt, wt):
+    """fp32 [M, N] = xt [M, K] @ wt [N, K]^T for a weight gradient (K = padded token count): split-K over the contraction."""
+    _chk_cuda(xt, wt)
+    M, K = xt.shape
+    N = wt.shape[0]
+    assert wt.shape[1] == K and xt.dtype == bf16 and wt.dtype == bf16
+    lib = L.lib()
+    splits = lib.mm_gemm_wgrad_splits(M, N, K) if N % 4 == 0 else 1
+    if splits <= 1:
+        return gemm(xt, wt, out_f32=True)
+    ws = torch.empty(splits, M, N, dtype=torch.float32, device=xt.device)
+    out = torch.empty(M, N, dtype=torch.float32, device=xt.device)
+    L.check(lib.mm_gemm_wgrad(L.stream(), L.ptr(xt), xt.stride(0), L.ptr(wt), wt.stride(0), M, N, K, splits, L.ptr(ws), L.ptr(out)), 'mm_gemm_wgrad')
+    return out
+
+
 def to_bf16(x):
     _chk_cuda(x)
     assert x.dtype == torch.float32 and x.is_contiguous()

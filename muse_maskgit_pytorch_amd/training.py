@@ -26,7 +26,7 @@ def _t(x):
 
 def _wgrad(dy, x):
     """dW [N, K] = dY^T X for dY [M, N], X [M, K] (bf16) -> fp32."""
-    return ops.gemm(_t(dy), _t(x), out_f32=True)
+    return ops.gemm_wgrad(_t(dy), _t(x))
 
 
 def _dgrad(dy, w):
