@@ -153,6 +153,7 @@ class Transformer(nn.Module):
         self._handle = None
         self._handle_key = None
         self._ws = None
+        self.grad_sync = None          # optional parallel.GradBucketer: data-parallel gradient averaging inside the backward
 
     # ---- packing (once per parameter version / device)
     def _pack_ff(self, ff, keep):
@@ -317,7 +318,7 @@ class Transformer(nn.Module):
             if exists(conditioning_token_ids):
                 raise NotImplementedError('training with conditioning token ids (super-res) is a later scope row (SURVEY 8f-1)')
             from .training import transformer_loss
-            return transformer_loss(self, x, text_embeds, labels, ignore_index, cond_drop_prob)
+            return transformer_loss(self, x, text_embeds, labels, ignore_index, cond_drop_prob, grad_sync=getattr(self, 'grad_sync', None))
         with torch.no_grad():
             return self._forward_no_grad(x, return_embed, return_logits, labels, ignore_index, self_cond_embed, cond_drop_prob,
                                          conditioning_token_ids, texts, text_embeds, _embed_only)

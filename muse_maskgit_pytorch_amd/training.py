@@ -166,6 +166,11 @@ class TransformerTrainFn(torch.autograd.Function):
         dres = torch.zeros(M, D, dtype=torch.float32, device=dev)
         G['final.gamma'] = ops.layernorm_bwd(sv['xL'], de, f32(P['final.gamma']), dres, accumulate=False, row_index=ctx.row_index)
         dcx = None
+        sync = cfg.get('sync')
+        if sync is not None:
+            for k in ('to_logits', 'final.gamma'):
+                G[k] = G[k].contiguous()
+            sync.push([G['to_logits'], G['final.gamma']])
         for i in reversed(range(cfg['depth'])):
             lw, ls = sv['layers'][i]
             # ---- feed forward
@@ -219,6 +224,8 @@ class TransformerTrainFn(torch.autograd.Function):
             dwqkv = _wgrad(dqkv, ls['u'])
             G[a + 'to_q.weight'], G[a + 'to_kv.weight'] = dwqkv[:I], dwqkv[I:]
             G[a + 'norm.gamma'] = ops.layernorm_bwd(ls['x0'], du, f32(P[a + 'norm.gamma']), dres)
+            if sync is not None:      # this layer's gradients are final: average them across ranks while the layers below run
+                sync.push([G[k] for k in cfg['names'] if k.startswith(f'{i}.')])
         # ---- embeddings / text projection
         G['token_emb'], G['pos_emb'] = ops.embed_bwd(ctx.ids, dres, P['token_emb'].shape[0])
         if n < P['pos_emb'].shape[0]:
@@ -227,6 +234,9 @@ class TransformerTrainFn(torch.autograd.Function):
             G['pos_emb'] = full
         if cfg['has_proj']:
             G['text_proj'] = _wgrad(ops.to_bf16(dcx), sv['te_b'])
+        if sync is not None:
+            sync.push([G[k] for k in ('token_emb', 'pos_emb', 'text_proj') if k in G])
+            sync.finish()
         grads = []
         for name in cfg['names']:
             g = G[name].to(P[name].dtype).reshape(P[name].shape)
@@ -235,8 +245,9 @@ class TransformerTrainFn(torch.autograd.Function):
         return (None, None, None, None, None, None, *grads)
 
 
-def transformer_loss(tr, ids, text_embeds, labels, ignore_index, cond_drop_prob):
-    """Differentiable CE loss of Transformer.forward(labels=...) (mmp.py:337-346) on the MI355X training path."""
+def transformer_loss(tr, ids, text_embeds, labels, ignore_index, cond_drop_prob, grad_sync=None):
+    """Differentiable CE loss of Transformer.forward(labels=...) (mmp.py:337-346) on the MI355X training path.
+    grad_sync: an optional parallel.GradBucketer -- data-parallel gradient averaging overlapped with the backward."""
     if tr.self_cond:
         raise NotImplementedError('training with self-conditioning is a later scope row (SURVEY 8f-2)')
     if tr.dim_out == 1:
@@ -264,5 +275,5 @@ def transformer_loss(tr, ids, text_embeds, labels, ignore_index, cond_drop_prob)
         betas[f'{i}.ff.b1'] = ff[0].beta.float().contiguous()
         betas[f'{i}.ff.b2'] = ff[3].beta.float().contiguous()
     cfg = dict(depth=tb.cfg['depth'], heads=tb.cfg['heads'], dim=tr.dim, F=tb.layers[0][2][4].weight.shape[1], names=pr.names,
-               has_proj=pr.has_proj, betas=betas)
+               has_proj=pr.has_proj, betas=betas, sync=grad_sync)
     return TransformerTrainFn.apply(cfg, ids, te, ctx_mask.to(torch.uint8).contiguous(), labels_rows, row_index, *pr.tensors)

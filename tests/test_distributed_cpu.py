@@ -68,3 +68,41 @@ def test_sharded_generate_two_ranks_gloo():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from muse_maskgit_pytorch_amd.parallel import GradBucketer
+    torch.manual_seed(rank)
+    layers = [[torch.randn(5, 7), torch.randn(3)[:2], torch.randn(2, 1, 4)] for _ in range(3)]
+    ok = True
+    expect = []
+    for l in layers:                       # what the average must be, via plain blocking all-reduces
+        for t in l:
+            e = t.clone().contiguous()
+            dist.all_reduce(e)
+            expect.append(e / world)
+    gb = GradBucketer(dist)
+    for l in layers:
+        gb.push(l)
+    gb.finish()
+    for t, e in zip([t for l in layers for t in l], expect):
+        ok = ok and torch.allclose(t, e)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_bucketer_two_ranks_gloo():
+    """parallel.GradBucketer (the per-layer async all-reduce the training backward issues): averaged gradients, views included."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok in res), res
