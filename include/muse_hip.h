@@ -159,6 +159,12 @@ int mm_geglu_ln_bwd(mm_stream_t stream, const void* h, int64_t ldh, const void* 
 int mm_ce_bwd(mm_stream_t stream, const float* logits, int64_t ld, int R, int V, const int64_t* labels, float scale, void* dl,
               int64_t ldd);
 
+/* Backward of the TokenCritic head + loss (mmp.py:345-346, 383-386): logits x [rows] = e [rows][D] . w [D], loss = mean BCE-with-logits
+ * against y [rows].  de bf16 [rows][ldde] = g * w, dw fp32 [D] = sum g * e with g = (sigmoid(x) - y) / rows;
+ * ws: mm_ln_bwd_workspace_floats(rows, D). */
+int mm_bce_head_bwd(mm_stream_t stream, const void* e, int64_t lde, const float* x, const float* y, const float* w, int rows, int D,
+                    void* de, int64_t ldde, float* dw, float* ws);
+
 /* Embedding backward (mmp.py:322-323): dx fp32 [B*n][D]; dpos fp32 [n][D] is overwritten, dtoken fp32 [rows of the table][D]
  * must be zeroed by the caller and is accumulated with fp32 atomics (the one non-deterministic sum of the backward pass). */
 int mm_embed_bwd(mm_stream_t stream, const int64_t* ids, int B, int n, int D, const float* dx, float* dtoken, float* dpos);

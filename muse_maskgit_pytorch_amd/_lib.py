@@ -76,6 +76,7 @@ SIGNATURES = {
     'mm_layernorm_bwd': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_vp, c_i64, c_int, c_vp, c_vp]),
     'mm_geglu_ln_bwd': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp]),
     'mm_ce_bwd': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_f32, c_vp, c_i64]),
+    'mm_bce_head_bwd': (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_i64, c_vp, c_vp]),
     'mm_embed_bwd': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     'mm_scatter_rows_bf16': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
     'mm_attention_bwd': (c_int, [c_vp] + [c_vp, c_i64, c_i64, c_i64] * 8 + [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32]),

@@ -253,6 +253,14 @@ int mm_ce_bwd(mm_stream_t stream, const float* logits, int64_t ld, int R, int V,
     return k_ce_bwd((hipStream_t)stream, logits, ld, R, V, labels, scale, (bf16_t*)dl, ldd);
 }
 
+int mm_bce_head_bwd(mm_stream_t stream, const void* e, int64_t lde, const float* x, const float* y, const float* w, int rows, int D,
+                    void* de, int64_t ldde, float* dw, float* ws) {
+    if (rows == 0) return MM_OK;
+    CHK_PTR(e, "e"); CHK_PTR(x, "x"); CHK_PTR(y, "y"); CHK_PTR(w, "w"); CHK_PTR(de, "de"); CHK_PTR(dw, "dw"); CHK_PTR(ws, "ws");
+    CHK_ALIGN16(e, "e"); CHK_ALIGN16(de, "de");
+    return k_bce_head_bwd((hipStream_t)stream, (const bf16_t*)e, lde, x, y, w, rows, D, (bf16_t*)de, ldde, dw, ws);
+}
+
 int mm_embed_bwd(mm_stream_t stream, const int64_t* ids, int B, int n, int D, const float* dx, float* dtoken, float* dpos) {
     if (B == 0) return MM_OK;
     CHK_PTR(ids, "ids"); CHK_PTR(dx, "dx"); CHK_PTR(dtoken, "dtoken"); CHK_PTR(dpos, "dpos");

@@ -84,6 +84,8 @@ int k_layernorm_bwd(hipStream_t s, const float* x, long ldx, const bf16_t* dy, l
 int k_geglu_ln_bwd(hipStream_t s, const bf16_t* h, long ldh, const bf16_t* dz, long lddz, const float* gamma, int rows, int F, int Fp,
                    bf16_t* dh, long lddh, float* dgamma, float* ws);
 int k_ce_bwd(hipStream_t s, const float* logits, long ld, int R, int V, const int64_t* labels, float scale, bf16_t* dl, long ldd);
+int k_bce_head_bwd(hipStream_t s, const bf16_t* e, long lde, const float* x, const float* y, const float* w, int rows, int D, bf16_t* de,
+                   long ldde, float* dw, float* ws);
 int k_embed_bwd(hipStream_t s, const int64_t* ids, int B, int n, int D, const float* dx, float* dtoken, float* dpos);
 int k_scatter_rows_bf16(hipStream_t s, const bf16_t* src, const int32_t* row_index, int R, int D, bf16_t* dst);
 int k_attention_bwd(hipStream_t s, const bf16_t* q, long q_sb, long q_sh, long q_sn, const bf16_t* k, long k_sb, long k_sh, long k_sn,

@@ -361,6 +361,61 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------ BCE head backward (TokenCritic)
+// logits x_m = e_m . w (Linear(dim, 1), mmp.py:383-386), loss = mean_m BCEWithLogits(x_m, y_m) (mmp.py:345-346):
+//   g_m = (sigmoid(x_m) - y_m) / M,   de_m = g_m * w (bf16),   dw = sum_m g_m * e_m  (per-workgroup partials, reduced by colsum)
+template <int NIT>      // 16-byte iterations per lane over D
+__global__ __launch_bounds__(256) void bce_head_bwd_kernel(const bf16_t* __restrict__ e, long lde, const float* __restrict__ x,
+                                                           const float* __restrict__ y, const float* __restrict__ w, int rows, int D,
+                                                           float inv_count, bf16_t* __restrict__ de, long ldde, float* __restrict__ dw_part) {
+    __shared__ float red[4][64 * 8 * NIT];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nch = D >> 3;
+    float wv[NIT][8], acc[NIT][8];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int c = it * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { wv[it][j] = c < nch ? w[c * 8 + j] : 0.f; acc[it][j] = 0.f; }
+    }
+    const int row0 = (blockIdx.x * 4 + wid) * LNB_ROWS;
+    for (int rr = 0; rr < LNB_ROWS; ++rr) {
+        const int row = row0 + rr;
+        if (row >= rows) break;
+        const float g = (1.f / (1.f + expf(-x[row])) - y[row]) * inv_count;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = it * 64 + lane;
+            if (c < nch) {
+                float ev[8], ov[8];
+                unpack8(*reinterpret_cast<const uint4*>(e + (long)row * lde + c * 8), ev);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { acc[it][j] += g * ev[j]; ov[j] = g * wv[it][j]; }
+                *reinterpret_cast<uint4*>(de + (long)row * ldde + c * 8) = pack8(ov);
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[wid][(it * 64 + lane) * 8 + j] = acc[it][j];
+    __syncthreads();
+    if (wid == 0) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = it * 64 + lane;
+            if (c < nch) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float s2 = red[0][c * 8 + j];
+                    for (int w2 = 1; w2 < 4; ++w2) s2 += red[w2][c * 8 + j];
+                    dw_part[(long)blockIdx.x * D + c * 8 + j] = s2;
+                }
+            }
+        }
+    }
+}
+
 // bf16 rows scattered into a zero-initialised [M][D] bf16 buffer (gradient of a row gather)
 __global__ __launch_bounds__(256) void scatter_rows_bf16_kernel(const bf16_t* __restrict__ src, const int32_t* __restrict__ row_index, int R, int D,
                                                                 bf16_t* __restrict__ dst) {
@@ -423,6 +478,22 @@ int k_ce_bwd(hipStream_t s, const float* logits, long ld, int R, int V, const in
     if (V % 4 || (ld % 4) || (ldd % 4)) return mm_set_error(MM_ERR_SHAPE, "ce_bwd: V and strides must be multiples of 4");
     hipLaunchKernelGGL(ce_bwd_kernel, dim3(R), dim3(256), 0, s, logits, ld, V, labels, scale, dl, ldd);
     return mm_check_launch("ce_bwd_kernel");
+}
+
+int k_bce_head_bwd(hipStream_t s, const bf16_t* e, long lde, const float* x, const float* y, const float* w, int rows, int D, bf16_t* de,
+                   long ldde, float* dw, float* ws) {
+    if (rows <= 0) return MM_OK;
+    if (D % 8 || D > 2048 || (lde % 8) || (ldde % 8)) return mm_set_error(MM_ERR_SHAPE, "bce_head_bwd: D multiple of 8, <= 2048");
+    const int blocks = (rows + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS);
+    const int nit = (D / 8 + 63) / 64;
+    const float inv = 1.f / (float)rows;
+    if (nit <= 1) hipLaunchKernelGGL(bce_head_bwd_kernel<1>, dim3(blocks), dim3(256), 0, s, e, lde, x, y, w, rows, D, inv, de, ldde, ws);
+    else if (nit <= 2) hipLaunchKernelGGL(bce_head_bwd_kernel<2>, dim3(blocks), dim3(256), 0, s, e, lde, x, y, w, rows, D, inv, de, ldde, ws);
+    else hipLaunchKernelGGL(bce_head_bwd_kernel<4>, dim3(blocks), dim3(256), 0, s, e, lde, x, y, w, rows, D, inv, de, ldde, ws);
+    int rc = mm_check_launch("bce_head_bwd_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_kernel, dim3((D + 63) / 64), dim3(256), 0, s, ws, blocks, (long)D, dw);
+    return mm_check_launch("colsum_kernel");
 }
 
 int k_embed_bwd(hipStream_t s, const int64_t* ids, int B, int n, int D, const float* dx, float* dtoken, float* dpos) {

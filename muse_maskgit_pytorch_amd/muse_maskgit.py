@@ -310,7 +310,7 @@ class Transformer(nn.Module):
         returns the bf16 [b*n, dim] embed for the fused CFG GEMM.  With `labels`, autograd enabled and trainable parameters the
         cross-entropy comes from the differentiable MI355X training path (training.py: hand-written backward); otherwise the loss
         is computed forward-only."""
-        if (exists(labels) and not return_logits and self.dim_out != 1 and torch.is_grad_enabled() and self.to_logits.weight.requires_grad
+        if (exists(labels) and not return_logits and torch.is_grad_enabled() and self.to_logits.weight.requires_grad
                 and bool((labels != ignore_index).any())):      # all rows ignored: NaN like F.cross_entropy, nothing to differentiate
             assert exists(texts) ^ exists(text_embeds)
             if exists(texts):
@@ -603,13 +603,41 @@ class MaskGit(nn.Module):
         hand-written MI355X backward; `loss.backward()` fills the transformer's .grad), under torch.no_grad() it is forward only.
         The random masking uses torch's device generator exactly like the reference does on a GPU."""
         with torch.no_grad():
-            x, labels, text_embeds, cond_token_ids, cond_drop_prob = self._training_inputs(images_or_ids, ignore_index, cond_images,
-                                                                                         cond_token_ids, texts, text_embeds, cond_drop_prob)
-        ce_loss = self.transformer(x, text_embeds=text_embeds, conditioning_token_ids=cond_token_ids, labels=labels,
-                                   cond_drop_prob=cond_drop_prob, ignore_index=ignore_index)
+            x, labels, text_embeds, cond_token_ids, cond_drop_prob, ids, mask = self._training_inputs(
+                images_or_ids, ignore_index, cond_images, cond_token_ids, texts, text_embeds, cond_drop_prob)
+        tr = self.transformer
         if not exists(self.token_critic) or train_only_generator:
-            return ce_loss
-        raise NotImplementedError('token-critic loss (mmp.py:726-741) is a later scope row (SURVEY 8f-2)')
+            return tr(x, text_embeds=text_embeds, conditioning_token_ids=cond_token_ids, labels=labels, cond_drop_prob=cond_drop_prob,
+                      ignore_index=ignore_index)
+        # ---- generator loss + the logits of the labelled positions (the only ones the critic input can differ at: mask <= labels)
+        trainable = torch.is_grad_enabled() and tr.to_logits.weight.requires_grad
+        dev = tr.token_emb.weight.device
+        if trainable:
+            if exists(cond_token_ids):
+                raise NotImplementedError('training with conditioning token ids (super-res) is a later scope row (SURVEY 8f-1)')
+            from .training import transformer_loss
+            ce_loss, logits_rows, row_index = transformer_loss(tr, x, text_embeds, labels, ignore_index, cond_drop_prob,
+                                                               grad_sync=tr.grad_sync, return_logits=True)
+        else:
+            ce_loss, logits = tr(x, text_embeds=text_embeds, conditioning_token_ids=cond_token_ids, labels=labels,
+                                 cond_drop_prob=cond_drop_prob, ignore_index=ignore_index, return_logits=True)
+            row_index = torch.nonzero(labels.reshape(-1) != ignore_index).reshape(-1).to(torch.int32)
+            logits_rows = logits.reshape(-1, logits.shape[-1])[row_index.long()].contiguous()
+        with torch.no_grad():
+            # token critic loss (mmp.py:726-741): sample ids from the generator's logits (plain Gumbel sampling, no top-k), the critic
+            # learns to tell which positions differ from the real ids
+            import random as _random
+            T = default(sample_temperature, _random.random())
+            V = logits_rows.shape[1]
+            pred, _ = ops.sample_rows(logits_rows, V, max(T, 1e-10), noise_kind=L.MM_NOISE_PHILOX,
+                                      seed=int(torch.randint(0, 2 ** 62, (1,)).item()))
+            sampled = x.reshape(-1).clone()
+            sampled[row_index.long()] = pred
+            critic_input = torch.where(mask, sampled.reshape(x.shape), x)
+            critic_labels = (ids != critic_input).float()
+        bce_loss = self.token_critic(critic_input, text_embeds=text_embeds, conditioning_token_ids=cond_token_ids, labels=critic_labels,
+                                     cond_drop_prob=cond_drop_prob)
+        return ce_loss + self.critic_loss_weight * bce_loss
 
     def _training_inputs(self, images_or_ids, ignore_index, cond_images, cond_token_ids, texts, text_embeds, cond_drop_prob):
         dev = self.transformer.token_emb.weight.device
@@ -643,7 +671,7 @@ class MaskGit(nn.Module):
             text_embeds = self.transformer.encode_text(texts)
         if self.transformer.self_cond:
             raise NotImplementedError('self-conditioning is a later scope row (SURVEY 8f-2)')
-        return x, labels, text_embeds, cond_token_ids, cond_drop_prob
+        return x, labels, text_embeds, cond_token_ids, cond_drop_prob, ids, mask
 
 
 class Muse(nn.Module):

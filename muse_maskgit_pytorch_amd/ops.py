@@ -410,6 +410,18 @@ def ce_bwd(logits, labels, scale):
     return dl
 
 
+def bce_head_bwd(e, x, y, w):
+    """TokenCritic head + BCE backward: e bf16 [rows, D], x / y fp32 [rows], w fp32 [D] -> (de bf16 [rows, D], dw fp32 [D])."""
+    _chk_cuda(e, x, y, w)
+    rows, D = e.shape
+    de = torch.empty(rows, D, dtype=bf16, device=e.device)
+    dw = torch.empty(D, dtype=torch.float32, device=e.device)
+    ws = torch.empty(L.lib().mm_ln_bwd_workspace_floats(rows, D), dtype=torch.float32, device=e.device)
+    L.check(L.lib().mm_bce_head_bwd(L.stream(), L.ptr(e), e.stride(0), L.ptr(x.contiguous()), L.ptr(y.contiguous()), L.ptr(w.contiguous()), rows, D,
+                                    L.ptr(de), D, L.ptr(dw), L.ptr(ws)), 'mm_bce_head_bwd')
+    return de, dw
+
+
 def embed_bwd(ids, dx, table_rows):
     """ids int64 [B,n], dx fp32 [B*n, D] -> (dtoken fp32 [table_rows, D], dpos fp32 [n, D])."""
     _chk_cuda(ids, dx)

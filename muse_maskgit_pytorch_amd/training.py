@@ -136,19 +136,27 @@ class TransformerTrainFn(torch.autograd.Function):
             x = ops.gemm(z, lw['w2p'], out_f32=True, resid=x)
             ls.update(u3=u3, h=hh, z=z)
             sv['layers'].append((lw, ls))
-        # ---- head on the rows that carry a label (mmp.py:330-343): rows with ignore_index contribute nothing to the loss
         W['wl'] = P['to_logits'].detach().to(bf16).contiguous()
-        e = ops.layernorm(x, f32(P['final.gamma']), cfg['betas']['final'], row_index=row_index)
-        logits = ops.gemm(e, W['wl'], out_f32=True)
-        loss = ops.ce_loss(logits, labels_rows, -100)
+        if cfg['bce']:
+            # ---- TokenCritic head (mmp.py:345-346, 383-386): one logit per position, BCE against float labels over ALL positions
+            e = ops.layernorm(x, f32(P['final.gamma']), cfg['betas']['final'])
+            logits = ops.gemm(e, W['wl'], out_f32=True)                     # [M, 1]
+            loss = ops.bce_loss(logits.reshape(-1), labels_rows)
+        else:
+            # ---- head on the rows that carry a label (mmp.py:330-343): rows with ignore_index contribute nothing to the loss
+            e = ops.layernorm(x, f32(P['final.gamma']), cfg['betas']['final'], row_index=row_index)
+            logits = ops.gemm(e, W['wl'], out_f32=True)
+            loss = ops.ce_loss(logits, labels_rows, -100)
         sv.update(xL=x, e=e, logits=logits, W=W)
         ctx.sv, ctx.cfg = sv, cfg
         ctx.P = {k: v.detach() for k, v in P.items()}
         ctx.ids, ctx.labels_rows, ctx.row_index, ctx.ctx_mask = ids, labels_rows, row_index, ctx_mask
-        return loss.clone()
+        logits_out = logits.detach()
+        ctx.mark_non_differentiable(logits_out)
+        return loss.clone(), logits_out
 
     @staticmethod
-    def backward(ctx, gloss):
+    def backward(ctx, gloss, _glogits=None):
         sv, cfg, P = ctx.sv, ctx.cfg, ctx.P
         b, n, Lt = sv['b'], sv['n'], sv['Lt']
         D, H, F = cfg['dim'], cfg['heads'], cfg['F']
@@ -158,13 +166,18 @@ class TransformerTrainFn(torch.autograd.Function):
         dev = ctx.ids.device
         G = {}
         f32 = lambda t: t.float().contiguous()
-        R = ctx.row_index.numel()
         # ---- head
-        dl = ops.ce_bwd(sv['logits'], ctx.labels_rows, 1.0 / R)
-        G['to_logits'] = _wgrad(dl, sv['e'])
-        de = _dgrad(dl, sv['W']['wl'])
         dres = torch.zeros(M, D, dtype=torch.float32, device=dev)
-        G['final.gamma'] = ops.layernorm_bwd(sv['xL'], de, f32(P['final.gamma']), dres, accumulate=False, row_index=ctx.row_index)
+        if cfg['bce']:
+            de, dwl = ops.bce_head_bwd(sv['e'], sv['logits'].reshape(-1), ctx.labels_rows, sv['W']['wl'].float().reshape(-1))
+            G['to_logits'] = dwl.reshape(1, D)
+            G['final.gamma'] = ops.layernorm_bwd(sv['xL'], de, f32(P['final.gamma']), dres, accumulate=False)
+        else:
+            R = ctx.row_index.numel()
+            dl = ops.ce_bwd(sv['logits'], ctx.labels_rows, 1.0 / R)
+            G['to_logits'] = _wgrad(dl, sv['e'])
+            de = _dgrad(dl, sv['W']['wl'])
+            G['final.gamma'] = ops.layernorm_bwd(sv['xL'], de, f32(P['final.gamma']), dres, accumulate=False, row_index=ctx.row_index)
         dcx = None
         sync = cfg.get('sync')
         if sync is not None:
@@ -245,13 +258,11 @@ class TransformerTrainFn(torch.autograd.Function):
         return (None, None, None, None, None, None, *grads)
 
 
-def transformer_loss(tr, ids, text_embeds, labels, ignore_index, cond_drop_prob, grad_sync=None):
+def transformer_loss(tr, ids, text_embeds, labels, ignore_index, cond_drop_prob, grad_sync=None, return_logits=False):
     """Differentiable CE loss of Transformer.forward(labels=...) (mmp.py:337-346) on the MI355X training path.
     grad_sync: an optional parallel.GradBucketer -- data-parallel gradient averaging overlapped with the backward."""
     if tr.self_cond:
         raise NotImplementedError('training with self-conditioning is a later scope row (SURVEY 8f-2)')
-    if tr.dim_out == 1:
-        raise NotImplementedError('critic (BCE) training is a later scope row (SURVEY 8f-2)')
     dev = tr.token_emb.weight.device
     ids = ids.to(device=dev, dtype=torch.long).contiguous()
     b, n = ids.shape
@@ -262,10 +273,15 @@ def transformer_loss(tr, ids, text_embeds, labels, ignore_index, cond_drop_prob,
         ctx_mask = torch.zeros_like(ctx_mask)
     elif cond_drop_prob > 0.:                                                          # mmp.py:308-310, 393-399
         ctx_mask = ctx_mask & (torch.rand((b, 1), device=dev) < (1. - cond_drop_prob))
-    labels = labels.to(device=dev, dtype=torch.long).reshape(-1)
-    row_index = torch.nonzero(labels != ignore_index).reshape(-1).to(torch.int32).contiguous()
-    assert row_index.numel() > 0, 'no position carries a label'
-    labels_rows = labels[row_index.long()].contiguous()
+    bce = tr.dim_out == 1
+    if bce:                                                                            # TokenCritic: float targets at every position
+        labels_rows = labels.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+        row_index = torch.zeros(1, dtype=torch.int32, device=dev)
+    else:
+        labels = labels.to(device=dev, dtype=torch.long).reshape(-1)
+        row_index = torch.nonzero(labels != ignore_index).reshape(-1).to(torch.int32).contiguous()
+        assert row_index.numel() > 0, 'no position carries a label'
+        labels_rows = labels[row_index.long()].contiguous()
     pr = _Params(tr)
     tb = tr.transformer_blocks
     betas = {'final': tb.norm.beta.float().contiguous()}
@@ -275,5 +291,8 @@ def transformer_loss(tr, ids, text_embeds, labels, ignore_index, cond_drop_prob,
         betas[f'{i}.ff.b1'] = ff[0].beta.float().contiguous()
         betas[f'{i}.ff.b2'] = ff[3].beta.float().contiguous()
     cfg = dict(depth=tb.cfg['depth'], heads=tb.cfg['heads'], dim=tr.dim, F=tb.layers[0][2][4].weight.shape[1], names=pr.names,
-               has_proj=pr.has_proj, betas=betas, sync=grad_sync)
-    return TransformerTrainFn.apply(cfg, ids, te, ctx_mask.to(torch.uint8).contiguous(), labels_rows, row_index, *pr.tensors)
+               has_proj=pr.has_proj, betas=betas, sync=grad_sync, bce=bce)
+    loss, logits = TransformerTrainFn.apply(cfg, ids, te, ctx_mask.to(torch.uint8).contiguous(), labels_rows, row_index, *pr.tensors)
+    if return_logits:
+        return loss, logits, row_index          # logits of the labelled rows only (CE) / of every position (BCE)
+    return loss

@@ -477,3 +477,39 @@ def test_training_step_gradients_match_autograd(golden):
     with torch.no_grad():
         loss2 = t(l['x'].to(DEV), text_embeds=te.to(DEV), labels=l['labels'].to(DEV), ignore_index=-1)
     assert loss2.item() < loss.item()
+
+
+def test_token_critic_training_gradients_and_maskgit_critic_loss(golden):
+    """the TokenCritic's BCE (mmp.py:345-346) through the hand-written backward vs oracle autograd, and the full
+    MaskGit.forward with a token critic (mmp.py:726-741): generator CE + critic BCE, both differentiable."""
+    g, l = golden('transformer_tiny.pt'), golden('loss_tiny.pt')
+    te = g['text_embeds']
+    critic = mm.TokenCritic(num_tokens=512, seq_len=64, dim=128, depth=1, dim_head=64, heads=8, t5_name='t5-small')
+    critic.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in l['critic_sd'].items()})
+    critic = critic.to(DEV)
+    x = l['x'].clamp(max=511)
+    loss = critic(x.to(DEV), text_embeds=te.to(DEV), labels=l['critic_labels'].to(DEV))
+    assert loss.requires_grad and abs(loss.item() - l['critic_bce'].item()) < 2e-3
+    loss.backward()
+    sd = {k: (v.float().clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in l['critic_sd'].items()}
+    ref = O.transformer_loss(sd, dict(depth=1, heads=8), x, te, l['critic_labels'])
+    ref.backward()
+    for name, p in critic.named_parameters():
+        if name.startswith('self_cond_to_init_embed') or name == 'norm.gamma':
+            continue
+        rg, gg = sd[name].grad, p.grad.float().cpu()
+        rel = (gg - rg).abs().max().item() / (rg.abs().max().item() + 1e-20)
+        cos = torch.nn.functional.cosine_similarity(gg.flatten(), rg.flatten(), dim=0).item()
+        assert rel < 5e-2 and cos > 0.99, f'{name}: rel {rel:.3e} cos {cos:.5f}'
+    # MaskGit.forward with a critic: both networks receive gradients
+    _, t = _tiny_transformer(golden)
+    for p in critic.parameters():
+        p.grad = None
+    mg = mm.MaskGit(image_size=128, transformer=t, vae=None, token_critic=critic)
+    ids = torch.randint(0, 512, (2, 64), generator=torch.Generator().manual_seed(4))
+    total = mg(ids.to(DEV), text_embeds=te.to(DEV), cond_drop_prob=0.)
+    total.backward()
+    assert torch.isfinite(total) and t.to_logits.weight.grad is not None and critic.to_logits.weight.grad is not None
+    assert t.to_logits.weight.grad.abs().max() > 0 and critic.to_logits.weight.grad.abs().max() > 0
+    with torch.no_grad():
+        assert torch.isfinite(mg(ids.to(DEV), text_embeds=te.to(DEV), cond_drop_prob=0.))
