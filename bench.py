@@ -111,7 +111,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get('MM_BENCH_FORCE_DIST'):      # (the env switch exercises the RCCL path on a single GPU)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
@@ -130,7 +130,7 @@ def main():
         ids = mg.generate([''] * B, timesteps=T, cond_scale=3, text_embeds=te, seed=1000 + i, row_offset=rank * B, return_ids=True)
         e_mid = torch.cuda.Event(enable_timing=True)
         e_mid.record()
-        all_ids = allgather_ids(ids, dist) if world > 1 else ids      # one RCCL all-gather of token grids
+        all_ids = allgather_ids(ids, dist) if dist is not None else ids      # one RCCL all-gather of token grids
         images = mg.vae.decode_from_ids(ids)
         return all_ids, images, e_mid
 
