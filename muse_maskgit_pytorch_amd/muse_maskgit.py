@@ -315,10 +315,9 @@ class Transformer(nn.Module):
             assert exists(texts) ^ exists(text_embeds)
             if exists(texts):
                 text_embeds = self.encode_text(texts)
-            if exists(conditioning_token_ids):
-                raise NotImplementedError('training with conditioning token ids (super-res) is a later scope row (SURVEY 8f-1)')
             from .training import transformer_loss
-            return transformer_loss(self, x, text_embeds, labels, ignore_index, cond_drop_prob, grad_sync=getattr(self, 'grad_sync', None))
+            return transformer_loss(self, x, text_embeds, labels, ignore_index, cond_drop_prob, grad_sync=getattr(self, 'grad_sync', None),
+                                    self_cond_embed=self_cond_embed, conditioning_token_ids=conditioning_token_ids)
         with torch.no_grad():
             return self._forward_no_grad(x, return_embed, return_logits, labels, ignore_index, self_cond_embed, cond_drop_prob,
                                          conditioning_token_ids, texts, text_embeds, _embed_only)
@@ -606,21 +605,27 @@ class MaskGit(nn.Module):
             x, labels, text_embeds, cond_token_ids, cond_drop_prob, ids, mask = self._training_inputs(
                 images_or_ids, ignore_index, cond_images, cond_token_ids, texts, text_embeds, cond_drop_prob)
         tr = self.transformer
+        # self conditioning (mmp.py:694-707): with probability self_cond_prob the embed of a first, gradient-free pass is fed back
+        self_cond_embed = None
+        if tr.self_cond:
+            import random as _random
+            if _random.random() < self.self_cond_prob:
+                with torch.no_grad():
+                    _, self_cond_embed = tr(x, text_embeds=text_embeds, conditioning_token_ids=cond_token_ids, cond_drop_prob=0., return_embed=True)
         if not exists(self.token_critic) or train_only_generator:
-            return tr(x, text_embeds=text_embeds, conditioning_token_ids=cond_token_ids, labels=labels, cond_drop_prob=cond_drop_prob,
-                      ignore_index=ignore_index)
+            return tr(x, text_embeds=text_embeds, self_cond_embed=self_cond_embed, conditioning_token_ids=cond_token_ids, labels=labels,
+                      cond_drop_prob=cond_drop_prob, ignore_index=ignore_index)
         # ---- generator loss + the logits of the labelled positions (the only ones the critic input can differ at: mask <= labels)
         trainable = torch.is_grad_enabled() and tr.to_logits.weight.requires_grad
         dev = tr.token_emb.weight.device
         if trainable:
-            if exists(cond_token_ids):
-                raise NotImplementedError('training with conditioning token ids (super-res) is a later scope row (SURVEY 8f-1)')
             from .training import transformer_loss
             ce_loss, logits_rows, row_index = transformer_loss(tr, x, text_embeds, labels, ignore_index, cond_drop_prob,
-                                                               grad_sync=tr.grad_sync, return_logits=True)
+                                                               grad_sync=tr.grad_sync, return_logits=True, self_cond_embed=self_cond_embed,
+                                                               conditioning_token_ids=cond_token_ids)
         else:
-            ce_loss, logits = tr(x, text_embeds=text_embeds, conditioning_token_ids=cond_token_ids, labels=labels,
-                                 cond_drop_prob=cond_drop_prob, ignore_index=ignore_index, return_logits=True)
+            ce_loss, logits = tr(x, text_embeds=text_embeds, self_cond_embed=self_cond_embed, conditioning_token_ids=cond_token_ids,
+                                 labels=labels, cond_drop_prob=cond_drop_prob, ignore_index=ignore_index, return_logits=True)
             row_index = torch.nonzero(labels.reshape(-1) != ignore_index).reshape(-1).to(torch.int32)
             logits_rows = logits.reshape(-1, logits.shape[-1])[row_index.long()].contiguous()
         with torch.no_grad():
@@ -669,8 +674,6 @@ class MaskGit(nn.Module):
         x = torch.where(mask, torch.full_like(ids, mask_id), ids)
         if exists(texts):
             text_embeds = self.transformer.encode_text(texts)
-        if self.transformer.self_cond:
-            raise NotImplementedError('self-conditioning is a later scope row (SURVEY 8f-2)')
         return x, labels, text_embeds, cond_token_ids, cond_drop_prob, ids, mask
 
 

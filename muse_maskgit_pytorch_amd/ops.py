@@ -422,13 +422,13 @@ def bce_head_bwd(e, x, y, w):
     return de, dw
 
 
-def embed_bwd(ids, dx, table_rows):
-    """ids int64 [B,n], dx fp32 [B*n, D] -> (dtoken fp32 [table_rows, D], dpos fp32 [n, D])."""
-    _chk_cuda(ids, dx)
+def embed_bwd(ids, dx, table_rows, dtoken=None):
+    """ids int64 [B,n], dx fp32 [B*n, D] -> (dtoken fp32 [table_rows, D], dpos fp32 [n, D]); dtoken: accumulate into this table."""
+    _chk_cuda(ids, dx, dtoken)
     B, n = ids.shape
     D = dx.shape[1]
     assert dx.is_contiguous() and dx.dtype == torch.float32
-    dtok = torch.zeros(table_rows, D, dtype=torch.float32, device=dx.device)
+    dtok = dtoken if dtoken is not None else torch.zeros(table_rows, D, dtype=torch.float32, device=dx.device)
     dpos = torch.empty(n, D, dtype=torch.float32, device=dx.device)
     L.check(L.lib().mm_embed_bwd(L.stream(), L.ptr(ids.contiguous()), B, n, D, L.ptr(dx), L.ptr(dtok), L.ptr(dpos)), 'mm_embed_bwd')
     return dtok, dpos

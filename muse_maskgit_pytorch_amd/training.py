@@ -5,8 +5,8 @@ torch.autograd.Function, so that `loss = maskgit(images_or_ids, ...); loss.backw
 Every arithmetic step is a C-ABI operator of libmuse_hip.so (include/muse_hip.h): bf16 MFMA GEMMs (activation gradients
 bf16, parameter gradients fp32), the MFMA attention backward, LayerNorm / GEGLU / cross-entropy / embedding gradient kernels.
 torch supplies memory, the autograd tape and the optimizer; parameters stay fp32 nn.Parameters (bf16 copies are packed per
-step), gradients land in .grad like with the reference.  First scope: the base model -- no self-conditioning, no
-super-res conditioning ids (those raise).  Linear layers:  dX = dY W  and  dW = dY^T X  are NT GEMMs on transposed copies.
+step), gradients land in .grad like with the reference.  Covers the generator (cross-entropy), the TokenCritic (BCE),
+self-conditioning and super-res conditioning ids.  Linear layers:  dX = dY W  and  dW = dY^T X  are NT GEMMs on transposed copies.
 """
 import torch
 
@@ -67,19 +67,60 @@ class _Params:
             add(f'{i}.ff.w2', ff[4].weight)
         add('final.gamma', tb.norm.gamma)
         add('to_logits', tr.to_logits.weight)
+        if tr.self_cond:                                       # mmp.py:237-238, 325-328
+            ff = tr.self_cond_to_init_embed
+            add('sc.ff.g1', ff[0].gamma)
+            add('sc.ff.w1', ff[1].weight)
+            add('sc.ff.g2', ff[3].gamma)
+            add('sc.ff.w2', ff[4].weight)
+
+
+def _ff_forward(P, pre, betas, x_in, resid, dev):
+    """FeedForward (mmp.py:79-89) on fp32 rows x_in, output added to `resid`; returns (y, weights, saved)."""
+    f32 = lambda t: t.detach().float().contiguous()
+    w1, w2 = P[pre + 'w1'].detach(), P[pre + 'w2'].detach()
+    F, D = w2.shape[1], w1.shape[1]
+    Fp = _pad64(F)
+    w1p = torch.zeros(2 * Fp, D, dtype=bf16, device=dev)
+    w1p[:F] = w1[:F]
+    w1p[Fp:Fp + F] = w1[F:]
+    w2p = ops.pad_cols(w2.to(bf16), 64)
+    u = ops.layernorm(x_in, f32(P[pre + 'g1']), betas[pre + 'b1'])
+    h = ops.gemm(u, w1p)
+    z = ops.geglu_ln(h, F, f32(P[pre + 'g2']), betas[pre + 'b2'])
+    y = ops.gemm(z, w2p, out_f32=True, resid=resid)
+    return y, dict(w1p=w1p, w2p=w2p), dict(x_in=x_in, u=u, h=h, z=z, F=F)
+
+
+def _ff_backward(P, pre, lw, ls, dres, G, need_dx=True):
+    """dres: fp32 gradient of the FF's output rows; fills G[pre + ...]; adds the input gradient into dres when need_dx."""
+    f32 = lambda t: t.float().contiguous()
+    F = ls['F']
+    Fp = _pad64(F)
+    dy = ops.to_bf16(dres)
+    dz = _dgrad(dy, lw['w2p'])
+    G[pre + 'w2'] = _wgrad(dy, ls['z'])[:, :F]
+    dh, G[pre + 'g2'] = ops.geglu_ln_bwd(ls['h'], dz, F, f32(P[pre + 'g2']))
+    dw1p = _wgrad(dh, ls['u'])
+    G[pre + 'w1'] = torch.cat([dw1p[:F], dw1p[Fp:Fp + F]], 0)
+    du = _dgrad(dh, lw['w1p'])
+    if need_dx:
+        G[pre + 'g1'] = ops.layernorm_bwd(ls['x_in'], du, f32(P[pre + 'g1']), dres)
+    else:
+        scratch = torch.empty_like(dres)
+        G[pre + 'g1'] = ops.layernorm_bwd(ls['x_in'], du, f32(P[pre + 'g1']), scratch, accumulate=False)
 
 
 class TransformerTrainFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, cfg, ids, te, ctx_mask, labels_rows, row_index, *params):
+    def forward(ctx, cfg, ids, te, ctx_mask, labels_rows, row_index, sce, cond_ids, *params):
         """cfg: dict(depth, heads, dim, F, names, betas ...); ids int64 [b, n]; te fp32 [b, L, td]; ctx_mask uint8 [b, L];
         row_index int32 [R] = flat positions with a label, labels_rows int64 [R]."""
         P = dict(zip(cfg['names'], params))
         dev = ids.device
         b, n = ids.shape
-        D, H, F = cfg['dim'], cfg['heads'], cfg['F']
+        D, H = cfg['dim'], cfg['heads']
         I = H * 64
-        Fp = _pad64(F)
         M = b * n
         Lt = te.shape[1]
         W = {}           # bf16 operand copies of this step
@@ -93,7 +134,19 @@ class TransformerTrainFn(torch.autograd.Function):
             cx = ops.gemm(te_b, W['tp'])                                                                             # mmp.py:302
         else:
             cx = te_b
-        sv['te_b'], sv['cx'] = te_b, cx
+        nc = 0
+        if cond_ids is not None:                                # mmp.py:314-318: conditioning image ids join the context, always attended
+            nc = cond_ids.shape[1]
+            cemb = P['token_emb'].detach().to(bf16)[cond_ids.reshape(-1)].reshape(b, nc, D)
+            cx = torch.cat([cx.reshape(b, Lt, D), cemb], 1).reshape(b * (Lt + nc), D).contiguous()
+            ctx_mask = torch.cat([ctx_mask, torch.ones(b, nc, dtype=ctx_mask.dtype, device=dev)], 1).contiguous()
+        Lc = Lt + nc
+        sv['te_b'], sv['cx'], sv['Lc'] = te_b, cx, Lc
+        if cfg['self_cond']:                                    # mmp.py:325-328
+            if sce is None:
+                sce = torch.zeros(M, D, dtype=torch.float32, device=dev)
+            x, lwsc, lssc = _ff_forward(P, 'sc.ff.', cfg['betas'], sce, x, dev)
+            sv['sc'] = (lwsc, lssc)
         for i in range(cfg['depth']):
             lw, ls = {}, {}
             # ---- self attention (mmp.py:137-162, 186)
@@ -117,24 +170,14 @@ class TransformerTrainFn(torch.autograd.Function):
             u2 = ops.layernorm(x, f32(P[c + 'norm.gamma']), cfg['betas'][c])
             q2 = ops.gemm(u2, lw['wq2'])
             kv2 = ops.gemm(cx, lw['wkv2'])
-            o2 = ops.attend(_heads(q2, b, n, H), _heads(kv2, b, Lt, H), _heads(kv2, b, Lt, H, I), key_mask=ctx_mask, normalize=True,
+            o2 = ops.attend(_heads(q2, b, n, H), _heads(kv2, b, Lc, H), _heads(kv2, b, Lc, H, I), key_mask=ctx_mask, normalize=True,
                             q_scale=f32(P[c + 'q_scale']), k_scale=f32(P[c + 'k_scale']), null_k=f32(P[c + 'null_kv'][0, :, 0]),
                             null_v=f32(P[c + 'null_kv'][1, :, 0]), out_rows=True)
             x = ops.gemm(o2, lw['wo2'], out_f32=True, resid=x)
             ls.update(u2=u2, q2=q2, kv2=kv2, o2=o2)
             # ---- feed forward (mmp.py:79-89, 188)
-            w1 = P[f'{i}.ff.w1'].detach()
-            w1p = torch.zeros(2 * Fp, D, dtype=bf16, device=dev)
-            w1p[:F] = w1[:F]
-            w1p[Fp:Fp + F] = w1[F:]
-            lw['w1p'] = w1p
-            lw['w2p'] = ops.pad_cols(P[f'{i}.ff.w2'].detach().to(bf16), 64)
-            ls['x2'] = x
-            u3 = ops.layernorm(x, f32(P[f'{i}.ff.g1']), cfg['betas'][f'{i}.ff.b1'])
-            hh = ops.gemm(u3, w1p)
-            z = ops.geglu_ln(hh, F, f32(P[f'{i}.ff.g2']), cfg['betas'][f'{i}.ff.b2'])
-            x = ops.gemm(z, lw['w2p'], out_f32=True, resid=x)
-            ls.update(u3=u3, h=hh, z=z)
+            x, lwf, lsf = _ff_forward(P, f'{i}.ff.', cfg['betas'], x, x, dev)
+            lw['ff'], ls['ff'] = lwf, lsf
             sv['layers'].append((lw, ls))
         W['wl'] = P['to_logits'].detach().to(bf16).contiguous()
         if cfg['bce']:
@@ -150,7 +193,7 @@ class TransformerTrainFn(torch.autograd.Function):
         sv.update(xL=x, e=e, logits=logits, W=W)
         ctx.sv, ctx.cfg = sv, cfg
         ctx.P = {k: v.detach() for k, v in P.items()}
-        ctx.ids, ctx.labels_rows, ctx.row_index, ctx.ctx_mask = ids, labels_rows, row_index, ctx_mask
+        ctx.ids, ctx.labels_rows, ctx.row_index, ctx.ctx_mask, ctx.cond_ids = ids, labels_rows, row_index, ctx_mask, cond_ids
         logits_out = logits.detach()
         ctx.mark_non_differentiable(logits_out)
         return loss.clone(), logits_out
@@ -158,13 +201,13 @@ class TransformerTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss, _glogits=None):
         sv, cfg, P = ctx.sv, ctx.cfg, ctx.P
-        b, n, Lt = sv['b'], sv['n'], sv['Lt']
-        D, H, F = cfg['dim'], cfg['heads'], cfg['F']
+        b, n, Lt, Lc = sv['b'], sv['n'], sv['Lt'], sv['Lc']
+        D, H = cfg['dim'], cfg['heads']
         I = H * 64
-        Fp = _pad64(F)
         M = b * n
         dev = ctx.ids.device
         G = {}
+        need_dcx = cfg['has_proj'] or ctx.cond_ids is not None
         f32 = lambda t: t.float().contiguous()
         # ---- head
         dres = torch.zeros(M, D, dtype=torch.float32, device=dev)
@@ -187,14 +230,7 @@ class TransformerTrainFn(torch.autograd.Function):
         for i in reversed(range(cfg['depth'])):
             lw, ls = sv['layers'][i]
             # ---- feed forward
-            dy = ops.to_bf16(dres)
-            dz = _dgrad(dy, lw['w2p'])
-            G[f'{i}.ff.w2'] = _wgrad(dy, ls['z'])[:, :F]
-            dh, G[f'{i}.ff.g2'] = ops.geglu_ln_bwd(ls['h'], dz, F, f32(P[f'{i}.ff.g2']))
-            du3 = _dgrad(dh, lw['w1p'])
-            dw1p = _wgrad(dh, ls['u3'])
-            G[f'{i}.ff.w1'] = torch.cat([dw1p[:F], dw1p[Fp:Fp + F]], 0)
-            G[f'{i}.ff.g1'] = ops.layernorm_bwd(ls['x2'], du3, f32(P[f'{i}.ff.g1']), dres)
+            _ff_backward(P, f'{i}.ff.', lw['ff'], ls['ff'], dres, G)
             # ---- cross attention
             c = f'{i}.ca.'
             dy = ops.to_bf16(dres)
@@ -202,20 +238,19 @@ class TransformerTrainFn(torch.autograd.Function):
             G[c + 'to_out.weight'] = _wgrad(dy, ls['o2'])
             qs, ks = f32(P[c + 'q_scale']), f32(P[c + 'k_scale'])
             nk, nv = f32(P[c + 'null_kv'][0, :, 0]), f32(P[c + 'null_kv'][1, :, 0])
-            dqn, dkn, dv, dnk, dnv = ops.attention_bwd(_heads(ls['q2'], b, n, H), _heads(ls['kv2'], b, Lt, H), _heads(ls['kv2'], b, Lt, H, I),
+            dqn, dkn, dv, dnk, dnv = ops.attention_bwd(_heads(ls['q2'], b, n, H), _heads(ls['kv2'], b, Lc, H), _heads(ls['kv2'], b, Lc, H, I),
                                                        _heads(ls['o2'], b, n, H), _heads(do2, b, n, H), qs, ks, nk, nv, key_mask=ctx.ctx_mask)
             dq2, dqs = ops.qk_norm_bwd(ls['q2'], dqn.reshape(M, I), qs, H)
-            dk2, dks = ops.qk_norm_bwd(ls['kv2'], dkn.reshape(b * Lt, I), ks, H)
+            dk2, dks = ops.qk_norm_bwd(ls['kv2'], dkn.reshape(b * Lc, I), ks, H)
             dnull, dks_n = ops.qk_norm_bwd(None, None, ks, H, x_f32=nk, dy_f32=dnk)
             G[c + 'q_scale'], G[c + 'k_scale'] = dqs, dks + dks_n
             G[c + 'null_kv'] = torch.stack([ops.colsum(dnull.reshape(b, H * 64)), ops.colsum(dnv.reshape(b, H * 64))], 0).reshape(2, H, 1, 64)
-            dkv2 = torch.cat([dk2, dv.reshape(b * Lt, I)], 1)
+            dkv2 = torch.cat([dk2, dv.reshape(b * Lc, I)], 1)
             du2 = _dgrad(dq2, lw['wq2'])
             G[c + 'to_q.weight'] = _wgrad(dq2, ls['u2'])
             G[c + 'to_kv.weight'] = _wgrad(dkv2, sv['cx'])
-            if cfg['has_proj']:
-                d1 = ops.gemm(dkv2, _t(lw['wkv2']), out_f32=True, resid=dcx)
-                dcx = d1
+            if need_dcx:
+                dcx = ops.gemm(dkv2, _t(lw['wkv2']), out_f32=True, resid=dcx)
             G[c + 'norm.gamma'] = ops.layernorm_bwd(ls['x1'], du2, f32(P[c + 'norm.gamma']), dres)
             # ---- self attention
             a = f'{i}.sa.'
@@ -239,14 +274,20 @@ class TransformerTrainFn(torch.autograd.Function):
             G[a + 'norm.gamma'] = ops.layernorm_bwd(ls['x0'], du, f32(P[a + 'norm.gamma']), dres)
             if sync is not None:      # this layer's gradients are final: average them across ranks while the layers below run
                 sync.push([G[k] for k in cfg['names'] if k.startswith(f'{i}.')])
+        if cfg['self_cond']:
+            _ff_backward(P, 'sc.ff.', sv['sc'][0], sv['sc'][1], dres, G, need_dx=False)       # the embed fed back is detached (mmp.py:707)
         # ---- embeddings / text projection
         G['token_emb'], G['pos_emb'] = ops.embed_bwd(ctx.ids, dres, P['token_emb'].shape[0])
+        if ctx.cond_ids is not None:                            # the conditioning ids were embedded with the same table (mmp.py:316)
+            nc = ctx.cond_ids.shape[1]
+            dcond = dcx.reshape(b, Lc, D)[:, Lt:].reshape(b * nc, D).contiguous()
+            ops.embed_bwd(ctx.cond_ids, dcond, P['token_emb'].shape[0], dtoken=G['token_emb'])
         if n < P['pos_emb'].shape[0]:
             full = torch.zeros_like(P['pos_emb'], dtype=torch.float32)
             full[:n] = G['pos_emb']
             G['pos_emb'] = full
         if cfg['has_proj']:
-            G['text_proj'] = _wgrad(ops.to_bf16(dcx), sv['te_b'])
+            G['text_proj'] = _wgrad(ops.to_bf16(dcx.reshape(b, Lc, D)[:, :Lt].reshape(b * Lt, D).contiguous()), sv['te_b'])
         if sync is not None:
             sync.push([G[k] for k in ('token_emb', 'pos_emb', 'text_proj') if k in G])
             sync.finish()
@@ -255,14 +296,13 @@ class TransformerTrainFn(torch.autograd.Function):
             g = G[name].to(P[name].dtype).reshape(P[name].shape)
             grads.append(g * gloss if gloss.numel() == 1 and float(gloss) != 1.0 else g)
         ctx.sv = None
-        return (None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, None, *grads)
 
 
-def transformer_loss(tr, ids, text_embeds, labels, ignore_index, cond_drop_prob, grad_sync=None, return_logits=False):
+def transformer_loss(tr, ids, text_embeds, labels, ignore_index, cond_drop_prob, grad_sync=None, return_logits=False,
+                     self_cond_embed=None, conditioning_token_ids=None):
     """Differentiable CE loss of Transformer.forward(labels=...) (mmp.py:337-346) on the MI355X training path.
     grad_sync: an optional parallel.GradBucketer -- data-parallel gradient averaging overlapped with the backward."""
-    if tr.self_cond:
-        raise NotImplementedError('training with self-conditioning is a later scope row (SURVEY 8f-2)')
     dev = tr.token_emb.weight.device
     ids = ids.to(device=dev, dtype=torch.long).contiguous()
     b, n = ids.shape
@@ -290,9 +330,17 @@ def transformer_loss(tr, ids, text_embeds, labels, ignore_index, cond_drop_prob,
         betas[f'{i}.ca.'] = ca.norm.beta.float().contiguous()
         betas[f'{i}.ff.b1'] = ff[0].beta.float().contiguous()
         betas[f'{i}.ff.b2'] = ff[3].beta.float().contiguous()
-    cfg = dict(depth=tb.cfg['depth'], heads=tb.cfg['heads'], dim=tr.dim, F=tb.layers[0][2][4].weight.shape[1], names=pr.names,
-               has_proj=pr.has_proj, betas=betas, sync=grad_sync, bce=bce)
-    loss, logits = TransformerTrainFn.apply(cfg, ids, te, ctx_mask.to(torch.uint8).contiguous(), labels_rows, row_index, *pr.tensors)
+    betas['sc.ff.b1'] = tr.self_cond_to_init_embed[0].beta.float().contiguous()
+    betas['sc.ff.b2'] = tr.self_cond_to_init_embed[3].beta.float().contiguous()
+    sce = None
+    if tr.self_cond and self_cond_embed is not None:
+        sce = self_cond_embed.detach().to(device=dev, dtype=torch.float32).reshape(b * n, tr.dim).contiguous()
+    cond_ids = None
+    if conditioning_token_ids is not None:
+        cond_ids = conditioning_token_ids.reshape(b, -1).to(device=dev, dtype=torch.long).contiguous()
+    cfg = dict(depth=tb.cfg['depth'], heads=tb.cfg['heads'], dim=tr.dim, names=pr.names, has_proj=pr.has_proj, betas=betas,
+               sync=grad_sync, bce=bce, self_cond=bool(tr.self_cond))
+    loss, logits = TransformerTrainFn.apply(cfg, ids, te, ctx_mask.to(torch.uint8).contiguous(), labels_rows, row_index, sce, cond_ids, *pr.tensors)
     if return_logits:
         return loss, logits, row_index          # logits of the labelled rows only (CE) / of every position (BCE)
     return loss

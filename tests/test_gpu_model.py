@@ -513,3 +513,44 @@ def test_token_critic_training_gradients_and_maskgit_critic_loss(golden):
     assert t.to_logits.weight.grad.abs().max() > 0 and critic.to_logits.weight.grad.abs().max() > 0
     with torch.no_grad():
         assert torch.isfinite(mg(ids.to(DEV), text_embeds=te.to(DEV), cond_drop_prob=0.))
+
+
+def test_training_self_cond_and_super_res_gradients():
+    """Training-path coverage of the two remaining reference configurations: self-conditioning (mmp.py:325-328,
+    694-707) and super-res conditioning ids joined to the context (mmp.py:314-318), gradients vs oracle autograd."""
+    torch.manual_seed(11)
+    t = mm.MaskGitTransformer(num_tokens=512, seq_len=64, dim=128, depth=1, dim_head=64, heads=8, t5_name='t5-small', self_cond=True)
+    with torch.no_grad():
+        for p in t.parameters():
+            p.copy_(p.to(torch.bfloat16).float())
+    sd_cpu = {k: v.detach().clone() for k, v in t.state_dict().items()}
+    t = t.to(DEV)
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, 513, (2, 64), generator=g)
+    labels = torch.where(ids == 512, torch.randint(0, 512, (2, 64), generator=g), torch.full_like(ids, -1))
+    labels[0, :3] = torch.tensor([5, 6, 7]); ids[0, :3] = 512
+    te = torch.randn(2, 6, 512, generator=g)
+    te[1, 4:] = 0
+    sce = torch.randn(2, 64, 128, generator=g)
+    cond = torch.randint(0, 512, (2, 4, 4), generator=g)
+    loss = t(ids.to(DEV), text_embeds=te.to(DEV), labels=labels.to(DEV), ignore_index=-1, self_cond_embed=sce.to(DEV),
+             conditioning_token_ids=cond.to(DEV))
+    loss.backward()
+    sd = {k: (v.float().clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd_cpu.items()}
+    ref = O.transformer_loss(sd, dict(depth=1, heads=8, self_cond=True), ids, te, labels, ignore_index=-1, self_cond_embed=sce,
+                             conditioning_token_ids=cond)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 2e-2 * abs(ref.item())
+    for name, p in t.named_parameters():
+        if name == 'norm.gamma':
+            continue
+        rg, gg = sd[name].grad, p.grad.float().cpu()
+        rel = (gg - rg).abs().max().item() / (rg.abs().max().item() + 1e-20)
+        cos = torch.nn.functional.cosine_similarity(gg.flatten(), rg.flatten(), dim=0).item()
+        assert rel < 5e-2 and cos > 0.99, f'{name}: rel {rel:.3e} cos {cos:.5f}'
+    # MaskGit.forward with self-conditioning switched on end to end
+    mg = mm.MaskGit(image_size=128, transformer=t, vae=None, self_cond_prob=1.0)
+    t.zero_grad()
+    l2 = mg(torch.randint(0, 512, (2, 64), generator=g).to(DEV), text_embeds=te.to(DEV))
+    l2.backward()
+    assert torch.isfinite(l2) and t.self_cond_to_init_embed[1].weight.grad.abs().max() > 0
