@@ -53,6 +53,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {      // n is wave-uniform
         case 4: __builtin_amdgcn_s_waitcnt(0x0F74); break;
         case 5: __builtin_amdgcn_s_waitcnt(0x0F75); break;
         case 6: __builtin_amdgcn_s_waitcnt(0x0F76); break;
+        case 8: __builtin_amdgcn_s_waitcnt(0x0F78); break;
         default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
     }
 }
@@ -65,6 +66,12 @@ __device__ __forceinline__ uint4 lds_read_b128_raw(const unsigned char* ptr) {
     u32x4_t v;
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
     return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+// the logits are written once and read once by the sampler, 1.35 GB per launch against 4 MiB of L2 per XCD: a non-temporal store
+// keeps them from evicting the weight / activation tiles the other CUs of the XCD are about to re-read
+__device__ __forceinline__ void store_stream(float* ptr, const uint4 v) {
+    __builtin_nontemporal_store(u32x4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_t*>(ptr));
 }
 
 struct LoadCur {
@@ -130,6 +137,7 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
     }
     LOAD_NEXT(0);
     LOAD_NEXT(1);
+    LOAD_NEXT(2);
 
     f32x4_t acc[4][8];
     f32x4_t held[2][4];             // second half of the previous tile's output (tokens 32..63 of this wave), combined
@@ -152,78 +160,96 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
 #define PIECE_ROW(q_) ((q_) * 8 + wid)
 #define PIECE_TOKEN(hrow_, half_) (pm0 + ((hrow_) >> 5) * 64 + (half_) * 32 + ((hrow_) & 31))
 
+    // Software pipeline of one k-step (fragments: afA/afB = the 4 weight fragments of the current / next step, p0 / p1 = two
+    // 2-fragment activation buffers).  Entering step g, afA and p0 (token pair 0) of step g are in registers:
+    //     read p1 <- pair 1 | MFMA pair 0 | read p0 <- pair 2 | MFMA pair 1 | read p1 <- pair 3
+    //     wait (DMA of step g+1 landed; my reads of stage g done) - BARRIER - stage g is free: issue the DMA of step g+3
+    //     MFMA pair 2 | read afB, p0 <- step g+1 (weights, pair 0) | MFMA pair 3 | store the piece read after the barrier
+    // so every MFMA group runs with the reads of a later group in flight, also across the barrier.
+#define X_FRAG(st_, j_) (*reinterpret_cast<const u32x4_t*>(smem + (st_) * STG_B + wm * 8192 + rd + (j_) * 1024))
+#define W_FRAG(st_, i_) (*reinterpret_cast<const u32x4_t*>(smem + (st_) * STG_B + XT_B + wn * 4096 + rd + (i_) * 1024))
+#define MFMA_PAIR(af_, src_, j_)                                                                               \
+    if (!ABL(p, 4)) {                                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                         \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                          \
+            _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                      \
+                acc[a][2 * (j_) + h] = mfma16(af_[a], src_[h], acc[a][2 * (j_) + h]);                          \
+        __builtin_amdgcn_s_setprio(0);                                                                         \
+    } else { asm volatile("" ::"v"(af_[0]), "v"(af_[1]), "v"(af_[2]), "v"(af_[3]), "v"(src_[0]), "v"(src_[1])); }
+#define STEP(AF_, AFN_)                                                                                        \
+    {                                                                                                          \
+        const int st_ = g % NST, stn_ = (g + 1) % NST;                                                         \
+        p1[0] = X_FRAG(st_, 2); p1[1] = X_FRAG(st_, 3);                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        MFMA_PAIR(AF_, p0, 0)                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        p0[0] = X_FRAG(st_, 4); p0[1] = X_FRAG(st_, 5);                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        MFMA_PAIR(AF_, p1, 1)                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        p1[0] = X_FRAG(st_, 6); p1[1] = X_FRAG(st_, 7);                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        /* step g+1 has landed once only what this wave issued after ITS DMA can be in flight: the store of step g-2, the */ \
+        /* 4 DMA instructions of step g+2, the store of step g-1 */                                            \
+        wait_vmcnt(((g + 2 < steps_total && !ABL(p, 2)) ? 4 : 0) + st1 + st2);                                 \
+        WAIT_LGKM0();                                                                                          \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        if (kt == KH && have_prev) {                                                                           \
+            /* every wave has read the last piece of the first half (step KH-1 at the latest): second half -> ct */ \
+            HELD_TO_CT();                                                                                      \
+            WAIT_LGKM0();                                                                                      \
+            __builtin_amdgcn_s_barrier();                                                                      \
+        }                                                                                                      \
+        /* this step's piece of the previous tile: first half during steps 0..7, second half during steps KH..KH+7 */ \
+        const int half_ = kt >= KH ? 1 : 0;                                                                    \
+        const int q_ = kt - (half_ ? KH : 0);                                                                  \
+        const int hrow_ = PIECE_ROW(q_);                                                                       \
+        const int ptok_ = PIECE_TOKEN(hrow_, half_);                                                           \
+        const bool piece_ = have_prev && q_ < 8 && ptok_ < p.M && !ABL(p, 1);      /* wave-uniform */          \
+        uint4 pv_ = make_uint4(0, 0, 0, 0);                                                                    \
+        if (piece_) pv_ = lds_read_b128_raw(ct + hrow_ * 1024 + ((lane ^ (hrow_ & 7)) << 4));                  \
+        float* pv_ptr_ = reinterpret_cast<float*>(p.out) + (size_t)ptok_ * p.ldc + pn0 + lane * 4;             \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        LOAD_NEXT(st_);                                     /* step g+3 into the stage just consumed */        \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        MFMA_PAIR(AF_, p0, 2)                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        if (g + 1 < steps_total) {                                                                             \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) AFN_[i] = W_FRAG(stn_, i);                           \
+            p0[0] = X_FRAG(stn_, 0); p0[1] = X_FRAG(stn_, 1);                                                  \
+        }                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        MFMA_PAIR(AF_, p1, 3)                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        st2 = st1;                                                                                             \
+        st1 = 0;                                                                                               \
+        if (piece_) {                                                                                          \
+            WAIT_LGKM0();                                       /* the raw read of pv_ (the fragments are long there) */ \
+            __builtin_amdgcn_sched_barrier(0);                                                                 \
+            store_stream(pv_ptr_, pv_);                                                                        \
+            st1 = 1;                                                                                           \
+        }                                                                                                      \
+        ++g;                                                                                                   \
+        ++kt;                                                                                                  \
+    }
+
+    // prologue: step 0 has landed once only the DMA of steps 1 and 2 (8 instructions) is in flight
+    wait_vmcnt(steps_total > 2 ? 8 : (steps_total > 1 ? 4 : 0));
+    __builtin_amdgcn_s_barrier();
+    u32x4_t afA[4], afB[4], p0[2], p1[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) afA[i] = W_FRAG(0, i);
+    p0[0] = X_FRAG(0, 0); p0[1] = X_FRAG(0, 1);
+
     while (true) {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = 0; b < 8; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        for (int kt = 0; kt < KT; ++kt) {
-            // stage g % 3 has landed once only what this wave issued AFTER its DMA of step g can still be in flight: the store of
-            // step g-2, the 4 DMA instructions of step g+1, the store of step g-1
-            wait_vmcnt(((g + 1 < steps_total && !ABL(p, 2)) ? 4 : 0) + st1 + st2);
-            WAIT_LGKM0();
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt == KH && have_prev) {
-                // every wave has read the last piece of the first half (step KH-1 at the latest): second half -> ct
-                HELD_TO_CT();
-                WAIT_LGKM0();
-                __builtin_amdgcn_s_barrier();
-            }
-            // this step's piece of the previous tile: first half during steps 0..7, second half during steps KH..KH+7
-            const int half = kt >= KH ? 1 : 0;
-            const int q = kt - (half ? KH : 0);
-            const int hrow = PIECE_ROW(q);
-            const int ptok = PIECE_TOKEN(hrow, half);
-            const bool piece = have_prev && q < 8 && ptok < p.M && !ABL(p, 1);      // wave-uniform
-            uint4 pv = make_uint4(0, 0, 0, 0);
-            if (piece) pv = lds_read_b128_raw(ct + hrow * 1024 + ((lane ^ (hrow & 7)) << 4));
-            float* pv_ptr = reinterpret_cast<float*>(p.out) + (size_t)ptok * p.ldc + pn0 + lane * 4;
-            __builtin_amdgcn_sched_barrier(0);
-            LOAD_NEXT((g + 2) % NST);                                   // step g+2: its stage was last read in step g-1
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned char* xs = smem + (g % NST) * STG_B + wm * 8192 + rd;
-            const unsigned char* ws = smem + (g % NST) * STG_B + XT_B + wn * 4096 + rd;
-            // fragment reads run one token-block PAIR ahead of the MFMAs that consume them (two 2-fragment buffers): the LDS pipe
-            // and the matrix pipe overlap inside the wave, and the register cost stays at 16 + 16 VGPRs
-            u32x4_t af[4], p0[2], p1[2];
-#define READ_PAIR(dst_, j_)                                                                                    \
-            dst_[0] = *reinterpret_cast<const u32x4_t*>(xs + (2 * (j_)) * 1024);                               \
-            dst_[1] = *reinterpret_cast<const u32x4_t*>(xs + (2 * (j_) + 1) * 1024);
-#define MFMA_PAIR(src_, j_)                                                                                    \
-            if (!ABL(p, 4)) {                                                                                  \
-                __builtin_amdgcn_s_setprio(1);                                                                 \
-                _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                  \
-                    _Pragma("unroll") for (int a = 0; a < 4; ++a)                                              \
-                        acc[a][2 * (j_) + h] = mfma16(af[a], src_[h], acc[a][2 * (j_) + h]);                   \
-                __builtin_amdgcn_s_setprio(0);                                                                 \
-            } else { asm volatile("" ::"v"(af[0]), "v"(af[1]), "v"(af[2]), "v"(af[3]), "v"(src_[0]), "v"(src_[1])); }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const u32x4_t*>(ws + i * 1024);
-            READ_PAIR(p0, 0)
-            READ_PAIR(p1, 1)
-            __builtin_amdgcn_sched_barrier(0);
-            MFMA_PAIR(p0, 0)
-            __builtin_amdgcn_sched_barrier(0);
-            READ_PAIR(p0, 2)
-            __builtin_amdgcn_sched_barrier(0);
-            MFMA_PAIR(p1, 1)
-            __builtin_amdgcn_sched_barrier(0);
-            READ_PAIR(p1, 3)
-            __builtin_amdgcn_sched_barrier(0);
-            MFMA_PAIR(p0, 2)
-            __builtin_amdgcn_sched_barrier(0);
-            MFMA_PAIR(p1, 3)
-            __builtin_amdgcn_sched_barrier(0);
-            st2 = st1;
-            st1 = 0;
-            if (piece) {
-                WAIT_LGKM0();                                           // the raw read of pv
-                __builtin_amdgcn_sched_barrier(0);
-                *reinterpret_cast<uint4*>(pv_ptr) = pv;
-                st1 = 1;
-            }
-            ++g;
+        for (int kt = 0; kt < KT;) {      // KT is even: two steps per trip, the weight fragments ping-pong between afA and afB
+            STEP(afA, afB)
+            STEP(afB, afA)
         }
         // ---- tile end: all pieces of the previous tile have been read; combine this tile and park it
         int tile_m, tile_n;
@@ -270,7 +296,7 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
             const int ptok = PIECE_TOKEN(hrow, half);
             if (ptok < p.M && !ABL(p, 1)) {
                 const uint4 pv = *reinterpret_cast<const uint4*>(ct + hrow * 1024 + ((lane ^ (hrow & 7)) << 4));
-                *reinterpret_cast<uint4*>(reinterpret_cast<float*>(p.out) + (size_t)ptok * p.ldc + pn0 + lane * 4) = pv;
+                store_stream(reinterpret_cast<float*>(p.out) + (size_t)ptok * p.ldc + pn0 + lane * 4, pv);
             }
         }
         WAIT_LGKM0();
@@ -284,7 +310,7 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
 // the 256-column tile, fp32 output with 16-byte aligned rows, enough tiles for one workgroup per CU
 bool mm_gemm_cfg2_eligible(const GemmArgs& a) {
     if (a.mode != MODE_CFG || a.out_kind != OUT_F32 || a.bias || a.act != ACT_NONE || a.resid_bf16 || a.resid_f32) return false;
-    if ((a.K % BK) != 0 || a.K < 16 * BK || (a.N % BN) != 0) return false;
+    if ((a.K % (2 * BK)) != 0 || a.K < 16 * BK || (a.N % BN) != 0) return false;
     if ((a.ldc % 4) || (((uintptr_t)a.out) & 15)) return false;
     const long tiles = (long)((a.M + TOK - 1) / TOK) * (a.N / BN);
     return tiles >= 256;
