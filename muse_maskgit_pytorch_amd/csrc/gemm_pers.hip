@@ -24,6 +24,13 @@
 #define ABL(p_, bit_) 0
 #endif
 
+// experiment switch: non-temporal output stores
+#ifdef MM_NT_DENSE
+#define ST16(ptr_, v_) __builtin_nontemporal_store(u32x4_t{(v_).x, (v_).y, (v_).z, (v_).w}, reinterpret_cast<u32x4_t*>(ptr_))
+#else
+#define ST16(ptr_, v_) (*reinterpret_cast<uint4*>(ptr_) = (v_))
+#endif
+
 namespace {
 
 constexpr int BMB = 256, BNB = 128, BK = 64;
@@ -151,11 +158,11 @@ __device__ __forceinline__ void write_piece(const GemmArgs& p, const uint4 v, in
     } else if (p.epi == EPI_GEGLU) {
         const int row = piece * 64 + (t >> 3), c = t & 7;
         const int m = m0 + row;
-        if (m < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + tile_n * 64 + c * 8) = v;
+        if (m < p.M) ST16(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + tile_n * 64 + c * 8, v);
     } else {
         const int row = piece * 32 + (t >> 4), c = t & 15;
         const int m = m0 + row;
-        if (m < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + n0 + c * 8) = v;
+        if (m < p.M) ST16(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + n0 + c * 8, v);
     }
 }
 
@@ -170,12 +177,12 @@ __device__ __forceinline__ void store_piece(const GemmArgs& p, const unsigned ch
         const int row = piece * 64 + (t >> 3), c = t & 7;
         const uint4 v = *reinterpret_cast<const uint4*>(ct + row * 128 + ((c ^ (row & 7)) << 4));
         const int m = m0 + row;
-        if (m < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + tile_n * 64 + c * 8) = v;
+        if (m < p.M) ST16(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + tile_n * 64 + c * 8, v);
     } else {
         const int row = piece * 32 + (t >> 4), c = t & 15;
         const uint4 v = *reinterpret_cast<const uint4*>(ct + row * 256 + ((c ^ (row & 15)) << 4));
         const int m = m0 + row;
-        if (m < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + n0 + c * 8) = v;
+        if (m < p.M) ST16(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + n0 + c * 8, v);
     }
 }
 
