@@ -28,8 +28,6 @@ def build(force=False, verbose=False):
     flags = list(FLAGS)
     if os.environ.get('MM_GEMM_ABLATE'):      # tools/gemm_bench.py ablations only: run-time skip-stores / -DMA / -MFMA switches in the k-loops
         flags.append('-DMM_GEMM_ABLATE')
-    if os.environ.get('MM_NT_DENSE'):
-        flags.append('-DMM_NT_DENSE')
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)

@@ -24,12 +24,8 @@
 #define ABL(p_, bit_) 0
 #endif
 
-// experiment switch: non-temporal output stores
-#ifdef MM_NT_DENSE
-#define ST16(ptr_, v_) __builtin_nontemporal_store(u32x4_t{(v_).x, (v_).y, (v_).z, (v_).w}, reinterpret_cast<u32x4_t*>(ptr_))
-#else
+// (non-temporal output stores were tried here as in gemm_cfg.hip: no effect -- these outputs are 50 MB and re-read by the next kernel)
 #define ST16(ptr_, v_) (*reinterpret_cast<uint4*>(ptr_) = (v_))
-#endif
 
 namespace {
 
