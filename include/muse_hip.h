@@ -122,6 +122,15 @@ int mm_ce_loss(mm_stream_t stream, const float* logits, int64_t ld, int R, int V
                float* row_loss_ws, float* out);
 int mm_bce_loss(mm_stream_t stream, const float* x, const float* y, int n, float* out);
 
+/* Nearest-codebook vector quantisation (the north star's "L2 nearest-codebook VQ lookup"; EXTENSION with a self-defined oracle:
+ * the reference's VectorQuantize branch, vqgan_vae.py:297-303, 336-342, 433-435, cannot run).  x fp32 [N][ldx] (C used), codebook fp32
+ * [K][C], C % 4 == 0, C <= 256.  ids[r] = argmin_k |x_r - e_k|^2, or argmax_k of the cosine similarity when cosine != 0
+ * (vq use_cosine_sim = True, the reference's default kwargs); ties -> lower index.  aux_ws: K floats of scratch.
+ * mm_vq_gather: out[r][:] = codebook[ids[r]][:]. */
+int mm_vq_nearest(mm_stream_t stream, const float* x, int64_t ldx, int N, int C, const float* codebook, int K, int cosine,
+                  float* aux_ws, int64_t* ids);
+int mm_vq_gather(mm_stream_t stream, const int64_t* ids, int64_t N, int C, const float* codebook, float* out);
+
 /* ---- backward operators of the transformer training step (MaskGit.forward, mmp.py:623-741, which the reference
  *      differentiates with torch autograd).  Activation gradients are bf16, the residual-stream gradient and every parameter
  *      gradient fp32.  Linear layers: dX = dY * W and dW = dY^T * X are mm_gemm_bf16 calls on transposed copies

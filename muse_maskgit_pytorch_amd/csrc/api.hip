@@ -184,6 +184,20 @@ int mm_bce_loss(mm_stream_t stream, const float* x, const float* y, int n, float
     return k_bce_loss((hipStream_t)stream, x, y, n, out);
 }
 
+int mm_vq_nearest(mm_stream_t stream, const float* x, int64_t ldx, int N, int C, const float* codebook, int K, int cosine,
+                  float* aux_ws, int64_t* ids) {
+    if (N == 0) return MM_OK;
+    CHK_PTR(x, "x"); CHK_PTR(codebook, "codebook"); CHK_PTR(aux_ws, "aux_ws"); CHK_PTR(ids, "ids");
+    if ((((uintptr_t)codebook) & 7) || (ldx < C)) return mm_set_error(MM_ERR_ALIGN, "vq_nearest: codebook must be 8-byte aligned, ldx >= C");
+    return k_vq_nearest((hipStream_t)stream, x, ldx, N, C, codebook, K, cosine, aux_ws, ids);
+}
+
+int mm_vq_gather(mm_stream_t stream, const int64_t* ids, int64_t N, int C, const float* codebook, float* out) {
+    if (N == 0) return MM_OK;
+    CHK_PTR(ids, "ids"); CHK_PTR(codebook, "codebook"); CHK_PTR(out, "out"); CHK_ALIGN16(codebook, "codebook"); CHK_ALIGN16(out, "out");
+    return k_vq_gather((hipStream_t)stream, ids, N, C, codebook, out);
+}
+
 int mm_gemm_wgrad_splits(int M, int N, int K) {
     const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
     const int kt = K / 64;

@@ -75,6 +75,10 @@ struct AttnArgs {
 };
 int k_attention(hipStream_t s, const AttnArgs& a);
 
+// vq.hip
+int k_vq_nearest(hipStream_t s, const float* x, long ldx, int N, int C, const float* cb, int K, int cosine, float* aux, int64_t* ids);
+int k_vq_gather(hipStream_t s, const int64_t* ids, long N, int C, const float* cb, float* out);
+
 // train.hip / attention_bwd.hip: backward operators
 int k_transpose_bf16(hipStream_t s, const bf16_t* in, long rows, long cols, long ldi, bf16_t* out, long ldo);
 int k_colsum(hipStream_t s, const float* part, int nparts, long D, float* out);

@@ -487,3 +487,24 @@ def qk_norm_bwd(x, dy, scale, heads, x_f32=None, dy_f32=None):
     L.check(lib.mm_qk_norm_bwd(L.stream(), L.ptr(x), x.stride(0), None, heads, L.ptr(dy), dy.stride(0), None, L.ptr(scale), rows, heads,
                                L.ptr(dx), heads * 64, None, L.ptr(part)), 'mm_qk_norm_bwd')
     return dx, colsum(part)
+
+
+# ------------------------------------------------------------------------------------------------ vector quantisation (extension)
+def vq_nearest(x, codebook, cosine=False):
+    """x fp32 [N, C], codebook fp32 [K, C] -> int64 [N]: nearest code (L2), or most cosine-similar code.  Ties -> lower index."""
+    _chk_cuda(x, codebook)
+    assert x.dtype == torch.float32 and codebook.dtype == torch.float32 and x.stride(1) == 1 and codebook.is_contiguous()
+    N, C = x.shape
+    K = codebook.shape[0]
+    ids = torch.empty(N, dtype=torch.long, device=x.device)
+    aux = torch.empty(K, dtype=torch.float32, device=x.device)
+    L.check(L.lib().mm_vq_nearest(L.stream(), L.ptr(x), x.stride(0), N, C, L.ptr(codebook), K, int(cosine), L.ptr(aux), L.ptr(ids)), 'mm_vq_nearest')
+    return ids
+
+
+def vq_gather(ids, codebook):
+    _chk_cuda(ids, codebook)
+    N, C = ids.numel(), codebook.shape[1]
+    out = torch.empty(N, C, dtype=torch.float32, device=codebook.device)
+    L.check(L.lib().mm_vq_gather(L.stream(), L.ptr(ids.reshape(-1).contiguous()), N, C, L.ptr(codebook.contiguous()), L.ptr(out)), 'mm_vq_gather')
+    return out.reshape(*ids.shape, C)

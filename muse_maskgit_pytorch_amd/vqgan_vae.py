@@ -104,6 +104,44 @@ class LFQ(nn.Module):
         self.register_buffer('mask', 2 ** torch.arange(self.codebook_dim - 1, -1, -1))
 
 
+class VectorQuantize(nn.Module):
+    """EXTENSION (parity unpinned by nature): eval-mode parameter container + lookup of a vector-quantize-pytorch
+    `VectorQuantize(dim, codebook_size, codebook_dim=256, use_cosine_sim=True)` as the reference MEANS to build it at
+    vqgan_vae.py:336-342 (that call is a TypeError -- a missing comma -- and its decode branch reads a codebook attribute that does not
+    exist, :433-435).  project_in Linear(dim, codebook_dim) -> nearest code (cosine similarity, or Euclidean) -> project_out
+    Linear(codebook_dim, dim).  Codebook training (EMA / k-means) is not part of the hot path."""
+
+    def __init__(self, *, dim, codebook_size, codebook_dim=256, use_cosine_sim=True, **_):
+        super().__init__()
+        self.dim, self.codebook_size, self.codebook_dim, self.use_cosine_sim = dim, codebook_size, codebook_dim, use_cosine_sim
+        has_proj = dim != codebook_dim
+        self.project_in = nn.Linear(dim, codebook_dim) if has_proj else nn.Identity()
+        self.project_out = nn.Linear(codebook_dim, dim) if has_proj else nn.Identity()
+        cb = torch.randn(codebook_size, codebook_dim)
+        self.codebook = nn.Parameter(torch.nn.functional.normalize(cb, dim=-1) if use_cosine_sim else cb)
+
+    def _proj(self, x_nhwc, lin):
+        """bf16 NHWC rows through a Linear(+bias) as a 1x1 convolution GEMM; returns NHWC bf16."""
+        if not isinstance(lin, nn.Linear):
+            return x_nhwc
+        w = ops.pad_cols(lin.weight.detach().to(torch.bfloat16), 64)
+        return ops.conv2d_nhwc(x_nhwc, w, lin.out_features, 1, 1, 1, (0, 0), bias=lin.bias.detach().float().contiguous())
+
+    @torch.no_grad()
+    def encode_nhwc(self, x_nhwc):
+        """x (B,h,w,dim) bf16 -> (ids (B,h,w) int64, quantized (B,h,w,dim) bf16)."""
+        B, h, w, _ = x_nhwc.shape
+        z = self._proj(x_nhwc, self.project_in).reshape(B * h * w, self.codebook_dim).float().contiguous()
+        ids = ops.vq_nearest(z, self.codebook.detach().float().contiguous(), cosine=self.use_cosine_sim)
+        return ids.reshape(B, h, w), self.codes_nhwc(ids.reshape(B, h, w))
+
+    @torch.no_grad()
+    def codes_nhwc(self, ids):
+        B, h, w = ids.shape
+        codes = ops.vq_gather(ids, self.codebook.detach().float().contiguous()).to(torch.bfloat16).reshape(B, h, w, self.codebook_dim)
+        return self._proj(codes.contiguous(), self.project_out)
+
+
 class VQGanVAE(nn.Module):
     def __init__(self, *, dim, channels=3, layers=4, l2_recon_loss=False, use_hinge_loss=True, vgg=None,
                  lookup_free_quantization=True, codebook_size=65536,
@@ -117,9 +155,12 @@ class VQGanVAE(nn.Module):
         self.enc_dec = ResnetEncDec(dim=dim, channels=channels, layers=layers, **encdec_kwargs)
         self.lookup_free_quantization = lookup_free_quantization
         if not lookup_free_quantization:
-            # the reference's VectorQuantize branch cannot be constructed (vqgan_vae.py:337-342 is a TypeError)
-            raise NotImplementedError('only lookup_free_quantization=True is executable in the reference')
-        self.quantizer = LFQ(dim=self.enc_dec.encoded_dim, codebook_size=codebook_size, **lfq_kwargs)
+            # EXTENSION: the reference's VectorQuantize branch cannot be constructed (vqgan_vae.py:337-342 is a TypeError); this is
+            # what it evidently means (vq_kwargs defaults: codebook_dim 256, cosine similarity) -- eval-mode lookup only
+            vq = {k[len('vq_'):]: v for k, v in kwargs.items() if k.startswith('vq_')} or dict(vq_kwargs)
+            self.quantizer = VectorQuantize(dim=self.enc_dec.encoded_dim, codebook_size=codebook_size, **vq)
+        else:
+            self.quantizer = LFQ(dim=self.enc_dec.encoded_dim, codebook_size=codebook_size, **lfq_kwargs)
         self._vgg = None
         self.discr = None
         self.use_vgg_and_gan = use_vgg_and_gan
@@ -192,7 +233,9 @@ class VQGanVAE(nn.Module):
         P['head'] = dict(w=ops.pack_conv_weight(last.weight.detach()), b=f32(last.bias), cout=last.out_channels)
         q = self.quantizer
         P['bits'] = q.codebook_dim
-        if isinstance(q.project_in, nn.Linear):
+        if not self.lookup_free_quantization:
+            P['lfq'] = None
+        elif isinstance(q.project_in, nn.Linear):
             P['lfq'] = dict(wi=f32(q.project_in.weight), bi=f32(q.project_in.bias), wo=f32(q.project_out.weight), bo=f32(q.project_out.bias))
         else:
             P['lfq'] = dict(wi=None, bi=None, wo=None, bo=None)
@@ -218,6 +261,9 @@ class VQGanVAE(nn.Module):
             h = ops.conv2d_nhwc(h, c1['w'], c1['cout'], 3, 3, 1, (-1, -1), bias=c1['b'])
             h = ops.groupnorm_nhwc(h, g1['groups'], g1['g'], g1['b'], act=True)
             x = ops.conv2d_nhwc(h, c2['w'], c2['cout'], 1, 1, 1, (0, 0), bias=c2['b'], resid=x)
+        if not self.lookup_free_quantization:
+            ids, q = self.quantizer.encode_nhwc(x)
+            return ops.nhwc_to_nchw_f32(q), ids, torch.zeros((), device=fmap.device)
         lf = P['lfq']
         ids, q = ops.lfq_encode(x, P['bits'], lf['wi'], lf['bi'], lf['wo'], lf['bo'])
         return ops.nhwc_to_nchw_f32(q), ids, torch.zeros((), device=fmap.device)
@@ -248,6 +294,8 @@ class VQGanVAE(nn.Module):
     def decode_from_ids(self, ids):
         """vqgan_vae.py:427-438: ids (B,h,w) int64 -> image (B,C,H,W) fp32 (unclamped)."""
         P = self._pack()
+        if not self.lookup_free_quantization:
+            return self._decode_nhwc(self.quantizer.codes_nhwc(ids.to(self.device)))
         lf = P['lfq']
         x = ops.lfq_decode(ids, P['bits'], self.enc_dec.encoded_dim, lf['wo'], lf['bo'])     # (B,h,w,C) NHWC bf16
         return self._decode_nhwc(x)

@@ -554,3 +554,19 @@ def test_training_self_cond_and_super_res_gradients():
     l2 = mg(torch.randint(0, 512, (2, 64), generator=g).to(DEV), text_embeds=te.to(DEV))
     l2.backward()
     assert torch.isfinite(l2) and t.self_cond_to_init_embed[1].weight.grad.abs().max() > 0
+
+
+def test_vqgan_with_vector_quantize_extension():
+    """EXTENSION: VQGanVAE(lookup_free_quantization=False) -- the reference's VectorQuantize branch cannot run, so the
+    check is self-consistency: encode picks the most cosine-similar code of the projected features (recomputed in fp32 from the same
+    bf16 projections), and decode_from_ids(encode(img).ids) equals decode(encode(img).fmap)."""
+    torch.manual_seed(3)
+    vae = mm.VQGanVAE(dim=16, codebook_size=1024, lookup_free_quantization=False, vq_codebook_dim=32).to(DEV).eval()
+    img = torch.randn(2, 3, 64, 64, device=DEV)
+    fmap, ids, aux = vae.encode(img)
+    assert ids.shape == (2, 4, 4) and ids.dtype == torch.long and fmap.shape == (2, 128, 4, 4) and float(aux) == 0.
+    assert (ids >= 0).all() and (ids < 1024).all() and ids.unique().numel() > 4
+    a = vae.decode_from_ids(ids)
+    b = vae.decode(fmap)
+    assert torch.isfinite(a).all() and (a - b).abs().max() < 2e-2 * b.abs().max()
+    assert 'quantizer.codebook' in vae.state_dict()

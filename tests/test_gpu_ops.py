@@ -533,3 +533,29 @@ def test_glu_groupnorm_lfq_layout():
     img = rnd(2, 3, 8, 8, gen=g)
     check_close(r16(ops.nchw_to_nhwc8(img.to(DEV)).float().cpu()), r16(emu.nchw_to_nhwc8(img)), atol=0, what='nchw->nhwc8')
     check_close(ops.nhwc_to_nchw_f32(x.to(DEV, bf16)), emu.nhwc_to_nchw_f32(x), atol=0, what='nhwc->nchw')
+
+
+@pytest.mark.parametrize('N,K,C,cosine', [(100, 512, 32, False), (1000, 8192, 256, True), (257, 1000, 64, False), (33, 65536, 256, True)])
+def test_vq_nearest_lookup(N, K, C, cosine):
+    """EXTENSION (self-defined oracle: the reference's VectorQuantize branch cannot run): nearest-codebook lookup,
+    Euclidean and cosine.  fp32 MFMA vs torch fp32 differ in summation order, so rows whose top-2 margin is below 1e-4 are only
+    required to pick a code within 1e-4 of the optimum; all others must match exactly.  Exact ties -> the lower index."""
+    g = torch.Generator().manual_seed(N + K)
+    x = rnd(N, C, gen=g)
+    cb = rnd(K, C, gen=g)
+    cb[7] = cb[3]                              # an exact duplicate: the lower index must win wherever code 3 is nearest
+    x[0] = cb[3] * 1.5 if cosine else cb[3]
+    if cosine:
+        sc = torch.nn.functional.normalize(x, dim=-1) @ torch.nn.functional.normalize(cb, dim=-1).t()
+    else:
+        sc = x @ cb.t() - 0.5 * (cb * cb).sum(-1)[None]
+    top2 = sc.topk(2, dim=-1)
+    ref = sc.argmax(-1)
+    got = ops.vq_nearest(x.to(DEV), cb.to(DEV), cosine=cosine).cpu()
+    assert got[0] == 3
+    clear = (top2.values[:, 0] - top2.values[:, 1]) > 1e-4
+    clear[0] = False
+    assert torch.equal(got[clear], ref[clear])
+    assert (sc.gather(1, got[:, None])[:, 0] >= top2.values[:, 0] - 1e-4).all()
+    q = ops.vq_gather(got.to(DEV).reshape(N), cb.to(DEV)).cpu()
+    assert torch.equal(q, cb[got])
