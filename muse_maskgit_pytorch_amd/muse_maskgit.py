@@ -375,13 +375,22 @@ class SelfCritic(nn.Module):
         _, embeds = self.net.forward_with_neg_prompt(x, *args, return_embed=True, **kwargs)
         return self._pred(embeds)
 
-    @torch.no_grad()
     def forward(self, x, *args, labels=None, **kwargs):
-        _, embeds = self.net(x, *args, return_embed=True, **kwargs)
-        logits = self._pred(embeds)
-        if not exists(labels):
-            return logits
-        return ops.bce_loss(logits.reshape(-1), labels.to(logits.device))
+        """mmp.py:364-374.  With labels and autograd enabled the BCE is differentiable w.r.t. the head AND the generator (training.py)."""
+        if exists(labels) and torch.is_grad_enabled() and self.to_pred.weight.requires_grad and not args:
+            from .training import transformer_loss
+            text_embeds = kwargs.get('text_embeds')
+            if not exists(text_embeds):
+                text_embeds = self.net.encode_text(kwargs['texts'])
+            return transformer_loss(self.net, x, text_embeds, labels, None, kwargs.get('cond_drop_prob', 0.), grad_sync=self.net.grad_sync,
+                                    self_cond_embed=kwargs.get('self_cond_embed'), conditioning_token_ids=kwargs.get('conditioning_token_ids'),
+                                    head=self.to_pred)
+        with torch.no_grad():
+            _, embeds = self.net(x, *args, return_embed=True, **kwargs)
+            logits = self._pred(embeds)
+            if not exists(labels):
+                return logits
+            return ops.bce_loss(logits.reshape(-1), labels.to(logits.device))
 
 
 class MaskGitTransformer(Transformer):

@@ -42,7 +42,7 @@ def _heads(t, b, n, h, col0=0):
 class _Params:
     """fixed order of the parameters that receive gradients"""
 
-    def __init__(self, tr):
+    def __init__(self, tr, head=None):
         self.names, self.tensors = [], []
         tb = tr.transformer_blocks
 
@@ -66,7 +66,11 @@ class _Params:
             add(f'{i}.ff.g2', ff[3].gamma)
             add(f'{i}.ff.w2', ff[4].weight)
         add('final.gamma', tb.norm.gamma)
-        add('to_logits', tr.to_logits.weight)
+        if head is None:
+            add('to_logits', tr.to_logits.weight)
+        else:                                                  # SelfCritic: Linear(dim, 1) with bias on the generator's embed (mmp.py:352-374)
+            add('head.weight', head.weight)
+            add('head.bias', head.bias)
         if tr.self_cond:                                       # mmp.py:237-238, 325-328
             ff = tr.self_cond_to_init_embed
             add('sc.ff.g1', ff[0].gamma)
@@ -179,11 +183,17 @@ class TransformerTrainFn(torch.autograd.Function):
             x, lwf, lsf = _ff_forward(P, f'{i}.ff.', cfg['betas'], x, x, dev)
             lw['ff'], ls['ff'] = lwf, lsf
             sv['layers'].append((lw, ls))
-        W['wl'] = P['to_logits'].detach().to(bf16).contiguous()
+        hw = 'head.weight' if cfg['ext_head'] else 'to_logits'
+        W['wl'] = P[hw].detach().to(bf16).contiguous()
         if cfg['bce']:
-            # ---- TokenCritic head (mmp.py:345-346, 383-386): one logit per position, BCE against float labels over ALL positions
+            # ---- TokenCritic / SelfCritic head (mmp.py:345-346, 352-374, 383-386): one logit per position, BCE against float labels
+            #      over ALL positions
             e = ops.layernorm(x, f32(P['final.gamma']), cfg['betas']['final'])
-            logits = ops.gemm(e, W['wl'], out_f32=True)                     # [M, 1]
+            if cfg['ext_head']:
+                logits = ops.conv2d_nhwc(e.reshape(M, 1, 1, D), ops.pad_cols(W['wl'], 64), 1, 1, 1, 1, (0, 0), bias=f32(P['head.bias']),
+                                         out_nchw_f32=True).reshape(M, 1)
+            else:
+                logits = ops.gemm(e, W['wl'], out_f32=True)                 # [M, 1]
             loss = ops.bce_loss(logits.reshape(-1), labels_rows)
         else:
             # ---- head on the rows that carry a label (mmp.py:330-343): rows with ignore_index contribute nothing to the loss
@@ -213,7 +223,11 @@ class TransformerTrainFn(torch.autograd.Function):
         dres = torch.zeros(M, D, dtype=torch.float32, device=dev)
         if cfg['bce']:
             de, dwl = ops.bce_head_bwd(sv['e'], sv['logits'].reshape(-1), ctx.labels_rows, sv['W']['wl'].float().reshape(-1))
-            G['to_logits'] = dwl.reshape(1, D)
+            if cfg['ext_head']:
+                G['head.weight'] = dwl.reshape(1, D)
+                G['head.bias'] = ((torch.sigmoid(sv['logits'].reshape(-1)) - ctx.labels_rows).sum() / M).reshape(1)      # 1 scalar: host-side reduction
+            else:
+                G['to_logits'] = dwl.reshape(1, D)
             G['final.gamma'] = ops.layernorm_bwd(sv['xL'], de, f32(P['final.gamma']), dres, accumulate=False)
         else:
             R = ctx.row_index.numel()
@@ -224,9 +238,10 @@ class TransformerTrainFn(torch.autograd.Function):
         dcx = None
         sync = cfg.get('sync')
         if sync is not None:
-            for k in ('to_logits', 'final.gamma'):
+            head_keys = [k for k in ('to_logits', 'head.weight', 'head.bias', 'final.gamma') if k in G]
+            for k in head_keys:
                 G[k] = G[k].contiguous()
-            sync.push([G['to_logits'], G['final.gamma']])
+            sync.push([G[k] for k in head_keys])
         for i in reversed(range(cfg['depth'])):
             lw, ls = sv['layers'][i]
             # ---- feed forward
@@ -300,7 +315,7 @@ class TransformerTrainFn(torch.autograd.Function):
 
 
 def transformer_loss(tr, ids, text_embeds, labels, ignore_index, cond_drop_prob, grad_sync=None, return_logits=False,
-                     self_cond_embed=None, conditioning_token_ids=None):
+                     self_cond_embed=None, conditioning_token_ids=None, head=None):
     """Differentiable CE loss of Transformer.forward(labels=...) (mmp.py:337-346) on the MI355X training path.
     grad_sync: an optional parallel.GradBucketer -- data-parallel gradient averaging overlapped with the backward."""
     dev = tr.token_emb.weight.device
@@ -313,7 +328,7 @@ def transformer_loss(tr, ids, text_embeds, labels, ignore_index, cond_drop_prob,
         ctx_mask = torch.zeros_like(ctx_mask)
     elif cond_drop_prob > 0.:                                                          # mmp.py:308-310, 393-399
         ctx_mask = ctx_mask & (torch.rand((b, 1), device=dev) < (1. - cond_drop_prob))
-    bce = tr.dim_out == 1
+    bce = tr.dim_out == 1 or head is not None      # `head`: an external Linear(dim, 1) on the embed (SelfCritic)
     if bce:                                                                            # TokenCritic: float targets at every position
         labels_rows = labels.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
         row_index = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -322,7 +337,7 @@ def transformer_loss(tr, ids, text_embeds, labels, ignore_index, cond_drop_prob,
         row_index = torch.nonzero(labels != ignore_index).reshape(-1).to(torch.int32).contiguous()
         assert row_index.numel() > 0, 'no position carries a label'
         labels_rows = labels[row_index.long()].contiguous()
-    pr = _Params(tr)
+    pr = _Params(tr, head)
     tb = tr.transformer_blocks
     betas = {'final': tb.norm.beta.float().contiguous()}
     for i, (sa, ca, ff) in enumerate(tb.layers):
@@ -339,7 +354,7 @@ def transformer_loss(tr, ids, text_embeds, labels, ignore_index, cond_drop_prob,
     if conditioning_token_ids is not None:
         cond_ids = conditioning_token_ids.reshape(b, -1).to(device=dev, dtype=torch.long).contiguous()
     cfg = dict(depth=tb.cfg['depth'], heads=tb.cfg['heads'], dim=tr.dim, names=pr.names, has_proj=pr.has_proj, betas=betas,
-               sync=grad_sync, bce=bce, self_cond=bool(tr.self_cond))
+               sync=grad_sync, bce=bce, self_cond=bool(tr.self_cond), ext_head=head is not None)
     loss, logits = TransformerTrainFn.apply(cfg, ids, te, ctx_mask.to(torch.uint8).contiguous(), labels_rows, row_index, sce, cond_ids, *pr.tensors)
     if return_logits:
         return loss, logits, row_index          # logits of the labelled rows only (CE) / of every position (BCE)

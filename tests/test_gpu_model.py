@@ -570,3 +570,42 @@ def test_vqgan_with_vector_quantize_extension():
     b = vae.decode(fmap)
     assert torch.isfinite(a).all() and (a - b).abs().max() < 2e-2 * b.abs().max()
     assert 'quantizer.codebook' in vae.state_dict()
+
+
+def test_self_critic_training_gradients(golden):
+    """SelfCritic (mmp.py:352-374): BCE of a Linear(dim, 1) head on the generator's embed, differentiable into head and generator."""
+    g, l = golden('transformer_tiny.pt'), golden('loss_tiny.pt')
+    _, t = _tiny_transformer(golden)
+    te = g['text_embeds']
+    from muse_maskgit_pytorch_amd.muse_maskgit import SelfCritic
+    sc = SelfCritic(t).to(DEV)
+    with torch.no_grad():
+        sc.to_pred.weight.copy_((torch.randn(1, 128, generator=torch.Generator().manual_seed(2)) * 0.3).to(torch.bfloat16).float())
+        sc.to_pred.bias.fill_(0.25)
+    x = l['x'].clamp(max=511)
+    y = l['critic_labels']
+    loss = sc(x.to(DEV), text_embeds=te.to(DEV), labels=y.to(DEV))
+    loss.backward()
+    sd = {k: (v.float().clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in g['sd'].items()}
+    w = sc.to_pred.weight.detach().cpu().clone().requires_grad_(True)
+    b = sc.to_pred.bias.detach().cpu().clone().requires_grad_(True)
+    _, emb = O.transformer_forward(sd, dict(depth=2, heads=8), x, te, 0., return_embed=True)
+    ref = torch.nn.functional.binary_cross_entropy_with_logits((emb @ w.t() + b)[..., 0], y)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 2e-2 * abs(ref.item())
+    pairs = [('to_pred.weight', sc.to_pred.weight.grad, w.grad), ('to_pred.bias', sc.to_pred.bias.grad, b.grad)]
+    for name, p in t.named_parameters():
+        if name.startswith('self_cond_to_init_embed') or name in ('norm.gamma', 'to_logits.weight'):
+            continue
+        pairs.append((name, p.grad, sd[name].grad))
+    for name, gg, rg in pairs:
+        gg = gg.float().cpu()
+        rel = (gg - rg).abs().max().item() / (rg.abs().max().item() + 1e-20)
+        cos = torch.nn.functional.cosine_similarity(gg.flatten(), rg.flatten(), dim=0).item()
+        assert rel < 5e-2 and cos > 0.99, f'{name}: rel {rel:.3e} cos {cos:.5f}'
+    # MaskGit with self_token_critic=True end to end
+    t.zero_grad()
+    mg = mm.MaskGit(image_size=128, transformer=t, vae=None, self_token_critic=True).to(DEV)
+    total = mg(torch.randint(0, 512, (2, 64), generator=torch.Generator().manual_seed(9)).to(DEV), text_embeds=te.to(DEV), cond_drop_prob=0.)
+    total.backward()
+    assert torch.isfinite(total) and mg.token_critic.to_pred.weight.grad.abs().max() > 0 and t.to_logits.weight.grad.abs().max() > 0
