@@ -180,10 +180,15 @@ int mm_embed_bwd(mm_stream_t stream, const int64_t* ids, int B, int n, int D, co
 /* dst[row_index[r]][:] = src[r][:] for r < R; bf16, D % 8 == 0 (gradient of a row gather; dst zeroed by the caller). */
 int mm_scatter_rows_bf16(mm_stream_t stream, const void* src, const int32_t* row_index, int R, int D, void* dst);
 
+/* out[i] = bf16(sum over p of parts[p][i]), fp32 accumulation in index order; parts bf16 [P][n] contiguous, n % 8 == 0 (the partial
+ * key / value gradients of the 256-query chunks of a long sequence). */
+int mm_sum_parts_bf16(mm_stream_t stream, const void* parts, int P, int64_t n, void* out);
+
 /* Backward of mm_attend in its Muse form (normalize = 1, null key/value, scale 8; mmp.py:137-162, attend.py:109-140).
  * q/k/v: the forward inputs (raw projections), o: the forward output, dout: its gradient (all bf16, strided like mm_attend).
  * Outputs: dqn / dkn = gradients w.r.t. the NORMALISED, scaled q / k (feed mm_qk_norm_bwd), dv; dnk / dnv fp32 [B*H][64] =
- * gradients of the normalised null key / the null value per (batch, head).  nq in {64, 128, 256}. */
+ * gradients of the normalised null key / the null value per (batch, head).  nq in {64, 128, 256}; longer sequences: one call per
+ * 256-query chunk (the log-sum-exp is per query, so chunks are independent), partial dkn / dv / dnk / dnv summed afterwards. */
 int mm_attention_bwd(mm_stream_t stream, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const void* k, int64_t k_sb,
                      int64_t k_sh, int64_t k_sn, const void* v, int64_t v_sb, int64_t v_sh, int64_t v_sn, const void* o,
                      int64_t o_sb, int64_t o_sh, int64_t o_sn, const void* dout, int64_t do_sb, int64_t do_sh, int64_t do_sn,

@@ -81,6 +81,7 @@ SIGNATURES = {
     'mm_bce_head_bwd': (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_i64, c_vp, c_vp]),
     'mm_embed_bwd': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     'mm_scatter_rows_bf16': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
+    'mm_sum_parts_bf16': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp]),
     'mm_attention_bwd': (c_int, [c_vp] + [c_vp, c_i64, c_i64, c_i64] * 8 + [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32]),
     'mm_qk_norm_bwd_blocks': (c_i64, [c_i64]),
     'mm_qk_norm_bwd': (c_int, [c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_vp]),

@@ -287,6 +287,12 @@ int mm_scatter_rows_bf16(mm_stream_t stream, const void* src, const int32_t* row
     return k_scatter_rows_bf16((hipStream_t)stream, (const bf16_t*)src, row_index, R, D, (bf16_t*)dst);
 }
 
+int mm_sum_parts_bf16(mm_stream_t stream, const void* parts, int P, int64_t n, void* out) {
+    if (n == 0) return MM_OK;
+    CHK_PTR(parts, "parts"); CHK_PTR(out, "out"); CHK_ALIGN16(parts, "parts"); CHK_ALIGN16(out, "out");
+    return k_sum_parts_bf16((hipStream_t)stream, (const bf16_t*)parts, P, n, (bf16_t*)out);
+}
+
 int mm_attention_bwd(mm_stream_t stream, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const void* k, int64_t k_sb,
                      int64_t k_sh, int64_t k_sn, const void* v, int64_t v_sb, int64_t v_sh, int64_t v_sn, const void* o,
                      int64_t o_sb, int64_t o_sh, int64_t o_sn, const void* dout, int64_t do_sb, int64_t do_sh, int64_t do_sn,

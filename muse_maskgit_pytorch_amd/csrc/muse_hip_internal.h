@@ -91,6 +91,7 @@ int k_ce_bwd(hipStream_t s, const float* logits, long ld, int R, int V, const in
 int k_bce_head_bwd(hipStream_t s, const bf16_t* e, long lde, const float* x, const float* y, const float* w, int rows, int D, bf16_t* de,
                    long ldde, float* dw, float* ws);
 int k_embed_bwd(hipStream_t s, const int64_t* ids, int B, int n, int D, const float* dx, float* dtoken, float* dpos);
+int k_sum_parts_bf16(hipStream_t s, const bf16_t* parts, int P, long n, bf16_t* out);
 int k_scatter_rows_bf16(hipStream_t s, const bf16_t* src, const int32_t* row_index, int R, int D, bf16_t* dst);
 int k_attention_bwd(hipStream_t s, const bf16_t* q, long q_sb, long q_sh, long q_sn, const bf16_t* k, long k_sb, long k_sh, long k_sn,
                     const bf16_t* v, long v_sb, long v_sh, long v_sn, const bf16_t* o, long o_sb, long o_sh, long o_sn,

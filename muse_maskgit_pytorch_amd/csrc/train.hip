@@ -416,6 +416,20 @@ __global__ __launch_bounds__(256) void bce_head_bwd_kernel(const bf16_t* __restr
     }
 }
 
+// out[i] = bf16(sum_p parts[p][i]) with fp32 accumulation in index order (partial dK / dV of query chunks)
+__global__ __launch_bounds__(256) void sum_parts_bf16_kernel(const bf16_t* __restrict__ parts, int P, long n, bf16_t* __restrict__ out) {
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (long)gridDim.x * 256 * 8) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < P; ++p) {
+            float f[8];
+            unpack8(*reinterpret_cast<const uint4*>(parts + (long)p * n + i), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += f[j];
+        }
+        *reinterpret_cast<uint4*>(out + i) = pack8(acc);
+    }
+}
+
 // bf16 rows scattered into a zero-initialised [M][D] bf16 buffer (gradient of a row gather)
 __global__ __launch_bounds__(256) void scatter_rows_bf16_kernel(const bf16_t* __restrict__ src, const int32_t* __restrict__ row_index, int R, int D,
                                                                 bf16_t* __restrict__ dst) {
@@ -494,6 +508,15 @@ int k_bce_head_bwd(hipStream_t s, const bf16_t* e, long lde, const float* x, con
     if (rc) return rc;
     hipLaunchKernelGGL(colsum_kernel, dim3((D + 63) / 64), dim3(256), 0, s, ws, blocks, (long)D, dw);
     return mm_check_launch("colsum_kernel");
+}
+
+int k_sum_parts_bf16(hipStream_t s, const bf16_t* parts, int P, long n, bf16_t* out) {
+    if (n <= 0) return MM_OK;
+    if (n % 8) return mm_set_error(MM_ERR_SHAPE, "sum_parts_bf16: element count must be a multiple of 8");
+    long blocks = (n / 8 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(sum_parts_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, parts, P, n, out);
+    return mm_check_launch("sum_parts_bf16_kernel");
 }
 
 int k_embed_bwd(hipStream_t s, const int64_t* ids, int B, int n, int D, const float* dx, float* dtoken, float* dpos) {

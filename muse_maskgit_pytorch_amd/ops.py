@@ -444,27 +444,42 @@ def scatter_rows(src, row_index, M):
 
 def attention_bwd(q, k, v, o, dout, q_scale, k_scale, null_k, null_v, key_mask=None, scale=8.0):
     """Muse attention backward.  q/o/dout (b,h,n,64), k/v (b,h,j,64) bf16 strided views.  Returns dqn (b,n,h*64), dkn, dv (b,j,h*64)
-    bf16 -- gradients w.r.t. the normalised q / k and v -- and dnk, dnv fp32 (b*h, 64) for the null key / value."""
+    bf16 -- gradients w.r.t. the normalised q / k and v -- and dnk, dnv fp32 (b*h, 64) for the null key / value.
+    n > 256 (super-res): one kernel call per 256-query chunk, the chunks' partial key / value gradients are summed afterwards."""
     _chk_cuda(q, k, v, o, dout, key_mask)
     b, h, n, d = q.shape
     j = k.shape[2]
     dev = q.device
+    jj = max(j, 1)
+    chunks = 1 if n <= 256 else n // 256
+    assert n <= 256 or n % 256 == 0, 'attention_bwd: sequences longer than 256 must be a multiple of 256'
+    nq = n // chunks
     dqn = torch.empty(b, n, h * 64, dtype=bf16, device=dev)
-    dkn = torch.empty(b, max(j, 1), h * 64, dtype=bf16, device=dev)
-    dv = torch.empty(b, max(j, 1), h * 64, dtype=bf16, device=dev)
-    dnk = torch.empty(b * h, 64, dtype=torch.float32, device=dev)
-    dnv = torch.empty(b * h, 64, dtype=torch.float32, device=dev)
+    dkn = torch.empty(chunks, b, jj, h * 64, dtype=bf16, device=dev)
+    dv = torch.empty(chunks, b, jj, h * 64, dtype=bf16, device=dev)
+    dnk = torch.empty(chunks, b * h, 64, dtype=torch.float32, device=dev)
+    dnv = torch.empty(chunks, b * h, 64, dtype=torch.float32, device=dev)
     km = key_mask.to(torch.uint8).contiguous() if key_mask is not None else None
 
     def st(t):
         return (L.ptr(t), t.stride(0), t.stride(1), t.stride(2))
 
-    def st_bnh(t, rows):
-        return (L.ptr(t), rows * h * 64, 64, h * 64)
-    L.check(L.lib().mm_attention_bwd(L.stream(), *st(q), *st(k), *st(v), *st(o), *st(dout), *st_bnh(dqn, n), *st_bnh(dkn, max(j, 1)),
-                                     *st_bnh(dv, max(j, 1)), L.ptr(dnk), L.ptr(dnv), b, h, n, j, L.ptr(km), j, L.ptr(q_scale), L.ptr(k_scale),
-                                     L.ptr(null_k), L.ptr(null_v), float(scale)), 'mm_attention_bwd')
-    return dqn, dkn[:, :j], dv[:, :j], dnk, dnv
+    for c in range(chunks):
+        qs = slice(c * nq, (c + 1) * nq)
+        dq_c = dqn[:, qs]
+        L.check(L.lib().mm_attention_bwd(L.stream(), *st(q[:, :, qs]), *st(k), *st(v), *st(o[:, :, qs]), *st(dout[:, :, qs]),
+                                         L.ptr(dq_c), n * h * 64, 64, h * 64, L.ptr(dkn[c]), jj * h * 64, 64, h * 64,
+                                         L.ptr(dv[c]), jj * h * 64, 64, h * 64, L.ptr(dnk[c]), L.ptr(dnv[c]), b, h, nq, j, L.ptr(km), j,
+                                         L.ptr(q_scale), L.ptr(k_scale), L.ptr(null_k), L.ptr(null_v), float(scale)), 'mm_attention_bwd')
+    if chunks == 1:
+        return dqn, dkn[0][:, :j], dv[0][:, :j], dnk[0], dnv[0]
+    per = b * jj * h * 64
+    dkn_s = torch.empty(b, jj, h * 64, dtype=bf16, device=dev)
+    dv_s = torch.empty(b, jj, h * 64, dtype=bf16, device=dev)
+    L.check(L.lib().mm_sum_parts_bf16(L.stream(), L.ptr(dkn), chunks, per, L.ptr(dkn_s)), 'mm_sum_parts_bf16')
+    L.check(L.lib().mm_sum_parts_bf16(L.stream(), L.ptr(dv), chunks, per, L.ptr(dv_s)), 'mm_sum_parts_bf16')
+    return (dqn, dkn_s[:, :j], dv_s[:, :j], colsum(dnk.reshape(chunks, b * h * 64)).reshape(b * h, 64),
+            colsum(dnv.reshape(chunks, b * h * 64)).reshape(b * h, 64))
 
 
 def qk_norm_bwd(x, dy, scale, heads, x_f32=None, dy_f32=None):

@@ -128,7 +128,7 @@ def _attn_ref(q, k, v, qs, ks, nk, nv, mask):
     return torch.einsum('bhij,bhjd->bhid', sim.softmax(-1), vv), qn, kn
 
 
-@pytest.mark.parametrize('n,j,masked', [(64, 64, False), (256, 256, False), (64, 7, True), (128, 40, True), (256, 33, True)])
+@pytest.mark.parametrize('n,j,masked', [(64, 64, False), (256, 256, False), (64, 7, True), (128, 40, True), (256, 33, True), (512, 300, True), (1024, 1024, False)])
 def test_attention_bwd_and_qk_norm_bwd(ops, n, j, masked):
     g = torch.Generator().manual_seed(n + j)
     b, h = 2, 3
