@@ -609,3 +609,54 @@ def test_self_critic_training_gradients(golden):
     total = mg(torch.randint(0, 512, (2, 64), generator=torch.Generator().manual_seed(9)).to(DEV), text_embeds=te.to(DEV), cond_drop_prob=0.)
     total.backward()
     assert torch.isfinite(total) and mg.token_critic.to_pred.weight.grad.abs().max() > 0 and t.to_logits.weight.grad.abs().max() > 0
+
+
+def test_full_size_c2_properties():
+    """BASELINE configs[1] at FULL size (dim 512, depth 8, seq_len 256, codebook 65536; B = 8 to keep the fp32 oracle out of it):
+    size-independent properties instead of an oracle comparison --
+      * guidance linearity: forward_with_cond_scale(s) = null + (cond - null) * s; s = 1 is the conditional pass, s = 0 the null pass;
+      * batch invariance: a sample's logits do not depend on its batch mates;
+      * the decode loop: every step masks exactly the scheduled count per sample, final ids are < codebook size and carry no mask id,
+        the same seed reproduces the ids, and a sharded run (row_offset) reproduces the unsharded one;
+      * the persistent logits kernel equals the non-persistent one bit for bit at this size."""
+    import bench
+    from muse_maskgit_pytorch_amd import _lib
+    mg, _ = bench.build_models(DEV)
+    tr = mg.transformer
+    B, n, V = 8, 256, 65536
+    te = bench.synth_text(B, 32, 512).to(DEV)
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(0, V, (B, n), generator=g)
+    ids[torch.rand(B, n, generator=g) < 0.6] = tr.mask_id
+    ids = ids.to(DEV)
+    cond = tr(ids, text_embeds=te, cond_drop_prob=0.)
+    null = tr(ids, text_embeds=te, cond_drop_prob=1.)
+    s3 = tr.forward_with_cond_scale(ids, text_embeds=te, cond_scale=3.)
+    ref3 = null + (cond - null) * 3.
+    assert (s3 - ref3).abs().max() <= 2e-5 * ref3.abs().max() + 1e-5
+    assert torch.equal(tr.forward_with_cond_scale(ids, text_embeds=te, cond_scale=1.), cond)
+    s0 = tr.forward_with_cond_scale(ids, text_embeds=te, cond_scale=0.)
+    assert (s0 - null).abs().max() <= 1e-5 * null.abs().max() + 1e-6
+    sub = tr(ids[2:5], text_embeds=te[2:5], cond_drop_prob=0.)
+    assert torch.equal(sub, cond[2:5])
+    lib = _lib.lib()
+    lib.mm_debug_set(4096)
+    try:
+        s3_np = tr.forward_with_cond_scale(ids, text_embeds=te, cond_scale=3.)
+    finally:
+        lib.mm_debug_set(0)
+    assert torch.equal(s3, s3_np)
+    trace = {}
+    out = mg.generate([''] * B, text_embeds=te, timesteps=18, seed=11, return_ids=True, trace=trace)
+    assert out.shape == (B, 16, 16) and (out >= 0).all() and (out < V).all()
+    counts = mg._mask_counts(18, n)
+    assert counts == [256, 254, 251, 246, 238, 229, 217, 204, 189, 172, 154, 134, 114, 92, 70, 47, 23, 1]      # SURVEY A16
+    for step in range(18):
+        assert ((trace['masked_ids'][step] == tr.mask_id).sum(-1) == counts[step]).all()
+        assert (trace['ids'][step] != tr.mask_id).all()
+    assert torch.equal(out, mg.generate([''] * B, text_embeds=te, timesteps=18, seed=11, return_ids=True))
+    lo = mg.generate([''] * 4, text_embeds=te[:4], timesteps=18, seed=11, return_ids=True, row_offset=0)
+    hi = mg.generate([''] * 4, text_embeds=te[4:], timesteps=18, seed=11, return_ids=True, row_offset=4)
+    assert torch.equal(torch.cat([lo, hi]), out)
+    img = mg.vae.decode_from_ids(out)
+    assert img.shape == (B, 3, 256, 256) and torch.isfinite(img).all()
