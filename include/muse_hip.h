@@ -122,6 +122,17 @@ int mm_ce_loss(mm_stream_t stream, const float* logits, int64_t ld, int R, int V
                float* row_loss_ws, float* out);
 int mm_bce_loss(mm_stream_t stream, const float* x, const float* y, int n, float* out);
 
+/* ---- fp8 weights (BASELINE configs[4]: "fp8 MFMA weights"; W8A16: e4m3 weights, bf16 activations, fp32 accumulate).
+ * mm_quantize_e4m3_rows: w fp32 [rows][ldw] -> wq OCP-e4m3 bytes [rows][Kp] (columns K..Kp-1 zero, Kp % 64 == 0 for the GEMM) with one
+ * scale per row, scale = max|w_row| / 448 (1 for an all-zero row), wq = rne(w / scale).
+ * mm_gemm_w8a16: out[M][N] = x[M][K] (bf16) * dequant(wq[N][K], scale[N])^T; the weight tile travels as fp8 (half the bytes) and is
+ * widened to bf16 in registers (exact), the scale multiplies the fp32 accumulators.  x_null != NULL: the guidance form
+ * null + (cond - null) * cond_scale like mm_gemm_cfg_logits (fp32 output).  The self-defined oracle is the bf16 path on the
+ * de-quantised weights (SURVEY 8c "L2"). */
+int mm_quantize_e4m3_rows(mm_stream_t stream, const float* w, int64_t ldw, int rows, int K, int Kp, void* wq, float* scale);
+int mm_gemm_w8a16(mm_stream_t stream, const void* x, const void* x_null, int64_t ldx, const void* wq, int64_t ldw, const float* scale,
+                  int M, int N, int K, void* out, int64_t ldc, int out_f32, const float* resid_f32, float cond_scale);
+
 /* Nearest-codebook vector quantisation (the north star's "L2 nearest-codebook VQ lookup"; EXTENSION with a self-defined oracle:
  * the reference's VectorQuantize branch, vqgan_vae.py:297-303, 336-342, 433-435, cannot run).  x fp32 [N][ldx] (C used), codebook fp32
  * [K][C], C % 4 == 0, C <= 256.  ids[r] = argmin_k |x_r - e_k|^2, or argmax_k of the cosine similarity when cosine != 0

@@ -67,6 +67,8 @@ SIGNATURES = {
                                c_u32, c_vp, c_vp, c_vp, c_vp]),
     'mm_ce_loss': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_i64, c_vp, c_vp]),
     'mm_bce_loss': (c_int, [c_vp, c_vp, c_vp, c_int, c_vp]),
+    'mm_quantize_e4m3_rows': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp]),
+    'mm_gemm_w8a16': (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_int, c_vp, c_f32]),
     'mm_vq_nearest': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp]),
     'mm_vq_gather': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp]),
     'mm_gemm_wgrad_splits': (c_int, [c_int, c_int, c_int]),

@@ -28,6 +28,7 @@ struct GemmArgs {
     int act; float cfg_scale;
     int epi;                      // EPI_GEGLU: W rows are GEGLU-interleaved, the tile emits N/2 columns of gate*gelu(x)
     int tiles_m, tiles_n;         // filled by mm_gemm_launch
+    const float* w_scale;         // non-null: W is fp8 e4m3 [N][ldw bytes] with one dequantisation scale per row (W8A16)
     int splits; long split_stride; // split-K (weight gradients): gridDim.y = splits, split s sums k-tiles [s*K/splits, (s+1)*K/splits) into out + s*split_stride floats
     int debug;                    // ablation bits (mm_debug_set): 1 = no epilogue stores, 2 = no DMA after tile 0, 4 = no MFMA, 8 = force the 128x128 kernel, 4096 = no persistent kernel
 };
@@ -58,6 +59,7 @@ int k_add_rowvec(hipStream_t s, float* x, long ldx, int rows, int D, const float
 int k_ln_bf16(hipStream_t s, const bf16_t* a, long lda, int rows, int F, int Fp, const float* gamma, const float* beta,
               bf16_t* out, long ldo);
 int k_f32_to_bf16(hipStream_t s, const float* x, bf16_t* out, long count);
+int k_quantize_e4m3_rows(hipStream_t s, const float* w, long ldw, int rows, int K, int Kp, unsigned char* wq, float* scale);
 
 struct AttnArgs {
     const bf16_t* q; long q_sb, q_sh, q_sn;      // element strides: batch, head, token (d contiguous, dh = 64)

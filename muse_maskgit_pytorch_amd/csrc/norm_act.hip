@@ -219,6 +219,35 @@ int k_add_rowvec(hipStream_t s, float* x, long ldx, int rows, int D, const float
     return mm_check_launch("add_rowvec_kernel");
 }
 
+// per-row symmetric quantisation to OCP fp8 e4m3: scale = max|w| / 448, wq = rne(w / scale); columns K..Kp-1 are zero
+__global__ __launch_bounds__(256) void quantize_e4m3_rows_kernel(const float* __restrict__ w, long ldw, int rows, int K, int Kp,
+                                                                 unsigned char* __restrict__ wq, float* __restrict__ scale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* wr = w + (long)row * ldw;
+    float m = 0.f;
+    for (int c = lane; c < K; c += 64) m = fmaxf(m, fabsf(wr[c]));
+    m = wave_max(m);
+    const float sc = m > 0.f ? m / 448.f : 1.f;
+    if (lane == 0) scale[row] = sc;
+    for (int c = lane * 4; c < Kp; c += 256) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (c + j < K) ? wr[c + j] / sc : 0.f;      // IEEE division: the same value torch's w / scale rounds
+        int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
+        *reinterpret_cast<int*>(wq + (long)row * Kp + c) = pk;
+    }
+}
+
+int k_quantize_e4m3_rows(hipStream_t s, const float* w, long ldw, int rows, int K, int Kp, unsigned char* wq, float* scale) {
+    if (rows <= 0) return MM_OK;
+    if (Kp % 4 || Kp < K) return mm_set_error(MM_ERR_SHAPE, "quantize_e4m3_rows: padded width must be a multiple of 4 and >= K");
+    hipLaunchKernelGGL(quantize_e4m3_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, w, ldw, rows, K, Kp, wq, scale);
+    return mm_check_launch("quantize_e4m3_rows_kernel");
+}
+
 int k_f32_to_bf16(hipStream_t s, const float* x, bf16_t* out, long count) {
     if (count <= 0) return MM_OK;
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(count)), dim3(256), 0, s, x, out, count);

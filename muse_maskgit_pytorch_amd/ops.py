@@ -523,3 +523,30 @@ def vq_gather(ids, codebook):
     out = torch.empty(N, C, dtype=torch.float32, device=codebook.device)
     L.check(L.lib().mm_vq_gather(L.stream(), L.ptr(ids.reshape(-1).contiguous()), N, C, L.ptr(codebook.contiguous()), L.ptr(out)), 'mm_vq_gather')
     return out.reshape(*ids.shape, C)
+
+
+# ------------------------------------------------------------------------------------------------ fp8 weights (W8A16)
+def quantize_e4m3_rows(w):
+    """fp32/bf16 [N, K] -> (wq uint8 [N, Kp] OCP-e4m3 bytes, Kp = K rounded up to 64, zero padded; scale fp32 [N])."""
+    _chk_cuda(w)
+    w = w.detach().float().contiguous()
+    N, K = w.shape
+    Kp = (K + 63) // 64 * 64
+    wq = torch.empty(N, Kp, dtype=torch.uint8, device=w.device)
+    scale = torch.empty(N, dtype=torch.float32, device=w.device)
+    L.check(L.lib().mm_quantize_e4m3_rows(L.stream(), L.ptr(w), K, N, K, Kp, L.ptr(wq), L.ptr(scale)), 'mm_quantize_e4m3_rows')
+    return wq, scale
+
+
+def gemm_w8a16(x, wq, scale, out_f32=False, resid=None, x_null=None, cond_scale=1.0):
+    """x bf16 [M, Kp] @ dequant(wq [N, Kp], scale [N])^T; x_null: guidance form null + (cond - null) * cond_scale (fp32)."""
+    _chk_cuda(x, wq, scale, resid, x_null)
+    M, K = x.shape
+    N = wq.shape[0]
+    assert wq.dtype == torch.uint8 and wq.shape[1] == K and x.dtype == bf16
+    f32o = out_f32 or x_null is not None
+    ldc = (N + 7) // 8 * 8
+    out = torch.empty(M, ldc, dtype=torch.float32 if f32o else bf16, device=x.device)[:, :N]
+    L.check(L.lib().mm_gemm_w8a16(L.stream(), L.ptr(x), L.ptr(x_null), x.stride(0), L.ptr(wq), wq.stride(0), L.ptr(scale), M, N, K, L.ptr(out),
+                                  out.stride(0), int(f32o), L.ptr(resid), float(cond_scale)), 'mm_gemm_w8a16')
+    return out
