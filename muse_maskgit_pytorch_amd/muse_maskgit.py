@@ -154,6 +154,8 @@ class Transformer(nn.Module):
         self._handle_key = None
         self._ws = None
         self.grad_sync = None          # optional parallel.GradBucketer: data-parallel gradient averaging inside the backward
+        self.weight_format = 'bf16'    # 'fp8': W8A16 inference (BASELINE configs[4]), see quantize_weights_fp8()
+        self._fp8 = None
 
     # ---- packing (once per parameter version / device)
     def _pack_ff(self, ff, keep):
@@ -256,6 +258,8 @@ class Transformer(nn.Module):
         return ctx, mask
 
     def _run(self, ids, ctx, mask, self_cond_embed=None, want_embed=True, want_logits=True):
+        if self.weight_format == 'fp8':
+            return self._run_fp8(ids, ctx, mask, self_cond_embed, want_embed, want_logits)
         h = self._model()
         dev = self.token_emb.weight.device
         ids = ids.to(device=dev, dtype=torch.long).contiguous()
@@ -273,6 +277,108 @@ class Transformer(nn.Module):
                                                L.ptr(embed), L.ptr(logits), L.ptr(ws), ws.numel()), 'mm_transformer_forward')
         return embed, logits
 
+    # ---- fp8 weights (BASELINE configs[4] "fp8 MFMA weights"; W8A16: e4m3 weights with one scale per output row, bf16 activations)
+    def quantize_weights_fp8(self, enabled=True):
+        """Switch inference to fp8 (OCP e4m3) Linear weights: every nn.Linear of the blocks and to_logits is quantised per output row
+        (`mm_quantize_e4m3_rows`) and multiplied through `mm_gemm_w8a16` (fp8 weight tiles widened to bf16 in registers -- exact --
+        fp32 accumulate, scale applied to the accumulators).  Embeddings, norms, scales, null k/v and the text projection stay as they
+        are.  The forward then runs operator by operator from Python and `MaskGit.generate` takes its stepwise loop; the fused bf16
+        engine is untouched.  Self-defined oracle (SURVEY 8c "L2"): the fp32 oracle on the de-quantised weights (`fp8_dequantized_state_dict`)."""
+        self.weight_format = 'fp8' if enabled else 'bf16'
+        self._fp8 = None
+        return self
+
+    def _fp8_pack(self):
+        key = (str(self.token_emb.weight.device),) + tuple(p._version for p in self.parameters())
+        if self._fp8 is not None and self._fp8['key'] == key:
+            return self._fp8
+        q = ops.quantize_e4m3_rows
+        f32c = lambda x: x.detach().float().contiguous()
+        P = dict(key=key, layers=[])
+
+        def ff_pack(ff):
+            w1, w2 = ff[1].weight.detach(), ff[4].weight.detach()
+            F, D = w2.shape[1], w1.shape[1]
+            Fp = (F + 63) // 64 * 64
+            w1p = torch.zeros(2 * Fp, D, dtype=torch.float32, device=w1.device)          # plain [x | gate] halves, each padded to Fp rows
+            w1p[:F] = w1[:F]
+            w1p[Fp:Fp + F] = w1[F:]
+            return dict(F=F, g1=f32c(ff[0].gamma), b1=ff[0].beta.float().contiguous(), w1=q(w1p), g2=f32c(ff[3].gamma),
+                        b2=ff[3].beta.float().contiguous(), w2=q(w2))
+
+        def attn_pack(a, fused):
+            d = dict(g=f32c(a.norm.gamma), b=a.norm.beta.float().contiguous(), wo=q(a.to_out.weight), nk=f32c(a.null_kv[0, :, 0, :]),
+                     nv=f32c(a.null_kv[1, :, 0, :]), qs=f32c(a.q_scale), ks=f32c(a.k_scale))
+            if fused:
+                d['wqkv'] = q(torch.cat([a.to_q.weight.detach(), a.to_kv.weight.detach()], 0))
+            else:
+                d['wq'], d['wkv'] = q(a.to_q.weight), q(a.to_kv.weight)
+            return d
+        for sa, ca, ff in self.transformer_blocks.layers:
+            P['layers'].append(dict(sa=attn_pack(sa, True), ca=attn_pack(ca, False), ff=ff_pack(ff)))
+        P['sc'] = ff_pack(self.self_cond_to_init_embed)
+        P['wl'] = q(self.to_logits.weight)
+        P['tok'], P['pos'] = self.token_emb.weight.detach().to(bf16).contiguous(), self.pos_emb.weight.detach().to(bf16).contiguous()
+        P['fg'], P['fb'] = f32c(self.transformer_blocks.norm.gamma), self.transformer_blocks.norm.beta.float().contiguous()
+        self._fp8 = P
+        return P
+
+    def fp8_dequantized_state_dict(self):
+        """state_dict with every fp8-quantised Linear weight replaced by its de-quantised value (what the W8A16 path multiplies by)."""
+        sd = {k: v.detach().clone() for k, v in self.state_dict().items()}
+
+        def dq(w):
+            wq, sc = ops.quantize_e4m3_rows(w)
+            return (wq[:, :w.shape[1]].view(torch.float8_e4m3fn).float() * sc[:, None]).to(w.dtype)
+        for k in list(sd):
+            if k.startswith('transformer_blocks.layers.') and k.endswith('.weight') or k == 'to_logits.weight' or k.startswith('self_cond_to_init_embed.') and k.endswith('.weight'):
+                sd[k] = dq(sd[k])
+        return sd
+
+    def _run_fp8(self, ids, ctx, mask, self_cond_embed, want_embed, want_logits):
+        P = self._fp8_pack()
+        dev = self.token_emb.weight.device
+        ids = ids.to(device=dev, dtype=torch.long).contiguous()
+        b, n = ids.shape
+        H = self.transformer_blocks.cfg['heads']
+        I = H * 64
+        m = ctx.shape[1]
+        cx = ctx.reshape(b * m, self.dim)
+        heads = lambda t, rows, c0=0: t[:, c0:c0 + I].unflatten(0, (b, rows)).unflatten(2, (H, 64)).permute(0, 2, 1, 3)
+        g8 = lambda x_, w_, **kw: ops.gemm_w8a16(x_, w_[0], w_[1], **kw)
+
+        def ff(fp, x_in, resid):
+            u = ops.layernorm(x_in, fp['g1'], fp['b1'])
+            z = ops.geglu_ln(g8(u, fp['w1']), fp['F'], fp['g2'], fp['b2'])
+            return g8(z, fp['w2'], out_f32=True, resid=resid)
+        x = ops.embed(ids, P['tok'], P['pos'])
+        if self.self_cond:
+            sce = torch.zeros_like(x) if not exists(self_cond_embed) else self_cond_embed.to(device=dev, dtype=torch.float32).reshape(b * n, self.dim).contiguous()
+            x = ff(P['sc'], sce, x)
+        for lp in P['layers']:
+            a = lp['sa']
+            qkv = g8(ops.layernorm(x, a['g'], a['b']), a['wqkv'])
+            o = ops.attend(heads(qkv, n), heads(qkv, n, I), heads(qkv, n, 2 * I), normalize=True, q_scale=a['qs'], k_scale=a['ks'], null_k=a['nk'],
+                           null_v=a['nv'], out_rows=True)
+            x = g8(o, a['wo'], out_f32=True, resid=x)
+            c = lp['ca']
+            q2 = g8(ops.layernorm(x, c['g'], c['b']), c['wq'])
+            kv2 = g8(cx, c['wkv'])
+            o2 = ops.attend(heads(q2, n), heads(kv2, m), heads(kv2, m, I), key_mask=mask, normalize=True, q_scale=c['qs'], k_scale=c['ks'],
+                            null_k=c['nk'], null_v=c['nv'], out_rows=True)
+            x = g8(o2, c['wo'], out_f32=True, resid=x)
+            x = ff(lp['ff'], x, x)
+        embed = ops.layernorm(x, P['fg'], P['fb'])
+        logits = g8(embed, P['wl'], out_f32=True) if want_logits else None
+        return embed, logits
+
+    def _cfg_logits(self, emb_a, emb_b, cond_scale):
+        """to_logits on two passes + b + (a - b) * cond_scale as one GEMM (mmp.py:250-254, 332)."""
+        if self.weight_format == 'fp8':
+            wl = self._fp8_pack()['wl']
+            return ops.gemm_w8a16(emb_a, wl[0], wl[1], x_null=emb_b, cond_scale=cond_scale)
+        return ops.gemm_cfg_logits(emb_a, emb_b, self._model().packed['wl'], cond_scale)
+
     # ---- reference surface
     def forward_with_cond_scale(self, *args, cond_scale=3., return_embed=False, **kwargs):
         """mmp.py:240-259.  Both passes run to the final LayerNorm; to_logits and the guidance combine
@@ -283,8 +389,7 @@ class Transformer(nn.Module):
         b, n = x.shape
         emb_c = self.forward(x, *args[1:], _embed_only=True, cond_drop_prob=0., **kwargs)
         emb_n = self.forward(x, *args[1:], _embed_only=True, cond_drop_prob=1., **kwargs)
-        h = self._model()
-        scaled = ops.gemm_cfg_logits(emb_c, emb_n, h.packed['wl'], cond_scale).reshape(b, n, self.dim_out)
+        scaled = self._cfg_logits(emb_c, emb_n, cond_scale).reshape(b, n, self.dim_out)
         if return_embed:
             return scaled, emb_c.float().reshape(b, n, self.dim)
         return scaled
@@ -298,7 +403,7 @@ class Transformer(nn.Module):
         b, n = x.shape
         emb_p = self.forward(x, _embed_only=True, cond_drop_prob=0., text_embeds=text_embed, **kwargs)
         emb_n = self.forward(x, _embed_only=True, cond_drop_prob=0., text_embeds=neg_text_embed, **kwargs)
-        scaled = ops.gemm_cfg_logits(emb_p, emb_n, self._model().packed['wl'], cond_scale).reshape(b, n, self.dim_out)
+        scaled = self._cfg_logits(emb_p, emb_n, cond_scale).reshape(b, n, self.dim_out)
         if return_embed:
             return scaled, emb_p.float().reshape(b, n, self.dim)
         return scaled
@@ -473,7 +578,8 @@ class MaskGit(nn.Module):
         use_token_critic = exists(self.token_critic) and not force_not_use_token_critic
         if exists(negative_texts) or exists(neg_text_embeds):
             assert exists(neg_text_embeds) or len(texts) == len(negative_texts)       # mmp.py:541
-        if exists(negative_texts) or exists(neg_text_embeds) or use_token_critic or can_remask_prev_masked or self.self_cond or cond_scale == 1:
+        if (exists(negative_texts) or exists(neg_text_embeds) or use_token_critic or can_remask_prev_masked or self.self_cond or cond_scale == 1
+                or tr.weight_format == 'fp8'):
             # decode variants that need logits / scores at EVERY position: stepwise loop over the same C-ABI operators
             return self._generate_stepwise(texts, cond_images, fmap_size, temperature, topk_filter_thres, can_remask_prev_masked,
                                            use_token_critic, timesteps, cond_scale, critic_noise_scale, text_embeds, noise, noise_kind,

@@ -1,6 +1,6 @@
 """Runs MaskGit.generate on the other BASELINE.json configurations at full size (tools only: sanity + timing, bf16).
 C4 super-res 512x512 (seq_len 1024, cond_image_size 256, B = 8) and the C5 paper-scale shape (dim 1024, depth 24, heads 16, codebook 8192,
-B = 32) -- C5 in bf16 (its fp8 weights are not built)."""
+B = 32) -- C5 both in bf16 (fused engine) and with fp8 weights (W8A16, stepwise operator path)."""
 import os
 import sys
 import time
@@ -50,6 +50,10 @@ def main():
         flops = B * 36 * depth * layer
         print(f'C5 shape in bf16 (dim 1024, depth 24, heads 16, V=8192, B={B}): {dt * 1e3:.1f} ms per generate = {B / dt:.1f} images/s, '
               f'~{flops / dt / 1e12:.0f} TFLOP/s on the transformer blocks', flush=True)
+        tr.quantize_weights_fp8()
+        dt8, img8 = timed(lambda: mg.generate([''] * B, text_embeds=te, timesteps=18, seed=1), n=1)
+        assert img8.shape == (B, 3, 256, 256) and torch.isfinite(img8).all()
+        print(f'C5 with fp8 (e4m3) weights, W8A16, operator-by-operator path: {dt8 * 1e3:.1f} ms per generate = {B / dt8:.1f} images/s', flush=True)
 
 
 if __name__ == '__main__':
