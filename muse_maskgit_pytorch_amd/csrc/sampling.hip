@@ -148,6 +148,11 @@ struct SampleShared {
 
 __device__ __forceinline__ int hslot(int b) { return ((b & 31) << 6) | (b >> 5); }
 
+// workgroup barrier for LDS-only hand-offs: __syncthreads() also drains vmcnt(0), which would wait for the NEXT row's prefetch
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // inclusive suffix sum over the wave: result[l] = sum of x over lanes >= l
 __device__ __forceinline__ uint32_t wave_suffix_sum(uint32_t x, int lane) {
 #pragma unroll
@@ -193,35 +198,40 @@ template <int VEC_IT, bool FULL>
 __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
     __shared__ SampleShared S;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int row = blockIdx.x;
     const int V = p.V;
+    int row = blockIdx.x;                 // persistent: this workgroup samples rows blockIdx.x, + gridDim.x, ...
+    if (row >= p.R) return;
+
+    // ---- the one HBM read of a row: element index e = (it*ST + tid)*4 + c.  Padding (e >= V) is -inf: neutral for the max and for
+    //      exp(); min / histogram / list passes skip it by index.
+    float v[VEC_IT * 4];
+    // buffer loads: one resource descriptor per row (wave-uniform), ONE per-lane byte offset, the 32 steps as scalar offsets -- plain
+    // global loads made the compiler keep 32 separate 64-bit addresses alive across the loop (and spill them)
+    const int voff = tid * 16;
+#define LOAD_CHUNK(rs_, it0_, it1_)                                                                            \
+    _Pragma("unroll") for (int it = (it0_); it < (it1_); ++it) {                                               \
+        if (it < VEC_IT) {                                                                                     \
+            const int e = (it * ST + tid) * 4;                                                                 \
+            u32x4_t x = __builtin_amdgcn_raw_buffer_load_b128(rs_, voff, it * ST * 16, 0);                     \
+            const bool ok_ = FULL || e < V;       /* out-of-range reads return 0: make them the -inf padding */ \
+            v[it * 4 + 0] = ok_ ? __uint_as_float(x[0]) : -INFINITY; v[it * 4 + 1] = ok_ ? __uint_as_float(x[1]) : -INFINITY; \
+            v[it * 4 + 2] = ok_ ? __uint_as_float(x[2]) : -INFINITY; v[it * 4 + 3] = ok_ ? __uint_as_float(x[3]) : -INFINITY; \
+        }                                                                                                      \
+    }
+#define ROW_RSRC(row_) __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.logits + (size_t)(row_) * p.ld), 0, V * 4, 0x00020000)
+#define LOAD_ROW(row_) { const __amdgpu_buffer_rsrc_t rs_ = ROW_RSRC(row_); LOAD_CHUNK(rs_, 0, VEC_IT) }
+    LOAD_ROW(row)
+    for (;;) {
+    int tidv = tid;                       // per-row copy the compiler cannot hoist: the 128 element indices derived from it would otherwise
+    asm volatile("" : "+v"(tidv));      // be kept in registers across rows (loop-invariant) and spill
     const float* lr = p.logits + (size_t)row * p.ld;
     const long pos_flat = p.rows ? (long)p.rows[row] : (long)row;
-
-    // ---- the one HBM read of the row: element index e = (it*ST + tid)*4 + c
-    float v[VEC_IT * 4];
-#pragma unroll
-    for (int it = 0; it < VEC_IT; ++it) {
-        const int e = (it * ST + tid) * 4;
-        float4 x = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-        if (FULL || e < V) x = *reinterpret_cast<const float4*>(lr + e);
-        v[it * 4 + 0] = x.x; v[it * 4 + 1] = x.y; v[it * 4 + 2] = x.z; v[it * 4 + 3] = x.w;
-    }
-    // padding (e >= V) is -inf: neutral for the max and for exp(); min / histogram / list passes skip it by index
-    const int stop = (p.debug >> 8) & 7;      // ablation only: leave after phase `stop` (tools/sample_bench.py)
-    if (stop == 1) {
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < VEC_IT * 4; ++i) s += v[i];
-        if (s == 12345.678f) p.score_out[row] = s;
-        return;
-    }
 
     // ---- A: row max / min / mean / variance
     float vmax = -INFINITY, vmin = INFINITY, s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int it = 0; it < VEC_IT; ++it) {
-        const bool ok = FULL || (it * ST + tid) * 4 < V;
+        const bool ok = FULL || (it * ST + tidv) * 4 < V;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float x = v[it * 4 + c];
@@ -242,7 +252,6 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
     vmax = S.redf[0]; vmin = S.redf2[0]; s1 = S.bval[0]; s2 = S.bx[0];
 #pragma unroll
     for (int i = 1; i < NW; ++i) { vmax = fmaxf(vmax, S.redf[i]); vmin = fminf(vmin, S.redf2[i]); s1 += S.bval[i]; s2 += S.bx[i]; }
-    if (stop == 2) { if (vmax + s1 == 12345.678f) p.score_out[row] = s2; return; }
 
     // ---- B: softmax denominator on the unfiltered logits (fast exp: v_exp_f32, ~1e-6 relative per term)
     float se = 0.f;
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
         if (fast && !(p.debug & 16)) {
 #pragma unroll
             for (int it = 0; it < VEC_IT; ++it) {
-                if (FULL || (it * ST + tid) * 4 < V) {
+                if (FULL || (it * ST + tidv) * 4 < V) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const float x = opaque(v[it * 4 + c]);
@@ -312,12 +321,10 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
         for (int i = tid; i < NB; i += ST) S.hist[i] = 0;
         __syncthreads();
     }
-    if (stop == 3) { if (se == 12345.678f) p.score_out[row] = (float)tbin; return; }
     float sumexp = 0.f;
 #pragma unroll
     for (int i = 0; i < NW; ++i) sumexp += S.redse[i];
     bool slow = !fast || !found || cnt > CAND_CAP;
-    if (stop == 4) { if (sumexp == 12345.678f) p.score_out[row] = (float)tbin; return; }
 
     // ---- D: append every value with bin >= tbin to this wave's slice (no atomics: ballot prefix + running count).
     //      Straight-line: with ~10 % kept a ballot is practically never empty, so no branch around the bookkeeping.
@@ -329,7 +336,7 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
         const float edge = lo + (float)tbin / inv_w - (fabsf(lo) + span) * 1e-6f;
 #pragma unroll
         for (int it = 0; it < VEC_IT; ++it) {
-            const int e = (it * ST + tid) * 4;
+            const int e = (it * ST + tidv) * 4;
             const bool ok = FULL || e < V;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -343,7 +350,14 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
         }
         if (wcount > WSLICE && lane == 0) S.slow = 1;
     }
-    if (stop == 5) { if (sumexp == 12345.678f) p.score_out[row] = (float)wcount; return; }
+    // ---- the row's values are dead from here on (everything below works on the LDS lists): start the NEXT row's HBM read now, it
+    //      lands in the same registers while the exact select and the Gumbel phase (~40 % of a row's time) run
+    const int nrow = row + (int)gridDim.x;
+    const bool has_next = nrow < p.R;
+    // (issued in instalments -- 8 loads here, 3 per trip of the Gumbel loop below: a wave that issues all 32 at once sits in the
+    //  issue queue for about as long as the load takes, measured 13 k cycles of a 75 k-cycle row)
+    const __amdgpu_buffer_rsrc_t nrs = ROW_RSRC(has_next ? nrow : row);
+    if (has_next) LOAD_CHUNK(nrs, 0, 8)
     const int cw = min(wcount, WSLICE);
     if (!slow) {
         // members of bin tbin in this wave's own slice (a few per wave) -> the shared candidate list
@@ -353,7 +367,7 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
             if (x >= lo && min(NB - 1, (int)((x - lo) * inv_w)) == tbin) { const int sl = atomicAdd(&S.ncand, 1); if (sl < CAND_CAP) S.cand[sl] = fkey(x); }
         }
     }
-    __syncthreads();
+    lds_barrier();
     slow = slow || S.slow != 0;
 
     uint32_t thr;
@@ -369,22 +383,25 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
             for (int j = 0; j < n_c; ++j) { const uint32_t kj = S.cand[j]; gt += kj > ki; ge += kj >= ki; }
             if (gt < need_in && need_in <= ge) S.thr = ki;      // every thread that satisfies this holds the same key
         }
-        __syncthreads();
+        lds_barrier();
         thr = S.thr;
     } else {
         thr = slow_threshold(lr, V, need, S);
     }
-    if (stop == 6) { if (sumexp == 12345.678f) p.score_out[row] = (float)thr; return; }
 
     // ---- Gumbel argmax over the kept entries (mmp.py:410-411); ties -> lower index like torch.argmax
     const float T = p.temperature;
     float best = -INFINITY, best_x = 0.f;
     int best_i = 0x7FFFFFFF;
     if (!slow) {
-        // each wave walks its own slice, 4 independent entries per lane per trip so the RNG's multiply chains overlap
-        for (int base = 0; base < cw; base += 256) {
+        // each wave walks its own slice, 2 independent entries per lane per trip so the RNG's multiply chains overlap
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+        for (int trip = 0; trip < WSLICE / 128; ++trip) {
+            if (has_next) LOAD_CHUNK(nrs, 8 + 3 * trip, 8 + 3 * trip + 3)
+            const int base = trip * 128;
+            if (base >= cw) continue;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
                 const int i = base + u * 64 + lane;
                 if (i < cw) {
                     const uint2 ent = mykv[i];
@@ -405,6 +422,8 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
             if (y > best || (y == best && idx < best_i)) { best = y; best_i = idx; best_x = x; }
         }
     }
+    if (has_next && slow) LOAD_CHUNK(nrs, 8, VEC_IT)          // the fast path issued these inside its loop
+    if (has_next && !slow) LOAD_CHUNK(nrs, 8 + 3 * (WSLICE / 128), VEC_IT)
     // wave reduce (value desc, index asc)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -414,7 +433,7 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
         if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; best_x = ox; }
     }
     if (lane == 0) { S.bval[wid] = best; S.redi[wid] = best_i; S.bx[wid] = best_x; }
-    __syncthreads();
+    lds_barrier();
     if (tid == 0) {
         for (int i = 1; i < NW; ++i)
             if (S.bval[i] > best || (S.bval[i] == best && S.redi[i] < best_i)) { best = S.bval[i]; best_i = S.redi[i]; best_x = S.bx[i]; }
@@ -425,6 +444,13 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
         if (p.pred_out) p.pred_out[row] = (int64_t)best_i;
         if (p.score_out) p.score_out[row] = score;
     }
+    if (!has_next) break;
+    row = nrow;
+    lds_barrier();                      // the shared state of this row is done with before the next row's pass A rewrites it
+    }
+#undef LOAD_ROW
+#undef LOAD_CHUNK
+#undef ROW_RSRC
 }
 
 }  // namespace
@@ -462,7 +488,9 @@ int k_sample_rows(hipStream_t s, const SampleArgs& a_in) {
         return mm_set_error(MM_ERR_ALIGN, "sample_rows: logits/noise strides must be multiples of 4, noise required in tensor modes");
     if (!(a.temperature > 0.f)) return mm_set_error(MM_ERR_SHAPE, "sample_rows: temperature must be > 0 (clamp to 1e-10 like mmp.py:411)");
     const int vec_it = (a.V + ST * 4 - 1) / (ST * 4);
-    dim3 g(a.R), b(ST);
+    // balanced persistent grid: at most ~one workgroup per CU, every workgroup the same number of rows (+-1)
+    const int rows_per_wg = (a.R + 255) / 256;
+    dim3 g((a.R + rows_per_wg - 1) / rows_per_wg), b(ST);
     const bool full = a.V == vec_it * ST * 4;
 #define LAUNCH_S(N)                                                                   \
     if (full) hipLaunchKernelGGL((sample_kernel<N, true>), g, b, 0, s, a);            \

@@ -29,8 +29,12 @@ if args and args[0] == 'insitu':
 else:
     logits = torch.randn(R, V, device='cuda') * 0.6
 k = math.ceil(0.1 * V)
+Rs = [R]
+if args and args[0] == 'rows':
+    Rs = [256, 512, 1024, 2048, 8192]; args = args[1:]
 for fl in [int(a) for a in (args or ['0'])]:
     _lib.lib().mm_debug_set(fl)
-    t = timeit(lambda: ops.sample_rows(logits, k, 0.7, noise_kind=_lib.MM_NOISE_PHILOX, seed=1))
-    print(f'dbg{fl:4d}: {t*1e6:8.1f} us  {R*V*4/t/1e9:7.1f} GB/s', flush=True)
+    for Rn in Rs:
+        t = timeit(lambda: ops.sample_rows(logits[:Rn], k, 0.7, noise_kind=_lib.MM_NOISE_PHILOX, seed=1))
+        print(f'dbg{fl:4d} rows {Rn:5d}: {t*1e6:8.1f} us  {Rn*V*4/t/1e9:7.1f} GB/s  {t*1e6/((Rn+255)//256):6.1f} us per row-round', flush=True)
 _lib.lib().mm_debug_set(0)
