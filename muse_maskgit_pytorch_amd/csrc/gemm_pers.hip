@@ -1,6 +1,6 @@
 // Persistent variant of the 256x128 bf16 MFMA GEMM (gemm_big.hip) for the GEMM classes whose epilogue is a pure store:
 //   MODE_DENSE, bf16 output (q|k|v projection, FF w1 with the fused GEGLU epilogue)
-//   MODE_CFG,   fp32 logits  (to_logits of both guidance passes + the combine)
+//   MODE_CFG,   fp32 logits  (to_logits of both guidance passes + the combine; only when gemm_cfg.hip's 256-column tile does not apply)
 // Measured on the non-persistent kernels (tools/gemm_bench.py ablation): the output stores are 25-40 % of the kernel and
 // overlap with nothing -- every workgroup on the chip reaches its store phase at about the same time (HBM idle during the
 // MFMA phase, MFMA idle during the store phase) -- and every tile pays a DMA-latency bubble at its start.  Storing straight
@@ -9,8 +9,12 @@
 //   * two 48 KiB DMA stages + a 64 KiB output tile `ct` in LDS (160 KiB = the whole CU);
 //   * at the end of a tile the accumulators are combined (CFG / GEGLU) and transposed into ct (XOR-swizzled rows);
 //   * ct is written out row-contiguously, 16 B per lane, ONE 8 KiB piece per k-iteration of the NEXT tile, i.e. inside its
-//     MFMA stream; the LDS-DMA of the next tile's first k-tile is already in flight across the tile boundary;
-//   * counted s_waitcnt vmcnt(N): behind the DMA we wait for there is at most the one store of the previous iteration.
+//     MFMA stream (the piece is read from ct right after the barrier, with a raw ds_read, and stored after the MFMAs);
+//   * a DMA cursor of its own runs two k-steps ahead of the MFMAs, across tile boundaries;
+//   * the fragments are double-buffered over the two 32-wide halves of a stage: the ds_reads of the next half (after the
+//     barrier: of the next stage) are in flight while the MFMAs of the current half run;
+//   * counted waits as __builtin_amdgcn_s_waitcnt (the compiler's waitcnt pass must see them): behind the DMA we wait for
+//     there is at most the one store of the previous iteration.
 // Same tile shape and MFMA order as gemm.hip / gemm_big.hip -> bit-identical results.
 #include "common.h"
 #include "muse_hip_internal.h"

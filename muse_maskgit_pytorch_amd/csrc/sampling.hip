@@ -98,19 +98,20 @@ __global__ __launch_bounds__(256) void philox_fill_kernel(uint64_t seed, uint64_
 }
 
 // ------------------------------------------------------------------------------------------------ sample rows
-// Structure (one 512-thread workgroup per row, the row lives in registers, 128 values per lane at V = 65536):
-//   A  max / min of the row                                     (2 VALU per value)
+// Structure (persistent 512-thread workgroups, one row at a time in registers, 128 values per lane at V = 65536):
+//   A  max / min / mean / variance of the row                   (4 VALU per value)
 //   B  sum exp(x - max)                                         (softmax denominator of mmp.py:603)
-//   C  2048-bin value-linear histogram in LDS                   (non-returning LDS atomics)
-//      -> one wave scans it: bin t that holds the k-th largest value, and how many values lie above t
+//   C  2048-bin value-linear histogram of the row's upper tail  (non-returning LDS atomics; full-range retry pass if the tail
+//      estimate missed) -> every wave scans it: bin t that holds the k-th largest value, how many values lie above t
 //   D  every value with bin >= t is appended (value, index) to this WAVE's private slice of an LDS list --
 //      slot = running wave count + lane prefix of the ballot, so no atomics and no waits
+//   -- the row's registers are dead here: the NEXT row's HBM read starts (instalments, see below) --
 //   then short loops over the ~k listed entries only: exact k-th largest inside bin t (rank counting), Gumbel
 //   noise + argmax over the entries >= that threshold.
 // Passes A-D are the only fully unrolled code (the register file cannot be indexed dynamically); keeping them to a few
 // instructions per value matters: the first version of this kernel spent its time fetching ~50k instructions per row.
 // Rows the fast path cannot take (span 0 / non-finite, > 2048 values inside bin t, a wave slice overflowing -- i.e.
-// massive ties) go through slow_row(): bisection on the integer keys, re-reading the row from L2.
+// massive ties) go through slow_threshold(): bisection on the integer keys, re-reading the row from L2.
 constexpr int ST = 512;          // threads per row: 8 waves = 2 per SIMD -> up to 256 VGPRs each
 constexpr int NW = ST / 64;
 constexpr int NB = 2048;         // histogram bins
