@@ -170,23 +170,17 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
 #define W_FRAG(st_, i_) (*reinterpret_cast<const u32x4_t*>(smem + (st_) * STG_B + XT_B + wn * 4096 + rd + (i_) * 1024))
 #define MFMA_PAIR(af_, src_, j_)                                                                               \
     if (!ABL(p, 4)) {                                                                                          \
-        __builtin_amdgcn_s_setprio(1);                                                                         \
         _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                          \
             _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                      \
                 acc[a][2 * (j_) + h] = mfma16(af_[a], src_[h], acc[a][2 * (j_) + h]);                          \
-        __builtin_amdgcn_s_setprio(0);                                                                         \
     } else { asm volatile("" ::"v"(af_[0]), "v"(af_[1]), "v"(af_[2]), "v"(af_[3]), "v"(src_[0]), "v"(src_[1])); }
 #define STEP(AF_, AFN_)                                                                                        \
     {                                                                                                          \
         const int st_ = g % NST, stn_ = (g + 1) % NST;                                                         \
         p1[0] = X_FRAG(st_, 2); p1[1] = X_FRAG(st_, 3);                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                     \
         MFMA_PAIR(AF_, p0, 0)                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                     \
         p0[0] = X_FRAG(st_, 4); p0[1] = X_FRAG(st_, 5);                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                     \
         MFMA_PAIR(AF_, p1, 1)                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                     \
         p1[0] = X_FRAG(st_, 6); p1[1] = X_FRAG(st_, 7);                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         /* step g+1 has landed once only what this wave issued after ITS DMA can be in flight: the store of step g-2, the */ \
@@ -214,12 +208,10 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
         LOAD_NEXT(st_);                                     /* step g+3 into the stage just consumed */        \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         MFMA_PAIR(AF_, p0, 2)                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                     \
         if (g + 1 < steps_total) {                                                                             \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) AFN_[i] = W_FRAG(stn_, i);                           \
             p0[0] = X_FRAG(stn_, 0); p0[1] = X_FRAG(stn_, 1);                                                  \
         }                                                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                     \
         MFMA_PAIR(AF_, p1, 3)                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         st2 = st1;                                                                                             \
