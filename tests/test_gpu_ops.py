@@ -605,3 +605,33 @@ def test_fp8_weight_quantiser_and_w8a16_gemm(M, N, K):
     if N % 8 == 0:                                               # the residual shares the output's row stride
         res = rnd(M, N, gen=g).to(DEV)
         assert torch.equal(ops.gemm_w8a16(xd, wq, scale, out_f32=True, resid=res), got + res)
+
+
+def test_gemm_kernel_family_random_shapes_bit_identical():
+    """Race screen for the counted-vmcnt / LDS-DMA pipelines: random (ragged) shapes through whatever kernel the dispatcher picks
+    (persistent, 256x128 three-stage, guidance 128x256) against the 128x128 kernel (debug bit 8), several repetitions each."""
+    if DRY:
+        pytest.skip('kernel-structure test')
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(77)
+    shapes = []
+    for _ in range(10):
+        M = int(torch.randint(300, 20000, (1,), generator=g))
+        N = int(torch.randint(2, 40, (1,), generator=g)) * 128
+        K = int(torch.randint(1, 24, (1,), generator=g)) * 64
+        shapes.append((M, N, K))
+    for M, N, K in shapes:
+        x = r16(rnd(M, K, gen=g)).to(DEV, bf16)
+        x2 = r16(rnd(M, K, gen=g)).to(DEV, bf16)
+        w = r16(rnd(N, K, gen=g, scale=0.1)).to(DEV, bf16)
+        res = rnd(M, N, gen=g).to(DEV)
+        runs = [lambda: ops.gemm(x, w), lambda: ops.gemm(x, w, out_f32=True, resid=res), lambda: ops.gemm_cfg_logits(x, x2, w, 2.5)]
+        lib.mm_debug_set(8)
+        try:
+            refs = [f() for f in runs]
+        finally:
+            lib.mm_debug_set(0)
+        for rep in range(3):
+            for f, ref in zip(runs, refs):
+                got = f()
+                assert torch.equal(got, ref), f'shape {(M, N, K)} rep {rep}: {(got != ref).sum().item()} elements differ'
