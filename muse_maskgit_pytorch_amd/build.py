@@ -28,6 +28,8 @@ def build(force=False, verbose=False):
     flags = list(FLAGS)
     if os.environ.get('MM_GEMM_ABLATE'):      # tools/gemm_bench.py ablations only: run-time skip-stores / -DMA / -MFMA switches in the k-loops
         flags.append('-DMM_GEMM_ABLATE')
+    if os.environ.get('MM_GEMM_TIMING'):      # tools/cfg2_timing.py only: cycle stamps inside gemm_cfg2_kernel
+        flags.append('-DMM_GEMM_TIMING')
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)

@@ -34,6 +34,13 @@
 #define ABL(p_, bit_) 0
 #endif
 
+#ifdef MM_GEMM_TIMING      // tools/cfg2_timing.py only: s_memtime stamps of workgroup 0 / wave 0 along its tiles
+__device__ unsigned long long g_cfg2_stamps[1024];
+#define TSTAMP() if (ts_on && ts_i < 1024) { g_cfg2_stamps[ts_i++] = __builtin_readcyclecounter(); }
+#else
+#define TSTAMP()
+#endif
+
 namespace {
 
 constexpr int TOK = 128, BN = 256, BK = 32, NST = 3;
@@ -45,15 +52,12 @@ constexpr int SMEM_B = CT_OFF + 65536;      // 160 KiB
 
 #define WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
 
-__device__ __forceinline__ void wait_vmcnt(int n) {      // n is wave-uniform
+__device__ __forceinline__ void wait_vmcnt(int n) {      // n is wave-uniform, 0..15
     switch (n) {
-        case 0: __builtin_amdgcn_s_waitcnt(0x0F70); break;
-        case 1: __builtin_amdgcn_s_waitcnt(0x0F71); break;
-        case 2: __builtin_amdgcn_s_waitcnt(0x0F72); break;
-        case 4: __builtin_amdgcn_s_waitcnt(0x0F74); break;
-        case 5: __builtin_amdgcn_s_waitcnt(0x0F75); break;
-        case 6: __builtin_amdgcn_s_waitcnt(0x0F76); break;
-        case 8: __builtin_amdgcn_s_waitcnt(0x0F78); break;
+#define WV_CASE(i_) case i_: __builtin_amdgcn_s_waitcnt(0x0F70 + i_); break;
+        WV_CASE(1) WV_CASE(2) WV_CASE(3) WV_CASE(4) WV_CASE(5) WV_CASE(6) WV_CASE(7) WV_CASE(8) WV_CASE(9) WV_CASE(10)
+        WV_CASE(11) WV_CASE(12) WV_CASE(13) WV_CASE(14) WV_CASE(15)
+#undef WV_CASE
         default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
     }
 }
@@ -79,21 +83,30 @@ struct LoadCur {
     const bf16_t* w[2];
 };
 
+constexpr int WIDE_CFG = 0, WIDE_GEGLU = 1;
+
+template <int WMODE>
 __device__ __forceinline__ void cfg_tile_setup(const GemmArgs& p, int vb, int wid, int lane, LoadCur& lc) {
     int tile_m, tile_n;
     xcd_grouped_tile(vb, p.tiles_m, p.tiles_n, 8, tile_m, tile_n);
-    const int m0 = tile_m * TOK, n0 = tile_n * BN;
+    const int m0 = tile_m * (WMODE == WIDE_CFG ? TOK : 2 * TOK), n0 = tile_n * BN;
     const int c = (lane & 3) ^ ((-(lane >> 4)) & 3);      // logical 16-byte chunk this lane fetches into physical chunk lane & 3
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         // activation block xb of the tile: wave row wm = xb >> 3, pass h = (xb >> 2) & 1 (0 cond, 1 null), token block tb = xb & 3
         const int xb = 2 * wid + i;
-        const int tok = m0 + (xb >> 3) * 64 + (xb & 3) * 16 + (lane >> 2);
-        lc.x[i] = (((xb >> 2) & 1) ? p.X2 : p.X) + (size_t)(tok < p.M ? tok : 0) * p.ldx + c * 8;   // clamped rows: never stored
+        if constexpr (WMODE == WIDE_CFG) {
+            const int tok = m0 + (xb >> 3) * 64 + (xb & 3) * 16 + (lane >> 2);
+            lc.x[i] = (((xb >> 2) & 1) ? p.X2 : p.X) + (size_t)(tok < p.M ? tok : 0) * p.ldx + c * 8;   // clamped rows: never stored
+        } else {                                               // plain activation rows: block xb = rows 16*xb .. of the 256-row tile
+            const int m = m0 + xb * 16 + (lane >> 2);
+            lc.x[i] = p.X + (size_t)(m < p.M ? m : 0) * p.ldx + c * 8;
+        }
         lc.w[i] = p.W + (size_t)(n0 + xb * 16 + (lane >> 2)) * p.ldw + c * 8;
     }
 }
 
+template <int WMODE>
 __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ct = smem + CT_OFF;
@@ -117,7 +130,7 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
     LoadCur lc;
     int l_vb = vb, l_k = 0;
     bool l_live = true;
-    cfg_tile_setup(p, l_vb, wid, lane, lc);
+    cfg_tile_setup<WMODE>(p, l_vb, wid, lane, lc);
 #define LOAD_NEXT(st_)                                                                                         \
     if (l_live) {                                                                                              \
         if (!ABL(p, 2)) {                                                                                      \
@@ -132,7 +145,7 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
             l_k = 0;                                                                                           \
             l_vb += G;                                                                                         \
             l_live = l_vb < total;                                                                             \
-            if (l_live) cfg_tile_setup(p, l_vb, wid, lane, lc);                                                \
+            if (l_live) cfg_tile_setup<WMODE>(p, l_vb, wid, lane, lc);                                                \
         }                                                                                                      \
     }
     LOAD_NEXT(0);
@@ -189,21 +202,33 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
         WAIT_LGKM0();                                                                                          \
         __builtin_amdgcn_s_barrier();                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        if (kt == KH && have_prev) {                                                                           \
+        if (WMODE == WIDE_CFG && kt == KH && have_prev) {                                                      \
             /* every wave has read the last piece of the first half (step KH-1 at the latest): second half -> ct */ \
             HELD_TO_CT();                                                                                      \
             WAIT_LGKM0();                                                                                      \
             __builtin_amdgcn_s_barrier();                                                                      \
         }                                                                                                      \
-        /* this step's piece of the previous tile: first half during steps 0..7, second half during steps KH..KH+7 */ \
-        const int half_ = kt >= KH ? 1 : 0;                                                                    \
+        /* this step's piece of the previous tile.  CFG: first half during steps 0..7, second half during steps KH..KH+7, one */ \
+        /* token row (1 KiB fp32) per wave.  GEGLU: the whole 256 x 128 bf16 tile during steps 0..7, 4 rows (256 B each) per wave */ \
+        const int half_ = (WMODE == WIDE_CFG && kt >= KH) ? 1 : 0;                                             \
         const int q_ = kt - (half_ ? KH : 0);                                                                  \
-        const int hrow_ = PIECE_ROW(q_);                                                                       \
-        const int ptok_ = PIECE_TOKEN(hrow_, half_);                                                           \
+        int prow_, ptok_;                                                                                      \
+        const unsigned char* psrc_;                                                                            \
+        unsigned char* pv_ptr_;                                                                                \
+        if constexpr (WMODE == WIDE_CFG) {                                                                     \
+            prow_ = PIECE_ROW(q_);                                                                             \
+            ptok_ = PIECE_TOKEN(prow_, half_);                                                                 \
+            psrc_ = ct + prow_ * 1024 + ((lane ^ (prow_ & 7)) << 4);                                           \
+            pv_ptr_ = reinterpret_cast<unsigned char*>(reinterpret_cast<float*>(p.out) + (size_t)ptok_ * p.ldc + pn0 + lane * 4); \
+        } else {                                                                                               \
+            prow_ = q_ * 32 + 4 * wid + (lane >> 4);                                                           \
+            ptok_ = pm0 + q_ * 32 + 4 * wid;                   /* first of this wave's 4 rows: decides (wave-uniformly) the issue */ \
+            psrc_ = ct + prow_ * 256 + (((lane & 15) ^ (prow_ & 15)) << 4);                                    \
+            pv_ptr_ = reinterpret_cast<unsigned char*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)(pm0 + prow_) * p.ldc + (pn0 >> 1) + (lane & 15) * 8); \
+        }                                                                                                      \
         const bool piece_ = have_prev && q_ < 8 && ptok_ < p.M && !ABL(p, 1);      /* wave-uniform */          \
         uint4 pv_ = make_uint4(0, 0, 0, 0);                                                                    \
-        if (piece_) pv_ = lds_read_b128_raw(ct + hrow_ * 1024 + ((lane ^ (hrow_ & 7)) << 4));                  \
-        float* pv_ptr_ = reinterpret_cast<float*>(p.out) + (size_t)ptok_ * p.ldc + pn0 + lane * 4;             \
+        if (piece_) pv_ = lds_read_b128_raw(psrc_);                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         LOAD_NEXT(st_);                                     /* step g+3 into the stage just consumed */        \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
@@ -219,13 +244,19 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
         if (piece_) {                                                                                          \
             WAIT_LGKM0();                                       /* the raw read of pv_ (the fragments are long there) */ \
             __builtin_amdgcn_sched_barrier(0);                                                                 \
-            store_stream(pv_ptr_, pv_);                                                                        \
+            if constexpr (WMODE == WIDE_CFG) store_stream(reinterpret_cast<float*>(pv_ptr_), pv_);             \
+            else if (pm0 + prow_ < p.M) *reinterpret_cast<uint4*>(pv_ptr_) = pv_;      /* re-read by the next kernel: a plain store */ \
             st1 = 1;                                                                                           \
         }                                                                                                      \
         ++g;                                                                                                   \
         ++kt;                                                                                                  \
     }
 
+#ifdef MM_GEMM_TIMING
+    const bool ts_on = blockIdx.x == 0 && wid == 0;
+    int ts_i = 0;
+#endif
+    TSTAMP()
     // prologue: step 0 has landed once only the DMA of steps 1 and 2 (8 instructions) is in flight
     wait_vmcnt(steps_total > 2 ? 8 : (steps_total > 1 ? 4 : 0));
     __builtin_amdgcn_s_barrier();
@@ -240,36 +271,57 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
 #pragma unroll
             for (int b = 0; b < 8; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         for (int kt = 0; kt < KT;) {      // KT is even: two steps per trip, the weight fragments ping-pong between afA and afB
+            TSTAMP()
             STEP(afA, afB)
+            TSTAMP()
             STEP(afB, afA)
         }
+        TSTAMP()
         // ---- tile end: all pieces of the previous tile have been read; combine this tile and park it
         int tile_m, tile_n;
         xcd_grouped_tile(vb, p.tiles_m, p.tiles_n, 8, tile_m, tile_n);
         WAIT_LGKM0();
         __builtin_amdgcn_s_barrier();
+        TSTAMP()
+        if constexpr (WMODE == WIDE_CFG) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+            for (int b = 0; b < 4; ++b) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                f32x4_t v;
+                for (int a = 0; a < 4; ++a) {
+                    f32x4_t v;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float cv = acc[a][b][r], nl = acc[a][b + 4][r];
-                    v[r] = nl + (cv - nl) * p.cfg_scale;      // muse_maskgit_pytorch.py:254
-                }
-                if (b < 2) {
-                    if (!ABL(p, 16)) {
-                        const int hrow = wm * 32 + b * 16 + fr;
-                        const int c = wn * 16 + a * 4 + fg;
-                        *reinterpret_cast<f32x4_t*>(ct + hrow * 1024 + ((c ^ (hrow & 7)) << 4)) = v;
+                    for (int r = 0; r < 4; ++r) {
+                        const float cv = acc[a][b][r], nl = acc[a][b + 4][r];
+                        v[r] = nl + (cv - nl) * p.cfg_scale;      // muse_maskgit_pytorch.py:254
                     }
-                } else {
-                    held[b - 2][a] = v;
+                    if (b < 2) {
+                        if (!ABL(p, 16)) {
+                            const int hrow = wm * 32 + b * 16 + fr;
+                            const int c = wn * 16 + a * 4 + fg;
+                            *reinterpret_cast<f32x4_t*>(ct + hrow * 1024 + ((c ^ (hrow & 7)) << 4)) = v;
+                        }
+                    } else {
+                        held[b - 2][a] = v;
+                    }
+                }
+            }
+        } else {
+            // GEGLU (mmp.py:72-77): the weight rows are interleaved so that fragments a = 0,1 hold the gelu half and a = 2,3 the gate
+            // half of the SAME 32 output columns of this wave; the tile emits 256 rows x 128 columns of bf16 = the whole 64 KiB ct
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int row = wm * 128 + b * 16 + fr;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int col = wn * 32 + a * 16 + fg * 4;
+                    *reinterpret_cast<uint2*>(ct + row * 256 + (((col >> 3) ^ (row & 15)) << 4) + (fg & 1) * 8) =
+                        make_uint2(pack_bf16x2(geglu_f(acc[a][b][0], acc[a + 2][b][0]), geglu_f(acc[a][b][1], acc[a + 2][b][1])),
+                                   pack_bf16x2(geglu_f(acc[a][b][2], acc[a + 2][b][2]), geglu_f(acc[a][b][3], acc[a + 2][b][3])));
                 }
             }
         }
-        pm0 = tile_m * TOK; pn0 = tile_n * BN;
+        TSTAMP()
+        pm0 = tile_m * (WMODE == WIDE_CFG ? TOK : 2 * TOK); pn0 = tile_n * BN;
         have_prev = true;
         vb += G;
         if (vb >= total) break;
@@ -277,48 +329,78 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
     // ---- drain the last tile
     WAIT_LGKM0();
     __builtin_amdgcn_s_barrier();
-    for (int half = 0; half < 2; ++half) {
-        if (half) {
-            HELD_TO_CT();
+    if constexpr (WMODE == WIDE_CFG) {
+        for (int half = 0; half < 2; ++half) {
+            if (half) {
+                HELD_TO_CT();
+                WAIT_LGKM0();
+                __builtin_amdgcn_s_barrier();
+            }
+            for (int q = 0; q < 8; ++q) {
+                const int hrow = PIECE_ROW(q);
+                const int ptok = PIECE_TOKEN(hrow, half);
+                if (ptok < p.M && !ABL(p, 1)) {
+                    const uint4 pv = *reinterpret_cast<const uint4*>(ct + hrow * 1024 + ((lane ^ (hrow & 7)) << 4));
+                    store_stream(reinterpret_cast<float*>(p.out) + (size_t)ptok * p.ldc + pn0 + lane * 4, pv);
+                }
+            }
             WAIT_LGKM0();
             __builtin_amdgcn_s_barrier();
         }
+    } else {
         for (int q = 0; q < 8; ++q) {
-            const int hrow = PIECE_ROW(q);
-            const int ptok = PIECE_TOKEN(hrow, half);
-            if (ptok < p.M && !ABL(p, 1)) {
-                const uint4 pv = *reinterpret_cast<const uint4*>(ct + hrow * 1024 + ((lane ^ (hrow & 7)) << 4));
-                store_stream(reinterpret_cast<float*>(p.out) + (size_t)ptok * p.ldc + pn0 + lane * 4, pv);
+            const int row = q * 32 + 4 * wid + (lane >> 4);
+            if (pm0 + row < p.M && !ABL(p, 1)) {
+                const uint4 pv = *reinterpret_cast<const uint4*>(ct + row * 256 + (((lane & 15) ^ (row & 15)) << 4));
+                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)(pm0 + row) * p.ldc + (pn0 >> 1) + (lane & 15) * 8) = pv;
             }
         }
-        WAIT_LGKM0();
-        __builtin_amdgcn_s_barrier();
     }
 }
 
 }  // namespace
 
-// K a multiple of 32 with at least 16 k-steps (the 16 store pieces of a tile ride on the next tile's k-loop), N a multiple of
-// the 256-column tile, fp32 output with 16-byte aligned rows, enough tiles for one workgroup per CU
+// K a multiple of 64 with at least 16 k-steps of 32 (the store pieces of a tile ride on the next tile's k-loop), N a multiple of
+// the 256-row weight tile, 16-byte aligned output rows, enough tiles for one workgroup per CU.
+// CFG: fp32 logits of both guidance passes + the combine.  GEGLU: FF w1 with the fused gate * gelu(x) epilogue (bf16, N/2 columns).
 bool mm_gemm_cfg2_eligible(const GemmArgs& a) {
-    if (a.mode != MODE_CFG || a.out_kind != OUT_F32 || a.bias || a.act != ACT_NONE || a.resid_bf16 || a.resid_f32) return false;
-    if ((a.K % (2 * BK)) != 0 || a.K < 16 * BK || (a.N % BN) != 0) return false;
-    if ((a.ldc % 4) || (((uintptr_t)a.out) & 15)) return false;
-    const long tiles = (long)((a.M + TOK - 1) / TOK) * (a.N / BN);
-    return tiles >= 256;
+    if (a.bias || a.act != ACT_NONE || a.resid_bf16 || a.resid_f32) return false;
+    if ((a.K % (2 * BK)) != 0 || a.K < 16 * BK || (a.N % BN) != 0 || (((uintptr_t)a.out) & 15)) return false;
+    if (a.mode == MODE_CFG) {
+        if (a.out_kind != OUT_F32 || (a.ldc % 4)) return false;
+        return (long)((a.M + TOK - 1) / TOK) * (a.N / BN) >= 256;
+    }
+    if (a.mode == MODE_DENSE && a.epi == EPI_GEGLU) {
+        if (a.out_kind != OUT_BF16 || (a.ldc % 8)) return false;
+        const long tiles = (long)((a.M + 2 * TOK - 1) / (2 * TOK)) * (a.N / BN);
+        // measured (tools/gemm_bench.py, MI355X): per 256 x 256 of output the k-loop is ~7 % faster than gemm_pers', the tile end
+        // costs about the same, and the coarser tile loses more to the last partial round -- a win only for long K on tile counts
+        // that fill the CUs evenly (16384 x 4096 x 2048: 253 vs 267 us); FF w1 of the base config (K = 512) stays on gemm_pers
+        return a.K >= 1024 && tiles >= 256 && ((tiles % 256) == 0 || tiles >= 4096);
+    }
+    return false;
 }
 
 int mm_gemm_cfg2_launch(GemmArgs a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cfg2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cfg2_kernel<WIDE_CFG>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cfg2_kernel<WIDE_GEGLU>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
         if (e != hipSuccess) return mm_set_hip_error(e, "gemm_cfg2 hipFuncSetAttribute");
         attr_set = true;
     }
+    const bool cfg = a.mode == MODE_CFG;
     a.tiles_n = a.N / BN;
-    a.tiles_m = (a.M + TOK - 1) / TOK;
+    a.tiles_m = cfg ? (a.M + TOK - 1) / TOK : (a.M + 2 * TOK - 1) / (2 * TOK);
     const int total = a.tiles_m * a.tiles_n;
     const int grid = total < 256 ? total : 256;
-    hipLaunchKernelGGL(gemm_cfg2_kernel, dim3(grid), dim3(512), SMEM_B, stream, a);
+    if (cfg) hipLaunchKernelGGL(gemm_cfg2_kernel<WIDE_CFG>, dim3(grid), dim3(512), SMEM_B, stream, a);
+    else hipLaunchKernelGGL(gemm_cfg2_kernel<WIDE_GEGLU>, dim3(grid), dim3(512), SMEM_B, stream, a);
     return mm_check_launch("gemm_cfg2_kernel");
 }
+
+#ifdef MM_GEMM_TIMING
+extern "C" int mm_debug_cfg2_stamps(unsigned long long* host_dst, int n) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_cfg2_stamps), sizeof(unsigned long long) * n);
+}
+#endif

@@ -180,9 +180,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
 // ------------------------------------------------------------------------------------------------ GEGLU + inner LayerNorm backward
 // forward (norm_act.hip geglu_ln_kernel): a = gate * gelu_erf(x) over the F valid of Fp columns, z = LN(a; gamma).
 // gelu'(x) = Phi(x) + x * phi(x)
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_f(float x) { return x * gelu_phi(x); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
-    return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+    return gelu_phi(x) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
 }
 
 template <int NIT>      // 16-byte iterations per lane: 3 (Fp <= 1536) / 6 / 12
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void geglu_ln_bwd_kernel(const bf16_t* __restr
                 unpack8(*reinterpret_cast<const uint4*>(hr + Fp + c * 8), gv);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float cdf = 0.5f * (1.f + erff(xv[j] * 0.70710678118654752440f));      // Phi(x): gelu = x Phi, gelu' = Phi + x phi
+                    const float cdf = gelu_phi(xv[j]);      // Phi(x): gelu = x Phi, gelu' = Phi + x phi
                     ph[it][j] = cdf;
                     const float val = (c * 8 + j < F) ? gv[j] * (xv[j] * cdf) : 0.f;
                     a[it][j] = val;

@@ -181,14 +181,15 @@ def test_gemm_large_tile_kernel_is_bit_identical_to_small(M, N, K):
 
 
 @pytest.mark.parametrize('kind,M,N,K', [('dense', 16384, 1536, 512), ('dense', 8192, 2048, 1024), ('dense', 9000, 4096, 512),
-                                         ('geglu', 16384, 2816, 512), ('cfg', 8128, 8192, 512), ('cfg', 4096, 65536, 512),
+                                         ('geglu', 16384, 2816, 512), ('geglu', 16300, 4096, 1024), ('geglu', 8192, 8192, 1024),
+                                         ('geglu_pers', 16384, 4096, 1024), ('cfg', 8128, 8192, 512), ('cfg', 4096, 65536, 512),
                                          ('cfg', 4000, 8192, 1024), ('cfg', 1000, 16384, 512), ('cfg', 130, 65536, 512),
                                          ('cfg_pers', 8128, 8192, 512), ('cfg_pers', 4096, 65536, 512)])
 def test_gemm_persistent_kernel_is_bit_identical(kind, M, N, K):
     """>= 256 tiles of 256x128 with a pure-store epilogue take the persistent kernel (gemm_pers.hip: DMA cursor running ahead
     across tile boundaries, double-buffered fragments, stores overlapped with the next tile, counted vmcnt); debug bit 4096
     disables it; the guidance logits take gemm_cfg.hip (128 tokens x 256 columns, K in steps of 32, output in two halves; debug
-    bit 8192 falls back to gemm_pers).  Identical MFMA sequence -> identical bits; repeated runs to shake out pipeline races
+    bit 8192 falls back to gemm_pers), and so does FF w1 with its GEGLU epilogue in the 256 x 256 variant of that kernel.  Identical MFMA sequence -> identical bits; repeated runs to shake out pipeline races
     (ragged M included)."""
     if DRY:
         pytest.skip('kernel-structure test')
@@ -198,7 +199,7 @@ def test_gemm_persistent_kernel_is_bit_identical(kind, M, N, K):
     if kind in ('cfg', 'cfg_pers'):
         xc, xn = r16(rnd(M, K, gen=g)).to(DEV, bf16), r16(rnd(M, K, gen=g)).to(DEV, bf16)
         run = lambda: ops.gemm_cfg_logits(xc, xn, w, 3.0)
-    elif kind == 'geglu':
+    elif kind in ('geglu', 'geglu_pers'):
         x = r16(rnd(M, K, gen=g)).to(DEV, bf16)
         run = lambda: ops.gemm_geglu(x, w)
     else:
@@ -206,7 +207,7 @@ def test_gemm_persistent_kernel_is_bit_identical(kind, M, N, K):
         run = lambda: ops.gemm(x, w)
     lib.mm_debug_set(4096)
     ref = run()
-    lib.mm_debug_set(8192 if kind == 'cfg_pers' else 0)
+    lib.mm_debug_set(8192 if kind in ('cfg_pers', 'geglu_pers') else 0)
     try:
         for rep in range(6):
             got = run()

@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from muse_maskgit_pytorch_amd import _lib, ops
 
-SHAPES = [('qkv', 16384, 1536, 512), ('out', 16384, 512, 512), ('w1', 16384, 2816, 512), ('w2', 16384, 512, 1408),
+SHAPES = [('qkv', 16384, 1536, 512), ('out', 16384, 512, 512), ('w1', 16384, 2816, 512), ('w1geglu', 16384, 2816, 512), ('w1geglu', 16384, 5632, 1024), ('w2', 16384, 512, 1408),
           ('big', 8192, 8192, 8192), ('logits', 8192, 65536, 512)]
 
 
@@ -32,12 +32,14 @@ def main():
         x = torch.randn(M, K + pad, device=dev).bfloat16()[:, :K]
         w = (torch.randn(N, K + pad, device=dev) * 0.05).bfloat16()[:, :K]
         out_bf = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-        line = f'{name:7s} M={M:6d} N={N:6d} K={K:5d}'
+        line = f'{name:8s} M={M:6d} N={N:6d} K={K:5d}'
         for fl in flags:
             _lib.lib().mm_debug_set(fl)
             if name == 'logits':
                 o32 = torch.empty(M // 2, N, device=dev, dtype=torch.float32)
                 t = timeit(lambda: ops.gemm_cfg_logits(x[:M // 2], x[M // 2:], w, 3.0, out=o32), 5)
+            elif name == 'w1geglu':
+                t = timeit(lambda: ops.gemm_geglu(x, w))
             else:
                 t = timeit(lambda: ops.gemm(x, w, out=out_bf))
             line += f' | dbg{fl}: {t * 1e6:8.1f} us {2 * M * N * K / t / 1e12:7.1f} TF'
