@@ -132,6 +132,8 @@ def lib():
             fn.argtypes = args
         if l.mm_abi_version() != 1:
             raise MuseHipError('libmuse_hip ABI version mismatch')
+        if os.environ.get('MM_DEBUG'):      # tools / A-B runs only: kernel-selection bits (see muse_hip_internal.h)
+            l.mm_debug_set(int(os.environ['MM_DEBUG'], 0))
         _lib = l
     return _lib
 

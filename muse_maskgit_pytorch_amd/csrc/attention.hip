@@ -277,6 +277,244 @@ __global__ __launch_bounds__(NWV * 64) void attention_kernel(const AttnArgs p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ all keys resident (nk <= 256)
+// Self-attention of the 256-token configs: ONE 512-thread workgroup per (batch, head) takes all (up to 256) queries, so K and V
+// are fetched, and K is normalised, once per (batch, head) instead of once per 128 queries, and the whole key axis sits in LDS:
+//   * K^ (l2-normalised * k_scale, bf16) goes through registers into 128-byte rows with the chunk XOR (row & 7) as above;
+//   * V is NOT transposed by the VALU: LDS-DMA (global_load_lds) copies it as [4 d-blocks][256 keys][16 d] (32-byte rows) and the
+//     P.V B-operand is fetched with ds_read_b64_tr_b16, gfx950's transposing LDS read -- within a 16-lane group, lane c receives
+//     element (c & 3) of the 8 bytes addressed by lanes (c >> 2), 4 + (c >> 2), 8 + .., 12 + ..; with lane l addressing byte 8*l of
+//     a 16-key x 16-d block that is V[4 consecutive keys 4*fg ..][d0 + c].  (A row-major [key][64 d] image with an XOR swizzle is
+//     conflict-free by the ordinary bank rule and still ran this kernel at 53 us instead of 34: the transposing read has its own
+//     conflict classes, MI355X_MICROARCH.md LDS table.)
+//   * no online softmax and no P buffer: S^T = K^ Q^T for all 16 key blocks stays in registers (a lane owns 4 keys x 16 blocks of
+//     ONE query), softmax is two cross-lane steps, and two 16-key accumulator blocks, packed to bf16, ARE an A operand of the
+//     P.V MFMA (contraction slot 8*fg + j <-> key block (j >> 2), key 4*fg + (j & 3)) as long as V's fragment uses the same slot
+//     order -- which the two transposing reads per fragment do;
+//   * the null key/value enters the softmax as one more score per query and O starts at p_null * v_null.
+// LDS: 32 KiB K^ + 32 KiB V + 8 x 512 B output transposition = 68 KiB -> two workgroups per CU, 128 VGPRs per wave.
+constexpr int FULL_NK = 256;
+constexpr int FULL_SMEM = 2 * FULL_NK * 128 + 8 * 512 + 512;
+
+typedef short v4i16_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint2 lds_read_tr16(const unsigned char* ptr) {
+    typedef __attribute__((address_space(3))) v4i16_t* lds_v4_t;
+    const v4i16_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)ptr);
+    return __builtin_bit_cast(uint2, r);
+}
+
+template <int NKB>      // 16-key blocks: nk = 16 * NKB exactly (128, 192 or 256 keys) -- no per-score validity tests anywhere
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attention_full_kernel(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+    unsigned char* Ks = fsm;
+    unsigned char* Vs = fsm + FULL_NK * 128;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    unsigned char* Os = fsm + 2 * FULL_NK * 128 + w * 512;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int kb_ = p.kv_batch_mod > 0 ? b % p.kv_batch_mod : b;
+    const bf16_t* kbase = p.k + (size_t)kb_ * p.k_sb + (size_t)h * p.k_sh;
+    const bf16_t* vbase = p.v + (size_t)kb_ * p.v_sb + (size_t)h * p.v_sh;
+    constexpr int nk = NKB * 16;
+
+    // ---- V: 4 LDS-DMA instructions per wave, each 32 keys x one 16-d block = 1 KiB of the [4 d-blocks][256 keys][16 d] image
+    //      (rows of the image beyond nk are never read)
+    {
+        typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int key = w * 32 + (lane >> 1);
+            const bf16_t* src = vbase + (size_t)(key < nk ? key : 0) * p.v_sn + i * 16 + (lane & 1) * 8;
+            __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(Vs + i * 8192 + w * 1024), 16, 0, 0);
+        }
+    }
+    // ---- K: half a key row (32 d) per thread
+    const int s_key = t >> 1, s_half = t & 1;
+    uint4 kr[4];
+    {
+        const bf16_t* kp = kbase + (size_t)(s_key < nk ? s_key : 0) * p.k_sn + s_half * 32;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) kr[c] = *reinterpret_cast<const uint4*>(kp + c * 8);
+    }
+    // ---- the per-dim query scales and the normalised null key (mmp.py:145-149; bf16-rounded like a real key), as fp32 rows in LDS:
+    //      every wave reads its 16 dims of both per query block with four 16-byte reads instead of 32 scalar global loads
+    float* qs_row = reinterpret_cast<float*>(fsm + 2 * FULL_NK * 128 + 8 * 512);
+    float* nk_row = qs_row + 64;
+    if (w == 0) {
+        qs_row[lane] = p.normalize ? p.q_scale[lane] : 1.f;
+        float nkv = 0.f;
+        if (p.null_k) {
+            const float nkl = p.null_k[h * DH + lane];
+            const float ninv = p.normalize ? 1.f / fmaxf(sqrtf(wave_sum(nkl * nkl)), 1e-12f) : 1.f;
+            nkv = bf16_to_f32(f32_to_bf16(nkl * ninv * (p.normalize ? p.k_scale[lane] : 1.f)));
+        }
+        nk_row[lane] = nkv;
+    }
+    // ---- K^ -> LDS
+    {
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        float f[4][8];
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (s_key >= nk) kr[c] = z;
+            unpack8(kr[c], f[c]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += f[c][j] * f[c][j];
+        }
+        if (p.normalize) {
+            ss += __shfl_xor(ss, 1, 64);
+            const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[c][j] = f[c][j] * inv * p.k_scale[s_half * 32 + c * 8 + j];
+                kr[c] = pack8(f[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *reinterpret_cast<uint4*>(Ks + sw_off(s_key, s_half * 4 + c)) = kr[c];
+    }
+    __syncthreads();      // (drains vmcnt too: the V copy has landed)
+
+    const float c1 = p.scale * 1.4426950408889634f;
+    float nvv[4];                        // this lane's dims of the (bf16-rounded) null value
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) nvv[dt] = p.null_k ? bf16_to_f32(f32_to_bf16(p.null_v[h * DH + dt * 16 + fr])) : 0.f;
+#pragma unroll 1
+    for (int qb = 0; qb < 2; ++qb) {
+        // ---- Q fragments of this wave's two 16-query blocks (B operand of S^T): query fr, d = ks*32 + 8*fg .. +7
+        uint4 qf[2];
+        float s_null;
+        {
+            const int qi = blockIdx.x * 256 + w * 32 + qb * 16 + fr;
+            const bool q_ok = qi < p.nq;
+            const bf16_t* qp = p.q + (size_t)b * p.q_sb + (size_t)h * p.q_sh + (size_t)(q_ok ? qi : 0) * p.q_sn;
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            const uint4 l0 = *reinterpret_cast<const uint4*>(qp + 8 * fg);
+            const uint4 l1 = *reinterpret_cast<const uint4*>(qp + 32 + 8 * fg);
+            qf[0] = q_ok ? l0 : z;
+            qf[1] = q_ok ? l1 : z;
+            float qv0[8], qv1[8];
+            unpack8(qf[0], qv0);
+            unpack8(qf[1], qv1);
+            if (p.normalize) {
+                float ss = 0.f;
+    #pragma unroll
+                for (int j = 0; j < 8; ++j) ss += qv0[j] * qv0[j] + qv1[j] * qv1[j];
+                ss += __shfl_xor(ss, 16, 64);
+                ss += __shfl_xor(ss, 32, 64);
+                const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);      // F.normalize eps (mmp.py:41-42)
+    #pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    qv0[j] = qv0[j] * inv * qs_row[8 * fg + j];
+                    qv1[j] = qv1[j] * inv * qs_row[32 + 8 * fg + j];
+                }
+                qf[0] = pack8(qv0);
+                qf[1] = pack8(qv1);
+                unpack8(qf[0], qv0);   // what the MFMA sees
+                unpack8(qf[1], qv1);
+            }
+            s_null = NEG_BIG;
+            if (p.null_k) {
+                float part = 0.f;
+    #pragma unroll
+                for (int j = 0; j < 8; ++j) part += qv0[j] * nk_row[8 * fg + j] + qv1[j] * nk_row[32 + 8 * fg + j];
+                part += __shfl_xor(part, 16, 64);
+                part += __shfl_xor(part, 32, 64);
+                s_null = part;      // raw units, like the scores
+            }
+        }
+        // ---- S^T = K^ Q^T: acc_s[kb][r] -> key kb*16 + 4*fg + r, query fr.  The scores stay in the MFMA's raw units (q^ . k^):
+        //      softmax(scale * s) = exp2((s - max s) * scale * log2 e) is one FMA + v_exp_f32 per score (scale > 0: mmp.py:98 has 8)
+        f32x4_t acc_s[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            acc_s[kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint4 kf = *reinterpret_cast<const uint4*>(Ks + sw_off(kb * 16 + fr, ks * 4 + fg));
+                acc_s[kb] = mfma16(kf, qf[ks], acc_s[kb]);
+            }
+        }
+        float m = s_null;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {      // two v_max3_f32 per accumulator
+            m = __builtin_fmaxf(__builtin_fmaxf(m, acc_s[kb][0]), acc_s[kb][1]);
+            m = __builtin_fmaxf(__builtin_fmaxf(m, acc_s[kb][2]), acc_s[kb][3]);
+        }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        // (the weights are rounded to bf16 for the PV MFMA, so the hardware exp2, ~1e-6 relative, is exact enough)
+        const float mc = -m * c1;
+        // packed fp32 (v_pk_fma_f32 / v_pk_add_f32): this kernel is bound by VALU issue, not by the MFMA pipe
+        const f32x2_t c1v = {c1, c1}, mcv = {mc, mc};
+        f32x2_t ps2 = {0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const f32x2_t a2 = {acc_s[kb][2 * hh], acc_s[kb][2 * hh + 1]};
+                const f32x2_t x2 = __builtin_elementwise_fma(a2, c1v, mcv);
+                const f32x2_t e2 = {__builtin_amdgcn_exp2f(x2[0]), __builtin_amdgcn_exp2f(x2[1])};
+                acc_s[kb][2 * hh] = e2[0];
+                acc_s[kb][2 * hh + 1] = e2[1];
+                ps2 += e2;
+            }
+        }
+        float psum = ps2[0] + ps2[1];
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        const float p_null = p.null_k ? __builtin_amdgcn_exp2f(__builtin_fmaf(s_null, c1, mc)) : 0.f;
+        const float linv = 1.f / (psum + p_null);
+        // ---- O = p_null * v_null + P V: acc_o[dt][r] -> query 4*fg + r, d = dt*16 + fr
+        f32x4_t acc_o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float pn = __shfl(p_null, 4 * fg + r, 64);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                acc_o[dt][r] = pn * nvv[dt];
+        }
+        // transposing reads: a 16-key x 16-d block is 512 contiguous bytes of the image and lane l supplies byte 8*l of it (key
+        // 4*fg + (fr >> 2), d 4*(fr & 3) .. +3) -- the one layout the LDS serves without bank conflicts for this instruction
+#pragma unroll
+        for (int ks = 0; ks < NKB / 2; ++ks) {
+            {
+                const float pa[4] = {acc_s[2 * ks][0], acc_s[2 * ks][1], acc_s[2 * ks][2], acc_s[2 * ks][3]};
+                const float pb[4] = {acc_s[2 * ks + 1][0], acc_s[2 * ks + 1][1], acc_s[2 * ks + 1][2], acc_s[2 * ks + 1][3]};
+                const uint4 pf = make_uint4(pack_bf16x2(pa[0], pa[1]), pack_bf16x2(pa[2], pa[3]), pack_bf16x2(pb[0], pb[1]), pack_bf16x2(pb[2], pb[3]));
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const uint2 lo = lds_read_tr16(Vs + dt * 8192 + ks * 1024 + lane * 8);
+                    const uint2 hi = lds_read_tr16(Vs + dt * 8192 + ks * 1024 + 512 + lane * 8);
+                    acc_o[dt] = mfma16(pf, make_uint4(lo.x, lo.y, hi.x, hi.y), acc_o[dt]);
+                }
+            }
+        }
+        // ---- O / l -> bf16, transposed through 512 B of LDS per wave, 4 queries (one accumulator register index r) per pass, so that
+        //      a lane stores 16 B of one 128-byte output row instead of 16 scattered 2-byte values
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float lr = __shfl(linv, 4 * fg + r, 64);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<bf16_t*>(Os + fg * 128 + (dt * 16 + fr) * 2) = f32_to_bf16(acc_o[dt][r] * lr);
+            __builtin_amdgcn_wave_barrier();
+            const int qo = blockIdx.x * 256 + w * 32 + qb * 16 + 4 * (lane >> 3) + r;      // lanes 0..31: row lane >> 3, chunk lane & 7
+            if (lane < 32 && qo < p.nq) {
+                const uint4 val = *reinterpret_cast<const uint4*>(Os + lane * 16);
+                *reinterpret_cast<uint4*>(p.out + (size_t)b * p.o_sb + (size_t)h * p.o_sh + (size_t)qo * p.o_sn + (lane & 7) * 8) = val;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int k_attention(hipStream_t s, const AttnArgs& a_in) {
@@ -290,8 +528,22 @@ int k_attention(hipStream_t s, const AttnArgs& a_in) {
         return mm_set_error(MM_ERR_ALIGN, "attention: q/k/v strides must be multiples of 8 elements");
     if (a.normalize && (!a.q_scale || !a.k_scale)) return mm_set_error(MM_ERR_SHAPE, "attention: normalize needs q_scale/k_scale");
     const int reps = 1 + ((g_mm_debug >> 16) & 0xFF);      // tools/attn_bench.py: back-to-back launches from C
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_full_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, FULL_SMEM);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_full_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, FULL_SMEM);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_full_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, FULL_SMEM);
+        if (e != hipSuccess) return mm_set_hip_error(e, "attention_full hipFuncSetAttribute");
+        attr_set = true;
+    }
     for (int r = 0; r < reps; ++r) {
-        if (a.nq >= 128 && a.nk >= 128 && !(g_mm_debug & 2048)) {
+        if (a.nq >= 128 && (a.nk == 128 || a.nk == 192 || a.nk == 256) && !a.key_mask && a.scale > 0.f && !(g_mm_debug & 32768)) {
+            // all keys resident: one workgroup per (batch, head, 256 queries)
+            dim3 grid((a.nq + 255) / 256, a.H, a.B);
+            if (a.nk == 256) hipLaunchKernelGGL(attention_full_kernel<16>, grid, dim3(512), FULL_SMEM, s, a);
+            else if (a.nk == 192) hipLaunchKernelGGL(attention_full_kernel<12>, grid, dim3(512), FULL_SMEM, s, a);
+            else hipLaunchKernelGGL(attention_full_kernel<8>, grid, dim3(512), FULL_SMEM, s, a);
+        } else if (a.nq >= 128 && a.nk >= 128 && !(g_mm_debug & 2048)) {
             dim3 grid((a.nq + 127) / 128, a.H, a.B);
             hipLaunchKernelGGL(attention_kernel<8>, grid, dim3(512), 0, s, a);
         } else {

@@ -52,12 +52,15 @@ constexpr int SMEM_B = CT_OFF + 65536;      // 160 KiB
 
 #define WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
 
-__device__ __forceinline__ void wait_vmcnt(int n) {      // n is wave-uniform, 0..15
+__device__ __forceinline__ void wait_vmcnt(int n) {      // n is wave-uniform
     switch (n) {
-#define WV_CASE(i_) case i_: __builtin_amdgcn_s_waitcnt(0x0F70 + i_); break;
-        WV_CASE(1) WV_CASE(2) WV_CASE(3) WV_CASE(4) WV_CASE(5) WV_CASE(6) WV_CASE(7) WV_CASE(8) WV_CASE(9) WV_CASE(10)
-        WV_CASE(11) WV_CASE(12) WV_CASE(13) WV_CASE(14) WV_CASE(15)
-#undef WV_CASE
+        case 0: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+        case 1: __builtin_amdgcn_s_waitcnt(0x0F71); break;
+        case 2: __builtin_amdgcn_s_waitcnt(0x0F72); break;
+        case 4: __builtin_amdgcn_s_waitcnt(0x0F74); break;
+        case 5: __builtin_amdgcn_s_waitcnt(0x0F75); break;
+        case 6: __builtin_amdgcn_s_waitcnt(0x0F76); break;
+        case 8: __builtin_amdgcn_s_waitcnt(0x0F78); break;
         default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
     }
 }

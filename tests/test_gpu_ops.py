@@ -310,9 +310,11 @@ def test_attend_seam_against_reference_golden(golden):
     assert err.mean() < 5e-3 and (err > 0.05).float().mean() < 0.01, (err.mean().item(), err.max().item())
 
 
-@pytest.mark.parametrize('n,j,masked', [(64, 64, False), (256, 256, False), (256, 37, True), (100, 300, True), (16, 1, False)])
+@pytest.mark.parametrize('n,j,masked', [(64, 64, False), (256, 256, False), (256, 37, True), (100, 300, True), (16, 1, False),
+                                        (256, 192, False), (200, 128, False), (512, 256, False), (130, 129, False)])
 def test_attention_fused_norm_null(n, j, masked):
-    """mmp.py:143-159 fused: l2norm + scales + null kv + key mask, strided q/k/v straight from projection buffers."""
+    """mmp.py:143-159 fused: l2norm + scales + null kv + key mask, strided q/k/v straight from projection buffers.
+    j in {128, 192, 256} without a key mask and n >= 128 take the all-keys-resident kernel (attention_full_kernel)."""
     g = torch.Generator().manual_seed(n * 3 + j)
     b, h = 2, 8
     q = r16(rnd(b, n, h * 64, gen=g))

@@ -12,7 +12,10 @@ def timeit(fn, iters=20):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / iters
 
-for (b, n, j, tag) in [(64, 256, 256, 'self'), (32, 256, 32, 'cross')]:
+shapes = [(64, 256, 256, 'self'), (32, 256, 32, 'cross')]
+if os.environ.get('ATTN_SWEEP'):      # workgroup-count sweep of the self-attention shape
+    shapes = [(b_, 256, 256, 'self') for b_ in (8, 16, 32, 64, 128)]
+for (b, n, j, tag) in shapes:
     h = 8
     qkv = torch.randn(b, n, 3 * h * 64, device='cuda').bfloat16()
     kv = torch.randn(b, j, 2 * h * 64, device='cuda').bfloat16()
@@ -26,7 +29,7 @@ for (b, n, j, tag) in [(64, 256, 256, 'self'), (32, 256, 32, 'cross')]:
         q4 = qkv.view(b, n, 3 * h, 64)[:, :, :h].permute(0, 2, 1, 3)
         k4 = kv.view(b, j, 2 * h, 64)[:, :, :h].permute(0, 2, 1, 3)
         v4 = kv.view(b, j, 2 * h, 64)[:, :, h:].permute(0, 2, 1, 3)
-    line = f'{tag:6s}'
+    line = f'{tag:6s} b={b:3d}'
     for fl in [int(a) for a in (sys.argv[1:] or ['0'])]:
         _lib.lib().mm_debug_set(fl | (49 << 16))          # 50 launches per call from C
         t = timeit(lambda: ops.attend(q4, k4, v4, None, 8.0, True, qs, ks, nk, nv), 4) / 50
