@@ -543,7 +543,7 @@ int k_attention(hipStream_t s, const AttnArgs& a_in) {
             if (a.nk == 256) hipLaunchKernelGGL(attention_full_kernel<16>, grid, dim3(512), FULL_SMEM, s, a);
             else if (a.nk == 192) hipLaunchKernelGGL(attention_full_kernel<12>, grid, dim3(512), FULL_SMEM, s, a);
             else hipLaunchKernelGGL(attention_full_kernel<8>, grid, dim3(512), FULL_SMEM, s, a);
-        } else if (a.nq >= 128 && a.nk >= 128 && !(g_mm_debug & 2048)) {
+        } else if (a.nq >= 128 && !(g_mm_debug & 2048)) {      // (also for short contexts: 11.3 vs 13.7 us at 256 queries x 32 keys)
             dim3 grid((a.nq + 127) / 128, a.H, a.B);
             hipLaunchKernelGGL(attention_kernel<8>, grid, dim3(512), 0, s, a);
         } else {

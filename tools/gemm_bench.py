@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from muse_maskgit_pytorch_amd import _lib, ops
 
-SHAPES = [('qkv', 16384, 1536, 512), ('out', 16384, 512, 512), ('w1', 16384, 2816, 512), ('w1geglu', 16384, 2816, 512), ('w1geglu', 16384, 5632, 1024), ('w2', 16384, 512, 1408),
+SHAPES = [('xq', 8192, 512, 512), ('xkv', 1024, 1024, 512), ('qkv', 16384, 1536, 512), ('out', 16384, 512, 512), ('w1', 16384, 2816, 512), ('w1geglu', 16384, 2816, 512), ('w1geglu', 16384, 5632, 1024), ('w2', 16384, 512, 1408),
           ('big', 8192, 8192, 8192), ('logits', 8192, 65536, 512)]
 
 
