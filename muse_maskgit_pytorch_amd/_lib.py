@@ -8,7 +8,7 @@ import os
 import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libmuse_hip.so')
+LIB_PATH = os.environ.get('MM_LIB') or os.path.join(HERE, 'libmuse_hip.so')      # MM_LIB: tools-only A/B of two builds
 HEADER_PATH = os.path.join(HERE, '..', 'include', 'muse_hip.h')
 
 MM_OK = 0

@@ -81,32 +81,29 @@ __device__ __forceinline__ void store_stream(float* ptr, const uint4 v) {
     __builtin_nontemporal_store(u32x4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_t*>(ptr));
 }
 
+// The DMA uses BUFFER loads (buffer_load_dwordx4 ... lds): a tile is addressed by wave-uniform resource descriptors (its first
+// activation / weight row) plus ONE 32-bit per-lane offset that never changes (row-in-tile * pitch + swizzled chunk), and the k
+// position is a scalar offset.  Against global_load_lds with per-lane 64-bit addresses this halves the address data each DMA
+// instruction moves, removes the per-tile 64-bit address arithmetic, and lets the descriptor's num_records zero-fill the rows
+// beyond M instead of clamping them.
 struct LoadCur {
-    const bf16_t* x[2];
-    const bf16_t* w[2];
+    __amdgpu_buffer_rsrc_t x[2];      // CFG: cond rows / null rows of the tile; GEGLU: both the tile's activation rows
+    __amdgpu_buffer_rsrc_t w;
 };
 
 constexpr int WIDE_CFG = 0, WIDE_GEGLU = 1;
 
 template <int WMODE>
-__device__ __forceinline__ void cfg_tile_setup(const GemmArgs& p, int vb, int wid, int lane, LoadCur& lc) {
+__device__ __forceinline__ void cfg_tile_setup(const GemmArgs& p, int vb, LoadCur& lc) {
     int tile_m, tile_n;
     xcd_grouped_tile(vb, p.tiles_m, p.tiles_n, 8, tile_m, tile_n);
     const int m0 = tile_m * (WMODE == WIDE_CFG ? TOK : 2 * TOK), n0 = tile_n * BN;
-    const int c = (lane & 3) ^ ((-(lane >> 4)) & 3);      // logical 16-byte chunk this lane fetches into physical chunk lane & 3
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        // activation block xb of the tile: wave row wm = xb >> 3, pass h = (xb >> 2) & 1 (0 cond, 1 null), token block tb = xb & 3
-        const int xb = 2 * wid + i;
-        if constexpr (WMODE == WIDE_CFG) {
-            const int tok = m0 + (xb >> 3) * 64 + (xb & 3) * 16 + (lane >> 2);
-            lc.x[i] = (((xb >> 2) & 1) ? p.X2 : p.X) + (size_t)(tok < p.M ? tok : 0) * p.ldx + c * 8;   // clamped rows: never stored
-        } else {                                               // plain activation rows: block xb = rows 16*xb .. of the 256-row tile
-            const int m = m0 + xb * 16 + (lane >> 2);
-            lc.x[i] = p.X + (size_t)(m < p.M ? m : 0) * p.ldx + c * 8;
-        }
-        lc.w[i] = p.W + (size_t)(n0 + xb * 16 + (lane >> 2)) * p.ldw + c * 8;
-    }
+    const int rows_left = p.M - m0;                                                     // > 0
+    const int xrows = rows_left < (WMODE == WIDE_CFG ? TOK : 2 * TOK) ? rows_left : (WMODE == WIDE_CFG ? TOK : 2 * TOK);
+    const unsigned xbytes = (unsigned)xrows * (unsigned)p.ldx * 2u;                     // reads past the last real row return 0
+    lc.x[0] = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.X + (size_t)m0 * p.ldx), 0, xbytes, 0x00020000);
+    lc.x[1] = (WMODE == WIDE_CFG) ? __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.X2 + (size_t)m0 * p.ldx), 0, xbytes, 0x00020000) : lc.x[0];
+    lc.w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W + (size_t)n0 * p.ldw), 0, (unsigned)BN * (unsigned)p.ldw * 2u, 0x00020000);
 }
 
 template <int WMODE>
@@ -133,22 +130,38 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
     LoadCur lc;
     int l_vb = vb, l_k = 0;
     bool l_live = true;
-    cfg_tile_setup<WMODE>(p, l_vb, wid, lane, lc);
+    cfg_tile_setup<WMODE>(p, l_vb, lc);
+    // per-lane byte offsets inside a tile, fixed for the whole kernel.  A DMA instruction covers one 16-row block: lane l fetches
+    // row l >> 2, logical 16-byte chunk (l & 3) ^ swizzle into physical chunk l & 3.  This wave stages blocks 2*wid, 2*wid + 1 of
+    // both operands; activation block xb: CFG wave row xb >> 3, pass (xb >> 2) & 1 (0 cond, 1 null), token block xb & 3.
+    int voff_x[2], voff_w[2];
+    {
+        const int c = (lane & 3) ^ ((-(lane >> 4)) & 3);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int xb = 2 * wid + i;
+            const int xrow = (WMODE == WIDE_CFG) ? (xb >> 3) * 64 + (xb & 3) * 16 + (lane >> 2) : xb * 16 + (lane >> 2);
+            voff_x[i] = xrow * p.ldx * 2 + c * 16;
+            voff_w[i] = (xb * 16 + (lane >> 2)) * p.ldw * 2 + c * 16;
+        }
+    }
+    const bool x_null0 = (WMODE == WIDE_CFG) && (((2 * wid) >> 2) & 1);      // wave-uniform: blocks 2*wid and 2*wid + 1 share the pass
 #define LOAD_NEXT(st_)                                                                                         \
     if (l_live) {                                                                                              \
         if (!ABL(p, 2)) {                                                                                      \
             unsigned char* xs_ = smem + (st_) * STG_B + wid * 2048;                                            \
-            const int k0_ = l_k * BK;                                                                          \
-            __builtin_amdgcn_global_load_lds(lc.x[0] + k0_, (lds_ptr_t)(xs_), 16, 0, 0);                       \
-            __builtin_amdgcn_global_load_lds(lc.x[1] + k0_, (lds_ptr_t)(xs_ + 1024), 16, 0, 0);                \
-            __builtin_amdgcn_global_load_lds(lc.w[0] + k0_, (lds_ptr_t)(xs_ + XT_B), 16, 0, 0);                \
-            __builtin_amdgcn_global_load_lds(lc.w[1] + k0_, (lds_ptr_t)(xs_ + XT_B + 1024), 16, 0, 0);         \
+            const int k0_ = l_k * (BK * 2);                                                                    \
+            const __amdgpu_buffer_rsrc_t rx_ = x_null0 ? lc.x[1] : lc.x[0];                                    \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, (lds_ptr_t)(xs_), 16, voff_x[0], k0_, 0, 0);         \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, (lds_ptr_t)(xs_ + 1024), 16, voff_x[1], k0_, 0, 0);  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(lc.w, (lds_ptr_t)(xs_ + XT_B), 16, voff_w[0], k0_, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(lc.w, (lds_ptr_t)(xs_ + XT_B + 1024), 16, voff_w[1], k0_, 0, 0); \
         }                                                                                                      \
         if (++l_k == KT) {                                                                                     \
             l_k = 0;                                                                                           \
             l_vb += G;                                                                                         \
             l_live = l_vb < total;                                                                             \
-            if (l_live) cfg_tile_setup<WMODE>(p, l_vb, wid, lane, lc);                                                \
+            if (l_live) cfg_tile_setup<WMODE>(p, l_vb, lc);                                                    \
         }                                                                                                      \
     }
     LOAD_NEXT(0);
