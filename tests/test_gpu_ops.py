@@ -295,6 +295,34 @@ def test_gemm_geglu_fused_and_layernorm_inner(M, D, F_):
     assert (got[:, F_:].float() == 0).all()
 
 
+def test_geglu_gelu_is_exact_over_the_whole_range():
+    """common.h gelu_phi evaluates the erfc tail directly (rcp + exp2 + 8 FMAs) instead of libm's erff: the exact (erf) GELU of
+    mmp.py:72-77 to within the bf16 rounding of the result (+ 1e-4 relative) for every input, including the far negative tail where the 1 + erf form
+    cancels.  x values are produced exactly by a one-hot GEMM (x = 1 * w), the gate is exactly 1."""
+    if DRY:
+        pytest.skip('kernel-structure test')
+    F_, D = 64, 64
+    xs = torch.cat((torch.linspace(-12, 12, 4001), torch.tensor([0.0, -0.0, 1e-4, -1e-4, -5.0, -6.5, -8.0, 30.0, -30.0])))
+    xs = r16(xs)
+    M = (xs.numel() + F_ - 1) // F_
+    xs = F.pad(xs, (0, M * F_ - xs.numel()))
+    # row m of X holds the F_ values x[m*F_ .. ] in its first F_ features and a 1 in feature F_ - 1 + ... : use two one-hot blocks
+    X = torch.zeros(M, 2 * D)
+    X[:, :F_] = xs.view(M, F_)
+    X[:, D] = 1.0
+    w1 = torch.zeros(2 * F_, 2 * D)
+    w1[torch.arange(F_), torch.arange(F_)] = 1.0        # gelu half: h[:, j] = x_j
+    w1[F_ + torch.arange(F_), D] = 1.0                  # gate half: exactly 1
+    a = ops.gemm_geglu(X.to(DEV, bf16), ops.pack_w1_geglu(w1.to(DEV), F_))
+    got = a[:, :F_].float().cpu().reshape(-1).double()
+    x64 = xs.double()
+    ref = x64 * 0.5 * torch.special.erfc(-x64 / 2 ** 0.5)
+    err = (got - ref).abs()
+    tol = ref.abs() * (2.0 ** -8 + 1e-4) + (ref.abs() < 1e-37) * 1e-37          # half a bf16 ulp + 1e-4 relative (+ the flush of sub-normal results)
+    bad = err > tol
+    assert not bad.any(), (xs[bad][:5], got[bad][:5], ref[bad][:5])
+
+
 # ------------------------------------------------------------------------------------------------ attention
 def test_attend_seam_against_reference_golden(golden):
     """bare Attend(q,k,v,mask) on the reference's own tensors (golden from attend.py's math branch)."""
