@@ -40,37 +40,25 @@ constexpr int SMEM_B = CT_OFF + 65536;              // + 64 KiB output tile = 16
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
+// The DMA uses BUFFER loads (buffer_load_dwordx4 ... lds), see gemm_cfg.hip: a tile is two / three wave-uniform resource descriptors
+// (first weight row, first activation row of the cond / null pass), the per-lane byte offsets never change, and rows beyond M are
+// zero-filled by the descriptor's num_records -- the tile switch is a handful of scalar instructions.
 struct TilePtrs {
-    const bf16_t* w[2];
-    const bf16_t* x[4];
-    int m0, n0, tile_n;
+    __amdgpu_buffer_rsrc_t w;
+    __amdgpu_buffer_rsrc_t x[2];      // CFG: cond / null rows; dense: x[1] = x[0]
 };
 
 template <int MODE>
-__device__ __forceinline__ void tile_setup(const GemmArgs& p, int vb, int wid, int lane, TilePtrs& tp) {
+__device__ __forceinline__ void tile_setup(const GemmArgs& p, int vb, TilePtrs& tp) {
     int tile_m, tile_n;
     xcd_grouped_tile(vb, p.tiles_m, p.tiles_n, 8, tile_m, tile_n);
-    tp.tile_n = tile_n;
-    tp.n0 = tile_n * BNB;
-    tp.m0 = tile_m * (MODE == MODE_CFG ? 128 : BMB);
-    const int chunk = (lane & 7) ^ (lane >> 3);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int n = tp.n0 + 16 * wid + 8 * i + (lane >> 3);
-        tp.w[i] = p.W + (size_t)(n < p.N ? n : 0) * p.ldw + chunk * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = 32 * wid + 8 * i + (lane >> 3);
-        if constexpr (MODE == MODE_CFG) {
-            const int wm = r >> 6, jj = r & 63;
-            const int tok = tp.m0 + wm * 32 + (jj & 31);
-            tp.x[i] = ((jj >> 5) ? p.X2 : p.X) + (size_t)(tok < p.M ? tok : 0) * p.ldx + chunk * 8;
-        } else {
-            const int m = tp.m0 + r;
-            tp.x[i] = p.X + (size_t)(m < p.M ? m : 0) * p.ldx + chunk * 8;
-        }
-    }
+    constexpr int rows = (MODE == MODE_CFG) ? 128 : BMB;
+    const int n0 = tile_n * BNB, m0 = tile_m * rows;
+    const int left = p.M - m0;
+    const unsigned xbytes = (unsigned)(left < rows ? left : rows) * (unsigned)p.ldx * 2u;
+    tp.w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W + (size_t)n0 * p.ldw), 0, (unsigned)BNB * (unsigned)p.ldw * 2u, 0x00020000);
+    tp.x[0] = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.X + (size_t)m0 * p.ldx), 0, xbytes, 0x00020000);
+    tp.x[1] = (MODE == MODE_CFG) ? __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.X2 + (size_t)m0 * p.ldx), 0, xbytes, 0x00020000) : tp.x[0];
 }
 
 // accumulators -> ct (LDS).  Layouts (all rows XOR-swizzled at 16-byte chunk granularity):
@@ -202,15 +190,32 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(const GemmArgs p) {
     const int npieces = (MODE == MODE_DENSE && p.epi == EPI_GEGLU) ? 4 : 8;
 
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    // per-lane byte offsets inside a tile (fixed for the whole kernel): a DMA instruction covers 8 rows, lane l fetches row l >> 3,
+    // logical chunk (l & 7) ^ (row & 7) into physical chunk l & 7; this wave stages weight rows 16*wid + 8*i and activation rows
+    // 32*wid + 8*i (CFG: row r = wave row r >> 6, pass (r >> 5) & 1 -- wave-uniform --, token (r >> 6)*32 + (r & 31))
+    int voff_w[2], voff_x[4];
+    {
+        const int chunk = (lane & 7) ^ (lane >> 3);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) voff_w[i] = (16 * wid + 8 * i + (lane >> 3)) * p.ldw * 2 + chunk * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 32 * wid + 8 * i + (lane >> 3);
+            const int xrow = (MODE == MODE_CFG) ? (r >> 6) * 32 + (r & 31) : r;
+            voff_x[i] = xrow * p.ldx * 2 + chunk * 16;
+        }
+    }
+    const bool x_null = (MODE == MODE_CFG) && (wid & 1);
 #define ISSUE_TILE(tp_, kt_, st_)                                                                             \
     {                                                                                                         \
-        const int k0_ = (kt_) * BK;                                                                           \
+        const int k0_ = (kt_) * (BK * 2);                                                                     \
         unsigned char* ws_ = smem + (st_) * STAGE_B + wid * 2048;                                             \
         unsigned char* xs_ = smem + (st_) * STAGE_B + W_BYTES + wid * 4096;                                   \
+        const __amdgpu_buffer_rsrc_t rx_ = x_null ? (tp_).x[1] : (tp_).x[0];                                  \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
-            __builtin_amdgcn_global_load_lds((tp_).w[i] + k0_, (lds_ptr_t)(ws_ + i * 1024), 16, 0, 0);        \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds((tp_).w, (lds_ptr_t)(ws_ + i * 1024), 16, voff_w[i], k0_, 0, 0); \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
-            __builtin_amdgcn_global_load_lds((tp_).x[i] + k0_, (lds_ptr_t)(xs_ + i * 1024), 16, 0, 0);        \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, (lds_ptr_t)(xs_ + i * 1024), 16, voff_x[i], k0_, 0, 0);     \
     }
 
     int vb = blockIdx.x;
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(const GemmArgs p) {
     TilePtrs lc;
     int l_vb = vb, l_k = 0;
     bool l_live = true;
-    tile_setup<MODE>(p, l_vb, wid, lane, lc);
+    tile_setup<MODE>(p, l_vb, lc);
 #define LOAD_NEXT(st_)                                                                                        \
     if (l_live) {                                                                                             \
         if (!ABL(p, 2)) ISSUE_TILE(lc, l_k, st_);                                                         \
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(const GemmArgs p) {
             l_k = 0;                                                                                          \
             l_vb += G;                                                                                        \
             l_live = l_vb < total;                                                                            \
-            if (l_live) tile_setup<MODE>(p, l_vb, wid, lane, lc);                                             \
+            if (l_live) tile_setup<MODE>(p, l_vb, lc);                                                        \
         }                                                                                                     \
     }
     LOAD_NEXT(0);
@@ -255,6 +260,14 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(const GemmArgs p) {
             _Pragma("unroll") for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(af_[a], bf_[b], acc[a][b]);      \
         __builtin_amdgcn_s_setprio(0);                                                                        \
     } else { _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(af_[i]), "v"(bf_[i])); }
+    // first half-step of a tile: C = 0 as an inline constant instead of 64 accumulator clears per tile
+#define MFMA_HALF0(af_, bf_)                                                                                  \
+    {                                                                                                         \
+        __builtin_amdgcn_s_setprio(1);                                                                        \
+        _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                         \
+            _Pragma("unroll") for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(af_[a], bf_[b], f32x4_t{0.f, 0.f, 0.f, 0.f}); \
+        __builtin_amdgcn_s_setprio(0);                                                                        \
+    }
 
     // step 0 has landed once only step 1's six DMA instructions are still in flight
     if (steps_total > 1 && !ABL(p, 2)) __builtin_amdgcn_s_waitcnt(0x0F76);      // vmcnt(6)
@@ -268,59 +281,68 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(const GemmArgs p) {
     int g = 0;                  // global k-step counter: the stage of step g is g & 1
     int st_prev = 0;            // VMEM stores this wave issued in the previous step (they sit behind the DMA we wait for)
 
+    // Output pieces of the PREVIOUS tile ride on this tile's k-steps: piece q is read from ct right after the barrier of step q
+    // (q <= KT - 2), so every read of the old ct is complete before anybody passes the barrier of step KT - 1 -- and the tile end can
+    // overwrite ct without a barrier of its own; the new ct is first read after the barrier of the next tile's step 0, which every
+    // wave reaches with its own ct writes retired (lgkmcnt(0)).  When a tile has exactly as many k-steps as pieces, step KT - 2
+    // reads two pieces and the second one is stored in step KT - 1.
+    const bool two_in_one = KT == npieces;
+    uint4 pv2 = make_uint4(0, 0, 0, 0);
+#define STEP_BODY(FIRST_)                                                                                     \
+    {                                                                                                         \
+        const int st = g & 1;                                                                                 \
+        /* a0/b0 were requested 16 MFMAs ago: retiring them HERE (a wait the compiler's scoreboard sees) keeps it from placing */ \
+        /* an lgkmcnt(0) behind the a1/b1 reads below, which would serialise those reads with the first MFMA half */ \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                     /* lgkmcnt(0) */                               \
+        READ_FRAGS(a1, b1, st, 1);                                                                            \
+        if (FIRST_ && !ABL(p, 4)) MFMA_HALF0(a0, b0) else MFMA_HALF(a0, b0)                                   \
+        /* step g+1 (issued after the previous barrier) has landed once at most the store of the previous step is in flight. */ \
+        /* A ragged tile may skip a whole store instruction (all lanes predicated off): then st_prev = 0 -- under-counting */ \
+        /* only makes the wait conservative, over-counting would let the DMA we need slip. */                 \
+        /* (waits as builtins, not inline asm: the compiler's own waitcnt pass must SEE them, or it assumes the LDS-DMA may still */ \
+        /*  be in flight and drains vmcnt(0) in front of later ds_reads) */                                   \
+        if (st_prev) __builtin_amdgcn_s_waitcnt(0x0F71); else __builtin_amdgcn_s_waitcnt(0x0F70);      /* vmcnt(1) / vmcnt(0) */ \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                     /* lgkmcnt(0): my reads of stage st (and my ct writes) are complete */ \
+        __builtin_amdgcn_s_barrier();                           /* everybody's are: stage st is free, step g+1 is visible */ \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        /* read the piece(s) BEFORE the DMA issue (nothing but the previous store is in flight here), store after the MFMAs */ \
+        const bool piece = have_prev && kt < npieces && kt <= KT - 2 && !ABL(p, 1);                           \
+        const bool piece_late = have_prev && two_in_one && kt == KT - 1 && !ABL(p, 1);                        \
+        uint4 pv = make_uint4(0, 0, 0, 0);                                                                    \
+        if (piece) pv = read_piece<MODE>(p, ct, kt, t);                                                       \
+        if (piece && two_in_one && kt == KT - 2) pv2 = read_piece<MODE>(p, ct, KT - 1, t);                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        LOAD_NEXT(st);                                          /* step g+2 */                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        if (g + 1 < steps_total) READ_FRAGS(a0, b0, st ^ 1, 0);                                               \
+        MFMA_HALF(a1, b1);                                                                                    \
+        st_prev = 0;                                                                                          \
+        if (piece || piece_late) {                                                                            \
+            __builtin_amdgcn_s_waitcnt(0xC07F);                 /* the raw ds_read of pv (and, long done, a0/b0) */ \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+            write_piece<MODE>(p, piece ? pv : pv2, kt, t, prv_m0, prv_n0, prv_tile_n);                        \
+            st_prev = (prv_m0 + tile_rows <= p.M) ? 1 : 0;                                                    \
+        }                                                                                                     \
+        ++g;                                                                                                  \
+    }
+
     while (true) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        for (int kt = 0; kt < KT; ++kt) {
-            const int st = g & 1;
-            // a0/b0 were requested 16 MFMAs ago: retiring them HERE (a wait the compiler's scoreboard sees) keeps it from placing
-            // an lgkmcnt(0) behind the a1/b1 reads below, which would serialise those reads with the first MFMA half
-            __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0)
-            READ_FRAGS(a1, b1, st, 1);
-            MFMA_HALF(a0, b0);
-            // step g+1 (issued after the previous barrier) has landed once at most the store of the previous step is in flight.
-            // A ragged tile may skip a whole store instruction (all lanes predicated off): then st_prev = 0 -- under-counting
-            // only makes the wait conservative, over-counting would let the DMA we need slip.
-            // (waits as builtins, not inline asm: the compiler's own waitcnt pass must SEE them, or it assumes the LDS-DMA may still
-            //  be in flight and drains vmcnt(0) in front of later ds_reads)
-            if (st_prev) __builtin_amdgcn_s_waitcnt(0x0F71); else __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(1) / vmcnt(0)
-            __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): my reads of stage st are complete
-            __builtin_amdgcn_s_barrier();                           // everybody's are: stage st is free, step g+1 is visible
-            __builtin_amdgcn_sched_barrier(0);
-            // one 8 KiB piece of the previous tile's output goes from ct to HBM inside this tile's MFMA stream: read it BEFORE
-            // the DMA issue (nothing but the previous store is in flight here), store it after the MFMAs
-            const bool piece = kt < npieces && have_prev && !ABL(p, 1);
-            uint4 pv = make_uint4(0, 0, 0, 0);
-            if (piece) pv = read_piece<MODE>(p, ct, kt, t);
-            __builtin_amdgcn_sched_barrier(0);
-            LOAD_NEXT(st);                                          // step g+2
-            __builtin_amdgcn_sched_barrier(0);
-            if (g + 1 < steps_total) READ_FRAGS(a0, b0, st ^ 1, 0);
-            MFMA_HALF(a1, b1);
-            st_prev = 0;
-            if (piece) {
-                __builtin_amdgcn_s_waitcnt(0xC07F);                 // the raw ds_read of pv (and, long done, a0/b0)
-                __builtin_amdgcn_sched_barrier(0);
-                write_piece<MODE>(p, pv, kt, t, prv_m0, prv_n0, prv_tile_n);
-                st_prev = (prv_m0 + tile_rows <= p.M) ? 1 : 0;
-            }
-            ++g;
+        {
+            const int kt = 0;
+            STEP_BODY(true)
         }
-        // tile boundary: everyone is done reading the previous ct -> overwrite it with this tile's output
+        for (int kt = 1; kt < KT; ++kt) STEP_BODY(false)
+        // tile boundary: nobody reads the previous ct any more (see above) -> overwrite it with this tile's output
         int tile_m, tile_n;
         xcd_grouped_tile(vb, p.tiles_m, p.tiles_n, 8, tile_m, tile_n);
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_s_barrier();
         if (!ABL(p, 16)) acc_to_ct<MODE>(p, acc, ct, wave_m, wave_n, fr, fg);
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_s_barrier();
         prv_m0 = tile_m * tile_rows; prv_n0 = tile_n * BNB; prv_tile_n = tile_n; have_prev = true;
         vb += G;
         if (vb >= total) break;
     }
     // drain the last tile
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
     if (!ABL(p, 1))
         for (int q = 0; q < npieces; ++q) store_piece<MODE>(p, ct, q, t, prv_m0, prv_n0, prv_tile_n);
 }
