@@ -145,8 +145,8 @@ int ff_block(const mm_transformer* t, hipStream_t s, const mm_ff_weights& w, con
     return MM_OK;
 }
 
-// x += SelfAttention(x) over `seqs` sequences of n tokens  (mmp.py:126-162 with context = None, :189)
-int self_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weights& w, int seqs, int n, Bufs& b) {
+// b.att = heads of SelfAttention(LN(x)) over `seqs` sequences of n tokens, before the output projection  (mmp.py:126-159, context = None)
+int self_attn_core(const mm_transformer* t, hipStream_t s, const mm_attn_weights& w, int seqs, int n, Bufs& b) {
     const int D = t->d.dim, I = t->I, H = t->d.heads;
     const int rows = seqs * n;
     RC(k_layernorm(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, b.xn, D));
@@ -167,9 +167,13 @@ int self_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weight
     a.B = seqs; a.H = H; a.nq = n; a.nk = n;
     a.normalize = 1; a.q_scale = w.q_scale; a.k_scale = w.k_scale; a.null_k = w.null_k; a.null_v = w.null_v;
     a.scale = 8.f;
-    RC(k_attention(s, a));
-    RC(gemm_dense(s, b.att, I, (const bf16_t*)w.w_out, I, rows, D, I, b.x, D, OUT_F32, b.x));
-    return MM_OK;
+    return k_attention(s, a);
+}
+
+// x += SelfAttention(x) over `seqs` sequences of n tokens  (mmp.py:126-162 with context = None, :189)
+int self_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weights& w, int seqs, int n, Bufs& b) {
+    RC(self_attn_core(t, s, w, seqs, n, b));
+    return gemm_dense(s, b.att, t->I, (const bf16_t*)w.w_out, t->I, seqs * n, t->d.dim, t->I, b.x, t->d.dim, OUT_F32, b.x);
 }
 
 // x += CrossAttention(x, ctx) for `seqs` sequences; ckv = ctx @ to_kv^T given as [kv_seqs*m][2I]  (mmp.py:191)
@@ -333,6 +337,8 @@ struct GenBufs {
     bf16_t* embc;           // [B*n][D]
     bf16_t* embn;           // [B*n][D]
     float* logits;          // [B*n][V]
+    float* xc;              // [2*B*n][D]: the last layer's residual stream, compacted to the sampled rows
+    bf16_t* attc;           // [2*B*n][I]
     void* ctx_ws; size_t ctx_ws_bytes;
 };
 void carve_gen(Carver& c, const mm_transformer* t, int B, int n, int L, int nc, GenBufs& g) {
@@ -347,6 +353,8 @@ void carve_gen(Carver& c, const mm_transformer* t, int B, int n, int L, int nc, 
     g.embc = c.take<bf16_t>((size_t)B * n * D);
     g.embn = c.take<bf16_t>((size_t)B * n * D);
     g.logits = c.take<float>((size_t)B * n * t->d.dim_out);
+    g.xc = c.take<float>((size_t)2 * B * n * D);
+    g.attc = c.take<bf16_t>((size_t)2 * B * n * I);
     g.ctx_ws_bytes = mm_context_workspace_bytes(t, B, L);
     g.ctx_ws = c.take<unsigned char>(g.ctx_ws_bytes);
 }
@@ -454,10 +462,33 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
             const hipError_t e = hipMemcpyAsync(b.x + (size_t)M * D, b.x, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s);
             if (e != hipSuccess) return mm_set_hip_error(e, "generate: x copy");
         }
+        // Only the R = B*k rows sampled at this step are read after the last layer (final norm + to_logits, below), and after the last
+        // self-attention has mixed the tokens every operator is row-wise: its output projection, the cross-attention (its queries) and
+        // the feed-forward run on the COMPACTED rows [cond R | null R] (every sample has exactly k of them, position-sorted, so a
+        // sample's queries stay contiguous).  Identical values for the rows that matter; (1 - k/n) of that work is skipped.
+        const bool compact_last = k < n && !(g_mm_debug & 16384);
         for (int l = 0; l < t->d.depth; ++l) {
             const mm_layer_weights& w = t->layers[l];
-            RC(self_attn_block(t, s, w.self_attn, 2 * B, n, b));
             const bf16_t* ckv_l = g.ckv + (size_t)l * B * m * 2 * I;
+            if (l == t->d.depth - 1 && compact_last) {
+                RC(self_attn_core(t, s, w.self_attn, 2 * B, n, b));
+                RC(k_gather_rows16(s, b.x, (long)D * 4, g.rows, R, 0, D * 4, g.xc));
+                RC(k_gather_rows16(s, b.x, (long)D * 4, g.rows, R, M, D * 4, g.xc + (size_t)R * D));
+                RC(k_gather_rows16(s, b.att, (long)I * 2, g.rows, R, 0, I * 2, g.attc));
+                RC(k_gather_rows16(s, b.att, (long)I * 2, g.rows, R, M, I * 2, g.attc + (size_t)R * I));
+                RC(gemm_dense(s, g.attc, I, (const bf16_t*)w.self_attn.w_out, I, 2 * R, D, I, g.xc, D, OUT_F32, g.xc));
+                Bufs bc = b;
+                bc.x = g.xc; bc.att = g.attc;
+                if (nc == 0) {
+                    RC(cross_attn_block(t, s, w.cross_attn, B, k, ckv_l, m, 0, g.masks, bc));
+                    RC(k_add_rowvec(s, g.xc + (size_t)R * D, D, R, D, g.cvec + (size_t)l * D));
+                } else {
+                    RC(cross_attn_block(t, s, w.cross_attn, 2 * B, k, ckv_l, m, B, g.masks, bc));
+                }
+                RC(ff_block(t, s, w.ff, g.xc, g.xc, 2 * R, bc));
+                break;
+            }
+            RC(self_attn_block(t, s, w.self_attn, 2 * B, n, b));
             if (nc == 0) {
                 RC(cross_attn_block(t, s, w.cross_attn, B, n, ckv_l, m, 0, g.masks, b));
                 RC(k_add_rowvec(s, b.x + (size_t)M * D, D, M, D, g.cvec + (size_t)l * D));
@@ -467,8 +498,13 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
             RC(ff_block(t, s, w.ff, b.x, b.x, 2 * M, b));
         }
         // final norm + to_logits + CFG only at the rows that are sampled this step
-        RC(k_layernorm(s, b.x, D, R, D, t->d.final_gamma, t->d.final_beta, g.rows, g.embc, D));
-        RC(k_layernorm(s, b.x + (size_t)M * D, D, R, D, t->d.final_gamma, t->d.final_beta, g.rows, g.embn, D));
+        if (compact_last) {
+            RC(k_layernorm(s, g.xc, D, R, D, t->d.final_gamma, t->d.final_beta, nullptr, g.embc, D));
+            RC(k_layernorm(s, g.xc + (size_t)R * D, D, R, D, t->d.final_gamma, t->d.final_beta, nullptr, g.embn, D));
+        } else {
+            RC(k_layernorm(s, b.x, D, R, D, t->d.final_gamma, t->d.final_beta, g.rows, g.embc, D));
+            RC(k_layernorm(s, b.x + (size_t)M * D, D, R, D, t->d.final_gamma, t->d.final_beta, g.rows, g.embn, D));
+        }
         {
             GemmArgs a;
             memset(&a, 0, sizeof(a));

@@ -153,6 +153,17 @@ __global__ __launch_bounds__(256) void add_rowvec_kernel(float* __restrict__ x, 
     }
 }
 
+// dst[r][0..bytes) = src[rows[r] + row_add][0..bytes) for 16-byte aligned rows (the last layer's compaction to the sampled rows)
+__global__ __launch_bounds__(256) void gather_rows16_kernel(const unsigned char* __restrict__ src, long src_pitch, const int32_t* __restrict__ rows,
+                                                            int R, int row_add, int chunks, unsigned char* __restrict__ dst) {
+    const long total = (long)R * chunks;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / chunks), c = (int)(i - (long)r * chunks);
+        *reinterpret_cast<uint4*>(dst + ((long)r * chunks + c) * 16) =
+            *reinterpret_cast<const uint4*>(src + (long)(rows[r] + row_add) * src_pitch + (long)c * 16);
+    }
+}
+
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, long count) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
         out[i] = f32_to_bf16(x[i]);
@@ -217,6 +228,14 @@ int k_add_rowvec(hipStream_t s, float* x, long ldx, int rows, int D, const float
     if (D % 4 || ldx % 4) return mm_set_error(MM_ERR_ALIGN, "add_rowvec: dim/stride must be multiples of 4");
     hipLaunchKernelGGL(add_rowvec_kernel, dim3(grid_for((long)rows * (D / 4))), dim3(256), 0, s, x, ldx, rows, D, vec);
     return mm_check_launch("add_rowvec_kernel");
+}
+
+int k_gather_rows16(hipStream_t s, const void* src, long src_pitch_bytes, const int32_t* rows, int R, int row_add, int row_bytes, void* dst) {
+    if (R <= 0) return MM_OK;
+    if ((row_bytes % 16) || (src_pitch_bytes % 16)) return mm_set_error(MM_ERR_ALIGN, "gather_rows: rows must be multiples of 16 bytes");
+    hipLaunchKernelGGL(gather_rows16_kernel, dim3(grid_for((long)R * (row_bytes / 16))), dim3(256), 0, s, (const unsigned char*)src,
+                       src_pitch_bytes, rows, R, row_add, row_bytes / 16, (unsigned char*)dst);
+    return mm_check_launch("gather_rows16_kernel");
 }
 
 // per-row symmetric quantisation to OCP fp8 e4m3: scale = max|w| / 448, wq = rne(w / scale); columns K..Kp-1 are zero
