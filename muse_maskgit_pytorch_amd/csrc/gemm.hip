@@ -20,6 +20,13 @@
 #include "common.h"
 #include "muse_hip_internal.h"
 
+#ifdef MM_GEMM_TIMING      // tools/small_gemm_timing.py only: shader-clock stamps of workgroup 0 / wave 0
+__device__ unsigned long long g_gemm_stamps[64];
+#define TSTAMP(i_) if (blockIdx.x == 0 && threadIdx.x < 64) { g_gemm_stamps[i_] = __builtin_readcyclecounter(); }
+#else
+#define TSTAMP(i_)
+#endif
+
 namespace {
 
 constexpr int BT = 128;   // tile edge (both n and m)
@@ -42,6 +49,7 @@ __device__ __attribute__((aligned(16))) const unsigned int g_zero_page[64] = {0}
 template <int MODE, bool W8 = false>      // W8: the weight operand is fp8 e4m3 (one scale per output row), dequantised to bf16 in registers
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TSTAMP(0)
     const int t = threadIdx.x;
     const int lane = t & 63, wid = t >> 6;
     const int wave_n = wid >> 1, wave_m = wid & 1;
@@ -147,8 +155,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     const int KT = p.K / BK / nsplit;
     const int kt0 = (int)blockIdx.y * KT;
     void* const outp = p.splits > 1 ? static_cast<void*>(reinterpret_cast<float*>(p.out) + (size_t)blockIdx.y * p.split_stride) : p.out;
+    TSTAMP(1)
     ISSUE_TILE(kt0, 0);
+    // fp32 residual (attention / FF output projections: out = x + ...): this lane's 16 x 16 B of the 64 KiB tile are fetched NOW, behind
+    // the first k-tile's DMA -- in the epilogue the read-modify-write of all workgroups at once was a pure latency / bandwidth tail
+    // (cycle stamps, 8192 x 512 x 512: write-out 16.1 k cycles with the residual read there, 2.3 k without)
+    constexpr bool RESID_PF = (MODE == MODE_DENSE) && !W8;
+    float4 rres[RESID_PF ? BT / 8 : 1];
+    const bool resid_pf = RESID_PF && p.resid_f32 && p.out_kind == OUT_F32 && p.splits <= 1 && (p.N % 4) == 0;
+    if constexpr (RESID_PF) {
+        if (resid_pf) {
+            const int n_ = n0 + (t & 31) * 4;
+#pragma unroll
+            for (int pass = 0; pass < BT / 8; ++pass) {
+                const int m_ = m0 + pass * 8 + (t >> 5);
+                rres[pass] = (m_ < p.M && n_ < p.N) ? *reinterpret_cast<const float4*>(p.resid_f32 + (size_t)m_ * p.ldr + n_) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
     __syncthreads();        // with an LDS-DMA in flight this is vmcnt(0) + s_barrier
+    TSTAMP(2)
 
     const int fr = lane & 15, fg = lane >> 4;
 #define COMPUTE_TILE(stage_)                                                                                       \
@@ -180,8 +206,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         __builtin_amdgcn_sched_barrier(0);   // keep the DMA issue ahead of the MFMA block
         COMPUTE_TILE(kt & 1);
         __syncthreads();
+        TSTAMP(3 + kt)
     }
     COMPUTE_TILE((KT - 1) & 1);
+    TSTAMP(40)
 
     // ---- epilogue.  A lane holds out[m][n..n+3] per fragment (16 rows x 64 B per store instruction): storing that
     //      directly touches half cache lines and was measured at 35-45 % of the kernel.  Instead the tile goes
@@ -218,6 +246,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     }
 
     __syncthreads();                       // every wave is done reading the last stage
+    TSTAMP(41)
     float* ct = reinterpret_cast<float*>(smem);
     constexpr int CT_LD = BT + 4;          // floats per tile row (528 B)
     const bool geglu = (MODE == MODE_DENSE) && p.epi == EPI_GEGLU;
@@ -267,6 +296,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         }
     }
     __syncthreads();
+    TSTAMP(42)
 
     if (geglu) {
         // 64 output columns per tile row (128 B bf16): 8 lanes x 8 columns per row, 32 rows per pass
@@ -301,6 +331,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         // 4 columns per lane: 32 lanes cover one 512-byte tile row, 8 rows per pass
         const int c4 = (t & 31) * 4;
         const int n = n0 + c4;
+        if constexpr (RESID_PF) {
+            if (resid_pf) {      // the residual is already in registers: a pure store phase
+#pragma unroll
+                for (int pass = 0; pass < BT / 8; ++pass) {
+                    const int ml = pass * 8 + (t >> 5);
+                    const int m = m0 + ml;
+                    if (m >= p.M || n >= p.N) continue;
+                    const float4 cv = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c4);
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + (size_t)m * p.ldc + n) =
+                        make_float4(cv.x + rres[pass].x, cv.y + rres[pass].y, cv.z + rres[pass].z, cv.w + rres[pass].w);
+                }
+                TSTAMP(43)
+                return;
+            }
+        }
 #pragma unroll 4
         for (int pass = 0; pass < TROWS / 8; ++pass) {
             const int ml = pass * 8 + (t >> 5);
@@ -361,6 +406,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             }
         }
     }
+    TSTAMP(43)
 }
 
 template <int MODE, bool W8 = false>
@@ -421,3 +467,9 @@ int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
     }
     return mm_set_error(MM_ERR_SHAPE, "gemm: bad mode");
 }
+
+#ifdef MM_GEMM_TIMING
+extern "C" int mm_debug_gemm_stamps(unsigned long long* host_dst, int n) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_gemm_stamps), sizeof(unsigned long long) * n);
+}
+#endif

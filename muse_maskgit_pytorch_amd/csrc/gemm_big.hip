@@ -113,6 +113,22 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
 
     const int fr = lane & 15, fg = lane >> 4;
     const int KT = p.K / BK;
+    // fp32 residual (out = x + ...: attention out-projection, FF w2): this lane's 16 x 16 B of the tile's 128 KiB are fetched FIRST, ahead
+    // of the DMA (VMEM returns in order, so the counted waits below see them retire before k-tile 0).  Read in the epilogue, the
+    // residual made the write-out a read-modify-write latency tail of every workgroup at once (gemm.hip: 16 k vs 2.3 k cycles).
+    constexpr bool RESID_PF = MODE == MODE_DENSE;
+    float4 rres[RESID_PF ? BMB / 16 : 1];
+    const bool resid_pf = RESID_PF && p.resid_f32 && p.out_kind == OUT_F32 && p.epi != EPI_GEGLU && (p.N % 4) == 0;
+    if constexpr (RESID_PF) {
+        if (resid_pf) {
+            const int n_ = n0 + (t & 31) * 4;
+#pragma unroll
+            for (int pass = 0; pass < BMB / 16; ++pass) {
+                const int m_ = m0 + pass * 16 + (t >> 5);
+                rres[pass] = (m_ < p.M && n_ < p.N) ? *reinterpret_cast<const float4*>(p.resid_f32 + (size_t)m_ * p.ldr + n_) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
     ISSUE_TILE(0, 0);
     if (KT > 1) ISSUE_TILE(1, 1);
 
@@ -226,6 +242,20 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
     if (p.out_kind == OUT_F32) {
         const int c4 = (t & 31) * 4;
         const int n = n0 + c4;
+        if constexpr (RESID_PF) {
+            if (resid_pf) {      // the residual is already in registers: a pure store phase
+#pragma unroll
+                for (int pass = 0; pass < BMB / 16; ++pass) {
+                    const int ml = pass * 16 + (t >> 5);
+                    const int m = m0 + ml;
+                    if (m >= p.M || n >= p.N) continue;
+                    const float4 cv = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c4);
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) =
+                        make_float4(cv.x + rres[pass].x, cv.y + rres[pass].y, cv.z + rres[pass].z, cv.w + rres[pass].w);
+                }
+                return;
+            }
+        }
 #pragma unroll 4
         for (int pass = 0; pass < TROWS / 16; ++pass) {
             const int ml = pass * 16 + (t >> 5);
