@@ -129,9 +129,12 @@ void carve_bufs(Carver& c, const mm_transformer* t, size_t rows, Bufs& b) {
 }
 
 // dst += FF(src)   (mmp.py:79-89 with the residual of :193 / the self-cond add of :328)
-int ff_block(const mm_transformer* t, hipStream_t s, const mm_ff_weights& w, const float* src, float* dst, int rows, Bufs& b) {
+// addvec != NULL (src == dst): rows [add_from, rows) first get the row vector added in place, inside the first LayerNorm's pass
+int ff_block(const mm_transformer* t, hipStream_t s, const mm_ff_weights& w, const float* src, float* dst, int rows, Bufs& b,
+             const float* addvec = nullptr, int add_from = 0) {
     const int D = t->d.dim, F = t->d.ff_inner, Fp = t->Fp;
-    RC(k_layernorm(s, src, D, rows, D, w.ln1_gamma, w.ln1_beta, nullptr, b.xn, D));
+    if (addvec) RC(k_layernorm_addvec(s, dst, D, rows, D, w.ln1_gamma, w.ln1_beta, addvec, add_from, b.xn, D));
+    else RC(k_layernorm(s, src, D, rows, D, w.ln1_gamma, w.ln1_beta, nullptr, b.xn, D));
     {   // Linear(D, 2F) with the GEGLU fused into the epilogue: w1 is packed GEGLU-interleaved, the GEMM emits gate*gelu(x)
         GemmArgs a;
         memset(&a, 0, sizeof(a));
@@ -481,21 +484,21 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
                 bc.x = g.xc; bc.att = g.attc;
                 if (nc == 0) {
                     RC(cross_attn_block(t, s, w.cross_attn, B, k, ckv_l, m, 0, g.masks, bc));
-                    RC(k_add_rowvec(s, g.xc + (size_t)R * D, D, R, D, g.cvec + (size_t)l * D));
+                    RC(ff_block(t, s, w.ff, g.xc, g.xc, 2 * R, bc, g.cvec + (size_t)l * D, R));      // null rows += to_out(null_v)
                 } else {
                     RC(cross_attn_block(t, s, w.cross_attn, 2 * B, k, ckv_l, m, B, g.masks, bc));
+                    RC(ff_block(t, s, w.ff, g.xc, g.xc, 2 * R, bc));
                 }
-                RC(ff_block(t, s, w.ff, g.xc, g.xc, 2 * R, bc));
                 break;
             }
             RC(self_attn_block(t, s, w.self_attn, 2 * B, n, b));
             if (nc == 0) {
                 RC(cross_attn_block(t, s, w.cross_attn, B, n, ckv_l, m, 0, g.masks, b));
-                RC(k_add_rowvec(s, b.x + (size_t)M * D, D, M, D, g.cvec + (size_t)l * D));
+                RC(ff_block(t, s, w.ff, b.x, b.x, 2 * M, b, g.cvec + (size_t)l * D, M));      // null rows += to_out(null_v) (the constant cross-attention)
             } else {
                 RC(cross_attn_block(t, s, w.cross_attn, 2 * B, n, ckv_l, m, B, g.masks, b));
+                RC(ff_block(t, s, w.ff, b.x, b.x, 2 * M, b));
             }
-            RC(ff_block(t, s, w.ff, b.x, b.x, 2 * M, b));
         }
         // final norm + to_logits + CFG only at the rows that are sampled this step
         if (compact_last) {

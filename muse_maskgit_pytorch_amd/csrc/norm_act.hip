@@ -28,10 +28,13 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
 // F.layer_norm(x, (D,), gamma, beta), eps 1e-5 (muse_maskgit_pytorch.py:63-70); fp32 in, bf16 out.
 // Optional row gather (row_index) so the final norm only touches the rows that are sampled.
 constexpr int LN_MAX_IT = 8;   // D <= 64 lanes * 4 * 8 = 2048
-template <int NIT>             // float4 iterations per lane: instantiated for 2 / 4 / 8 so small dims keep registers (and occupancy)
+// ADD: rows >= add_from first get the row vector `addvec` added IN PLACE (x is then also an output) -- the null pass's constant
+// cross-attention output (model.hip) rides on the LayerNorm that follows it instead of costing its own pass over the stream.
+template <int NIT, bool ADD = false>             // float4 iterations per lane: instantiated for 2 / 4 / 8 so small dims keep registers (and occupancy)
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long ldx, int rows, int D,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        const int32_t* __restrict__ row_index, bf16_t* __restrict__ out, long ldo) {
+                                                        const int32_t* __restrict__ row_index, bf16_t* __restrict__ out, long ldo,
+                                                        const float* __restrict__ addvec = nullptr, int add_from = 0, float* xw = nullptr) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -45,6 +48,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         const int c = it * 64 + lane;
         if (c < nvec) {
             v[it] = *reinterpret_cast<const float4*>(xr + c * 4);
+            if constexpr (ADD) {
+                if (row >= add_from) {
+                    const float4 av = *reinterpret_cast<const float4*>(addvec + c * 4);
+                    v[it].x += av.x; v[it].y += av.y; v[it].z += av.z; v[it].w += av.w;
+                    *reinterpret_cast<float4*>(xw + src * ldx + c * 4) = v[it];
+                }
+            }
             sum += (v[it].x + v[it].y) + (v[it].z + v[it].w);
         }
     }
@@ -192,9 +202,23 @@ int k_layernorm(hipStream_t s, const float* x, long ldx, int rows, int D, const 
     if (D % 4 || D > 64 * 4 * LN_MAX_IT) return mm_set_error(MM_ERR_SHAPE, "layernorm: dim must be a multiple of 4 and <= 2048");
     if (ldx % 4 || ldo % 4) return mm_set_error(MM_ERR_ALIGN, "layernorm: strides must be multiples of 4 elements");
     const int nit = (D / 4 + 63) / 64;
-    if (nit <= 2) hipLaunchKernelGGL(layernorm_kernel<2>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, D, gamma, beta, row_index, out, ldo);
-    else if (nit <= 4) hipLaunchKernelGGL(layernorm_kernel<4>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, D, gamma, beta, row_index, out, ldo);
-    else hipLaunchKernelGGL(layernorm_kernel<8>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, D, gamma, beta, row_index, out, ldo);
+    if (nit <= 2) hipLaunchKernelGGL((layernorm_kernel<2, false>), dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, D, gamma, beta, row_index, out, ldo, nullptr, 0, nullptr);
+    else if (nit <= 4) hipLaunchKernelGGL((layernorm_kernel<4, false>), dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, D, gamma, beta, row_index, out, ldo, nullptr, 0, nullptr);
+    else hipLaunchKernelGGL((layernorm_kernel<8, false>), dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, D, gamma, beta, row_index, out, ldo, nullptr, 0, nullptr);
+    return mm_check_launch("layernorm_kernel");
+}
+
+// x[add_from..rows) += addvec (in place), then out = LayerNorm(x) for all rows
+int k_layernorm_addvec(hipStream_t s, float* x, long ldx, int rows, int D, const float* gamma, const float* beta, const float* addvec,
+                       int add_from, bf16_t* out, long ldo) {
+    if (rows <= 0) return MM_OK;
+    if (D % 4 || D > 64 * 4 * LN_MAX_IT) return mm_set_error(MM_ERR_SHAPE, "layernorm: dim must be a multiple of 4 and <= 2048");
+    if (ldx % 4 || ldo % 4) return mm_set_error(MM_ERR_ALIGN, "layernorm: strides must be multiples of 4 elements");
+    const int nit = (D / 4 + 63) / 64;
+    const dim3 grid((rows + 3) / 4), block(256);
+    if (nit <= 2) hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, block, 0, s, x, ldx, rows, D, gamma, beta, nullptr, out, ldo, addvec, add_from, x);
+    else if (nit <= 4) hipLaunchKernelGGL((layernorm_kernel<4, true>), grid, block, 0, s, x, ldx, rows, D, gamma, beta, nullptr, out, ldo, addvec, add_from, x);
+    else hipLaunchKernelGGL((layernorm_kernel<8, true>), grid, block, 0, s, x, ldx, rows, D, gamma, beta, nullptr, out, ldo, addvec, add_from, x);
     return mm_check_launch("layernorm_kernel");
 }
 
