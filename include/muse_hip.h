@@ -268,6 +268,11 @@ typedef struct mm_ff_weights {
     const float* ln2_gamma;  /* [Fp]: F gains, zero padded */
     const float* ln2_beta;
     const void* w2;          /* bf16 [D][Fp], columns >= F zero                                            */
+    /* optional (all three or none): LayerNorm(inner) folded into the w2 GEMM -- z . W2^T with z = (a - mean) * rstd * gamma + beta
+     * is rstd * (a . W2g^T) - rstd * mean * c1 + c2, which saves the LayerNorm's pass over the [rows][Fp] activation:          */
+    const void* w2_folded;   /* bf16 [D][Fp] = bf16(w2[o][f] * ln2_gamma[f])                                   */
+    const float* ln2_c1;     /* [D]: sum_f float(w2_folded[o][f])                                          */
+    const float* ln2_c2;     /* [D]: sum_f ln2_beta[f] * float(w2[o][f])                                   */
 } mm_ff_weights;
 
 typedef struct mm_layer_weights {

@@ -26,7 +26,7 @@ class AttnWeights(C.Structure):
 
 
 class FFWeights(C.Structure):
-    _fields_ = [(n, c_vp) for n in ('ln1_gamma', 'ln1_beta', 'w1', 'ln2_gamma', 'ln2_beta', 'w2')]
+    _fields_ = [(n, c_vp) for n in ('ln1_gamma', 'ln1_beta', 'w1', 'ln2_gamma', 'ln2_beta', 'w2', 'w2_folded', 'ln2_c1', 'ln2_c2')]
 
 
 class LayerWeights(C.Structure):

@@ -32,7 +32,7 @@ namespace {
 constexpr int BT = 128;   // tile edge (both n and m)
 constexpr int BK = 64;    // k per stage
 constexpr int STAGE_BYTES = 2 * BT * BK * 2;   // W tile + X tile
-constexpr int SMEM_BYTES = BT * (BT + 4) * 4;  // max(2 stages = 64 KiB, fp32 output tile with padded rows = 66 KiB)
+constexpr int SMEM_BYTES = BT * (BT + 4) * 4 + BT * 8;  // max(2 stages = 64 KiB, fp32 output tile with padded rows = 66 KiB) + 1 KiB of per-row LayerNorm (mean, rstd)
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
@@ -173,6 +173,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             }
         }
     }
+    // LayerNorm(inner) folded into this GEMM (GemmArgs::ln_c1): per-row mean / rstd from the w1 kernel's partial sums, parked behind the tile
+    float2* ln_stat = reinterpret_cast<float2*>(smem + BT * (BT + 4) * 4);
+    if constexpr (RESID_PF) {
+        if (resid_pf && p.ln_c1) {      // 256 threads = 2 per tile row
+            const int r_ = t >> 1, m_ = m0 + r_;
+            const float2 st = ln_stats_from_partials(p.ln_part, p.ln_np, m_ < p.M ? m_ : 0, p.ln_F, t & 1, m_ < p.M);
+            if (!(t & 1)) ln_stat[r_] = st;
+        }
+    }
     __syncthreads();        // with an LDS-DMA in flight this is vmcnt(0) + s_barrier
     TSTAMP(2)
 
@@ -256,6 +265,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         if (geglu) {
             // W rows are interleaved per wave: fragments a = 0,1 hold the gelu half, a = 2,3 the gate half of the SAME
             // 32 output columns -> gate * gelu(x) is lane-local; the tile emits 64 columns
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const int nl = wave_n * 32 + a * 16 + fg * 4;
@@ -263,7 +273,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = geglu_f(acc[a][b][r], acc[a + 2][b][r]);
                 *reinterpret_cast<float4*>(ct + ml * CT_LD + nl) = make_float4(v[0], v[1], v[2], v[3]);
+                if (p.ln_part) ln_partial_add(v, s1, s2);
             }
+            if (p.ln_part) ln_partial_store(p.ln_part, p.ln_np, m0 + ml, tile_n * 2 + wave_n, m0 + ml < p.M, fg, s1, s2);      // LayerNorm(inner) partial sums (common.h)
             continue;
         }
 #pragma unroll
@@ -333,12 +345,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         const int n = n0 + c4;
         if constexpr (RESID_PF) {
             if (resid_pf) {      // the residual is already in registers: a pure store phase
+                float4 lc1 = make_float4(0.f, 0.f, 0.f, 0.f), lc2 = lc1;
+                if (p.ln_c1 && n < p.N) { lc1 = *reinterpret_cast<const float4*>(p.ln_c1 + n); lc2 = *reinterpret_cast<const float4*>(p.ln_c2 + n); }
 #pragma unroll
                 for (int pass = 0; pass < BT / 8; ++pass) {
                     const int ml = pass * 8 + (t >> 5);
                     const int m = m0 + ml;
                     if (m >= p.M || n >= p.N) continue;
-                    const float4 cv = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c4);
+                    float4 cv = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c4);
+                    if (p.ln_c1) {      // z = (a - mean) * rstd * gamma + beta contracted with W2:  rstd * (a . W2g) - rstd * mean * c1 + c2
+                        const float2 st = ln_stat[ml];
+                        const float rs = st.y, rm = st.x * st.y;
+                        cv.x = rs * cv.x - rm * lc1.x + lc2.x; cv.y = rs * cv.y - rm * lc1.y + lc2.y;
+                        cv.z = rs * cv.z - rm * lc1.z + lc2.z; cv.w = rs * cv.w - rm * lc1.w + lc2.w;
+                    }
                     *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + (size_t)m * p.ldc + n) =
                         make_float4(cv.x + rres[pass].x, cv.y + rres[pass].y, cv.z + rres[pass].z, cv.w + rres[pass].w);
                 }
@@ -453,6 +473,17 @@ int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
         a.tiles_n = (a.N + BT - 1) / BT;
         a.tiles_m = (a.M + BT - 1) / BT;
         return launch<MODE_DENSE>(a, stream);
+    }
+    if (a.ln_part && !a.ln_c1) {
+        // FF w1 that also emits the LayerNorm(inner) partial sums (every GEGLU epilogue of the family does, identically)
+        if (a.epi != EPI_GEGLU || a.w_scale) return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: LayerNorm partial sums ride on the GEGLU epilogue");
+        a.ln_np = a.N / 64;
+    }
+    if (a.ln_c1) {
+        // FF w2 with the LayerNorm(inner) folded in: the fp32-residual epilogue of the 128x128 / 256x128 kernels
+        if (a.mode != MODE_DENSE || !a.resid_f32 || a.out_kind != OUT_F32 || (a.N % 4) || !a.ln_part || !a.ln_c2 || a.ln_np <= 0 || a.ln_F <= 0 ||
+            a.w_scale || a.splits > 1)
+            return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: folded LayerNorm needs a dense fp32-residual GEMM");
     }
     if (!(a.debug & (8 | 4096 | 8192)) && mm_gemm_cfg2_eligible(a)) return mm_gemm_cfg2_launch(a, stream);
     if (!(a.debug & (8 | 4096)) && mm_gemm_pers_eligible(a)) return mm_gemm_pers_launch(a, stream);

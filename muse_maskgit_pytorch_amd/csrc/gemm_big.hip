@@ -26,7 +26,7 @@ constexpr int X_BYTES = BMB * BK * 2;              // 32 KiB
 constexpr int STAGE_B = W_BYTES + X_BYTES;         // 48 KiB
 constexpr int NSTAGE = 3;
 constexpr int CT_LD = BNB + 4;                     // fp32 output tile row stride (floats)
-constexpr int SMEM_B = NSTAGE * STAGE_B;           // 144 KiB >= 256 * 132 * 4 = 132 KiB
+constexpr int SMEM_B = NSTAGE * STAGE_B + BMB * 8;  // 144 KiB of stages (>= the 132 KiB fp32 output tile) + 2 KiB of per-row LayerNorm (mean, rstd)
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
@@ -129,6 +129,15 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
             }
         }
     }
+    // LayerNorm(inner) folded into this GEMM (GemmArgs::ln_c1): per-row mean / rstd from the w1 kernel's partial sums, parked in LDS
+    float2* ln_stat = reinterpret_cast<float2*>(smem + NSTAGE * STAGE_B);
+    if constexpr (RESID_PF) {
+        if (p.ln_c1) {      // 512 threads = 2 per tile row
+            const int r_ = t >> 1, m_ = m0 + r_;
+            const float2 st = ln_stats_from_partials(p.ln_part, p.ln_np, m_ < p.M ? m_ : 0, p.ln_F, t & 1, m_ < p.M);
+            if (!(t & 1)) ln_stat[r_] = st;
+        }
+    }
     ISSUE_TILE(0, 0);
     if (KT > 1) ISSUE_TILE(1, 1);
 
@@ -175,6 +184,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
     for (int b = 0; b < MT; ++b) {
         const int ml = (MODE == MODE_CFG) ? (wave_m * 32 + b * 16 + fr) : (wave_m * 64 + b * 16 + fr);
         if (geglu) {      // see gemm.hip: fragments 0,1 = gelu half, 2,3 = gate half of the same 32 output columns
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const int nl = wave_n * 32 + a * 16 + fg * 4;
@@ -182,7 +192,9 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = geglu_f(acc[a][b][r], acc[a + 2][b][r]);
                 *reinterpret_cast<float4*>(ct + ml * CT_LD + nl) = make_float4(v[0], v[1], v[2], v[3]);
+                if (p.ln_part) ln_partial_add(v, s1, s2);
             }
+            if (p.ln_part) ln_partial_store(p.ln_part, p.ln_np, m0 + ml, tile_n * 2 + wave_n, m0 + ml < p.M, fg, s1, s2);
             continue;
         }
 #pragma unroll
@@ -244,12 +256,20 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
         const int n = n0 + c4;
         if constexpr (RESID_PF) {
             if (resid_pf) {      // the residual is already in registers: a pure store phase
+                float4 lc1 = make_float4(0.f, 0.f, 0.f, 0.f), lc2 = lc1;
+                if (p.ln_c1 && n < p.N) { lc1 = *reinterpret_cast<const float4*>(p.ln_c1 + n); lc2 = *reinterpret_cast<const float4*>(p.ln_c2 + n); }
 #pragma unroll
                 for (int pass = 0; pass < BMB / 16; ++pass) {
                     const int ml = pass * 16 + (t >> 5);
                     const int m = m0 + ml;
                     if (m >= p.M || n >= p.N) continue;
-                    const float4 cv = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c4);
+                    float4 cv = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c4);
+                    if (p.ln_c1) {      // z = (a - mean) * rstd * gamma + beta contracted with W2:  rstd * (a . W2g) - rstd * mean * c1 + c2
+                        const float2 st = ln_stat[ml];
+                        const float rs = st.y, rm = st.x * st.y;
+                        cv.x = rs * cv.x - rm * lc1.x + lc2.x; cv.y = rs * cv.y - rm * lc1.y + lc2.y;
+                        cv.z = rs * cv.z - rm * lc1.z + lc2.z; cv.w = rs * cv.w - rm * lc1.w + lc2.w;
+                    }
                     *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) =
                         make_float4(cv.x + rres[pass].x, cv.y + rres[pass].y, cv.z + rres[pass].z, cv.w + rres[pass].w);
                 }

@@ -327,13 +327,17 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
                 const int row = wm * 128 + b * 16 + fr;
+                float s1 = 0.f, s2 = 0.f;      // LayerNorm(inner) partial sums (common.h)
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
                     const int col = wn * 32 + a * 16 + fg * 4;
+                    const float v[4] = {geglu_f(acc[a][b][0], acc[a + 2][b][0]), geglu_f(acc[a][b][1], acc[a + 2][b][1]),
+                                        geglu_f(acc[a][b][2], acc[a + 2][b][2]), geglu_f(acc[a][b][3], acc[a + 2][b][3])};
                     *reinterpret_cast<uint2*>(ct + row * 256 + (((col >> 3) ^ (row & 15)) << 4) + (fg & 1) * 8) =
-                        make_uint2(pack_bf16x2(geglu_f(acc[a][b][0], acc[a + 2][b][0]), geglu_f(acc[a][b][1], acc[a + 2][b][1])),
-                                   pack_bf16x2(geglu_f(acc[a][b][2], acc[a + 2][b][2]), geglu_f(acc[a][b][3], acc[a + 2][b][3])));
+                        make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                    if (p.ln_part) ln_partial_add(v, s1, s2);
                 }
+                if (p.ln_part) ln_partial_store(p.ln_part, p.ln_np, tile_m * (2 * TOK) + row, tile_n * 4 + wn, tile_m * (2 * TOK) + row < p.M, fg, s1, s2);
             }
         }
         TSTAMP()

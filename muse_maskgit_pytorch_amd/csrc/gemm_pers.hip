@@ -67,7 +67,7 @@ __device__ __forceinline__ void tile_setup(const GemmArgs& p, int vb, TilePtrs& 
 //   GEGLU : 256 rows x  64 bf16 (128 B rows,  8 chunks, swizzle row & 7)
 template <int MODE>
 __device__ __forceinline__ void acc_to_ct(const GemmArgs& p, const f32x4_t (&acc)[4][4], unsigned char* ct, int wave_m, int wave_n,
-                                          int fr, int fg) {
+                                          int fr, int fg, int m0, int tile_n) {
     if constexpr (MODE == MODE_CFG) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
@@ -88,13 +88,17 @@ __device__ __forceinline__ void acc_to_ct(const GemmArgs& p, const f32x4_t (&acc
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int row = wave_m * 64 + b * 16 + fr;
+            float s1 = 0.f, s2 = 0.f;      // LayerNorm(inner) partial sums of this row's 32 columns of the wave (common.h)
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const int col = wave_n * 32 + a * 16 + fg * 4;
+                const float v[4] = {geglu_f(acc[a][b][0], acc[a + 2][b][0]), geglu_f(acc[a][b][1], acc[a + 2][b][1]),
+                                    geglu_f(acc[a][b][2], acc[a + 2][b][2]), geglu_f(acc[a][b][3], acc[a + 2][b][3])};
                 *reinterpret_cast<uint2*>(ct + row * 128 + (((col >> 3) ^ (row & 7)) << 4) + (fg & 1) * 8) =
-                    make_uint2(pack_bf16x2(geglu_f(acc[a][b][0], acc[a + 2][b][0]), geglu_f(acc[a][b][1], acc[a + 2][b][1])),
-                               pack_bf16x2(geglu_f(acc[a][b][2], acc[a + 2][b][2]), geglu_f(acc[a][b][3], acc[a + 2][b][3])));
+                    make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                if (p.ln_part) ln_partial_add(v, s1, s2);
             }
+            if (p.ln_part) ln_partial_store(p.ln_part, p.ln_np, m0 + row, tile_n * 2 + wave_n, m0 + row < p.M, fg, s1, s2);
         }
     } else {
 #pragma unroll
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(const GemmArgs p) {
         // tile boundary: nobody reads the previous ct any more (see above) -> overwrite it with this tile's output
         int tile_m, tile_n;
         xcd_grouped_tile(vb, p.tiles_m, p.tiles_n, 8, tile_m, tile_n);
-        if (!ABL(p, 16)) acc_to_ct<MODE>(p, acc, ct, wave_m, wave_n, fr, fg);
+        if (!ABL(p, 16)) acc_to_ct<MODE>(p, acc, ct, wave_m, wave_n, fr, fg, tile_m * tile_rows, tile_n);
         prv_m0 = tile_m * tile_rows; prv_n0 = tile_n * BNB; prv_tile_n = tile_n; have_prev = true;
         vb += G;
         if (vb >= total) break;

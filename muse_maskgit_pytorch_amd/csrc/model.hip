@@ -116,6 +116,7 @@ struct Bufs {       // activation scratch for `rows` token rows
     bf16_t* att;    // [rows][I]
     bf16_t* h;      // [rows][2Fp]
     bf16_t* a;      // [rows][Fp]
+    float* lnp;     // [rows][Fp / 32][2]: LayerNorm(inner) partial sums of the folded feed-forward
 };
 
 void carve_bufs(Carver& c, const mm_transformer* t, size_t rows, Bufs& b) {
@@ -126,6 +127,7 @@ void carve_bufs(Carver& c, const mm_transformer* t, size_t rows, Bufs& b) {
     b.att = c.take<bf16_t>(rows * I);
     b.h = c.take<bf16_t>(rows * 2 * Fp);
     b.a = c.take<bf16_t>(rows * Fp);
+    b.lnp = c.take<float>(rows * (Fp / 32) * 2);
 }
 
 // dst += FF(src)   (mmp.py:79-89 with the residual of :193 / the self-cond add of :328)
@@ -135,17 +137,32 @@ int ff_block(const mm_transformer* t, hipStream_t s, const mm_ff_weights& w, con
     const int D = t->d.dim, F = t->d.ff_inner, Fp = t->Fp;
     if (addvec) RC(k_layernorm_addvec(s, dst, D, rows, D, w.ln1_gamma, w.ln1_beta, addvec, add_from, b.xn, D));
     else RC(k_layernorm(s, src, D, rows, D, w.ln1_gamma, w.ln1_beta, nullptr, b.xn, D));
-    {   // Linear(D, 2F) with the GEGLU fused into the epilogue: w1 is packed GEGLU-interleaved, the GEMM emits gate*gelu(x)
-        GemmArgs a;
-        memset(&a, 0, sizeof(a));
-        a.mode = MODE_DENSE; a.epi = EPI_GEGLU;
-        a.W = (const bf16_t*)w.w1; a.N = 2 * Fp; a.ldw = D; a.K = D; a.M = rows; a.X = b.xn; a.ldx = D;
-        a.out = b.h; a.ldc = Fp; a.out_kind = OUT_BF16;
-        RC(mm_gemm_launch(a, s));
+    GemmArgs a1;      // Linear(D, 2F) with the GEGLU fused into the epilogue: w1 is packed GEGLU-interleaved, the GEMM emits gate*gelu(x)
+    memset(&a1, 0, sizeof(a1));
+    a1.mode = MODE_DENSE; a1.epi = EPI_GEGLU;
+    a1.W = (const bf16_t*)w.w1; a1.N = 2 * Fp; a1.ldw = D; a1.K = D; a1.M = rows; a1.X = b.xn; a1.ldx = D;
+    a1.out = b.h; a1.ldc = Fp; a1.out_kind = OUT_BF16;
+    GemmArgs a2;      // Linear(F, D) + residual
+    memset(&a2, 0, sizeof(a2));
+    a2.mode = MODE_DENSE;
+    a2.W = (const bf16_t*)w.w2; a2.N = D; a2.ldw = Fp; a2.K = Fp; a2.M = rows; a2.ldx = Fp;
+    a2.out = dst; a2.ldc = D; a2.out_kind = OUT_F32; a2.resid_f32 = dst; a2.ldr = D;
+    // LayerNorm(inner) folded into the GEMM pair (mmp.py:86-88): w1's epilogue emits per-row partial sums of its bf16 output, w2 runs on
+    // that output directly with the gains folded into its weights and applies mean / rstd / bias in its epilogue -- the LayerNorm's
+    // own pass over the [rows][Fp] activation (read + write, 2.8 ms per generate at the base config) disappears.  Every kernel of the
+    // GEMM family implements both halves identically, so the result does not depend on which kernel a shape is dispatched to.
+    const bool fold = w.w2_folded && w.ln2_c1 && w.ln2_c2 && !(g_mm_debug & (1 << 24)) && (D % 4) == 0;
+    if (fold) {
+        a1.ln_part = b.lnp;
+        RC(mm_gemm_launch(a1, s));
+        a2.W = (const bf16_t*)w.w2_folded; a2.X = b.h;
+        a2.ln_part = b.lnp; a2.ln_np = 2 * Fp / 64; a2.ln_F = F; a2.ln_c1 = w.ln2_c1; a2.ln_c2 = w.ln2_c2;
+        return mm_gemm_launch(a2, s);
     }
+    RC(mm_gemm_launch(a1, s));
     RC(k_ln_bf16(s, b.h, Fp, rows, F, Fp, w.ln2_gamma, w.ln2_beta, b.a, Fp));
-    RC(gemm_dense(s, b.a, Fp, (const bf16_t*)w.w2, Fp, rows, D, Fp, dst, D, OUT_F32, dst));
-    return MM_OK;
+    a2.X = b.a;
+    return mm_gemm_launch(a2, s);
 }
 
 // b.att = heads of SelfAttention(LN(x)) over `seqs` sequences of n tokens, before the output projection  (mmp.py:126-159, context = None)

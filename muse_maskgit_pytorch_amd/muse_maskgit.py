@@ -168,8 +168,14 @@ class Transformer(nn.Module):
         assert w2p.shape[1] == Fp
         t = dict(g1=ff[0].gamma.detach().float().contiguous(), b1=ff[0].beta.float().contiguous(), w1=w1p,
                  g2=ops.pad_cols(ff[3].gamma.detach().float(), Fp), b2=ops.pad_cols(ff[3].beta.float(), Fp), w2=w2p)
+        # LayerNorm(inner) folded into w2 (mm_ff_weights.w2_folded): gains into the weights, the mean / bias terms as two [D] vectors
+        w2f = (w2p.float() * t['g2']).to(bf16).contiguous()
+        t['w2f'] = w2f
+        t['c1'] = w2f.float().sum(dim=1).contiguous()
+        t['c2'] = (w2p.float() * t['b2']).sum(dim=1).contiguous()
         keep.append(t)
-        fw = L.FFWeights(L.ptr(t['g1']), L.ptr(t['b1']), L.ptr(t['w1']), L.ptr(t['g2']), L.ptr(t['b2']), L.ptr(t['w2']))
+        fw = L.FFWeights(L.ptr(t['g1']), L.ptr(t['b1']), L.ptr(t['w1']), L.ptr(t['g2']), L.ptr(t['b2']), L.ptr(t['w2']),
+                         L.ptr(t['w2f']), L.ptr(t['c1']), L.ptr(t['c2']))
         return fw, F, Fp
 
     def _pack_attn(self, a, keep, fused):

@@ -611,6 +611,31 @@ def test_self_critic_training_gradients(golden):
     assert torch.isfinite(total) and mg.token_critic.to_pred.weight.grad.abs().max() > 0 and t.to_logits.weight.grad.abs().max() > 0
 
 
+def test_ff_inner_layernorm_fold_matches_the_unfolded_path(golden):
+    """mmp.py:86-88: LayerNorm(inner) between the GEGLU and the second Linear is folded into the GEMM pair (w1's epilogue emits per-row
+    partial sums, w2 = gains folded into the weights + a mean / rstd / bias epilogue).  Debug bit 1 << 24 runs the unfolded path
+    (GEGLU GEMM -> LayerNorm kernel -> GEMM): the two agree to bf16 noise, and both stay within the oracle tolerance."""
+    from muse_maskgit_pytorch_amd import _lib
+    g, t = _tiny_transformer(golden)
+    te = g['text_embeds']
+    ids = g['ids'].to(DEV)
+    folded = t(ids, text_embeds=te.to(DEV))
+    lib = _lib.lib()
+    lib.mm_debug_set(1 << 24)
+    try:
+        unfolded = t(ids, text_embeds=te.to(DEV))
+    finally:
+        lib.mm_debug_set(0)
+    scale = unfolded.abs().max()
+    d = (folded - unfolded).abs()
+    assert d.max() > 0, 'the debug bit did not change the path'
+    assert d.max() < 0.02 * scale and d.mean() < 2e-3 * scale, (d.max().item(), d.mean().item(), scale.item())
+    sd = {k: (v.float().cpu() if v.is_floating_point() else v.cpu()) for k, v in t.state_dict().items()}
+    ref = O.transformer_forward(sd, dict(depth=g['cfg']['depth'], heads=g['cfg']['heads']), g['ids'], te, 0., rp=O.bf16_round)
+    e = _report('folded FF logits vs oracle', folded, ref)
+    assert e.max() < 0.03 * ref.abs().max()
+
+
 def test_full_size_c2_properties():
     """BASELINE configs[1] at FULL size (dim 512, depth 8, seq_len 256, codebook 65536; B = 8 to keep the fp32 oracle out of it):
     size-independent properties instead of an oracle comparison --
