@@ -73,36 +73,38 @@ __device__ __forceinline__ float geglu_f(float x, float gate) {
     return gate * (x * gelu_phi(x));
 }
 
-// LayerNorm(inner) folded into the FF GEMM pair: partial sums (sum, sum of squares) of one output row's 32 GEGLU columns held by a wave
-// (8 values per lane = fragments a = 0,1 x 4 registers, lane groups fg = 0..3), on the bf16-ROUNDED values the next GEMM will read.
-// ONE definition for every GEMM kernel with a GEGLU epilogue: the same summation order -> bit-identical statistics whichever
-// kernel a shape is dispatched to.
-__device__ __forceinline__ void ln_partial_add(const float (&v)[4], float& s1, float& s2) {
-    const float r0 = __uint_as_float(((uint32_t)__builtin_bit_cast(unsigned short, (__bf16)v[0])) << 16);
-    const float r1 = __uint_as_float(((uint32_t)__builtin_bit_cast(unsigned short, (__bf16)v[1])) << 16);
-    const float r2 = __uint_as_float(((uint32_t)__builtin_bit_cast(unsigned short, (__bf16)v[2])) << 16);
-    const float r3 = __uint_as_float(((uint32_t)__builtin_bit_cast(unsigned short, (__bf16)v[3])) << 16);
-    s1 += (r0 + r1) + (r2 + r3);
-    s2 += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
-}
-// ... reduced over the 4 lane groups and stored by lane group 0: part[(row * np + idx) * 2 ..] = (sum, sum of squares)
-__device__ __forceinline__ void ln_partial_store(float* part, int np, long row, int idx, bool row_ok, int fg, float s1, float s2) {
-    s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-    if (fg == 0 && row_ok) *reinterpret_cast<float2*>(part + ((size_t)row * np + idx) * 2) = make_float2(s1, s2);
+// LayerNorm(inner) folded into the FF GEMM pair.  Partial sums (sum, sum of squares) of 64 consecutive GEGLU outputs of one row, taken
+// where every GEMM kernel of the family has them as bf16 in registers on their way to HBM: 8 adjacent lanes x 16 B of one row.  The 8
+// lanes are combined with DPP (no LDS), every lane of the group ends up with the same result.  ONE definition for all kernels: the same
+// values in the same order -> bit-identical statistics whichever kernel a shape is dispatched to.
+__device__ __forceinline__ float2 ln_partial_row64(const uint4 v) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    float f[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u); }
+    float s1 = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+    float s2 = ((f[0] * f[0] + f[1] * f[1]) + (f[2] * f[2] + f[3] * f[3])) + ((f[4] * f[4] + f[5] * f[5]) + (f[6] * f[6] + f[7] * f[7]));
+    // lanes ^1, ^2 (quad permutes) and the mirrored half row (lane i <-> 7 - i of each 8): commutative pairwise sums, identical in all 8 lanes
+#define MM_DPP_ADD(x_, ctrl_) x_ += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x_), ctrl_, 0xF, 0xF, true))
+    MM_DPP_ADD(s1, 0xB1); MM_DPP_ADD(s2, 0xB1);      // quad_perm [1,0,3,2]
+    MM_DPP_ADD(s1, 0x4E); MM_DPP_ADD(s2, 0x4E);      // quad_perm [2,3,0,1]
+    MM_DPP_ADD(s1, 0x141); MM_DPP_ADD(s2, 0x141);    // row_half_mirror
+#undef MM_DPP_ADD
+    return make_float2(s1, s2);
 }
 // per-row (mean, rstd) from the np partials, F valid features (eps = 1e-5 like nn.LayerNorm).  Called by TWO ADJACENT LANES per row
 // (half = lane & 1): each sums its half of the partials in index order, the halves are added as (first + second) -- one canonical
-// order for every kernel; the loads go out in batches of 8 (a plain loop waits for every single load: 44 L2 round trips per row).
+// order for every kernel; the loads go out in batches of 8 (a plain loop waits for every single load: one L2 round trip per partial).
 // Valid in the lane with half == 0.
 __device__ __forceinline__ float2 ln_stats_from_partials(const float* part, int np, long row, int F, int half, bool row_ok) {
-    const int nh = np >> 1;                                   // np is even (N / 64 with N a multiple of 128)
-    const float2* pp = reinterpret_cast<const float2*>(part) + (size_t)row * np + half * nh;
+    const int n0 = (np + 1) >> 1;
+    const int cnt = half ? np - n0 : n0;
+    const float2* pp = reinterpret_cast<const float2*>(part) + (size_t)row * np + (half ? n0 : 0);
     float s1 = 0.f, s2 = 0.f;
-    for (int i = 0; i < nh; i += 8) {
+    for (int i = 0; i < n0; i += 8) {
         float2 v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (row_ok && i + j < nh) ? pp[i + j] : make_float2(0.f, 0.f);
+        for (int j = 0; j < 8; ++j) v[j] = (row_ok && i + j < cnt) ? pp[i + j] : make_float2(0.f, 0.f);
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s1 += v[j].x; s2 += v[j].y; }
     }

@@ -265,7 +265,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         if (geglu) {
             // W rows are interleaved per wave: fragments a = 0,1 hold the gelu half, a = 2,3 the gate half of the SAME
             // 32 output columns -> gate * gelu(x) is lane-local; the tile emits 64 columns
-            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const int nl = wave_n * 32 + a * 16 + fg * 4;
@@ -273,9 +272,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = geglu_f(acc[a][b][r], acc[a + 2][b][r]);
                 *reinterpret_cast<float4*>(ct + ml * CT_LD + nl) = make_float4(v[0], v[1], v[2], v[3]);
-                if (p.ln_part) ln_partial_add(v, s1, s2);
             }
-            if (p.ln_part) ln_partial_store(p.ln_part, p.ln_np, m0 + ml, tile_n * 2 + wave_n, m0 + ml < p.M, fg, s1, s2);      // LayerNorm(inner) partial sums (common.h)
             continue;
         }
 #pragma unroll
@@ -318,10 +315,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         for (int pass = 0; pass < BT / 32; ++pass) {
             const int ml = pass * 32 + (t >> 3);
             const int m = m0 + ml;
-            if (m >= p.M || no >= p.N / 2) continue;
             const float4 lo = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c8);
             const float4 hi = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c8 + 4);
             float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            const uint4 pk = pack8(v);
+            if (p.ln_part) {      // LayerNorm(inner) partial sums of this row's 64 columns (common.h); all 8 lanes of a row take part
+                const float2 st = ln_partial_row64(pk);
+                if ((t & 7) == 0 && m < p.M) *reinterpret_cast<float2*>(p.ln_part + ((size_t)m * p.ln_np + tile_n) * 2) = st;
+            }
+            if (m >= p.M || no >= p.N / 2) continue;
             *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(outp) + (size_t)m * p.ldc + no) = pack8(v);
         }
         return;
@@ -477,7 +479,7 @@ int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
     if (a.ln_part && !a.ln_c1) {
         // FF w1 that also emits the LayerNorm(inner) partial sums (every GEGLU epilogue of the family does, identically)
         if (a.epi != EPI_GEGLU || a.w_scale) return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: LayerNorm partial sums ride on the GEGLU epilogue");
-        a.ln_np = a.N / 64;
+        a.ln_np = a.N / 128;
     }
     if (a.ln_c1) {
         // FF w2 with the LayerNorm(inner) folded in: the fp32-residual epilogue of the 128x128 / 256x128 kernels

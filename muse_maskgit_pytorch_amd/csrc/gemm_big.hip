@@ -184,7 +184,6 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
     for (int b = 0; b < MT; ++b) {
         const int ml = (MODE == MODE_CFG) ? (wave_m * 32 + b * 16 + fr) : (wave_m * 64 + b * 16 + fr);
         if (geglu) {      // see gemm.hip: fragments 0,1 = gelu half, 2,3 = gate half of the same 32 output columns
-            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const int nl = wave_n * 32 + a * 16 + fg * 4;
@@ -192,9 +191,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = geglu_f(acc[a][b][r], acc[a + 2][b][r]);
                 *reinterpret_cast<float4*>(ct + ml * CT_LD + nl) = make_float4(v[0], v[1], v[2], v[3]);
-                if (p.ln_part) ln_partial_add(v, s1, s2);
             }
-            if (p.ln_part) ln_partial_store(p.ln_part, p.ln_np, m0 + ml, tile_n * 2 + wave_n, m0 + ml < p.M, fg, s1, s2);
             continue;
         }
 #pragma unroll
@@ -242,11 +239,16 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
         for (int pass = 0; pass < BMB / 64; ++pass) {
             const int ml = pass * 64 + (t >> 3);
             const int m = m0 + ml;
-            if (m >= p.M || no >= p.N / 2) continue;
             const float4 lo = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c8);
             const float4 hi = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c8 + 4);
             float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + no) = pack8(v);
+            const uint4 pk = pack8(v);
+            if (p.ln_part) {      // LayerNorm(inner) partial sums of this row's 64 columns (common.h); all 8 lanes of a row take part
+                const float2 st = ln_partial_row64(pk);
+                if ((t & 7) == 0 && m < p.M) *reinterpret_cast<float2*>(p.ln_part + ((size_t)m * p.ln_np + tile_n) * 2) = st;
+            }
+            if (m >= p.M || no >= p.N / 2) continue;
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + no) = pk;
         }
         return;
     }

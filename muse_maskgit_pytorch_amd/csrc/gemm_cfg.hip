@@ -261,7 +261,14 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
             WAIT_LGKM0();                                       /* the raw read of pv_ (the fragments are long there) */ \
             __builtin_amdgcn_sched_barrier(0);                                                                 \
             if constexpr (WMODE == WIDE_CFG) store_stream(reinterpret_cast<float*>(pv_ptr_), pv_);             \
-            else if (pm0 + prow_ < p.M) *reinterpret_cast<uint4*>(pv_ptr_) = pv_;      /* re-read by the next kernel: a plain store */ \
+            else {                                                                                             \
+                if (p.ln_part) {      /* LayerNorm(inner) partial sums of the row's two 64-column groups (common.h) */ \
+                    const float2 lst_ = ln_partial_row64(pv_);                                                 \
+                    if ((lane & 7) == 0 && pm0 + prow_ < p.M)                                                  \
+                        *reinterpret_cast<float2*>(p.ln_part + ((size_t)(pm0 + prow_) * p.ln_np + (pn0 >> 7) + ((lane >> 3) & 1)) * 2) = lst_; \
+                }                                                                                              \
+                if (pm0 + prow_ < p.M) *reinterpret_cast<uint4*>(pv_ptr_) = pv_;      /* re-read by the next kernel: a plain store */ \
+            }                                                                                                  \
             st1 = 1;                                                                                           \
         }                                                                                                      \
         ++g;                                                                                                   \
@@ -327,20 +334,15 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
                 const int row = wm * 128 + b * 16 + fr;
-                float s1 = 0.f, s2 = 0.f;      // LayerNorm(inner) partial sums (common.h)
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
                     const int col = wn * 32 + a * 16 + fg * 4;
-                    const float v[4] = {geglu_f(acc[a][b][0], acc[a + 2][b][0]), geglu_f(acc[a][b][1], acc[a + 2][b][1]),
-                                        geglu_f(acc[a][b][2], acc[a + 2][b][2]), geglu_f(acc[a][b][3], acc[a + 2][b][3])};
                     *reinterpret_cast<uint2*>(ct + row * 256 + (((col >> 3) ^ (row & 15)) << 4) + (fg & 1) * 8) =
-                        make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                    if (p.ln_part) ln_partial_add(v, s1, s2);
+                        make_uint2(pack_bf16x2(geglu_f(acc[a][b][0], acc[a + 2][b][0]), geglu_f(acc[a][b][1], acc[a + 2][b][1])),
+                                   pack_bf16x2(geglu_f(acc[a][b][2], acc[a + 2][b][2]), geglu_f(acc[a][b][3], acc[a + 2][b][3])));
                 }
-                if (p.ln_part) ln_partial_store(p.ln_part, p.ln_np, tile_m * (2 * TOK) + row, tile_n * 4 + wn, tile_m * (2 * TOK) + row < p.M, fg, s1, s2);
             }
         }
-        TSTAMP()
         pm0 = tile_m * (WMODE == WIDE_CFG ? TOK : 2 * TOK); pn0 = tile_n * BN;
         have_prev = true;
         vb += G;
@@ -370,10 +372,14 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
     } else {
         for (int q = 0; q < 8; ++q) {
             const int row = q * 32 + 4 * wid + (lane >> 4);
-            if (pm0 + row < p.M && !ABL(p, 1)) {
-                const uint4 pv = *reinterpret_cast<const uint4*>(ct + row * 256 + (((lane & 15) ^ (row & 15)) << 4));
-                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)(pm0 + row) * p.ldc + (pn0 >> 1) + (lane & 15) * 8) = pv;
+            const uint4 pv = *reinterpret_cast<const uint4*>(ct + row * 256 + (((lane & 15) ^ (row & 15)) << 4));
+            if (p.ln_part) {
+                const float2 lst = ln_partial_row64(pv);
+                if ((lane & 7) == 0 && pm0 + row < p.M)
+                    *reinterpret_cast<float2*>(p.ln_part + ((size_t)(pm0 + row) * p.ln_np + (pn0 >> 7) + ((lane >> 3) & 1)) * 2) = lst;
             }
+            if (pm0 + row < p.M && !ABL(p, 1))
+                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)(pm0 + row) * p.ldc + (pn0 >> 1) + (lane & 15) * 8) = pv;
         }
     }
 }

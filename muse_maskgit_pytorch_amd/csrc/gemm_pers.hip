@@ -67,7 +67,7 @@ __device__ __forceinline__ void tile_setup(const GemmArgs& p, int vb, TilePtrs& 
 //   GEGLU : 256 rows x  64 bf16 (128 B rows,  8 chunks, swizzle row & 7)
 template <int MODE>
 __device__ __forceinline__ void acc_to_ct(const GemmArgs& p, const f32x4_t (&acc)[4][4], unsigned char* ct, int wave_m, int wave_n,
-                                          int fr, int fg, int m0, int tile_n) {
+                                          int fr, int fg) {
     if constexpr (MODE == MODE_CFG) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
@@ -88,17 +88,13 @@ __device__ __forceinline__ void acc_to_ct(const GemmArgs& p, const f32x4_t (&acc
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int row = wave_m * 64 + b * 16 + fr;
-            float s1 = 0.f, s2 = 0.f;      // LayerNorm(inner) partial sums of this row's 32 columns of the wave (common.h)
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const int col = wave_n * 32 + a * 16 + fg * 4;
-                const float v[4] = {geglu_f(acc[a][b][0], acc[a + 2][b][0]), geglu_f(acc[a][b][1], acc[a + 2][b][1]),
-                                    geglu_f(acc[a][b][2], acc[a + 2][b][2]), geglu_f(acc[a][b][3], acc[a + 2][b][3])};
                 *reinterpret_cast<uint2*>(ct + row * 128 + (((col >> 3) ^ (row & 7)) << 4) + (fg & 1) * 8) =
-                    make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                if (p.ln_part) ln_partial_add(v, s1, s2);
+                    make_uint2(pack_bf16x2(geglu_f(acc[a][b][0], acc[a + 2][b][0]), geglu_f(acc[a][b][1], acc[a + 2][b][1])),
+                               pack_bf16x2(geglu_f(acc[a][b][2], acc[a + 2][b][2]), geglu_f(acc[a][b][3], acc[a + 2][b][3])));
             }
-            if (p.ln_part) ln_partial_store(p.ln_part, p.ln_np, m0 + row, tile_n * 2 + wave_n, m0 + row < p.M, fg, s1, s2);
         }
     } else {
 #pragma unroll
@@ -150,6 +146,10 @@ __device__ __forceinline__ void write_piece(const GemmArgs& p, const uint4 v, in
     } else if (p.epi == EPI_GEGLU) {
         const int row = piece * 64 + (t >> 3), c = t & 7;
         const int m = m0 + row;
+        if (p.ln_part) {      // LayerNorm(inner) partial sums of this row's 64 columns (common.h), inside the next tile's k-loop
+            const float2 st = ln_partial_row64(v);
+            if (c == 0 && m < p.M) *reinterpret_cast<float2*>(p.ln_part + ((size_t)m * p.ln_np + tile_n) * 2) = st;
+        }
         if (m < p.M) ST16(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + tile_n * 64 + c * 8, v);
     } else {
         const int row = piece * 32 + (t >> 4), c = t & 15;
@@ -169,6 +169,10 @@ __device__ __forceinline__ void store_piece(const GemmArgs& p, const unsigned ch
         const int row = piece * 64 + (t >> 3), c = t & 7;
         const uint4 v = *reinterpret_cast<const uint4*>(ct + row * 128 + ((c ^ (row & 7)) << 4));
         const int m = m0 + row;
+        if (p.ln_part) {
+            const float2 st = ln_partial_row64(v);
+            if (c == 0 && m < p.M) *reinterpret_cast<float2*>(p.ln_part + ((size_t)m * p.ln_np + tile_n) * 2) = st;
+        }
         if (m < p.M) ST16(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + tile_n * 64 + c * 8, v);
     } else {
         const int row = piece * 32 + (t >> 4), c = t & 15;
@@ -291,6 +295,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(const GemmArgs p) {
     // wave reaches with its own ct writes retired (lgkmcnt(0)).  When a tile has exactly as many k-steps as pieces, step KT - 2
     // reads two pieces and the second one is stored in step KT - 1.
     const bool two_in_one = KT == npieces;
+    const bool stat_store = (MODE == MODE_DENSE) && p.epi == EPI_GEGLU && p.ln_part != nullptr;
     uint4 pv2 = make_uint4(0, 0, 0, 0);
 #define STEP_BODY(FIRST_)                                                                                     \
     {                                                                                                         \
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(const GemmArgs p) {
         /* only makes the wait conservative, over-counting would let the DMA we need slip. */                 \
         /* (waits as builtins, not inline asm: the compiler's own waitcnt pass must SEE them, or it assumes the LDS-DMA may still */ \
         /*  be in flight and drains vmcnt(0) in front of later ds_reads) */                                   \
-        if (st_prev) __builtin_amdgcn_s_waitcnt(0x0F71); else __builtin_amdgcn_s_waitcnt(0x0F70);      /* vmcnt(1) / vmcnt(0) */ \
+        if (st_prev == 2) __builtin_amdgcn_s_waitcnt(0x0F72); else if (st_prev) __builtin_amdgcn_s_waitcnt(0x0F71); else __builtin_amdgcn_s_waitcnt(0x0F70);      /* vmcnt(2 / 1 / 0) */ \
         __builtin_amdgcn_s_waitcnt(0xC07F);                     /* lgkmcnt(0): my reads of stage st (and my ct writes) are complete */ \
         __builtin_amdgcn_s_barrier();                           /* everybody's are: stage st is free, step g+1 is visible */ \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(const GemmArgs p) {
             __builtin_amdgcn_s_waitcnt(0xC07F);                 /* the raw ds_read of pv (and, long done, a0/b0) */ \
             __builtin_amdgcn_sched_barrier(0);                                                                \
             write_piece<MODE>(p, piece ? pv : pv2, kt, t, prv_m0, prv_n0, prv_tile_n);                        \
-            st_prev = (prv_m0 + tile_rows <= p.M) ? 1 : 0;                                                    \
+            st_prev = (prv_m0 + tile_rows <= p.M) ? (stat_store ? 2 : 1) : 0;      /* (a folded FF's statistics store is a second one) */ \
         }                                                                                                     \
         ++g;                                                                                                  \
     }
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(const GemmArgs p) {
         // tile boundary: nobody reads the previous ct any more (see above) -> overwrite it with this tile's output
         int tile_m, tile_n;
         xcd_grouped_tile(vb, p.tiles_m, p.tiles_n, 8, tile_m, tile_n);
-        if (!ABL(p, 16)) acc_to_ct<MODE>(p, acc, ct, wave_m, wave_n, fr, fg, tile_m * tile_rows, tile_n);
+        if (!ABL(p, 16)) acc_to_ct<MODE>(p, acc, ct, wave_m, wave_n, fr, fg);
         prv_m0 = tile_m * tile_rows; prv_n0 = tile_n * BNB; prv_tile_n = tile_n; have_prev = true;
         vb += G;
         if (vb >= total) break;

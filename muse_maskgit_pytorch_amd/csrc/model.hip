@@ -156,7 +156,7 @@ int ff_block(const mm_transformer* t, hipStream_t s, const mm_ff_weights& w, con
         a1.ln_part = b.lnp;
         RC(mm_gemm_launch(a1, s));
         a2.W = (const bf16_t*)w.w2_folded; a2.X = b.h;
-        a2.ln_part = b.lnp; a2.ln_np = 2 * Fp / 64; a2.ln_F = F; a2.ln_c1 = w.ln2_c1; a2.ln_c2 = w.ln2_c2;
+        a2.ln_part = b.lnp; a2.ln_np = 2 * Fp / 128; a2.ln_F = F; a2.ln_c1 = w.ln2_c1; a2.ln_c2 = w.ln2_c2;
         return mm_gemm_launch(a2, s);
     }
     RC(mm_gemm_launch(a1, s));

@@ -31,9 +31,9 @@ struct GemmArgs {
     const float* w_scale;         // non-null: W is fp8 e4m3 [N][ldw bytes] with one dequantisation scale per row (W8A16)
     int splits; long split_stride; // split-K (weight gradients): gridDim.y = splits, split s sums k-tiles [s*K/splits, (s+1)*K/splits) into out + s*split_stride floats
     // LayerNorm(inner) folded into the FF GEMM pair (model.hip ff_block):
-    //   w1 + GEGLU (persistent kernel): ln_part != NULL -> per output row and 64-column half-tile the sum and sum of squares of the
-    //     bf16-rounded outputs go to ln_part[(row * ln_np + part) * 2 ..], part = 2 * tile_n + wave_n, ln_np = N / 64;
-    //   w2 (256x128 kernel, fp32 + residual): ln_c1 != NULL -> out = rstd*acc - rstd*mean*ln_c1[n] + ln_c2[n] + resid with
+    //   w1 + GEGLU (any kernel of the family): ln_part != NULL -> per output row and 64 output columns the sum and sum of squares of
+    //     the bf16 outputs go to ln_part[(row * ln_np + part) * 2 ..], part = output column / 64, ln_np = N / 128;
+    //   w2 (128x128 / 256x128 kernel, fp32 + residual): ln_c1 != NULL -> out = rstd*acc - rstd*mean*ln_c1[n] + ln_c2[n] + resid with
     //     mean / rstd of each row from the ln_np partials over ln_F valid features.
     float* ln_part; int ln_np; int ln_F; const float* ln_c1; const float* ln_c2;
     int debug;                    // ablation bits (mm_debug_set): 1 = no epilogue stores, 2 = no DMA after tile 0, 4 = no MFMA, 8 = force the 128x128 kernel, 4096 = no persistent kernel
