@@ -162,3 +162,21 @@ def test_ff_packing_layout():
     assert torch.allclose(fused[:, :341], ref, atol=1e-5) and fused[:, 341:].abs().sum() == 0
     assert w2p.shape == (128, 384) and w2p[:, 341:].abs().sum() == 0
     assert int(128 * 4 * 2 / 3) == 341 and int(512 * 4 * 2 / 3) == 1365
+    # LayerNorm(inner) folded into w2 (mm_ff_weights.w2_folded / ln2_c1 / ln2_c2): emulating the two GEMM epilogues -- per-row sum and
+    # sum of squares in partial groups of 64 columns, rstd * (a . W2g^T) - rstd * mean * c1 + c2 -- reproduces LayerNorm(a) @ w2^T
+    with torch.no_grad():
+        ff[3].gamma.copy_(1 + 0.3 * torch.randn(341))
+    keep = []
+    t._pack_ff(ff, keep)
+    k = keep[0]
+    a = torch.randn(5, 384).bfloat16().float()
+    a[:, 341:] = 0
+    parts = a.reshape(5, 6, 64)
+    s1, s2 = parts.sum(-1).sum(-1, keepdim=True), (parts * parts).sum(-1).sum(-1, keepdim=True)
+    mean = s1 / 341
+    rstd = 1 / torch.sqrt((s2 / 341 - mean * mean).clamp(min=0) + 1e-5)
+    folded = rstd * (a @ k['w2f'].float().t()) - rstd * mean * k['c1'] + k['c2']
+    z = torch.nn.functional.layer_norm(a[:, :341], (341,), ff[3].gamma.detach(), None)
+    ref2 = z @ ff[4].weight.detach().bfloat16().float().t()
+    assert k['w2f'].shape == (128, 384) and k['w2f'][:, 341:].abs().sum() == 0
+    assert (folded - ref2).abs().max() < 2e-2 * ref2.abs().max()      # = the bf16 rounding of w2 * gamma
