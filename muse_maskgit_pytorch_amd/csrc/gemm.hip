@@ -487,7 +487,9 @@ int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
             a.w_scale || a.splits > 1)
             return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: folded LayerNorm needs a dense fp32-residual GEMM");
     }
-    if (!(a.debug & (8 | 4096 | 8192)) && mm_gemm_cfg2_eligible(a)) return mm_gemm_cfg2_launch(a, stream);
+    // (the 256x256 GEGLU variant also emits the LayerNorm partial sums, but that path has no full-size test yet: a folded FF keeps w1 on
+    //  the 256x128 persistent kernel)
+    if (!(a.debug & (8 | 4096 | 8192)) && !a.ln_part && mm_gemm_cfg2_eligible(a)) return mm_gemm_cfg2_launch(a, stream);
     if (!(a.debug & (8 | 4096)) && mm_gemm_pers_eligible(a)) return mm_gemm_pers_launch(a, stream);
     if (!(a.debug & 8) && mm_gemm_big_eligible(a)) return mm_gemm_big_launch(a, stream);
     a.tiles_n = (a.N + BT - 1) / BT;
