@@ -25,6 +25,8 @@
 // may still be writing and drains vmcnt(0) in front of ds_reads.
 // The accumulation order per output element (k ascending in chunks of 32, one MFMA each) equals gemm.hip / gemm_big.hip /
 // gemm_pers.hip: results are bit-identical to those kernels.
+// Second instantiation (WIDE_GEGLU): FF w1 with the GEGLU epilogue on a 256-row x 256-weight-row tile for long K (see
+// mm_gemm_cfg2_eligible); same pipeline, the bf16 output tile (64 KiB) goes through ct in one piece schedule.
 #include "common.h"
 #include "muse_hip_internal.h"
 
