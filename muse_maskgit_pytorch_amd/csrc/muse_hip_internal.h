@@ -61,7 +61,6 @@ int k_layernorm(hipStream_t s, const float* x, long ldx, int rows, int D, const 
                 const int32_t* row_index, bf16_t* out, long ldo);
 int k_geglu_ln(hipStream_t s, const bf16_t* h, long ldh, int rows, int F, int Fp, const float* gamma, const float* beta,
                bf16_t* out, long ldo);
-int k_add_rowvec(hipStream_t s, float* x, long ldx, int rows, int D, const float* vec);
 int k_layernorm_addvec(hipStream_t s, float* x, long ldx, int rows, int D, const float* gamma, const float* beta, const float* addvec,
                        int add_from, bf16_t* out, long ldo);
 int k_gather_rows16(hipStream_t s, const void* src, long src_pitch_bytes, const int32_t* rows, int R, int row_add, int row_bytes, void* dst);

@@ -150,19 +150,6 @@ __global__ __launch_bounds__(256) void geglu_ln_kernel(const bf16_t* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void add_rowvec_kernel(float* __restrict__ x, long ldx, int rows, int D, const float* __restrict__ vec) {
-    const int nvec = D >> 2;
-    const long total = (long)rows * nvec;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int row = (int)(i / nvec), c = (int)(i - (long)row * nvec);
-        float4* px = reinterpret_cast<float4*>(x + (long)row * ldx + c * 4);
-        const float4 v = *reinterpret_cast<const float4*>(vec + c * 4);
-        float4 a = *px;
-        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-        *px = a;
-    }
-}
-
 // dst[r][0..bytes) = src[rows[r] + row_add][0..bytes) for 16-byte aligned rows (the last layer's compaction to the sampled rows)
 __global__ __launch_bounds__(256) void gather_rows16_kernel(const unsigned char* __restrict__ src, long src_pitch, const int32_t* __restrict__ rows,
                                                             int R, int row_add, int chunks, unsigned char* __restrict__ dst) {
@@ -245,13 +232,6 @@ int k_ln_bf16(hipStream_t s, const bf16_t* a, long lda, int rows, int F, int Fp,
     else if (nit <= 6) hipLaunchKernelGGL((geglu_ln_kernel<6, true>), dim3((rows + 3) / 4), dim3(256), 0, s, a, lda, rows, F, Fp, gamma, beta, out, ldo);
     else hipLaunchKernelGGL((geglu_ln_kernel<12, true>), dim3((rows + 3) / 4), dim3(256), 0, s, a, lda, rows, F, Fp, gamma, beta, out, ldo);
     return mm_check_launch("ln_bf16_kernel");
-}
-
-int k_add_rowvec(hipStream_t s, float* x, long ldx, int rows, int D, const float* vec) {
-    if (rows <= 0) return MM_OK;
-    if (D % 4 || ldx % 4) return mm_set_error(MM_ERR_ALIGN, "add_rowvec: dim/stride must be multiples of 4");
-    hipLaunchKernelGGL(add_rowvec_kernel, dim3(grid_for((long)rows * (D / 4))), dim3(256), 0, s, x, ldx, rows, D, vec);
-    return mm_check_launch("add_rowvec_kernel");
 }
 
 int k_gather_rows16(hipStream_t s, const void* src, long src_pitch_bytes, const int32_t* rows, int R, int row_add, int row_bytes, void* dst) {
