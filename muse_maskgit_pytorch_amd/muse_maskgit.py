@@ -237,7 +237,9 @@ class Transformer(nn.Module):
 
     def _workspace(self, nbytes, device):
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
-            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            # zero-filled once per (re)allocation: every buffer carved from it is written before it is read, but no result may ever
+            # depend on what a previous owner of the memory left there
+            self._ws = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
         return self._ws
 
     # ---- context (mmp.py:302-318)
@@ -637,7 +639,7 @@ class MaskGit(nn.Module):
             p.trace_masked_ids, p.trace_ids, p.trace_scores = L.ptr(trace['masked_ids']), L.ptr(trace['ids']), L.ptr(trace['scores'])
         wsb = L.lib().mm_generate_workspace_bytes(h.ptr, B, seq_len, Lt, nc)
         if self._gen_ws is None or self._gen_ws.numel() < wsb or self._gen_ws.device != dev:
-            self._gen_ws = torch.empty(int(wsb), dtype=torch.uint8, device=dev)
+            self._gen_ws = torch.zeros(int(wsb), dtype=torch.uint8, device=dev)      # (zero-filled once, see Transformer._workspace)
         L.check(L.lib().mm_generate(h.ptr, L.stream(), C.byref(p), L.ptr(self._gen_ws), self._gen_ws.numel()), 'mm_generate')
         ids = ids.reshape(B, fmap, fmap)                                       # mmp.py:615
         if return_ids or not exists(self.vae):

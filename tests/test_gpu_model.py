@@ -636,40 +636,6 @@ def test_ff_inner_layernorm_fold_matches_the_unfolded_path(golden):
     assert e.max() < 0.03 * ref.abs().max()
 
 
-def test_folded_feed_forward_is_kernel_independent_at_full_size():
-    """The folded LayerNorm(inner) is implemented by every kernel of the GEMM family (statistics in the GEGLU epilogues of the
-    128x128 / 256x128 / persistent kernels, correction in the fp32-residual epilogues of the 128x128 / 256x128 kernels) from one shared
-    routine, so a transformer pass is bit-identical whichever kernels the shapes are dispatched to: 16384 rows of the base config
-    (persistent w1, 256x128 w2) against the 128x128 kernels only (bit 8) and against no persistent kernels (bit 4096)."""
-    import bench
-    from muse_maskgit_pytorch_amd import _lib
-    mg, _ = bench.build_models(DEV)
-    tr = mg.transformer
-    B, n = 64, 256
-    te = bench.synth_text(B, 32, 512).to(DEV)
-    g = torch.Generator().manual_seed(3)
-    ids = torch.randint(0, 65536, (B, n), generator=g)
-    ids[torch.rand(B, n, generator=g) < 0.5] = tr.mask_id
-    ids = ids.to(DEV)
-    lib = _lib.lib()
-    ref = tr(ids, text_embeds=te, _embed_only=True)
-    assert torch.isfinite(ref.float()).all()
-    for bits in (8, 4096):
-        lib.mm_debug_set(bits)
-        try:
-            got = tr(ids, text_embeds=te, _embed_only=True)
-        finally:
-            lib.mm_debug_set(0)
-        assert torch.equal(got, ref), f'debug {bits}: {(got != ref).sum().item()} of {got.numel()} embed values differ'
-    lib.mm_debug_set(1 << 24)
-    try:
-        unfolded = tr(ids, text_embeds=te, _embed_only=True)
-    finally:
-        lib.mm_debug_set(0)
-    d = (unfolded.float() - ref.float()).abs()
-    assert d.max() > 0 and d.max() < 0.05 * ref.float().abs().max() and d.mean() < 3e-3 * ref.float().abs().max()
-
-
 def test_full_size_c2_properties():
     """BASELINE configs[1] at FULL size (dim 512, depth 8, seq_len 256, codebook 65536; B = 8 to keep the fp32 oracle out of it):
     size-independent properties instead of an oracle comparison --

@@ -1,0 +1,50 @@
+"""Full-size kernel-independence of a transformer pass (runs last: `-x` in front of it would otherwise hide the rest of the suite)."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def test_folded_feed_forward_is_kernel_independent_at_full_size():
+    """The folded LayerNorm(inner) is implemented by every kernel of the GEMM family (statistics in the GEGLU epilogues of the
+    128x128 / 256x128 / persistent kernels, correction in the fp32-residual epilogues of the 128x128 / 256x128 kernels) from one shared
+    routine, so a transformer pass is bit-identical whichever kernels the shapes are dispatched to: 16384 rows of the base config
+    (persistent w1, 256x128 w2) against the 128x128 kernels only (bit 8) and against no persistent kernels (bit 4096)."""
+    import bench
+    from muse_maskgit_pytorch_amd import _lib
+    mg, _ = bench.build_models(DEV)
+    tr = mg.transformer
+    B, n = 64, 256
+    te = bench.synth_text(B, 32, 512).to(DEV)
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, 65536, (B, n), generator=g)
+    ids[torch.rand(B, n, generator=g) < 0.5] = tr.mask_id
+    ids = ids.to(DEV)
+    lib = _lib.lib()
+    ref = tr(ids, text_embeds=te, _embed_only=True)
+    assert torch.isfinite(ref.float()).all()
+    for bits in (8, 4096):
+        lib.mm_debug_set(bits)
+        try:
+            got = tr(ids, text_embeds=te, _embed_only=True)
+        finally:
+            lib.mm_debug_set(0)
+        ne = (got != ref)
+        if ne.any():      # reported in full: which rows, how far (one unexplained failure of this comparison was seen inside a full-suite run)
+            rows = ne.any(dim=1).nonzero().flatten()
+            print(f'[kernel independence] debug {bits}: {int(ne.sum())} of {got.numel()} values differ in {rows.numel()} rows '
+                  f'(first {rows[:8].tolist()}), max |diff| {(got.float() - ref.float()).abs().max().item():.4g}')
+        assert torch.equal(got, ref), f'debug {bits}: {(got != ref).sum().item()} of {got.numel()} embed values differ'
+    lib.mm_debug_set(1 << 24)
+    try:
+        unfolded = tr(ids, text_embeds=te, _embed_only=True)
+    finally:
+        lib.mm_debug_set(0)
+    d = (unfolded.float() - ref.float()).abs()
+    assert d.max() > 0 and d.max() < 0.05 * ref.float().abs().max() and d.mean() < 3e-3 * ref.float().abs().max()
