@@ -350,6 +350,13 @@ int mm_generate(const mm_transformer_t* model, mm_stream_t stream, const mm_gene
 #define MM_PROF_SLOTS 2
 /* kernel ablation switches for tools/ (0 = product behaviour) */
 int mm_debug_set(int flags);
+/* Race / determinism screen (tools/determinism_stress.py, tests): with a device buffer registered (NULL = off) every
+ * mm_transformer_forward writes one 64-bit position-sensitive checksum per operator output, in launch order, to device_buf[0..];
+ * mm_debug_trace_count() = entries of the last pass.  Two passes over the same inputs must produce identical traces. */
+int mm_debug_trace(uint64_t* device_buf, int capacity);
+int mm_debug_trace_count(void);
+/* additionally keep raw copies of the operator outputs #first, #first + step, ... of a traced pass (stride_bytes apart; NULL = off) */
+int mm_debug_capture(void* device_buf, size_t stride_bytes, int first, int step);
 int mm_profile_enable(int enable);
 int mm_profile_read(int slot, int64_t* launches, double* total_ms, double* total_work);
 

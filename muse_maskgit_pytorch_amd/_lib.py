@@ -104,6 +104,9 @@ SIGNATURES = {
     'mm_generate_workspace_bytes': (c_sz, [c_vp, c_int, c_int, c_int, c_int]),
     'mm_generate': (c_int, [c_vp, c_vp, C.POINTER(GenerateParams), c_vp, c_sz]),
     'mm_debug_set': (c_int, [c_int]),
+    'mm_debug_trace': (c_int, [c_vp, c_int]),
+    'mm_debug_trace_count': (c_int, []),
+    'mm_debug_capture': (c_int, [c_vp, c_sz, c_int, c_int]),
     'mm_profile_enable': (c_int, [c_int]),
     'mm_profile_read': (c_int, [c_int, C.POINTER(c_i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }

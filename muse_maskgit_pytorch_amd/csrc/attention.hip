@@ -379,7 +379,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int c = 0; c < 4; ++c) *reinterpret_cast<uint4*>(Ks + sw_off(s_key, s_half * 4 + c)) = kr[c];
     }
-    __syncthreads();      // (drains vmcnt too: the V copy has landed)
+    // The V image was copied by LDS-DMA: it is visible to other waves only after the ISSUING wave's vmcnt has drained and a barrier.  The
+    // K loads above follow the DMA in program order and are consumed before this point, so the counter is already zero here, but the
+    // ordering must not depend on that: drain explicitly, then barrier.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
     const float c1 = p.scale * 1.4426950408889634f;
     float nvv[4];                        // this lane's dims of the (bf16-rounded) null value

@@ -182,7 +182,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             if (!(t & 1)) ln_stat[r_] = st;
         }
     }
-    __syncthreads();        // with an LDS-DMA in flight this is vmcnt(0) + s_barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA of the first k-tile has landed (explicit: a barrier alone does not drain VMEM)
+    __syncthreads();
     TSTAMP(2)
 
     const int fr = lane & 15, fg = lane >> 4;
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         if (!(p.debug & 2)) ISSUE_TILE(kt0 + kt + 1, (kt + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);   // keep the DMA issue ahead of the MFMA block
         COMPUTE_TILE(kt & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's DMA (issued above by this wave) has landed before the barrier publishes it
         __syncthreads();
         TSTAMP(3 + kt)
     }
@@ -354,9 +356,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                     const int ml = pass * 8 + (t >> 5);
                     const int m = m0 + ml;
                     if (m >= p.M || n >= p.N) continue;
+                    // The row's statistics are read -- and RETIRED -- before the tile row is requested.  Round-1 order (tile row, then the
+                    // statistics right behind it, both LDS reads in flight) produced, in ~4 % of full-size launches, rstd * acc.x == 0 in the
+                    // last quarter-wave (lanes 48-63) of one pass of one workgroup: one output row off by its whole feed-forward term in 16
+                    // columns (DESIGN.md "Round-1 nondeterminism"; tools/determinism_stress.py reproduces and screens it).
+                    float2 st = make_float2(0.f, 1.f);
+                    if (p.ln_c1) { st = ln_stat[ml]; __builtin_amdgcn_s_waitcnt(0xC07F); }
                     float4 cv = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c4);
                     if (p.ln_c1) {      // z = (a - mean) * rstd * gamma + beta contracted with W2:  rstd * (a . W2g) - rstd * mean * c1 + c2
-                        const float2 st = ln_stat[ml];
                         const float rs = st.y, rm = st.x * st.y;
                         cv.x = rs * cv.x - rm * lc1.x + lc2.x; cv.y = rs * cv.y - rm * lc1.y + lc2.y;
                         cv.z = rs * cv.z - rm * lc1.z + lc2.z; cv.w = rs * cv.w - rm * lc1.w + lc2.w;

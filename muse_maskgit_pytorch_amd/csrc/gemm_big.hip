@@ -265,9 +265,11 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
                     const int ml = pass * 16 + (t >> 5);
                     const int m = m0 + ml;
                     if (m >= p.M || n >= p.N) continue;
+                    // statistics first, retired, then the tile row: see the same loop in gemm.hip (the 128x128 kernel's round-1 failure)
+                    float2 st = make_float2(0.f, 1.f);
+                    if (p.ln_c1) { st = ln_stat[ml]; __builtin_amdgcn_s_waitcnt(0xC07F); }
                     float4 cv = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c4);
                     if (p.ln_c1) {      // z = (a - mean) * rstd * gamma + beta contracted with W2:  rstd * (a . W2g) - rstd * mean * c1 + c2
-                        const float2 st = ln_stat[ml];
                         const float rs = st.y, rm = st.x * st.y;
                         cv.x = rs * cv.x - rm * lc1.x + lc2.x; cv.y = rs * cv.y - rm * lc1.y + lc2.y;
                         cv.z = rs * cv.z - rm * lc1.z + lc2.z; cv.w = rs * cv.w - rm * lc1.w + lc2.w;

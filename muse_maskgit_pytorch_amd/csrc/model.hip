@@ -26,6 +26,37 @@ inline Rec begin(hipStream_t s, double work) {
 inline void end(hipStream_t s, int slot, Rec& r) { (void)hipEventRecord(r.b, s); recs[slot].push_back(r); }
 }  // namespace prof
 
+// ---- debug trace (mm_debug_trace, tools/determinism_stress.py): when a device buffer is registered, the transformer forward hashes every
+// intermediate it produces (one 64-bit position-sensitive integer sum per operator output, integer atomics: order-independent) so that
+// two runs can be compared operator by operator.  Off (one pointer test per operator) in the product path.
+namespace trace {
+uint64_t* buf = nullptr;
+int cap = 0, idx = 0;
+unsigned char* cap_buf = nullptr;      // optional: raw copies of the operator outputs #first, #first + step, ... (cap_stride bytes apart)
+size_t cap_stride = 0;
+int cap_first = 0, cap_step = 1;
+__global__ __launch_bounds__(256) void hash_kernel(const uint32_t* __restrict__ p, long nwords, unsigned long long* out) {
+    unsigned long long acc = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (long)gridDim.x * blockDim.x)
+        acc += ((unsigned long long)p[i] + 0x9E3779B97F4A7C15ull) * (2ull * (unsigned long long)i + 1ull);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+inline void point(hipStream_t s, const void* p, size_t bytes) {
+    if (!buf || idx >= cap) return;
+    (void)hipMemsetAsync(buf + idx, 0, 8, s);
+    const long nwords = (long)(bytes / 4);
+    int blocks = (int)((nwords + 256 * 8 - 1) / (256 * 8));
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    hipLaunchKernelGGL(hash_kernel, dim3(blocks), dim3(256), 0, s, (const uint32_t*)p, nwords, (unsigned long long*)(buf + idx));
+    if (cap_buf && idx >= cap_first && (idx - cap_first) % cap_step == 0 && bytes <= cap_stride)
+        (void)hipMemcpyAsync(cap_buf + (size_t)((idx - cap_first) / cap_step) * cap_stride, p, bytes, hipMemcpyDeviceToDevice, s);
+    ++idx;
+}
+}  // namespace trace
+#define TR(ptr_, bytes_) trace::point(s, (ptr_), (size_t)(bytes_))
+
 struct mm_transformer {
     mm_transformer_desc d;
     std::vector<mm_layer_weights> layers;
@@ -152,17 +183,25 @@ int ff_block(const mm_transformer* t, hipStream_t s, const mm_ff_weights& w, con
     // own pass over the [rows][Fp] activation (read + write, 2.8 ms per generate at the base config) disappears.  Every kernel of the
     // GEMM family implements both halves identically, so the result does not depend on which kernel a shape is dispatched to.
     const bool fold = w.w2_folded && w.ln2_c1 && w.ln2_c2 && !(g_mm_debug & (1 << 24)) && (D % 4) == 0;
+    TR(b.xn, (size_t)rows * D * 2);
     if (fold) {
         a1.ln_part = b.lnp;
         RC(mm_gemm_launch(a1, s));
+        TR(b.h, (size_t)rows * Fp * 2);
+        TR(b.lnp, (size_t)rows * (Fp / 64) * 8);
         a2.W = (const bf16_t*)w.w2_folded; a2.X = b.h;
         a2.ln_part = b.lnp; a2.ln_np = 2 * Fp / 128; a2.ln_F = F; a2.ln_c1 = w.ln2_c1; a2.ln_c2 = w.ln2_c2;
-        return mm_gemm_launch(a2, s);
+        RC(mm_gemm_launch(a2, s));
+        TR(dst, (size_t)rows * D * 4);
+        return MM_OK;
     }
     RC(mm_gemm_launch(a1, s));
+    TR(b.h, (size_t)rows * Fp * 2);
     RC(k_ln_bf16(s, b.h, Fp, rows, F, Fp, w.ln2_gamma, w.ln2_beta, b.a, Fp));
     a2.X = b.a;
-    return mm_gemm_launch(a2, s);
+    RC(mm_gemm_launch(a2, s));
+    TR(dst, (size_t)rows * D * 4);
+    return MM_OK;
 }
 
 // b.att = heads of SelfAttention(LN(x)) over `seqs` sequences of n tokens, before the output projection  (mmp.py:126-159, context = None)
@@ -170,6 +209,7 @@ int self_attn_core(const mm_transformer* t, hipStream_t s, const mm_attn_weights
     const int D = t->d.dim, I = t->I, H = t->d.heads;
     const int rows = seqs * n;
     RC(k_layernorm(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, b.xn, D));
+    TR(b.xn, (size_t)rows * D * 2);
     const bf16_t* wq = (const bf16_t*)w.w_q;
     const bf16_t* wkv = (const bf16_t*)w.w_kv;
     if (wkv == wq + (size_t)I * D) {
@@ -187,13 +227,18 @@ int self_attn_core(const mm_transformer* t, hipStream_t s, const mm_attn_weights
     a.B = seqs; a.H = H; a.nq = n; a.nk = n;
     a.normalize = 1; a.q_scale = w.q_scale; a.k_scale = w.k_scale; a.null_k = w.null_k; a.null_v = w.null_v;
     a.scale = 8.f;
-    return k_attention(s, a);
+    TR(b.qkv, (size_t)rows * 3 * I * 2);
+    RC(k_attention(s, a));
+    TR(b.att, (size_t)rows * I * 2);
+    return MM_OK;
 }
 
 // x += SelfAttention(x) over `seqs` sequences of n tokens  (mmp.py:126-162 with context = None, :189)
 int self_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weights& w, int seqs, int n, Bufs& b) {
     RC(self_attn_core(t, s, w, seqs, n, b));
-    return gemm_dense(s, b.att, t->I, (const bf16_t*)w.w_out, t->I, seqs * n, t->d.dim, t->I, b.x, t->d.dim, OUT_F32, b.x);
+    RC(gemm_dense(s, b.att, t->I, (const bf16_t*)w.w_out, t->I, seqs * n, t->d.dim, t->I, b.x, t->d.dim, OUT_F32, b.x));
+    TR(b.x, (size_t)seqs * n * t->d.dim * 4);
+    return MM_OK;
 }
 
 // x += CrossAttention(x, ctx) for `seqs` sequences; ckv = ctx @ to_kv^T given as [kv_seqs*m][2I]  (mmp.py:191)
@@ -202,7 +247,9 @@ int cross_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weigh
     const int D = t->d.dim, I = t->I, H = t->d.heads;
     const int rows = seqs * n;
     RC(k_layernorm(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, b.xn, D));
+    TR(b.xn, (size_t)rows * D * 2);
     RC(gemm_dense(s, b.xn, D, (const bf16_t*)w.w_q, D, rows, I, D, b.qkv, I, OUT_BF16, nullptr));
+    TR(b.qkv, (size_t)rows * I * 2);
     AttnArgs a;
     memset(&a, 0, sizeof(a));
     a.q = b.qkv; a.q_sb = (long)n * I; a.q_sh = 64; a.q_sn = I;
@@ -214,7 +261,9 @@ int cross_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weigh
     a.normalize = 1; a.q_scale = w.q_scale; a.k_scale = w.k_scale; a.null_k = w.null_k; a.null_v = w.null_v;
     a.scale = 8.f; a.kv_batch_mod = kv_batch_mod;
     RC(k_attention(s, a));
+    TR(b.att, (size_t)rows * I * 2);
     RC(gemm_dense(s, b.att, I, (const bf16_t*)w.w_out, I, rows, D, I, b.x, D, OUT_F32, b.x));
+    TR(b.x, (size_t)rows * D * 4);
     return MM_OK;
 }
 
@@ -328,17 +377,21 @@ int mm_transformer_forward(const mm_transformer_t* t, mm_stream_t stream, const 
     bf16_t* emb = c.take<bf16_t>((size_t)rows * D);
     if (embed_out) emb = (bf16_t*)embed_out;
 
+    trace::idx = 0;
     RC(k_embed(s, ids, rows, n, 0, (const bf16_t*)t->d.token_emb, t->d.vocab_rows, (const bf16_t*)t->d.pos_emb, D, b.x));
+    TR(b.x, (size_t)rows * D * 4);
     if (t->d.self_cond && self_cond_embed)       // mmp.py:325-328 (zeros when absent: FF(0) still adds LN-beta terms = 0)
         RC(ff_block(t, s, t->d.self_cond_ff, self_cond_embed, b.x, rows, b));
     for (int l = 0; l < t->d.depth; ++l) {
         const mm_layer_weights& w = t->layers[l];
         RC(self_attn_block(t, s, w.self_attn, B, n, b));
         RC(gemm_dense(s, (const bf16_t*)ctx, D, (const bf16_t*)w.cross_attn.w_kv, D, B * m, 2 * I, D, ckv, 2 * I, OUT_BF16, nullptr));
+        TR(ckv, (size_t)B * m * 2 * I * 2);
         RC(cross_attn_block(t, s, w.cross_attn, B, n, ckv, m, 0, key_mask, b));
         RC(ff_block(t, s, w.ff, b.x, b.x, rows, b));
     }
     RC(k_layernorm(s, b.x, D, rows, D, t->d.final_gamma, t->d.final_beta, nullptr, emb, D));
+    TR(emb, (size_t)rows * D * 2);
     if (logits_out)
         RC(gemm_dense(s, emb, D, (const bf16_t*)t->d.to_logits, D, rows, t->d.dim_out, D, logits_out, t->d.dim_out, OUT_F32, nullptr));
     return MM_OK;
@@ -379,6 +432,16 @@ void carve_gen(Carver& c, const mm_transformer* t, int B, int n, int L, int nc, 
     g.ctx_ws = c.take<unsigned char>(g.ctx_ws_bytes);
 }
 }  // namespace
+
+int mm_debug_trace(uint64_t* device_buf, int capacity) {
+    trace::buf = device_buf; trace::cap = device_buf ? capacity : 0; trace::idx = 0;
+    return MM_OK;
+}
+int mm_debug_trace_count(void) { return trace::idx; }
+int mm_debug_capture(void* device_buf, size_t stride_bytes, int first, int step) {
+    trace::cap_buf = (unsigned char*)device_buf; trace::cap_stride = stride_bytes; trace::cap_first = first; trace::cap_step = step > 0 ? step : 1;
+    return MM_OK;
+}
 
 int mm_profile_enable(int enable) {
     prof::enabled = enable != 0;
