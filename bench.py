@@ -28,6 +28,30 @@ PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0          # HBM3E spec
 
 
+CONFIGS = {
+    # name: (transformer kwargs, vae kwargs, image_size, cond_image_size, default images per GPU, description)
+    'c2': (dict(num_tokens=65536, seq_len=256, dim=512, depth=8, dim_head=64, heads=8, ff_mult=4), dict(dim=256, codebook_size=65536), 256, None, 32,
+           'BASELINE configs[1]: base 256x256, MaskGit.generate (18 steps, cond_scale 3, top-k 0.9, Philox Gumbel noise) + VQGanVAE(dim=256, codebook 65536) decode'),
+    'c4': (dict(num_tokens=65536, seq_len=1024, dim=512, depth=8, dim_head=64, heads=8, ff_mult=4), dict(dim=256, codebook_size=65536), 512, 256, 8,
+           'BASELINE configs[3]: super-res 512x512 (1024 tokens, 256 low-res condition ids + text in the cross-attention context), VQGanVAE encode of the '
+           '256x256 condition image + 18-step generate + 512x512 decode'),
+    'c5': (dict(num_tokens=8192, seq_len=256, dim=1024, depth=24, dim_head=64, heads=16, ff_mult=4), dict(dim=256, codebook_size=8192), 256, None, 32,
+           'BASELINE configs[4] shape: paper-scale base (dim 1024, depth 24, 16 heads, codebook 8192), 18-step generate + decode'),
+}
+
+
+def build_config(name, device):
+    """MaskGit of a named BASELINE configuration (random init, torch.manual_seed(0))."""
+    import muse_maskgit_pytorch_amd as mm
+    tkw, vkw, image_size, cond_size, _, _ = CONFIGS[name]
+    torch.manual_seed(0)
+    vae = mm.VQGanVAE(**vkw)
+    tr = mm.MaskGitTransformer(t5_name='t5-small', **tkw)
+    kw = dict(cond_image_size=cond_size) if cond_size else {}
+    mg = mm.MaskGit(vae=vae, transformer=tr, image_size=image_size, **kw)
+    return mg.to(device).eval(), image_size
+
+
 def build_models(device, tiny=False):
     import muse_maskgit_pytorch_amd as mm
     torch.manual_seed(0)
@@ -54,10 +78,23 @@ def synth_text(total, L, dim, seed=0):
     return te
 
 
-def cpu_baseline(mg, te_one, timesteps, cond_scale, sample_steps=18, max_threads=32):
-    """The reference algorithm (oracle port, fp32 torch on the host cores) on a bounded sample of the same workload:
-    batch 1, `sample_steps` of the 18 decode steps (every reference step costs the same: it always runs the full
-    2-pass transformer and the full-vocabulary tail) + one VAE decode, extrapolated to a full generate."""
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(mg, te_two, timesteps, cond_scale, sample_steps=5, max_threads=32):
+    """The reference algorithm on the host cores, beside the GPU number (never the thing measured as `value`).  kind = "port": the oracle
+    (oracle/muse_oracle.py, a functional fp32 torch restatement pinned bit-exactly to goldens of the unmodified reference) -- the reference
+    package itself is absent from the GPU box.  Protocol (bounded to ~20 s): batch 2, one untimed warm-up step, then
+    3 timed runs of `sample_steps` of the 18 decode steps each (every reference step costs the same: it always runs the full two-pass
+    transformer and the full-vocabulary sampling tail), median run extrapolated to 18 steps, plus one VAE decode of the batch."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import muse_oracle as O
     cores = min(os.cpu_count(), max_threads)   # torch's intra-op pool stops scaling (and regresses) far below 256 threads
@@ -67,28 +104,93 @@ def cpu_baseline(mg, te_one, timesteps, cond_scale, sample_steps=18, max_threads
     vsd = {k: (v.detach().float().cpu() if v.is_floating_point() else v.detach().cpu()) for k, v in mg.vae.state_dict().items()}
     cfg = dict(depth=tr.transformer_blocks.cfg['depth'], heads=tr.transformer_blocks.cfg['heads'])
     n, V = tr.seq_len, tr.num_tokens
+    Bc = te_two.shape[0]
     sample_steps = min(sample_steps, timesteps)
     counts = O.mask_counts(timesteps, n)
     temps = O.step_temperatures(timesteps, 1.)
-    ids = torch.full((1, n), tr.mask_id, dtype=torch.long)
-    scores = torch.zeros(1, n)
     g = torch.Generator().manual_seed(0)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        for s in range(sample_steps):
+
+    def run(steps):
+        ids = torch.full((Bc, n), tr.mask_id, dtype=torch.long)
+        scores = torch.zeros(Bc, n)
+        t0 = time.perf_counter()
+        for s in range(steps):
             sel = O.select_topk_stable(scores, counts[s])
             ids = torch.where(sel, torch.full_like(ids, tr.mask_id), ids)
-            logits = O.forward_with_cond_scale(sd, cfg, ids, te_one, cond_scale)
-            gum = O.gumbel_from_uniform(torch.rand(1, n, V, generator=g))
+            logits = O.forward_with_cond_scale(sd, cfg, ids, te_two, cond_scale)
+            gum = O.gumbel_from_uniform(torch.rand(Bc, n, V, generator=g))
             ids, scores, _ = O.sample_step(logits, gum, ids, tr.mask_id, temps[s])
-        t1 = time.perf_counter()
+        return time.perf_counter() - t0, ids
+
+    with torch.no_grad():
+        run(1)                                         # warm-up
+        times = sorted(run(sample_steps)[0] for _ in range(3))
+        loop = times[1] / sample_steps * timesteps     # median run, extrapolated
+        _, ids = run(1)
         f = int(math.isqrt(n))
-        O.vae_decode_from_ids(vsd, ids.clamp(max=V - 1).reshape(1, f, f))
-        t2 = time.perf_counter()
-    per_image = (t1 - t0) / sample_steps * timesteps + (t2 - t1)
-    return dict(value=1.0 / per_image, unit='images/sec', cores=cores, kind='port',
-                sample=f'batch 1, {sample_steps} of {timesteps} decode steps ({t1 - t0:.1f} s) + 1 VAE decode ({t2 - t1:.1f} s), '
-                       f'extrapolated x{timesteps / sample_steps:g}; oracle/muse_oracle.py fp32 torch')
+        t1 = time.perf_counter()
+        O.vae_decode_from_ids(vsd, ids.clamp(max=V - 1).reshape(Bc, f, f))
+        dec = time.perf_counter() - t1
+    per_batch = loop + dec
+    return dict(value=Bc / per_batch, unit='images/sec', cores=cores, kind='port', cpu_model=_cpu_model(), host_cpus=os.cpu_count(),
+                sample=f'batch {Bc}, 1 warm-up step + 3 runs of {sample_steps} of {timesteps} decode steps (median {times[1]:.1f} s, runs {times[0]:.1f}-{times[2]:.1f} s), '
+                       f'extrapolated x{timesteps / sample_steps:g}, + 1 VAE decode ({dec:.1f} s); oracle/muse_oracle.py (fp32 torch port of the reference: '
+                       f'the reference package is not present on the GPU box), {cores} torch threads')
+
+
+def executed_flops_per_generate(tr, B, n, m_text, nc, counts):
+    """MFMA flops the fused engine actually executes for one generate of B images (GEMMs + attention products; SURVEY 8d asks for the
+    EXECUTED count for the utilisation figure): 2B sequences through every layer, cross-attention on the cond half only when the null
+    pass's is a constant (no condition ids), the last layer's row-wise tail and the logits only at the k_t sampled rows of each step."""
+    cfgb = tr.transformer_blocks.cfg
+    D, depth, H = tr.dim, cfgb['depth'], cfgb['heads']
+    I = H * cfgb['dim_head']
+    F = int(D * cfgb['ff_mult'] * 2 / 3)
+    Fp = (F + 63) // 64 * 64
+    V = tr.dim_out
+    m = m_text + nc
+    total = 2.0 * B * m * D * 2 * I * depth                                 # cross-attention K/V of every layer, once
+    for k in counts:
+        rows2, R2 = 2 * B * n, 2 * B * k
+        cross_rows = (2 * B if nc else B) * n
+        full = depth - 1 if k < n else depth
+        per_layer = (2.0 * rows2 * D * 3 * I + 4.0 * 2 * B * H * n * (n + 1) * 64 + 2.0 * rows2 * I * D      # self: q|k|v, QK^T + PV, out
+                     + 2.0 * cross_rows * D * I * 2 + 4.0 * (cross_rows // n) * H * n * (m + 1) * 64        # cross: q, out, attention
+                     + 2.0 * rows2 * D * 2 * Fp + 2.0 * rows2 * Fp * D)                                     # FF
+        total += full * per_layer
+        if k < n:      # last layer: token mixing on all rows, everything behind it on the compacted rows
+            cr = (2 * B if nc else B) * k
+            total += (2.0 * rows2 * D * 3 * I + 4.0 * 2 * B * H * n * (n + 1) * 64 + 2.0 * R2 * I * D
+                      + 2.0 * cr * D * I * 2 + 4.0 * (cr // max(k, 1)) * H * k * (m + 1) * 64 + 2.0 * R2 * D * 2 * Fp + 2.0 * R2 * Fp * D)
+        total += 2.0 * 2 * B * k * V * D                                        # guidance logits: cond + null rows
+    return total
+
+
+def reference_flops_per_generate(tr, B, n, m_text, nc, timesteps):
+    """what the reference computes for the same call (SURVEY 8d formula): 2 full passes per step over all n rows, logits at every row"""
+    cfgb = tr.transformer_blocks.cfg
+    D, depth, H = tr.dim, cfgb['depth'], cfgb['heads']
+    I = H * cfgb['dim_head']
+    F = int(D * cfgb['ff_mult'] * 2 / 3)
+    m = m_text + nc
+    layer = 2.0 * n * D * I * 4 + 4.0 * H * n * (n + 1) * 64 + 2.0 * n * D * I * 2 + 2.0 * m * D * 2 * I + 4.0 * H * n * (m + 1) * 64 + 6.0 * n * D * F
+    return B * 2 * timesteps * (depth * layer + 2.0 * n * D * tr.dim_out)
+
+
+def _respawn_under_torchrun(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher: become the launcher (one process per GPU over RCCL), like the driver's
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -96,17 +198,21 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--batch', type=int, default=32, help='images per GPU per step')
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='c2', help='c2 = the metric configuration (BASELINE configs[1]); c4 super-res, c5 paper-scale shape')
+    ap.add_argument('--batch', type=int, default=None, help='images per GPU per step (default: 32; 8 for c4)')
     ap.add_argument('--timesteps', type=int, default=18)
     ap.add_argument('--text-len', type=int, default=32)
     ap.add_argument('--tiny', action='store_true', help='configs[0] plumbing case instead of the metric config')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(_respawn_under_torchrun(args))
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}'
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs (no CPU fallback exists)'
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
@@ -114,20 +220,31 @@ def main():
     if world > 1 or os.environ.get('MM_BENCH_FORCE_DIST'):      # (the env switch exercises the RCCL path on a single GPU)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from muse_maskgit_pytorch_amd import _lib
     from muse_maskgit_pytorch_amd.parallel import allgather_ids
     _lib.require_device()
-    mg, image_size = build_models(dev, tiny=args.tiny)
+    if args.tiny:
+        mg, image_size = build_models(dev, tiny=True)
+        desc, cond_size = 'C1 tiny plumbing config', None
+    else:
+        mg, image_size = build_config(args.config, dev)
+        desc, cond_size = CONFIGS[args.config][5], CONFIGS[args.config][3]
     tr = mg.transformer
-    B, T = args.batch, args.timesteps
+    B = args.batch or (32 if args.tiny else CONFIGS[args.config][4])
+    T = args.timesteps
     n = (image_size // 16) ** 2
     te_all = synth_text(world * B, args.text_len, tr.text_embed_dim)
     te = te_all[rank * B:(rank + 1) * B].to(dev)
+    cond = None
+    if cond_size:
+        cond = torch.randn(world * B, 3, cond_size, cond_size, generator=torch.Generator().manual_seed(5))[rank * B:(rank + 1) * B].to(dev)
+    nc = (cond_size // 16) ** 2 if cond_size else 0
 
     def step(i):
-        ids = mg.generate([''] * B, timesteps=T, cond_scale=3, text_embeds=te, seed=1000 + i, row_offset=rank * B, return_ids=True)
+        ids = mg.generate([''] * B, timesteps=T, cond_scale=3, text_embeds=te, cond_images=cond, seed=1000 + i, row_offset=rank * B, return_ids=True)
         e_mid = torch.cuda.Event(enable_timing=True)
         e_mid.record()
         all_ids = allgather_ids(ids, dist) if dist is not None else ids      # one RCCL all-gather of token grids
@@ -172,53 +289,63 @@ def main():
     if rank == 0:
         # HBM traffic per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
         # (separate runs: counters cannot be collected inside the timed region); null when no summary is committed
-        pmc = {}
-        try:
-            with open(os.path.join(ROOT, 'profiles', 'r01_bench_b32_pmc_summary.json')) as f:
-                for name, v in json.load(f).items():
-                    pmc[name] = v
-        except OSError:
-            pass
+        pmc, pmc_file = {}, None
+        for cand in ('r02_bench_b32_pmc_summary.json', 'r01_bench_b32_pmc_summary.json'):
+            try:
+                with open(os.path.join(ROOT, 'profiles', cand)) as f:
+                    pmc, pmc_file = json.load(f), cand
+                break
+            except OSError:
+                continue
 
         def traffic_of(substr):
             for name, v in pmc.items():
                 if substr in name:
                     return v['hbm_bytes_per_launch']
             return None
+        metric_cfg = (not args.tiny) and args.config == 'c2' and B == 32
         total_images = world * B * args.steps
         value = total_images / elapsed
         passes = 2 * T
-        tok_s_gpu = B * n * passes * args.steps / (loop_ms / 1e3)
+        counts = mg._mask_counts(T, n)
+        ex_flops = executed_flops_per_generate(tr, B, n, args.text_len, nc, counts)
+        ref_flops = reference_flops_per_generate(tr, B, n, args.text_len, nc, T)
+        loop_s = loop_ms / 1e3 / args.steps
         g_cnt, g_ms, g_flops = prof[0]
         s_cnt, s_ms, s_bytes = prof[1]
         out = {
-            'metric': 'images/sec (256x256 base, 18 decode steps)', 'value': value, 'unit': 'images/sec', 'n_gpus': world,
+            'metric': 'images/sec (256x256 base, 18 decode steps)' if args.config == 'c2' and not args.tiny else f'images/sec ({image_size}x{image_size}, {T} decode steps, config {args.config})',
+            'value': value, 'unit': 'images/sec', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': ('C1 tiny plumbing config' if args.tiny else
-                                    'BASELINE configs[1]: base 256x256, MaskGit.generate (18 steps, cond_scale 3, top-k 0.9, '
-                                    'Philox Gumbel noise) + VQGanVAE(dim=256, codebook 65536) decode'),
-                       'images_per_gpu_per_step': B, 'global_batch': world * B, 'seq_len': n, 'timesteps': T,
-                       'text_len': args.text_len, 'parallelism': f'dp{world} (batch-sharded, 1 all-gather of ids per step)',
+            'config': {'workload': desc, 'images_per_gpu_per_step': B, 'global_batch': world * B, 'seq_len': n, 'timesteps': T,
+                       'text_len': args.text_len, 'cond_ids': nc, 'parallelism': f'dp{world} (batch-sharded, 1 all-gather of ids per step)',
                        'weights': 'random init (module defaults, torch.manual_seed(0))'},
-            'transformer_tok_per_s_per_gpu': tok_s_gpu,
+            # reference-equivalent: the reference's 2 * timesteps full passes over all n positions / the decode-loop time (comparable across
+            # implementations); executed: token rows that actually pass through the transformer blocks here (2B sequences per step)
+            'transformer_tok_per_s_per_gpu': B * n * passes / loop_s,
+            'transformer_tok_per_s_per_gpu_kind': 'reference-equivalent (36 full passes per generate; 37 % of the logits rows and the null pass\'s cross-attention are provably dead work and skipped)',
+            'executed_tok_per_s_per_gpu': 2 * B * n * T / loop_s,
             'decode_loop_ms_per_step': loop_ms / args.steps,
+            'executed_tflops_decode_loop': ex_flops / loop_s / 1e12,
+            'executed_mfma_frac_decode_loop': ex_flops / loop_s / 1e12 / PEAK_BF16_TFLOPS,
+            'reference_equivalent_tflops_decode_loop': ref_flops / loop_s / 1e12,
             'roofline': {'kernel': 'gemm_cfg2_kernel (to_logits + classifier-free guidance, persistent 128-token x 256-column MFMA GEMM)', 'bound': 'mfma',
                          'achieved': g_flops / (g_ms * 1e-3) / 1e12 if g_ms else None, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': (g_flops / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if g_ms else None,
-                         'traffic': traffic_of('gemm_cfg2_kernel') if not args.tiny and B == 32 else None,
-                         'traffic_source': 'profiles/r01_bench_b32_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch, FETCH x2 gfx950 correction)',
+                         'traffic': traffic_of('gemm_cfg2_kernel') if metric_cfg else None,
+                         'traffic_source': f'profiles/{pmc_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch, FETCH x2 gfx950 correction)' if pmc_file else None,
                          'launches': g_cnt, 'avg_launch_ms': g_ms / g_cnt if g_cnt else None,
                          'algorithmic_flops_per_launch': g_flops / g_cnt if g_cnt else None},
             'roofline_hbm': {'kernel': 'sample_kernel (top-k + Gumbel argmax + confidence)', 'bound': 'hbm',
                              'achieved': s_bytes / (s_ms * 1e-3) / 1e9 if s_ms else None, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                              'frac': (s_bytes / (s_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if s_ms else None,
-                             'traffic': traffic_of('sample_kernel') if not args.tiny and B == 32 else None,
+                             'traffic': traffic_of('sample_kernel') if metric_cfg else None,
                              'algorithmic_bytes_per_launch': s_bytes / s_cnt if s_cnt else None,
                              'launches': s_cnt, 'avg_launch_ms': s_ms / s_cnt if s_cnt else None},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(mg, te_all[:1], T, 3.)
+        if world == 1 and not args.no_cpu_baseline and not args.tiny and args.config == 'c2':
+            out['cpu_baseline'] = cpu_baseline(mg, te_all[:2], T, 3.)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

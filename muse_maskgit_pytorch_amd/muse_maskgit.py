@@ -202,7 +202,7 @@ class Transformer(nn.Module):
         dev = self.token_emb.weight.device
         if dev.type != 'cuda':
             raise L.MuseHipError('Transformer parameters are not on the GPU; the MI355X path has no CPU fallback')
-        key = (str(dev),) + tuple(p._version for p in self.parameters())
+        key = self._pack_key()
         if self._handle is not None and self._handle_key == key:
             return self._handle
         h = _Handle()
@@ -234,6 +234,27 @@ class Transformer(nn.Module):
         h.packed = t
         self._handle, self._handle_key = h, key
         return h
+
+    def _pack_key(self):
+        """identity of the packed (bf16 / fp8, kernel-layout) weight copies: device + (storage pointer, in-place version) of every parameter and
+        buffer.  `.data` surgery that keeps the storage and does not bump the version counter (EMA `p.data.copy_`, `p.data.lerp_`) is NOT
+        visible here: call `invalidate_packed_weights()` after such edits."""
+        ts = list(self.parameters()) + list(self.buffers())
+        return (str(self.token_emb.weight.device),) + tuple((t.data_ptr(), t._version) for t in ts)
+
+    def invalidate_packed_weights(self):
+        """Drop the packed device copies of the weights (rebuilt on the next call).  Needed only after edits the version counters cannot
+        see (`param.data.copy_(...)`, raw pointer writes); `load_state_dict`, `.to()`, optimizer steps and in-place ops are detected."""
+        self._handle, self._handle_key, self._fp8 = None, None, None
+        return self
+
+    def _apply(self, fn, *args, **kwargs):
+        self._handle, self._handle_key, self._fp8 = None, None, None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._handle, self._handle_key, self._fp8 = None, None, None
+        return super().load_state_dict(*args, **kwargs)
 
     def _workspace(self, nbytes, device):
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
@@ -297,7 +318,7 @@ class Transformer(nn.Module):
         return self
 
     def _fp8_pack(self):
-        key = (str(self.token_emb.weight.device),) + tuple(p._version for p in self.parameters())
+        key = self._pack_key()
         if self._fp8 is not None and self._fp8['key'] == key:
             return self._fp8
         q = ops.quantize_e4m3_rows
@@ -423,8 +444,10 @@ class Transformer(nn.Module):
         returns the bf16 [b*n, dim] embed for the fused CFG GEMM.  With `labels`, autograd enabled and trainable parameters the
         cross-entropy comes from the differentiable MI355X training path (training.py: hand-written backward); otherwise the loss
         is computed forward-only."""
-        if (exists(labels) and not return_logits and torch.is_grad_enabled() and self.to_logits.weight.requires_grad
-                and bool((labels != ignore_index).any())):      # all rows ignored: NaN like F.cross_entropy, nothing to differentiate
+        # (the reference returns (logits, embed) before it looks at labels, mmp.py:334-335; the ignore_index emptiness test only applies to the
+        #  cross-entropy head: a TokenCritic's float 0/1 labels may legitimately all equal the default ignore_index 0)
+        if (exists(labels) and not return_logits and not return_embed and torch.is_grad_enabled() and self.to_logits.weight.requires_grad
+                and (self.dim_out == 1 or bool((labels != ignore_index).any()))):      # CE with all rows ignored: NaN like F.cross_entropy, nothing to differentiate
             assert exists(texts) ^ exists(text_embeds)
             if exists(texts):
                 text_embeds = self.encode_text(texts)

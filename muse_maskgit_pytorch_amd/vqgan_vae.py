@@ -201,36 +201,60 @@ class VQGanVAE(nn.Module):
         self.load_state_dict(torch.load(str(path)))
 
     # ---- packed (bf16, kernel layout) weights, rebuilt when parameters change
+    def _pack_key(self):
+        ts = list(self.parameters()) + list(self.buffers())
+        return (str(self.device),) + tuple((t.data_ptr(), t._version) for t in ts)
+
+    def invalidate_packed_weights(self):
+        """Drop the packed device copies (needed only after `.data` edits the version counters cannot see)."""
+        self._packed = None
+        return self
+
+    def _apply(self, fn, *args, **kwargs):
+        self._packed = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._packed = None
+        return super().load_state_dict(*args, **kwargs)
+
     def _pack(self):
-        key = (str(self.device),) + tuple(p._version for p in self.parameters())
+        key = self._pack_key()
         if self._packed is not None and self._packed['key'] == key:
             return self._packed
         ed = self.enc_dec
         f32 = lambda t: t.detach().float().contiguous()
-        P = dict(key=key, enc=[], dec=[])
-        enc0 = ed.encoders[0]
-        P['stem'] = dict(w=ops.pack_conv_weight_cin8(enc0.weight.detach()), b=f32(enc0.bias), k=enc0.kernel_size[0], cout=enc0.out_channels)
-        for i in range(1, ed.layers + 1):
-            c = ed.encoders[i][0]
-            P['enc'].append(dict(w=ops.pack_conv_weight(c.weight.detach()), b=f32(c.bias), cout=c.out_channels))
 
-        def pack_block(net, idx_convs, idx_gns):
-            out = dict(convs=[], gns=[])
-            for i in idx_convs:
-                out['convs'].append(dict(w=ops.pack_conv_weight(net[i].weight.detach()), b=f32(net[i].bias), cout=net[i].out_channels,
-                                         k=net[i].kernel_size[0]))
-            for i in idx_gns:
-                out['gns'].append(dict(g=f32(net[i].weight), b=f32(net[i].bias), groups=net[i].num_groups))
-            return out
+        def conv(c, cin8=False):
+            return dict(w=(ops.pack_conv_weight_cin8 if cin8 else ops.pack_conv_weight)(c.weight.detach()), b=f32(c.bias), cout=c.out_channels,
+                        k=c.kernel_size[0])
 
-        P['enc_res'] = [pack_block(m.net, (0, 3, 6), (1, 4)) for m in ed.encoders[ed.layers + 1:]]
-        n_glu = len(ed.decoders) - ed.layers - 1
-        P['dec_res'] = [pack_block(m.net, (0, 3, 6), (2, 5)) for m in ed.decoders[:n_glu]]
-        for m in ed.decoders[n_glu:n_glu + ed.layers]:
-            ct = m[0]
-            P['dec'].append(dict(w=ops.pack_convT_weight(ct.weight.detach()), b=f32(ct.bias), cout=ct.out_channels))
-        last = ed.decoders[-1]
-        P['head'] = dict(w=ops.pack_conv_weight(last.weight.detach()), b=f32(last.bias), cout=last.out_channels)
+        def block(net, idx_convs, idx_gns):
+            return dict(convs=[conv(net[i]) for i in idx_convs],
+                        gns=[dict(g=f32(net[i].weight), b=f32(net[i].bias), groups=net[i].num_groups) for i in idx_gns])
+
+        def pack_module(m, first_encoder=False):
+            """one entry of ResnetEncDec.encoders / .decoders (vqgan_vae.py:223-232), dispatched on its type: the lists interleave
+            down / up-sampling convolutions with residual blocks when num_resnet_blocks is a tuple"""
+            if isinstance(m, ResBlock):
+                return dict(kind='res', **block(m.net, (0, 3, 6), (1, 4)))
+            if isinstance(m, GLUResBlock):
+                return dict(kind='glu', **block(m.net, (0, 3, 6), (2, 5)))
+            if isinstance(m, nn.Sequential) and isinstance(m[0], nn.ConvTranspose2d):
+                ct = m[0]
+                if ct.kernel_size != (4, 4) or ct.stride != (2, 2) or ct.padding != (1, 1):
+                    raise NotImplementedError('MI355X VQGanVAE: only ConvTranspose2d(4, 2, 1) up-sampling (the reference builds no other)')
+                return dict(kind='up', w=ops.pack_convT_weight(ct.weight.detach()), b=f32(ct.bias), cout=ct.out_channels)
+            if isinstance(m, nn.Sequential) and isinstance(m[0], nn.Conv2d):
+                c = m[0]
+                if c.kernel_size != (4, 4) or c.stride != (2, 2) or c.padding != (1, 1):
+                    raise NotImplementedError('MI355X VQGanVAE: only Conv2d(4, 2, 1) down-sampling (the reference builds no other)')
+                return dict(kind='down', **conv(c))
+            if isinstance(m, nn.Conv2d):
+                return dict(kind='stem' if first_encoder else 'head', **conv(m, cin8=first_encoder))
+            raise NotImplementedError(f'MI355X VQGanVAE: unsupported layer {type(m).__name__} in the encoder / decoder list')
+
+        P = dict(key=key, enc=[pack_module(m, i == 0) for i, m in enumerate(ed.encoders)], dec=[pack_module(m) for m in ed.decoders])
         q = self.quantizer
         P['bits'] = q.codebook_dim
         if not self.lookup_free_quantization:
@@ -243,24 +267,49 @@ class VQGanVAE(nn.Module):
         return P
 
     # ---- hot path
+    @staticmethod
+    def _run_layer(x, e):
+        """one packed layer on NHWC bf16 activations"""
+        kind = e['kind']
+        if kind == 'stem':                                            # Conv2d(channels, dim, k, padding k // 2)
+            return ops.conv2d_nhwc(x, e['w'], e['cout'], e['k'], e['k'], 1, (-(e['k'] // 2), -(e['k'] // 2)), bias=e['b'])
+        if kind == 'down':                                            # Conv2d(4, stride 2, pad 1) + LeakyReLU(0.1)
+            B, H, W, _ = x.shape
+            return ops.conv2d_nhwc(x, e['w'], e['cout'], 4, 4, 2, (-1, -1), out_hw=(H // 2, W // 2), bias=e['b'], act=True)
+        if kind == 'res':                                             # ResBlock (vqgan_vae.py:267-281)
+            c0, c1, c2 = e['convs']
+            g0, g1 = e['gns']
+            h = ops.conv2d_nhwc(x, c0['w'], c0['cout'], 3, 3, 1, (-1, -1), bias=c0['b'])
+            h = ops.groupnorm_nhwc(h, g0['groups'], g0['g'], g0['b'], act=True)
+            h = ops.conv2d_nhwc(h, c1['w'], c1['cout'], 3, 3, 1, (-1, -1), bias=c1['b'])
+            h = ops.groupnorm_nhwc(h, g1['groups'], g1['g'], g1['b'], act=True)
+            return ops.conv2d_nhwc(h, c2['w'], c2['cout'], 1, 1, 1, (0, 0), bias=c2['b'], resid=x)
+        if kind == 'glu':                                             # GLUResBlock (vqgan_vae.py:251-265)
+            c0, c1, c2 = e['convs']
+            g0, g1 = e['gns']
+            h = ops.conv2d_nhwc(x, c0['w'], c0['cout'], 3, 3, 1, (-1, -1), bias=c0['b'])
+            h = ops.groupnorm_nhwc(ops.glu_nhwc(h), g0['groups'], g0['g'], g0['b'])
+            h = ops.conv2d_nhwc(h, c1['w'], c1['cout'], 3, 3, 1, (-1, -1), bias=c1['b'])
+            h = ops.groupnorm_nhwc(ops.glu_nhwc(h), g1['groups'], g1['g'], g1['b'])
+            return ops.conv2d_nhwc(h, c2['w'], c2['cout'], 1, 1, 1, (0, 0), bias=c2['b'], resid=x)
+        if kind == 'up':                                              # ConvTranspose2d(4,2,1) + LeakyReLU as 4 parity convs
+            B, H, W, _ = x.shape
+            out = torch.empty(B, 2 * H, 2 * W, e['cout'], dtype=torch.bfloat16, device=x.device)
+            for (py, px), w in e['w'].items():
+                ops.conv2d_nhwc(x, w, e['cout'], 2, 2, 1, (py - 1, px - 1), out_hw=(H, W), os_=2, parity=(py, px),
+                                full_hw=(2 * H, 2 * W), bias=e['b'], act=True, out=out)
+            return out
+        if kind == 'head':                                            # Conv2d(dim, channels, 1) -> NCHW fp32 image
+            return ops.conv2d_nhwc(x, e['w'], e['cout'], 1, 1, 1, (0, 0), bias=e['b'], out_nchw_f32=True)
+        raise AssertionError(kind)
+
     @torch.no_grad()
     def encode(self, fmap):
         """vqgan_vae.py:422-425: image (B,C,H,W) fp32 -> (quantized fmap (B,C',h,w) fp32, ids (B,h,w) int64, aux loss 0)."""
         P = self._pack()
         x = ops.nchw_to_nhwc8(fmap)
-        st = P['stem']
-        x = ops.conv2d_nhwc(x, st['w'], st['cout'], st['k'], st['k'], 1, (-(st['k'] // 2), -(st['k'] // 2)), bias=st['b'])
-        for e in P['enc']:                                        # Conv2d(4, stride 2, pad 1) + LeakyReLU(0.1)
-            B, H, W, _ = x.shape
-            x = ops.conv2d_nhwc(x, e['w'], e['cout'], 4, 4, 2, (-1, -1), out_hw=(H // 2, W // 2), bias=e['b'], act=True)
-        for r in P['enc_res']:                                    # ResBlock (vqgan_vae.py:267-281)
-            c0, c1, c2 = r['convs']
-            g0, g1 = r['gns']
-            h = ops.conv2d_nhwc(x, c0['w'], c0['cout'], 3, 3, 1, (-1, -1), bias=c0['b'])
-            h = ops.groupnorm_nhwc(h, g0['groups'], g0['g'], g0['b'], act=True)
-            h = ops.conv2d_nhwc(h, c1['w'], c1['cout'], 3, 3, 1, (-1, -1), bias=c1['b'])
-            h = ops.groupnorm_nhwc(h, g1['groups'], g1['g'], g1['b'], act=True)
-            x = ops.conv2d_nhwc(h, c2['w'], c2['cout'], 1, 1, 1, (0, 0), bias=c2['b'], resid=x)
+        for e in P['enc']:                                            # ResnetEncDec.encode (vqgan_vae.py:241-244), in list order
+            x = self._run_layer(x, e)
         if not self.lookup_free_quantization:
             ids, q = self.quantizer.encode_nhwc(x)
             return ops.nhwc_to_nchw_f32(q), ids, torch.zeros((), device=fmap.device)
@@ -271,24 +320,9 @@ class VQGanVAE(nn.Module):
     @torch.no_grad()
     def _decode_nhwc(self, x):
         """ResnetEncDec.decode (vqgan_vae.py:246-249) on NHWC bf16 -> NCHW fp32 image."""
-        P = self._pack()
-        for r in P['dec_res']:                                    # GLUResBlock (vqgan_vae.py:251-265)
-            c0, c1, c2 = r['convs']
-            g0, g1 = r['gns']
-            h = ops.conv2d_nhwc(x, c0['w'], c0['cout'], 3, 3, 1, (-1, -1), bias=c0['b'])
-            h = ops.groupnorm_nhwc(ops.glu_nhwc(h), g0['groups'], g0['g'], g0['b'])
-            h = ops.conv2d_nhwc(h, c1['w'], c1['cout'], 3, 3, 1, (-1, -1), bias=c1['b'])
-            h = ops.groupnorm_nhwc(ops.glu_nhwc(h), g1['groups'], g1['g'], g1['b'])
-            x = ops.conv2d_nhwc(h, c2['w'], c2['cout'], 1, 1, 1, (0, 0), bias=c2['b'], resid=x)
-        for d in P['dec']:                                        # ConvTranspose2d(4,2,1) + LeakyReLU as 4 parity convs
-            B, H, W, _ = x.shape
-            out = torch.empty(B, 2 * H, 2 * W, d['cout'], dtype=torch.bfloat16, device=x.device)
-            for (py, px), w in d['w'].items():
-                ops.conv2d_nhwc(x, w, d['cout'], 2, 2, 1, (py - 1, px - 1), out_hw=(H, W), os_=2, parity=(py, px),
-                                full_hw=(2 * H, 2 * W), bias=d['b'], act=True, out=out)
-            x = out
-        hd = P['head']
-        return ops.conv2d_nhwc(x, hd['w'], hd['cout'], 1, 1, 1, (0, 0), bias=hd['b'], out_nchw_f32=True)
+        for e in self._pack()['dec']:
+            x = self._run_layer(x, e)
+        return x
 
     @torch.no_grad()
     def decode_from_ids(self, ids):

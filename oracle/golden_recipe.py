@@ -1,0 +1,72 @@
+"""TEST INFRASTRUCTURE ONLY.  The deterministic recipe of the BASE-SIZE (BASELINE configs[1]) golden run, shared by
+oracle/make_golden_base.py (which applies it to the UNMODIFIED reference's classes in the build container) and by the tests (which apply
+it to this package's classes on the GPU box -- the reference does not travel).  A base transformer has 103 M parameters, so the
+checkpoint cannot be a committed fixture: both sides REBUILD it from `torch.manual_seed` + the module constructors (the reference's and
+this package's constructors create the same parameters in the same order from the same generator stream -- asserted, parameter by
+parameter, in make_golden_base.py and tests/test_host_logic.py) followed by the edits below, and the per-step Gumbel noise is rebuilt
+from the CPU generator stream the reference consumed (mmp.py:406-408: one `zeros_like(logits).uniform_(0, 1)` per decode step, nothing
+else draws).  Checksums of both are stored in the fixture and asserted before anything is compared.
+"""
+import torch
+
+BASE_CFG = dict(num_tokens=65536, seq_len=256, dim=512, depth=8, dim_head=64, heads=8, ff_mult=4, t5_name='t5-small')      # README.md:61-70
+VAE_CFG = dict(dim=256, codebook_size=65536)                                                                          # README.md:23-26
+B, N, L, T = 2, 256, 32, 18
+WEIGHT_SEED, VAE_SEED, EDIT_SEED, INPUT_SEED, NOISE_SEED = 0, 1, 4321, 77, 20260924
+PEAK = 8.0      # to_logits scale of the decode run: well-separated confidences (SURVEY 8c determinism control 3)
+
+
+def build_transformer(cls, peaky):
+    """cls = MaskGitTransformer of the reference or of this package.  Module-default init under WEIGHT_SEED, learned scales / norm gains
+    made non-trivial, optionally peaky logits, everything rounded to bf16-representable fp32 (exactly loadable by the bf16 engine)."""
+    torch.manual_seed(WEIGHT_SEED)
+    tr = cls(**BASE_CFG)
+    gen = torch.Generator().manual_seed(EDIT_SEED)
+    with torch.no_grad():
+        for name, p in tr.named_parameters():
+            if name.endswith('q_scale') or name.endswith('k_scale') or name.endswith('gamma'):
+                p.mul_(1 + 0.2 * torch.randn(p.shape, generator=gen))
+        if peaky:
+            tr.to_logits.weight.mul_(PEAK)
+        for p in tr.parameters():
+            p.copy_(p.to(torch.bfloat16).float())
+    return tr.eval()
+
+
+def build_vae(cls):
+    torch.manual_seed(VAE_SEED)
+    vae = cls(**VAE_CFG)
+    with torch.no_grad():
+        for p in vae.parameters():
+            p.copy_(p.to(torch.bfloat16).float())
+    return vae.eval()
+
+
+def inputs():
+    """ids with ~half the positions masked, zero-padded text embeddings (t5.py:93), VAE inputs."""
+    g = torch.Generator().manual_seed(INPUT_SEED)
+    ids = torch.randint(0, BASE_CFG['num_tokens'], (B, N), generator=g)
+    ids[torch.rand(B, N, generator=g) < 0.5] = BASE_CFG['num_tokens']          # mask id
+    te = torch.randn(B, L, 512, generator=g)
+    te[1, L - 5:] = 0
+    vae_ids = torch.randint(0, VAE_CFG['codebook_size'], (B, 16, 16), generator=g)
+    image = torch.randn(B, 3, 256, 256, generator=g)
+    return dict(ids=ids, text_embeds=te, vae_ids=vae_ids, image=image)
+
+
+def noise_stream(steps=T):
+    """the U(0,1) tensors the reference's gumbel_noise drew during generate(), step by step, from torch's CPU generator"""
+    torch.manual_seed(NOISE_SEED)
+    for _ in range(steps):
+        yield torch.zeros(B, N, BASE_CFG['num_tokens']).uniform_(0, 1)
+
+
+def checksum(t):
+    """order-sensitive fp64 checksum of a tensor (weights / noise reproduction check)"""
+    f = t.detach().double().flatten()
+    w = torch.arange(1, f.numel() + 1, dtype=torch.float64).remainder(1009.0) + 1.0
+    return float((f * w).sum())
+
+
+def state_checksum(module):
+    return {k: checksum(v) for k, v in module.state_dict().items() if v.is_floating_point()}

@@ -1,0 +1,118 @@
+"""TEST INFRASTRUCTURE ONLY.  Base-size (BASELINE configs[1]: dim 512, depth 8, 65536-entry codebook, 256 tokens, VQGanVAE dim 256) golden
+vectors from the UNMODIFIED reference run on CPU in fp32 ("Transformer.forward logits for ... a D=512/V=65536 B=2 case; full
+generate traces ... base (T=18, B=2)").  Run in the build container only:   python oracle/make_golden_base.py     (~4 min)
+
+The checkpoint (103 M + 325 M parameters) and the noise (18 x 2 x 256 x 65536 uniforms) are NOT stored: oracle/golden_recipe.py rebuilds
+both from seeds, here with the reference's classes and on the GPU box with this package's; their checksums are stored and asserted.
+Stored: the inputs' checksums, logits at 8 full rows + every 128th vocabulary column of all 512 rows (cond / null / guidance-combined), the
+final-LayerNorm embed, per-step ids and scores of the 18-step decode and its final ids, decoded pixels (strided + one full crop), LFQ
+encode ids and the pre-sign projections.
+"""
+import os
+import sys
+import time
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import golden_recipe as R  # noqa: E402
+from reference_harness import reference_modules  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden', 'base_c2.pt')
+FULL_ROWS = [0, 77, 255, 256, 300, 301, 448, 511]      # flat (b * n + pos) rows stored with all 65536 logits
+COL_STRIDE = 128
+
+
+def main():
+    t0 = time.time()
+    pkg, mmp, vaemod, att = reference_modules()
+    inp = R.inputs()
+    ids, te = inp['ids'], inp['text_embeds']
+    out = dict(recipe=dict(B=R.B, N=R.N, L=R.L, T=R.T, peak=R.PEAK), full_rows=FULL_ROWS, col_stride=COL_STRIDE,
+               input_checksum={k: R.checksum(v.float()) for k, v in inp.items()})
+
+    # ---------------------------------------------------------------- Transformer.forward (mmp.py:279-335) + guidance (:240-259), plain init
+    tr = R.build_transformer(pkg.MaskGitTransformer, peaky=False)
+    out['weight_checksum'] = R.state_checksum(tr)
+    with torch.no_grad():
+        lc, emb = tr(ids, text_embeds=te, cond_drop_prob=0., return_embed=True)
+        ln = tr(ids, text_embeds=te, cond_drop_prob=1.)
+        sc = tr.forward_with_cond_scale(ids, text_embeds=te, cond_scale=3.)
+
+    def sample(lg):
+        f = lg.reshape(R.B * R.N, -1)
+        return dict(rows=f[FULL_ROWS].clone(), cols=f[:, ::COL_STRIDE].clone(), absmax=f.abs().max().item(), std=f.std().item())
+
+    out['forward'] = dict(logits_cond=sample(lc), logits_null=sample(ln), logits_scaled=sample(sc), embed=emb.clone())
+    print(f'forward done {time.time() - t0:.0f}s: logits std {lc.std().item():.3f} absmax {lc.abs().max().item():.2f}')
+    del lc, ln, sc
+
+    # ---------------------------------------------------------------- VQGanVAE decode / encode at dim 256 (vqgan_vae.py:422-441)
+    vae = R.build_vae(pkg.VQGanVAE)
+    vae_eval = vae.copy_for_eval()
+    out['vae_weight_checksum'] = R.state_checksum(vae_eval)
+    with torch.no_grad():
+        dec = vae_eval.decode_from_ids(inp['vae_ids'])
+        fmap, enc_ids, _ = vae_eval.encode(inp['image'])
+        pre = vae_eval.enc_dec.encode(inp['image'])                                   # (B, 2048, 16, 16) before the quantizer
+        t_in = vae_eval.quantizer.project_in(pre.permute(0, 2, 3, 1).reshape(R.B, 256, -1))   # (B, 256, 16): the values whose signs are the id bits
+    out['vae'] = dict(decoded_strided=dec[:, :, ::4, ::4].clone(), decoded_crop=dec[:, :, 96:160, 96:160].clone(), decoded_absmax=dec.abs().max().item(),
+                      enc_ids=enc_ids.clone(), enc_pre_sign=t_in.clone(), enc_fmap_strided=fmap[:, ::16].clone())
+    print(f'vae done {time.time() - t0:.0f}s: decoded absmax {dec.abs().max().item():.3f}, min |pre-sign| {t_in.abs().min().item():.3g}')
+
+    # ---------------------------------------------------------------- MaskGit.generate (mmp.py:491-621), peaky logits, 18 steps
+    with torch.no_grad():
+        tr.to_logits.weight.mul_(R.PEAK)      # == build_transformer(peaky=True): scaling a bf16 value by 8 is exact
+    chk = R.state_checksum(R.build_transformer(pkg.MaskGitTransformer, peaky=True))
+    assert chk == R.state_checksum(tr)
+    out['weight_checksum_peaky'] = chk
+    mg = pkg.MaskGit(vae=vae, transformer=tr, image_size=256)
+    tr.encode_text = lambda texts, te=te: te
+    rec = dict(step_in_ids=[], noise_checksum=[], noise_head=[])
+    orig_fw = tr.forward_with_cond_scale
+
+    def fw(ids_, *a, **kw):
+        rec['step_in_ids'].append(ids_.clone().to(torch.int32))
+        return orig_fw(ids_, *a, **kw)
+
+    tr.forward_with_cond_scale = fw
+    log = mmp.log
+
+    def gumbel_noise(t):      # identical draw to mmp.py:406-408, plus bookkeeping
+        noise = torch.zeros_like(t).uniform_(0, 1)
+        rec['noise_checksum'].append(R.checksum(noise))
+        rec['noise_head'].append(noise.flatten()[:8].clone())
+        return -log(-log(noise))
+
+    orig_gn = mmp.gumbel_noise
+    mmp.gumbel_noise = gumbel_noise
+    final = {}
+    orig_dec = mg.vae.decode_from_ids
+
+    def dec_rec(i):
+        final['ids'] = i.clone()
+        return orig_dec(i)
+
+    mg.vae.decode_from_ids = dec_rec
+    # per-step state: wrap torch.Tensor.topk? simpler: the ids entering step s+1 with their mask positions give the state after step s
+    torch.manual_seed(R.NOISE_SEED)
+    with torch.no_grad():
+        images = mg.generate(['a', 'b'], timesteps=R.T, cond_scale=3.)
+    mmp.gumbel_noise = orig_gn
+    tr.forward_with_cond_scale = orig_fw
+    assert len(rec['noise_checksum']) == R.T
+    # cross-check of the noise recipe: the stream rebuilt from the seed is what the reference consumed
+    for s, u in enumerate(R.noise_stream()):
+        assert R.checksum(u) == rec['noise_checksum'][s], f'noise recipe does not reproduce step {s}'
+        if s == 1:
+            break
+    out['generate'] = dict(step_in_ids=torch.stack(rec['step_in_ids']), final_ids=final['ids'].clone(), noise_checksum=rec['noise_checksum'],
+                           noise_head=torch.stack(rec['noise_head']), images_strided=images[:, :, ::4, ::4].clone(),
+                           images_absmax=images.abs().max().item())
+    torch.save(out, OUT)
+    print(f'wrote {OUT} ({os.path.getsize(OUT) / 1e6:.1f} MB) in {time.time() - t0:.0f}s')
+
+
+if __name__ == '__main__':
+    main()

@@ -180,3 +180,136 @@ def test_ff_packing_layout():
     ref2 = z @ ff[4].weight.detach().bfloat16().float().t()
     assert k['w2f'].shape == (128, 384) and k['w2f'][:, 341:].abs().sum() == 0
     assert (folded - ref2).abs().max() < 2e-2 * ref2.abs().max()      # = the bf16 rounding of w2 * gamma
+
+
+# ------------------------------------------------------------------------------------------------ round-2 host logic
+def test_text_condition_pair_contract():
+    """t5.py:59-99 / mmp.py:304: the explicit (embeds, mask) pair <-> the zero-padded single tensor the hot path consumes."""
+    from muse_maskgit_pytorch_amd import t5
+    g = torch.Generator().manual_seed(0)
+    e = torch.randn(3, 6, 16, generator=g)
+    m = torch.tensor([[1, 1, 1, 1, 0, 0], [1, 1, 1, 1, 1, 1], [1, 0, 0, 0, 0, 0]], dtype=torch.bool)
+    packed = t5.pack_text_condition(e, m)
+    assert torch.equal(packed[m], e[m]) and (packed[~m] == 0).all()
+    e2, m2 = t5.unpack_text_condition(packed)
+    assert torch.equal(m2, m) and torch.equal(t5.derive_text_mask(packed), m)
+    # a kept position whose embedding is all-zero cannot be expressed by the reference's zeros-are-padding contract: rejected, not dropped
+    e[1, 2] = 0
+    with pytest.raises(ValueError):
+        t5.pack_text_condition(e, m)
+    with pytest.raises(ValueError):
+        t5.pack_text_condition(torch.randn(1, t5.MAX_LENGTH + 1, 8), torch.ones(1, t5.MAX_LENGTH + 1, dtype=torch.bool))
+    # the oracle derives the same mask (it is the reference's expression)
+    assert torch.equal((packed != 0).any(dim=-1), m)
+
+
+def test_token_critic_all_zero_labels_still_take_the_differentiable_path(monkeypatch):
+    """A TokenCritic's float labels may all be 0 == the default ignore_index; that must not demote the call to the no-grad branch
+    (ADVICE r1).  And return_embed wins over labels like in the reference (mmp.py:334-335)."""
+    from muse_maskgit_pytorch_amd import training
+    calls = []
+    monkeypatch.setattr(training, 'transformer_loss', lambda *a, **k: calls.append('train') or torch.zeros(()))
+    critic = mm.TokenCritic(num_tokens=512, seq_len=64, dim=128, depth=1, t5_name='t5-small')
+    critic(torch.zeros(1, 4, dtype=torch.long), text_embeds=torch.randn(1, 3, 512), labels=torch.zeros(1, 4))
+    assert calls == ['train']
+    gen = mm.MaskGitTransformer(num_tokens=512, seq_len=64, dim=128, depth=1, t5_name='t5-small')
+    calls.clear()
+    with pytest.raises(_lib.MuseHipError):       # all rows ignored for the CE head: forward-only branch (which needs the GPU)
+        gen(torch.zeros(1, 4, dtype=torch.long), text_embeds=torch.randn(1, 3, 512), labels=torch.zeros(1, 4, dtype=torch.long))
+    with pytest.raises(_lib.MuseHipError):       # return_embed requested: never the loss branch
+        gen(torch.zeros(1, 4, dtype=torch.long), text_embeds=torch.randn(1, 3, 512), labels=torch.ones(1, 4, dtype=torch.long), return_embed=True)
+    assert calls == []
+
+
+def test_packed_weight_cache_key_sees_storage_and_version_changes():
+    t = mm.MaskGitTransformer(num_tokens=512, seq_len=64, dim=128, depth=1, t5_name='t5-small')
+    k0 = t._pack_key()
+    with torch.no_grad():
+        t.to_logits.weight.mul_(2.)                       # in-place: version bump
+    k1 = t._pack_key()
+    assert k1 != k0
+    t.to_logits.weight.data = t.to_logits.weight.data.clone()      # new storage, same version
+    assert t._pack_key() != k1
+    t._handle, t._handle_key = object(), t._pack_key()
+    t.load_state_dict(t.state_dict())
+    assert t._handle is None                              # load_state_dict drops the packed copies
+    t._handle = object()
+    t.invalidate_packed_weights()
+    assert t._handle is None
+    v = mm.VQGanVAE(dim=16, codebook_size=512)
+    v._packed = dict(key=v._pack_key())
+    v.float()                                             # _apply
+    assert v._packed is None
+
+
+def test_vae_pack_walks_interleaved_resnet_blocks():
+    """num_resnet_blocks as a tuple interleaves residual blocks with the down / up-sampling convolutions (vqgan_vae.py:218-231); the packer
+    dispatches on the layer type instead of assuming the default layout."""
+    v = mm.VQGanVAE(dim=16, codebook_size=512, encdec_num_resnet_blocks=(1, 0, 2, 1))
+    kinds_e = [e['kind'] for e in v._pack()['enc']]
+    kinds_d = [e['kind'] for e in v._pack()['dec']]
+    assert kinds_e == ['stem', 'down', 'res', 'down', 'down', 'res', 'res', 'down', 'res']
+    assert kinds_d == ['glu', 'up', 'glu', 'glu', 'up', 'up', 'glu', 'up', 'head']
+    d = mm.VQGanVAE(dim=16, codebook_size=512)
+    assert [e['kind'] for e in d._pack()['enc']] == ['stem', 'down', 'down', 'down', 'down', 'res']
+    assert [e['kind'] for e in d._pack()['dec']] == ['glu', 'up', 'up', 'up', 'up', 'head']
+
+
+def test_seeded_construction_matches_the_base_golden_recipe(golden):
+    """The base-size golden stores no checkpoint: both sides rebuild it from seeds (oracle/golden_recipe.py).  This package's classes must
+    reproduce the reference's parameters exactly -- checked against the checksums the reference run stored."""
+    import golden_recipe as R
+    g = golden('base_c2.pt')
+    tr = R.build_transformer(mm.MaskGitTransformer, peaky=False)
+    got = R.state_checksum(tr)
+    assert got == g['weight_checksum']
+    with torch.no_grad():
+        tr.to_logits.weight.mul_(R.PEAK)
+    assert R.state_checksum(tr) == g['weight_checksum_peaky']
+    inp = R.inputs()
+    assert {k: R.checksum(v.float()) for k, v in inp.items()} == g['input_checksum']
+    vae = R.build_vae(mm.VQGanVAE).copy_for_eval()
+    assert R.state_checksum(vae) == g['vae_weight_checksum']
+    u0 = next(iter(R.noise_stream()))
+    assert R.checksum(u0) == g['generate']['noise_checksum'][0] and torch.equal(u0.flatten()[:8], g['generate']['noise_head'][0])
+
+
+def test_patch_reference_mode_2_keeps_the_reference_classes():
+    """SURVEY 8b mode 2: hot methods swapped on the reference's own classes; isinstance (what @beartype checks, mmp.py:427,745) still
+    holds, the shadow shares the reference module's tensors, and without a GPU the patched methods raise (no fallback)."""
+    import reference_harness as H
+    if not H.reference_available():
+        pytest.skip('the reference package only exists in the build container')
+    pkg, mmp, vaemod, att = H.reference_modules()
+    from muse_maskgit_pytorch_amd import patch
+    orig = mmp.MaskGit.generate
+    names = mm.patch_reference(pkg)
+    try:
+        assert 'MaskGit.generate' in names and 'Attend.forward' in names and mmp.MaskGit.generate is not orig
+        assert mm.patch_reference(pkg) == names                              # idempotent
+        tr = pkg.MaskGitTransformer(num_tokens=512, seq_len=64, dim=128, depth=2, dim_head=64, heads=8, t5_name='t5-small')
+        vae = pkg.VQGanVAE(dim=16, codebook_size=512)
+        mg = pkg.MaskGit(vae=vae, transformer=tr, image_size=128)
+        assert isinstance(mg.transformer, pkg.MaskGitTransformer) and isinstance(mg.vae, pkg.VQGanVAE) and isinstance(mg, pkg.MaskGit)
+        sh = patch._transformer_shadow(tr)
+        assert type(sh) is mm.MaskGitTransformer and patch._transformer_shadow(tr) is sh
+        own = dict(sh.named_parameters())
+        for k, p in tr.named_parameters():
+            assert own[k] is p
+        assert not any(t.is_meta for t in list(sh.parameters()) + list(sh.buffers()))
+        vsh = patch._vae_shadow(mg.vae)
+        assert all(dict(vsh.named_parameters())[k] is p for k, p in mg.vae.named_parameters() if k in dict(vsh.named_parameters()))
+        assert not any(t.is_meta for t in list(vsh.parameters()) + list(vsh.buffers()))
+        msh = patch._maskgit_shadow(mg)
+        assert msh.transformer is sh and msh.vae is vsh and msh.mask_id == 512
+        crit = pkg.TokenCritic(num_tokens=512, seq_len=64, dim=128, depth=1, dim_head=64, heads=8, t5_name='t5-small')
+        assert type(patch._transformer_shadow(crit)) is mm.TokenCritic
+        if not torch.cuda.is_available():
+            with pytest.raises(_lib.MuseHipError):
+                tr(torch.zeros(1, 4, dtype=torch.long), text_embeds=torch.randn(1, 3, 512))
+            tr.encode_text = lambda texts: torch.randn(len(texts), 3, 512)      # per-instance attribute, as reference users override it (mmp.py:229)
+            with pytest.raises(_lib.MuseHipError):
+                mg.generate(['a'], timesteps=2)
+    finally:
+        mm.unpatch_reference()
+    assert mmp.MaskGit.generate is orig

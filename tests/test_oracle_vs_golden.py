@@ -152,3 +152,81 @@ def test_training_forward_losses_match_reference(golden):
     assert abs(O.transformer_loss(sd, cfg, l['x'], g['text_embeds'], l['labels'], ignore_index=-1, cond_drop_prob=1.).item() - l['loss_drop'].item()) < 1e-4
     bce = O.transformer_loss(sd_f32(l['critic_sd']), dict(depth=1, heads=8), l['x'].clamp(max=511), g['text_embeds'], l['critic_labels'])
     assert abs(bce.item() - l['critic_bce'].item()) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ base size (BASELINE configs[1])
+@pytest.fixture(scope='module')
+def base_setup(golden):
+    """checkpoint + inputs of the base-size golden run, rebuilt from the seeded recipe (oracle/golden_recipe.py) with this package's classes"""
+    import golden_recipe as R
+    import muse_maskgit_pytorch_amd as mm
+    g = golden('base_c2.pt')
+    tr = R.build_transformer(mm.MaskGitTransformer, peaky=False)
+    assert R.state_checksum(tr) == g['weight_checksum']
+    sd = {k: v.detach().clone() for k, v in tr.state_dict().items()}
+    return g, R, sd, R.inputs()
+
+
+def _check_samples(R, logits, rec, tol=3e-5):
+    f = logits.reshape(R.B * R.N, -1)
+    close(f[[0, 77, 255, 256, 300, 301, 448, 511]], rec['rows'], tol)
+    close(f[:, ::128], rec['cols'], tol)
+
+
+def test_oracle_forward_matches_reference_at_base_size(base_setup):
+    g, R, sd, inp = base_setup
+    cfg = dict(depth=8, heads=8)
+    with torch.no_grad():
+        lc, emb = O.transformer_forward(sd, cfg, inp['ids'], inp['text_embeds'], 0., return_embed=True)
+        ln = O.transformer_forward(sd, cfg, inp['ids'], inp['text_embeds'], 1.)
+    fw = g['forward']
+    _check_samples(R, lc, fw['logits_cond']); _check_samples(R, ln, fw['logits_null'])
+    close(emb, fw['embed'], 3e-5)
+    _check_samples(R, ln + (lc - ln) * 3., fw['logits_scaled'])
+
+
+def test_oracle_decode_steps_match_reference_at_base_size(base_setup):
+    """teacher-forced on the reference's recorded per-step inputs: the oracle's guidance pass + sampling tail + re-mask selection reproduce
+    the reference's next state bit for bit at V = 65536 (first, a middle and the last step; the noise is the reference's, rebuilt from its seed)"""
+    g, R, sd, inp = base_setup
+    sd = dict(sd)
+    sd['to_logits.weight'] = sd['to_logits.weight'] * R.PEAK
+    gen = g['generate']
+    cfg = dict(depth=8, heads=8)
+    counts, temps = O.mask_counts(R.T, R.N), O.step_temperatures(R.T, 1.)
+    steps = (0, 9, R.T - 1)
+    mask_id = 65536
+    for s, u in enumerate(R.noise_stream()):
+        assert R.checksum(u) == gen['noise_checksum'][s]
+        if s not in steps:
+            continue
+        ids_in = gen['step_in_ids'][s].long()
+        with torch.no_grad():
+            logits = O.forward_with_cond_scale(sd, cfg, ids_in, inp['text_embeds'], 3.)
+            # (rows whose k-th largest logit has a duplicate exist at V = 65536 -- torch.topk's choice among them is implementation-defined --
+            #  but the lowest kept logit never wins the Gumbel argmax here: the resulting states below are bit-equal)
+            new_ids, scores, _ = O.sample_step(logits, O.gumbel_from_uniform(u), ids_in, mask_id, temps[s])
+        if s == R.T - 1:
+            assert torch.equal(new_ids.reshape(gen['final_ids'].shape), gen['final_ids'])
+        else:
+            assert not O.boundary_ties(scores, counts[s + 1]).any()
+            sel = O.select_topk_stable(scores, counts[s + 1])
+            nxt = torch.where(sel, torch.full_like(new_ids, mask_id), new_ids)
+            assert torch.equal(nxt, gen['step_in_ids'][s + 1].long()), f'state after step {s} differs'
+
+
+def test_oracle_vae_matches_reference_at_dim_256(golden):
+    import golden_recipe as R
+    import muse_maskgit_pytorch_amd as mm
+    g = golden('base_c2.pt')
+    vae = R.build_vae(mm.VQGanVAE).copy_for_eval()
+    assert R.state_checksum(vae) == g['vae_weight_checksum']
+    sd = sd_f32(vae.state_dict())
+    inp = R.inputs()
+    with torch.no_grad():
+        dec = O.vae_decode_from_ids(sd, inp['vae_ids'])
+        fmap, ids = O.vae_encode(sd, inp['image'])
+    v = g['vae']
+    close(dec[:, :, ::4, ::4], v['decoded_strided'], 2e-5); close(dec[:, :, 96:160, 96:160], v['decoded_crop'], 2e-5)
+    assert torch.equal(ids, v['enc_ids'])
+    close(fmap[:, ::16], v['enc_fmap_strided'], 2e-5)
