@@ -245,6 +245,44 @@ int mm_lfq_encode(mm_stream_t stream, const void* x, int64_t count, int C, int b
 int mm_nchw_f32_to_nhwc8_bf16(mm_stream_t stream, const float* img, int B, int C, int H, int W, void* out);
 int mm_nhwc_bf16_to_nchw_f32(mm_stream_t stream, const void* x, int B, int C, int H, int W, float* out);
 
+/* ------------------------------------------------------------------------------------------------ parity engine (fp32)
+ * Precision level L0: fp32 storage + fp32 MFMA (v_mfma_f32_32x32x2_f32), the reference's operator sequence one to one, no
+ * fusion that changes a rounding point.  This is what `set_precision('parity')` of the Python classes runs: logits / pixels within 1e-3
+ * of the reference's fp32 CPU run and bit-equal token ids at full size (tests/test_gpu_base_size.py).  All pointers fp32 unless noted. */
+
+/* nn.Linear: out[m][n] = sum_k x[m][k] * w[n][k] (+ bias[n]) (LeakyReLU(0.1) if act) (+ resid[m][n], same stride as out)  (mmp.py:85,88,118-124,233,332) */
+int mm_f32_gemm(mm_stream_t stream, const float* x, int64_t ldx, const float* w, int64_t ldw, int M, int N, int K, float* out, int64_t ldc,
+                const float* bias, int act, const float* resid);
+/* Conv2d / one parity class of ConvTranspose2d(4,2,1) as in mm_conv2d_nhwc, on NHWC fp32; w [Cout][TH*TW*Cin], k = (ty*TW+tx)*Cin+ci
+ * (vqgan_vae.py:224-232, 255-261, 271-277) */
+int mm_f32_conv2d_nhwc(mm_stream_t stream, const float* in, int B, int Hin, int Win, int Cin, const float* w, int Cout, int TH, int TW, int stride,
+                       int off_y, int off_x, int Hv, int Wv, int os, int py, int px, int Hout, int Wout, const float* bias, int act,
+                       const float* resid, float* out, int out_nchw);
+int mm_f32_layernorm(mm_stream_t stream, const float* x, int64_t ldx, int rows, int D, const float* gamma, const float* beta, float* out,
+                     int64_t ldo);                                                                              /* mmp.py:63-70 */
+/* GEGLU (mmp.py:72-77): h [rows][ldh] = [x half (F) | gate half (F)] -> out[r][c] = gate * gelu_erf(x) */
+int mm_f32_geglu(mm_stream_t stream, const float* h, int64_t ldh, int64_t rows, int F, float* out, int64_t ldo);
+/* out = null + (cond - null) * cond_scale  (mmp.py:254) */
+int mm_f32_cfg_combine(mm_stream_t stream, const float* cond, const float* null_, float cond_scale, int64_t n, float* out);
+/* x[row] = token_emb[ids[row]] + pos_emb[row % n] (mmp.py:322-323); pos_emb NULL = plain gather (condition ids, mmp.py:316) */
+int mm_f32_embed(mm_stream_t stream, const int64_t* ids, int64_t rows, int n, const float* token_emb, int vocab_rows, const float* pos_emb, int D,
+                 float* x, int64_t ldx);
+/* mask[row] = any(text_embeds[row] != 0)  (mmp.py:304) */
+int mm_f32_text_mask(mm_stream_t stream, const float* text_embeds, int64_t rows, int D, uint8_t* mask);
+/* mm_attend semantics (attend.py:109-140 + mmp.py:145-157) on fp32 operands, dim_head 64 */
+int mm_f32_attend(mm_stream_t stream, const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const float* k, int64_t k_sb, int64_t k_sh, int64_t k_sn,
+                  const float* v, int64_t v_sb, int64_t v_sh, int64_t v_sn, float* out, int64_t o_sb, int64_t o_sh, int64_t o_sn, int B, int H, int nq, int nk,
+                  const uint8_t* key_mask, int64_t km_sb, int normalize, const float* q_scale, const float* k_scale, const float* null_k,
+                  const float* null_v, float scale);
+int mm_f32_glu_nhwc(mm_stream_t stream, const float* x, int64_t rows, int C, float* out);
+int mm_f32_groupnorm_nhwc(mm_stream_t stream, const float* x, int B, int HW, int C, int groups, const float* gamma, const float* beta, int act,
+                          float* out);
+int mm_f32_lfq_decode(mm_stream_t stream, const int64_t* ids, int64_t count, int bits, int C, const float* w, const float* b, float* out);
+/* ids from the signs of the projected features t_in [count][bits] (LFQ.forward in eval mode, vqgan_vae.py:424) */
+int mm_f32_lfq_bits(mm_stream_t stream, const float* t_in, int64_t count, int bits, int64_t* ids);
+int mm_f32_nchw_to_nhwc(mm_stream_t stream, const float* in, int B, int C, int HW, float* out);
+int mm_f32_nhwc_to_nchw(mm_stream_t stream, const float* in, int B, int C, int HW, float* out);
+
 /* ------------------------------------------------------------------------------------------------ transformer */
 
 typedef struct mm_attn_weights {

@@ -95,6 +95,20 @@ SIGNATURES = {
     'mm_lfq_encode': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'mm_nchw_f32_to_nhwc8_bf16': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     'mm_nhwc_bf16_to_nchw_f32': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    'mm_f32_gemm': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_int, c_vp]),
+    'mm_f32_conv2d_nhwc': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int] + [c_int] * 12 + [c_vp, c_int, c_vp, c_vp, c_int]),
+    'mm_f32_layernorm': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_i64]),
+    'mm_f32_geglu': (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_i64]),
+    'mm_f32_cfg_combine': (c_int, [c_vp, c_vp, c_vp, c_f32, c_i64, c_vp]),
+    'mm_f32_embed': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_i64]),
+    'mm_f32_text_mask': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp]),
+    'mm_f32_attend': (c_int, [c_vp] + [c_vp, c_i64, c_i64, c_i64] * 4 + [c_int, c_int, c_int, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_f32]),
+    'mm_f32_glu_nhwc': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp]),
+    'mm_f32_groupnorm_nhwc': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp]),
+    'mm_f32_lfq_decode': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
+    'mm_f32_lfq_bits': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp]),
+    'mm_f32_nchw_to_nhwc': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    'mm_f32_nhwc_to_nchw': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     'mm_transformer_create': (c_int, [C.POINTER(TransformerDesc), C.POINTER(c_vp)]),
     'mm_transformer_destroy': (None, [c_vp]),
     'mm_context_workspace_bytes': (c_sz, [c_vp, c_int, c_int]),

@@ -17,6 +17,7 @@ from torch import nn
 
 from . import _lib as L
 from . import ops
+from . import parity as P32
 from .attend import Attend
 from .t5 import DEFAULT_T5_NAME, get_encoded_dim, t5_encode_text
 from .vqgan_vae import VQGanVAE
@@ -156,6 +157,7 @@ class Transformer(nn.Module):
         self.grad_sync = None          # optional parallel.GradBucketer: data-parallel gradient averaging inside the backward
         self.weight_format = 'bf16'    # 'fp8': W8A16 inference (BASELINE configs[4]), see quantize_weights_fp8()
         self._fp8 = None
+        self.precision = 'bf16'        # 'parity': fp32 storage + fp32 MFMA, the reference's operator sequence (set_precision)
 
     # ---- packing (once per parameter version / device)
     def _pack_ff(self, ff, keep):
@@ -256,6 +258,15 @@ class Transformer(nn.Module):
         self._handle, self._handle_key, self._fp8 = None, None, None
         return super().load_state_dict(*args, **kwargs)
 
+    def set_precision(self, precision):
+        """'bf16' (default): the production engine -- bf16 operands, fp32 accumulation / residual stream / logits.
+        'parity': precision level L0 -- fp32 storage and fp32 MFMA through the reference's exact operator sequence
+        (parity.py / csrc/parity.hip); logits within 1e-3 of the reference's fp32 run and bit-equal ids at full size.  Inference only."""
+        if precision not in ('bf16', 'parity'):
+            raise ValueError(f"precision must be 'bf16' or 'parity', got {precision!r}")
+        self.precision = precision
+        return self
+
     def _workspace(self, nbytes, device):
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
             # zero-filled once per (re)allocation: every buffer carved from it is written before it is read, but no result may ever
@@ -289,6 +300,7 @@ class Transformer(nn.Module):
     def _run(self, ids, ctx, mask, self_cond_embed=None, want_embed=True, want_logits=True):
         if self.weight_format == 'fp8':
             return self._run_fp8(ids, ctx, mask, self_cond_embed, want_embed, want_logits)
+        assert self.precision == 'bf16'
         h = self._model()
         dev = self.token_emb.weight.device
         ids = ids.to(device=dev, dtype=torch.long).contiguous()
@@ -403,6 +415,8 @@ class Transformer(nn.Module):
 
     def _cfg_logits(self, emb_a, emb_b, cond_scale):
         """to_logits on two passes + b + (a - b) * cond_scale as one GEMM (mmp.py:250-254, 332)."""
+        if self.precision == 'parity':
+            return P32.cfg_logits(self, emb_a, emb_b, cond_scale)
         if self.weight_format == 'fp8':
             wl = self._fp8_pack()['wl']
             return ops.gemm_w8a16(emb_a, wl[0], wl[1], x_null=emb_b, cond_scale=cond_scale)
@@ -449,6 +463,8 @@ class Transformer(nn.Module):
         if (exists(labels) and not return_logits and not return_embed and torch.is_grad_enabled() and self.to_logits.weight.requires_grad
                 and (self.dim_out == 1 or bool((labels != ignore_index).any()))):      # CE with all rows ignored: NaN like F.cross_entropy, nothing to differentiate
             assert exists(texts) ^ exists(text_embeds)
+            if self.precision == 'parity':
+                raise NotImplementedError("precision 'parity' is an inference / verification mode: train with set_precision('bf16')")
             if exists(texts):
                 text_embeds = self.encode_text(texts)
             from .training import transformer_loss
@@ -465,11 +481,19 @@ class Transformer(nn.Module):
         assert exists(texts) ^ exists(text_embeds)
         if exists(texts):
             text_embeds = self.encode_text(texts)
+        if self.precision == 'parity':
+            embed, logits = P32.transformer_run(self, x, text_embeds, cond_drop_prob, conditioning_token_ids, self_cond_embed, want_logits=not _embed_only)
+            if _embed_only:
+                return embed
+            return self._finish_forward(embed, logits, b, n, return_embed, return_logits, labels, ignore_index)
         ctx, mask = self._context(text_embeds, conditioning_token_ids, cond_drop_prob)
         if _embed_only:
             embed, _ = self._run(x, ctx, mask, self_cond_embed, want_embed=True, want_logits=False)
             return embed
         embed, logits = self._run(x, ctx, mask, self_cond_embed)
+        return self._finish_forward(embed, logits, b, n, return_embed, return_logits, labels, ignore_index)
+
+    def _finish_forward(self, embed, logits, b, n, return_embed, return_logits, labels, ignore_index):
         if return_embed:
             return logits.reshape(b, n, self.dim_out), embed.float().reshape(b, n, self.dim)
         if not exists(labels):
@@ -495,6 +519,8 @@ class SelfCritic(nn.Module):
 
     def _pred(self, embeds):
         b, n, d = embeds.shape
+        if self.net.precision == 'parity':
+            return P32.linear_head(embeds.reshape(b * n, d).float().contiguous(), self.to_pred).reshape(b, n, 1)
         w = ops.pad_cols(self.to_pred.weight.detach().to(bf16), 64)                    # [1, D] as a 1x1 conv weight
         x = embeds.reshape(b * n, 1, 1, d).to(bf16).contiguous()
         out = ops.conv2d_nhwc(x, w, 1, 1, 1, 1, (0, 0), bias=self.to_pred.bias.detach().float().contiguous(), out_nchw_f32=True)
@@ -584,6 +610,16 @@ class MaskGit(nn.Module):
         assert path.exists()
         self.load_state_dict(torch.load(str(path)))
 
+    def set_precision(self, precision):
+        """'bf16' | 'parity' for the transformer, the token critic and both VAEs (see Transformer.set_precision)."""
+        self.transformer.set_precision(precision)
+        if isinstance(self.token_critic, Transformer):
+            self.token_critic.set_precision(precision)
+        for v in (self.vae, self.cond_vae):
+            if exists(v):
+                v.set_precision(precision)
+        return self
+
     def _mask_counts(self, timesteps, seq_len, device='cpu'):
         """mmp.py:556-559 with the user's noise_schedule, evaluated up front instead of one host sync per step."""
         out = []
@@ -610,7 +646,7 @@ class MaskGit(nn.Module):
         if exists(negative_texts) or exists(neg_text_embeds):
             assert exists(neg_text_embeds) or len(texts) == len(negative_texts)       # mmp.py:541
         if (exists(negative_texts) or exists(neg_text_embeds) or use_token_critic or can_remask_prev_masked or self.self_cond or cond_scale == 1
-                or tr.weight_format == 'fp8'):
+                or tr.weight_format == 'fp8' or tr.precision == 'parity'):
             # decode variants that need logits / scores at EVERY position: stepwise loop over the same C-ABI operators
             return self._generate_stepwise(texts, cond_images, fmap_size, temperature, topk_filter_thres, can_remask_prev_masked,
                                            use_token_critic, timesteps, cond_scale, critic_noise_scale, text_embeds, noise, noise_kind,
@@ -706,6 +742,8 @@ class MaskGit(nn.Module):
         self_cond_embed = None
         for step in range(timesteps):
             ops.mask_step(scores, ids, counts[step], self.mask_id, want_rows=False)                  # mmp.py:558-563
+            if trace is not None:
+                trace.setdefault('masked_ids', []).append(ids.clone())
             is_mask = ids == self.mask_id
             if exists(nte):
                 logits, embed = tr.forward_with_neg_prompt(ids, te, nte, cond_scale=cond_scale, return_embed=True, self_cond_embed=self_cond_embed,

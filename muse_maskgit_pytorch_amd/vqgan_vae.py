@@ -168,6 +168,7 @@ class VQGanVAE(nn.Module):
             dims = (dim, *[dim * 2 ** t for t in range(discr_layers)])
             self.discr = Discriminator(dims=dims, channels=channels)
         self._packed = None
+        self.precision = 'bf16'        # 'parity': fp32 storage + fp32 MFMA (set_precision)
 
     # ---- reference surface
     @property
@@ -199,6 +200,14 @@ class VQGanVAE(nn.Module):
         path = Path(path)
         assert path.exists()
         self.load_state_dict(torch.load(str(path)))
+
+    def set_precision(self, precision):
+        """'bf16' (default): NHWC bf16 activations, bf16 MFMA convolutions.  'parity': NHWC fp32 activations, fp32 MFMA convolutions, the
+        reference's layer sequence one to one (parity.py / csrc/parity.hip) -- pixels within 1e-3 and LFQ ids equal to the fp32 reference."""
+        if precision not in ('bf16', 'parity'):
+            raise ValueError(f"precision must be 'bf16' or 'parity', got {precision!r}")
+        self.precision = precision
+        return self
 
     # ---- packed (bf16, kernel layout) weights, rebuilt when parameters change
     def _pack_key(self):
@@ -306,6 +315,9 @@ class VQGanVAE(nn.Module):
     @torch.no_grad()
     def encode(self, fmap):
         """vqgan_vae.py:422-425: image (B,C,H,W) fp32 -> (quantized fmap (B,C',h,w) fp32, ids (B,h,w) int64, aux loss 0)."""
+        if self.precision == 'parity' and self.lookup_free_quantization:
+            from . import parity
+            return parity.vae_encode(self, fmap)
         P = self._pack()
         x = ops.nchw_to_nhwc8(fmap)
         for e in P['enc']:                                            # ResnetEncDec.encode (vqgan_vae.py:241-244), in list order
@@ -327,6 +339,9 @@ class VQGanVAE(nn.Module):
     @torch.no_grad()
     def decode_from_ids(self, ids):
         """vqgan_vae.py:427-438: ids (B,h,w) int64 -> image (B,C,H,W) fp32 (unclamped)."""
+        if self.precision == 'parity' and self.lookup_free_quantization:
+            from . import parity
+            return parity.vae_decode_from_ids(self, ids)
         P = self._pack()
         if not self.lookup_free_quantization:
             return self._decode_nhwc(self.quantizer.codes_nhwc(ids.to(self.device)))
@@ -337,6 +352,9 @@ class VQGanVAE(nn.Module):
     @torch.no_grad()
     def decode(self, fmap):
         """vqgan_vae.py:440-441: fmap (B,C,h,w) fp32 -> image."""
+        if self.precision == 'parity':
+            from . import parity
+            return parity.vae_decode(self, fmap)
         x = fmap.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
         return self._decode_nhwc(x)
 

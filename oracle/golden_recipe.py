@@ -62,10 +62,11 @@ def noise_stream(steps=T):
 
 
 def checksum(t):
-    """order-sensitive fp64 checksum of a tensor (weights / noise reproduction check)"""
-    f = t.detach().double().flatten()
-    w = torch.arange(1, f.numel() + 1, dtype=torch.float64).remainder(1009.0) + 1.0
-    return float((f * w).sum())
+    """order-sensitive EXACT checksum of a tensor's fp32 bit patterns (weights / inputs / noise reproduction check): integer arithmetic, so it
+    does not depend on the summation order of the host's reduction kernels (an fp64 sum differed in the last digit between two CPUs)"""
+    bits = t.detach().to(torch.float32).cpu().contiguous().view(torch.int32).flatten().to(torch.int64)
+    w = torch.arange(1, bits.numel() + 1, dtype=torch.int64).remainder(1009) + 1
+    return int((bits * w).sum().item())
 
 
 def state_checksum(module):

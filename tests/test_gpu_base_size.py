@@ -1,0 +1,159 @@
+"""BASELINE configs[1] AT FULL SIZE against the reference: dim 512, depth 8, 65536-entry codebook, 256 tokens, VQGanVAE(dim=256), B = 2,
+18 decode steps.  tests/golden/base_c2.pt was recorded from the UNMODIFIED reference (oracle/make_golden_base.py); checkpoint and noise are
+rebuilt from the seeded recipe (oracle/golden_recipe.py) and their checksums asserted first.
+
+Two engines are compared with the same fixture:
+  precision 'parity' -- fp32 storage + fp32 MFMA (csrc/parity.hip): the north star's bar, logits / pixels within 1e-3 absolute, ids 100 %.
+  precision 'bf16'   -- the production engine: bounds are what bf16 operands achieve at this size (stated per assert), ids compared
+                        through the oracle tail on the engine's own logits (bit-exact) and, informationally, with the reference run.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import golden_recipe as R
+import muse_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+FULL_ROWS = [0, 77, 255, 256, 300, 301, 448, 511]
+PRECISIONS = ['parity', 'bf16']
+
+
+@pytest.fixture(scope='module')
+def base(golden):
+    import muse_maskgit_pytorch_amd as mm
+    g = golden('base_c2.pt')
+    tr = R.build_transformer(mm.MaskGitTransformer, peaky=False)
+    assert R.state_checksum(tr) == g['weight_checksum'], 'the seeded recipe did not reproduce the reference checkpoint'
+    vae = R.build_vae(mm.VQGanVAE)
+    mg = mm.MaskGit(vae=vae, transformer=tr, image_size=256).to(DEV).eval()
+    assert R.state_checksum(mg.vae) == g['vae_weight_checksum']
+    inp = R.inputs()
+    assert {k: R.checksum(v.float()) for k, v in inp.items()} == g['input_checksum']
+    return g, mg, inp
+
+
+@pytest.fixture(scope='module')
+def noise(golden):
+    g = golden('base_c2.pt')
+    us = []
+    for s, u in enumerate(R.noise_stream()):
+        assert R.checksum(u) == g['generate']['noise_checksum'][s], f'noise recipe does not reproduce step {s}'
+        us.append(u)
+    return torch.stack(us)          # [T, B, n, V] uniforms, 2.4 GB
+
+
+def _err(name, got, ref, abs_tol):
+    d = (got.float().cpu() - ref).abs()
+    print(f'[base-size parity] {name}: max abs err {d.max().item():.3g}, mean {d.mean().item():.3g} (reference absmax {ref.abs().max().item():.3g}); bound {abs_tol:g}')
+    assert d.max().item() <= abs_tol, f'{name}: {d.max().item()} > {abs_tol}'
+
+
+def _samples(logits):
+    f = logits.reshape(R.B * R.N, -1)
+    return f[FULL_ROWS], f[:, ::128]
+
+
+@pytest.mark.parametrize('precision', PRECISIONS)
+def test_transformer_forward_logits_at_base_size(base, precision):
+    """Transformer.forward (mmp.py:279-335) and forward_with_cond_scale (:240-259): logits of 8 full rows + every 128th vocabulary column of
+    all 512 rows, and the final-LayerNorm embed, against the reference's fp32 run.  Random-init logits are unit scale (std 0.59, |max| 3.2),
+    so the absolute bound IS the north star's 1e-3 for the parity engine; the bf16 engine's bound is what 8 layers of bf16 operands give."""
+    g, mg, inp = base
+    tr = mg.transformer.set_precision(precision)
+    try:
+        ids, te = inp['ids'].to(DEV), inp['text_embeds'].to(DEV)
+        lc, emb = tr(ids, text_embeds=te, cond_drop_prob=0., return_embed=True)
+        ln = tr(ids, text_embeds=te, cond_drop_prob=1.)
+        sc = tr.forward_with_cond_scale(ids, text_embeds=te, cond_scale=3.)
+    finally:
+        tr.set_precision('bf16')
+    fw = g['forward']
+    tol = 1e-3 if precision == 'parity' else 2.5e-2
+    for name, got, rec in (('logits(cond)', lc, fw['logits_cond']), ('logits(null)', ln, fw['logits_null'])):
+        rows, cols = _samples(got)
+        _err(f'{precision} {name} full rows', rows, rec['rows'], tol)
+        _err(f'{precision} {name} strided columns', cols, rec['cols'], tol)
+    rows, cols = _samples(sc)
+    _err(f'{precision} logits(guidance 3.0) full rows', rows, fw['logits_scaled']['rows'], tol * 5)      # null + 3 (cond - null): errors add up to 5x
+    _err(f'{precision} logits(guidance 3.0) strided columns', cols, fw['logits_scaled']['cols'], tol * 5)
+    _err(f'{precision} embed', emb.reshape(R.B, R.N, -1), fw['embed'], 1e-3 if precision == 'parity' else 4e-2)
+
+
+@pytest.mark.parametrize('precision', PRECISIONS)
+def test_generate_at_base_size_against_the_reference_run(base, noise, precision):
+    """MaskGit.generate (mmp.py:491-621), 18 steps, the reference's own noise, peaky logits.  parity: every step's re-masked ids and the final
+    ids equal the reference's.  bf16: the fused engine (logits only at masked rows, constant null cross-attention, compacted last layer) is
+    checked bit-exactly at V = 65536 through the oracle tail fed with the GENERAL path's logits on the engine's own states (three steps),
+    and its agreement with the fp32 reference trajectory is reported (bf16 operands may flip a near-tie; the run then follows another path)."""
+    g, mg, inp = base
+    gen = g['generate']
+    tr = mg.transformer
+    te = inp['text_embeds'].to(DEV)
+    with torch.no_grad():
+        tr.to_logits.weight.mul_(R.PEAK)
+    mg.set_precision(precision)
+    try:
+        assert R.state_checksum(tr) == g['weight_checksum_peaky']
+        trace = {}
+        u = noise.to(DEV)
+        ids = mg.generate(['a', 'b'], timesteps=R.T, cond_scale=3., text_embeds=te, noise=u, noise_kind='uniform', return_ids=True, trace=trace)
+        masked = torch.stack(list(trace['masked_ids'])).cpu() if isinstance(trace['masked_ids'], list) else trace['masked_ids'].cpu()
+        ref_in = gen['step_in_ids'].long()
+        agree_steps = [(masked[s] == ref_in[s]).float().mean().item() for s in range(R.T)]
+        final_agree = (ids.cpu().reshape(gen['final_ids'].shape) == gen['final_ids']).float().mean().item()
+        print(f'[base-size parity] {precision} generate: final ids equal to the reference run: {100 * final_agree:.2f} %; per-step state agreement min '
+              f'{100 * min(agree_steps):.2f} % (step {agree_steps.index(min(agree_steps))})')
+        if precision == 'parity':
+            assert min(agree_steps) == 1.0 and final_agree == 1.0
+        else:
+            assert final_agree >= 0.90
+            # the fused engine against the general path + oracle tail at full vocabulary, on its own states
+            counts, temps = O.mask_counts(R.T, R.N), O.step_temperatures(R.T, 1.)
+            st_ids = trace['ids'].cpu()
+            for s in (0, 7, R.T - 1):
+                ids_in = masked[s]
+                logits = tr.forward_with_cond_scale(ids_in.to(DEV), text_embeds=te, cond_scale=3.).cpu()
+                new_ids, scores, _ = O.sample_step(logits, O.gumbel_from_uniform(noise[s]), ids_in, 65536, temps[s])
+                assert torch.equal(new_ids, st_ids[s]), f'bf16 fused engine vs general path + oracle tail: ids after step {s} differ in {(new_ids != st_ids[s]).sum().item()} places'
+        del u
+    finally:
+        mg.set_precision('bf16')
+        with torch.no_grad():
+            tr.to_logits.weight.div_(R.PEAK)
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('precision', PRECISIONS)
+def test_vqgan_vae_dim_256_against_the_reference(base, precision):
+    """VQGanVAE(dim=256) decode_from_ids / encode (vqgan_vae.py:422-441), the VAE the bench decodes with.  Pixels: 1e-3 of the image scale
+    (|max| 0.063 at random init) for the parity engine.  LFQ ids: a bit is the SIGN of a projection, so ids are compared where the reference's
+    own pre-sign value clears the engine's error band (all 16 bits of the position), and the fraction of positions covered is reported."""
+    g, mg, inp = base
+    v = g['vae']
+    vae = mg.vae.set_precision(precision)
+    try:
+        dec = vae.decode_from_ids(inp['vae_ids'].to(DEV))
+        fmap, ids, _ = vae.encode(inp['image'].to(DEV))
+    finally:
+        vae.set_precision('bf16')
+    scale = v['decoded_absmax']
+    tol = (1e-3 if precision == 'parity' else 8e-3) * scale
+    _err(f'{precision} decoded pixels (strided)', dec[:, :, ::4, ::4], v['decoded_strided'], tol)
+    _err(f'{precision} decoded pixels (64x64 crop)', dec[:, :, 96:160, 96:160], v['decoded_crop'], tol)
+    pre = v['enc_pre_sign']                                   # (B, 256, 16): the reference's values whose signs are the id bits
+    band = (2e-5 if precision == 'parity' else 2e-2) * pre.abs().max().item()
+    safe = (pre.abs() > band).all(dim=-1)                     # positions whose 16 bits are all outside the band
+    same = ids.cpu().reshape(R.B, -1) == v['enc_ids'].reshape(R.B, -1)
+    print(f'[base-size parity] {precision} LFQ encode: {100 * same.float().mean().item():.2f} % of ids equal the reference; '
+          f'{100 * safe.float().mean().item():.1f} % of positions have every pre-sign value outside +-{band:.3g}')
+    assert bool(same[safe].all()), f'{(~same[safe]).sum().item()} ids differ at positions whose bits are all outside the error band'
+    if precision == 'parity':
+        assert safe.float().mean().item() > 0.95 and same.float().mean().item() > 0.99
+    d = (fmap[:, ::16].float().cpu() - v['enc_fmap_strided']).abs().amax(dim=1)          # (B, 16, 16): project_out(+-1 codes) of equal ids is the same sum
+    assert d[same.reshape(R.B, 16, 16)].max().item() <= (1e-5 if precision == 'parity' else 2e-2)

@@ -716,3 +716,45 @@ def test_fp8_weight_mode_vs_fake_quant_oracle(golden):
     finally:
         t.quantize_weights_fp8(False)
     assert torch.equal(t(g['ids'].to(DEV), text_embeds=te.to(DEV)), bf)
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'parity'])
+def test_muse_cascade_base_to_superres(precision):
+    """Muse.forward (mmp.py:758-791): base.generate -> images -> superres.generate(cond_images = those images).  The cascade must equal
+    its two stages run by hand with the same seeds, and the super-resolution stage's ids are checked against the oracle tail fed with
+    the HIP transformer's logits (condition ids from the low-res VAE in the cross-attention context, visible in the null pass too)."""
+    torch.manual_seed(0)
+    vae_lo = mm.VQGanVAE(dim=16, codebook_size=512)
+    vae_hi = mm.VQGanVAE(dim=16, codebook_size=512)
+    base_tr = mm.MaskGitTransformer(num_tokens=512, seq_len=16, dim=128, depth=2, dim_head=64, heads=8, t5_name='t5-small')
+    sr_tr = mm.MaskGitTransformer(num_tokens=512, seq_len=64, dim=128, depth=2, dim_head=64, heads=8, t5_name='t5-small')
+    with torch.no_grad():
+        base_tr.to_logits.weight.mul_(8.); sr_tr.to_logits.weight.mul_(8.)
+    base = mm.MaskGit(vae=vae_lo, transformer=base_tr, image_size=64).to(DEV)
+    sr = mm.MaskGit(vae=vae_hi, cond_vae=vae_lo, transformer=sr_tr, image_size=128, cond_image_size=64).to(DEV)
+    base.set_precision(precision); sr.set_precision(precision)
+    te = torch.randn(2, 6, 512)
+    te[0, 4:] = 0
+    for tr_ in (base_tr, sr_tr):
+        tr_.encode_text = lambda texts, te=te: te          # per-instance attribute, as reference users override it (mmp.py:229)
+    muse = mm.Muse(base=base, superres=sr)
+    torch.manual_seed(11)
+    hi, lo = muse(['a', 'b'], timesteps=5, superres_timesteps=4, return_lowres=True, return_pil_images=False)
+    assert lo.shape == (2, 3, 64, 64) and hi.shape == (2, 3, 128, 128) and torch.isfinite(hi).all()
+    # the same two stages by hand (generate draws its Philox seed from torch's generator when none is given)
+    torch.manual_seed(11)
+    lo2 = base.generate(['a', 'b'], timesteps=5, cond_scale=3.)
+    hi2 = sr.generate(['a', 'b'], timesteps=4, cond_scale=3., cond_images=lo2)
+    assert torch.equal(lo, lo2) and torch.equal(hi, hi2)
+    # super-res ids against the oracle tail on the HIP logits, injected noise
+    _, cids, _ = sr.cond_vae.encode(lo)
+    assert cids.shape == (2, 4, 4)
+    T, B, n, V = 4, 2, 64, 512
+    uni = torch.rand(T, B, n, V, generator=torch.Generator().manual_seed(3))
+    got = sr.generate(['a', 'b'], timesteps=T, cond_images=lo, noise=uni, noise_kind='uniform', return_ids=True).reshape(B, n).cpu()
+
+    def demask(ids, step):
+        return sr_tr.forward_with_cond_scale(ids.to(DEV), text_embeds=te.to(DEV), conditioning_token_ids=cids, cond_scale=3.).cpu()
+
+    ref = O.generate_ids(demask, B, n, 512, lambda s, shp: O.gumbel_from_uniform(uni[s]), timesteps=T)
+    assert torch.equal(got, ref), 'super-resolution decode loop differs from the oracle tail on the same logits'
