@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 1
+#define MM_ABI_VERSION 2
 
 #define MM_OK 0
 #define MM_ERR_SHAPE (-1)
@@ -113,6 +113,31 @@ int mm_sample_rows(mm_stream_t stream, const float* logits, int64_t ld, int R, i
                    const int32_t* rows, float temperature, int noise_kind, const float* noise, int64_t noise_ld,
                    uint64_t seed, uint64_t row_offset, uint32_t step, int64_t* ids, float* scores,
                    int64_t* pred_out, float* score_out);
+
+/* ---- sampling without the logits round trip (csrc/sampling_fused.hip; mmp.py:576-609, SURVEY.md 8d "fused floor").
+ * The guidance-logits GEMM emits, per token row and 256-column tile, {max, sum exp, mask of kept lanes} and the values of every lane (4
+ * consecutive columns) whose largest value reaches thr_lo[row], instead of the logits; mm_fused_sample finishes the row (exact k-th
+ * largest, Gumbel argmax, confidence) from those.  Buffers, caller-owned: stats 16 B x [R][V/256]; cand 16 B x [R][V/256][MM_FUSED_SLOT];
+ * fail_flag int32 [1] (zero it; set to 1 if some row's candidates could not be proven to contain its kept set -- then repeat on the
+ * logits path, mm_gemm_cfg_logits + mm_sample_rows).  V % 256 == 0.
+ *   mm_fused_threshold : thr_lo[r] = mean_r + z sigma_r of row r's logits over the vocabulary, from the row's embeddings (bf16 cond / null,
+ *                        combined with cond_scale) and the vocabulary statistics of to_logits (wmean fp32 [D], wcov bf16 [D][D], D % 64 == 0);
+ *                        z = mm_fused_z(k_keep, V, margin) (normal quantile of the kept fraction minus a safety margin in sigmas);
+ *                        ws: mm_fused_threshold_workspace_bytes(R, D) bytes of scratch
+ *   mm_gemm_cfg_logits_fused : mm_gemm_cfg_logits whose epilogue emits stats / cand instead of writing the logits
+ *   mm_fused_emit      : the same emission from materialised logits (tests; shapes the 256-column GEMM does not take)
+ *   mm_fused_sample    : the finishing kernel; remaining arguments as in mm_sample_rows */
+#define MM_FUSED_SLOT 64
+float mm_fused_z(int k_keep, int V, float margin);
+size_t mm_fused_threshold_workspace_bytes(int R, int D);
+int mm_fused_threshold(mm_stream_t stream, const void* emb_cond, const void* emb_null, int64_t ld, int R, int D, float cond_scale, const float* wmean,
+                       const void* wcov, float z, void* ws, float* thr);
+int mm_gemm_cfg_logits_fused(mm_stream_t stream, const void* x_cond, const void* x_null, int64_t ldx, const void* w, int64_t ldw, int M, int N, int K,
+                             float cond_scale, const float* thr, void* stats, void* cand);
+int mm_fused_emit(mm_stream_t stream, const float* logits, int64_t ld, int R, int V, const float* thr, void* stats, void* cand);
+int mm_fused_sample(mm_stream_t stream, const float* thr, const void* stats, const void* cand, int R, int V, int k_keep, const int32_t* rows,
+                    float temperature, int noise_kind, const float* noise, int64_t noise_ld, uint64_t seed, uint64_t row_offset, uint32_t step,
+                    int64_t* ids, float* scores, int64_t* pred_out, float* score_out, int32_t* fail_flag);
 
 /* Training-forward losses of Transformer.forward (mmp.py:337-348), forward only:
  *   mm_ce_loss : F.cross_entropy over the vocabulary with ignore_index, mean over the non-ignored rows; logits fp32 [R][ld],
@@ -330,6 +355,10 @@ typedef struct mm_transformer_desc {
     const float* final_beta;
     const void* to_logits;          /* bf16 [dim_out][D]                                                     */
     mm_ff_weights self_cond_ff;     /* self_cond_to_init_embed (used only when self_cond != 0)               */
+    /* optional (both or none): statistics of to_logits over the vocabulary -- mean of its rows (fp32 [D]) and their covariance (bf16 [D][D]).  With them
+     * mm_generate samples without materialising the logits (mm_fused_*): a row's k-th largest logit is bounded from the row's embedding. */
+    const float* logits_wmean;
+    const void* logits_wcov;
 } mm_transformer_desc;
 
 typedef struct mm_transformer mm_transformer_t;
@@ -360,8 +389,9 @@ int mm_transformer_forward(const mm_transformer_t* model, mm_stream_t stream, co
  * left)/T, 1e-10)).  noise (GUMBEL/UNIFORM modes): fp32 [timesteps][B][n][V].  Outputs: ids int64 [B][n],
  * scores fp32 [B][n].  Optional traces [timesteps][B][n]: trace_masked_ids (ids after the re-mask scatter),
  * trace_ids / trace_scores (state after each step). */
+#define MM_GEN_NO_FUSED_SAMPLING 1   /* flags: always materialise the logits (mm_gemm_cfg_logits + mm_sample_rows) */
 typedef struct mm_generate_params {
-    int32_t batch, n, timesteps, k_keep, noise_kind, nc, L, reserved;
+    int32_t batch, n, timesteps, k_keep, noise_kind, nc, L, flags;
     float cond_scale;
     float pad0;
     uint64_t seed, row_offset;
@@ -375,6 +405,10 @@ typedef struct mm_generate_params {
     int64_t* trace_masked_ids;
     int64_t* trace_ids;
     float* trace_scores;
+    /* device int32 [1], zeroed by the caller, or NULL (= no fused sampling).  Fused sampling bounds every row's k-th largest logit BEFORE the
+     * logits exist; the finishing kernel verifies the bound per row and sets *status = 1 when a row's candidates cannot be proven to contain
+     * its kept set (heavy-tailed logits).  The ids of that call are then invalid: repeat it with MM_GEN_NO_FUSED_SAMPLING. */
+    int32_t* status;
 } mm_generate_params;
 
 size_t mm_generate_workspace_bytes(const mm_transformer_t* model, int B, int n, int L, int nc);

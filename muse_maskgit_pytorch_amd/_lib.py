@@ -13,6 +13,7 @@ HEADER_PATH = os.path.join(HERE, '..', 'include', 'muse_hip.h')
 
 MM_OK = 0
 MM_NOISE_NONE, MM_NOISE_GUMBEL, MM_NOISE_UNIFORM, MM_NOISE_PHILOX = 0, 1, 2, 3
+MM_GEN_NO_FUSED_SAMPLING = 1
 
 c_i64, c_int, c_f32, c_vp, c_u64, c_u32, c_sz = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_uint64, C.c_uint32, C.c_size_t
 
@@ -37,15 +38,15 @@ class TransformerDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('dim', 'depth', 'heads', 'dim_head', 'ff_inner', 'ff_inner_padded', 'seq_len',
                                          'num_tokens', 'vocab_rows', 'dim_out', 'text_dim', 'self_cond')] + \
                [('token_emb', c_vp), ('pos_emb', c_vp), ('text_proj', c_vp), ('layers', C.POINTER(LayerWeights)),
-                ('final_gamma', c_vp), ('final_beta', c_vp), ('to_logits', c_vp), ('self_cond_ff', FFWeights)]
+                ('final_gamma', c_vp), ('final_beta', c_vp), ('to_logits', c_vp), ('self_cond_ff', FFWeights), ('logits_wmean', c_vp), ('logits_wcov', c_vp)]
 
 
 class GenerateParams(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ('batch', 'n', 'timesteps', 'k_keep', 'noise_kind', 'nc', 'L', 'reserved')] + \
+    _fields_ = [(n, C.c_int32) for n in ('batch', 'n', 'timesteps', 'k_keep', 'noise_kind', 'nc', 'L', 'flags')] + \
                [('cond_scale', c_f32), ('pad0', c_f32), ('seed', c_u64), ('row_offset', c_u64),
                 ('mask_counts', C.POINTER(C.c_int32)), ('temperatures', C.POINTER(c_f32)),
                 ('text_embeds', c_vp), ('cond_ids', c_vp), ('noise', c_vp), ('ids', c_vp), ('scores', c_vp),
-                ('trace_masked_ids', c_vp), ('trace_ids', c_vp), ('trace_scores', c_vp)]
+                ('trace_masked_ids', c_vp), ('trace_ids', c_vp), ('trace_scores', c_vp), ('status', c_vp)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/muse_hip.h must appear here (tests check both ways)
@@ -65,6 +66,12 @@ SIGNATURES = {
     'mm_mask_step': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_i64, c_vp]),
     'mm_sample_rows': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_f32, c_int, c_vp, c_i64, c_u64, c_u64,
                                c_u32, c_vp, c_vp, c_vp, c_vp]),
+    'mm_fused_z': (c_f32, [c_int, c_int, c_f32]),
+    'mm_fused_threshold_workspace_bytes': (c_sz, [c_int, c_int]),
+    'mm_fused_threshold': (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_f32, c_vp, c_vp, c_f32, c_vp, c_vp]),
+    'mm_gemm_cfg_logits_fused': (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_f32, c_vp, c_vp, c_vp]),
+    'mm_fused_emit': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
+    'mm_fused_sample': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_f32, c_int, c_vp, c_i64, c_u64, c_u64, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'mm_ce_loss': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_i64, c_vp, c_vp]),
     'mm_bce_loss': (c_int, [c_vp, c_vp, c_vp, c_int, c_vp]),
     'mm_quantize_e4m3_rows': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp]),
@@ -147,7 +154,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.mm_abi_version() != 1:
+        if l.mm_abi_version() != 2:
             raise MuseHipError('libmuse_hip ABI version mismatch')
         if os.environ.get('MM_DEBUG'):      # tools / A-B runs only: kernel-selection bits (see muse_hip_internal.h)
             l.mm_debug_set(int(os.environ['MM_DEBUG'], 0))

@@ -79,6 +79,54 @@ int mm_gemm_cfg_logits(mm_stream_t stream, const void* x_cond, const void* x_nul
     return mm_gemm_launch(a, (hipStream_t)stream);
 }
 
+float mm_fused_z(int k_keep, int V, float margin) { return k_fused_z(k_keep, V, margin); }
+size_t mm_fused_threshold_workspace_bytes(int R, int D) { return k_fused_threshold_ws_bytes(R, D); }
+
+int mm_fused_threshold(mm_stream_t stream, const void* emb_cond, const void* emb_null, int64_t ld, int R, int D, float cond_scale, const float* wmean,
+                       const void* wcov, float z, void* ws, float* thr) {
+    if (R == 0) return MM_OK;
+    CHK_PTR(emb_cond, "emb_cond"); CHK_PTR(emb_null, "emb_null"); CHK_PTR(wmean, "wmean"); CHK_PTR(wcov, "wcov"); CHK_PTR(ws, "ws"); CHK_PTR(thr, "thr");
+    CHK_ALIGN16(wcov, "wcov"); CHK_ALIGN16(ws, "ws");
+    return k_fused_threshold((hipStream_t)stream, (const bf16_t*)emb_cond, (const bf16_t*)emb_null, (long)ld, R, D, cond_scale, wmean, (const bf16_t*)wcov, z, ws, thr);
+}
+
+int mm_gemm_cfg_logits_fused(mm_stream_t stream, const void* x_cond, const void* x_null, int64_t ldx, const void* w, int64_t ldw, int M, int N, int K,
+                             float cond_scale, const float* thr, void* stats, void* cand) {
+    if (M == 0 || N == 0) return MM_OK;
+    CHK_PTR(x_cond, "x_cond"); CHK_PTR(x_null, "x_null"); CHK_PTR(w, "w"); CHK_PTR(thr, "thr"); CHK_PTR(stats, "stats"); CHK_PTR(cand, "cand");
+    CHK_ALIGN16(x_cond, "x_cond"); CHK_ALIGN16(x_null, "x_null"); CHK_ALIGN16(w, "w"); CHK_ALIGN16(stats, "stats"); CHK_ALIGN16(cand, "cand");
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mode = MODE_CFG;
+    a.W = (const bf16_t*)w; a.N = N; a.ldw = (int)ldw; a.K = K;
+    a.M = M; a.X = (const bf16_t*)x_cond; a.X2 = (const bf16_t*)x_null; a.ldx = (int)ldx;
+    a.out = nullptr; a.ldc = N; a.out_kind = OUT_F32; a.cfg_scale = cond_scale;
+    a.fs_thr = thr; a.fs_stats = (float4*)stats; a.fs_cand = (float4*)cand;
+    return mm_gemm_launch(a, (hipStream_t)stream);
+}
+
+int mm_fused_emit(mm_stream_t stream, const float* logits, int64_t ld, int R, int V, const float* thr, void* stats, void* cand) {
+    if (R == 0) return MM_OK;
+    CHK_PTR(logits, "logits"); CHK_PTR(thr, "thr"); CHK_PTR(stats, "stats"); CHK_PTR(cand, "cand");
+    CHK_ALIGN16(logits, "logits"); CHK_ALIGN16(stats, "stats"); CHK_ALIGN16(cand, "cand");
+    if (ld % 4) return mm_set_error(MM_ERR_ALIGN, "fused_emit: ld must be a multiple of 4");
+    return k_fused_emit((hipStream_t)stream, logits, (long)ld, R, V, thr, (float4*)stats, (float4*)cand);
+}
+
+int mm_fused_sample(mm_stream_t stream, const float* thr, const void* stats, const void* cand, int R, int V, int k_keep, const int32_t* rows,
+                    float temperature, int noise_kind, const float* noise, int64_t noise_ld, uint64_t seed, uint64_t row_offset, uint32_t step,
+                    int64_t* ids, float* scores, int64_t* pred_out, float* score_out, int32_t* fail_flag) {
+    if (R == 0) return MM_OK;
+    CHK_PTR(thr, "thr"); CHK_PTR(stats, "stats"); CHK_PTR(cand, "cand"); CHK_PTR(fail_flag, "fail_flag");
+    FusedSampleArgs a;
+    memset(&a, 0, sizeof(a));
+    a.thr = thr; a.stats = (const float4*)stats; a.cand = (const float4*)cand;
+    a.R = R; a.V = V; a.k_keep = k_keep; a.rows = rows; a.temperature = temperature; a.noise_kind = noise_kind; a.noise = noise; a.noise_ld = (long)noise_ld;
+    a.seed = seed; a.row_offset = row_offset; a.step = step; a.ids = ids; a.scores = scores; a.pred_out = pred_out; a.score_out = score_out;
+    a.fail_flag = fail_flag;
+    return k_sample_fused((hipStream_t)stream, a);
+}
+
 int mm_embed(mm_stream_t stream, const int64_t* ids, int rows, int n, const void* token_emb, int vocab_rows,
              const void* pos_emb, int dim, float* x) {
     if (rows == 0) return MM_OK;

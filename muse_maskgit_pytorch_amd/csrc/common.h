@@ -132,6 +132,40 @@ __device__ __forceinline__ int wave_sum_i(int v) {
     return v;
 }
 
+// 16-lane-row reductions on DPP (no LDS crossbar traffic) + 4 readlanes across the rows: every lane ends up with the wave's value.  Fixed order
+// -> deterministic.  Used where a reduction rides inside an LDS-issue-bound k-loop (the fused-sampling emission of gemm_cfg.hip).
+#define MM_DPP_F(x_, ctrl_) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x_), ctrl_, 0xF, 0xF, true))
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    v = fmaxf(v, MM_DPP_F(v, 0xB1)); v = fmaxf(v, MM_DPP_F(v, 0x4E)); v = fmaxf(v, MM_DPP_F(v, 0x141)); v = fmaxf(v, MM_DPP_F(v, 0x140));
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += MM_DPP_F(v, 0xB1); v += MM_DPP_F(v, 0x4E); v += MM_DPP_F(v, 0x141); v += MM_DPP_F(v, 0x140);
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (a + b) + (c + d);
+}
+#undef MM_DPP_F
+
+// Fused sampling (sampling_fused.hip): what leaves the guidance-logits GEMM instead of the logits.  One 256-column piece of a logits row is
+// held by a wave as 4 consecutive values per lane (lane l: columns 4l .. 4l+3 of the tile).  A lane whose largest value reaches thr keeps its
+// four values: the kept lanes' float4s are stored lane-compacted into the tile's slot (at most 64 x 16 B: the slot cannot overflow) and the
+// tile's statistics record {max, sum exp(x - max), 64-bit mask of the kept lanes}.  Two VMEM instructions per piece, no atomics.
+constexpr int FS_SLOT = 64;
+__device__ __forceinline__ void fused_emit_piece(const float4 x, int row, int tile, int NT, int lane, float thr, float4* __restrict__ stats,
+                                                 float4* __restrict__ cand) {
+    const float m4 = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
+    const float m = wave_max_dpp(m4);
+    const float e = wave_sum_dpp((__expf(x.x - m) + __expf(x.y - m)) + (__expf(x.z - m) + __expf(x.w - m)));
+    const bool kp = m4 >= thr;
+    const unsigned long long bal = __ballot(kp);
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+    if (kp) cand[((size_t)row * NT + tile) * FS_SLOT + rank] = x;
+    if (lane == 0) stats[(size_t)row * NT + tile] = make_float4(m, e, __uint_as_float((uint32_t)bal), __uint_as_float((uint32_t)(bal >> 32)));
+}
+
 // XCD-aware tile order: block b is dispatched to XCD b % 8 (observed, used for speed only), so give
 // every XCD one contiguous run of the linear tile index (bijective for any tile count), then walk
 // that run in groups of GROUP_M row-tiles so a group's activation tiles stay in the XCD's 4 MiB L2

@@ -77,6 +77,15 @@ __device__ __forceinline__ uint4 lds_read_b128_raw(const unsigned char* ptr) {
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
+// Scalar (SMEM) load of one float at a wave-uniform address; the value is valid after the caller's next lgkmcnt(0) wait.  Inline asm on purpose:
+// as an ordinary load it becomes a global_load (the kernel stores to global memory, so the compiler will not prove the location read-only) and,
+// worse, the compiler's waitcnt pass then drains vmcnt(0) -- the whole LDS-DMA pipeline -- in front of its first use (measured: +38 % kernel time).
+__device__ __forceinline__ float sload_f32(const float* ptr) {
+    float v;
+    asm volatile("s_load_dword %0, %1, 0x0" : "=s"(v) : "s"(ptr) : "memory");
+    return v;
+}
+
 // the logits are written once and read once by the sampler, 1.35 GB per launch against 4 MiB of L2 per XCD: a non-temporal store
 // keeps them from evicting the weight / activation tiles the other CUs of the XCD are about to re-read
 __device__ __forceinline__ void store_stream(float* ptr, const uint4 v) {
@@ -170,6 +179,10 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
     LOAD_NEXT(1);
     LOAD_NEXT(2);
 
+    // fused sampling: no logits leave the kernel; every piece emits tile statistics + the kept lanes' values instead (common.h
+    // fused_emit_piece).  Its VMEM instructions per piece: 1 statistics store (always issued) + 1 predicated value store.  The counted waits
+    // below only need a LOWER bound of what was issued behind a DMA (under-counting waits for more, never for less): st1 = 1 stays right.
+    const bool fused = (WMODE == WIDE_CFG) && p.fs_stats != nullptr;
     f32x4_t acc[4][8];
     f32x4_t held[2][4];             // second half of the previous tile's output (tokens 32..63 of this wave), combined
     bool have_prev = false;
@@ -246,7 +259,9 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
         }                                                                                                      \
         const bool piece_ = have_prev && q_ < 8 && ptok_ < p.M && !ABL(p, 1);      /* wave-uniform */          \
         uint4 pv_ = make_uint4(0, 0, 0, 0);                                                                    \
+        float fthr_ = 0.f;                                                                                     \
         if (piece_) pv_ = lds_read_b128_raw(psrc_);                                                            \
+        if (WMODE == WIDE_CFG && fused && piece_) fthr_ = sload_f32(p.fs_thr + __builtin_amdgcn_readfirstlane(ptok_));      \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         LOAD_NEXT(st_);                                     /* step g+3 into the stage just consumed */        \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
@@ -262,7 +277,11 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
         if (piece_) {                                                                                          \
             WAIT_LGKM0();                                       /* the raw read of pv_ (the fragments are long there) */ \
             __builtin_amdgcn_sched_barrier(0);                                                                 \
-            if constexpr (WMODE == WIDE_CFG) store_stream(reinterpret_cast<float*>(pv_ptr_), pv_);             \
+            if constexpr (WMODE == WIDE_CFG) {                                                                 \
+                if (fused) fused_emit_piece(make_float4(__uint_as_float(pv_.x), __uint_as_float(pv_.y), __uint_as_float(pv_.z), __uint_as_float(pv_.w)), \
+                                            ptok_, pn0 >> 8, p.tiles_n, lane, fthr_, p.fs_stats, p.fs_cand); \
+                else store_stream(reinterpret_cast<float*>(pv_ptr_), pv_);                                     \
+            }                                                                                                  \
             else {                                                                                             \
                 if (p.ln_part) {      /* LayerNorm(inner) partial sums of the row's two 64-column groups (common.h) */ \
                     const float2 lst_ = ln_partial_row64(pv_);                                                 \
@@ -365,7 +384,9 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
                 const int ptok = PIECE_TOKEN(hrow, half);
                 if (ptok < p.M && !ABL(p, 1)) {
                     const uint4 pv = *reinterpret_cast<const uint4*>(ct + hrow * 1024 + ((lane ^ (hrow & 7)) << 4));
-                    store_stream(reinterpret_cast<float*>(p.out) + (size_t)ptok * p.ldc + pn0 + lane * 4, pv);
+                    if (fused) fused_emit_piece(make_float4(__uint_as_float(pv.x), __uint_as_float(pv.y), __uint_as_float(pv.z), __uint_as_float(pv.w)), ptok,
+                                                pn0 >> 8, p.tiles_n, lane, p.fs_thr[ptok], p.fs_stats, p.fs_cand);
+                    else store_stream(reinterpret_cast<float*>(p.out) + (size_t)ptok * p.ldc + pn0 + lane * 4, pv);
                 }
             }
             WAIT_LGKM0();
@@ -394,6 +415,7 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
 bool mm_gemm_cfg2_eligible(const GemmArgs& a) {
     if (a.bias || a.act != ACT_NONE || a.resid_bf16 || a.resid_f32) return false;
     if ((a.K % (2 * BK)) != 0 || a.K < 16 * BK || (a.N % BN) != 0 || (((uintptr_t)a.out) & 15)) return false;
+    if (a.fs_stats && a.mode != MODE_CFG) return false;
     if (a.mode == MODE_CFG) {
         if (a.out_kind != OUT_F32 || (a.ldc % 4)) return false;
         return (long)((a.M + TOK - 1) / TOK) * (a.N / BN) >= 256;

@@ -399,6 +399,7 @@ int mm_transformer_forward(const mm_transformer_t* t, mm_stream_t stream, const 
 
 // ------------------------------------------------------------------------------------------------ generate
 namespace {
+constexpr float FS_MARGIN = 0.20f;    // the bound sits this many sigmas below the Gaussian quantile of the kept fraction: ~14 % instead of 10 % pass
 struct GenBufs {
     Bufs b;                 // 2B sequences
     bf16_t* ctx;            // [B][m][D]
@@ -412,6 +413,11 @@ struct GenBufs {
     float* logits;          // [B*n][V]
     float* xc;              // [2*B*n][D]: the last layer's residual stream, compacted to the sampled rows
     bf16_t* attc;           // [2*B*n][I]
+    // fused sampling (sampling_fused.hip): what the guidance-logits GEMM emits instead of the logits
+    float* fs_thr;          // [B*n]
+    float4* fs_stats;       // [B*n][V/256]
+    float4* fs_cand;        // [B*n][V/256][FS_SLOT]
+    void* fs_ws;            // scratch of the bound estimate (k_fused_threshold)
     void* ctx_ws; size_t ctx_ws_bytes;
 };
 void carve_gen(Carver& c, const mm_transformer* t, int B, int n, int L, int nc, GenBufs& g) {
@@ -428,6 +434,12 @@ void carve_gen(Carver& c, const mm_transformer* t, int B, int n, int L, int nc, 
     g.logits = c.take<float>((size_t)B * n * t->d.dim_out);
     g.xc = c.take<float>((size_t)2 * B * n * D);
     g.attc = c.take<bf16_t>((size_t)2 * B * n * I);
+    const bool fs = t->d.logits_wcov && (t->d.dim_out % 256) == 0 && (D % 64) == 0;
+    const size_t NT = fs ? (size_t)t->d.dim_out / 256 : 0;
+    g.fs_thr = c.take<float>(fs ? (size_t)B * n : 0);
+    g.fs_stats = c.take<float4>((size_t)B * n * NT);
+    g.fs_cand = c.take<float4>((size_t)B * n * NT * FS_SLOT);
+    g.fs_ws = c.take<unsigned char>(fs ? k_fused_threshold_ws_bytes(B * n, D) : 0);
     g.ctx_ws_bytes = mm_context_workspace_bytes(t, B, L);
     g.ctx_ws = c.take<unsigned char>(g.ctx_ws_bytes);
 }
@@ -588,26 +600,52 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
             RC(k_layernorm(s, b.x, D, R, D, t->d.final_gamma, t->d.final_beta, g.rows, g.embc, D));
             RC(k_layernorm(s, b.x + (size_t)M * D, D, R, D, t->d.final_gamma, t->d.final_beta, g.rows, g.embn, D));
         }
-        {
-            GemmArgs a;
-            memset(&a, 0, sizeof(a));
-            a.mode = MODE_CFG;
-            a.W = (const bf16_t*)t->d.to_logits; a.N = V; a.ldw = D; a.K = D;
-            a.M = R; a.X = g.embc; a.X2 = g.embn; a.ldx = D;
-            a.out = g.logits; a.ldc = V; a.out_kind = OUT_F32; a.cfg_scale = p->cond_scale;
+        GemmArgs a;
+        memset(&a, 0, sizeof(a));
+        a.mode = MODE_CFG;
+        a.W = (const bf16_t*)t->d.to_logits; a.N = V; a.ldw = D; a.K = D;
+        a.M = R; a.X = g.embc; a.X2 = g.embn; a.ldx = D;
+        a.out = g.logits; a.ldc = V; a.out_kind = OUT_F32; a.cfg_scale = p->cond_scale;
+        a.debug = g_mm_debug;
+        // Sampling without the logits round trip: the GEMM emits tile statistics + the candidates above a per-row lower bound of the k-th largest
+        // logit (estimated from the row's embeddings and the vocabulary statistics of to_logits), the finishing kernel verifies the bound.
+        const bool fused = t->d.logits_wcov && t->d.logits_wmean && p->status && !(p->flags & MM_GEN_NO_FUSED_SAMPLING) && (V % 256) == 0 &&
+                           !(g_mm_debug & (8 | 4096 | 8192 | (1 << 25))) && mm_gemm_cfg2_eligible(a);
+        const double gemm_flops = 2.0 * 2.0 * (double)R * (double)V * (double)D;      // cond + null rows
+        if (fused) {
+            RC(k_fused_threshold(s, g.embc, g.embn, D, R, D, p->cond_scale, t->d.logits_wmean, (const bf16_t*)t->d.logits_wcov, k_fused_z(p->k_keep, V, FS_MARGIN),
+                                 g.fs_ws, g.fs_thr));
+            a.out = nullptr;
+            a.fs_thr = g.fs_thr; a.fs_stats = g.fs_stats; a.fs_cand = g.fs_cand;
             prof::Rec pr;
-            if (prof::enabled) pr = prof::begin(s, 2.0 * 2.0 * (double)R * (double)V * (double)D);   // cond + null rows
+            if (prof::enabled) pr = prof::begin(s, gemm_flops);
             RC(mm_gemm_launch(a, s));
             if (prof::enabled) prof::end(s, 0, pr);
-        }
-        SampleArgs sa;
-        memset(&sa, 0, sizeof(sa));
-        sa.logits = g.logits; sa.ld = V; sa.R = R; sa.V = V; sa.k_keep = p->k_keep; sa.rows = g.rows;
-        sa.temperature = p->temperatures[step]; sa.noise_kind = p->noise_kind;
-        sa.noise = p->noise ? p->noise + (size_t)step * M * V : nullptr; sa.noise_ld = V;
-        sa.seed = p->seed; sa.row_offset = p->row_offset * (uint64_t)n; sa.step = (uint32_t)step;
-        sa.ids = p->ids; sa.scores = p->scores;
-        {
+            FusedSampleArgs fa;
+            memset(&fa, 0, sizeof(fa));
+            fa.thr = g.fs_thr; fa.stats = g.fs_stats; fa.cand = g.fs_cand;
+            fa.R = R; fa.V = V; fa.k_keep = p->k_keep; fa.rows = g.rows;
+            fa.temperature = p->temperatures[step]; fa.noise_kind = p->noise_kind;
+            fa.noise = p->noise ? p->noise + (size_t)step * M * V : nullptr; fa.noise_ld = V;
+            fa.seed = p->seed; fa.row_offset = p->row_offset * (uint64_t)n; fa.step = (uint32_t)step;
+            fa.ids = p->ids; fa.scores = p->scores; fa.fail_flag = p->status;
+            if (prof::enabled) pr = prof::begin(s, 4.0 * (double)R * (double)V);      // logits-equivalent bytes (what a logits-reading sampler reads)
+            RC(k_sample_fused(s, fa));                                                                  // mmp.py:576-609
+            if (prof::enabled) prof::end(s, 1, pr);
+        } else {
+            {
+                prof::Rec pr;
+                if (prof::enabled) pr = prof::begin(s, gemm_flops);
+                RC(mm_gemm_launch(a, s));
+                if (prof::enabled) prof::end(s, 0, pr);
+            }
+            SampleArgs sa;
+            memset(&sa, 0, sizeof(sa));
+            sa.logits = g.logits; sa.ld = V; sa.R = R; sa.V = V; sa.k_keep = p->k_keep; sa.rows = g.rows;
+            sa.temperature = p->temperatures[step]; sa.noise_kind = p->noise_kind;
+            sa.noise = p->noise ? p->noise + (size_t)step * M * V : nullptr; sa.noise_ld = V;
+            sa.seed = p->seed; sa.row_offset = p->row_offset * (uint64_t)n; sa.step = (uint32_t)step;
+            sa.ids = p->ids; sa.scores = p->scores;
             prof::Rec pr;
             if (prof::enabled) pr = prof::begin(s, 4.0 * (double)R * (double)V);      // one fp32 read of each row
             RC(k_sample_rows(s, sa));                                                                // mmp.py:576-609

@@ -36,6 +36,9 @@ struct GemmArgs {
     //   w2 (128x128 / 256x128 kernel, fp32 + residual): ln_c1 != NULL -> out = rstd*acc - rstd*mean*ln_c1[n] + ln_c2[n] + resid with
     //     mean / rstd of each row from the ln_np partials over ln_F valid features.
     float* ln_part; int ln_np; int ln_F; const float* ln_c1; const float* ln_c2;
+    // fused sampling (MODE_CFG on gemm_cfg.hip only): when fs_stats != NULL the logits are NOT written; every 256-column piece of a row emits its
+    // statistics and its candidates >= fs_thr[row] instead (common.h fused_emit_piece)
+    const float* fs_thr; float4* fs_stats; float4* fs_cand;
     int debug;                    // ablation bits (mm_debug_set): 1 = no epilogue stores, 2 = no DMA after tile 0, 4 = no MFMA, 8 = force the 128x128 kernel, 4096 = no persistent kernel
 };
 extern int g_mm_debug;
@@ -129,6 +132,25 @@ struct SampleArgs {
     float z_lo;                                  // histogram lower bound in sigmas above the row mean (set by k_sample_rows)
 };
 int k_sample_rows(hipStream_t s, const SampleArgs& a);
+// sampling_fused.hip: sampling from what the guidance-logits GEMM emits instead of the logits (tile statistics + candidates)
+struct FusedSampleArgs {
+    const float* thr;                            // [R] the lower bound the candidates were emitted with (lower edge of the select histogram)
+    const float4* stats;                         // [R][V/256]: {tile max, sum exp(x - tile max), mask of the kept lanes (2 x 32 bits)}
+    const float4* cand;                          // [R][V/256][FS_SLOT]: the kept lanes' 4 values each, lane-compacted
+    int R, V, k_keep;
+    const int32_t* rows;                         // [R] flat position of each row (default: r)
+    float temperature; int noise_kind; const float* noise; long noise_ld;
+    uint64_t seed; uint64_t row_offset; uint32_t step;
+    int64_t* ids; float* scores; int64_t* pred_out; float* score_out;
+    int* fail_flag;                              // set to 1 when a row's candidate set cannot be proven complete (caller falls back to the logits path)
+};
+float k_fused_z(int k_keep, int V, float margin);
+// thr[r] = mean_r + z sigma_r of row r's logits over the vocabulary; ws: k_fused_threshold_ws_bytes(R, D) bytes of scratch; wcov bf16 [D][D]
+size_t k_fused_threshold_ws_bytes(int R, int D);
+int k_fused_threshold(hipStream_t s, const bf16_t* ec, const bf16_t* en, long ld, int R, int D, float cond_scale, const float* wmean, const bf16_t* wcov,
+                      float z, void* ws, float* thr);
+int k_fused_emit(hipStream_t s, const float* logits, long ld, int R, int V, const float* thr, float4* stats, float4* cand);
+int k_sample_fused(hipStream_t s, const FusedSampleArgs& a);
 int k_philox_fill(hipStream_t s, uint64_t seed, uint64_t row_offset, uint32_t step, int rows, int V, float* out);
 int k_text_context(hipStream_t s, const float* text, int rows, int text_dim, int L, int m, bf16_t* out_bf16, long ldo,
                    uint8_t* mask, int drop_text);

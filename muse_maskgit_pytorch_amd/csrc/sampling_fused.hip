@@ -1,0 +1,394 @@
+// Sampling without the logits round trip (muse_maskgit_pytorch.py:576-609; SURVEY.md 8d "fused floor = 0 bytes of logits to HBM").
+//
+// The guidance-logits GEMM (gemm_cfg.hip) does not write its [R][V] fp32 output any more.  While a 256-column tile of a token row is
+// on its way out of the accumulators (4 consecutive values per lane) the epilogue emits, per (row, tile):
+//     stats  {tile max, sum exp(x - tile max), 64-bit mask of the lanes it kept}                            16 B
+//     cand   the 4 values of every lane whose largest value reaches thr_lo[row], lane-compacted              16 B per kept lane (~45 % of them)
+// thr_lo[row] is a LOWER bound estimate of the row's k-th largest logit, known BEFORE the GEMM runs: a row's logits over the vocabulary
+// are <e, w_v> for the row's (guidance-combined) embedding e, so their mean and variance are <e, mean_w> and e' Cov_w e with the weight
+// statistics packed once per model (k_fused_threshold: one small MFMA GEMM against Cov_w); thr_lo = mean + (z_k - margin) sigma.
+// A finishing kernel (sample_fused_kernel) then works on the ~9 k values >= thr_lo of a row instead of 65536 logits: exact k-th largest
+// (value-linear histogram in LDS + rank counting inside one bin), Gumbel argmax over the entries >= it, confidence
+// 1 - exp(x_pred - max) / sum from the tile statistics combined in a fixed order (deterministic).
+// The candidate set is a superset of the kept set iff at least k values passed thr_lo; the finishing kernel CHECKS that (and its list
+// capacity) per row and raises a device flag otherwise -- the caller then repeats the generate on the logits path (sampling.hip), so
+// the result never depends on the estimate, only the speed does.  Same ids as sample_kernel on the same logits (tests).
+#include <math.h>
+#include <string.h>
+
+#include "common.h"
+#include "muse_hip_internal.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t fkey(float f) {      // order-preserving float -> uint32 (as in sampling.hip)
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t k, uint32_t (&out)[2]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p = (uint64_t)0xD256D193u * c0;
+        const uint32_t n0 = (uint32_t)(p >> 32) ^ k ^ c1;
+        c1 = (uint32_t)p;
+        c0 = n0;
+        k += 0x9E3779B9u;
+    }
+    out[0] = c0; out[1] = c1;
+}
+__device__ __forceinline__ void philox_uniform2(uint64_t seed, uint64_t row_global, uint32_t step, uint32_t col2, float (&u)[2]) {      // == sampling.hip
+    const uint64_t ctr = (row_global << 24) | ((uint64_t)(step & 0xFFu) << 16) | (uint64_t)(col2 & 0xFFFFu);
+    const uint32_t key = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x85EBCA6Bu) ^ ((step >> 8) * 0xC2B2AE35u);
+    uint32_t o[2];
+    philox2x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), key, o);
+    u[0] = (float)(o[0] >> 8) * (1.0f / 16777216.0f);
+    u[1] = (float)(o[1] >> 8) * (1.0f / 16777216.0f);
+}
+__device__ __forceinline__ float gumbel_of(float u) {
+    const float a = logf(fmaxf(u, 1e-20f));
+    return -logf(fmaxf(-a, 1e-20f));
+}
+__device__ __forceinline__ float noise_gumbel(const FusedSampleArgs& p, long pos_flat, int idx) {
+    if (p.noise_kind == MM_NOISE_GUMBEL) return p.noise[(size_t)pos_flat * p.noise_ld + idx];
+    if (p.noise_kind == MM_NOISE_UNIFORM) return gumbel_of(p.noise[(size_t)pos_flat * p.noise_ld + idx]);
+    if (p.noise_kind == MM_NOISE_PHILOX) {
+        float u[2];
+        philox_uniform2(p.seed, p.row_offset + (uint64_t)pos_flat, p.step, (uint32_t)(idx >> 1), u);
+        return gumbel_of((idx & 1) ? u[1] : u[0]);
+    }
+    return 0.f;
+}
+
+// ---- thr_lo[r] = mean_r + z * sigma_r with mean_r = <e_r, wmean>, sigma_r^2 = e_r' Cov e_r, e_r = null_r + (cond_r - null_r) * s (what the GEMM
+//      multiplies, mmp.py:254, by linearity).  Three launches: e (bf16) and mean per row, T = E Cov on the bf16 MFMA GEMM, sigma from <e, T>.
+__global__ __launch_bounds__(256) void fused_combine_kernel(const bf16_t* __restrict__ ec, const bf16_t* __restrict__ en, long ld, int R, int D, float s,
+                                                            const float* __restrict__ wmean, bf16_t* __restrict__ ebf, float* __restrict__ mu) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    float m = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        const float a = bf16_to_f32(ec[(size_t)row * ld + c]), b = bf16_to_f32(en[(size_t)row * ld + c]);
+        const bf16_t eb = f32_to_bf16(b + (a - b) * s);
+        ebf[(size_t)row * D + c] = eb;
+        m += bf16_to_f32(eb) * wmean[c];
+    }
+    m = wave_sum(m);
+    if (lane == 0) mu[row] = m;
+}
+__global__ __launch_bounds__(256) void fused_sigma_kernel(const bf16_t* __restrict__ ebf, const float* __restrict__ tq, const float* __restrict__ mu, int R, int D,
+                                                          float z, float* __restrict__ thr) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    float q = 0.f;
+    for (int c = lane; c < D; c += 64) q += bf16_to_f32(ebf[(size_t)row * D + c]) * tq[(size_t)row * D + c];
+    q = wave_sum(q);
+    if (lane == 0) thr[row] = mu[row] + z * sqrtf(fmaxf(q, 0.f));
+}
+
+// ---- the GEMM epilogue's emission, as a stand-alone kernel over materialised logits (tests; shapes the 256-column GEMM does not take)
+__global__ __launch_bounds__(256) void fused_emit_kernel(const float* __restrict__ logits, long ld, int R, int V, const float* __restrict__ thr,
+                                                         float4* __restrict__ stats, float4* __restrict__ cand) {
+    const int NT = V / 256;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long piece = (long)blockIdx.x * 4 + w;              // (row, tile)
+    if (piece >= (long)R * NT) return;
+    const int row = (int)(piece / NT), tile = (int)(piece - (long)row * NT);
+    const float4 x4 = *reinterpret_cast<const float4*>(logits + (size_t)row * ld + tile * 256 + lane * 4);
+    fused_emit_piece(x4, row, tile, NT, lane, thr[row], stats, cand);
+}
+
+// ---- finishing kernel: 512-thread workgroups, two per CU (78 KiB of LDS each), one row at a time
+constexpr int FT = 512, FW = FT / 64;
+constexpr int WSL = 1408;                       // per-wave slice of the candidate list; a wave gathers 1/8 of the tiles: ~1150 +- 35 values at V = 65536
+constexpr int LIST_CAP = FW * WSL;              // 11264 candidates of one row held in LDS as (fp32 value, u16 index): 66 KiB
+constexpr int NBF = 1024;                       // value-linear histogram bins over [thr_lo, row max]
+constexpr int CANDF = 1024;                     // exact-select capacity (members of the bin that holds the k-th largest)
+
+struct FusedShared {
+    float xs[LIST_CAP];
+    uint16_t cols[LIST_CAP];
+    uint32_t hist[NBF];                         // TRANSPOSED (hslotf): lane l's 16 consecutive bins form a conflict-free column
+    uint32_t cand[CANDF];
+    float redf[FW], redx[FW];
+    int redi[FW];
+    unsigned long long masks[256];
+    int wcnt[FW];
+    int ncand;
+    uint32_t thr_key;
+};
+__device__ __forceinline__ int hslotf(int b) { return ((b & 15) << 6) | (b >> 4); }
+
+__global__ __launch_bounds__(FT, 2) void sample_fused_kernel(const FusedSampleArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fs_raw[];
+    FusedShared& S = *reinterpret_cast<FusedShared*>(fs_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int NT = p.V / 256;
+    for (int row = blockIdx.x; row < p.R; row += gridDim.x) {
+        const long pos_flat = p.rows ? (long)p.rows[row] : (long)row;
+        // ---- tile statistics -> row max, softmax denominator; the kept-lane masks are parked in LDS for the gather
+        float tmax = -INFINITY, tsum = 0.f;
+        if (tid < NT) {
+            const float4 st = p.stats[(size_t)row * NT + tid];
+            tmax = st.x; tsum = st.y;
+            S.masks[tid] = (unsigned long long)__float_as_uint(st.z) | ((unsigned long long)__float_as_uint(st.w) << 32);
+        }
+        const float wm = wave_max(tmax);
+        if (lane == 0) S.redf[wid] = wm;
+        if (tid == 0) S.ncand = 0;
+        for (int i = tid; i < NBF; i += FT) S.hist[i] = 0;
+        __syncthreads();
+        float M = S.redf[0];
+#pragma unroll
+        for (int w2 = 1; w2 < FW; ++w2) M = fmaxf(M, S.redf[w2]);
+        // softmax denominator: sum_t tsum_t * exp(tmax_t - M), combined in a fixed order (deterministic)
+        const float term = wave_sum((tid < NT) ? tsum * expf(tmax - M) : 0.f);
+        if (lane == 0) S.redx[wid] = term;
+        // ---- gather: wave w takes tiles w, w + 8, ...: the kept lanes' float4s (coalesced reads, issued 8 tiles at a time), every value >= the
+        //      bound is appended to THIS WAVE's slice of the LDS list (running count + ballot prefix: no atomics) and binned
+        const float lo = p.thr[row];
+        const float span = M - lo;
+        const bool fast = (span >= 1e-30f) && (span < 3.0e38f);
+        const float inv_w = fast ? (float)NBF / span : 0.f;
+        float* myx = S.xs + wid * WSL;
+        uint16_t* myc = S.cols + wid * WSL;
+        int wcount = 0;                                           // wave-uniform
+        for (int t0 = wid; t0 < NT; t0 += FW * 8) {
+            float4 v[8];
+            bool mine[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t_ = t0 + u * FW;
+                mine[u] = false;
+                v[u] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                if (t_ < NT) {
+                    const unsigned long long mask = S.masks[t_];
+                    mine[u] = (mask >> lane) & 1ull;
+                    if (mine[u]) v[u] = p.cand[((size_t)row * NT + t_) * FS_SLOT + __popcll(mask & ((1ull << lane) - 1ull))];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t_ = t0 + u * FW;
+                const float xv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool kp = mine[u] && xv[i] >= lo;
+                    const unsigned long long bal = __ballot(kp);
+                    const int idx = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, (uint32_t)wcount));
+                    if (kp && idx < WSL) {
+                        myx[idx] = xv[i]; myc[idx] = (uint16_t)(t_ * 256 + lane * 4 + i);
+                        if (fast) atomicAdd(&S.hist[hslotf(min(NBF - 1, max(0, (int)((xv[i] - lo) * inv_w))))], 1u);
+                    }
+                    wcount += __popcll(bal);
+                }
+            }
+        }
+        if (lane == 0) S.wcnt[wid] = wcount;
+        __syncthreads();
+        float sumexp = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < FW; ++w2) sumexp += S.redx[w2];
+        int total = 0;
+        bool fits = true;
+#pragma unroll
+        for (int w2 = 0; w2 < FW; ++w2) { total += S.wcnt[w2]; fits = fits && S.wcnt[w2] <= WSL; }
+        // the candidate set holds the kept set iff >= k values passed the lower bound and every wave's slice held its share
+        const bool ok = total >= p.k_keep && fits;
+        if (!ok) {
+            if (tid == 0) { atomicExch(p.fail_flag, 1); if (p.ids) p.ids[pos_flat] = 0; if (p.scores) p.scores[pos_flat] = 0.f; }
+            __syncthreads();
+            continue;
+        }
+        // ---- bin that holds the k-th largest value (every wave scans redundantly), its members -> exact select by rank counting
+        const int need = p.k_keep;
+        int tbin = 0, above = 0, bcnt = 0;
+        if (fast) {
+            uint32_t mine = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) mine += S.hist[j * 64 + lane];          // bins 16*lane .. 16*lane + 15
+            uint32_t suf = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t t_ = (uint32_t)__shfl_down((int)suf, o, 64); if (lane + o < 64) suf += t_; }
+            const uint32_t ab = suf - mine;
+            const unsigned long long own = __ballot(ab < (uint32_t)need && (uint32_t)need <= suf);
+            const int Lq = __ffsll((long long)own) - 1;                           // total >= need, so some lane owns it
+            uint32_t abq = (uint32_t)__shfl((int)ab, Lq, 64);
+#pragma unroll 1
+            for (int j = 15; j >= 0; --j) {
+                const uint32_t h = S.hist[j * 64 + Lq];
+                if (abq < (uint32_t)need && (uint32_t)need <= abq + h) { tbin = Lq * 16 + j; bcnt = (int)h; break; }
+                abq += h;
+            }
+            above = (int)abq;
+        }
+        const bool slow = !fast || bcnt > CANDF;
+        uint32_t thr;
+        if (!slow) {
+            for (int i = tid; i < FW * WSL; i += FT) {
+                if (i % WSL >= S.wcnt[i / WSL]) continue;
+                const float x = S.xs[i];
+                if (min(NBF - 1, max(0, (int)((x - lo) * inv_w))) == tbin) { const int sl = atomicAdd(&S.ncand, 1); if (sl < CANDF) S.cand[sl] = fkey(x); }
+            }
+            __syncthreads();
+            const int need_in = need - above, n_c = min(S.ncand, CANDF);
+            for (int i = tid; i < n_c; i += FT) {
+                const uint32_t ki = S.cand[i];
+                int gt = 0, ge = 0;
+#pragma unroll 4
+                for (int j = 0; j < n_c; ++j) { const uint32_t kj = S.cand[j]; gt += kj > ki; ge += kj >= ki; }
+                if (gt < need_in && need_in <= ge) S.thr_key = ki;      // every thread that satisfies this holds the same key
+            }
+            __syncthreads();
+            thr = S.thr_key;
+        } else {
+            // massive ties / degenerate span: bisection over the 32 key bits on the LDS list
+            uint32_t prefix = 0;
+            for (int bit = 31; bit >= 0; --bit) {
+                const uint32_t trial = prefix | (1u << bit);
+                int c = 0;
+                for (int i = tid; i < FW * WSL; i += FT) c += (i % WSL < S.wcnt[i / WSL]) && fkey(S.xs[i]) >= trial;
+                c = wave_sum_i(c);
+                __syncthreads();
+                if (lane == 0) S.redi[wid] = c;
+                __syncthreads();
+                int tot = 0;
+                for (int w2 = 0; w2 < FW; ++w2) tot += S.redi[w2];
+                if (tot >= need) prefix = trial;
+            }
+            __syncthreads();
+            thr = prefix;
+        }
+        // ---- every wave squeezes its slice down to the kept entries (value >= the k-th largest), in place: the write position never passes the
+        //      read position, so the Gumbel loop below runs on dense lanes (71 % of the candidates are kept, interleaved at random)
+        {
+            const int cw = S.wcnt[wid];
+            float* myx2 = S.xs + wid * WSL;
+            uint16_t* myc2 = S.cols + wid * WSL;
+            int wpos = 0;                                         // wave-uniform
+            for (int b0 = 0; b0 < cw; b0 += 64) {
+                const int i = b0 + lane;
+                const float x = i < cw ? myx2[i] : 0.f;
+                const uint16_t c = i < cw ? myc2[i] : (uint16_t)0;
+                const bool kp = i < cw && fkey(x) >= thr;
+                const unsigned long long bal = __ballot(kp);
+                const int idx = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, (uint32_t)wpos));
+                if (kp) { myx2[idx] = x; myc2[idx] = c; }        // (same wave: LDS accesses complete in program order)
+                wpos += __popcll(bal);
+            }
+            __syncthreads();
+            if (lane == 0) S.wcnt[wid] = wpos;
+            __syncthreads();
+        }
+        // ---- Gumbel argmax over the kept entries (mmp.py:410-411); ties -> lower index.  Thread t takes entries t, t + 512, ... of the
+        //      concatenation of the slices (each slice dense now)
+        const float T = p.temperature;
+        float best = -INFINITY, best_x = 0.f;
+        int best_i = 0x7FFFFFFF;
+        int ktotal = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < FW; ++w2) ktotal += S.wcnt[w2];
+        for (int g = tid; g < ktotal; g += FT) {
+            int rem = g, w2 = 0;                                  // slice that holds the g-th kept entry
+#pragma unroll
+            for (int q = 0; q < FW - 1; ++q) {
+                const int c_ = S.wcnt[q];
+                const bool past = (w2 == q) && rem >= c_;
+                rem -= past ? c_ : 0;
+                w2 += past ? 1 : 0;
+            }
+            const int i = w2 * WSL + rem;
+            const float x = S.xs[i];
+            const int idx = (int)S.cols[i];
+            const float y = x / T + noise_gumbel(p, pos_flat, idx);
+            if (y > best || (y == best && idx < best_i)) { best = y; best_i = idx; best_x = x; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(best_i, o, 64);
+            const float ox = __shfl_xor(best_x, o, 64);
+            if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; best_x = ox; }
+        }
+        if (lane == 0) { S.redf[wid] = best; S.redi[wid] = best_i; S.redx[wid] = best_x; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int i = 1; i < FW; ++i)
+                if (S.redf[i] > best || (S.redf[i] == best && S.redi[i] < best_i)) { best = S.redf[i]; best_i = S.redi[i]; best_x = S.redx[i]; }
+            const float score = 1.f - expf(best_x - M) / sumexp;      // mmp.py:603-606 on the unfiltered logits
+            if (p.ids) p.ids[pos_flat] = (int64_t)best_i;
+            if (p.scores) p.scores[pos_flat] = score;
+            if (p.pred_out) p.pred_out[row] = (int64_t)best_i;
+            if (p.score_out) p.score_out[row] = score;
+        }
+        __syncthreads();
+    }
+}
+
+double norm_quantile(double pq) {      // Acklam's rational approximation (placement of the lower bound only, never a result)
+    static const double a[] = {-3.969683028665376e+01, 2.209460984245205e+02, -2.759285104469687e+02, 1.383577518672690e+02, -3.066479806614716e+01, 2.506628277459239e+00};
+    static const double b[] = {-5.447609879822406e+01, 1.615858368580409e+02, -1.556989798598866e+02, 6.680131188771972e+01, -1.328068155288572e+01};
+    static const double c[] = {-7.784894002430293e-03, -3.223964580411365e-01, -2.400758277161838e+00, -2.549732539343734e+00, 4.374664141464968e+00, 2.938163982698783e+00};
+    static const double d[] = {7.784695709041462e-03, 3.224671290700398e-01, 2.445134137142996e+00, 3.754408661907416e+00};
+    if (pq <= 0.0) return -1e9;
+    if (pq >= 1.0) return 1e9;
+    if (pq < 0.02425) { const double q = sqrt(-2 * log(pq)); return (((((c[0]*q+c[1])*q+c[2])*q+c[3])*q+c[4])*q+c[5]) / ((((d[0]*q+d[1])*q+d[2])*q+d[3])*q+1); }
+    if (pq > 1 - 0.02425) { const double q = sqrt(-2 * log(1 - pq)); return -(((((c[0]*q+c[1])*q+c[2])*q+c[3])*q+c[4])*q+c[5]) / ((((d[0]*q+d[1])*q+d[2])*q+d[3])*q+1); }
+    const double q = pq - 0.5, r = q * q;
+    return (((((a[0]*r+a[1])*r+a[2])*r+a[3])*r+a[4])*r+a[5])*q / (((((b[0]*r+b[1])*r+b[2])*r+b[3])*r+b[4])*r+1);
+}
+
+}  // namespace
+
+float k_fused_z(int k_keep, int V, float margin) { return (float)(norm_quantile(1.0 - (double)k_keep / (double)V) - (double)margin); }
+
+size_t k_fused_threshold_ws_bytes(int R, int D) { return ((size_t)R * D * 2 + 255) / 256 * 256 + (size_t)R * D * 4 + (size_t)R * 4 + 512; }
+
+int k_fused_threshold(hipStream_t s, const bf16_t* ec, const bf16_t* en, long ld, int R, int D, float cond_scale, const float* wmean, const bf16_t* wcov,
+                      float z, void* ws, float* thr) {
+    if (R <= 0) return MM_OK;
+    if (D <= 0 || (D % 64)) return mm_set_error(MM_ERR_SHAPE, "fused_threshold: D must be a positive multiple of 64");
+    unsigned char* w8 = (unsigned char*)ws;
+    bf16_t* ebf = (bf16_t*)w8;
+    float* tq = (float*)(w8 + ((size_t)R * D * 2 + 255) / 256 * 256);
+    float* mu = tq + (size_t)R * D;
+    hipLaunchKernelGGL(fused_combine_kernel, dim3((R + 3) / 4), dim3(256), 0, s, ec, en, ld, R, D, cond_scale, wmean, ebf, mu);
+    int rc = mm_check_launch("fused_combine_kernel");
+    if (rc) return rc;
+    GemmArgs a;      // T = E Cov' (Cov is symmetric): [R][D] x [D][D] on the bf16 MFMA GEMM, fp32 out
+    memset(&a, 0, sizeof(a));
+    a.mode = MODE_DENSE;
+    a.W = wcov; a.N = D; a.ldw = D; a.K = D; a.M = R; a.X = ebf; a.ldx = D;
+    a.out = tq; a.ldc = D; a.out_kind = OUT_F32;
+    rc = mm_gemm_launch(a, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fused_sigma_kernel, dim3((R + 3) / 4), dim3(256), 0, s, ebf, tq, mu, R, D, z, thr);
+    return mm_check_launch("fused_sigma_kernel");
+}
+
+int k_fused_emit(hipStream_t s, const float* logits, long ld, int R, int V, const float* thr, float4* stats, float4* cand) {
+    if (R <= 0) return MM_OK;
+    if (V <= 0 || (V % 256)) return mm_set_error(MM_ERR_SHAPE, "fused_emit: V must be a multiple of 256");
+    const long pieces = (long)R * (V / 256);
+    hipLaunchKernelGGL(fused_emit_kernel, dim3((unsigned)((pieces + 3) / 4)), dim3(256), 0, s, logits, ld, R, V, thr, stats, cand);
+    return mm_check_launch("fused_emit_kernel");
+}
+
+int k_sample_fused(hipStream_t s, const FusedSampleArgs& a) {
+    if (a.R <= 0) return MM_OK;
+    if (a.V <= 0 || (a.V % 256) || a.V > 65536) return mm_set_error(MM_ERR_SHAPE, "sample_fused: V must be a multiple of 256 and <= 65536");
+    if (a.k_keep < 1 || a.k_keep > a.V) return mm_set_error(MM_ERR_SHAPE, "sample_fused: k_keep out of range");
+    if ((a.noise_kind == MM_NOISE_GUMBEL || a.noise_kind == MM_NOISE_UNIFORM) && !a.noise) return mm_set_error(MM_ERR_SHAPE, "sample_fused: noise tensor required");
+    if (!(a.temperature > 0.f)) return mm_set_error(MM_ERR_SHAPE, "sample_fused: temperature must be > 0");
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sample_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(FusedShared));
+        if (e != hipSuccess) return mm_set_hip_error(e, "sample_fused hipFuncSetAttribute");
+        attr_set = true;
+    }
+    const int grid = a.R < 512 ? a.R : 512;       // two workgroups per CU, persistent over the rows
+    hipLaunchKernelGGL(sample_fused_kernel, dim3(grid), dim3(FT), sizeof(FusedShared), s, a);
+    return mm_check_launch("sample_fused_kernel");
+}

@@ -221,6 +221,14 @@ class Transformer(nn.Module):
         t = dict(tok=self.token_emb.weight.detach().to(bf16).contiguous(), pos=self.pos_emb.weight.detach().to(bf16).contiguous(),
                  fg=f32c(tb.norm.gamma), fb=f32c(tb.norm.beta), wl=self.to_logits.weight.detach().to(bf16).contiguous(),
                  tp=self.text_embed_proj.weight.detach().to(bf16).contiguous() if isinstance(self.text_embed_proj, nn.Linear) else None)
+        # vocabulary statistics of to_logits for sampling without materialised logits (mm_transformer_desc.logits_wmean / _wcov): the mean of the
+        # weight rows and their covariance; a row's logits over the vocabulary have mean <e, wmean> and variance e' wcov e.  Pack-time only.
+        t['wmean'] = t['wcov'] = None
+        if self.dim_out % 256 == 0 and self.dim_out >= 4096:
+            wt = t['wl'].float().t().contiguous()                       # [D][V]
+            t['wmean'] = wt.mean(dim=1).contiguous()
+            t['wcov'] = (P32.gemm(wt, wt) / float(self.dim_out) - torch.outer(t['wmean'], t['wmean'])).to(bf16).contiguous()
+            del wt
         h.keep.append(t)
         h.keep.append(layers)
         d = L.TransformerDesc()
@@ -232,6 +240,7 @@ class Transformer(nn.Module):
         d.layers = C.cast(layers, C.POINTER(L.LayerWeights))
         d.final_gamma, d.final_beta, d.to_logits = L.ptr(t['fg']), L.ptr(t['fb']), L.ptr(t['wl'])
         d.self_cond_ff = sc_ff
+        d.logits_wmean, d.logits_wcov = L.ptr(t['wmean']), L.ptr(t['wcov'])
         L.check(L.lib().mm_transformer_create(C.byref(d), C.byref(h.ptr)), 'mm_transformer_create')
         h.packed = t
         self._handle, self._handle_key = h, key
@@ -601,6 +610,7 @@ class MaskGit(nn.Module):
         self.self_cond_prob = self_cond_prob
         self.no_mask_token_prob = no_mask_token_prob
         self._gen_ws = None
+        self.fused_sampling_fallbacks = 0      # generate() calls repeated on the logits path because a row's candidate bound could not be verified
 
     def save(self, path):
         torch.save(self.state_dict(), path)
@@ -634,13 +644,14 @@ class MaskGit(nn.Module):
                  force_not_use_token_critic=False, timesteps=18, cond_scale=3, critic_noise_scale=1,
                  *, text_embeds: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None, noise_kind: str = 'philox',
                  seed: Optional[int] = None, row_offset: int = 0, return_ids: bool = False, trace: Optional[dict] = None,
-                 critic_noise: Optional[torch.Tensor] = None, neg_text_embeds: Optional[torch.Tensor] = None):
+                 critic_noise: Optional[torch.Tensor] = None, neg_text_embeds: Optional[torch.Tensor] = None, fused_sampling: bool = True):
         """mmp.py:491-621.  Keyword-only extras (not in the reference): `text_embeds` bypasses the T5 call,
         `noise` (+ `noise_kind` 'gumbel' | 'uniform') injects the per-step noise tensor [T,B,n,V] for parity runs,
         `seed` / `row_offset` key the on-device Philox stream (row_offset = global index of this shard's first
         sample, so sharded runs reproduce the unsharded ids), `trace` receives per-step states, `critic_noise` [T,B,n]
         injects the U(0,1) draws of the token-critic score annealing (mmp.py:601).  `negative_texts` (or `neg_text_embeds`) is an
-        EXTENSION: the reference's negative-prompt path cannot run (see Transformer.forward_with_neg_prompt)."""
+        EXTENSION: the reference's negative-prompt path cannot run (see Transformer.forward_with_neg_prompt).  `fused_sampling=False` forces
+        the decode loop to materialise the logits (same ids; tests / A-B timing)."""
         tr = self.transformer
         use_token_critic = exists(self.token_critic) and not force_not_use_token_critic
         if exists(negative_texts) or exists(neg_text_embeds):
@@ -699,7 +710,22 @@ class MaskGit(nn.Module):
         wsb = L.lib().mm_generate_workspace_bytes(h.ptr, B, seq_len, Lt, nc)
         if self._gen_ws is None or self._gen_ws.numel() < wsb or self._gen_ws.device != dev:
             self._gen_ws = torch.zeros(int(wsb), dtype=torch.uint8, device=dev)      # (zero-filled once, see Transformer._workspace)
+        # Sampling without the logits round trip (mm_fused_*): every row's k-th largest logit is bounded before its logits exist and the bound is
+        # VERIFIED per row on the device; a row it cannot be proven for (heavy-tailed logits) raises `status` and the call is repeated on the
+        # logits path -- the ids never depend on the estimate.  Reading the flag is the one host synchronisation of generate(); under stream
+        # capture (hipGraph) it is not possible, so capture uses the logits path.
+        capturing = torch.cuda.is_current_stream_capturing()
+        status = None
+        if fused_sampling and not capturing:
+            status = torch.zeros(1, dtype=torch.int32, device=dev)
+            p.status = L.ptr(status)
+        else:
+            p.flags = L.MM_GEN_NO_FUSED_SAMPLING
         L.check(L.lib().mm_generate(h.ptr, L.stream(), C.byref(p), L.ptr(self._gen_ws), self._gen_ws.numel()), 'mm_generate')
+        if status is not None and int(status.item()) != 0:
+            self.fused_sampling_fallbacks += 1
+            p.flags, p.status = L.MM_GEN_NO_FUSED_SAMPLING, None
+            L.check(L.lib().mm_generate(h.ptr, L.stream(), C.byref(p), L.ptr(self._gen_ws), self._gen_ws.numel()), 'mm_generate')
         ids = ids.reshape(B, fmap, fmap)                                       # mmp.py:615
         if return_ids or not exists(self.vae):
             return ids

@@ -550,3 +550,54 @@ def gemm_w8a16(x, wq, scale, out_f32=False, resid=None, x_null=None, cond_scale=
     L.check(L.lib().mm_gemm_w8a16(L.stream(), L.ptr(x), L.ptr(x_null), x.stride(0), L.ptr(wq), wq.stride(0), L.ptr(scale), M, N, K, L.ptr(out),
                                   out.stride(0), int(f32o), L.ptr(resid), float(cond_scale)), 'mm_gemm_w8a16')
     return out
+
+
+# ------------------------------------------------------------------------------------------------ fused sampling (no logits round trip)
+FUSED_SLOT = 64
+
+
+def fused_buffers(R, V, device):
+    """caller-owned scratch of the fused sampling path for R rows of a V-entry vocabulary (include/muse_hip.h, mm_fused_*)"""
+    NT = V // 256
+    return dict(stats=torch.empty(R, NT, 4, dtype=torch.float32, device=device), cand=torch.empty(R, NT, FUSED_SLOT, 4, dtype=torch.float32, device=device),
+                fail=torch.zeros(1, dtype=torch.int32, device=device))
+
+
+def fused_z(k_keep, V, margin=0.20):
+    return float(L.lib().mm_fused_z(int(k_keep), int(V), float(margin)))
+
+
+def fused_threshold(emb_cond, emb_null, cond_scale, wmean, wcov_bf16, z):
+    _chk_cuda(emb_cond, emb_null, wmean, wcov_bf16)
+    assert wcov_bf16.dtype == bf16 and wmean.dtype == torch.float32
+    R, D = emb_cond.shape
+    thr = torch.empty(R, dtype=torch.float32, device=emb_cond.device)
+    ws = torch.empty(int(L.lib().mm_fused_threshold_workspace_bytes(R, D)), dtype=torch.uint8, device=emb_cond.device)
+    L.check(L.lib().mm_fused_threshold(L.stream(), L.ptr(emb_cond), L.ptr(emb_null), emb_cond.stride(0), R, D, float(cond_scale), L.ptr(wmean), L.ptr(wcov_bf16),
+                                       float(z), L.ptr(ws), L.ptr(thr)), 'mm_fused_threshold')
+    return thr
+
+
+def gemm_cfg_logits_fused(x_cond, x_null, w, cond_scale, thr, fb):
+    _chk_cuda(x_cond, x_null, w, thr)
+    M, K = x_cond.shape
+    N = w.shape[0]
+    L.check(L.lib().mm_gemm_cfg_logits_fused(L.stream(), L.ptr(x_cond), L.ptr(x_null), x_cond.stride(0), L.ptr(w), w.stride(0), M, N, K, float(cond_scale),
+                                             L.ptr(thr), L.ptr(fb['stats']), L.ptr(fb['cand'])), 'mm_gemm_cfg_logits_fused')
+
+
+def fused_emit(logits, thr, fb):
+    _chk_cuda(logits, thr)
+    R, V = logits.shape
+    L.check(L.lib().mm_fused_emit(L.stream(), L.ptr(logits), logits.stride(0), R, V, L.ptr(thr), L.ptr(fb['stats']), L.ptr(fb['cand'])), 'mm_fused_emit')
+
+
+def fused_sample(fb, thr, R, V, k_keep, temperature, rows=None, noise_kind=L.MM_NOISE_NONE, noise=None, seed=0, row_offset=0, step=0):
+    """-> (pred int64 [R], score fp32 [R]); fb['fail'] is set to 1 if a row's candidates could not be proven complete"""
+    dev = fb['stats'].device
+    pred = torch.empty(R, dtype=torch.long, device=dev)
+    score = torch.empty(R, dtype=torch.float32, device=dev)
+    L.check(L.lib().mm_fused_sample(L.stream(), L.ptr(thr), L.ptr(fb['stats']), L.ptr(fb['cand']), R, V, int(k_keep), L.ptr(rows), float(temperature),
+                                    int(noise_kind), L.ptr(noise), noise.stride(0) if noise is not None else 0, int(seed), int(row_offset), int(step), None, None,
+                                    L.ptr(pred), L.ptr(score), L.ptr(fb['fail'])), 'mm_fused_sample')
+    return pred, score

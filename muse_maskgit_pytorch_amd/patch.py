@@ -128,6 +128,7 @@ def _maskgit_shadow(ref):
               'critic_loss_weight', 'self_cond_prob', 'no_mask_token_prob'):
         setattr(sh, k, getattr(ref, k))
     sh._gen_ws = None
+    sh.fused_sampling_fallbacks = 0
     ref.__dict__[_SHADOW] = sh
     return sh
 

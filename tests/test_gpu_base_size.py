@@ -121,6 +121,10 @@ def test_generate_at_base_size_against_the_reference_run(base, noise, precision)
                 logits = tr.forward_with_cond_scale(ids_in.to(DEV), text_embeds=te, cond_scale=3.).cpu()
                 new_ids, scores, _ = O.sample_step(logits, O.gumbel_from_uniform(noise[s]), ids_in, 65536, temps[s])
                 assert torch.equal(new_ids, st_ids[s]), f'bf16 fused engine vs general path + oracle tail: ids after step {s} differ in {(new_ids != st_ids[s]).sum().item()} places'
+            # sampling without the logits round trip (default) against the logits path: same ids, no fallback needed
+            assert mg.fused_sampling_fallbacks == 0
+            ids2 = mg.generate(['a', 'b'], timesteps=R.T, cond_scale=3., text_embeds=te, noise=u, noise_kind='uniform', return_ids=True, fused_sampling=False)
+            assert torch.equal(ids, ids2), f'fused sampling vs logits path: {(ids != ids2).sum().item()} ids differ'
         del u
     finally:
         mg.set_precision('bf16')

@@ -1,0 +1,139 @@
+"""Sampling without the logits round trip (csrc/sampling_fused.hip + the emission in gemm_cfg.hip) against the logits path
+(mm_gemm_cfg_logits + mm_sample_rows, itself bit-exact against the oracle: tests/test_gpu_ops.py): same predicted ids on the same logits,
+confidences to fp32 round-off, for every noise mode; the GEMM's emission equals the emission computed from its materialised logits; rows
+whose candidate set cannot be proven complete raise the flag instead of returning a wrong id."""
+import math
+
+import pytest
+import torch
+
+import muse_maskgit_pytorch_amd as mm
+from muse_maskgit_pytorch_amd import _lib, ops
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _both(logits, k_keep, T, **kw):
+    R, V = logits.shape
+    ref_pred, ref_score = ops.sample_rows(logits, k_keep, T, **kw)
+    fb = ops.fused_buffers(R, V, DEV)
+    z = ops.fused_z(k_keep, V)
+    thr = (logits.mean(dim=1) + z * logits.std(dim=1)).contiguous()
+    ops.fused_emit(logits, thr, fb)
+    pred, score = ops.fused_sample(fb, thr, R, V, k_keep, T, **kw)
+    return ref_pred, ref_score, pred, score, fb
+
+
+@pytest.mark.parametrize('V,R', [(65536, 37), (8192, 64), (1024, 5), (256, 3)])
+@pytest.mark.parametrize('mode', ['philox', 'uniform', 'none'])
+def test_fused_sample_equals_sample_rows(V, R, mode):
+    g = torch.Generator().manual_seed(V + R)
+    logits = (torch.randn(R, V, generator=g) * 2.5 + torch.randn(R, 1, generator=g)).to(DEV)
+    k_keep = math.ceil(0.1 * V)
+    kw = {}
+    if mode == 'philox':
+        kw = dict(noise_kind=_lib.MM_NOISE_PHILOX, seed=1234, row_offset=77, step=5)
+    elif mode == 'uniform':
+        kw = dict(noise_kind=_lib.MM_NOISE_UNIFORM, noise=torch.rand(R, V, generator=g).to(DEV))
+    for T in (1.0, 0.5, 1e-10):
+        ref_pred, ref_score, pred, score, fb = _both(logits, k_keep, T, **kw)
+        assert int(fb['fail'].item()) == 0
+        assert torch.equal(pred, ref_pred), f'T={T}: {(pred != ref_pred).sum().item()} of {R} ids differ'
+        assert (score - ref_score).abs().max().item() < 2e-6
+
+
+def test_fused_sample_hot_tile_and_failure_paths():
+    """a tile whose 256 entries all pass the bound fills its slot completely (it cannot overflow), still exact; a heavy-tailed row whose
+    bound estimate keeps fewer than k entries raises the flag (the caller repeats on the logits path)"""
+    g = torch.Generator().manual_seed(9)
+    R, V = 6, 65536
+    logits = torch.randn(R, V, generator=g)
+    logits[:, 512:768] += 6.0                                        # one hot tile: 256 candidates in a 64-entry slot
+    logits = logits.to(DEV)
+    k_keep = math.ceil(0.1 * V)
+    ref_pred, ref_score, pred, score, fb = _both(logits, k_keep, 1.0, noise_kind=_lib.MM_NOISE_PHILOX, seed=5)
+    assert int(fb['fail'].item()) == 0
+    assert torch.equal(pred, ref_pred) and (score - ref_score).abs().max().item() < 2e-6
+    # heavy tail: a few huge outliers inflate sigma, the Gaussian bound lands far above the true 90th percentile
+    lt = torch.randn(4, V, generator=g)
+    lt[:, :40] = 4000.
+    lt = lt.to(DEV)
+    fb = ops.fused_buffers(4, V, DEV)
+    thr = (lt.mean(dim=1) + ops.fused_z(k_keep, V) * lt.std(dim=1)).contiguous()
+    ops.fused_emit(lt, thr, fb)
+    ops.fused_sample(fb, thr, 4, V, k_keep, 1.0)
+    assert int(fb['fail'].item()) == 1
+
+
+@pytest.mark.parametrize('M', [4608, 5140, 129])
+def test_gemm_emission_equals_emission_from_its_logits(M):
+    """the guidance-logits GEMM with the fused epilogue emits exactly what fused_emit computes from the logits the plain GEMM writes;
+    and the threshold estimated from the embeddings + vocabulary statistics keeps >= k candidates per row"""
+    torch.manual_seed(M)
+    V, D = 65536, 512
+    W = (torch.randn(V, D) * (D ** -0.5)).to(torch.bfloat16).to(DEV)
+    ec = torch.randn(M, D).to(torch.bfloat16).to(DEV)
+    en = torch.randn(M, D).to(torch.bfloat16).to(DEV)
+    s = 3.0
+    Wf = W.float()
+    wmean = Wf.mean(dim=0).contiguous()
+    wcov = ((Wf.t() @ Wf) / V - torch.outer(wmean, wmean)).to(torch.bfloat16).contiguous()
+    k_keep = math.ceil(0.1 * V)
+    z = ops.fused_z(k_keep, V)
+    thr = ops.fused_threshold(ec, en, s, wmean, wcov, z)
+    logits = ops.gemm_cfg_logits(ec, en, W, s)
+    direct = logits.mean(dim=1) + z * logits.std(dim=1)
+    assert (thr - direct).abs().max().item() < 0.02 * logits.std().item()
+    fa, fb = ops.fused_buffers(M, V, DEV), ops.fused_buffers(M, V, DEV)
+    ops.fused_emit(logits, thr, fa)
+    ops.gemm_cfg_logits_fused(ec, en, W, s, thr, fb)
+    assert torch.equal(fa['stats'].view(torch.int32), fb['stats'].view(torch.int32))
+    masks = fa['stats'][..., 2:].contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    lanes = sum(((masks >> b) & 1) for b in range(32)).sum(dim=-1)                          # kept lanes per (row, tile)
+    valid = torch.arange(ops.FUSED_SLOT, device=DEV)[None, None, :] < lanes[..., None]
+    assert torch.equal(fa['cand'][valid].view(torch.int32), fb['cand'][valid].view(torch.int32))
+    total = (logits >= thr[:, None]).sum(dim=1)
+    assert int(total.min().item()) >= k_keep and int(total.max().item()) < 11264
+    pa, sa = ops.fused_sample(fa, thr, M, V, k_keep, 1.0, noise_kind=_lib.MM_NOISE_PHILOX, seed=3)
+    pb, sb = ops.fused_sample(fb, thr, M, V, k_keep, 1.0, noise_kind=_lib.MM_NOISE_PHILOX, seed=3)
+    ref_pred, ref_score = ops.sample_rows(logits, k_keep, 1.0, noise_kind=_lib.MM_NOISE_PHILOX, seed=3)
+    assert int(fa['fail'].item()) == 0 and int(fb['fail'].item()) == 0
+    assert torch.equal(pa, ref_pred) and torch.equal(pb, ref_pred) and torch.equal(sa, sb)
+
+
+def test_generate_with_fused_sampling_at_bench_size_and_its_fallback():
+    """mm_generate at B = 32: the fused path is taken (no fallback on Gaussian-like logits), is repeatable, and a model whose logits defeat
+    the bound (a few enormous to_logits rows) falls back to the logits path and returns that path's ids"""
+    import bench
+    mg, _ = bench.build_models(DEV)
+    tr = mg.transformer
+    with torch.no_grad():
+        tr.to_logits.weight.mul_(8.)          # well-separated confidences: the two paths' last-bit score differences cannot reorder the re-masking
+    te = bench.synth_text(32, 32, 512).to(DEV)
+    ta, tb = {}, {}
+    a = mg.generate([''] * 32, timesteps=18, cond_scale=3, text_embeds=te, seed=7, return_ids=True, trace=ta)
+    assert mg.fused_sampling_fallbacks == 0 and tr._model().packed['wcov'] is not None
+    b = mg.generate([''] * 32, timesteps=18, cond_scale=3, text_embeds=te, seed=7, return_ids=True, fused_sampling=False, trace=tb)
+    # Same logits, same noise -> the same predictions wherever the two paths sample the same state.  The confidences agree to round-off only
+    # (the softmax denominator is summed in a different order), so a re-masking decision between two tokens whose scores differ in the last
+    # bit may go the other way; from there the trajectories differ by design (the reference has the same sensitivity).  Step 0 starts from
+    # the same all-masked state and must agree exactly; afterwards the first divergence must be such a last-bit tie.
+    assert torch.equal(ta['ids'][0], tb['ids'][0])
+    assert (ta['scores'][0] - tb['scores'][0]).abs().max().item() < 1e-6
+    same = [bool(torch.equal(ta['masked_ids'][s_], tb['masked_ids'][s_])) for s_ in range(18)]
+    if not all(same):
+        s0 = same.index(False)                     # first step whose re-masked state differs: the scores of step s0 - 1 decided it
+        sa, sb = ta['scores'][s0 - 1], tb['scores'][s0 - 1]
+        assert torch.equal(ta['ids'][s0 - 1], tb['ids'][s0 - 1]) and (sa - sb).abs().max().item() < 1e-6
+        print(f'[fused sampling] trajectories part at step {s0}: a last-bit confidence difference reordered the re-masking; final agreement '
+              f'{100 * (a == b).float().mean().item():.2f} %')
+    assert (a == b).float().mean().item() > 0.99
+    assert torch.equal(a, mg.generate([''] * 32, timesteps=18, cond_scale=3, text_embeds=te, seed=7, return_ids=True))
+    # heavy-tailed vocabulary: 30 huge rows inflate sigma, the Gaussian bound keeps fewer than k entries -> flag -> logits path
+    with torch.no_grad():
+        tr.to_logits.weight[:30].mul_(400.)
+    c = mg.generate([''] * 32, timesteps=6, cond_scale=3, text_embeds=te, seed=7, return_ids=True)
+    assert mg.fused_sampling_fallbacks == 1
+    d = mg.generate([''] * 32, timesteps=6, cond_scale=3, text_embeds=te, seed=7, return_ids=True, fused_sampling=False)
+    assert torch.equal(c, d)
