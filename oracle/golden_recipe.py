@@ -16,11 +16,15 @@ WEIGHT_SEED, VAE_SEED, EDIT_SEED, INPUT_SEED, NOISE_SEED = 0, 1, 4321, 77, 20260
 PEAK = 8.0      # to_logits scale of the decode run: well-separated confidences (SURVEY 8c determinism control 3)
 
 
-def build_transformer(cls, peaky):
+C4_CFG = dict(num_tokens=65536, seq_len=1024, dim=512, depth=8, dim_head=64, heads=8, ff_mult=4, t5_name='t5-small')      # BASELINE configs[3]
+C4_T, C4_NOISE_SEED, C4_WEIGHT_SEED = 6, 20260925, 2
+
+
+def build_transformer(cls, peaky, cfg=None, seed=None):
     """cls = MaskGitTransformer of the reference or of this package.  Module-default init under WEIGHT_SEED, learned scales / norm gains
     made non-trivial, optionally peaky logits, everything rounded to bf16-representable fp32 (exactly loadable by the bf16 engine)."""
-    torch.manual_seed(WEIGHT_SEED)
-    tr = cls(**BASE_CFG)
+    torch.manual_seed(WEIGHT_SEED if seed is None else seed)
+    tr = cls(**(BASE_CFG if cfg is None else cfg))
     gen = torch.Generator().manual_seed(EDIT_SEED)
     with torch.no_grad():
         for name, p in tr.named_parameters():
@@ -54,11 +58,22 @@ def inputs():
     return dict(ids=ids, text_embeds=te, vae_ids=vae_ids, image=image)
 
 
-def noise_stream(steps=T):
+def noise_stream(steps=T, seed=NOISE_SEED, shape=None):
     """the U(0,1) tensors the reference's gumbel_noise drew during generate(), step by step, from torch's CPU generator"""
-    torch.manual_seed(NOISE_SEED)
+    torch.manual_seed(seed)
     for _ in range(steps):
-        yield torch.zeros(B, N, BASE_CFG['num_tokens']).uniform_(0, 1)
+        yield torch.zeros(*(shape or (B, N, BASE_CFG['num_tokens']))).uniform_(0, 1)
+
+
+def c4_inputs():
+    """super-resolution case, batch 1: 1024 token ids (half masked), text, a 256 x 256 low-resolution condition image"""
+    g = torch.Generator().manual_seed(INPUT_SEED + 1)
+    ids = torch.randint(0, 65536, (1, 1024), generator=g)
+    ids[torch.rand(1, 1024, generator=g) < 0.5] = 65536
+    te = torch.randn(1, L, 512, generator=g)
+    te[0, L - 3:] = 0
+    cond_image = torch.randn(1, 3, 256, 256, generator=g)
+    return dict(ids=ids, text_embeds=te, cond_image=cond_image)
 
 
 def checksum(t):

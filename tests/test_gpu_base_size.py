@@ -161,3 +161,81 @@ def test_vqgan_vae_dim_256_against_the_reference(base, precision):
         assert safe.float().mean().item() > 0.95 and same.float().mean().item() > 0.99
     d = (fmap[:, ::16].float().cpu() - v['enc_fmap_strided']).abs().amax(dim=1)          # (B, 16, 16): project_out(+-1 codes) of equal ids is the same sum
     assert d[same.reshape(R.B, 16, 16)].max().item() <= (1e-5 if precision == 'parity' else 2e-2)
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs[3]: super-resolution at full size
+C4_ROWS = [0, 77, 255, 256, 511, 700, 1000, 1023]
+
+
+@pytest.fixture(scope='module')
+def superres(golden):
+    import muse_maskgit_pytorch_amd as mm
+    g = golden('superres_c4.pt')
+    tr = R.build_transformer(mm.MaskGitTransformer, peaky=False, cfg=R.C4_CFG, seed=R.C4_WEIGHT_SEED)
+    assert R.state_checksum(tr) == g['weight_checksum']
+    mg = mm.MaskGit(vae=R.build_vae(mm.VQGanVAE), transformer=tr, image_size=512, cond_image_size=256).to(DEV).eval()
+    assert R.state_checksum(mg.vae) == g['vae_weight_checksum']
+    inp = R.c4_inputs()
+    assert {k: R.checksum(v.float()) for k, v in inp.items()} == g['input_checksum']
+    return g, mg, inp
+
+
+@pytest.mark.parametrize('precision', PRECISIONS)
+def test_superres_forward_and_generate_at_full_size(superres, precision):
+    """configs[3] (1024 tokens, 256 low-resolution condition ids + text in the cross-attention context, V = 65536), batch 1, against the
+    reference's fp32 run: condition ids from the low-resolution VAE, logits of the conditioned / null / guidance passes, and a 6-step
+    generate with the reference's noise.  parity engine: ids 100 %, logits within 1e-3; bf16 engine: its own bounds, ids reported."""
+    g, mg, inp = superres
+    tr = mg.transformer
+    te = inp['text_embeds'].to(DEV)
+    mg.set_precision(precision)
+    try:
+        _, cids, _ = mg.cond_vae.encode(inp['cond_image'].to(DEV))
+        agree = (cids.cpu() == g['cond_ids']).float().mean().item()
+        print(f'[super-res parity] {precision} condition ids equal to the reference: {100 * agree:.2f} %')
+        if precision == 'parity':
+            assert agree == 1.0
+        cids = g['cond_ids'].to(DEV)                         # the forward is compared on the reference's condition ids
+        ids = inp['ids'].to(DEV)
+        lc, emb = tr(ids, text_embeds=te, cond_drop_prob=0., conditioning_token_ids=cids, return_embed=True)
+        ln = tr(ids, text_embeds=te, cond_drop_prob=1., conditioning_token_ids=cids)
+        sc = tr.forward_with_cond_scale(ids, text_embeds=te, conditioning_token_ids=cids, cond_scale=3.)
+        fw = g['forward']
+        tol = 1e-3 if precision == 'parity' else 2.5e-2
+        for name, got, rec, k in (('logits(cond)', lc, fw['logits_cond'], 1), ('logits(null)', ln, fw['logits_null'], 1), ('logits(guidance)', sc, fw['logits_scaled'], 5)):
+            f = got.reshape(1024, -1)
+            _err(f'{precision} super-res {name} full rows', f[C4_ROWS], rec['rows'], tol * k)
+            _err(f'{precision} super-res {name} strided columns', f[:, ::128], rec['cols'], tol * k)
+        _err(f'{precision} super-res embed', emb.reshape(1, 1024, -1), fw['embed'], 1e-3 if precision == 'parity' else 4e-2)
+        # ---- generate, peaky logits, the reference's noise
+        gen = g['generate']
+        us = []
+        for s, u in enumerate(R.noise_stream(R.C4_T, R.C4_NOISE_SEED, (1, 1024, 65536))):
+            assert R.checksum(u) == gen['noise_checksum'][s]
+            us.append(u)
+        noise = torch.stack(us).to(DEV)
+        with torch.no_grad():
+            tr.to_logits.weight.mul_(R.PEAK)
+        try:
+            assert R.state_checksum(tr) == g['weight_checksum_peaky']
+            trace = {}
+            out = mg.generate(['a'], cond_images=inp['cond_image'].to(DEV), timesteps=R.C4_T, cond_scale=3., text_embeds=te, noise=noise, noise_kind='uniform',
+                              return_ids=True, trace=trace)
+            masked = torch.stack(list(trace['masked_ids'])).cpu() if isinstance(trace['masked_ids'], list) else trace['masked_ids'].cpu()
+            steps = [(masked[s] == gen['step_in_ids'][s].long()).float().mean().item() for s in range(R.C4_T)]
+            final = (out.cpu().reshape(gen['final_ids'].shape) == gen['final_ids']).float().mean().item()
+            print(f'[super-res parity] {precision} generate: final ids equal to the reference run {100 * final:.2f} %, per-step states min {100 * min(steps):.2f} %')
+            if precision == 'parity':
+                assert final == 1.0 and min(steps) == 1.0
+            else:
+                assert final >= 0.85
+                assert mg.fused_sampling_fallbacks == 0
+                out2 = mg.generate(['a'], cond_images=inp['cond_image'].to(DEV), timesteps=R.C4_T, cond_scale=3., text_embeds=te, noise=noise, noise_kind='uniform',
+                                   return_ids=True, fused_sampling=False)
+                assert (out == out2).float().mean().item() > 0.99
+        finally:
+            with torch.no_grad():
+                tr.to_logits.weight.div_(R.PEAK)
+    finally:
+        mg.set_precision('bf16')
+        torch.cuda.empty_cache()

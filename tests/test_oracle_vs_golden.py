@@ -230,3 +230,23 @@ def test_oracle_vae_matches_reference_at_dim_256(golden):
     close(dec[:, :, ::4, ::4], v['decoded_strided'], 2e-5); close(dec[:, :, 96:160, 96:160], v['decoded_crop'], 2e-5)
     assert torch.equal(ids, v['enc_ids'])
     close(fmap[:, ::16], v['enc_fmap_strided'], 2e-5)
+
+
+def test_oracle_forward_matches_reference_at_superres_size(golden):
+    """BASELINE configs[3] at full size (1024 tokens, 256 condition ids in the cross-attention context, V = 65536), batch 1"""
+    import golden_recipe as R
+    import muse_maskgit_pytorch_amd as mm
+    g = golden('superres_c4.pt')
+    tr = R.build_transformer(mm.MaskGitTransformer, peaky=False, cfg=R.C4_CFG, seed=R.C4_WEIGHT_SEED)
+    assert R.state_checksum(tr) == g['weight_checksum']
+    sd = {k: v.detach() for k, v in tr.state_dict().items()}
+    inp = R.c4_inputs()
+    cfg = dict(depth=8, heads=8)
+    with torch.no_grad():
+        lc, emb = O.transformer_forward(sd, cfg, inp['ids'], inp['text_embeds'], 0., conditioning_token_ids=g['cond_ids'], return_embed=True)
+        ln = O.transformer_forward(sd, cfg, inp['ids'], inp['text_embeds'], 1., conditioning_token_ids=g['cond_ids'])
+    fw = g['forward']
+    for got, rec in ((lc, fw['logits_cond']), (ln, fw['logits_null']), (ln + (lc - ln) * 3., fw['logits_scaled'])):
+        f = got.reshape(1024, -1)
+        close(f[g['full_rows']], rec['rows'], 3e-5); close(f[:, ::128], rec['cols'], 3e-5)
+    close(emb, fw['embed'], 3e-5)
