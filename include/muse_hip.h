@@ -270,6 +270,42 @@ int mm_lfq_encode(mm_stream_t stream, const void* x, int64_t count, int C, int b
 int mm_nchw_f32_to_nhwc8_bf16(mm_stream_t stream, const float* img, int B, int C, int H, int W, void* out);
 int mm_nhwc_bf16_to_nchw_f32(mm_stream_t stream, const void* x, int B, int C, int H, int W, float* out);
 
+/* ---- composite VQGanVAE entry points (vqgan_vae.py:422-441): the ResnetEncDec layer list + LFQ on one stream, one call per encode / decode.
+ * A layer is one entry of ResnetEncDec.encoders / .decoders (vqgan_vae.py:223-232); weights packed as for mm_conv2d_nhwc (bf16 [Cout][Kp]),
+ * biases / GroupNorm parameters fp32. */
+#define MM_VAE_STEM 0   /* Conv2d(channels, dim, k, padding k/2): w[0] packed with Cin padded to 8, b[0]                       */
+#define MM_VAE_DOWN 1   /* Conv2d(4, stride 2, pad 1) + LeakyReLU(0.1): w[0], b[0]                                             */
+#define MM_VAE_RES 2    /* ResBlock: conv3 w[0] b[0], GroupNorm gn_g/gn_b[0], conv3 w[1] b[1], GroupNorm [1], conv1 w[2] b[2]   */
+#define MM_VAE_GLU 3    /* GLUResBlock: conv3 (C -> 2C) w[0] b[0], GLU, GroupNorm [0], conv3 w[1] b[1], GLU, GroupNorm [1], conv1 w[2] b[2] */
+#define MM_VAE_UP 4     /* ConvTranspose2d(4,2,1) + LeakyReLU(0.1): w[0..3] = parity matrices (py*2+px), b[0]                   */
+#define MM_VAE_HEAD 5   /* Conv2d(dim, channels, 1): w[0], b[0]; writes the NCHW fp32 image                                     */
+typedef struct mm_vae_layer {
+    int32_t kind, cout, k, groups;
+    const void* w[4];
+    const float* b[3];
+    const float* gn_g[2];
+    const float* gn_b[2];
+} mm_vae_layer;
+typedef struct mm_vae_desc {
+    int32_t channels, encoded_dim, bits, n_enc, n_dec, reserved;
+    const mm_vae_layer* enc;        /* host array [n_enc]: stem, then down-sampling convolutions / residual blocks in list order */
+    const mm_vae_layer* dec;        /* host array [n_dec]: GLU blocks / up-sampling convolutions in list order, head last       */
+    const float* lfq_wi; const float* lfq_bi;      /* project_in  [bits][encoded_dim], [bits]  (NULL when encoded_dim == bits) */
+    const float* lfq_wo; const float* lfq_bo;      /* project_out [encoded_dim][bits], [encoded_dim]                            */
+} mm_vae_desc;
+typedef struct mm_vae mm_vae_t;
+int mm_vae_create(const mm_vae_desc* desc, mm_vae_t** out);
+void mm_vae_destroy(mm_vae_t* vae);
+size_t mm_vae_decode_workspace_bytes(const mm_vae_t* vae, int B, int h, int w);
+size_t mm_vae_encode_workspace_bytes(const mm_vae_t* vae, int B, int H, int W);
+/* VQGanVAE.decode_from_ids (vqgan_vae.py:427-438): ids int64 [B][h][w] -> image fp32 [B][channels][h*2^ups][w*2^ups] */
+int mm_vae_decode_from_ids(const mm_vae_t* vae, mm_stream_t stream, const int64_t* ids, int B, int h, int w, float* image, void* workspace,
+                           size_t workspace_bytes);
+/* VQGanVAE.encode (vqgan_vae.py:422-425): image fp32 [B][channels][H][W] -> ids int64 [B][h][w] (+ the quantized feature map fp32
+ * [B][encoded_dim][h][w] when fmap_out != NULL) */
+int mm_vae_encode(const mm_vae_t* vae, mm_stream_t stream, const float* image, int B, int H, int W, float* fmap_out, int64_t* ids_out, void* workspace,
+                  size_t workspace_bytes);
+
 /* ------------------------------------------------------------------------------------------------ parity engine (fp32)
  * Precision level L0: fp32 storage + fp32 MFMA (v_mfma_f32_32x32x2_f32), the reference's operator sequence one to one, no
  * fusion that changes a rounding point.  This is what `set_precision('parity')` of the Python classes runs: logits / pixels within 1e-3
@@ -390,6 +426,7 @@ int mm_transformer_forward(const mm_transformer_t* model, mm_stream_t stream, co
  * scores fp32 [B][n].  Optional traces [timesteps][B][n]: trace_masked_ids (ids after the re-mask scatter),
  * trace_ids / trace_scores (state after each step). */
 #define MM_GEN_NO_FUSED_SAMPLING 1   /* flags: always materialise the logits (mm_gemm_cfg_logits + mm_sample_rows) */
+#define MM_GEN_CAN_REMASK 2          /* flags: can_remask_prev_masked (mmp.py:608-609): every position is sampled and scored at every step */
 typedef struct mm_generate_params {
     int32_t batch, n, timesteps, k_keep, noise_kind, nc, L, flags;
     float cond_scale;
@@ -409,9 +446,24 @@ typedef struct mm_generate_params {
      * logits exist; the finishing kernel verifies the bound per row and sets *status = 1 when a row's candidates cannot be proven to contain
      * its kept set (heavy-tailed logits).  The ids of that call are then invalid: repeat it with MM_GEN_NO_FUSED_SAMPLING. */
     int32_t* status;
+    /* ---- decode variants, all inside the same loop (zero / NULL = off).  cond_scale == 1 runs the single conditional pass (mmp.py:247-248); a
+     * transformer created with self_cond feeds every step's cond-pass embed into the next step (mmp.py:325-328, 574).
+     * Critic scores (mmp.py:590-601): scores = critic(ids) + (u - 0.5) * critic_noise_scale * (timesteps - 1 - step) / timesteps replace the
+     * sampler's 1 - p.  `critic` = a TokenCritic (transformer with dim_out == 1, its own embeddings / context); critic_head_w / _b = a SelfCritic
+     * (mmp.py:352-374): Linear(dim, 1) (bf16 [dim] weight, fp32 [1] bias) on this model's cond-pass embed of the new ids.  Exclusive. */
+    const mm_transformer_t* critic;
+    const void* critic_head_w;
+    const float* critic_head_b;
+    const float* critic_noise;      /* device fp32 [timesteps][B][n]: the U(0,1) draws of mmp.py:601 (required with a critic) */
+    float critic_noise_scale;
+    float pad1;
+    void* critic_workspace;         /* device, >= mm_generate_critic_workspace_bytes(critic or model, ...) */
+    size_t critic_workspace_bytes;
 } mm_generate_params;
 
 size_t mm_generate_workspace_bytes(const mm_transformer_t* model, int B, int n, int L, int nc);
+/* workspace of the critic passes: pass the TokenCritic handle, or the generator's own handle for a SelfCritic */
+size_t mm_generate_critic_workspace_bytes(const mm_transformer_t* critic, int B, int n, int L, int nc);
 int mm_generate(const mm_transformer_t* model, mm_stream_t stream, const mm_generate_params* params,
                 void* workspace, size_t workspace_bytes);
 

@@ -14,6 +14,7 @@ HEADER_PATH = os.path.join(HERE, '..', 'include', 'muse_hip.h')
 MM_OK = 0
 MM_NOISE_NONE, MM_NOISE_GUMBEL, MM_NOISE_UNIFORM, MM_NOISE_PHILOX = 0, 1, 2, 3
 MM_GEN_NO_FUSED_SAMPLING = 1
+MM_GEN_CAN_REMASK = 2
 
 c_i64, c_int, c_f32, c_vp, c_u64, c_u32, c_sz = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_uint64, C.c_uint32, C.c_size_t
 
@@ -41,12 +42,23 @@ class TransformerDesc(C.Structure):
                 ('final_gamma', c_vp), ('final_beta', c_vp), ('to_logits', c_vp), ('self_cond_ff', FFWeights), ('logits_wmean', c_vp), ('logits_wcov', c_vp)]
 
 
+class VaeLayer(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('kind', 'cout', 'k', 'groups')] + [('w', c_vp * 4), ('b', c_vp * 3), ('gn_g', c_vp * 2), ('gn_b', c_vp * 2)]
+
+
+class VaeDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('channels', 'encoded_dim', 'bits', 'n_enc', 'n_dec', 'reserved')] + \
+               [('enc', C.POINTER(VaeLayer)), ('dec', C.POINTER(VaeLayer)), ('lfq_wi', c_vp), ('lfq_bi', c_vp), ('lfq_wo', c_vp), ('lfq_bo', c_vp)]
+
+
 class GenerateParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('batch', 'n', 'timesteps', 'k_keep', 'noise_kind', 'nc', 'L', 'flags')] + \
                [('cond_scale', c_f32), ('pad0', c_f32), ('seed', c_u64), ('row_offset', c_u64),
                 ('mask_counts', C.POINTER(C.c_int32)), ('temperatures', C.POINTER(c_f32)),
                 ('text_embeds', c_vp), ('cond_ids', c_vp), ('noise', c_vp), ('ids', c_vp), ('scores', c_vp),
-                ('trace_masked_ids', c_vp), ('trace_ids', c_vp), ('trace_scores', c_vp), ('status', c_vp)]
+                ('trace_masked_ids', c_vp), ('trace_ids', c_vp), ('trace_scores', c_vp), ('status', c_vp),
+                ('critic', c_vp), ('critic_head_w', c_vp), ('critic_head_b', c_vp), ('critic_noise', c_vp), ('critic_noise_scale', c_f32),
+                ('pad1', c_f32), ('critic_workspace', c_vp), ('critic_workspace_bytes', c_sz)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/muse_hip.h must appear here (tests check both ways)
@@ -102,6 +114,12 @@ SIGNATURES = {
     'mm_lfq_encode': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'mm_nchw_f32_to_nhwc8_bf16': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     'mm_nhwc_bf16_to_nchw_f32': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    'mm_vae_create': (c_int, [C.POINTER(VaeDesc), C.POINTER(c_vp)]),
+    'mm_vae_destroy': (None, [c_vp]),
+    'mm_vae_decode_workspace_bytes': (c_sz, [c_vp, c_int, c_int, c_int]),
+    'mm_vae_encode_workspace_bytes': (c_sz, [c_vp, c_int, c_int, c_int]),
+    'mm_vae_decode_from_ids': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_sz]),
+    'mm_vae_encode': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_sz]),
     'mm_f32_gemm': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_int, c_vp]),
     'mm_f32_conv2d_nhwc': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int] + [c_int] * 12 + [c_vp, c_int, c_vp, c_vp, c_int]),
     'mm_f32_layernorm': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_i64]),
@@ -122,6 +140,7 @@ SIGNATURES = {
     'mm_transformer_context': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_sz]),
     'mm_transformer_workspace_bytes': (c_sz, [c_vp, c_int, c_int, c_int]),
     'mm_transformer_forward': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_sz]),
+    'mm_generate_critic_workspace_bytes': (c_sz, [c_vp, c_int, c_int, c_int, c_int]),
     'mm_generate_workspace_bytes': (c_sz, [c_vp, c_int, c_int, c_int, c_int]),
     'mm_generate': (c_int, [c_vp, c_vp, C.POINTER(GenerateParams), c_vp, c_sz]),
     'mm_debug_set': (c_int, [c_int]),

@@ -105,6 +105,29 @@ __global__ __launch_bounds__(256) void gather_cond_kernel(const bf16_t* __restri
     }
 }
 
+// self-conditioning input of the next step: the fp32 view of the bf16 cond-pass embed (what the reference hands back as `embed`, mmp.py:574)
+__global__ void bf16_to_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = bf16_to_f32(x[i]);
+}
+
+// can_remask_prev_masked (mmp.py:582-588, 603-609): every position was sampled; ids only change where the token was masked, the scores are the
+// sampled token's 1 - p at EVERY position
+__global__ void merge_pred_kernel(int64_t* __restrict__ ids, const int64_t* __restrict__ pred, float* __restrict__ scores, const float* __restrict__ conf,
+                                  int64_t mask_id, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        if (ids[i] == mask_id) ids[i] = pred[i];
+        scores[i] = conf[i];
+    }
+}
+
+// token-critic scores with the annealed noise (mmp.py:590-601): scores = critic + (u - 0.5) * critic_noise_scale * (steps_until_x0 / timesteps),
+// each product rounded to fp32 like the reference's tensor-times-scalar chain
+__global__ void critic_scores_kernel(const float* __restrict__ critic, const float* __restrict__ u, float noise_scale, float ratio,
+                                     float* __restrict__ scores, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        scores[i] = __fadd_rn(critic[i], __fmul_rn(__fmul_rn(__fadd_rn(u[i], -0.5f), noise_scale), ratio));
+}
+
 __global__ void fill_i64_kernel(int64_t* p, long n, int64_t v) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -419,7 +442,30 @@ struct GenBufs {
     float4* fs_cand;        // [B*n][V/256][FS_SLOT]
     void* fs_ws;            // scratch of the bound estimate (k_fused_threshold)
     void* ctx_ws; size_t ctx_ws_bytes;
+    // decode variants
+    float* sce;             // [B*n][D] fp32: the previous step's cond-pass embed (self-conditioning transformers)
+    bf16_t* emb_all;        // [B*n][D] the cond-pass embed of every position, as the final LayerNorm emits it
+    int64_t* pred;          // [B*n] compact sampler outputs (can_remask_prev_masked)
+    float* conf;            // [B*n]
 };
+// what a critic (mmp.py:590-601) needs per decode: its own context (a TokenCritic has its own embeddings / text projection), one forward workspace,
+// the embeds of its passes and the raw scores
+struct CriticBufs {
+    bf16_t* ctx; uint8_t* masks; void* ctx_ws; size_t ctx_ws_bytes;
+    bf16_t* embc; bf16_t* embn; float* sc; void* fwd_ws; size_t fwd_ws_bytes;
+};
+void carve_critic(Carver& c, const mm_transformer* ct, int B, int n, int L, int nc, CriticBufs& k) {
+    const int m = L + nc;
+    k.ctx = c.take<bf16_t>((size_t)B * m * ct->d.dim);
+    k.masks = c.take<uint8_t>((size_t)2 * B * m);
+    k.ctx_ws_bytes = mm_context_workspace_bytes(ct, B, L);
+    k.ctx_ws = c.take<unsigned char>(k.ctx_ws_bytes);
+    k.embc = c.take<bf16_t>((size_t)B * n * ct->d.dim);
+    k.embn = c.take<bf16_t>((size_t)B * n * ct->d.dim);
+    k.sc = c.take<float>((size_t)B * n + 64);
+    k.fwd_ws_bytes = mm_transformer_workspace_bytes(ct, B, n, m);
+    k.fwd_ws = c.take<unsigned char>(k.fwd_ws_bytes);
+}
 void carve_gen(Carver& c, const mm_transformer* t, int B, int n, int L, int nc, GenBufs& g) {
     const int D = t->d.dim, I = t->I, m = L + nc;
     carve_bufs(c, t, (size_t)2 * B * n, g.b);
@@ -442,6 +488,10 @@ void carve_gen(Carver& c, const mm_transformer* t, int B, int n, int L, int nc, 
     g.fs_ws = c.take<unsigned char>(fs ? k_fused_threshold_ws_bytes(B * n, D) : 0);
     g.ctx_ws_bytes = mm_context_workspace_bytes(t, B, L);
     g.ctx_ws = c.take<unsigned char>(g.ctx_ws_bytes);
+    g.sce = c.take<float>(t->d.self_cond ? (size_t)B * n * D : 0);
+    g.emb_all = c.take<bf16_t>(t->d.self_cond ? (size_t)B * n * D : 0);
+    g.pred = c.take<int64_t>((size_t)B * n);
+    g.conf = c.take<float>((size_t)B * n);
 }
 }  // namespace
 
@@ -488,6 +538,14 @@ size_t mm_generate_workspace_bytes(const mm_transformer_t* t, int B, int n, int 
     return c.used() + 256;
 }
 
+size_t mm_generate_critic_workspace_bytes(const mm_transformer_t* critic, int B, int n, int L, int nc) {
+    if (!critic) return 0;
+    Carver c(nullptr);
+    CriticBufs k;
+    carve_critic(c, critic, B, n, L, nc, k);
+    return c.used() + 256;
+}
+
 int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate_params* p, void* workspace, size_t workspace_bytes) {
     RC(check_model(t));
     if (!p) return mm_set_error(MM_ERR_SHAPE, "generate: params is NULL");
@@ -496,10 +554,25 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
     const int D = t->d.dim, I = t->I, V = t->d.dim_out;
     if (B <= 0 || n <= 0 || n > t->d.seq_len || T <= 0) return mm_set_error(MM_ERR_SHAPE, "generate: bad batch/n/timesteps");
     if (t->d.vocab_rows != t->d.num_tokens + 1) return mm_set_error(MM_ERR_SHAPE, "generate: transformer has no mask id (MaskGitTransformer required)");
-    if (t->d.self_cond) return mm_set_error(MM_ERR_UNSUPPORTED, "generate: self-conditioning transformers use the stepwise path");
     if (!p->mask_counts || !p->temperatures || !p->ids || !p->scores) return mm_set_error(MM_ERR_SHAPE, "generate: schedule / outputs required");
     if (m <= 0) return mm_set_error(MM_ERR_SHAPE, "generate: empty context");
-    if (p->cond_scale == 1.f) return mm_set_error(MM_ERR_UNSUPPORTED, "generate: cond_scale == 1 (single pass) uses the stepwise path");
+    // decode variants (mmp.py:556-609): single pass at cond_scale == 1 (mmp.py:247-248), self-conditioning (:325-328, 574), re-masking of
+    // previously unmasked tokens (:608-609), token critic / self critic scores (:590-601)
+    const bool single = p->cond_scale == 1.f;
+    const int P = single ? 1 : 2;                                  // passes of the transformer per step
+    const bool can_remask = (p->flags & MM_GEN_CAN_REMASK) != 0;
+    const bool self_cond = t->d.self_cond != 0;
+    const mm_transformer* critic = p->critic;
+    const bool self_critic = p->critic_head_w != nullptr;
+    const mm_transformer* cmodel = critic ? critic : (self_critic ? t : nullptr);      // the network the critic scores come from
+    if (critic && self_critic) return mm_set_error(MM_ERR_SHAPE, "generate: token critic and self critic are exclusive (mmp.py:456)");
+    if (critic && critic->d.dim_out != 1) return mm_set_error(MM_ERR_SHAPE, "generate: the token critic must have dim_out == 1");
+    if (cmodel) {
+        if (!p->critic_noise) return mm_set_error(MM_ERR_SHAPE, "generate: critic_noise [timesteps][B][n] required with a critic");
+        if (self_critic && !p->critic_head_b) return mm_set_error(MM_ERR_SHAPE, "generate: critic_head_b required with critic_head_w");
+        if (!p->critic_workspace || p->critic_workspace_bytes < mm_generate_critic_workspace_bytes(cmodel, B, n, L, nc))
+            return mm_set_error(MM_ERR_WORKSPACE, "generate: critic workspace too small (mm_generate_critic_workspace_bytes)");
+    }
     if ((p->noise_kind == MM_NOISE_GUMBEL || p->noise_kind == MM_NOISE_UNIFORM) && !p->noise)
         return mm_set_error(MM_ERR_SHAPE, "generate: noise tensor required for this noise_kind");
     if (workspace_bytes < mm_generate_workspace_bytes(t, B, n, L, nc)) return mm_set_error(MM_ERR_WORKSPACE, "generate: workspace too small");
@@ -528,7 +601,7 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
         const mm_attn_weights& w = t->layers[l].cross_attn;
         bf16_t* ckv_l = g.ckv + (size_t)l * B * m * 2 * I;
         RC(gemm_dense(s, g.ctx, D, (const bf16_t*)w.w_kv, D, B * m, 2 * I, D, ckv_l, 2 * I, OUT_BF16, nullptr));
-        if (nc == 0) {
+        if (nc == 0 && P == 2) {
             // softmax over the single unmasked (null) key is exactly 1 -> attention out = bf16(null_v) for every
             // query, so the null pass's cross-attention is the constant row to_out(null_v)
             RC(k_f32_to_bf16(s, w.null_v, g.nullv, I));
@@ -541,11 +614,28 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
         const hipError_t e = hipMemsetAsync(p->scores, 0, (size_t)M * 4, s);                          // mmp.py:520
         if (e != hipSuccess) return mm_set_hip_error(e, "generate: memset scores");
     }
+    // the critic's step-invariant context: a TokenCritic embeds / projects the text and the conditioning ids with its own weights; the self
+    // critic reads the generator's cond-pass context
+    CriticBufs cb;
+    memset(&cb, 0, sizeof(cb));
+    if (cmodel) {
+        Carver cc(p->critic_workspace);
+        carve_critic(cc, cmodel, B, n, L, nc, cb);
+        RC(mm_transformer_context(cmodel, stream, p->text_embeds, B, L, p->cond_ids, nc, 0, cb.ctx, cb.masks, cb.ctx_ws, cb.ctx_ws_bytes));
+        hipError_t e = hipMemsetAsync(cb.masks + (size_t)B * m, 0, (size_t)B * m, s);
+        if (e != hipSuccess) return mm_set_hip_error(e, "generate: memset critic masks");
+        if (nc > 0) {
+            e = hipMemset2DAsync(cb.masks + (size_t)B * m + L, m, 1, nc, B, s);
+            if (e != hipSuccess) return mm_set_hip_error(e, "generate: memset2d critic masks");
+        }
+    }
 
     Bufs& b = g.b;
+    const int seqs = P * B;          // sequences of one transformer pass over the batch: [cond B | null B]
     for (int step = 0; step < T; ++step) {
         const int k = p->mask_counts[step];
-        const int R = B * k;
+        const int R = can_remask ? M : B * k;                                                     // rows sampled at this step
+        const int32_t* rows = can_remask ? nullptr : g.rows;
         RC(k_mask_step(s, p->scores, p->ids, B, n, k, mask_id, g.rows));                            // mmp.py:558-563
         if (p->trace_masked_ids) {
             const hipError_t e = hipMemcpyAsync(p->trace_masked_ids + (size_t)step * M, p->ids, (size_t)M * 8, hipMemcpyDeviceToDevice, s);
@@ -553,7 +643,9 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
         }
         // both CFG halves see the same ids: rows [0, M) = cond pass, [M, 2M) = null pass (mmp.py:250-252)
         RC(k_embed(s, p->ids, M, n, 0, (const bf16_t*)t->d.token_emb, t->d.vocab_rows, (const bf16_t*)t->d.pos_emb, D, b.x));
-        {
+        if (self_cond && step > 0)                      // x += self_cond_to_init_embed(previous cond embed), mmp.py:325-328 (FF(zeros) = 0 at step 0)
+            RC(ff_block(t, s, t->d.self_cond_ff, g.sce, b.x, M, b));
+        if (P == 2) {
             const hipError_t e = hipMemcpyAsync(b.x + (size_t)M * D, b.x, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s);
             if (e != hipSuccess) return mm_set_hip_error(e, "generate: x copy");
         }
@@ -561,45 +653,51 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
         // self-attention has mixed the tokens every operator is row-wise: its output projection, the cross-attention (its queries) and
         // the feed-forward run on the COMPACTED rows [cond R | null R] (every sample has exactly k of them, position-sorted, so a
         // sample's queries stay contiguous).  Identical values for the rows that matter; (1 - k/n) of that work is skipped.
-        const bool compact_last = k < n && !(g_mm_debug & 16384);
+        // (Self-conditioning needs the embed of every position for the next step, re-masking samples every position: no compaction.)
+        const bool compact_last = k < n && !(g_mm_debug & 16384) && !self_cond && !can_remask;
         for (int l = 0; l < t->d.depth; ++l) {
             const mm_layer_weights& w = t->layers[l];
             const bf16_t* ckv_l = g.ckv + (size_t)l * B * m * 2 * I;
-            if (l == t->d.depth - 1 && compact_last) {
-                RC(self_attn_core(t, s, w.self_attn, 2 * B, n, b));
-                RC(k_gather_rows16(s, b.x, (long)D * 4, g.rows, R, 0, D * 4, g.xc));
-                RC(k_gather_rows16(s, b.x, (long)D * 4, g.rows, R, M, D * 4, g.xc + (size_t)R * D));
-                RC(k_gather_rows16(s, b.att, (long)I * 2, g.rows, R, 0, I * 2, g.attc));
-                RC(k_gather_rows16(s, b.att, (long)I * 2, g.rows, R, M, I * 2, g.attc + (size_t)R * I));
-                RC(gemm_dense(s, g.attc, I, (const bf16_t*)w.self_attn.w_out, I, 2 * R, D, I, g.xc, D, OUT_F32, g.xc));
-                Bufs bc = b;
-                bc.x = g.xc; bc.att = g.attc;
-                if (nc == 0) {
-                    RC(cross_attn_block(t, s, w.cross_attn, B, k, ckv_l, m, 0, g.masks, bc));
-                    RC(ff_block(t, s, w.ff, g.xc, g.xc, 2 * R, bc, g.cvec + (size_t)l * D, R));      // null rows += to_out(null_v)
-                } else {
-                    RC(cross_attn_block(t, s, w.cross_attn, 2 * B, k, ckv_l, m, B, g.masks, bc));
-                    RC(ff_block(t, s, w.ff, g.xc, g.xc, 2 * R, bc));
+            const bool last_compact = l == t->d.depth - 1 && compact_last;
+            const int nq = last_compact ? k : n;             // queries per sequence from here on
+            const int Mq = B * nq;
+            Bufs bc = b;
+            if (last_compact) {
+                RC(self_attn_core(t, s, w.self_attn, seqs, n, b));
+                for (int h = 0; h < P; ++h) {
+                    RC(k_gather_rows16(s, b.x, (long)D * 4, g.rows, R, h * M, D * 4, g.xc + (size_t)h * R * D));
+                    RC(k_gather_rows16(s, b.att, (long)I * 2, g.rows, R, h * M, I * 2, g.attc + (size_t)h * R * I));
                 }
-                break;
-            }
-            RC(self_attn_block(t, s, w.self_attn, 2 * B, n, b));
-            if (nc == 0) {
-                RC(cross_attn_block(t, s, w.cross_attn, B, n, ckv_l, m, 0, g.masks, b));
-                RC(ff_block(t, s, w.ff, b.x, b.x, 2 * M, b, g.cvec + (size_t)l * D, M));      // null rows += to_out(null_v) (the constant cross-attention)
+                RC(gemm_dense(s, g.attc, I, (const bf16_t*)w.self_attn.w_out, I, P * R, D, I, g.xc, D, OUT_F32, g.xc));
+                bc.x = g.xc; bc.att = g.attc;
             } else {
-                RC(cross_attn_block(t, s, w.cross_attn, 2 * B, n, ckv_l, m, B, g.masks, b));
-                RC(ff_block(t, s, w.ff, b.x, b.x, 2 * M, b));
+                RC(self_attn_block(t, s, w.self_attn, seqs, n, b));
+            }
+            if (P == 2 && nc == 0) {
+                RC(cross_attn_block(t, s, w.cross_attn, B, nq, ckv_l, m, 0, g.masks, bc));
+                RC(ff_block(t, s, w.ff, bc.x, bc.x, 2 * Mq, bc, g.cvec + (size_t)l * D, Mq));      // null rows += to_out(null_v) (the constant cross-attention)
+            } else {
+                RC(cross_attn_block(t, s, w.cross_attn, seqs, nq, ckv_l, m, P == 2 ? B : 0, g.masks, bc));
+                RC(ff_block(t, s, w.ff, bc.x, bc.x, P * Mq, bc));
             }
         }
         // final norm + to_logits + CFG only at the rows that are sampled this step
         if (compact_last) {
             RC(k_layernorm(s, g.xc, D, R, D, t->d.final_gamma, t->d.final_beta, nullptr, g.embc, D));
-            RC(k_layernorm(s, g.xc + (size_t)R * D, D, R, D, t->d.final_gamma, t->d.final_beta, nullptr, g.embn, D));
+            if (P == 2) RC(k_layernorm(s, g.xc + (size_t)R * D, D, R, D, t->d.final_gamma, t->d.final_beta, nullptr, g.embn, D));
         } else {
-            RC(k_layernorm(s, b.x, D, R, D, t->d.final_gamma, t->d.final_beta, g.rows, g.embc, D));
-            RC(k_layernorm(s, b.x + (size_t)M * D, D, R, D, t->d.final_gamma, t->d.final_beta, g.rows, g.embn, D));
+            if (self_cond) {      // the cond pass's embed at EVERY position is the next step's self-conditioning input (mmp.py:574)
+                RC(k_layernorm(s, b.x, D, M, D, t->d.final_gamma, t->d.final_beta, nullptr, g.emb_all, D));
+                hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(1024), dim3(256), 0, s, g.emb_all, g.sce, (long)M * D);
+                RC(mm_check_launch("bf16_to_f32_kernel"));
+            }
+            RC(k_layernorm(s, b.x, D, R, D, t->d.final_gamma, t->d.final_beta, rows, g.embc, D));
+            if (P == 2) RC(k_layernorm(s, b.x + (size_t)M * D, D, R, D, t->d.final_gamma, t->d.final_beta, rows, g.embn, D));
         }
+        int64_t* ids_out = can_remask ? nullptr : p->ids;
+        float* scores_out = can_remask ? nullptr : p->scores;
+        int64_t* pred_out = can_remask ? g.pred : nullptr;
+        float* conf_out = can_remask ? g.conf : nullptr;
         GemmArgs a;
         memset(&a, 0, sizeof(a));
         a.mode = MODE_CFG;
@@ -609,9 +707,9 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
         a.debug = g_mm_debug;
         // Sampling without the logits round trip: the GEMM emits tile statistics + the candidates above a per-row lower bound of the k-th largest
         // logit (estimated from the row's embeddings and the vocabulary statistics of to_logits), the finishing kernel verifies the bound.
-        const bool fused = t->d.logits_wcov && t->d.logits_wmean && p->status && !(p->flags & MM_GEN_NO_FUSED_SAMPLING) && (V % 256) == 0 &&
+        const bool fused = !single && t->d.logits_wcov && t->d.logits_wmean && p->status && !(p->flags & MM_GEN_NO_FUSED_SAMPLING) && (V % 256) == 0 &&
                            !(g_mm_debug & (8 | 4096 | 8192 | (1 << 25))) && mm_gemm_cfg2_eligible(a);
-        const double gemm_flops = 2.0 * 2.0 * (double)R * (double)V * (double)D;      // cond + null rows
+        const double gemm_flops = 2.0 * (double)P * (double)R * (double)V * (double)D;      // cond + null rows
         if (fused) {
             RC(k_fused_threshold(s, g.embc, g.embn, D, R, D, p->cond_scale, t->d.logits_wmean, (const bf16_t*)t->d.logits_wcov, k_fused_z(p->k_keep, V, FS_MARGIN),
                                  g.fs_ws, g.fs_thr));
@@ -624,11 +722,11 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
             FusedSampleArgs fa;
             memset(&fa, 0, sizeof(fa));
             fa.thr = g.fs_thr; fa.stats = g.fs_stats; fa.cand = g.fs_cand;
-            fa.R = R; fa.V = V; fa.k_keep = p->k_keep; fa.rows = g.rows;
+            fa.R = R; fa.V = V; fa.k_keep = p->k_keep; fa.rows = rows;
             fa.temperature = p->temperatures[step]; fa.noise_kind = p->noise_kind;
             fa.noise = p->noise ? p->noise + (size_t)step * M * V : nullptr; fa.noise_ld = V;
             fa.seed = p->seed; fa.row_offset = p->row_offset * (uint64_t)n; fa.step = (uint32_t)step;
-            fa.ids = p->ids; fa.scores = p->scores; fa.fail_flag = p->status;
+            fa.ids = ids_out; fa.scores = scores_out; fa.pred_out = pred_out; fa.score_out = conf_out; fa.fail_flag = p->status;
             if (prof::enabled) pr = prof::begin(s, 4.0 * (double)R * (double)V);      // logits-equivalent bytes (what a logits-reading sampler reads)
             RC(k_sample_fused(s, fa));                                                                  // mmp.py:576-609
             if (prof::enabled) prof::end(s, 1, pr);
@@ -636,20 +734,54 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
             {
                 prof::Rec pr;
                 if (prof::enabled) pr = prof::begin(s, gemm_flops);
-                RC(mm_gemm_launch(a, s));
+                if (single)      // cond_scale == 1: the plain to_logits of the one pass (mmp.py:247-248, 332)
+                    RC(gemm_dense(s, g.embc, D, (const bf16_t*)t->d.to_logits, D, R, V, D, g.logits, V, OUT_F32, nullptr));
+                else
+                    RC(mm_gemm_launch(a, s));
                 if (prof::enabled) prof::end(s, 0, pr);
             }
             SampleArgs sa;
             memset(&sa, 0, sizeof(sa));
-            sa.logits = g.logits; sa.ld = V; sa.R = R; sa.V = V; sa.k_keep = p->k_keep; sa.rows = g.rows;
+            sa.logits = g.logits; sa.ld = V; sa.R = R; sa.V = V; sa.k_keep = p->k_keep; sa.rows = rows;
             sa.temperature = p->temperatures[step]; sa.noise_kind = p->noise_kind;
             sa.noise = p->noise ? p->noise + (size_t)step * M * V : nullptr; sa.noise_ld = V;
             sa.seed = p->seed; sa.row_offset = p->row_offset * (uint64_t)n; sa.step = (uint32_t)step;
-            sa.ids = p->ids; sa.scores = p->scores;
+            sa.ids = ids_out; sa.scores = scores_out; sa.pred_out = pred_out; sa.score_out = conf_out;
             prof::Rec pr;
             if (prof::enabled) pr = prof::begin(s, 4.0 * (double)R * (double)V);      // one fp32 read of each row
             RC(k_sample_rows(s, sa));                                                                // mmp.py:576-609
             if (prof::enabled) prof::end(s, 1, pr);
+        }
+        if (can_remask) {
+            hipLaunchKernelGGL(merge_pred_kernel, dim3((M + 255) / 256), dim3(256), 0, s, p->ids, g.pred, p->scores, g.conf, mask_id, (long)M);
+            RC(mm_check_launch("merge_pred_kernel"));
+        }
+        if (cmodel) {
+            // critic scores of the freshly sampled ids at every position (mmp.py:590-601)
+            if (critic) {        // TokenCritic.forward_with_cond_scale: both passes + the guidance combine of its 1-wide head
+                RC(mm_transformer_forward(critic, stream, p->ids, B, n, cb.ctx, cb.masks, m, nullptr, cb.embc, nullptr, cb.fwd_ws, cb.fwd_ws_bytes));
+                const int Dc = critic->d.dim;
+                if (single) {
+                    RC(gemm_dense(s, cb.embc, Dc, (const bf16_t*)critic->d.to_logits, Dc, M, 1, Dc, cb.sc, 1, OUT_F32, nullptr));
+                } else {
+                    RC(mm_transformer_forward(critic, stream, p->ids, B, n, cb.ctx, cb.masks + (size_t)B * m, m, nullptr, cb.embn, nullptr, cb.fwd_ws,
+                                              cb.fwd_ws_bytes));
+                    GemmArgs ca;
+                    memset(&ca, 0, sizeof(ca));
+                    ca.mode = MODE_CFG;
+                    ca.W = (const bf16_t*)critic->d.to_logits; ca.N = 1; ca.ldw = Dc; ca.K = Dc;
+                    ca.M = M; ca.X = cb.embc; ca.X2 = cb.embn; ca.ldx = Dc;
+                    ca.out = cb.sc; ca.ldc = 1; ca.out_kind = OUT_F32; ca.cfg_scale = p->cond_scale;
+                    RC(mm_gemm_launch(ca, s));
+                }
+            } else {             // SelfCritic (mmp.py:352-374): Linear(dim, 1) on the generator's cond-pass embed of the new ids (no self-conditioning input)
+                RC(mm_transformer_forward(t, stream, p->ids, B, n, cb.ctx, cb.masks, m, nullptr, cb.embc, nullptr, cb.fwd_ws, cb.fwd_ws_bytes));
+                RC(mm_conv2d_nhwc(stream, cb.embc, M, 1, 1, D, p->critic_head_w, 1, 1, 1, 1, 0, 0, 1, 1, 1, 0, 0, 1, 1, p->critic_head_b, 0, nullptr, cb.sc, 1));
+            }
+            const float ratio = (float)((double)(T - 1 - step) / (double)T);
+            hipLaunchKernelGGL(critic_scores_kernel, dim3((M + 255) / 256), dim3(256), 0, s, cb.sc, p->critic_noise + (size_t)step * M, p->critic_noise_scale, ratio,
+                               p->scores, (long)M);
+            RC(mm_check_launch("critic_scores_kernel"));
         }
         if (p->trace_ids) {
             const hipError_t e = hipMemcpyAsync(p->trace_ids + (size_t)step * M, p->ids, (size_t)M * 8, hipMemcpyDeviceToDevice, s);

@@ -644,24 +644,31 @@ class MaskGit(nn.Module):
                  force_not_use_token_critic=False, timesteps=18, cond_scale=3, critic_noise_scale=1,
                  *, text_embeds: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None, noise_kind: str = 'philox',
                  seed: Optional[int] = None, row_offset: int = 0, return_ids: bool = False, trace: Optional[dict] = None,
-                 critic_noise: Optional[torch.Tensor] = None, neg_text_embeds: Optional[torch.Tensor] = None, fused_sampling: bool = True):
+                 critic_noise: Optional[torch.Tensor] = None, neg_text_embeds: Optional[torch.Tensor] = None, fused_sampling: bool = True,
+                 stepwise: bool = False):
         """mmp.py:491-621.  Keyword-only extras (not in the reference): `text_embeds` bypasses the T5 call,
         `noise` (+ `noise_kind` 'gumbel' | 'uniform') injects the per-step noise tensor [T,B,n,V] for parity runs,
         `seed` / `row_offset` key the on-device Philox stream (row_offset = global index of this shard's first
         sample, so sharded runs reproduce the unsharded ids), `trace` receives per-step states, `critic_noise` [T,B,n]
         injects the U(0,1) draws of the token-critic score annealing (mmp.py:601).  `negative_texts` (or `neg_text_embeds`) is an
         EXTENSION: the reference's negative-prompt path cannot run (see Transformer.forward_with_neg_prompt).  `fused_sampling=False` forces
-        the decode loop to materialise the logits (same ids; tests / A-B timing)."""
+        the decode loop to materialise the logits (same ids; tests / A-B timing).  Every decode variant of the reference -- token critic / self critic
+        scores, self-conditioning, can_remask_prev_masked, cond_scale == 1 -- runs inside the one mm_generate call; `stepwise=True` runs the same
+        loop one operator call at a time from Python instead (tests: the two must agree bit for bit)."""
         tr = self.transformer
         use_token_critic = exists(self.token_critic) and not force_not_use_token_critic
         if exists(negative_texts) or exists(neg_text_embeds):
             assert exists(neg_text_embeds) or len(texts) == len(negative_texts)       # mmp.py:541
-        if (exists(negative_texts) or exists(neg_text_embeds) or use_token_critic or can_remask_prev_masked or self.self_cond or cond_scale == 1
-                or tr.weight_format == 'fp8' or tr.precision == 'parity'):
-            # decode variants that need logits / scores at EVERY position: stepwise loop over the same C-ABI operators
+        critic = self.token_critic if use_token_critic else None
+        critic_net = critic.net if isinstance(critic, SelfCritic) else critic
+        if (exists(negative_texts) or exists(neg_text_embeds) or stepwise or tr.weight_format == 'fp8' or tr.precision == 'parity'
+                or (exists(critic_net) and (critic_net.weight_format == 'fp8' or critic_net.precision == 'parity'))):
+            # the negative-prompt extension and the fp8 / parity engines run the loop one step at a time over the same C-ABI operators
             return self._generate_stepwise(texts, cond_images, fmap_size, temperature, topk_filter_thres, can_remask_prev_masked,
                                            use_token_critic, timesteps, cond_scale, critic_noise_scale, text_embeds, noise, noise_kind,
                                            seed, row_offset, return_ids, trace, critic_noise, negative_texts, neg_text_embeds)
+        if can_remask_prev_masked and not use_token_critic:                    # mmp.py:548-549
+            assert self.no_mask_token_prob > 0., 'without training with some of the non-masked tokens forced to predict, not sure if the logits will be meaningful for these token'
         if exists(fmap_size):
             fmap = fmap_size
         else:
@@ -701,6 +708,27 @@ class MaskGit(nn.Module):
         ids = torch.empty(B, seq_len, dtype=torch.long, device=dev)
         scores = torch.empty(B, seq_len, dtype=torch.float32, device=dev)
         p.text_embeds, p.cond_ids, p.noise, p.ids, p.scores = L.ptr(te), L.ptr(cond_ids), L.ptr(noise), L.ptr(ids), L.ptr(scores)
+        keep = []                                                              # tensors the C call reads must outlive it
+        if can_remask_prev_masked:
+            p.flags |= L.MM_GEN_CAN_REMASK
+        if exists(critic):
+            if isinstance(critic, SelfCritic):
+                keep += [critic.to_pred.weight.detach().to(device=dev, dtype=bf16).reshape(-1).contiguous(),
+                         critic.to_pred.bias.detach().to(device=dev, dtype=torch.float32).contiguous()]
+                p.critic_head_w, p.critic_head_b = L.ptr(keep[-2]), L.ptr(keep[-1])
+                ch = h
+            else:
+                ch = critic._model()
+                p.critic = ch.ptr
+            cn = critic_noise if exists(critic_noise) else torch.rand(timesteps, B, seq_len, device=dev)      # mmp.py:601
+            cn = cn.to(device=dev, dtype=torch.float32).reshape(timesteps, B, seq_len).contiguous()
+            keep.append(cn)
+            p.critic_noise, p.critic_noise_scale = L.ptr(cn), float(critic_noise_scale)
+            cwsb = L.lib().mm_generate_critic_workspace_bytes(ch.ptr, B, seq_len, Lt, nc)
+            cws = getattr(self, '_critic_ws', None)
+            if cws is None or cws.numel() < cwsb or cws.device != dev:
+                cws = self._critic_ws = torch.zeros(int(cwsb), dtype=torch.uint8, device=dev)
+            p.critic_workspace, p.critic_workspace_bytes = L.ptr(cws), cws.numel()
         if trace is not None:
             trace['masked_ids'] = torch.empty(timesteps, B, seq_len, dtype=torch.long, device=dev)
             trace['ids'] = torch.empty(timesteps, B, seq_len, dtype=torch.long, device=dev)
@@ -720,11 +748,11 @@ class MaskGit(nn.Module):
             status = torch.zeros(1, dtype=torch.int32, device=dev)
             p.status = L.ptr(status)
         else:
-            p.flags = L.MM_GEN_NO_FUSED_SAMPLING
+            p.flags |= L.MM_GEN_NO_FUSED_SAMPLING
         L.check(L.lib().mm_generate(h.ptr, L.stream(), C.byref(p), L.ptr(self._gen_ws), self._gen_ws.numel()), 'mm_generate')
         if status is not None and int(status.item()) != 0:
             self.fused_sampling_fallbacks += 1
-            p.flags, p.status = L.MM_GEN_NO_FUSED_SAMPLING, None
+            p.flags, p.status = p.flags | L.MM_GEN_NO_FUSED_SAMPLING, None
             L.check(L.lib().mm_generate(h.ptr, L.stream(), C.byref(p), L.ptr(self._gen_ws), self._gen_ws.numel()), 'mm_generate')
         ids = ids.reshape(B, fmap, fmap)                                       # mmp.py:615
         if return_ids or not exists(self.vae):

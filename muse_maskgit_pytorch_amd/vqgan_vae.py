@@ -14,6 +14,7 @@ from pathlib import Path
 import torch
 from torch import nn
 
+from . import _lib as L
 from . import ops
 
 
@@ -272,8 +273,55 @@ class VQGanVAE(nn.Module):
             P['lfq'] = dict(wi=f32(q.project_in.weight), bi=f32(q.project_in.bias), wo=f32(q.project_out.weight), bo=f32(q.project_out.bias))
         else:
             P['lfq'] = dict(wi=None, bi=None, wo=None, bo=None)
+        P['handle'] = self._make_handle(P) if self.lookup_free_quantization else None
         self._packed = P
         return P
+
+    composite = True    # False: run encode / decode_from_ids operator by operator (mm_conv2d_nhwc, ...) instead of the one-call C entry points
+
+    def _make_handle(self, P):
+        """mm_vae_create over the packed layer list: encode / decode_from_ids then run as ONE C call each (csrc/vae_model.hip)."""
+        import ctypes as C
+        import weakref
+        kinds = dict(stem=0, down=1, res=2, glu=3, up=4, head=5)
+        keep = []
+
+        def layer(e):
+            l = L.VaeLayer()
+            l.kind, l.k, l.groups = kinds[e['kind']], e.get('k', 0), 0
+            if e['kind'] in ('res', 'glu'):
+                l.cout = e['convs'][2]['cout']
+                l.groups = e['gns'][0]['groups']
+                for i, c in enumerate(e['convs']):
+                    l.w[i], l.b[i] = L.ptr(c['w']), L.ptr(c['b'])
+                for i, g in enumerate(e['gns']):
+                    l.gn_g[i], l.gn_b[i] = L.ptr(g['g']), L.ptr(g['b'])
+            elif e['kind'] == 'up':
+                l.cout = e['cout']
+                for (py, px), w in e['w'].items():
+                    l.w[py * 2 + px] = L.ptr(w)
+                l.b[0] = L.ptr(e['b'])
+            else:
+                l.cout, l.w[0], l.b[0] = e['cout'], L.ptr(e['w']), L.ptr(e['b'])
+            return l
+
+        enc = (L.VaeLayer * len(P['enc']))(*[layer(e) for e in P['enc']])
+        dec = (L.VaeLayer * len(P['dec']))(*[layer(e) for e in P['dec']])
+        lf = P['lfq']
+        d = L.VaeDesc(channels=self.channels, encoded_dim=self.enc_dec.encoded_dim, bits=P['bits'], n_enc=len(P['enc']), n_dec=len(P['dec']),
+                      enc=enc, dec=dec, lfq_wi=L.ptr(lf['wi']), lfq_bi=L.ptr(lf['bi']), lfq_wo=L.ptr(lf['wo']), lfq_bo=L.ptr(lf['bo']))
+        h = C.c_void_p()
+        L.check(L.lib().mm_vae_create(C.byref(d), C.byref(h)), 'mm_vae_create')
+        holder = type('VaeHandle', (), {})()
+        holder.h = h
+        weakref.finalize(holder, L.lib().mm_vae_destroy, h)
+        return holder
+
+    def _workspace(self, nbytes, device):
+        ws = getattr(self, '_ws', None)
+        if ws is None or ws.numel() < nbytes or ws.device != device:
+            ws = self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return ws
 
     # ---- hot path
     @staticmethod
@@ -319,6 +367,17 @@ class VQGanVAE(nn.Module):
             from . import parity
             return parity.vae_encode(self, fmap)
         P = self._pack()
+        if self.composite and P['handle'] is not None:                # the whole encoder + LFQ in one C call (mm_vae_encode)
+            ops._chk_cuda(fmap)
+            fmap = fmap.float().contiguous()
+            B, _, H, W = fmap.shape
+            f = 2 ** self.enc_dec.layers
+            lib, h = L.lib(), P['handle'].h
+            ws = self._workspace(lib.mm_vae_encode_workspace_bytes(h, B, H, W), fmap.device)
+            q = torch.empty(B, self.enc_dec.encoded_dim, H // f, W // f, dtype=torch.float32, device=fmap.device)
+            ids = torch.empty(B, H // f, W // f, dtype=torch.long, device=fmap.device)
+            L.check(lib.mm_vae_encode(h, L.stream(), L.ptr(fmap), B, H, W, L.ptr(q), L.ptr(ids), L.ptr(ws), ws.numel()), 'mm_vae_encode')
+            return q, ids, torch.zeros((), device=fmap.device)
         x = ops.nchw_to_nhwc8(fmap)
         for e in P['enc']:                                            # ResnetEncDec.encode (vqgan_vae.py:241-244), in list order
             x = self._run_layer(x, e)
@@ -345,9 +404,18 @@ class VQGanVAE(nn.Module):
         P = self._pack()
         if not self.lookup_free_quantization:
             return self._decode_nhwc(self.quantizer.codes_nhwc(ids.to(self.device)))
-        lf = P['lfq']
-        x = ops.lfq_decode(ids, P['bits'], self.enc_dec.encoded_dim, lf['wo'], lf['bo'])     # (B,h,w,C) NHWC bf16
-        return self._decode_nhwc(x)
+        if not (self.composite and P['handle'] is not None):
+            lf = P['lfq']
+            return self._decode_nhwc(ops.lfq_decode(ids, P['bits'], self.enc_dec.encoded_dim, lf['wo'], lf['bo']))
+        ops._chk_cuda(ids)                                            # LFQ + the whole decoder in one C call (mm_vae_decode_from_ids)
+        ids = ids.long().contiguous()
+        B, h_, w_ = ids.shape
+        f = 2 ** self.enc_dec.layers
+        lib, h = L.lib(), P['handle'].h
+        ws = self._workspace(lib.mm_vae_decode_workspace_bytes(h, B, h_, w_), ids.device)
+        img = torch.empty(B, self.channels, h_ * f, w_ * f, dtype=torch.float32, device=ids.device)
+        L.check(lib.mm_vae_decode_from_ids(h, L.stream(), L.ptr(ids), B, h_, w_, L.ptr(img), L.ptr(ws), ws.numel()), 'mm_vae_decode_from_ids')
+        return img
 
     @torch.no_grad()
     def decode(self, fmap):

@@ -137,3 +137,42 @@ def test_generate_with_fused_sampling_at_bench_size_and_its_fallback():
     assert mg.fused_sampling_fallbacks == 1
     d = mg.generate([''] * 32, timesteps=6, cond_scale=3, text_embeds=te, seed=7, return_ids=True, fused_sampling=False)
     assert torch.equal(c, d)
+
+
+@pytest.mark.parametrize('name', ['self_critic', 'token_critic', 'self_cond', 'can_remask'])
+def test_decode_variants_inside_mm_generate_with_fused_sampling(name):
+    """The decode variants at a vocabulary where the fused sampler applies (V = 8192): one mm_generate call (fused sampling on) against the
+    stepwise loop over the public operators (logits materialised).  With a critic the re-masking scores depend on the sampled ids only, so the
+    two must agree exactly; otherwise the confidences agree to round-off and step 0 must be identical."""
+    torch.manual_seed(11)
+    kw = dict(num_tokens=8192, seq_len=64, dim=256, depth=2, dim_head=64, heads=4, t5_name='t5-small')
+    t = mm.MaskGitTransformer(self_cond=name == 'self_cond', **kw)
+    with torch.no_grad():
+        t.to_logits.weight.mul_(6.)
+    extra, gkw = {}, {}
+    if name == 'token_critic':
+        extra['token_critic'] = mm.TokenCritic(**kw)
+    elif name == 'self_critic':
+        extra['self_token_critic'] = True
+    elif name == 'can_remask':
+        extra['no_mask_token_prob'] = 0.25
+        gkw['can_remask_prev_masked'] = True
+    mg = mm.MaskGit(image_size=128, transformer=t, vae=None, **extra).to(DEV)
+    B, T = 4, 6
+    te = torch.randn(B, 7, 512, device=DEV)
+    if name in ('token_critic', 'self_critic'):
+        gkw['critic_noise'] = torch.rand(T, B, 64, device=DEV)
+    ta, tb = {}, {}
+    a = mg.generate([''] * B, timesteps=T, text_embeds=te, seed=5, fmap_size=8, trace=ta, **gkw)
+    assert mg.fused_sampling_fallbacks == 0 and t._model().packed['wcov'] is not None
+    b = mg.generate([''] * B, timesteps=T, text_embeds=te, seed=5, fmap_size=8, trace=tb, stepwise=True, **gkw)
+    assert torch.equal(ta['ids'][0], torch.stack(tb['ids'])[0])
+    if name in ('token_critic', 'self_critic'):
+        assert torch.equal(a, b)
+        assert torch.equal(ta['scores'], torch.stack(tb['scores']))
+    else:
+        assert (ta['scores'][0] - tb['scores'][0]).abs().max().item() < 1e-6
+        assert (a == b).float().mean().item() > 0.98
+    # the logits path of the same call is the stepwise loop bit for bit
+    c = mg.generate([''] * B, timesteps=T, text_embeds=te, seed=5, fmap_size=8, fused_sampling=False, **gkw)
+    assert torch.equal(c, b)

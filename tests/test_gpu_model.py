@@ -164,6 +164,34 @@ def test_generate_philox_is_shard_invariant_and_seeded(golden):
     assert not torch.equal(full, mg.generate(['x'] * 4, timesteps=6, text_embeds=te, seed=78, fmap_size=8))
 
 
+def test_vae_composite_entry_points_equal_the_operator_sequence():
+    """mm_vae_encode / mm_vae_decode_from_ids (one C call each) against the same layer list run operator by operator through the C-ABI:
+    the same kernels in the same order, so bit-identical -- for the default layout and for interleaved residual blocks."""
+    for kw in (dict(dim=32, codebook_size=8192), dict(dim=16, codebook_size=512, encdec_num_resnet_blocks=(1, 0, 2, 1), layers=4)):
+        torch.manual_seed(3)
+        v = mm.VQGanVAE(use_vgg_and_gan=False, **kw).to(DEV).eval()
+        f = 2 ** v.enc_dec.layers
+        ids = torch.randint(0, kw['codebook_size'], (3, 4, 6), device=DEV)
+        img = torch.randn(3, 3, 4 * f, 6 * f, device=DEV)
+        a_dec, (a_q, a_ids, _) = v.decode_from_ids(ids), v.encode(img)
+        v.composite = False
+        b_dec, (b_q, b_ids, _) = v.decode_from_ids(ids), v.encode(img)
+        assert a_dec.shape == (3, 3, 4 * f, 6 * f) and torch.equal(a_dec, b_dec)
+        assert torch.equal(a_ids, b_ids) and torch.equal(a_q, b_q)
+        # capturable: no allocation / synchronisation inside the call
+        v.composite = True
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            v.decode_from_ids(ids)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=s):
+                c_dec = v.decode_from_ids(ids)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(c_dec, a_dec)
+
+
 def test_vae_decode_encode_vs_reference_and_oracle(golden):
     gv = golden('vae_tiny.pt')
     sd = sd_f32(gv['sd'])
@@ -368,7 +396,8 @@ def test_generate_stepwise_variants(golden):
 @pytest.mark.parametrize('name', ['token_critic', 'self_critic', 'cond_scale_1', 'can_remask', 'self_cond'])
 def test_generate_variants_vs_reference_goldens(golden, name):
     """mmp.py:540-609 decode variants replayed with the reference's recorded noise:
-    (1) the HIP stepwise loop must equal, bit for bit, the oracle loop fed by the HIP transformer (same logits, same noise);
+    (1) the HIP decode loop -- every variant runs inside the one mm_generate call -- must equal, bit for bit, the oracle loop fed by the HIP
+        transformer (same logits, same noise), and the same loop driven operator by operator from Python (stepwise=True);
     (2) against the fp32 reference's final ids the agreement is reported (bf16 GEMM operands can flip a near-tie and the
         loop then diverges by design); >= 90 % must agree."""
     gv, gt = golden('generate_variants_tiny.pt')[name], golden('transformer_tiny.pt')
@@ -413,7 +442,14 @@ def test_generate_variants_vs_reference_goldens(golden, name):
         return logits.cpu()
 
     free = O.generate_ids(demask, B, n, 512, lambda s, shp: O.gumbel_from_uniform(uni[s]), timesteps=T, **okw)
-    assert torch.equal(got, free), f'{name}: HIP stepwise loop differs from the oracle loop on the same logits'
+    assert torch.equal(got, free), f'{name}: the HIP decode loop (one mm_generate call) differs from the oracle loop on the same logits'
+    # the same loop one operator call at a time from Python: bit-identical ids AND per-step states
+    trace_s = {}
+    step = mg.generate(['a', 'b'], timesteps=T, text_embeds=te, noise=uni, noise_kind='uniform', fmap_size=8, cond_scale=cond_scale,
+                       trace=trace_s, stepwise=True, **kw).reshape(B, n).cpu()
+    assert torch.equal(got, step), f'{name}: mm_generate differs from the stepwise loop'
+    for key in ('masked_ids', 'ids', 'scores'):
+        assert torch.equal(trace[key].cpu(), torch.stack(trace_s[key]).cpu()), f'{name}: per-step {key} differ between mm_generate and the stepwise loop'
     ref = gv['final_ids'].reshape(B, n)
     agree = (got == ref).float().mean().item()
     print(f'[parity] decode variant {name}: final ids equal to the fp32 reference {agree * 100:.1f} %')

@@ -127,6 +127,7 @@ def test_vae_host_orchestration_against_reference_golden(golden, monkeypatch):
     emu.install(monkeypatch, ops)
     v = mm.VQGanVAE(**gv['cfg']).copy_for_eval()
     v.load_state_dict(sd_f32(gv['sd']))
+    v.composite = False                      # operator by operator: each operator is what the emulation replaces
     dec = v.decode_from_ids(gv['ids'])
     assert dec.shape == gv['decoded'].shape
     assert (dec - gv['decoded']).abs().max() < 2e-4 * gv['decoded'].abs().max().clamp(min=1)
@@ -253,6 +254,27 @@ def test_vae_pack_walks_interleaved_resnet_blocks():
     d = mm.VQGanVAE(dim=16, codebook_size=512)
     assert [e['kind'] for e in d._pack()['enc']] == ['stem', 'down', 'down', 'down', 'down', 'res']
     assert [e['kind'] for e in d._pack()['dec']] == ['glu', 'up', 'up', 'up', 'up', 'head']
+
+
+def test_vae_composite_handle_and_workspace_queries():
+    """mm_vae_create over the packed layer list (host structs only, no launch): the workspace queries grow with the batch and the map size,
+    and the entry points reject NULL / undersized arguments with the documented codes."""
+    import ctypes as C
+    from muse_maskgit_pytorch_amd import _lib as L
+    v = mm.VQGanVAE(dim=16, codebook_size=512, encdec_num_resnet_blocks=(1, 0, 2, 1))
+    h = v._pack()['handle'].h
+    lib = L.lib()
+    d1, d2, d3 = (lib.mm_vae_decode_workspace_bytes(h, b, s, s) for b, s in ((1, 8), (2, 8), (2, 16)))
+    assert 0 < d1 < d2 < d3
+    e1, e2 = lib.mm_vae_encode_workspace_bytes(h, 1, 64, 64), lib.mm_vae_encode_workspace_bytes(h, 2, 128, 128)
+    assert 0 < e1 < e2
+    assert lib.mm_vae_decode_workspace_bytes(None, 1, 8, 8) == 0
+    assert lib.mm_vae_decode_from_ids(None, None, None, 1, 8, 8, None, None, 0) == -1
+    buf = C.create_string_buffer(64)
+    assert lib.mm_vae_decode_from_ids(h, None, buf, 1, 8, 8, buf, buf, 64) == -6
+    assert lib.mm_vae_encode(h, None, buf, 1, 64, 64, None, buf, buf, 64) == -6
+    out = C.c_void_p()
+    assert lib.mm_vae_create(None, C.byref(out)) == -1
 
 
 def test_seeded_construction_matches_the_base_golden_recipe(golden):
