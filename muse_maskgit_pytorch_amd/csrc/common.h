@@ -166,6 +166,30 @@ __device__ __forceinline__ void fused_emit_piece(const float4 x, int row, int ti
     if (lane == 0) stats[(size_t)row * NT + tile] = make_float4(m, e, __uint_as_float((uint32_t)bal), __uint_as_float((uint32_t)(bal >> 32)));
 }
 
+// The same emission for a kernel that hands over many pieces per wave (the persistent guidance GEMM: 16 rows of a tile per wave): a store
+// instruction per piece is what the emission costs there (measured: the statistics store and the candidate store each add ~11 % to the GEMM),
+// so the statistics of piece j are parked in LANE j of `parked` and leave with ONE store per 16 pieces (fused_flush_stats).  Returns whether
+// the candidate store was issued (wave-uniform; the caller's counted s_waitcnt vmcnt needs the exact number of VMEM instructions).
+__device__ __forceinline__ bool fused_emit_piece_parked(const float4 x, int row, int tile, int NT, int lane, float thr, float4* __restrict__ cand, int j,
+                                                        float4& parked) {
+    const float m4 = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
+    const float m = wave_max_dpp(m4);
+    const float e = wave_sum_dpp((__expf(x.x - m) + __expf(x.y - m)) + (__expf(x.z - m) + __expf(x.w - m)));
+    const bool kp = m4 >= thr;
+    const unsigned long long bal = __ballot(kp);
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+    const bool any = bal != 0ull;
+    if (any) {
+        if (kp) cand[((size_t)row * NT + tile) * FS_SLOT + rank] = x;
+    }
+    if (lane == j) parked = make_float4(m, e, __uint_as_float((uint32_t)bal), __uint_as_float((uint32_t)(bal >> 32)));
+    return any;
+}
+// lane j (< count) stores the parked statistics of piece j to row rows_of_lane (its own piece's token row; < 0: the piece did not exist)
+__device__ __forceinline__ void fused_flush_stats(const float4 parked, int row_of_lane, int tile, int NT, float4* __restrict__ stats) {
+    if (row_of_lane >= 0) stats[(size_t)row_of_lane * NT + tile] = parked;
+}
+
 // XCD-aware tile order: block b is dispatched to XCD b % 8 (observed, used for speed only), so give
 // every XCD one contiguous run of the linear tile index (bijective for any tile count), then walk
 // that run in groups of GROUP_M row-tiles so a group's activation tiles stay in the XCD's 4 MiB L2

@@ -59,9 +59,11 @@ __device__ __forceinline__ void wait_vmcnt(int n) {      // n is wave-uniform
         case 0: __builtin_amdgcn_s_waitcnt(0x0F70); break;
         case 1: __builtin_amdgcn_s_waitcnt(0x0F71); break;
         case 2: __builtin_amdgcn_s_waitcnt(0x0F72); break;
+        case 3: __builtin_amdgcn_s_waitcnt(0x0F73); break;
         case 4: __builtin_amdgcn_s_waitcnt(0x0F74); break;
         case 5: __builtin_amdgcn_s_waitcnt(0x0F75); break;
         case 6: __builtin_amdgcn_s_waitcnt(0x0F76); break;
+        case 7: __builtin_amdgcn_s_waitcnt(0x0F77); break;
         case 8: __builtin_amdgcn_s_waitcnt(0x0F78); break;
         default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
     }
@@ -185,6 +187,7 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
     const bool fused = (WMODE == WIDE_CFG) && p.fs_stats != nullptr;
     f32x4_t acc[4][8];
     f32x4_t held[2][4];             // second half of the previous tile's output (tokens 32..63 of this wave), combined
+    float4 parked = make_float4(0.f, 0.f, 0.f, 0.f);      // fused sampling: lane j holds the statistics of this wave's j-th piece of the previous tile
     bool have_prev = false;
     int pm0 = 0, pn0 = 0;
     int g = 0;                      // global k-step counter of the compute cursor
@@ -278,9 +281,13 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
             WAIT_LGKM0();                                       /* the raw read of pv_ (the fragments are long there) */ \
             __builtin_amdgcn_sched_barrier(0);                                                                 \
             if constexpr (WMODE == WIDE_CFG) {                                                                 \
-                if (fused) fused_emit_piece(make_float4(__uint_as_float(pv_.x), __uint_as_float(pv_.y), __uint_as_float(pv_.z), __uint_as_float(pv_.w)), \
-                                            ptok_, pn0 >> 8, p.tiles_n, lane, fthr_, p.fs_stats, p.fs_cand); \
-                else store_stream(reinterpret_cast<float*>(pv_ptr_), pv_);                                     \
+                if (fused) {                                                                                   \
+                    st1 = fused_emit_piece_parked(make_float4(__uint_as_float(pv_.x), __uint_as_float(pv_.y), __uint_as_float(pv_.z), __uint_as_float(pv_.w)), \
+                                                  ptok_, pn0 >> 8, p.tiles_n, lane, fthr_, p.fs_cand, half_ * 8 + q_, parked) ? 1 : 0; \
+                } else {                                                                                       \
+                    store_stream(reinterpret_cast<float*>(pv_ptr_), pv_);                                      \
+                    st1 = 1;                                                                                   \
+                }                                                                                              \
             }                                                                                                  \
             else {                                                                                             \
                 if (p.ln_part) {      /* LayerNorm(inner) partial sums of the row's two 64-column groups (common.h) */ \
@@ -289,8 +296,14 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
                         *reinterpret_cast<float2*>(p.ln_part + ((size_t)(pm0 + prow_) * p.ln_np + (pn0 >> 7) + ((lane >> 3) & 1)) * 2) = lst_; \
                 }                                                                                              \
                 if (pm0 + prow_ < p.M) *reinterpret_cast<uint4*>(pv_ptr_) = pv_;      /* re-read by the next kernel: a plain store */ \
+                st1 = 1;                                                                                       \
             }                                                                                                  \
-            st1 = 1;                                                                                           \
+        }                                                                                                      \
+        /* the 16 pieces of the previous tile are out: one store of their parked statistics (lane j = piece j: half j >> 3, q = j & 7) */ \
+        if (WMODE == WIDE_CFG && fused && have_prev && half_ == 1 && q_ == 7) {                                \
+            const int ftok_ = PIECE_TOKEN(PIECE_ROW(lane & 7), (lane >> 3) & 1);                               \
+            fused_flush_stats(parked, (lane < 16 && ftok_ < p.M) ? ftok_ : -1, pn0 >> 8, p.tiles_n, p.fs_stats); \
+            st1 += 1;                                                                                          \
         }                                                                                                      \
         ++g;                                                                                                   \
         ++kt;                                                                                                  \
@@ -384,13 +397,17 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
                 const int ptok = PIECE_TOKEN(hrow, half);
                 if (ptok < p.M && !ABL(p, 1)) {
                     const uint4 pv = *reinterpret_cast<const uint4*>(ct + hrow * 1024 + ((lane ^ (hrow & 7)) << 4));
-                    if (fused) fused_emit_piece(make_float4(__uint_as_float(pv.x), __uint_as_float(pv.y), __uint_as_float(pv.z), __uint_as_float(pv.w)), ptok,
-                                                pn0 >> 8, p.tiles_n, lane, p.fs_thr[ptok], p.fs_stats, p.fs_cand);
+                    if (fused) fused_emit_piece_parked(make_float4(__uint_as_float(pv.x), __uint_as_float(pv.y), __uint_as_float(pv.z), __uint_as_float(pv.w)), ptok,
+                                                       pn0 >> 8, p.tiles_n, lane, p.fs_thr[ptok], p.fs_cand, half * 8 + q, parked);
                     else store_stream(reinterpret_cast<float*>(p.out) + (size_t)ptok * p.ldc + pn0 + lane * 4, pv);
                 }
             }
             WAIT_LGKM0();
             __builtin_amdgcn_s_barrier();
+        }
+        if (fused) {
+            const int ftok = PIECE_TOKEN(PIECE_ROW(lane & 7), (lane >> 3) & 1);
+            fused_flush_stats(parked, (lane < 16 && ftok < p.M) ? ftok : -1, pn0 >> 8, p.tiles_n, p.fs_stats);
         }
     } else {
         for (int q = 0; q < 8; ++q) {
@@ -440,6 +457,7 @@ int mm_gemm_cfg2_launch(GemmArgs a, hipStream_t stream) {
         attr_set = true;
     }
     const bool cfg = a.mode == MODE_CFG;
+    if (cfg && (g_mm_debug & (1 << 26))) return mm_gemm_cfg3_launch(a, stream);      // bit 1 << 26: the phase-split experiment of gemm_cfg3.hip (same values; measured no faster)
     a.tiles_n = a.N / BN;
     a.tiles_m = cfg ? (a.M + TOK - 1) / TOK : (a.M + 2 * TOK - 1) / (2 * TOK);
     const int total = a.tiles_m * a.tiles_n;
