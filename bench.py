@@ -177,6 +177,61 @@ def reference_flops_per_generate(tr, B, n, m_text, nc, timesteps):
     return B * 2 * timesteps * (depth * layer + 2.0 * n * D * tr.dim_out)
 
 
+def train_bench(args, dev, rank, world, dist):
+    """MaskGit.forward (muse_maskgit_pytorch.py:623-741: random masking, cond-dropped forward, cross-entropy on the masked positions) + the
+    hand-written backward (training.py) + torch.optim.AdamW on the C2 base transformer, token ids as input (no VAE in the step).  One process per
+    GPU; with N > 1 the gradients are averaged by parallel.GradBucketer (bucketed asynchronous RCCL all-reduces overlapped with the backward)."""
+    import muse_maskgit_pytorch_amd as mm
+    from muse_maskgit_pytorch_amd.parallel import GradBucketer
+    torch.manual_seed(0)
+    tr = mm.MaskGitTransformer(num_tokens=65536, seq_len=256, dim=512, depth=8, dim_head=64, heads=8, ff_mult=4, t5_name='t5-small').to(dev)
+    mg = mm.MaskGit(vae=None, transformer=tr, image_size=256)
+    if dist is not None:
+        tr.grad_sync = GradBucketer(dist)
+    B, n = args.batch or 32, 256
+    g = torch.Generator().manual_seed(100 + rank)
+    ids = torch.randint(0, 65536, (B, n), generator=g).to(dev)
+    te = synth_text(world * B, args.text_len, tr.text_embed_dim)[rank * B:(rank + 1) * B].to(dev)
+    opt = torch.optim.AdamW(tr.parameters(), lr=1e-4)
+    losses = []
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = mg(ids, text_embeds=te)
+        loss.backward()
+        opt.step()
+        losses.append(loss.detach())
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], device=dev)
+    if dist is not None:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        sec = dt.item() / args.steps
+        print(json.dumps({
+            'metric': 'training tokens/sec (C2 base transformer: MaskGit.forward + backward + AdamW)', 'value': world * B * n / sec, 'unit': 'tokens/sec',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': sec * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'bf16 (fp32 master weights, fp32 gradients)', 'data': 'synthetic',
+            'config': {'workload': 'training step of the BASELINE configs[1] transformer (dim 512, depth 8, 256 tokens, codebook 65536), token ids in, '
+                                   'cosine-schedule random masking, cond_drop_prob 0.5, AdamW', 'sequences_per_gpu_per_step': B, 'global_batch': world * B,
+                       'seq_len': n, 'parallelism': f'dp{world} (bucketed gradient all-reduce overlapped with the backward)'},
+            'note': 'secondary line: BASELINE.json names no training metric; orchestrated from Python over the C-ABI operators (training.py)',
+            'loss_first': float(losses[0]), 'loss_last': float(losses[-1])}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
+
+
 def _respawn_under_torchrun(args):
     """`python bench.py --gpus N` with N > 1 and no launcher: become the launcher (one process per GPU over RCCL), like the driver's
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`."""
@@ -205,6 +260,8 @@ def main():
     ap.add_argument('--tiny', action='store_true', help='configs[0] plumbing case instead of the metric config')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fused-sampling', action='store_true', help='materialise the logits (round-1 path) for A/B timing')
+    ap.add_argument('--train', action='store_true', help='time the TRAINING step of the C2 base transformer (MaskGit.forward + backward + AdamW) instead of '
+                    'generation: a second, separately labelled line -- not the BASELINE metric')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -227,6 +284,8 @@ def main():
     from muse_maskgit_pytorch_amd import _lib
     from muse_maskgit_pytorch_amd.parallel import allgather_ids
     _lib.require_device()
+    if args.train:
+        return train_bench(args, dev, rank, world, dist)
     if args.tiny:
         mg, image_size = build_models(dev, tiny=True)
         desc, cond_size = 'C1 tiny plumbing config', None

@@ -5,7 +5,7 @@
 //   layernorm_bwd       : LayerNorm(x; gamma) with fp32 x (mmp.py:63-70); dx is ACCUMULATED into the residual-stream gradient
 //   geglu_ln_bwd        : gradient of LayerNorm_inner(gate * gelu(x)) w.r.t. the w1 output h = [x | gate] (mmp.py:72-77, 86)
 //   ce_bwd              : d(mean cross-entropy)/d(logits) in bf16 (mmp.py:343)
-//   embed_bwd           : token / position embedding gradients (mmp.py:322-323)
+//   embed_bwd           : token / position embedding gradients (mmp.py:322-323), fixed summation order
 //   colsum partial sums : gamma gradients are reduced deterministically (per-workgroup partials, then one pass over them)
 // All row kernels keep a row in registers: one wave per row, a lane owns fixed columns, so the gamma partial of a workgroup is a
 // plain per-lane accumulation over its rows.
@@ -345,20 +345,71 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
 }
 
 // ------------------------------------------------------------------------------------------------ embedding backward
-// x[b*n + p] = token_emb[ids] + pos_emb[p]  ->  dpos[p] = sum_b dx[b*n + p] (fixed order), dtoken[id] += dx (fp32 atomics: many
-// rows share the mask id, and the order of those additions is not fixed -- the only non-deterministic sum of the backward pass)
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, int B, int n, int D, const float* __restrict__ dx,
-                                                        float* __restrict__ dtoken, float* __restrict__ dpos) {
+// x[b*n + p] = token_emb[ids] + pos_emb[p]  ->  dpos[p] = sum_b dx[b*n + p], dtoken[id] += sum over the rows that carry id.  Both sums run in
+// a FIXED order (ascending row index), so the whole backward pass is bit-reproducible: many rows share an id (the mask id covers half the
+// batch), and fp32 atomics would add them in whatever order the hardware schedules.
+__global__ __launch_bounds__(256) void embed_pos_bwd_kernel(int B, int n, int D, const float* __restrict__ dx, float* __restrict__ dpos) {
     const int p = blockIdx.x;
     for (int d = threadIdx.x; d < D; d += 256) {
         float s = 0.f;
-        for (int b = 0; b < B; ++b) {
-            const float v = dx[((long)b * n + p) * D + d];
-            s += v;
-            atomicAdd(dtoken + ids[(long)b * n + p] * D + d, v);
-        }
+        for (int b = 0; b < B; ++b) s += dx[((long)b * n + p) * D + d];
         dpos[(long)p * D + d] = s;
     }
+}
+// one workgroup per token row r: if r is the FIRST row with its id, it sums the gradient rows of every row with that id in ascending order and
+// is the only writer of dtoken[id]; any other workgroup leaves after the look-back.  Matches are found 256 rows at a time (one ballot per wave).
+template <int NC>      // columns per thread: D <= 256 * NC
+__global__ __launch_bounds__(256) void embed_token_bwd_kernel(const int64_t* __restrict__ ids, int R, int D, const float* __restrict__ dx,
+                                                              float* __restrict__ dtoken) {
+    constexpr int U = 32 / NC;      // matching rows per trip: U * NC loads in flight per lane
+    __shared__ unsigned long long masks[4];
+    __shared__ int seen;
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t id = ids[r];
+    if (tid == 0) seen = 0;
+    __syncthreads();
+    bool hit = false;
+    for (int j = tid; j < r; j += 256) hit |= ids[j] == id;
+    if (__ballot(hit) != 0ull && lane == 0) seen = 1;
+    __syncthreads();
+    if (seen) return;
+    float acc[NC];     // columns tid, tid + 256, ...
+#pragma unroll
+    for (int i = 0; i < NC; ++i) acc[i] = 0.f;
+    for (int base = r & ~255; base < R; base += 256) {
+        const int j = base + tid;
+        const unsigned long long m = __ballot(j >= r && j < R && ids[j] == id);
+        if (lane == 0) masks[wid] = m;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            unsigned long long mm = masks[w];
+            while (mm) {      // U matching rows per trip: their loads are in flight together, the additions stay in ascending row order
+                int jj[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    jj[u] = mm ? base + w * 64 + __builtin_ctzll(mm) : -1;
+                    mm &= mm - 1;      // (0 stays 0)
+                }
+                float v[U][NC];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int i = 0; i < NC; ++i)
+                        v[u][i] = (jj[u] >= 0 && tid + i * 256 < D) ? dx[(long)jj[u] * D + tid + i * 256] : 0.f;
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (jj[u] >= 0) {
+#pragma unroll
+                        for (int i = 0; i < NC; ++i) acc[i] += v[u][i];
+                    }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+        if (tid + i * 256 < D) dtoken[id * D + tid + i * 256] += acc[i];
 }
 
 // ------------------------------------------------------------------------------------------------ BCE head backward (TokenCritic)
@@ -521,8 +572,15 @@ int k_sum_parts_bf16(hipStream_t s, const bf16_t* parts, int P, long n, bf16_t* 
 
 int k_embed_bwd(hipStream_t s, const int64_t* ids, int B, int n, int D, const float* dx, float* dtoken, float* dpos) {
     if (B <= 0) return MM_OK;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(n), dim3(256), 0, s, ids, B, n, D, dx, dtoken, dpos);
-    return mm_check_launch("embed_bwd_kernel");
+    if (D > 2048) return mm_set_error(MM_ERR_SHAPE, "embed_bwd: D <= 2048");
+    hipLaunchKernelGGL(embed_pos_bwd_kernel, dim3(n), dim3(256), 0, s, B, n, D, dx, dpos);
+    int rc = mm_check_launch("embed_pos_bwd_kernel");
+    if (rc) return rc;
+    if (D <= 256) hipLaunchKernelGGL(embed_token_bwd_kernel<1>, dim3(B * n), dim3(256), 0, s, ids, B * n, D, dx, dtoken);
+    else if (D <= 512) hipLaunchKernelGGL(embed_token_bwd_kernel<2>, dim3(B * n), dim3(256), 0, s, ids, B * n, D, dx, dtoken);
+    else if (D <= 1024) hipLaunchKernelGGL(embed_token_bwd_kernel<4>, dim3(B * n), dim3(256), 0, s, ids, B * n, D, dx, dtoken);
+    else hipLaunchKernelGGL(embed_token_bwd_kernel<8>, dim3(B * n), dim3(256), 0, s, ids, B * n, D, dx, dtoken);
+    return mm_check_launch("embed_token_bwd_kernel");
 }
 
 int k_scatter_rows_bf16(hipStream_t s, const bf16_t* src, const int32_t* row_index, int R, int D, bf16_t* dst) {

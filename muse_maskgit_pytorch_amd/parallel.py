@@ -17,9 +17,12 @@ def allgather_ids(ids, dist, group=None):
     decode step leaves no mask id, mmp.py:584-588), so they travel as int32: 4 bytes/token, 32 KiB per rank at C2."""
     world = dist.get_world_size(group)
     send = ids.to(torch.int32).contiguous()
+    dev = send.device
+    if dist.get_backend(group) == 'gloo':                     # CPU rendezvous (tests, or ranks sharing one device): 32 KiB through host memory
+        send = send.cpu()
     out = torch.empty((world * send.shape[0],) + tuple(send.shape[1:]), dtype=torch.int32, device=send.device)
     dist.all_gather_into_tensor(out, send, group=group)      # concatenated along dim 0 in rank order
-    return out.to(torch.long)
+    return out.to(device=dev, dtype=torch.long)
 
 
 def generate_sharded(maskgit, text_embeds, dist, seed, **kw):

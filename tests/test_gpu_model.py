@@ -515,6 +515,24 @@ def test_training_step_gradients_match_autograd(golden):
     assert loss2.item() < loss.item()
 
 
+def test_training_step_is_bit_reproducible(golden):
+    """two identical training steps (same masking noise) give bit-identical gradients for every parameter: no atomics are left in the
+    backward (the embedding gradient sums rows in a fixed order)"""
+    _, t = _tiny_transformer(golden)
+    mg = mm.MaskGit(image_size=128, transformer=t, vae=None)
+    ids = torch.randint(0, 512, (4, 64), generator=torch.Generator().manual_seed(2)).to(DEV)
+    te = torch.randn(4, 5, 512, generator=torch.Generator().manual_seed(3)).to(DEV)
+    grads = []
+    for _ in range(2):
+        t.zero_grad(set_to_none=True)
+        torch.manual_seed(77)
+        mg(ids, text_embeds=te).backward()
+        grads.append({k: p.grad.clone() for k, p in t.named_parameters() if p.grad is not None})
+    assert len(grads[0]) > 20 and grads[0].keys() == grads[1].keys()
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), f'gradient of {k} differs between two identical steps'
+
+
 def test_token_critic_training_gradients_and_maskgit_critic_loss(golden):
     """the TokenCritic's BCE (mmp.py:345-346) through the hand-written backward vs oracle autograd, and the full
     MaskGit.forward with a token critic (mmp.py:726-741): generator CE + critic BCE, both differentiable."""

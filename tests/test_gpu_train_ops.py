@@ -112,6 +112,20 @@ def test_ce_bwd_and_embed_bwd(ops):
     ((tok[ids] + pos[torch.arange(n)]).reshape(B * n, D) * dx).sum().backward()
     dtok, dpos = ops.embed_bwd(ids.to(DEV), dx.to(DEV), T)
     assert rel_err(dtok, tok.grad) < 1e-5 and rel_err(dpos, pos.grad) < 1e-5
+    # many rows share one id (the mask id in training): the sum runs in ascending row order -> equal to a sequential fp32 sum, bit for bit,
+    # and repeatable; more rows than one 256-row scan chunk, ids straddling the chunk boundaries
+    B, n, D, T = 9, 128, 192, 40
+    ids = torch.randint(0, T, (B, n), generator=g)
+    ids[ids % 3 == 0] = 39
+    dx = torch.randn(B * n, D, generator=g)
+    a_tok, a_pos = ops.embed_bwd(ids.to(DEV), dx.to(DEV), T)
+    b_tok, b_pos = ops.embed_bwd(ids.to(DEV), dx.to(DEV), T)
+    assert torch.equal(a_tok, b_tok) and torch.equal(a_pos, b_pos)
+    seq = torch.zeros(T, D)
+    flat = ids.reshape(-1)
+    for j in range(B * n):
+        seq[flat[j]] += dx[j]
+    assert torch.equal(a_tok.cpu(), seq)
 
 
 def _attn_ref(q, k, v, qs, ks, nk, nv, mask):
