@@ -422,7 +422,10 @@ int mm_transformer_forward(const mm_transformer_t* t, mm_stream_t stream, const 
 
 // ------------------------------------------------------------------------------------------------ generate
 namespace {
-constexpr float FS_MARGIN = 0.20f;    // the bound sits this many sigmas below the Gaussian quantile of the kept fraction: ~14 % instead of 10 % pass
+#ifndef MM_FS_MARGIN
+#define MM_FS_MARGIN 0.20f
+#endif
+constexpr float FS_MARGIN = MM_FS_MARGIN;    // the bound sits this many sigmas below the Gaussian quantile of the kept fraction: ~14 % instead of 10 % pass
 struct GenBufs {
     Bufs b;                 // 2B sequences
     bf16_t* ctx;            // [B][m][D]
