@@ -388,6 +388,7 @@ def main():
             'transformer_tok_per_s_per_gpu': B * n * passes / loop_s,
             'transformer_tok_per_s_per_gpu_kind': 'reference-equivalent (36 full passes per generate; 37 % of the logits rows and the null pass\'s cross-attention are provably dead work and skipped)',
             'executed_tok_per_s_per_gpu': 2 * B * n * T / loop_s,
+            'generated_tok_per_s_per_gpu': B * n / loop_s,      # image tokens produced / decode-loop time
             'decode_loop_ms_per_step': loop_ms / args.steps,
             'executed_tflops_decode_loop': ex_flops / loop_s / 1e12,
             'executed_mfma_frac_decode_loop': ex_flops / loop_s / 1e12 / PEAK_BF16_TFLOPS,
