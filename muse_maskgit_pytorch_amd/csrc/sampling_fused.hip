@@ -19,6 +19,9 @@
 #include "common.h"
 #include "muse_hip_internal.h"
 
+#ifndef MM_EXP
+#define MM_EXP 0
+#endif
 namespace {
 
 __device__ __forceinline__ uint32_t fkey(float f) {      // order-preserving float -> uint32 (as in sampling.hip)
@@ -105,6 +108,7 @@ constexpr int FT = 512, FW = FT / 64;
 constexpr int WSL = 1408;                       // per-wave slice of the candidate list; a wave gathers 1/8 of the tiles: ~1150 +- 35 values at V = 65536
 constexpr int LIST_CAP = FW * WSL;              // 11264 candidates of one row held in LDS as (fp32 value, u16 index): 66 KiB
 constexpr int NBF = 1024;                       // value-linear histogram bins over [thr_lo, row max]
+constexpr int GU = 16;                          // tiles per wave whose candidate loads are in flight together (2 rounds per row at V = 65536)
 constexpr int CANDF = 1024;                     // exact-select capacity (members of the bin that holds the k-th largest)
 
 struct FusedShared {
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(FT, 2) void sample_fused_kernel(const FusedSampleAr
         // softmax denominator: sum_t tsum_t * exp(tmax_t - M), combined in a fixed order (deterministic)
         const float term = wave_sum((tid < NT) ? tsum * expf(tmax - M) : 0.f);
         if (lane == 0) S.redx[wid] = term;
-        // ---- gather: wave w takes tiles w, w + 8, ...: the kept lanes' float4s (coalesced reads, issued 8 tiles at a time), every value >= the
+        // ---- gather: wave w takes tiles w, w + 8, ...: the kept lanes' float4s (coalesced reads, issued GU tiles at a time), every value >= the
         //      bound is appended to THIS WAVE's slice of the LDS list (running count + ballot prefix: no atomics) and binned
         const float lo = p.thr[row];
         const float span = M - lo;
@@ -155,11 +159,11 @@ __global__ __launch_bounds__(FT, 2) void sample_fused_kernel(const FusedSampleAr
         float* myx = S.xs + wid * WSL;
         uint16_t* myc = S.cols + wid * WSL;
         int wcount = 0;                                           // wave-uniform
-        for (int t0 = wid; t0 < NT; t0 += FW * 8) {
-            float4 v[8];
-            bool mine[8];
+        for (int t0 = wid; t0 < NT; t0 += FW * GU) {
+            float4 v[GU];
+            bool mine[GU];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < GU; ++u) {
                 const int t_ = t0 + u * FW;
                 mine[u] = false;
                 v[u] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(FT, 2) void sample_fused_kernel(const FusedSampleAr
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < GU; ++u) {
                 const int t_ = t0 + u * FW;
                 const float xv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
@@ -186,6 +190,7 @@ __global__ __launch_bounds__(FT, 2) void sample_fused_kernel(const FusedSampleAr
                 }
             }
         }
+        if (MM_EXP == 1) { __syncthreads(); continue; }      /* tools: gather only */
         if (lane == 0) S.wcnt[wid] = wcount;
         __syncthreads();
         float sumexp = 0.f;
@@ -261,6 +266,7 @@ __global__ __launch_bounds__(FT, 2) void sample_fused_kernel(const FusedSampleAr
             __syncthreads();
             thr = prefix;
         }
+        if (MM_EXP == 2) { __syncthreads(); continue; }      /* tools: + threshold */
         // ---- every wave squeezes its slice down to the kept entries (value >= the k-th largest), in place: the write position never passes the
         //      read position, so the Gumbel loop below runs on dense lanes (71 % of the candidates are kept, interleaved at random)
         {
@@ -282,28 +288,21 @@ __global__ __launch_bounds__(FT, 2) void sample_fused_kernel(const FusedSampleAr
             if (lane == 0) S.wcnt[wid] = wpos;
             __syncthreads();
         }
-        // ---- Gumbel argmax over the kept entries (mmp.py:410-411); ties -> lower index.  Thread t takes entries t, t + 512, ... of the
-        //      concatenation of the slices (each slice dense now)
+        if (MM_EXP == 3) { __syncthreads(); continue; }      /* tools: + compaction */
+        // ---- Gumbel argmax over the kept entries (mmp.py:410-411); ties -> lower index
         const float T = p.temperature;
         float best = -INFINITY, best_x = 0.f;
         int best_i = 0x7FFFFFFF;
-        int ktotal = 0;
-#pragma unroll
-        for (int w2 = 0; w2 < FW; ++w2) ktotal += S.wcnt[w2];
-        for (int g = tid; g < ktotal; g += FT) {
-            int rem = g, w2 = 0;                                  // slice that holds the g-th kept entry
-#pragma unroll
-            for (int q = 0; q < FW - 1; ++q) {
-                const int c_ = S.wcnt[q];
-                const bool past = (w2 == q) && rem >= c_;
-                rem -= past ? c_ : 0;
-                w2 += past ? 1 : 0;
+        {      // every wave scans its own (dense) slice: the result does not depend on which lane sees which entry (ties go by column index)
+            const int cw = S.wcnt[wid];
+            const float* myx3 = S.xs + wid * WSL;
+            const uint16_t* myc3 = S.cols + wid * WSL;
+            for (int i = lane; i < cw; i += 64) {
+                const float x = myx3[i];
+                const int idx = (int)myc3[i];
+                const float y = x / T + noise_gumbel(p, pos_flat, idx);
+                if (y > best || (y == best && idx < best_i)) { best = y; best_i = idx; best_x = x; }
             }
-            const int i = w2 * WSL + rem;
-            const float x = S.xs[i];
-            const int idx = (int)S.cols[i];
-            const float y = x / T + noise_gumbel(p, pos_flat, idx);
-            if (y > best || (y == best && idx < best_i)) { best = y; best_i = idx; best_x = x; }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
