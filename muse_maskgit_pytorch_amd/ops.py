@@ -401,12 +401,14 @@ def geglu_ln_bwd(h, dz, F, gamma):
     return dh, dg[:F]
 
 
-def ce_bwd(logits, labels, scale):
+def ce_bwd(logits, labels, scale, pad_to=1):
+    """d(mean CE)/d(logits) as bf16 [R, Vp]: Vp = V rounded up to `pad_to`, the padding columns zero (a GEMM contraction dim downstream)."""
     _chk_cuda(logits, labels)
     R, V = logits.shape
     assert logits.dtype == torch.float32 and labels.dtype == torch.long and logits.stride(1) == 1
-    dl = torch.empty(R, V, dtype=bf16, device=logits.device)
-    L.check(L.lib().mm_ce_bwd(L.stream(), L.ptr(logits), logits.stride(0), R, V, L.ptr(labels.contiguous()), float(scale), L.ptr(dl), V), 'mm_ce_bwd')
+    Vp = (V + pad_to - 1) // pad_to * pad_to
+    dl = torch.empty(R, Vp, dtype=bf16, device=logits.device) if Vp == V else torch.zeros(R, Vp, dtype=bf16, device=logits.device)
+    L.check(L.lib().mm_ce_bwd(L.stream(), L.ptr(logits), logits.stride(0), R, V, L.ptr(labels.contiguous()), float(scale), L.ptr(dl), Vp), 'mm_ce_bwd')
     return dl
 
 
@@ -445,15 +447,14 @@ def scatter_rows(src, row_index, M):
 def attention_bwd(q, k, v, o, dout, q_scale, k_scale, null_k, null_v, key_mask=None, scale=8.0):
     """Muse attention backward.  q/o/dout (b,h,n,64), k/v (b,h,j,64) bf16 strided views.  Returns dqn (b,n,h*64), dkn, dv (b,j,h*64)
     bf16 -- gradients w.r.t. the normalised q / k and v -- and dnk, dnv fp32 (b*h, 64) for the null key / value.
-    n > 256 (super-res): one kernel call per 256-query chunk, the chunks' partial key / value gradients are summed afterwards."""
+    One kernel call per block of <= 256 queries (blocks shorter than the kernel's 64 / 128 / 256 are padded), the blocks' partial key /
+    value gradients are summed afterwards."""
     _chk_cuda(q, k, v, o, dout, key_mask)
     b, h, n, d = q.shape
     j = k.shape[2]
     dev = q.device
     jj = max(j, 1)
-    chunks = 1 if n <= 256 else n // 256
-    assert n <= 256 or n % 256 == 0, 'attention_bwd: sequences longer than 256 must be a multiple of 256'
-    nq = n // chunks
+    chunks = (n + 255) // 256
     dqn = torch.empty(b, n, h * 64, dtype=bf16, device=dev)
     dkn = torch.empty(chunks, b, jj, h * 64, dtype=bf16, device=dev)
     dv = torch.empty(chunks, b, jj, h * 64, dtype=bf16, device=dev)
@@ -465,12 +466,27 @@ def attention_bwd(q, k, v, o, dout, q_scale, k_scale, null_k, null_v, key_mask=N
         return (L.ptr(t), t.stride(0), t.stride(1), t.stride(2))
 
     for c in range(chunks):
-        qs = slice(c * nq, (c + 1) * nq)
-        dq_c = dqn[:, qs]
-        L.check(L.lib().mm_attention_bwd(L.stream(), *st(q[:, :, qs]), *st(k), *st(v), *st(o[:, :, qs]), *st(dout[:, :, qs]),
-                                         L.ptr(dq_c), n * h * 64, 64, h * 64, L.ptr(dkn[c]), jj * h * 64, 64, h * 64,
-                                         L.ptr(dv[c]), jj * h * 64, 64, h * 64, L.ptr(dnk[c]), L.ptr(dnv[c]), b, h, nq, j, L.ptr(km), j,
+        lo = c * 256
+        nq = min(256, n - lo)
+        nqp = 64 if nq <= 64 else (128 if nq <= 128 else 256)        # the kernel's query-block sizes
+        qs = slice(lo, lo + nq)
+        qc, oc, dc, dq_c, dq_sb = q[:, :, qs], o[:, :, qs], dout[:, :, qs], dqn[:, qs], n * h * 64
+        if nqp != nq:
+            # pad the query block: the extra queries repeat query 0 with a zero output gradient, so dS = P * (dP - delta) is exactly 0 for
+            # them and they add nothing to the key / value gradients; their own dq rows are dropped
+            def padq(t, zero=False):
+                out = torch.zeros(b, h, nqp, 64, dtype=bf16, device=dev) if zero else t[:, :, :1].expand(b, h, nqp, 64).contiguous()
+                out[:, :, :nq] = t
+                return out
+            qc, oc, dc = padq(qc), padq(oc), padq(dc, zero=True)
+            dq_c = torch.empty(b, nqp, h * 64, dtype=bf16, device=dev)
+            dq_sb = nqp * h * 64
+        L.check(L.lib().mm_attention_bwd(L.stream(), *st(qc), *st(k), *st(v), *st(oc), *st(dc),
+                                         L.ptr(dq_c), dq_sb, 64, h * 64, L.ptr(dkn[c]), jj * h * 64, 64, h * 64,
+                                         L.ptr(dv[c]), jj * h * 64, 64, h * 64, L.ptr(dnk[c]), L.ptr(dnv[c]), b, h, nqp, j, L.ptr(km), j,
                                          L.ptr(q_scale), L.ptr(k_scale), L.ptr(null_k), L.ptr(null_v), float(scale)), 'mm_attention_bwd')
+        if nqp != nq:
+            dqn[:, qs] = dq_c[:, :nq]
     if chunks == 1:
         return dqn, dkn[0][:, :j], dv[0][:, :j], dnk[0], dnv[0]
     per = b * jj * h * 64

@@ -185,6 +185,13 @@ class TransformerTrainFn(torch.autograd.Function):
             sv['layers'].append((lw, ls))
         hw = 'head.weight' if cfg['ext_head'] else 'to_logits'
         W['wl'] = P[hw].detach().to(bf16).contiguous()
+        V = W['wl'].shape[0]
+        if not cfg['bce'] and V % 64:      # a vocabulary that is not a multiple of 64: zero weight rows pad it (V is a contraction dim of the backward)
+            if V % 4:
+                raise NotImplementedError('MI355X training path: num_tokens must be a multiple of 4')
+            wl_p = torch.zeros(_pad64(V), D, dtype=bf16, device=dev)
+            wl_p[:V] = W['wl']
+            W['wl'] = wl_p
         if cfg['bce']:
             # ---- TokenCritic / SelfCritic head (mmp.py:345-346, 352-374, 383-386): one logit per position, BCE against float labels
             #      over ALL positions
@@ -198,13 +205,13 @@ class TransformerTrainFn(torch.autograd.Function):
         else:
             # ---- head on the rows that carry a label (mmp.py:330-343): rows with ignore_index contribute nothing to the loss
             e = ops.layernorm(x, f32(P['final.gamma']), cfg['betas']['final'], row_index=row_index)
-            logits = ops.gemm(e, W['wl'], out_f32=True)
+            logits = ops.gemm(e, W['wl'], out_f32=True)[:, :V]            # (a view: the padding columns are never read)
             loss = ops.ce_loss(logits, labels_rows, -100)
         sv.update(xL=x, e=e, logits=logits, W=W)
         ctx.sv, ctx.cfg = sv, cfg
         ctx.P = {k: v.detach() for k, v in P.items()}
         ctx.ids, ctx.labels_rows, ctx.row_index, ctx.ctx_mask, ctx.cond_ids = ids, labels_rows, row_index, ctx_mask, cond_ids
-        logits_out = logits.detach()
+        logits_out = logits.detach().contiguous()
         ctx.mark_non_differentiable(logits_out)
         return loss.clone(), logits_out
 
@@ -231,8 +238,8 @@ class TransformerTrainFn(torch.autograd.Function):
             G['final.gamma'] = ops.layernorm_bwd(sv['xL'], de, f32(P['final.gamma']), dres, accumulate=False)
         else:
             R = ctx.row_index.numel()
-            dl = ops.ce_bwd(sv['logits'], ctx.labels_rows, 1.0 / R)
-            G['to_logits'] = _wgrad(dl, sv['e'])
+            dl = ops.ce_bwd(sv['logits'], ctx.labels_rows, 1.0 / R, pad_to=64)
+            G['to_logits'] = _wgrad(dl, sv['e'])[:sv['logits'].shape[1]]
             de = _dgrad(dl, sv['W']['wl'])
             G['final.gamma'] = ops.layernorm_bwd(sv['xL'], de, f32(P['final.gamma']), dres, accumulate=False, row_index=ctx.row_index)
         dcx = None
