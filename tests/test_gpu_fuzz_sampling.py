@@ -57,4 +57,6 @@ def test_samplers_match_the_oracle_on_random_shapes(seed):
             assert torch.equal(p2.cpu(), pred_ref), f'fused_sample ids: V={V} R={R} k={k_keep} T={temperature} scale={scale}'
             assert (s2.cpu() - score_ref).abs().max().item() <= 2e-6
         else:
-            assert k_keep > 0.4 * V or V <= 512, 'the candidate list only overflows for very large kept fractions'
+            # the flag may only go up when a row's candidates cannot fit the finishing kernel's list (11264 values, 1408 per wave slice)
+            most = int((logits >= thr.cpu()[:, None]).sum(1).max())
+            assert most > 9500, f'fail flag with at most {most} candidates per row: V={V} k={k_keep}'
