@@ -20,6 +20,11 @@ C4_CFG = dict(num_tokens=65536, seq_len=1024, dim=512, depth=8, dim_head=64, hea
 C4_T, C4_NOISE_SEED, C4_WEIGHT_SEED = 6, 20260925, 2
 
 
+# BASELINE configs[4] shape (paper-scale base): dim 1024, depth 24, 16 heads, codebook 8192; t5-small embeddings (512) -> the text projection runs
+C5_CFG = dict(num_tokens=8192, seq_len=256, dim=1024, depth=24, dim_head=64, heads=16, ff_mult=4, t5_name='t5-small')
+C5_T, C5_NOISE_SEED, C5_WEIGHT_SEED = 5, 20260926, 3
+
+
 def build_transformer(cls, peaky, cfg=None, seed=None):
     """cls = MaskGitTransformer of the reference or of this package.  Module-default init under WEIGHT_SEED, learned scales / norm gains
     made non-trivial, optionally peaky logits, everything rounded to bf16-representable fp32 (exactly loadable by the bf16 engine)."""
@@ -74,6 +79,16 @@ def c4_inputs():
     te[0, L - 3:] = 0
     cond_image = torch.randn(1, 3, 256, 256, generator=g)
     return dict(ids=ids, text_embeds=te, cond_image=cond_image)
+
+
+def c5_inputs():
+    """paper-scale case, batch 2: 256 token ids (half masked), zero-padded text embeddings"""
+    g = torch.Generator().manual_seed(INPUT_SEED + 2)
+    ids = torch.randint(0, 8192, (2, 256), generator=g)
+    ids[torch.rand(2, 256, generator=g) < 0.5] = 8192
+    te = torch.randn(2, L, 512, generator=g)
+    te[1, L - 7:] = 0
+    return dict(ids=ids, text_embeds=te)
 
 
 def checksum(t):

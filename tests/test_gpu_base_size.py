@@ -239,3 +239,71 @@ def test_superres_forward_and_generate_at_full_size(superres, precision):
     finally:
         mg.set_precision('bf16')
         torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs[4] shape: paper-scale transformer at full size
+C5_ROWS = [0, 77, 255, 256, 300, 411, 500, 511]
+
+
+@pytest.fixture(scope='module')
+def paper(golden):
+    import muse_maskgit_pytorch_amd as mm
+    g = golden('paper_c5.pt')
+    tr = R.build_transformer(mm.MaskGitTransformer, peaky=False, cfg=R.C5_CFG, seed=R.C5_WEIGHT_SEED)
+    assert R.state_checksum(tr) == g['weight_checksum']
+    mg = mm.MaskGit(vae=None, transformer=tr, image_size=256).to(DEV).eval()
+    inp = R.c5_inputs()
+    assert {k: R.checksum(v.float()) for k, v in inp.items()} == g['input_checksum']
+    return g, mg, inp
+
+
+@pytest.mark.parametrize('precision', PRECISIONS)
+def test_paper_scale_forward_and_generate_at_full_size(paper, precision):
+    """configs[4] shape (dim 1024, depth 24, 16 heads, V = 8192, the 512 -> 1024 text projection), batch 2, against the reference's fp32 run:
+    logits of the conditioned / null / guidance passes, the embed, and a 5-step generate with the reference's noise.
+    parity engine: ids 100 %, logits within 1e-3; bf16 engine: its own bounds (24 layers of bf16 activations), ids reported."""
+    g, mg, inp = paper
+    tr = mg.transformer
+    te, ids = inp['text_embeds'].to(DEV), inp['ids'].to(DEV)
+    mg.set_precision(precision)
+    try:
+        lc, emb = tr(ids, text_embeds=te, cond_drop_prob=0., return_embed=True)
+        ln = tr(ids, text_embeds=te, cond_drop_prob=1.)
+        sc = tr.forward_with_cond_scale(ids, text_embeds=te, cond_scale=3.)
+        fw = g['forward']
+        tol = 1e-3 if precision == 'parity' else 3.5e-2
+        for name, got, rec, k in (('logits(cond)', lc, fw['logits_cond'], 1), ('logits(null)', ln, fw['logits_null'], 1), ('logits(guidance)', sc, fw['logits_scaled'], 3)):
+            f = got.reshape(512, -1)
+            _err(f'{precision} paper-scale {name} full rows', f[C5_ROWS], rec['rows'], tol * k)
+            _err(f'{precision} paper-scale {name} strided columns', f[:, ::16], rec['cols'], tol * k)
+        _err(f'{precision} paper-scale embed', emb[:, ::4], fw['embed'], 1e-3 if precision == 'parity' else 0.06)
+        gen = g['generate']
+        us = []
+        for s, u in enumerate(R.noise_stream(R.C5_T, R.C5_NOISE_SEED, (2, 256, 8192))):
+            assert R.checksum(u) == gen['noise_checksum'][s]
+            us.append(u)
+        noise = torch.stack(us).to(DEV)
+        with torch.no_grad():
+            tr.to_logits.weight.mul_(R.PEAK)
+        try:
+            assert R.state_checksum(tr) == g['weight_checksum_peaky']
+            trace = {}
+            out = mg.generate(['a', 'b'], fmap_size=16, timesteps=R.C5_T, cond_scale=3., text_embeds=te, noise=noise, noise_kind='uniform', return_ids=True,
+                              trace=trace)
+            masked = torch.stack(list(trace['masked_ids'])).cpu() if isinstance(trace['masked_ids'], list) else trace['masked_ids'].cpu()
+            steps = [(masked[s] == gen['step_in_ids'][s].long()).float().mean().item() for s in range(R.C5_T)]
+            final = (out.cpu().reshape(gen['final_ids'].shape) == gen['final_ids']).float().mean().item()
+            print(f'[paper-scale parity] {precision} generate: final ids equal to the reference run {100 * final:.2f} %, per-step states min {100 * min(steps):.2f} %')
+            if precision == 'parity':
+                assert final == 1.0 and min(steps) == 1.0
+            else:
+                assert final >= 0.80
+                out2 = mg.generate(['a', 'b'], fmap_size=16, timesteps=R.C5_T, cond_scale=3., text_embeds=te, noise=noise, noise_kind='uniform', return_ids=True,
+                                   fused_sampling=False)
+                assert (out == out2).float().mean().item() > 0.99
+        finally:
+            with torch.no_grad():
+                tr.to_logits.weight.div_(R.PEAK)
+    finally:
+        mg.set_precision('bf16')
+        torch.cuda.empty_cache()

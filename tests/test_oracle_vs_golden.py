@@ -250,3 +250,24 @@ def test_oracle_forward_matches_reference_at_superres_size(golden):
         f = got.reshape(1024, -1)
         close(f[g['full_rows']], rec['rows'], 3e-5); close(f[:, ::128], rec['cols'], 3e-5)
     close(emb, fw['embed'], 3e-5)
+
+
+def test_oracle_forward_matches_reference_at_paper_scale_shape(golden):
+    """BASELINE configs[4] shape at full size (dim 1024, depth 24, 16 heads, V = 8192, text projection 512 -> 1024), batch 2"""
+    import golden_recipe as R
+    import muse_maskgit_pytorch_amd as mm
+    g = golden('paper_c5.pt')
+    tr = R.build_transformer(mm.MaskGitTransformer, peaky=False, cfg=R.C5_CFG, seed=R.C5_WEIGHT_SEED)
+    assert R.state_checksum(tr) == g['weight_checksum']
+    sd = {k: v.detach() for k, v in tr.state_dict().items()}
+    inp = R.c5_inputs()
+    assert {k: R.checksum(v.float()) for k, v in inp.items()} == g['input_checksum']
+    cfg = dict(depth=24, heads=16)
+    with torch.no_grad():
+        lc, emb = O.transformer_forward(sd, cfg, inp['ids'], inp['text_embeds'], 0., return_embed=True)
+        ln = O.transformer_forward(sd, cfg, inp['ids'], inp['text_embeds'], 1.)
+    fw = g['forward']
+    for got, rec in ((lc, fw['logits_cond']), (ln, fw['logits_null']), (ln + (lc - ln) * 3., fw['logits_scaled'])):
+        f = got.reshape(512, -1)
+        close(f[g['full_rows']], rec['rows'], 5e-5); close(f[:, ::16], rec['cols'], 5e-5)
+    close(emb[:, ::4], fw['embed'], 5e-5)
