@@ -307,3 +307,38 @@ def test_paper_scale_forward_and_generate_at_full_size(paper, precision):
     finally:
         mg.set_precision('bf16')
         torch.cuda.empty_cache()
+
+
+def test_training_gradients_at_base_size():
+    """The training path at BASELINE configs[1] size (dim 512, depth 8, V = 65536, B = 2 x 256 tokens): loss and every parameter gradient of
+    the hand-written MI355X backward against torch autograd of the oracle on the same (bf16-representable) weights -- the fixed-shape
+    gradient tests run at the tiny widths only."""
+    import muse_oracle as O
+    import muse_maskgit_pytorch_amd as mm
+    tr = R.build_transformer(mm.MaskGitTransformer, peaky=False).train()
+    sd0 = {k: v.detach().clone() for k, v in tr.state_dict().items()}
+    inp = R.inputs()
+    ids, te = inp['ids'], inp['text_embeds']
+    g = torch.Generator().manual_seed(11)
+    labels = torch.randint(0, 65536, ids.shape, generator=g)
+    labels[ids != 65536] = -1                                      # loss on the masked positions, like MaskGit.forward (mmp.py:700-712)
+    tr = tr.to(DEV)
+    loss = tr(ids.to(DEV), text_embeds=te.to(DEV), labels=labels.to(DEV), ignore_index=-1)
+    loss.backward()
+    sd = {k: (v.float().clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd0.items()}
+    ref = O.transformer_loss(sd, dict(depth=8, heads=8), ids, te, labels, ignore_index=-1, rp=O.bf16_round)
+    ref.backward()
+    print(f'[base-size parity] training loss {loss.item():.5f} vs oracle {ref.item():.5f}')
+    assert abs(loss.item() - ref.item()) < 1e-2 * abs(ref.item())
+    worst = (0., '')
+    for name, p in tr.named_parameters():
+        if name.startswith('self_cond_to_init_embed') or name == 'norm.gamma':
+            continue
+        rg, gg = sd[name].grad, p.grad.float().cpu()
+        rel = (gg - rg).abs().max().item() / (rg.abs().max().item() + 1e-20)
+        cos = torch.nn.functional.cosine_similarity(gg.flatten(), rg.flatten(), dim=0).item()
+        worst = max(worst, (rel, name))
+        assert rel < 4e-2 and cos > 0.995, f'{name}: rel {rel:.3e} cos {cos:.5f}'
+    print(f'[base-size parity] training gradients: worst per-tensor relative error {worst[0]:.3e} ({worst[1]})')
+    del tr
+    torch.cuda.empty_cache()
