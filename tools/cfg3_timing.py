@@ -1,4 +1,5 @@
-"""Cycle stamps inside gemm_cfg3_kernel (tools/build_exp.sh <N> gemm_cfg3 -DMM_GEMM_TIMING, run with MM_LIB=.../libmuse_exp<N>.so); tools only.
+"""Cycle stamps inside gemm_cfg3_kernel (tools/build_exp.sh <N> gemm_cfg3 -DMM_GEMM_TIMING, run with MM_LIB=.../libmuse_exp<N>.so MM_DEBUG=0x4000000);
+tools only.  The stamps perturb the phases they measure: use them for the shape of a step, ablation builds (MM_EXP) for magnitudes.
 Per k-step and wave group: C start | MFMAs issued | (wait, barrier) L start | DMA issued | load-phase work done | waits done | (barrier)."""
 import ctypes, os, sys, torch
 import numpy as np
@@ -24,7 +25,7 @@ for grp, name in ((0, 'A'), (1, 'B')):
     seg = np.diff(t, axis=2)                                     # [tile][kt][5]: C, wait+barrier, DMA issue, L work, final wait
     mid = slice(2, tiles - 1)
     names = ['C (MFMA issue)', 'wait+barrier', 'DMA issue', 'L work', 'final wait']
-    print(f'group {name}: {tiles} tiles; ticks are 10 ns (100 MHz)')
+    print(f'group {name}: {tiles} tiles; shader-clock cycles (each stamp itself costs ~100: s_memtime + lgkmcnt(0) + one store)')
     for i, nm in enumerate(names):
         print(f'  {nm:16s}', np.round(seg[mid, :, i].mean(0), 1))
     bar = t[mid, 1:, 0] - t[mid, :-1, -1]
