@@ -335,3 +335,64 @@ def test_patch_reference_mode_2_keeps_the_reference_classes():
     finally:
         mm.unpatch_reference()
     assert mmp.MaskGit.generate is orig
+
+
+def test_mm_generate_rejects_bad_parameters_before_any_launch():
+    """Argument validation of the decode entry point (host structs only: every error below is returned before the first kernel launch, so it
+    runs without a GPU): schedule, outputs, critic combinations, workspaces."""
+    import ctypes as C
+    from muse_maskgit_pytorch_amd import _lib as L
+    lib = L.lib()
+    dummy = torch.zeros(64, dtype=torch.uint8)
+
+    class H:      # a transformer handle over dummy pointers: mm_transformer_create copies the description, nothing dereferences it here
+        def __init__(self, dim_out, vocab_rows):
+            self.layers = (L.LayerWeights * 1)()
+            d = L.TransformerDesc(dim=128, depth=1, heads=2, dim_head=64, ff_inner=341, ff_inner_padded=384, seq_len=64, num_tokens=512,
+                                  vocab_rows=vocab_rows, dim_out=dim_out, text_dim=512, self_cond=0)
+            d.token_emb = d.pos_emb = d.text_proj = d.final_gamma = d.final_beta = d.to_logits = L.ptr(dummy)
+            d.layers = self.layers
+            self.ptr = C.c_void_p()
+            assert lib.mm_transformer_create(C.byref(d), C.byref(self.ptr)) == 0
+            self.desc = d
+
+        def __del__(self):
+            lib.mm_transformer_destroy(self.ptr)
+
+    h, hc = H(512, 513), H(1, 512)
+    lib = L.lib()
+    buf = torch.zeros(1 << 16, dtype=torch.uint8)
+    B, n, T = 2, 64, 3
+
+    def params(**over):
+        p = L.GenerateParams()
+        p.batch, p.n, p.timesteps, p.k_keep, p.nc, p.L = B, n, T, 52, 0, 5
+        p.cond_scale, p.noise_kind = 3.0, L.MM_NOISE_PHILOX
+        cnt, tmp = (C.c_int32 * T)(64, 40, 1), (C.c_float * T)(1.0, 0.6, 0.3)
+        p.mask_counts, p.temperatures = cnt, tmp
+        p.text_embeds = p.ids = p.scores = L.ptr(buf)
+        p._keep = (cnt, tmp)
+        for k, v in over.items():
+            setattr(p, k, v)
+        return p
+
+    def rc(p, ws_bytes=0):
+        return lib.mm_generate(h.ptr, None, C.byref(p), L.ptr(buf), ws_bytes)
+
+    need = lib.mm_generate_workspace_bytes(h.ptr, B, n, 5, 0)
+    assert need > 0 and lib.mm_generate_critic_workspace_bytes(hc.ptr, B, n, 5, 0) > 0 and lib.mm_generate_critic_workspace_bytes(None, B, n, 5, 0) == 0
+    assert rc(params()) == -6                                            # workspace too small (nothing launched)
+    assert rc(params(timesteps=0), need) == -1
+    bad = params()
+    bad.mask_counts = (C.c_int32 * T)(64, 10, 20)                        # must be non-increasing
+    assert rc(bad, need) == -1
+    bad = params()
+    bad.mask_counts = (C.c_int32 * T)(32, 10, 1)                         # the first step masks everything
+    assert rc(bad, need) == -1
+    assert rc(params(noise_kind=L.MM_NOISE_GUMBEL), need) == -1          # tensor noise mode without a noise tensor
+    assert rc(params(critic=hc.ptr, critic_head_w=L.ptr(buf), critic_head_b=L.ptr(buf), critic_noise=L.ptr(buf)), need) == -1      # exclusive
+    assert rc(params(critic=hc.ptr), need) == -1                         # a critic needs its noise
+    assert rc(params(critic_head_w=L.ptr(buf), critic_noise=L.ptr(buf)), need) == -1      # a self-critic head needs its bias
+    assert rc(params(critic=hc.ptr, critic_noise=L.ptr(buf), critic_workspace=L.ptr(buf), critic_workspace_bytes=64), need) == -6
+    assert rc(params(critic=h.ptr, critic_noise=L.ptr(buf), critic_workspace=L.ptr(buf), critic_workspace_bytes=1 << 16), need) == -1     # dim_out != 1
+    assert b'dim_out' in lib.mm_last_error()
