@@ -18,8 +18,9 @@ def _case(rng):
     heads = rng.choice([2, 4, 8])
     cfg = dict(B=rng.randint(1, 5), fmap=rng.choice([4, 6, 8, 10]), dim=rng.choice([128, 256, 512]), heads=heads, depth=rng.randint(1, 2),
                V=rng.choice([512, 1000, 4096, 8192]), L=rng.randint(1, 9), nc=rng.choice([0, 0, 16]), T=rng.randint(2, 7),
-               variant=rng.choice(['plain', 'plain', 'token_critic', 'self_critic', 'self_cond', 'can_remask', 'cond_scale_1']),
-               cond_scale=rng.choice([1.5, 3.0, 4.0]))
+               # the variants combine freely (mmp.py:540-609): a critic (token / self), self-conditioning, re-masking, single pass
+               critic=rng.choice([None, None, 'token', 'self']), self_cond=rng.random() < 0.3, can_remask=rng.random() < 0.25,
+               cond_scale=rng.choice([1, 1.5, 3.0, 4.0]))
     return cfg
 
 
@@ -30,18 +31,18 @@ def test_mm_generate_equals_the_stepwise_loop_on_random_shapes(seed):
     torch.manual_seed(seed)
     n = c['fmap'] ** 2
     kw = dict(num_tokens=c['V'], seq_len=n, dim=c['dim'], depth=c['depth'], dim_head=64, heads=c['heads'], t5_name='t5-small')
-    t = mm.MaskGitTransformer(self_cond=c['variant'] == 'self_cond', **kw)
+    t = mm.MaskGitTransformer(self_cond=c['self_cond'], **kw)
     with torch.no_grad():
         t.to_logits.weight.mul_(6.)
     extra, gkw = {}, {}
-    if c['variant'] == 'token_critic':
+    if c['critic'] == 'token':
         extra['token_critic'] = mm.TokenCritic(**dict(kw, dim=rng.choice([128, 256]), heads=rng.choice([2, 4])))
-    elif c['variant'] == 'self_critic':
+    elif c['critic'] == 'self':
         extra['self_token_critic'] = True
-    elif c['variant'] == 'can_remask':
+    if c['can_remask']:
         extra['no_mask_token_prob'] = 0.25
         gkw['can_remask_prev_masked'] = True
-    cond_scale = 1 if c['variant'] == 'cond_scale_1' else c['cond_scale']
+    cond_scale = c['cond_scale']
     vae = cond = None
     image_size = 16 * c['fmap']
     if c['nc']:
@@ -56,7 +57,7 @@ def test_mm_generate_equals_the_stepwise_loop_on_random_shapes(seed):
     te = torch.randn(c['B'], c['L'], 512, device=DEV)
     if c['L'] > 2 and c['B'] > 1:
         te[1, c['L'] // 2:] = 0.                                       # zero-padded text rows = masked keys
-    critic = c['variant'] in ('token_critic', 'self_critic')
+    critic = c['critic'] is not None
     if critic:
         gkw['critic_noise'] = torch.rand(c['T'], c['B'], n, device=DEV)
     common = dict(timesteps=c['T'], text_embeds=te, seed=seed, fmap_size=c['fmap'], cond_scale=cond_scale, cond_images=cond, return_ids=True, **gkw)
