@@ -652,7 +652,8 @@ class MaskGit(nn.Module):
         sample, so sharded runs reproduce the unsharded ids), `trace` receives per-step states, `critic_noise` [T,B,n]
         injects the U(0,1) draws of the token-critic score annealing (mmp.py:601).  `negative_texts` (or `neg_text_embeds`) is an
         EXTENSION: the reference's negative-prompt path cannot run (see Transformer.forward_with_neg_prompt).  `fused_sampling=False` forces
-        the decode loop to materialise the logits (same ids; tests / A-B timing).  Every decode variant of the reference -- token critic / self critic
+        the decode loop to materialise the logits (same ids; tests / A-B timing); `fused_sampling='deferred'` leaves the device status flag in
+        `self.fused_status` instead of reading it (hipGraph capture of the fused path: check it after every replay).  Every decode variant of the reference -- token critic / self critic
         scores, self-conditioning, can_remask_prev_masked, cond_scale == 1 -- runs inside the one mm_generate call; `stepwise=True` runs the same
         loop one operator call at a time from Python instead (tests: the two must agree bit for bit)."""
         tr = self.transformer
@@ -740,17 +741,22 @@ class MaskGit(nn.Module):
             self._gen_ws = torch.zeros(int(wsb), dtype=torch.uint8, device=dev)      # (zero-filled once, see Transformer._workspace)
         # Sampling without the logits round trip (mm_fused_*): every row's k-th largest logit is bounded before its logits exist and the bound is
         # VERIFIED per row on the device; a row it cannot be proven for (heavy-tailed logits) raises `status` and the call is repeated on the
-        # logits path -- the ids never depend on the estimate.  Reading the flag is the one host synchronisation of generate(); under stream
-        # capture (hipGraph) it is not possible, so capture uses the logits path.
+        # logits path -- the ids never depend on the estimate.  Reading the flag is the one host synchronisation of generate().  Under stream
+        # capture (hipGraph) the read is not possible: by default capture takes the logits path; with fused_sampling='deferred' the fused path
+        # is captured and the flag tensor is left in `self.fused_status` (zeroed inside the graph) for the caller to check after each replay --
+        # non-zero means that replay's ids are invalid and the call has to be repeated with fused_sampling=False.
         capturing = torch.cuda.is_current_stream_capturing()
+        deferred = fused_sampling == 'deferred'
         status = None
-        if fused_sampling and not capturing:
+        if fused_sampling and (deferred or not capturing):
             status = torch.zeros(1, dtype=torch.int32, device=dev)
             p.status = L.ptr(status)
         else:
             p.flags |= L.MM_GEN_NO_FUSED_SAMPLING
         L.check(L.lib().mm_generate(h.ptr, L.stream(), C.byref(p), L.ptr(self._gen_ws), self._gen_ws.numel()), 'mm_generate')
-        if status is not None and int(status.item()) != 0:
+        if deferred:
+            self.fused_status = status
+        elif status is not None and int(status.item()) != 0:
             self.fused_sampling_fallbacks += 1
             p.flags, p.status = p.flags | L.MM_GEN_NO_FUSED_SAMPLING, None
             L.check(L.lib().mm_generate(h.ptr, L.stream(), C.byref(p), L.ptr(self._gen_ws), self._gen_ws.numel()), 'mm_generate')

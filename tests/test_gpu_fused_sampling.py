@@ -176,3 +176,26 @@ def test_decode_variants_inside_mm_generate_with_fused_sampling(name):
     # the logits path of the same call is the stepwise loop bit for bit
     c = mg.generate([''] * B, timesteps=T, text_embeds=te, seed=5, fmap_size=8, fused_sampling=False, **gkw)
     assert torch.equal(c, b)
+
+
+def test_fused_sampling_inside_a_hip_graph_with_the_deferred_status_flag():
+    """generate(fused_sampling='deferred') under stream capture: the fused path (no logits) is captured, the device flag is left for the caller;
+    replays reproduce the eager fused ids and leave the flag at 0"""
+    torch.manual_seed(2)
+    t = mm.MaskGitTransformer(num_tokens=8192, seq_len=64, dim=256, depth=2, dim_head=64, heads=4, t5_name='t5-small')
+    with torch.no_grad():
+        t.to_logits.weight.mul_(6.)
+    mg = mm.MaskGit(image_size=128, transformer=t, vae=None).to(DEV)
+    te = torch.randn(4, 7, 512, device=DEV)
+    eager = mg.generate([''] * 4, timesteps=6, text_embeds=te, seed=9, fmap_size=8)
+    assert mg.fused_sampling_fallbacks == 0
+    torch.cuda.synchronize()
+    graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            captured = mg.generate([''] * 4, timesteps=6, text_embeds=te, seed=9, fmap_size=8, fused_sampling='deferred')
+    for _ in range(2):
+        captured.fill_(-1)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert int(mg.fused_status.item()) == 0 and torch.equal(captured, eager)
