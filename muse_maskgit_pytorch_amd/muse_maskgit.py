@@ -768,8 +768,10 @@ class MaskGit(nn.Module):
     def _generate_stepwise(self, texts, cond_images, fmap_size, temperature, thres, can_remask, use_critic, timesteps, cond_scale,
                            critic_noise_scale, text_embeds, noise, noise_kind, seed, row_offset, return_ids, trace, critic_noise=None,
                            negative_texts=None, neg_text_embeds=None):
-        """mmp.py:556-609 one step at a time through the public operators (general transformer forward over all positions):
-        token critic / self critic scores, self-conditioning, can_remask_prev_masked, cond_scale == 1."""
+        """mmp.py:556-609 one step at a time through the public operators (general transformer forward over all positions, logits of every
+        position materialised): the loop of the negative-prompt extension and of the fp8 / parity engines, and -- `generate(stepwise=True)` --
+        the cross-check of mm_generate, which runs the same variants (critics, self-conditioning, can_remask_prev_masked, cond_scale == 1)
+        inside one C call."""
         tr = self.transformer
         dev = tr.token_emb.weight.device
         fmap = fmap_size if exists(fmap_size) else self.vae.get_encoded_fmap_size(self.image_size)
