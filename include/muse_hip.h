@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 2
+#define MM_ABI_VERSION 3
 
 #define MM_OK 0
 #define MM_ERR_SHAPE (-1)
@@ -344,6 +344,11 @@ int mm_f32_lfq_bits(mm_stream_t stream, const float* t_in, int64_t count, int bi
 int mm_f32_nchw_to_nhwc(mm_stream_t stream, const float* in, int B, int C, int HW, float* out);
 int mm_f32_nhwc_to_nchw(mm_stream_t stream, const float* in, int B, int C, int HW, float* out);
 
+/* ---- precision tier 'bf16x3' (mm_transformer_desc.split_products): operand form of an fp32 matrix.  out bf16 [rows][products * K] = the
+ * first `products` (3, 5 or 6) of the segments [h | m | l | h | m | h], x = h + m + l exactly (h = bf16(x), m = bf16(x - h), l = x - h - m).
+ * Feed the result to mm_gemm_bf16 / mm_gemm_cfg_logits with K' = products * K against a weight packed the same way. */
+int mm_split_rows(mm_stream_t stream, const float* x, int64_t ldx, int64_t rows, int K, int products, void* out);
+
 /* ------------------------------------------------------------------------------------------------ transformer */
 
 typedef struct mm_attn_weights {
@@ -395,6 +400,16 @@ typedef struct mm_transformer_desc {
      * mm_generate samples without materialising the logits (mm_fused_*): a row's k-th largest logit is bounded from the row's embedding. */
     const float* logits_wmean;
     const void* logits_wcov;
+    /* Precision tier 'bf16x3' (0 = the bf16 engine above).  P = 3, 5 or 6: fp32-grade results on the bf16 matrix pipe -- every activation that
+     * feeds a Linear is kept as the exact three-term bf16 split of its fp32 value, x = h + m + l, and multiplied as a K-concatenation of P
+     * term pairs X' = [xh|xm|xl|xh|xm|xh][:P] . W' = [wh|wh|wh|wm|wm|wl][:P] (fp32 accumulation in the MFMA): P = 3 when every weight is
+     * bf16-representable (m = l = 0), 5 for two-term weights, 6 for general fp32 weights.  With P != 0 the pointers above change meaning:
+     * every Linear weight (w_q, w_kv, w_out, w1, w2, text_proj, to_logits) is the segment pack bf16 [out][P * in]; w1 is the PLAIN
+     * [2*Fp][P*D] matrix (rows [0, F) = gelu half, rows [Fp, Fp + F) = gate half, the rest zero; w2_folded / ln2_c1 / ln2_c2 unused);
+     * token_emb / pos_emb are fp32 tables; ctx and the `embed` output are bf16 [.][P * D]; q|k|v, GEMM outputs, the residual stream and
+     * the logits are fp32; attention runs on the fp32 MFMA.  Reference arithmetic matched: fp32 end to end (mmp.py:240-259, 279-335). */
+    int32_t split_products;
+    int32_t reserved0;
 } mm_transformer_desc;
 
 typedef struct mm_transformer mm_transformer_t;

@@ -39,7 +39,8 @@ class TransformerDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('dim', 'depth', 'heads', 'dim_head', 'ff_inner', 'ff_inner_padded', 'seq_len',
                                          'num_tokens', 'vocab_rows', 'dim_out', 'text_dim', 'self_cond')] + \
                [('token_emb', c_vp), ('pos_emb', c_vp), ('text_proj', c_vp), ('layers', C.POINTER(LayerWeights)),
-                ('final_gamma', c_vp), ('final_beta', c_vp), ('to_logits', c_vp), ('self_cond_ff', FFWeights), ('logits_wmean', c_vp), ('logits_wcov', c_vp)]
+                ('final_gamma', c_vp), ('final_beta', c_vp), ('to_logits', c_vp), ('self_cond_ff', FFWeights), ('logits_wmean', c_vp), ('logits_wcov', c_vp),
+                ('split_products', C.c_int32), ('reserved0', C.c_int32)]
 
 
 class VaeLayer(C.Structure):
@@ -134,6 +135,7 @@ SIGNATURES = {
     'mm_f32_lfq_bits': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp]),
     'mm_f32_nchw_to_nhwc': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     'mm_f32_nhwc_to_nchw': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    'mm_split_rows': (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp]),
     'mm_transformer_create': (c_int, [C.POINTER(TransformerDesc), C.POINTER(c_vp)]),
     'mm_transformer_destroy': (None, [c_vp]),
     'mm_context_workspace_bytes': (c_sz, [c_vp, c_int, c_int]),
@@ -173,7 +175,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.mm_abi_version() != 2:
+        if l.mm_abi_version() != 3:
             raise MuseHipError('libmuse_hip ABI version mismatch')
         if os.environ.get('MM_DEBUG'):      # tools / A-B runs only: kernel-selection bits (see muse_hip_internal.h)
             l.mm_debug_set(int(os.environ['MM_DEBUG'], 0))

@@ -154,11 +154,19 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 // four values: the kept lanes' float4s are stored lane-compacted into the tile's slot (at most 64 x 16 B: the slot cannot overflow) and the
 // tile's statistics record {max, sum exp(x - max), 64-bit mask of the kept lanes}.  Two VMEM instructions per piece, no atomics.
 constexpr int FS_SLOT = 64;
+// max and sum exp(x - max) of one 256-column piece held as 4 consecutive values per lane.  ONE definition for the GEMM emission, fused_emit and
+// the logits-path sampler (sampling.hip): the softmax denominator of a row is combined from these per-tile numbers in one fixed order on every
+// path, so the confidences 1 - p -- and with them the next step's re-masking -- are bit-identical whichever path sampled the row.
+__device__ __forceinline__ void tile_softmax_stats(const float4 x, float& m, float& e) {
+    const float m4 = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
+    m = wave_max_dpp(m4);
+    e = wave_sum_dpp((__expf(x.x - m) + __expf(x.y - m)) + (__expf(x.z - m) + __expf(x.w - m)));
+}
 __device__ __forceinline__ void fused_emit_piece(const float4 x, int row, int tile, int NT, int lane, float thr, float4* __restrict__ stats,
                                                  float4* __restrict__ cand) {
     const float m4 = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
-    const float m = wave_max_dpp(m4);
-    const float e = wave_sum_dpp((__expf(x.x - m) + __expf(x.y - m)) + (__expf(x.z - m) + __expf(x.w - m)));
+    float m, e;
+    tile_softmax_stats(x, m, e);
     const bool kp = m4 >= thr;
     const unsigned long long bal = __ballot(kp);
     const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
@@ -173,8 +181,8 @@ __device__ __forceinline__ void fused_emit_piece(const float4 x, int row, int ti
 __device__ __forceinline__ bool fused_emit_piece_parked(const float4 x, int row, int tile, int NT, int lane, float thr, float4* __restrict__ cand, int j,
                                                         float4& parked) {
     const float m4 = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
-    const float m = wave_max_dpp(m4);
-    const float e = wave_sum_dpp((__expf(x.x - m) + __expf(x.y - m)) + (__expf(x.z - m) + __expf(x.w - m)));
+    float m, e;
+    tile_softmax_stats(x, m, e);
     const bool kp = m4 >= thr;
     const unsigned long long bal = __ballot(kp);
     const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
@@ -188,6 +196,31 @@ __device__ __forceinline__ bool fused_emit_piece_parked(const float4 x, int row,
 // lane j (< count) stores the parked statistics of piece j to row rows_of_lane (its own piece's token row; < 0: the piece did not exist)
 __device__ __forceinline__ void fused_flush_stats(const float4 parked, int row_of_lane, int tile, int NT, float4* __restrict__ stats) {
     if (row_of_lane >= 0) stats[(size_t)row_of_lane * NT + tile] = parked;
+}
+
+// ---- 'bf16x3' precision tier (split.hip): an fp32 value as the exact sum of three bf16 terms, x = h + m + l
+__device__ __forceinline__ void split3(float x, float& h, float& m, float& l) {
+    h = bf16_to_f32(f32_to_bf16(x));
+    const float r1 = x - h;
+    m = bf16_to_f32(f32_to_bf16(r1));
+    l = r1 - m;                           // <= 8 significant bits: its bf16 conversion is exact
+}
+
+// which term (0 = h, 1 = m, 2 = l) segment s of X' carries: [h m l h m h]
+__device__ __forceinline__ int seg_term(int s) { return s < 3 ? s : (s < 5 ? s - 3 : 0); }
+
+// four consecutive values of one row -> the P segments of that row (8-byte stores)
+__device__ __forceinline__ void store_split4(bf16_t* orow, int K, int P, int col, const float (&v)[4]) {
+    float t[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split3(v[j], t[0][j], t[1][j], t[2][j]);
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {          // unrolled: the term index is a compile-time constant (no scratch for t)
+        if (s < P) {
+            const int k = seg_term(s);
+            *reinterpret_cast<uint2*>(orow + (long)s * K + col) = make_uint2(pack_bf16x2(t[k][0], t[k][1]), pack_bf16x2(t[k][2], t[k][3]));
+        }
+    }
 }
 
 // XCD-aware tile order: block b is dispatched to XCD b % 8 (observed, used for speed only), so give

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
 
     // fused sampling: no logits leave the kernel; every piece emits tile statistics + the kept lanes' values instead (common.h
     // fused_emit_piece).  Its VMEM instructions per piece: 1 statistics store (always issued) + 1 predicated value store.  The counted waits
-    // below only need a LOWER bound of what was issued behind a DMA (under-counting waits for more, never for less): st1 = 1 stays right.
+    // below only need a LOWER bound of what was issued behind a DMA (under-counting waits for more, never for less).
     const bool fused = (WMODE == WIDE_CFG) && p.fs_stats != nullptr;
     f32x4_t acc[4][8];
     f32x4_t held[2][4];             // second half of the previous tile's output (tokens 32..63 of this wave), combined
@@ -303,7 +303,10 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
         if (WMODE == WIDE_CFG && fused && have_prev && half_ == 1 && q_ == 7) {                                \
             const int ftok_ = PIECE_TOKEN(PIECE_ROW(lane & 7), (lane >> 3) & 1);                               \
             fused_flush_stats(parked, (lane < 16 && ftok_ < p.M) ? ftok_ : -1, pn0 >> 8, p.tiles_n, p.fs_stats); \
-            st1 += 1;                                                                                          \
+            /* the store is predicated per lane and skipped (s_cbranch_execz) when none of this wave's 16 pieces exists, i.e. when even its */ \
+            /* first token row pm0 + wid lies beyond M (edge tile with fewer than 8 rows): count it only when it was issued -- an over-count */ \
+            /* would let the next counted wait pass with one LDS-DMA still in flight */                        \
+            st1 += (pm0 + wid < p.M) ? 1 : 0;                                                                  \
         }                                                                                                      \
         ++g;                                                                                                   \
         ++kt;                                                                                                  \

@@ -62,6 +62,8 @@ struct mm_transformer {
     std::vector<mm_layer_weights> layers;
     int I;    // heads * dim_head
     int Fp;
+    int P;    // 0: bf16 engine.  3 / 5 / 6: the 'bf16x3' precision tier (split.hip) -- every GEMM operand is P bf16 segments of an fp32 value, the
+              // weights are packed to match ([N][P*K]), tables / q|k|v / GEMM outputs are fp32, attention runs on the fp32 MFMA (attention_f32.hip)
 };
 
 namespace {
@@ -173,14 +175,16 @@ struct Bufs {       // activation scratch for `rows` token rows
     float* lnp;     // [rows][Fp / 32][2]: LayerNorm(inner) partial sums of the folded feed-forward
 };
 
+// precision tier: GEMM operands (xn, att, a) are P segments wide, GEMM outputs (qkv, h) are fp32
 void carve_bufs(Carver& c, const mm_transformer* t, size_t rows, Bufs& b) {
     const int D = t->d.dim, I = t->I, Fp = t->Fp;
+    const size_t seg = t->P ? (size_t)t->P : 1, f32 = t->P ? 2 : 1;
     b.x = c.take<float>(rows * D);
-    b.xn = c.take<bf16_t>(rows * D);
-    b.qkv = c.take<bf16_t>(rows * 3 * I);
-    b.att = c.take<bf16_t>(rows * I);
-    b.h = c.take<bf16_t>(rows * 2 * Fp);
-    b.a = c.take<bf16_t>(rows * Fp);
+    b.xn = c.take<bf16_t>(rows * D * seg);
+    b.qkv = c.take<bf16_t>(rows * 3 * I * f32);
+    b.att = c.take<bf16_t>(rows * I * seg);
+    b.h = c.take<bf16_t>(rows * 2 * Fp * f32);
+    b.a = c.take<bf16_t>(rows * Fp * seg);
     b.lnp = c.take<float>(rows * (Fp / 32) * 2);
 }
 
@@ -189,6 +193,16 @@ void carve_bufs(Carver& c, const mm_transformer* t, size_t rows, Bufs& b) {
 int ff_block(const mm_transformer* t, hipStream_t s, const mm_ff_weights& w, const float* src, float* dst, int rows, Bufs& b,
              const float* addvec = nullptr, int add_from = 0) {
     const int D = t->d.dim, F = t->d.ff_inner, Fp = t->Fp;
+    if (t->P) {      // precision tier: LN -> P segments -> w1 (fp32 out, plain [x | gate] halves) -> GEGLU + LN(inner) -> P segments -> w2 + residual
+        const int P = t->P;
+        RC(k_layernorm_split(s, addvec ? dst : src, D, rows, D, w.ln1_gamma, w.ln1_beta, nullptr, P, b.xn, nullptr, addvec, add_from, addvec ? dst : nullptr));
+        float* hf = reinterpret_cast<float*>(b.h);
+        RC(gemm_dense(s, b.xn, P * D, (const bf16_t*)w.w1, P * D, rows, 2 * Fp, P * D, hf, 2 * Fp, OUT_F32, nullptr));
+        RC(k_geglu_ln_split(s, hf, 2 * Fp, rows, F, Fp, w.ln2_gamma, w.ln2_beta, P, b.a));
+        RC(gemm_dense(s, b.a, P * Fp, (const bf16_t*)w.w2, P * Fp, rows, D, P * Fp, dst, D, OUT_F32, dst));
+        TR(dst, (size_t)rows * D * 4);
+        return MM_OK;
+    }
     if (addvec) RC(k_layernorm_addvec(s, dst, D, rows, D, w.ln1_gamma, w.ln1_beta, addvec, add_from, b.xn, D));
     else RC(k_layernorm(s, src, D, rows, D, w.ln1_gamma, w.ln1_beta, nullptr, b.xn, D));
     GemmArgs a1;      // Linear(D, 2F) with the GEGLU fused into the epilogue: w1 is packed GEGLU-interleaved, the GEMM emits gate*gelu(x)
@@ -231,6 +245,29 @@ int ff_block(const mm_transformer* t, hipStream_t s, const mm_ff_weights& w, con
 int self_attn_core(const mm_transformer* t, hipStream_t s, const mm_attn_weights& w, int seqs, int n, Bufs& b) {
     const int D = t->d.dim, I = t->I, H = t->d.heads;
     const int rows = seqs * n;
+    if (t->P) {      // precision tier: q|k|v stay fp32, the attention runs on the fp32 MFMA and writes its output as P segments
+        const int P = t->P;
+        RC(k_layernorm_split(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, P, b.xn, nullptr, nullptr, 0, nullptr));
+        const bf16_t* wq = (const bf16_t*)w.w_q;
+        const bf16_t* wkv = (const bf16_t*)w.w_kv;
+        float* qkv = reinterpret_cast<float*>(b.qkv);
+        if (wkv == wq + (size_t)I * P * D) {
+            RC(gemm_dense(s, b.xn, P * D, wq, P * D, rows, 3 * I, P * D, qkv, 3 * I, OUT_F32, nullptr));
+        } else {
+            RC(gemm_dense(s, b.xn, P * D, wq, P * D, rows, I, P * D, qkv, 3 * I, OUT_F32, nullptr));
+            RC(gemm_dense(s, b.xn, P * D, wkv, P * D, rows, 2 * I, P * D, qkv + I, 3 * I, OUT_F32, nullptr));
+        }
+        AttnF32Args a;
+        memset(&a, 0, sizeof(a));
+        a.q = qkv; a.q_sb = (long)n * 3 * I; a.q_sh = 64; a.q_sn = 3 * I;
+        a.k = qkv + I; a.k_sb = a.q_sb; a.k_sh = 64; a.k_sn = 3 * I;
+        a.v = qkv + 2 * I; a.v_sb = a.q_sb; a.v_sh = 64; a.v_sn = 3 * I;
+        a.out_split = b.att; a.os_sb = (long)n * P * I; a.os_sn = (long)P * I; a.os_seg = I; a.P = P;
+        a.B = seqs; a.H = H; a.nq = n; a.nk = n;
+        a.normalize = 1; a.q_scale = w.q_scale; a.k_scale = w.k_scale; a.null_k = w.null_k; a.null_v = w.null_v;
+        a.scale = 8.f;
+        return k_attention_f32(s, a);
+    }
     RC(k_layernorm(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, b.xn, D));
     TR(b.xn, (size_t)rows * D * 2);
     const bf16_t* wq = (const bf16_t*)w.w_q;
@@ -259,7 +296,8 @@ int self_attn_core(const mm_transformer* t, hipStream_t s, const mm_attn_weights
 // x += SelfAttention(x) over `seqs` sequences of n tokens  (mmp.py:126-162 with context = None, :189)
 int self_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weights& w, int seqs, int n, Bufs& b) {
     RC(self_attn_core(t, s, w, seqs, n, b));
-    RC(gemm_dense(s, b.att, t->I, (const bf16_t*)w.w_out, t->I, seqs * n, t->d.dim, t->I, b.x, t->d.dim, OUT_F32, b.x));
+    const int KI = (t->P ? t->P : 1) * t->I;      // precision tier: P segments per operand row
+    RC(gemm_dense(s, b.att, KI, (const bf16_t*)w.w_out, KI, seqs * n, t->d.dim, KI, b.x, t->d.dim, OUT_F32, b.x));
     TR(b.x, (size_t)seqs * n * t->d.dim * 4);
     return MM_OK;
 }
@@ -269,6 +307,27 @@ int cross_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weigh
                      int m, int kv_batch_mod, const uint8_t* key_mask, Bufs& b) {
     const int D = t->d.dim, I = t->I, H = t->d.heads;
     const int rows = seqs * n;
+    if (t->P) {      // precision tier: ckv is fp32 [kv_seqs*m][2I]
+        const int P = t->P;
+        RC(k_layernorm_split(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, P, b.xn, nullptr, nullptr, 0, nullptr));
+        float* q = reinterpret_cast<float*>(b.qkv);
+        RC(gemm_dense(s, b.xn, P * D, (const bf16_t*)w.w_q, P * D, rows, I, P * D, q, I, OUT_F32, nullptr));
+        const float* kv = reinterpret_cast<const float*>(ckv);
+        AttnF32Args a;
+        memset(&a, 0, sizeof(a));
+        a.q = q; a.q_sb = (long)n * I; a.q_sh = 64; a.q_sn = I;
+        a.k = kv; a.k_sb = (long)m * 2 * I; a.k_sh = 64; a.k_sn = 2 * I;
+        a.v = kv + I; a.v_sb = a.k_sb; a.v_sh = 64; a.v_sn = 2 * I;
+        a.out_split = b.att; a.os_sb = (long)n * P * I; a.os_sn = (long)P * I; a.os_seg = I; a.P = P;
+        a.B = seqs; a.H = H; a.nq = n; a.nk = m;
+        a.key_mask = key_mask; a.km_sb = m;
+        a.normalize = 1; a.q_scale = w.q_scale; a.k_scale = w.k_scale; a.null_k = w.null_k; a.null_v = w.null_v;
+        a.scale = 8.f; a.kv_batch_mod = kv_batch_mod;
+        RC(k_attention_f32(s, a));
+        RC(gemm_dense(s, b.att, P * I, (const bf16_t*)w.w_out, P * I, rows, D, P * I, b.x, D, OUT_F32, b.x));
+        TR(b.x, (size_t)rows * D * 4);
+        return MM_OK;
+    }
     RC(k_layernorm(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, b.xn, D));
     TR(b.xn, (size_t)rows * D * 2);
     RC(gemm_dense(s, b.xn, D, (const bf16_t*)w.w_q, D, rows, I, D, b.qkv, I, OUT_BF16, nullptr));
@@ -309,6 +368,8 @@ int mm_transformer_create(const mm_transformer_desc* desc, mm_transformer_t** ou
     if (d.text_proj && (d.text_dim % 64)) return mm_set_error(MM_ERR_SHAPE, "transformer: text_dim must be a multiple of 64 when projected");
     if (!d.text_proj && d.text_dim != d.dim) return mm_set_error(MM_ERR_SHAPE, "transformer: text_proj is NULL but text_dim != dim");
     if (!d.token_emb || !d.pos_emb || !d.to_logits || !d.final_gamma) return mm_set_error(MM_ERR_SHAPE, "transformer: missing weight pointer");
+    if (d.split_products != 0 && d.split_products != 3 && d.split_products != 5 && d.split_products != 6)
+        return mm_set_error(MM_ERR_SHAPE, "transformer: split_products must be 0 (bf16 engine), 3, 5 or 6 (precision tier)");
     mm_transformer* t = new (std::nothrow) mm_transformer();
     if (!t) return mm_set_error(MM_ERR_HIP, "out of host memory");
     t->d = d;
@@ -316,6 +377,7 @@ int mm_transformer_create(const mm_transformer_desc* desc, mm_transformer_t** ou
     t->d.layers = t->layers.data();
     t->I = d.heads * d.dim_head;
     t->Fp = d.ff_inner_padded;
+    t->P = d.split_products;
     *out = t;
     return MM_OK;
 }
@@ -326,8 +388,8 @@ size_t mm_context_workspace_bytes(const mm_transformer_t* t, int B, int L) {
     if (!t) return 0;
     Carver c(nullptr);
     if (t->d.text_proj) {
-        c.take<bf16_t>((size_t)B * L * t->d.text_dim);
-        c.take<bf16_t>((size_t)B * L * t->d.dim);
+        c.take<bf16_t>((size_t)B * L * t->d.text_dim * (t->P ? t->P : 1));
+        c.take<bf16_t>((size_t)B * L * t->d.dim * (t->P ? 2 : 1));      // precision tier: the projection leaves its GEMM as fp32
     }
     return c.used() + 256;
 }
@@ -343,6 +405,23 @@ int mm_transformer_context(const mm_transformer_t* t, mm_stream_t stream, const 
     if (nc > 0 && !cond_ids) return mm_set_error(MM_ERR_SHAPE, "context: cond_ids is NULL");
     if (workspace_bytes < mm_context_workspace_bytes(t, B, L)) return mm_set_error(MM_ERR_WORKSPACE, "context: workspace too small");
     bf16_t* ctxp = (bf16_t*)ctx;
+    if (t->P) {      // precision tier: ctx bf16 [B][m][P*D] (P segments per row), token table fp32
+        const int P = t->P, td = t->d.text_dim;
+        if (L > 0) {
+            if (!t->d.text_proj) {
+                RC(k_split_rows(s, text_embeds, td, (long)B * L, td, P, L, (long)m * P * D, ctxp, key_mask, m, drop_text));
+            } else {
+                Carver c(workspace);
+                bf16_t* tb = c.take<bf16_t>((size_t)B * L * td * P);
+                float* proj = reinterpret_cast<float*>(c.take<bf16_t>((size_t)B * L * D * 2));
+                RC(k_split_rows(s, text_embeds, td, (long)B * L, td, P, L, (long)L * P * td, tb, key_mask, m, drop_text));
+                RC(gemm_dense(s, tb, P * td, (const bf16_t*)t->d.text_proj, P * td, B * L, D, P * td, proj, D, OUT_F32, nullptr));
+                RC(k_split_rows(s, proj, D, (long)B * L, D, P, L, (long)m * P * D, ctxp, nullptr, 0, 0));
+            }
+        }
+        if (nc > 0) RC(k_gather_split(s, (const float*)t->d.token_emb, D, P, cond_ids, B, nc, t->d.vocab_rows, ctxp, key_mask, m, L));
+        return MM_OK;
+    }
     if (L > 0) {
         if (!t->d.text_proj) {
             hipLaunchKernelGGL(text_context_kernel, dim3((B * L + 3) / 4), dim3(256), 0, s, text_embeds, B, L, t->d.text_dim, ctxp,
@@ -378,8 +457,8 @@ size_t mm_transformer_workspace_bytes(const mm_transformer_t* t, int B, int n, i
     Carver c(nullptr);
     Bufs b;
     carve_bufs(c, t, (size_t)B * n, b);
-    c.take<bf16_t>((size_t)B * m * 2 * t->I);    // cross K/V of one layer
-    c.take<bf16_t>((size_t)B * n * t->d.dim);    // embed when the caller does not want it
+    c.take<bf16_t>((size_t)B * m * 2 * t->I * (t->P ? 2 : 1));    // cross K/V of one layer (fp32 in the precision tier)
+    c.take<bf16_t>((size_t)B * n * t->d.dim * (t->P ? t->P : 1));  // embed when the caller does not want it
     return c.used() + 256;
 }
 
@@ -396,27 +475,30 @@ int mm_transformer_forward(const mm_transformer_t* t, mm_stream_t stream, const 
     Carver c(workspace);
     Bufs b;
     carve_bufs(c, t, (size_t)rows, b);
-    bf16_t* ckv = c.take<bf16_t>((size_t)B * m * 2 * I);
-    bf16_t* emb = c.take<bf16_t>((size_t)rows * D);
+    const int P = t->P, KD = (P ? P : 1) * D;      // operand row width of the GEMMs that read [.][D] activations
+    bf16_t* ckv = c.take<bf16_t>((size_t)B * m * 2 * I * (P ? 2 : 1));
+    bf16_t* emb = c.take<bf16_t>((size_t)rows * KD);
     if (embed_out) emb = (bf16_t*)embed_out;
 
     trace::idx = 0;
-    RC(k_embed(s, ids, rows, n, 0, (const bf16_t*)t->d.token_emb, t->d.vocab_rows, (const bf16_t*)t->d.pos_emb, D, b.x));
+    if (P) RC(k_embed_f32(s, ids, rows, n, (const float*)t->d.token_emb, t->d.vocab_rows, (const float*)t->d.pos_emb, D, b.x));
+    else RC(k_embed(s, ids, rows, n, 0, (const bf16_t*)t->d.token_emb, t->d.vocab_rows, (const bf16_t*)t->d.pos_emb, D, b.x));
     TR(b.x, (size_t)rows * D * 4);
     if (t->d.self_cond && self_cond_embed)       // mmp.py:325-328 (zeros when absent: FF(0) still adds LN-beta terms = 0)
         RC(ff_block(t, s, t->d.self_cond_ff, self_cond_embed, b.x, rows, b));
     for (int l = 0; l < t->d.depth; ++l) {
         const mm_layer_weights& w = t->layers[l];
         RC(self_attn_block(t, s, w.self_attn, B, n, b));
-        RC(gemm_dense(s, (const bf16_t*)ctx, D, (const bf16_t*)w.cross_attn.w_kv, D, B * m, 2 * I, D, ckv, 2 * I, OUT_BF16, nullptr));
+        RC(gemm_dense(s, (const bf16_t*)ctx, KD, (const bf16_t*)w.cross_attn.w_kv, KD, B * m, 2 * I, KD, ckv, 2 * I, P ? OUT_F32 : OUT_BF16, nullptr));
         TR(ckv, (size_t)B * m * 2 * I * 2);
         RC(cross_attn_block(t, s, w.cross_attn, B, n, ckv, m, 0, key_mask, b));
         RC(ff_block(t, s, w.ff, b.x, b.x, rows, b));
     }
-    RC(k_layernorm(s, b.x, D, rows, D, t->d.final_gamma, t->d.final_beta, nullptr, emb, D));
+    if (P) RC(k_layernorm_split(s, b.x, D, rows, D, t->d.final_gamma, t->d.final_beta, nullptr, P, emb, nullptr, nullptr, 0, nullptr));
+    else RC(k_layernorm(s, b.x, D, rows, D, t->d.final_gamma, t->d.final_beta, nullptr, emb, D));
     TR(emb, (size_t)rows * D * 2);
     if (logits_out)
-        RC(gemm_dense(s, emb, D, (const bf16_t*)t->d.to_logits, D, rows, t->d.dim_out, D, logits_out, t->d.dim_out, OUT_F32, nullptr));
+        RC(gemm_dense(s, emb, KD, (const bf16_t*)t->d.to_logits, KD, rows, t->d.dim_out, KD, logits_out, t->d.dim_out, OUT_F32, nullptr));
     return MM_OK;
 }
 
@@ -459,30 +541,32 @@ struct CriticBufs {
 };
 void carve_critic(Carver& c, const mm_transformer* ct, int B, int n, int L, int nc, CriticBufs& k) {
     const int m = L + nc;
-    k.ctx = c.take<bf16_t>((size_t)B * m * ct->d.dim);
+    const size_t seg = ct->P ? (size_t)ct->P : 1;
+    k.ctx = c.take<bf16_t>((size_t)B * m * ct->d.dim * seg);
     k.masks = c.take<uint8_t>((size_t)2 * B * m);
     k.ctx_ws_bytes = mm_context_workspace_bytes(ct, B, L);
     k.ctx_ws = c.take<unsigned char>(k.ctx_ws_bytes);
-    k.embc = c.take<bf16_t>((size_t)B * n * ct->d.dim);
-    k.embn = c.take<bf16_t>((size_t)B * n * ct->d.dim);
+    k.embc = c.take<bf16_t>((size_t)B * n * ct->d.dim * seg);
+    k.embn = c.take<bf16_t>((size_t)B * n * ct->d.dim * seg);
     k.sc = c.take<float>((size_t)B * n + 64);
     k.fwd_ws_bytes = mm_transformer_workspace_bytes(ct, B, n, m);
     k.fwd_ws = c.take<unsigned char>(k.fwd_ws_bytes);
 }
 void carve_gen(Carver& c, const mm_transformer* t, int B, int n, int L, int nc, GenBufs& g) {
     const int D = t->d.dim, I = t->I, m = L + nc;
+    const size_t seg = t->P ? (size_t)t->P : 1, f32 = t->P ? 2 : 1;      // precision tier: operands P segments wide, cross K/V fp32
     carve_bufs(c, t, (size_t)2 * B * n, g.b);
-    g.ctx = c.take<bf16_t>((size_t)B * m * D);
+    g.ctx = c.take<bf16_t>((size_t)B * m * D * seg);
     g.masks = c.take<uint8_t>((size_t)2 * B * m);
-    g.ckv = c.take<bf16_t>((size_t)t->d.depth * B * m * 2 * I);
+    g.ckv = c.take<bf16_t>((size_t)t->d.depth * B * m * 2 * I * f32);
     g.cvec = c.take<float>((size_t)t->d.depth * D);
-    g.nullv = c.take<bf16_t>((size_t)I + 64);
+    g.nullv = c.take<bf16_t>((size_t)I * seg + 64);
     g.rows = c.take<int32_t>((size_t)B * n);
-    g.embc = c.take<bf16_t>((size_t)B * n * D);
-    g.embn = c.take<bf16_t>((size_t)B * n * D);
+    g.embc = c.take<bf16_t>((size_t)B * n * D * seg);
+    g.embn = c.take<bf16_t>((size_t)B * n * D * seg);
     g.logits = c.take<float>((size_t)B * n * t->d.dim_out);
     g.xc = c.take<float>((size_t)2 * B * n * D);
-    g.attc = c.take<bf16_t>((size_t)2 * B * n * I);
+    g.attc = c.take<bf16_t>((size_t)2 * B * n * I * seg);
     const bool fs = t->d.logits_wcov && (t->d.dim_out % 256) == 0 && (D % 64) == 0;
     const size_t NT = fs ? (size_t)t->d.dim_out / 256 : 0;
     g.fs_thr = c.take<float>(fs ? (size_t)B * n : 0);
@@ -555,6 +639,7 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
     hipStream_t s = (hipStream_t)stream;
     const int B = p->batch, n = p->n, T = p->timesteps, L = p->L, nc = p->nc, m = L + nc;
     const int D = t->d.dim, I = t->I, V = t->d.dim_out;
+    const int PT = t->P, KD = (PT ? PT : 1) * D, KI = (PT ? PT : 1) * I;      // precision tier: operand rows are P segments wide
     if (B <= 0 || n <= 0 || n > t->d.seq_len || T <= 0) return mm_set_error(MM_ERR_SHAPE, "generate: bad batch/n/timesteps");
     if (t->d.vocab_rows != t->d.num_tokens + 1) return mm_set_error(MM_ERR_SHAPE, "generate: transformer has no mask id (MaskGitTransformer required)");
     if (!p->mask_counts || !p->temperatures || !p->ids || !p->scores) return mm_set_error(MM_ERR_SHAPE, "generate: schedule / outputs required");
@@ -570,6 +655,7 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
     const mm_transformer* cmodel = critic ? critic : (self_critic ? t : nullptr);      // the network the critic scores come from
     if (critic && self_critic) return mm_set_error(MM_ERR_SHAPE, "generate: token critic and self critic are exclusive (mmp.py:456)");
     if (critic && critic->d.dim_out != 1) return mm_set_error(MM_ERR_SHAPE, "generate: the token critic must have dim_out == 1");
+    if (critic && critic->P != t->P) return mm_set_error(MM_ERR_SHAPE, "generate: the token critic must be packed for the same precision tier as the generator");
     if (cmodel) {
         if (!p->critic_noise) return mm_set_error(MM_ERR_SHAPE, "generate: critic_noise [timesteps][B][n] required with a critic");
         if (self_critic && !p->critic_head_b) return mm_set_error(MM_ERR_SHAPE, "generate: critic_head_b required with critic_head_w");
@@ -602,13 +688,14 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
     }
     for (int l = 0; l < t->d.depth; ++l) {
         const mm_attn_weights& w = t->layers[l].cross_attn;
-        bf16_t* ckv_l = g.ckv + (size_t)l * B * m * 2 * I;
-        RC(gemm_dense(s, g.ctx, D, (const bf16_t*)w.w_kv, D, B * m, 2 * I, D, ckv_l, 2 * I, OUT_BF16, nullptr));
+        bf16_t* ckv_l = g.ckv + (size_t)l * B * m * 2 * I * (PT ? 2 : 1);
+        RC(gemm_dense(s, g.ctx, KD, (const bf16_t*)w.w_kv, KD, B * m, 2 * I, KD, ckv_l, 2 * I, PT ? OUT_F32 : OUT_BF16, nullptr));
         if (nc == 0 && P == 2) {
             // softmax over the single unmasked (null) key is exactly 1 -> attention out = bf16(null_v) for every
             // query, so the null pass's cross-attention is the constant row to_out(null_v)
-            RC(k_f32_to_bf16(s, w.null_v, g.nullv, I));
-            RC(gemm_dense(s, g.nullv, I, (const bf16_t*)w.w_out, I, 1, D, I, g.cvec + (size_t)l * D, D, OUT_F32, nullptr));
+            if (PT) RC(k_split_rows(s, w.null_v, I, 1, I, PT, 0, 0, g.nullv, nullptr, 0, 0));
+            else RC(k_f32_to_bf16(s, w.null_v, g.nullv, I));
+            RC(gemm_dense(s, g.nullv, KI, (const bf16_t*)w.w_out, KI, 1, D, KI, g.cvec + (size_t)l * D, D, OUT_F32, nullptr));
         }
     }
     {
@@ -645,7 +732,8 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
             if (e != hipSuccess) return mm_set_hip_error(e, "generate: trace copy");
         }
         // both CFG halves see the same ids: rows [0, M) = cond pass, [M, 2M) = null pass (mmp.py:250-252)
-        RC(k_embed(s, p->ids, M, n, 0, (const bf16_t*)t->d.token_emb, t->d.vocab_rows, (const bf16_t*)t->d.pos_emb, D, b.x));
+        if (PT) RC(k_embed_f32(s, p->ids, M, n, (const float*)t->d.token_emb, t->d.vocab_rows, (const float*)t->d.pos_emb, D, b.x));
+        else RC(k_embed(s, p->ids, M, n, 0, (const bf16_t*)t->d.token_emb, t->d.vocab_rows, (const bf16_t*)t->d.pos_emb, D, b.x));
         if (self_cond && step > 0)                      // x += self_cond_to_init_embed(previous cond embed), mmp.py:325-328 (FF(zeros) = 0 at step 0)
             RC(ff_block(t, s, t->d.self_cond_ff, g.sce, b.x, M, b));
         if (P == 2) {
@@ -660,7 +748,7 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
         const bool compact_last = k < n && !(g_mm_debug & 16384) && !self_cond && !can_remask;
         for (int l = 0; l < t->d.depth; ++l) {
             const mm_layer_weights& w = t->layers[l];
-            const bf16_t* ckv_l = g.ckv + (size_t)l * B * m * 2 * I;
+            const bf16_t* ckv_l = g.ckv + (size_t)l * B * m * 2 * I * (PT ? 2 : 1);
             const bool last_compact = l == t->d.depth - 1 && compact_last;
             const int nq = last_compact ? k : n;             // queries per sequence from here on
             const int Mq = B * nq;
@@ -669,9 +757,9 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
                 RC(self_attn_core(t, s, w.self_attn, seqs, n, b));
                 for (int h = 0; h < P; ++h) {
                     RC(k_gather_rows16(s, b.x, (long)D * 4, g.rows, R, h * M, D * 4, g.xc + (size_t)h * R * D));
-                    RC(k_gather_rows16(s, b.att, (long)I * 2, g.rows, R, h * M, I * 2, g.attc + (size_t)h * R * I));
+                    RC(k_gather_rows16(s, b.att, (long)KI * 2, g.rows, R, h * M, KI * 2, g.attc + (size_t)h * R * KI));
                 }
-                RC(gemm_dense(s, g.attc, I, (const bf16_t*)w.self_attn.w_out, I, P * R, D, I, g.xc, D, OUT_F32, g.xc));
+                RC(gemm_dense(s, g.attc, KI, (const bf16_t*)w.self_attn.w_out, KI, P * R, D, KI, g.xc, D, OUT_F32, g.xc));
                 bc.x = g.xc; bc.att = g.attc;
             } else {
                 RC(self_attn_block(t, s, w.self_attn, seqs, n, b));
@@ -685,7 +773,19 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
             }
         }
         // final norm + to_logits + CFG only at the rows that are sampled this step
-        if (compact_last) {
+        if (PT) {
+            const float* fg = t->d.final_gamma;
+            const float* fb = t->d.final_beta;
+            if (compact_last) {
+                RC(k_layernorm_split(s, g.xc, D, R, D, fg, fb, nullptr, PT, g.embc, nullptr, nullptr, 0, nullptr));
+                if (P == 2) RC(k_layernorm_split(s, g.xc + (size_t)R * D, D, R, D, fg, fb, nullptr, PT, g.embn, nullptr, nullptr, 0, nullptr));
+            } else {
+                if (self_cond)      // the cond pass's fp32 embed at every position is the next step's self-conditioning input (mmp.py:574)
+                    RC(k_layernorm_split(s, b.x, D, M, D, fg, fb, nullptr, PT, nullptr, g.sce, nullptr, 0, nullptr));
+                RC(k_layernorm_split(s, b.x, D, R, D, fg, fb, rows, PT, g.embc, nullptr, nullptr, 0, nullptr));
+                if (P == 2) RC(k_layernorm_split(s, b.x + (size_t)M * D, D, R, D, fg, fb, rows, PT, g.embn, nullptr, nullptr, 0, nullptr));
+            }
+        } else if (compact_last) {
             RC(k_layernorm(s, g.xc, D, R, D, t->d.final_gamma, t->d.final_beta, nullptr, g.embc, D));
             if (P == 2) RC(k_layernorm(s, g.xc + (size_t)R * D, D, R, D, t->d.final_gamma, t->d.final_beta, nullptr, g.embn, D));
         } else {
@@ -704,8 +804,8 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
         GemmArgs a;
         memset(&a, 0, sizeof(a));
         a.mode = MODE_CFG;
-        a.W = (const bf16_t*)t->d.to_logits; a.N = V; a.ldw = D; a.K = D;
-        a.M = R; a.X = g.embc; a.X2 = g.embn; a.ldx = D;
+        a.W = (const bf16_t*)t->d.to_logits; a.N = V; a.ldw = KD; a.K = KD;
+        a.M = R; a.X = g.embc; a.X2 = g.embn; a.ldx = KD;
         a.out = g.logits; a.ldc = V; a.out_kind = OUT_F32; a.cfg_scale = p->cond_scale;
         a.debug = g_mm_debug;
         // Sampling without the logits round trip: the GEMM emits tile statistics + the candidates above a per-row lower bound of the k-th largest
@@ -714,7 +814,7 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
                            !(g_mm_debug & (8 | 4096 | 8192 | (1 << 25))) && mm_gemm_cfg2_eligible(a);
         const double gemm_flops = 2.0 * (double)P * (double)R * (double)V * (double)D;      // cond + null rows
         if (fused) {
-            RC(k_fused_threshold(s, g.embc, g.embn, D, R, D, p->cond_scale, t->d.logits_wmean, (const bf16_t*)t->d.logits_wcov, k_fused_z(p->k_keep, V, FS_MARGIN),
+            RC(k_fused_threshold(s, g.embc, g.embn, KD, R, D, p->cond_scale, t->d.logits_wmean, (const bf16_t*)t->d.logits_wcov, k_fused_z(p->k_keep, V, FS_MARGIN),
                                  g.fs_ws, g.fs_thr));
             a.out = nullptr;
             a.fs_thr = g.fs_thr; a.fs_stats = g.fs_stats; a.fs_cand = g.fs_cand;
@@ -738,7 +838,7 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
                 prof::Rec pr;
                 if (prof::enabled) pr = prof::begin(s, gemm_flops);
                 if (single)      // cond_scale == 1: the plain to_logits of the one pass (mmp.py:247-248, 332)
-                    RC(gemm_dense(s, g.embc, D, (const bf16_t*)t->d.to_logits, D, R, V, D, g.logits, V, OUT_F32, nullptr));
+                    RC(gemm_dense(s, g.embc, KD, (const bf16_t*)t->d.to_logits, KD, R, V, KD, g.logits, V, OUT_F32, nullptr));
                 else
                     RC(mm_gemm_launch(a, s));
                 if (prof::enabled) prof::end(s, 0, pr);
@@ -763,7 +863,7 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
             // critic scores of the freshly sampled ids at every position (mmp.py:590-601)
             if (critic) {        // TokenCritic.forward_with_cond_scale: both passes + the guidance combine of its 1-wide head
                 RC(mm_transformer_forward(critic, stream, p->ids, B, n, cb.ctx, cb.masks, m, nullptr, cb.embc, nullptr, cb.fwd_ws, cb.fwd_ws_bytes));
-                const int Dc = critic->d.dim;
+                const int Dc = (critic->P ? critic->P : 1) * critic->d.dim;      // operand row width of the critic's head
                 if (single) {
                     RC(gemm_dense(s, cb.embc, Dc, (const bf16_t*)critic->d.to_logits, Dc, M, 1, Dc, cb.sc, 1, OUT_F32, nullptr));
                 } else {
@@ -779,7 +879,16 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
                 }
             } else {             // SelfCritic (mmp.py:352-374): Linear(dim, 1) on the generator's cond-pass embed of the new ids (no self-conditioning input)
                 RC(mm_transformer_forward(t, stream, p->ids, B, n, cb.ctx, cb.masks, m, nullptr, cb.embc, nullptr, cb.fwd_ws, cb.fwd_ws_bytes));
-                RC(mm_conv2d_nhwc(stream, cb.embc, M, 1, 1, D, p->critic_head_w, 1, 1, 1, 1, 0, 0, 1, 1, 1, 0, 0, 1, 1, p->critic_head_b, 0, nullptr, cb.sc, 1));
+                if (PT) {      // precision tier: critic_head_w is the [1][P*D] segment pack of the Linear(dim, 1) weight
+                    GemmArgs ha;
+                    memset(&ha, 0, sizeof(ha));
+                    ha.mode = MODE_DENSE;
+                    ha.W = (const bf16_t*)p->critic_head_w; ha.N = 1; ha.ldw = KD; ha.K = KD; ha.M = M; ha.X = cb.embc; ha.ldx = KD;
+                    ha.out = cb.sc; ha.ldc = 1; ha.out_kind = OUT_F32; ha.bias = p->critic_head_b;
+                    RC(mm_gemm_launch(ha, s));
+                } else {
+                    RC(mm_conv2d_nhwc(stream, cb.embc, M, 1, 1, D, p->critic_head_w, 1, 1, 1, 1, 0, 0, 1, 1, 1, 0, 0, 1, 1, p->critic_head_b, 0, nullptr, cb.sc, 1));
+                }
             }
             const float ratio = (float)((double)(T - 1 - step) / (double)T);
             hipLaunchKernelGGL(critic_scores_kernel, dim3((M + 255) / 256), dim3(256), 0, s, cb.sc, p->critic_noise + (size_t)step * M, p->critic_noise_scale, ratio,

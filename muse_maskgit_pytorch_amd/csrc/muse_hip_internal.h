@@ -117,6 +117,31 @@ long k_qk_norm_bwd_blocks(long nvec);
 int k_qk_norm_bwd(hipStream_t s, const bf16_t* x, long ldx, const float* x_f32, int H, const bf16_t* dy, long lddy, const float* dy_f32,
                   const float* scale, long rows, int heads_per_row, bf16_t* dx, long lddx, float* dx_f32, float* dscale_part);
 
+// ---- 'bf16x3' precision tier (split.hip, attention_f32.hip): fp32 values as P bf16 segments [h|m|l|h|m|h][:P] per row
+int k_split_rows(hipStream_t s, const float* x, long ldx, long rows, int K, int P, int rows_per_batch, long out_batch_stride, bf16_t* out,
+                 uint8_t* nz_mask, int mask_bstride, int drop);
+int k_gather_split(hipStream_t s, const float* table, int D, int P, const int64_t* idx, int B, int nc, int vocab_rows, bf16_t* ctx, uint8_t* mask,
+                   int m, int L);
+// out (P segments, optional) / out_f32 (optional) = LayerNorm(x[row_index ? row_index[r] : r]); addvec != NULL: rows >= add_from get addvec added in place (xw = x) first
+int k_layernorm_split(hipStream_t s, const float* x, long ldx, int rows, int D, const float* gamma, const float* beta, const int32_t* row_index,
+                      int P, bf16_t* out, float* out_f32, const float* addvec, int add_from, float* xw);
+int k_geglu_ln_split(hipStream_t s, const float* h, long ldh, int rows, int F, int Fp, const float* gamma, const float* beta, int P, bf16_t* out);
+int k_embed_f32(hipStream_t s, const int64_t* ids, long rows, int n, const float* tok, int vocab_rows, const float* pos, int D, float* x);
+struct AttnF32Args {
+    const float* q; long q_sb, q_sh, q_sn;       // element strides: batch, head, token (d contiguous, dh = 64)
+    const float* k; long k_sb, k_sh, k_sn;
+    const float* v; long v_sb, v_sh, v_sn;
+    float* out; long o_sb, o_sh, o_sn;           // optional fp32 output
+    bf16_t* out_split; long os_sb, os_sn; int os_seg, P;   // optional P-segment output: element (b, token, h, d) of segment s at b*os_sb + token*os_sn + s*os_seg + h*64 + d
+    int B, H, nq, nk;
+    const uint8_t* key_mask; long km_sb;
+    int normalize;
+    const float* q_scale; const float* k_scale; const float* null_k; const float* null_v;
+    float scale;
+    int kv_batch_mod;
+};
+int k_attention_f32(hipStream_t s, const AttnF32Args& a);
+
 int k_mask_step(hipStream_t s, float* scores, int64_t* ids, int B, int n, int k, int64_t mask_id, int32_t* rows_out);
 struct SampleArgs {
     const float* logits; long ld;                // [R][V] CFG-combined logits of the gathered rows

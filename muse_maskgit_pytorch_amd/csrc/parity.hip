@@ -524,6 +524,22 @@ int mm_f32_attend(mm_stream_t stream, const float* q, int64_t q_sb, int64_t q_sh
     if (normalize && (!q_scale || !k_scale)) return mm_set_error(MM_ERR_SHAPE, "f32 attend: normalize needs q_scale / k_scale");
     if ((null_k == nullptr) != (null_v == nullptr)) return mm_set_error(MM_ERR_SHAPE, "f32 attend: null_k and null_v come together");
     if (nk + (null_k ? 1 : 0) <= 0) return mm_set_error(MM_ERR_SHAPE, "f32 attend: no keys");
+    {   // 16-byte aligned rows (every call of parity.py): the fp32-MFMA kernel of attention_f32.hip; anything else: the scalar kernel below
+        const int64_t st[] = {q_sb, q_sh, q_sn, k_sb, k_sh, k_sn, v_sb, v_sh, v_sn, o_sb, o_sh, o_sn};
+        bool aligned = ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)out)) & 15) == 0;
+        for (int64_t x : st) aligned = aligned && (x % 4) == 0;
+        if (aligned) {
+            AttnF32Args m;
+            memset(&m, 0, sizeof(m));
+            m.q = q; m.q_sb = q_sb; m.q_sh = q_sh; m.q_sn = q_sn;
+            m.k = k; m.k_sb = k_sb; m.k_sh = k_sh; m.k_sn = k_sn;
+            m.v = v; m.v_sb = v_sb; m.v_sh = v_sh; m.v_sn = v_sn;
+            m.out = out; m.o_sb = o_sb; m.o_sh = o_sh; m.o_sn = o_sn;
+            m.B = B; m.H = H; m.nq = nq; m.nk = nk; m.key_mask = key_mask; m.km_sb = km_sb; m.normalize = normalize;
+            m.q_scale = q_scale; m.k_scale = k_scale; m.null_k = null_k; m.null_v = null_v; m.scale = scale;
+            return k_attention_f32((hipStream_t)stream, m);
+        }
+    }
     F32AttnArgs a;
     a.q = q; a.q_sb = q_sb; a.q_sh = q_sh; a.q_sn = q_sn;
     a.k = k; a.k_sb = k_sb; a.k_sh = k_sh; a.k_sn = k_sn;

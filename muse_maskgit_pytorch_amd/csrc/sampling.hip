@@ -138,6 +138,7 @@ struct SampleShared {
     float bval[NW];
     float bx[NW];
     float redse[NW];
+    float tmax[256], tsum[256];   // per 256-column tile: max and sum exp(x - max) (common.h tile_softmax_stats), V % 256 == 0 only
     int redi[NW];
     uint32_t hist[NB];            // TRANSPOSED: bin b lives at hslot(b), so lane l's 32 consecutive bins form a conflict-free column
     uint32_t cand[CAND_CAP];
@@ -255,13 +256,29 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
     for (int i = 1; i < NW; ++i) { vmax = fmaxf(vmax, S.redf[i]); vmin = fminf(vmin, S.redf2[i]); s1 += S.bval[i]; s2 += S.bx[i]; }
 
     // ---- B: softmax denominator on the unfiltered logits (fast exp: v_exp_f32, ~1e-6 relative per term)
+    // V a multiple of 256 (every vocabulary the fused sampler of sampling_fused.hip serves): per-tile statistics with the SAME function and,
+    // below, the same combination order as that path -- a wave's 4 values per lane of iteration `it` are exactly the 256-column tile
+    // it * 8 + wid in the GEMM emission's lane layout -- so a row gets bit-identical confidences whichever path samples it.
+    const bool tilewise = (V & 255) == 0;
     float se = 0.f;
     if (!(p.debug & 128)) {
+        if (tilewise) {
 #pragma unroll
-        for (int i = 0; i < VEC_IT * 4; ++i) se += __expf(opaque(v[i]) - vmax);
+            for (int it = 0; it < VEC_IT; ++it) {
+                const int tile = it * NW + wid;
+                if (FULL || tile * 256 < V) {      // wave-uniform
+                    float tm, te;
+                    tile_softmax_stats(make_float4(opaque(v[it * 4]), opaque(v[it * 4 + 1]), opaque(v[it * 4 + 2]), opaque(v[it * 4 + 3])), tm, te);
+                    if (lane == 0) { S.tmax[tile] = tm; S.tsum[tile] = te; }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < VEC_IT * 4; ++i) se += __expf(opaque(v[i]) - vmax);
+        }
     }
     se = wave_sum(se);
-    if (lane == 0) S.redse[wid] = se;        // published by the barrier that closes the histogram pass
+    if (lane == 0 && !tilewise) S.redse[wid] = se;        // published by the barrier that closes the histogram pass
 
     // ---- C: value-linear histogram of the row's UPPER TAIL (bin 0 = smallest), then every wave scans it (redundantly: no
     //      broadcast, no extra barrier) for the bin t holding the k-th largest value.
@@ -322,9 +339,10 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
         for (int i = tid; i < NB; i += ST) S.hist[i] = 0;
         __syncthreads();
     }
-    float sumexp = 0.f;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) sumexp += S.redse[i];
+    if (tilewise) {      // sum_t tsum_t * exp(tmax_t - max), thread t = tile t, butterfly per wave, waves in order: sample_fused_kernel's expression
+        const float term = wave_sum((tid < (V >> 8) && !(p.debug & 128)) ? S.tsum[tid] * expf(S.tmax[tid] - vmax) : 0.f);
+        if (lane == 0) S.redse[wid] = term;      // (the tile statistics were published by the histogram pass's barrier; read at the row's end)
+    }
     bool slow = !fast || !found || cnt > CAND_CAP;
 
     // ---- D: append every value with bin >= tbin to this wave's slice (no atomics: ballot prefix + running count).
@@ -438,6 +456,9 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
     if (tid == 0) {
         for (int i = 1; i < NW; ++i)
             if (S.bval[i] > best || (S.bval[i] == best && S.redi[i] < best_i)) { best = S.bval[i]; best_i = S.redi[i]; best_x = S.bx[i]; }
+        float sumexp = 0.f;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) sumexp += S.redse[i];
         const float prob = expf(best_x - vmax) / sumexp;
         const float score = 1.f - prob;
         if (p.ids) p.ids[pos_flat] = (int64_t)best_i;

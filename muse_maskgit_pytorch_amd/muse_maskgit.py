@@ -153,11 +153,14 @@ class Transformer(nn.Module):
         self.self_cond_to_init_embed = FeedForward(dim)
         self._handle = None
         self._handle_key = None
+        self._handle_x3 = None         # packed weights + C handle of the 'bf16x3' precision tier (built on first use)
+        self._handle_x3_key = None
+        self._x3_min_products = 0      # MaskGit raises it so that a generator and its token critic are packed with the same number of term products
         self._ws = None
         self.grad_sync = None          # optional parallel.GradBucketer: data-parallel gradient averaging inside the backward
         self.weight_format = 'bf16'    # 'fp8': W8A16 inference (BASELINE configs[4]), see quantize_weights_fp8()
         self._fp8 = None
-        self.precision = 'bf16'        # 'parity': fp32 storage + fp32 MFMA, the reference's operator sequence (set_precision)
+        self.precision = 'bf16'        # 'bf16x3': fp32-grade tier on the bf16 matrix pipe inside the same C loop; 'parity': fp32 MFMA, operator by operator (set_precision)
 
     # ---- packing (once per parameter version / device)
     def _pack_ff(self, ff, keep):
@@ -205,6 +208,11 @@ class Transformer(nn.Module):
         if dev.type != 'cuda':
             raise L.MuseHipError('Transformer parameters are not on the GPU; the MI355X path has no CPU fallback')
         key = self._pack_key()
+        if self.precision == 'bf16x3':
+            key = key + (self._x3_min_products,)
+            if self._handle_x3 is None or self._handle_x3_key != key:
+                self._handle_x3, self._handle_x3_key = self._model_x3(), key
+            return self._handle_x3
         if self._handle is not None and self._handle_key == key:
             return self._handle
         h = _Handle()
@@ -246,6 +254,95 @@ class Transformer(nn.Module):
         self._handle, self._handle_key = h, key
         return h
 
+    def linear_weights(self):
+        """every nn.Linear weight of the hot path (what the precision tier packs as bf16 term segments)"""
+        ws = [self.to_logits.weight]
+        if isinstance(self.text_embed_proj, nn.Linear):
+            ws.append(self.text_embed_proj.weight)
+        ffs = [ff for _, _, ff in self.transformer_blocks.layers] + [self.self_cond_to_init_embed]
+        for ff in ffs:
+            ws += [ff[1].weight, ff[4].weight]
+        for sa, ca, _ in self.transformer_blocks.layers:
+            for a in (sa, ca):
+                ws += [a.to_q.weight, a.to_kv.weight, a.to_out.weight]
+        return ws
+
+    def split_products(self):
+        """term pairs per product of the 'bf16x3' tier for THIS checkpoint: 3 when every Linear weight is bf16-representable (a checkpoint
+        trained / stored in bf16), 5 for two-term weights, 6 for general fp32 weights (csrc/split.hip)"""
+        key = self._pack_key()
+        if getattr(self, '_x3_terms', None) is None or self._x3_terms[0] != key:      # one pass over the weights per parameter version
+            self._x3_terms = (key, max(ops.weight_terms(w) for w in self.linear_weights()))
+        return max(ops.products_for_terms(self._x3_terms[1]), self._x3_min_products)
+
+    def _model_x3(self):
+        """weights of the 'bf16x3' precision tier (mm_transformer_desc.split_products): Linear weights as term-segment packs [out][P*in], fp32
+        tables / norms, plain (not GEGLU-interleaved) w1 with both halves padded to Fp"""
+        h = _Handle()
+        tb = self.transformer_blocks
+        cfg = tb.cfg
+        P = self.split_products()
+        f32c = lambda x: x.detach().float().contiguous()
+        pack = lambda w, pad_k=1: ops.split_pack_weight(w, P, pad_k)
+
+        def pack_ff(ff):
+            w1, w2 = ff[1].weight.detach().float(), ff[4].weight.detach().float()
+            F, D = w2.shape[1], w1.shape[1]
+            Fp = (F + 63) // 64 * 64
+            w1p = torch.zeros(2 * Fp, D, dtype=torch.float32, device=w1.device)
+            w1p[:F] = w1[:F]
+            w1p[Fp:Fp + F] = w1[F:]
+            t = dict(g1=f32c(ff[0].gamma), b1=ff[0].beta.float().contiguous(), w1=pack(w1p), g2=ops.pad_cols(f32c(ff[3].gamma), Fp),
+                     b2=ops.pad_cols(ff[3].beta.float(), Fp), w2=pack(w2, 64))
+            h.keep.append(t)
+            return L.FFWeights(L.ptr(t['g1']), L.ptr(t['b1']), L.ptr(t['w1']), L.ptr(t['g2']), L.ptr(t['b2']), L.ptr(t['w2']), None, None, None), F, Fp
+
+        def pack_attn(a, fused):
+            I, D = a.to_q.weight.shape
+            if fused:
+                wqkv = pack(torch.cat([a.to_q.weight.detach(), a.to_kv.weight.detach()], dim=0))
+                wq_ptr = wqkv.data_ptr()
+                wkv_ptr, wkeep = wq_ptr + I * P * D * 2, wqkv
+            else:
+                wq, wkv = pack(a.to_q.weight), pack(a.to_kv.weight)
+                wq_ptr, wkv_ptr, wkeep = wq.data_ptr(), wkv.data_ptr(), (wq, wkv)
+            t = dict(g=f32c(a.norm.gamma), b=f32c(a.norm.beta), w=wkeep, wo=pack(a.to_out.weight), nk=f32c(a.null_kv[0, :, 0, :]),
+                     nv=f32c(a.null_kv[1, :, 0, :]), qs=f32c(a.q_scale), ks=f32c(a.k_scale))
+            h.keep.append(t)
+            return L.AttnWeights(L.ptr(t['g']), L.ptr(t['b']), C.c_void_p(wq_ptr), C.c_void_p(wkv_ptr), L.ptr(t['wo']), L.ptr(t['nk']), L.ptr(t['nv']),
+                                 L.ptr(t['qs']), L.ptr(t['ks']))
+        layers = (L.LayerWeights * cfg['depth'])()
+        F = Fp = 0
+        for i, (sa, ca, ff) in enumerate(tb.layers):
+            layers[i].self_attn = pack_attn(sa, True)
+            layers[i].cross_attn = pack_attn(ca, False)
+            layers[i].ff, F, Fp = pack_ff(ff)
+        sc_ff, _, _ = pack_ff(self.self_cond_to_init_embed)
+        t = dict(tok=f32c(self.token_emb.weight), pos=f32c(self.pos_emb.weight), fg=f32c(tb.norm.gamma), fb=f32c(tb.norm.beta), wl=pack(self.to_logits.weight),
+                 tp=pack(self.text_embed_proj.weight) if isinstance(self.text_embed_proj, nn.Linear) else None, P=P)
+        t['wmean'] = t['wcov'] = None
+        if self.dim_out % 256 == 0 and self.dim_out >= 4096:      # vocabulary statistics for the fused sampler's bound (an estimate: bf16 inputs suffice)
+            wt = self.to_logits.weight.detach().float().t().contiguous()
+            t['wmean'] = wt.mean(dim=1).contiguous()
+            t['wcov'] = (P32.gemm(wt, wt) / float(self.dim_out) - torch.outer(t['wmean'], t['wmean'])).to(bf16).contiguous()
+            del wt
+        h.keep.append(t)
+        h.keep.append(layers)
+        d = L.TransformerDesc()
+        d.dim, d.depth, d.heads, d.dim_head = self.dim, cfg['depth'], cfg['heads'], cfg['dim_head']
+        d.ff_inner, d.ff_inner_padded = F, Fp
+        d.seq_len, d.num_tokens, d.vocab_rows, d.dim_out = self.seq_len, self.num_tokens, self.token_emb.weight.shape[0], self.dim_out
+        d.text_dim, d.self_cond = self.text_embed_dim, int(bool(self.self_cond))
+        d.token_emb, d.pos_emb, d.text_proj = L.ptr(t['tok']), L.ptr(t['pos']), L.ptr(t['tp'])
+        d.layers = C.cast(layers, C.POINTER(L.LayerWeights))
+        d.final_gamma, d.final_beta, d.to_logits = L.ptr(t['fg']), L.ptr(t['fb']), L.ptr(t['wl'])
+        d.self_cond_ff = sc_ff
+        d.logits_wmean, d.logits_wcov = L.ptr(t['wmean']), L.ptr(t['wcov'])
+        d.split_products = P
+        L.check(L.lib().mm_transformer_create(C.byref(d), C.byref(h.ptr)), 'mm_transformer_create')
+        h.packed = t
+        return h
+
     def _pack_key(self):
         """identity of the packed (bf16 / fp8, kernel-layout) weight copies: device + (storage pointer, in-place version) of every parameter and
         buffer.  `.data` surgery that keeps the storage and does not bump the version counter (EMA `p.data.copy_`, `p.data.lerp_`) is NOT
@@ -257,22 +354,29 @@ class Transformer(nn.Module):
         """Drop the packed device copies of the weights (rebuilt on the next call).  Needed only after edits the version counters cannot
         see (`param.data.copy_(...)`, raw pointer writes); `load_state_dict`, `.to()`, optimizer steps and in-place ops are detected."""
         self._handle, self._handle_key, self._fp8 = None, None, None
+        self._handle_x3, self._handle_x3_key = None, None
         return self
 
     def _apply(self, fn, *args, **kwargs):
         self._handle, self._handle_key, self._fp8 = None, None, None
+        self._handle_x3, self._handle_x3_key = None, None
         return super()._apply(fn, *args, **kwargs)
 
     def load_state_dict(self, *args, **kwargs):
         self._handle, self._handle_key, self._fp8 = None, None, None
+        self._handle_x3, self._handle_x3_key = None, None
         return super().load_state_dict(*args, **kwargs)
 
     def set_precision(self, precision):
         """'bf16' (default): the production engine -- bf16 operands, fp32 accumulation / residual stream / logits.
-        'parity': precision level L0 -- fp32 storage and fp32 MFMA through the reference's exact operator sequence
-        (parity.py / csrc/parity.hip); logits within 1e-3 of the reference's fp32 run and bit-equal ids at full size.  Inference only."""
-        if precision not in ('bf16', 'parity'):
-            raise ValueError(f"precision must be 'bf16' or 'parity', got {precision!r}")
+        'bf16x3': the tolerance-meeting tier INSIDE the same C entry points (mm_transformer_forward / mm_generate): activations that feed a
+        Linear are kept as exact three-term bf16 splits and multiplied as 3 (bf16-representable checkpoint) / 5 / 6 (general fp32 weights)
+        term products on the bf16 matrix pipe, fp32 everywhere else, attention on the fp32 MFMA (csrc/split.hip, attention_f32.hip);
+        logits within 1e-3 of the reference's fp32 run and bit-equal ids at full size.  Inference only.
+        'parity': precision level L0 -- fp32 storage and fp32 MFMA through the reference's exact operator sequence, one
+        operator call at a time from Python (parity.py / csrc/parity.hip): the verification baseline of the tier above.  Inference only."""
+        if precision not in ('bf16', 'bf16x3', 'parity'):
+            raise ValueError(f"precision must be 'bf16', 'bf16x3' or 'parity', got {precision!r}")
         self.precision = precision
         return self
 
@@ -295,7 +399,8 @@ class Transformer(nn.Module):
             cids = conditioning_token_ids.reshape(b, -1).to(device=dev, dtype=torch.long).contiguous()
             nc = cids.shape[1]
         m = Lt + nc
-        ctx = torch.empty(b, m, self.dim, dtype=bf16, device=dev)
+        seg = h.packed['P'] if self.precision == 'bf16x3' else 1          # precision tier: P bf16 segments per context row
+        ctx = torch.empty(b, m, seg * self.dim, dtype=bf16, device=dev)
         mask = torch.empty(b, m, dtype=torch.uint8, device=dev)
         wsb = L.lib().mm_context_workspace_bytes(h.ptr, b, Lt)
         ws = torch.empty(int(wsb), dtype=torch.uint8, device=dev)
@@ -309,14 +414,15 @@ class Transformer(nn.Module):
     def _run(self, ids, ctx, mask, self_cond_embed=None, want_embed=True, want_logits=True):
         if self.weight_format == 'fp8':
             return self._run_fp8(ids, ctx, mask, self_cond_embed, want_embed, want_logits)
-        assert self.precision == 'bf16'
+        assert self.precision in ('bf16', 'bf16x3')
         h = self._model()
         dev = self.token_emb.weight.device
         ids = ids.to(device=dev, dtype=torch.long).contiguous()
         b, n = ids.shape
         assert n <= self.seq_len                                              # mmp.py:293
         m = ctx.shape[1]
-        embed = torch.empty(b * n, self.dim, dtype=bf16, device=dev) if want_embed else None
+        seg = h.packed['P'] if self.precision == 'bf16x3' else 1          # precision tier: the embed leaves as P bf16 segments per row (see _embed_f32)
+        embed = torch.empty(b * n, seg * self.dim, dtype=bf16, device=dev) if want_embed else None
         logits = torch.empty(b * n, self.dim_out, dtype=torch.float32, device=dev) if want_logits else None
         sce = None
         if self.self_cond and exists(self_cond_embed):
@@ -326,6 +432,13 @@ class Transformer(nn.Module):
         L.check(L.lib().mm_transformer_forward(h.ptr, L.stream(), L.ptr(ids), b, n, L.ptr(ctx), L.ptr(mask), m, L.ptr(sce),
                                                L.ptr(embed), L.ptr(logits), L.ptr(ws), ws.numel()), 'mm_transformer_forward')
         return embed, logits
+
+    def _embed_f32(self, embed):
+        """fp32 [rows, dim] view of what `_run` / `forward(_embed_only=True)` returned: the bf16 embed, or -- precision tier -- the exact sum of
+        its three bf16 terms"""
+        if embed.shape[-1] != self.dim:
+            return ops.unsplit_rows(embed, embed.shape[-1] // self.dim, self.dim)
+        return embed.float()
 
     # ---- fp8 weights (BASELINE configs[4] "fp8 MFMA weights"; W8A16: e4m3 weights with one scale per output row, bf16 activations)
     def quantize_weights_fp8(self, enabled=True):
@@ -443,7 +556,7 @@ class Transformer(nn.Module):
         emb_n = self.forward(x, *args[1:], _embed_only=True, cond_drop_prob=1., **kwargs)
         scaled = self._cfg_logits(emb_c, emb_n, cond_scale).reshape(b, n, self.dim_out)
         if return_embed:
-            return scaled, emb_c.float().reshape(b, n, self.dim)
+            return scaled, self._embed_f32(emb_c).reshape(b, n, self.dim)
         return scaled
 
     def forward_with_neg_prompt(self, x, text_embed: torch.Tensor, neg_text_embed: torch.Tensor, cond_scale=3., return_embed=False, **kwargs):
@@ -457,7 +570,7 @@ class Transformer(nn.Module):
         emb_n = self.forward(x, _embed_only=True, cond_drop_prob=0., text_embeds=neg_text_embed, **kwargs)
         scaled = self._cfg_logits(emb_p, emb_n, cond_scale).reshape(b, n, self.dim_out)
         if return_embed:
-            return scaled, emb_p.float().reshape(b, n, self.dim)
+            return scaled, self._embed_f32(emb_p).reshape(b, n, self.dim)
         return scaled
 
     def forward(self, x, return_embed=False, return_logits=False, labels=None, ignore_index=0, self_cond_embed=None,
@@ -472,8 +585,8 @@ class Transformer(nn.Module):
         if (exists(labels) and not return_logits and not return_embed and torch.is_grad_enabled() and self.to_logits.weight.requires_grad
                 and (self.dim_out == 1 or bool((labels != ignore_index).any()))):      # CE with all rows ignored: NaN like F.cross_entropy, nothing to differentiate
             assert exists(texts) ^ exists(text_embeds)
-            if self.precision == 'parity':
-                raise NotImplementedError("precision 'parity' is an inference / verification mode: train with set_precision('bf16')")
+            if self.precision != 'bf16':
+                raise NotImplementedError(f"precision {self.precision!r} is an inference mode: train with set_precision('bf16')")
             if exists(texts):
                 text_embeds = self.encode_text(texts)
             from .training import transformer_loss
@@ -504,7 +617,7 @@ class Transformer(nn.Module):
 
     def _finish_forward(self, embed, logits, b, n, return_embed, return_logits, labels, ignore_index):
         if return_embed:
-            return logits.reshape(b, n, self.dim_out), embed.float().reshape(b, n, self.dim)
+            return logits.reshape(b, n, self.dim_out), self._embed_f32(embed).reshape(b, n, self.dim)
         if not exists(labels):
             return logits.reshape(b, n, self.dim_out)
         # training-forward losses (mmp.py:340-348), forward only: no autograd graph is built on this path
@@ -530,6 +643,11 @@ class SelfCritic(nn.Module):
         b, n, d = embeds.shape
         if self.net.precision == 'parity':
             return P32.linear_head(embeds.reshape(b * n, d).float().contiguous(), self.to_pred).reshape(b, n, 1)
+        if self.net.precision == 'bf16x3':      # Linear(dim, 1) as term products; the head's own weight decides how many
+            P = max(self.net._model().packed['P'], ops.products_for_terms(ops.weight_terms(self.to_pred.weight)))
+            x = ops.split_rows(embeds.reshape(b * n, d).float().contiguous(), P)
+            out = ops.gemm(x, ops.split_pack_weight(self.to_pred.weight, P), out_f32=True)
+            return (out + self.to_pred.bias.detach().float()).reshape(b, n, 1)
         w = ops.pad_cols(self.to_pred.weight.detach().to(bf16), 64)                    # [1, D] as a 1x1 conv weight
         x = embeds.reshape(b * n, 1, 1, d).to(bf16).contiguous()
         out = ops.conv2d_nhwc(x, w, 1, 1, 1, 1, (0, 0), bias=self.to_pred.bias.detach().float().contiguous(), out_nchw_f32=True)
@@ -621,13 +739,15 @@ class MaskGit(nn.Module):
         self.load_state_dict(torch.load(str(path)))
 
     def set_precision(self, precision):
-        """'bf16' | 'parity' for the transformer, the token critic and both VAEs (see Transformer.set_precision)."""
+        """'bf16' | 'bf16x3' | 'parity' for the transformer and the token critic (see Transformer.set_precision); the VAEs take 'bf16' or their
+        fp32 engine ('parity', also under 'bf16x3': the decoder is outside the decode loop and already meets 1e-3 in bf16, the fp32 engine
+        makes the LFQ encode ids of a super-resolution condition image exact)."""
         self.transformer.set_precision(precision)
         if isinstance(self.token_critic, Transformer):
             self.token_critic.set_precision(precision)
         for v in (self.vae, self.cond_vae):
             if exists(v):
-                v.set_precision(precision)
+                v.set_precision('parity' if precision == 'bf16x3' else precision)
         return self
 
     def _mask_counts(self, timesteps, seq_len, device='cpu'):
@@ -686,6 +806,16 @@ class MaskGit(nn.Module):
             _, cond_ids, _ = self.cond_vae.encode(cond_images)
             cond_ids = cond_ids.reshape(B, -1).contiguous()
             nc = cond_ids.shape[1]
+        if tr.precision == 'bf16x3' and exists(critic):      # one term-product count for the generator and its critic (token critic network or self-critic head)
+            tr._x3_min_products = 0
+            if isinstance(critic, Transformer):
+                critic._x3_min_products = 0
+                need = critic.split_products()
+            else:
+                need = ops.products_for_terms(ops.weight_terms(critic.to_pred.weight))
+            tr._x3_min_products = max(tr.split_products(), need)
+            if isinstance(critic, Transformer):
+                critic._x3_min_products = tr._x3_min_products
         h = tr._model()
         counts = self._mask_counts(timesteps, seq_len)
         temps = ops.step_temperatures(timesteps, temperature)
@@ -714,8 +844,11 @@ class MaskGit(nn.Module):
             p.flags |= L.MM_GEN_CAN_REMASK
         if exists(critic):
             if isinstance(critic, SelfCritic):
-                keep += [critic.to_pred.weight.detach().to(device=dev, dtype=bf16).reshape(-1).contiguous(),
-                         critic.to_pred.bias.detach().to(device=dev, dtype=torch.float32).contiguous()]
+                if tr.precision == 'bf16x3':
+                    hw = ops.split_pack_weight(critic.to_pred.weight.detach().to(dev), h.packed['P']).reshape(-1).contiguous()
+                else:
+                    hw = ops.pad_cols(critic.to_pred.weight.detach().to(device=dev, dtype=bf16), 64).reshape(-1).contiguous()
+                keep += [hw, critic.to_pred.bias.detach().to(device=dev, dtype=torch.float32).contiguous()]
                 p.critic_head_w, p.critic_head_b = L.ptr(keep[-2]), L.ptr(keep[-1])
                 ch = h
             else:

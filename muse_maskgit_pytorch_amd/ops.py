@@ -617,3 +617,60 @@ def fused_sample(fb, thr, R, V, k_keep, temperature, rows=None, noise_kind=L.MM_
                                     int(noise_kind), L.ptr(noise), noise.stride(0) if noise is not None else 0, int(seed), int(row_offset), int(step), None, None,
                                     L.ptr(pred), L.ptr(score), L.ptr(fb['fail'])), 'mm_fused_sample')
     return pred, score
+
+
+# ---- precision tier 'bf16x3' (csrc/split.hip): fp32 values as sums of bf16 terms
+SPLIT_W_SEGMENTS = (0, 0, 0, 1, 1, 2)      # which weight term (0 = h, 1 = m, 2 = l) each segment of W' carries; X' carries [h m l h m h]
+
+
+def split_terms(w):
+    """The exact three-term bf16 split of an fp32 tensor: w = h + m + l (h = bf16(w), m = bf16(w - h), l = w - h - m).  Layout / dtype
+    preparation of weights at pack time (plain torch casts); activations are split by the kernels of csrc/split.hip."""
+    w = w.detach().float()
+    h = w.to(bf16)
+    r = w - h.float()
+    m = r.to(bf16)
+    l = (r - m.float()).to(bf16)
+    return h, m, l
+
+
+def weight_terms(w):
+    """1 if every value of w is bf16-representable, 2 if two bf16 terms are exact, else 3."""
+    h, m, l = split_terms(w)
+    if not bool(m.float().abs().max() > 0):
+        return 1
+    return 2 if not bool(l.float().abs().max() > 0) else 3
+
+
+def products_for_terms(terms):
+    """term pairs (activation term i, weight term j) with i + j <= 2 that exist for a weight of `terms` bf16 terms: 3, 5 or 6"""
+    return {1: 3, 2: 5, 3: 6}[int(terms)]
+
+
+def split_pack_weight(w, products, pad_k=1):
+    """nn.Linear weight fp32 [N][K] -> bf16 [N][products * Kp], the segments [wh|wh|wh|wm|wm|wl][:products] (each zero-padded to Kp =
+    K rounded up to pad_k); multiplies the activation pack [xh|xm|xl|xh|xm|xh] written by the split kernels."""
+    terms = split_terms(w)
+    N, K = w.shape
+    Kp = (K + pad_k - 1) // pad_k * pad_k
+    out = torch.zeros(N, products, Kp, dtype=bf16, device=w.device)
+    for s in range(products):
+        out[:, s, :K] = terms[SPLIT_W_SEGMENTS[s]]
+    return out.reshape(N, products * Kp).contiguous()
+
+
+def split_rows(x, products):
+    """fp32 [rows][K] -> bf16 [rows][products * K] (mm_split_rows): the GEMM operand form of the precision tier"""
+    _chk_cuda(x)
+    x = x.float()
+    assert x.dim() == 2 and x.stride(1) == 1 and x.shape[1] % 4 == 0 and x.stride(0) % 4 == 0
+    rows, K = x.shape
+    out = torch.empty(rows, products * K, dtype=bf16, device=x.device)
+    L.check(L.lib().mm_split_rows(L.stream(), L.ptr(x), x.stride(0), rows, K, products, L.ptr(out)), 'mm_split_rows')
+    return out
+
+
+def unsplit_rows(xs, products, K):
+    """the fp32 value of a segment pack: h + m + l (exact)"""
+    v = xs.reshape(xs.shape[0], products, K)[:, :3].float()
+    return (v[:, 0] + v[:, 1]) + v[:, 2]

@@ -2,8 +2,11 @@
 18 decode steps.  tests/golden/base_c2.pt was recorded from the UNMODIFIED reference (oracle/make_golden_base.py); checkpoint and noise are
 rebuilt from the seeded recipe (oracle/golden_recipe.py) and their checksums asserted first.
 
-Two engines are compared with the same fixture:
-  precision 'parity' -- fp32 storage + fp32 MFMA (csrc/parity.hip): the north star's bar, logits / pixels within 1e-3 absolute, ids 100 %.
+Three engines are compared with the same fixture:
+  precision 'bf16x3' -- the tolerance-meeting tier INSIDE mm_generate / mm_transformer_forward (csrc/split.hip: exact three-term bf16 splits
+                        of every GEMM activation on the bf16 matrix pipe, 3 products for these bf16-representable checkpoints; fp32 MFMA
+                        attention): the north star's bar, logits within 1e-3 absolute, every step's ids 100 %, through the C loop.
+  precision 'parity' -- fp32 storage + fp32 MFMA (csrc/parity.hip), operator by operator from Python: same bar, the tier's verification baseline.
   precision 'bf16'   -- the production engine: bounds are what bf16 operands achieve at this size (stated per assert), ids compared
                         through the oracle tail on the engine's own logits (bit-exact) and, informationally, with the reference run.
 """
@@ -21,7 +24,8 @@ import muse_oracle as O
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 FULL_ROWS = [0, 77, 255, 256, 300, 301, 448, 511]
-PRECISIONS = ['parity', 'bf16']
+PRECISIONS = ['parity', 'bf16x3', 'bf16']
+EXACT = ('parity', 'bf16x3')      # the engines held to the north star's bar
 
 
 @pytest.fixture(scope='module')
@@ -74,7 +78,7 @@ def test_transformer_forward_logits_at_base_size(base, precision):
     finally:
         tr.set_precision('bf16')
     fw = g['forward']
-    tol = 1e-3 if precision == 'parity' else 2.5e-2
+    tol = 1e-3 if precision in EXACT else 2.5e-2
     for name, got, rec in (('logits(cond)', lc, fw['logits_cond']), ('logits(null)', ln, fw['logits_null'])):
         rows, cols = _samples(got)
         _err(f'{precision} {name} full rows', rows, rec['rows'], tol)
@@ -82,7 +86,7 @@ def test_transformer_forward_logits_at_base_size(base, precision):
     rows, cols = _samples(sc)
     _err(f'{precision} logits(guidance 3.0) full rows', rows, fw['logits_scaled']['rows'], tol * 5)      # null + 3 (cond - null): errors add up to 5x
     _err(f'{precision} logits(guidance 3.0) strided columns', cols, fw['logits_scaled']['cols'], tol * 5)
-    _err(f'{precision} embed', emb.reshape(R.B, R.N, -1), fw['embed'], 1e-3 if precision == 'parity' else 4e-2)
+    _err(f'{precision} embed', emb.reshape(R.B, R.N, -1), fw['embed'], 1e-3 if precision in EXACT else 4e-2)
 
 
 @pytest.mark.parametrize('precision', PRECISIONS)
@@ -109,7 +113,9 @@ def test_generate_at_base_size_against_the_reference_run(base, noise, precision)
         final_agree = (ids.cpu().reshape(gen['final_ids'].shape) == gen['final_ids']).float().mean().item()
         print(f'[base-size parity] {precision} generate: final ids equal to the reference run: {100 * final_agree:.2f} %; per-step state agreement min '
               f'{100 * min(agree_steps):.2f} % (step {agree_steps.index(min(agree_steps))})')
-        if precision == 'parity':
+        if precision == 'bf16x3':      # the tier runs inside the one mm_generate call (the stepwise loop returns lists), 3 term products here
+            assert isinstance(trace['masked_ids'], torch.Tensor) and tr.split_products() == 3
+        if precision in EXACT:
             assert min(agree_steps) == 1.0 and final_agree == 1.0
         else:
             assert final_agree >= 0.90
@@ -133,7 +139,7 @@ def test_generate_at_base_size_against_the_reference_run(base, noise, precision)
         torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize('precision', PRECISIONS)
+@pytest.mark.parametrize('precision', ['parity', 'bf16'])
 def test_vqgan_vae_dim_256_against_the_reference(base, precision):
     """VQGanVAE(dim=256) decode_from_ids / encode (vqgan_vae.py:422-441), the VAE the bench decodes with.  Pixels: 1e-3 of the image scale
     (|max| 0.063 at random init) for the parity engine.  LFQ ids: a bit is the SIGN of a projection, so ids are compared where the reference's
@@ -193,7 +199,7 @@ def test_superres_forward_and_generate_at_full_size(superres, precision):
         _, cids, _ = mg.cond_vae.encode(inp['cond_image'].to(DEV))
         agree = (cids.cpu() == g['cond_ids']).float().mean().item()
         print(f'[super-res parity] {precision} condition ids equal to the reference: {100 * agree:.2f} %')
-        if precision == 'parity':
+        if precision in EXACT:
             assert agree == 1.0
         cids = g['cond_ids'].to(DEV)                         # the forward is compared on the reference's condition ids
         ids = inp['ids'].to(DEV)
@@ -201,12 +207,12 @@ def test_superres_forward_and_generate_at_full_size(superres, precision):
         ln = tr(ids, text_embeds=te, cond_drop_prob=1., conditioning_token_ids=cids)
         sc = tr.forward_with_cond_scale(ids, text_embeds=te, conditioning_token_ids=cids, cond_scale=3.)
         fw = g['forward']
-        tol = 1e-3 if precision == 'parity' else 2.5e-2
+        tol = 1e-3 if precision in EXACT else 2.5e-2
         for name, got, rec, k in (('logits(cond)', lc, fw['logits_cond'], 1), ('logits(null)', ln, fw['logits_null'], 1), ('logits(guidance)', sc, fw['logits_scaled'], 5)):
             f = got.reshape(1024, -1)
             _err(f'{precision} super-res {name} full rows', f[C4_ROWS], rec['rows'], tol * k)
             _err(f'{precision} super-res {name} strided columns', f[:, ::128], rec['cols'], tol * k)
-        _err(f'{precision} super-res embed', emb.reshape(1, 1024, -1), fw['embed'], 1e-3 if precision == 'parity' else 4e-2)
+        _err(f'{precision} super-res embed', emb.reshape(1, 1024, -1), fw['embed'], 1e-3 if precision in EXACT else 4e-2)
         # ---- generate, peaky logits, the reference's noise
         gen = g['generate']
         us = []
@@ -225,14 +231,16 @@ def test_superres_forward_and_generate_at_full_size(superres, precision):
             steps = [(masked[s] == gen['step_in_ids'][s].long()).float().mean().item() for s in range(R.C4_T)]
             final = (out.cpu().reshape(gen['final_ids'].shape) == gen['final_ids']).float().mean().item()
             print(f'[super-res parity] {precision} generate: final ids equal to the reference run {100 * final:.2f} %, per-step states min {100 * min(steps):.2f} %')
-            if precision == 'parity':
+            if precision == 'bf16x3':
+                assert isinstance(trace['masked_ids'], torch.Tensor)
+            if precision in EXACT:
                 assert final == 1.0 and min(steps) == 1.0
             else:
                 assert final >= 0.85
                 assert mg.fused_sampling_fallbacks == 0
                 out2 = mg.generate(['a'], cond_images=inp['cond_image'].to(DEV), timesteps=R.C4_T, cond_scale=3., text_embeds=te, noise=noise, noise_kind='uniform',
                                    return_ids=True, fused_sampling=False)
-                assert (out == out2).float().mean().item() > 0.99
+                assert torch.equal(out, out2)      # both sampling paths give bit-identical confidences (common.h tile_softmax_stats)
         finally:
             with torch.no_grad():
                 tr.to_logits.weight.div_(R.PEAK)
@@ -271,12 +279,12 @@ def test_paper_scale_forward_and_generate_at_full_size(paper, precision):
         ln = tr(ids, text_embeds=te, cond_drop_prob=1.)
         sc = tr.forward_with_cond_scale(ids, text_embeds=te, cond_scale=3.)
         fw = g['forward']
-        tol = 1e-3 if precision == 'parity' else 3.5e-2
+        tol = 1e-3 if precision in EXACT else 3.5e-2
         for name, got, rec, k in (('logits(cond)', lc, fw['logits_cond'], 1), ('logits(null)', ln, fw['logits_null'], 1), ('logits(guidance)', sc, fw['logits_scaled'], 3)):
             f = got.reshape(512, -1)
             _err(f'{precision} paper-scale {name} full rows', f[C5_ROWS], rec['rows'], tol * k)
             _err(f'{precision} paper-scale {name} strided columns', f[:, ::16], rec['cols'], tol * k)
-        _err(f'{precision} paper-scale embed', emb[:, ::4], fw['embed'], 1e-3 if precision == 'parity' else 0.06)
+        _err(f'{precision} paper-scale embed', emb[:, ::4], fw['embed'], 1e-3 if precision in EXACT else 0.06)
         gen = g['generate']
         us = []
         for s, u in enumerate(R.noise_stream(R.C5_T, R.C5_NOISE_SEED, (2, 256, 8192))):
@@ -294,13 +302,15 @@ def test_paper_scale_forward_and_generate_at_full_size(paper, precision):
             steps = [(masked[s] == gen['step_in_ids'][s].long()).float().mean().item() for s in range(R.C5_T)]
             final = (out.cpu().reshape(gen['final_ids'].shape) == gen['final_ids']).float().mean().item()
             print(f'[paper-scale parity] {precision} generate: final ids equal to the reference run {100 * final:.2f} %, per-step states min {100 * min(steps):.2f} %')
-            if precision == 'parity':
+            if precision == 'bf16x3':
+                assert isinstance(trace['masked_ids'], torch.Tensor)
+            if precision in EXACT:
                 assert final == 1.0 and min(steps) == 1.0
             else:
                 assert final >= 0.80
                 out2 = mg.generate(['a', 'b'], fmap_size=16, timesteps=R.C5_T, cond_scale=3., text_embeds=te, noise=noise, noise_kind='uniform', return_ids=True,
                                    fused_sampling=False)
-                assert (out == out2).float().mean().item() > 0.99
+                assert torch.equal(out, out2)      # both sampling paths give bit-identical confidences (common.h tile_softmax_stats)
         finally:
             with torch.no_grad():
                 tr.to_logits.weight.div_(R.PEAK)

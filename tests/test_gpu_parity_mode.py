@@ -1,4 +1,6 @@
-"""precision = 'parity' (fp32 storage + fp32 MFMA, csrc/parity.hip) against the UNMODIFIED REFERENCE's recorded outputs -- not against a
+"""precision = 'parity' (fp32 storage + fp32 MFMA, csrc/parity.hip) and precision = 'bf16x3' (the tier inside mm_generate: exact bf16 term
+splits on the bf16 matrix pipe, csrc/split.hip -- the tiny fixtures carry general fp32 weights, so this is its 6-product form; the full-size
+fixtures are bf16-representable and run its 3-product form) against the UNMODIFIED REFERENCE's recorded outputs -- not against a
 rounding-point oracle: logits / pixels within 1e-3 absolute on unit scale (1e-3 x scale where the fixture's logits were made peaky), token
 ids and LFQ ids 100 % equal, for every tiny fixture of round 1 (forward, guidance, T = 4 / 18 decode, all five decode variants, VAE).
 The full-size counterpart is tests/test_gpu_base_size.py.  Operator-level checks against fp64 torch come first."""
@@ -99,15 +101,21 @@ def test_f32_conv_groupnorm_glu_vs_torch():
 
 
 # ------------------------------------------------------------------------------------------------ tiny fixtures of the reference
-def _tiny(golden):
+TIERS = ['parity', 'bf16x3']
+
+
+def _tiny(golden, precision='parity'):
     g = golden('transformer_tiny.pt')
     t = mm.MaskGitTransformer(t5_name='t5-small', **g['cfg'])
     t.load_state_dict(sd_f32(g['sd']))
-    return g, t.to(DEV).eval().set_precision('parity')
+    return g, t.to(DEV).eval().set_precision(precision)
 
 
-def test_parity_forward_and_guidance_vs_reference_golden(golden):
-    g, t = _tiny(golden)
+@pytest.mark.parametrize('precision', TIERS)
+def test_parity_forward_and_guidance_vs_reference_golden(golden, precision):
+    g, t = _tiny(golden, precision)
+    if precision == 'bf16x3':
+        assert t.split_products() == 6          # general fp32 weights: all six term pairs
     ids, te = g['ids'].to(DEV), g['text_embeds'].to(DEV)
     lc, emb = t(ids, text_embeds=te, return_embed=True)
     ln = t(ids, text_embeds=te, cond_drop_prob=1.)
@@ -120,9 +128,10 @@ def test_parity_forward_and_guidance_vs_reference_golden(golden):
     assert torch.equal(lc.cpu().argmax(-1), g['logits_cond'].argmax(-1))
 
 
+@pytest.mark.parametrize('precision', TIERS)
 @pytest.mark.parametrize('T', [4, 18])
-def test_parity_generate_ids_equal_the_reference_run(golden, T):
-    g, t = _tiny(golden)
+def test_parity_generate_ids_equal_the_reference_run(golden, T, precision):
+    g, t = _tiny(golden, precision)
     gen = golden(f'generate_tiny_T{T}.pt')
     mg = mm.MaskGit(image_size=128, transformer=t, vae=None)
     uni = torch.stack(gen['uniform'])
@@ -133,8 +142,9 @@ def test_parity_generate_ids_equal_the_reference_run(golden, T):
     assert torch.equal(ids.reshape(gen['final_ids'].shape).cpu(), gen['final_ids'])
 
 
+@pytest.mark.parametrize('precision', TIERS)
 @pytest.mark.parametrize('name', ['token_critic', 'self_critic', 'cond_scale_1', 'can_remask', 'self_cond'])
-def test_parity_decode_variants_equal_the_reference_run(golden, name):
+def test_parity_decode_variants_equal_the_reference_run(golden, name, precision):
     gv, gt = golden('generate_variants_tiny.pt')[name], golden('transformer_tiny.pt')
     te = gt['text_embeds']
     T, B, n = gv['timesteps'], 2, 64
@@ -143,7 +153,7 @@ def test_parity_decode_variants_equal_the_reference_run(golden, name):
         t.load_state_dict(sd_f32(gv['sd']))
         t = t.to(DEV)
     else:
-        _, t = _tiny(golden)
+        _, t = _tiny(golden, precision)
     kw = {}
     if name == 'token_critic':
         critic = mm.TokenCritic(num_tokens=512, seq_len=64, dim=128, depth=1, dim_head=64, heads=8, t5_name='t5-small')
@@ -158,7 +168,7 @@ def test_parity_decode_variants_equal_the_reference_run(golden, name):
         kw['can_remask_prev_masked'] = True
     else:
         mg = mm.MaskGit(image_size=128, transformer=t, vae=None)
-    mg.set_precision('parity')
+    mg.set_precision(precision)
     if name in ('token_critic', 'self_critic'):
         kw['critic_noise'] = torch.stack([u.reshape(B, n) for u in gv['critic_uniform']])
     trace = {}
