@@ -10,7 +10,9 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
   roofline     : the dominant kernel = the fused to_logits+CFG MFMA GEMM, timed with HIP events on its launch stream
                  inside the timed region (mm_profile_*), algorithmic flops / measured time vs 2.5 PFLOP/s dense bf16;
   roofline_hbm : the HBM-bound sampling kernel the same way (algorithmic bytes = one fp32 read of each sampled row);
-  cpu_baseline : the CPU oracle (port of the reference algorithm, torch fp32 on the host cores) on a bounded sample.
+  cpu_baseline : the CPU oracle (port of the reference algorithm, torch fp32 on the host cores) on a bounded sample;
+  parity_tier  : the same workload through precision 'bf16x3' -- the engine that meets the north star's tolerance (logits within 1e-3 of the fp32
+                 reference, ids bit-exact: tests/test_gpu_base_size.py) inside the same mm_generate call -- timed after the main region.
 """
 import argparse
 import json
@@ -177,6 +179,69 @@ def reference_flops_per_generate(tr, B, n, m_text, nc, timesteps):
     return B * 2 * timesteps * (depth * layer + 2.0 * n * D * tr.dim_out)
 
 
+def parity_tier_leg(mg, tr, step, args, B, T, n, nc, image_size, counts, lib, bf16_s_per_step):
+    """The same step through precision 'bf16x3' (csrc/split.hip): every GEMM activation as its exact three-term bf16 split, multiplied as term
+    products on the bf16 MFMA kernels of the main line, fp32 everywhere else, attention on the fp32 MFMA, VAE decode on the fp32 engine -- the
+    tier that holds logits within 1e-3 of the reference's fp32 run and reproduces its ids bit for bit (tests/test_gpu_base_size.py).  Timed
+    with the checkpoint the main line effectively multiplies by: the bf16 engine rounds every Linear weight to bf16 when it packs, so the
+    parameters are rounded to bf16 first -- a bf16-representable checkpoint, 3 term products per GEMM -- and, for one step, with the raw fp32
+    initialisation (6 term products)."""
+    import ctypes as C
+    from muse_maskgit_pytorch_amd import _lib
+
+    def timed(steps):
+        step(-100)
+        torch.cuda.synchronize()
+        lib.mm_profile_enable(1)
+        t0 = time.perf_counter()
+        marks = []
+        for i in range(steps):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _, images, e_mid = step(i)
+            marks.append((e0, e_mid))
+        torch.cuda.synchronize()
+        sec = (time.perf_counter() - t0) / steps
+        lib.mm_profile_enable(0)
+        prof = []
+        for slot in range(2):
+            cnt, ms, work = C.c_int64(), C.c_double(), C.c_double()
+            _lib.check(lib.mm_profile_read(slot, C.byref(cnt), C.byref(ms), C.byref(work)), 'mm_profile_read')
+            prof.append((cnt.value, ms.value, work.value))
+        assert torch.isfinite(images).all() and images.shape == (B, 3, image_size, image_size)
+        return sec, sum(a.elapsed_time(b) for a, b in marks) / steps, prof
+
+    mg.set_precision('bf16x3')
+    try:
+        sec6, loop6, _ = timed(1)                       # raw fp32 initialisation: general weights, 6 term products
+        p6 = tr._model().packed['P']
+        with torch.no_grad():
+            for p_ in list(mg.transformer.parameters()) + list(mg.vae.parameters()):
+                p_.copy_(p_.to(torch.bfloat16).float())
+        sec, loop_ms, prof = timed(max(1, min(args.steps, 5)))
+        P = tr._model().packed['P']
+        g_cnt, g_ms, g_flops = prof[0]
+        ex = executed_flops_per_generate(tr, B, n, args.text_len, nc, counts)
+        return {
+            'precision': 'bf16x3', 'value': B / sec, 'unit': 'images/sec', 'ms_per_step': sec * 1e3, 'decode_loop_ms_per_step': loop_ms,
+            'x_bf16_engine_time': sec / bf16_s_per_step, 'term_products': P,
+            'checkpoint': 'the main line\'s parameters rounded to bf16 (what the bf16 engine multiplies by): bf16-representable weights need 3 term products',
+            'tolerance': 'logits <= 1e-3 absolute and ids bit-exact against the reference fp32 run at this size (tests/test_gpu_base_size.py, precision bf16x3); '
+                         'VAE decode on the fp32 engine',
+            'roofline': {'kernel': 'gemm_cfg2_kernel on K = 3 x dim (term products of to_logits + guidance)', 'bound': 'mfma',
+                         'achieved': P * g_flops / (g_ms * 1e-3) / 1e12 if g_ms else None, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': (P * g_flops / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if g_ms else None,
+                         'flops_kind': 'executed bf16 MFMA flops (term products x the algorithmic 2 x 2 x R x V x D)',
+                         'algorithmic_frac': (g_flops / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if g_ms else None,
+                         'launches': g_cnt, 'avg_launch_ms': g_ms / g_cnt if g_cnt else None, 'traffic': None},
+            'executed_bf16_tflops_decode_loop_gemms_x_products': P * ex / (loop_ms * 1e-3) / 1e12,
+            'fp32_checkpoint': {'term_products': p6, 'value': B / sec6, 'ms_per_step': sec6 * 1e3, 'decode_loop_ms_per_step': loop6, 'steps': 1,
+                                'note': 'same tier on the raw fp32 initialisation: general fp32 weights need all six term pairs'},
+        }
+    finally:
+        mg.set_precision('bf16')
+
+
 def train_bench(args, dev, rank, world, dist):
     """MaskGit.forward (muse_maskgit_pytorch.py:623-741: random masking, cond-dropped forward, cross-entropy on the masked positions) + the
     hand-written backward (training.py) + torch.optim.AdamW on the C2 base transformer, token ids as input (no VAE in the step).  One process per
@@ -260,6 +325,7 @@ def main():
     ap.add_argument('--tiny', action='store_true', help='configs[0] plumbing case instead of the metric config')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fused-sampling', action='store_true', help='materialise the logits (round-1 path) for A/B timing')
+    ap.add_argument('--no-parity-tier', action='store_true', help="skip the second timed leg (precision 'bf16x3', the tolerance-meeting tier)")
     ap.add_argument('--train', action='store_true', help='time the TRAINING step of the C2 base transformer (MaskGit.forward + backward + AdamW) instead of '
                     'generation: a second, separately labelled line -- not the BASELINE metric')
     args = ap.parse_args()
@@ -413,6 +479,8 @@ def main():
                              'launches': s_cnt, 'avg_launch_ms': s_ms / s_cnt if s_cnt else None},
             'fused_sampling': {'enabled': fused_on, 'fallbacks_to_logits_path': mg.fused_sampling_fallbacks},
         }
+        if world == 1 and not args.no_parity_tier and not args.tiny:
+            out['parity_tier'] = parity_tier_leg(mg, tr, step, args, B, T, n, nc, image_size, counts, lib, elapsed / args.steps)
         if world == 1 and not args.no_cpu_baseline and not args.tiny and args.config == 'c2':
             out['cpu_baseline'] = cpu_baseline(mg, te_all[:2], T, 3.)
         print(json.dumps(out))

@@ -1,6 +1,6 @@
 """precision = 'parity' (fp32 storage + fp32 MFMA, csrc/parity.hip) and precision = 'bf16x3' (the tier inside mm_generate: exact bf16 term
-splits on the bf16 matrix pipe, csrc/split.hip -- the tiny fixtures carry general fp32 weights, so this is its 6-product form; the full-size
-fixtures are bf16-representable and run its 3-product form) against the UNMODIFIED REFERENCE's recorded outputs -- not against a
+splits on the bf16 matrix pipe, csrc/split.hip; all reference fixtures are bf16-representable checkpoints = its 3-product form, the 5- and
+6-product forms for general fp32 weights are checked against fp64 and against the fp32 engine in tests/test_gpu_bf16x3.py) against the UNMODIFIED REFERENCE's recorded outputs -- not against a
 rounding-point oracle: logits / pixels within 1e-3 absolute on unit scale (1e-3 x scale where the fixture's logits were made peaky), token
 ids and LFQ ids 100 % equal, for every tiny fixture of round 1 (forward, guidance, T = 4 / 18 decode, all five decode variants, VAE).
 The full-size counterpart is tests/test_gpu_base_size.py.  Operator-level checks against fp64 torch come first."""
@@ -115,7 +115,7 @@ def _tiny(golden, precision='parity'):
 def test_parity_forward_and_guidance_vs_reference_golden(golden, precision):
     g, t = _tiny(golden, precision)
     if precision == 'bf16x3':
-        assert t.split_products() == 6          # general fp32 weights: all six term pairs
+        assert t.split_products() == 3          # the fixture's weights are bf16-representable (the 5 / 6-product forms: tests/test_gpu_bf16x3.py)
     ids, te = g['ids'].to(DEV), g['text_embeds'].to(DEV)
     lc, emb = t(ids, text_embeds=te, return_embed=True)
     ln = t(ids, text_embeds=te, cond_drop_prob=1.)
