@@ -124,7 +124,8 @@ int mm_sample_rows(mm_stream_t stream, const float* logits, int64_t ld, int R, i
  *                        combined with cond_scale) and the vocabulary statistics of to_logits (wmean fp32 [D], wcov bf16 [D][D], D % 64 == 0);
  *                        z = mm_fused_z(k_keep, V, margin) (normal quantile of the kept fraction minus a safety margin in sigmas);
  *                        ws: mm_fused_threshold_workspace_bytes(R, D) bytes of scratch
- *   mm_gemm_cfg_logits_fused : mm_gemm_cfg_logits whose epilogue emits stats / cand instead of writing the logits
+ *   mm_gemm_cfg_logits_fused : mm_gemm_cfg_logits whose epilogue emits stats / cand instead of writing the logits; x_null == NULL: x_cond holds
+ *                        the already mixed embeddings (mm_cfg_mix) and the product is the single pass mm_generate runs (cond_scale ignored)
  *   mm_fused_emit      : the same emission from materialised logits (tests; shapes the 256-column GEMM does not take)
  *   mm_fused_sample    : the finishing kernel; remaining arguments as in mm_sample_rows */
 #define MM_FUSED_SLOT 64
@@ -348,6 +349,13 @@ int mm_f32_nhwc_to_nchw(mm_stream_t stream, const float* in, int B, int C, int H
  * first `products` (3, 5 or 6) of the segments [h | m | l | h | m | h], x = h + m + l exactly (h = bf16(x), m = bf16(x - h), l = x - h - m).
  * Feed the result to mm_gemm_bf16 / mm_gemm_cfg_logits with K' = products * K against a weight packed the same way. */
 int mm_split_rows(mm_stream_t stream, const float* x, int64_t ldx, int64_t rows, int K, int products, void* out);
+
+/* Classifier-free guidance applied to the EMBEDDINGS (round 3): to_logits is linear (mmp.py:332), so null + (cond - null) * s of the two passes'
+ * logits (mmp.py:254) equals to_logits(e) with e = e_null + (e_cond - e_null) * s -- ONE [R x V x D] product instead of two.  mm_generate and
+ * Transformer.forward_with_cond_scale mix first and multiply once (mm_gemm_bf16 / the fused-sampling GEMM on the mixed rows).
+ * products == 0: bf16 rows [R][ld] in, bf16 [R][D] out (rounded once); products = 3 / 5 / 6: term-segment packs in and out (exact fp32 mix). */
+int mm_cfg_mix(mm_stream_t stream, const void* emb_cond, const void* emb_null, int64_t ld, int64_t rows, int D, int products, float cond_scale,
+               void* out);
 
 /* ------------------------------------------------------------------------------------------------ transformer */
 

@@ -136,6 +136,7 @@ SIGNATURES = {
     'mm_f32_nchw_to_nhwc': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     'mm_f32_nhwc_to_nchw': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     'mm_split_rows': (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp]),
+    'mm_cfg_mix': (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_f32, c_vp]),
     'mm_transformer_create': (c_int, [C.POINTER(TransformerDesc), C.POINTER(c_vp)]),
     'mm_transformer_destroy': (None, [c_vp]),
     'mm_context_workspace_bytes': (c_sz, [c_vp, c_int, c_int]),

@@ -93,11 +93,13 @@ int mm_fused_threshold(mm_stream_t stream, const void* emb_cond, const void* emb
 int mm_gemm_cfg_logits_fused(mm_stream_t stream, const void* x_cond, const void* x_null, int64_t ldx, const void* w, int64_t ldw, int M, int N, int K,
                              float cond_scale, const float* thr, void* stats, void* cand) {
     if (M == 0 || N == 0) return MM_OK;
-    CHK_PTR(x_cond, "x_cond"); CHK_PTR(x_null, "x_null"); CHK_PTR(w, "w"); CHK_PTR(thr, "thr"); CHK_PTR(stats, "stats"); CHK_PTR(cand, "cand");
+    CHK_PTR(x_cond, "x_cond"); CHK_PTR(w, "w"); CHK_PTR(thr, "thr"); CHK_PTR(stats, "stats"); CHK_PTR(cand, "cand");
     CHK_ALIGN16(x_cond, "x_cond"); CHK_ALIGN16(x_null, "x_null"); CHK_ALIGN16(w, "w"); CHK_ALIGN16(stats, "stats"); CHK_ALIGN16(cand, "cand");
     GemmArgs a;
     memset(&a, 0, sizeof(a));
-    a.mode = MODE_CFG;
+    // x_null == NULL: x_cond holds the already MIXED embeddings (mm_cfg_mix) -- the single-pass form mm_generate uses; cond_scale is ignored
+    a.mode = x_null ? MODE_CFG : MODE_DENSE;
+    a.wide_tok = x_null ? 0 : 1;
     a.W = (const bf16_t*)w; a.N = N; a.ldw = (int)ldw; a.K = K;
     a.M = M; a.X = (const bf16_t*)x_cond; a.X2 = (const bf16_t*)x_null; a.ldx = (int)ldx;
     a.out = nullptr; a.ldc = N; a.out_kind = OUT_F32; a.cfg_scale = cond_scale;

@@ -497,7 +497,8 @@ int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
     // (the 256x256 GEGLU variant also emits the LayerNorm partial sums, but that path has no full-size test yet: a folded FF keeps w1 on
     //  the 256x128 persistent kernel)
     if (a.fs_stats) {      // fused sampling: only the 256-column guidance kernel implements the emission (model.hip checks eligibility first)
-        if (a.mode != MODE_CFG || !mm_gemm_cfg2_eligible(a)) return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: fused sampling needs the 256-column guidance-logits kernel");
+        if ((a.mode != MODE_CFG && !(a.mode == MODE_DENSE && a.wide_tok)) || !mm_gemm_cfg2_eligible(a))
+            return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: fused sampling needs the 256-column guidance-logits kernel");
         return mm_gemm_cfg2_launch(a, stream);
     }
     if (!(a.debug & (8 | 4096 | 8192)) && !a.ln_part && mm_gemm_cfg2_eligible(a)) return mm_gemm_cfg2_launch(a, stream);

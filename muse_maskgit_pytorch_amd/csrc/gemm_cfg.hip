@@ -27,6 +27,10 @@
 // gemm_pers.hip: results are bit-identical to those kernels.
 // Second instantiation (WIDE_GEGLU): FF w1 with the GEGLU epilogue on a 256-row x 256-weight-row tile for long K (see
 // mm_gemm_cfg2_eligible); same pipeline, the bf16 output tile (64 KiB) goes through ct in one piece schedule.
+// Third instantiation (WIDE_MIX, round 3): the guidance logits as ONE pass.  null + (cond - null) * s is linear in the embedding
+// (mmp.py:254 with logits = embed @ W^T, :332), so the decode loop mixes the two passes' final embeddings first (mm_cfg_mix) and multiplies
+// once: 128 mixed token rows x 256 columns per tile, half the MFMAs and 3/4 of the operand stream of the two-pass tile for the same
+// 128 x 256 logits, the SAME output path (pieces through ct, logits store or fused-sampling emission) -- the formats downstream do not change.
 #include "common.h"
 #include "muse_hip_internal.h"
 
@@ -104,15 +108,16 @@ struct LoadCur {
     __amdgpu_buffer_rsrc_t w;
 };
 
-constexpr int WIDE_CFG = 0, WIDE_GEGLU = 1;
+constexpr int WIDE_CFG = 0, WIDE_GEGLU = 1, WIDE_MIX = 2;
 
 template <int WMODE>
 __device__ __forceinline__ void cfg_tile_setup(const GemmArgs& p, int vb, LoadCur& lc) {
     int tile_m, tile_n;
     xcd_grouped_tile(vb, p.tiles_m, p.tiles_n, 8, tile_m, tile_n);
-    const int m0 = tile_m * (WMODE == WIDE_CFG ? TOK : 2 * TOK), n0 = tile_n * BN;
+    constexpr int TROWS = (WMODE == WIDE_GEGLU) ? 2 * TOK : TOK;      // activation rows of a tile per operand
+    const int m0 = tile_m * TROWS, n0 = tile_n * BN;
     const int rows_left = p.M - m0;                                                     // > 0
-    const int xrows = rows_left < (WMODE == WIDE_CFG ? TOK : 2 * TOK) ? rows_left : (WMODE == WIDE_CFG ? TOK : 2 * TOK);
+    const int xrows = rows_left < TROWS ? rows_left : TROWS;
     const unsigned xbytes = (unsigned)xrows * (unsigned)p.ldx * 2u;                     // reads past the last real row return 0
     lc.x[0] = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.X + (size_t)m0 * p.ldx), 0, xbytes, 0x00020000);
     lc.x[1] = (WMODE == WIDE_CFG) ? __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.X2 + (size_t)m0 * p.ldx), 0, xbytes, 0x00020000) : lc.x[0];
@@ -133,6 +138,8 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
     const int KT = p.K / BK;
     const int KH = KT >> 1;
     const int rd = fr * 64 + ((fg ^ ((-(fr >> 2)) & 3)) << 4);      // this lane's fragment offset inside a 16-row block
+    constexpr bool TOKT = WMODE != WIDE_GEGLU;      // token-row tiles with an fp32 output (two-pass guidance / single mixed pass)
+    constexpr int NDMA = (WMODE == WIDE_MIX) ? 3 : 4;      // LDS-DMA instructions per wave and k-step
 
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     int vb = blockIdx.x;
@@ -153,7 +160,8 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int xb = 2 * wid + i;
-            const int xrow = (WMODE == WIDE_CFG) ? (xb >> 3) * 64 + (xb & 3) * 16 + (lane >> 2) : xb * 16 + (lane >> 2);
+            // WIDE_MIX: 8 activation blocks per stage, this wave stages block wid (voff_x[1] unused)
+            const int xrow = (WMODE == WIDE_CFG) ? (xb >> 3) * 64 + (xb & 3) * 16 + (lane >> 2) : (WMODE == WIDE_MIX ? wid * 16 + (lane >> 2) : xb * 16 + (lane >> 2));
             voff_x[i] = xrow * p.ldx * 2 + c * 16;
             voff_w[i] = (xb * 16 + (lane >> 2)) * p.ldw * 2 + c * 16;
         }
@@ -165,8 +173,12 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
             unsigned char* xs_ = smem + (st_) * STG_B + wid * 2048;                                            \
             const int k0_ = l_k * (BK * 2);                                                                    \
             const __amdgpu_buffer_rsrc_t rx_ = x_null0 ? lc.x[1] : lc.x[0];                                    \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, (lds_ptr_t)(xs_), 16, voff_x[0], k0_, 0, 0);         \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, (lds_ptr_t)(xs_ + 1024), 16, voff_x[1], k0_, 0, 0);  \
+            if constexpr (WMODE == WIDE_MIX) {                                                                 \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, (lds_ptr_t)(smem + (st_) * STG_B + wid * 1024), 16, voff_x[0], k0_, 0, 0); \
+            } else {                                                                                           \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, (lds_ptr_t)(xs_), 16, voff_x[0], k0_, 0, 0);     \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, (lds_ptr_t)(xs_ + 1024), 16, voff_x[1], k0_, 0, 0); \
+            }                                                                                                  \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(lc.w, (lds_ptr_t)(xs_ + XT_B), 16, voff_w[0], k0_, 0, 0); \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(lc.w, (lds_ptr_t)(xs_ + XT_B + 1024), 16, voff_w[1], k0_, 0, 0); \
         }                                                                                                      \
@@ -184,7 +196,7 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
     // fused sampling: no logits leave the kernel; every piece emits tile statistics + the kept lanes' values instead (common.h
     // fused_emit_piece).  Its VMEM instructions per piece: 1 statistics store (always issued) + 1 predicated value store.  The counted waits
     // below only need a LOWER bound of what was issued behind a DMA (under-counting waits for more, never for less).
-    const bool fused = (WMODE == WIDE_CFG) && p.fs_stats != nullptr;
+    const bool fused = TOKT && p.fs_stats != nullptr;
     f32x4_t acc[4][8];
     f32x4_t held[2][4];             // second half of the previous tile's output (tokens 32..63 of this wave), combined
     float4 parked = make_float4(0.f, 0.f, 0.f, 0.f);      // fused sampling: lane j holds the statistics of this wave's j-th piece of the previous tile
@@ -213,7 +225,7 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
     //     wait (DMA of step g+1 landed; my reads of stage g done) - BARRIER - stage g is free: issue the DMA of step g+3
     //     MFMA pair 2 | read afB, p0 <- step g+1 (weights, pair 0) | MFMA pair 3 | store the piece read after the barrier
     // so every MFMA group runs with the reads of a later group in flight, also across the barrier.
-#define X_FRAG(st_, j_) (*reinterpret_cast<const u32x4_t*>(smem + (st_) * STG_B + wm * 8192 + rd + (j_) * 1024))
+#define X_FRAG(st_, j_) (*reinterpret_cast<const u32x4_t*>(smem + (st_) * STG_B + wm * (WMODE == WIDE_MIX ? 4096 : 8192) + rd + (j_) * 1024))
 #define W_FRAG(st_, i_) (*reinterpret_cast<const u32x4_t*>(smem + (st_) * STG_B + XT_B + wn * 4096 + rd + (i_) * 1024))
 #define MFMA_PAIR(af_, src_, j_)                                                                               \
     if (!ABL(p, 4)) {                                                                                          \
@@ -226,17 +238,19 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
         const int st_ = g % NST, stn_ = (g + 1) % NST;                                                         \
         p1[0] = X_FRAG(st_, 2); p1[1] = X_FRAG(st_, 3);                                                        \
         MFMA_PAIR(AF_, p0, 0)                                                                                  \
-        p0[0] = X_FRAG(st_, 4); p0[1] = X_FRAG(st_, 5);                                                        \
-        MFMA_PAIR(AF_, p1, 1)                                                                                  \
-        p1[0] = X_FRAG(st_, 6); p1[1] = X_FRAG(st_, 7);                                                        \
+        if constexpr (WMODE != WIDE_MIX) {      /* WIDE_MIX: 4 activation blocks per wave, pairs 0 and 1 only */ \
+            p0[0] = X_FRAG(st_, 4); p0[1] = X_FRAG(st_, 5);                                                    \
+            MFMA_PAIR(AF_, p1, 1)                                                                              \
+            p1[0] = X_FRAG(st_, 6); p1[1] = X_FRAG(st_, 7);                                                    \
+        }                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         /* step g+1 has landed once only what this wave issued after ITS DMA can be in flight: the store of step g-2, the */ \
         /* 4 DMA instructions of step g+2, the store of step g-1 */                                            \
-        wait_vmcnt(((g + 2 < steps_total && !ABL(p, 2)) ? 4 : 0) + st1 + st2);                                 \
+        wait_vmcnt(((g + 2 < steps_total && !ABL(p, 2)) ? NDMA : 0) + st1 + st2);                              \
         WAIT_LGKM0();                                                                                          \
         __builtin_amdgcn_s_barrier();                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        if (WMODE == WIDE_CFG && kt == KH && have_prev) {                                                      \
+        if (TOKT && kt == KH && have_prev) {                                                                   \
             /* every wave has read the last piece of the first half (step KH-1 at the latest): second half -> ct */ \
             HELD_TO_CT();                                                                                      \
             WAIT_LGKM0();                                                                                      \
@@ -244,12 +258,12 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
         }                                                                                                      \
         /* this step's piece of the previous tile.  CFG: first half during steps 0..7, second half during steps KH..KH+7, one */ \
         /* token row (1 KiB fp32) per wave.  GEGLU: the whole 256 x 128 bf16 tile during steps 0..7, 4 rows (256 B each) per wave */ \
-        const int half_ = (WMODE == WIDE_CFG && kt >= KH) ? 1 : 0;                                             \
+        const int half_ = (TOKT && kt >= KH) ? 1 : 0;                                                          \
         const int q_ = kt - (half_ ? KH : 0);                                                                  \
         int prow_, ptok_;                                                                                      \
         const unsigned char* psrc_;                                                                            \
         unsigned char* pv_ptr_;                                                                                \
-        if constexpr (WMODE == WIDE_CFG) {                                                                     \
+        if constexpr (TOKT) {                                                                                  \
             prow_ = PIECE_ROW(q_);                                                                             \
             ptok_ = PIECE_TOKEN(prow_, half_);                                                                 \
             psrc_ = ct + prow_ * 1024 + ((lane ^ (prow_ & 7)) << 4);                                           \
@@ -264,23 +278,23 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
         uint4 pv_ = make_uint4(0, 0, 0, 0);                                                                    \
         float fthr_ = 0.f;                                                                                     \
         if (piece_) pv_ = lds_read_b128_raw(psrc_);                                                            \
-        if (WMODE == WIDE_CFG && fused && piece_) fthr_ = sload_f32(p.fs_thr + __builtin_amdgcn_readfirstlane(ptok_));      \
+        if (TOKT && fused && piece_) fthr_ = sload_f32(p.fs_thr + __builtin_amdgcn_readfirstlane(ptok_));     \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         LOAD_NEXT(st_);                                     /* step g+3 into the stage just consumed */        \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        MFMA_PAIR(AF_, p0, 2)                                                                                  \
+        if constexpr (WMODE != WIDE_MIX) { MFMA_PAIR(AF_, p0, 2) }                                             \
         if (g + 1 < steps_total) {                                                                             \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) AFN_[i] = W_FRAG(stn_, i);                           \
             p0[0] = X_FRAG(stn_, 0); p0[1] = X_FRAG(stn_, 1);                                                  \
         }                                                                                                      \
-        MFMA_PAIR(AF_, p1, 3)                                                                                  \
+        if constexpr (WMODE != WIDE_MIX) { MFMA_PAIR(AF_, p1, 3) } else { MFMA_PAIR(AF_, p1, 1) }              \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         st2 = st1;                                                                                             \
         st1 = 0;                                                                                               \
         if (piece_) {                                                                                          \
             WAIT_LGKM0();                                       /* the raw read of pv_ (the fragments are long there) */ \
             __builtin_amdgcn_sched_barrier(0);                                                                 \
-            if constexpr (WMODE == WIDE_CFG) {                                                                 \
+            if constexpr (TOKT) {                                                                              \
                 if (fused) {                                                                                   \
                     st1 = fused_emit_piece_parked(make_float4(__uint_as_float(pv_.x), __uint_as_float(pv_.y), __uint_as_float(pv_.z), __uint_as_float(pv_.w)), \
                                                   ptok_, pn0 >> 8, p.tiles_n, lane, fthr_, p.fs_cand, half_ * 8 + q_, parked) ? 1 : 0; \
@@ -300,7 +314,7 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
             }                                                                                                  \
         }                                                                                                      \
         /* the 16 pieces of the previous tile are out: one store of their parked statistics (lane j = piece j: half j >> 3, q = j & 7) */ \
-        if (WMODE == WIDE_CFG && fused && have_prev && half_ == 1 && q_ == 7) {                                \
+        if (TOKT && fused && have_prev && half_ == 1 && q_ == 7) {                                             \
             const int ftok_ = PIECE_TOKEN(PIECE_ROW(lane & 7), (lane >> 3) & 1);                               \
             fused_flush_stats(parked, (lane < 16 && ftok_ < p.M) ? ftok_ : -1, pn0 >> 8, p.tiles_n, p.fs_stats); \
             /* the store is predicated per lane and skipped (s_cbranch_execz) when none of this wave's 16 pieces exists, i.e. when even its */ \
@@ -318,7 +332,7 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
 #endif
     TSTAMP()
     // prologue: step 0 has landed once only the DMA of steps 1 and 2 (8 instructions) is in flight
-    wait_vmcnt(steps_total > 2 ? 8 : (steps_total > 1 ? 4 : 0));
+    wait_vmcnt(steps_total > 2 ? 2 * NDMA : (steps_total > 1 ? NDMA : 0));
     __builtin_amdgcn_s_barrier();
     u32x4_t afA[4], afB[4], p0[2], p1[2];
 #pragma unroll
@@ -343,16 +357,20 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
         WAIT_LGKM0();
         __builtin_amdgcn_s_barrier();
         TSTAMP()
-        if constexpr (WMODE == WIDE_CFG) {
+        if constexpr (TOKT) {
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     f32x4_t v;
+                    if constexpr (WMODE == WIDE_MIX) {
+                        v = acc[a][b];      // the passes were combined in the embedding (mm_cfg_mix): these ARE the guidance logits
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float cv = acc[a][b][r], nl = acc[a][b + 4][r];
-                        v[r] = nl + (cv - nl) * p.cfg_scale;      // muse_maskgit_pytorch.py:254
+                        for (int r = 0; r < 4; ++r) {
+                            const float cv = acc[a][b][r], nl = acc[a][b + 4][r];
+                            v[r] = nl + (cv - nl) * p.cfg_scale;      // muse_maskgit_pytorch.py:254
+                        }
                     }
                     if (b < 2) {
                         if (!ABL(p, 16)) {
@@ -380,7 +398,7 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
                 }
             }
         }
-        pm0 = tile_m * (WMODE == WIDE_CFG ? TOK : 2 * TOK); pn0 = tile_n * BN;
+        pm0 = tile_m * (TOKT ? TOK : 2 * TOK); pn0 = tile_n * BN;
         have_prev = true;
         vb += G;
         if (vb >= total) break;
@@ -388,7 +406,7 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
     // ---- drain the last tile
     WAIT_LGKM0();
     __builtin_amdgcn_s_barrier();
-    if constexpr (WMODE == WIDE_CFG) {
+    if constexpr (TOKT) {
         for (int half = 0; half < 2; ++half) {
             if (half) {
                 HELD_TO_CT();
@@ -435,8 +453,8 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
 bool mm_gemm_cfg2_eligible(const GemmArgs& a) {
     if (a.bias || a.act != ACT_NONE || a.resid_bf16 || a.resid_f32) return false;
     if ((a.K % (2 * BK)) != 0 || a.K < 16 * BK || (a.N % BN) != 0 || (((uintptr_t)a.out) & 15)) return false;
-    if (a.fs_stats && a.mode != MODE_CFG) return false;
-    if (a.mode == MODE_CFG) {
+    if (a.fs_stats && a.mode != MODE_CFG && !(a.mode == MODE_DENSE && a.wide_tok)) return false;
+    if (a.mode == MODE_CFG || (a.mode == MODE_DENSE && a.wide_tok && a.epi == EPI_NONE)) {      // fp32 logits of 128-token tiles: two-pass guidance / one mixed pass
         if (a.out_kind != OUT_F32 || (a.ldc % 4)) return false;
         return (long)((a.M + TOK - 1) / TOK) * (a.N / BN) >= 256;
     }
@@ -456,16 +474,19 @@ int mm_gemm_cfg2_launch(GemmArgs a, hipStream_t stream) {
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cfg2_kernel<WIDE_CFG>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cfg2_kernel<WIDE_GEGLU>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cfg2_kernel<WIDE_MIX>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
         if (e != hipSuccess) return mm_set_hip_error(e, "gemm_cfg2 hipFuncSetAttribute");
         attr_set = true;
     }
     const bool cfg = a.mode == MODE_CFG;
+    const bool mix = a.mode == MODE_DENSE && a.wide_tok && a.epi == EPI_NONE;
     if (cfg && (g_mm_debug & (1 << 26))) return mm_gemm_cfg3_launch(a, stream);      // bit 1 << 26: the phase-split experiment of gemm_cfg3.hip (same values; measured no faster)
     a.tiles_n = a.N / BN;
-    a.tiles_m = cfg ? (a.M + TOK - 1) / TOK : (a.M + 2 * TOK - 1) / (2 * TOK);
+    a.tiles_m = (cfg || mix) ? (a.M + TOK - 1) / TOK : (a.M + 2 * TOK - 1) / (2 * TOK);
     const int total = a.tiles_m * a.tiles_n;
     const int grid = total < 256 ? total : 256;
     if (cfg) hipLaunchKernelGGL(gemm_cfg2_kernel<WIDE_CFG>, dim3(grid), dim3(512), SMEM_B, stream, a);
+    else if (mix) hipLaunchKernelGGL(gemm_cfg2_kernel<WIDE_MIX>, dim3(grid), dim3(512), SMEM_B, stream, a);
     else hipLaunchKernelGGL(gemm_cfg2_kernel<WIDE_GEGLU>, dim3(grid), dim3(512), SMEM_B, stream, a);
     return mm_check_launch("gemm_cfg2_kernel");
 }

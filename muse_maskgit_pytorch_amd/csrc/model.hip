@@ -518,6 +518,7 @@ struct GenBufs {
     int32_t* rows;          // [B*n]
     bf16_t* embc;           // [B*n][D]
     bf16_t* embn;           // [B*n][D]
+    bf16_t* embm;           // [B*n][D]: null + (cond - null) * cond_scale of the two passes' embeddings -- the ONE operand of the guidance-logits GEMM
     float* logits;          // [B*n][V]
     float* xc;              // [2*B*n][D]: the last layer's residual stream, compacted to the sampled rows
     bf16_t* attc;           // [2*B*n][I]
@@ -564,6 +565,7 @@ void carve_gen(Carver& c, const mm_transformer* t, int B, int n, int L, int nc, 
     g.rows = c.take<int32_t>((size_t)B * n);
     g.embc = c.take<bf16_t>((size_t)B * n * D * seg);
     g.embn = c.take<bf16_t>((size_t)B * n * D * seg);
+    g.embm = c.take<bf16_t>((size_t)B * n * D * seg);
     g.logits = c.take<float>((size_t)B * n * t->d.dim_out);
     g.xc = c.take<float>((size_t)2 * B * n * D);
     g.attc = c.take<bf16_t>((size_t)2 * B * n * I * seg);
@@ -801,20 +803,28 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
         float* scores_out = can_remask ? nullptr : p->scores;
         int64_t* pred_out = can_remask ? g.pred : nullptr;
         float* conf_out = can_remask ? g.conf : nullptr;
+        // Guidance in the embedding (round 3): to_logits is linear (mmp.py:332), so null + (cond - null) * s of the logits (mmp.py:254) is to_logits of
+        // e = e_null + (e_cond - e_null) * s.  The two passes' final embeddings are mixed first (k_cfg_mix) and multiplied ONCE: half the flops of the
+        // loop's dominant GEMM; the general path (Transformer.forward_with_cond_scale) does the same, so the two stay bit-identical.
+        const bf16_t* emb_in = g.embc;
+        if (!single) {
+            RC(k_cfg_mix(s, g.embc, g.embn, KD, R, D, PT, p->cond_scale, g.embm));
+            emb_in = g.embm;
+        }
         GemmArgs a;
         memset(&a, 0, sizeof(a));
-        a.mode = MODE_CFG;
+        a.mode = MODE_DENSE; a.wide_tok = 1;
         a.W = (const bf16_t*)t->d.to_logits; a.N = V; a.ldw = KD; a.K = KD;
-        a.M = R; a.X = g.embc; a.X2 = g.embn; a.ldx = KD;
-        a.out = g.logits; a.ldc = V; a.out_kind = OUT_F32; a.cfg_scale = p->cond_scale;
+        a.M = R; a.X = emb_in; a.ldx = KD;
+        a.out = g.logits; a.ldc = V; a.out_kind = OUT_F32;
         a.debug = g_mm_debug;
         // Sampling without the logits round trip: the GEMM emits tile statistics + the candidates above a per-row lower bound of the k-th largest
         // logit (estimated from the row's embeddings and the vocabulary statistics of to_logits), the finishing kernel verifies the bound.
-        const bool fused = !single && t->d.logits_wcov && t->d.logits_wmean && p->status && !(p->flags & MM_GEN_NO_FUSED_SAMPLING) && (V % 256) == 0 &&
+        const bool fused = t->d.logits_wcov && t->d.logits_wmean && p->status && !(p->flags & MM_GEN_NO_FUSED_SAMPLING) && (V % 256) == 0 &&
                            !(g_mm_debug & (8 | 4096 | 8192 | (1 << 25))) && mm_gemm_cfg2_eligible(a);
-        const double gemm_flops = 2.0 * (double)P * (double)R * (double)V * (double)D;      // cond + null rows
+        const double gemm_flops = 2.0 * (double)R * (double)V * (double)KD;      // EXECUTED bf16 MFMA flops: one pass over the mixed rows (x the term products in the precision tier)
         if (fused) {
-            RC(k_fused_threshold(s, g.embc, g.embn, KD, R, D, p->cond_scale, t->d.logits_wmean, (const bf16_t*)t->d.logits_wcov, k_fused_z(p->k_keep, V, FS_MARGIN),
+            RC(k_fused_threshold(s, emb_in, emb_in, KD, R, D, 1.f, t->d.logits_wmean, (const bf16_t*)t->d.logits_wcov, k_fused_z(p->k_keep, V, FS_MARGIN),
                                  g.fs_ws, g.fs_thr));
             a.out = nullptr;
             a.fs_thr = g.fs_thr; a.fs_stats = g.fs_stats; a.fs_cand = g.fs_cand;
@@ -837,10 +847,7 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
             {
                 prof::Rec pr;
                 if (prof::enabled) pr = prof::begin(s, gemm_flops);
-                if (single)      // cond_scale == 1: the plain to_logits of the one pass (mmp.py:247-248, 332)
-                    RC(gemm_dense(s, g.embc, KD, (const bf16_t*)t->d.to_logits, KD, R, V, KD, g.logits, V, OUT_F32, nullptr));
-                else
-                    RC(mm_gemm_launch(a, s));
+                RC(mm_gemm_launch(a, s));      // (cond_scale == 1: the plain to_logits of the one pass, mmp.py:247-248, 332)
                 if (prof::enabled) prof::end(s, 0, pr);
             }
             SampleArgs sa;

@@ -39,6 +39,8 @@ struct GemmArgs {
     // fused sampling (MODE_CFG on gemm_cfg.hip only): when fs_stats != NULL the logits are NOT written; every 256-column piece of a row emits its
     // statistics and its candidates >= fs_thr[row] instead (common.h fused_emit_piece)
     const float* fs_thr; float4* fs_stats; float4* fs_cand;
+    int wide_tok;                 // MODE_DENSE, fp32 out: request the persistent 128-token x 256-column kernel of gemm_cfg.hip (WIDE_MIX: the guidance logits of
+                                  // the MIXED embedding as one pass; takes fs_* like MODE_CFG); falls back to the other kernels when not eligible
     int debug;                    // ablation bits (mm_debug_set): 1 = no epilogue stores, 2 = no DMA after tile 0, 4 = no MFMA, 8 = force the 128x128 kernel, 4096 = no persistent kernel
 };
 extern int g_mm_debug;
@@ -127,6 +129,8 @@ int k_layernorm_split(hipStream_t s, const float* x, long ldx, int rows, int D, 
                       int P, bf16_t* out, float* out_f32, const float* addvec, int add_from, float* xw);
 int k_geglu_ln_split(hipStream_t s, const float* h, long ldh, int rows, int F, int Fp, const float* gamma, const float* beta, int P, bf16_t* out);
 int k_embed_f32(hipStream_t s, const int64_t* ids, long rows, int n, const float* tok, int vocab_rows, const float* pos, int D, float* x);
+// e = en + (ec - en) * s on embedding rows: bf16 (P == 0, out [rows][D]) or term-segment packs (out [rows][P * D])
+int k_cfg_mix(hipStream_t s, const bf16_t* ec, const bf16_t* en, long ld, long rows, int D, int P, float cond_scale, bf16_t* out);
 struct AttnF32Args {
     const float* q; long q_sb, q_sh, q_sn;       // element strides: batch, head, token (d contiguous, dh = 64)
     const float* k; long k_sb, k_sh, k_sn;

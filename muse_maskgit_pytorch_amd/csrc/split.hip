@@ -185,6 +185,39 @@ __global__ __launch_bounds__(256) void embed_f32v_kernel(const int64_t* __restri
     }
 }
 
+// The two guidance passes combined in the EMBEDDING: logits = embed @ W^T (mmp.py:332) is linear, so null + (cond - null) * s (mmp.py:254) of the
+// logits equals the logits of e = e_null + (e_cond - e_null) * s -- one [R x V x D] product instead of two.  P == 0: bf16 rows in, the mix
+// rounded to bf16 once; P > 0 (precision tier): the rows are term-segment packs, mixed as exact fp32 values (h + m) + l and re-split.
+__global__ __launch_bounds__(256) void cfg_mix_kernel(const bf16_t* __restrict__ ec, const bf16_t* __restrict__ en, long ld, long rows, int D, int P, float s,
+                                                      bf16_t* __restrict__ out) {
+    const int chunks = D >> 2;
+    const long total = rows * chunks;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / chunks;
+        const int c = (int)(i - r * chunks) * 4;
+        float cv[4], nv[4], o[4];
+        if (P == 0) {
+            const uint2 a = *reinterpret_cast<const uint2*>(ec + r * ld + c), b = *reinterpret_cast<const uint2*>(en + r * ld + c);
+            cv[0] = bf16lo(a.x); cv[1] = bf16hi(a.x); cv[2] = bf16lo(a.y); cv[3] = bf16hi(a.y);
+            nv[0] = bf16lo(b.x); nv[1] = bf16hi(b.x); nv[2] = bf16lo(b.y); nv[3] = bf16hi(b.y);
+        } else {
+            float t[2][3][4];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint2 a = *reinterpret_cast<const uint2*>(ec + r * ld + (long)k * D + c), b = *reinterpret_cast<const uint2*>(en + r * ld + (long)k * D + c);
+                t[0][k][0] = bf16lo(a.x); t[0][k][1] = bf16hi(a.x); t[0][k][2] = bf16lo(a.y); t[0][k][3] = bf16hi(a.y);
+                t[1][k][0] = bf16lo(b.x); t[1][k][1] = bf16hi(b.x); t[1][k][2] = bf16lo(b.y); t[1][k][3] = bf16hi(b.y);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { cv[j] = (t[0][0][j] + t[0][1][j]) + t[0][2][j]; nv[j] = (t[1][0][j] + t[1][1][j]) + t[1][2][j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = nv[j] + (cv[j] - nv[j]) * s;
+        if (P == 0) *reinterpret_cast<uint2*>(out + r * D + c) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+        else store_split4(out + r * (long)P * D, D, P, c, o);
+    }
+}
+
 inline bool bad_p(int P) { return P != 3 && P != 5 && P != 6; }
 
 }  // namespace
@@ -246,7 +279,24 @@ int k_embed_f32(hipStream_t s, const int64_t* ids, long rows, int n, const float
     return mm_check_launch("embed_f32v_kernel");
 }
 
+int k_cfg_mix(hipStream_t s, const bf16_t* ec, const bf16_t* en, long ld, long rows, int D, int P, float cond_scale, bf16_t* out) {
+    if (rows <= 0) return MM_OK;
+    if (P != 0 && bad_p(P)) return mm_set_error(MM_ERR_SHAPE, "cfg_mix: products must be 0 (bf16 rows), 3, 5 or 6");
+    if ((D % 4) || (ld % 4)) return mm_set_error(MM_ERR_ALIGN, "cfg_mix: dim and the row stride must be multiples of 4");
+    long blocks = (rows * (D / 4) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(cfg_mix_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ec, en, ld, rows, D, P, cond_scale, out);
+    return mm_check_launch("cfg_mix_kernel");
+}
+
 extern "C" {
+
+// e = e_null + (e_cond - e_null) * cond_scale on the final embeddings of the two guidance passes (see cfg_mix_kernel): bf16 rows [R][ld] -> bf16
+// [R][D] (products == 0), or term-segment packs [R][ld >= products * D] -> [R][products * D] (precision tier)
+int mm_cfg_mix(mm_stream_t stream, const void* emb_cond, const void* emb_null, int64_t ld, int64_t rows, int D, int products, float cond_scale, void* out) {
+    if (rows > 0 && (!emb_cond || !emb_null || !out)) return mm_set_error(MM_ERR_SHAPE, "cfg_mix: NULL pointer");
+    return k_cfg_mix((hipStream_t)stream, (const bf16_t*)emb_cond, (const bf16_t*)emb_null, ld, rows, D, products, cond_scale, (bf16_t*)out);
+}
 
 // fp32 rows -> the P-segment bf16 operand form of the 'bf16x3' tier (X' of the header comment); out [rows][P * K]
 int mm_split_rows(mm_stream_t stream, const float* x, int64_t ldx, int64_t rows, int K, int products, void* out) {

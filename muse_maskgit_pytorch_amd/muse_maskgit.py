@@ -536,18 +536,20 @@ class Transformer(nn.Module):
         return embed, logits
 
     def _cfg_logits(self, emb_a, emb_b, cond_scale):
-        """to_logits on two passes + b + (a - b) * cond_scale as one GEMM (mmp.py:250-254, 332)."""
+        """the guidance-combined logits b + (a - b) * cond_scale of two passes (mmp.py:250-254, 332) from their final embeddings."""
         if self.precision == 'parity':
             return P32.cfg_logits(self, emb_a, emb_b, cond_scale)
         if self.weight_format == 'fp8':
             wl = self._fp8_pack()['wl']
             return ops.gemm_w8a16(emb_a, wl[0], wl[1], x_null=emb_b, cond_scale=cond_scale)
-        return ops.gemm_cfg_logits(emb_a, emb_b, self._model().packed['wl'], cond_scale)
+        # guidance in the embedding: to_logits is linear, so b + (a - b) * s of the logits is to_logits(e_b + (e_a - e_b) * s): mix, then ONE GEMM
+        # (what mm_generate does; every GEMM kernel of the family accumulates in the same order, so the two agree bit for bit)
+        return ops.gemm(ops.cfg_mix(emb_a, emb_b, cond_scale, self.dim), self._model().packed['wl'], out_f32=True)
 
     # ---- reference surface
     def forward_with_cond_scale(self, *args, cond_scale=3., return_embed=False, **kwargs):
-        """mmp.py:240-259.  Both passes run to the final LayerNorm; to_logits and the guidance combine
-        null + (cond - null) * cond_scale are one fused MFMA GEMM (mm_gemm_cfg_logits)."""
+        """mmp.py:240-259.  Both passes run to the final LayerNorm; the guidance combine null + (cond - null) * cond_scale is applied to the two
+        embeddings (mm_cfg_mix; to_logits is linear) and to_logits runs once on the result."""
         if cond_scale == 1:
             return self.forward(*args, return_embed=return_embed, cond_drop_prob=0., **kwargs)
         x = args[0] if args else kwargs.pop('x')

@@ -595,6 +595,7 @@ def fused_threshold(emb_cond, emb_null, cond_scale, wmean, wcov_bf16, z):
 
 
 def gemm_cfg_logits_fused(x_cond, x_null, w, cond_scale, thr, fb):
+    """x_null None: x_cond are mixed embeddings (cfg_mix), one pass"""
     _chk_cuda(x_cond, x_null, w, thr)
     M, K = x_cond.shape
     N = w.shape[0]
@@ -674,3 +675,16 @@ def unsplit_rows(xs, products, K):
     """the fp32 value of a segment pack: h + m + l (exact)"""
     v = xs.reshape(xs.shape[0], products, K)[:, :3].float()
     return (v[:, 0] + v[:, 1]) + v[:, 2]
+
+
+def cfg_mix(emb_cond, emb_null, cond_scale, D):
+    """e = e_null + (e_cond - e_null) * cond_scale on the final embeddings (mm_cfg_mix): bf16 [R, D] rows, or term-segment packs [R, P*D] of the
+    precision tier (mixed as exact fp32 values and re-split).  to_logits of the result is the guidance-combined logits of mmp.py:254."""
+    _chk_cuda(emb_cond, emb_null)
+    assert emb_cond.dtype == bf16 and emb_null.dtype == bf16 and emb_cond.shape == emb_null.shape and emb_cond.stride(0) == emb_null.stride(0)
+    R, W = emb_cond.shape
+    P = W // D if W != D else 0
+    assert W == max(P, 1) * D and emb_cond.stride(1) == 1 and emb_null.stride(1) == 1
+    out = torch.empty(R, W, dtype=bf16, device=emb_cond.device)
+    L.check(L.lib().mm_cfg_mix(L.stream(), L.ptr(emb_cond), L.ptr(emb_null), emb_cond.stride(0), R, D, P, float(cond_scale), L.ptr(out)), 'mm_cfg_mix')
+    return out

@@ -96,6 +96,23 @@ def test_gemm_emission_equals_emission_from_its_logits(M):
     assert torch.equal(fa['cand'][valid].view(torch.int32), fb['cand'][valid].view(torch.int32))
     total = (logits >= thr[:, None]).sum(dim=1)
     assert int(total.min().item()) >= k_keep and int(total.max().item()) < 11264
+    # the single-pass form mm_generate runs (round 3): the embeddings are mixed first (mm_cfg_mix) and multiplied once on the 128 x 256 kernel's
+    # third instantiation; its logits (any dense kernel of the family) and its emission must agree with each other the same way
+    em = ops.cfg_mix(ec, en, s, D)
+    lm = ops.gemm(em, W, out_f32=True)
+    assert (lm - logits).abs().max().item() < 0.08 * logits.std().item()          # same quantity, bf16 rounding of the mix instead of the two operands
+    thr_m = ops.fused_threshold(em, em, 1.0, wmean, wcov, z)
+    fm, fn = ops.fused_buffers(M, V, DEV), ops.fused_buffers(M, V, DEV)
+    ops.fused_emit(lm.contiguous(), thr_m, fm)
+    ops.gemm_cfg_logits_fused(em, None, W, 1.0, thr_m, fn)
+    assert torch.equal(fm['stats'].view(torch.int32), fn['stats'].view(torch.int32))
+    masks_m = fm['stats'][..., 2:].contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    lanes_m = sum(((masks_m >> b) & 1) for b in range(32)).sum(dim=-1)
+    valid_m = torch.arange(ops.FUSED_SLOT, device=DEV)[None, None, :] < lanes_m[..., None]
+    assert torch.equal(fm['cand'][valid_m].view(torch.int32), fn['cand'][valid_m].view(torch.int32))
+    pm, sm = ops.fused_sample(fn, thr_m, M, V, k_keep, 1.0, noise_kind=_lib.MM_NOISE_PHILOX, seed=3)
+    rp_, rs_ = ops.sample_rows(lm.contiguous(), k_keep, 1.0, noise_kind=_lib.MM_NOISE_PHILOX, seed=3)
+    assert int(fn['fail'].item()) == 0 and torch.equal(pm, rp_) and torch.equal(sm, rs_)
     pa, sa = ops.fused_sample(fa, thr, M, V, k_keep, 1.0, noise_kind=_lib.MM_NOISE_PHILOX, seed=3)
     pb, sb = ops.fused_sample(fb, thr, M, V, k_keep, 1.0, noise_kind=_lib.MM_NOISE_PHILOX, seed=3)
     ref_pred, ref_score = ops.sample_rows(logits, k_keep, 1.0, noise_kind=_lib.MM_NOISE_PHILOX, seed=3)
