@@ -481,7 +481,7 @@ def main():
                              'traffic': traffic_of('sample_fused_kernel' if fused_on else 'sample_kernel') if metric_cfg else None,
                              'algorithmic_bytes_per_launch': s_bytes / s_cnt if s_cnt else None,
                              'launches': s_cnt, 'avg_launch_ms': s_ms / s_cnt if s_cnt else None},
-            'fused_sampling': {'enabled': fused_on, 'fallbacks_to_logits_path': mg.fused_sampling_fallbacks},
+            'fused_sampling': {'enabled': fused_on, 'fallbacks_to_logits_path': mg.fused_sampling_fallbacks, 'rows_finished_by_on_device_fallback': mg.fused_row_fallbacks},
         }
         if world == 1 and not args.no_parity_tier and not args.tiny:
             out['parity_tier'] = parity_tier_leg(mg, tr, step, args, B, T, n, nc, image_size, counts, lib, elapsed / args.steps)

@@ -127,7 +127,9 @@ int mm_sample_rows(mm_stream_t stream, const float* logits, int64_t ld, int R, i
  *   mm_gemm_cfg_logits_fused : mm_gemm_cfg_logits whose epilogue emits stats / cand instead of writing the logits; x_null == NULL: x_cond holds
  *                        the already mixed embeddings (mm_cfg_mix) and the product is the single pass mm_generate runs (cond_scale ignored)
  *   mm_fused_emit      : the same emission from materialised logits (tests; shapes the 256-column GEMM does not take)
- *   mm_fused_sample    : the finishing kernel; remaining arguments as in mm_sample_rows */
+ *   mm_fused_sample    : the finishing kernel; remaining arguments as in mm_sample_rows.  A row whose candidates cannot be proven complete is
+ *                        appended to fail_rows[atomicAdd(fail_count, 1)] (device int32 [fail_cap] / [1], optional) for the caller to finish on
+ *                        the logits path (mm_generate does, on the device); without a list, or when it is full, *fail_flag is set to 1 */
 #define MM_FUSED_SLOT 64
 float mm_fused_z(int k_keep, int V, float margin);
 size_t mm_fused_threshold_workspace_bytes(int R, int D);
@@ -138,7 +140,8 @@ int mm_gemm_cfg_logits_fused(mm_stream_t stream, const void* x_cond, const void*
 int mm_fused_emit(mm_stream_t stream, const float* logits, int64_t ld, int R, int V, const float* thr, void* stats, void* cand);
 int mm_fused_sample(mm_stream_t stream, const float* thr, const void* stats, const void* cand, int R, int V, int k_keep, const int32_t* rows,
                     float temperature, int noise_kind, const float* noise, int64_t noise_ld, uint64_t seed, uint64_t row_offset, uint32_t step,
-                    int64_t* ids, float* scores, int64_t* pred_out, float* score_out, int32_t* fail_flag);
+                    int64_t* ids, float* scores, int64_t* pred_out, float* score_out, int32_t* fail_flag, int32_t* fail_rows, int32_t* fail_count,
+                    int fail_cap);
 
 /* Training-forward losses of Transformer.forward (mmp.py:337-348), forward only:
  *   mm_ce_loss : F.cross_entropy over the vocabulary with ignore_index, mean over the non-ignored rows; logits fp32 [R][ld],
@@ -465,9 +468,11 @@ typedef struct mm_generate_params {
     int64_t* trace_masked_ids;
     int64_t* trace_ids;
     float* trace_scores;
-    /* device int32 [1], zeroed by the caller, or NULL (= no fused sampling).  Fused sampling bounds every row's k-th largest logit BEFORE the
-     * logits exist; the finishing kernel verifies the bound per row and sets *status = 1 when a row's candidates cannot be proven to contain
-     * its kept set (heavy-tailed logits).  The ids of that call are then invalid: repeat it with MM_GEN_NO_FUSED_SAMPLING. */
+    /* device int32 [2], zeroed by the caller, or NULL (= no fused sampling).  Fused sampling bounds every row's k-th largest logit BEFORE the
+     * logits exist; the finishing kernel verifies the bound per row.  A row it cannot be proven for (heavy-tailed logits) is finished on the
+     * logits path INSIDE the same step, on the device (its logits recomputed, sample_rows' kernel; the ids never depend on which path sampled a
+     * row); status[1] counts those rows.  Only when more than 128 rows fail in one step is status[0] set to 1: the ids of that call are then
+     * invalid, repeat it with MM_GEN_NO_FUSED_SAMPLING. */
     int32_t* status;
     /* ---- decode variants, all inside the same loop (zero / NULL = off).  cond_scale == 1 runs the single conditional pass (mmp.py:247-248); a
      * transformer created with self_cond feeds every step's cond-pass embed into the next step (mmp.py:325-328, 574).

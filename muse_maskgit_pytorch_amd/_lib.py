@@ -84,7 +84,7 @@ SIGNATURES = {
     'mm_fused_threshold': (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_f32, c_vp, c_vp, c_f32, c_vp, c_vp]),
     'mm_gemm_cfg_logits_fused': (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_f32, c_vp, c_vp, c_vp]),
     'mm_fused_emit': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
-    'mm_fused_sample': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_f32, c_int, c_vp, c_i64, c_u64, c_u64, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'mm_fused_sample': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_f32, c_int, c_vp, c_i64, c_u64, c_u64, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int]),
     'mm_ce_loss': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_i64, c_vp, c_vp]),
     'mm_bce_loss': (c_int, [c_vp, c_vp, c_vp, c_int, c_vp]),
     'mm_quantize_e4m3_rows': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp]),

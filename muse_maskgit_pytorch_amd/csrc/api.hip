@@ -117,15 +117,17 @@ int mm_fused_emit(mm_stream_t stream, const float* logits, int64_t ld, int R, in
 
 int mm_fused_sample(mm_stream_t stream, const float* thr, const void* stats, const void* cand, int R, int V, int k_keep, const int32_t* rows,
                     float temperature, int noise_kind, const float* noise, int64_t noise_ld, uint64_t seed, uint64_t row_offset, uint32_t step,
-                    int64_t* ids, float* scores, int64_t* pred_out, float* score_out, int32_t* fail_flag) {
+                    int64_t* ids, float* scores, int64_t* pred_out, float* score_out, int32_t* fail_flag, int32_t* fail_rows, int32_t* fail_count,
+                    int fail_cap) {
     if (R == 0) return MM_OK;
     CHK_PTR(thr, "thr"); CHK_PTR(stats, "stats"); CHK_PTR(cand, "cand"); CHK_PTR(fail_flag, "fail_flag");
+    if ((fail_rows == nullptr) != (fail_count == nullptr) || (fail_rows && fail_cap <= 0)) return mm_set_error(MM_ERR_SHAPE, "fused_sample: fail_rows / fail_count / fail_cap go together");
     FusedSampleArgs a;
     memset(&a, 0, sizeof(a));
     a.thr = thr; a.stats = (const float4*)stats; a.cand = (const float4*)cand;
     a.R = R; a.V = V; a.k_keep = k_keep; a.rows = rows; a.temperature = temperature; a.noise_kind = noise_kind; a.noise = noise; a.noise_ld = (long)noise_ld;
     a.seed = seed; a.row_offset = row_offset; a.step = step; a.ids = ids; a.scores = scores; a.pred_out = pred_out; a.score_out = score_out;
-    a.fail_flag = fail_flag;
+    a.fail_flag = fail_flag; a.fail_rows = fail_rows; a.fail_count = fail_count; a.fail_cap = fail_cap;
     return k_sample_fused((hipStream_t)stream, a);
 }
 

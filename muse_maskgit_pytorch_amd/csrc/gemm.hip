@@ -57,6 +57,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     xcd_grouped_tile(blockIdx.x, p.tiles_m, p.tiles_n, 16, tile_m, tile_n);
     const int n0 = tile_n * BT;
     const int m0 = tile_m * (MODE == MODE_CFG ? 64 : BT);   // CFG: 64 tokens x {cond, null} per tile
+    // device-side row count (the per-row fallback of the fused sampler: the number of rows to redo is only known on the device): tiles
+    // beyond it leave at once, so a launch sized for the capacity costs a launch and nothing else when no row failed
+    if (p.m_dev && m0 >= *p.m_dev) return;
 
     // ---- per-lane DMA geometry.  Wave w stages tile rows [32w, 32w+32) with 4 instructions of 8 rows each; within an
     //      instruction lane l lands on (row l>>3, physical chunk l&7), which must hold logical chunk (l&7) ^ (row & 7).
@@ -501,6 +504,7 @@ int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
             return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: fused sampling needs the 256-column guidance-logits kernel");
         return mm_gemm_cfg2_launch(a, stream);
     }
+    if (a.m_dev) a.debug |= 8;      // only the 128x128 kernel reads the device-side row count
     if (!(a.debug & (8 | 4096 | 8192)) && !a.ln_part && mm_gemm_cfg2_eligible(a)) return mm_gemm_cfg2_launch(a, stream);
     if (!(a.debug & (8 | 4096)) && mm_gemm_pers_eligible(a)) return mm_gemm_pers_launch(a, stream);
     if (!(a.debug & 8) && mm_gemm_big_eligible(a)) return mm_gemm_big_launch(a, stream);

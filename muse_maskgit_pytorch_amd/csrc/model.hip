@@ -507,6 +507,8 @@ namespace {
 #ifndef MM_FS_MARGIN
 #define MM_FS_MARGIN 0.20f
 #endif
+constexpr int FB_CAP = 128;      // rows per step the on-device fallback can finish (one row tile of the 128 x 128 GEMM); more raise the status flag
+constexpr int FB_STEPS = 1024;   // per-step counters carved (timesteps beyond this run without the list: flag only)
 constexpr float FS_MARGIN = MM_FS_MARGIN;    // the bound sits this many sigmas below the Gaussian quantile of the kept fraction: ~14 % instead of 10 % pass
 struct GenBufs {
     Bufs b;                 // 2B sequences
@@ -527,6 +529,12 @@ struct GenBufs {
     float4* fs_stats;       // [B*n][V/256]
     float4* fs_cand;        // [B*n][V/256][FS_SLOT]
     void* fs_ws;            // scratch of the bound estimate (k_fused_threshold)
+    // on-device per-row fallback of the fused sampler: rows whose bound could not be verified are listed by the finishing kernel and finished
+    // on the logits path inside the same step (their logits recomputed by a small dense GEMM, sampled by sample_kernel)
+    int32_t* fb_rows;       // [FB_CAP] rows listed this step
+    int32_t* fb_cnt;        // [timesteps <= FB_STEPS] one counter per step (zeroed at the start of the call)
+    bf16_t* fb_x;           // [FB_CAP][KD] their (mixed) embeddings
+    float* fb_logits;       // [FB_CAP][V]
     void* ctx_ws; size_t ctx_ws_bytes;
     // decode variants
     float* sce;             // [B*n][D] fp32: the previous step's cond-pass embed (self-conditioning transformers)
@@ -575,6 +583,10 @@ void carve_gen(Carver& c, const mm_transformer* t, int B, int n, int L, int nc, 
     g.fs_stats = c.take<float4>((size_t)B * n * NT);
     g.fs_cand = c.take<float4>((size_t)B * n * NT * FS_SLOT);
     g.fs_ws = c.take<unsigned char>(fs ? k_fused_threshold_ws_bytes(B * n, D) : 0);
+    g.fb_rows = c.take<int32_t>(fs ? FB_CAP : 0);
+    g.fb_cnt = c.take<int32_t>(fs ? FB_STEPS : 0);
+    g.fb_x = c.take<bf16_t>(fs ? (size_t)FB_CAP * D * seg : 0);
+    g.fb_logits = c.take<float>(fs ? (size_t)FB_CAP * t->d.dim_out : 0);
     g.ctx_ws_bytes = mm_context_workspace_bytes(t, B, L);
     g.ctx_ws = c.take<unsigned char>(g.ctx_ws_bytes);
     g.sce = c.take<float>(t->d.self_cond ? (size_t)B * n * D : 0);
@@ -722,6 +734,10 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
         }
     }
 
+    if (g.fb_cnt && p->status) {
+        const hipError_t e = hipMemsetAsync(g.fb_cnt, 0, (size_t)FB_STEPS * 4, s);
+        if (e != hipSuccess) return mm_set_hip_error(e, "generate: memset fallback counters");
+    }
     Bufs& b = g.b;
     const int seqs = P * B;          // sequences of one transformer pass over the batch: [cond B | null B]
     for (int step = 0; step < T; ++step) {
@@ -840,9 +856,33 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
             fa.noise = p->noise ? p->noise + (size_t)step * M * V : nullptr; fa.noise_ld = V;
             fa.seed = p->seed; fa.row_offset = p->row_offset * (uint64_t)n; fa.step = (uint32_t)step;
             fa.ids = ids_out; fa.scores = scores_out; fa.pred_out = pred_out; fa.score_out = conf_out; fa.fail_flag = p->status;
+            const bool row_fallback = step < FB_STEPS;
+            if (row_fallback) { fa.fail_rows = g.fb_rows; fa.fail_count = g.fb_cnt + step; fa.fail_cap = FB_CAP; }
             if (prof::enabled) pr = prof::begin(s, 4.0 * (double)R * (double)V);      // logits-equivalent bytes (what a logits-reading sampler reads)
             RC(k_sample_fused(s, fa));                                                                  // mmp.py:576-609
             if (prof::enabled) prof::end(s, 1, pr);
+            if (row_fallback) {
+                // Rows whose candidate bound could not be verified (heavy-tailed logits) are finished HERE, on the logits path: gather their
+                // embeddings, recompute their logits with the 128 x 128 dense kernel (same MFMA order as the persistent kernel: the same
+                // values), sample them with sample_kernel (same per-tile softmax statistics: the same confidences).  The row count lives on
+                // the device; with no failed row the three launches exit at once.  Only more than FB_CAP rows in one step raise *status.
+                RC(k_gather_rows16_counted(s, emb_in, (long)KD * 2, g.fb_rows, g.fb_cnt + step, FB_CAP, KD * 2, g.fb_x, p->status + 1));
+                GemmArgs fg;
+                memset(&fg, 0, sizeof(fg));
+                fg.mode = MODE_DENSE;
+                fg.W = (const bf16_t*)t->d.to_logits; fg.N = V; fg.ldw = KD; fg.K = KD; fg.M = FB_CAP; fg.X = g.fb_x; fg.ldx = KD;
+                fg.out = g.fb_logits; fg.ldc = V; fg.out_kind = OUT_F32; fg.m_dev = g.fb_cnt + step;
+                RC(mm_gemm_launch(fg, s));
+                SampleArgs fs_;
+                memset(&fs_, 0, sizeof(fs_));
+                fs_.logits = g.fb_logits; fs_.ld = V; fs_.R = FB_CAP; fs_.V = V; fs_.k_keep = p->k_keep; fs_.rows = rows;
+                fs_.temperature = p->temperatures[step]; fs_.noise_kind = p->noise_kind;
+                fs_.noise = p->noise ? p->noise + (size_t)step * M * V : nullptr; fs_.noise_ld = V;
+                fs_.seed = p->seed; fs_.row_offset = p->row_offset * (uint64_t)n; fs_.step = (uint32_t)step;
+                fs_.ids = ids_out; fs_.scores = scores_out; fs_.pred_out = pred_out; fs_.score_out = conf_out;
+                fs_.src_rows = g.fb_rows; fs_.count_dev = g.fb_cnt + step;
+                RC(k_sample_rows(s, fs_));
+            }
         } else {
             {
                 prof::Rec pr;
@@ -876,13 +916,10 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
                 } else {
                     RC(mm_transformer_forward(critic, stream, p->ids, B, n, cb.ctx, cb.masks + (size_t)B * m, m, nullptr, cb.embn, nullptr, cb.fwd_ws,
                                               cb.fwd_ws_bytes));
-                    GemmArgs ca;
-                    memset(&ca, 0, sizeof(ca));
-                    ca.mode = MODE_CFG;
-                    ca.W = (const bf16_t*)critic->d.to_logits; ca.N = 1; ca.ldw = Dc; ca.K = Dc;
-                    ca.M = M; ca.X = cb.embc; ca.X2 = cb.embn; ca.ldx = Dc;
-                    ca.out = cb.sc; ca.ldc = 1; ca.out_kind = OUT_F32; ca.cfg_scale = p->cond_scale;
-                    RC(mm_gemm_launch(ca, s));
+                    // guidance in the embedding, like the generator's logits (and like TokenCritic.forward_with_cond_scale on the general path):
+                    // mix the two passes' embeddings (in place over the null pass's), then the 1-wide head once
+                    RC(k_cfg_mix(s, cb.embc, cb.embn, Dc, M, critic->d.dim, critic->P, p->cond_scale, cb.embn));
+                    RC(gemm_dense(s, cb.embn, Dc, (const bf16_t*)critic->d.to_logits, Dc, M, 1, Dc, cb.sc, 1, OUT_F32, nullptr));
                 }
             } else {             // SelfCritic (mmp.py:352-374): Linear(dim, 1) on the generator's cond-pass embed of the new ids (no self-conditioning input)
                 RC(mm_transformer_forward(t, stream, p->ids, B, n, cb.ctx, cb.masks, m, nullptr, cb.embc, nullptr, cb.fwd_ws, cb.fwd_ws_bytes));

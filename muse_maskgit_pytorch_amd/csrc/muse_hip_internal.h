@@ -39,6 +39,7 @@ struct GemmArgs {
     // fused sampling (MODE_CFG on gemm_cfg.hip only): when fs_stats != NULL the logits are NOT written; every 256-column piece of a row emits its
     // statistics and its candidates >= fs_thr[row] instead (common.h fused_emit_piece)
     const float* fs_thr; float4* fs_stats; float4* fs_cand;
+    const int* m_dev;             // optional device-side row count (<= M): row tiles at or beyond it exit immediately (128x128 kernel only)
     int wide_tok;                 // MODE_DENSE, fp32 out: request the persistent 128-token x 256-column kernel of gemm_cfg.hip (WIDE_MIX: the guidance logits of
                                   // the MIXED embedding as one pass; takes fs_* like MODE_CFG); falls back to the other kernels when not eligible
     int debug;                    // ablation bits (mm_debug_set): 1 = no epilogue stores, 2 = no DMA after tile 0, 4 = no MFMA, 8 = force the 128x128 kernel, 4096 = no persistent kernel
@@ -70,6 +71,8 @@ int k_geglu_ln(hipStream_t s, const bf16_t* h, long ldh, int rows, int F, int Fp
 int k_layernorm_addvec(hipStream_t s, float* x, long ldx, int rows, int D, const float* gamma, const float* beta, const float* addvec,
                        int add_from, bf16_t* out, long ldo);
 int k_gather_rows16(hipStream_t s, const void* src, long src_pitch_bytes, const int32_t* rows, int R, int row_add, int row_bytes, void* dst);
+int k_gather_rows16_counted(hipStream_t s, const void* src, long src_pitch_bytes, const int32_t* rows, const int32_t* count, int cap, int row_bytes, void* dst,
+                            int32_t* total);
 int k_ln_bf16(hipStream_t s, const bf16_t* a, long lda, int rows, int F, int Fp, const float* gamma, const float* beta,
               bf16_t* out, long ldo);
 int k_f32_to_bf16(hipStream_t s, const float* x, bf16_t* out, long count);
@@ -160,6 +163,9 @@ struct SampleArgs {
     int64_t* pred_out; float* score_out;         // optional compact outputs [R]
     int debug;                                   // ablation bits 16 / 32 / 64 / 128 (tools/sample_bench.py)
     float z_lo;                                  // histogram lower bound in sigmas above the row mean (set by k_sample_rows)
+    // per-row fallback of the fused sampler: logits row i belongs to original row src_rows[i] (whose position / compact output slot / noise
+    // stream it samples for), and only the first min(R, *count_dev) rows exist
+    const int32_t* src_rows; const int32_t* count_dev;
 };
 int k_sample_rows(hipStream_t s, const SampleArgs& a);
 // sampling_fused.hip: sampling from what the guidance-logits GEMM emits instead of the logits (tile statistics + candidates)
@@ -173,6 +179,10 @@ struct FusedSampleArgs {
     uint64_t seed; uint64_t row_offset; uint32_t step;
     int64_t* ids; float* scores; int64_t* pred_out; float* score_out;
     int* fail_flag;                              // set to 1 when a row's candidate set cannot be proven complete (caller falls back to the logits path)
+    // optional on-device fallback list: a failing row is appended to fail_rows[atomicAdd(fail_count, 1)] (capacity fail_cap) instead of raising the
+    // flag; the flag is raised only when the list overflows.  The caller finishes the listed rows on the logits path (model.hip).
+    int32_t* fail_rows; int32_t* fail_count; int fail_cap;
+    int debug;                                   // set by k_sample_fused from mm_debug_set (bit 1 << 27: test hook of the fallback)
 };
 float k_fused_z(int k_keep, int V, float margin);
 // thr[r] = mean_r + z sigma_r of row r's logits over the vocabulary; ws: k_fused_threshold_ws_bytes(R, D) bytes of scratch; wcov bf16 [D][D]

@@ -161,6 +161,20 @@ __global__ __launch_bounds__(256) void gather_rows16_kernel(const unsigned char*
     }
 }
 
+// the same gather for a row list whose length lives on the device (the fused sampler's fallback list): dst[i] = src[rows[i]] for i < min(*count, cap);
+// thread 0 adds that number to *total (telemetry) when given
+__global__ __launch_bounds__(256) void gather_rows16_counted_kernel(const unsigned char* __restrict__ src, long src_pitch, const int32_t* __restrict__ rows,
+                                                                    const int32_t* __restrict__ count, int cap, int chunks, unsigned char* __restrict__ dst,
+                                                                    int32_t* total) {
+    const int n = min(*count, cap);
+    if (total && n > 0 && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(total, n);
+    const long items = (long)n * chunks;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < items; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / chunks), c = (int)(i - (long)r * chunks);
+        *reinterpret_cast<uint4*>(dst + ((long)r * chunks + c) * 16) = *reinterpret_cast<const uint4*>(src + (long)rows[r] * src_pitch + (long)c * 16);
+    }
+}
+
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, long count) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
         out[i] = f32_to_bf16(x[i]);
@@ -240,6 +254,15 @@ int k_gather_rows16(hipStream_t s, const void* src, long src_pitch_bytes, const 
     hipLaunchKernelGGL(gather_rows16_kernel, dim3(grid_for((long)R * (row_bytes / 16))), dim3(256), 0, s, (const unsigned char*)src,
                        src_pitch_bytes, rows, R, row_add, row_bytes / 16, (unsigned char*)dst);
     return mm_check_launch("gather_rows16_kernel");
+}
+
+int k_gather_rows16_counted(hipStream_t s, const void* src, long src_pitch_bytes, const int32_t* rows, const int32_t* count, int cap, int row_bytes, void* dst,
+                            int32_t* total) {
+    if (cap <= 0) return MM_OK;
+    if ((row_bytes % 16) || (src_pitch_bytes % 16)) return mm_set_error(MM_ERR_ALIGN, "gather_rows: rows must be multiples of 16 bytes");
+    hipLaunchKernelGGL(gather_rows16_counted_kernel, dim3(grid_for((long)cap * (row_bytes / 16))), dim3(256), 0, s, (const unsigned char*)src, src_pitch_bytes,
+                       rows, count, cap, row_bytes / 16, (unsigned char*)dst, total);
+    return mm_check_launch("gather_rows16_counted_kernel");
 }
 
 // per-row symmetric quantisation to OCP fp8 e4m3: scale = max|w| / 448, wq = rne(w / scale); columns K..Kp-1 are zero

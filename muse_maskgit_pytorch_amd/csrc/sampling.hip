@@ -202,7 +202,8 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int V = p.V;
     int row = blockIdx.x;                 // persistent: this workgroup samples rows blockIdx.x, + gridDim.x, ...
-    if (row >= p.R) return;
+    const int Rn = p.count_dev ? min(p.R, *p.count_dev) : p.R;      // (fallback launches: the row count lives on the device)
+    if (row >= Rn) return;
 
     // ---- the one HBM read of a row: element index e = (it*ST + tid)*4 + c.  Padding (e >= V) is -inf: neutral for the max and for
     //      exp(); min / histogram / list passes skip it by index.
@@ -227,7 +228,8 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
     int tidv = tid;                       // per-row copy the compiler cannot hoist: the 128 element indices derived from it would otherwise
     asm volatile("" : "+v"(tidv));      // be kept in registers across rows (loop-invariant) and spill
     const float* lr = p.logits + (size_t)row * p.ld;
-    const long pos_flat = p.rows ? (long)p.rows[row] : (long)row;
+    const int orow = p.src_rows ? p.src_rows[row] : row;      // the row this logits row was computed for
+    const long pos_flat = p.rows ? (long)p.rows[orow] : (long)orow;
 
     // ---- A: row max / min / mean / variance
     float vmax = -INFINITY, vmin = INFINITY, s1 = 0.f, s2 = 0.f;
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
     // ---- the row's values are dead from here on (everything below works on the LDS lists): start the NEXT row's HBM read now, it
     //      lands in the same registers while the exact select and the Gumbel phase (~40 % of a row's time) run
     const int nrow = row + (int)gridDim.x;
-    const bool has_next = nrow < p.R;
+    const bool has_next = nrow < Rn;
     // (issued in instalments -- 8 loads here, 3 per trip of the Gumbel loop below: a wave that issues all 32 at once sits in the
     //  issue queue for about as long as the load takes, measured 13 k cycles of a 75 k-cycle row)
     const __amdgpu_buffer_rsrc_t nrs = ROW_RSRC(has_next ? nrow : row);
@@ -463,8 +465,8 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
         const float score = 1.f - prob;
         if (p.ids) p.ids[pos_flat] = (int64_t)best_i;
         if (p.scores) p.scores[pos_flat] = score;
-        if (p.pred_out) p.pred_out[row] = (int64_t)best_i;
-        if (p.score_out) p.score_out[row] = score;
+        if (p.pred_out) p.pred_out[orow] = (int64_t)best_i;
+        if (p.score_out) p.score_out[orow] = score;
     }
     if (!has_next) break;
     row = nrow;

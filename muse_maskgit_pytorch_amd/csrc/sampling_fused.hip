@@ -201,9 +201,16 @@ __global__ __launch_bounds__(FT, 2) void sample_fused_kernel(const FusedSampleAr
 #pragma unroll
         for (int w2 = 0; w2 < FW; ++w2) { total += S.wcnt[w2]; fits = fits && S.wcnt[w2] <= WSL; }
         // the candidate set holds the kept set iff >= k values passed the lower bound and every wave's slice held its share
-        const bool ok = total >= p.k_keep && fits;
+        // (debug bit 1 << 27, tests only: every 97th row is declared unverifiable, so the on-device fallback runs on Gaussian logits too)
+        const bool ok = total >= p.k_keep && fits && !((p.debug & (1 << 27)) && row % 97 == 5);
         if (!ok) {
-            if (tid == 0) { atomicExch(p.fail_flag, 1); if (p.ids) p.ids[pos_flat] = 0; if (p.scores) p.scores[pos_flat] = 0.f; }
+            if (tid == 0) {
+                // the bound could not be verified for this row: hand it to the on-device fallback (its logits are recomputed and sampled by
+                // sample_kernel inside the same generate, model.hip); only a full list -- or a caller without one -- raises the flag
+                int slot = -1;
+                if (p.fail_rows) { slot = atomicAdd(p.fail_count, 1); if (slot < p.fail_cap) p.fail_rows[slot] = row; }
+                if (!p.fail_rows || slot >= p.fail_cap) { atomicExch(p.fail_flag, 1); if (p.ids) p.ids[pos_flat] = 0; if (p.scores) p.scores[pos_flat] = 0.f; }
+            }
             __syncthreads();
             continue;
         }
@@ -375,7 +382,9 @@ int k_fused_emit(hipStream_t s, const float* logits, long ld, int R, int V, cons
     return mm_check_launch("fused_emit_kernel");
 }
 
-int k_sample_fused(hipStream_t s, const FusedSampleArgs& a) {
+int k_sample_fused(hipStream_t s, const FusedSampleArgs& a_in) {
+    FusedSampleArgs a = a_in;
+    a.debug = g_mm_debug;
     if (a.R <= 0) return MM_OK;
     if (a.V <= 0 || (a.V % 256) || a.V > 65536) return mm_set_error(MM_ERR_SHAPE, "sample_fused: V must be a multiple of 256 and <= 65536");
     if (a.k_keep < 1 || a.k_keep > a.V) return mm_set_error(MM_ERR_SHAPE, "sample_fused: k_keep out of range");

@@ -730,7 +730,8 @@ class MaskGit(nn.Module):
         self.self_cond_prob = self_cond_prob
         self.no_mask_token_prob = no_mask_token_prob
         self._gen_ws = None
-        self.fused_sampling_fallbacks = 0      # generate() calls repeated on the logits path because a row's candidate bound could not be verified
+        self.fused_sampling_fallbacks = 0      # generate() calls repeated on the logits path (more than 128 rows of one step failed the candidate bound)
+        self.fused_row_fallbacks = 0           # rows whose bound could not be verified and that the on-device per-row fallback finished
 
     def save(self, path):
         torch.save(self.state_dict(), path)
@@ -884,14 +885,17 @@ class MaskGit(nn.Module):
         deferred = fused_sampling == 'deferred'
         status = None
         if fused_sampling and (deferred or not capturing):
-            status = torch.zeros(1, dtype=torch.int32, device=dev)
+            status = torch.zeros(2, dtype=torch.int32, device=dev)      # [0] list overflow (repeat on the logits path), [1] rows finished by the on-device fallback
             p.status = L.ptr(status)
         else:
             p.flags |= L.MM_GEN_NO_FUSED_SAMPLING
         L.check(L.lib().mm_generate(h.ptr, L.stream(), C.byref(p), L.ptr(self._gen_ws), self._gen_ws.numel()), 'mm_generate')
         if deferred:
             self.fused_status = status
-        elif status is not None and int(status.item()) != 0:
+        elif status is not None:
+            st = status.tolist()
+            self.fused_row_fallbacks += st[1]
+        if not deferred and status is not None and st[0] != 0:
             self.fused_sampling_fallbacks += 1
             p.flags, p.status = p.flags | L.MM_GEN_NO_FUSED_SAMPLING, None
             L.check(L.lib().mm_generate(h.ptr, L.stream(), C.byref(p), L.ptr(self._gen_ws), self._gen_ws.numel()), 'mm_generate')

@@ -609,14 +609,16 @@ def fused_emit(logits, thr, fb):
     L.check(L.lib().mm_fused_emit(L.stream(), L.ptr(logits), logits.stride(0), R, V, L.ptr(thr), L.ptr(fb['stats']), L.ptr(fb['cand'])), 'mm_fused_emit')
 
 
-def fused_sample(fb, thr, R, V, k_keep, temperature, rows=None, noise_kind=L.MM_NOISE_NONE, noise=None, seed=0, row_offset=0, step=0):
-    """-> (pred int64 [R], score fp32 [R]); fb['fail'] is set to 1 if a row's candidates could not be proven complete"""
+def fused_sample(fb, thr, R, V, k_keep, temperature, rows=None, noise_kind=L.MM_NOISE_NONE, noise=None, seed=0, row_offset=0, step=0, fail_list=None):
+    """-> (pred int64 [R], score fp32 [R]); fb['fail'] is set to 1 if a row's candidates could not be proven complete -- or, with
+    fail_list = (rows int32 [cap], count int32 [1]), such rows are appended to the list instead (entries of pred / score undefined for them)"""
     dev = fb['stats'].device
     pred = torch.empty(R, dtype=torch.long, device=dev)
     score = torch.empty(R, dtype=torch.float32, device=dev)
+    fr, fc = fail_list if fail_list is not None else (None, None)
     L.check(L.lib().mm_fused_sample(L.stream(), L.ptr(thr), L.ptr(fb['stats']), L.ptr(fb['cand']), R, V, int(k_keep), L.ptr(rows), float(temperature),
                                     int(noise_kind), L.ptr(noise), noise.stride(0) if noise is not None else 0, int(seed), int(row_offset), int(step), None, None,
-                                    L.ptr(pred), L.ptr(score), L.ptr(fb['fail'])), 'mm_fused_sample')
+                                    L.ptr(pred), L.ptr(score), L.ptr(fb['fail']), L.ptr(fr), L.ptr(fc), fr.numel() if fr is not None else 0), 'mm_fused_sample')
     return pred, score
 
 

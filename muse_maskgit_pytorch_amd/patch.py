@@ -129,6 +129,7 @@ def _maskgit_shadow(ref):
         setattr(sh, k, getattr(ref, k))
     sh._gen_ws = None
     sh.fused_sampling_fallbacks = 0
+    sh.fused_row_fallbacks = 0
     ref.__dict__[_SHADOW] = sh
     return sh
 

@@ -204,4 +204,71 @@ def test_fused_sampling_inside_a_hip_graph_with_the_deferred_status_flag():
         captured.fill_(-1)
         graph.replay()
         torch.cuda.synchronize()
-        assert int(mg.fused_status.item()) == 0 and torch.equal(captured, eager)
+        assert int(mg.fused_status[0].item()) == 0 and torch.equal(captured, eager)
+
+
+@pytest.mark.parametrize('family', ['zipf_bias', 'hot_tokens', 'row_temperature', 'student_t', 'bimodal'])
+def test_non_gaussian_logits_are_finished_row_by_row(family):
+    """Trained checkpoints do not have Gaussian logits.  Families that defeat the Gaussian bound for SOME rows: the finishing kernel must list
+    exactly the rows it cannot prove, the listed rows finished on the logits path must complete a result that equals sample_rows on every row
+    (ids and confidences), and nothing else may be wrong.  The fraction of rows that needed the fallback is reported per family."""
+    g = torch.Generator().manual_seed(hash(family) % 1000)
+    R, V = 96, 65536
+    base = torch.randn(R, V, generator=g)
+    if family == 'zipf_bias':          # every row has its own popularity ranking: a log-rank bias, long left tail, a few dominant tokens
+        ranks = torch.stack([torch.randperm(V, generator=g) for _ in range(R)]).float()
+        logits = base - 1.2 * torch.log1p(ranks) * torch.linspace(0.2, 1.5, R)[:, None]
+    elif family == 'hot_tokens':       # 8 hot tokens per row, 12 sigma above the rest
+        logits = base.clone()
+        idx = torch.stack([torch.randperm(V, generator=g)[:8] for _ in range(R)])
+        logits.scatter_add_(1, idx, torch.full((R, 8), 12.))
+    elif family == 'row_temperature':  # per-row temperature 0.3 .. 3 (still bell-shaped: the bound must hold everywhere)
+        logits = base * torch.logspace(-0.52, 0.48, R)[:, None]
+    elif family == 'student_t':        # heavy tails on both sides (t, 3 degrees of freedom)
+        logits = base / torch.sqrt(torch.distributions.Chi2(3.).sample((R, V)) / 3.)
+    else:                              # two populations: 5 % of the vocabulary shifted up by 4 sigma in half the rows
+        logits = base.clone()
+        logits[::2, : V // 20] += 4.
+    logits = logits.contiguous().to(DEV)
+    k_keep = math.ceil(0.1 * V)
+    kw = dict(noise_kind=_lib.MM_NOISE_PHILOX, seed=99, row_offset=3, step=2)
+    ref_pred, ref_score = ops.sample_rows(logits, k_keep, 1.0, **kw)
+    fb = ops.fused_buffers(R, V, DEV)
+    thr = (logits.mean(dim=1) + ops.fused_z(k_keep, V) * logits.std(dim=1)).contiguous()
+    ops.fused_emit(logits, thr, fb)
+    fail_rows, fail_count = torch.full((128,), -1, dtype=torch.int32, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+    pred, score = ops.fused_sample(fb, thr, R, V, k_keep, 1.0, fail_list=(fail_rows, fail_count), **kw)
+    nf = int(fail_count.item())
+    assert int(fb['fail'].item()) == 0 and nf <= 128
+    failed = fail_rows[:nf].long().sort().values
+    # exactly the rows with fewer than k values above their bound are listed
+    short = ((logits >= thr[:, None]).sum(dim=1) < k_keep).nonzero().flatten()
+    assert torch.equal(failed, short), f'{family}: listed {failed.tolist()} but rows short of candidates are {short.tolist()}'
+    if nf:
+        p2, s2 = ops.sample_rows(logits[failed].contiguous(), k_keep, 1.0, rows=failed.to(torch.int32), **kw)      # rows: the positions that key the noise stream
+        pred[failed], score[failed] = p2, s2
+    print(f'[fused sampling] {family}: {nf} of {R} rows ({100 * nf / R:.0f} %) needed the per-row fallback')
+    assert torch.equal(pred, ref_pred) and torch.equal(score, ref_score)
+    if family == 'row_temperature':
+        assert nf == 0
+
+
+def test_generate_finishes_unverifiable_rows_on_the_device():
+    """mm_generate with the test hook that declares every 97th row unverifiable: those rows take the on-device fallback (gather -> 128 x 128 dense
+    GEMM with a device-side row count -> sample_kernel) and the ids, the per-step states and the confidences equal the run without the hook bit
+    for bit; the counter reports the rows, no whole-call fallback happens."""
+    import bench
+    mg, _ = bench.build_models(DEV)
+    te = bench.synth_text(32, 32, 512).to(DEV)
+    ta, tb = {}, {}
+    a = mg.generate([''] * 32, timesteps=8, cond_scale=3, text_embeds=te, seed=11, return_ids=True, trace=ta)
+    assert mg.fused_row_fallbacks == 0 and mg.fused_sampling_fallbacks == 0
+    _lib.lib().mm_debug_set(1 << 27)
+    try:
+        b = mg.generate([''] * 32, timesteps=8, cond_scale=3, text_embeds=te, seed=11, return_ids=True, trace=tb)
+    finally:
+        _lib.lib().mm_debug_set(0)
+    counts = mg._mask_counts(8, 256)
+    expect = sum(len(range(5, 32 * k, 97)) for k in counts)
+    assert mg.fused_sampling_fallbacks == 0 and mg.fused_row_fallbacks == expect, (mg.fused_row_fallbacks, expect)
+    assert torch.equal(a, b) and torch.equal(ta['ids'], tb['ids']) and torch.equal(ta['scores'], tb['scores'])
