@@ -754,7 +754,11 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
         else RC(k_embed(s, p->ids, M, n, 0, (const bf16_t*)t->d.token_emb, t->d.vocab_rows, (const bf16_t*)t->d.pos_emb, D, b.x));
         if (self_cond && step > 0)                      // x += self_cond_to_init_embed(previous cond embed), mmp.py:325-328 (FF(zeros) = 0 at step 0)
             RC(ff_block(t, s, t->d.self_cond_ff, g.sce, b.x, M, b));
-        if (P == 2) {
+        // Both guidance halves start from the same ids, so their residual streams are identical until the first cross-attention: layer 0's
+        // self-attention runs on the cond half only and the stream is duplicated behind it (below) instead of in front of it.
+        const bool compact_last0 = p->mask_counts[step] < n && !(g_mm_debug & 16384) && !self_cond && !can_remask;
+        const bool share0 = P == 2 && !(t->d.depth == 1 && compact_last0);
+        if (P == 2 && !share0) {
             const hipError_t e = hipMemcpyAsync(b.x + (size_t)M * D, b.x, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s);
             if (e != hipSuccess) return mm_set_hip_error(e, "generate: x copy");
         }
@@ -779,6 +783,10 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
                 }
                 RC(gemm_dense(s, g.attc, KI, (const bf16_t*)w.self_attn.w_out, KI, P * R, D, KI, g.xc, D, OUT_F32, g.xc));
                 bc.x = g.xc; bc.att = g.attc;
+            } else if (l == 0 && share0) {
+                RC(self_attn_block(t, s, w.self_attn, B, n, b));
+                const hipError_t e = hipMemcpyAsync(b.x + (size_t)M * D, b.x, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s);
+                if (e != hipSuccess) return mm_set_hip_error(e, "generate: x copy");
             } else {
                 RC(self_attn_block(t, s, w.self_attn, seqs, n, b));
             }
