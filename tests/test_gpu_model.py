@@ -67,12 +67,22 @@ def test_transformer_forward_vs_reference_and_oracle(golden):
 
 
 def test_forward_with_cond_scale_is_the_fused_cfg_gemm(golden):
+    """since round 3 the guidance combine (mmp.py:254) is applied to the two passes' final embeddings and to_logits runs once (it is linear,
+    mmp.py:332): forward_with_cond_scale equals to_logits(mix) bit for bit, and the two-pass combination null + (cond - null) * s of separately
+    multiplied logits to the bf16 rounding of the mixed operand"""
+    from muse_maskgit_pytorch_amd import ops
     g, t = _tiny_transformer(golden)
     ids, te = g['ids'].to(DEV), g['text_embeds'].to(DEV)
     scaled, embed = t.forward_with_cond_scale(ids, text_embeds=te, cond_scale=3., return_embed=True)
     cond = t(ids, text_embeds=te)
     null = t(ids, text_embeds=te, cond_drop_prob=1.)
-    assert torch.equal(scaled, null + (cond - null) * 3.)          # mmp.py:254, same fp32 arithmetic
+    ec = t(ids, text_embeds=te, _embed_only=True)
+    en = t(ids, text_embeds=te, cond_drop_prob=1., _embed_only=True)
+    mix = ops.cfg_mix(ec, en, 3., t.dim)
+    assert torch.equal(mix.float(), (en.float() + (ec.float() - en.float()) * 3.).bfloat16().float())
+    assert torch.equal(scaled.reshape(-1, scaled.shape[-1]), ops.gemm(mix, t._model().packed['wl'], out_f32=True))
+    two_pass = null + (cond - null) * 3.                             # mmp.py:254 on separately multiplied logits
+    assert (scaled - two_pass).abs().max().item() < 0.02 * two_pass.abs().max().item()
     e = _report('scaled logits vs reference golden', scaled, g['logits_scaled'])
     assert e.max() < 0.1 * g['logits_scaled'].abs().max()
     assert torch.equal(t.forward_with_cond_scale(ids, text_embeds=te, cond_scale=1.), cond)
