@@ -703,7 +703,7 @@ def test_ff_inner_layernorm_fold_matches_the_unfolded_path(golden):
 def test_full_size_c2_properties():
     """BASELINE configs[1] at FULL size (dim 512, depth 8, seq_len 256, codebook 65536; B = 8 to keep the fp32 oracle out of it):
     size-independent properties instead of an oracle comparison --
-      * guidance linearity: forward_with_cond_scale(s) = null + (cond - null) * s; s = 1 is the conditional pass, s = 0 the null pass;
+      * guidance linearity: forward_with_cond_scale(s) = null + (cond - null) * s (to bf16 operand rounding); s = 1 is the conditional pass, s = 0 the null pass;
       * batch invariance: a sample's logits do not depend on its batch mates;
       * the decode loop: every step masks exactly the scheduled count per sample, final ids are < codebook size and carry no mask id,
         the same seed reproduces the ids, and a sharded run (row_offset) reproduces the unsharded one;
@@ -722,7 +722,8 @@ def test_full_size_c2_properties():
     null = tr(ids, text_embeds=te, cond_drop_prob=1.)
     s3 = tr.forward_with_cond_scale(ids, text_embeds=te, cond_scale=3.)
     ref3 = null + (cond - null) * 3.
-    assert (s3 - ref3).abs().max() <= 2e-5 * ref3.abs().max() + 1e-5
+    # (round 3: the combine is applied to the two embeddings and to_logits runs once -- the same quantity up to the bf16 rounding of the mixed operand)
+    assert (s3 - ref3).abs().max() <= 2e-2 * ref3.abs().max()
     assert torch.equal(tr.forward_with_cond_scale(ids, text_embeds=te, cond_scale=1.), cond)
     s0 = tr.forward_with_cond_scale(ids, text_embeds=te, cond_scale=0.)
     assert (s0 - null).abs().max() <= 1e-5 * null.abs().max() + 1e-6
