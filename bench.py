@@ -399,10 +399,15 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     lib.mm_profile_enable(0)
+    rank_times = None
     if dist is not None:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = tmax.item()
+        # value uses the MAX over ranks; the per-rank spread and the number of ranks RCCL actually connected go into the line so that a
+        # driver-run scaling point is self-checking
+        mine = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_times = [t.item() for t in every]
+        elapsed = max(rank_times)
     assert torch.isfinite(images).all() and images.shape == (B, 3, image_size, image_size)
 
     import ctypes as C
@@ -481,6 +486,9 @@ def main():
                              'traffic': traffic_of('sample_fused_kernel' if fused_on else 'sample_kernel') if metric_cfg else None,
                              'algorithmic_bytes_per_launch': s_bytes / s_cnt if s_cnt else None,
                              'launches': s_cnt, 'avg_launch_ms': s_ms / s_cnt if s_cnt else None},
+            'multi_gpu': ({'ranks_in_process_group': dist.get_world_size(), 'backend': dist.get_backend(), 'ids_gather': 'mm_allgather_ids (library-owned RCCL communicator)',
+                           'devices_visible_to_rank0': torch.cuda.device_count(), 'per_rank_elapsed_s': {'min': min(rank_times), 'max': max(rank_times)},
+                           'per_rank_images_per_s': [B * args.steps / t_ for t_ in rank_times]} if dist is not None else None),
             'fused_sampling': {'enabled': fused_on, 'fallbacks_to_logits_path': mg.fused_sampling_fallbacks, 'rows_finished_by_on_device_fallback': mg.fused_row_fallbacks},
         }
         if world == 1 and not args.no_parity_tier and not args.tiny:

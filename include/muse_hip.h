@@ -495,6 +495,21 @@ size_t mm_generate_critic_workspace_bytes(const mm_transformer_t* critic, int B,
 int mm_generate(const mm_transformer_t* model, mm_stream_t stream, const mm_generate_params* params,
                 void* workspace, size_t workspace_bytes);
 
+/* ------------------------------------------------------------------------------------------------ multi-GPU: the one collective of the path
+ * Inference shards by sample (one process per GPU); mm_generate needs no communication (every reduction of MaskGit.generate is per sample,
+ * mmp.py:561,576,580,603).  What remains is ONE all-gather of the generated token grids: ids int64 [count] per rank (all < codebook size) travel as
+ * int32 over RCCL (xGMI) on the caller's stream and arrive as int64 [world * count] in rank order.  RCCL is resolved at run time (the RCCL already
+ * loaded in the process, else librccl.so): MM_ERR_UNSUPPORTED when there is none.  Bootstrap like ncclCommInitRank: rank 0 calls
+ * mm_comm_unique_id (128 bytes), shares them by any host channel, every rank calls mm_comm_create on its own device. */
+typedef struct mm_comm mm_comm_t;
+int mm_comm_unique_id(void* id_out_128_bytes);
+int mm_comm_create(const void* unique_id_128_bytes, int rank, int world, mm_comm_t** out);
+void mm_comm_destroy(mm_comm_t* comm);
+int mm_comm_world(const mm_comm_t* comm);
+int mm_comm_rank(const mm_comm_t* comm);
+size_t mm_allgather_ids_workspace_bytes(const mm_comm_t* comm, int64_t count);
+int mm_allgather_ids(mm_comm_t* comm, mm_stream_t stream, const int64_t* ids, int64_t count, int64_t* out, void* workspace, size_t workspace_bytes);
+
 /* ---- in-library kernel timing (bench.py's roofline leg).  When enabled, mm_generate brackets its two dominant
  * kernels with HIP events on the launch stream: slot 0 = the CFG to_logits GEMM (MFMA-bound), slot 1 = sample_rows
  * (HBM-bound).  mm_profile_read synchronises those events and returns, per slot, the launch count, the summed

@@ -146,6 +146,13 @@ SIGNATURES = {
     'mm_generate_critic_workspace_bytes': (c_sz, [c_vp, c_int, c_int, c_int, c_int]),
     'mm_generate_workspace_bytes': (c_sz, [c_vp, c_int, c_int, c_int, c_int]),
     'mm_generate': (c_int, [c_vp, c_vp, C.POINTER(GenerateParams), c_vp, c_sz]),
+    'mm_comm_unique_id': (c_int, [c_vp]),
+    'mm_comm_create': (c_int, [c_vp, c_int, c_int, C.POINTER(c_vp)]),
+    'mm_comm_destroy': (None, [c_vp]),
+    'mm_comm_world': (c_int, [c_vp]),
+    'mm_comm_rank': (c_int, [c_vp]),
+    'mm_allgather_ids_workspace_bytes': (c_sz, [c_vp, c_i64]),
+    'mm_allgather_ids': (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_sz]),
     'mm_debug_set': (c_int, [c_int]),
     'mm_debug_trace': (c_int, [c_vp, c_int]),
     'mm_debug_trace_count': (c_int, []),

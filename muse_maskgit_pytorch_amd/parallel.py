@@ -12,10 +12,58 @@ def shard_bounds(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+class IdsGather:
+    """The path's one collective through the C ABI (include/muse_hip.h mm_comm_* / mm_allgather_ids): an RCCL communicator of the library's own,
+    one rank per GPU, bootstrapped like ncclCommInitRank -- rank 0's 128-byte unique id is shared through the torch.distributed group that
+    already exists for the rendezvous -- and one ncclAllGather of int32 ids on the current stream per call (no host synchronisation)."""
+
+    def __init__(self, dist, group=None):
+        import ctypes as C
+        from . import _lib as L
+        self.L, self.C = L, C
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        uid = (C.c_ubyte * 128)()
+        if self.rank == 0:
+            L.check(L.lib().mm_comm_unique_id(uid), 'mm_comm_unique_id')
+        box = [bytes(uid)]
+        dist.broadcast_object_list(box, src=0, group=group)
+        self.ptr = C.c_void_p()
+        L.check(L.lib().mm_comm_create(box[0], self.rank, self.world, C.byref(self.ptr)), 'mm_comm_create')
+        self.ws = None
+
+    def __call__(self, ids):
+        L = self.L
+        send = ids.to(torch.long).contiguous()
+        count = send.numel()
+        out = torch.empty((self.world * send.shape[0],) + tuple(send.shape[1:]), dtype=torch.long, device=send.device)
+        wsb = L.lib().mm_allgather_ids_workspace_bytes(self.ptr, count)
+        if self.ws is None or self.ws.numel() < wsb or self.ws.device != send.device:
+            self.ws = torch.empty(int(wsb), dtype=torch.uint8, device=send.device)
+        L.check(L.lib().mm_allgather_ids(self.ptr, L.stream(), L.ptr(send), count, L.ptr(out), L.ptr(self.ws), self.ws.numel()), 'mm_allgather_ids')
+        return out
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.L.lib().mm_comm_destroy(self.ptr)
+        except Exception:
+            pass
+
+
+_GATHERS = {}
+
+
 def allgather_ids(ids, dist, group=None):
     """ids int64 (b, f, f), same b on every rank -> (world*b, f, f).  Final ids are < codebook_size <= 65536 (the last
-    decode step leaves no mask id, mmp.py:584-588), so they travel as int32: 4 bytes/token, 32 KiB per rank at C2."""
+    decode step leaves no mask id, mmp.py:584-588), so they travel as int32: 4 bytes/token, 32 KiB per rank at C2.
+    Backend 'nccl' (one rank per GPU): the library's own RCCL all-gather (IdsGather, C ABI); backend 'gloo' (CPU rendezvous of the tests,
+    or ranks sharing one device): torch.distributed through host memory."""
     world = dist.get_world_size(group)
+    if dist.get_backend(group) == 'nccl':
+        key = id(group) if group is not None else 0
+        if key not in _GATHERS:
+            _GATHERS[key] = IdsGather(dist, group)
+        return _GATHERS[key](ids)
     send = ids.to(torch.int32).contiguous()
     dev = send.device
     if dist.get_backend(group) == 'gloo':                     # CPU rendezvous (tests, or ranks sharing one device): 32 KiB through host memory
