@@ -76,8 +76,7 @@ def test_patched_foreign_classes_compute_on_the_gpu(stub):
     # Attend.forward (the operator seam) on a foreign Attend
     att = stub.attend.Attend(scale=8)
     q, k, v = (torch.randn(2, 4, n_, 64, device=DEV) for n_ in (64, 33, 33))
-    mask = torch.rand(2, 4, 64, 33, device=DEV) < 0.7
-    mask[..., 0] = True
+    mask = (torch.rand(2, 1, 1, 33, device=DEV) < 0.7).expand(2, 4, 64, 33)          # a key-padding mask, the only kind the reference builds (mmp.py:155-157)
     assert torch.equal(att(q, k, v, mask=mask), mm.attend.Attend(scale=8)(q, k, v, mask=mask))
 
 
