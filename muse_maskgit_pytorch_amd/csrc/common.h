@@ -152,15 +152,60 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 // Fused sampling (sampling_fused.hip): what leaves the guidance-logits GEMM instead of the logits.  One 256-column piece of a logits row is
 // held by a wave as 4 consecutive values per lane (lane l: columns 4l .. 4l+3 of the tile).  A lane whose largest value reaches thr keeps its
 // four values: the kept lanes' float4s are stored lane-compacted into the tile's slot (at most 64 x 16 B: the slot cannot overflow) and the
-// tile's statistics record {max, sum exp(x - max), 64-bit mask of the kept lanes}.  Two VMEM instructions per piece, no atomics.
+// tile's statistics record {max, sum exp(x - max), 64-bit mask of the kept granules}.  No atomics.
 constexpr int FS_SLOT = 64;
-// max and sum exp(x - max) of one 256-column piece held as 4 consecutive values per lane.  ONE definition for the GEMM emission, fused_emit and
-// the logits-path sampler (sampling.hip): the softmax denominator of a row is combined from these per-tile numbers in one fixed order on every
-// path, so the confidences 1 - p -- and with them the next step's re-masking -- are bit-identical whichever path sampled the row.
-__device__ __forceinline__ void tile_softmax_stats(const float4 x, float& m, float& e) {
-    const float m4 = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
-    m = wave_max_dpp(m4);
-    e = wave_sum_dpp((__expf(x.x - m) + __expf(x.y - m)) + (__expf(x.z - m) + __expf(x.w - m)));
+// Softmax statistics of one 256-column piece of a logits row and the order of its candidate granules, in ONE canonical form shared by every
+// producer -- the guidance GEMM's epilogue (from its accumulator fragments, gemm_cfg.hip), fused_emit (from materialised logits) and the
+// logits-path sampler (sampling.hip) -- so that a row's softmax denominator, its confidence 1 - p and the next step's re-masking are
+// bit-identical whichever path sampled the row.  The form is the one the GEMM's accumulator layout gives WITHOUT any lane exchange: a piece is 4
+// quarters q of 64 columns (one per wave of the GEMM's vocabulary split); in a quarter, column c = 16 a + 4 f + r is value r of granule (a, f) --
+// GEMM: accumulator fragment a of lane group f, which holds the 4 granules a = 0..3 of its f.  Per LANE GROUP (q, f):
+//     ml = max of its 16 values;   g(a) = (e0 + e1) + (e2 + e3),  e_r = exp(x_r - ml)  (v_exp_f32 form);   pl = (g(0) + g(1)) + (g(2) + g(3))
+// and over the 16 groups of the piece:
+//     M = max ml;   t(q, f) = pl * exp(ml - M);   w(q) = (t(q,0) + t(q,1)) + (t(q,2) + t(q,3));   E = (w(0) + w(1)) + (w(2) + w(3))
+// Candidate granules (kept when their largest value reaches the row's bound) are numbered j = 16 q + 4 f + a -- a group's granules adjacent -- so
+// that a group's 4 keep bits are one nibble of the piece's 64-bit mask; the slot holds the kept granules in ascending j.
+__device__ __forceinline__ void tile_combine16(const float (&ml)[16], const float (&pl)[16], float& M, float& E) {
+    float m = ml[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) m = fmaxf(m, ml[i]);
+    float w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        w[q] = (pl[4 * q] * __expf(ml[4 * q] - m) + pl[4 * q + 1] * __expf(ml[4 * q + 1] - m)) + (pl[4 * q + 2] * __expf(ml[4 * q + 2] - m) + pl[4 * q + 3] * __expf(ml[4 * q + 3] - m));
+    M = m;
+    E = (w[0] + w[1]) + (w[2] + w[3]);
+}
+// ROW layout (lane l holds columns 4 l .. 4 l + 3 of the piece: quarter q = l >> 4, granule a = (l >> 2) & 3 of lane group f = l & 3); every
+// lane returns the piece's (M, E)
+__device__ __forceinline__ void tile_softmax_stats(const float4 x, float& M, float& E) {
+#define MM_DPP_F(x_, ctrl_) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x_), ctrl_, 0xF, 0xF, true))
+    float ml = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
+    ml = fmaxf(ml, __shfl_xor(ml, 4, 64));      // over a (lanes f, 4 + f, 8 + f, 12 + f of the 16-lane row)
+    ml = fmaxf(ml, __shfl_xor(ml, 8, 64));
+    float pl = (__expf(x.x - ml) + __expf(x.y - ml)) + (__expf(x.z - ml) + __expf(x.w - ml));      // g(a)
+    pl += __shfl_xor(pl, 4, 64);                // g(a) + g(a ^ 1)
+    pl += __shfl_xor(pl, 8, 64);                // (g(0) + g(1)) + (g(2) + g(3))
+    float mr = fmaxf(ml, MM_DPP_F(ml, 0xB1));   // over f: the row's (quarter's) max
+    mr = fmaxf(mr, MM_DPP_F(mr, 0x4E));
+    float m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mr), 0));
+#pragma unroll
+    for (int q = 1; q < 4; ++q) m = fmaxf(m, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mr), 16 * q)));
+    float t = pl * __expf(ml - m);
+    t += MM_DPP_F(t, 0xB1);                     // t(q, f) + t(q, f ^ 1)
+    t += MM_DPP_F(t, 0x4E);                     // w(q)
+#undef MM_DPP_F
+    float w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 16 * q));
+    M = m;
+    E = (w[0] + w[1]) + (w[2] + w[3]);
+}
+// candidate order: row-layout lane l = 16 q + 4 a + f  <->  granule number j = 16 q + 4 f + a (a 4 x 4 transpose inside every 16-bit group)
+__device__ __forceinline__ int granule_number(int lane) { return (lane & 48) | ((lane & 3) << 2) | ((lane >> 2) & 3); }
+__device__ __forceinline__ unsigned long long granule_mask_from_lanes(unsigned long long v) {      // bit l of v -> bit granule_number(l)
+    return (v & 0x8421842184218421ull) | ((v & 0x0842084208420842ull) << 3) | ((v & 0x0084008400840084ull) << 6) | ((v & 0x0008000800080008ull) << 9) |
+           ((v >> 3) & 0x0842084208420842ull) | ((v >> 6) & 0x0084008400840084ull) | ((v >> 9) & 0x0008000800080008ull);
 }
 __device__ __forceinline__ void fused_emit_piece(const float4 x, int row, int tile, int NT, int lane, float thr, float4* __restrict__ stats,
                                                  float4* __restrict__ cand) {
@@ -168,34 +213,9 @@ __device__ __forceinline__ void fused_emit_piece(const float4 x, int row, int ti
     float m, e;
     tile_softmax_stats(x, m, e);
     const bool kp = m4 >= thr;
-    const unsigned long long bal = __ballot(kp);
-    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-    if (kp) cand[((size_t)row * NT + tile) * FS_SLOT + rank] = x;
-    if (lane == 0) stats[(size_t)row * NT + tile] = make_float4(m, e, __uint_as_float((uint32_t)bal), __uint_as_float((uint32_t)(bal >> 32)));
-}
-
-// The same emission for a kernel that hands over many pieces per wave (the persistent guidance GEMM: 16 rows of a tile per wave): a store
-// instruction per piece is what the emission costs there (measured: the statistics store and the candidate store each add ~11 % to the GEMM),
-// so the statistics of piece j are parked in LANE j of `parked` and leave with ONE store per 16 pieces (fused_flush_stats).  Returns whether
-// the candidate store was issued (wave-uniform; the caller's counted s_waitcnt vmcnt needs the exact number of VMEM instructions).
-__device__ __forceinline__ bool fused_emit_piece_parked(const float4 x, int row, int tile, int NT, int lane, float thr, float4* __restrict__ cand, int j,
-                                                        float4& parked) {
-    const float m4 = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
-    float m, e;
-    tile_softmax_stats(x, m, e);
-    const bool kp = m4 >= thr;
-    const unsigned long long bal = __ballot(kp);
-    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-    const bool any = bal != 0ull;
-    if (any) {
-        if (kp) cand[((size_t)row * NT + tile) * FS_SLOT + rank] = x;
-    }
-    if (lane == j) parked = make_float4(m, e, __uint_as_float((uint32_t)bal), __uint_as_float((uint32_t)(bal >> 32)));
-    return any;
-}
-// lane j (< count) stores the parked statistics of piece j to row rows_of_lane (its own piece's token row; < 0: the piece did not exist)
-__device__ __forceinline__ void fused_flush_stats(const float4 parked, int row_of_lane, int tile, int NT, float4* __restrict__ stats) {
-    if (row_of_lane >= 0) stats[(size_t)row_of_lane * NT + tile] = parked;
+    const unsigned long long mask = granule_mask_from_lanes(__ballot(kp));
+    if (kp) cand[((size_t)row * NT + tile) * FS_SLOT + __popcll(mask & ((1ull << granule_number(lane)) - 1ull))] = x;
+    if (lane == 0) stats[(size_t)row * NT + tile] = make_float4(m, e, __uint_as_float((uint32_t)mask), __uint_as_float((uint32_t)(mask >> 32)));
 }
 
 // ---- 'bf16x3' precision tier (split.hip): an fp32 value as the exact sum of three bf16 terms, x = h + m + l

@@ -58,18 +58,15 @@ constexpr int SMEM_B = CT_OFF + 65536;      // 160 KiB
 
 #define WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
 
-__device__ __forceinline__ void wait_vmcnt(int n) {      // n is wave-uniform
+// vmcnt is a 6-bit field split over the s_waitcnt immediate: bits 3:0 and 15:14 (lgkmcnt 0xF and expcnt 7 = no wait on those)
+#define MM_VMCNT_IMM(n_) (0x0F70 | ((n_) & 15) | (((n_) >> 4) << 14))
+__device__ __forceinline__ void wait_vmcnt(int n) {      // n is wave-uniform; values above 31 wait for 31 (waiting for more is always safe)
     switch (n) {
-        case 0: __builtin_amdgcn_s_waitcnt(0x0F70); break;
-        case 1: __builtin_amdgcn_s_waitcnt(0x0F71); break;
-        case 2: __builtin_amdgcn_s_waitcnt(0x0F72); break;
-        case 3: __builtin_amdgcn_s_waitcnt(0x0F73); break;
-        case 4: __builtin_amdgcn_s_waitcnt(0x0F74); break;
-        case 5: __builtin_amdgcn_s_waitcnt(0x0F75); break;
-        case 6: __builtin_amdgcn_s_waitcnt(0x0F76); break;
-        case 7: __builtin_amdgcn_s_waitcnt(0x0F77); break;
-        case 8: __builtin_amdgcn_s_waitcnt(0x0F78); break;
-        default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+#define MM_W(n_) case n_: __builtin_amdgcn_s_waitcnt(MM_VMCNT_IMM(n_)); break;
+        MM_W(0) MM_W(1) MM_W(2) MM_W(3) MM_W(4) MM_W(5) MM_W(6) MM_W(7) MM_W(8) MM_W(9) MM_W(10) MM_W(11) MM_W(12) MM_W(13) MM_W(14) MM_W(15)
+        MM_W(16) MM_W(17) MM_W(18) MM_W(19) MM_W(20) MM_W(21) MM_W(22) MM_W(23) MM_W(24) MM_W(25) MM_W(26) MM_W(27) MM_W(28) MM_W(29) MM_W(30)
+#undef MM_W
+        default: if (n < 0) __builtin_amdgcn_s_waitcnt(MM_VMCNT_IMM(0)); else __builtin_amdgcn_s_waitcnt(MM_VMCNT_IMM(31)); break;
     }
 }
 
@@ -81,15 +78,6 @@ __device__ __forceinline__ uint4 lds_read_b128_raw(const unsigned char* ptr) {
     u32x4_t v;
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
     return make_uint4(v[0], v[1], v[2], v[3]);
-}
-
-// Scalar (SMEM) load of one float at a wave-uniform address; the value is valid after the caller's next lgkmcnt(0) wait.  Inline asm on purpose:
-// as an ordinary load it becomes a global_load (the kernel stores to global memory, so the compiler will not prove the location read-only) and,
-// worse, the compiler's waitcnt pass then drains vmcnt(0) -- the whole LDS-DMA pipeline -- in front of its first use (measured: +38 % kernel time).
-__device__ __forceinline__ float sload_f32(const float* ptr) {
-    float v;
-    asm volatile("s_load_dword %0, %1, 0x0" : "=s"(v) : "s"(ptr) : "memory");
-    return v;
 }
 
 // the logits are written once and read once by the sampler, 1.35 GB per launch against 4 MiB of L2 per XCD: a non-temporal store
@@ -193,13 +181,19 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
     LOAD_NEXT(1);
     LOAD_NEXT(2);
 
-    // fused sampling: no logits leave the kernel; every piece emits tile statistics + the kept lanes' values instead (common.h
-    // fused_emit_piece).  Its VMEM instructions per piece: 1 statistics store (always issued) + 1 predicated value store.  The counted waits
-    // below only need a LOWER bound of what was issued behind a DMA (under-counting waits for more, never for less).
+    // Fused sampling (round 3: from the ACCUMULATORS): no logits leave the kernel and nothing goes through the staging tile.  At the end of a tile
+    // every wave holds 64 tokens x 64 columns as fragments -- a lane owns four GRANULES (4 consecutive columns) of one token per token block, which
+    // is exactly the candidate unit of sampling_fused.hip -- so a lane's share of the statistics is a purely in-lane reduction, the 16 lane groups
+    // of a token (4 vocabulary quarters x 4) meet through 18 KiB of LDS (keep nibbles + (max, sum exp) pairs: no lane exchange at all), and each
+    // kept granule is stored straight to its slot (rank = kept granules of the token's 256-column piece in front of it).  The k-loop of a fused
+    // launch carries no output work.
+    // The counted waits only need a LOWER bound of what was issued behind a DMA (under-counting waits for more, never for less).
     const bool fused = TOKT && p.fs_stats != nullptr;
+    unsigned char* xch = ct;                       // fused: [128 tokens][16 lane groups] keep nibbles (2 KiB) | (group max, group sum exp) (float2, 16 KiB)
+    float* lthr = reinterpret_cast<float*>(ct + 32768);     // fused: the tile's 128 per-token bounds (1 KiB, written by LDS-DMA at the tile's first k-step)
+    const __amdgpu_buffer_rsrc_t thr_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fused ? p.fs_thr : nullptr), 0, fused ? (unsigned)p.M * 4u : 0u, 0x00020000);
     f32x4_t acc[4][8];
     f32x4_t held[2][4];             // second half of the previous tile's output (tokens 32..63 of this wave), combined
-    float4 parked = make_float4(0.f, 0.f, 0.f, 0.f);      // fused sampling: lane j holds the statistics of this wave's j-th piece of the previous tile
     bool have_prev = false;
     int pm0 = 0, pn0 = 0;
     int g = 0;                      // global k-step counter of the compute cursor
@@ -276,11 +270,14 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
         }                                                                                                      \
         const bool piece_ = have_prev && q_ < 8 && ptok_ < p.M && !ABL(p, 1);      /* wave-uniform */          \
         uint4 pv_ = make_uint4(0, 0, 0, 0);                                                                    \
-        float fthr_ = 0.f;                                                                                     \
         if (piece_) pv_ = lds_read_b128_raw(psrc_);                                                            \
-        if (TOKT && fused && piece_) fthr_ = sload_f32(p.fs_thr + __builtin_amdgcn_readfirstlane(ptok_));     \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         LOAD_NEXT(st_);                                     /* step g+3 into the stage just consumed */        \
+        if (TOKT && fused && kt == 0 && wid == 0) {         /* this tile's per-token bounds -> LDS (one more DMA of wave 0: its counted waits */ \
+            int tm_, tn_;                                   /* under-count by one for two steps, which only waits for more) */ \
+            xcd_grouped_tile(vb, p.tiles_m, p.tiles_n, 8, tm_, tn_);                                           \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(thr_rs, (lds_ptr_t)(lthr), 16, lane * 16, tm_ * TOK * 4, 0, 0); \
+        }                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         if constexpr (WMODE != WIDE_MIX) { MFMA_PAIR(AF_, p0, 2) }                                             \
         if (g + 1 < steps_total) {                                                                             \
@@ -295,13 +292,8 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
             WAIT_LGKM0();                                       /* the raw read of pv_ (the fragments are long there) */ \
             __builtin_amdgcn_sched_barrier(0);                                                                 \
             if constexpr (TOKT) {                                                                              \
-                if (fused) {                                                                                   \
-                    st1 = fused_emit_piece_parked(make_float4(__uint_as_float(pv_.x), __uint_as_float(pv_.y), __uint_as_float(pv_.z), __uint_as_float(pv_.w)), \
-                                                  ptok_, pn0 >> 8, p.tiles_n, lane, fthr_, p.fs_cand, half_ * 8 + q_, parked) ? 1 : 0; \
-                } else {                                                                                       \
-                    store_stream(reinterpret_cast<float*>(pv_ptr_), pv_);                                      \
-                    st1 = 1;                                                                                   \
-                }                                                                                              \
+                store_stream(reinterpret_cast<float*>(pv_ptr_), pv_);                                          \
+                st1 = 1;                                                                                       \
             }                                                                                                  \
             else {                                                                                             \
                 if (p.ln_part) {      /* LayerNorm(inner) partial sums of the row's two 64-column groups (common.h) */ \
@@ -312,15 +304,6 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
                 if (pm0 + prow_ < p.M) *reinterpret_cast<uint4*>(pv_ptr_) = pv_;      /* re-read by the next kernel: a plain store */ \
                 st1 = 1;                                                                                       \
             }                                                                                                  \
-        }                                                                                                      \
-        /* the 16 pieces of the previous tile are out: one store of their parked statistics (lane j = piece j: half j >> 3, q = j & 7) */ \
-        if (TOKT && fused && have_prev && half_ == 1 && q_ == 7) {                                             \
-            const int ftok_ = PIECE_TOKEN(PIECE_ROW(lane & 7), (lane >> 3) & 1);                               \
-            fused_flush_stats(parked, (lane < 16 && ftok_ < p.M) ? ftok_ : -1, pn0 >> 8, p.tiles_n, p.fs_stats); \
-            /* the store is predicated per lane and skipped (s_cbranch_execz) when none of this wave's 16 pieces exists, i.e. when even its */ \
-            /* first token row pm0 + wid lies beyond M (edge tile with fewer than 8 rows): count it only when it was issued -- an over-count */ \
-            /* would let the next counted wait pass with one LDS-DMA still in flight */                        \
-            st1 += (pm0 + wid < p.M) ? 1 : 0;                                                                  \
         }                                                                                                      \
         ++g;                                                                                                   \
         ++kt;                                                                                                  \
@@ -357,7 +340,95 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
         WAIT_LGKM0();
         __builtin_amdgcn_s_barrier();
         TSTAMP()
+        bool emitted = false;
         if constexpr (TOKT) {
+            if (fused) {
+                // ---- fused-sampling emission straight from the accumulator fragments (see the comment at `fused`; canonical form: common.h)
+                emitted = true;
+                const int m0t = tile_m * TOK;
+                const int tilec = tile_n;                          // the piece index of this tile's 256 columns in a row of V / 256 pieces
+                unsigned char* xnib = xch;                                                  // [128 tokens][16 lane groups] keep nibbles (one byte each)
+                float2* xml = reinterpret_cast<float2*>(xch + 2048);                         // [128 tokens][16 lane groups] (ml, pl)
+                unsigned kbits[4];
+                int nstore = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int tokl = wm * 64 + b * 16 + fr;
+                    const bool valid = m0t + tokl < p.M;
+                    const float thr = lthr[tokl];
+                    if constexpr (WMODE == WIDE_CFG) {      // combine the two passes in place: the null fragments are dead afterwards (mmp.py:254)
+#pragma unroll
+                        for (int a = 0; a < 4; ++a)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float cv = acc[a][b][r], nl = acc[a][b + 4][r];
+                                acc[a][b][r] = nl + (cv - nl) * p.cfg_scale;
+                            }
+                    }
+                    // this lane IS lane group (wn, fg) of the token: its 4 granules a = 0..3, no lane exchange anywhere
+                    float gm[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) gm[a] = fmaxf(fmaxf(acc[a][b][0], acc[a][b][1]), fmaxf(acc[a][b][2], acc[a][b][3]));
+                    const float ml = fmaxf(fmaxf(gm[0], gm[1]), fmaxf(gm[2], gm[3]));
+                    float gs[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        gs[a] = (__expf(acc[a][b][0] - ml) + __expf(acc[a][b][1] - ml)) + (__expf(acc[a][b][2] - ml) + __expf(acc[a][b][3] - ml));
+                    const float pl = (gs[0] + gs[1]) + (gs[2] + gs[3]);
+                    unsigned kb = 0;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) kb |= (valid && gm[a] >= thr) ? (1u << a) : 0u;
+                    kbits[b] = kb;
+                    xnib[tokl * 16 + wn * 4 + fg] = (unsigned char)kb;
+                    xml[tokl * 16 + wn * 4 + fg] = make_float2(ml, pl);
+                }
+                WAIT_LGKM0();
+                __builtin_amdgcn_s_barrier();      // all 16 lane groups of every token have published their nibble and (ml, pl)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int tokl = wm * 64 + b * 16 + fr;
+                    const int tok = m0t + tokl;
+                    uint4 nb = *reinterpret_cast<const uint4*>(xnib + tokl * 16);      // 16 bytes = the 16 groups' nibbles, quarter by quarter
+                    uint32_t h16[4] = {nb.x, nb.y, nb.z, nb.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {                                      // 0x0n0n0n0n -> 0xnnnn (group f of the quarter in bits 4 f .. 4 f + 3)
+                        h16[q] = (h16[q] | (h16[q] >> 4)) & 0x00FF00FFu;
+                        h16[q] = (h16[q] | (h16[q] >> 8)) & 0x0000FFFFu;
+                    }
+                    const unsigned long long mask64 = (unsigned long long)(h16[0] | (h16[1] << 16)) | ((unsigned long long)(h16[2] | (h16[3] << 16)) << 32);
+                    float4* slot = p.fs_cand + ((size_t)tok * p.tiles_n + tilec) * FS_SLOT;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const int jn = wn * 16 + fg * 4 + a;            // granule number (common.h granule_number)
+                        const bool kp = (kbits[b] >> a) & 1u;
+                        if (__ballot(kp) != 0ull) {                     // wave-uniform: the store below is ISSUED (exact VMEM count for the waits)
+                            if (kp) slot[__popcll(mask64 & ((1ull << jn) - 1ull))] = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+                            ++nstore;
+                        }
+                    }
+                    if (b == wn) {      // one record per (token, piece): this wave combines the 16 tokens of token block b == wn (its lanes fg == 0)
+                        const bool w_ = fg == 0 && tok < p.M;
+                        if (__ballot(w_) != 0ull) {
+                            if (w_) {
+                                float mq[16], pq[16];
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) {
+                                    const float4 v2 = *reinterpret_cast<const float4*>(xml + tokl * 16 + 2 * i);
+                                    mq[2 * i] = v2.x; pq[2 * i] = v2.y; mq[2 * i + 1] = v2.z; pq[2 * i + 1] = v2.w;
+                                }
+                                float M_, E_;
+                                tile_combine16(mq, pq, M_, E_);
+                                p.fs_stats[(size_t)tok * p.tiles_n + tilec] = make_float4(M_, E_, __uint_as_float((uint32_t)mask64), __uint_as_float((uint32_t)(mask64 >> 32)));
+                            }
+                            ++nstore;
+                        }
+                    }
+                }
+                st1 += nstore;      // issued after this wave's last DMA: the next two steps' counted waits allow for them
+            }
+        }
+        if constexpr (TOKT) {
+            if (!emitted) {
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
 #pragma unroll
@@ -383,6 +454,7 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
                     }
                 }
             }
+            }
         } else {
             // GEGLU (mmp.py:72-77): the weight rows are interleaved so that fragments a = 0,1 hold the gelu half and a = 2,3 the gate
             // half of the SAME 32 output columns of this wave; the tile emits 256 rows x 128 columns of bf16 = the whole 64 KiB ct
@@ -399,7 +471,7 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
             }
         }
         pm0 = tile_m * (TOKT ? TOK : 2 * TOK); pn0 = tile_n * BN;
-        have_prev = true;
+        have_prev = !emitted;      // (a fused tile has left already: nothing rides on the next tile's k-loop)
         vb += G;
         if (vb >= total) break;
     }
@@ -407,6 +479,7 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
     WAIT_LGKM0();
     __builtin_amdgcn_s_barrier();
     if constexpr (TOKT) {
+        if (fused) return;
         for (int half = 0; half < 2; ++half) {
             if (half) {
                 HELD_TO_CT();
@@ -418,17 +491,11 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
                 const int ptok = PIECE_TOKEN(hrow, half);
                 if (ptok < p.M && !ABL(p, 1)) {
                     const uint4 pv = *reinterpret_cast<const uint4*>(ct + hrow * 1024 + ((lane ^ (hrow & 7)) << 4));
-                    if (fused) fused_emit_piece_parked(make_float4(__uint_as_float(pv.x), __uint_as_float(pv.y), __uint_as_float(pv.z), __uint_as_float(pv.w)), ptok,
-                                                       pn0 >> 8, p.tiles_n, lane, p.fs_thr[ptok], p.fs_cand, half * 8 + q, parked);
-                    else store_stream(reinterpret_cast<float*>(p.out) + (size_t)ptok * p.ldc + pn0 + lane * 4, pv);
+                    store_stream(reinterpret_cast<float*>(p.out) + (size_t)ptok * p.ldc + pn0 + lane * 4, pv);
                 }
             }
             WAIT_LGKM0();
             __builtin_amdgcn_s_barrier();
-        }
-        if (fused) {
-            const int ftok = PIECE_TOKEN(PIECE_ROW(lane & 7), (lane >> 3) & 1);
-            fused_flush_stats(parked, (lane < 16 && ftok < p.M) ? ftok : -1, pn0 >> 8, p.tiles_n, p.fs_stats);
         }
     } else {
         for (int q = 0; q < 8; ++q) {
@@ -480,7 +547,6 @@ int mm_gemm_cfg2_launch(GemmArgs a, hipStream_t stream) {
     }
     const bool cfg = a.mode == MODE_CFG;
     const bool mix = a.mode == MODE_DENSE && a.wide_tok && a.epi == EPI_NONE;
-    if (cfg && (g_mm_debug & (1 << 26))) return mm_gemm_cfg3_launch(a, stream);      // bit 1 << 26: the phase-split experiment of gemm_cfg3.hip (same values; measured no faster)
     a.tiles_n = a.N / BN;
     a.tiles_m = (cfg || mix) ? (a.M + TOK - 1) / TOK : (a.M + 2 * TOK - 1) / (2 * TOK);
     const int total = a.tiles_m * a.tiles_n;

@@ -52,7 +52,6 @@ int mm_gemm_big_launch(GemmArgs a, hipStream_t stream);
 bool mm_gemm_pers_eligible(const GemmArgs& a);
 bool mm_gemm_cfg2_eligible(const GemmArgs& a);     // gemm_cfg.hip: persistent 128 tokens x 256 columns, guidance logits
 int mm_gemm_cfg2_launch(GemmArgs a, hipStream_t stream);
-int mm_gemm_cfg3_launch(GemmArgs a, hipStream_t stream);      // gemm_cfg3.hip: same tile, compute / load phases with the wave groups half a step apart
 // gemm_pers.hip: persistent 256x128, stores overlapped with the next tile
 int mm_gemm_pers_launch(GemmArgs a, hipStream_t stream);
 
