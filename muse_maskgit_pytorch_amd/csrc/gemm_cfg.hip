@@ -54,7 +54,7 @@ constexpr int XT_B = 2 * TOK * BK * 2;      // 16 KiB: 256 activation rows (128 
 constexpr int WT_B = BN * BK * 2;           // 16 KiB
 constexpr int STG_B = XT_B + WT_B;          // 32 KiB
 constexpr int CT_OFF = NST * STG_B;         // 96 KiB
-constexpr int SMEM_B = CT_OFF + 65536;      // 160 KiB
+constexpr int SMEM_B = CT_OFF + 65536;      // 160 KiB (every instantiation is launched with all of it: Geo<>)
 
 #define WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
 
@@ -96,7 +96,19 @@ struct LoadCur {
     __amdgpu_buffer_rsrc_t w;
 };
 
-constexpr int WIDE_CFG = 0, WIDE_GEGLU = 1, WIDE_MIX = 2;
+constexpr int WIDE_CFG = 0, WIDE_GEGLU = 1, WIDE_MIX = 2, WIDE_MIXF = 3;
+// WIDE_MIXF = WIDE_MIX with the fused-sampling emission ONLY (mm_generate's default path).  That epilogue needs no staging tile, and the k-loop of
+// this family is bound by the LATENCY of the LDS-DMA, not its rate: a k-step costs ~0.9-1.0 us whether it carries 32 or 16 MFMAs per wave,
+// i.e. DMA latency / look-ahead (two steps with three stages).  The 64 KiB of the staging tile become stages: FIVE stages of 24 KiB (8 KiB of
+// activation rows + 16 KiB of weight rows), the DMA four k-steps ahead of the MFMAs.
+template <int WMODE> struct Geo {
+    static constexpr bool mix = WMODE == WIDE_MIX || WMODE == WIDE_MIXF;
+    static constexpr int nst = WMODE == WIDE_MIXF ? 5 : 3;                    // LDS stages
+    static constexpr int xtb = mix ? 8192 : 16384;                            // activation bytes of a stage
+    static constexpr int stg = (WMODE == WIDE_MIXF) ? 24576 : 32768;          // stage stride
+    static constexpr int woff = (WMODE == WIDE_MIXF) ? 8192 : 16384;          // weight rows inside a stage
+    static constexpr int ct_off = nst * stg;                                  // staging tile / exchange area behind the stages
+};
 
 template <int WMODE>
 __device__ __forceinline__ void cfg_tile_setup(const GemmArgs& p, int vb, LoadCur& lc) {
@@ -115,7 +127,10 @@ __device__ __forceinline__ void cfg_tile_setup(const GemmArgs& p, int vb, LoadCu
 template <int WMODE>
 __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* ct = smem + CT_OFF;
+    typedef Geo<WMODE> G_;
+    constexpr int NST = G_::nst, STG_B = G_::stg, XT_B = G_::woff;      // (shadow the file-level three-stage constants)
+    constexpr bool MIXK = G_::mix;                                      // one mixed pass: 4 activation blocks per wave, 3 DMA instructions per step
+    unsigned char* ct = smem + G_::ct_off;
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -127,7 +142,7 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
     const int KH = KT >> 1;
     const int rd = fr * 64 + ((fg ^ ((-(fr >> 2)) & 3)) << 4);      // this lane's fragment offset inside a 16-row block
     constexpr bool TOKT = WMODE != WIDE_GEGLU;      // token-row tiles with an fp32 output (two-pass guidance / single mixed pass)
-    constexpr int NDMA = (WMODE == WIDE_MIX) ? 3 : 4;      // LDS-DMA instructions per wave and k-step
+    constexpr int NDMA = MIXK ? 3 : 4;      // LDS-DMA instructions per wave and k-step
 
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     int vb = blockIdx.x;
@@ -149,7 +164,7 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
         for (int i = 0; i < 2; ++i) {
             const int xb = 2 * wid + i;
             // WIDE_MIX: 8 activation blocks per stage, this wave stages block wid (voff_x[1] unused)
-            const int xrow = (WMODE == WIDE_CFG) ? (xb >> 3) * 64 + (xb & 3) * 16 + (lane >> 2) : (WMODE == WIDE_MIX ? wid * 16 + (lane >> 2) : xb * 16 + (lane >> 2));
+            const int xrow = (WMODE == WIDE_CFG) ? (xb >> 3) * 64 + (xb & 3) * 16 + (lane >> 2) : (MIXK ? wid * 16 + (lane >> 2) : xb * 16 + (lane >> 2));
             voff_x[i] = xrow * p.ldx * 2 + c * 16;
             voff_w[i] = (xb * 16 + (lane >> 2)) * p.ldw * 2 + c * 16;
         }
@@ -161,7 +176,7 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
             unsigned char* xs_ = smem + (st_) * STG_B + wid * 2048;                                            \
             const int k0_ = l_k * (BK * 2);                                                                    \
             const __amdgpu_buffer_rsrc_t rx_ = x_null0 ? lc.x[1] : lc.x[0];                                    \
-            if constexpr (WMODE == WIDE_MIX) {                                                                 \
+            if constexpr (MIXK) {                                                                              \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, (lds_ptr_t)(smem + (st_) * STG_B + wid * 1024), 16, voff_x[0], k0_, 0, 0); \
             } else {                                                                                           \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, (lds_ptr_t)(xs_), 16, voff_x[0], k0_, 0, 0);     \
@@ -177,9 +192,8 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
             if (l_live) cfg_tile_setup<WMODE>(p, l_vb, lc);                                                    \
         }                                                                                                      \
     }
-    LOAD_NEXT(0);
-    LOAD_NEXT(1);
-    LOAD_NEXT(2);
+#pragma unroll
+    for (int st0 = 0; st0 < NST; ++st0) { LOAD_NEXT(st0); }
 
     // Fused sampling (round 3: from the ACCUMULATORS): no logits leave the kernel and nothing goes through the staging tile.  At the end of a tile
     // every wave holds 64 tokens x 64 columns as fragments -- a lane owns four GRANULES (4 consecutive columns) of one token per token block, which
@@ -188,16 +202,16 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
     // kept granule is stored straight to its slot (rank = kept granules of the token's 256-column piece in front of it).  The k-loop of a fused
     // launch carries no output work.
     // The counted waits only need a LOWER bound of what was issued behind a DMA (under-counting waits for more, never for less).
-    const bool fused = TOKT && p.fs_stats != nullptr;
+    const bool fused = TOKT && (WMODE == WIDE_MIXF || p.fs_stats != nullptr);
     unsigned char* xch = ct;                       // fused: [128 tokens][16 lane groups] keep nibbles (2 KiB) | (group max, group sum exp) (float2, 16 KiB)
-    float* lthr = reinterpret_cast<float*>(ct + 32768);     // fused: the tile's 128 per-token bounds (1 KiB, written by LDS-DMA at the tile's first k-step)
+    float* lthr = reinterpret_cast<float*>(ct + 18432);     // fused: the tile's 128 per-token bounds (1 KiB, written by LDS-DMA at the tile's first k-step)
     const __amdgpu_buffer_rsrc_t thr_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fused ? p.fs_thr : nullptr), 0, fused ? (unsigned)p.M * 4u : 0u, 0x00020000);
     f32x4_t acc[4][8];
     f32x4_t held[2][4];             // second half of the previous tile's output (tokens 32..63 of this wave), combined
     bool have_prev = false;
     int pm0 = 0, pn0 = 0;
     int g = 0;                      // global k-step counter of the compute cursor
-    int st1 = 0, st2 = 0;           // did this wave issue a store in the previous / second-previous k-step (wave-uniform)
+    int st1 = 0, st2 = 0, st3 = 0, st4 = 0;      // VMEM stores this wave issued in the previous .. fourth-previous k-step (wave-uniform; NST - 1 of them matter)
 
 #define HELD_TO_CT()                                                                                           \
     {                                                                                                          \
@@ -219,7 +233,7 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
     //     wait (DMA of step g+1 landed; my reads of stage g done) - BARRIER - stage g is free: issue the DMA of step g+3
     //     MFMA pair 2 | read afB, p0 <- step g+1 (weights, pair 0) | MFMA pair 3 | store the piece read after the barrier
     // so every MFMA group runs with the reads of a later group in flight, also across the barrier.
-#define X_FRAG(st_, j_) (*reinterpret_cast<const u32x4_t*>(smem + (st_) * STG_B + wm * (WMODE == WIDE_MIX ? 4096 : 8192) + rd + (j_) * 1024))
+#define X_FRAG(st_, j_) (*reinterpret_cast<const u32x4_t*>(smem + (st_) * STG_B + wm * (MIXK ? 4096 : 8192) + rd + (j_) * 1024))
 #define W_FRAG(st_, i_) (*reinterpret_cast<const u32x4_t*>(smem + (st_) * STG_B + XT_B + wn * 4096 + rd + (i_) * 1024))
 #define MFMA_PAIR(af_, src_, j_)                                                                               \
     if (!ABL(p, 4)) {                                                                                          \
@@ -232,7 +246,7 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
         const int st_ = g % NST, stn_ = (g + 1) % NST;                                                         \
         p1[0] = X_FRAG(st_, 2); p1[1] = X_FRAG(st_, 3);                                                        \
         MFMA_PAIR(AF_, p0, 0)                                                                                  \
-        if constexpr (WMODE != WIDE_MIX) {      /* WIDE_MIX: 4 activation blocks per wave, pairs 0 and 1 only */ \
+        if constexpr (!MIXK) {                  /* one mixed pass: 4 activation blocks per wave, pairs 0 and 1 only */ \
             p0[0] = X_FRAG(st_, 4); p0[1] = X_FRAG(st_, 5);                                                    \
             MFMA_PAIR(AF_, p1, 1)                                                                              \
             p1[0] = X_FRAG(st_, 6); p1[1] = X_FRAG(st_, 7);                                                    \
@@ -240,7 +254,12 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         /* step g+1 has landed once only what this wave issued after ITS DMA can be in flight: the store of step g-2, the */ \
         /* 4 DMA instructions of step g+2, the store of step g-1 */                                            \
-        wait_vmcnt(((g + 2 < steps_total && !ABL(p, 2)) ? NDMA : 0) + st1 + st2);                              \
+        /* (general form: the DMAs of steps g+2 .. g+NST-1 and the stores of the last NST-1 steps were issued behind the DMA of step g+1) */ \
+        {                                                                                                      \
+            int ahead_ = steps_total - (g + 2);                                                                \
+            ahead_ = ahead_ < 0 ? 0 : (ahead_ > NST - 2 ? NST - 2 : ahead_);                                   \
+            wait_vmcnt((ABL(p, 2) ? 0 : ahead_ * NDMA) + st1 + st2 + (NST > 3 ? st3 + st4 : 0));               \
+        }                                                                                                      \
         WAIT_LGKM0();                                                                                          \
         __builtin_amdgcn_s_barrier();                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
@@ -279,13 +298,14 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(thr_rs, (lds_ptr_t)(lthr), 16, lane * 16, tm_ * TOK * 4, 0, 0); \
         }                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        if constexpr (WMODE != WIDE_MIX) { MFMA_PAIR(AF_, p0, 2) }                                             \
+        if constexpr (!MIXK) { MFMA_PAIR(AF_, p0, 2) }                                                         \
         if (g + 1 < steps_total) {                                                                             \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) AFN_[i] = W_FRAG(stn_, i);                           \
             p0[0] = X_FRAG(stn_, 0); p0[1] = X_FRAG(stn_, 1);                                                  \
         }                                                                                                      \
-        if constexpr (WMODE != WIDE_MIX) { MFMA_PAIR(AF_, p1, 3) } else { MFMA_PAIR(AF_, p1, 1) }              \
+        if constexpr (!MIXK) { MFMA_PAIR(AF_, p1, 3) } else { MFMA_PAIR(AF_, p1, 1) }                          \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
+        st4 = st3; st3 = st2;                                                                                  \
         st2 = st1;                                                                                             \
         st1 = 0;                                                                                               \
         if (piece_) {                                                                                          \
@@ -315,7 +335,7 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
 #endif
     TSTAMP()
     // prologue: step 0 has landed once only the DMA of steps 1 and 2 (8 instructions) is in flight
-    wait_vmcnt(steps_total > 2 ? 2 * NDMA : (steps_total > 1 ? NDMA : 0));
+    wait_vmcnt((steps_total > NST - 1 ? NST - 1 : steps_total - 1) * NDMA);
     __builtin_amdgcn_s_barrier();
     u32x4_t afA[4], afB[4], p0[2], p1[2];
 #pragma unroll
@@ -434,7 +454,7 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     f32x4_t v;
-                    if constexpr (WMODE == WIDE_MIX) {
+                    if constexpr (MIXK) {
                         v = acc[a][b];      // the passes were combined in the embedding (mm_cfg_mix): these ARE the guidance logits
                     } else {
 #pragma unroll
@@ -542,6 +562,7 @@ int mm_gemm_cfg2_launch(GemmArgs a, hipStream_t stream) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cfg2_kernel<WIDE_CFG>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cfg2_kernel<WIDE_GEGLU>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cfg2_kernel<WIDE_MIX>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cfg2_kernel<WIDE_MIXF>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
         if (e != hipSuccess) return mm_set_hip_error(e, "gemm_cfg2 hipFuncSetAttribute");
         attr_set = true;
     }
@@ -552,6 +573,7 @@ int mm_gemm_cfg2_launch(GemmArgs a, hipStream_t stream) {
     const int total = a.tiles_m * a.tiles_n;
     const int grid = total < 256 ? total : 256;
     if (cfg) hipLaunchKernelGGL(gemm_cfg2_kernel<WIDE_CFG>, dim3(grid), dim3(512), SMEM_B, stream, a);
+    else if (mix && a.fs_stats && !(g_mm_debug & (1 << 26))) hipLaunchKernelGGL(gemm_cfg2_kernel<WIDE_MIXF>, dim3(grid), dim3(512), SMEM_B, stream, a);      // (bit 1 << 26: A/B against three stages)
     else if (mix) hipLaunchKernelGGL(gemm_cfg2_kernel<WIDE_MIX>, dim3(grid), dim3(512), SMEM_B, stream, a);
     else hipLaunchKernelGGL(gemm_cfg2_kernel<WIDE_GEGLU>, dim3(grid), dim3(512), SMEM_B, stream, a);
     return mm_check_launch("gemm_cfg2_kernel");
