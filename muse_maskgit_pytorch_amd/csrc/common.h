@@ -163,8 +163,9 @@ constexpr int FS_SLOT = 64;
 //     ml = max of its 16 values;   g(a) = (e0 + e1) + (e2 + e3),  e_r = exp(x_r - ml)  (v_exp_f32 form);   pl = (g(0) + g(1)) + (g(2) + g(3))
 // and over the 16 groups of the piece:
 //     M = max ml;   t(q, f) = pl * exp(ml - M);   w(q) = (t(q,0) + t(q,1)) + (t(q,2) + t(q,3));   E = (w(0) + w(1)) + (w(2) + w(3))
-// Candidate granules (kept when their largest value reaches the row's bound) are numbered j = 16 q + 4 f + a -- a group's granules adjacent -- so
-// that a group's 4 keep bits are one nibble of the piece's 64-bit mask; the slot holds the kept granules in ascending j.
+// Candidate granules (kept when their largest value reaches the row's bound) keep the ROW-LAYOUT order j = 16 q + 4 a + f = (column / 4): the slot
+// holds the kept granules in ascending j, bit j of the piece's 64-bit mask says whether granule j was kept.  (In the GEMM a token's four lane groups
+// f = 0..3 then hold ADJACENT granules for a fixed fragment a, so one store instruction writes up to 64 contiguous bytes per token.)
 __device__ __forceinline__ void tile_combine16(const float (&ml)[16], const float (&pl)[16], float& M, float& E) {
     float m = ml[0];
 #pragma unroll
@@ -201,20 +202,14 @@ __device__ __forceinline__ void tile_softmax_stats(const float4 x, float& M, flo
     M = m;
     E = (w[0] + w[1]) + (w[2] + w[3]);
 }
-// candidate order: row-layout lane l = 16 q + 4 a + f  <->  granule number j = 16 q + 4 f + a (a 4 x 4 transpose inside every 16-bit group)
-__device__ __forceinline__ int granule_number(int lane) { return (lane & 48) | ((lane & 3) << 2) | ((lane >> 2) & 3); }
-__device__ __forceinline__ unsigned long long granule_mask_from_lanes(unsigned long long v) {      // bit l of v -> bit granule_number(l)
-    return (v & 0x8421842184218421ull) | ((v & 0x0842084208420842ull) << 3) | ((v & 0x0084008400840084ull) << 6) | ((v & 0x0008000800080008ull) << 9) |
-           ((v >> 3) & 0x0842084208420842ull) | ((v >> 6) & 0x0084008400840084ull) | ((v >> 9) & 0x0008000800080008ull);
-}
 __device__ __forceinline__ void fused_emit_piece(const float4 x, int row, int tile, int NT, int lane, float thr, float4* __restrict__ stats,
                                                  float4* __restrict__ cand) {
     const float m4 = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
     float m, e;
     tile_softmax_stats(x, m, e);
     const bool kp = m4 >= thr;
-    const unsigned long long mask = granule_mask_from_lanes(__ballot(kp));
-    if (kp) cand[((size_t)row * NT + tile) * FS_SLOT + __popcll(mask & ((1ull << granule_number(lane)) - 1ull))] = x;
+    const unsigned long long mask = __ballot(kp);
+    if (kp) cand[((size_t)row * NT + tile) * FS_SLOT + __popcll(mask & ((1ull << lane) - 1ull))] = x;
     if (lane == 0) stats[(size_t)row * NT + tile] = make_float4(m, e, __uint_as_float((uint32_t)mask), __uint_as_float((uint32_t)(mask >> 32)));
 }
 

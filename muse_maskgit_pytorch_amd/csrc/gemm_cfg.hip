@@ -96,13 +96,17 @@ struct LoadCur {
     __amdgpu_buffer_rsrc_t w;
 };
 
-constexpr int WIDE_CFG = 0, WIDE_GEGLU = 1, WIDE_MIX = 2, WIDE_MIXF = 3;
+constexpr int WIDE_CFG = 0, WIDE_GEGLU = 1, WIDE_MIX = 2, WIDE_MIXF = 3, WIDE_MIX2 = 4;
+// WIDE_MIX2 = the fused-only single pass on a 256-token x 256-column tile: the two-pass tile's geometry (each wave 2 x 64 tokens x 64 columns, 128
+// accumulator VGPRs) with the "null" half of the activation stage holding the NEXT 128 tokens instead of the second pass.  Measured with in-kernel
+// stamps (tools/mixf_timing.py): the k-loop of this family streams its operands at ~16 B per clock and CU through the LDS-DMA path whatever the
+// look-ahead, so the lever is flops per operand byte -- 128 flop/B here against 85 for 128 x 256 -- and the accumulator emission needs no output tile.
 // WIDE_MIXF = WIDE_MIX with the fused-sampling emission ONLY (mm_generate's default path).  That epilogue needs no staging tile, and the k-loop of
 // this family is bound by the LATENCY of the LDS-DMA, not its rate: a k-step costs ~0.9-1.0 us whether it carries 32 or 16 MFMAs per wave,
 // i.e. DMA latency / look-ahead (two steps with three stages).  The 64 KiB of the staging tile become stages: FIVE stages of 24 KiB (8 KiB of
 // activation rows + 16 KiB of weight rows), the DMA four k-steps ahead of the MFMAs.
 template <int WMODE> struct Geo {
-    static constexpr bool mix = WMODE == WIDE_MIX || WMODE == WIDE_MIXF;
+    static constexpr bool mix = WMODE == WIDE_MIX || WMODE == WIDE_MIXF;      // 128-token single pass: 4 activation blocks per wave
     static constexpr int nst = WMODE == WIDE_MIXF ? 5 : 3;                    // LDS stages
     static constexpr int xtb = mix ? 8192 : 16384;                            // activation bytes of a stage
     static constexpr int stg = (WMODE == WIDE_MIXF) ? 24576 : 32768;          // stage stride
@@ -114,9 +118,16 @@ template <int WMODE>
 __device__ __forceinline__ void cfg_tile_setup(const GemmArgs& p, int vb, LoadCur& lc) {
     int tile_m, tile_n;
     xcd_grouped_tile(vb, p.tiles_m, p.tiles_n, 8, tile_m, tile_n);
-    constexpr int TROWS = (WMODE == WIDE_GEGLU) ? 2 * TOK : TOK;      // activation rows of a tile per operand
+    constexpr int TROWS = (WMODE == WIDE_GEGLU || WMODE == WIDE_MIX2) ? 2 * TOK : TOK;      // activation rows of a tile
     const int m0 = tile_m * TROWS, n0 = tile_n * BN;
     const int rows_left = p.M - m0;                                                     // > 0
+    if constexpr (WMODE == WIDE_MIX2) {      // descriptor 0: tokens [m0, m0 + 128), descriptor 1: tokens [m0 + 128, m0 + 256)
+        const int r0 = rows_left < TOK ? rows_left : TOK, r1 = rows_left - TOK < 0 ? 0 : (rows_left - TOK < TOK ? rows_left - TOK : TOK);
+        lc.x[0] = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.X + (size_t)m0 * p.ldx), 0, (unsigned)r0 * (unsigned)p.ldx * 2u, 0x00020000);
+        lc.x[1] = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.X + (size_t)(m0 + (r1 ? TOK : 0)) * p.ldx), 0, (unsigned)r1 * (unsigned)p.ldx * 2u, 0x00020000);
+        lc.w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W + (size_t)n0 * p.ldw), 0, (unsigned)BN * (unsigned)p.ldw * 2u, 0x00020000);
+        return;
+    }
     const int xrows = rows_left < TROWS ? rows_left : TROWS;
     const unsigned xbytes = (unsigned)xrows * (unsigned)p.ldx * 2u;                     // reads past the last real row return 0
     lc.x[0] = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.X + (size_t)m0 * p.ldx), 0, xbytes, 0x00020000);
@@ -130,6 +141,9 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
     typedef Geo<WMODE> G_;
     constexpr int NST = G_::nst, STG_B = G_::stg, XT_B = G_::woff;      // (shadow the file-level three-stage constants)
     constexpr bool MIXK = G_::mix;                                      // one mixed pass: 4 activation blocks per wave, 3 DMA instructions per step
+    constexpr bool MIX2 = WMODE == WIDE_MIX2;                           // 256-token single pass on the two-pass tile's geometry
+    constexpr bool TWOX = WMODE == WIDE_CFG || MIX2;                    // two activation descriptors per stage (cond / null passes, or tokens 0..127 / 128..255)
+    constexpr int TTOK = MIX2 ? 2 * TOK : TOK;                          // tokens of a tile (TOKT modes)
     unsigned char* ct = smem + G_::ct_off;
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -164,12 +178,12 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
         for (int i = 0; i < 2; ++i) {
             const int xb = 2 * wid + i;
             // WIDE_MIX: 8 activation blocks per stage, this wave stages block wid (voff_x[1] unused)
-            const int xrow = (WMODE == WIDE_CFG) ? (xb >> 3) * 64 + (xb & 3) * 16 + (lane >> 2) : (MIXK ? wid * 16 + (lane >> 2) : xb * 16 + (lane >> 2));
+            const int xrow = TWOX ? (xb >> 3) * 64 + (xb & 3) * 16 + (lane >> 2) : (MIXK ? wid * 16 + (lane >> 2) : xb * 16 + (lane >> 2));
             voff_x[i] = xrow * p.ldx * 2 + c * 16;
             voff_w[i] = (xb * 16 + (lane >> 2)) * p.ldw * 2 + c * 16;
         }
     }
-    const bool x_null0 = (WMODE == WIDE_CFG) && (((2 * wid) >> 2) & 1);      // wave-uniform: blocks 2*wid and 2*wid + 1 share the pass
+    const bool x_null0 = TWOX && (((2 * wid) >> 2) & 1);      // wave-uniform: blocks 2*wid and 2*wid + 1 share the pass
 #define LOAD_NEXT(st_)                                                                                         \
     if (l_live) {                                                                                              \
         if (!ABL(p, 2)) {                                                                                      \
@@ -202,9 +216,9 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
     // kept granule is stored straight to its slot (rank = kept granules of the token's 256-column piece in front of it).  The k-loop of a fused
     // launch carries no output work.
     // The counted waits only need a LOWER bound of what was issued behind a DMA (under-counting waits for more, never for less).
-    const bool fused = TOKT && (WMODE == WIDE_MIXF || p.fs_stats != nullptr);
-    unsigned char* xch = ct;                       // fused: [128 tokens][16 lane groups] keep nibbles (2 KiB) | (group max, group sum exp) (float2, 16 KiB)
-    float* lthr = reinterpret_cast<float*>(ct + 18432);     // fused: the tile's 128 per-token bounds (1 KiB, written by LDS-DMA at the tile's first k-step)
+    const bool fused = TOKT && (WMODE == WIDE_MIXF || MIX2 || p.fs_stats != nullptr);
+    unsigned char* xch = ct;                       // fused: [tokens][4 quarters] keep-nibble words (16 B per token) | [tokens][16 lane groups] (group max, group sum exp) (float2)
+    float* lthr = reinterpret_cast<float*>(ct + TTOK * (16 + 128));      // fused: the tile's per-token bounds (1 KiB, written by LDS-DMA at the tile's first k-step)
     const __amdgpu_buffer_rsrc_t thr_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fused ? p.fs_thr : nullptr), 0, fused ? (unsigned)p.M * 4u : 0u, 0x00020000);
     f32x4_t acc[4][8];
     f32x4_t held[2][4];             // second half of the previous tile's output (tokens 32..63 of this wave), combined
@@ -295,7 +309,7 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
         if (TOKT && fused && kt == 0 && wid == 0) {         /* this tile's per-token bounds -> LDS (one more DMA of wave 0: its counted waits */ \
             int tm_, tn_;                                   /* under-count by one for two steps, which only waits for more) */ \
             xcd_grouped_tile(vb, p.tiles_m, p.tiles_n, 8, tm_, tn_);                                           \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(thr_rs, (lds_ptr_t)(lthr), 16, lane * 16, tm_ * TOK * 4, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(thr_rs, (lds_ptr_t)(lthr), 16, lane * 16, tm_ * TTOK * 4, 0, 0); \
         }                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         if constexpr (!MIXK) { MFMA_PAIR(AF_, p0, 2) }                                                         \
@@ -365,15 +379,19 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
             if (fused) {
                 // ---- fused-sampling emission straight from the accumulator fragments (see the comment at `fused`; canonical form: common.h)
                 emitted = true;
-                const int m0t = tile_m * TOK;
+                int le_ = lane;                                     // opaque copy: keeps the emission's per-lane address arithmetic out of the k-loop's
+                asm volatile("" : "+v"(le_));                       // live ranges (hoisted, it spilled loop-invariant values to scratch = VMEM traffic in the loop)
+                const int FR_ = le_ & 15, FG_ = le_ >> 4;
+                const int m0t = tile_m * TTOK;
+                constexpr int NBLK = MIX2 ? 8 : 4;                 // token blocks of 16 per wave
                 const int tilec = tile_n;                          // the piece index of this tile's 256 columns in a row of V / 256 pieces
-                unsigned char* xnib = xch;                                                  // [128 tokens][16 lane groups] keep nibbles (one byte each)
-                float2* xml = reinterpret_cast<float2*>(xch + 2048);                         // [128 tokens][16 lane groups] (ml, pl)
-                unsigned kbits[4];
+                uint32_t* xnib4 = reinterpret_cast<uint32_t*>(xch);                          // [128 tokens][4 quarters]: 4 keep nibbles (fragment a in byte a)
+                float2* xml = reinterpret_cast<float2*>(xch + TTOK * 16);                    // [tokens][16 lane groups] (ml, pl)
+                unsigned kbits = 0;                                                          // this lane's keep bits, 4 per token block
                 int nstore = 0;
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int tokl = wm * 64 + b * 16 + fr;
+                for (int b = 0; b < NBLK; ++b) {
+                    const int tokl = (b >> 2) * TOK + wm * 64 + (b & 3) * 16 + FR_;
                     const bool valid = m0t + tokl < p.M;
                     const float thr = lthr[tokl];
                     if constexpr (WMODE == WIDE_CFG) {      // combine the two passes in place: the null fragments are dead afterwards (mmp.py:254)
@@ -385,7 +403,7 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
                                 acc[a][b][r] = nl + (cv - nl) * p.cfg_scale;
                             }
                     }
-                    // this lane IS lane group (wn, fg) of the token: its 4 granules a = 0..3, no lane exchange anywhere
+                    // this lane IS lane group (wn, FG_) of the token: its 4 granules a = 0..3, no lane exchange anywhere
                     float gm[4];
 #pragma unroll
                     for (int a = 0; a < 4; ++a) gm[a] = fmaxf(fmaxf(acc[a][b][0], acc[a][b][1]), fmaxf(acc[a][b][2], acc[a][b][3]));
@@ -395,23 +413,34 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
                     for (int a = 0; a < 4; ++a)
                         gs[a] = (__expf(acc[a][b][0] - ml) + __expf(acc[a][b][1] - ml)) + (__expf(acc[a][b][2] - ml) + __expf(acc[a][b][3] - ml));
                     const float pl = (gs[0] + gs[1]) + (gs[2] + gs[3]);
-                    unsigned kb = 0;
+                    // keep bits.  The piece's mask is in row-layout order j = 16 wn + 4 a + FG_; the four lane groups of a token hold bits 4 a + 0..3
+                    // of fragment a, collected from the wave's ballot (lane = 16 FG_ + FR_) into one nibble per (token, fragment)
+                    unsigned kb = 0, nib4 = 0;
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) kb |= (valid && gm[a] >= thr) ? (1u << a) : 0u;
-                    kbits[b] = kb;
-                    xnib[tokl * 16 + wn * 4 + fg] = (unsigned char)kb;
-                    xml[tokl * 16 + wn * 4 + fg] = make_float2(ml, pl);
+                    for (int a = 0; a < 4; ++a) {
+                        const bool kp = valid && gm[a] >= thr;
+                        kb |= kp ? (1u << a) : 0u;
+                        const unsigned long long bal = __ballot(kp);
+                        const uint32_t lo = (uint32_t)bal, hi = (uint32_t)(bal >> 32);
+                        const uint32_t nb = ((lo >> FR_) & 1u) | (((lo >> (16 + FR_)) & 1u) << 1) | (((hi >> FR_) & 1u) << 2) | (((hi >> (16 + FR_)) & 1u) << 3);
+                        nib4 |= nb << (8 * a);
+                    }
+                    kbits |= kb << (4 * b);
+                    if (FG_ == 0) xnib4[tokl * 4 + wn] = nib4;      // bytes a = 0..3 of quarter wn: 0x0n0n0n0n
+                    xml[tokl * 16 + wn * 4 + FG_] = make_float2(ml, pl);
                 }
+                TSTAMP()
                 WAIT_LGKM0();
                 __builtin_amdgcn_s_barrier();      // all 16 lane groups of every token have published their nibble and (ml, pl)
+                TSTAMP()
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int tokl = wm * 64 + b * 16 + fr;
+                for (int b = 0; b < NBLK; ++b) {
+                    const int tokl = (b >> 2) * TOK + wm * 64 + (b & 3) * 16 + FR_;
                     const int tok = m0t + tokl;
-                    uint4 nb = *reinterpret_cast<const uint4*>(xnib + tokl * 16);      // 16 bytes = the 16 groups' nibbles, quarter by quarter
+                    uint4 nb = *reinterpret_cast<const uint4*>(xnib4 + tokl * 4);      // the 4 quarters' nibble words
                     uint32_t h16[4] = {nb.x, nb.y, nb.z, nb.w};
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {                                      // 0x0n0n0n0n -> 0xnnnn (group f of the quarter in bits 4 f .. 4 f + 3)
+                    for (int q = 0; q < 4; ++q) {                                      // 0x0n0n0n0n -> 0xnnnn (fragment a of the quarter in bits 4 a .. 4 a + 3)
                         h16[q] = (h16[q] | (h16[q] >> 4)) & 0x00FF00FFu;
                         h16[q] = (h16[q] | (h16[q] >> 8)) & 0x0000FFFFu;
                     }
@@ -419,32 +448,41 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
                     float4* slot = p.fs_cand + ((size_t)tok * p.tiles_n + tilec) * FS_SLOT;
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
-                        const int jn = wn * 16 + fg * 4 + a;            // granule number (common.h granule_number)
-                        const bool kp = (kbits[b] >> a) & 1u;
+                        const int jn = wn * 16 + a * 4 + FG_;            // the granule's position in the piece (column / 4): lane groups FG_ = 0..3 adjacent
+                        const bool kp = (kbits >> (4 * b + a)) & 1u;
                         if (__ballot(kp) != 0ull) {                     // wave-uniform: the store below is ISSUED (exact VMEM count for the waits)
                             if (kp) slot[__popcll(mask64 & ((1ull << jn) - 1ull))] = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
                             ++nstore;
                         }
                     }
-                    if (b == wn) {      // one record per (token, piece): this wave combines the 16 tokens of token block b == wn (its lanes fg == 0)
-                        const bool w_ = fg == 0 && tok < p.M;
+                    if ((b & 3) == wn) {      // one record per (token, piece): this wave combines the 16 tokens of the token blocks b with (b & 3) == wn (its lanes FG_ == 0)
+                        const bool w_ = FG_ == 0 && tok < p.M;
                         if (__ballot(w_) != 0ull) {
                             if (w_) {
-                                float mq[16], pq[16];
+                                // tile_combine16 (common.h) streamed from LDS in two sweeps (max, then the weighted sums in the canonical order):
+                                // 32 live values would not fit beside 128 accumulator registers
+                                const float2* gq = xml + tokl * 16;
+                                float M_ = -INFINITY;
 #pragma unroll
                                 for (int i = 0; i < 8; ++i) {
-                                    const float4 v2 = *reinterpret_cast<const float4*>(xml + tokl * 16 + 2 * i);
-                                    mq[2 * i] = v2.x; pq[2 * i] = v2.y; mq[2 * i + 1] = v2.z; pq[2 * i + 1] = v2.w;
+                                    const float4 v2 = *reinterpret_cast<const float4*>(gq + 2 * i);
+                                    M_ = fmaxf(M_, fmaxf(v2.x, v2.z));
                                 }
-                                float M_, E_;
-                                tile_combine16(mq, pq, M_, E_);
+                                float wq[4];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const float4 u = *reinterpret_cast<const float4*>(gq + 4 * q), v2 = *reinterpret_cast<const float4*>(gq + 4 * q + 2);
+                                    wq[q] = (u.y * __expf(u.x - M_) + u.w * __expf(u.z - M_)) + (v2.y * __expf(v2.x - M_) + v2.w * __expf(v2.z - M_));
+                                }
+                                const float E_ = (wq[0] + wq[1]) + (wq[2] + wq[3]);
                                 p.fs_stats[(size_t)tok * p.tiles_n + tilec] = make_float4(M_, E_, __uint_as_float((uint32_t)mask64), __uint_as_float((uint32_t)(mask64 >> 32)));
                             }
                             ++nstore;
                         }
                     }
                 }
-                st1 += nstore;      // issued after this wave's last DMA: the next two steps' counted waits allow for them
+                st1 += nstore;      // issued after this wave's last DMA: the next NST - 1 steps' counted waits allow for them
+                TSTAMP()
             }
         }
         if constexpr (TOKT) {
@@ -563,16 +601,21 @@ int mm_gemm_cfg2_launch(GemmArgs a, hipStream_t stream) {
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cfg2_kernel<WIDE_GEGLU>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cfg2_kernel<WIDE_MIX>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cfg2_kernel<WIDE_MIXF>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_cfg2_kernel<WIDE_MIX2>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
         if (e != hipSuccess) return mm_set_hip_error(e, "gemm_cfg2 hipFuncSetAttribute");
         attr_set = true;
     }
     const bool cfg = a.mode == MODE_CFG;
     const bool mix = a.mode == MODE_DENSE && a.wide_tok && a.epi == EPI_NONE;
+    // fused single pass: 256-token tiles when the launch has enough rows to fill them (fewer operand bytes per flop), 128-token tiles with five stages
+    // otherwise (debug bits, A/B only: 1 << 26 three-stage 128-token kernel, 1 << 28 no 256-token tiles; the values are the same)
+    const bool mix2 = mix && a.fs_stats && a.M >= 1024 && !(g_mm_debug & ((1 << 26) | (1 << 28)));
     a.tiles_n = a.N / BN;
-    a.tiles_m = (cfg || mix) ? (a.M + TOK - 1) / TOK : (a.M + 2 * TOK - 1) / (2 * TOK);
+    a.tiles_m = ((cfg || mix) && !mix2) ? (a.M + TOK - 1) / TOK : (a.M + 2 * TOK - 1) / (2 * TOK);
     const int total = a.tiles_m * a.tiles_n;
     const int grid = total < 256 ? total : 256;
     if (cfg) hipLaunchKernelGGL(gemm_cfg2_kernel<WIDE_CFG>, dim3(grid), dim3(512), SMEM_B, stream, a);
+    else if (mix2) hipLaunchKernelGGL(gemm_cfg2_kernel<WIDE_MIX2>, dim3(grid), dim3(512), SMEM_B, stream, a);
     else if (mix && a.fs_stats && !(g_mm_debug & (1 << 26))) hipLaunchKernelGGL(gemm_cfg2_kernel<WIDE_MIXF>, dim3(grid), dim3(512), SMEM_B, stream, a);      // (bit 1 << 26: A/B against three stages)
     else if (mix) hipLaunchKernelGGL(gemm_cfg2_kernel<WIDE_MIX>, dim3(grid), dim3(512), SMEM_B, stream, a);
     else hipLaunchKernelGGL(gemm_cfg2_kernel<WIDE_GEGLU>, dim3(grid), dim3(512), SMEM_B, stream, a);
