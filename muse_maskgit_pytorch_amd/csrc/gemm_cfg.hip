@@ -80,6 +80,14 @@ __device__ __forceinline__ uint4 lds_read_b128_raw(const unsigned char* ptr) {
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
+// max of 4 as two instructions (fmaxf would add a canonicalising v_max x, x per operand: these are MFMA results, never signalling NaNs)
+__device__ __forceinline__ float max4_asm(float a, float b, float c, float d) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(r), "v"(d));
+    return r;
+}
+
 // the logits are written once and read once by the sampler, 1.35 GB per launch against 4 MiB of L2 per XCD: a non-temporal store
 // keeps them from evicting the weight / activation tiles the other CUs of the XCD are about to re-read
 __device__ __forceinline__ void store_stream(float* ptr, const uint4 v) {
@@ -387,7 +395,6 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
                 const int tilec = tile_n;                          // the piece index of this tile's 256 columns in a row of V / 256 pieces
                 uint32_t* xnib4 = reinterpret_cast<uint32_t*>(xch);                          // [128 tokens][4 quarters]: 4 keep nibbles (fragment a in byte a)
                 float2* xml = reinterpret_cast<float2*>(xch + TTOK * 16);                    // [tokens][16 lane groups] (ml, pl)
-                unsigned kbits = 0;                                                          // this lane's keep bits, 4 per token block
                 int nstore = 0;
 #pragma unroll
                 for (int b = 0; b < NBLK; ++b) {
@@ -406,12 +413,13 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
                     // this lane IS lane group (wn, FG_) of the token: its 4 granules a = 0..3, no lane exchange anywhere
                     float gm[4];
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) gm[a] = fmaxf(fmaxf(acc[a][b][0], acc[a][b][1]), fmaxf(acc[a][b][2], acc[a][b][3]));
-                    const float ml = fmaxf(fmaxf(gm[0], gm[1]), fmaxf(gm[2], gm[3]));
+                    for (int a = 0; a < 4; ++a) gm[a] = max4_asm(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+                    const float ml = max4_asm(gm[0], gm[1], gm[2], gm[3]);
+                    const float cl = -ml * 1.4426950408889634f;
                     float gs[4];
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
-                        gs[a] = (__expf(acc[a][b][0] - ml) + __expf(acc[a][b][1] - ml)) + (__expf(acc[a][b][2] - ml) + __expf(acc[a][b][3] - ml));
+                        gs[a] = (fs_exp(acc[a][b][0], cl) + fs_exp(acc[a][b][1], cl)) + (fs_exp(acc[a][b][2], cl) + fs_exp(acc[a][b][3], cl));
                     const float pl = (gs[0] + gs[1]) + (gs[2] + gs[3]);
                     // keep bits.  The piece's mask is in row-layout order j = 16 wn + 4 a + FG_; the four lane groups of a token hold bits 4 a + 0..3
                     // of fragment a, collected from the wave's ballot (lane = 16 FG_ + FR_) into one nibble per (token, fragment)
@@ -425,60 +433,59 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
                         const uint32_t nb = ((lo >> FR_) & 1u) | (((lo >> (16 + FR_)) & 1u) << 1) | (((hi >> FR_) & 1u) << 2) | (((hi >> (16 + FR_)) & 1u) << 3);
                         nib4 |= nb << (8 * a);
                     }
-                    kbits |= kb << (4 * b);
                     if (FG_ == 0) xnib4[tokl * 4 + wn] = nib4;      // bytes a = 0..3 of quarter wn: 0x0n0n0n0n
                     xml[tokl * 16 + wn * 4 + FG_] = make_float2(ml, pl);
+                    // this quarter's kept granules go out NOW (their sub-slot positions need nothing from the other three waves): the stores of one
+                    // token block are in flight while the next block's statistics are computed
+                    uint32_t m16 = (nib4 | (nib4 >> 4)) & 0x00FF00FFu;
+                    m16 = (m16 | (m16 >> 8)) & 0x0000FFFFu;          // bit 4 a + f of the quarter
+                    float4* slot = p.fs_cand + ((size_t)(m0t + tokl) * p.tiles_n + tilec) * FS_SLOT + wn * 16;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const bool kp = (kb >> a) & 1u;
+                        if (__ballot(kp) != 0ull) {                     // wave-uniform: the store below is ISSUED (exact VMEM count for the waits)
+                            if (kp) slot[__popc(m16 & ((1u << (4 * a + FG_)) - 1u))] = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+                            ++nstore;
+                        }
+                    }
                 }
                 TSTAMP()
                 WAIT_LGKM0();
                 __builtin_amdgcn_s_barrier();      // all 16 lane groups of every token have published their nibble and (ml, pl)
                 TSTAMP()
+                // one record per (token, piece): this wave combines the tokens of the token blocks b with (b & 3) == wn (its lanes FG_ == 0)
 #pragma unroll
-                for (int b = 0; b < NBLK; ++b) {
-                    const int tokl = (b >> 2) * TOK + wm * 64 + (b & 3) * 16 + FR_;
+                for (int hb = 0; hb < NBLK / 4; ++hb) {
+                    const int tokl = hb * TOK + wm * 64 + wn * 16 + FR_;
                     const int tok = m0t + tokl;
-                    uint4 nb = *reinterpret_cast<const uint4*>(xnib4 + tokl * 4);      // the 4 quarters' nibble words
-                    uint32_t h16[4] = {nb.x, nb.y, nb.z, nb.w};
+                    const bool w_ = FG_ == 0 && tok < p.M;
+                    if (__ballot(w_) != 0ull) {
+                        if (w_) {
+                            const uint4 nb = *reinterpret_cast<const uint4*>(xnib4 + tokl * 4);      // the 4 quarters' nibble words
+                            uint32_t h16[4] = {nb.x, nb.y, nb.z, nb.w};
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {                                      // 0x0n0n0n0n -> 0xnnnn (fragment a of the quarter in bits 4 a .. 4 a + 3)
-                        h16[q] = (h16[q] | (h16[q] >> 4)) & 0x00FF00FFu;
-                        h16[q] = (h16[q] | (h16[q] >> 8)) & 0x0000FFFFu;
-                    }
-                    const unsigned long long mask64 = (unsigned long long)(h16[0] | (h16[1] << 16)) | ((unsigned long long)(h16[2] | (h16[3] << 16)) << 32);
-                    float4* slot = p.fs_cand + ((size_t)tok * p.tiles_n + tilec) * FS_SLOT;
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        const int jn = wn * 16 + a * 4 + FG_;            // the granule's position in the piece (column / 4): lane groups FG_ = 0..3 adjacent
-                        const bool kp = (kbits >> (4 * b + a)) & 1u;
-                        if (__ballot(kp) != 0ull) {                     // wave-uniform: the store below is ISSUED (exact VMEM count for the waits)
-                            if (kp) slot[__popcll(mask64 & ((1ull << jn) - 1ull))] = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
-                            ++nstore;
-                        }
-                    }
-                    if ((b & 3) == wn) {      // one record per (token, piece): this wave combines the 16 tokens of the token blocks b with (b & 3) == wn (its lanes FG_ == 0)
-                        const bool w_ = FG_ == 0 && tok < p.M;
-                        if (__ballot(w_) != 0ull) {
-                            if (w_) {
-                                // tile_combine16 (common.h) streamed from LDS in two sweeps (max, then the weighted sums in the canonical order):
-                                // 32 live values would not fit beside 128 accumulator registers
-                                const float2* gq = xml + tokl * 16;
-                                float M_ = -INFINITY;
-#pragma unroll
-                                for (int i = 0; i < 8; ++i) {
-                                    const float4 v2 = *reinterpret_cast<const float4*>(gq + 2 * i);
-                                    M_ = fmaxf(M_, fmaxf(v2.x, v2.z));
-                                }
-                                float wq[4];
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    const float4 u = *reinterpret_cast<const float4*>(gq + 4 * q), v2 = *reinterpret_cast<const float4*>(gq + 4 * q + 2);
-                                    wq[q] = (u.y * __expf(u.x - M_) + u.w * __expf(u.z - M_)) + (v2.y * __expf(v2.x - M_) + v2.w * __expf(v2.z - M_));
-                                }
-                                const float E_ = (wq[0] + wq[1]) + (wq[2] + wq[3]);
-                                p.fs_stats[(size_t)tok * p.tiles_n + tilec] = make_float4(M_, E_, __uint_as_float((uint32_t)mask64), __uint_as_float((uint32_t)(mask64 >> 32)));
+                            for (int q = 0; q < 4; ++q) {                                      // 0x0n0n0n0n -> 0xnnnn (fragment a of the quarter in bits 4 a .. 4 a + 3)
+                                h16[q] = (h16[q] | (h16[q] >> 4)) & 0x00FF00FFu;
+                                h16[q] = (h16[q] | (h16[q] >> 8)) & 0x0000FFFFu;
                             }
-                            ++nstore;
+                            // tile_combine16 (common.h) streamed from LDS in two sweeps (max, then the weighted sums in the canonical order)
+                            const float2* gq = xml + tokl * 16;
+                            float M_ = -INFINITY;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const float4 v2 = *reinterpret_cast<const float4*>(gq + 2 * i);
+                                M_ = fmaxf(M_, fmaxf(v2.x, v2.z));
+                            }
+                            float wq[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float4 u = *reinterpret_cast<const float4*>(gq + 4 * q), v2 = *reinterpret_cast<const float4*>(gq + 4 * q + 2);
+                                wq[q] = (u.y * __expf(u.x - M_) + u.w * __expf(u.z - M_)) + (v2.y * __expf(v2.x - M_) + v2.w * __expf(v2.z - M_));
+                            }
+                            const float E_ = (wq[0] + wq[1]) + (wq[2] + wq[3]);
+                            p.fs_stats[(size_t)tok * p.tiles_n + tilec] = make_float4(M_, E_, __uint_as_float(h16[0] | (h16[1] << 16)), __uint_as_float(h16[2] | (h16[3] << 16)));
                         }
+                        ++nstore;
                     }
                 }
                 st1 += nstore;      // issued after this wave's last DMA: the next NST - 1 steps' counted waits allow for them

@@ -168,9 +168,9 @@ __global__ __launch_bounds__(FT, 2) void sample_fused_kernel(const FusedSampleAr
                 mine[u] = false;
                 v[u] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
                 if (t_ < NT) {
-                    const unsigned long long mask = S.masks[t_];      // bit j = granule j (columns 4 j .. 4 j + 3 of the piece) was kept; the slot is in ascending j
+                    const unsigned long long mask = S.masks[t_];      // bit j = granule j (columns 4 j .. 4 j + 3 of the piece) was kept; position in the slot: common.h fs_slot_index
                     mine[u] = (mask >> lane) & 1ull;
-                    if (mine[u]) v[u] = p.cand[((size_t)row * NT + t_) * FS_SLOT + __popcll(mask & ((1ull << lane) - 1ull))];
+                    if (mine[u]) v[u] = p.cand[((size_t)row * NT + t_) * FS_SLOT + fs_slot_index(mask, lane)];
                 }
             }
 #pragma unroll

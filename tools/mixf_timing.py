@@ -36,7 +36,7 @@ d = np.diff(t, axis=1)
 mid = slice(2, ntiles - 1)
 print('prologue:', t[0, 0] - ts[0], 'cycles')
 print('mean cycles per k-step index:', np.round(d[mid, :KT - 0].mean(0)[:KT], 0))
-names = ['loop end -> tile-end barrier passed', 'statistics + LDS publish', 'exchange barrier', 'ranks + candidate / statistics stores issued']
+names = ['loop end -> tile-end barrier passed', 'statistics + candidate stores + LDS publish', 'exchange barrier', 'statistics records']
 for i, nme in enumerate(names):
     print(f'{nme:45s}', round(d[mid, KT + i].mean()))
 nxt = t[1:, 0] - t[:-1, -1]
