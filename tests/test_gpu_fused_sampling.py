@@ -67,6 +67,16 @@ def test_fused_sample_hot_tile_and_failure_paths():
     assert int(fb['fail'].item()) == 1
 
 
+def _valid_slots(stats):
+    """which of the 64 slot entries of every (row, piece) hold a candidate: the slot is four sub-slots of 16 (one per 64-column quarter), sub-slot q
+    holds as many entries as quarter q's 16 mask bits have set (common.h fs_slot_index)"""
+    m = stats[..., 2:].contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF           # [R, NT, 2]: mask bits 0..31, 32..63
+    q16 = torch.stack([m[..., 0] & 0xFFFF, m[..., 0] >> 16, m[..., 1] & 0xFFFF, m[..., 1] >> 16], dim=-1)      # [R, NT, 4]
+    cnt = sum(((q16 >> b) & 1) for b in range(16))                                            # kept granules per quarter
+    pos = torch.arange(ops.FUSED_SLOT, device=stats.device)
+    return (pos[None, None, :] & 15) < cnt[..., (pos >> 4)]
+
+
 @pytest.mark.parametrize("M", [4608, 5140, 129, 135, 391, 3])      # 135 = B 1 x k 135 (ADVICE r2: edge tiles with 1..7 rows; waves without a piece must not count a statistics store)
 def test_gemm_emission_equals_emission_from_its_logits(M):
     """the guidance-logits GEMM with the fused epilogue emits exactly what fused_emit computes from the logits the plain GEMM writes;
@@ -90,9 +100,7 @@ def test_gemm_emission_equals_emission_from_its_logits(M):
     ops.fused_emit(logits, thr, fa)
     ops.gemm_cfg_logits_fused(ec, en, W, s, thr, fb)
     assert torch.equal(fa['stats'].view(torch.int32), fb['stats'].view(torch.int32))
-    masks = fa['stats'][..., 2:].contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
-    lanes = sum(((masks >> b) & 1) for b in range(32)).sum(dim=-1)                          # kept lanes per (row, tile)
-    valid = torch.arange(ops.FUSED_SLOT, device=DEV)[None, None, :] < lanes[..., None]
+    valid = _valid_slots(fa['stats'])
     assert torch.equal(fa['cand'][valid].view(torch.int32), fb['cand'][valid].view(torch.int32))
     total = (logits >= thr[:, None]).sum(dim=1)
     assert int(total.min().item()) >= k_keep and int(total.max().item()) < 11264
@@ -106,9 +114,7 @@ def test_gemm_emission_equals_emission_from_its_logits(M):
     ops.fused_emit(lm.contiguous(), thr_m, fm)
     ops.gemm_cfg_logits_fused(em, None, W, 1.0, thr_m, fn)
     assert torch.equal(fm['stats'].view(torch.int32), fn['stats'].view(torch.int32))
-    masks_m = fm['stats'][..., 2:].contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
-    lanes_m = sum(((masks_m >> b) & 1) for b in range(32)).sum(dim=-1)
-    valid_m = torch.arange(ops.FUSED_SLOT, device=DEV)[None, None, :] < lanes_m[..., None]
+    valid_m = _valid_slots(fm['stats'])
     assert torch.equal(fm['cand'][valid_m].view(torch.int32), fn['cand'][valid_m].view(torch.int32))
     pm, sm = ops.fused_sample(fn, thr_m, M, V, k_keep, 1.0, noise_kind=_lib.MM_NOISE_PHILOX, seed=3)
     rp_, rs_ = ops.sample_rows(lm.contiguous(), k_keep, 1.0, noise_kind=_lib.MM_NOISE_PHILOX, seed=3)
