@@ -160,7 +160,7 @@ constexpr int FS_SLOT = 64;
 // bit-identical whichever path sampled the row.  The form is the one the GEMM's accumulator layout gives WITHOUT any lane exchange: a piece is 4
 // quarters q of 64 columns (one per wave of the GEMM's vocabulary split); in a quarter, column c = 16 a + 4 f + r is value r of granule (a, f) --
 // GEMM: accumulator fragment a of lane group f, which holds the 4 granules a = 0..3 of its f.  Per LANE GROUP (q, f):
-//     ml = max of its 16 values;   g(a) = (e0 + e1) + (e2 + e3),  e_r = exp2(fma(x_r, log2 e, -ml log2 e))  (fs_exp: one FMA + v_exp_f32);
+//     ml = max of its 16 values;   g(a) = (e0 + e1) + (e2 + e3),  e_r = exp2((x_r - ml) log2 e)  (fs_exp: v_exp_f32);
 //     pl = (g(0) + g(1)) + (g(2) + g(3))
 // and over the 16 groups of the piece:
 //     M = max ml;   t(q, f) = pl * exp(ml - M);   w(q) = (t(q,0) + t(q,1)) + (t(q,2) + t(q,3));   E = (w(0) + w(1)) + (w(2) + w(3))
@@ -173,8 +173,9 @@ __device__ __forceinline__ int fs_slot_index(unsigned long long mask, int j) {
     const uint32_t m16 = (uint32_t)(mask >> (j & 48)) & 0xFFFFu;
     return (j & 48) + __popc(m16 & ((1u << (j & 15)) - 1u));
 }
-// exp(x - ml) with c = -ml * log2(e) prepared once per lane group: one FMA + v_exp_f32 (x <= ml: no overflow; far tails flush to 0)
-__device__ __forceinline__ float fs_exp(float x, float c) { return __builtin_amdgcn_exp2f(__builtin_fmaf(x, 1.4426950408889634f, c)); }
+// exp(x - ml) as v_exp_f32((x - ml) * log2 e): the subtraction first -- exact near the maximum, so the largest value contributes exactly 1 (an FMA
+// form x * log2 e - ml * log2 e rounds the product of the MAGNITUDES: 2e-6 off at |ml| ~ 40, enough to push a dominant token's 1 - p below 0)
+__device__ __forceinline__ float fs_exp(float x, float ml) { return __builtin_amdgcn_exp2f((x - ml) * 1.4426950408889634f); }
 __device__ __forceinline__ void tile_combine16(const float (&ml)[16], const float (&pl)[16], float& M, float& E) {
     float m = ml[0];
 #pragma unroll
@@ -193,8 +194,7 @@ __device__ __forceinline__ void tile_softmax_stats(const float4 x, float& M, flo
     float ml = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
     ml = fmaxf(ml, __shfl_xor(ml, 4, 64));      // over a (lanes f, 4 + f, 8 + f, 12 + f of the 16-lane row)
     ml = fmaxf(ml, __shfl_xor(ml, 8, 64));
-    const float cl = -ml * 1.4426950408889634f;
-    float pl = (fs_exp(x.x, cl) + fs_exp(x.y, cl)) + (fs_exp(x.z, cl) + fs_exp(x.w, cl));      // g(a)
+    float pl = (fs_exp(x.x, ml) + fs_exp(x.y, ml)) + (fs_exp(x.z, ml) + fs_exp(x.w, ml));      // g(a)
     pl += __shfl_xor(pl, 4, 64);                // g(a) + g(a ^ 1)
     pl += __shfl_xor(pl, 8, 64);                // (g(0) + g(1)) + (g(2) + g(3))
     float mr = fmaxf(ml, MM_DPP_F(ml, 0xB1));   // over f: the row's (quarter's) max

@@ -415,11 +415,10 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
 #pragma unroll
                     for (int a = 0; a < 4; ++a) gm[a] = max4_asm(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
                     const float ml = max4_asm(gm[0], gm[1], gm[2], gm[3]);
-                    const float cl = -ml * 1.4426950408889634f;
                     float gs[4];
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
-                        gs[a] = (fs_exp(acc[a][b][0], cl) + fs_exp(acc[a][b][1], cl)) + (fs_exp(acc[a][b][2], cl) + fs_exp(acc[a][b][3], cl));
+                        gs[a] = (fs_exp(acc[a][b][0], ml) + fs_exp(acc[a][b][1], ml)) + (fs_exp(acc[a][b][2], ml) + fs_exp(acc[a][b][3], ml));
                     const float pl = (gs[0] + gs[1]) + (gs[2] + gs[3]);
                     // keep bits.  The piece's mask is in row-layout order j = 16 wn + 4 a + FG_; the four lane groups of a token hold bits 4 a + 0..3
                     // of fragment a, collected from the wave's ballot (lane = 16 FG_ + FR_) into one nibble per (token, fragment)

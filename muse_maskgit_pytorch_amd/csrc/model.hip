@@ -505,7 +505,7 @@ int mm_transformer_forward(const mm_transformer_t* t, mm_stream_t stream, const 
 // ------------------------------------------------------------------------------------------------ generate
 namespace {
 #ifndef MM_FS_MARGIN
-#define MM_FS_MARGIN 0.20f
+#define MM_FS_MARGIN 0.12f
 #endif
 constexpr int FB_CAP = 128;      // rows per step the on-device fallback can finish (one row tile of the 128 x 128 GEMM); more raise the status flag
 constexpr int FB_STEPS = 1024;   // per-step counters carved (timesteps beyond this run without the list: flag only)
