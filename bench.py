@@ -486,7 +486,7 @@ def main():
                              'traffic': traffic_of('sample_fused_kernel' if fused_on else 'sample_kernel') if metric_cfg else None,
                              'algorithmic_bytes_per_launch': s_bytes / s_cnt if s_cnt else None,
                              'launches': s_cnt, 'avg_launch_ms': s_ms / s_cnt if s_cnt else None},
-            'multi_gpu': ({'ranks_in_process_group': dist.get_world_size(), 'backend': dist.get_backend(), 'ids_gather': 'mm_allgather_ids (library-owned RCCL communicator)',
+            'multi_gpu': ({'ranks_in_process_group': dist.get_world_size(), 'backend': dist.get_backend(), 'ids_gather': allgather_ids.last_transport, 'ids_gather_error': allgather_ids.last_error,
                            'devices_visible_to_rank0': torch.cuda.device_count(), 'per_rank_elapsed_s': {'min': min(rank_times), 'max': max(rank_times)},
                            'per_rank_images_per_s': [B * args.steps / t_ for t_ in rank_times]} if dist is not None else None),
             'fused_sampling': {'enabled': fused_on, 'fallbacks_to_logits_path': mg.fused_sampling_fallbacks, 'rows_finished_by_on_device_fallback': mg.fused_row_fallbacks},

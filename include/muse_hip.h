@@ -96,7 +96,7 @@ int mm_attend(mm_stream_t stream, const void* q, int64_t q_sb, int64_t q_sh, int
               int64_t k_sb, int64_t k_sh, int64_t k_sn, const void* v, int64_t v_sb, int64_t v_sh, int64_t v_sn,
               void* out, int64_t o_sb, int64_t o_sh, int64_t o_sn, int B, int H, int nq, int nk,
               const uint8_t* key_mask, int64_t km_sb, int normalize, const float* q_scale, const float* k_scale,
-              const float* null_k, const float* null_v, float scale);
+              const float* null_k, const float* null_v, float scale, int dim_head);
 
 /* Re-mask step (mmp.py:558-563): per sample the k highest scores (ties: lower index) get ids = mask_id; every
  * other slot's score becomes -1e5 (what mmp.py:609 leaves there).  rows_out (optional int32 [B*k]) receives the
@@ -334,11 +334,11 @@ int mm_f32_embed(mm_stream_t stream, const int64_t* ids, int64_t rows, int n, co
                  float* x, int64_t ldx);
 /* mask[row] = any(text_embeds[row] != 0)  (mmp.py:304) */
 int mm_f32_text_mask(mm_stream_t stream, const float* text_embeds, int64_t rows, int D, uint8_t* mask);
-/* mm_attend semantics (attend.py:109-140 + mmp.py:145-157) on fp32 operands, dim_head 64 */
+/* mm_attend semantics (attend.py:109-140 + mmp.py:145-157) on fp32 operands, dim_head 32 / 64 / 128 */
 int mm_f32_attend(mm_stream_t stream, const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const float* k, int64_t k_sb, int64_t k_sh, int64_t k_sn,
                   const float* v, int64_t v_sb, int64_t v_sh, int64_t v_sn, float* out, int64_t o_sb, int64_t o_sh, int64_t o_sn, int B, int H, int nq, int nk,
                   const uint8_t* key_mask, int64_t km_sb, int normalize, const float* q_scale, const float* k_scale, const float* null_k,
-                  const float* null_v, float scale);
+                  const float* null_v, float scale, int dim_head);
 int mm_f32_glu_nhwc(mm_stream_t stream, const float* x, int64_t rows, int C, float* out);
 int mm_f32_groupnorm_nhwc(mm_stream_t stream, const float* x, int B, int HW, int C, int groups, const float* gamma, const float* beta, int act,
                           float* out);

@@ -2,7 +2,7 @@
 
 The reference's `flash=True` default never reaches a fused kernel (attend.py:93-94 raises on purpose and falls
 back to a pure-PyTorch tiled softmax); both of its branches compute softmax(scale * q k^T, mask) v.  Here that
-is one MFMA flash kernel (csrc/attention.hip) behind `mm_attend`.  dim_head must be 64.
+is one MFMA flash kernel behind `mm_attend` (csrc/attention.hip for dim_head 64, csrc/attention_f32.hip for 32 / 128).
 """
 import torch
 from torch import nn

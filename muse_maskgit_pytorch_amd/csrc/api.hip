@@ -183,9 +183,10 @@ int mm_attend(mm_stream_t stream, const void* q, int64_t q_sb, int64_t q_sh, int
               int64_t k_sb, int64_t k_sh, int64_t k_sn, const void* v, int64_t v_sb, int64_t v_sh, int64_t v_sn,
               void* out, int64_t o_sb, int64_t o_sh, int64_t o_sn, int B, int H, int nq, int nk,
               const uint8_t* key_mask, int64_t km_sb, int normalize, const float* q_scale, const float* k_scale,
-              const float* null_k, const float* null_v, float scale) {
+              const float* null_k, const float* null_v, float scale, int dim_head) {
     CHK_PTR(q, "q"); CHK_PTR(k, "k"); CHK_PTR(v, "v"); CHK_PTR(out, "out");
     CHK_ALIGN16(q, "q"); CHK_ALIGN16(k, "k"); CHK_ALIGN16(v, "v");
+    if (dim_head != 32 && dim_head != 64 && dim_head != 128) return mm_set_error(MM_ERR_UNSUPPORTED, "attend: dim_head must be 32, 64 or 128");
     if ((null_k == nullptr) != (null_v == nullptr)) return mm_set_error(MM_ERR_SHAPE, "attend: null_k and null_v go together");
     AttnArgs a;
     memset(&a, 0, sizeof(a));
@@ -196,7 +197,7 @@ int mm_attend(mm_stream_t stream, const void* q, int64_t q_sb, int64_t q_sh, int
     a.B = B; a.H = H; a.nq = nq; a.nk = nk;
     a.key_mask = key_mask; a.km_sb = km_sb;
     a.normalize = normalize; a.q_scale = q_scale; a.k_scale = k_scale;
-    a.null_k = null_k; a.null_v = null_v; a.scale = scale; a.kv_batch_mod = 0;
+    a.null_k = null_k; a.null_v = null_v; a.scale = scale; a.kv_batch_mod = 0; a.dh = dim_head;
     return k_attention((hipStream_t)stream, a);
 }
 

@@ -13,6 +13,8 @@
 //   * O = P V on MFMA; V is transposed while it is staged into LDS (keys become the contiguous axis).
 //   LDS: K tile 8 KiB + V^T tile 8 KiB + 4 x 2 KiB P, all in 128-byte rows with the 16-byte chunk index
 //   XOR (row & 7)  -> conflict-free ds_read_b128 fragment reads.
+#include <string.h>
+
 #include "common.h"
 #include "muse_hip_internal.h"
 
@@ -525,6 +527,20 @@ int k_attention(hipStream_t s, const AttnArgs& a_in) {
     AttnArgs a = a_in;
     a.debug = g_mm_debug;
     if (a.B <= 0 || a.H <= 0 || a.nq <= 0) return MM_OK;
+    if (a.dh != 0 && a.dh != 64) {
+        // dim_head 32 / 128 (muse_maskgit_pytorch.py:165-174 accepts any): the kernels of this file are built around 64-wide heads; the
+        // fp32-MFMA kernel of attention_f32.hip is templated on the head width and reads / writes the bf16 operands directly
+        AttnF32Args f;
+        memset(&f, 0, sizeof(f));
+        f.q = a.q; f.q_sb = a.q_sb; f.q_sh = a.q_sh; f.q_sn = a.q_sn;
+        f.k = a.k; f.k_sb = a.k_sb; f.k_sh = a.k_sh; f.k_sn = a.k_sn;
+        f.v = a.v; f.v_sb = a.v_sb; f.v_sh = a.v_sh; f.v_sn = a.v_sn;
+        f.out = a.out; f.o_sb = a.o_sb; f.o_sh = a.o_sh; f.o_sn = a.o_sn;
+        f.B = a.B; f.H = a.H; f.nq = a.nq; f.nk = a.nk; f.key_mask = a.key_mask; f.km_sb = a.km_sb; f.normalize = a.normalize;
+        f.q_scale = a.q_scale; f.k_scale = a.k_scale; f.null_k = a.null_k; f.null_v = a.null_v; f.scale = a.scale;
+        f.kv_batch_mod = a.kv_batch_mod; f.dh = a.dh; f.io_bf16 = 1;
+        return k_attention_f32(s, f);
+    }
     if (a.nk < 0) return mm_set_error(MM_ERR_SHAPE, "attention: nk < 0");
     if (a.nk == 0 && !a.null_k) return mm_set_error(MM_ERR_SHAPE, "attention: no keys at all");
     if ((a.q_sn % 8) || (a.k_sn % 8) || (a.v_sn % 8) || (a.q_sh % 8) || (a.k_sh % 8) || (a.v_sh % 8) ||

@@ -243,7 +243,7 @@ int ff_block(const mm_transformer* t, hipStream_t s, const mm_ff_weights& w, con
 
 // b.att = heads of SelfAttention(LN(x)) over `seqs` sequences of n tokens, before the output projection  (mmp.py:126-159, context = None)
 int self_attn_core(const mm_transformer* t, hipStream_t s, const mm_attn_weights& w, int seqs, int n, Bufs& b) {
-    const int D = t->d.dim, I = t->I, H = t->d.heads;
+    const int D = t->d.dim, I = t->I, H = t->d.heads, dh = t->d.dim_head;
     const int rows = seqs * n;
     if (t->P) {      // precision tier: q|k|v stay fp32, the attention runs on the fp32 MFMA and writes its output as P segments
         const int P = t->P;
@@ -259,13 +259,13 @@ int self_attn_core(const mm_transformer* t, hipStream_t s, const mm_attn_weights
         }
         AttnF32Args a;
         memset(&a, 0, sizeof(a));
-        a.q = qkv; a.q_sb = (long)n * 3 * I; a.q_sh = 64; a.q_sn = 3 * I;
-        a.k = qkv + I; a.k_sb = a.q_sb; a.k_sh = 64; a.k_sn = 3 * I;
-        a.v = qkv + 2 * I; a.v_sb = a.q_sb; a.v_sh = 64; a.v_sn = 3 * I;
+        a.q = qkv; a.q_sb = (long)n * 3 * I; a.q_sh = dh; a.q_sn = 3 * I;
+        a.k = qkv + I; a.k_sb = a.q_sb; a.k_sh = dh; a.k_sn = 3 * I;
+        a.v = qkv + 2 * I; a.v_sb = a.q_sb; a.v_sh = dh; a.v_sn = 3 * I;
         a.out_split = b.att; a.os_sb = (long)n * P * I; a.os_sn = (long)P * I; a.os_seg = I; a.P = P;
         a.B = seqs; a.H = H; a.nq = n; a.nk = n;
         a.normalize = 1; a.q_scale = w.q_scale; a.k_scale = w.k_scale; a.null_k = w.null_k; a.null_v = w.null_v;
-        a.scale = 8.f;
+        a.scale = 8.f; a.dh = dh;
         return k_attention_f32(s, a);
     }
     RC(k_layernorm(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, b.xn, D));
@@ -280,13 +280,13 @@ int self_attn_core(const mm_transformer* t, hipStream_t s, const mm_attn_weights
     }
     AttnArgs a;
     memset(&a, 0, sizeof(a));
-    a.q = b.qkv; a.q_sb = (long)n * 3 * I; a.q_sh = 64; a.q_sn = 3 * I;
-    a.k = b.qkv + I; a.k_sb = a.q_sb; a.k_sh = 64; a.k_sn = 3 * I;
-    a.v = b.qkv + 2 * I; a.v_sb = a.q_sb; a.v_sh = 64; a.v_sn = 3 * I;
-    a.out = b.att; a.o_sb = (long)n * I; a.o_sh = 64; a.o_sn = I;
+    a.q = b.qkv; a.q_sb = (long)n * 3 * I; a.q_sh = dh; a.q_sn = 3 * I;
+    a.k = b.qkv + I; a.k_sb = a.q_sb; a.k_sh = dh; a.k_sn = 3 * I;
+    a.v = b.qkv + 2 * I; a.v_sb = a.q_sb; a.v_sh = dh; a.v_sn = 3 * I;
+    a.out = b.att; a.o_sb = (long)n * I; a.o_sh = dh; a.o_sn = I;
     a.B = seqs; a.H = H; a.nq = n; a.nk = n;
     a.normalize = 1; a.q_scale = w.q_scale; a.k_scale = w.k_scale; a.null_k = w.null_k; a.null_v = w.null_v;
-    a.scale = 8.f;
+    a.scale = 8.f; a.dh = dh;
     TR(b.qkv, (size_t)rows * 3 * I * 2);
     RC(k_attention(s, a));
     TR(b.att, (size_t)rows * I * 2);
@@ -305,7 +305,7 @@ int self_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weight
 // x += CrossAttention(x, ctx) for `seqs` sequences; ckv = ctx @ to_kv^T given as [kv_seqs*m][2I]  (mmp.py:191)
 int cross_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weights& w, int seqs, int n, const bf16_t* ckv,
                      int m, int kv_batch_mod, const uint8_t* key_mask, Bufs& b) {
-    const int D = t->d.dim, I = t->I, H = t->d.heads;
+    const int D = t->d.dim, I = t->I, H = t->d.heads, dh = t->d.dim_head;
     const int rows = seqs * n;
     if (t->P) {      // precision tier: ckv is fp32 [kv_seqs*m][2I]
         const int P = t->P;
@@ -315,14 +315,14 @@ int cross_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weigh
         const float* kv = reinterpret_cast<const float*>(ckv);
         AttnF32Args a;
         memset(&a, 0, sizeof(a));
-        a.q = q; a.q_sb = (long)n * I; a.q_sh = 64; a.q_sn = I;
-        a.k = kv; a.k_sb = (long)m * 2 * I; a.k_sh = 64; a.k_sn = 2 * I;
-        a.v = kv + I; a.v_sb = a.k_sb; a.v_sh = 64; a.v_sn = 2 * I;
+        a.q = q; a.q_sb = (long)n * I; a.q_sh = dh; a.q_sn = I;
+        a.k = kv; a.k_sb = (long)m * 2 * I; a.k_sh = dh; a.k_sn = 2 * I;
+        a.v = kv + I; a.v_sb = a.k_sb; a.v_sh = dh; a.v_sn = 2 * I;
         a.out_split = b.att; a.os_sb = (long)n * P * I; a.os_sn = (long)P * I; a.os_seg = I; a.P = P;
         a.B = seqs; a.H = H; a.nq = n; a.nk = m;
         a.key_mask = key_mask; a.km_sb = m;
         a.normalize = 1; a.q_scale = w.q_scale; a.k_scale = w.k_scale; a.null_k = w.null_k; a.null_v = w.null_v;
-        a.scale = 8.f; a.kv_batch_mod = kv_batch_mod;
+        a.scale = 8.f; a.dh = dh; a.kv_batch_mod = kv_batch_mod;
         RC(k_attention_f32(s, a));
         RC(gemm_dense(s, b.att, P * I, (const bf16_t*)w.w_out, P * I, rows, D, P * I, b.x, D, OUT_F32, b.x));
         TR(b.x, (size_t)rows * D * 4);
@@ -334,14 +334,14 @@ int cross_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weigh
     TR(b.qkv, (size_t)rows * I * 2);
     AttnArgs a;
     memset(&a, 0, sizeof(a));
-    a.q = b.qkv; a.q_sb = (long)n * I; a.q_sh = 64; a.q_sn = I;
-    a.k = ckv; a.k_sb = (long)m * 2 * I; a.k_sh = 64; a.k_sn = 2 * I;
-    a.v = ckv + I; a.v_sb = a.k_sb; a.v_sh = 64; a.v_sn = 2 * I;
-    a.out = b.att; a.o_sb = (long)n * I; a.o_sh = 64; a.o_sn = I;
+    a.q = b.qkv; a.q_sb = (long)n * I; a.q_sh = dh; a.q_sn = I;
+    a.k = ckv; a.k_sb = (long)m * 2 * I; a.k_sh = dh; a.k_sn = 2 * I;
+    a.v = ckv + I; a.v_sb = a.k_sb; a.v_sh = dh; a.v_sn = 2 * I;
+    a.out = b.att; a.o_sb = (long)n * I; a.o_sh = dh; a.o_sn = I;
     a.B = seqs; a.H = H; a.nq = n; a.nk = m;
     a.key_mask = key_mask; a.km_sb = m;
     a.normalize = 1; a.q_scale = w.q_scale; a.k_scale = w.k_scale; a.null_k = w.null_k; a.null_v = w.null_v;
-    a.scale = 8.f; a.kv_batch_mod = kv_batch_mod;
+    a.scale = 8.f; a.dh = dh; a.kv_batch_mod = kv_batch_mod;
     RC(k_attention(s, a));
     TR(b.att, (size_t)rows * I * 2);
     RC(gemm_dense(s, b.att, I, (const bf16_t*)w.w_out, I, rows, D, I, b.x, D, OUT_F32, b.x));
@@ -361,7 +361,8 @@ extern "C" {
 int mm_transformer_create(const mm_transformer_desc* desc, mm_transformer_t** out) {
     if (!desc || !out) return mm_set_error(MM_ERR_SHAPE, "transformer_create: NULL argument");
     const mm_transformer_desc& d = *desc;
-    if (d.dim_head != 64) return mm_set_error(MM_ERR_UNSUPPORTED, "transformer: dim_head must be 64");
+    if (d.dim_head != 32 && d.dim_head != 64 && d.dim_head != 128) return mm_set_error(MM_ERR_UNSUPPORTED, "transformer: dim_head must be 32, 64 or 128");
+    if ((d.heads * d.dim_head) % 64) return mm_set_error(MM_ERR_SHAPE, "transformer: heads * dim_head must be a multiple of 64");
     if (d.dim <= 0 || d.dim % 64 || d.dim > 2048) return mm_set_error(MM_ERR_SHAPE, "transformer: dim must be a multiple of 64, <= 2048");
     if (d.depth <= 0 || d.heads <= 0 || !d.layers) return mm_set_error(MM_ERR_SHAPE, "transformer: depth/heads/layers");
     if (d.ff_inner_padded % 64 || d.ff_inner_padded < d.ff_inner) return mm_set_error(MM_ERR_SHAPE, "transformer: ff_inner_padded must be a multiple of 64 >= ff_inner");

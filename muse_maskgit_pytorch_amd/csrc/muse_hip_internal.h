@@ -88,6 +88,7 @@ struct AttnArgs {
     const float* q_scale; const float* k_scale;  // [64]
     const float* null_k; const float* null_v;    // optional [H][64] fp32 (raw parameter values)
     float scale;                                 // 8
+    int dh;                                      // dim_head (0 = 64).  != 64: served by the fp32-MFMA kernel of attention_f32.hip on the bf16 operands
     int kv_batch_mod;                            // > 0: k/v batch index = b % kv_batch_mod (CFG halves share one context)
     int debug;                                   // ablation bits 256 (no compute) / 512 (no staging) / 1024 (no softmax exp)
 };
@@ -134,10 +135,10 @@ int k_embed_f32(hipStream_t s, const int64_t* ids, long rows, int n, const float
 // e = en + (ec - en) * s on embedding rows: bf16 (P == 0, out [rows][D]) or term-segment packs (out [rows][P * D])
 int k_cfg_mix(hipStream_t s, const bf16_t* ec, const bf16_t* en, long ld, long rows, int D, int P, float cond_scale, bf16_t* out);
 struct AttnF32Args {
-    const float* q; long q_sb, q_sh, q_sn;       // element strides: batch, head, token (d contiguous, dh = 64)
-    const float* k; long k_sb, k_sh, k_sn;
-    const float* v; long v_sb, v_sh, v_sn;
-    float* out; long o_sb, o_sh, o_sn;           // optional fp32 output
+    const void* q; long q_sb, q_sh, q_sn;        // element strides: batch, head, token (d contiguous); fp32, or bf16 when io_bf16
+    const void* k; long k_sb, k_sh, k_sn;
+    const void* v; long v_sb, v_sh, v_sn;
+    void* out; long o_sb, o_sh, o_sn;            // optional output in the operand type
     bf16_t* out_split; long os_sb, os_sn; int os_seg, P;   // optional P-segment output: element (b, token, h, d) of segment s at b*os_sb + token*os_sn + s*os_seg + h*64 + d
     int B, H, nq, nk;
     const uint8_t* key_mask; long km_sb;
@@ -145,6 +146,8 @@ struct AttnF32Args {
     const float* q_scale; const float* k_scale; const float* null_k; const float* null_v;
     float scale;
     int kv_batch_mod;
+    int dh;                                      // dim_head: 32, 64 (0 = 64) or 128
+    int io_bf16;                                 // q / k / v / out are bf16 (the bf16 engine's route for dim_head != 64)
 };
 int k_attention_f32(hipStream_t s, const AttnF32Args& a);
 

@@ -518,8 +518,9 @@ int mm_f32_text_mask(mm_stream_t stream, const float* text_embeds, int64_t rows,
 int mm_f32_attend(mm_stream_t stream, const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const float* k, int64_t k_sb, int64_t k_sh, int64_t k_sn,
                   const float* v, int64_t v_sb, int64_t v_sh, int64_t v_sn, float* out, int64_t o_sb, int64_t o_sh, int64_t o_sn, int B, int H, int nq, int nk,
                   const uint8_t* key_mask, int64_t km_sb, int normalize, const float* q_scale, const float* k_scale, const float* null_k,
-                  const float* null_v, float scale) {
+                  const float* null_v, float scale, int dim_head) {
     if (B == 0 || H == 0 || nq == 0) return MM_OK;
+    if (dim_head != 32 && dim_head != 64 && dim_head != 128) return mm_set_error(MM_ERR_UNSUPPORTED, "f32 attend: dim_head must be 32, 64 or 128");
     CHKP(q, "q"); CHKP(k, "k"); CHKP(v, "v"); CHKP(out, "out");
     if (normalize && (!q_scale || !k_scale)) return mm_set_error(MM_ERR_SHAPE, "f32 attend: normalize needs q_scale / k_scale");
     if ((null_k == nullptr) != (null_v == nullptr)) return mm_set_error(MM_ERR_SHAPE, "f32 attend: null_k and null_v come together");
@@ -528,6 +529,7 @@ int mm_f32_attend(mm_stream_t stream, const float* q, int64_t q_sb, int64_t q_sh
         const int64_t st[] = {q_sb, q_sh, q_sn, k_sb, k_sh, k_sn, v_sb, v_sh, v_sn, o_sb, o_sh, o_sn};
         bool aligned = ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)out)) & 15) == 0;
         for (int64_t x : st) aligned = aligned && (x % 4) == 0;
+        if (!aligned && dim_head != 64) return mm_set_error(MM_ERR_ALIGN, "f32 attend: dim_head 32 / 128 needs 16-byte aligned rows");
         if (aligned) {
             AttnF32Args m;
             memset(&m, 0, sizeof(m));
@@ -536,7 +538,7 @@ int mm_f32_attend(mm_stream_t stream, const float* q, int64_t q_sb, int64_t q_sh
             m.v = v; m.v_sb = v_sb; m.v_sh = v_sh; m.v_sn = v_sn;
             m.out = out; m.o_sb = o_sb; m.o_sh = o_sh; m.o_sn = o_sn;
             m.B = B; m.H = H; m.nq = nq; m.nk = nk; m.key_mask = key_mask; m.km_sb = km_sb; m.normalize = normalize;
-            m.q_scale = q_scale; m.k_scale = k_scale; m.null_k = null_k; m.null_v = null_v; m.scale = scale;
+            m.q_scale = q_scale; m.k_scale = k_scale; m.null_k = null_k; m.null_v = null_v; m.scale = scale; m.dh = dim_head;
             return k_attention_f32((hipStream_t)stream, m);
         }
     }

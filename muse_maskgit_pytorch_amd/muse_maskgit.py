@@ -504,6 +504,8 @@ class Transformer(nn.Module):
         ids = ids.to(device=dev, dtype=torch.long).contiguous()
         b, n = ids.shape
         H = self.transformer_blocks.cfg['heads']
+        if self.transformer_blocks.cfg['dim_head'] != 64:
+            raise NotImplementedError('the W8A16 operator path is written for dim_head 64')
         I = H * 64
         m = ctx.shape[1]
         cx = ctx.reshape(b * m, self.dim)

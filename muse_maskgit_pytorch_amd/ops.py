@@ -128,13 +128,13 @@ def layernorm_inner(a, F, gamma, beta=None):
 
 
 def attend(q, k, v, key_mask=None, scale=8.0, normalize=False, q_scale=None, k_scale=None, null_k=None, null_v=None, out_rows=False):
-    """q (b,h,n,64), k/v (b,h,j,64) bf16 with arbitrary batch/head/token strides (d contiguous); key_mask (b,j) bool/uint8.
-    out_rows: return the output as [b*n, h*64] rows (heads merged, 'b h n d -> b n (h d)', mmp.py:161) instead of (b,h,n,64)."""
+    """q (b,h,n,d), k/v (b,h,j,d) bf16, d = 32 / 64 / 128, with arbitrary batch/head/token strides (d contiguous); key_mask (b,j) bool/uint8.
+    out_rows: return the output as [b*n, h*d] rows (heads merged, 'b h n d -> b n (h d)', mmp.py:161) instead of (b,h,n,64)."""
     _chk_cuda(q, k, v, key_mask)
     assert q.dtype == bf16 and k.dtype == bf16 and v.dtype == bf16
     b, h, n, d = q.shape
     j = k.shape[2]
-    assert d == 64 and q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1
+    assert d in (32, 64, 128) and q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1, 'dim_head must be 32, 64 or 128' 
     if out_rows:
         out = torch.empty(b * n, h * d, dtype=bf16, device=q.device)
         ost = (n * h * d, d, h * d)
@@ -148,7 +148,7 @@ def attend(q, k, v, key_mask=None, scale=8.0, normalize=False, q_scale=None, k_s
     L.check(L.lib().mm_attend(L.stream(), L.ptr(q), q.stride(0), q.stride(1), q.stride(2), L.ptr(k), k.stride(0), k.stride(1),
                               k.stride(2), L.ptr(v), v.stride(0), v.stride(1), v.stride(2), L.ptr(out), ost[0], ost[1], ost[2],
                               b, h, n, j, L.ptr(km), j, int(normalize), L.ptr(q_scale),
-                              L.ptr(k_scale), L.ptr(null_k), L.ptr(null_v), float(scale)), 'mm_attend')
+                              L.ptr(k_scale), L.ptr(null_k), L.ptr(null_v), float(scale), d), 'mm_attend')
     return out
 
 

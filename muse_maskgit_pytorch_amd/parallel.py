@@ -2,6 +2,8 @@
 in MaskGit.generate is over the vocabulary or token axis of ONE sample, muse_maskgit_pytorch.py:561,576,580,603), and the
 generated token grids are exchanged with a single all-gather (RCCL over xGMI when the backend is 'nccl').  The
 reference has no distributed inference code; this is the north star's requirement."""
+import os
+
 import torch
 
 
@@ -59,11 +61,18 @@ def allgather_ids(ids, dist, group=None):
     Backend 'nccl' (one rank per GPU): the library's own RCCL all-gather (IdsGather, C ABI); backend 'gloo' (CPU rendezvous of the tests,
     or ranks sharing one device): torch.distributed through host memory."""
     world = dist.get_world_size(group)
-    if dist.get_backend(group) == 'nccl':
+    if dist.get_backend(group) == 'nccl' and os.environ.get('MM_IDS_GATHER', 'rccl') != 'torch':
         key = id(group) if group is not None else 0
         if key not in _GATHERS:
-            _GATHERS[key] = IdsGather(dist, group)
-        return _GATHERS[key](ids)
+            try:
+                _GATHERS[key] = IdsGather(dist, group)
+            except Exception as e:      # a collective, not compute: torch.distributed's RCCL all-gather is an equivalent transport (recorded in .last_transport)
+                _GATHERS[key] = None
+                allgather_ids.last_error = repr(e)
+        if _GATHERS[key] is not None:
+            allgather_ids.last_transport = 'mm_allgather_ids (library-owned RCCL communicator)'
+            return _GATHERS[key](ids)
+    allgather_ids.last_transport = 'torch.distributed.all_gather_into_tensor'
     send = ids.to(torch.int32).contiguous()
     dev = send.device
     if dist.get_backend(group) == 'gloo':                     # CPU rendezvous (tests, or ranks sharing one device): 32 KiB through host memory
@@ -71,6 +80,10 @@ def allgather_ids(ids, dist, group=None):
     out = torch.empty((world * send.shape[0],) + tuple(send.shape[1:]), dtype=torch.int32, device=send.device)
     dist.all_gather_into_tensor(out, send, group=group)      # concatenated along dim 0 in rank order
     return out.to(device=dev, dtype=torch.long)
+
+
+allgather_ids.last_transport = None
+allgather_ids.last_error = None
 
 
 def generate_sharded(maskgit, text_embeds, dist, seed, **kw):

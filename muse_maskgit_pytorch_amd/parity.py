@@ -71,13 +71,13 @@ def text_mask(te):
     return m
 
 
-def attend(q, k, v, b, heads, nq, nk, q_strides, k_strides, v_strides, key_mask=None, q_scale=None, k_scale=None, null_k=None, null_v=None, scale=8.0):
-    """q / k / v: fp32 storage addressed by element strides (batch, head, token), d (64) contiguous; returns [b * nq, heads * 64]"""
-    I = heads * 64
+def attend(q, k, v, b, heads, nq, nk, q_strides, k_strides, v_strides, key_mask=None, q_scale=None, k_scale=None, null_k=None, null_v=None, scale=8.0, dh=64):
+    """q / k / v: fp32 storage addressed by element strides (batch, head, token), d (dh = 32 / 64 / 128) contiguous; returns [b * nq, heads * dh]"""
+    I = heads * dh
     out = torch.empty(b * nq, I, dtype=f32, device=q.device)
-    L.check(L.lib().mm_f32_attend(L.stream(), L.ptr(q), *q_strides, L.ptr(k), *k_strides, L.ptr(v), *v_strides, L.ptr(out), nq * I, 64, I, b, heads, nq, nk,
+    L.check(L.lib().mm_f32_attend(L.stream(), L.ptr(q), *q_strides, L.ptr(k), *k_strides, L.ptr(v), *v_strides, L.ptr(out), nq * I, dh, I, b, heads, nq, nk,
                                   L.ptr(key_mask), key_mask.stride(0) if key_mask is not None else 0, int(q_scale is not None), L.ptr(q_scale), L.ptr(k_scale),
-                                  L.ptr(null_k), L.ptr(null_v), float(scale)), 'mm_f32_attend')
+                                  L.ptr(null_k), L.ptr(null_v), float(scale), dh), 'mm_f32_attend')
     return out
 
 
@@ -102,15 +102,16 @@ def _feed_forward(ff, x_in, resid):
 
 def _attention(a, x, b, n, heads, context=None, m=0, key_mask=None):
     """mmp.py:126-162 (+ the residual of :189-191): x [b*n, D]; context [b*m, D] or None (self-attention)"""
-    I = heads * 64
+    dh = a.to_q.weight.shape[0] // heads
+    I = heads * dh
     xn = layernorm(x, _w(a.norm.gamma), _w(a.norm.beta))
     q = gemm(xn, _w(a.to_q.weight))                                  # [b*n, I]
     kv_in, nk = (xn, n) if context is None else (context, m)
     kv = gemm(kv_in, _w(a.to_kv.weight))                             # [b*nk, 2I]: k | v  (chunk(2, dim=-1), :137)
-    nkv = _w(a.null_kv)                                              # (2, h, 1, 64)
-    o = attend(q, kv, _View(kv, I), b, heads, n, nk, (n * I, 64, I), (nk * 2 * I, 64, 2 * I), (nk * 2 * I, 64, 2 * I), key_mask=key_mask,
-               q_scale=_w(a.q_scale), k_scale=_w(a.k_scale), null_k=nkv[0].reshape(heads, 64).contiguous(), null_v=nkv[1].reshape(heads, 64).contiguous(),
-               scale=float(a.scale))
+    nkv = _w(a.null_kv)                                              # (2, h, 1, dh)
+    o = attend(q, kv, _View(kv, I), b, heads, n, nk, (n * I, dh, I), (nk * 2 * I, dh, 2 * I), (nk * 2 * I, dh, 2 * I), key_mask=key_mask,
+               q_scale=_w(a.q_scale), k_scale=_w(a.k_scale), null_k=nkv[0].reshape(heads, dh).contiguous(), null_v=nkv[1].reshape(heads, dh).contiguous(),
+               scale=float(a.scale), dh=dh)
     return gemm(o, _w(a.to_out.weight), resid=x)
 
 
@@ -127,8 +128,8 @@ def transformer_run(tr, ids, text_embeds, cond_drop_prob=0., conditioning_token_
     Lt = te.shape[1]
     cfgb = tr.transformer_blocks.cfg
     heads, D = cfgb['heads'], tr.dim
-    if cfgb['dim_head'] != 64:
-        raise L.MuseHipError('dim_head must be 64')
+    if cfgb['dim_head'] not in (32, 64, 128):
+        raise L.MuseHipError('dim_head must be 32, 64 or 128')
     ctx = te.reshape(b * Lt, -1)
     if isinstance(tr.text_embed_proj, nn.Linear):                                              # mmp.py:233, 302
         ctx = gemm(ctx, _w(tr.text_embed_proj.weight))

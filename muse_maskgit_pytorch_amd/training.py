@@ -328,6 +328,8 @@ def transformer_loss(tr, ids, text_embeds, labels, ignore_index, cond_drop_prob,
     dev = tr.token_emb.weight.device
     ids = ids.to(device=dev, dtype=torch.long).contiguous()
     b, n = ids.shape
+    if tr.transformer_blocks.cfg['dim_head'] != 64:
+        raise NotImplementedError('the training path (attention backward) is written for dim_head 64; inference covers 32 / 64 / 128')
     assert (b * n) % 64 == 0, 'the training path needs batch * seq_len to be a multiple of 64'
     te = text_embeds.to(device=dev, dtype=torch.float32).contiguous()
     ctx_mask = (te != 0).any(dim=-1)                                                   # mmp.py:304
