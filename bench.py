@@ -23,6 +23,8 @@ import time
 
 import torch
 
+_RECORD_OUT = sys.stdout
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -283,7 +285,7 @@ def train_bench(args, dev, rank, world, dist):
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     if rank == 0:
         sec = dt.item() / args.steps
-        print(json.dumps({
+        _RECORD_OUT.write(json.dumps({
             'metric': 'training tokens/sec (C2 base transformer: MaskGit.forward + backward + AdamW)', 'value': world * B * n / sec, 'unit': 'tokens/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': sec * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16 (fp32 master weights, fp32 gradients)', 'data': 'synthetic',
@@ -291,7 +293,8 @@ def train_bench(args, dev, rank, world, dist):
                                    'cosine-schedule random masking, cond_drop_prob 0.5, AdamW', 'sequences_per_gpu_per_step': B, 'global_batch': world * B,
                        'seq_len': n, 'parallelism': f'dp{world} (bucketed gradient all-reduce overlapped with the backward)'},
             'note': 'secondary line: BASELINE.json names no training metric; orchestrated from Python over the C-ABI operators (training.py)',
-            'loss_first': float(losses[0]), 'loss_last': float(losses[-1])}), flush=True)
+            'loss_first': float(losses[0]), 'loss_last': float(losses[-1])}) + '\n')
+        _RECORD_OUT.flush()
     if dist is not None:
         dist.destroy_process_group()
     return 0
@@ -332,6 +335,12 @@ def main():
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(_respawn_under_torchrun(args))
+    # stdout carries exactly ONE line, the JSON record: libraries that chat on file descriptor 1 (RCCL prints a version banner when a communicator
+    # is created) are sent to stderr, the record goes to the original descriptor
+    global _RECORD_OUT
+    sys.stdout.flush()
+    _RECORD_OUT = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -495,7 +504,8 @@ def main():
             out['parity_tier'] = parity_tier_leg(mg, tr, step, args, B, T, n, nc, image_size, counts, lib, elapsed / args.steps)
         if world == 1 and not args.no_cpu_baseline and not args.tiny and args.config == 'c2':
             out['cpu_baseline'] = cpu_baseline(mg, te_all[:2], T, 3.)
-        print(json.dumps(out))
+        _RECORD_OUT.write(json.dumps(out) + '\n')
+        _RECORD_OUT.flush()
     if dist is not None:
         dist.destroy_process_group()
 

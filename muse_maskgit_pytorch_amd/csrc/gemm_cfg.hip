@@ -393,8 +393,8 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
                 const int m0t = tile_m * TTOK;
                 constexpr int NBLK = MIX2 ? 8 : 4;                 // token blocks of 16 per wave
                 const int tilec = tile_n;                          // the piece index of this tile's 256 columns in a row of V / 256 pieces
-                uint32_t* xnib4 = reinterpret_cast<uint32_t*>(xch);                          // [128 tokens][4 quarters]: 4 keep nibbles (fragment a in byte a)
-                float2* xml = reinterpret_cast<float2*>(xch + TTOK * 16);                    // [tokens][16 lane groups] (ml, pl)
+                uint32_t* xnib4 = reinterpret_cast<uint32_t*>(xch);                          // [4 quarters][tokens]: 4 keep nibbles (fragment a in byte a)
+                float2* xml = reinterpret_cast<float2*>(xch + TTOK * 16);                    // [16 lane groups][tokens] (ml, pl)
                 int nstore = 0;
 #pragma unroll
                 for (int b = 0; b < NBLK; ++b) {
@@ -432,8 +432,10 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
                         const uint32_t nb = ((lo >> FR_) & 1u) | (((lo >> (16 + FR_)) & 1u) << 1) | (((hi >> FR_) & 1u) << 2) | (((hi >> (16 + FR_)) & 1u) << 3);
                         nib4 |= nb << (8 * a);
                     }
-                    if (FG_ == 0) xnib4[tokl * 4 + wn] = nib4;      // bytes a = 0..3 of quarter wn: 0x0n0n0n0n
-                    xml[tokl * 16 + wn * 4 + FG_] = make_float2(ml, pl);
+                    // (both exchange arrays are [lane group / quarter][token]: a wave's 16 tokens are adjacent words -- token-major rows were a 16-way
+                    //  bank conflict on every write, SQ_LDS_BANK_CONFLICT 0.39 of the kernel's LDS cycles)
+                    if (FG_ == 0) xnib4[wn * TTOK + tokl] = nib4;      // bytes a = 0..3 of quarter wn: 0x0n0n0n0n
+                    xml[(wn * 4 + FG_) * TTOK + tokl] = make_float2(ml, pl);
                     // this quarter's kept granules go out NOW (their sub-slot positions need nothing from the other three waves): the stores of one
                     // token block are in flight while the next block's statistics are computed
                     uint32_t m16 = (nib4 | (nib4 >> 4)) & 0x00FF00FFu;
@@ -460,26 +462,22 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
                     const bool w_ = FG_ == 0 && tok < p.M;
                     if (__ballot(w_) != 0ull) {
                         if (w_) {
-                            const uint4 nb = *reinterpret_cast<const uint4*>(xnib4 + tokl * 4);      // the 4 quarters' nibble words
-                            uint32_t h16[4] = {nb.x, nb.y, nb.z, nb.w};
+                            uint32_t h16[4] = {xnib4[tokl], xnib4[TTOK + tokl], xnib4[2 * TTOK + tokl], xnib4[3 * TTOK + tokl]};      // the 4 quarters' nibble words
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {                                      // 0x0n0n0n0n -> 0xnnnn (fragment a of the quarter in bits 4 a .. 4 a + 3)
                                 h16[q] = (h16[q] | (h16[q] >> 4)) & 0x00FF00FFu;
                                 h16[q] = (h16[q] | (h16[q] >> 8)) & 0x0000FFFFu;
                             }
                             // tile_combine16 (common.h) streamed from LDS in two sweeps (max, then the weighted sums in the canonical order)
-                            const float2* gq = xml + tokl * 16;
+                            const float2* gq = xml + tokl;                          // lane group g of this token: gq[g * TTOK]
                             float M_ = -INFINITY;
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) {
-                                const float4 v2 = *reinterpret_cast<const float4*>(gq + 2 * i);
-                                M_ = fmaxf(M_, fmaxf(v2.x, v2.z));
-                            }
+                            for (int i = 0; i < 16; ++i) M_ = fmaxf(M_, gq[i * TTOK].x);
                             float wq[4];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                const float4 u = *reinterpret_cast<const float4*>(gq + 4 * q), v2 = *reinterpret_cast<const float4*>(gq + 4 * q + 2);
-                                wq[q] = (u.y * __expf(u.x - M_) + u.w * __expf(u.z - M_)) + (v2.y * __expf(v2.x - M_) + v2.w * __expf(v2.z - M_));
+                                const float2 u0 = gq[(4 * q) * TTOK], u1 = gq[(4 * q + 1) * TTOK], u2 = gq[(4 * q + 2) * TTOK], u3 = gq[(4 * q + 3) * TTOK];
+                                wq[q] = (u0.y * __expf(u0.x - M_) + u1.y * __expf(u1.x - M_)) + (u2.y * __expf(u2.x - M_) + u3.y * __expf(u3.x - M_));
                             }
                             const float E_ = (wq[0] + wq[1]) + (wq[2] + wq[3]);
                             p.fs_stats[(size_t)tok * p.tiles_n + tilec] = make_float4(M_, E_, __uint_as_float(h16[0] | (h16[1] << 16)), __uint_as_float(h16[2] | (h16[3] << 16)));

@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/sq
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for c in SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE; do
-  timeout 400 rocprofv3 --pmc $c -d $OUT/$c -o bench --output-format csv -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/$c.log 2>&1
+  timeout 400 rocprofv3 --pmc $c -d $OUT/$c -o bench --output-format csv -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity-tier > $OUT/$c.log 2>&1
 done
 cd $ROOT
 python - <<'PY'
