@@ -159,6 +159,17 @@ int mm_bce_loss(mm_stream_t stream, const float* x, const float* y, int n, float
  * null + (cond - null) * cond_scale like mm_gemm_cfg_logits (fp32 output).  The self-defined oracle is the bf16 path on the
  * de-quantised weights (SURVEY 8c "L2"). */
 int mm_quantize_e4m3_rows(mm_stream_t stream, const float* w, int64_t ldw, int rows, int K, int Kp, void* wq, float* scale);
+/* fp8 engine (BASELINE configs[4] "fp8 MFMA weights"; the Linear layers mmp.py:85,88,118-124,233): e4m3 x e4m3 products on the K = 128 fp8 MFMA
+ * (v_mfma_f32_16x16x128_f8f6f4), fp32 accumulation, per-row scales on both operands applied to the accumulators:
+ *     out[m][n] = x_scale[m] * w_scale[n] * sum_k xq[m][k] * wq[n][k]
+ * mm_quantize_act_e4m3: activation rows (bf16, or fp32 when x_is_f32) -> e4m3 [rows][Kp] + scale[rows] (max |x| / 448, the weights' rule of
+ *     mm_quantize_e4m3_rows); Kp % 128 == 0 for the GEMM (columns K..Kp-1 are written as zero).
+ * mm_gemm_fp8: K % 128 == 0 (padded), N % 128 == 0, ldx / ldw in bytes (= elements).  epilogue 0: out bf16 [M][ldc]; 1: GEGLU on w1 packed
+ *     value/gate-interleaved in 64-row blocks (mm_ff_weights.w1), out bf16 [M][N / 2]; 2: out fp32 [M][ldc] = resid_f32 (same layout, may alias
+ *     out, may be NULL) + product.  Self-defined numerics: the oracle is the fp32 restatement on the de-quantised operands. */
+int mm_quantize_act_e4m3(mm_stream_t stream, const void* x, int x_is_f32, int64_t ldx, int rows, int K, int Kp, void* xq, float* scale);
+int mm_gemm_fp8(mm_stream_t stream, const void* xq, int64_t ldx, const float* x_scale, const void* wq, int64_t ldw, const float* w_scale, int M, int N, int K,
+                void* out, int64_t ldc, int epilogue, const float* resid_f32);
 int mm_gemm_w8a16(mm_stream_t stream, const void* x, const void* x_null, int64_t ldx, const void* wq, int64_t ldw, const float* scale,
                   int M, int N, int K, void* out, int64_t ldc, int out_f32, const float* resid_f32, float cond_scale);
 

@@ -237,6 +237,22 @@ int mm_bce_loss(mm_stream_t stream, const float* x, const float* y, int n, float
     return k_bce_loss((hipStream_t)stream, x, y, n, out);
 }
 
+int mm_quantize_act_e4m3(mm_stream_t stream, const void* x, int x_is_f32, int64_t ldx, int rows, int K, int Kp, void* xq, float* scale) {
+    if (!x || !xq || !scale) return mm_set_error(MM_ERR_SHAPE, "quantize_act_e4m3: NULL pointer");
+    return k_quantize_act_e4m3((hipStream_t)stream, x, x_is_f32, ldx, rows, K, Kp, (unsigned char*)xq, scale);
+}
+
+int mm_gemm_fp8(mm_stream_t stream, const void* xq, int64_t ldx, const float* x_scale, const void* wq, int64_t ldw, const float* w_scale, int M, int N, int K,
+                void* out, int64_t ldc, int epilogue, const float* resid_f32) {
+    if (epilogue < 0 || epilogue > 2) return mm_set_error(MM_ERR_SHAPE, "gemm_fp8: epilogue must be 0 (bf16), 1 (GEGLU, bf16) or 2 (fp32 + residual)");
+    GemmF8Args a;
+    memset(&a, 0, sizeof(a));
+    a.X = (const unsigned char*)xq; a.ldx = ldx; a.sx = x_scale;
+    a.W = (const unsigned char*)wq; a.ldw = ldw; a.sw = w_scale;
+    a.M = M; a.N = N; a.K = K; a.out = out; a.ldc = ldc; a.epi = epilogue; a.resid = resid_f32; a.ldr = ldc;
+    return k_gemm_fp8((hipStream_t)stream, a);
+}
+
 int mm_quantize_e4m3_rows(mm_stream_t stream, const float* w, int64_t ldw, int rows, int K, int Kp, void* wq, float* scale) {
     if (rows == 0) return MM_OK;
     CHK_PTR(w, "w"); CHK_PTR(wq, "wq"); CHK_PTR(scale, "scale");

@@ -77,6 +77,21 @@ int k_ln_bf16(hipStream_t s, const bf16_t* a, long lda, int rows, int F, int Fp,
 int k_f32_to_bf16(hipStream_t s, const float* x, bf16_t* out, long count);
 int k_quantize_e4m3_rows(hipStream_t s, const float* w, long ldw, int rows, int K, int Kp, unsigned char* wq, float* scale);
 
+// fp8 engine (gemm_fp8.hip): out = sx[m] * sw[n] * (xq . wq) on the K = 128 fp8 MFMA.  epi 0: bf16 out; 1: GEGLU of the interleaved w1 rows, bf16 out
+// [M][N / 2]; 2: fp32 out = resid + product
+struct GemmF8Args {
+    const unsigned char* X; long ldx; const float* sx;      // e4m3 [M][ldx bytes], per-row scale
+    const unsigned char* W; long ldw; const float* sw;      // e4m3 [N][ldw bytes], per-row scale
+    int M, N, K;                                            // K: padded contraction length, a multiple of 128
+    void* out; long ldc;
+    int epi;
+    const float* resid; long ldr;
+    int tiles_m, tiles_n;                                   // set by the launcher
+};
+int k_gemm_fp8(hipStream_t s, const GemmF8Args& a);
+// activation rows -> e4m3 + per-row scale (max |x| / 448); columns K..Kp-1 zero.  bf16 or fp32 input
+int k_quantize_act_e4m3(hipStream_t s, const void* x, int x_f32, long ldx, int rows, int K, int Kp, unsigned char* xq, float* scale);
+
 struct AttnArgs {
     const bf16_t* q; long q_sb, q_sh, q_sn;      // element strides: batch, head, token (d contiguous, dh = 64)
     const bf16_t* k; long k_sb, k_sh, k_sn;

@@ -287,6 +287,69 @@ __global__ __launch_bounds__(256) void quantize_e4m3_rows_kernel(const float* __
     }
 }
 
+// activation rows (bf16 or fp32) -> e4m3 + per-row scale for the fp8 engine (gemm_fp8.hip): same rule as the weights (scale = max |x| / 448, IEEE division,
+// round to nearest even), one wave per row, 8 values per lane and pass
+template <bool F32>
+__global__ __launch_bounds__(256) void quantize_act_e4m3_kernel(const void* __restrict__ xin, long ldx, int rows, int K, int Kp, unsigned char* __restrict__ xq,
+                                                                float* __restrict__ scale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float m = 0.f;
+    for (int c = lane * 8; c < K; c += 512) {
+        float v[8];
+        if constexpr (F32) {
+            const float* xr = reinterpret_cast<const float*>(xin) + (long)row * ldx + c;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (c + j < K) ? xr[j] : 0.f;
+        } else {
+            const bf16_t* xr = reinterpret_cast<const bf16_t*>(xin) + (long)row * ldx + c;
+            if (c + 8 <= K) unpack8(*reinterpret_cast<const uint4*>(xr), v);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (c + j < K) ? bf16_to_f32(xr[j]) : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
+    }
+    m = wave_max(m);
+    const float sc = m > 0.f ? m / 448.f : 1.f;
+    if (lane == 0) scale[row] = sc;
+    for (int c = lane * 8; c < Kp; c += 512) {
+        float v[8];
+        if constexpr (F32) {
+            const float* xr = reinterpret_cast<const float*>(xin) + (long)row * ldx + c;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (c + j < K) ? xr[j] / sc : 0.f;
+        } else {
+            const bf16_t* xr = reinterpret_cast<const bf16_t*>(xin) + (long)row * ldx + c;
+            if (c + 8 <= K) {
+                unpack8(*reinterpret_cast<const uint4*>(xr), v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = v[j] / sc;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (c + j < K) ? bf16_to_f32(xr[j]) / sc : 0.f;
+            }
+        }
+        int p0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+        p0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], p0, true);
+        int p1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], 0, false);
+        p1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], p1, true);
+        *reinterpret_cast<int2*>(xq + (long)row * Kp + c) = make_int2(p0, p1);
+    }
+}
+
+int k_quantize_act_e4m3(hipStream_t s, const void* x, int x_f32, long ldx, int rows, int K, int Kp, unsigned char* xq, float* scale) {
+    if (rows <= 0) return MM_OK;
+    if (Kp % 8 || Kp < K) return mm_set_error(MM_ERR_SHAPE, "quantize_act_e4m3: padded width must be a multiple of 8 and >= K");
+    if (!x_f32 && ((ldx % 8) || (((uintptr_t)x) & 15))) return mm_set_error(MM_ERR_ALIGN, "quantize_act_e4m3: bf16 rows must be 16-byte aligned");
+    if (x_f32) hipLaunchKernelGGL(quantize_act_e4m3_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, K, Kp, xq, scale);
+    else hipLaunchKernelGGL(quantize_act_e4m3_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, K, Kp, xq, scale);
+    return mm_check_launch("quantize_act_e4m3_kernel");
+}
+
 int k_quantize_e4m3_rows(hipStream_t s, const float* w, long ldw, int rows, int K, int Kp, unsigned char* wq, float* scale) {
     if (rows <= 0) return MM_OK;
     if (Kp % 4 || Kp < K) return mm_set_error(MM_ERR_SHAPE, "quantize_e4m3_rows: padded width must be a multiple of 4 and >= K");
