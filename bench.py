@@ -328,6 +328,8 @@ def main():
     ap.add_argument('--tiny', action='store_true', help='configs[0] plumbing case instead of the metric config')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fused-sampling', action='store_true', help='materialise the logits (round-1 path) for A/B timing')
+    ap.add_argument('--fp8', action='store_true', help="secondary line: run the transformer on the fp8 engine (precision 'fp8', BASELINE configs[4] \"fp8 MFMA weights\"; "
+                    "use with --config c5).  Never the headline: the metric configuration is quoted in bf16")
     ap.add_argument('--no-parity-tier', action='store_true', help="skip the second timed leg (precision 'bf16x3', the tolerance-meeting tier)")
     ap.add_argument('--train', action='store_true', help='time the TRAINING step of the C2 base transformer (MaskGit.forward + backward + AdamW) instead of '
                     'generation: a second, separately labelled line -- not the BASELINE metric')
@@ -368,6 +370,9 @@ def main():
         mg, image_size = build_config(args.config, dev)
         desc, cond_size = CONFIGS[args.config][5], CONFIGS[args.config][3]
     tr = mg.transformer
+    if args.fp8:
+        mg.set_precision('fp8')
+        args.no_parity_tier = True
     B = args.batch or (32 if args.tiny else CONFIGS[args.config][4])
     T = args.timesteps
     n = (image_size // 16) ** 2
@@ -444,7 +449,7 @@ def main():
                 if substr in name:
                     return v['hbm_bytes_per_launch']
             return None
-        metric_cfg = (not args.tiny) and args.config == 'c2' and B == 32
+        metric_cfg = (not args.tiny) and args.config == 'c2' and B == 32 and not args.fp8
         fused_on = tr._model().packed.get('wcov') is not None and not args.no_fused_sampling
         total_images = world * B * args.steps
         value = total_images / elapsed
@@ -459,8 +464,10 @@ def main():
             'metric': 'images/sec (256x256 base, 18 decode steps)' if args.config == 'c2' and not args.tiny else f'images/sec ({image_size}x{image_size}, {T} decode steps, config {args.config})',
             'value': value, 'unit': 'images/sec', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': desc, 'images_per_gpu_per_step': B, 'global_batch': world * B, 'seq_len': n, 'timesteps': T,
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'fp8 (e4m3 weights and activations on the fp8 MFMA for the blocks\' Linear layers; attention / to_logits / sampling / VAE bf16)' if args.fp8 else 'bf16',
+            'data': 'synthetic',
+            'config': {'workload': desc + (' [fp8 engine]' if args.fp8 else ''), 'images_per_gpu_per_step': B, 'global_batch': world * B, 'seq_len': n, 'timesteps': T,
                        'text_len': args.text_len, 'cond_ids': nc, 'parallelism': f'dp{world} (batch-sharded, 1 all-gather of ids per step)',
                        'weights': 'random init (module defaults, torch.manual_seed(0))'},
             # reference-equivalent: the reference's 2 * timesteps full passes over all n positions / the decode-loop time (comparable across

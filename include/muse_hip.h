@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 3
+#define MM_ABI_VERSION 4
 
 #define MM_OK 0
 #define MM_ERR_SHAPE (-1)
@@ -151,13 +151,9 @@ int mm_ce_loss(mm_stream_t stream, const float* logits, int64_t ld, int R, int V
                float* row_loss_ws, float* out);
 int mm_bce_loss(mm_stream_t stream, const float* x, const float* y, int n, float* out);
 
-/* ---- fp8 weights (BASELINE configs[4]: "fp8 MFMA weights"; W8A16: e4m3 weights, bf16 activations, fp32 accumulate).
- * mm_quantize_e4m3_rows: w fp32 [rows][ldw] -> wq OCP-e4m3 bytes [rows][Kp] (columns K..Kp-1 zero, Kp % 64 == 0 for the GEMM) with one
- * scale per row, scale = max|w_row| / 448 (1 for an all-zero row), wq = rne(w / scale).
- * mm_gemm_w8a16: out[M][N] = x[M][K] (bf16) * dequant(wq[N][K], scale[N])^T; the weight tile travels as fp8 (half the bytes) and is
- * widened to bf16 in registers (exact), the scale multiplies the fp32 accumulators.  x_null != NULL: the guidance form
- * null + (cond - null) * cond_scale like mm_gemm_cfg_logits (fp32 output).  The self-defined oracle is the bf16 path on the
- * de-quantised weights (SURVEY 8c "L2"). */
+/* ---- fp8 engine (BASELINE configs[4]: "fp8 MFMA weights").
+ * mm_quantize_e4m3_rows: w fp32 [rows][ldw] -> wq OCP-e4m3 bytes [rows][Kp] (columns K..Kp-1 zero; Kp % 128 == 0 for mm_gemm_fp8) with one
+ * scale per row, scale = max|w_row| / 448 (1 for an all-zero row), wq = rne(w / scale). */
 int mm_quantize_e4m3_rows(mm_stream_t stream, const float* w, int64_t ldw, int rows, int K, int Kp, void* wq, float* scale);
 /* fp8 engine (BASELINE configs[4] "fp8 MFMA weights"; the Linear layers mmp.py:85,88,118-124,233): e4m3 x e4m3 products on the K = 128 fp8 MFMA
  * (v_mfma_f32_16x16x128_f8f6f4), fp32 accumulation, per-row scales on both operands applied to the accumulators:
@@ -170,8 +166,6 @@ int mm_quantize_e4m3_rows(mm_stream_t stream, const float* w, int64_t ldw, int r
 int mm_quantize_act_e4m3(mm_stream_t stream, const void* x, int x_is_f32, int64_t ldx, int rows, int K, int Kp, void* xq, float* scale);
 int mm_gemm_fp8(mm_stream_t stream, const void* xq, int64_t ldx, const float* x_scale, const void* wq, int64_t ldw, const float* w_scale, int M, int N, int K,
                 void* out, int64_t ldc, int epilogue, const float* resid_f32);
-int mm_gemm_w8a16(mm_stream_t stream, const void* x, const void* x_null, int64_t ldx, const void* wq, int64_t ldw, const float* scale,
-                  int M, int N, int K, void* out, int64_t ldc, int out_f32, const float* resid_f32, float cond_scale);
 
 /* Nearest-codebook vector quantisation (the north star's "L2 nearest-codebook VQ lookup"; EXTENSION with a self-defined oracle:
  * the reference's VectorQuantize branch, vqgan_vae.py:297-303, 336-342, 433-435, cannot run).  x fp32 [N][ldx] (C used), codebook fp32
@@ -383,6 +377,11 @@ typedef struct mm_attn_weights {
     const float* null_v;     /* fp32 [H][64]  null_kv[1]                                                   */
     const float* q_scale;    /* fp32 [64]                                                                  */
     const float* k_scale;    /* fp32 [64]                                                                  */
+    /* fp8 engine (mm_transformer_desc.fp8): w_q / w_kv / w_out are OCP e4m3 [rows][in] and these are their per-row scales (fp32 [I] / [2I] / [D]);
+     * the cross-attention's w_kv stays bf16 (w_kv_scale unused there: the context projection runs once per generate).  NULL otherwise. */
+    const float* w_q_scale;
+    const float* w_kv_scale;
+    const float* w_out_scale;
 } mm_attn_weights;
 
 typedef struct mm_ff_weights {
@@ -399,6 +398,9 @@ typedef struct mm_ff_weights {
     const void* w2_folded;   /* bf16 [D][Fp] = bf16(w2[o][f] * ln2_gamma[f])                                   */
     const float* ln2_c1;     /* [D]: sum_f float(w2_folded[o][f])                                          */
     const float* ln2_c2;     /* [D]: sum_f ln2_beta[f] * float(w2[o][f])                                   */
+    /* fp8 engine: w1 (same GEGLU interleave) / w2 are e4m3 [2*Fp][D] / [D][Fp] with these per-row scales (fp32 [2*Fp] / [D]); w2_folded unused */
+    const float* w1_scale;
+    const float* w2_scale;
 } mm_ff_weights;
 
 typedef struct mm_layer_weights {
@@ -431,7 +433,12 @@ typedef struct mm_transformer_desc {
      * token_emb / pos_emb are fp32 tables; ctx and the `embed` output are bf16 [.][P * D]; q|k|v, GEMM outputs, the residual stream and
      * the logits are fp32; attention runs on the fp32 MFMA.  Reference arithmetic matched: fp32 end to end (mmp.py:240-259, 279-335). */
     int32_t split_products;
-    int32_t reserved0;
+    /* fp8 engine (BASELINE configs[4] "fp8 MFMA weights"), fp8 != 0: the Linear weights of the layers (and of self_cond_ff) are OCP e4m3 rows with the
+     * per-row scales of mm_attn_weights / mm_ff_weights (mm_quantize_e4m3_rows); their input activations are quantised per token row inside the producing
+     * kernels and the products run on v_mfma_f32_16x16x128_f8f6f4 (mm_gemm_fp8).  Embeddings, text_proj, the cross-attention's w_kv, attention, to_logits
+     * and the sampling are the bf16 engine's.  dim, heads * dim_head and ff_inner_padded must be multiples of 128; split_products must be 0.
+     * Self-defined numerics: the oracle is the fp32 restatement with the same per-row fake quantisation at every Linear of the layers. */
+    int32_t fp8;
 } mm_transformer_desc;
 
 typedef struct mm_transformer mm_transformer_t;

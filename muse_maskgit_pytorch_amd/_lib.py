@@ -24,11 +24,11 @@ class MuseHipError(RuntimeError):
 
 
 class AttnWeights(C.Structure):
-    _fields_ = [(n, c_vp) for n in ('ln_gamma', 'ln_beta', 'w_q', 'w_kv', 'w_out', 'null_k', 'null_v', 'q_scale', 'k_scale')]
+    _fields_ = [(n, c_vp) for n in ('ln_gamma', 'ln_beta', 'w_q', 'w_kv', 'w_out', 'null_k', 'null_v', 'q_scale', 'k_scale', 'w_q_scale', 'w_kv_scale', 'w_out_scale')]
 
 
 class FFWeights(C.Structure):
-    _fields_ = [(n, c_vp) for n in ('ln1_gamma', 'ln1_beta', 'w1', 'ln2_gamma', 'ln2_beta', 'w2', 'w2_folded', 'ln2_c1', 'ln2_c2')]
+    _fields_ = [(n, c_vp) for n in ('ln1_gamma', 'ln1_beta', 'w1', 'ln2_gamma', 'ln2_beta', 'w2', 'w2_folded', 'ln2_c1', 'ln2_c2', 'w1_scale', 'w2_scale')]
 
 
 class LayerWeights(C.Structure):
@@ -40,7 +40,7 @@ class TransformerDesc(C.Structure):
                                          'num_tokens', 'vocab_rows', 'dim_out', 'text_dim', 'self_cond')] + \
                [('token_emb', c_vp), ('pos_emb', c_vp), ('text_proj', c_vp), ('layers', C.POINTER(LayerWeights)),
                 ('final_gamma', c_vp), ('final_beta', c_vp), ('to_logits', c_vp), ('self_cond_ff', FFWeights), ('logits_wmean', c_vp), ('logits_wcov', c_vp),
-                ('split_products', C.c_int32), ('reserved0', C.c_int32)]
+                ('split_products', C.c_int32), ('fp8', C.c_int32)]
 
 
 class VaeLayer(C.Structure):
@@ -88,7 +88,8 @@ SIGNATURES = {
     'mm_ce_loss': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_i64, c_vp, c_vp]),
     'mm_bce_loss': (c_int, [c_vp, c_vp, c_vp, c_int, c_vp]),
     'mm_quantize_e4m3_rows': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp]),
-    'mm_gemm_w8a16': (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_int, c_vp, c_f32]),
+    'mm_quantize_act_e4m3': (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_int, c_int, c_vp, c_vp]),
+    'mm_gemm_fp8': (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_int, c_vp]),
     'mm_vq_nearest': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp]),
     'mm_vq_gather': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp]),
     'mm_gemm_wgrad_splits': (c_int, [c_int, c_int, c_int]),
@@ -183,7 +184,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.mm_abi_version() != 3:
+        if l.mm_abi_version() != 4:
             raise MuseHipError('libmuse_hip ABI version mismatch')
         if os.environ.get('MM_DEBUG'):      # tools / A-B runs only: kernel-selection bits (see muse_hip_internal.h)
             l.mm_debug_set(int(os.environ['MM_DEBUG'], 0))

@@ -259,21 +259,6 @@ int mm_quantize_e4m3_rows(mm_stream_t stream, const float* w, int64_t ldw, int r
     return k_quantize_e4m3_rows((hipStream_t)stream, w, ldw, rows, K, Kp, (unsigned char*)wq, scale);
 }
 
-int mm_gemm_w8a16(mm_stream_t stream, const void* x, const void* x_null, int64_t ldx, const void* wq, int64_t ldw, const float* scale,
-                  int M, int N, int K, void* out, int64_t ldc, int out_f32, const float* resid_f32, float cond_scale) {
-    if (M == 0 || N == 0) return MM_OK;
-    CHK_PTR(x, "x"); CHK_PTR(wq, "wq"); CHK_PTR(scale, "scale"); CHK_PTR(out, "out");
-    CHK_ALIGN16(x, "x"); CHK_ALIGN16(wq, "wq"); CHK_ALIGN16(out, "out");
-    GemmArgs a;
-    memset(&a, 0, sizeof(a));
-    a.mode = x_null ? MODE_CFG : MODE_DENSE;
-    a.W = (const bf16_t*)wq; a.N = N; a.ldw = (int)ldw; a.K = K; a.w_scale = scale;
-    a.M = M; a.X = (const bf16_t*)x; a.X2 = (const bf16_t*)x_null; a.ldx = (int)ldx;
-    a.out = out; a.ldc = ldc; a.out_kind = (out_f32 || x_null) ? OUT_F32 : OUT_BF16;
-    a.resid_f32 = resid_f32; a.ldr = ldc; a.cfg_scale = cond_scale;
-    if (x_null && resid_f32) return mm_set_error(MM_ERR_SHAPE, "gemm_w8a16: the guidance form takes no residual");
-    return mm_gemm_launch(a, (hipStream_t)stream);
-}
 
 int mm_vq_nearest(mm_stream_t stream, const float* x, int64_t ldx, int N, int C, const float* codebook, int K, int cosine,
                   float* aux_ws, int64_t* ids) {

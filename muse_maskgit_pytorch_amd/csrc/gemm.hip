@@ -36,17 +36,10 @@ constexpr int SMEM_BYTES = BT * (BT + 4) * 4 + BT * 8;  // max(2 stages = 64 KiB
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
-// 8 fp8 e4m3 (OCP) values -> 8 bf16: exact (3 mantissa bits fit in bf16's 7)
-__device__ __forceinline__ u32x4_t fp8x8_to_bf16x8(const uint2 q) {
-    const auto a = __builtin_amdgcn_cvt_pk_f32_fp8((int)q.x, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)q.x, true);
-    const auto c = __builtin_amdgcn_cvt_pk_f32_fp8((int)q.y, false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)q.y, true);
-    return u32x4_t{pack_bf16x2(a[0], a[1]), pack_bf16x2(b[0], b[1]), pack_bf16x2(c[0], c[1]), pack_bf16x2(d[0], d[1])};
-}
-
 // source of the implicit-GEMM loader for taps that fall into the zero padding
 __device__ __attribute__((aligned(16))) const unsigned int g_zero_page[64] = {0};
 
-template <int MODE, bool W8 = false>      // W8: the weight operand is fp8 e4m3 (one scale per output row), dequantised to bf16 in registers
+template <int MODE>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TSTAMP(0)
@@ -74,20 +67,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         const int r = row0 + 8 * i;
         const int n = n0 + r;
         // out-of-range rows are clamped to row 0: they only feed outputs the epilogue never stores
-        if constexpr (W8) {
-            // fp8 rows are 64 B per k-tile: a DMA instruction covers 16 rows (lane l -> row l >> 2, physical 16-byte chunk l & 3 holding
-            // logical chunk (l & 3) ^ ((-(row >> 2)) & 3): conflict-free ds_read_b64 of the fragments); wave w stages rows 32w + 16i
-            if (i < 2) {
-                const int r8 = 32 * wid + 16 * i + (lane >> 2);
-                const int n8 = n0 + r8;
-                const int c8 = (lane & 3) ^ ((-(lane >> 4)) & 3);
-                wptr[i] = reinterpret_cast<const bf16_t*>(reinterpret_cast<const unsigned char*>(p.W) + (size_t)(n8 < p.N ? n8 : 0) * p.ldw + c8 * 16);
-            } else {
-                wptr[i] = p.W;
-            }
-        } else {
-            wptr[i] = p.W + (size_t)(n < p.N ? n : 0) * p.ldw + chunk * 8;
-        }
+        wptr[i] = p.W + (size_t)(n < p.N ? n : 0) * p.ldw + chunk * 8;
         if constexpr (MODE == MODE_DENSE) {
             const int m = m0 + r;
             xok[i] = m < p.M;
@@ -116,15 +96,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         const int k0_ = (kt_) * BK;                                                                                \
         unsigned char* ws_ = smem + (stage_) * STAGE_BYTES + wid * 4096;   /* this wave's 32 rows of the W tile */ \
         unsigned char* xs_ = ws_ + BT * BK * 2;                                                                    \
-        if constexpr (W8) {                                                                                        \
-            unsigned char* w8_ = smem + (stage_) * STAGE_BYTES + wid * 2048;   /* 32 rows x 64 B */                \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned char*>(wptr[i]) + k0_,            \
-                                                 (lds_ptr_t)(w8_ + i * 1024), 16, 0, 0);                           \
-        } else {                                                                                                   \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
-                __builtin_amdgcn_global_load_lds(wptr[i] + k0_, (lds_ptr_t)(ws_ + i * 1024), 16, 0, 0);            \
-        }                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
+            __builtin_amdgcn_global_load_lds(wptr[i] + k0_, (lds_ptr_t)(ws_ + i * 1024), 16, 0, 0);                \
         if constexpr (MODE != MODE_CONV) {                                                                         \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
                 __builtin_amdgcn_global_load_lds(xptr[i] + k0_, (lds_ptr_t)(xs_ + i * 1024), 16, 0, 0);            \
@@ -163,7 +136,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     // fp32 residual (attention / FF output projections: out = x + ...): this lane's 16 x 16 B of the 64 KiB tile are fetched NOW, behind
     // the first k-tile's DMA -- in the epilogue the read-modify-write of all workgroups at once was a pure latency / bandwidth tail
     // (cycle stamps, 8192 x 512 x 512: write-out 16.1 k cycles with the residual read there, 2.3 k without)
-    constexpr bool RESID_PF = (MODE == MODE_DENSE) && !W8;
+    constexpr bool RESID_PF = (MODE == MODE_DENSE);
     float4 rres[RESID_PF ? BT / 8 : 1];
     const bool resid_pf = RESID_PF && p.resid_f32 && p.out_kind == OUT_F32 && p.splits <= 1 && (p.N % 4) == 0;
     if constexpr (RESID_PF) {
@@ -197,14 +170,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                         \
             u32x4_t af[4], bfm[4];                                                                                 \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                        \
-                if constexpr (W8) {                                                                                \
-                    const int r_ = wave_n * 64 + i * 16 + fr;                                                      \
-                    const uint2 q_ = *reinterpret_cast<const uint2*>(ws_ + r_ * 64 +                               \
-                        (((ks * 2 + (fg >> 1)) ^ ((-(r_ >> 2)) & 3)) << 4) + (fg & 1) * 8);                        \
-                    af[i] = fp8x8_to_bf16x8(q_);                                                                   \
-                } else {                                                                                           \
-                    af[i] = *reinterpret_cast<const u32x4_t*>(ws_ + lds_off(wave_n * 64 + i * 16 + fr, ks * 4 + fg)); \
-                }                                                                                                  \
+                af[i] = *reinterpret_cast<const u32x4_t*>(ws_ + lds_off(wave_n * 64 + i * 16 + fr, ks * 4 + fg)); \
                 bfm[i] = *reinterpret_cast<const u32x4_t*>(xs_ + lds_off(wave_m * 64 + i * 16 + fr, ks * 4 + fg)); \
             }                                                                                                      \
             if (!(p.debug & 4)) {                                                                                  \
@@ -293,10 +259,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r];
-            }
-            if constexpr (W8) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= (n0 + nl + r < p.N) ? p.w_scale[n0 + nl + r] : 0.f;      // per-output-row dequantisation scale
             }
             if (p.bias) {
 #pragma unroll
@@ -441,18 +403,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     TSTAMP(43)
 }
 
-template <int MODE, bool W8 = false>
+template <int MODE>
 int launch(const GemmArgs& a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_kernel<MODE, W8>)),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_kernel<MODE>)),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
         if (e != hipSuccess) return mm_set_hip_error(e, "gemm hipFuncSetAttribute");
         attr_set = true;
     }
     const int blocks = a.tiles_m * a.tiles_n;
     if (blocks <= 0) return MM_OK;
-    hipLaunchKernelGGL((gemm_kernel<MODE, W8>), dim3(blocks, a.splits > 1 ? a.splits : 1), dim3(256), SMEM_BYTES, stream, a);
+    hipLaunchKernelGGL((gemm_kernel<MODE>), dim3(blocks, a.splits > 1 ? a.splits : 1), dim3(256), SMEM_BYTES, stream, a);
     return mm_check_launch("gemm_kernel");
 }
 
@@ -463,7 +425,7 @@ int g_mm_debug = 0;
 int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
     a.debug = g_mm_debug;
     if (a.K <= 0 || (a.K % BK) != 0) return mm_set_error(MM_ERR_SHAPE, "gemm: K must be a positive multiple of 64 (pad at pack time)");
-    if ((!a.w_scale && (a.ldw % 8) != 0) || (a.mode != MODE_CONV && (a.ldx % 8) != 0)) return mm_set_error(MM_ERR_ALIGN, "gemm: row strides must be multiples of 8 elements (16 B)");
+    if ((a.ldw % 8) != 0 || (a.mode != MODE_CONV && (a.ldx % 8) != 0)) return mm_set_error(MM_ERR_ALIGN, "gemm: row strides must be multiples of 8 elements (16 B)");
     if (a.mode == MODE_CONV && (a.Cin % 8) != 0) return mm_set_error(MM_ERR_SHAPE, "conv: Cin must be a multiple of 8");
     if (a.out_kind != OUT_NCHW_F32 && a.N >= 8 && ((a.out_kind == OUT_F32 && (a.ldc % 4)) || (a.out_kind == OUT_BF16 && (a.ldc % 8))))
         return mm_set_error(MM_ERR_ALIGN, "gemm: ldc must be a multiple of 4 (fp32 out) / 8 (bf16 out) elements");
@@ -472,13 +434,6 @@ int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
         return mm_set_error(MM_ERR_DTYPE, "gemm: the residual must have the output's dtype");
     if (a.epi == EPI_GEGLU && (a.mode != MODE_DENSE || (a.N % 128) || a.out_kind != OUT_BF16 || a.bias || a.resid_f32 || a.resid_bf16))
         return mm_set_error(MM_ERR_SHAPE, "gemm: GEGLU epilogue needs a dense bf16 GEMM with N % 128 == 0");
-    if (a.w_scale) {
-        // W8A16: fp8 e4m3 weights (ldw in BYTES = elements), dense / CFG only, on the 128x128 kernel
-        if (a.mode == MODE_CONV || a.epi != EPI_NONE || a.splits > 1 || (a.ldw % 16)) return mm_set_error(MM_ERR_SHAPE, "gemm: fp8 weights need a dense or CFG GEMM with 16-byte aligned weight rows");
-        a.tiles_n = (a.N + BT - 1) / BT;
-        a.tiles_m = (a.M + (a.mode == MODE_CFG ? 64 : BT) - 1) / (a.mode == MODE_CFG ? 64 : BT);
-        return a.mode == MODE_CFG ? launch<MODE_CFG, true>(a, stream) : launch<MODE_DENSE, true>(a, stream);
-    }
     if (a.splits > 1) {
         if (a.mode != MODE_DENSE || a.out_kind != OUT_F32 || a.resid_f32 || a.bias || a.epi != EPI_NONE || (a.K / BK) % a.splits)
             return mm_set_error(MM_ERR_SHAPE, "gemm: split-K needs a plain dense fp32-output GEMM with K/64 divisible by the split count");
@@ -488,13 +443,13 @@ int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
     }
     if (a.ln_part && !a.ln_c1) {
         // FF w1 that also emits the LayerNorm(inner) partial sums (every GEGLU epilogue of the family does, identically)
-        if (a.epi != EPI_GEGLU || a.w_scale) return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: LayerNorm partial sums ride on the GEGLU epilogue");
+        if (a.epi != EPI_GEGLU) return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: LayerNorm partial sums ride on the GEGLU epilogue");
         a.ln_np = a.N / 128;
     }
     if (a.ln_c1) {
         // FF w2 with the LayerNorm(inner) folded in: the fp32-residual epilogue of the 128x128 / 256x128 kernels
         if (a.mode != MODE_DENSE || !a.resid_f32 || a.out_kind != OUT_F32 || (a.N % 4) || !a.ln_part || !a.ln_c2 || a.ln_np <= 0 || a.ln_F <= 0 ||
-            a.w_scale || a.splits > 1)
+            a.splits > 1)
             return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: folded LayerNorm needs a dense fp32-residual GEMM");
     }
     // (the 256x256 GEGLU variant also emits the LayerNorm partial sums, but that path has no full-size test yet: a folded FF keeps w1 on

@@ -62,6 +62,8 @@ struct mm_transformer {
     std::vector<mm_layer_weights> layers;
     int I;    // heads * dim_head
     int Fp;
+    int F8;   // fp8 engine (mm_transformer_desc.fp8): the layers' Linear weights are e4m3 rows + per-row scales, their activations are quantised per token
+              // row by the producing kernel (fp8_act.hip), the products run on the K = 128 fp8 MFMA (gemm_fp8.hip); attention, to_logits, sampling: bf16 engine
     int P;    // 0: bf16 engine.  3 / 5 / 6: the 'bf16x3' precision tier (split.hip) -- every GEMM operand is P bf16 segments of an fp32 value, the
               // weights are packed to match ([N][P*K]), tables / q|k|v / GEMM outputs are fp32, attention runs on the fp32 MFMA (attention_f32.hip)
 };
@@ -173,6 +175,8 @@ struct Bufs {       // activation scratch for `rows` token rows
     bf16_t* h;      // [rows][2Fp]
     bf16_t* a;      // [rows][Fp]
     float* lnp;     // [rows][Fp / 32][2]: LayerNorm(inner) partial sums of the folded feed-forward
+    unsigned char* q8;   // fp8 engine: the e4m3 rows of the activation that feeds the next Linear, [rows][max(D, I, Fp)]
+    float* q8s;          // ... and their per-row scales [rows]
 };
 
 // precision tier: GEMM operands (xn, att, a) are P segments wide, GEMM outputs (qkv, h) are fp32
@@ -186,6 +190,28 @@ void carve_bufs(Carver& c, const mm_transformer* t, size_t rows, Bufs& b) {
     b.h = c.take<bf16_t>(rows * 2 * Fp * f32);
     b.a = c.take<bf16_t>(rows * Fp * seg);
     b.lnp = c.take<float>(rows * (Fp / 32) * 2);
+    b.q8 = nullptr; b.q8s = nullptr;
+    if (t->F8) {
+        const size_t w = (size_t)(D > I ? (D > Fp ? D : Fp) : (I > Fp ? I : Fp));
+        b.q8 = c.take<unsigned char>(rows * w);
+        b.q8s = c.take<float>(rows);
+    }
+}
+
+// fp8 engine: out = act . W^T on the fp8 MFMA; act given as e4m3 rows + scales (b.q8 / b.q8s, written by the producer in front of this call)
+int f8_linear(hipStream_t s, const Bufs& b, int K, const void* w, const float* w_scale, int M, int N, void* out, long ldc, int epi, const float* resid) {
+    GemmF8Args a;
+    memset(&a, 0, sizeof(a));
+    a.X = b.q8; a.ldx = K; a.sx = b.q8s;
+    a.W = (const unsigned char*)w; a.ldw = K; a.sw = w_scale;
+    a.M = M; a.N = N; a.K = K; a.out = out; a.ldc = ldc; a.epi = epi; a.resid = resid; a.ldr = ldc;
+    return k_gemm_fp8(s, a);
+}
+// ... with a bf16 activation (attention output): quantise its rows first
+int f8_linear_bf16(hipStream_t s, Bufs& b, const bf16_t* act, long lda, int K, const void* w, const float* w_scale, int M, int N, void* out, long ldc, int epi,
+                   const float* resid) {
+    RC(k_quantize_act_e4m3(s, act, 0, lda, M, K, K, b.q8, b.q8s));
+    return f8_linear(s, b, K, w, w_scale, M, N, out, ldc, epi, resid);
 }
 
 // dst += FF(src)   (mmp.py:79-89 with the residual of :193 / the self-cond add of :328)
@@ -200,6 +226,15 @@ int ff_block(const mm_transformer* t, hipStream_t s, const mm_ff_weights& w, con
         RC(gemm_dense(s, b.xn, P * D, (const bf16_t*)w.w1, P * D, rows, 2 * Fp, P * D, hf, 2 * Fp, OUT_F32, nullptr));
         RC(k_geglu_ln_split(s, hf, 2 * Fp, rows, F, Fp, w.ln2_gamma, w.ln2_beta, P, b.a));
         RC(gemm_dense(s, b.a, P * Fp, (const bf16_t*)w.w2, P * Fp, rows, D, P * Fp, dst, D, OUT_F32, dst));
+        TR(dst, (size_t)rows * D * 4);
+        return MM_OK;
+    }
+    if (t->F8) {      // fp8 engine: LN -> e4m3 | w1 + GEGLU (bf16) | LN(inner) -> e4m3 | w2 + residual
+        RC(k_layernorm_q8(s, const_cast<float*>(addvec ? dst : src), D, rows, D, w.ln1_gamma, w.ln1_beta, addvec, add_from, b.q8, D, b.q8s));
+        RC(f8_linear(s, b, D, w.w1, w.w1_scale, rows, 2 * Fp, b.h, Fp, 1, nullptr));
+        TR(b.h, (size_t)rows * Fp * 2);
+        RC(k_ln_inner_q8(s, b.h, Fp, rows, F, Fp, w.ln2_gamma, w.ln2_beta, b.q8, Fp, b.q8s));
+        RC(f8_linear(s, b, Fp, w.w2, w.w2_scale, rows, D, dst, D, 2, dst));
         TR(dst, (size_t)rows * D * 4);
         return MM_OK;
     }
@@ -268,15 +303,26 @@ int self_attn_core(const mm_transformer* t, hipStream_t s, const mm_attn_weights
         a.scale = 8.f; a.dh = dh;
         return k_attention_f32(s, a);
     }
-    RC(k_layernorm(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, b.xn, D));
-    TR(b.xn, (size_t)rows * D * 2);
     const bf16_t* wq = (const bf16_t*)w.w_q;
     const bf16_t* wkv = (const bf16_t*)w.w_kv;
+    if (t->F8) {      // fp8 engine: LN -> e4m3, q|k|v on the fp8 MFMA (bf16 out); the attention itself is the bf16 engine's
+        RC(k_layernorm_q8(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, 0, b.q8, D, b.q8s));
+        const unsigned char* q8w = (const unsigned char*)w.w_q;
+        if ((const unsigned char*)w.w_kv == q8w + (size_t)I * D && w.w_kv_scale == w.w_q_scale + I) {
+            RC(f8_linear(s, b, D, w.w_q, w.w_q_scale, rows, 3 * I, b.qkv, 3 * I, 0, nullptr));
+        } else {
+            RC(f8_linear(s, b, D, w.w_q, w.w_q_scale, rows, I, b.qkv, 3 * I, 0, nullptr));
+            RC(f8_linear(s, b, D, w.w_kv, w.w_kv_scale, rows, 2 * I, b.qkv + I, 3 * I, 0, nullptr));
+        }
+    } else {
+    RC(k_layernorm(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, b.xn, D));
+    TR(b.xn, (size_t)rows * D * 2);
     if (wkv == wq + (size_t)I * D) {
         RC(gemm_dense(s, b.xn, D, wq, D, rows, 3 * I, D, b.qkv, 3 * I, OUT_BF16, nullptr));
     } else {
         RC(gemm_dense(s, b.xn, D, wq, D, rows, I, D, b.qkv, 3 * I, OUT_BF16, nullptr));
         RC(gemm_dense(s, b.xn, D, wkv, D, rows, 2 * I, D, b.qkv + I, 3 * I, OUT_BF16, nullptr));
+    }
     }
     AttnArgs a;
     memset(&a, 0, sizeof(a));
@@ -297,7 +343,8 @@ int self_attn_core(const mm_transformer* t, hipStream_t s, const mm_attn_weights
 int self_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weights& w, int seqs, int n, Bufs& b) {
     RC(self_attn_core(t, s, w, seqs, n, b));
     const int KI = (t->P ? t->P : 1) * t->I;      // precision tier: P segments per operand row
-    RC(gemm_dense(s, b.att, KI, (const bf16_t*)w.w_out, KI, seqs * n, t->d.dim, KI, b.x, t->d.dim, OUT_F32, b.x));
+    if (t->F8) RC(f8_linear_bf16(s, b, b.att, t->I, t->I, w.w_out, w.w_out_scale, seqs * n, t->d.dim, b.x, t->d.dim, 2, b.x));
+    else RC(gemm_dense(s, b.att, KI, (const bf16_t*)w.w_out, KI, seqs * n, t->d.dim, KI, b.x, t->d.dim, OUT_F32, b.x));
     TR(b.x, (size_t)seqs * n * t->d.dim * 4);
     return MM_OK;
 }
@@ -328,9 +375,14 @@ int cross_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weigh
         TR(b.x, (size_t)rows * D * 4);
         return MM_OK;
     }
-    RC(k_layernorm(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, b.xn, D));
-    TR(b.xn, (size_t)rows * D * 2);
-    RC(gemm_dense(s, b.xn, D, (const bf16_t*)w.w_q, D, rows, I, D, b.qkv, I, OUT_BF16, nullptr));
+    if (t->F8) {      // fp8 engine: LN -> e4m3, q projection on the fp8 MFMA (the context's k | v projection stays bf16: once per generate)
+        RC(k_layernorm_q8(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, 0, b.q8, D, b.q8s));
+        RC(f8_linear(s, b, D, w.w_q, w.w_q_scale, rows, I, b.qkv, I, 0, nullptr));
+    } else {
+        RC(k_layernorm(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, b.xn, D));
+        TR(b.xn, (size_t)rows * D * 2);
+        RC(gemm_dense(s, b.xn, D, (const bf16_t*)w.w_q, D, rows, I, D, b.qkv, I, OUT_BF16, nullptr));
+    }
     TR(b.qkv, (size_t)rows * I * 2);
     AttnArgs a;
     memset(&a, 0, sizeof(a));
@@ -344,7 +396,8 @@ int cross_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weigh
     a.scale = 8.f; a.dh = dh; a.kv_batch_mod = kv_batch_mod;
     RC(k_attention(s, a));
     TR(b.att, (size_t)rows * I * 2);
-    RC(gemm_dense(s, b.att, I, (const bf16_t*)w.w_out, I, rows, D, I, b.x, D, OUT_F32, b.x));
+    if (t->F8) RC(f8_linear_bf16(s, b, b.att, I, I, w.w_out, w.w_out_scale, rows, D, b.x, D, 2, b.x));
+    else RC(gemm_dense(s, b.att, I, (const bf16_t*)w.w_out, I, rows, D, I, b.x, D, OUT_F32, b.x));
     TR(b.x, (size_t)rows * D * 4);
     return MM_OK;
 }
@@ -379,6 +432,20 @@ int mm_transformer_create(const mm_transformer_desc* desc, mm_transformer_t** ou
     t->I = d.heads * d.dim_head;
     t->Fp = d.ff_inner_padded;
     t->P = d.split_products;
+    t->F8 = d.fp8 ? 1 : 0;
+    if (t->F8) {
+        bool ok = t->P == 0 && (d.dim % 128) == 0 && (t->I % 128) == 0 && (t->Fp % 128) == 0;
+        for (int l = 0; ok && l < d.depth; ++l) {
+            const mm_layer_weights& w = t->layers[l];
+            ok = w.self_attn.w_q_scale && w.self_attn.w_kv_scale && w.self_attn.w_out_scale && w.cross_attn.w_q_scale && w.cross_attn.w_out_scale &&
+                 w.ff.w1_scale && w.ff.w2_scale;
+        }
+        if (ok && d.self_cond) ok = d.self_cond_ff.w1_scale && d.self_cond_ff.w2_scale;
+        if (!ok) {
+            delete t;
+            return mm_set_error(MM_ERR_SHAPE, "transformer: the fp8 engine needs dim, heads * dim_head and ff_inner_padded to be multiples of 128, split_products == 0 and a scale vector for every e4m3 weight");
+        }
+    }
     *out = t;
     return MM_OK;
 }
@@ -710,7 +777,8 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
             // query, so the null pass's cross-attention is the constant row to_out(null_v)
             if (PT) RC(k_split_rows(s, w.null_v, I, 1, I, PT, 0, 0, g.nullv, nullptr, 0, 0));
             else RC(k_f32_to_bf16(s, w.null_v, g.nullv, I));
-            RC(gemm_dense(s, g.nullv, KI, (const bf16_t*)w.w_out, KI, 1, D, KI, g.cvec + (size_t)l * D, D, OUT_F32, nullptr));
+            if (t->F8) RC(f8_linear_bf16(s, g.b, g.nullv, I, I, w.w_out, w.w_out_scale, 1, D, g.cvec + (size_t)l * D, D, 2, nullptr));
+            else RC(gemm_dense(s, g.nullv, KI, (const bf16_t*)w.w_out, KI, 1, D, KI, g.cvec + (size_t)l * D, D, OUT_F32, nullptr));
         }
     }
     {
@@ -782,7 +850,8 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
                     RC(k_gather_rows16(s, b.x, (long)D * 4, g.rows, R, h * M, D * 4, g.xc + (size_t)h * R * D));
                     RC(k_gather_rows16(s, b.att, (long)KI * 2, g.rows, R, h * M, KI * 2, g.attc + (size_t)h * R * KI));
                 }
-                RC(gemm_dense(s, g.attc, KI, (const bf16_t*)w.self_attn.w_out, KI, P * R, D, KI, g.xc, D, OUT_F32, g.xc));
+                if (t->F8) RC(f8_linear_bf16(s, b, g.attc, I, I, w.self_attn.w_out, w.self_attn.w_out_scale, P * R, D, g.xc, D, 2, g.xc));
+                else RC(gemm_dense(s, g.attc, KI, (const bf16_t*)w.self_attn.w_out, KI, P * R, D, KI, g.xc, D, OUT_F32, g.xc));
                 bc.x = g.xc; bc.att = g.attc;
             } else if (l == 0 && share0) {
                 RC(self_attn_block(t, s, w.self_attn, B, n, b));

@@ -28,7 +28,6 @@ struct GemmArgs {
     int act; float cfg_scale;
     int epi;                      // EPI_GEGLU: W rows are GEGLU-interleaved, the tile emits N/2 columns of gate*gelu(x)
     int tiles_m, tiles_n;         // filled by mm_gemm_launch
-    const float* w_scale;         // non-null: W is fp8 e4m3 [N][ldw bytes] with one dequantisation scale per row (W8A16)
     int splits; long split_stride; // split-K (weight gradients): gridDim.y = splits, split s sums k-tiles [s*K/splits, (s+1)*K/splits) into out + s*split_stride floats
     // LayerNorm(inner) folded into the FF GEMM pair (model.hip ff_block):
     //   w1 + GEGLU (any kernel of the family): ln_part != NULL -> per output row and 64 output columns the sum and sum of squares of
@@ -91,6 +90,10 @@ struct GemmF8Args {
 int k_gemm_fp8(hipStream_t s, const GemmF8Args& a);
 // activation rows -> e4m3 + per-row scale (max |x| / 448); columns K..Kp-1 zero.  bf16 or fp32 input
 int k_quantize_act_e4m3(hipStream_t s, const void* x, int x_f32, long ldx, int rows, int K, int Kp, unsigned char* xq, float* scale);
+// LayerNorm -> e4m3 rows + scales (fp8_act.hip); addvec != NULL: rows >= add_from get it added to x in place first
+int k_layernorm_q8(hipStream_t s, float* x, long ldx, int rows, int D, const float* gamma, const float* beta, const float* addvec, int add_from,
+                   unsigned char* q8, long ldq, float* qs);
+int k_ln_inner_q8(hipStream_t s, const bf16_t* a, long lda, int rows, int F, int Fp, const float* gamma, const float* beta, unsigned char* q8, long ldq, float* qs);
 
 struct AttnArgs {
     const bf16_t* q; long q_sb, q_sh, q_sn;      // element strides: batch, head, token (d contiguous, dh = 64)

@@ -158,8 +158,8 @@ class Transformer(nn.Module):
         self._x3_min_products = 0      # MaskGit raises it so that a generator and its token critic are packed with the same number of term products
         self._ws = None
         self.grad_sync = None          # optional parallel.GradBucketer: data-parallel gradient averaging inside the backward
-        self.weight_format = 'bf16'    # 'fp8': W8A16 inference (BASELINE configs[4]), see quantize_weights_fp8()
-        self._fp8 = None
+        self._handle_f8 = None         # packed weights + C handle of the fp8 engine (precision 'fp8', built on first use)
+        self._handle_f8_key = None
         self.precision = 'bf16'        # 'bf16x3': fp32-grade tier on the bf16 matrix pipe inside the same C loop; 'parity': fp32 MFMA, operator by operator (set_precision)
 
     # ---- packing (once per parameter version / device)
@@ -213,6 +213,10 @@ class Transformer(nn.Module):
             if self._handle_x3 is None or self._handle_x3_key != key:
                 self._handle_x3, self._handle_x3_key = self._model_x3(), key
             return self._handle_x3
+        if self.precision == 'fp8':
+            if self._handle_f8 is None or self._handle_f8_key != key:
+                self._handle_f8, self._handle_f8_key = self._model_fp8(), key
+            return self._handle_f8
         if self._handle is not None and self._handle_key == key:
             return self._handle
         h = _Handle()
@@ -353,17 +357,17 @@ class Transformer(nn.Module):
     def invalidate_packed_weights(self):
         """Drop the packed device copies of the weights (rebuilt on the next call).  Needed only after edits the version counters cannot
         see (`param.data.copy_(...)`, raw pointer writes); `load_state_dict`, `.to()`, optimizer steps and in-place ops are detected."""
-        self._handle, self._handle_key, self._fp8 = None, None, None
+        self._handle, self._handle_key, self._handle_f8 = None, None, None
         self._handle_x3, self._handle_x3_key = None, None
         return self
 
     def _apply(self, fn, *args, **kwargs):
-        self._handle, self._handle_key, self._fp8 = None, None, None
+        self._handle, self._handle_key, self._handle_f8 = None, None, None
         self._handle_x3, self._handle_x3_key = None, None
         return super()._apply(fn, *args, **kwargs)
 
     def load_state_dict(self, *args, **kwargs):
-        self._handle, self._handle_key, self._fp8 = None, None, None
+        self._handle, self._handle_key, self._handle_f8 = None, None, None
         self._handle_x3, self._handle_x3_key = None, None
         return super().load_state_dict(*args, **kwargs)
 
@@ -374,9 +378,11 @@ class Transformer(nn.Module):
         term products on the bf16 matrix pipe, fp32 everywhere else, attention on the fp32 MFMA (csrc/split.hip, attention_f32.hip);
         logits within 1e-3 of the reference's fp32 run and bit-equal ids at full size.  Inference only.
         'parity': precision level L0 -- fp32 storage and fp32 MFMA through the reference's exact operator sequence, one
-        operator call at a time from Python (parity.py / csrc/parity.hip): the verification baseline of the tier above.  Inference only."""
-        if precision not in ('bf16', 'bf16x3', 'parity'):
-            raise ValueError(f"precision must be 'bf16', 'bf16x3' or 'parity', got {precision!r}")
+        operator call at a time from Python (parity.py / csrc/parity.hip): the verification baseline of the tier above.  Inference only.
+        'fp8': the fp8 engine (BASELINE configs[4]) inside the same C entry points -- e4m3 weights and activations on the K = 128 fp8 MFMA for the
+        Linear layers of the blocks (quantize_weights_fp8); self-defined numerics.  Inference only."""
+        if precision not in ('bf16', 'bf16x3', 'parity', 'fp8'):
+            raise ValueError(f"precision must be 'bf16', 'bf16x3', 'parity' or 'fp8', got {precision!r}")
         self.precision = precision
         return self
 
@@ -412,9 +418,7 @@ class Transformer(nn.Module):
         return ctx, mask
 
     def _run(self, ids, ctx, mask, self_cond_embed=None, want_embed=True, want_logits=True):
-        if self.weight_format == 'fp8':
-            return self._run_fp8(ids, ctx, mask, self_cond_embed, want_embed, want_logits)
-        assert self.precision in ('bf16', 'bf16x3')
+        assert self.precision in ('bf16', 'bf16x3', 'fp8')
         h = self._model()
         dev = self.token_emb.weight.device
         ids = ids.to(device=dev, dtype=torch.long).contiguous()
@@ -440,110 +444,109 @@ class Transformer(nn.Module):
             return ops.unsplit_rows(embed, embed.shape[-1] // self.dim, self.dim)
         return embed.float()
 
-    # ---- fp8 weights (BASELINE configs[4] "fp8 MFMA weights"; W8A16: e4m3 weights with one scale per output row, bf16 activations)
+    # ---- fp8 engine (BASELINE configs[4] "fp8 MFMA weights"): e4m3 weights AND activations on the K = 128 fp8 MFMA, inside the same C entry points
     def quantize_weights_fp8(self, enabled=True):
-        """Switch inference to fp8 (OCP e4m3) Linear weights: every nn.Linear of the blocks and to_logits is quantised per output row
-        (`mm_quantize_e4m3_rows`) and multiplied through `mm_gemm_w8a16` (fp8 weight tiles widened to bf16 in registers -- exact --
-        fp32 accumulate, scale applied to the accumulators).  Embeddings, norms, scales, null k/v and the text projection stay as they
-        are.  The forward then runs operator by operator from Python and `MaskGit.generate` takes its stepwise loop; the fused bf16
-        engine is untouched.  Self-defined oracle (SURVEY 8c "L2"): the fp32 oracle on the de-quantised weights (`fp8_dequantized_state_dict`)."""
-        self.weight_format = 'fp8' if enabled else 'bf16'
-        self._fp8 = None
-        return self
+        """Switch inference to the fp8 engine (`set_precision('fp8')`): the Linear weights of the blocks are quantised per output row to OCP e4m3
+        (`mm_quantize_e4m3_rows`), their input activations per token row inside the producing kernels, and the products run on
+        v_mfma_f32_16x16x128_f8f6f4 (`mm_gemm_fp8`) inside `mm_transformer_forward` / `mm_generate`.  Embeddings, norms, the text projection, the
+        cross-attention's key/value projection of the context, attention, to_logits and the sampling are the bf16 engine's.  Self-defined oracle
+        (SURVEY 8c "L2"): the fp32 restatement with the same per-row fake quantisation at the same Linear inputs, run on `fp8_dequantized_state_dict()`
+        (tests/test_gpu_fp8_engine.py)."""
+        return self.set_precision('fp8' if enabled else 'bf16')
 
-    def _fp8_pack(self):
-        key = self._pack_key()
-        if self._fp8 is not None and self._fp8['key'] == key:
-            return self._fp8
-        q = ops.quantize_e4m3_rows
-        f32c = lambda x: x.detach().float().contiguous()
-        P = dict(key=key, layers=[])
-
-        def ff_pack(ff):
-            w1, w2 = ff[1].weight.detach(), ff[4].weight.detach()
-            F, D = w2.shape[1], w1.shape[1]
-            Fp = (F + 63) // 64 * 64
-            w1p = torch.zeros(2 * Fp, D, dtype=torch.float32, device=w1.device)          # plain [x | gate] halves, each padded to Fp rows
-            w1p[:F] = w1[:F]
-            w1p[Fp:Fp + F] = w1[F:]
-            return dict(F=F, g1=f32c(ff[0].gamma), b1=ff[0].beta.float().contiguous(), w1=q(w1p), g2=f32c(ff[3].gamma),
-                        b2=ff[3].beta.float().contiguous(), w2=q(w2))
-
-        def attn_pack(a, fused):
-            d = dict(g=f32c(a.norm.gamma), b=a.norm.beta.float().contiguous(), wo=q(a.to_out.weight), nk=f32c(a.null_kv[0, :, 0, :]),
-                     nv=f32c(a.null_kv[1, :, 0, :]), qs=f32c(a.q_scale), ks=f32c(a.k_scale))
-            if fused:
-                d['wqkv'] = q(torch.cat([a.to_q.weight.detach(), a.to_kv.weight.detach()], 0))
-            else:
-                d['wq'], d['wkv'] = q(a.to_q.weight), q(a.to_kv.weight)
-            return d
-        for sa, ca, ff in self.transformer_blocks.layers:
-            P['layers'].append(dict(sa=attn_pack(sa, True), ca=attn_pack(ca, False), ff=ff_pack(ff)))
-        P['sc'] = ff_pack(self.self_cond_to_init_embed)
-        P['wl'] = q(self.to_logits.weight)
-        P['tok'], P['pos'] = self.token_emb.weight.detach().to(bf16).contiguous(), self.pos_emb.weight.detach().to(bf16).contiguous()
-        P['fg'], P['fb'] = f32c(self.transformer_blocks.norm.gamma), self.transformer_blocks.norm.beta.float().contiguous()
-        self._fp8 = P
-        return P
+    FP8_LINEARS = ('0.to_q.weight', '0.to_kv.weight', '0.to_out.weight', '1.to_q.weight', '1.to_out.weight', '2.1.weight', '2.4.weight')
 
     def fp8_dequantized_state_dict(self):
-        """state_dict with every fp8-quantised Linear weight replaced by its de-quantised value (what the W8A16 path multiplies by)."""
+        """state_dict with every Linear weight the fp8 engine quantises replaced by its de-quantised value (what the engine multiplies by)."""
         sd = {k: v.detach().clone() for k, v in self.state_dict().items()}
 
         def dq(w):
             wq, sc = ops.quantize_e4m3_rows(w)
             return (wq[:, :w.shape[1]].view(torch.float8_e4m3fn).float() * sc[:, None]).to(w.dtype)
         for k in list(sd):
-            if k.startswith('transformer_blocks.layers.') and k.endswith('.weight') or k == 'to_logits.weight' or k.startswith('self_cond_to_init_embed.') and k.endswith('.weight'):
+            if (k.startswith('transformer_blocks.layers.') and k.split('.', 3)[3] in self.FP8_LINEARS) or \
+                    (k.startswith('self_cond_to_init_embed.') and k.endswith('.weight')):
                 sd[k] = dq(sd[k])
         return sd
 
-    def _run_fp8(self, ids, ctx, mask, self_cond_embed, want_embed, want_logits):
-        P = self._fp8_pack()
-        dev = self.token_emb.weight.device
-        ids = ids.to(device=dev, dtype=torch.long).contiguous()
-        b, n = ids.shape
-        H = self.transformer_blocks.cfg['heads']
-        if self.transformer_blocks.cfg['dim_head'] != 64:
-            raise NotImplementedError('the W8A16 operator path is written for dim_head 64')
-        I = H * 64
-        m = ctx.shape[1]
-        cx = ctx.reshape(b * m, self.dim)
-        heads = lambda t, rows, c0=0: t[:, c0:c0 + I].unflatten(0, (b, rows)).unflatten(2, (H, 64)).permute(0, 2, 1, 3)
-        g8 = lambda x_, w_, **kw: ops.gemm_w8a16(x_, w_[0], w_[1], **kw)
+    def _model_fp8(self):
+        """weights of the fp8 engine (mm_transformer_desc.fp8): the layers' Linear weights as e4m3 rows + per-row scales, everything else as the bf16
+        engine packs it; the feed-forward's inner width is padded to a multiple of 128 (the fp8 MFMA's k-step)"""
+        h = _Handle()
+        tb = self.transformer_blocks
+        cfg = tb.cfg
+        if self.dim % 128 or (cfg['heads'] * cfg['dim_head']) % 128:
+            raise NotImplementedError('the fp8 engine needs dim and heads * dim_head to be multiples of 128')
+        f32c = lambda x: x.detach().float().contiguous()
+        q = ops.quantize_e4m3_rows
 
-        def ff(fp, x_in, resid):
-            u = ops.layernorm(x_in, fp['g1'], fp['b1'])
-            z = ops.geglu_ln(g8(u, fp['w1']), fp['F'], fp['g2'], fp['b2'])
-            return g8(z, fp['w2'], out_f32=True, resid=resid)
-        x = ops.embed(ids, P['tok'], P['pos'])
-        if self.self_cond:
-            sce = torch.zeros_like(x) if not exists(self_cond_embed) else self_cond_embed.to(device=dev, dtype=torch.float32).reshape(b * n, self.dim).contiguous()
-            x = ff(P['sc'], sce, x)
-        for lp in P['layers']:
-            a = lp['sa']
-            qkv = g8(ops.layernorm(x, a['g'], a['b']), a['wqkv'])
-            o = ops.attend(heads(qkv, n), heads(qkv, n, I), heads(qkv, n, 2 * I), normalize=True, q_scale=a['qs'], k_scale=a['ks'], null_k=a['nk'],
-                           null_v=a['nv'], out_rows=True)
-            x = g8(o, a['wo'], out_f32=True, resid=x)
-            c = lp['ca']
-            q2 = g8(ops.layernorm(x, c['g'], c['b']), c['wq'])
-            kv2 = g8(cx, c['wkv'])
-            o2 = ops.attend(heads(q2, n), heads(kv2, m), heads(kv2, m, I), key_mask=mask, normalize=True, q_scale=c['qs'], k_scale=c['ks'],
-                            null_k=c['nk'], null_v=c['nv'], out_rows=True)
-            x = g8(o2, c['wo'], out_f32=True, resid=x)
-            x = ff(lp['ff'], x, x)
-        embed = ops.layernorm(x, P['fg'], P['fb'])
-        logits = g8(embed, P['wl'], out_f32=True) if want_logits else None
-        return embed, logits
+        def pack_ff(ff):
+            w1, w2 = ff[1].weight.detach(), ff[4].weight.detach()
+            F = w2.shape[1]
+            Fp = (F + 127) // 128 * 128
+            w1q, w1s = q(ops.pack_w1_geglu(w1, Fp).float())                      # the bf16 engine's GEGLU interleave, quantised row by row
+            w2p = torch.zeros(w2.shape[0], Fp, dtype=torch.float32, device=w2.device)
+            w2p[:, :F] = w2.float()
+            w2q, w2s = q(w2p)
+            t = dict(g1=f32c(ff[0].gamma), b1=ff[0].beta.float().contiguous(), w1=w1q, w1s=w1s, g2=ops.pad_cols(f32c(ff[3].gamma), Fp),
+                     b2=ops.pad_cols(ff[3].beta.float(), Fp), w2=w2q, w2s=w2s)
+            h.keep.append(t)
+            return L.FFWeights(L.ptr(t['g1']), L.ptr(t['b1']), L.ptr(t['w1']), L.ptr(t['g2']), L.ptr(t['b2']), L.ptr(t['w2']), None, None, None,
+                               L.ptr(t['w1s']), L.ptr(t['w2s'])), F, Fp
+
+        def pack_attn(a, fused):
+            I, D = a.to_q.weight.shape
+            t = dict(g=f32c(a.norm.gamma), b=f32c(a.norm.beta), nk=f32c(a.null_kv[0, :, 0, :]), nv=f32c(a.null_kv[1, :, 0, :]), qs=f32c(a.q_scale),
+                     ks=f32c(a.k_scale))
+            t['wo'], t['wos'] = q(a.to_out.weight)
+            if fused:      # q | k | v as one e4m3 matrix with one scale vector: a single GEMM
+                t['w'], t['ws'] = q(torch.cat([a.to_q.weight.detach(), a.to_kv.weight.detach()], dim=0))
+                wq_ptr, wkv_ptr = t['w'].data_ptr(), t['w'].data_ptr() + I * D
+                wqs_ptr, wkvs_ptr = t['ws'].data_ptr(), t['ws'].data_ptr() + I * 4
+            else:          # cross-attention: q on the fp8 MFMA; the context's k | v projection stays bf16 (once per generate)
+                t['w'], t['ws'] = q(a.to_q.weight)
+                t['wkv'] = a.to_kv.weight.detach().to(bf16).contiguous()
+                wq_ptr, wkv_ptr, wqs_ptr, wkvs_ptr = t['w'].data_ptr(), t['wkv'].data_ptr(), t['ws'].data_ptr(), None
+            h.keep.append(t)
+            return L.AttnWeights(L.ptr(t['g']), L.ptr(t['b']), C.c_void_p(wq_ptr), C.c_void_p(wkv_ptr), L.ptr(t['wo']), L.ptr(t['nk']), L.ptr(t['nv']),
+                                 L.ptr(t['qs']), L.ptr(t['ks']), C.c_void_p(wqs_ptr), C.c_void_p(wkvs_ptr), L.ptr(t['wos']))
+        layers = (L.LayerWeights * cfg['depth'])()
+        F = Fp = 0
+        for i, (sa, ca, ff) in enumerate(tb.layers):
+            layers[i].self_attn = pack_attn(sa, True)
+            layers[i].cross_attn = pack_attn(ca, False)
+            layers[i].ff, F, Fp = pack_ff(ff)
+        sc_ff, _, _ = pack_ff(self.self_cond_to_init_embed)
+        t = dict(tok=self.token_emb.weight.detach().to(bf16).contiguous(), pos=self.pos_emb.weight.detach().to(bf16).contiguous(),
+                 fg=f32c(tb.norm.gamma), fb=f32c(tb.norm.beta), wl=self.to_logits.weight.detach().to(bf16).contiguous(),
+                 tp=self.text_embed_proj.weight.detach().to(bf16).contiguous() if isinstance(self.text_embed_proj, nn.Linear) else None)
+        t['wmean'] = t['wcov'] = None
+        if self.dim_out % 256 == 0 and self.dim_out >= 4096:
+            wt = t['wl'].float().t().contiguous()
+            t['wmean'] = wt.mean(dim=1).contiguous()
+            t['wcov'] = (P32.gemm(wt, wt) / float(self.dim_out) - torch.outer(t['wmean'], t['wmean'])).to(bf16).contiguous()
+            del wt
+        h.keep.append(t)
+        h.keep.append(layers)
+        d = L.TransformerDesc()
+        d.dim, d.depth, d.heads, d.dim_head = self.dim, cfg['depth'], cfg['heads'], cfg['dim_head']
+        d.ff_inner, d.ff_inner_padded = F, Fp
+        d.seq_len, d.num_tokens, d.vocab_rows, d.dim_out = self.seq_len, self.num_tokens, self.token_emb.weight.shape[0], self.dim_out
+        d.text_dim, d.self_cond = self.text_embed_dim, int(bool(self.self_cond))
+        d.token_emb, d.pos_emb, d.text_proj = L.ptr(t['tok']), L.ptr(t['pos']), L.ptr(t['tp'])
+        d.layers = C.cast(layers, C.POINTER(L.LayerWeights))
+        d.final_gamma, d.final_beta, d.to_logits = L.ptr(t['fg']), L.ptr(t['fb']), L.ptr(t['wl'])
+        d.self_cond_ff = sc_ff
+        d.logits_wmean, d.logits_wcov = L.ptr(t['wmean']), L.ptr(t['wcov'])
+        d.fp8 = 1
+        L.check(L.lib().mm_transformer_create(C.byref(d), C.byref(h.ptr)), 'mm_transformer_create')
+        h.packed = t
+        return h
 
     def _cfg_logits(self, emb_a, emb_b, cond_scale):
         """the guidance-combined logits b + (a - b) * cond_scale of two passes (mmp.py:250-254, 332) from their final embeddings."""
         if self.precision == 'parity':
             return P32.cfg_logits(self, emb_a, emb_b, cond_scale)
-        if self.weight_format == 'fp8':
-            wl = self._fp8_pack()['wl']
-            return ops.gemm_w8a16(emb_a, wl[0], wl[1], x_null=emb_b, cond_scale=cond_scale)
         # guidance in the embedding: to_logits is linear, so b + (a - b) * s of the logits is to_logits(e_b + (e_a - e_b) * s): mix, then ONE GEMM
         # (what mm_generate does; every GEMM kernel of the family accumulates in the same order, so the two agree bit for bit)
         return ops.gemm(ops.cfg_mix(emb_a, emb_b, cond_scale, self.dim), self._model().packed['wl'], out_f32=True)
@@ -744,7 +747,7 @@ class MaskGit(nn.Module):
         self.load_state_dict(torch.load(str(path)))
 
     def set_precision(self, precision):
-        """'bf16' | 'bf16x3' | 'parity' for the transformer and the token critic (see Transformer.set_precision); the VAEs take 'bf16' or their
+        """'bf16' | 'bf16x3' | 'parity' | 'fp8' for the transformer and the token critic (see Transformer.set_precision); the VAEs take 'bf16' or their
         fp32 engine ('parity', also under 'bf16x3': the decoder is outside the decode loop and already meets 1e-3 in bf16, the fp32 engine
         makes the LFQ encode ids of a super-resolution condition image exact)."""
         self.transformer.set_precision(precision)
@@ -752,7 +755,7 @@ class MaskGit(nn.Module):
             self.token_critic.set_precision(precision)
         for v in (self.vae, self.cond_vae):
             if exists(v):
-                v.set_precision('parity' if precision == 'bf16x3' else precision)
+                v.set_precision({'bf16x3': 'parity', 'fp8': 'bf16'}.get(precision, precision))      # (the fp8 engine covers the transformer's Linear layers)
         return self
 
     def _mask_counts(self, timesteps, seq_len, device='cpu'):
@@ -787,8 +790,8 @@ class MaskGit(nn.Module):
             assert exists(neg_text_embeds) or len(texts) == len(negative_texts)       # mmp.py:541
         critic = self.token_critic if use_token_critic else None
         critic_net = critic.net if isinstance(critic, SelfCritic) else critic
-        if (exists(negative_texts) or exists(neg_text_embeds) or stepwise or tr.weight_format == 'fp8' or tr.precision == 'parity'
-                or (exists(critic_net) and (critic_net.weight_format == 'fp8' or critic_net.precision == 'parity'))):
+        if (exists(negative_texts) or exists(neg_text_embeds) or stepwise or tr.precision == 'parity'
+                or (exists(critic_net) and critic_net.precision == 'parity')):
             # the negative-prompt extension and the fp8 / parity engines run the loop one step at a time over the same C-ABI operators
             return self._generate_stepwise(texts, cond_images, fmap_size, temperature, topk_filter_thres, can_remask_prev_masked,
                                            use_token_critic, timesteps, cond_scale, critic_noise_scale, text_embeds, noise, noise_kind,

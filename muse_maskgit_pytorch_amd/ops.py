@@ -543,28 +543,41 @@ def vq_gather(ids, codebook):
 
 # ------------------------------------------------------------------------------------------------ fp8 weights (W8A16)
 def quantize_e4m3_rows(w):
-    """fp32/bf16 [N, K] -> (wq uint8 [N, Kp] OCP-e4m3 bytes, Kp = K rounded up to 64, zero padded; scale fp32 [N])."""
+    """fp32/bf16 [N, K] -> (wq uint8 [N, Kp] OCP-e4m3 bytes, Kp = K rounded up to 128 -- the fp8 MFMA's k-step --, zero padded; scale fp32 [N])."""
     _chk_cuda(w)
     w = w.detach().float().contiguous()
     N, K = w.shape
-    Kp = (K + 63) // 64 * 64
+    Kp = (K + 127) // 128 * 128
     wq = torch.empty(N, Kp, dtype=torch.uint8, device=w.device)
     scale = torch.empty(N, dtype=torch.float32, device=w.device)
     L.check(L.lib().mm_quantize_e4m3_rows(L.stream(), L.ptr(w), K, N, K, Kp, L.ptr(wq), L.ptr(scale)), 'mm_quantize_e4m3_rows')
     return wq, scale
 
 
-def gemm_w8a16(x, wq, scale, out_f32=False, resid=None, x_null=None, cond_scale=1.0):
-    """x bf16 [M, Kp] @ dequant(wq [N, Kp], scale [N])^T; x_null: guidance form null + (cond - null) * cond_scale (fp32)."""
-    _chk_cuda(x, wq, scale, resid, x_null)
+def quantize_act_e4m3(x, Kp=None):
+    """activation rows (bf16 or fp32 [M, K]) -> (xq uint8 [M, Kp] OCP-e4m3 bytes, scale fp32 [M]); Kp defaults to K rounded up to 128"""
+    _chk_cuda(x)
+    x = x.contiguous()
     M, K = x.shape
+    Kp = Kp or (K + 127) // 128 * 128
+    xq = torch.empty(M, Kp, dtype=torch.uint8, device=x.device)
+    scale = torch.empty(M, dtype=torch.float32, device=x.device)
+    assert x.dtype in (bf16, torch.float32)
+    L.check(L.lib().mm_quantize_act_e4m3(L.stream(), L.ptr(x), int(x.dtype == torch.float32), x.stride(0), M, K, Kp, L.ptr(xq), L.ptr(scale)), 'mm_quantize_act_e4m3')
+    return xq, scale
+
+
+def gemm_fp8(xq, x_scale, wq, w_scale, epilogue=0, resid=None):
+    """e4m3 x e4m3 on the K = 128 fp8 MFMA: out[m][n] = x_scale[m] * w_scale[n] * sum_k xq[m][k] wq[n][k].  epilogue 0: bf16 [M, N]; 1: GEGLU over
+    w1 rows interleaved in 64-row blocks (32 values | 32 gates), bf16 [M, N / 2]; 2: fp32 [M, N] (+ resid)"""
+    _chk_cuda(xq, x_scale, wq, w_scale, resid)
+    M, K = xq.shape
     N = wq.shape[0]
-    assert wq.dtype == torch.uint8 and wq.shape[1] == K and x.dtype == bf16
-    f32o = out_f32 or x_null is not None
-    ldc = (N + 7) // 8 * 8
-    out = torch.empty(M, ldc, dtype=torch.float32 if f32o else bf16, device=x.device)[:, :N]
-    L.check(L.lib().mm_gemm_w8a16(L.stream(), L.ptr(x), L.ptr(x_null), x.stride(0), L.ptr(wq), wq.stride(0), L.ptr(scale), M, N, K, L.ptr(out),
-                                  out.stride(0), int(f32o), L.ptr(resid), float(cond_scale)), 'mm_gemm_w8a16')
+    assert xq.dtype == torch.uint8 and wq.dtype == torch.uint8 and wq.shape[1] == K and K % 128 == 0
+    oc = N // 2 if epilogue == 1 else N
+    out = torch.empty(M, oc, dtype=torch.float32 if epilogue == 2 else bf16, device=xq.device)
+    L.check(L.lib().mm_gemm_fp8(L.stream(), L.ptr(xq), xq.stride(0), L.ptr(x_scale), L.ptr(wq), wq.stride(0), L.ptr(w_scale), M, N, K, L.ptr(out), out.stride(0),
+                                int(epilogue), L.ptr(resid)), 'mm_gemm_fp8')
     return out
 
 

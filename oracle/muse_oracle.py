@@ -39,6 +39,36 @@ def _rp(rp, t):
     return t if rp is None else rp(t)
 
 
+def e4m3_rows(t):
+    """per-row fake quantisation to OCP e4m3 (the fp8 engine's rule for weights and activations: scale = max |row| / 448, 1 for a zero row;
+    row / scale rounded to nearest even; the product uses value * scale)"""
+    amax = t.abs().amax(dim=-1, keepdim=True)
+    scale = torch.where(amax > 0, amax / 448., torch.ones_like(amax))
+    return (t / scale).to(torch.float8_e4m3fn).to(torch.float32) * scale
+
+
+class Fp8Rounding:
+    """rounding points of the fp8 engine (self-defined numerics, SURVEY 8c "L2"; csrc/gemm_fp8.hip, fp8_act.hip): called like bf16_round wherever the
+    HIP pipeline stores bf16, and `gq` is applied to the activation that feeds one of the layers' Linear weights -- the fp32 LayerNorm output (NOT
+    rounded to bf16 first: the LayerNorm kernels quantise their fp32 values) or the bf16 attention output.  Use with the de-quantised weights
+    (Transformer.fp8_dequantized_state_dict)."""
+
+    def __call__(self, t):
+        return bf16_round(t)
+
+    @staticmethod
+    def gq(t):
+        return e4m3_rows(t)
+
+
+def _lin_in(rp, t, stored_bf16=False):
+    """the activation a Linear multiplies: fp8 engine -> fake-quantised rows (of the bf16-stored value if the producer stores bf16), else rp(t)"""
+    gq = getattr(rp, 'gq', None)
+    if gq is None:
+        return _rp(rp, t)
+    return gq(_rp(rp, t)) if stored_bf16 else gq(t)
+
+
 # ----------------------------------------------------------------------------- operators
 
 def layer_norm(x, gamma, beta):
@@ -54,10 +84,10 @@ def geglu(x):
 
 def feed_forward(x, sd, prefix, rp=None):
     """muse_maskgit_pytorch.py:79-89 -- LN(D) -> Linear(D,2F) -> GEGLU -> LN(F) -> Linear(F,D), no bias."""
-    h = _rp(rp, layer_norm(x, sd[prefix + '0.gamma'], sd[prefix + '0.beta']))
+    h = _lin_in(rp, layer_norm(x, sd[prefix + '0.gamma'], sd[prefix + '0.beta']))
     h = h @ sd[prefix + '1.weight'].t()
     h = _rp(rp, geglu(h))          # HIP path: GEGLU runs on the fp32 accumulators in the GEMM epilogue, its result is stored bf16
-    h = _rp(rp, layer_norm(h, sd[prefix + '3.gamma'], sd[prefix + '3.beta']))
+    h = _lin_in(rp, layer_norm(h, sd[prefix + '3.gamma'], sd[prefix + '3.beta']))
     return h @ sd[prefix + '4.weight'].t()
 
 
@@ -82,8 +112,8 @@ def attention(x, sd, prefix, heads, context=None, context_mask=None, rp=None):
     """muse_maskgit_pytorch.py:126-162."""
     b, n, _ = x.shape
     h = heads
-    xn = _rp(rp, layer_norm(x, sd[prefix + 'norm.gamma'], sd[prefix + 'norm.beta']))
-    kv_in = context if context is not None else xn
+    xn = _lin_in(rp, layer_norm(x, sd[prefix + 'norm.gamma'], sd[prefix + 'norm.beta']))
+    kv_in = context if context is not None else xn          # (fp8 engine: the context's k | v projection stays bf16 -- context is not quantised)
     q = _rp(rp, xn @ sd[prefix + 'to_q.weight'].t())
     kv = _rp(rp, kv_in @ sd[prefix + 'to_kv.weight'].t())
     k, v = kv.chunk(2, dim=-1)
@@ -103,6 +133,8 @@ def attention(x, sd, prefix, heads, context=None, context_mask=None, rp=None):
         mask = F.pad(context_mask[:, None, None, :].expand(b, h, n, -1), (1, 0), value=True)
     out = _rp(rp, attend(q, k, v, mask=mask, rp=rp))
     out = out.permute(0, 2, 1, 3).reshape(b, n, -1)
+    if getattr(rp, 'gq', None) is not None:
+        out = rp.gq(out)                                    # fp8 engine: the bf16 attention output is quantised per token row in front of to_out
     return out @ sd[prefix + 'to_out.weight'].t()
 
 

@@ -752,37 +752,6 @@ def test_full_size_c2_properties():
     assert img.shape == (B, 3, 256, 256) and torch.isfinite(img).all()
 
 
-def test_fp8_weight_mode_vs_fake_quant_oracle(golden):
-    """BASELINE configs[4] ("fp8 MFMA weights") as W8A16: self-defined oracle = the oracle transformer on the DE-QUANTISED weights (SURVEY
-    8c L2).  Logits within the bf16-path tolerance of that oracle; guidance fused; the decode loop (stepwise) bit-exact against the oracle
-    tail on its own logits; the fp8 logits differ from the bf16 ones (the mode is really on)."""
-    g, t = _tiny_transformer(golden)
-    te = g['text_embeds']
-    bf = t(g['ids'].to(DEV), text_embeds=te.to(DEV))
-    t.quantize_weights_fp8()
-    try:
-        sd = {k: (v.float().cpu() if v.is_floating_point() else v.cpu()) for k, v in t.fp8_dequantized_state_dict().items()}
-        cfg = dict(depth=g['cfg']['depth'], heads=g['cfg']['heads'])
-        got = t(g['ids'].to(DEV), text_embeds=te.to(DEV))
-        ref = O.transformer_forward(sd, cfg, g['ids'], te, 0., rp=O.bf16_round)
-        e = _report('fp8-weight logits vs fake-quant oracle', got, ref)
-        assert e.max() < 0.03 * ref.abs().max()
-        assert (got - bf).abs().max() > 1e-3 * bf.abs().max()
-        s3 = t.forward_with_cond_scale(g['ids'].to(DEV), text_embeds=te.to(DEV), cond_scale=3.)
-        null = t(g['ids'].to(DEV), text_embeds=te.to(DEV), cond_drop_prob=1.)
-        assert (s3 - (null + (got - null) * 3.)).abs().max() < 1e-4 * s3.abs().max() + 1e-4
-        B, n, T = 2, 64, 4
-        gumbel = O.gumbel_from_uniform(torch.rand(T, B, n, 512, generator=torch.Generator().manual_seed(21)))
-        mg = mm.MaskGit(image_size=128, transformer=t, vae=None)
-        ids = mg.generate(['a', 'b'], timesteps=T, text_embeds=te, noise=gumbel, noise_kind='gumbel', fmap_size=8)
-        free = O.generate_ids(lambda i, s: t.forward_with_cond_scale(i.to(DEV), text_embeds=te.to(DEV), cond_scale=3.).cpu(), B, n, 512,
-                              lambda s, shp: gumbel[s], timesteps=T)
-        assert torch.equal(ids.reshape(B, n).cpu(), free)
-    finally:
-        t.quantize_weights_fp8(False)
-    assert torch.equal(t(g['ids'].to(DEV), text_embeds=te.to(DEV)), bf)
-
-
 @pytest.mark.parametrize('precision', ['bf16', 'parity'])
 def test_muse_cascade_base_to_superres(precision):
     """Muse.forward (mmp.py:758-791): base.generate -> images -> superres.generate(cond_images = those images).  The cascade must equal

@@ -594,54 +594,6 @@ def test_vq_nearest_lookup(N, K, C, cosine):
     assert torch.equal(q, cb[got])
 
 
-@pytest.mark.parametrize('M,N,K', [(300, 512, 512), (1000, 2730, 1024), (64, 8192, 1024), (128, 200, 1365)])
-def test_fp8_weight_quantiser_and_w8a16_gemm(M, N, K):
-    """BASELINE configs[4] ("fp8 MFMA weights"), self-defined oracle: per-row e4m3 quantisation must equal torch's
-    float8_e4m3fn cast of w / scale bit for bit; the W8A16 GEMM must equal, bit for bit, the bf16 GEMM on the de-quantised weights
-    followed by the per-row scale (the fp8 -> bf16 widening is exact), and stay within bf16-GEMM tolerance of the fp32 product."""
-    if DRY:
-        pytest.skip('no CPU emulation of this operator')
-    g = torch.Generator().manual_seed(M + N)
-    w = rnd(N, K, gen=g, scale=0.05)
-    w[3] = 0
-    x = r16(rnd(M, K, gen=g))
-    wq, scale = ops.quantize_e4m3_rows(w.to(DEV))
-    Kp = (K + 63) // 64 * 64
-    assert wq.shape == (N, Kp) and wq.dtype == torch.uint8
-    ref_scale = w.abs().amax(-1) / 448.
-    ref_scale[ref_scale == 0] = 1.
-    assert torch.allclose(scale.cpu(), ref_scale, rtol=1e-6, atol=0)
-    ref_q = (w / scale.cpu()[:, None]).to(torch.float8_e4m3fn)
-    assert torch.equal(wq.cpu()[:, :K].view(torch.float8_e4m3fn).float(), ref_q.float())
-    assert (wq.cpu()[:, K:] == 0).all()
-    dq = torch.zeros(N, Kp)
-    dq[:, :K] = ref_q.float()                                    # de-quantised weights before the scale: exactly representable in bf16
-    xp = torch.zeros(M, Kp)
-    xp[:, :K] = x
-    xd = xp.to(DEV, bf16)
-    got = ops.gemm_w8a16(xd, wq, scale, out_f32=True)
-    plain = ops.gemm(xd, dq.to(DEV, bf16), out_f32=True)
-    lib = _lib.lib()
-    lib.mm_debug_set(8)                                          # same 128x128 kernel for the comparison
-    try:
-        plain = ops.gemm(xd, dq.to(DEV, bf16), out_f32=True)
-    finally:
-        lib.mm_debug_set(0)
-    assert torch.equal(got, plain * scale[None, :])
-    exact = x.double() @ (dq[:, :K].double() * scale.cpu().double()[:, None]).t()
-    check_close(got, exact, atol=2e-3, what='w8a16 vs fp64 on the de-quantised weights')
-    # guidance form
-    x2 = torch.zeros(M, Kp)
-    x2[:, :K] = r16(rnd(M, K, gen=g))
-    cfg = ops.gemm_w8a16(xd, wq, scale, x_null=x2.to(DEV, bf16), cond_scale=3.0)
-    nul = ops.gemm_w8a16(x2.to(DEV, bf16), wq, scale, out_f32=True)
-    assert (cfg - (nul + (got - nul) * 3.0)).abs().max() <= 2e-5 * got.abs().max() + 1e-6
-    # bf16 output + residual epilogues
-    if N % 8 == 0:                                               # the residual shares the output's row stride
-        res = rnd(M, N, gen=g).to(DEV)
-        assert torch.equal(ops.gemm_w8a16(xd, wq, scale, out_f32=True, resid=res), got + res)
-
-
 def test_gemm_kernel_family_random_shapes_bit_identical():
     """Race screen for the counted-vmcnt / LDS-DMA pipelines: random (ragged) shapes through whatever kernel the dispatcher picks
     (persistent, 256x128 three-stage, guidance 128x256) against the 128x128 kernel (debug bit 8), several repetitions each."""
