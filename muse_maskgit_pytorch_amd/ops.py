@@ -560,6 +560,8 @@ def quantize_act_e4m3(x, Kp=None):
     x = x.contiguous()
     M, K = x.shape
     Kp = Kp or (K + 127) // 128 * 128
+    if x.dtype == bf16 and K % 8:          # bf16 rows are read 16 bytes at a time
+        x = pad_cols(x, 8)
     xq = torch.empty(M, Kp, dtype=torch.uint8, device=x.device)
     scale = torch.empty(M, dtype=torch.float32, device=x.device)
     assert x.dtype in (bf16, torch.float32)

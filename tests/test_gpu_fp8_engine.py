@@ -135,29 +135,52 @@ def test_fp8_engine_decode_variants_match_the_stepwise_loop(variant):
 
 
 def test_fp8_engine_at_paper_scale(golden):
-    """BASELINE configs[4] at full size (dim 1024, depth 24, 16 heads, V = 8192, the 512 -> 1024 text projection; paper_c5.pt inputs and checkpoint): the
-    engine's logits against the fake-quant oracle on the same inputs (pinned: same quantisation at the same 168 Linear inputs), and -- informational --
-    against the reference's fp32 logits of the golden (what 24 layers of e4m3 activations cost)."""
+    """BASELINE configs[4] at full size (dim 1024, depth 24, 16 heads, inner width 2730 -> 2816, V = 8192, the 512 -> 1024 text projection; paper_c5.pt
+    inputs and checkpoint).  Per-row e4m3 rounding is discontinuous, so over 24 layers the engine and its fake-quant oracle drift apart like two draws of
+    the same quantisation noise (a last-bit difference of an fp32 accumulation flips an e4m3 rounding, 6 % of that element, and propagates).  Pinned in
+    two ways: (a) LAYER PAIRS of the checkpoint (first two, last two) as depth-2 models, engine against oracle, where the flips are few: a few 1e-3 of the
+    logit scale on average; (b) the whole stack statistically: the engine is no further from the reference's fp32 logits (golden) than the oracle's own
+    quantisation noise is."""
     g = golden('paper_c5.pt')
-    tr = R.build_transformer(mm.MaskGitTransformer, peaky=False, cfg=R.C5_CFG, seed=R.C5_WEIGHT_SEED)
-    assert R.state_checksum(tr) == g['weight_checksum']
-    tr = tr.to(DEV).eval()
+    big = R.build_transformer(mm.MaskGitTransformer, peaky=False, cfg=R.C5_CFG, seed=R.C5_WEIGHT_SEED)
+    assert R.state_checksum(big) == g['weight_checksum']
     inp = R.c5_inputs()
     te, ids = inp['text_embeds'], inp['ids']
+    bsd = big.state_dict()
+    for pair in ((0, 1), (22, 23)):
+        cfg2 = dict(R.C5_CFG, depth=2)
+        t2 = mm.MaskGitTransformer(**cfg2)
+        sd2 = {}
+        for k, v in bsd.items():
+            if k.startswith('transformer_blocks.layers.'):
+                li = int(k.split('.')[2])
+                if li in pair:
+                    sd2[k.replace(f'layers.{li}.', f'layers.{pair.index(li)}.', 1)] = v
+            else:
+                sd2[k] = v
+        t2.load_state_dict(sd2)
+        t2 = t2.to(DEV).eval().set_precision('fp8')
+        got = t2(ids.to(DEV), text_embeds=te.to(DEV), cond_drop_prob=0.)
+        ref = O.transformer_forward(_fake_quant_sd(t2), dict(depth=2, heads=R.C5_CFG['heads']), ids, te, 0., rp=O.Fp8Rounding())
+        err, scale = (got.cpu() - ref).abs(), ref.abs().max().item()
+        print(f'[fp8 engine] paper-scale layers {pair} vs fake-quant oracle: max {err.max().item():.4g}, mean {err.mean().item():.4g}, scale {scale:.4g}')
+        assert err.max().item() < 0.06 * scale and err.mean().item() < 0.004 * scale
+        del t2
+    tr = big.to(DEV).eval()
     tr.set_precision('fp8')
     try:
         got = tr(ids.to(DEV), text_embeds=te.to(DEV), cond_drop_prob=0.)
-        sd = _fake_quant_sd(tr)
-        ref = O.transformer_forward(sd, dict(depth=R.C5_CFG['depth'], heads=R.C5_CFG['heads']), ids, te, 0., rp=O.Fp8Rounding())
-        err = (got.cpu() - ref).abs()
-        scale = ref.abs().max().item()
-        print(f'[fp8 engine] paper-scale logits vs fake-quant oracle: max {err.max().item():.4g}, mean {err.mean().item():.4g}, scale {scale:.4g}')
-        assert err.max().item() < 0.08 * scale and err.mean().item() < 0.008 * scale
+        ref = O.transformer_forward(_fake_quant_sd(tr), dict(depth=R.C5_CFG['depth'], heads=R.C5_CFG['heads']), ids, te, 0., rp=O.Fp8Rounding())
+        err, scale = (got.cpu() - ref).abs(), ref.abs().max().item()
         rows = g['forward']['logits_cond']['rows']
+        q_noise = (ref.reshape(512, -1)[C5_ROWS] - rows).abs()
         d = (got.reshape(512, -1)[C5_ROWS].cpu() - rows).abs()
-        print(f'[fp8 engine] paper-scale logits vs the reference fp32 run: max {d.max().item():.4g}, mean {d.mean().item():.4g} on scale {rows.abs().max().item():.4g}; '
-              f'arg-max agreement {100 * (got.reshape(512, -1)[C5_ROWS].cpu().argmax(-1) == rows.argmax(-1)).float().mean().item():.1f} %')
-        assert d.mean().item() < 0.05 * rows.abs().max().item()
+        print(f'[fp8 engine] paper-scale (24 layers) logits: engine vs fake-quant oracle max {err.max().item():.4g} mean {err.mean().item():.4g}; fake-quant oracle vs the '
+              f'reference fp32 run max {q_noise.max().item():.4g} mean {q_noise.mean().item():.4g}; engine vs the reference fp32 run max {d.max().item():.4g} mean '
+              f'{d.mean().item():.4g} (scale {scale:.4g}); arg-max agreement with the reference '
+              f'{100 * (got.reshape(512, -1)[C5_ROWS].cpu().argmax(-1) == rows.argmax(-1)).float().mean().item():.1f} %')
+        assert d.mean().item() <= 1.25 * q_noise.mean().item() and d.max().item() <= 1.6 * q_noise.max().item()
+        assert err.mean().item() <= 1.5 * q_noise.mean().item()
     finally:
         tr.set_precision('bf16')
         torch.cuda.empty_cache()
