@@ -8,7 +8,10 @@
 // One 512-thread workgroup = 8 waves (2 token halves x 4 column quarters) computes a 256-token x (64 NF)-column tile (NF = 4: 256 columns, NF = 2:
 // 128 columns for the narrow projections); a wave owns 128 tokens x 16 NF columns as 8 x NF accumulator fragments (128 / 64 VGPRs).
 //   * k-step = 128 fp8 = 128-byte rows: both operands arrive by LDS-DMA (buffer_load ... lds, 16 B per lane) into two stages of 256 + 64 NF rows,
-//     16-byte chunks XOR-swizzled by (row & 7): the fragment reads (lane: row fr, 32 contiguous k-bytes at 32 * fg = two ds_read_b128) are conflict-free;
+//     16-byte chunks XOR-swizzled by (row & 7).  A lane's 32 k-values of a fragment are chunks fg and fg + 4 of row fr -- NOT the contiguous 32 bytes at
+//     32 fg: the contraction runs over all 128 k whichever lane holds which, as long as both operands use the same assignment, and with this one the two
+//     ds_read_b128 per fragment are conflict-free (chunks 2 fg, 2 fg + 1 collide 2-way under the same swizzle: measured, the LDS reads alone then cost
+//     more than the MFMAs);
 //   * one barrier per k-step: wait for this step's DMA, barrier (everybody is done with the other stage), issue the next step's DMA into it, compute;
 //   * the weight fragment is the MFMA's A operand, so a lane ends up with 4 consecutive output columns of one token: the epilogue scales them, runs
 //     GEGLU on the (value, gate) fragment pairs of the interleaved w1 packing, and goes through LDS (the stages are free by then) so that every global
@@ -84,15 +87,15 @@ __global__ __launch_bounds__(512) void gemm_fp8_kernel(const GemmF8Args p) {
 #pragma unroll
         for (int a = 0; a < NF; ++a) {
             const int row = a * 16 + fr;
-            const u32x4_t lo = *reinterpret_cast<const u32x4_t*>(ws + sw128(row, 2 * fg));
-            const u32x4_t hi = *reinterpret_cast<const u32x4_t*>(ws + sw128(row, 2 * fg + 1));
+            const u32x4_t lo = *reinterpret_cast<const u32x4_t*>(ws + sw128(row, fg));
+            const u32x4_t hi = *reinterpret_cast<const u32x4_t*>(ws + sw128(row, fg + 4));
             wf[a] = i32x8_t{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
         }
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             const int row = b * 16 + fr;
-            const u32x4_t lo = *reinterpret_cast<const u32x4_t*>(xs + sw128(row, 2 * fg));
-            const u32x4_t hi = *reinterpret_cast<const u32x4_t*>(xs + sw128(row, 2 * fg + 1));
+            const u32x4_t lo = *reinterpret_cast<const u32x4_t*>(xs + sw128(row, fg));
+            const u32x4_t hi = *reinterpret_cast<const u32x4_t*>(xs + sw128(row, fg + 4));
             const i32x8_t xf = i32x8_t{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
 #pragma unroll
             for (int a = 0; a < NF; ++a)
