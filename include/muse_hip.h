@@ -87,10 +87,10 @@ int mm_gemm_geglu(mm_stream_t stream, const void* x, int64_t ldx, const void* w1
 int mm_layernorm_inner(mm_stream_t stream, const void* a, int64_t lda, int rows, int F, int Fp, const float* gamma,
                        const float* beta, void* out, int64_t ldo);
 
-/* The Attend seam (attend.py:109-140): softmax(scale * q k^T, key mask) v.  dim_head must be 64.
+/* The Attend seam (attend.py:109-140): softmax(scale * q k^T, key mask) v.  dim_head = 32, 64 or 128 (last argument).
  * Element strides (batch, head, token) per operand, d contiguous.  nk = number of keys.
- * normalize != 0 additionally fuses mmp.py:145-153: q,k are L2-normalised and scaled by q_scale/k_scale [64]
- * in-kernel and a learned null key/value (null_k/null_v fp32 [heads][64], raw parameters) is prepended.
+ * normalize != 0 additionally fuses mmp.py:145-153: q,k are L2-normalised and scaled by q_scale/k_scale [dim_head]
+ * in-kernel and a learned null key/value (null_k/null_v fp32 [heads][dim_head], raw parameters) is prepended.
  * key_mask: optional uint8 [B][nk] (1 = keep), row stride km_sb. */
 int mm_attend(mm_stream_t stream, const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const void* k,
               int64_t k_sb, int64_t k_sh, int64_t k_sn, const void* v, int64_t v_sb, int64_t v_sh, int64_t v_sn,
