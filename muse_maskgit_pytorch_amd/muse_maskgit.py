@@ -122,6 +122,31 @@ class _Handle:
     def __init__(self):
         self.keep = []
         self.ptr = C.c_void_p()
+        self.desc = None           # the mm_transformer_desc the handle was created from (re-used by ensure_logits_stats)
+        self.packed = None
+        self.stats_src = None      # callable -> fp32 [V][D] to_logits weights for the vocabulary statistics, or None when they do not apply
+
+    def create(self, d, packed):
+        self.desc, self.packed = d, packed
+        L.check(L.lib().mm_transformer_create(C.byref(d), C.byref(self.ptr)), 'mm_transformer_create')
+
+    def ensure_logits_stats(self):
+        """vocabulary statistics of to_logits for sampling without materialised logits (mm_transformer_desc.logits_wmean / _wcov): the mean of the
+        weight rows and their covariance; a row's logits over the vocabulary have mean <e, wmean> and variance e' wcov e.  Computed on the first
+        generate() that wants the fused sampler -- a [D][V] fp32 copy and a D x V x D fp32 GEMM, which a forward()-only user (training with
+        self-conditioning repacks every optimizer step) never pays -- then the C handle is re-created from the same packed tensors."""
+        if self.stats_src is None or self.packed.get('wcov') is not None:
+            return self
+        wt = self.stats_src().t().contiguous()                      # [D][V]
+        V = wt.shape[1]
+        self.packed['wmean'] = wt.mean(dim=1).contiguous()
+        self.packed['wcov'] = (P32.gemm(wt, wt) / float(V) - torch.outer(self.packed['wmean'], self.packed['wmean'])).to(bf16).contiguous()
+        del wt
+        self.desc.logits_wmean, self.desc.logits_wcov = L.ptr(self.packed['wmean']), L.ptr(self.packed['wcov'])
+        L.lib().mm_transformer_destroy(self.ptr)
+        self.ptr = C.c_void_p()
+        L.check(L.lib().mm_transformer_create(C.byref(self.desc), C.byref(self.ptr)), 'mm_transformer_create')
+        return self
 
     def __del__(self):
         try:
@@ -233,14 +258,9 @@ class Transformer(nn.Module):
         t = dict(tok=self.token_emb.weight.detach().to(bf16).contiguous(), pos=self.pos_emb.weight.detach().to(bf16).contiguous(),
                  fg=f32c(tb.norm.gamma), fb=f32c(tb.norm.beta), wl=self.to_logits.weight.detach().to(bf16).contiguous(),
                  tp=self.text_embed_proj.weight.detach().to(bf16).contiguous() if isinstance(self.text_embed_proj, nn.Linear) else None)
-        # vocabulary statistics of to_logits for sampling without materialised logits (mm_transformer_desc.logits_wmean / _wcov): the mean of the
-        # weight rows and their covariance; a row's logits over the vocabulary have mean <e, wmean> and variance e' wcov e.  Pack-time only.
-        t['wmean'] = t['wcov'] = None
+        t['wmean'] = t['wcov'] = None                                  # filled by _Handle.ensure_logits_stats on the first fused generate()
         if self.dim_out % 256 == 0 and self.dim_out >= 4096:
-            wt = t['wl'].float().t().contiguous()                       # [D][V]
-            t['wmean'] = wt.mean(dim=1).contiguous()
-            t['wcov'] = (P32.gemm(wt, wt) / float(self.dim_out) - torch.outer(t['wmean'], t['wmean'])).to(bf16).contiguous()
-            del wt
+            h.stats_src = lambda t=t: t['wl'].float()
         h.keep.append(t)
         h.keep.append(layers)
         d = L.TransformerDesc()
@@ -253,8 +273,7 @@ class Transformer(nn.Module):
         d.final_gamma, d.final_beta, d.to_logits = L.ptr(t['fg']), L.ptr(t['fb']), L.ptr(t['wl'])
         d.self_cond_ff = sc_ff
         d.logits_wmean, d.logits_wcov = L.ptr(t['wmean']), L.ptr(t['wcov'])
-        L.check(L.lib().mm_transformer_create(C.byref(d), C.byref(h.ptr)), 'mm_transformer_create')
-        h.packed = t
+        h.create(d, t)
         self._handle, self._handle_key = h, key
         return h
 
@@ -325,11 +344,8 @@ class Transformer(nn.Module):
         t = dict(tok=f32c(self.token_emb.weight), pos=f32c(self.pos_emb.weight), fg=f32c(tb.norm.gamma), fb=f32c(tb.norm.beta), wl=pack(self.to_logits.weight),
                  tp=pack(self.text_embed_proj.weight) if isinstance(self.text_embed_proj, nn.Linear) else None, P=P)
         t['wmean'] = t['wcov'] = None
-        if self.dim_out % 256 == 0 and self.dim_out >= 4096:      # vocabulary statistics for the fused sampler's bound (an estimate: bf16 inputs suffice)
-            wt = self.to_logits.weight.detach().float().t().contiguous()
-            t['wmean'] = wt.mean(dim=1).contiguous()
-            t['wcov'] = (P32.gemm(wt, wt) / float(self.dim_out) - torch.outer(t['wmean'], t['wmean'])).to(bf16).contiguous()
-            del wt
+        if self.dim_out % 256 == 0 and self.dim_out >= 4096:      # (an estimate: the fp32 weights as they are)
+            h.stats_src = lambda: self.to_logits.weight.detach().float()
         h.keep.append(t)
         h.keep.append(layers)
         d = L.TransformerDesc()
@@ -343,8 +359,7 @@ class Transformer(nn.Module):
         d.self_cond_ff = sc_ff
         d.logits_wmean, d.logits_wcov = L.ptr(t['wmean']), L.ptr(t['wcov'])
         d.split_products = P
-        L.check(L.lib().mm_transformer_create(C.byref(d), C.byref(h.ptr)), 'mm_transformer_create')
-        h.packed = t
+        h.create(d, t)
         return h
 
     def _pack_key(self):
@@ -522,10 +537,7 @@ class Transformer(nn.Module):
                  tp=self.text_embed_proj.weight.detach().to(bf16).contiguous() if isinstance(self.text_embed_proj, nn.Linear) else None)
         t['wmean'] = t['wcov'] = None
         if self.dim_out % 256 == 0 and self.dim_out >= 4096:
-            wt = t['wl'].float().t().contiguous()
-            t['wmean'] = wt.mean(dim=1).contiguous()
-            t['wcov'] = (P32.gemm(wt, wt) / float(self.dim_out) - torch.outer(t['wmean'], t['wmean'])).to(bf16).contiguous()
-            del wt
+            h.stats_src = lambda t=t: t['wl'].float()
         h.keep.append(t)
         h.keep.append(layers)
         d = L.TransformerDesc()
@@ -539,8 +551,7 @@ class Transformer(nn.Module):
         d.self_cond_ff = sc_ff
         d.logits_wmean, d.logits_wcov = L.ptr(t['wmean']), L.ptr(t['wcov'])
         d.fp8 = 1
-        L.check(L.lib().mm_transformer_create(C.byref(d), C.byref(h.ptr)), 'mm_transformer_create')
-        h.packed = t
+        h.create(d, t)
         return h
 
     def _cfg_logits(self, emb_a, emb_b, cond_scale):
@@ -825,6 +836,11 @@ class MaskGit(nn.Module):
             if isinstance(critic, Transformer):
                 critic._x3_min_products = tr._x3_min_products
         h = tr._model()
+        if fused_sampling and not torch.cuda.is_current_stream_capturing():
+            h.ensure_logits_stats()              # vocabulary statistics of to_logits: first fused generate() only (not inside a capture: it allocates)
+        elif fused_sampling == 'deferred' and h.stats_src is not None and h.packed.get('wcov') is None:
+            raise RuntimeError("generate(fused_sampling='deferred') under stream capture needs the vocabulary statistics of to_logits: run one eager "
+                               'generate() with the same weights before capturing')
         counts = self._mask_counts(timesteps, seq_len)
         temps = ops.step_temperatures(timesteps, temperature)
         V = tr.dim_out
@@ -897,6 +913,8 @@ class MaskGit(nn.Module):
         L.check(L.lib().mm_generate(h.ptr, L.stream(), C.byref(p), L.ptr(self._gen_ws), self._gen_ws.numel()), 'mm_generate')
         if deferred:
             self.fused_status = status
+            # a captured graph replays reads of every tensor this call handed to the library: they stay alive with the module, not with this frame
+            self._deferred_keep = (keep, te, cond_ids, noise, ids, scores, trace, self._gen_ws, getattr(self, '_critic_ws', None))
         elif status is not None:
             st = status.tolist()
             self.fused_row_fallbacks += st[1]
