@@ -184,3 +184,43 @@ def test_fp8_engine_at_paper_scale(golden):
     finally:
         tr.set_precision('bf16')
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('seed', list(range(8)))
+def test_fp8_engine_matches_its_oracle_on_random_shapes(seed):
+    """seeded random shapes (batch, ragged lengths, width, heads, depth <= 2, vocabulary, text length with zero-padded rows, conditioning ids,
+    self-conditioning): the fp8 engine against the fake-quant oracle, both guidance passes and the guidance combine"""
+    import random
+    rng = random.Random(900 + seed)
+    B, n = rng.randint(1, 4), rng.choice([9, 16, 50, 64, 100, 130])
+    dim, heads, depth = rng.choice([128, 256, 384, 512]), rng.choice([2, 4, 8]), rng.randint(1, 2)
+    V, L = rng.choice([300, 512, 1000]), rng.randint(1, 9)
+    self_cond, nc = rng.random() < 0.3, rng.choice([0, 0, 9])
+    torch.manual_seed(seed)
+    t = mm.MaskGitTransformer(num_tokens=V, seq_len=n, dim=dim, depth=depth, dim_head=64, heads=heads, t5_name='t5-small', self_cond=self_cond)
+    with torch.no_grad():
+        for p in t.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(0, V + 1, (B, n), generator=g)
+    te = torch.randn(B, L, 512, generator=g)
+    if B > 1 and L > 2:
+        te[1, L // 2:] = 0.
+    cids = torch.randint(0, V, (B, nc), generator=g) if nc else None
+    sce = torch.randn(B, n, dim, generator=g) if self_cond else None
+    t = t.to(DEV).eval().set_precision('fp8')
+    sd = _fake_quant_sd(t)
+    cfg = dict(depth=depth, heads=heads, self_cond=self_cond)
+    kw = dict(conditioning_token_ids=cids.to(DEV) if nc else None, self_cond_embed=sce.to(DEV) if self_cond else None)
+    okw = dict(conditioning_token_ids=cids, self_cond_embed=sce)
+    what = f'B={B} n={n} dim={dim} heads={heads} depth={depth} V={V} L={L} nc={nc} self_cond={self_cond}'
+    for drop in (0., 1.):
+        got = t(ids.to(DEV), text_embeds=te.to(DEV), cond_drop_prob=drop, **kw).float().cpu()
+        ref = O.transformer_forward(sd, cfg, ids, te, drop, rp=O.Fp8Rounding(), **okw)
+        scale = max(ref.abs().max().item(), 1.0)
+        err = (got - ref).abs()
+        assert err.max().item() <= 0.08 * scale and err.mean().item() <= 0.01 * scale, f'drop={drop}: max {err.max().item():.3g} mean {err.mean().item():.3g} on scale {scale:.3g}; {what}'
+    got = t.forward_with_cond_scale(ids.to(DEV), text_embeds=te.to(DEV), cond_scale=3., **kw).float().cpu()
+    ref = O.forward_with_cond_scale(sd, cfg, ids, te, 3., rp=O.Fp8Rounding(), **okw)
+    assert (got - ref).abs().max().item() <= 0.2 * max(ref.abs().max().item(), 1.0), f'guidance; {what}'
