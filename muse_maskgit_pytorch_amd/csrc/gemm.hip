@@ -452,15 +452,13 @@ int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
             a.splits > 1)
             return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: folded LayerNorm needs a dense fp32-residual GEMM");
     }
-    // (the 256x256 GEGLU variant also emits the LayerNorm partial sums, but that path has no full-size test yet: a folded FF keeps w1 on
-    //  the 256x128 persistent kernel)
     if (a.fs_stats) {      // fused sampling: only the 256-column guidance kernel implements the emission (model.hip checks eligibility first)
         if ((a.mode != MODE_CFG && !(a.mode == MODE_DENSE && a.wide_tok)) || !mm_gemm_cfg2_eligible(a))
             return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: fused sampling needs the 256-column guidance-logits kernel");
         return mm_gemm_cfg2_launch(a, stream);
     }
     if (a.m_dev) a.debug |= 8;      // only the 128x128 kernel reads the device-side row count
-    if (!(a.debug & (8 | 4096 | 8192)) && !a.ln_part && mm_gemm_cfg2_eligible(a)) return mm_gemm_cfg2_launch(a, stream);
+    if (!(a.debug & (8 | 4096 | 8192)) && mm_gemm_cfg2_eligible(a)) return mm_gemm_cfg2_launch(a, stream);
     if (!(a.debug & (8 | 4096)) && mm_gemm_pers_eligible(a)) return mm_gemm_pers_launch(a, stream);
     if (!(a.debug & 8) && mm_gemm_big_eligible(a)) return mm_gemm_big_launch(a, stream);
     a.tiles_n = (a.N + BT - 1) / BT;

@@ -344,7 +344,7 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
                         *reinterpret_cast<float2*>(p.ln_part + ((size_t)(pm0 + prow_) * p.ln_np + (pn0 >> 7) + ((lane >> 3) & 1)) * 2) = lst_; \
                 }                                                                                              \
                 if (pm0 + prow_ < p.M) *reinterpret_cast<uint4*>(pv_ptr_) = pv_;      /* re-read by the next kernel: a plain store */ \
-                st1 = 1;                                                                                       \
+                st1 = p.ln_part ? 2 : 1;                        /* (the wave's first row is valid -- piece_ --, so both stores were issued) */ \
             }                                                                                                  \
         }                                                                                                      \
         ++g;                                                                                                   \
@@ -590,10 +590,11 @@ bool mm_gemm_cfg2_eligible(const GemmArgs& a) {
     if (a.mode == MODE_DENSE && a.epi == EPI_GEGLU) {
         if (a.out_kind != OUT_BF16 || (a.ldc % 8)) return false;
         const long tiles = (long)((a.M + 2 * TOK - 1) / (2 * TOK)) * (a.N / BN);
-        // measured (tools/gemm_bench.py, MI355X): per 256 x 256 of output the k-loop is ~7 % faster than gemm_pers', the tile end
-        // costs about the same, and the coarser tile loses more to the last partial round -- a win only for long K on tile counts
-        // that fill the CUs evenly (16384 x 4096 x 2048: 253 vs 267 us); FF w1 of the base config (K = 512) stays on gemm_pers
-        return a.K >= 1024 && tiles >= 256 && ((tiles % 256) == 0 || tiles >= 4096);
+        // measured (tools/gemm_harness, MI355X): per 256 x 256 of output the k-loop is ~7 % faster than gemm_pers', the tile end costs about the
+        // same, and the coarser tile loses more to the last partial round -- a win when the tile count fills the last round of CUs well
+        // (FF w1 of the base config, 16384 x 2816 x 512 = 704 tiles = 2.75 rounds: 66.3 vs 71.3 us; 16384 x 4096 x 2048: 253 vs 267 us)
+        const long rounds = (tiles + 255) / 256;
+        return tiles >= 256 && (tiles * 10 >= rounds * 256 * 9 || tiles >= 4096);
     }
     return false;
 }
