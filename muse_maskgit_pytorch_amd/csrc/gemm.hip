@@ -458,6 +458,7 @@ int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
         return mm_gemm_cfg2_launch(a, stream);
     }
     if (a.m_dev) a.debug |= 8;      // only the 128x128 kernel reads the device-side row count
+    if (!(a.debug & (8 | 4096 | 8192 | (1 << 30))) && mm_gemm_wide_eligible(a)) return mm_gemm_wide_launch(a, stream);      // (bit 1 << 30: A/B against the older kernels)
     if (!(a.debug & (8 | 4096 | 8192)) && mm_gemm_cfg2_eligible(a)) return mm_gemm_cfg2_launch(a, stream);
     if (!(a.debug & (8 | 4096)) && mm_gemm_pers_eligible(a)) return mm_gemm_pers_launch(a, stream);
     if (!(a.debug & 8) && mm_gemm_big_eligible(a)) return mm_gemm_big_launch(a, stream);

@@ -1,0 +1,172 @@
+// bf16 GEMM on a 256-token x 256-weight-row tile with a 64-deep k-step ("more flops per barrier"), for FF w1 + GEGLU (+ the LayerNorm(inner) partial
+// sums of the folded feed-forward) and for plain bf16-output projections whose tile count fills the CUs.
+//
+// Why another kernel: every k-loop of this family loses a roughly constant ~0.3-0.6 us per barrier interval whatever the tile and the look-ahead
+// (256 x 256 x 32 with three stages and a hand-placed software pipeline: 1970 cycles per 1031-cycle step; the fp8 kernel's plain
+// two-stage loop with 64 KiB per step: 0.33 us lost per 0.71 us of MFMAs).  So this kernel simply maximises the work between two barriers that fits
+// the LDS: two stages of (256 + 256) rows x 128 bytes = 128 KiB, 64 MFMAs per wave and step, ONE barrier per step, the next step's LDS-DMA issued
+// right behind it, fragments read and MFMAs issued in program order for the compiler to interleave -- the structure of gemm_fp8.hip with the bf16
+// instruction.  Non-persistent: a tile's epilogue goes through the (then free) stages so that every global store is 16 bytes of one output row per lane.
+// Accumulation order per output element: k ascending in chunks of 32, one MFMA each -- the order of every GEMM kernel of the family: bit-identical
+// results (and bit-identical LayerNorm partial sums: common.h ln_partial_row64 over the same bf16 values).
+#include "common.h"
+#include "muse_hip_internal.h"
+
+namespace {
+
+constexpr int TM = 256, TN = 256, BKB = 128;      // tile; bytes per k-step row (64 bf16)
+constexpr int X_B = TM * BKB, W_B = TN * BKB, STG = X_B + W_B, SMEM = 2 * STG;
+
+__device__ __forceinline__ int sw128(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+template <bool GEGLU>
+__global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+    int tile_m, tile_n;
+    xcd_grouped_tile(blockIdx.x, p.tiles_m, p.tiles_n, 8, tile_m, tile_n);
+    const int m0 = tile_m * TM, n0 = tile_n * TN;
+    const int KT = p.K / 64;
+
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const int rows_left = p.M - m0;
+    const unsigned xbytes = (unsigned)(rows_left < TM ? rows_left : TM) * (unsigned)p.ldx * 2u;      // rows beyond M read as zero
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.X + (size_t)m0 * p.ldx), 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W + (size_t)n0 * p.ldw), 0, (unsigned)TN * (unsigned)p.ldw * 2u, 0x00020000);
+    // a DMA instruction covers 8 rows: lane l fetches row l >> 3, logical chunk (l & 7) ^ (row & 7) into physical chunk l & 7; this wave stages token rows
+    // 32 wid .. + 31 and weight rows 32 wid .. + 31 (4 + 4 instructions per step)
+    const int dchunk = ((lane & 7) ^ (lane >> 3)) * 16;
+    int voff_x[4], voff_w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        voff_x[i] = (32 * wid + 8 * i + (lane >> 3)) * p.ldx * 2 + dchunk;
+        voff_w[i] = (32 * wid + 8 * i + (lane >> 3)) * p.ldw * 2 + dchunk;
+    }
+#define ISSUE(kt_, st_)                                                                                                                \
+    {                                                                                                                                  \
+        unsigned char* xs_ = smem + (st_) * STG + wid * 4096;                                                                          \
+        unsigned char* ws_ = smem + (st_) * STG + X_B + wid * 4096;                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                                  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(xs_ + i * 1024), 16, voff_x[i], (kt_) * BKB, 0, 0);              \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                                  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(ws_ + i * 1024), 16, voff_w[i], (kt_) * BKB, 0, 0);              \
+    }
+
+    f32x4_t acc[4][8];      // [weight fragment a][token fragment b]: lane (fr, fg) holds weight rows 16 a + 4 fg .. + 3 for token 16 b + fr
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    ISSUE(0, 0);
+    for (int kt = 0; kt < KT; ++kt) {
+        const int st = kt & 1;
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this step's DMA (the only one in flight) has landed
+        __builtin_amdgcn_s_barrier();            // ... for everybody, and everybody is done reading the other stage
+        if (kt + 1 < KT) ISSUE(kt + 1, st ^ 1);
+        const unsigned char* xs = smem + st * STG + (wm * 128) * BKB;
+        const unsigned char* ws = smem + st * STG + X_B + (wn * 64) * BKB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {         // two 32-deep MFMA sub-steps, k ascending
+            u32x4_t wf[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) wf[a] = *reinterpret_cast<const u32x4_t*>(ws + sw128(a * 16 + fr, ks * 4 + fg));
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const u32x4_t xf = *reinterpret_cast<const u32x4_t*>(xs + sw128(b * 16 + fr, ks * 4 + fg));
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a][b] = mfma16(wf[a], xf, acc[a][b]);
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();                // the stages are free: they become the output staging tile
+
+    if constexpr (GEGLU) {
+        // interleaved w1 packing: within a wave's 64 weight rows the first 32 are values, the next 32 their gates -> 128 output columns per tile
+        constexpr int ROWB = 256;                // staging row bytes (128 bf16)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int row = wm * 128 + b * 16 + fr;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int col = wn * 32 + a * 16 + 4 * fg;
+                *reinterpret_cast<uint2*>(smem + row * ROWB + (((col >> 3) ^ (row & 7)) << 4) + (col & 4) * 2) =
+                    make_uint2(pack_bf16x2(geglu_f(acc[a][b][0], acc[a + 2][b][0]), geglu_f(acc[a][b][1], acc[a + 2][b][1])),
+                               pack_bf16x2(geglu_f(acc[a][b][2], acc[a + 2][b][2]), geglu_f(acc[a][b][3], acc[a + 2][b][3])));
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+#pragma unroll 2
+        for (int i = t; i < TM * 16; i += 512) {              // 16 chunks of 8 columns per row; 8 adjacent lanes = 64 columns = one LayerNorm part
+            const int row = i >> 4, c = i & 15;
+            const int m = m0 + row;
+            const uint4 v = *reinterpret_cast<const uint4*>(smem + row * ROWB + ((c ^ (row & 7)) << 4));
+            if (p.ln_part) {                                  // LayerNorm(inner) partial sums of this row's 64 columns (common.h): all 8 lanes take part
+                const float2 stv = ln_partial_row64(v);
+                if ((c & 7) == 0 && m < p.M) *reinterpret_cast<float2*>(p.ln_part + ((size_t)m * p.ln_np + tile_n * 2 + (c >> 3)) * 2) = stv;
+            }
+            if (m < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + tile_n * 128 + c * 8) = v;
+        }
+    } else {
+        constexpr int ROWB = 512;                // 256 bf16
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int row = wm * 128 + b * 16 + fr;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int col = wn * 64 + a * 16 + 4 * fg;
+                *reinterpret_cast<uint2*>(smem + row * ROWB + (((col >> 3) ^ (row & 7)) << 4) + (col & 4) * 2) =
+                    make_uint2(pack_bf16x2(acc[a][b][0], acc[a][b][1]), pack_bf16x2(acc[a][b][2], acc[a][b][3]));
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+#pragma unroll 2
+        for (int i = t; i < TM * 32; i += 512) {
+            const int row = i >> 5, c = i & 31;
+            const int m = m0 + row;
+            if (m < p.M) {
+                const uint4 v = *reinterpret_cast<const uint4*>(smem + row * ROWB + ((c ^ (row & 7)) << 4));
+                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + n0 + c * 8) = v;
+            }
+        }
+    }
+#undef ISSUE
+}
+
+template <bool GEGLU>
+int launch_wide(GemmArgs a, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<GEGLU>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) return mm_set_hip_error(e, "gemm_wide hipFuncSetAttribute");
+        attr_set = true;
+    }
+    a.tiles_m = (a.M + TM - 1) / TM;
+    a.tiles_n = a.N / TN;
+    hipLaunchKernelGGL((gemm_wide_kernel<GEGLU>), dim3(a.tiles_m * a.tiles_n), dim3(512), SMEM, stream, a);
+    return mm_check_launch("gemm_wide_kernel");
+}
+
+}  // namespace
+
+// dense bf16-output GEMMs without bias / activation / residual (plain or GEGLU with optional LayerNorm partial sums), K % 64 == 0, N % 256 == 0, 16-byte
+// aligned rows, and a tile count that fills the last round of CUs to >= 90 % (a coarse tile loses the remainder)
+bool mm_gemm_wide_eligible(const GemmArgs& a) {
+    if (a.mode != MODE_DENSE || a.bias || a.act != ACT_NONE || a.resid_bf16 || a.resid_f32 || a.out_kind != OUT_BF16 || a.fs_stats || a.m_dev) return false;
+    if (a.epi != EPI_NONE && a.epi != EPI_GEGLU) return false;
+    if ((a.K % 64) || a.K < 128 || (a.N % TN) || (a.ldx % 8) || (a.ldw % 8) || (a.ldc % 8) || (((uintptr_t)a.out) & 15)) return false;
+    if (a.ln_part && a.epi != EPI_GEGLU) return false;
+    const long tiles = (long)((a.M + TM - 1) / TM) * (a.N / TN);
+    const long rounds = (tiles + 255) / 256;
+    return tiles >= 256 && tiles * 10 >= rounds * 256 * 9;
+}
+
+int mm_gemm_wide_launch(GemmArgs a, hipStream_t stream) {
+    return a.epi == EPI_GEGLU ? launch_wide<true>(a, stream) : launch_wide<false>(a, stream);
+}

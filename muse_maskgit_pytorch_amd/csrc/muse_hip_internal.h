@@ -49,7 +49,9 @@ int mm_gemm_launch(GemmArgs a, hipStream_t stream);
 bool mm_gemm_big_eligible(const GemmArgs& a);      // gemm_big.hip: 256x128 tile, 3-stage counted-vmcnt pipeline
 int mm_gemm_big_launch(GemmArgs a, hipStream_t stream);
 bool mm_gemm_pers_eligible(const GemmArgs& a);
-bool mm_gemm_cfg2_eligible(const GemmArgs& a);     // gemm_cfg.hip: persistent 128 tokens x 256 columns, guidance logits
+bool mm_gemm_cfg2_eligible(const GemmArgs& a);
+bool mm_gemm_wide_eligible(const GemmArgs& a);      // gemm_wide.hip: 256 x 256 x 64 tile, one barrier per 64-deep step
+int mm_gemm_wide_launch(GemmArgs a, hipStream_t stream);     // gemm_cfg.hip: persistent 128 tokens x 256 columns, guidance logits
 int mm_gemm_cfg2_launch(GemmArgs a, hipStream_t stream);
 // gemm_pers.hip: persistent 256x128, stores overlapped with the next tile
 int mm_gemm_pers_launch(GemmArgs a, hipStream_t stream);

@@ -170,7 +170,7 @@ int main(int argc, char** argv) {
     mm_debug_set(debug);
     if (want("fp8")) {
         struct Shape { const char* name; int M, N, K, epi; };
-        const Shape shapes[] = {{"c5 qkv", 16384, 3072, 1024, 0}, {"c5 out", 16384, 1024, 1024, 2}, {"c5 w1", 16384, 5632, 1024, 1}, {"c5 w2", 16384, 1024, 2816, 2}, {"long k", 16384, 1024, 8192, 0},
+        const Shape shapes[] = {{"c5 qkv", 16384, 3072, 1024, 0}, {"c5 out", 16384, 1024, 1024, 2}, {"c5 w1", 16384, 5632, 1024, 1}, {"c5 w2", 16384, 1024, 2816, 2}, {"long k", 16384, 1024, 8192, 0}, {"nf2 lk", 16384, 512, 8192, 0}, {"nf4 lk2", 32768, 1024, 8192, 0}, {"nf2 lk2", 32768, 512, 8192, 0},
                                 {"c2 qkv", 16384, 1536, 512, 0}, {"c2 out", 16384, 512, 512, 2}, {"c2 w1", 16384, 2816, 512, 1}, {"c2 w2", 16384, 512, 1408, 2}};
         for (const Shape& sh : shapes) {
             std::vector<uint8_t> hx((size_t)sh.M * sh.K), hw((size_t)sh.N * sh.K);
