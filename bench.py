@@ -230,7 +230,7 @@ def parity_tier_leg(mg, tr, step, args, B, T, n, nc, image_size, counts, lib, bf
             'checkpoint': 'the main line\'s parameters rounded to bf16 (what the bf16 engine multiplies by): bf16-representable weights need 3 term products',
             'tolerance': 'logits <= 1e-3 absolute and ids bit-exact against the reference fp32 run at this size (tests/test_gpu_base_size.py, precision bf16x3); '
                          'VAE decode on the fp32 engine',
-            'roofline': {'kernel': 'gemm_cfg2_kernel<4> (WIDE_MIX2) on K = products x dim (term products of to_logits on the guidance-mixed embeddings)', 'bound': 'mfma',
+            'roofline': {'kernel': 'gemm_wide_fused_kernel on K = products x dim (term products of to_logits on the guidance-mixed embeddings)', 'bound': 'mfma',
                          'achieved': g_flops / (g_ms * 1e-3) / 1e12 if g_ms else None, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': (g_flops / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if g_ms else None,
                          'flops_kind': 'executed bf16 MFMA flops (term products x 2 R V D of the one mixed pass)',
@@ -482,10 +482,10 @@ def main():
             'reference_equivalent_tflops_decode_loop': ref_flops / loop_s / 1e12,
             # the guidance logits: since round 3 ONE pass over the mixed embeddings e_null + (e_cond - e_null) * s (to_logits is linear): `achieved` counts the
             # EXECUTED flops 2 R V D per launch; the reference's two passes + combine would be twice that for the same logits
-            'roofline': {'kernel': 'gemm_cfg2_kernel<4> (WIDE_MIX2: to_logits of the guidance-mixed embeddings + fused-sampling emission from the accumulators, persistent 256-token x 256-column MFMA GEMM)', 'bound': 'mfma',
+            'roofline': {'kernel': 'gemm_wide_fused_kernel (to_logits of the guidance-mixed embeddings + fused-sampling emission from the accumulators; persistent 256-token x 256-column x 64-deep MFMA GEMM, one barrier per k-step)', 'bound': 'mfma',
                          'achieved': g_flops / (g_ms * 1e-3) / 1e12 if g_ms else None, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': (g_flops / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if g_ms else None,
-                         'traffic': traffic_of('gemm_cfg2_kernel') if metric_cfg else None,
+                         'traffic': traffic_of('gemm_wide_fused_kernel') if metric_cfg else None,
                          'traffic_source': f'profiles/{pmc_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch, FETCH x2 gfx950 correction)' if pmc_file else None,
                          'launches': g_cnt, 'avg_launch_ms': g_ms / g_cnt if g_cnt else None,
                          'algorithmic_flops_per_launch': g_flops / g_cnt if g_cnt else None,

@@ -614,6 +614,7 @@ int mm_gemm_cfg2_launch(GemmArgs a, hipStream_t stream) {
     const bool mix = a.mode == MODE_DENSE && a.wide_tok && a.epi == EPI_NONE;
     // fused single pass: 256-token tiles when the launch has enough rows to fill them (fewer operand bytes per flop), 128-token tiles with five stages
     // otherwise (debug bits, A/B only: 1 << 26 three-stage 128-token kernel, 1 << 28 no 256-token tiles; the values are the same)
+    if (mix && !(g_mm_debug & ((1 << 26) | (1 << 28) | (1 << 30))) && mm_gemm_wide_fused_eligible(a)) return mm_gemm_wide_fused_launch(a, stream);      // (bit 1 << 30: A/B)
     const bool mix2 = mix && a.fs_stats && a.M >= 1024 && !(g_mm_debug & ((1 << 26) | (1 << 28)));
     a.tiles_n = a.N / BN;
     a.tiles_m = ((cfg || mix) && !mix2) ? (a.M + TOK - 1) / TOK : (a.M + 2 * TOK - 1) / (2 * TOK);

@@ -139,6 +139,195 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs p) {
 #undef ISSUE
 }
 
+// ---- the logits GEMM of the decode loop on the same k-loop: to_logits of the guidance-mixed embeddings with the fused-sampling emission straight from the
+// accumulators (the tile end of gemm_cfg2_kernel<WIDE_MIX2>, same canonical statistics and candidate format: common.h tile_softmax_stats / fs_slot_index).
+// Persistent (one workgroup per CU walks its tiles): the first k-step of the NEXT tile is requested during the last step of the current one, into the stage
+// that step does not read, so the emission (whose exchange arrays live in the other stage) covers its latency.  K % 128 == 0 (an even number of steps: the
+// stage parity is the same for every tile).
+#define MM_VMCNT_IMM(n_) (0x0F70 | ((n_) & 15) | (((n_) >> 4) << 14))
+__device__ __forceinline__ void wait_vmcnt_w(int n) {      // wave-uniform n; above 31: wait for 31 (waiting for more is always safe)
+    switch (n) {
+#define MM_W(n_) case n_: __builtin_amdgcn_s_waitcnt(MM_VMCNT_IMM(n_)); break;
+        MM_W(0) MM_W(1) MM_W(2) MM_W(3) MM_W(4) MM_W(5) MM_W(6) MM_W(7) MM_W(8) MM_W(9) MM_W(10) MM_W(11) MM_W(12) MM_W(13) MM_W(14) MM_W(15)
+        MM_W(16) MM_W(17) MM_W(18) MM_W(19) MM_W(20) MM_W(21) MM_W(22) MM_W(23) MM_W(24) MM_W(25) MM_W(26) MM_W(27) MM_W(28) MM_W(29) MM_W(30)
+#undef MM_W
+        default: if (n < 0) __builtin_amdgcn_s_waitcnt(MM_VMCNT_IMM(0)); else __builtin_amdgcn_s_waitcnt(MM_VMCNT_IMM(31)); break;
+    }
+}
+__device__ __forceinline__ float max4_w(float a, float b, float c, float d) {      // (MFMA results: no canonicalising v_max x, x needed)
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(r), "v"(d));
+    return r;
+}
+
+constexpr int SMEM_F = SMEM + 1024;      // + the tile's per-token bounds
+
+__global__ __launch_bounds__(512) void gemm_wide_fused_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int total = p.tiles_m * p.tiles_n, G = gridDim.x;
+    const int KT = p.K / 64;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    unsigned char* xch = smem + STG;                                           // exchange arrays of the emission: stage 1 (free at a tile's end)
+    float* lthr = reinterpret_cast<float*>(smem + SMEM);                       // this tile's per-token bounds (LDS-DMA at its first k-step)
+    const __amdgpu_buffer_rsrc_t thr_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.fs_thr), 0, (unsigned)p.M * 4u, 0x00020000);
+    const int dchunk = ((lane & 7) ^ (lane >> 3)) * 16;
+    int voff_x[4], voff_w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        voff_x[i] = (32 * wid + 8 * i + (lane >> 3)) * p.ldx * 2 + dchunk;
+        voff_w[i] = (32 * wid + 8 * i + (lane >> 3)) * p.ldw * 2 + dchunk;
+    }
+    int vb = blockIdx.x;
+    if (vb >= total) return;
+    __amdgpu_buffer_rsrc_t rx, rw;
+    int tile_m, tile_n;
+#define TILE_SETUP(vb_)                                                                                                                \
+    {                                                                                                                                  \
+        xcd_grouped_tile(vb_, p.tiles_m, p.tiles_n, 8, tile_m, tile_n);                                                                \
+        const int left_ = p.M - tile_m * TM;                                                                                           \
+        rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.X + (size_t)tile_m * TM * p.ldx), 0,                              \
+                                               (unsigned)(left_ < TM ? left_ : TM) * (unsigned)p.ldx * 2u, 0x00020000);                \
+        rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W + (size_t)tile_n * TN * p.ldw), 0, (unsigned)TN * (unsigned)p.ldw * 2u, 0x00020000); \
+    }
+#define ISSUE(kt_, st_)                                                                                                                \
+    {                                                                                                                                  \
+        unsigned char* xs_ = smem + (st_) * STG + wid * 4096;                                                                          \
+        unsigned char* ws_ = smem + (st_) * STG + X_B + wid * 4096;                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                                  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(xs_ + i * 1024), 16, voff_x[i], (kt_) * BKB, 0, 0);              \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                                  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(ws_ + i * 1024), 16, voff_w[i], (kt_) * BKB, 0, 0);              \
+    }
+    TILE_SETUP(vb);
+    ISSUE(0, 0);
+    int pending = 0;                 // VMEM stores this wave issued BEHIND the DMA of the coming tile's first step (the previous tile's emission)
+    f32x4_t acc[4][8];
+    while (true) {
+        const int cur_m = tile_m, cur_n = tile_n;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 8; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < KT; ++kt) {
+            const int st = kt & 1;
+            if (kt == 0) wait_vmcnt_w(pending); else __builtin_amdgcn_s_waitcnt(0x0F70);      // this step's DMA has landed (in-order retirement: only younger stores may be in flight)
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < KT) {
+                ISSUE(kt + 1, st ^ 1);
+            } else if (vb + G < total) {      // last step (stage 1, KT even): the next tile's first step goes into stage 0
+                TILE_SETUP(vb + G);
+                ISSUE(0, 0);
+            }
+            if (kt == 0 && wid == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(thr_rs, (lds_ptr_t)(lthr), 16, lane * 16, cur_m * TM * 4, 0, 0);
+            const unsigned char* xs = smem + st * STG + (wm * 128) * BKB;
+            const unsigned char* ws = smem + st * STG + X_B + (wn * 64) * BKB;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4_t wf[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) wf[a] = *reinterpret_cast<const u32x4_t*>(ws + sw128(a * 16 + fr, ks * 4 + fg));
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const u32x4_t xf = *reinterpret_cast<const u32x4_t*>(xs + sw128(b * 16 + fr, ks * 4 + fg));
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) acc[a][b] = mfma16(wf[a], xf, acc[a][b]);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();            // everybody is done with stage 1: it becomes the exchange area
+        // ---- emission from the accumulators (gemm_cfg.hip, tile end of WIDE_MIX2; token of fragment block b: 128 wm + 16 b + fr)
+        int le_ = lane;
+        asm volatile("" : "+v"(le_));            // opaque copy: keeps the emission's address arithmetic out of the k-loop's live ranges
+        const int FR_ = le_ & 15, FG_ = le_ >> 4;
+        const int m0t = cur_m * TM;
+        uint32_t* xnib4 = reinterpret_cast<uint32_t*>(xch);                          // [4 quarters][tokens]: 4 keep nibbles (fragment a in byte a)
+        float2* xml = reinterpret_cast<float2*>(xch + TM * 16);                      // [16 lane groups][tokens] (ml, pl)
+        int nstore = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int tokl = wm * 128 + b * 16 + FR_;
+            const bool valid = m0t + tokl < p.M;
+            const float thr = lthr[tokl];
+            float gm[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) gm[a] = max4_w(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+            const float ml = max4_w(gm[0], gm[1], gm[2], gm[3]);
+            float gs[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                gs[a] = (fs_exp(acc[a][b][0], ml) + fs_exp(acc[a][b][1], ml)) + (fs_exp(acc[a][b][2], ml) + fs_exp(acc[a][b][3], ml));
+            const float pl = (gs[0] + gs[1]) + (gs[2] + gs[3]);
+            unsigned kb = 0, nib4 = 0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const bool kp = valid && gm[a] >= thr;
+                kb |= kp ? (1u << a) : 0u;
+                const unsigned long long bal = __ballot(kp);
+                const uint32_t lo = (uint32_t)bal, hi = (uint32_t)(bal >> 32);
+                const uint32_t nb = ((lo >> FR_) & 1u) | (((lo >> (16 + FR_)) & 1u) << 1) | (((hi >> FR_) & 1u) << 2) | (((hi >> (16 + FR_)) & 1u) << 3);
+                nib4 |= nb << (8 * a);
+            }
+            if (FG_ == 0) xnib4[wn * TM + tokl] = nib4;
+            xml[(wn * 4 + FG_) * TM + tokl] = make_float2(ml, pl);
+            uint32_t m16 = (nib4 | (nib4 >> 4)) & 0x00FF00FFu;
+            m16 = (m16 | (m16 >> 8)) & 0x0000FFFFu;          // bit 4 a + f of the quarter
+            float4* slot = p.fs_cand + ((size_t)(m0t + tokl) * p.tiles_n + cur_n) * FS_SLOT + wn * 16;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const bool kp = (kb >> a) & 1u;
+                if (__ballot(kp) != 0ull) {                     // wave-uniform: the store below is ISSUED (exact VMEM count for the wait)
+                    if (kp) slot[__popc(m16 & ((1u << (4 * a + FG_)) - 1u))] = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+                    ++nstore;
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();      // all 16 lane groups of every token have published their nibbles and (ml, pl)
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {   // one record per (token, piece): this wave combines the tokens of its half's blocks wn and wn + 4
+            const int tokl = wm * 128 + (hb * 4 + wn) * 16 + FR_;
+            const int tok = m0t + tokl;
+            const bool w_ = FG_ == 0 && tok < p.M;
+            if (__ballot(w_) != 0ull) {
+                if (w_) {
+                    uint32_t h16[4] = {xnib4[tokl], xnib4[TM + tokl], xnib4[2 * TM + tokl], xnib4[3 * TM + tokl]};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        h16[q] = (h16[q] | (h16[q] >> 4)) & 0x00FF00FFu;
+                        h16[q] = (h16[q] | (h16[q] >> 8)) & 0x0000FFFFu;
+                    }
+                    const float2* gq = xml + tokl;              // tile_combine16 (common.h), streamed from LDS in two sweeps
+                    float M_ = -INFINITY;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) M_ = fmaxf(M_, gq[i * TM].x);
+                    float wq[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float2 u0 = gq[(4 * q) * TM], u1 = gq[(4 * q + 1) * TM], u2 = gq[(4 * q + 2) * TM], u3 = gq[(4 * q + 3) * TM];
+                        wq[q] = (u0.y * __expf(u0.x - M_) + u1.y * __expf(u1.x - M_)) + (u2.y * __expf(u2.x - M_) + u3.y * __expf(u3.x - M_));
+                    }
+                    const float E_ = (wq[0] + wq[1]) + (wq[2] + wq[3]);
+                    p.fs_stats[(size_t)tok * p.tiles_n + cur_n] = make_float4(M_, E_, __uint_as_float(h16[0] | (h16[1] << 16)), __uint_as_float(h16[2] | (h16[3] << 16)));
+                }
+                ++nstore;
+            }
+        }
+        pending = nstore;
+        vb += G;
+        if (vb >= total) break;
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();      // the exchange area (stage 1) is read out before the next tile's second step lands in it
+    }
+#undef ISSUE
+#undef TILE_SETUP
+}
+
 template <bool GEGLU>
 int launch_wide(GemmArgs a, hipStream_t stream) {
     static bool attr_set = false;
@@ -165,6 +354,26 @@ bool mm_gemm_wide_eligible(const GemmArgs& a) {
     const long tiles = (long)((a.M + TM - 1) / TM) * (a.N / TN);
     const long rounds = (tiles + 255) / 256;
     return tiles >= 256 && tiles * 10 >= rounds * 256 * 9;
+}
+
+// the single-pass logits GEMM with the fused-sampling emission (x = the guidance-mixed embeddings): K % 128 == 0, N % 256 == 0
+bool mm_gemm_wide_fused_eligible(const GemmArgs& a) {
+    return a.mode == MODE_DENSE && a.wide_tok && a.fs_stats && a.fs_cand && a.fs_thr && !a.bias && a.act == ACT_NONE && !a.resid_f32 && !a.resid_bf16 &&
+           a.epi == EPI_NONE && (a.K % 128) == 0 && a.K >= 128 && (a.N % TN) == 0 && (a.ldx % 8) == 0 && (a.ldw % 8) == 0 && a.M >= 1024;
+}
+
+int mm_gemm_wide_fused_launch(GemmArgs a, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_F);
+        if (e != hipSuccess) return mm_set_hip_error(e, "gemm_wide_fused hipFuncSetAttribute");
+        attr_set = true;
+    }
+    a.tiles_m = (a.M + TM - 1) / TM;
+    a.tiles_n = a.N / TN;
+    const int total = a.tiles_m * a.tiles_n;
+    hipLaunchKernelGGL(gemm_wide_fused_kernel, dim3(total < 256 ? total : 256), dim3(512), SMEM_F, stream, a);
+    return mm_check_launch("gemm_wide_fused_kernel");
 }
 
 int mm_gemm_wide_launch(GemmArgs a, hipStream_t stream) {

@@ -51,7 +51,9 @@ int mm_gemm_big_launch(GemmArgs a, hipStream_t stream);
 bool mm_gemm_pers_eligible(const GemmArgs& a);
 bool mm_gemm_cfg2_eligible(const GemmArgs& a);
 bool mm_gemm_wide_eligible(const GemmArgs& a);      // gemm_wide.hip: 256 x 256 x 64 tile, one barrier per 64-deep step
-int mm_gemm_wide_launch(GemmArgs a, hipStream_t stream);     // gemm_cfg.hip: persistent 128 tokens x 256 columns, guidance logits
+int mm_gemm_wide_launch(GemmArgs a, hipStream_t stream);
+bool mm_gemm_wide_fused_eligible(const GemmArgs& a);      // the fused-sampling logits GEMM on the same k-loop (persistent)
+int mm_gemm_wide_fused_launch(GemmArgs a, hipStream_t stream);     // gemm_cfg.hip: persistent 128 tokens x 256 columns, guidance logits
 int mm_gemm_cfg2_launch(GemmArgs a, hipStream_t stream);
 // gemm_pers.hip: persistent 256x128, stores overlapped with the next tile
 int mm_gemm_pers_launch(GemmArgs a, hipStream_t stream);
