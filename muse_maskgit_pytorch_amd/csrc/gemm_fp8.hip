@@ -12,7 +12,8 @@
 //     32 fg: the contraction runs over all 128 k whichever lane holds which, as long as both operands use the same assignment, and with this one the two
 //     ds_read_b128 per fragment are conflict-free (chunks 2 fg, 2 fg + 1 collide 2-way under the same swizzle: measured, the LDS reads alone then cost
 //     more than the MFMAs);
-//   * one barrier per k-step: wait for this step's DMA, barrier (everybody is done with the other stage), issue the next step's DMA into it, compute;
+//   * one barrier per k-step: wait for this step's DMA, barrier (everybody is done with the other stage), compute -- the next step's DMA into the other
+//     stage is issued behind the first half of the step's MFMAs;
 //   * the weight fragment is the MFMA's A operand, so a lane ends up with 4 consecutive output columns of one token: the epilogue scales them, runs
 //     GEGLU on the (value, gate) fragment pairs of the interleaved w1 packing, and goes through LDS (the stages are free by then) so that every global
 //     store -- and every residual read -- is 16 bytes of one output row per lane.
@@ -80,7 +81,6 @@ __global__ __launch_bounds__(512) void gemm_fp8_kernel(const GemmF8Args p) {
         const int st = kt & 1;
         __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this step's DMA (the only one in flight) has landed
         __builtin_amdgcn_s_barrier();            // ... for everybody, and everybody is done reading the other stage
-        if (kt + 1 < KT) ISSUE(kt + 1, st ^ 1);
         const unsigned char* xs = smem + st * STG + (wm * 128) * BKB;
         const unsigned char* ws = smem + st * STG + X_B + (wn * 16 * NF) * BKB;
         i32x8_t wf[NF];
@@ -100,6 +100,7 @@ __global__ __launch_bounds__(512) void gemm_fp8_kernel(const GemmF8Args p) {
 #pragma unroll
             for (int a = 0; a < NF; ++a)
                 acc[a][b] = mfma_f8(wf[a], xf, acc[a][b]);
+            if (b == (NF == 4 ? 3 : 0) && kt + 1 < KT) ISSUE(kt + 1, st ^ 1);      // behind the first 16 (NF = 4) / 2 (NF = 2) MFMAs of the step (placement measured: tools/gemm_harness)
         }
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);

@@ -66,7 +66,6 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs p) {
         const int st = kt & 1;
         __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this step's DMA (the only one in flight) has landed
         __builtin_amdgcn_s_barrier();            // ... for everybody, and everybody is done reading the other stage
-        if (kt + 1 < KT) ISSUE(kt + 1, st ^ 1);
         const unsigned char* xs = smem + st * STG + (wm * 128) * BKB;
         const unsigned char* ws = smem + st * STG + X_B + (wn * 64) * BKB;
 #pragma unroll
@@ -80,6 +79,9 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int a = 0; a < 4; ++a) acc[a][b] = mfma16(wf[a], xf, acc[a][b]);
             }
+            // The next step's DMA goes out BEHIND the first sub-step: right behind the barrier it delays the first MFMAs of both waves of a SIMD, behind
+            // the second sub-step it lands too late (FF w1 of the base config, tools/gemm_harness: 62.0 / 58.6 / 67.7 us for the three placements)
+            if (ks == 0 && kt + 1 < KT) ISSUE(kt + 1, st ^ 1);
         }
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -217,6 +219,8 @@ __global__ __launch_bounds__(512) void gemm_wide_fused_kernel(const GemmArgs p) 
             const int st = kt & 1;
             if (kt == 0) wait_vmcnt_w(pending); else __builtin_amdgcn_s_waitcnt(0x0F70);      // this step's DMA has landed (in-order retirement: only younger stores may be in flight)
             __builtin_amdgcn_s_barrier();
+            // (here the DMA issue stays right behind the barrier: behind the first sub-step -- what the non-persistent kernel above does -- measured 2 %
+            //  slower in this kernel, same box, 583-586 vs 594-597 us per launch at R = 5140)
             if (kt + 1 < KT) {
                 ISSUE(kt + 1, st ^ 1);
             } else if (vb + G < total) {      // last step (stage 1, KT even): the next tile's first step goes into stage 0
