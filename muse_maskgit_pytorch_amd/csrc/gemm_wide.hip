@@ -14,14 +14,15 @@
 
 namespace {
 
-constexpr int TM = 256, TN = 256, BKB = 128;      // tile; bytes per k-step row (64 bf16)
+constexpr int TM = 256, TN = 256, BKB = 128;      // tile (TN: the 256-row weight tile; the dense kernel also has a 192-row form); bytes per k-step row (64 bf16)
 constexpr int X_B = TM * BKB, W_B = TN * BKB, STG = X_B + W_B, SMEM = 2 * STG;
 
 __device__ __forceinline__ int sw128(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
-template <bool GEGLU>
+template <bool GEGLU, int NFW>      // NFW: weight fragments per wave -- 4: 256-row weight tile, 3: 192-row tile (N a multiple of 192 but not of 256: q|k|v of the base config)
 __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TN = 64 * NFW, W_B = TN * BKB, STG = X_B + W_B;
     const int t = threadIdx.x, lane = t & 63;
     const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wid >> 2, wn = wid & 3;
@@ -43,21 +44,21 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         voff_x[i] = (32 * wid + 8 * i + (lane >> 3)) * p.ldx * 2 + dchunk;
-        voff_w[i] = (32 * wid + 8 * i + (lane >> 3)) * p.ldw * 2 + dchunk;
+        voff_w[i] = (8 * NFW * wid + 8 * (i < NFW ? i : 0) + (lane >> 3)) * p.ldw * 2 + dchunk;
     }
 #define ISSUE(kt_, st_)                                                                                                                \
     {                                                                                                                                  \
         unsigned char* xs_ = smem + (st_) * STG + wid * 4096;                                                                          \
-        unsigned char* ws_ = smem + (st_) * STG + X_B + wid * 4096;                                                                    \
+        unsigned char* ws_ = smem + (st_) * STG + X_B + wid * (NFW * 1024);                                                            \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                                  \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(xs_ + i * 1024), 16, voff_x[i], (kt_) * BKB, 0, 0);              \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < NFW; ++i)                                                                                \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(ws_ + i * 1024), 16, voff_w[i], (kt_) * BKB, 0, 0);              \
     }
 
-    f32x4_t acc[4][8];      // [weight fragment a][token fragment b]: lane (fr, fg) holds weight rows 16 a + 4 fg .. + 3 for token 16 b + fr
+    f32x4_t acc[NFW][8];    // [weight fragment a][token fragment b]: lane (fr, fg) holds weight rows 16 a + 4 fg .. + 3 for token 16 b + fr
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < NFW; ++a)
 #pragma unroll
         for (int b = 0; b < 8; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
@@ -67,17 +68,17 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs p) {
         __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this step's DMA (the only one in flight) has landed
         __builtin_amdgcn_s_barrier();            // ... for everybody, and everybody is done reading the other stage
         const unsigned char* xs = smem + st * STG + (wm * 128) * BKB;
-        const unsigned char* ws = smem + st * STG + X_B + (wn * 64) * BKB;
+        const unsigned char* ws = smem + st * STG + X_B + (wn * 16 * NFW) * BKB;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {         // two 32-deep MFMA sub-steps, k ascending
-            u32x4_t wf[4];
+            u32x4_t wf[NFW];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) wf[a] = *reinterpret_cast<const u32x4_t*>(ws + sw128(a * 16 + fr, ks * 4 + fg));
+            for (int a = 0; a < NFW; ++a) wf[a] = *reinterpret_cast<const u32x4_t*>(ws + sw128(a * 16 + fr, ks * 4 + fg));
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
                 const u32x4_t xf = *reinterpret_cast<const u32x4_t*>(xs + sw128(b * 16 + fr, ks * 4 + fg));
 #pragma unroll
-                for (int a = 0; a < 4; ++a) acc[a][b] = mfma16(wf[a], xf, acc[a][b]);
+                for (int a = 0; a < NFW; ++a) acc[a][b] = mfma16(wf[a], xf, acc[a][b]);
             }
             // The next step's DMA goes out BEHIND the first sub-step: right behind the barrier it delays the first MFMAs of both waves of a SIMD, behind
             // the second sub-step it lands too late (FF w1 of the base config, tools/gemm_harness: 62.0 / 58.6 / 67.7 us for the three placements)
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs p) {
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_s_barrier();                // the stages are free: they become the output staging tile
 
-    if constexpr (GEGLU) {
+    if constexpr (GEGLU && NFW == 4) {
         // interleaved w1 packing: within a wave's 64 weight rows the first 32 are values, the next 32 their gates -> 128 output columns per tile
         constexpr int ROWB = 256;                // staging row bytes (128 bf16)
 #pragma unroll
@@ -115,13 +116,13 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs p) {
             if (m < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + tile_n * 128 + c * 8) = v;
         }
     } else {
-        constexpr int ROWB = 512;                // 256 bf16
+        constexpr int ROWB = TN * 2, CPR = TN / 8;      // staging row bytes, 16-byte chunks per row
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             const int row = wm * 128 + b * 16 + fr;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const int col = wn * 64 + a * 16 + 4 * fg;
+            for (int a = 0; a < NFW; ++a) {
+                const int col = wn * 16 * NFW + a * 16 + 4 * fg;
                 *reinterpret_cast<uint2*>(smem + row * ROWB + (((col >> 3) ^ (row & 7)) << 4) + (col & 4) * 2) =
                     make_uint2(pack_bf16x2(acc[a][b][0], acc[a][b][1]), pack_bf16x2(acc[a][b][2], acc[a][b][3]));
             }
@@ -129,8 +130,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs p) {
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
 #pragma unroll 2
-        for (int i = t; i < TM * 32; i += 512) {
-            const int row = i >> 5, c = i & 31;
+        for (int i = t; i < TM * CPR; i += 512) {
+            const int row = i / CPR, c = i - row * CPR;
             const int m = m0 + row;
             if (m < p.M) {
                 const uint4 v = *reinterpret_cast<const uint4*>(smem + row * ROWB + ((c ^ (row & 7)) << 4));
@@ -332,32 +333,43 @@ __global__ __launch_bounds__(512) void gemm_wide_fused_kernel(const GemmArgs p) 
 #undef TILE_SETUP
 }
 
-template <bool GEGLU>
+template <bool GEGLU, int NFW>
 int launch_wide(GemmArgs a, hipStream_t stream) {
+    constexpr int SM = 2 * (TM + 64 * NFW) * BKB;
     static bool attr_set = false;
     if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<GEGLU>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<GEGLU, NFW>), hipFuncAttributeMaxDynamicSharedMemorySize, SM);
         if (e != hipSuccess) return mm_set_hip_error(e, "gemm_wide hipFuncSetAttribute");
         attr_set = true;
     }
     a.tiles_m = (a.M + TM - 1) / TM;
-    a.tiles_n = a.N / TN;
-    hipLaunchKernelGGL((gemm_wide_kernel<GEGLU>), dim3(a.tiles_m * a.tiles_n), dim3(512), SMEM, stream, a);
+    a.tiles_n = a.N / (64 * NFW);
+    hipLaunchKernelGGL((gemm_wide_kernel<GEGLU, NFW>), dim3(a.tiles_m * a.tiles_n), dim3(512), SM, stream, a);
     return mm_check_launch("gemm_wide_kernel");
+}
+
+// weight-tile height (in 64-row units) whose tile count fills the last round of CUs to >= 90 %: 4 (256 rows) first, then 3 (192 rows, dense only); 0: none
+int wide_nfw(const GemmArgs& a) {
+    const long tm = (a.M + TM - 1) / TM;
+    for (int nfw = 4; nfw >= 3; --nfw) {
+        const int tn = 64 * nfw;
+        if ((a.N % tn) || (nfw == 3 && a.epi != EPI_NONE)) continue;
+        const long tiles = tm * (a.N / tn), rounds = (tiles + 255) / 256;
+        if (tiles >= 256 && tiles * 10 >= rounds * 256 * 9) return nfw;
+    }
+    return 0;
 }
 
 }  // namespace
 
-// dense bf16-output GEMMs without bias / activation / residual (plain or GEGLU with optional LayerNorm partial sums), K % 64 == 0, N % 256 == 0, 16-byte
-// aligned rows, and a tile count that fills the last round of CUs to >= 90 % (a coarse tile loses the remainder)
+// dense bf16-output GEMMs without bias / activation / residual (plain or GEGLU with optional LayerNorm partial sums), K % 64 == 0, N % 256 == 0 (or % 192, plain
+// only), 16-byte aligned rows, and a tile count that fills the last round of CUs to >= 90 % (a coarse tile loses the remainder)
 bool mm_gemm_wide_eligible(const GemmArgs& a) {
     if (a.mode != MODE_DENSE || a.bias || a.act != ACT_NONE || a.resid_bf16 || a.resid_f32 || a.out_kind != OUT_BF16 || a.fs_stats || a.m_dev) return false;
     if (a.epi != EPI_NONE && a.epi != EPI_GEGLU) return false;
-    if ((a.K % 64) || a.K < 128 || (a.N % TN) || (a.ldx % 8) || (a.ldw % 8) || (a.ldc % 8) || (((uintptr_t)a.out) & 15)) return false;
+    if ((a.K % 64) || a.K < 128 || (a.ldx % 8) || (a.ldw % 8) || (a.ldc % 8) || (((uintptr_t)a.out) & 15)) return false;
     if (a.ln_part && a.epi != EPI_GEGLU) return false;
-    const long tiles = (long)((a.M + TM - 1) / TM) * (a.N / TN);
-    const long rounds = (tiles + 255) / 256;
-    return tiles >= 256 && tiles * 10 >= rounds * 256 * 9;
+    return wide_nfw(a) != 0;
 }
 
 // the single-pass logits GEMM with the fused-sampling emission (x = the guidance-mixed embeddings): K % 128 == 0, N % 256 == 0
@@ -381,5 +393,6 @@ int mm_gemm_wide_fused_launch(GemmArgs a, hipStream_t stream) {
 }
 
 int mm_gemm_wide_launch(GemmArgs a, hipStream_t stream) {
-    return a.epi == EPI_GEGLU ? launch_wide<true>(a, stream) : launch_wide<false>(a, stream);
+    if (a.epi == EPI_GEGLU) return launch_wide<true, 4>(a, stream);
+    return wide_nfw(a) == 4 ? launch_wide<false, 4>(a, stream) : launch_wide<false, 3>(a, stream);
 }
