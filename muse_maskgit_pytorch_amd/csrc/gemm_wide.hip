@@ -19,134 +19,6 @@ constexpr int X_B = TM * BKB, W_B = TN * BKB, STG = X_B + W_B, SMEM = 2 * STG;
 
 __device__ __forceinline__ int sw128(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
-template <bool GEGLU, int NFW>      // NFW: weight fragments per wave -- 4: 256-row weight tile, 3: 192-row tile (N a multiple of 192 but not of 256: q|k|v of the base config)
-__global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int TN = 64 * NFW, W_B = TN * BKB, STG = X_B + W_B;
-    const int t = threadIdx.x, lane = t & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wid >> 2, wn = wid & 3;
-    const int fr = lane & 15, fg = lane >> 4;
-    int tile_m, tile_n;
-    xcd_grouped_tile(blockIdx.x, p.tiles_m, p.tiles_n, 8, tile_m, tile_n);
-    const int m0 = tile_m * TM, n0 = tile_n * TN;
-    const int KT = p.K / 64;
-
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    const int rows_left = p.M - m0;
-    const unsigned xbytes = (unsigned)(rows_left < TM ? rows_left : TM) * (unsigned)p.ldx * 2u;      // rows beyond M read as zero
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.X + (size_t)m0 * p.ldx), 0, xbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W + (size_t)n0 * p.ldw), 0, (unsigned)TN * (unsigned)p.ldw * 2u, 0x00020000);
-    // a DMA instruction covers 8 rows: lane l fetches row l >> 3, logical chunk (l & 7) ^ (row & 7) into physical chunk l & 7; this wave stages token rows
-    // 32 wid .. + 31 and weight rows 32 wid .. + 31 (4 + 4 instructions per step)
-    const int dchunk = ((lane & 7) ^ (lane >> 3)) * 16;
-    int voff_x[4], voff_w[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        voff_x[i] = (32 * wid + 8 * i + (lane >> 3)) * p.ldx * 2 + dchunk;
-        voff_w[i] = (8 * NFW * wid + 8 * (i < NFW ? i : 0) + (lane >> 3)) * p.ldw * 2 + dchunk;
-    }
-#define ISSUE(kt_, st_)                                                                                                                \
-    {                                                                                                                                  \
-        unsigned char* xs_ = smem + (st_) * STG + wid * 4096;                                                                          \
-        unsigned char* ws_ = smem + (st_) * STG + X_B + wid * (NFW * 1024);                                                            \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                                  \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(xs_ + i * 1024), 16, voff_x[i], (kt_) * BKB, 0, 0);              \
-        _Pragma("unroll") for (int i = 0; i < NFW; ++i)                                                                                \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(ws_ + i * 1024), 16, voff_w[i], (kt_) * BKB, 0, 0);              \
-    }
-
-    f32x4_t acc[NFW][8];    // [weight fragment a][token fragment b]: lane (fr, fg) holds weight rows 16 a + 4 fg .. + 3 for token 16 b + fr
-#pragma unroll
-    for (int a = 0; a < NFW; ++a)
-#pragma unroll
-        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    ISSUE(0, 0);
-    for (int kt = 0; kt < KT; ++kt) {
-        const int st = kt & 1;
-        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this step's DMA (the only one in flight) has landed
-        __builtin_amdgcn_s_barrier();            // ... for everybody, and everybody is done reading the other stage
-        const unsigned char* xs = smem + st * STG + (wm * 128) * BKB;
-        const unsigned char* ws = smem + st * STG + X_B + (wn * 16 * NFW) * BKB;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {         // two 32-deep MFMA sub-steps, k ascending
-            u32x4_t wf[NFW];
-#pragma unroll
-            for (int a = 0; a < NFW; ++a) wf[a] = *reinterpret_cast<const u32x4_t*>(ws + sw128(a * 16 + fr, ks * 4 + fg));
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const u32x4_t xf = *reinterpret_cast<const u32x4_t*>(xs + sw128(b * 16 + fr, ks * 4 + fg));
-#pragma unroll
-                for (int a = 0; a < NFW; ++a) acc[a][b] = mfma16(wf[a], xf, acc[a][b]);
-            }
-            // The next step's DMA goes out BEHIND the first sub-step: right behind the barrier it delays the first MFMAs of both waves of a SIMD, behind
-            // the second sub-step it lands too late (FF w1 of the base config, tools/gemm_harness: 62.0 / 58.6 / 67.7 us for the three placements)
-            if (ks == 0 && kt + 1 < KT) ISSUE(kt + 1, st ^ 1);
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_s_barrier();                // the stages are free: they become the output staging tile
-
-    if constexpr (GEGLU && NFW == 4) {
-        // interleaved w1 packing: within a wave's 64 weight rows the first 32 are values, the next 32 their gates -> 128 output columns per tile
-        constexpr int ROWB = 256;                // staging row bytes (128 bf16)
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const int row = wm * 128 + b * 16 + fr;
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const int col = wn * 32 + a * 16 + 4 * fg;
-                *reinterpret_cast<uint2*>(smem + row * ROWB + (((col >> 3) ^ (row & 7)) << 4) + (col & 4) * 2) =
-                    make_uint2(pack_bf16x2(geglu_f(acc[a][b][0], acc[a + 2][b][0]), geglu_f(acc[a][b][1], acc[a + 2][b][1])),
-                               pack_bf16x2(geglu_f(acc[a][b][2], acc[a + 2][b][2]), geglu_f(acc[a][b][3], acc[a + 2][b][3])));
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_s_barrier();
-#pragma unroll 2
-        for (int i = t; i < TM * 16; i += 512) {              // 16 chunks of 8 columns per row; 8 adjacent lanes = 64 columns = one LayerNorm part
-            const int row = i >> 4, c = i & 15;
-            const int m = m0 + row;
-            const uint4 v = *reinterpret_cast<const uint4*>(smem + row * ROWB + ((c ^ (row & 7)) << 4));
-            if (p.ln_part) {                                  // LayerNorm(inner) partial sums of this row's 64 columns (common.h): all 8 lanes take part
-                const float2 stv = ln_partial_row64(v);
-                if ((c & 7) == 0 && m < p.M) *reinterpret_cast<float2*>(p.ln_part + ((size_t)m * p.ln_np + tile_n * 2 + (c >> 3)) * 2) = stv;
-            }
-            if (m < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + tile_n * 128 + c * 8) = v;
-        }
-    } else {
-        constexpr int ROWB = TN * 2, CPR = TN / 8;      // staging row bytes, 16-byte chunks per row
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const int row = wm * 128 + b * 16 + fr;
-#pragma unroll
-            for (int a = 0; a < NFW; ++a) {
-                const int col = wn * 16 * NFW + a * 16 + 4 * fg;
-                *reinterpret_cast<uint2*>(smem + row * ROWB + (((col >> 3) ^ (row & 7)) << 4) + (col & 4) * 2) =
-                    make_uint2(pack_bf16x2(acc[a][b][0], acc[a][b][1]), pack_bf16x2(acc[a][b][2], acc[a][b][3]));
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_s_barrier();
-#pragma unroll 2
-        for (int i = t; i < TM * CPR; i += 512) {
-            const int row = i / CPR, c = i - row * CPR;
-            const int m = m0 + row;
-            if (m < p.M) {
-                const uint4 v = *reinterpret_cast<const uint4*>(smem + row * ROWB + ((c ^ (row & 7)) << 4));
-                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + n0 + c * 8) = v;
-            }
-        }
-    }
-#undef ISSUE
-}
-
-// ---- the logits GEMM of the decode loop on the same k-loop: to_logits of the guidance-mixed embeddings with the fused-sampling emission straight from the
-// accumulators (the tile end of gemm_cfg2_kernel<WIDE_MIX2>, same canonical statistics and candidate format: common.h tile_softmax_stats / fs_slot_index).
-// Persistent (one workgroup per CU walks its tiles): the first k-step of the NEXT tile is requested during the last step of the current one, into the stage
-// that step does not read, so the emission (whose exchange arrays live in the other stage) covers its latency.  K % 128 == 0 (an even number of steps: the
-// stage parity is the same for every tile).
 #define MM_VMCNT_IMM(n_) (0x0F70 | ((n_) & 15) | (((n_) >> 4) << 14))
 __device__ __forceinline__ void wait_vmcnt_w(int n) {      // wave-uniform n; above 31: wait for 31 (waiting for more is always safe)
     switch (n) {
@@ -157,6 +29,170 @@ __device__ __forceinline__ void wait_vmcnt_w(int n) {      // wave-uniform n; ab
         default: if (n < 0) __builtin_amdgcn_s_waitcnt(MM_VMCNT_IMM(0)); else __builtin_amdgcn_s_waitcnt(MM_VMCNT_IMM(31)); break;
     }
 }
+template <bool GEGLU, int NFW>      // NFW: weight fragments per wave -- 4: 256-row weight tile, 3: 192-row tile (N a multiple of 192 but not of 256: q|k|v of the base config)
+__global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TN = 64 * NFW, W_B = TN * BKB, STG = X_B + W_B;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int total = p.tiles_m * p.tiles_n, G = gridDim.x;
+    const int KT = p.K / 64;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    // a DMA instruction covers 8 rows: lane l fetches row l >> 3, logical chunk (l & 7) ^ (row & 7) into physical chunk l & 7; this wave stages token rows
+    // 32 wid .. + 31 and weight rows 8 NFW wid .. (4 + NFW instructions per step)
+    const int dchunk = ((lane & 7) ^ (lane >> 3)) * 16;
+    int voff_x[4], voff_w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        voff_x[i] = (32 * wid + 8 * i + (lane >> 3)) * p.ldx * 2 + dchunk;
+        voff_w[i] = (8 * NFW * wid + 8 * (i < NFW ? i : 0) + (lane >> 3)) * p.ldw * 2 + dchunk;
+    }
+    int vb = blockIdx.x;
+    if (vb >= total) return;
+    __amdgpu_buffer_rsrc_t rx, rw;
+    int tile_m, tile_n;
+#define TILE_SETUP(vb_)                                                                                                                \
+    {                                                                                                                                  \
+        xcd_grouped_tile(vb_, p.tiles_m, p.tiles_n, 8, tile_m, tile_n);                                                                \
+        const int left_ = p.M - tile_m * TM;                                                                                           \
+        rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.X + (size_t)tile_m * TM * p.ldx), 0,                              \
+                                               (unsigned)(left_ < TM ? left_ : TM) * (unsigned)p.ldx * 2u, 0x00020000);      /* rows beyond M read as zero */ \
+        rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W + (size_t)tile_n * TN * p.ldw), 0, (unsigned)TN * (unsigned)p.ldw * 2u, 0x00020000); \
+    }
+#define ISSUE(kt_, st_)                                                                                                                \
+    {                                                                                                                                  \
+        unsigned char* xs_ = smem + (st_) * STG + wid * 4096;                                                                          \
+        unsigned char* ws_ = smem + (st_) * STG + X_B + wid * (NFW * 1024);                                                            \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                                  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(xs_ + i * 1024), 16, voff_x[i], (kt_) * BKB, 0, 0);              \
+        _Pragma("unroll") for (int i = 0; i < NFW; ++i)                                                                                \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(ws_ + i * 1024), 16, voff_w[i], (kt_) * BKB, 0, 0);              \
+    }
+    // Persistent when the step count is even (the launcher then starts one workgroup per CU): the NEXT tile's first k-step is requested during the last step of
+    // the current one, into stage 0, which that step (odd index: stage 1) does not read; the epilogue stages its output through stage 1 and its global stores
+    // are still retiring while the next tile's first steps run (the wait of that tile's step 0 counts them: VMEM retires in order).
+    TILE_SETUP(vb);
+    ISSUE(0, 0);
+    int pending = 0;                 // VMEM stores this wave issued BEHIND the DMA of the coming tile's first step
+    unsigned char* stg = smem + STG; // output staging: stage 1
+    f32x4_t acc[NFW][8];             // [weight fragment a][token fragment b]: lane (fr, fg) holds weight rows 16 a + 4 fg .. + 3 for token 16 b + fr
+    while (true) {
+        const int m0 = tile_m * TM, n0 = tile_n * TN, cur_n = tile_n;
+#pragma unroll
+        for (int a = 0; a < NFW; ++a)
+#pragma unroll
+            for (int b = 0; b < 8; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < KT; ++kt) {
+            const int st = kt & 1;
+            if (kt == 0) wait_vmcnt_w(pending); else __builtin_amdgcn_s_waitcnt(0x0F70);      // this step's DMA has landed (only younger stores may still be in flight)
+            __builtin_amdgcn_s_barrier();            // ... for everybody, and everybody is done reading the other stage
+            const unsigned char* xs = smem + st * STG + (wm * 128) * BKB;
+            const unsigned char* ws = smem + st * STG + X_B + (wn * 16 * NFW) * BKB;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {         // two 32-deep MFMA sub-steps, k ascending
+                u32x4_t wf[NFW];
+#pragma unroll
+                for (int a = 0; a < NFW; ++a) wf[a] = *reinterpret_cast<const u32x4_t*>(ws + sw128(a * 16 + fr, ks * 4 + fg));
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const u32x4_t xf = *reinterpret_cast<const u32x4_t*>(xs + sw128(b * 16 + fr, ks * 4 + fg));
+#pragma unroll
+                    for (int a = 0; a < NFW; ++a) acc[a][b] = mfma16(wf[a], xf, acc[a][b]);
+                }
+                // The next step's DMA goes out BEHIND the first sub-step: right behind the barrier it delays the first MFMAs of both waves of a SIMD, behind
+                // the second sub-step it lands too late (FF w1 of the base config, tools/gemm_harness: 62.0 / 58.6 / 67.7 us for the three placements)
+                if (ks == 0) {
+                    if (kt + 1 < KT) {
+                        ISSUE(kt + 1, st ^ 1);
+                    } else if (vb + G < total) {     // (only with an even KT: see the launcher)
+                        TILE_SETUP(vb + G);
+                        ISSUE(0, 0);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();                // everybody is done with stage 1: it becomes the output staging tile
+        const bool full = m0 + TM <= p.M;            // ragged tiles skip stores: their count is not wave-uniform, the next wait then takes everything
+        int nstore = 0;
+        if constexpr (GEGLU && NFW == 4) {
+            // interleaved w1 packing: within a wave's 64 weight rows the first 32 are values, the next 32 their gates -> 128 output columns per tile
+            constexpr int ROWB = 256;                // staging row bytes (128 bf16): 256 rows = 64 KiB = stage 1
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int row = wm * 128 + b * 16 + fr;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int col = wn * 32 + a * 16 + 4 * fg;
+                    *reinterpret_cast<uint2*>(stg + row * ROWB + (((col >> 3) ^ (row & 7)) << 4) + (col & 4) * 2) =
+                        make_uint2(pack_bf16x2(geglu_f(acc[a][b][0], acc[a + 2][b][0]), geglu_f(acc[a][b][1], acc[a + 2][b][1])),
+                                   pack_bf16x2(geglu_f(acc[a][b][2], acc[a + 2][b][2]), geglu_f(acc[a][b][3], acc[a + 2][b][3])));
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();
+#pragma unroll 2
+            for (int i = t; i < TM * 16; i += 512) {              // 16 chunks of 8 columns per row; 8 adjacent lanes = 64 columns = one LayerNorm part
+                const int row = i >> 4, c = i & 15;
+                const int m = m0 + row;
+                const uint4 v = *reinterpret_cast<const uint4*>(stg + row * ROWB + ((c ^ (row & 7)) << 4));
+                if (p.ln_part) {                                  // LayerNorm(inner) partial sums of this row's 64 columns (common.h): all 8 lanes take part
+                    const float2 stv = ln_partial_row64(v);
+                    if ((c & 7) == 0 && m < p.M) *reinterpret_cast<float2*>(p.ln_part + ((size_t)m * p.ln_np + cur_n * 2 + (c >> 3)) * 2) = stv;
+                }
+                if (m < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + cur_n * 128 + c * 8) = v;
+            }
+            nstore = (TM * 16 / 512) * (p.ln_part ? 2 : 1);
+        } else {
+            constexpr int ROWB = TN * 2, CPR = TN / 8;      // staging row bytes, 16-byte chunks per row; one token half (128 rows <= 64 KiB) at a time
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                if (wm == half) {
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {
+                        const int row = b * 16 + fr;
+#pragma unroll
+                        for (int a = 0; a < NFW; ++a) {
+                            const int col = wn * 16 * NFW + a * 16 + 4 * fg;
+                            *reinterpret_cast<uint2*>(stg + row * ROWB + (((col >> 3) ^ (row & 7)) << 4) + (col & 4) * 2) =
+                                make_uint2(pack_bf16x2(acc[a][b][0], acc[a][b][1]), pack_bf16x2(acc[a][b][2], acc[a][b][3]));
+                        }
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_s_barrier();
+#pragma unroll 2
+                for (int i = t; i < 128 * CPR; i += 512) {
+                    const int row = i / CPR, c = i - row * CPR;
+                    const int m = m0 + half * 128 + row;
+                    if (m < p.M) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(stg + row * ROWB + ((c ^ (row & 7)) << 4));
+                        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + n0 + c * 8) = v;
+                    }
+                }
+                if (half == 0) {
+                    __builtin_amdgcn_s_waitcnt(0xC07F);
+                    __builtin_amdgcn_s_barrier();      // the first half is read out before the second one overwrites it
+                }
+            }
+            nstore = 2 * (128 * CPR / 512);
+        }
+        pending = full ? nstore : 0;
+        vb += G;
+        if (vb >= total) break;
+        // (no barrier here: a wave reaches the next tile's first barrier only behind its own staging reads, and the DMA into stage 1 is issued behind that barrier)
+    }
+#undef ISSUE
+#undef TILE_SETUP
+}
+
+// ---- the logits GEMM of the decode loop on the same k-loop: to_logits of the guidance-mixed embeddings with the fused-sampling emission straight from the
+// accumulators (the tile end of gemm_cfg2_kernel<WIDE_MIX2>, same canonical statistics and candidate format: common.h tile_softmax_stats / fs_slot_index).
+// Persistent (one workgroup per CU walks its tiles): the first k-step of the NEXT tile is requested during the last step of the current one, into the stage
+// that step does not read, so the emission (whose exchange arrays live in the other stage) covers its latency.  K % 128 == 0 (an even number of steps: the
+// stage parity is the same for every tile).
 __device__ __forceinline__ float max4_w(float a, float b, float c, float d) {      // (MFMA results: no canonicalising v_max x, x needed)
     float r;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -344,7 +380,10 @@ int launch_wide(GemmArgs a, hipStream_t stream) {
     }
     a.tiles_m = (a.M + TM - 1) / TM;
     a.tiles_n = a.N / (64 * NFW);
-    hipLaunchKernelGGL((gemm_wide_kernel<GEGLU, NFW>), dim3(a.tiles_m * a.tiles_n), dim3(512), SM, stream, a);
+    const int total = a.tiles_m * a.tiles_n;
+    // persistent (one workgroup per CU) when the k-step count is even -- the prefetch across tiles relies on the stage parity --, one tile per workgroup otherwise
+    const int grid = ((a.K / 64) % 2 == 0 && !(g_mm_debug & (1 << 22))) ? (total < 256 ? total : 256) : total;
+    hipLaunchKernelGGL((gemm_wide_kernel<GEGLU, NFW>), dim3(grid), dim3(512), SM, stream, a);
     return mm_check_launch("gemm_wide_kernel");
 }
 
