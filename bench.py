@@ -319,8 +319,8 @@ def _respawn_under_torchrun(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', choices=sorted(CONFIGS), default='c2', help='c2 = the metric configuration (BASELINE configs[1]); c4 super-res, c5 paper-scale shape')
     ap.add_argument('--batch', type=int, default=None, help='images per GPU per step (default: 32; 8 for c4)')
     ap.add_argument('--timesteps', type=int, default=18)
