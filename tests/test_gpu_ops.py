@@ -594,6 +594,30 @@ def test_vq_nearest_lookup(N, K, C, cosine):
     assert torch.equal(q, cb[got])
 
 
+@pytest.mark.parametrize('M,N,K', [(16384, 1536, 512), (16384, 1536, 192), (16300, 1024, 320), (5000, 4096, 448), (16384, 3072, 1024), (9000, 2304, 640)])
+def test_gemm_wide_kernels_bit_identical_to_the_128x128_kernel(M, N, K):
+    """gemm_wide.hip (256 x 256 | 192 x 64 tile, persistent with an even k-step count, one tile per workgroup with an odd one): the plain bf16 projections
+    and the GEGLU + LayerNorm-partial-sum form against the 128x128 kernel (debug bit 8), ragged row counts included, three repetitions (race screen)"""
+    if DRY:
+        pytest.skip('kernel-structure test')
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = r16(rnd(M, K, gen=g)).to(DEV, bf16)
+    w = r16(rnd(N, K, gen=g, scale=0.1)).to(DEV, bf16)
+    runs = [lambda: ops.gemm(x, w)]
+    if N % 256 == 0:
+        runs.append(lambda: ops.gemm_geglu(x, w))
+    lib.mm_debug_set(8)
+    try:
+        refs = [f() for f in runs]
+    finally:
+        lib.mm_debug_set(0)
+    for rep in range(3):
+        for f, ref in zip(runs, refs):
+            got = f()
+            assert torch.equal(got, ref), f'shape {(M, N, K)} rep {rep}: {(got != ref).sum().item()} elements differ'
+
+
 def test_gemm_kernel_family_random_shapes_bit_identical():
     """Race screen for the counted-vmcnt / LDS-DMA pipelines: random (ragged) shapes through whatever kernel the dispatcher picks
     (persistent, 256x128 three-stage, guidance 128x256) against the 128x128 kernel (debug bit 8), several repetitions each."""
