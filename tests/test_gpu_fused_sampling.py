@@ -126,6 +126,32 @@ def test_gemm_emission_equals_emission_from_its_logits(M):
     assert torch.equal(pa, ref_pred) and torch.equal(pb, ref_pred) and torch.equal(sa, sb)
 
 
+@pytest.mark.parametrize('M,V,D', [(2500, 8192, 1024), (1100, 8192, 512), (1024, 65536, 576), (3000, 8192, 640)])
+def test_single_pass_emission_on_other_shapes(M, V, D):
+    """the single-pass logits GEMM with the accumulator emission (gemm_wide_fused_kernel where K % 128 == 0 and M >= 1024, gemm_cfg2 otherwise) at the
+    paper-scale shape (V = 8192, D = 1024: 16 k-steps, 32 column tiles), with fewer 256-row tiles than CUs (one tile per workgroup), with K % 128 != 0
+    (D = 576 -> the older kernel) and with ten k-steps (D = 640): statistics and candidates equal the emission computed from the materialised logits, the sampled ids / scores equal sample_rows"""
+    torch.manual_seed(M + V)
+    W = (torch.randn(V, D) * (D ** -0.5)).to(torch.bfloat16).to(DEV)
+    em = torch.randn(M, D).to(torch.bfloat16).to(DEV)
+    Wf = W.float()
+    wmean = Wf.mean(dim=0).contiguous()
+    wcov = ((Wf.t() @ Wf) / V - torch.outer(wmean, wmean)).to(torch.bfloat16).contiguous()
+    k_keep = math.ceil(0.1 * V)
+    thr = ops.fused_threshold(em, em, 1.0, wmean, wcov, ops.fused_z(k_keep, V))
+    lm = ops.gemm(em, W, out_f32=True).contiguous()
+    fm, fn = ops.fused_buffers(M, V, DEV), ops.fused_buffers(M, V, DEV)
+    ops.fused_emit(lm, thr, fm)
+    for rep in range(2):
+        ops.gemm_cfg_logits_fused(em, None, W, 1.0, thr, fn)
+        assert torch.equal(fm['stats'].view(torch.int32), fn['stats'].view(torch.int32))
+        valid = _valid_slots(fm['stats'])
+        assert torch.equal(fm['cand'][valid].view(torch.int32), fn['cand'][valid].view(torch.int32))
+    pm, sm = ops.fused_sample(fn, thr, M, V, k_keep, 1.0, noise_kind=_lib.MM_NOISE_PHILOX, seed=3)
+    rp_, rs_ = ops.sample_rows(lm, k_keep, 1.0, noise_kind=_lib.MM_NOISE_PHILOX, seed=3)
+    assert int(fn['fail'].item()) == 0 and torch.equal(pm, rp_) and torch.equal(sm, rs_)
+
+
 def test_generate_with_fused_sampling_at_bench_size_and_its_fallback():
     """mm_generate at B = 32: the fused path is taken (no fallback on Gaussian-like logits), is repeatable, and a model whose logits defeat
     the bound (a few enormous to_logits rows) falls back to the logits path and returns that path's ids"""
