@@ -115,10 +115,10 @@ int mm_sample_rows(mm_stream_t stream, const float* logits, int64_t ld, int R, i
                    int64_t* pred_out, float* score_out);
 
 /* ---- sampling without the logits round trip (csrc/sampling_fused.hip; mmp.py:576-609, SURVEY.md 8d "fused floor").
- * The guidance-logits GEMM emits, per token row and 256-column tile, {max, sum exp, mask of kept lanes} and the values of every lane (4
- * consecutive columns) whose largest value reaches thr_lo[row], instead of the logits; mm_fused_sample finishes the row (exact k-th
- * largest, Gumbel argmax, confidence) from those.  Buffers, caller-owned: stats 16 B x [R][V/256]; cand 16 B x [R][V/256][MM_FUSED_SLOT];
- * fail_flag int32 [1] (zero it; set to 1 if some row's candidates could not be proven to contain its kept set -- then repeat on the
+ * The guidance-logits GEMM emits, per token row and 256-column piece, a record {max, sum exp, 128-bit mask of the kept granules} and the kept GRANULES
+ * (two adjacent columns whose larger value reaches thr_lo[row]) compacted in column order, instead of the logits; mm_fused_sample finishes the row (exact
+ * k-th largest, Gumbel argmax, confidence) from those.  Buffers, caller-owned: stats 32 B x [R][V/256]; cand 16 B x [R][V/256][MM_FUSED_SLOT] (= 128 float2
+ * entries per piece); fail_flag int32 [1] (zero it; set to 1 if some row's candidates could not be proven to contain its kept set -- then repeat on the
  * logits path, mm_gemm_cfg_logits + mm_sample_rows).  V % 256 == 0.
  *   mm_fused_threshold : thr_lo[r] = mean_r + z sigma_r of row r's logits over the vocabulary, from the row's embeddings (bf16 cond / null,
  *                        combined with cond_scale) and the vocabulary statistics of to_logits (wmean fp32 [D], wcov bf16 [D][D], D % 64 == 0);

@@ -149,11 +149,12 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 }
 #undef MM_DPP_F
 
-// Fused sampling (sampling_fused.hip): what leaves the guidance-logits GEMM instead of the logits.  One 256-column piece of a logits row is
-// held by a wave as 4 consecutive values per lane (lane l: columns 4l .. 4l+3 of the tile).  A lane whose largest value reaches thr keeps its
-// four values: the kept lanes' float4s are stored lane-compacted into the tile's slot (at most 64 x 16 B: the slot cannot overflow) and the
-// tile's statistics record {max, sum exp(x - max), 64-bit mask of the kept granules}.  No atomics.
-constexpr int FS_SLOT = 64;
+// Fused sampling (sampling_fused.hip): what leaves the guidance-logits GEMM instead of the logits.  One 256-column piece of a logits row is 128 GRANULES of
+// two adjacent columns; a granule whose larger value reaches thr is kept: the kept granules (float2) are stored compacted, in column order, into the
+// piece's slot (at most 128 x 8 B: the slot cannot overflow), and the piece's record is two float4s: {max, sum exp(x - max), -, -} and the 128-bit mask of
+// the kept granules.  No atomics.
+constexpr int FS_SLOT = 64;      // float4 units of a (row, piece) candidate slot = 128 float2 entries
+constexpr int FS_REC = 2;        // float4 units of a (row, piece) record
 // Softmax statistics of one 256-column piece of a logits row and the order of its candidate granules, in ONE canonical form shared by every
 // producer -- the guidance GEMM's epilogue (from its accumulator fragments, gemm_cfg.hip), fused_emit (from materialised logits) and the
 // logits-path sampler (sampling.hip) -- so that a row's softmax denominator, its confidence 1 - p and the next step's re-masking are
@@ -164,14 +165,25 @@ constexpr int FS_SLOT = 64;
 //     pl = (g(0) + g(1)) + (g(2) + g(3))
 // and over the 16 groups of the piece:
 //     M = max ml;   t(q, f) = pl * exp(ml - M);   w(q) = (t(q,0) + t(q,1)) + (t(q,2) + t(q,3));   E = (w(0) + w(1)) + (w(2) + w(3))
-// Candidate granules (kept when their largest value reaches the row's bound) are numbered in ROW-LAYOUT order j = 16 q + 4 a + f = (column / 4);
-// bit j of the piece's 64-bit mask says whether granule j was kept.  The 64-entry slot of a (row, piece) is four SUB-SLOTS of 16, one per quarter q:
-// granule j sits at 16 q + (number of kept granules of quarter q in front of it).  A quarter is one wave of the GEMM, so a wave ranks and stores its
-// granules without waiting for the other three quarters (and a token's lane groups f = 0..3 hold adjacent granules for a fixed fragment a: one store
-// instruction writes up to 64 contiguous bytes per token).
-__device__ __forceinline__ int fs_slot_index(unsigned long long mask, int j) {
-    const uint32_t m16 = (uint32_t)(mask >> (j & 48)) & 0xFFFFu;
-    return (j & 48) + __popc(m16 & ((1u << (j & 15)) - 1u));
+// Candidate granules (two adjacent columns, kept when the larger value reaches the row's bound) are numbered in column order J = column / 2 =
+// 32 q + 8 a + 2 f + h (h: the half of lane group f's 4 values); word q of the piece's 128-bit mask holds quarter q, bit 8 a + 2 f + h.  Granule J sits at
+// position (number of kept granules in front of it) of the slot: ONE compacted list per (row, piece).  (Round 3 began with 4-column granules in four
+// per-quarter sub-slots -- a wave could store without waiting for the other quarters -- but 40 % of those granules were kept for 12 % of the values and
+// every sub-slot cost its own 128-byte line: 0.69 GB written and 0.80 GB fetched per step for 0.16 GB of values.  With 2-column granules 23 % are
+// kept and the list is dense; the GEMM's waves rank their granules behind the exchange they need anyway for the statistics.)
+__device__ __forceinline__ int fs_pos(const uint4 m, int q, int gq) {      // position of granule gq of quarter q in the slot
+    int base = 0;
+    if (q > 0) base += __popc(m.x);
+    if (q > 1) base += __popc(m.y);
+    if (q > 2) base += __popc(m.z);
+    const uint32_t mq = q == 0 ? m.x : (q == 1 ? m.y : (q == 2 ? m.z : m.w));
+    return base + __popc(mq & ((1u << gq) - 1u));
+}
+__device__ __forceinline__ uint32_t fs_interleave16(uint32_t even, uint32_t odd) {      // bit 2 i = bit i of `even`, bit 2 i + 1 = bit i of `odd` (16 bits each)
+    uint32_t a = even & 0xFFFFu, b = odd & 0xFFFFu;
+    a = (a | (a << 8)) & 0x00FF00FFu; a = (a | (a << 4)) & 0x0F0F0F0Fu; a = (a | (a << 2)) & 0x33333333u; a = (a | (a << 1)) & 0x55555555u;
+    b = (b | (b << 8)) & 0x00FF00FFu; b = (b | (b << 4)) & 0x0F0F0F0Fu; b = (b | (b << 2)) & 0x33333333u; b = (b | (b << 1)) & 0x55555555u;
+    return a | (b << 1);
 }
 // exp(x - ml) as v_exp_f32((x - ml) * log2 e): the subtraction first -- exact near the maximum, so the largest value contributes exactly 1 (an FMA
 // form x * log2 e - ml * log2 e rounds the product of the MAGNITUDES: 2e-6 off at |ml| ~ 40, enough to push a dominant token's 1 - p below 0)
@@ -214,13 +226,22 @@ __device__ __forceinline__ void tile_softmax_stats(const float4 x, float& M, flo
 }
 __device__ __forceinline__ void fused_emit_piece(const float4 x, int row, int tile, int NT, int lane, float thr, float4* __restrict__ stats,
                                                  float4* __restrict__ cand) {
-    const float m4 = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
     float m, e;
     tile_softmax_stats(x, m, e);
-    const bool kp = m4 >= thr;
-    const unsigned long long mask = __ballot(kp);
-    if (kp) cand[((size_t)row * NT + tile) * FS_SLOT + fs_slot_index(mask, lane)] = x;
-    if (lane == 0) stats[(size_t)row * NT + tile] = make_float4(m, e, __uint_as_float((uint32_t)mask), __uint_as_float((uint32_t)(mask >> 32)));
+    // row layout: lane l holds granules 2 l (x.x, x.y) and 2 l + 1 (x.z, x.w) of the piece
+    const bool kp0 = fmaxf(x.x, x.y) >= thr, kp1 = fmaxf(x.z, x.w) >= thr;
+    const unsigned long long b0 = __ballot(kp0), b1 = __ballot(kp1);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int pos0 = __popcll(b0 & below) + __popcll(b1 & below);
+    float2* slot = reinterpret_cast<float2*>(cand + ((size_t)row * NT + tile) * FS_SLOT);
+    if (kp0) slot[pos0] = make_float2(x.x, x.y);
+    if (kp1) slot[pos0 + (kp0 ? 1 : 0)] = make_float2(x.z, x.w);
+    if (lane == 0) {
+        float4* rec = stats + ((size_t)row * NT + tile) * FS_REC;
+        rec[0] = make_float4(m, e, 0.f, 0.f);
+        rec[1] = make_float4(__uint_as_float(fs_interleave16((uint32_t)b0, (uint32_t)b1)), __uint_as_float(fs_interleave16((uint32_t)(b0 >> 16), (uint32_t)(b1 >> 16))),
+                             __uint_as_float(fs_interleave16((uint32_t)(b0 >> 32), (uint32_t)(b1 >> 32))), __uint_as_float(fs_interleave16((uint32_t)(b0 >> 48), (uint32_t)(b1 >> 48))));
+    }
 }
 
 // ---- 'bf16x3' precision tier (split.hip): an fp32 value as the exact sum of three bf16 terms, x = h + m + l

@@ -80,6 +80,11 @@ __device__ __forceinline__ uint4 lds_read_b128_raw(const unsigned char* ptr) {
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
+__device__ __forceinline__ float max2_asm(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // max of 4 as two instructions (fmaxf would add a canonicalising v_max x, x per operand: these are MFMA results, never signalling NaNs)
 __device__ __forceinline__ float max4_asm(float a, float b, float c, float d) {
     float r;
@@ -393,9 +398,10 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
                 const int m0t = tile_m * TTOK;
                 constexpr int NBLK = MIX2 ? 8 : 4;                 // token blocks of 16 per wave
                 const int tilec = tile_n;                          // the piece index of this tile's 256 columns in a row of V / 256 pieces
-                uint32_t* xnib4 = reinterpret_cast<uint32_t*>(xch);                          // [4 quarters][tokens]: 4 keep nibbles (fragment a in byte a)
+                uint32_t* xmask = reinterpret_cast<uint32_t*>(xch);                          // [4 quarters][tokens]: the quarter's 32 keep bits of a token (bit 8 a + 2 f + h)
                 float2* xml = reinterpret_cast<float2*>(xch + TTOK * 16);                    // [16 lane groups][tokens] (ml, pl)
                 int nstore = 0;
+                uint32_t mq[8];                          // the quarter's 32 keep bits of this lane's token of block b (bit 8 a + 2 f + h), after the exchange
 #pragma unroll
                 for (int b = 0; b < NBLK; ++b) {
                     const int tokl = (b >> 2) * TOK + wm * 64 + (b & 3) * 16 + FR_;
@@ -410,50 +416,61 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
                                 acc[a][b][r] = nl + (cv - nl) * p.cfg_scale;
                             }
                     }
-                    // this lane IS lane group (wn, FG_) of the token: its 4 granules a = 0..3, no lane exchange anywhere
-                    float gm[4];
+                    // this lane IS lane group (wn, FG_) of the token: its 8 granules (a, h), no lane exchange anywhere
+                    float g2[4][2], gm[4];
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) gm[a] = max4_asm(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+                    for (int a = 0; a < 4; ++a) {
+                        g2[a][0] = max2_asm(acc[a][b][0], acc[a][b][1]);
+                        g2[a][1] = max2_asm(acc[a][b][2], acc[a][b][3]);
+                        gm[a] = max2_asm(g2[a][0], g2[a][1]);
+                    }
                     const float ml = max4_asm(gm[0], gm[1], gm[2], gm[3]);
                     float gs[4];
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
                         gs[a] = (fs_exp(acc[a][b][0], ml) + fs_exp(acc[a][b][1], ml)) + (fs_exp(acc[a][b][2], ml) + fs_exp(acc[a][b][3], ml));
                     const float pl = (gs[0] + gs[1]) + (gs[2] + gs[3]);
-                    // keep bits.  The piece's mask is in row-layout order j = 16 wn + 4 a + FG_; the four lane groups of a token hold bits 4 a + 0..3
-                    // of fragment a, collected from the wave's ballot (lane = 16 FG_ + FR_) into one nibble per (token, fragment)
-                    unsigned kb = 0, nib4 = 0;
+                    // keep bits: this lane's 8 granules sit at bits 8 a + 2 f + h of the quarter's word; the token's four lane groups (lanes FR_, 16 + FR_, 32 + FR_,
+                    // 48 + FR_) OR their shares together with two lane exchanges
+                    uint32_t m32 = 0;
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
-                        const bool kp = valid && gm[a] >= thr;
-                        kb |= kp ? (1u << a) : 0u;
-                        const unsigned long long bal = __ballot(kp);
-                        const uint32_t lo = (uint32_t)bal, hi = (uint32_t)(bal >> 32);
-                        const uint32_t nb = ((lo >> FR_) & 1u) | (((lo >> (16 + FR_)) & 1u) << 1) | (((hi >> FR_) & 1u) << 2) | (((hi >> (16 + FR_)) & 1u) << 3);
-                        nib4 |= nb << (8 * a);
+                        const uint32_t k2 = ((valid && g2[a][0] >= thr) ? 1u : 0u) | ((valid && g2[a][1] >= thr) ? 2u : 0u);
+                        m32 |= k2 << (8 * a);
                     }
-                    // (both exchange arrays are [lane group / quarter][token]: a wave's 16 tokens are adjacent words -- token-major rows were a 16-way
-                    //  bank conflict on every write, SQ_LDS_BANK_CONFLICT 0.39 of the kernel's LDS cycles)
-                    if (FG_ == 0) xnib4[wn * TTOK + tokl] = nib4;      // bytes a = 0..3 of quarter wn: 0x0n0n0n0n
+                    m32 <<= 2 * FG_;
+                    m32 |= (uint32_t)__shfl_xor((int)m32, 16, 64);
+                    m32 |= (uint32_t)__shfl_xor((int)m32, 32, 64);
+                    mq[b] = m32;
+                    if (FG_ == 0) xmask[wn * TTOK + tokl] = m32;
                     xml[(wn * 4 + FG_) * TTOK + tokl] = make_float2(ml, pl);
-                    // this quarter's kept granules go out NOW (their sub-slot positions need nothing from the other three waves): the stores of one
-                    // token block are in flight while the next block's statistics are computed
-                    uint32_t m16 = (nib4 | (nib4 >> 4)) & 0x00FF00FFu;
-                    m16 = (m16 | (m16 >> 8)) & 0x0000FFFFu;          // bit 4 a + f of the quarter
-                    float4* slot = p.fs_cand + ((size_t)(m0t + tokl) * p.tiles_n + tilec) * FS_SLOT + wn * 16;
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        const bool kp = (kb >> a) & 1u;
-                        if (__ballot(kp) != 0ull) {                     // wave-uniform: the store below is ISSUED (exact VMEM count for the waits)
-                            if (kp) slot[__popc(m16 & ((1u << (4 * a + FG_)) - 1u))] = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
-                            ++nstore;
-                        }
-                    }
                 }
                 TSTAMP()
                 WAIT_LGKM0();
-                __builtin_amdgcn_s_barrier();      // all 16 lane groups of every token have published their nibble and (ml, pl)
+                __builtin_amdgcn_s_barrier();      // all 16 lane groups of every token have published their masks and (ml, pl)
                 TSTAMP()
+                // ---- the kept granules go out compacted in column order: a quarter starts behind the kept granules of the quarters in front of it
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b) {
+                    const uint32_t mine = (mq[b] >> (2 * FG_)) & 0x03030303u;      // bit 8 a + h: this lane's granule (a, h) of block b
+                    if (__ballot(mine != 0u) == 0ull) continue;                   // wave-uniform
+                    const int tokl = (b >> 2) * TOK + wm * 64 + (b & 3) * 16 + FR_;
+                    int base = 0;                                                 // kept granules of the quarters in front of this one
+                    if (wn > 0) base += __popc(xmask[tokl]);
+                    if (wn > 1) base += __popc(xmask[TTOK + tokl]);
+                    if (wn > 2) base += __popc(xmask[2 * TTOK + tokl]);
+                    float2* slot = reinterpret_cast<float2*>(p.fs_cand + ((size_t)(m0t + tokl) * p.tiles_n + tilec) * FS_SLOT) + base;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const bool kp = (mine >> (8 * a + h)) & 1u;
+                            if (__ballot(kp) != 0ull) {                         // wave-uniform: the store below is ISSUED (exact VMEM count for the waits)
+                                if (kp) slot[__popc(mq[b] & ((1u << (8 * a + 2 * FG_ + h)) - 1u))] = make_float2(acc[a][b][2 * h], acc[a][b][2 * h + 1]);
+                                ++nstore;
+                            }
+                        }
+                }
                 // one record per (token, piece): this wave combines the tokens of the token blocks b with (b & 3) == wn (its lanes FG_ == 0)
 #pragma unroll
                 for (int hb = 0; hb < NBLK / 4; ++hb) {
@@ -462,12 +479,6 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
                     const bool w_ = FG_ == 0 && tok < p.M;
                     if (__ballot(w_) != 0ull) {
                         if (w_) {
-                            uint32_t h16[4] = {xnib4[tokl], xnib4[TTOK + tokl], xnib4[2 * TTOK + tokl], xnib4[3 * TTOK + tokl]};      // the 4 quarters' nibble words
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {                                      // 0x0n0n0n0n -> 0xnnnn (fragment a of the quarter in bits 4 a .. 4 a + 3)
-                                h16[q] = (h16[q] | (h16[q] >> 4)) & 0x00FF00FFu;
-                                h16[q] = (h16[q] | (h16[q] >> 8)) & 0x0000FFFFu;
-                            }
                             // tile_combine16 (common.h) streamed from LDS in two sweeps (max, then the weighted sums in the canonical order)
                             const float2* gq = xml + tokl;                          // lane group g of this token: gq[g * TTOK]
                             float M_ = -INFINITY;
@@ -480,9 +491,12 @@ __global__ __launch_bounds__(512) void gemm_cfg2_kernel(const GemmArgs p) {
                                 wq[q] = (u0.y * __expf(u0.x - M_) + u1.y * __expf(u1.x - M_)) + (u2.y * __expf(u2.x - M_) + u3.y * __expf(u3.x - M_));
                             }
                             const float E_ = (wq[0] + wq[1]) + (wq[2] + wq[3]);
-                            p.fs_stats[(size_t)tok * p.tiles_n + tilec] = make_float4(M_, E_, __uint_as_float(h16[0] | (h16[1] << 16)), __uint_as_float(h16[2] | (h16[3] << 16)));
+                            float4* rec = p.fs_stats + ((size_t)tok * p.tiles_n + tilec) * FS_REC;
+                            rec[0] = make_float4(M_, E_, 0.f, 0.f);
+                            rec[1] = make_float4(__uint_as_float(xmask[tokl]), __uint_as_float(xmask[TTOK + tokl]), __uint_as_float(xmask[2 * TTOK + tokl]),
+                                                 __uint_as_float(xmask[3 * TTOK + tokl]));
                         }
-                        ++nstore;
+                        nstore += 2;
                     }
                 }
                 st1 += nstore;      // issued after this wave's last DMA: the next NST - 1 steps' counted waits allow for them

@@ -193,6 +193,11 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs p) {
 // Persistent (one workgroup per CU walks its tiles): the first k-step of the NEXT tile is requested during the last step of the current one, into the stage
 // that step does not read, so the emission (whose exchange arrays live in the other stage) covers its latency.  K % 128 == 0 (an even number of steps: the
 // stage parity is the same for every tile).
+__device__ __forceinline__ float max2_w(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ float max4_w(float a, float b, float c, float d) {      // (MFMA results: no canonicalising v_max x, x needed)
     float r;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -287,49 +292,68 @@ __global__ __launch_bounds__(512) void gemm_wide_fused_kernel(const GemmArgs p) 
         asm volatile("" : "+v"(le_));            // opaque copy: keeps the emission's address arithmetic out of the k-loop's live ranges
         const int FR_ = le_ & 15, FG_ = le_ >> 4;
         const int m0t = cur_m * TM;
-        uint32_t* xnib4 = reinterpret_cast<uint32_t*>(xch);                          // [4 quarters][tokens]: 4 keep nibbles (fragment a in byte a)
+        uint32_t* xmask = reinterpret_cast<uint32_t*>(xch);                          // [4 quarters][tokens]: the quarter's 32 keep bits of a token (bit 8 a + 2 f + h)
         float2* xml = reinterpret_cast<float2*>(xch + TM * 16);                      // [16 lane groups][tokens] (ml, pl)
         int nstore = 0;
+        uint32_t mq[8];                          // the quarter's 32 keep bits of this lane's token of block b (bit 8 a + 2 f + h), after the exchange
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             const int tokl = wm * 128 + b * 16 + FR_;
             const bool valid = m0t + tokl < p.M;
             const float thr = lthr[tokl];
-            float gm[4];
+            // this lane IS lane group (wn, FG_) of the token: its 8 granules (a, h), no lane exchange anywhere
+            float g2[4][2], gm[4];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) gm[a] = max4_w(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+            for (int a = 0; a < 4; ++a) {
+                g2[a][0] = max2_w(acc[a][b][0], acc[a][b][1]);
+                g2[a][1] = max2_w(acc[a][b][2], acc[a][b][3]);
+                gm[a] = max2_w(g2[a][0], g2[a][1]);
+            }
             const float ml = max4_w(gm[0], gm[1], gm[2], gm[3]);
             float gs[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
                 gs[a] = (fs_exp(acc[a][b][0], ml) + fs_exp(acc[a][b][1], ml)) + (fs_exp(acc[a][b][2], ml) + fs_exp(acc[a][b][3], ml));
             const float pl = (gs[0] + gs[1]) + (gs[2] + gs[3]);
-            unsigned kb = 0, nib4 = 0;
+            // keep bits: this lane's 8 granules sit at bits 8 a + 2 f + h of the quarter's word; the token's four lane groups (lanes FR_, 16 + FR_, 32 + FR_,
+            // 48 + FR_) OR their shares together with two lane exchanges
+            uint32_t m32 = 0;
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                const bool kp = valid && gm[a] >= thr;
-                kb |= kp ? (1u << a) : 0u;
-                const unsigned long long bal = __ballot(kp);
-                const uint32_t lo = (uint32_t)bal, hi = (uint32_t)(bal >> 32);
-                const uint32_t nb = ((lo >> FR_) & 1u) | (((lo >> (16 + FR_)) & 1u) << 1) | (((hi >> FR_) & 1u) << 2) | (((hi >> (16 + FR_)) & 1u) << 3);
-                nib4 |= nb << (8 * a);
+                const uint32_t k2 = ((valid && g2[a][0] >= thr) ? 1u : 0u) | ((valid && g2[a][1] >= thr) ? 2u : 0u);
+                m32 |= k2 << (8 * a);
             }
-            if (FG_ == 0) xnib4[wn * TM + tokl] = nib4;
+            m32 <<= 2 * FG_;
+            m32 |= (uint32_t)__shfl_xor((int)m32, 16, 64);
+            m32 |= (uint32_t)__shfl_xor((int)m32, 32, 64);
+            mq[b] = m32;
+            if (FG_ == 0) xmask[wn * TM + tokl] = m32;
             xml[(wn * 4 + FG_) * TM + tokl] = make_float2(ml, pl);
-            uint32_t m16 = (nib4 | (nib4 >> 4)) & 0x00FF00FFu;
-            m16 = (m16 | (m16 >> 8)) & 0x0000FFFFu;          // bit 4 a + f of the quarter
-            float4* slot = p.fs_cand + ((size_t)(m0t + tokl) * p.tiles_n + cur_n) * FS_SLOT + wn * 16;
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const bool kp = (kb >> a) & 1u;
-                if (__ballot(kp) != 0ull) {                     // wave-uniform: the store below is ISSUED (exact VMEM count for the wait)
-                    if (kp) slot[__popc(m16 & ((1u << (4 * a + FG_)) - 1u))] = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
-                    ++nstore;
-                }
-            }
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_s_barrier();      // all 16 lane groups of every token have published their nibbles and (ml, pl)
+        __builtin_amdgcn_s_barrier();      // all 16 lane groups of every token have published their masks and (ml, pl)
+        // ---- the kept granules go out compacted in column order: a quarter starts behind the kept granules of the quarters in front of it
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint32_t mine = (mq[b] >> (2 * FG_)) & 0x03030303u;      // bit 8 a + h: this lane's granule (a, h) of block b
+            if (__ballot(mine != 0u) == 0ull) continue;                   // wave-uniform
+            const int tokl = wm * 128 + b * 16 + FR_;
+            int base = 0;                                                 // kept granules of the quarters in front of this one
+            if (wn > 0) base += __popc(xmask[tokl]);
+            if (wn > 1) base += __popc(xmask[TM + tokl]);
+            if (wn > 2) base += __popc(xmask[2 * TM + tokl]);
+            float2* slot = reinterpret_cast<float2*>(p.fs_cand + ((size_t)(m0t + tokl) * p.tiles_n + cur_n) * FS_SLOT) + base;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const bool kp = (mine >> (8 * a + h)) & 1u;
+                    if (__ballot(kp) != 0ull) {                         // wave-uniform: the store below is ISSUED (exact VMEM count for the waits)
+                        if (kp) slot[__popc(mq[b] & ((1u << (8 * a + 2 * FG_ + h)) - 1u))] = make_float2(acc[a][b][2 * h], acc[a][b][2 * h + 1]);
+                        ++nstore;
+                    }
+                }
+        }
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {   // one record per (token, piece): this wave combines the tokens of its half's blocks wn and wn + 4
             const int tokl = wm * 128 + (hb * 4 + wn) * 16 + FR_;
@@ -337,12 +361,6 @@ __global__ __launch_bounds__(512) void gemm_wide_fused_kernel(const GemmArgs p) 
             const bool w_ = FG_ == 0 && tok < p.M;
             if (__ballot(w_) != 0ull) {
                 if (w_) {
-                    uint32_t h16[4] = {xnib4[tokl], xnib4[TM + tokl], xnib4[2 * TM + tokl], xnib4[3 * TM + tokl]};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        h16[q] = (h16[q] | (h16[q] >> 4)) & 0x00FF00FFu;
-                        h16[q] = (h16[q] | (h16[q] >> 8)) & 0x0000FFFFu;
-                    }
                     const float2* gq = xml + tokl;              // tile_combine16 (common.h), streamed from LDS in two sweeps
                     float M_ = -INFINITY;
 #pragma unroll
@@ -354,9 +372,11 @@ __global__ __launch_bounds__(512) void gemm_wide_fused_kernel(const GemmArgs p) 
                         wq[q] = (u0.y * __expf(u0.x - M_) + u1.y * __expf(u1.x - M_)) + (u2.y * __expf(u2.x - M_) + u3.y * __expf(u3.x - M_));
                     }
                     const float E_ = (wq[0] + wq[1]) + (wq[2] + wq[3]);
-                    p.fs_stats[(size_t)tok * p.tiles_n + cur_n] = make_float4(M_, E_, __uint_as_float(h16[0] | (h16[1] << 16)), __uint_as_float(h16[2] | (h16[3] << 16)));
+                    float4* rec = p.fs_stats + ((size_t)tok * p.tiles_n + cur_n) * FS_REC;
+                    rec[0] = make_float4(M_, E_, 0.f, 0.f);
+                    rec[1] = make_float4(__uint_as_float(xmask[tokl]), __uint_as_float(xmask[TM + tokl]), __uint_as_float(xmask[2 * TM + tokl]), __uint_as_float(xmask[3 * TM + tokl]));
                 }
-                ++nstore;
+                nstore += 2;
             }
         }
         pending = nstore;

@@ -594,7 +594,7 @@ struct GenBufs {
     bf16_t* attc;           // [2*B*n][I]
     // fused sampling (sampling_fused.hip): what the guidance-logits GEMM emits instead of the logits
     float* fs_thr;          // [B*n]
-    float4* fs_stats;       // [B*n][V/256]
+    float4* fs_stats;       // [B*n][V/256][FS_REC]
     float4* fs_cand;        // [B*n][V/256][FS_SLOT]
     void* fs_ws;            // scratch of the bound estimate (k_fused_threshold)
     // on-device per-row fallback of the fused sampler: rows whose bound could not be verified are listed by the finishing kernel and finished
@@ -648,7 +648,7 @@ void carve_gen(Carver& c, const mm_transformer* t, int B, int n, int L, int nc, 
     const bool fs = t->d.logits_wcov && (t->d.dim_out % 256) == 0 && (D % 64) == 0;
     const size_t NT = fs ? (size_t)t->d.dim_out / 256 : 0;
     g.fs_thr = c.take<float>(fs ? (size_t)B * n : 0);
-    g.fs_stats = c.take<float4>((size_t)B * n * NT);
+    g.fs_stats = c.take<float4>((size_t)B * n * NT * FS_REC);
     g.fs_cand = c.take<float4>((size_t)B * n * NT * FS_SLOT);
     g.fs_ws = c.take<unsigned char>(fs ? k_fused_threshold_ws_bytes(B * n, D) : 0);
     g.fb_rows = c.take<int32_t>(fs ? FB_CAP : 0);

@@ -2,8 +2,8 @@
 //
 // The guidance-logits GEMM (gemm_cfg.hip) does not write its [R][V] fp32 output any more.  While a 256-column tile of a token row is
 // on its way out of the accumulators (4 consecutive values per lane) the epilogue emits, per (row, tile):
-//     stats  {tile max, sum exp(x - tile max), 64-bit mask of the lanes it kept}                            16 B
-//     cand   the 4 values of every lane whose largest value reaches thr_lo[row], lane-compacted              16 B per kept lane (~45 % of them)
+//     stats  {tile max, sum exp(x - tile max), -, -} + the 128-bit mask of the kept granules                32 B
+//     cand   the 2 values of every 2-column granule whose larger value reaches thr_lo[row], compacted        8 B per kept granule (~23 % of them)
 // thr_lo[row] is a LOWER bound estimate of the row's k-th largest logit, known BEFORE the GEMM runs: a row's logits over the vocabulary
 // are <e, w_v> for the row's (guidance-combined) embedding e, so their mean and variance are <e, mean_w> and e' Cov_w e with the weight
 // statistics packed once per model (k_fused_threshold: one small MFMA GEMM against Cov_w); thr_lo = mean + (z_k - margin) sigma.
@@ -118,7 +118,7 @@ struct FusedShared {
     uint32_t cand[CANDF];
     float redf[FW], redx[FW];
     int redi[FW];
-    unsigned long long masks[256];
+    uint4 masks[256];                           // per piece: the 128-bit mask of its kept granules (common.h fs_pos)
     int wcnt[FW];
     int ncand;
     uint32_t thr_key;
@@ -135,9 +135,9 @@ __global__ __launch_bounds__(FT, 2) void sample_fused_kernel(const FusedSampleAr
         // ---- tile statistics -> row max, softmax denominator; the kept-lane masks are parked in LDS for the gather
         float tmax = -INFINITY, tsum = 0.f;
         if (tid < NT) {
-            const float4 st = p.stats[(size_t)row * NT + tid];
+            const float4 st = p.stats[((size_t)row * NT + tid) * FS_REC], mk = p.stats[((size_t)row * NT + tid) * FS_REC + 1];
             tmax = st.x; tsum = st.y;
-            S.masks[tid] = (unsigned long long)__float_as_uint(st.z) | ((unsigned long long)__float_as_uint(st.w) << 32);
+            S.masks[tid] = make_uint4(__float_as_uint(mk.x), __float_as_uint(mk.y), __float_as_uint(mk.z), __float_as_uint(mk.w));
         }
         const float wm = wave_max(tmax);
         if (lane == 0) S.redf[wid] = wm;
@@ -161,16 +161,22 @@ __global__ __launch_bounds__(FT, 2) void sample_fused_kernel(const FusedSampleAr
         int wcount = 0;                                           // wave-uniform
         for (int t0 = wid; t0 < NT; t0 += FW * GU) {
             float4 v[GU];
-            bool mine[GU];
+            uint32_t mine_bits = 0;                               // bits 2 u + h: granule 2 lane + h (columns 4 lane + 2 h, + 1) of tile u was kept (packed: VGPR budget of 128 for two workgroups per CU)
 #pragma unroll
             for (int u = 0; u < GU; ++u) {
                 const int t_ = t0 + u * FW;
-                mine[u] = false;
                 v[u] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
                 if (t_ < NT) {
-                    const unsigned long long mask = S.masks[t_];      // bit j = granule j (columns 4 j .. 4 j + 3 of the piece) was kept; position in the slot: common.h fs_slot_index
-                    mine[u] = (mask >> lane) & 1ull;
-                    if (mine[u]) v[u] = p.cand[((size_t)row * NT + t_) * FS_SLOT + fs_slot_index(mask, lane)];
+                    const uint4 mask = S.masks[t_];                // word q = lane >> 4, bits 2 (lane & 15) + h; position in the slot: common.h fs_pos
+                    const int q = lane >> 4, gq = 2 * (lane & 15);
+                    const uint32_t mq = q == 0 ? mask.x : (q == 1 ? mask.y : (q == 2 ? mask.z : mask.w));
+                    const uint32_t mu = (mq >> gq) & 3u;
+                    mine_bits |= mu << (2 * u);
+                    if (mu) {
+                        const float2* slot = reinterpret_cast<const float2*>(p.cand + ((size_t)row * NT + t_) * FS_SLOT) + fs_pos(mask, q, gq);
+                        if (mu & 1u) { const float2 a = slot[0]; v[u].x = a.x; v[u].y = a.y; }
+                        if (mu & 2u) { const float2 a = slot[mu & 1u]; v[u].z = a.x; v[u].w = a.y; }
+                    }
                 }
             }
 #pragma unroll
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(FT, 2) void sample_fused_kernel(const FusedSampleAr
                 const float xv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const bool kp = mine[u] && xv[i] >= lo;
+                    const bool kp = ((mine_bits >> (2 * u + (i >> 1))) & 1u) && xv[i] >= lo;
                     const unsigned long long bal = __ballot(kp);
                     const int idx = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, (uint32_t)wcount));
                     if (kp && idx < WSL) {

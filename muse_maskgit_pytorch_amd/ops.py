@@ -588,9 +588,10 @@ FUSED_SLOT = 64
 
 
 def fused_buffers(R, V, device):
-    """caller-owned scratch of the fused sampling path for R rows of a V-entry vocabulary (include/muse_hip.h, mm_fused_*)"""
+    """caller-owned scratch of the fused sampling path for R rows of a V-entry vocabulary (include/muse_hip.h, mm_fused_*): per (row, 256-column piece) a
+    record of 2 float4s ({max, sum exp, -, -} and the 128-bit mask of the kept 2-column granules) and a slot of up to 128 float2 candidates"""
     NT = V // 256
-    return dict(stats=torch.empty(R, NT, 4, dtype=torch.float32, device=device), cand=torch.empty(R, NT, FUSED_SLOT, 4, dtype=torch.float32, device=device),
+    return dict(stats=torch.empty(R, NT, 8, dtype=torch.float32, device=device), cand=torch.empty(R, NT, FUSED_SLOT, 4, dtype=torch.float32, device=device),
                 fail=torch.zeros(1, dtype=torch.int32, device=device))
 
 

@@ -68,13 +68,13 @@ def test_fused_sample_hot_tile_and_failure_paths():
 
 
 def _valid_slots(stats):
-    """which of the 64 slot entries of every (row, piece) hold a candidate: the slot is four sub-slots of 16 (one per 64-column quarter), sub-slot q
-    holds as many entries as quarter q's 16 mask bits have set (common.h fs_slot_index)"""
-    m = stats[..., 2:].contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF           # [R, NT, 2]: mask bits 0..31, 32..63
-    q16 = torch.stack([m[..., 0] & 0xFFFF, m[..., 0] >> 16, m[..., 1] & 0xFFFF, m[..., 1] >> 16], dim=-1)      # [R, NT, 4]
-    cnt = sum(((q16 >> b) & 1) for b in range(16))                                            # kept granules per quarter
-    pos = torch.arange(ops.FUSED_SLOT, device=stats.device)
-    return (pos[None, None, :] & 15) < cnt[..., (pos >> 4)]
+    """which of the 128 float2 entries of every (row, piece) slot hold a candidate, as a mask over the slot viewed as [.., 64, 4] floats: the slot is one
+    compacted list, as long as the record's 128-bit mask has bits set (common.h fs_pos)"""
+    m = stats[..., 4:].contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF           # [R, NT, 4]: the four quarters' mask words
+    cnt = sum(((m >> b) & 1) for b in range(32)).sum(-1)                                      # kept granules of the piece
+    pos = torch.arange(2 * ops.FUSED_SLOT, device=stats.device)                               # float2 entry index
+    ok2 = pos[None, None, :] < cnt[..., None]                                                 # [R, NT, 128]
+    return ok2.reshape(*ok2.shape[:2], ops.FUSED_SLOT, 2).repeat_interleave(2, dim=-1)        # [R, NT, 64, 4]: two floats per entry
 
 
 @pytest.mark.parametrize("M", [4608, 5140, 129, 135, 391, 3])      # 135 = B 1 x k 135 (ADVICE r2: edge tiles with 1..7 rows; waves without a piece must not count a statistics store)

@@ -192,13 +192,14 @@ int main(int argc, char** argv) {
         void* x = dev_bf16((size_t)R * D, 1.f); void* w = dev_bf16((size_t)V * D, 0.02f);
         // logits ~ N(0, sigma^2), sigma = sqrt(D) * 0.02; thr_lo at the 12 % quantile + margin as in the decode loop
         const float sigma = sqrtf((float)D) * 0.02f;
-        std::vector<float> th(R, 1.17f * sigma);
+        const char* thr_env = getenv("MM_THR");      // bound in sigmas (default: the decode loop's 12 % quantile); larger = fewer candidates (rows then fail the count check: gather-only timing)
+        std::vector<float> th(R, (thr_env ? (float)atof(thr_env) : 1.17f) * sigma);
         float* thr; CK(hipMalloc(&thr, R * 4)); CK(hipMemcpy(thr, th.data(), R * 4, hipMemcpyHostToDevice));
         void *stats, *cand;
-        CK(hipMalloc(&stats, (size_t)R * (V / 256) * 16)); CK(hipMalloc(&cand, (size_t)R * (V / 256) * MM_FUSED_SLOT * 16));
+        CK(hipMalloc(&stats, (size_t)R * (V / 256) * 32)); CK(hipMalloc(&cand, (size_t)R * (V / 256) * MM_FUSED_SLOT * 16));
         if (want("logits")) {
             const double us = time_us([&] { MK(mm_gemm_cfg_logits_fused(nullptr, x, nullptr, D, w, D, R, V, D, 3.f, thr, stats, cand)); });
-            report("logits", us, 2.0 * R * (double)V * D, checksum(stats, (size_t)R * (V / 256) * 16));
+            report("logits", us, 2.0 * R * (double)V * D, checksum(stats, (size_t)R * (V / 256) * 32));
         }
         if (want("sample")) {
             MK(mm_gemm_cfg_logits_fused(nullptr, x, nullptr, D, w, D, R, V, D, 3.f, thr, stats, cand));
