@@ -24,12 +24,19 @@ class IdsGather:
         from . import _lib as L
         self.L, self.C = L, C
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
-        uid = (C.c_ubyte * 128)()
-        if self.rank == 0:
-            L.check(L.lib().mm_comm_unique_id(uid), 'mm_comm_unique_id')
-        box = [bytes(uid)]
-        dist.broadcast_object_list(box, src=0, group=group)
         self.ptr = C.c_void_p()
+        uid = (C.c_ubyte * 128)()
+        box = [None]
+        if self.rank == 0:          # a failure here must still reach the broadcast below, or the other ranks would wait in it forever
+            try:
+                L.check(L.lib().mm_comm_unique_id(uid), 'mm_comm_unique_id')
+                box = [bytes(uid)]
+            except Exception as e:
+                box = [None]
+                self._err0 = repr(e)
+        dist.broadcast_object_list(box, src=0, group=group)
+        if box[0] is None:
+            raise L.MuseHipError('mm_comm_unique_id failed on rank 0' + (': ' + getattr(self, '_err0', '') if self.rank == 0 else ''))
         L.check(L.lib().mm_comm_create(box[0], self.rank, self.world, C.byref(self.ptr)), 'mm_comm_create')
         self.ws = None
 
@@ -69,6 +76,13 @@ def allgather_ids(ids, dist, group=None):
             except Exception as e:      # a collective, not compute: torch.distributed's RCCL all-gather is an equivalent transport (recorded in .last_transport)
                 _GATHERS[key] = None
                 allgather_ids.last_error = repr(e)
+            # every rank must take the SAME transport (a rank whose communicator failed next to ranks whose did not would wait in a different
+            # collective forever): agree through the group that exists anyway
+            ok = torch.tensor([1 if _GATHERS[key] is not None else 0], dtype=torch.int32, device=ids.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok.item()) == 0 and _GATHERS[key] is not None:
+                _GATHERS[key] = None
+                allgather_ids.last_error = 'another rank could not create the library-owned communicator'
         if _GATHERS[key] is not None:
             allgather_ids.last_transport = 'mm_allgather_ids (library-owned RCCL communicator)'
             return _GATHERS[key](ids)
