@@ -5,8 +5,9 @@
 // (256 x 256 x 32 with three stages and a hand-placed software pipeline: 1970 cycles per 1031-cycle step; the fp8 kernel's plain
 // two-stage loop with 64 KiB per step: 0.33 us lost per 0.71 us of MFMAs).  So this kernel simply maximises the work between two barriers that fits
 // the LDS: two stages of (256 + 256) rows x 128 bytes = 128 KiB, 64 MFMAs per wave and step, ONE barrier per step, the next step's LDS-DMA issued
-// right behind it, fragments read and MFMAs issued in program order for the compiler to interleave -- the structure of gemm_fp8.hip with the bf16
-// instruction.  Non-persistent: a tile's epilogue goes through the (then free) stages so that every global store is 16 bytes of one output row per lane.
+// behind the first MFMA sub-step, fragments read and MFMAs issued in program order for the compiler to interleave -- the structure of gemm_fp8.hip with
+// the bf16 instruction.  Persistent when the k-step count is even: the next tile's first step is requested during the last step of the current one into
+// the stage that step does not read; the epilogue goes through the other stage so that every global store is 16 bytes of one output row per lane.
 // Accumulation order per output element: k ascending in chunks of 32, one MFMA each -- the order of every GEMM kernel of the family: bit-identical
 // results (and bit-identical LayerNorm partial sums: common.h ln_partial_row64 over the same bf16 values).
 #include "common.h"
