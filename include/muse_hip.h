@@ -261,7 +261,9 @@ int mm_philox_uniform(mm_stream_t stream, uint64_t seed, uint64_t row_offset, ui
  * Kp = TH*TW*Cin rounded up to 64 (zero padded).  Virtual output grid Hv x Wv per image; input pixel of tap
  * (ty,tx) = (y*stride + ty + off_y, x*stride + tx + off_x), zero outside.  Output pixel (y*os+py, x*os+px) of an
  * Hout x Wout image -> ConvTranspose2d(4,2,1) is four calls with os=2.  Epilogue: + bias[Cout],
- * LeakyReLU(0.1) if act, + resid (bf16, same shape as out).  out_nchw_f32 != 0 writes fp32 [B][Cout][Hout][Wout]. */
+ * LeakyReLU(0.1) if act, + resid (bf16, same shape as out).  out_nchw_f32 == 1 writes fp32 [B][Cout][Hout][Wout]; == 2 writes fp32 NHWC (Cout % 4 == 0)
+ * and takes resid as fp32 NHWC -- the precision tier's form: `in` holds P bf16 term segments per pixel (Cin = P x channels, mm_split_rows) and w the matching
+ * per-tap segment pack, so the product is exact to fp32. */
 int mm_conv2d_nhwc(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
                    int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
                    int Hout, int Wout, const float* bias, int act, const void* resid, void* out, int out_nchw_f32);

@@ -413,6 +413,7 @@ int mm_conv2d_nhwc(mm_stream_t stream, const void* in, int B, int Hin, int Win, 
     CHK_ALIGN16(in, "in"); CHK_ALIGN16(w, "w"); CHK_ALIGN16(out, "out");
     if (TH <= 0 || TW <= 0 || Cin <= 0 || Cout <= 0 || Hv <= 0 || Wv <= 0) return mm_set_error(MM_ERR_SHAPE, "conv: bad geometry");
     if (!out_nchw_f32 && (Cout % 8)) return mm_set_error(MM_ERR_SHAPE, "conv: NHWC bf16 output needs Cout % 8 == 0");
+    if (out_nchw_f32 == 2 && (Cout % 4)) return mm_set_error(MM_ERR_SHAPE, "conv: NHWC fp32 output needs Cout % 4 == 0");
     GemmArgs a;
     memset(&a, 0, sizeof(a));
     a.mode = MODE_CONV;
@@ -422,9 +423,11 @@ int mm_conv2d_nhwc(mm_stream_t stream, const void* in, int B, int Hin, int Win, 
     a.M = B * Hv * Wv; a.X = (const bf16_t*)in; a.ldx = Cin;
     a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.TW = TW; a.stride = stride; a.off_y = off_y; a.off_x = off_x;
     a.Hv = Hv; a.Wv = Wv; a.os = os; a.py = py; a.px = px; a.Hout = Hout; a.Wout = Wout;
-    a.out = out; a.ldc = Cout; a.out_kind = out_nchw_f32 ? OUT_NCHW_F32 : OUT_BF16;
+    a.out = out; a.ldc = Cout; a.out_kind = out_nchw_f32 == 2 ? OUT_F32 : (out_nchw_f32 ? OUT_NCHW_F32 : OUT_BF16);
     a.bias = bias; a.act = act ? ACT_LEAKY : ACT_NONE;
-    a.resid_bf16 = (const bf16_t*)resid; a.ldr = Cout;
+    if (out_nchw_f32 == 2) a.resid_f32 = (const float*)resid;      // fp32 NHWC in and out (the precision tier's convolutions: bf16 term segments in, fp32 out)
+    else a.resid_bf16 = (const bf16_t*)resid;
+    a.ldr = Cout;
     return mm_gemm_launch(a, (hipStream_t)stream);
 }
 

@@ -759,14 +759,14 @@ class MaskGit(nn.Module):
 
     def set_precision(self, precision):
         """'bf16' | 'bf16x3' | 'parity' | 'fp8' for the transformer and the token critic (see Transformer.set_precision); the VAEs take 'bf16' or their
-        fp32 engine ('parity', also under 'bf16x3': the decoder is outside the decode loop and already meets 1e-3 in bf16, the fp32 engine
-        makes the LFQ encode ids of a super-resolution condition image exact)."""
+        fp32 engine ('parity'); under 'bf16x3' they decode with exact bf16 term products on the bf16 MFMA and encode on the fp32 engine (exact LFQ ids of
+        a super-resolution condition image)."""
         self.transformer.set_precision(precision)
         if isinstance(self.token_critic, Transformer):
             self.token_critic.set_precision(precision)
         for v in (self.vae, self.cond_vae):
             if exists(v):
-                v.set_precision({'bf16x3': 'parity', 'fp8': 'bf16'}.get(precision, precision))      # (the fp8 engine covers the transformer's Linear layers)
+                v.set_precision({'fp8': 'bf16'}.get(precision, precision))      # (the fp8 engine covers the transformer's Linear layers)
         return self
 
     def _mask_counts(self, timesteps, seq_len, device='cpu'):

@@ -183,6 +183,47 @@ def conv(x, w_packed, cout, th, tw, stride=1, off=(0, 0), out_hw=None, os_=1, pa
     return out
 
 
+# ---- 'bf16x3' form of the convolutions (precision tier, decode path): the fp32 NHWC activation is split into P exact bf16 term segments per pixel
+#      (mm_split_rows), the weight is the matching per-tap segment pack, and the product runs on the bf16 MFMA implicit-GEMM kernels with fp32 output:
+#      exact to fp32 accumulation like the transformer's tier (csrc/split.hip), at bf16-MFMA rate x P instead of the 1/16-rate fp32 MFMA.
+_X3 = {'P': 0}          # > 0 while a bf16x3 decode runs (set by vae_decode_*): conv() then takes the split form
+
+
+def _pack_x3(w2d_taps, P):
+    """list of per-tap fp32 [Cout][Cin] matrices -> bf16 [Cout][Kp], k = tap * (P * Cin) + segment * Cin + ci, zero-padded to a multiple of 64"""
+    from . import ops
+    return ops.pad_cols(torch.cat([ops.split_pack_weight(wt.contiguous(), P) for wt in w2d_taps], dim=1), 64)
+
+
+def conv_x3(x, w_taps, cout, th, tw, stride=1, off=(0, 0), out_hw=None, os_=1, parity=(0, 0), full_hw=None, bias=None, act=False, resid=None, out=None,
+            out_nchw=False):
+    from . import ops
+    P = _X3['P']
+    B, H, W, Cin = x.shape
+    xs = ops.split_rows(x.reshape(-1, Cin), P).reshape(B, H, W, P * Cin)
+    Hv, Wv = out_hw if out_hw is not None else (H, W)
+    Hout, Wout = full_hw if full_hw is not None else (Hv * os_, Wv * os_)
+    if out is None:
+        out = torch.empty((B, cout, Hout, Wout) if out_nchw else (B, Hout, Wout, cout), dtype=f32, device=x.device)
+    if out_nchw:
+        assert resid is None
+    L.check(L.lib().mm_conv2d_nhwc(L.stream(), L.ptr(xs), B, H, W, P * Cin, L.ptr(_pack_x3(w_taps, P)), cout, th, tw, stride, off[0], off[1], Hv, Wv, os_,
+                                   parity[0], parity[1], Hout, Wout, L.ptr(bias), int(act), L.ptr(resid), L.ptr(out), 1 if out_nchw else 2), 'mm_conv2d_nhwc')
+    return out
+
+
+def _taps_conv(w):
+    """Conv2d weight [Cout, Cin, TH, TW] -> per-tap fp32 [Cout][Cin] matrices in (ty, tx) order"""
+    w = w.detach().to(f32)
+    return [w[:, :, ty, tx] for ty in range(w.shape[2]) for tx in range(w.shape[3])]
+
+
+def _taps_convT(w):
+    """ConvTranspose2d(4,2,1) weight [Cin, Cout, 4, 4] -> per output parity the four taps' fp32 [Cout][Cin] matrices (the tap algebra of pack_convT)"""
+    w = w.detach().to(f32)
+    return {(py, px): [w[:, :, 3 - py - 2 * ty, 3 - px - 2 * tx].t() for ty in range(2) for tx in range(2)] for py in range(2) for px in range(2)}
+
+
 def pack_conv(w):
     """Conv2d weight [Cout, Cin, TH, TW] -> fp32 [Cout, TH*TW*Cin], k = (ty*TW + tx)*Cin + ci"""
     return w.detach().to(f32).permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
@@ -216,6 +257,8 @@ def _groupnorm(x, gn, act=False):
 
 def _conv_module(x, c, **kw):
     k = c.kernel_size[0]
+    if _X3['P']:
+        return conv_x3(x, _taps_conv(c.weight), c.out_channels, k, k, 1, (-(k // 2), -(k // 2)), bias=_w(c.bias), **kw)
     return conv(x, pack_conv(c.weight), c.out_channels, k, k, 1, (-(k // 2), -(k // 2)), bias=_w(c.bias), **kw)
 
 
@@ -235,6 +278,11 @@ def _vae_layer(x, m, first=False, last=False):
         ct = m[0]
         B, H, W, _ = x.shape
         out = torch.empty(B, 2 * H, 2 * W, ct.out_channels, dtype=f32, device=x.device)
+        if _X3['P']:
+            for (py, px), taps in _taps_convT(ct.weight).items():
+                conv_x3(x, taps, ct.out_channels, 2, 2, 1, (py - 1, px - 1), out_hw=(H, W), os_=2, parity=(py, px), full_hw=(2 * H, 2 * W), bias=_w(ct.bias),
+                        act=True, out=out)
+            return out
         for (py, px), wp in pack_convT(ct.weight).items():
             conv(x, wp, ct.out_channels, 2, 2, 1, (py - 1, px - 1), out_hw=(H, W), os_=2, parity=(py, px), full_hw=(2 * H, 2 * W), bias=_w(ct.bias), act=True,
                  out=out)
@@ -263,10 +311,15 @@ def _nhwc_to_nchw(x):
 
 
 def vae_decode_nhwc(vae, x):
-    """ResnetEncDec.decode (vae.py:246-249): NHWC fp32 feature map -> NCHW fp32 image"""
+    """ResnetEncDec.decode (vae.py:246-249): NHWC fp32 feature map -> NCHW fp32 image.  vae.precision 'bf16x3': the convolutions take the split form above
+    (P from the checkpoint: 3 when every convolution weight is bf16-representable, else 5 / 6), everything else is the fp32 engine's."""
     dec = list(vae.enc_dec.decoders)
-    for i, m in enumerate(dec):
-        x = _vae_layer(x, m, last=(i == len(dec) - 1))
+    _X3['P'] = vae.x3_products() if getattr(vae, 'precision', 'bf16') == 'bf16x3' else 0
+    try:
+        for i, m in enumerate(dec):
+            x = _vae_layer(x, m, last=(i == len(dec) - 1))
+    finally:
+        _X3['P'] = 0
     return x
 
 

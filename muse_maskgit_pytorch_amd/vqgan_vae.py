@@ -204,11 +204,21 @@ class VQGanVAE(nn.Module):
 
     def set_precision(self, precision):
         """'bf16' (default): NHWC bf16 activations, bf16 MFMA convolutions.  'parity': NHWC fp32 activations, fp32 MFMA convolutions, the
-        reference's layer sequence one to one (parity.py / csrc/parity.hip) -- pixels within 1e-3 and LFQ ids equal to the fp32 reference."""
-        if precision not in ('bf16', 'parity'):
-            raise ValueError(f"precision must be 'bf16' or 'parity', got {precision!r}")
+        reference's layer sequence one to one (parity.py / csrc/parity.hip) -- pixels within 1e-3 and LFQ ids equal to the fp32 reference.
+        'bf16x3': the precision tier's decode -- the fp32 engine's layer sequence with every convolution run as exact bf16 term products on the bf16 MFMA
+        (parity.conv_x3): the same 1e-3 bar at a fraction of the fp32-MFMA time; encode stays on the fp32 engine."""
+        if precision not in ('bf16', 'parity', 'bf16x3'):
+            raise ValueError(f"precision must be 'bf16', 'parity' or 'bf16x3', got {precision!r}")
         self.precision = precision
         return self
+
+    def x3_products(self):
+        """term pairs per product of the 'bf16x3' decode for THIS checkpoint (3 when every decoder convolution weight is bf16-representable, else 5 / 6)"""
+        key = self._pack_key()
+        if getattr(self, '_x3_terms', None) is None or self._x3_terms[0] != key:
+            ws = [m.weight for m in self.enc_dec.decoders.modules() if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d))]
+            self._x3_terms = (key, max(ops.weight_terms(w.detach()) for w in ws))
+        return ops.products_for_terms(self._x3_terms[1])
 
     # ---- packed (bf16, kernel layout) weights, rebuilt when parameters change
     def _pack_key(self):
@@ -363,7 +373,7 @@ class VQGanVAE(nn.Module):
     @torch.no_grad()
     def encode(self, fmap):
         """vqgan_vae.py:422-425: image (B,C,H,W) fp32 -> (quantized fmap (B,C',h,w) fp32, ids (B,h,w) int64, aux loss 0)."""
-        if self.precision == 'parity' and self.lookup_free_quantization:
+        if self.precision in ('parity', 'bf16x3') and self.lookup_free_quantization:
             from . import parity
             return parity.vae_encode(self, fmap)
         P = self._pack()
@@ -398,7 +408,7 @@ class VQGanVAE(nn.Module):
     @torch.no_grad()
     def decode_from_ids(self, ids):
         """vqgan_vae.py:427-438: ids (B,h,w) int64 -> image (B,C,H,W) fp32 (unclamped)."""
-        if self.precision == 'parity' and self.lookup_free_quantization:
+        if self.precision in ('parity', 'bf16x3') and self.lookup_free_quantization:
             from . import parity
             return parity.vae_decode_from_ids(self, ids)
         P = self._pack()
@@ -420,7 +430,7 @@ class VQGanVAE(nn.Module):
     @torch.no_grad()
     def decode(self, fmap):
         """vqgan_vae.py:440-441: fmap (B,C,h,w) fp32 -> image."""
-        if self.precision == 'parity':
+        if self.precision in ('parity', 'bf16x3'):
             from . import parity
             return parity.vae_decode(self, fmap)
         x = fmap.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
