@@ -183,7 +183,7 @@ def reference_flops_per_generate(tr, B, n, m_text, nc, timesteps):
 
 def parity_tier_leg(mg, tr, step, args, B, T, n, nc, image_size, counts, lib, bf16_s_per_step):
     """The same step through precision 'bf16x3' (csrc/split.hip): every GEMM activation as its exact three-term bf16 split, multiplied as term
-    products on the bf16 MFMA kernels of the main line, fp32 everywhere else, attention on the fp32 MFMA, VAE decode on the fp32 engine -- the
+    products on the bf16 MFMA kernels of the main line, fp32 everywhere else, attention on the fp32 MFMA, VAE decode with its convolutions as exact bf16 term products on the bf16 MFMA (pixels 3e-8 from the reference at this size) -- the
     tier that holds logits within 1e-3 of the reference's fp32 run and reproduces its ids bit for bit (tests/test_gpu_base_size.py).  Timed
     with the checkpoint the main line effectively multiplies by: the bf16 engine rounds every Linear weight to bf16 when it packs, so the
     parameters are rounded to bf16 first -- a bf16-representable checkpoint, 3 term products per GEMM -- and, for one step, with the raw fp32
@@ -229,7 +229,7 @@ def parity_tier_leg(mg, tr, step, args, B, T, n, nc, image_size, counts, lib, bf
             'x_bf16_engine_time': sec / bf16_s_per_step, 'term_products': P,
             'checkpoint': 'the main line\'s parameters rounded to bf16 (what the bf16 engine multiplies by): bf16-representable weights need 3 term products',
             'tolerance': 'logits <= 1e-3 absolute and ids bit-exact against the reference fp32 run at this size (tests/test_gpu_base_size.py, precision bf16x3); '
-                         'VAE decode on the fp32 engine',
+                         'VAE decode with its convolutions as exact bf16 term products on the bf16 MFMA (pixels 3e-8 from the reference at this size)',
             'roofline': {'kernel': 'gemm_wide_fused_kernel on K = products x dim (term products of to_logits on the guidance-mixed embeddings)', 'bound': 'mfma',
                          'achieved': g_flops / (g_ms * 1e-3) / 1e12 if g_ms else None, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': (g_flops / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if g_ms else None,
