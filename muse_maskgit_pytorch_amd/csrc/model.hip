@@ -655,6 +655,10 @@ void carve_gen(Carver& c, const mm_transformer* t, int B, int n, int L, int nc, 
     g.fb_cnt = c.take<int32_t>(fs ? FB_STEPS : 0);
     g.fb_x = c.take<bf16_t>(fs ? (size_t)FB_CAP * D * seg : 0);
     g.fb_logits = c.take<float>(fs ? (size_t)FB_CAP * t->d.dim_out : 0);
+    if (!fs) {      // Carver::take(0) still hands out the (non-NULL) cursor: nothing was reserved, so nothing may be written through these
+        g.fs_thr = nullptr; g.fs_stats = nullptr; g.fs_cand = nullptr; g.fs_ws = nullptr;
+        g.fb_rows = nullptr; g.fb_cnt = nullptr; g.fb_x = nullptr; g.fb_logits = nullptr;
+    }
     g.ctx_ws_bytes = mm_context_workspace_bytes(t, B, L);
     g.ctx_ws = c.take<unsigned char>(g.ctx_ws_bytes);
     g.sce = c.take<float>(t->d.self_cond ? (size_t)B * n * D : 0);

@@ -372,18 +372,23 @@ class Transformer(nn.Module):
     def invalidate_packed_weights(self):
         """Drop the packed device copies of the weights (rebuilt on the next call).  Needed only after edits the version counters cannot
         see (`param.data.copy_(...)`, raw pointer writes); `load_state_dict`, `.to()`, optimizer steps and in-place ops are detected."""
-        self._handle, self._handle_key, self._handle_f8 = None, None, None
-        self._handle_x3, self._handle_x3_key = None, None
+        self._drop_packed()
         return self
 
-    def _apply(self, fn, *args, **kwargs):
-        self._handle, self._handle_key, self._handle_f8 = None, None, None
+    def _drop_packed(self):
+        """every cache derived from the parameter VALUES: the three engines' handles and the term count of the precision tier (keyed on
+        `_pack_key()`, which by its own docstring cannot see `.data` surgery -- so an explicit invalidation must not leave it behind)"""
+        self._handle, self._handle_key = None, None
+        self._handle_f8, self._handle_f8_key = None, None
         self._handle_x3, self._handle_x3_key = None, None
+        self._x3_terms = None
+
+    def _apply(self, fn, *args, **kwargs):
+        self._drop_packed()
         return super()._apply(fn, *args, **kwargs)
 
     def load_state_dict(self, *args, **kwargs):
-        self._handle, self._handle_key, self._handle_f8 = None, None, None
-        self._handle_x3, self._handle_x3_key = None, None
+        self._drop_packed()
         return super().load_state_dict(*args, **kwargs)
 
     def set_precision(self, precision):
@@ -499,7 +504,7 @@ class Transformer(nn.Module):
             w1, w2 = ff[1].weight.detach(), ff[4].weight.detach()
             F = w2.shape[1]
             Fp = (F + 127) // 128 * 128
-            w1q, w1s = q(ops.pack_w1_geglu(w1, Fp).float())                      # the bf16 engine's GEGLU interleave, quantised row by row
+            w1q, w1s = q(ops.pack_w1_geglu(w1.float(), Fp, dtype=torch.float32))   # the bf16 engine's GEGLU interleave as a row permutation of the fp32 weight, quantised row by row
             w2p = torch.zeros(w2.shape[0], Fp, dtype=torch.float32, device=w2.device)
             w2p[:, :F] = w2.float()
             w2q, w2s = q(w2p)

@@ -86,13 +86,14 @@ def geglu_ln(h, F, gamma, beta=None):
     return out
 
 
-def pack_w1_geglu(w1, Fp):
-    """FeedForward's first Linear weight [2F, D] (rows [0,F) = gelu half, [F,2F) = gate half, mmp.py:72-77,85) -> bf16
+def pack_w1_geglu(w1, Fp, dtype=bf16):
+    """FeedForward's first Linear weight [2F, D] (rows [0,F) = gelu half, [F,2F) = gate half, mmp.py:72-77,85) -> `dtype` (bf16; fp32 for
+    the fp8 engine, which quantises the interleaved rows itself: no bf16 rounding in between)
     [2*Fp, D] in the tile order the GEGLU-fused GEMM epilogue expects: per 128-row tile t and wave half w, 32 gelu-half
     rows (output columns 64t+32w .. +31) followed by the 32 gate-half rows of the same columns; columns >= F are zero."""
     F2, D = w1.shape
     F = F2 // 2
-    out = torch.zeros(2 * Fp, D, dtype=bf16, device=w1.device)
+    out = torch.zeros(2 * Fp, D, dtype=dtype, device=w1.device)
     r = torch.arange(2 * Fp, device=w1.device)
     t, rem = r // 128, r % 128
     w, rem2 = rem // 64, rem % 64
@@ -100,7 +101,7 @@ def pack_w1_geglu(w1, Fp):
     col = 64 * t + 32 * w + (rem2 % 32)                 # output column of this packed row
     src = torch.where(is_gate, col + F, col)
     valid = col < F
-    out[valid] = w1[src[valid]].to(bf16)
+    out[valid] = w1[src[valid]].to(dtype)
     return out
 
 

@@ -62,6 +62,28 @@ class IdsGather:
 _GATHERS = {}
 
 
+def _gather_key(dist, group):
+    """identity of a communicator: the group's GLOBAL rank tuple + the process-group object behind it (id() values are recycled once a group is
+    destroyed; torch gives every init_process_group / new_group a fresh object, whose id is only trusted while a weak reference to it is alive)"""
+    import weakref
+    pg = group if group is not None else dist.distributed_c10d._get_default_group()
+    ranks = tuple(dist.get_process_group_ranks(pg))
+    for k in [k for k, ref in _GATHER_REFS.items() if ref() is None]:      # groups that no longer exist: drop (and destroy) their communicators
+        _GATHER_REFS.pop(k, None)
+        _GATHERS.pop(k, None)
+    key = (id(pg), ranks)
+    if key not in _GATHER_REFS:
+        try:
+            _GATHER_REFS[key] = weakref.ref(pg)
+        except TypeError:                                                   # not weak-referenceable: never re-use across groups
+            _GATHERS.pop(key, None)
+            _GATHER_REFS[key] = lambda: True
+    return key
+
+
+_GATHER_REFS = {}
+
+
 def allgather_ids(ids, dist, group=None):
     """ids int64 (b, f, f), same b on every rank -> (world*b, f, f).  Final ids are < codebook_size <= 65536 (the last
     decode step leaves no mask id, mmp.py:584-588), so they travel as int32: 4 bytes/token, 32 KiB per rank at C2.
@@ -69,7 +91,7 @@ def allgather_ids(ids, dist, group=None):
     or ranks sharing one device): torch.distributed through host memory."""
     world = dist.get_world_size(group)
     if dist.get_backend(group) == 'nccl' and os.environ.get('MM_IDS_GATHER', 'rccl') != 'torch':
-        key = id(group) if group is not None else 0
+        key = _gather_key(dist, group)
         if key not in _GATHERS:
             try:
                 _GATHERS[key] = IdsGather(dist, group)

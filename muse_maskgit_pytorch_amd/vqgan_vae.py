@@ -226,16 +226,19 @@ class VQGanVAE(nn.Module):
         return (str(self.device),) + tuple((t.data_ptr(), t._version) for t in ts)
 
     def invalidate_packed_weights(self):
-        """Drop the packed device copies (needed only after `.data` edits the version counters cannot see)."""
+        """Drop the packed device copies and the precision tier's term count (needed only after `.data` edits the version counters cannot see)."""
         self._packed = None
+        self._x3_terms = None
         return self
 
     def _apply(self, fn, *args, **kwargs):
         self._packed = None
+        self._x3_terms = None
         return super()._apply(fn, *args, **kwargs)
 
     def load_state_dict(self, *args, **kwargs):
         self._packed = None
+        self._x3_terms = None
         return super().load_state_dict(*args, **kwargs)
 
     def _pack(self):

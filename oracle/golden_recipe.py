@@ -25,9 +25,11 @@ C5_CFG = dict(num_tokens=8192, seq_len=256, dim=1024, depth=24, dim_head=64, hea
 C5_T, C5_NOISE_SEED, C5_WEIGHT_SEED = 5, 20260926, 3
 
 
-def build_transformer(cls, peaky, cfg=None, seed=None):
+def build_transformer(cls, peaky, cfg=None, seed=None, bf16_weights=True):
     """cls = MaskGitTransformer of the reference or of this package.  Module-default init under WEIGHT_SEED, learned scales / norm gains
-    made non-trivial, optionally peaky logits, everything rounded to bf16-representable fp32 (exactly loadable by the bf16 engine)."""
+    made non-trivial, optionally peaky logits, everything rounded to bf16-representable fp32 (exactly loadable by the bf16 engine) --
+    or, `bf16_weights=False`, left as the GENERAL fp32 values the constructors and the edits produce (what every checkpoint the reference
+    trains looks like, mmp.py:85,88,118-124,233: the `*_fp32.pt` fixtures)."""
     torch.manual_seed(WEIGHT_SEED if seed is None else seed)
     tr = cls(**(BASE_CFG if cfg is None else cfg))
     gen = torch.Generator().manual_seed(EDIT_SEED)
@@ -37,17 +39,19 @@ def build_transformer(cls, peaky, cfg=None, seed=None):
                 p.mul_(1 + 0.2 * torch.randn(p.shape, generator=gen))
         if peaky:
             tr.to_logits.weight.mul_(PEAK)
-        for p in tr.parameters():
-            p.copy_(p.to(torch.bfloat16).float())
+        if bf16_weights:
+            for p in tr.parameters():
+                p.copy_(p.to(torch.bfloat16).float())
     return tr.eval()
 
 
-def build_vae(cls):
+def build_vae(cls, bf16_weights=True):
     torch.manual_seed(VAE_SEED)
     vae = cls(**VAE_CFG)
-    with torch.no_grad():
-        for p in vae.parameters():
-            p.copy_(p.to(torch.bfloat16).float())
+    if bf16_weights:
+        with torch.no_grad():
+            for p in vae.parameters():
+                p.copy_(p.to(torch.bfloat16).float())
     return vae.eval()
 
 

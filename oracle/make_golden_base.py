@@ -4,6 +4,9 @@ generate traces ... base (T=18, B=2)").  Run in the build container only:   pyth
 
 The checkpoint (103 M + 325 M parameters) and the noise (18 x 2 x 256 x 65536 uniforms) are NOT stored: oracle/golden_recipe.py rebuilds
 both from seeds, here with the reference's classes and on the GPU box with this package's; their checksums are stored and asserted.
+`--fp32` writes tests/golden/base_c2_fp32.pt instead: the same recipe WITHOUT the rounding of the parameters to bf16 -- general fp32 weights, what
+every checkpoint the reference initialises / trains holds (mmp.py:85,88,118-124,233) -- so that the fp32-grade engines ('parity', 'bf16x3'
+with all six term products) are compared with the reference's outputs on weights that are NOT bf16-representable.
 Stored: the inputs' checksums, logits at 8 full rows + every 128th vocabulary column of all 512 rows (cond / null / guidance-combined), the
 final-LayerNorm embed, per-step ids and scores of the 18-step decode and its final ids, decoded pixels (strided + one full crop), LFQ
 encode ids and the pre-sign projections.
@@ -19,7 +22,8 @@ sys.path.insert(0, HERE)
 import golden_recipe as R  # noqa: E402
 from reference_harness import reference_modules  # noqa: E402
 
-OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden', 'base_c2.pt')
+FP32 = '--fp32' in sys.argv
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden', 'base_c2_fp32.pt' if FP32 else 'base_c2.pt')
 FULL_ROWS = [0, 77, 255, 256, 300, 301, 448, 511]      # flat (b * n + pos) rows stored with all 65536 logits
 COL_STRIDE = 128
 
@@ -29,11 +33,11 @@ def main():
     pkg, mmp, vaemod, att = reference_modules()
     inp = R.inputs()
     ids, te = inp['ids'], inp['text_embeds']
-    out = dict(recipe=dict(B=R.B, N=R.N, L=R.L, T=R.T, peak=R.PEAK), full_rows=FULL_ROWS, col_stride=COL_STRIDE,
+    out = dict(recipe=dict(B=R.B, N=R.N, L=R.L, T=R.T, peak=R.PEAK, bf16_weights=not FP32), full_rows=FULL_ROWS, col_stride=COL_STRIDE,
                input_checksum={k: R.checksum(v.float()) for k, v in inp.items()})
 
     # ---------------------------------------------------------------- Transformer.forward (mmp.py:279-335) + guidance (:240-259), plain init
-    tr = R.build_transformer(pkg.MaskGitTransformer, peaky=False)
+    tr = R.build_transformer(pkg.MaskGitTransformer, peaky=False, bf16_weights=not FP32)
     out['weight_checksum'] = R.state_checksum(tr)
     with torch.no_grad():
         lc, emb = tr(ids, text_embeds=te, cond_drop_prob=0., return_embed=True)
@@ -49,7 +53,7 @@ def main():
     del lc, ln, sc
 
     # ---------------------------------------------------------------- VQGanVAE decode / encode at dim 256 (vqgan_vae.py:422-441)
-    vae = R.build_vae(pkg.VQGanVAE)
+    vae = R.build_vae(pkg.VQGanVAE, bf16_weights=not FP32)
     vae_eval = vae.copy_for_eval()
     out['vae_weight_checksum'] = R.state_checksum(vae_eval)
     with torch.no_grad():
@@ -63,8 +67,8 @@ def main():
 
     # ---------------------------------------------------------------- MaskGit.generate (mmp.py:491-621), peaky logits, 18 steps
     with torch.no_grad():
-        tr.to_logits.weight.mul_(R.PEAK)      # == build_transformer(peaky=True): scaling a bf16 value by 8 is exact
-    chk = R.state_checksum(R.build_transformer(pkg.MaskGitTransformer, peaky=True))
+        tr.to_logits.weight.mul_(R.PEAK)      # == build_transformer(peaky=True): scaling by 8 is exact (bf16-representable or not)
+    chk = R.state_checksum(R.build_transformer(pkg.MaskGitTransformer, peaky=True, bf16_weights=not FP32))
     assert chk == R.state_checksum(tr)
     out['weight_checksum_peaky'] = chk
     mg = pkg.MaskGit(vae=vae, transformer=tr, image_size=256)

@@ -5,6 +5,11 @@ operand rounded to the sum of `terms` bf16 values (terms = 2: x ~ h + l, 16-17 s
 reports the agreement with the reference run.  The fixture's weights are bf16-representable, so no weight-side split enters; the flag
 --wsplit rounds an fp32-perturbed copy of the weights to 2 bf16 terms as well and drops the lo*lo product (what the general 3-product form does).
 Attention (QK^T, softmax, PV) stays fp32, as in the tier under study.     python tools/split_precision_study.py --terms 2
+
+Round 4: `--fixture base_c2_fp32.pt` runs the study on the GENERAL fp32 checkpoint (weights split as well), `--fmt f16` splits into fp16 terms
+(11 significand bits each: two terms carry 22 bits) with `--wterms` weight terms and the term pairs i + j <= `--order` kept, `--ftz` flushes fp16
+subnormal terms (what a matrix pipe without fp16 denormal support would do), `--wscale` multiplies each weight matrix by a power of two before
+the split (and the product by its inverse).       python tools/split_precision_study.py --fixture base_c2_fp32.pt --fmt f16 --terms 2 --wterms 2 --order 1
 """
 import argparse
 import os
@@ -33,22 +38,54 @@ def split(t, terms):
     return acc
 
 
+def term_list(t, terms, fmt, ftz=False):
+    """t as a list of `terms` fp32 tensors holding its successive bf16 / fp16 terms"""
+    dt = torch.bfloat16 if fmt == 'bf16' else torch.float16
+    out, r = [], t
+    for _ in range(terms):
+        h = r.to(dt).float()
+        if ftz and fmt == 'f16':
+            h = torch.where(h.abs() < 2.0 ** -14, torch.zeros_like(h), h)
+        out.append(h)
+        r = r - h
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--terms', type=int, default=2)
     ap.add_argument('--steps', type=int, default=R.T)
+    ap.add_argument('--fixture', default='base_c2.pt')
+    ap.add_argument('--fmt', default='bf16', choices=['bf16', 'f16'])
+    ap.add_argument('--wterms', type=int, default=0, help='weight terms (0: weights as they are)')
+    ap.add_argument('--order', type=int, default=2, help='keep the term pairs with i + j <= order')
+    ap.add_argument('--ftz', action='store_true')
+    ap.add_argument('--wscale', type=float, default=1.0)
     args = ap.parse_args()
     import muse_maskgit_pytorch_amd as mm
-    g = torch.load(os.path.join(ROOT, 'tests', 'golden', 'base_c2.pt'))
-    tr = R.build_transformer(mm.MaskGitTransformer, peaky=True)
+    g = torch.load(os.path.join(ROOT, 'tests', 'golden', args.fixture))
+    tr = R.build_transformer(mm.MaskGitTransformer, peaky=True, bf16_weights=g['recipe'].get('bf16_weights', True))
     sd = {k: v.detach() for k, v in tr.state_dict().items()}
     inp = R.inputs()
     te = inp['text_embeds']
     rp = lambda t: split(t, args.terms)
     depth, heads = 8, 8
+    wcache = {}
 
     def lin(x, w):
-        return rp(x) @ w.t()
+        if args.wterms <= 0 and args.fmt == 'bf16':
+            return rp(x) @ w.t()
+        key = id(w)
+        if key not in wcache:
+            wcache[key] = [t.t().contiguous() for t in term_list(w * args.wscale, max(args.wterms, 1), args.fmt, args.ftz)] if args.wterms > 0 else [(w * args.wscale).t().contiguous()]
+        xs = term_list(x, args.terms, args.fmt, args.ftz)
+        acc = None
+        for i, xi in enumerate(xs):
+            for j, wj in enumerate(wcache[key]):
+                if i + j <= args.order:
+                    p = xi @ wj
+                    acc = p if acc is None else acc + p
+        return acc / args.wscale
 
     def attn(x, p, context=None, cmask=None):
         b, n, _ = x.shape
@@ -90,6 +127,19 @@ def main():
         e = O.layer_norm(x, sd['transformer_blocks.norm.gamma'], sd['transformer_blocks.norm.beta'])
         return lin(e, sd['to_logits.weight'])
 
+    # forward logits against the reference's recorded ones (plain, not peaky, to_logits: the fixture's unit-scale logits)
+    with torch.no_grad():
+        wl = sd['to_logits.weight']
+        sd['to_logits.weight'] = wl / R.PEAK
+        lc = forward(inp['ids'], False).reshape(R.B * R.N, -1)
+        sd['to_logits.weight'] = wl
+        wcache.clear()
+    fw = g['forward']['logits_cond']
+    e1 = (lc[g['full_rows']] - fw['rows']).abs().max().item()
+    e2 = (lc[:, ::g['col_stride']] - fw['cols']).abs().max().item()
+    print(f'forward logits(cond) vs the reference: max abs err {max(e1, e2):.3g} (logits absmax {fw["absmax"]:.3g})', flush=True)
+    if args.steps <= 0:
+        return
     noise = R.noise_stream()
     gen = g['generate']
     ref_in = gen['step_in_ids'].long()
@@ -109,7 +159,7 @@ def main():
 
     ids = O.generate_ids(demask, R.B, R.N, 65536, gumbel, timesteps=R.T)
     final = (ids.reshape(gen['final_ids'].shape) == gen['final_ids']).float().mean().item()
-    print(f'terms={args.terms}: final ids equal to the reference run: {100 * final:.3f} %')
+    print(f'{args.fixture} fmt={args.fmt} terms={args.terms} wterms={args.wterms} order={args.order} ftz={args.ftz} wscale={args.wscale}: final ids equal to the reference run: {100 * final:.3f} %')
 
 
 if __name__ == '__main__':
