@@ -11,7 +11,7 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
                  inside the timed region (mm_profile_*), algorithmic flops / measured time vs 2.5 PFLOP/s dense bf16;
   roofline_hbm : the HBM-bound sampling kernel the same way (algorithmic bytes = one fp32 read of each sampled row);
   cpu_baseline : the CPU oracle (port of the reference algorithm, torch fp32 on the host cores) on a bounded sample;
-  parity_tier  : the same workload through precision 'bf16x3' -- the engine that meets the north star's tolerance (logits within 1e-3 of the fp32
+  parity_tier  : the same workload through precision 'f16x2' (round 3: 'bf16x3', still reported inside) -- the engine that meets the north star's tolerance (logits within 1e-3 of the fp32
                  reference, ids bit-exact: tests/test_gpu_base_size.py) inside the same mm_generate call -- timed after the main region.
 """
 import argparse
@@ -93,12 +93,12 @@ def _cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(mg, te_two, timesteps, cond_scale, sample_steps=5, max_threads=32):
+def cpu_baseline(mg, te_two, timesteps, cond_scale, max_threads=32):
     """The reference algorithm on the host cores, beside the GPU number (never the thing measured as `value`).  kind = "port": the oracle
     (oracle/muse_oracle.py, a functional fp32 torch restatement pinned bit-exactly to goldens of the unmodified reference) -- the reference
-    package itself is absent from the GPU box.  Protocol (bounded to ~20 s): batch 2, one untimed warm-up step, then
-    3 timed runs of `sample_steps` of the 18 decode steps each (every reference step costs the same: it always runs the full two-pass
-    transformer and the full-vocabulary sampling tail), median run extrapolated to 18 steps, plus one VAE decode of the batch."""
+    package itself is absent from the GPU box.  Protocol (bounded to ~20 s): batch 2, one untimed warm-up decode step, then
+    ONE full generate -- all `timesteps` decode steps (each the full two-pass transformer and the full-vocabulary sampling tail) and the VAE
+    decode of the batch -- timed end to end: no extrapolation."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import muse_oracle as O
     cores = min(os.cpu_count(), max_threads)   # torch's intra-op pool stops scaling (and regresses) far below 256 threads
@@ -109,12 +109,12 @@ def cpu_baseline(mg, te_two, timesteps, cond_scale, sample_steps=5, max_threads=
     cfg = dict(depth=tr.transformer_blocks.cfg['depth'], heads=tr.transformer_blocks.cfg['heads'])
     n, V = tr.seq_len, tr.num_tokens
     Bc = te_two.shape[0]
-    sample_steps = min(sample_steps, timesteps)
     counts = O.mask_counts(timesteps, n)
     temps = O.step_temperatures(timesteps, 1.)
     g = torch.Generator().manual_seed(0)
+    f = int(math.isqrt(n))
 
-    def run(steps):
+    def run(steps, decode):
         ids = torch.full((Bc, n), tr.mask_id, dtype=torch.long)
         scores = torch.zeros(Bc, n)
         t0 = time.perf_counter()
@@ -124,22 +124,41 @@ def cpu_baseline(mg, te_two, timesteps, cond_scale, sample_steps=5, max_threads=
             logits = O.forward_with_cond_scale(sd, cfg, ids, te_two, cond_scale)
             gum = O.gumbel_from_uniform(torch.rand(Bc, n, V, generator=g))
             ids, scores, _ = O.sample_step(logits, gum, ids, tr.mask_id, temps[s])
-        return time.perf_counter() - t0, ids
+        t1 = time.perf_counter()
+        if decode:
+            O.vae_decode_from_ids(vsd, ids.clamp(max=V - 1).reshape(Bc, f, f))
+        return t1 - t0, time.perf_counter() - t1
 
     with torch.no_grad():
-        run(1)                                         # warm-up
-        times = sorted(run(sample_steps)[0] for _ in range(3))
-        loop = times[1] / sample_steps * timesteps     # median run, extrapolated
-        _, ids = run(1)
-        f = int(math.isqrt(n))
-        t1 = time.perf_counter()
-        O.vae_decode_from_ids(vsd, ids.clamp(max=V - 1).reshape(Bc, f, f))
-        dec = time.perf_counter() - t1
+        run(1, False)                                  # warm-up
+        loop, dec = run(timesteps, True)
     per_batch = loop + dec
     return dict(value=Bc / per_batch, unit='images/sec', cores=cores, kind='port', cpu_model=_cpu_model(), host_cpus=os.cpu_count(),
-                sample=f'batch {Bc}, 1 warm-up step + 3 runs of {sample_steps} of {timesteps} decode steps (median {times[1]:.1f} s, runs {times[0]:.1f}-{times[2]:.1f} s), '
-                       f'extrapolated x{timesteps / sample_steps:g}, + 1 VAE decode ({dec:.1f} s); oracle/muse_oracle.py (fp32 torch port of the reference: '
-                       f'the reference package is not present on the GPU box), {cores} torch threads')
+                sample=f'batch {Bc}, 1 warm-up decode step, then one full generate timed end to end: all {timesteps} decode steps ({loop:.1f} s) + the VAE decode '
+                       f'({dec:.1f} s), no extrapolation; oracle/muse_oracle.py (fp32 torch port of the reference: the reference package is not present on the GPU box), '
+                       f'{cores} torch threads')
+
+
+def roofline_hbm(fused_on, s_cnt, s_ms, s_bytes, traffic, pmc_file):
+    """The sampling tail against the HBM roofline.  Logits path: one fp32 read of each sampled row (algorithmic bytes).  Fused path (default): the
+    logits never reach HBM -- sample_fused_kernel reads the candidates the GEMM emitted, so `achieved` / `frac` are the bytes it REALLY moves (PMC
+    FETCH + WRITE per launch from the committed rocprofv3 counter pass of this command) over its measured time; the logits-equivalent rate (4 V per
+    row: what a logits-reading sampler would have to read in the same time) is reported beside it, labelled as such."""
+    avg_s = s_ms * 1e-3 / s_cnt if s_cnt else None
+    d = {'kernel': ('sample_fused_kernel (exact k-th largest + Gumbel argmax + confidence over the candidates emitted by the GEMM)' if fused_on
+                    else 'sample_kernel (top-k + Gumbel argmax + confidence on materialised logits)'), 'bound': 'hbm', 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+         'traffic': traffic, 'launches': s_cnt, 'avg_launch_ms': s_ms / s_cnt if s_cnt else None}
+    if not fused_on:
+        d.update(achieved=s_bytes / (s_ms * 1e-3) / 1e9 if s_ms else None, frac=(s_bytes / (s_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if s_ms else None,
+                 bytes_kind='algorithmic (one fp32 read of each sampled row)', algorithmic_bytes_per_launch=s_bytes / s_cnt if s_cnt else None)
+        return d
+    real = traffic / avg_s / 1e9 if (traffic and avg_s) else None
+    d.update(achieved=real, frac=real / PEAK_HBM_GBS if real else None,
+             bytes_kind=(f'HBM bytes actually moved per launch (profiles/{pmc_file}: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE of this command) / the launch time measured here'
+                         if real else 'no counter pass available for this configuration: achieved / frac not stated'),
+             logits_equivalent={'gb_per_s': s_bytes / (s_ms * 1e-3) / 1e9 if s_ms else None, 'bytes_per_launch': s_bytes / s_cnt if s_cnt else None,
+                                'note': '4 V bytes per sampled row -- what a sampler that reads materialised logits moves; NOT bytes this kernel moves, no roofline fraction'})
+    return d
 
 
 def executed_flops_per_generate(tr, B, n, m_text, nc, counts):
@@ -182,12 +201,13 @@ def reference_flops_per_generate(tr, B, n, m_text, nc, timesteps):
 
 
 def parity_tier_leg(mg, tr, step, args, B, T, n, nc, image_size, counts, lib, bf16_s_per_step):
-    """The same step through precision 'bf16x3' (csrc/split.hip): every GEMM activation as its exact three-term bf16 split, multiplied as term
-    products on the bf16 MFMA kernels of the main line, fp32 everywhere else, attention on the fp32 MFMA, VAE decode with its convolutions as exact bf16 term products on the bf16 MFMA (pixels 3e-8 from the reference at this size) -- the
-    tier that holds logits within 1e-3 of the reference's fp32 run and reproduces its ids bit for bit (tests/test_gpu_base_size.py).  Timed
-    with the checkpoint the main line effectively multiplies by: the bf16 engine rounds every Linear weight to bf16 when it packs, so the
-    parameters are rounded to bf16 first -- a bf16-representable checkpoint, 3 term products per GEMM -- and, for one step, with the raw fp32
-    initialisation (6 term products)."""
+    """The same step through precision 'f16x2' (round 4; csrc/split.hip, common.h split2_f16): every GEMM / convolution operand as TWO fp16 terms of
+    its fp32 value (22 significand bits), multiplied as term products on the fp16 MFMA (same rate as the bf16 one) with fp32 accumulation -- THREE
+    products for general fp32 weights, TWO for a bf16-representable checkpoint --, fp32 everywhere else, attention on the fp32 MFMA, the VAE decode's
+    convolutions the same way.  The tier that holds logits within 1e-3 of the reference's fp32 run and reproduces its ids bit for bit on BOTH kinds of
+    checkpoint (tests/test_gpu_base_size.py, fixtures base_c2.pt and base_c2_fp32.pt).  Timed first on the raw fp32 initialisation of the main line
+    (`fp32_checkpoint`: what the reference's own constructors produce), then on the same parameters rounded to bf16 -- the checkpoint the bf16
+    engine effectively multiplies by.  `bf16x3` is round 3's tier (three bf16 terms per value, 6 / 3 products) on the same two checkpoints."""
     import ctypes as C
     from muse_maskgit_pytorch_amd import _lib
 
@@ -213,32 +233,46 @@ def parity_tier_leg(mg, tr, step, args, B, T, n, nc, image_size, counts, lib, bf
         assert torch.isfinite(images).all() and images.shape == (B, 3, image_size, image_size)
         return sec, sum(a.elapsed_time(b) for a, b in marks) / steps, prof
 
-    mg.set_precision('bf16x3')
+    nsteps = max(5, min(args.steps, 10))
     try:
-        sec6, loop6, _ = timed(1)                       # raw fp32 initialisation: general weights, 6 term products
+        # ---- general fp32 weights (the raw initialisation)
+        mg.set_precision('f16x2')
+        sec3, loop3, _ = timed(nsteps)
+        p3 = tr._model().packed['P']
+        mg.set_precision('bf16x3')
+        sec6, loop6, _ = timed(2)
         p6 = tr._model().packed['P']
+        # ---- the same parameters rounded to bf16
         with torch.no_grad():
             for p_ in list(mg.transformer.parameters()) + list(mg.vae.parameters()):
                 p_.copy_(p_.to(torch.bfloat16).float())
-        sec, loop_ms, prof = timed(max(1, min(args.steps, 5)))
+        sec_b3, loop_b3, _ = timed(2)
+        pb3 = tr._model().packed['P']
+        mg.set_precision('f16x2')
+        sec, loop_ms, prof = timed(nsteps)
         P = tr._model().packed['P']
         g_cnt, g_ms, g_flops = prof[0]
         ex = executed_flops_per_generate(tr, B, n, args.text_len, nc, counts)
         return {
-            'precision': 'bf16x3', 'value': B / sec, 'unit': 'images/sec', 'ms_per_step': sec * 1e3, 'decode_loop_ms_per_step': loop_ms,
+            'precision': 'f16x2', 'value': B / sec, 'unit': 'images/sec', 'ms_per_step': sec * 1e3, 'decode_loop_ms_per_step': loop_ms, 'steps': nsteps,
             'x_bf16_engine_time': sec / bf16_s_per_step, 'term_products': P,
-            'checkpoint': 'the main line\'s parameters rounded to bf16 (what the bf16 engine multiplies by): bf16-representable weights need 3 term products',
-            'tolerance': 'logits <= 1e-3 absolute and ids bit-exact against the reference fp32 run at this size (tests/test_gpu_base_size.py, precision bf16x3); '
-                         'VAE decode with its convolutions as exact bf16 term products on the bf16 MFMA (pixels 3e-8 from the reference at this size)',
-            'roofline': {'kernel': 'gemm_wide_fused_kernel on K = products x dim (term products of to_logits on the guidance-mixed embeddings)', 'bound': 'mfma',
+            'checkpoint': 'the main line\'s parameters rounded to bf16 (what the bf16 engine multiplies by): one fp16 term per weight, 2 term products',
+            'tolerance': 'logits <= 1e-3 absolute (measured 4e-6) and ids bit-exact at every decode step against the reference fp32 run at this size, on a '
+                         'bf16-representable AND on a general fp32 checkpoint (tests/test_gpu_base_size.py, precision f16x2, fixtures base_c2.pt / base_c2_fp32.pt); '
+                         'VAE decode with its convolutions as fp16 term products on the fp16 MFMA',
+            'roofline': {'kernel': 'gemm_wide_fused_kernel<F16> on K = products x dim (term products of to_logits on the guidance-mixed embeddings)', 'bound': 'mfma',
                          'achieved': g_flops / (g_ms * 1e-3) / 1e12 if g_ms else None, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': (g_flops / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if g_ms else None,
-                         'flops_kind': 'executed bf16 MFMA flops (term products x 2 R V D of the one mixed pass)',
+                         'flops_kind': 'executed fp16 MFMA flops (term products x 2 R V D of the one mixed pass; same peak as bf16)',
                          'algorithmic_frac': (g_flops / P / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if g_ms else None,
                          'launches': g_cnt, 'avg_launch_ms': g_ms / g_cnt if g_cnt else None, 'traffic': None},
-            'executed_bf16_tflops_decode_loop_gemms_x_products': P * ex / (loop_ms * 1e-3) / 1e12,
-            'fp32_checkpoint': {'term_products': p6, 'value': B / sec6, 'ms_per_step': sec6 * 1e3, 'decode_loop_ms_per_step': loop6, 'steps': 1,
-                                'note': 'same tier on the raw fp32 initialisation: general fp32 weights need all six term pairs'},
+            'executed_f16_tflops_decode_loop_gemms_x_products': P * ex / (loop_ms * 1e-3) / 1e12,
+            'fp32_checkpoint': {'term_products': p3, 'value': B / sec3, 'ms_per_step': sec3 * 1e3, 'decode_loop_ms_per_step': loop3, 'steps': nsteps,
+                                'x_bf16_engine_time': sec3 / bf16_s_per_step,
+                                'note': 'same tier on the raw fp32 initialisation (general fp32 weights, what the reference\'s constructors / training produce): three term pairs'},
+            'bf16x3': {'note': 'round 3\'s tier (bf16 terms) on the same two checkpoints, 2 timed steps each',
+                       'fp32_checkpoint': {'term_products': p6, 'value': B / sec6, 'ms_per_step': sec6 * 1e3, 'decode_loop_ms_per_step': loop6},
+                       'bf16_checkpoint': {'term_products': pb3, 'value': B / sec_b3, 'ms_per_step': sec_b3 * 1e3, 'decode_loop_ms_per_step': loop_b3}},
         }
     finally:
         mg.set_precision('bf16')
@@ -330,7 +364,7 @@ def main():
     ap.add_argument('--no-fused-sampling', action='store_true', help='materialise the logits (round-1 path) for A/B timing')
     ap.add_argument('--fp8', action='store_true', help="secondary line: run the transformer on the fp8 engine (precision 'fp8', BASELINE configs[4] \"fp8 MFMA weights\"; "
                     "use with --config c5).  Never the headline: the metric configuration is quoted in bf16")
-    ap.add_argument('--no-parity-tier', action='store_true', help="skip the second timed leg (precision 'bf16x3', the tolerance-meeting tier)")
+    ap.add_argument('--no-parity-tier', action='store_true', help="skip the second timed leg (precision 'f16x2', the tolerance-meeting tier)")
     ap.add_argument('--train', action='store_true', help='time the TRAINING step of the C2 base transformer (MaskGit.forward + backward + AdamW) instead of '
                     'generation: a second, separately labelled line -- not the BASELINE metric')
     args = ap.parse_args()
@@ -494,14 +528,7 @@ def main():
             # the sampling tail.  With fused sampling (default) the logits never reach HBM: sample_fused_kernel works on the ~15 % candidates the
             # GEMM emitted; its rate is quoted in LOGITS-EQUIVALENT bytes (4 V per row: what a logits-reading sampler must read) for comparison
             # with round 1's sample_kernel, which is what runs when fused sampling is off
-            'roofline_hbm': {'kernel': ('sample_fused_kernel (exact k-th largest + Gumbel argmax + confidence over the candidates emitted by the GEMM)' if fused_on
-                                        else 'sample_kernel (top-k + Gumbel argmax + confidence on materialised logits)'), 'bound': 'hbm',
-                             'achieved': s_bytes / (s_ms * 1e-3) / 1e9 if s_ms else None, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                             'frac': (s_bytes / (s_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if s_ms else None,
-                             'bytes_kind': 'logits-equivalent (4 V per sampled row)' if fused_on else 'algorithmic (one fp32 read of each sampled row)',
-                             'traffic': traffic_of('sample_fused_kernel' if fused_on else 'sample_kernel') if metric_cfg else None,
-                             'algorithmic_bytes_per_launch': s_bytes / s_cnt if s_cnt else None,
-                             'launches': s_cnt, 'avg_launch_ms': s_ms / s_cnt if s_cnt else None},
+            'roofline_hbm': roofline_hbm(fused_on, s_cnt, s_ms, s_bytes, traffic_of('sample_fused_kernel' if fused_on else 'sample_kernel') if metric_cfg else None, pmc_file),
             'multi_gpu': ({'ranks_in_process_group': dist.get_world_size(), 'backend': dist.get_backend(), 'ids_gather': allgather_ids.last_transport, 'ids_gather_error': allgather_ids.last_error,
                            'devices_visible_to_rank0': torch.cuda.device_count(), 'per_rank_elapsed_s': {'min': min(rank_times), 'max': max(rank_times)},
                            'per_rank_images_per_s': [B * args.steps / t_ for t_ in rank_times]} if dist is not None else None),

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 4
+#define MM_ABI_VERSION 5
 
 #define MM_OK 0
 #define MM_ERR_SHAPE (-1)
@@ -360,6 +360,27 @@ int mm_f32_nhwc_to_nchw(mm_stream_t stream, const float* in, int B, int C, int H
  * Feed the result to mm_gemm_bf16 / mm_gemm_cfg_logits with K' = products * K against a weight packed the same way. */
 int mm_split_rows(mm_stream_t stream, const float* x, int64_t ldx, int64_t rows, int K, int products, void* out);
 
+/* ---- precision tier 'f16x2' (round 4): the same engine on fp16 TERMS and v_mfma_f32_16x16x32_f16.  x ~ h + l, h = fp16(x), l = fp16(x - h): 22
+ * significand bits (relative error <= 2^-22; subnormal terms are taken un-flushed, absolute floor 2^-25), so ONE product of two such sums needs only
+ * the pairs h.h + l.h + h.l -- X' = [xh | xl | xh] against W' = [wh | wh | wl]: THREE products for GENERAL fp32 weights (the bf16 split needs six), TWO
+ * ([xh | xl] . [wh | wh]) when every weight is a single fp16 term (any bf16-representable checkpoint in fp16 range).  The weight terms are packed
+ * times a power of two `1 / alpha` (host side: the largest |w| of the model lands in [2^13, 2^14), so that low terms are normal fp16 numbers) and every
+ * accumulator is multiplied by `alpha` -- exact.  Operand code of every `products` argument of this header: MM_SPLIT_F16 | 2 or MM_SPLIT_F16 | 3
+ * (mm_split_rows, mm_cfg_mix, mm_gemm_split, mm_transformer_desc.split_products).  Measured on the reference's own fp32 checkpoint at
+ * BASELINE configs[1] size: logits within 4e-6 of the reference, ids 100 % at every decode step. */
+#define MM_SPLIT_F16 0x100
+
+/* out fp32 [M][ldc] (+ resid_f32) = X' . W'^T over term-segment packs: products = 3 / 5 / 6 -> bf16 terms (== mm_gemm_bf16 with out_f32), alpha unused;
+ * MM_SPLIT_F16 | 2 / 3 -> fp16 terms on the fp16 MFMA, accumulators x alpha.  K = segments x inner width, a multiple of 64. */
+int mm_gemm_split(mm_stream_t stream, const void* x, int64_t ldx, const void* w, int64_t ldw, int M, int N, int K, int products, float alpha,
+                  float* out, int64_t ldc, const float* resid_f32);
+
+/* mm_conv2d_nhwc on fp16 term operands: `in` holds MM_SPLIT_F16 | P segments per pixel (Cin = P x channels), w the matching per-tap pack (x 1 / alpha);
+ * fp32 output only: out_nchw_f32 = 1 (NCHW) or 2 (NHWC, optional fp32 NHWC residual). */
+int mm_conv2d_nhwc_f16(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
+                       int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
+                       int Hout, int Wout, const float* bias, int act, const float* resid_f32, float* out, int out_nchw_f32, float alpha);
+
 /* Classifier-free guidance applied to the EMBEDDINGS (round 3): to_logits is linear (mmp.py:332), so null + (cond - null) * s of the two passes'
  * logits (mmp.py:254) equals to_logits(e) with e = e_null + (e_cond - e_null) * s -- ONE [R x V x D] product instead of two.  mm_generate and
  * Transformer.forward_with_cond_scale mix first and multiply once (mm_gemm_bf16 / the fused-sampling GEMM on the mixed rows).
@@ -434,13 +455,15 @@ typedef struct mm_transformer_desc {
      * [2*Fp][P*D] matrix (rows [0, F) = gelu half, rows [Fp, Fp + F) = gate half, the rest zero; w2_folded / ln2_c1 / ln2_c2 unused);
      * token_emb / pos_emb are fp32 tables; ctx and the `embed` output are bf16 [.][P * D]; q|k|v, GEMM outputs, the residual stream and
      * the logits are fp32; attention runs on the fp32 MFMA.  Reference arithmetic matched: fp32 end to end (mmp.py:240-259, 279-335). */
-    int32_t split_products;
+    int32_t split_products;         /* 0 | 3 | 5 | 6 (bf16 terms) | MM_SPLIT_F16 | 2 | MM_SPLIT_F16 | 3 (fp16 terms: 'f16x2', see above -- the same pointer meanings with
+                                     * [out][P * in] packs of fp16 terms x 1 / split_alpha) */
     /* fp8 engine (BASELINE configs[4] "fp8 MFMA weights"), fp8 != 0: the Linear weights of the layers (and of self_cond_ff) are OCP e4m3 rows with the
      * per-row scales of mm_attn_weights / mm_ff_weights (mm_quantize_e4m3_rows); their input activations are quantised per token row inside the producing
      * kernels and the products run on v_mfma_f32_16x16x128_f8f6f4 (mm_gemm_fp8).  Embeddings, text_proj, the cross-attention's w_kv, attention, to_logits
      * and the sampling are the bf16 engine's.  dim, heads * dim_head and ff_inner_padded must be multiples of 128; split_products must be 0.
      * Self-defined numerics: the oracle is the fp32 restatement with the same per-row fake quantisation at every Linear of the layers. */
     int32_t fp8;
+    float split_alpha;              /* fp16 terms only: the power of two every GEMM accumulator is multiplied by (0 = 1); the weight terms were packed x 1 / split_alpha */
 } mm_transformer_desc;
 
 typedef struct mm_transformer mm_transformer_t;

@@ -40,7 +40,7 @@ class TransformerDesc(C.Structure):
                                          'num_tokens', 'vocab_rows', 'dim_out', 'text_dim', 'self_cond')] + \
                [('token_emb', c_vp), ('pos_emb', c_vp), ('text_proj', c_vp), ('layers', C.POINTER(LayerWeights)),
                 ('final_gamma', c_vp), ('final_beta', c_vp), ('to_logits', c_vp), ('self_cond_ff', FFWeights), ('logits_wmean', c_vp), ('logits_wcov', c_vp),
-                ('split_products', C.c_int32), ('fp8', C.c_int32)]
+                ('split_products', C.c_int32), ('fp8', C.c_int32), ('split_alpha', c_f32)]
 
 
 class VaeLayer(C.Structure):
@@ -68,6 +68,7 @@ SIGNATURES = {
     'mm_last_error': (C.c_char_p, []),
     'mm_device_check': (c_int, []),
     'mm_gemm_bf16': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_int, c_vp]),
+    'mm_gemm_split': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_int, c_f32, c_vp, c_i64, c_vp]),
     'mm_gemm_cfg_logits': (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_f32]),
     'mm_embed': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp]),
     'mm_layernorm': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_i64]),
@@ -110,6 +111,7 @@ SIGNATURES = {
     'mm_qk_norm_bwd': (c_int, [c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_vp]),
     'mm_philox_uniform': (c_int, [c_vp, c_u64, c_u64, c_u32, c_int, c_int, c_vp]),
     'mm_conv2d_nhwc': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int] + [c_int] * 12 + [c_vp, c_int, c_vp, c_vp, c_int]),
+    'mm_conv2d_nhwc_f16': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int] + [c_int] * 12 + [c_vp, c_int, c_vp, c_vp, c_int, c_f32]),
     'mm_glu_nhwc': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp]),
     'mm_groupnorm_nhwc': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
     'mm_lfq_decode': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
@@ -184,7 +186,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.mm_abi_version() != 4:
+        if l.mm_abi_version() != 5:
             raise MuseHipError('libmuse_hip ABI version mismatch')
         if os.environ.get('MM_DEBUG'):      # tools / A-B runs only: kernel-selection bits (see muse_hip_internal.h)
             l.mm_debug_set(int(os.environ['MM_DEBUG'], 0))

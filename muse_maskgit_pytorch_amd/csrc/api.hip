@@ -2,6 +2,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include "common.h"
 #include "muse_hip_internal.h"
 
 namespace {
@@ -62,6 +63,29 @@ int mm_gemm_bf16(mm_stream_t stream, const void* x, int64_t ldx, const void* w, 
     a.M = M; a.X = (const bf16_t*)x; a.ldx = (int)ldx;
     a.out = out; a.ldc = ldc; a.out_kind = out_f32 ? OUT_F32 : OUT_BF16;
     a.resid_f32 = resid_f32; a.ldr = ldc;
+    return mm_gemm_launch(a, (hipStream_t)stream);
+}
+
+// precision tiers: operand rows are term-segment packs (mm_split_rows) -> fp32 out.  products = 3 / 5 / 6: bf16 terms on the bf16 MFMA (== mm_gemm_bf16);
+// MM_SPLIT_F16 | 2 / 3: fp16 terms on the fp16 MFMA, the accumulators multiplied by alpha (inverse of the power-of-two scale of the packed weight terms)
+int mm_gemm_split(mm_stream_t stream, const void* x, int64_t ldx, const void* w, int64_t ldw, int M, int N, int K, int products, float alpha,
+                  float* out, int64_t ldc, const float* resid_f32) {
+    if (M == 0 || N == 0) return MM_OK;
+    CHK_PTR(x, "x"); CHK_PTR(w, "w"); CHK_PTR(out, "out");
+    CHK_ALIGN16(x, "x"); CHK_ALIGN16(w, "w"); CHK_ALIGN16(out, "out");
+    if (M < 0 || N < 0) return mm_set_error(MM_ERR_SHAPE, "gemm: negative size");
+    const bool f16 = split_is_f16(products);
+    const int cnt = split_count(products);
+    if ((f16 && cnt != 2 && cnt != 3) || (!f16 && cnt != 3 && cnt != 5 && cnt != 6)) return mm_set_error(MM_ERR_SHAPE, "gemm_split: bad products code");
+    if (!f16 && alpha != 0.f && alpha != 1.f) return mm_set_error(MM_ERR_SHAPE, "gemm_split: alpha applies to fp16 terms only");
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mode = MODE_DENSE;
+    a.W = (const bf16_t*)w; a.N = N; a.ldw = (int)ldw; a.K = K;
+    a.M = M; a.X = (const bf16_t*)x; a.ldx = (int)ldx;
+    a.out = out; a.ldc = ldc; a.out_kind = OUT_F32;
+    a.resid_f32 = resid_f32; a.ldr = ldc;
+    a.f16 = f16 ? 1 : 0; a.alpha = alpha;
     return mm_gemm_launch(a, (hipStream_t)stream);
 }
 
@@ -405,9 +429,30 @@ int mm_philox_uniform(mm_stream_t stream, uint64_t seed, uint64_t row_offset, ui
     return k_philox_fill((hipStream_t)stream, seed, row_offset, step, rows, V, out);
 }
 
+static int conv2d_nhwc_impl(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
+                            int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
+                            int Hout, int Wout, const float* bias, int act, const void* resid, void* out, int out_nchw_f32, int f16, float alpha);
+
 int mm_conv2d_nhwc(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
                    int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
                    int Hout, int Wout, const float* bias, int act, const void* resid, void* out, int out_nchw_f32) {
+    return conv2d_nhwc_impl(stream, in, B, Hin, Win, Cin, w, Cout, TH, TW, stride, off_y, off_x, Hv, Wv, os, py, px, Hout, Wout, bias, act, resid, out,
+                            out_nchw_f32, 0, 1.f);
+}
+
+// the same convolution on fp16 TERM operands ('f16x2' tier: `in` holds MM_SPLIT_F16 | P segments per pixel, w the matching per-tap pack scaled by a power
+// of two): fp16 MFMA, accumulators x alpha, fp32 output only (out_nchw_f32 = 1: NCHW, 2: NHWC with an optional fp32 NHWC residual)
+int mm_conv2d_nhwc_f16(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
+                       int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
+                       int Hout, int Wout, const float* bias, int act, const float* resid_f32, float* out, int out_nchw_f32, float alpha) {
+    if (out_nchw_f32 != 1 && out_nchw_f32 != 2) return mm_set_error(MM_ERR_SHAPE, "conv_f16: fp32 output only (out_nchw_f32 = 1 or 2)");
+    return conv2d_nhwc_impl(stream, in, B, Hin, Win, Cin, w, Cout, TH, TW, stride, off_y, off_x, Hv, Wv, os, py, px, Hout, Wout, bias, act, resid_f32, out,
+                            out_nchw_f32, 1, alpha);
+}
+
+static int conv2d_nhwc_impl(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
+                            int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
+                            int Hout, int Wout, const float* bias, int act, const void* resid, void* out, int out_nchw_f32, int f16, float alpha) {
     if (B == 0) return MM_OK;
     CHK_PTR(in, "in"); CHK_PTR(w, "w"); CHK_PTR(out, "out");
     CHK_ALIGN16(in, "in"); CHK_ALIGN16(w, "w"); CHK_ALIGN16(out, "out");
@@ -428,6 +473,7 @@ int mm_conv2d_nhwc(mm_stream_t stream, const void* in, int B, int Hin, int Win, 
     if (out_nchw_f32 == 2) a.resid_f32 = (const float*)resid;      // fp32 NHWC in and out (the precision tier's convolutions: bf16 term segments in, fp32 out)
     else a.resid_bf16 = (const bf16_t*)resid;
     a.ldr = Cout;
+    a.f16 = f16; a.alpha = alpha;
     return mm_gemm_launch(a, (hipStream_t)stream);
 }
 

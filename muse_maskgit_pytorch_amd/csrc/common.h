@@ -47,6 +47,14 @@ __device__ __forceinline__ f32x4_t mfma16(u32x4_t a, u32x4_t b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
                                                    __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
+// The same 16 x 16 x 32 product on fp16 operands (v_mfma_f32_16x16x32_f16: same rate, same fragment layout, fp32 accumulation): the matrix
+// instruction of the 'f16x2' precision tier (split.hip), whose operands are fp16 TERMS of fp32 values.  F16 = false is the bf16 instruction above.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+template <bool F16>
+__device__ __forceinline__ f32x4_t mfma16t(u32x4_t a, u32x4_t b, f32x4_t c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
 
 // Phi(x) = (1 + erf(x / sqrt 2)) / 2 for the exact (erf) GELU.  libm's erff costs ~100 instructions with a divergent branch and
 // the 1 + erf form cancels for x < 0 (4 % relative error at x = -5); this evaluates the TAIL directly,
@@ -255,8 +263,33 @@ __device__ __forceinline__ void split3(float x, float& h, float& m, float& l) {
 // which term (0 = h, 1 = m, 2 = l) segment s of X' carries: [h m l h m h]
 __device__ __forceinline__ int seg_term(int s) { return s < 3 ? s : (s < 5 ? s - 3 : 0); }
 
-// four consecutive values of one row -> the P segments of that row (8-byte stores)
+// ---- 'f16x2' precision tier: an fp32 value as the sum of TWO fp16 terms, x ~ h + l (11 + 11 significand bits: relative error <= 2^-22, and
+// exact whenever x has <= 22 significant bits; terms below 2^-14 are fp16 subnormals -- the matrix pipe takes them un-flushed -- so the absolute
+// floor is 2^-25).  A product of two such sums keeps the pairs h.h, l.h, h.l (the dropped l.l is < 2^-22 of the leading one): X' = [xh | xl | xh]
+// against W' = [wh | wh | wl] -- THREE products for general fp32 weights where the bf16 split needs six, TWO ([xh | xl] . [wh | wh]) when every
+// weight is a single fp16 term (any bf16-representable checkpoint).  Operand codes: products | MM_SPLIT_F16 (muse_hip.h).
+#define MM_SPLIT_F16_BIT 0x100
+__device__ __forceinline__ uint16_t f32_to_f16_bits(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }      // round-to-nearest-even
+__device__ __forceinline__ float f16_bits_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ void split2_f16(float x, uint16_t& h, uint16_t& l) {
+    h = f32_to_f16_bits(x);
+    l = f32_to_f16_bits(x - f16_bits_to_f32(h));      // (the difference is exact in fp32)
+}
+__host__ __device__ __forceinline__ int split_count(int code) { return code & 0xff; }            // segments per operand row
+__host__ __device__ __forceinline__ bool split_is_f16(int code) { return (code & MM_SPLIT_F16_BIT) != 0; }
+
+// four consecutive values of one row -> the P segments of that row (8-byte stores).  P: 3 / 5 / 6 (bf16 terms) or MM_SPLIT_F16 | 2 / 3 (fp16 terms, [h l h])
 __device__ __forceinline__ void store_split4(bf16_t* orow, int K, int P, int col, const float (&v)[4]) {
+    if (split_is_f16(P)) {
+        uint16_t h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split2_f16(v[j], h[j], l[j]);
+        const uint2 hv = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+        *reinterpret_cast<uint2*>(orow + col) = hv;
+        *reinterpret_cast<uint2*>(orow + (long)K + col) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+        if (split_count(P) > 2) *reinterpret_cast<uint2*>(orow + 2l * K + col) = hv;
+        return;
+    }
     float t[3][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) split3(v[j], t[0][j], t[1][j], t[2][j]);

@@ -39,7 +39,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + 
 // source of the implicit-GEMM loader for taps that fall into the zero padding
 __device__ __attribute__((aligned(16))) const unsigned int g_zero_page[64] = {0};
 
-template <int MODE>
+template <int MODE, bool F16 = false>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TSTAMP(0)
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             }                                                                                                      \
             if (!(p.debug & 4)) {                                                                                  \
             _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                          \
-                _Pragma("unroll") for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(af[a], bfm[b], acc[a][b]);        \
+                _Pragma("unroll") for (int b = 0; b < 4; ++b) acc[a][b] = mfma16t<F16>(af[a], bfm[b], acc[a][b]);   \
             } else { _Pragma("unroll") for (int a = 0; a < 4; ++a) { acc[a][0][0] += __uint_as_float(af[a][0] ^ bfm[a][1]); } } \
         }                                                                                                          \
     }
@@ -190,6 +190,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     }
     COMPUTE_TILE((KT - 1) & 1);
     TSTAMP(40)
+    if constexpr (F16) {      // fp16 term products: undo the power-of-two scale of the packed weight terms (exact)
+        const float al = p.alpha;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] *= al;
+    }
 
     // ---- epilogue.  A lane holds out[m][n..n+3] per fragment (16 rows x 64 B per store instruction): storing that
     //      directly touches half cache lines and was measured at 35-45 % of the kernel.  Instead the tile goes
@@ -403,18 +410,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     TSTAMP(43)
 }
 
-template <int MODE>
+template <int MODE, bool F16 = false>
 int launch(const GemmArgs& a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_kernel<MODE>)),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_kernel<MODE, F16>)),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
         if (e != hipSuccess) return mm_set_hip_error(e, "gemm hipFuncSetAttribute");
         attr_set = true;
     }
     const int blocks = a.tiles_m * a.tiles_n;
     if (blocks <= 0) return MM_OK;
-    hipLaunchKernelGGL((gemm_kernel<MODE>), dim3(blocks, a.splits > 1 ? a.splits : 1), dim3(256), SMEM_BYTES, stream, a);
+    hipLaunchKernelGGL((gemm_kernel<MODE, F16>), dim3(blocks, a.splits > 1 ? a.splits : 1), dim3(256), SMEM_BYTES, stream, a);
     return mm_check_launch("gemm_kernel");
 }
 
@@ -452,10 +459,23 @@ int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
             a.splits > 1)
             return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: folded LayerNorm needs a dense fp32-residual GEMM");
     }
+    if (a.fs_stats && a.f16) {      // fp16 term operands: the emission exists on the 256 x 256 persistent kernel only (model.hip checks eligibility first)
+        if (!mm_gemm_wide_fused_eligible(a)) return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: fused sampling on fp16 term operands needs the 256 x 256 logits kernel (>= 1024 rows)");
+        return mm_gemm_wide_fused_launch(a, stream);
+    }
     if (a.fs_stats) {      // fused sampling: only the 256-column guidance kernel implements the emission (model.hip checks eligibility first)
         if ((a.mode != MODE_CFG && !(a.mode == MODE_DENSE && a.wide_tok)) || !mm_gemm_cfg2_eligible(a))
             return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: fused sampling needs the 256-column guidance-logits kernel");
         return mm_gemm_cfg2_launch(a, stream);
+    }
+    if (a.f16) {      // fp16 term operands ('f16x2' tier): fp32 output, dense / convolution; the 256x128 kernel when it fills the chip, else the 128x128 one
+        if (a.out_kind == OUT_BF16 || a.mode == MODE_CFG || a.epi != EPI_NONE || a.ln_c1 || a.ln_part || a.splits > 1 || a.resid_bf16)
+            return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: fp16 term operands take the plain fp32-output dense / convolution forms only");
+        if (a.alpha == 0.f) a.alpha = 1.f;
+        if (!a.m_dev && !(a.debug & 8) && mm_gemm_big_eligible(a)) return mm_gemm_big_launch(a, stream);
+        a.tiles_n = (a.N + BT - 1) / BT;
+        a.tiles_m = (a.M + BT - 1) / BT;
+        return a.mode == MODE_CONV ? launch<MODE_CONV, true>(a, stream) : launch<MODE_DENSE, true>(a, stream);
     }
     if (a.m_dev) a.debug |= 8;      // only the 128x128 kernel reads the device-side row count
     if (!(a.debug & (8 | 4096 | 8192 | (1 << 30))) && mm_gemm_wide_eligible(a)) return mm_gemm_wide_launch(a, stream);      // (bit 1 << 30: A/B against the older kernels)

@@ -208,6 +208,7 @@ __device__ __forceinline__ float max4_w(float a, float b, float c, float d) {   
 
 constexpr int SMEM_F = SMEM + 1024;      // + the tile's per-token bounds
 
+template <bool F16>      // F16: the operands are fp16 terms ('f16x2' tier) -> the fp16 MFMA, accumulators scaled by p.alpha before the emission
 __global__ __launch_bounds__(512) void gemm_wide_fused_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x, lane = t & 63;
@@ -282,9 +283,16 @@ __global__ __launch_bounds__(512) void gemm_wide_fused_kernel(const GemmArgs p) 
                 for (int b = 0; b < 8; ++b) {
                     const u32x4_t xf = *reinterpret_cast<const u32x4_t*>(xs + sw128(b * 16 + fr, ks * 4 + fg));
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) acc[a][b] = mfma16(wf[a], xf, acc[a][b]);
+                    for (int a = 0; a < 4; ++a) acc[a][b] = mfma16t<F16>(wf[a], xf, acc[a][b]);
                 }
             }
+        }
+        if constexpr (F16) {      // undo the power-of-two scale of the packed weight terms (exact) before statistics and candidates
+            const float al = p.alpha;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 8; ++b) acc[a][b] *= al;
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();            // everybody is done with stage 1: it becomes the exchange area
@@ -425,6 +433,7 @@ int wide_nfw(const GemmArgs& a) {
 // dense bf16-output GEMMs without bias / activation / residual (plain or GEGLU with optional LayerNorm partial sums), K % 64 == 0, N % 256 == 0 (or % 192, plain
 // only), 16-byte aligned rows, and a tile count that fills the last round of CUs to >= 90 % (a coarse tile loses the remainder)
 bool mm_gemm_wide_eligible(const GemmArgs& a) {
+    if (a.f16) return false;
     if (a.mode != MODE_DENSE || a.bias || a.act != ACT_NONE || a.resid_bf16 || a.resid_f32 || a.out_kind != OUT_BF16 || a.fs_stats || a.m_dev) return false;
     if (a.epi != EPI_NONE && a.epi != EPI_GEGLU) return false;
     if ((a.K % 64) || a.K < 128 || (a.ldx % 8) || (a.ldw % 8) || (a.ldc % 8) || (((uintptr_t)a.out) & 15)) return false;
@@ -441,14 +450,20 @@ bool mm_gemm_wide_fused_eligible(const GemmArgs& a) {
 int mm_gemm_wide_fused_launch(GemmArgs a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_F);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_F);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_F);
         if (e != hipSuccess) return mm_set_hip_error(e, "gemm_wide_fused hipFuncSetAttribute");
         attr_set = true;
     }
     a.tiles_m = (a.M + TM - 1) / TM;
     a.tiles_n = a.N / TN;
     const int total = a.tiles_m * a.tiles_n;
-    hipLaunchKernelGGL(gemm_wide_fused_kernel, dim3(total < 256 ? total : 256), dim3(512), SMEM_F, stream, a);
+    if (a.f16) {
+        if (a.alpha == 0.f) a.alpha = 1.f;
+        hipLaunchKernelGGL(gemm_wide_fused_kernel<true>, dim3(total < 256 ? total : 256), dim3(512), SMEM_F, stream, a);
+    } else {
+        hipLaunchKernelGGL(gemm_wide_fused_kernel<false>, dim3(total < 256 ? total : 256), dim3(512), SMEM_F, stream, a);
+    }
     return mm_check_launch("gemm_wide_fused_kernel");
 }
 

@@ -65,7 +65,11 @@ struct mm_transformer {
     int F8;   // fp8 engine (mm_transformer_desc.fp8): the layers' Linear weights are e4m3 rows + per-row scales, their activations are quantised per token
               // row by the producing kernel (fp8_act.hip), the products run on the K = 128 fp8 MFMA (gemm_fp8.hip); attention, to_logits, sampling: bf16 engine
     int P;    // 0: bf16 engine.  3 / 5 / 6: the 'bf16x3' precision tier (split.hip) -- every GEMM operand is P bf16 segments of an fp32 value, the
-              // weights are packed to match ([N][P*K]), tables / q|k|v / GEMM outputs are fp32, attention runs on the fp32 MFMA (attention_f32.hip)
+              // weights are packed to match ([N][P*K]), tables / q|k|v / GEMM outputs are fp32, attention runs on the fp32 MFMA (attention_f32.hip).
+              // 2 / 3 with F16: the 'f16x2' tier -- the same engine on fp16 terms (two per value) and the fp16 MFMA
+    int PC;   // the operand code the row producers take: P, or MM_SPLIT_F16 | P
+    int F16;  // fp16 terms
+    float alpha;   // fp16 terms: inverse of the power-of-two scale of the packed weight terms (mm_transformer_desc.split_alpha), applied to every accumulator
 };
 
 namespace {
@@ -132,6 +136,20 @@ __global__ void critic_scores_kernel(const float* __restrict__ critic, const flo
         scores[i] = __fadd_rn(critic[i], __fmul_rn(__fmul_rn(__fadd_rn(u[i], -0.5f), noise_scale), ratio));
 }
 
+// 'f16x2' tier: bf16 view of the leading (h) fp16 term of operand rows -- what the fused sampler's bound estimate (k_fused_threshold, a bf16 MFMA product) reads;
+// an estimate that the finishing kernel verifies, so bf16 is all it needs
+__global__ void f16_rows_to_bf16_kernel(const bf16_t* __restrict__ src, long ld, long rows, int D, bf16_t* __restrict__ out) {
+    const int chunks = D >> 2;
+    const long total = rows * chunks;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / chunks;
+        const int c = (int)(i - r * chunks) * 4;
+        const uint2 a = *reinterpret_cast<const uint2*>(src + r * ld + c);
+        *reinterpret_cast<uint2*>(out + r * D + c) = make_uint2(pack_bf16x2(f16_bits_to_f32((uint16_t)a.x), f16_bits_to_f32((uint16_t)(a.x >> 16))),
+                                                                 pack_bf16x2(f16_bits_to_f32((uint16_t)a.y), f16_bits_to_f32((uint16_t)(a.y >> 16))));
+    }
+}
+
 __global__ void fill_i64_kernel(int64_t* p, long n, int64_t v) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -157,11 +175,12 @@ struct Carver {
         if (_rc) return _rc; \
     } while (0)
 
-int gemm_dense(hipStream_t s, const bf16_t* X, int ldx, const bf16_t* W, int ldw, int M, int N, int K, void* out, long ldc,
+int gemm_dense(const mm_transformer* t, hipStream_t s, const bf16_t* X, int ldx, const bf16_t* W, int ldw, int M, int N, int K, void* out, long ldc,
                int out_kind, const float* resid) {
     GemmArgs a;
     memset(&a, 0, sizeof(a));
     a.mode = MODE_DENSE;
+    a.f16 = t->F16; a.alpha = t->alpha;      // 'f16x2' tier: fp16 term operands (every GEMM of such a model)
     a.W = W; a.N = N; a.ldw = ldw; a.K = K; a.M = M; a.X = X; a.ldx = ldx;
     a.out = out; a.ldc = ldc; a.out_kind = out_kind; a.resid_f32 = resid; a.ldr = ldc;
     return mm_gemm_launch(a, s);
@@ -221,11 +240,11 @@ int ff_block(const mm_transformer* t, hipStream_t s, const mm_ff_weights& w, con
     const int D = t->d.dim, F = t->d.ff_inner, Fp = t->Fp;
     if (t->P) {      // precision tier: LN -> P segments -> w1 (fp32 out, plain [x | gate] halves) -> GEGLU + LN(inner) -> P segments -> w2 + residual
         const int P = t->P;
-        RC(k_layernorm_split(s, addvec ? dst : src, D, rows, D, w.ln1_gamma, w.ln1_beta, nullptr, P, b.xn, nullptr, addvec, add_from, addvec ? dst : nullptr));
+        RC(k_layernorm_split(s, addvec ? dst : src, D, rows, D, w.ln1_gamma, w.ln1_beta, nullptr, t->PC, b.xn, nullptr, addvec, add_from, addvec ? dst : nullptr));
         float* hf = reinterpret_cast<float*>(b.h);
-        RC(gemm_dense(s, b.xn, P * D, (const bf16_t*)w.w1, P * D, rows, 2 * Fp, P * D, hf, 2 * Fp, OUT_F32, nullptr));
-        RC(k_geglu_ln_split(s, hf, 2 * Fp, rows, F, Fp, w.ln2_gamma, w.ln2_beta, P, b.a));
-        RC(gemm_dense(s, b.a, P * Fp, (const bf16_t*)w.w2, P * Fp, rows, D, P * Fp, dst, D, OUT_F32, dst));
+        RC(gemm_dense(t, s, b.xn, P * D, (const bf16_t*)w.w1, P * D, rows, 2 * Fp, P * D, hf, 2 * Fp, OUT_F32, nullptr));
+        RC(k_geglu_ln_split(s, hf, 2 * Fp, rows, F, Fp, w.ln2_gamma, w.ln2_beta, t->PC, b.a));
+        RC(gemm_dense(t, s, b.a, P * Fp, (const bf16_t*)w.w2, P * Fp, rows, D, P * Fp, dst, D, OUT_F32, dst));
         TR(dst, (size_t)rows * D * 4);
         return MM_OK;
     }
@@ -282,22 +301,22 @@ int self_attn_core(const mm_transformer* t, hipStream_t s, const mm_attn_weights
     const int rows = seqs * n;
     if (t->P) {      // precision tier: q|k|v stay fp32, the attention runs on the fp32 MFMA and writes its output as P segments
         const int P = t->P;
-        RC(k_layernorm_split(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, P, b.xn, nullptr, nullptr, 0, nullptr));
+        RC(k_layernorm_split(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, t->PC, b.xn, nullptr, nullptr, 0, nullptr));
         const bf16_t* wq = (const bf16_t*)w.w_q;
         const bf16_t* wkv = (const bf16_t*)w.w_kv;
         float* qkv = reinterpret_cast<float*>(b.qkv);
         if (wkv == wq + (size_t)I * P * D) {
-            RC(gemm_dense(s, b.xn, P * D, wq, P * D, rows, 3 * I, P * D, qkv, 3 * I, OUT_F32, nullptr));
+            RC(gemm_dense(t, s, b.xn, P * D, wq, P * D, rows, 3 * I, P * D, qkv, 3 * I, OUT_F32, nullptr));
         } else {
-            RC(gemm_dense(s, b.xn, P * D, wq, P * D, rows, I, P * D, qkv, 3 * I, OUT_F32, nullptr));
-            RC(gemm_dense(s, b.xn, P * D, wkv, P * D, rows, 2 * I, P * D, qkv + I, 3 * I, OUT_F32, nullptr));
+            RC(gemm_dense(t, s, b.xn, P * D, wq, P * D, rows, I, P * D, qkv, 3 * I, OUT_F32, nullptr));
+            RC(gemm_dense(t, s, b.xn, P * D, wkv, P * D, rows, 2 * I, P * D, qkv + I, 3 * I, OUT_F32, nullptr));
         }
         AttnF32Args a;
         memset(&a, 0, sizeof(a));
         a.q = qkv; a.q_sb = (long)n * 3 * I; a.q_sh = dh; a.q_sn = 3 * I;
         a.k = qkv + I; a.k_sb = a.q_sb; a.k_sh = dh; a.k_sn = 3 * I;
         a.v = qkv + 2 * I; a.v_sb = a.q_sb; a.v_sh = dh; a.v_sn = 3 * I;
-        a.out_split = b.att; a.os_sb = (long)n * P * I; a.os_sn = (long)P * I; a.os_seg = I; a.P = P;
+        a.out_split = b.att; a.os_sb = (long)n * P * I; a.os_sn = (long)P * I; a.os_seg = I; a.P = t->PC;
         a.B = seqs; a.H = H; a.nq = n; a.nk = n;
         a.normalize = 1; a.q_scale = w.q_scale; a.k_scale = w.k_scale; a.null_k = w.null_k; a.null_v = w.null_v;
         a.scale = 8.f; a.dh = dh;
@@ -318,10 +337,10 @@ int self_attn_core(const mm_transformer* t, hipStream_t s, const mm_attn_weights
     RC(k_layernorm(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, b.xn, D));
     TR(b.xn, (size_t)rows * D * 2);
     if (wkv == wq + (size_t)I * D) {
-        RC(gemm_dense(s, b.xn, D, wq, D, rows, 3 * I, D, b.qkv, 3 * I, OUT_BF16, nullptr));
+        RC(gemm_dense(t, s, b.xn, D, wq, D, rows, 3 * I, D, b.qkv, 3 * I, OUT_BF16, nullptr));
     } else {
-        RC(gemm_dense(s, b.xn, D, wq, D, rows, I, D, b.qkv, 3 * I, OUT_BF16, nullptr));
-        RC(gemm_dense(s, b.xn, D, wkv, D, rows, 2 * I, D, b.qkv + I, 3 * I, OUT_BF16, nullptr));
+        RC(gemm_dense(t, s, b.xn, D, wq, D, rows, I, D, b.qkv, 3 * I, OUT_BF16, nullptr));
+        RC(gemm_dense(t, s, b.xn, D, wkv, D, rows, 2 * I, D, b.qkv + I, 3 * I, OUT_BF16, nullptr));
     }
     }
     AttnArgs a;
@@ -344,7 +363,7 @@ int self_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weight
     RC(self_attn_core(t, s, w, seqs, n, b));
     const int KI = (t->P ? t->P : 1) * t->I;      // precision tier: P segments per operand row
     if (t->F8) RC(f8_linear_bf16(s, b, b.att, t->I, t->I, w.w_out, w.w_out_scale, seqs * n, t->d.dim, b.x, t->d.dim, 2, b.x));
-    else RC(gemm_dense(s, b.att, KI, (const bf16_t*)w.w_out, KI, seqs * n, t->d.dim, KI, b.x, t->d.dim, OUT_F32, b.x));
+    else RC(gemm_dense(t, s, b.att, KI, (const bf16_t*)w.w_out, KI, seqs * n, t->d.dim, KI, b.x, t->d.dim, OUT_F32, b.x));
     TR(b.x, (size_t)seqs * n * t->d.dim * 4);
     return MM_OK;
 }
@@ -356,22 +375,22 @@ int cross_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weigh
     const int rows = seqs * n;
     if (t->P) {      // precision tier: ckv is fp32 [kv_seqs*m][2I]
         const int P = t->P;
-        RC(k_layernorm_split(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, P, b.xn, nullptr, nullptr, 0, nullptr));
+        RC(k_layernorm_split(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, t->PC, b.xn, nullptr, nullptr, 0, nullptr));
         float* q = reinterpret_cast<float*>(b.qkv);
-        RC(gemm_dense(s, b.xn, P * D, (const bf16_t*)w.w_q, P * D, rows, I, P * D, q, I, OUT_F32, nullptr));
+        RC(gemm_dense(t, s, b.xn, P * D, (const bf16_t*)w.w_q, P * D, rows, I, P * D, q, I, OUT_F32, nullptr));
         const float* kv = reinterpret_cast<const float*>(ckv);
         AttnF32Args a;
         memset(&a, 0, sizeof(a));
         a.q = q; a.q_sb = (long)n * I; a.q_sh = dh; a.q_sn = I;
         a.k = kv; a.k_sb = (long)m * 2 * I; a.k_sh = dh; a.k_sn = 2 * I;
         a.v = kv + I; a.v_sb = a.k_sb; a.v_sh = dh; a.v_sn = 2 * I;
-        a.out_split = b.att; a.os_sb = (long)n * P * I; a.os_sn = (long)P * I; a.os_seg = I; a.P = P;
+        a.out_split = b.att; a.os_sb = (long)n * P * I; a.os_sn = (long)P * I; a.os_seg = I; a.P = t->PC;
         a.B = seqs; a.H = H; a.nq = n; a.nk = m;
         a.key_mask = key_mask; a.km_sb = m;
         a.normalize = 1; a.q_scale = w.q_scale; a.k_scale = w.k_scale; a.null_k = w.null_k; a.null_v = w.null_v;
         a.scale = 8.f; a.dh = dh; a.kv_batch_mod = kv_batch_mod;
         RC(k_attention_f32(s, a));
-        RC(gemm_dense(s, b.att, P * I, (const bf16_t*)w.w_out, P * I, rows, D, P * I, b.x, D, OUT_F32, b.x));
+        RC(gemm_dense(t, s, b.att, P * I, (const bf16_t*)w.w_out, P * I, rows, D, P * I, b.x, D, OUT_F32, b.x));
         TR(b.x, (size_t)rows * D * 4);
         return MM_OK;
     }
@@ -381,7 +400,7 @@ int cross_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weigh
     } else {
         RC(k_layernorm(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, b.xn, D));
         TR(b.xn, (size_t)rows * D * 2);
-        RC(gemm_dense(s, b.xn, D, (const bf16_t*)w.w_q, D, rows, I, D, b.qkv, I, OUT_BF16, nullptr));
+        RC(gemm_dense(t, s, b.xn, D, (const bf16_t*)w.w_q, D, rows, I, D, b.qkv, I, OUT_BF16, nullptr));
     }
     TR(b.qkv, (size_t)rows * I * 2);
     AttnArgs a;
@@ -397,7 +416,7 @@ int cross_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weigh
     RC(k_attention(s, a));
     TR(b.att, (size_t)rows * I * 2);
     if (t->F8) RC(f8_linear_bf16(s, b, b.att, I, I, w.w_out, w.w_out_scale, rows, D, b.x, D, 2, b.x));
-    else RC(gemm_dense(s, b.att, I, (const bf16_t*)w.w_out, I, rows, D, I, b.x, D, OUT_F32, b.x));
+    else RC(gemm_dense(t, s, b.att, I, (const bf16_t*)w.w_out, I, rows, D, I, b.x, D, OUT_F32, b.x));
     TR(b.x, (size_t)rows * D * 4);
     return MM_OK;
 }
@@ -422,8 +441,9 @@ int mm_transformer_create(const mm_transformer_desc* desc, mm_transformer_t** ou
     if (d.text_proj && (d.text_dim % 64)) return mm_set_error(MM_ERR_SHAPE, "transformer: text_dim must be a multiple of 64 when projected");
     if (!d.text_proj && d.text_dim != d.dim) return mm_set_error(MM_ERR_SHAPE, "transformer: text_proj is NULL but text_dim != dim");
     if (!d.token_emb || !d.pos_emb || !d.to_logits || !d.final_gamma) return mm_set_error(MM_ERR_SHAPE, "transformer: missing weight pointer");
-    if (d.split_products != 0 && d.split_products != 3 && d.split_products != 5 && d.split_products != 6)
-        return mm_set_error(MM_ERR_SHAPE, "transformer: split_products must be 0 (bf16 engine), 3, 5 or 6 (precision tier)");
+    if (d.split_products != 0 && d.split_products != 3 && d.split_products != 5 && d.split_products != 6 && d.split_products != (MM_SPLIT_F16 | 2) &&
+        d.split_products != (MM_SPLIT_F16 | 3))
+        return mm_set_error(MM_ERR_SHAPE, "transformer: split_products must be 0 (bf16 engine), 3, 5, 6 (bf16 terms) or MM_SPLIT_F16 | 2, 3 (fp16 terms)");
     mm_transformer* t = new (std::nothrow) mm_transformer();
     if (!t) return mm_set_error(MM_ERR_HIP, "out of host memory");
     t->d = d;
@@ -431,7 +451,10 @@ int mm_transformer_create(const mm_transformer_desc* desc, mm_transformer_t** ou
     t->d.layers = t->layers.data();
     t->I = d.heads * d.dim_head;
     t->Fp = d.ff_inner_padded;
-    t->P = d.split_products;
+    t->P = split_count(d.split_products);
+    t->PC = d.split_products;
+    t->F16 = split_is_f16(d.split_products) ? 1 : 0;
+    t->alpha = (t->F16 && d.split_alpha != 0.f) ? d.split_alpha : 1.f;
     t->F8 = d.fp8 ? 1 : 0;
     if (t->F8) {
         bool ok = t->P == 0 && (d.dim % 128) == 0 && (t->I % 128) == 0 && (t->Fp % 128) == 0;
@@ -477,17 +500,17 @@ int mm_transformer_context(const mm_transformer_t* t, mm_stream_t stream, const 
         const int P = t->P, td = t->d.text_dim;
         if (L > 0) {
             if (!t->d.text_proj) {
-                RC(k_split_rows(s, text_embeds, td, (long)B * L, td, P, L, (long)m * P * D, ctxp, key_mask, m, drop_text));
+                RC(k_split_rows(s, text_embeds, td, (long)B * L, td, t->PC, L, (long)m * P * D, ctxp, key_mask, m, drop_text));
             } else {
                 Carver c(workspace);
                 bf16_t* tb = c.take<bf16_t>((size_t)B * L * td * P);
                 float* proj = reinterpret_cast<float*>(c.take<bf16_t>((size_t)B * L * D * 2));
-                RC(k_split_rows(s, text_embeds, td, (long)B * L, td, P, L, (long)L * P * td, tb, key_mask, m, drop_text));
-                RC(gemm_dense(s, tb, P * td, (const bf16_t*)t->d.text_proj, P * td, B * L, D, P * td, proj, D, OUT_F32, nullptr));
-                RC(k_split_rows(s, proj, D, (long)B * L, D, P, L, (long)m * P * D, ctxp, nullptr, 0, 0));
+                RC(k_split_rows(s, text_embeds, td, (long)B * L, td, t->PC, L, (long)L * P * td, tb, key_mask, m, drop_text));
+                RC(gemm_dense(t, s, tb, P * td, (const bf16_t*)t->d.text_proj, P * td, B * L, D, P * td, proj, D, OUT_F32, nullptr));
+                RC(k_split_rows(s, proj, D, (long)B * L, D, t->PC, L, (long)m * P * D, ctxp, nullptr, 0, 0));
             }
         }
-        if (nc > 0) RC(k_gather_split(s, (const float*)t->d.token_emb, D, P, cond_ids, B, nc, t->d.vocab_rows, ctxp, key_mask, m, L));
+        if (nc > 0) RC(k_gather_split(s, (const float*)t->d.token_emb, D, t->PC, cond_ids, B, nc, t->d.vocab_rows, ctxp, key_mask, m, L));
         return MM_OK;
     }
     if (L > 0) {
@@ -502,7 +525,7 @@ int mm_transformer_context(const mm_transformer_t* t, mm_stream_t stream, const 
             hipLaunchKernelGGL(text_context_kernel, dim3((B * L + 3) / 4), dim3(256), 0, s, text_embeds, B, L, t->d.text_dim, tb,
                                L, (long)t->d.text_dim, key_mask, m, drop_text);
             RC(mm_check_launch("text_context_kernel"));
-            RC(gemm_dense(s, tb, t->d.text_dim, (const bf16_t*)t->d.text_proj, t->d.text_dim, B * L, D, t->d.text_dim, proj, D,
+            RC(gemm_dense(t, s, tb, t->d.text_dim, (const bf16_t*)t->d.text_proj, t->d.text_dim, B * L, D, t->d.text_dim, proj, D,
                           OUT_BF16, nullptr));
             const hipError_t e = hipMemcpy2DAsync(ctxp, (size_t)m * D * 2, proj, (size_t)L * D * 2, (size_t)L * D * 2, B,
                                                   hipMemcpyDeviceToDevice, s);
@@ -557,16 +580,16 @@ int mm_transformer_forward(const mm_transformer_t* t, mm_stream_t stream, const 
     for (int l = 0; l < t->d.depth; ++l) {
         const mm_layer_weights& w = t->layers[l];
         RC(self_attn_block(t, s, w.self_attn, B, n, b));
-        RC(gemm_dense(s, (const bf16_t*)ctx, KD, (const bf16_t*)w.cross_attn.w_kv, KD, B * m, 2 * I, KD, ckv, 2 * I, P ? OUT_F32 : OUT_BF16, nullptr));
+        RC(gemm_dense(t, s, (const bf16_t*)ctx, KD, (const bf16_t*)w.cross_attn.w_kv, KD, B * m, 2 * I, KD, ckv, 2 * I, P ? OUT_F32 : OUT_BF16, nullptr));
         TR(ckv, (size_t)B * m * 2 * I * 2);
         RC(cross_attn_block(t, s, w.cross_attn, B, n, ckv, m, 0, key_mask, b));
         RC(ff_block(t, s, w.ff, b.x, b.x, rows, b));
     }
-    if (P) RC(k_layernorm_split(s, b.x, D, rows, D, t->d.final_gamma, t->d.final_beta, nullptr, P, emb, nullptr, nullptr, 0, nullptr));
+    if (P) RC(k_layernorm_split(s, b.x, D, rows, D, t->d.final_gamma, t->d.final_beta, nullptr, t->PC, emb, nullptr, nullptr, 0, nullptr));
     else RC(k_layernorm(s, b.x, D, rows, D, t->d.final_gamma, t->d.final_beta, nullptr, emb, D));
     TR(emb, (size_t)rows * D * 2);
     if (logits_out)
-        RC(gemm_dense(s, emb, KD, (const bf16_t*)t->d.to_logits, KD, rows, t->d.dim_out, KD, logits_out, t->d.dim_out, OUT_F32, nullptr));
+        RC(gemm_dense(t, s, emb, KD, (const bf16_t*)t->d.to_logits, KD, rows, t->d.dim_out, KD, logits_out, t->d.dim_out, OUT_F32, nullptr));
     return MM_OK;
 }
 
@@ -589,6 +612,7 @@ struct GenBufs {
     bf16_t* embc;           // [B*n][D]
     bf16_t* embn;           // [B*n][D]
     bf16_t* embm;           // [B*n][D]: null + (cond - null) * cond_scale of the two passes' embeddings -- the ONE operand of the guidance-logits GEMM
+    bf16_t* embb;           // [B*n][D] ('f16x2' tier only): bf16 view of embm's leading term for the bound estimate
     float* logits;          // [B*n][V]
     float* xc;              // [2*B*n][D]: the last layer's residual stream, compacted to the sampled rows
     bf16_t* attc;           // [2*B*n][I]
@@ -642,6 +666,7 @@ void carve_gen(Carver& c, const mm_transformer* t, int B, int n, int L, int nc, 
     g.embc = c.take<bf16_t>((size_t)B * n * D * seg);
     g.embn = c.take<bf16_t>((size_t)B * n * D * seg);
     g.embm = c.take<bf16_t>((size_t)B * n * D * seg);
+    g.embb = c.take<bf16_t>(t->F16 ? (size_t)B * n * D : 0);
     g.logits = c.take<float>((size_t)B * n * t->d.dim_out);
     g.xc = c.take<float>((size_t)2 * B * n * D);
     g.attc = c.take<bf16_t>((size_t)2 * B * n * I * seg);
@@ -741,7 +766,7 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
     const mm_transformer* cmodel = critic ? critic : (self_critic ? t : nullptr);      // the network the critic scores come from
     if (critic && self_critic) return mm_set_error(MM_ERR_SHAPE, "generate: token critic and self critic are exclusive (mmp.py:456)");
     if (critic && critic->d.dim_out != 1) return mm_set_error(MM_ERR_SHAPE, "generate: the token critic must have dim_out == 1");
-    if (critic && critic->P != t->P) return mm_set_error(MM_ERR_SHAPE, "generate: the token critic must be packed for the same precision tier as the generator");
+    if (critic && critic->PC != t->PC) return mm_set_error(MM_ERR_SHAPE, "generate: the token critic must be packed for the same precision tier as the generator");
     if (cmodel) {
         if (!p->critic_noise) return mm_set_error(MM_ERR_SHAPE, "generate: critic_noise [timesteps][B][n] required with a critic");
         if (self_critic && !p->critic_head_b) return mm_set_error(MM_ERR_SHAPE, "generate: critic_head_b required with critic_head_w");
@@ -775,14 +800,14 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
     for (int l = 0; l < t->d.depth; ++l) {
         const mm_attn_weights& w = t->layers[l].cross_attn;
         bf16_t* ckv_l = g.ckv + (size_t)l * B * m * 2 * I * (PT ? 2 : 1);
-        RC(gemm_dense(s, g.ctx, KD, (const bf16_t*)w.w_kv, KD, B * m, 2 * I, KD, ckv_l, 2 * I, PT ? OUT_F32 : OUT_BF16, nullptr));
+        RC(gemm_dense(t, s, g.ctx, KD, (const bf16_t*)w.w_kv, KD, B * m, 2 * I, KD, ckv_l, 2 * I, PT ? OUT_F32 : OUT_BF16, nullptr));
         if (nc == 0 && P == 2) {
             // softmax over the single unmasked (null) key is exactly 1 -> attention out = bf16(null_v) for every
             // query, so the null pass's cross-attention is the constant row to_out(null_v)
-            if (PT) RC(k_split_rows(s, w.null_v, I, 1, I, PT, 0, 0, g.nullv, nullptr, 0, 0));
+            if (PT) RC(k_split_rows(s, w.null_v, I, 1, I, t->PC, 0, 0, g.nullv, nullptr, 0, 0));
             else RC(k_f32_to_bf16(s, w.null_v, g.nullv, I));
             if (t->F8) RC(f8_linear_bf16(s, g.b, g.nullv, I, I, w.w_out, w.w_out_scale, 1, D, g.cvec + (size_t)l * D, D, 2, nullptr));
-            else RC(gemm_dense(s, g.nullv, KI, (const bf16_t*)w.w_out, KI, 1, D, KI, g.cvec + (size_t)l * D, D, OUT_F32, nullptr));
+            else RC(gemm_dense(t, s, g.nullv, KI, (const bf16_t*)w.w_out, KI, 1, D, KI, g.cvec + (size_t)l * D, D, OUT_F32, nullptr));
         }
     }
     {
@@ -855,7 +880,7 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
                     RC(k_gather_rows16(s, b.att, (long)KI * 2, g.rows, R, h * M, KI * 2, g.attc + (size_t)h * R * KI));
                 }
                 if (t->F8) RC(f8_linear_bf16(s, b, g.attc, I, I, w.self_attn.w_out, w.self_attn.w_out_scale, P * R, D, g.xc, D, 2, g.xc));
-                else RC(gemm_dense(s, g.attc, KI, (const bf16_t*)w.self_attn.w_out, KI, P * R, D, KI, g.xc, D, OUT_F32, g.xc));
+                else RC(gemm_dense(t, s, g.attc, KI, (const bf16_t*)w.self_attn.w_out, KI, P * R, D, KI, g.xc, D, OUT_F32, g.xc));
                 bc.x = g.xc; bc.att = g.attc;
             } else if (l == 0 && share0) {
                 RC(self_attn_block(t, s, w.self_attn, B, n, b));
@@ -877,13 +902,13 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
             const float* fg = t->d.final_gamma;
             const float* fb = t->d.final_beta;
             if (compact_last) {
-                RC(k_layernorm_split(s, g.xc, D, R, D, fg, fb, nullptr, PT, g.embc, nullptr, nullptr, 0, nullptr));
-                if (P == 2) RC(k_layernorm_split(s, g.xc + (size_t)R * D, D, R, D, fg, fb, nullptr, PT, g.embn, nullptr, nullptr, 0, nullptr));
+                RC(k_layernorm_split(s, g.xc, D, R, D, fg, fb, nullptr, t->PC, g.embc, nullptr, nullptr, 0, nullptr));
+                if (P == 2) RC(k_layernorm_split(s, g.xc + (size_t)R * D, D, R, D, fg, fb, nullptr, t->PC, g.embn, nullptr, nullptr, 0, nullptr));
             } else {
                 if (self_cond)      // the cond pass's fp32 embed at every position is the next step's self-conditioning input (mmp.py:574)
-                    RC(k_layernorm_split(s, b.x, D, M, D, fg, fb, nullptr, PT, nullptr, g.sce, nullptr, 0, nullptr));
-                RC(k_layernorm_split(s, b.x, D, R, D, fg, fb, rows, PT, g.embc, nullptr, nullptr, 0, nullptr));
-                if (P == 2) RC(k_layernorm_split(s, b.x + (size_t)M * D, D, R, D, fg, fb, rows, PT, g.embn, nullptr, nullptr, 0, nullptr));
+                    RC(k_layernorm_split(s, b.x, D, M, D, fg, fb, nullptr, t->PC, nullptr, g.sce, nullptr, 0, nullptr));
+                RC(k_layernorm_split(s, b.x, D, R, D, fg, fb, rows, t->PC, g.embc, nullptr, nullptr, 0, nullptr));
+                if (P == 2) RC(k_layernorm_split(s, b.x + (size_t)M * D, D, R, D, fg, fb, rows, t->PC, g.embn, nullptr, nullptr, 0, nullptr));
             }
         } else if (compact_last) {
             RC(k_layernorm(s, g.xc, D, R, D, t->d.final_gamma, t->d.final_beta, nullptr, g.embc, D));
@@ -906,7 +931,7 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
         // loop's dominant GEMM; the general path (Transformer.forward_with_cond_scale) does the same, so the two stay bit-identical.
         const bf16_t* emb_in = g.embc;
         if (!single) {
-            RC(k_cfg_mix(s, g.embc, g.embn, KD, R, D, PT, p->cond_scale, g.embm));
+            RC(k_cfg_mix(s, g.embc, g.embn, KD, R, D, t->PC, p->cond_scale, g.embm));
             emb_in = g.embm;
         }
         GemmArgs a;
@@ -916,13 +941,26 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
         a.M = R; a.X = emb_in; a.ldx = KD;
         a.out = g.logits; a.ldc = V; a.out_kind = OUT_F32;
         a.debug = g_mm_debug;
+        a.f16 = t->F16; a.alpha = t->alpha;
         // Sampling without the logits round trip: the GEMM emits tile statistics + the candidates above a per-row lower bound of the k-th largest
         // logit (estimated from the row's embeddings and the vocabulary statistics of to_logits), the finishing kernel verifies the bound.
-        const bool fused = t->d.logits_wcov && t->d.logits_wmean && p->status && !(p->flags & MM_GEN_NO_FUSED_SAMPLING) && (V % 256) == 0 &&
-                           !(g_mm_debug & (8 | 4096 | 8192 | (1 << 25))) && mm_gemm_cfg2_eligible(a);
+        bool fused = t->d.logits_wcov && t->d.logits_wmean && p->status && !(p->flags & MM_GEN_NO_FUSED_SAMPLING) && (V % 256) == 0 &&
+                     !(g_mm_debug & (8 | 4096 | 8192 | (1 << 25))) && mm_gemm_cfg2_eligible(a);
+        if (fused && t->F16) {      // fp16 terms: the emission exists on the 256 x 256 kernel only (>= 1024 rows); smaller steps take the logits path
+            GemmArgs probe = a;
+            probe.fs_thr = g.fs_thr; probe.fs_stats = g.fs_stats; probe.fs_cand = g.fs_cand;
+            fused = mm_gemm_wide_fused_eligible(probe) && !(g_mm_debug & ((1 << 26) | (1 << 28) | (1 << 30)));
+        }
         const double gemm_flops = 2.0 * (double)R * (double)V * (double)KD;      // EXECUTED bf16 MFMA flops: one pass over the mixed rows (x the term products in the precision tier)
         if (fused) {
-            RC(k_fused_threshold(s, emb_in, emb_in, KD, R, D, 1.f, t->d.logits_wmean, (const bf16_t*)t->d.logits_wcov, k_fused_z(p->k_keep, V, FS_MARGIN),
+            const bf16_t* emb_est = emb_in;      // the rows the bound is estimated from: bf16 (the leading bf16 term in the 'bf16x3' tier)
+            long ld_est = KD;
+            if (t->F16) {
+                hipLaunchKernelGGL(f16_rows_to_bf16_kernel, dim3(1024), dim3(256), 0, s, emb_in, (long)KD, (long)R, D, g.embb);
+                RC(mm_check_launch("f16_rows_to_bf16_kernel"));
+                emb_est = g.embb; ld_est = D;
+            }
+            RC(k_fused_threshold(s, emb_est, emb_est, ld_est, R, D, 1.f, t->d.logits_wmean, (const bf16_t*)t->d.logits_wcov, k_fused_z(p->k_keep, V, FS_MARGIN),
                                  g.fs_ws, g.fs_thr));
             a.out = nullptr;
             a.fs_thr = g.fs_thr; a.fs_stats = g.fs_stats; a.fs_cand = g.fs_cand;
@@ -954,6 +992,7 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
                 fg.mode = MODE_DENSE;
                 fg.W = (const bf16_t*)t->d.to_logits; fg.N = V; fg.ldw = KD; fg.K = KD; fg.M = FB_CAP; fg.X = g.fb_x; fg.ldx = KD;
                 fg.out = g.fb_logits; fg.ldc = V; fg.out_kind = OUT_F32; fg.m_dev = g.fb_cnt + step;
+                fg.f16 = t->F16; fg.alpha = t->alpha;
                 RC(mm_gemm_launch(fg, s));
                 SampleArgs fs_;
                 memset(&fs_, 0, sizeof(fs_));
@@ -994,14 +1033,14 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
                 RC(mm_transformer_forward(critic, stream, p->ids, B, n, cb.ctx, cb.masks, m, nullptr, cb.embc, nullptr, cb.fwd_ws, cb.fwd_ws_bytes));
                 const int Dc = (critic->P ? critic->P : 1) * critic->d.dim;      // operand row width of the critic's head
                 if (single) {
-                    RC(gemm_dense(s, cb.embc, Dc, (const bf16_t*)critic->d.to_logits, Dc, M, 1, Dc, cb.sc, 1, OUT_F32, nullptr));
+                    RC(gemm_dense(critic, s, cb.embc, Dc, (const bf16_t*)critic->d.to_logits, Dc, M, 1, Dc, cb.sc, 1, OUT_F32, nullptr));
                 } else {
                     RC(mm_transformer_forward(critic, stream, p->ids, B, n, cb.ctx, cb.masks + (size_t)B * m, m, nullptr, cb.embn, nullptr, cb.fwd_ws,
                                               cb.fwd_ws_bytes));
                     // guidance in the embedding, like the generator's logits (and like TokenCritic.forward_with_cond_scale on the general path):
                     // mix the two passes' embeddings (in place over the null pass's), then the 1-wide head once
-                    RC(k_cfg_mix(s, cb.embc, cb.embn, Dc, M, critic->d.dim, critic->P, p->cond_scale, cb.embn));
-                    RC(gemm_dense(s, cb.embn, Dc, (const bf16_t*)critic->d.to_logits, Dc, M, 1, Dc, cb.sc, 1, OUT_F32, nullptr));
+                    RC(k_cfg_mix(s, cb.embc, cb.embn, Dc, M, critic->d.dim, critic->PC, p->cond_scale, cb.embn));
+                    RC(gemm_dense(critic, s, cb.embn, Dc, (const bf16_t*)critic->d.to_logits, Dc, M, 1, Dc, cb.sc, 1, OUT_F32, nullptr));
                 }
             } else {             // SelfCritic (mmp.py:352-374): Linear(dim, 1) on the generator's cond-pass embed of the new ids (no self-conditioning input)
                 RC(mm_transformer_forward(t, stream, p->ids, B, n, cb.ctx, cb.masks, m, nullptr, cb.embc, nullptr, cb.fwd_ws, cb.fwd_ws_bytes));
@@ -1011,6 +1050,7 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
                     ha.mode = MODE_DENSE;
                     ha.W = (const bf16_t*)p->critic_head_w; ha.N = 1; ha.ldw = KD; ha.K = KD; ha.M = M; ha.X = cb.embc; ha.ldx = KD;
                     ha.out = cb.sc; ha.ldc = 1; ha.out_kind = OUT_F32; ha.bias = p->critic_head_b;
+                    ha.f16 = t->F16; ha.alpha = t->alpha;
                     RC(mm_gemm_launch(ha, s));
                 } else {
                     RC(mm_conv2d_nhwc(stream, cb.embc, M, 1, 1, D, p->critic_head_w, 1, 1, 1, 1, 0, 0, 1, 1, 1, 0, 0, 1, 1, p->critic_head_b, 0, nullptr, cb.sc, 1));

@@ -42,6 +42,10 @@ struct GemmArgs {
     int wide_tok;                 // MODE_DENSE, fp32 out: request the persistent 128-token x 256-column kernel of gemm_cfg.hip (WIDE_MIX: the guidance logits of
                                   // the MIXED embedding as one pass; takes fs_* like MODE_CFG); falls back to the other kernels when not eligible
     int debug;                    // ablation bits (mm_debug_set): 1 = no epilogue stores, 2 = no DMA after tile 0, 4 = no MFMA, 8 = force the 128x128 kernel, 4096 = no persistent kernel
+    // 'f16x2' precision tier: both operands hold fp16 TERMS (common.h split2_f16) -> v_mfma_f32_16x16x32_f16; the fp32 accumulators are multiplied by
+    // `alpha` (the inverse of the power-of-two scale the weight terms were packed with; 0 = 1) before anything else in the epilogue.  fp32 output only,
+    // dense and convolution modes, on the 128x128 / 256x128 kernels and the fused-sampling logits kernel.
+    int f16; float alpha;
 };
 extern int g_mm_debug;
 

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
     if (row >= rows) return;
     const long b = row / rpb, j = row - b * rpb;
     const float* xr = x + row * ldx;
-    bf16_t* orow = out + b * out_bstride + j * (long)P * K;
+    bf16_t* orow = out + b * out_bstride + j * (long)split_count(P) * K;
     bool nz = false;
     for (int c = lane * 4; c < K; c += 256) {
         const float4 q = *reinterpret_cast<const float4*>(xr + c);
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void gather_split_kernel(const float* __restri
     long id = idx[r];
     id = id < 0 ? 0 : (id >= vocab_rows ? vocab_rows - 1 : id);
     const float* src = table + id * D;
-    bf16_t* orow = ctx + ((long)b * m + L + j) * (long)P * D;
+    bf16_t* orow = ctx + ((long)b * m + L + j) * (long)split_count(P) * D;
     for (int c = lane * 4; c < D; c += 256) {
         const float4 q = *reinterpret_cast<const float4*>(src + c);
         const float v[4] = {q.x, q.y, q.z, q.w};
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
             if (beta) bt = *reinterpret_cast<const float4*>(beta + c * 4);
             const float o[4] = {(v[it].x - mean) * rstd * g.x + bt.x, (v[it].y - mean) * rstd * g.y + bt.y,
                                 (v[it].z - mean) * rstd * g.z + bt.z, (v[it].w - mean) * rstd * g.w + bt.w};
-            if (out) store_split4(out + (long)row * P * D, D, P, c * 4, o);
+            if (out) store_split4(out + (long)row * split_count(P) * D, D, P, c * 4, o);
             if (out_f32) *reinterpret_cast<float4*>(out_f32 + (long)row * D + c * 4) = make_float4(o[0], o[1], o[2], o[3]);
         }
     }
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void geglu_ln_split_kernel(const float* __rest
         }
     }
     const float rstd = 1.f / sqrtf(wave_sum(sq) / (float)F + 1e-5f);
-    bf16_t* orow = out + (long)row * P * Fp;
+    bf16_t* orow = out + (long)row * split_count(P) * Fp;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int c = it * 64 + lane;
@@ -200,6 +200,18 @@ __global__ __launch_bounds__(256) void cfg_mix_kernel(const bf16_t* __restrict__
             const uint2 a = *reinterpret_cast<const uint2*>(ec + r * ld + c), b = *reinterpret_cast<const uint2*>(en + r * ld + c);
             cv[0] = bf16lo(a.x); cv[1] = bf16hi(a.x); cv[2] = bf16lo(a.y); cv[3] = bf16hi(a.y);
             nv[0] = bf16lo(b.x); nv[1] = bf16hi(b.x); nv[2] = bf16lo(b.y); nv[3] = bf16hi(b.y);
+        } else if (split_is_f16(P)) {      // two fp16 terms per value: segments 0 (h) and 1 (l)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const uint2 a = *reinterpret_cast<const uint2*>(ec + r * ld + (long)k * D + c), b = *reinterpret_cast<const uint2*>(en + r * ld + (long)k * D + c);
+                const uint32_t aw[2] = {a.x, a.y}, bw[2] = {b.x, b.y};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float av = f16_bits_to_f32((uint16_t)(aw[j >> 1] >> (16 * (j & 1)))), bv = f16_bits_to_f32((uint16_t)(bw[j >> 1] >> (16 * (j & 1))));
+                    cv[j] = k == 0 ? av : cv[j] + av;
+                    nv[j] = k == 0 ? bv : nv[j] + bv;
+                }
+            }
         } else {
             float t[2][3][4];
 #pragma unroll
@@ -214,18 +226,18 @@ __global__ __launch_bounds__(256) void cfg_mix_kernel(const bf16_t* __restrict__
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = nv[j] + (cv[j] - nv[j]) * s;
         if (P == 0) *reinterpret_cast<uint2*>(out + r * D + c) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
-        else store_split4(out + r * (long)P * D, D, P, c, o);
+        else store_split4(out + r * (long)split_count(P) * D, D, P, c, o);
     }
 }
 
-inline bool bad_p(int P) { return P != 3 && P != 5 && P != 6; }
+inline bool bad_p(int P) { return P != 3 && P != 5 && P != 6 && P != (MM_SPLIT_F16_BIT | 2) && P != (MM_SPLIT_F16_BIT | 3); }      // bf16 terms: 3 / 5 / 6; fp16 terms: MM_SPLIT_F16 | 2 / 3
 
 }  // namespace
 
 int k_split_rows(hipStream_t s, const float* x, long ldx, long rows, int K, int P, int rows_per_batch, long out_batch_stride, bf16_t* out,
                  uint8_t* nz_mask, int mask_bstride, int drop) {
     if (rows <= 0) return MM_OK;
-    if (bad_p(P)) return mm_set_error(MM_ERR_SHAPE, "split_rows: products must be 3, 5 or 6");
+    if (bad_p(P)) return mm_set_error(MM_ERR_SHAPE, "split_rows: products must be 3, 5, 6 (bf16 terms) or MM_SPLIT_F16 | 2, 3 (fp16 terms)");
     if ((K % 4) || (ldx % 4)) return mm_set_error(MM_ERR_ALIGN, "split_rows: K and the row stride must be multiples of 4");
     if (rows_per_batch <= 0) { rows_per_batch = (int)(rows > 0x7fffffff ? 0x7fffffff : rows); out_batch_stride = 0; }
     hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, ldx, rows, K, P, rows_per_batch, out_batch_stride, out,

@@ -25,6 +25,9 @@ from .vqgan_vae import VQGanVAE
 bf16 = torch.bfloat16
 
 
+SPLIT_TIERS = ('bf16x3', 'f16x2')      # the fp32-grade precision tiers inside the C entry points: bf16 terms (3 / 5 / 6 products), fp16 terms (2 / 3)
+
+
 def exists(v):
     return v is not None
 
@@ -181,6 +184,7 @@ class Transformer(nn.Module):
         self._handle_x3 = None         # packed weights + C handle of the 'bf16x3' precision tier (built on first use)
         self._handle_x3_key = None
         self._x3_min_products = 0      # MaskGit raises it so that a generator and its token critic are packed with the same number of term products
+        self._x3_extra_weights = ()    # MaskGit: the self-critic head's weight, packed with this model's term scale ('f16x2')
         self._ws = None
         self.grad_sync = None          # optional parallel.GradBucketer: data-parallel gradient averaging inside the backward
         self._handle_f8 = None         # packed weights + C handle of the fp8 engine (precision 'fp8', built on first use)
@@ -233,8 +237,8 @@ class Transformer(nn.Module):
         if dev.type != 'cuda':
             raise L.MuseHipError('Transformer parameters are not on the GPU; the MI355X path has no CPU fallback')
         key = self._pack_key()
-        if self.precision == 'bf16x3':
-            key = key + (self._x3_min_products,)
+        if self.precision in SPLIT_TIERS:
+            key = key + (self.precision, self._x3_min_products, tuple((w.data_ptr(), w._version) for w in self._x3_extra_weights))
             if self._handle_x3 is None or self._handle_x3_key != key:
                 self._handle_x3, self._handle_x3_key = self._model_x3(), key
             return self._handle_x3
@@ -290,13 +294,29 @@ class Transformer(nn.Module):
                 ws += [a.to_q.weight, a.to_kv.weight, a.to_out.weight]
         return ws
 
+    def split_scale(self):
+        """'f16x2' tier: the power of two the weight terms are packed with (ops.f16_weight_scale over every Linear weight of the hot path and the
+        self-critic head, when one rides along); every GEMM multiplies its accumulators by the inverse (mm_transformer_desc.split_alpha)"""
+        return ops.f16_weight_scale(self.linear_weights() + list(self._x3_extra_weights))
+
     def split_products(self):
-        """term pairs per product of the 'bf16x3' tier for THIS checkpoint: 3 when every Linear weight is bf16-representable (a checkpoint
-        trained / stored in bf16), 5 for two-term weights, 6 for general fp32 weights (csrc/split.hip)"""
-        key = self._pack_key()
+        """term pairs per product of the precision tier for THIS checkpoint.  'bf16x3': 3 when every Linear weight is bf16-representable (a
+        checkpoint trained / stored in bf16), 5 for two-term weights, 6 for general fp32 weights.  'f16x2': 2 when one fp16 term holds every
+        weight (any bf16-representable checkpoint), 3 for general fp32 weights (csrc/split.hip, common.h split2_f16)"""
+        f16 = self.precision == 'f16x2'
+        key = self._pack_key() + (f16,)
         if getattr(self, '_x3_terms', None) is None or self._x3_terms[0] != key:      # one pass over the weights per parameter version
-            self._x3_terms = (key, max(ops.weight_terms(w) for w in self.linear_weights()))
-        return max(ops.products_for_terms(self._x3_terms[1]), self._x3_min_products)
+            if f16:
+                sc = self.split_scale()
+                self._x3_terms = (key, max(ops.weight_terms_f16(w, sc) for w in self.linear_weights()))
+            else:
+                self._x3_terms = (key, max(ops.weight_terms(w) for w in self.linear_weights()))
+        need = (1 + self._x3_terms[1]) if f16 else ops.products_for_terms(self._x3_terms[1])
+        return max(need, self._x3_min_products)
+
+    def split_code(self):
+        """the operand code of the current precision tier (mm_transformer_desc.split_products): the product count, | MM_SPLIT_F16 for fp16 terms"""
+        return self.split_products() | (ops.MM_SPLIT_F16 if self.precision == 'f16x2' else 0)
 
     def _model_x3(self):
         """weights of the 'bf16x3' precision tier (mm_transformer_desc.split_products): Linear weights as term-segment packs [out][P*in], fp32
@@ -304,9 +324,11 @@ class Transformer(nn.Module):
         h = _Handle()
         tb = self.transformer_blocks
         cfg = tb.cfg
-        P = self.split_products()
+        PC = self.split_code()
+        P = ops.split_count(PC)
+        scale = self.split_scale() if ops.split_is_f16(PC) else 1.0
         f32c = lambda x: x.detach().float().contiguous()
-        pack = lambda w, pad_k=1: ops.split_pack_weight(w, P, pad_k)
+        pack = lambda w, pad_k=1: ops.split_pack_weight(w, PC, pad_k, scale)
 
         def pack_ff(ff):
             w1, w2 = ff[1].weight.detach().float(), ff[4].weight.detach().float()
@@ -342,7 +364,7 @@ class Transformer(nn.Module):
             layers[i].ff, F, Fp = pack_ff(ff)
         sc_ff, _, _ = pack_ff(self.self_cond_to_init_embed)
         t = dict(tok=f32c(self.token_emb.weight), pos=f32c(self.pos_emb.weight), fg=f32c(tb.norm.gamma), fb=f32c(tb.norm.beta), wl=pack(self.to_logits.weight),
-                 tp=pack(self.text_embed_proj.weight) if isinstance(self.text_embed_proj, nn.Linear) else None, P=P)
+                 tp=pack(self.text_embed_proj.weight) if isinstance(self.text_embed_proj, nn.Linear) else None, P=P, PC=PC, scale=scale, alpha=1.0 / scale)
         t['wmean'] = t['wcov'] = None
         if self.dim_out % 256 == 0 and self.dim_out >= 4096:      # (an estimate: the fp32 weights as they are)
             h.stats_src = lambda: self.to_logits.weight.detach().float()
@@ -358,7 +380,8 @@ class Transformer(nn.Module):
         d.final_gamma, d.final_beta, d.to_logits = L.ptr(t['fg']), L.ptr(t['fb']), L.ptr(t['wl'])
         d.self_cond_ff = sc_ff
         d.logits_wmean, d.logits_wcov = L.ptr(t['wmean']), L.ptr(t['wcov'])
-        d.split_products = P
+        d.split_products = PC
+        d.split_alpha = 1.0 / scale
         h.create(d, t)
         return h
 
@@ -397,12 +420,15 @@ class Transformer(nn.Module):
         Linear are kept as exact three-term bf16 splits and multiplied as 3 (bf16-representable checkpoint) / 5 / 6 (general fp32 weights)
         term products on the bf16 matrix pipe, fp32 everywhere else, attention on the fp32 MFMA (csrc/split.hip, attention_f32.hip);
         logits within 1e-3 of the reference's fp32 run and bit-equal ids at full size.  Inference only.
+        'f16x2' (round 4): the same tier on fp16 TERMS and the fp16 MFMA -- two terms per value (22 significand bits), 3 term products for
+        GENERAL fp32 weights and 2 for a bf16-representable checkpoint (half of what 'bf16x3' needs), weight terms scaled by a power of two so that
+        low terms stay normal numbers; logits within 1e-3 (measured 4e-6) and bit-equal ids at full size on both kinds of checkpoint.  Inference only.
         'parity': precision level L0 -- fp32 storage and fp32 MFMA through the reference's exact operator sequence, one
         operator call at a time from Python (parity.py / csrc/parity.hip): the verification baseline of the tier above.  Inference only.
         'fp8': the fp8 engine (BASELINE configs[4]) inside the same C entry points -- e4m3 weights and activations on the K = 128 fp8 MFMA for the
         Linear layers of the blocks (quantize_weights_fp8); self-defined numerics.  Inference only."""
-        if precision not in ('bf16', 'bf16x3', 'parity', 'fp8'):
-            raise ValueError(f"precision must be 'bf16', 'bf16x3', 'parity' or 'fp8', got {precision!r}")
+        if precision not in ('bf16', 'bf16x3', 'f16x2', 'parity', 'fp8'):
+            raise ValueError(f"precision must be 'bf16', 'f16x2', 'bf16x3', 'parity' or 'fp8', got {precision!r}")
         self.precision = precision
         return self
 
@@ -425,7 +451,7 @@ class Transformer(nn.Module):
             cids = conditioning_token_ids.reshape(b, -1).to(device=dev, dtype=torch.long).contiguous()
             nc = cids.shape[1]
         m = Lt + nc
-        seg = h.packed['P'] if self.precision == 'bf16x3' else 1          # precision tier: P bf16 segments per context row
+        seg = h.packed['P'] if self.precision in SPLIT_TIERS else 1          # precision tier: P term segments per context row
         ctx = torch.empty(b, m, seg * self.dim, dtype=bf16, device=dev)
         mask = torch.empty(b, m, dtype=torch.uint8, device=dev)
         wsb = L.lib().mm_context_workspace_bytes(h.ptr, b, Lt)
@@ -438,14 +464,14 @@ class Transformer(nn.Module):
         return ctx, mask
 
     def _run(self, ids, ctx, mask, self_cond_embed=None, want_embed=True, want_logits=True):
-        assert self.precision in ('bf16', 'bf16x3', 'fp8')
+        assert self.precision in ('bf16', 'fp8') + SPLIT_TIERS
         h = self._model()
         dev = self.token_emb.weight.device
         ids = ids.to(device=dev, dtype=torch.long).contiguous()
         b, n = ids.shape
         assert n <= self.seq_len                                              # mmp.py:293
         m = ctx.shape[1]
-        seg = h.packed['P'] if self.precision == 'bf16x3' else 1          # precision tier: the embed leaves as P bf16 segments per row (see _embed_f32)
+        seg = h.packed['P'] if self.precision in SPLIT_TIERS else 1          # precision tier: the embed leaves as P term segments per row (see _embed_f32)
         embed = torch.empty(b * n, seg * self.dim, dtype=bf16, device=dev) if want_embed else None
         logits = torch.empty(b * n, self.dim_out, dtype=torch.float32, device=dev) if want_logits else None
         sce = None
@@ -460,8 +486,8 @@ class Transformer(nn.Module):
     def _embed_f32(self, embed):
         """fp32 [rows, dim] view of what `_run` / `forward(_embed_only=True)` returned: the bf16 embed, or -- precision tier -- the exact sum of
         its three bf16 terms"""
-        if embed.shape[-1] != self.dim:
-            return ops.unsplit_rows(embed, embed.shape[-1] // self.dim, self.dim)
+        if self.precision in SPLIT_TIERS:
+            return ops.unsplit_rows(embed, self._model().packed['PC'], self.dim)
         return embed.float()
 
     # ---- fp8 engine (BASELINE configs[4] "fp8 MFMA weights"): e4m3 weights AND activations on the K = 128 fp8 MFMA, inside the same C entry points
@@ -565,6 +591,9 @@ class Transformer(nn.Module):
             return P32.cfg_logits(self, emb_a, emb_b, cond_scale)
         # guidance in the embedding: to_logits is linear, so b + (a - b) * s of the logits is to_logits(e_b + (e_a - e_b) * s): mix, then ONE GEMM
         # (what mm_generate does; every GEMM kernel of the family accumulates in the same order, so the two agree bit for bit)
+        if self.precision in SPLIT_TIERS:
+            pk = self._model().packed
+            return ops.gemm_split(ops.cfg_mix(emb_a, emb_b, cond_scale, self.dim, pk['PC']), pk['wl'], pk['PC'], pk['alpha'])
         return ops.gemm(ops.cfg_mix(emb_a, emb_b, cond_scale, self.dim), self._model().packed['wl'], out_f32=True)
 
     # ---- reference surface
@@ -670,6 +699,11 @@ class SelfCritic(nn.Module):
             P = max(self.net._model().packed['P'], ops.products_for_terms(ops.weight_terms(self.to_pred.weight)))
             x = ops.split_rows(embeds.reshape(b * n, d).float().contiguous(), P)
             out = ops.gemm(x, ops.split_pack_weight(self.to_pred.weight, P), out_f32=True)
+            return (out + self.to_pred.bias.detach().float()).reshape(b, n, 1)
+        if self.net.precision == 'f16x2':       # ... as fp16 term products (all three: the head is tiny), with its own power-of-two scale
+            PC, sc = ops.MM_SPLIT_F16 | 3, ops.f16_weight_scale([self.to_pred.weight])
+            x = ops.split_rows(embeds.reshape(b * n, d).float().contiguous(), PC)
+            out = ops.gemm_split(x, ops.split_pack_weight(self.to_pred.weight, PC, 1, sc), PC, 1.0 / sc)
             return (out + self.to_pred.bias.detach().float()).reshape(b, n, 1)
         w = ops.pad_cols(self.to_pred.weight.detach().to(bf16), 64)                    # [1, D] as a 1x1 conv weight
         x = embeds.reshape(b * n, 1, 1, d).to(bf16).contiguous()
@@ -830,16 +864,22 @@ class MaskGit(nn.Module):
             _, cond_ids, _ = self.cond_vae.encode(cond_images)
             cond_ids = cond_ids.reshape(B, -1).contiguous()
             nc = cond_ids.shape[1]
-        if tr.precision == 'bf16x3' and exists(critic):      # one term-product count for the generator and its critic (token critic network or self-critic head)
+        if tr.precision in SPLIT_TIERS and exists(critic):      # one term-product count for the generator and its critic (token critic network or self-critic head)
             tr._x3_min_products = 0
+            tr._x3_extra_weights = ()
             if isinstance(critic, Transformer):
                 critic._x3_min_products = 0
                 need = critic.split_products()
+            elif tr.precision == 'f16x2':      # the head rides on the generator's term scale
+                tr._x3_extra_weights = (critic.to_pred.weight,)
+                need = 1 + ops.weight_terms_f16(critic.to_pred.weight, tr.split_scale())
             else:
                 need = ops.products_for_terms(ops.weight_terms(critic.to_pred.weight))
             tr._x3_min_products = max(tr.split_products(), need)
             if isinstance(critic, Transformer):
                 critic._x3_min_products = tr._x3_min_products
+        elif tr.precision in SPLIT_TIERS:
+            tr._x3_extra_weights = ()
         h = tr._model()
         if fused_sampling and not torch.cuda.is_current_stream_capturing():
             h.ensure_logits_stats()              # vocabulary statistics of to_logits: first fused generate() only (not inside a capture: it allocates)
@@ -873,8 +913,8 @@ class MaskGit(nn.Module):
             p.flags |= L.MM_GEN_CAN_REMASK
         if exists(critic):
             if isinstance(critic, SelfCritic):
-                if tr.precision == 'bf16x3':
-                    hw = ops.split_pack_weight(critic.to_pred.weight.detach().to(dev), h.packed['P']).reshape(-1).contiguous()
+                if tr.precision in SPLIT_TIERS:
+                    hw = ops.split_pack_weight(critic.to_pred.weight.detach().to(dev), h.packed['PC'], 1, h.packed['scale']).reshape(-1).contiguous()
                 else:
                     hw = ops.pad_cols(critic.to_pred.weight.detach().to(device=dev, dtype=bf16), 64).reshape(-1).contiguous()
                 keep += [hw, critic.to_pred.bias.detach().to(device=dev, dtype=torch.float32).contiguous()]

@@ -667,16 +667,80 @@ def products_for_terms(terms):
     return {1: 3, 2: 5, 3: 6}[int(terms)]
 
 
-def split_pack_weight(w, products, pad_k=1):
+# ---- precision tier 'f16x2' (round 4): the same engine on fp16 terms.  x ~ h + l (11 + 11 significand bits), products h.h + l.h (+ h.l): X' = [xh|xl|xh][:P]
+#      against W' = [wh|wh|wl][:P] -- P = 3 for general fp32 weights, 2 when one fp16 term holds every weight.  Operand code: MM_SPLIT_F16 | P.
+MM_SPLIT_F16 = 0x100
+SPLIT_W_SEGMENTS_F16 = (0, 0, 1)
+
+
+def split_count(products):
+    """segments per operand row of an operand code (3 / 5 / 6 bf16 terms, MM_SPLIT_F16 | 2 / 3 fp16 terms)"""
+    return int(products) & 0xff
+
+
+def split_is_f16(products):
+    return bool(int(products) & MM_SPLIT_F16)
+
+
+def split_terms_f16(w, scale=1.0):
+    """two fp16 terms of scale * w (scale a power of two: exact): h = fp16(v), l = fp16(v - h); returned as fp16 tensors"""
+    v = w.detach().float() * float(scale)
+    h = v.to(torch.float16)
+    assert bool(torch.isfinite(h.float()).all()), 'fp16 overflow: the weight scale is too large'
+    l = (v - h.float()).to(torch.float16)
+    return h, l
+
+
+def f16_weight_scale(weights):
+    """the power of two that puts the largest |w| of `weights` into [2^13, 2^14): every low term of a weight within 2^-10 of the largest is then a
+    NORMAL fp16 number, and the absolute floor of the two-term split (2^-25 after scaling) is 2^-38 of the largest weight.  The GEMMs multiply
+    their accumulators by the inverse (mm_transformer_desc.split_alpha / GemmArgs.alpha): exact."""
+    import math
+    mx = max(float(w.detach().abs().max()) for w in weights)
+    if not mx > 0. or not math.isfinite(mx):
+        return 1.0
+    return 2.0 ** (13 - math.floor(math.log2(mx)))
+
+
+def weight_terms_f16(w, scale=1.0):
+    """1 if one fp16 term holds scale * w to within 2^-24 of its largest value (any bf16-representable checkpoint: 8 significant bits), else 2"""
+    v = w.detach().float() * float(scale)
+    r = (v - v.to(torch.float16).float()).abs().max()
+    return 1 if float(r) <= float(v.abs().max()) * 2.0 ** -24 else 2
+
+
+def split_pack_weight(w, products, pad_k=1, scale=1.0):
     """nn.Linear weight fp32 [N][K] -> bf16 [N][products * Kp], the segments [wh|wh|wh|wm|wm|wl][:products] (each zero-padded to Kp =
-    K rounded up to pad_k); multiplies the activation pack [xh|xm|xl|xh|xm|xh] written by the split kernels."""
-    terms = split_terms(w)
+    K rounded up to pad_k); multiplies the activation pack [xh|xm|xl|xh|xm|xh] written by the split kernels.
+    products = MM_SPLIT_F16 | 2 / 3: fp16 terms of scale * w, segments [wh|wh|wl][:P] (returned as a 16-bit container of dtype bfloat16)."""
     N, K = w.shape
     Kp = (K + pad_k - 1) // pad_k * pad_k
+    P = split_count(products)
+    if split_is_f16(products):
+        terms = split_terms_f16(w, scale)
+        out = torch.zeros(N, P, Kp, dtype=torch.float16, device=w.device)
+        for s in range(P):
+            out[:, s, :K] = terms[SPLIT_W_SEGMENTS_F16[s]]
+        return out.reshape(N, P * Kp).contiguous().view(bf16)
+    assert scale == 1.0
+    terms = split_terms(w)
     out = torch.zeros(N, products, Kp, dtype=bf16, device=w.device)
     for s in range(products):
         out[:, s, :K] = terms[SPLIT_W_SEGMENTS[s]]
     return out.reshape(N, products * Kp).contiguous()
+
+
+def gemm_split(xs, ws, products, alpha=1.0, resid=None):
+    """fp32 [M][N] = X' . W'^T over term-segment packs (mm_gemm_split): xs / ws from split_rows / split_pack_weight with the same operand code"""
+    _chk_cuda(xs, ws)
+    M, K = xs.shape
+    N = ws.shape[0]
+    assert ws.shape[1] == K and xs.stride(1) == 1 and ws.stride(1) == 1
+    ldc = (N + 3) // 4 * 4 if resid is None else N      # (fp32 rows are written 16 bytes at a time)
+    out = torch.empty(M, ldc, dtype=torch.float32, device=xs.device)
+    L.check(L.lib().mm_gemm_split(L.stream(), L.ptr(xs), xs.stride(0), L.ptr(ws), ws.stride(0), M, N, K, int(products), float(alpha), L.ptr(out), ldc,
+                                  L.ptr(resid)), 'mm_gemm_split')
+    return out[:, :N]
 
 
 def split_rows(x, products):
@@ -685,25 +749,30 @@ def split_rows(x, products):
     x = x.float()
     assert x.dim() == 2 and x.stride(1) == 1 and x.shape[1] % 4 == 0 and x.stride(0) % 4 == 0
     rows, K = x.shape
-    out = torch.empty(rows, products * K, dtype=bf16, device=x.device)
-    L.check(L.lib().mm_split_rows(L.stream(), L.ptr(x), x.stride(0), rows, K, products, L.ptr(out)), 'mm_split_rows')
+    out = torch.empty(rows, split_count(products) * K, dtype=bf16, device=x.device)
+    L.check(L.lib().mm_split_rows(L.stream(), L.ptr(x), x.stride(0), rows, K, int(products), L.ptr(out)), 'mm_split_rows')
     return out
 
 
 def unsplit_rows(xs, products, K):
-    """the fp32 value of a segment pack: h + m + l (exact)"""
-    v = xs.reshape(xs.shape[0], products, K)[:, :3].float()
+    """the fp32 value of a segment pack: h + m + l (exact); fp16 terms: h + l (the value to within 2^-22)"""
+    P = split_count(products)
+    if split_is_f16(products):
+        v = xs.view(torch.float16).reshape(xs.shape[0], P, K)[:, :2].float()
+        return v[:, 0] + v[:, 1]
+    v = xs.reshape(xs.shape[0], P, K)[:, :3].float()
     return (v[:, 0] + v[:, 1]) + v[:, 2]
 
 
-def cfg_mix(emb_cond, emb_null, cond_scale, D):
+def cfg_mix(emb_cond, emb_null, cond_scale, D, products=None):
     """e = e_null + (e_cond - e_null) * cond_scale on the final embeddings (mm_cfg_mix): bf16 [R, D] rows, or term-segment packs [R, P*D] of the
-    precision tier (mixed as exact fp32 values and re-split).  to_logits of the result is the guidance-combined logits of mmp.py:254."""
+    precision tiers (mixed as fp32 values and re-split; `products`: the operand code -- inferred from the width for bf16 terms).
+    to_logits of the result is the guidance-combined logits of mmp.py:254."""
     _chk_cuda(emb_cond, emb_null)
     assert emb_cond.dtype == bf16 and emb_null.dtype == bf16 and emb_cond.shape == emb_null.shape and emb_cond.stride(0) == emb_null.stride(0)
     R, W = emb_cond.shape
-    P = W // D if W != D else 0
-    assert W == max(P, 1) * D and emb_cond.stride(1) == 1 and emb_null.stride(1) == 1
+    P = (W // D if W != D else 0) if products is None else int(products)
+    assert W == max(split_count(P), 1) * D and emb_cond.stride(1) == 1 and emb_null.stride(1) == 1
     out = torch.empty(R, W, dtype=bf16, device=emb_cond.device)
     L.check(L.lib().mm_cfg_mix(L.stream(), L.ptr(emb_cond), L.ptr(emb_null), emb_cond.stride(0), R, D, P, float(cond_scale), L.ptr(out)), 'mm_cfg_mix')
     return out

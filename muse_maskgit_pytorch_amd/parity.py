@@ -186,28 +186,46 @@ def conv(x, w_packed, cout, th, tw, stride=1, off=(0, 0), out_hw=None, os_=1, pa
 # ---- 'bf16x3' form of the convolutions (precision tier, decode path): the fp32 NHWC activation is split into P exact bf16 term segments per pixel
 #      (mm_split_rows), the weight is the matching per-tap segment pack, and the product runs on the bf16 MFMA implicit-GEMM kernels with fp32 output:
 #      exact to fp32 accumulation like the transformer's tier (csrc/split.hip), at bf16-MFMA rate x P instead of the 1/16-rate fp32 MFMA.
-_X3 = {'P': 0}          # > 0 while a bf16x3 decode runs (set by vae_decode_*): conv() then takes the split form
+# 'f16x2' (round 4): the same form on fp16 terms -- MM_SPLIT_F16 | 2 / 3 segments per pixel, weight terms scaled by a power of two, fp16 MFMA (mm_conv2d_nhwc_f16).
+# The packed weights are cached per VAE and parameter version (`cache`): repacking 200 M decoder parameters on every decode cost more than the convolutions.
+_X3 = {'P': 0, 'code': 0, 'scale': 1.0, 'cache': None}          # P > 0 while a precision-tier decode runs (set by vae_decode_*): conv() then takes the split form
 
 
-def _pack_x3(w2d_taps, P):
-    """list of per-tap fp32 [Cout][Cin] matrices -> bf16 [Cout][Kp], k = tap * (P * Cin) + segment * Cin + ci, zero-padded to a multiple of 64"""
+def _pack_x3(w2d_taps, code, scale=1.0):
+    """list of per-tap fp32 [Cout][Cin] matrices -> 16-bit [Cout][Kp], k = tap * (P * Cin) + segment * Cin + ci, zero-padded to a multiple of 64"""
     from . import ops
-    return ops.pad_cols(torch.cat([ops.split_pack_weight(wt.contiguous(), P) for wt in w2d_taps], dim=1), 64)
+    return ops.pad_cols(torch.cat([ops.split_pack_weight(wt.contiguous(), code, 1, scale) for wt in w2d_taps], dim=1), 64)
+
+
+def _cached_pack(key, make_taps):
+    """the packed term segments of one convolution weight (key: the weight Parameter + a tag), built once per parameter version of the VAE"""
+    cache = _X3['cache']
+    if cache is None:
+        return _pack_x3(make_taps(), _X3['code'], _X3['scale'])
+    if key not in cache:
+        cache[key] = _pack_x3(make_taps(), _X3['code'], _X3['scale'])
+    return cache[key]
 
 
 def conv_x3(x, w_taps, cout, th, tw, stride=1, off=(0, 0), out_hw=None, os_=1, parity=(0, 0), full_hw=None, bias=None, act=False, resid=None, out=None,
             out_nchw=False):
     from . import ops
-    P = _X3['P']
+    P, code = _X3['P'], _X3['code']
     B, H, W, Cin = x.shape
-    xs = ops.split_rows(x.reshape(-1, Cin), P).reshape(B, H, W, P * Cin)
+    xs = ops.split_rows(x.reshape(-1, Cin), code).reshape(B, H, W, P * Cin)
+    wp = w_taps if torch.is_tensor(w_taps) else _pack_x3(w_taps, code, _X3['scale'])      # (already packed: _cached_pack)
     Hv, Wv = out_hw if out_hw is not None else (H, W)
     Hout, Wout = full_hw if full_hw is not None else (Hv * os_, Wv * os_)
     if out is None:
         out = torch.empty((B, cout, Hout, Wout) if out_nchw else (B, Hout, Wout, cout), dtype=f32, device=x.device)
     if out_nchw:
         assert resid is None
-    L.check(L.lib().mm_conv2d_nhwc(L.stream(), L.ptr(xs), B, H, W, P * Cin, L.ptr(_pack_x3(w_taps, P)), cout, th, tw, stride, off[0], off[1], Hv, Wv, os_,
+    if ops.split_is_f16(code):
+        L.check(L.lib().mm_conv2d_nhwc_f16(L.stream(), L.ptr(xs), B, H, W, P * Cin, L.ptr(wp), cout, th, tw, stride, off[0], off[1], Hv, Wv, os_,
+                                           parity[0], parity[1], Hout, Wout, L.ptr(bias), int(act), L.ptr(resid), L.ptr(out), 1 if out_nchw else 2,
+                                           1.0 / _X3['scale']), 'mm_conv2d_nhwc_f16')
+        return out
+    L.check(L.lib().mm_conv2d_nhwc(L.stream(), L.ptr(xs), B, H, W, P * Cin, L.ptr(wp), cout, th, tw, stride, off[0], off[1], Hv, Wv, os_,
                                    parity[0], parity[1], Hout, Wout, L.ptr(bias), int(act), L.ptr(resid), L.ptr(out), 1 if out_nchw else 2), 'mm_conv2d_nhwc')
     return out
 
@@ -258,7 +276,7 @@ def _groupnorm(x, gn, act=False):
 def _conv_module(x, c, **kw):
     k = c.kernel_size[0]
     if _X3['P']:
-        return conv_x3(x, _taps_conv(c.weight), c.out_channels, k, k, 1, (-(k // 2), -(k // 2)), bias=_w(c.bias), **kw)
+        return conv_x3(x, _cached_pack((c.weight, 'conv'), lambda: _taps_conv(c.weight)), c.out_channels, k, k, 1, (-(k // 2), -(k // 2)), bias=_w(c.bias), **kw)
     return conv(x, pack_conv(c.weight), c.out_channels, k, k, 1, (-(k // 2), -(k // 2)), bias=_w(c.bias), **kw)
 
 
@@ -279,9 +297,11 @@ def _vae_layer(x, m, first=False, last=False):
         B, H, W, _ = x.shape
         out = torch.empty(B, 2 * H, 2 * W, ct.out_channels, dtype=f32, device=x.device)
         if _X3['P']:
-            for (py, px), taps in _taps_convT(ct.weight).items():
-                conv_x3(x, taps, ct.out_channels, 2, 2, 1, (py - 1, px - 1), out_hw=(H, W), os_=2, parity=(py, px), full_hw=(2 * H, 2 * W), bias=_w(ct.bias),
-                        act=True, out=out)
+            for py in range(2):
+                for px in range(2):
+                    wp = _cached_pack((ct.weight, 'convT', py, px), lambda: _taps_convT(ct.weight)[(py, px)])
+                    conv_x3(x, wp, ct.out_channels, 2, 2, 1, (py - 1, px - 1), out_hw=(H, W), os_=2, parity=(py, px), full_hw=(2 * H, 2 * W), bias=_w(ct.bias),
+                            act=True, out=out)
             return out
         for (py, px), wp in pack_convT(ct.weight).items():
             conv(x, wp, ct.out_channels, 2, 2, 1, (py - 1, px - 1), out_hw=(H, W), os_=2, parity=(py, px), full_hw=(2 * H, 2 * W), bias=_w(ct.bias), act=True,
@@ -314,12 +334,15 @@ def vae_decode_nhwc(vae, x):
     """ResnetEncDec.decode (vae.py:246-249): NHWC fp32 feature map -> NCHW fp32 image.  vae.precision 'bf16x3': the convolutions take the split form above
     (P from the checkpoint: 3 when every convolution weight is bf16-representable, else 5 / 6), everything else is the fp32 engine's."""
     dec = list(vae.enc_dec.decoders)
-    _X3['P'] = vae.x3_products() if getattr(vae, 'precision', 'bf16') == 'bf16x3' else 0
+    if getattr(vae, 'precision', 'bf16') in ('bf16x3', 'f16x2'):
+        _X3['code'], _X3['scale'] = vae.x3_code(), vae.x3_scale()
+        _X3['P'] = _X3['code'] & 0xff
+        _X3['cache'] = vae.x3_pack_cache()
     try:
         for i, m in enumerate(dec):
             x = _vae_layer(x, m, last=(i == len(dec) - 1))
     finally:
-        _X3['P'] = 0
+        _X3['P'], _X3['code'], _X3['scale'], _X3['cache'] = 0, 0, 1.0, None
     return x
 
 

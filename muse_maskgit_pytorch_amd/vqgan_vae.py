@@ -207,18 +207,47 @@ class VQGanVAE(nn.Module):
         reference's layer sequence one to one (parity.py / csrc/parity.hip) -- pixels within 1e-3 and LFQ ids equal to the fp32 reference.
         'bf16x3': the precision tier's decode -- the fp32 engine's layer sequence with every convolution run as exact bf16 term products on the bf16 MFMA
         (parity.conv_x3): the same 1e-3 bar at a fraction of the fp32-MFMA time; encode stays on the fp32 engine."""
-        if precision not in ('bf16', 'parity', 'bf16x3'):
-            raise ValueError(f"precision must be 'bf16', 'parity' or 'bf16x3', got {precision!r}")
+        if precision not in ('bf16', 'parity', 'bf16x3', 'f16x2'):
+            raise ValueError(f"precision must be 'bf16', 'parity', 'bf16x3' or 'f16x2', got {precision!r}")
         self.precision = precision
         return self
 
-    def x3_products(self):
-        """term pairs per product of the 'bf16x3' decode for THIS checkpoint (3 when every decoder convolution weight is bf16-representable, else 5 / 6)"""
+    def _decoder_conv_weights(self):
+        return [m.weight for m in self.enc_dec.decoders.modules() if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d))]
+
+    def x3_scale(self):
+        """'f16x2' decode: the power of two the convolution weight terms are packed with (ops.f16_weight_scale over the decoder's convolutions)"""
+        if self.precision != 'f16x2':
+            return 1.0
         key = self._pack_key()
+        if getattr(self, '_x3_scale', None) is None or self._x3_scale[0] != key:
+            self._x3_scale = (key, ops.f16_weight_scale(self._decoder_conv_weights()))
+        return self._x3_scale[1]
+
+    def x3_products(self):
+        """term pairs per product of the precision tier's decode for THIS checkpoint.  'bf16x3': 3 when every decoder convolution weight is
+        bf16-representable, else 5 / 6; 'f16x2': 2 when one fp16 term holds every weight, else 3"""
+        f16 = self.precision == 'f16x2'
+        key = self._pack_key() + (f16,)
         if getattr(self, '_x3_terms', None) is None or self._x3_terms[0] != key:
-            ws = [m.weight for m in self.enc_dec.decoders.modules() if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d))]
-            self._x3_terms = (key, max(ops.weight_terms(w.detach()) for w in ws))
-        return ops.products_for_terms(self._x3_terms[1])
+            ws = self._decoder_conv_weights()
+            if f16:
+                sc = self.x3_scale()
+                self._x3_terms = (key, max(ops.weight_terms_f16(w.detach(), sc) for w in ws))
+            else:
+                self._x3_terms = (key, max(ops.weight_terms(w.detach()) for w in ws))
+        return (1 + self._x3_terms[1]) if f16 else ops.products_for_terms(self._x3_terms[1])
+
+    def x3_code(self):
+        return self.x3_products() | (ops.MM_SPLIT_F16 if self.precision == 'f16x2' else 0)
+
+    def x3_pack_cache(self):
+        """packed term segments of the decoder's convolution weights for the current tier, filled on first use (parity._cached_pack) and dropped with
+        the parameter version"""
+        key = self._pack_key() + (self.precision,)
+        if getattr(self, '_x3_packs', None) is None or self._x3_packs[0] != key:
+            self._x3_packs = (key, {})
+        return self._x3_packs[1]
 
     # ---- packed (bf16, kernel layout) weights, rebuilt when parameters change
     def _pack_key(self):
@@ -228,17 +257,17 @@ class VQGanVAE(nn.Module):
     def invalidate_packed_weights(self):
         """Drop the packed device copies and the precision tier's term count (needed only after `.data` edits the version counters cannot see)."""
         self._packed = None
-        self._x3_terms = None
+        self._x3_terms = self._x3_scale = self._x3_packs = None
         return self
 
     def _apply(self, fn, *args, **kwargs):
         self._packed = None
-        self._x3_terms = None
+        self._x3_terms = self._x3_scale = self._x3_packs = None
         return super()._apply(fn, *args, **kwargs)
 
     def load_state_dict(self, *args, **kwargs):
         self._packed = None
-        self._x3_terms = None
+        self._x3_terms = self._x3_scale = self._x3_packs = None
         return super().load_state_dict(*args, **kwargs)
 
     def _pack(self):
@@ -376,7 +405,7 @@ class VQGanVAE(nn.Module):
     @torch.no_grad()
     def encode(self, fmap):
         """vqgan_vae.py:422-425: image (B,C,H,W) fp32 -> (quantized fmap (B,C',h,w) fp32, ids (B,h,w) int64, aux loss 0)."""
-        if self.precision in ('parity', 'bf16x3') and self.lookup_free_quantization:
+        if self.precision in ('parity', 'bf16x3', 'f16x2') and self.lookup_free_quantization:
             from . import parity
             return parity.vae_encode(self, fmap)
         P = self._pack()
@@ -411,7 +440,7 @@ class VQGanVAE(nn.Module):
     @torch.no_grad()
     def decode_from_ids(self, ids):
         """vqgan_vae.py:427-438: ids (B,h,w) int64 -> image (B,C,H,W) fp32 (unclamped)."""
-        if self.precision in ('parity', 'bf16x3') and self.lookup_free_quantization:
+        if self.precision in ('parity', 'bf16x3', 'f16x2') and self.lookup_free_quantization:
             from . import parity
             return parity.vae_decode_from_ids(self, ids)
         P = self._pack()
@@ -433,7 +462,7 @@ class VQGanVAE(nn.Module):
     @torch.no_grad()
     def decode(self, fmap):
         """vqgan_vae.py:440-441: fmap (B,C,h,w) fp32 -> image."""
-        if self.precision in ('parity', 'bf16x3'):
+        if self.precision in ('parity', 'bf16x3', 'f16x2'):
             from . import parity
             return parity.vae_decode(self, fmap)
         x = fmap.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)

@@ -13,6 +13,8 @@ BASE_CFG = dict(num_tokens=65536, seq_len=256, dim=512, depth=8, dim_head=64, he
 VAE_CFG = dict(dim=256, codebook_size=65536)                                                                          # README.md:23-26
 B, N, L, T = 2, 256, 32, 18
 WEIGHT_SEED, VAE_SEED, EDIT_SEED, INPUT_SEED, NOISE_SEED = 0, 1, 4321, 77, 20260924
+INPUT_SEED_FP32 = 83      # inputs of the general-fp32 fixture (base_c2_fp32.pt): chosen by tools/find_golden_input_seed.py -- with seed 77 that checkpoint's reference
+                          # run has two confidences 4e-6 apart at a re-masking boundary, a coin flip for every implementation that is not bit-identical to it
 PEAK = 8.0      # to_logits scale of the decode run: well-separated confidences (SURVEY 8c determinism control 3)
 
 
@@ -55,9 +57,10 @@ def build_vae(cls, bf16_weights=True):
     return vae.eval()
 
 
-def inputs():
-    """ids with ~half the positions masked, zero-padded text embeddings (t5.py:93), VAE inputs."""
-    g = torch.Generator().manual_seed(INPUT_SEED)
+def inputs(seed=None):
+    """ids with ~half the positions masked, zero-padded text embeddings (t5.py:93), VAE inputs.  `seed`: INPUT_SEED by default; the general-fp32
+    fixture (base_c2_fp32.pt) uses INPUT_SEED_FP32 (fixture['recipe']['input_seed']), see tools/find_golden_input_seed.py for how it was chosen."""
+    g = torch.Generator().manual_seed(INPUT_SEED if seed is None else seed)
     ids = torch.randint(0, BASE_CFG['num_tokens'], (B, N), generator=g)
     ids[torch.rand(B, N, generator=g) < 0.5] = BASE_CFG['num_tokens']          # mask id
     te = torch.randn(B, L, 512, generator=g)

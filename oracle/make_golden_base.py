@@ -31,9 +31,10 @@ COL_STRIDE = 128
 def main():
     t0 = time.time()
     pkg, mmp, vaemod, att = reference_modules()
-    inp = R.inputs()
+    input_seed = R.INPUT_SEED_FP32 if FP32 else R.INPUT_SEED
+    inp = R.inputs(input_seed)
     ids, te = inp['ids'], inp['text_embeds']
-    out = dict(recipe=dict(B=R.B, N=R.N, L=R.L, T=R.T, peak=R.PEAK, bf16_weights=not FP32), full_rows=FULL_ROWS, col_stride=COL_STRIDE,
+    out = dict(recipe=dict(B=R.B, N=R.N, L=R.L, T=R.T, peak=R.PEAK, bf16_weights=not FP32, input_seed=input_seed), full_rows=FULL_ROWS, col_stride=COL_STRIDE,
                input_checksum={k: R.checksum(v.float()) for k, v in inp.items()})
 
     # ---------------------------------------------------------------- Transformer.forward (mmp.py:279-335) + guidance (:240-259), plain init

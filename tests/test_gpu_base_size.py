@@ -24,8 +24,8 @@ import muse_oracle as O
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 FULL_ROWS = [0, 77, 255, 256, 300, 301, 448, 511]
-PRECISIONS = ['parity', 'bf16x3', 'bf16']
-EXACT = ('parity', 'bf16x3')      # the engines held to the north star's bar
+PRECISIONS = ['parity', 'bf16x3', 'f16x2', 'bf16']
+EXACT = ('parity', 'bf16x3', 'f16x2')      # the engines held to the north star's bar
 
 
 @pytest.fixture(scope='module', params=['base_c2.pt', 'base_c2_fp32.pt'], ids=['bf16w', 'fp32w'])
@@ -42,7 +42,7 @@ def base(golden, request):
     vae = R.build_vae(mm.VQGanVAE, bf16_weights=bf16w)
     mg = mm.MaskGit(vae=vae, transformer=tr, image_size=256).to(DEV).eval()
     assert R.state_checksum(mg.vae) == g['vae_weight_checksum']
-    inp = R.inputs()
+    inp = R.inputs(g['recipe'].get('input_seed'))
     assert {k: R.checksum(v.float()) for k, v in inp.items()} == g['input_checksum']
     yield g, mg, inp
     del mg, tr, vae
@@ -84,8 +84,8 @@ def test_transformer_forward_logits_at_base_size(base, precision):
     g, mg, inp = base
     _skip_bf16_engine_on_fp32_weights(g, precision)
     tr = mg.transformer.set_precision(precision)
-    if precision == 'bf16x3':
-        assert tr.split_products() == (3 if g['recipe'].get('bf16_weights', True) else 6)
+    if precision in ('bf16x3', 'f16x2'):      # term products per GEMM: bf16 terms 3 / 6, fp16 terms 2 / 3 (bf16-representable / general fp32 checkpoint)
+        assert tr.split_products() == dict(bf16x3=(6, 3), f16x2=(3, 2))[precision][int(g['recipe'].get('bf16_weights', True))]
     try:
         ids, te = inp['ids'].to(DEV), inp['text_embeds'].to(DEV)
         lc, emb = tr(ids, text_embeds=te, cond_drop_prob=0., return_embed=True)
@@ -130,8 +130,9 @@ def test_generate_at_base_size_against_the_reference_run(base, noise, precision)
         final_agree = (ids.cpu().reshape(gen['final_ids'].shape) == gen['final_ids']).float().mean().item()
         print(f'[base-size parity] {precision} generate: final ids equal to the reference run: {100 * final_agree:.2f} %; per-step state agreement min '
               f'{100 * min(agree_steps):.2f} % (step {agree_steps.index(min(agree_steps))})')
-        if precision == 'bf16x3':      # the tier runs inside the one mm_generate call (the stepwise loop returns lists), 3 term products here
-            assert isinstance(trace['masked_ids'], torch.Tensor) and tr.split_products() == (3 if g['recipe'].get('bf16_weights', True) else 6)
+        if precision in ('bf16x3', 'f16x2'):      # the tiers run inside the one mm_generate call (the stepwise loop returns lists)
+            assert isinstance(trace['masked_ids'], torch.Tensor)
+            assert tr.split_products() == dict(bf16x3=(6, 3), f16x2=(3, 2))[precision][int(g['recipe'].get('bf16_weights', True))]
         if precision in EXACT:
             assert min(agree_steps) == 1.0 and final_agree == 1.0
         else:
@@ -156,7 +157,7 @@ def test_generate_at_base_size_against_the_reference_run(base, noise, precision)
         torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize('precision', ['parity', 'bf16x3', 'bf16'])
+@pytest.mark.parametrize('precision', ['parity', 'bf16x3', 'f16x2', 'bf16'])
 def test_vqgan_vae_dim_256_against_the_reference(base, precision):
     """VQGanVAE(dim=256) decode_from_ids / encode (vqgan_vae.py:422-441), the VAE the bench decodes with.  Pixels: 1e-3 of the image scale
     (|max| 0.063 at random init) for the parity engine.  LFQ ids: a bit is the SIGN of a projection, so ids are compared where the reference's
@@ -165,8 +166,8 @@ def test_vqgan_vae_dim_256_against_the_reference(base, precision):
     _skip_bf16_engine_on_fp32_weights(g, precision)
     v = g['vae']
     vae = mg.vae.set_precision(precision)
-    if precision == 'bf16x3':
-        assert vae.x3_products() == (3 if g['recipe'].get('bf16_weights', True) else 6)
+    if precision in ('bf16x3', 'f16x2'):
+        assert vae.x3_products() == dict(bf16x3=(6, 3), f16x2=(3, 2))[precision][int(g['recipe'].get('bf16_weights', True))]
     try:
         dec = vae.decode_from_ids(inp['vae_ids'].to(DEV))
         fmap, ids, _ = vae.encode(inp['image'].to(DEV))
@@ -251,7 +252,7 @@ def test_superres_forward_and_generate_at_full_size(superres, precision):
             steps = [(masked[s] == gen['step_in_ids'][s].long()).float().mean().item() for s in range(R.C4_T)]
             final = (out.cpu().reshape(gen['final_ids'].shape) == gen['final_ids']).float().mean().item()
             print(f'[super-res parity] {precision} generate: final ids equal to the reference run {100 * final:.2f} %, per-step states min {100 * min(steps):.2f} %')
-            if precision == 'bf16x3':
+            if precision in ('bf16x3', 'f16x2'):
                 assert isinstance(trace['masked_ids'], torch.Tensor)
             if precision in EXACT:
                 assert final == 1.0 and min(steps) == 1.0
@@ -322,7 +323,7 @@ def test_paper_scale_forward_and_generate_at_full_size(paper, precision):
             steps = [(masked[s] == gen['step_in_ids'][s].long()).float().mean().item() for s in range(R.C5_T)]
             final = (out.cpu().reshape(gen['final_ids'].shape) == gen['final_ids']).float().mean().item()
             print(f'[paper-scale parity] {precision} generate: final ids equal to the reference run {100 * final:.2f} %, per-step states min {100 * min(steps):.2f} %')
-            if precision == 'bf16x3':
+            if precision in ('bf16x3', 'f16x2'):
                 assert isinstance(trace['masked_ids'], torch.Tensor)
             if precision in EXACT:
                 assert final == 1.0 and min(steps) == 1.0

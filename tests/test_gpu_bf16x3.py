@@ -59,8 +59,65 @@ def _case(rng):
                 self_cond=rng.random() < 0.3, can_remask=rng.random() < 0.25, cond_scale=rng.choice([1, 3.0]), bf16_weights=rng.random() < 0.5)
 
 
+@pytest.mark.parametrize('products', [2, 3])
+def test_split_rows_f16_terms(products):
+    """'f16x2': segments [h | l | h][:P], h = fp16(x) and l = fp16(x - h) as torch's round-to-nearest-even conversions give them (subnormal terms kept)"""
+    g = torch.Generator().manual_seed(products)
+    x = torch.randn(37, 192, generator=g) * torch.logspace(-7, 4, 192)[None]
+    x[3, :8] = 0.
+    code = ops.MM_SPLIT_F16 | products
+    xs = ops.split_rows(x.to(DEV), code).cpu().view(torch.float16).reshape(37, products, 192)
+    h = x.half()
+    l = (x - h.float()).half()
+    order = [h, l, h][:products]
+    for s in range(products):
+        assert torch.equal(xs[:, s].view(torch.int16), order[s].view(torch.int16)), f'segment {s}'
+    back = ops.unsplit_rows(ops.split_rows(x.to(DEV), code), code, 192).cpu()
+    assert bool(((back - x).abs() <= x.abs() * 2.0 ** -21 + 2.0 ** -24).all())          # 22 bits, absolute floor of the subnormal low term
+
+
+def test_f16_mfma_takes_subnormal_terms_unflushed():
+    """the tier relies on v_mfma_f32_16x16x32_f16 multiplying fp16 SUBNORMAL operands exactly (the low terms of small values are subnormal):
+    a product whose operands are all subnormal must come out exactly, not as zero"""
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 128, 128, 64
+    xi = torch.randint(-1023, 1024, (M, K), generator=g).float()          # subnormal fp16: integer multiples of 2^-24 below 2^-14
+    wi = torch.randint(-1023, 1024, (N, K), generator=g).float()
+    x16, w16 = (xi * 2.0 ** -24).half(), (wi * 2.0 ** -24).half()
+    assert bool((x16.float() == xi * 2.0 ** -24).all()) and float(x16.float().abs().max()) < 2.0 ** -14
+    got = ops.gemm_split(x16.view(torch.bfloat16).to(DEV), w16.view(torch.bfloat16).to(DEV), ops.MM_SPLIT_F16 | 2, 2.0 ** 48).double().cpu()
+    ref = xi.double() @ wi.double().t()                                   # = the product x 2^48
+    assert float(ref.abs().max()) > 1e5
+    assert torch.equal(got, ref), f'max err {(got - ref).abs().max().item()} (a flushed operand would give 0)'
+
+
+@pytest.mark.parametrize('M,N,K', [(128, 256, 128), (300, 200, 64), (1, 65, 192), (513, 1408, 512)])
+@pytest.mark.parametrize('wkind', ['bf16', 'fp32', 'small'])
+def test_f16_term_product_gemm_has_fp32_accuracy(M, N, K, wkind):
+    """X'.W'^T over fp16 term pairs on the fp16 MFMA against fp64: the error class of an fp32 GEMM.  'small': weights 2^-12 of the others -- the
+    power-of-two scale of the packed terms keeps their low terms out of the subnormal range"""
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5
+    if wkind == 'bf16':
+        w = w.bfloat16().float()
+    elif wkind == 'small':
+        w = w * 2.0 ** -12
+    sc = ops.f16_weight_scale([w])
+    terms = ops.weight_terms_f16(w, sc)
+    assert terms == dict(bf16=1, fp32=2, small=2)[wkind]
+    code = ops.MM_SPLIT_F16 | (1 + terms)
+    ref = x.double() @ w.double().t()
+    got = ops.gemm_split(ops.split_rows(x.to(DEV), code), ops.split_pack_weight(w.to(DEV), code, 64, sc), code, 1.0 / sc).double().cpu()
+    f32 = P32.gemm(x.to(DEV), w.to(DEV)).double().cpu()
+    e, e32 = ((t - ref).abs().max().item() for t in (got, f32))
+    scale = max(1e-30, ref.abs().max().item())
+    print(f'[f16x2] gemm {M}x{N}x{K} {wkind} weights ({1 + terms} products, scale 2^{int(torch.log2(torch.tensor(sc)).item())}): max err {e:.3g}; fp32 MFMA {e32:.3g}; |ref| {scale:.3g}')
+    assert e <= 4e-6 * max(scale, 2.0 ** -12) and e <= 16 * e32 + 1e-6 * scale
+
+
+@pytest.mark.parametrize('tier', ['bf16x3', 'f16x2'])
 @pytest.mark.parametrize('seed', list(range(12)))
-def test_tier_mm_generate_equals_its_stepwise_loop_and_tracks_the_fp32_engine(seed):
+def test_tier_mm_generate_equals_its_stepwise_loop_and_tracks_the_fp32_engine(seed, tier):
     """one mm_generate call of the tier (compacted last layer, constant null cross-attention, fused sampling where the vocabulary allows)
     against the same tier run operator by operator from Python, and against the fp32-MFMA engine ('parity') on the same inputs"""
     rng = random.Random(7000 + seed)
@@ -89,18 +146,20 @@ def test_tier_mm_generate_equals_its_stepwise_loop_and_tracks_the_fp32_engine(se
     if c['critic'] is not None:
         gkw['critic_noise'] = torch.rand(c['T'], c['B'], n, device=DEV)
     common = dict(timesteps=c['T'], text_embeds=te, seed=seed, fmap_size=c['fmap'], cond_scale=c['cond_scale'], return_ids=True, **gkw)
-    mg.set_precision('bf16x3')
+    mg.set_precision(tier)
     ta, tb = {}, {}
     a = mg.generate([''] * c['B'], trace=ta, **common)
     b = mg.generate([''] * c['B'], trace=tb, stepwise=True, **common)
     nofuse = mg.generate([''] * c['B'], fused_sampling=False, **common)
     assert isinstance(ta['ids'], torch.Tensor) and isinstance(tb['ids'], list)
-    assert t._model().packed['P'] == (3 if c['bf16_weights'] and c['critic'] is None else 6)
+    mg.set_precision(tier)
+    lo, hi = (3, 6) if tier == 'bf16x3' else (2, 3)
+    assert t._model().packed['P'] == (lo if c['bf16_weights'] and c['critic'] is None else hi), (t._model().packed['P'], c)
     assert a.shape == (c['B'], c['fmap'], c['fmap']) and int(a.min()) >= 0 and int(a.max()) < c['V'], c
     mg.set_precision('parity')
     ref = mg.generate([''] * c['B'], **common)
     agree = lambda u, v: (u == v).float().mean().item()
-    print(f'[bf16x3] {c}: C loop vs stepwise {agree(a, b):.4f}, logits path vs stepwise {agree(nofuse, b):.4f}, vs fp32 engine {agree(a, ref):.4f}')
+    print(f'[{tier}] {c}: C loop vs stepwise {agree(a, b):.4f}, logits path vs stepwise {agree(nofuse, b):.4f}, vs fp32 engine {agree(a, ref):.4f}')
     # Philox noise, random-init weights: near-ties are rare but possible, so the engines are held to >= 97 % of the ids; the first step (no
     # history) must be identical between the two drivers of the tier
     assert torch.equal(ta['ids'][0], torch.stack(tb['ids'])[0]), f'first step differs: {c}'

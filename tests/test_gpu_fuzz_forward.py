@@ -1,7 +1,8 @@
 """Randomised parity of Transformer.forward / forward_with_cond_scale against the CPU oracle (oracle/muse_oracle.py, pinned to the reference's
 goldens) over seeded random shapes -- batch, length (not only multiples of the tile sizes), width, heads, depth, vocabulary, text length with
 zero-padded rows, conditioning ids, self-conditioning, text projection or not (t5-small has the transformer's width at dim 512):
-  * precision 'parity' (fp32 storage + fp32 MFMA) against the fp32 oracle: 1e-3 of the logit scale, as the north star states it;
+  * precision 'parity' (fp32 storage + fp32 MFMA) and the two term-product tiers 'bf16x3' / 'f16x2' (raw fp32 weights: all six / three term
+    products) against the fp32 oracle: 1e-3 of the logit scale, as the north star states it;
   * the bf16 engine against the oracle run at the same rounding points: the bound it achieves on the fixtures (3 % of the logit scale)."""
 import random
 
@@ -41,7 +42,7 @@ def test_forward_matches_the_oracle_on_random_shapes(seed):
     t = t.to(DEV)
     kw = dict(conditioning_token_ids=cids.to(DEV) if nc else None, self_cond_embed=sce.to(DEV) if self_cond else None)
     okw = dict(conditioning_token_ids=cids, self_cond_embed=sce)
-    for precision, rp, rel in (('parity', None, 1e-3), ('bf16', O.bf16_round, 3e-2)):
+    for precision, rp, rel in (('parity', None, 1e-3), ('bf16x3', None, 1e-3), ('f16x2', None, 1e-3), ('bf16', O.bf16_round, 3e-2)):      # (raw fp32 weights: the tiers take 6 / 3 term products)
         t.set_precision(precision)
         for drop in (0., 1.):
             got = t(ids.to(DEV), text_embeds=te.to(DEV), cond_drop_prob=drop, **kw).float().cpu()

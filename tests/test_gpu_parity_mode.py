@@ -101,7 +101,7 @@ def test_f32_conv_groupnorm_glu_vs_torch():
 
 
 # ------------------------------------------------------------------------------------------------ tiny fixtures of the reference
-TIERS = ['parity', 'bf16x3']
+TIERS = ['parity', 'bf16x3', 'f16x2']
 
 
 def _tiny(golden, precision='parity'):
@@ -116,6 +116,8 @@ def test_parity_forward_and_guidance_vs_reference_golden(golden, precision):
     g, t = _tiny(golden, precision)
     if precision == 'bf16x3':
         assert t.split_products() == 3          # the fixture's weights are bf16-representable (the 5 / 6-product forms: tests/test_gpu_bf16x3.py)
+    if precision == 'f16x2':
+        assert t.split_products() == 2          # ... and one fp16 term holds each of them
     ids, te = g['ids'].to(DEV), g['text_embeds'].to(DEV)
     lc, emb = t(ids, text_embeds=te, return_embed=True)
     ln = t(ids, text_embeds=te, cond_drop_prob=1.)
@@ -195,3 +197,45 @@ def test_parity_vae_vs_reference_golden(golden):
     assert torch.equal(ids.cpu(), gv['enc_ids']), f'{(ids.cpu() != gv["enc_ids"]).sum().item()} LFQ ids differ from the reference'
     _close('tiny quantized fmap vs reference', fmap, gv['enc_fmap'], 1e-5)
     _close('tiny decode(fmap) vs reference path', v.decode(gv['enc_fmap'].to(DEV)), O.vae_decode(sd_f32(gv['sd']), gv['enc_fmap']), 1e-3 * scale)
+
+
+# ------------------------------------------------------------------------------------------------ general fp32 weights (round 4)
+@pytest.mark.parametrize('precision', TIERS)
+def test_general_fp32_checkpoint_vs_reference_golden(golden, precision):
+    """tiny_fp32.pt (oracle/make_golden_fp32.py): the reference run on parameters that were NOT rounded to bf16 -- what every checkpoint the
+    reference initialises or trains holds.  Forward / guidance logits within the north star's bound, every step of a 4-step decode and the
+    final ids equal to the reference's, VAE pixels and LFQ ids; 'bf16x3' needs all six term products here, 'f16x2' three.  (An engine that
+    packed its weights through bf16 is 20x outside the logits bound on this fixture: test_oracle_vs_golden.py.)"""
+    g = golden('tiny_fp32.pt')
+    t = mm.MaskGitTransformer(t5_name='t5-small', **g['cfg'])
+    t.load_state_dict(g['sd'])
+    t = t.to(DEV).eval().set_precision(precision)
+    if precision != 'parity':
+        assert t.split_products() == dict(bf16x3=6, f16x2=3)[precision]
+    ids, te = g['ids'].to(DEV), g['text_embeds'].to(DEV)
+    lc, emb = t(ids, text_embeds=te, return_embed=True)
+    ln = t(ids, text_embeds=te, cond_drop_prob=1.)
+    sc = t.forward_with_cond_scale(ids, text_embeds=te, cond_scale=3.)
+    scale = g['logits_cond'].abs().max().item()          # to_logits x8: logits are ~20x unit scale
+    _close(f'{precision} fp32-checkpoint logits(cond) vs reference', lc, g['logits_cond'], 1e-3 * max(1., scale / 8))
+    _close(f'{precision} fp32-checkpoint logits(null) vs reference', ln, g['logits_null'], 1e-3 * max(1., scale / 8))
+    _close(f'{precision} fp32-checkpoint logits(guidance) vs reference', sc, g['logits_scaled'], 5e-3 * max(1., scale / 8))
+    _close(f'{precision} fp32-checkpoint embed vs reference', emb, g['embed'], 1e-3)
+    gen = g['generate']
+    v = mm.VQGanVAE(**g['vae']['cfg'])
+    v.load_state_dict(g['vae']['sd'], strict=False)
+    mg = mm.MaskGit(image_size=128, transformer=t, vae=v).to(DEV).eval()
+    mg.set_precision(precision)
+    trace = {}
+    out = mg.generate(['a', 'b'], timesteps=gen['timesteps'], text_embeds=g['text_embeds'], noise=torch.stack(gen['uniform']), noise_kind='uniform', trace=trace,
+                      return_ids=True)
+    for s_ in range(gen['timesteps']):
+        assert torch.equal(trace['masked_ids'][s_].cpu(), gen['step_ids'][s_]), f'ids entering step {s_} differ from the reference'
+    assert torch.equal(out.cpu(), gen['final_ids'])
+    px = gen['images'].abs().max().item()
+    _close(f'{precision} fp32-checkpoint decoded images vs reference', mg.vae.decode_from_ids(out), gen['images'], 1e-3 * px)
+    gv = g['vae']
+    _close(f'{precision} fp32-checkpoint decoded pixels vs reference', mg.vae.decode_from_ids(gv['ids'].to(DEV)), gv['decoded'], 1e-3 * gv['decoded'].abs().max().item())
+    _, eids, _ = mg.vae.encode(gv['image'].to(DEV))
+    safe = (gv['enc_pre_sign'].abs() > 2e-5 * gv['enc_pre_sign'].abs().max()).all(dim=-1).reshape(eids.shape)
+    assert bool((eids.cpu() == gv['enc_ids'])[safe].all()) and safe.float().mean().item() > 0.9

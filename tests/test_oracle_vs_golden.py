@@ -197,7 +197,7 @@ def base_setup(golden, request):
     sd = {k: v.detach().clone() for k, v in tr.state_dict().items()}
     w = sd['transformer_blocks.layers.0.2.1.weight']
     assert bool((w == w.to(torch.bfloat16).float()).all()) == bf16_weights
-    return g, R, sd, R.inputs()
+    return g, R, sd, R.inputs(g['recipe'].get('input_seed'))
 
 
 def _check_samples(R, logits, rec, tol=3e-5):
@@ -256,7 +256,7 @@ def test_oracle_vae_matches_reference_at_dim_256(golden, fixture):
     vae = R.build_vae(mm.VQGanVAE, bf16_weights=g['recipe'].get('bf16_weights', True)).copy_for_eval()
     assert R.state_checksum(vae) == g['vae_weight_checksum']
     sd = sd_f32(vae.state_dict())
-    inp = R.inputs()
+    inp = R.inputs(g['recipe'].get('input_seed'))
     with torch.no_grad():
         dec = O.vae_decode_from_ids(sd, inp['vae_ids'])
         fmap, ids = O.vae_encode(sd, inp['image'])

@@ -66,7 +66,7 @@ def main():
     g = torch.load(os.path.join(ROOT, 'tests', 'golden', args.fixture))
     tr = R.build_transformer(mm.MaskGitTransformer, peaky=True, bf16_weights=g['recipe'].get('bf16_weights', True))
     sd = {k: v.detach() for k, v in tr.state_dict().items()}
-    inp = R.inputs()
+    inp = R.inputs(g['recipe'].get('input_seed'))
     te = inp['text_embeds']
     rp = lambda t: split(t, args.terms)
     depth, heads = 8, 8
