@@ -405,6 +405,12 @@ typedef struct mm_attn_weights {
     const float* w_q_scale;
     const float* w_kv_scale;
     const float* w_out_scale;
+    /* optional, bf16 engine (all three or none; round 4): the block's LayerNorm folded into its first projection -- LayerNorm(x) . W^T =
+     * rstd * (x . Wg^T) - rstd * mean * c1 + c2, so the projection reads the RAW bf16 residual rows (written, with their statistics, by the
+     * residual-adding epilogue in front of it) and no LayerNorm pass runs:                                              */
+    const void* w_q_ln;      /* bf16, w_q's shape (self-attention: the concatenated q|k|v matrix [3I][D]) = bf16(W[n][k] * ln_gamma[k])       */
+    const float* ln_c1;      /* [rows of w_q_ln]: sum_k float(w_q_ln[n][k])                                            */
+    const float* ln_c2;      /* [rows of w_q_ln]: sum_k ln_beta[k] * W[n][k]  (NULL when ln_beta is NULL / zero)         */
 } mm_attn_weights;
 
 typedef struct mm_ff_weights {
@@ -424,6 +430,10 @@ typedef struct mm_ff_weights {
     /* fp8 engine: w1 (same GEGLU interleave) / w2 are e4m3 [2*Fp][D] / [D][Fp] with these per-row scales (fp32 [2*Fp] / [D]); w2_folded unused */
     const float* w1_scale;
     const float* w2_scale;
+    /* optional, bf16 engine (round 4): LayerNorm(dim) in front of w1 folded the same way (see mm_attn_weights.w_q_ln)           */
+    const void* w1_ln;       /* bf16 [2*Fp][D], w1's GEGLU-interleaved row order = bf16(w1[n][k] * ln1_gamma[k])                    */
+    const float* ln1_c1;     /* [2*Fp] in the same row order: sum_k float(w1_ln[n][k])                                   */
+    const float* ln1_c2;     /* [2*Fp]: sum_k ln1_beta[k] * w1[n][k]  (NULL when ln1_beta is NULL / zero)                */
 } mm_ff_weights;
 
 typedef struct mm_layer_weights {

@@ -24,11 +24,11 @@ class MuseHipError(RuntimeError):
 
 
 class AttnWeights(C.Structure):
-    _fields_ = [(n, c_vp) for n in ('ln_gamma', 'ln_beta', 'w_q', 'w_kv', 'w_out', 'null_k', 'null_v', 'q_scale', 'k_scale', 'w_q_scale', 'w_kv_scale', 'w_out_scale')]
+    _fields_ = [(n, c_vp) for n in ('ln_gamma', 'ln_beta', 'w_q', 'w_kv', 'w_out', 'null_k', 'null_v', 'q_scale', 'k_scale', 'w_q_scale', 'w_kv_scale', 'w_out_scale', 'w_q_ln', 'ln_c1', 'ln_c2')]
 
 
 class FFWeights(C.Structure):
-    _fields_ = [(n, c_vp) for n in ('ln1_gamma', 'ln1_beta', 'w1', 'ln2_gamma', 'ln2_beta', 'w2', 'w2_folded', 'ln2_c1', 'ln2_c2', 'w1_scale', 'w2_scale')]
+    _fields_ = [(n, c_vp) for n in ('ln1_gamma', 'ln1_beta', 'w1', 'ln2_gamma', 'ln2_beta', 'w2', 'w2_folded', 'ln2_c1', 'ln2_c2', 'w1_scale', 'w2_scale', 'w1_ln', 'ln1_c1', 'ln1_c2')]
 
 
 class LayerWeights(C.Structure):

@@ -123,6 +123,34 @@ __device__ __forceinline__ float2 ln_stats_from_partials(const float* part, int 
     return make_float2(mean, 1.f / sqrtf(var + 1e-5f));
 }
 
+// the same (mean, rstd) from np partials held by ONE lane (pp: the row's np float2 partials, e.g. in LDS): first half summed in index order, second half
+// summed in index order, the halves added -- bit-identical to ln_stats_from_partials (adding to 0.f first is exact)
+__device__ __forceinline__ float2 ln_stats_seq(const float2* pp, int np, int F) {
+    const int n0 = (np + 1) >> 1;
+    float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+    for (int i = 0; i < n0; ++i) { const float2 v = pp[i]; a1 += v.x; a2 += v.y; }
+    for (int i = n0; i < np; ++i) { const float2 v = pp[i]; b1 += v.x; b2 += v.y; }
+    const float s1 = a1 + b1, s2 = a2 + b2;
+    const float mean = s1 / (float)F;
+    const float var = fmaxf(s2 / (float)F - mean * mean, 0.f);
+    return make_float2(mean, 1.f / sqrtf(var + 1e-5f));
+}
+
+// LayerNorm(dim) folded into the GEMMs around it (round 4; GemmArgs::st_part / in_c1).  PRODUCER side: the fp32-residual epilogues (out = x + ...) hand 4
+// consecutive columns of one row to 32 adjacent lanes (one 128-column tile row): the row's (sum, sum of squares) over those 128 fp32 values, identical in
+// all 32 lanes.  DPP inside each 16-lane row (fixed pairing), one cross-row exchange.
+__device__ __forceinline__ float2 row_stats32(float s1, float s2) {
+#define MM_DPP_ADD(x_, ctrl_) x_ += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x_), ctrl_, 0xF, 0xF, true))
+    MM_DPP_ADD(s1, 0xB1); MM_DPP_ADD(s2, 0xB1);      // quad_perm [1,0,3,2]
+    MM_DPP_ADD(s1, 0x4E); MM_DPP_ADD(s2, 0x4E);      // quad_perm [2,3,0,1]
+    MM_DPP_ADD(s1, 0x141); MM_DPP_ADD(s2, 0x141);    // row_half_mirror
+    MM_DPP_ADD(s1, 0x140); MM_DPP_ADD(s2, 0x140);    // row_mirror
+#undef MM_DPP_ADD
+    s1 += __shfl_xor(s1, 16, 64);
+    s2 += __shfl_xor(s2, 16, 64);
+    return make_float2(s1, s2);
+}
+
 // full-wave (64-lane) butterfly reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -40,7 +40,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + 
 __device__ __attribute__((aligned(16))) const unsigned int g_zero_page[64] = {0};
 
 template <int MODE, bool F16 = false>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TSTAMP(0)
     const int t = threadIdx.x;
@@ -156,6 +156,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             const int r_ = t >> 1, m_ = m0 + r_;
             const float2 st = ln_stats_from_partials(p.ln_part, p.ln_np, m_ < p.M ? m_ : 0, p.ln_F, t & 1, m_ < p.M);
             if (!(t & 1)) ln_stat[r_] = st;
+        } else if (p.in_c1) {           // LayerNorm(dim) fold, consumer side (GemmArgs::in_c1): the operand rows are raw residual rows, their statistics come with them
+            const int r_ = t >> 1, m_ = m0 + r_;
+            const float2 st = ln_stats_from_partials(p.in_part, p.in_np, m_ < p.M ? m_ : 0, p.in_F, t & 1, m_ < p.M);
+            if (!(t & 1)) ln_stat[r_] = st;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA of the first k-tile has landed (explicit: a barrier alone does not drain VMEM)
@@ -198,6 +202,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             for (int b = 0; b < 4; ++b) acc[a][b] *= al;
     }
 
+    if constexpr (MODE == MODE_DENSE) {
+        if (p.in_c1) {
+            // LayerNorm(dim) fold, consumer side: X held the raw residual rows, W the gains -> acc = rstd * acc - rstd * mean * c1[n] + c2[n], applied on the
+            // accumulators (before GEGLU when there is one), the same expression in the same order as gemm_wide.hip's
+            const bool has_c2 = p.in_c2 != nullptr;
+            float4 c1v[4], c2v[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int n = n0 + wave_n * 64 + a * 16 + fg * 4;
+                c1v[a] = (n + 3 < p.N) ? *reinterpret_cast<const float4*>(p.in_c1 + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                c2v[a] = (has_c2 && n + 3 < p.N) ? *reinterpret_cast<const float4*>(p.in_c2 + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float2 stv = ln_stat[wave_m * 64 + b * 16 + fr];
+                const float rs = stv.y, rm = stv.x * stv.y;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    acc[a][b][0] = rs * acc[a][b][0] - rm * c1v[a].x + c2v[a].x;
+                    acc[a][b][1] = rs * acc[a][b][1] - rm * c1v[a].y + c2v[a].y;
+                    acc[a][b][2] = rs * acc[a][b][2] - rm * c1v[a].z + c2v[a].z;
+                    acc[a][b][3] = rs * acc[a][b][3] - rm * c1v[a].w + c2v[a].w;
+                }
+            }
+        }
+    }
     // ---- epilogue.  A lane holds out[m][n..n+3] per fragment (16 rows x 64 B per store instruction): storing that
     //      directly touches half cache lines and was measured at 35-45 % of the kernel.  Instead the tile goes
     //      through LDS (fp32, row stride 132 floats: conflict-free ds_write_b128) and is written out row-contiguously,
@@ -323,11 +353,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             if (resid_pf) {      // the residual is already in registers: a pure store phase
                 float4 lc1 = make_float4(0.f, 0.f, 0.f, 0.f), lc2 = lc1;
                 if (p.ln_c1 && n < p.N) { lc1 = *reinterpret_cast<const float4*>(p.ln_c1 + n); lc2 = *reinterpret_cast<const float4*>(p.ln_c2 + n); }
+                float4 arow = make_float4(0.f, 0.f, 0.f, 0.f);      // LayerNorm(dim) fold, producer side (GemmArgs::xb_out): see below
+                if (p.add_row && n < p.N) arow = *reinterpret_cast<const float4*>(p.add_row + n);
+                const bool fold_out = p.xb_out != nullptr;         // (wave-uniform)
 #pragma unroll
                 for (int pass = 0; pass < BT / 8; ++pass) {
                     const int ml = pass * 8 + (t >> 5);
                     const int m = m0 + ml;
-                    if (m >= p.M || n >= p.N) continue;
+                    const bool ok_ = m < p.M && n < p.N;
+                    if (!fold_out && !ok_) continue;
+                    if (fold_out && __ballot(ok_) == 0ull) continue;
                     // The row's statistics are read -- and RETIRED -- before the tile row is requested.  Round-1 order (tile row, then the
                     // statistics right behind it, both LDS reads in flight) produced, in ~4 % of full-size launches, rstd * acc.x == 0 in the
                     // last quarter-wave (lanes 48-63) of one pass of one workgroup: one output row off by its whole feed-forward term in 16
@@ -340,8 +375,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                         cv.x = rs * cv.x - rm * lc1.x + lc2.x; cv.y = rs * cv.y - rm * lc1.y + lc2.y;
                         cv.z = rs * cv.z - rm * lc1.z + lc2.z; cv.w = rs * cv.w - rm * lc1.w + lc2.w;
                     }
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + (size_t)m * p.ldc + n) =
-                        make_float4(cv.x + rres[pass].x, cv.y + rres[pass].y, cv.z + rres[pass].z, cv.w + rres[pass].w);
+                    float4 o = make_float4(cv.x + rres[pass].x, cv.y + rres[pass].y, cv.z + rres[pass].z, cv.w + rres[pass].w);
+                    if (p.add_row && m >= p.add_row_from) { o.x += arow.x; o.y += arow.y; o.z += arow.z; o.w += arow.w; }      // (acc + resid) + add_row
+                    if (ok_) *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + (size_t)m * p.ldc + n) = o;
+                    if (fold_out) {
+                        // the new residual row also leaves as bf16 (the operand of the GEMM behind the next LayerNorm, which then needs no pass of its own)
+                        // together with this 128-column tile's share of the row's (sum, sum of squares), taken from the fp32 values
+                        if (!ok_) o = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (ok_) *reinterpret_cast<uint2*>(p.xb_out + (size_t)m * p.ldxb + n) = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+                        const float2 st2 = row_stats32((o.x + o.y) + (o.z + o.w), (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w));
+                        if ((t & 31) == 0 && m < p.M) *reinterpret_cast<float2*>(p.st_part + ((size_t)m * p.st_np + tile_n) * 2) = st2;
+                    }
                 }
                 TSTAMP(43)
                 return;
@@ -476,6 +520,23 @@ int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
         a.tiles_n = (a.N + BT - 1) / BT;
         a.tiles_m = (a.M + BT - 1) / BT;
         return a.mode == MODE_CONV ? launch<MODE_CONV, true>(a, stream) : launch<MODE_DENSE, true>(a, stream);
+    }
+    if (a.in_c1) {      // LayerNorm(dim) fold, consumer side: the wide kernels or the 128x128 kernel (bf16 output, dense)
+        if (a.mode != MODE_DENSE || a.out_kind != OUT_BF16 || !a.in_part || a.in_np <= 0 || a.in_F <= 0 || a.resid_bf16 || a.bias || a.splits > 1 || a.m_dev || (a.N % 4))
+            return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: the LayerNorm(dim) fold needs a plain dense bf16-output GEMM");
+        if (!(a.debug & (8 | 4096 | 8192 | (1 << 30))) && mm_gemm_wide_eligible(a)) return mm_gemm_wide_launch(a, stream);
+        a.tiles_n = (a.N + BT - 1) / BT;
+        a.tiles_m = (a.M + BT - 1) / BT;
+        return launch<MODE_DENSE>(a, stream);
+    }
+    if (a.xb_out) {     // ... producer side: the fp32-residual epilogue of the 256x128 / 128x128 kernels
+        if (a.mode != MODE_DENSE || a.out_kind != OUT_F32 || !a.resid_f32 || (a.N % 4) || !a.st_part || a.splits > 1 || a.m_dev || a.epi != EPI_NONE)
+            return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: the LayerNorm(dim) fold is produced by the dense fp32-residual epilogue");
+        a.st_np = (a.N + 127) / 128;
+        if (!(a.debug & 8) && mm_gemm_big_eligible(a)) return mm_gemm_big_launch(a, stream);
+        a.tiles_n = (a.N + BT - 1) / BT;
+        a.tiles_m = (a.M + BT - 1) / BT;
+        return launch<MODE_DENSE>(a, stream);
     }
     if (a.m_dev) a.debug |= 8;      // only the 128x128 kernel reads the device-side row count
     if (!(a.debug & (8 | 4096 | 8192 | (1 << 30))) && mm_gemm_wide_eligible(a)) return mm_gemm_wide_launch(a, stream);      // (bit 1 << 30: A/B against the older kernels)

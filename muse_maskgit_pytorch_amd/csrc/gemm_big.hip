@@ -267,11 +267,16 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
             if (resid_pf) {      // the residual is already in registers: a pure store phase
                 float4 lc1 = make_float4(0.f, 0.f, 0.f, 0.f), lc2 = lc1;
                 if (p.ln_c1 && n < p.N) { lc1 = *reinterpret_cast<const float4*>(p.ln_c1 + n); lc2 = *reinterpret_cast<const float4*>(p.ln_c2 + n); }
+                float4 arow = make_float4(0.f, 0.f, 0.f, 0.f);      // LayerNorm(dim) fold, producer side (GemmArgs::xb_out): see below
+                if (p.add_row && n < p.N) arow = *reinterpret_cast<const float4*>(p.add_row + n);
+                const bool fold_out = p.xb_out != nullptr;         // (wave-uniform)
 #pragma unroll
                 for (int pass = 0; pass < BMB / 16; ++pass) {
                     const int ml = pass * 16 + (t >> 5);
                     const int m = m0 + ml;
-                    if (m >= p.M || n >= p.N) continue;
+                    const bool ok_ = m < p.M && n < p.N;
+                    if (!fold_out && !ok_) continue;
+                    if (fold_out && __ballot(ok_) == 0ull) continue;
                     // statistics first, retired, then the tile row: see the same loop in gemm.hip (the 128x128 kernel's round-1 failure)
                     float2 st = make_float2(0.f, 1.f);
                     if (p.ln_c1) { st = ln_stat[ml]; __builtin_amdgcn_s_waitcnt(0xC07F); }
@@ -281,8 +286,17 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
                         cv.x = rs * cv.x - rm * lc1.x + lc2.x; cv.y = rs * cv.y - rm * lc1.y + lc2.y;
                         cv.z = rs * cv.z - rm * lc1.z + lc2.z; cv.w = rs * cv.w - rm * lc1.w + lc2.w;
                     }
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) =
-                        make_float4(cv.x + rres[pass].x, cv.y + rres[pass].y, cv.z + rres[pass].z, cv.w + rres[pass].w);
+                    float4 o = make_float4(cv.x + rres[pass].x, cv.y + rres[pass].y, cv.z + rres[pass].z, cv.w + rres[pass].w);
+                    if (p.add_row && m >= p.add_row_from) { o.x += arow.x; o.y += arow.y; o.z += arow.z; o.w += arow.w; }      // (acc + resid) + add_row
+                    if (ok_) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = o;
+                    if (fold_out) {
+                        // the new residual row also leaves as bf16 (the operand of the GEMM behind the next LayerNorm, which then needs no pass of its own)
+                        // together with this 128-column tile's share of the row's (sum, sum of squares), taken from the fp32 values
+                        if (!ok_) o = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (ok_) *reinterpret_cast<uint2*>(p.xb_out + (size_t)m * p.ldxb + n) = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+                        const float2 st2 = row_stats32((o.x + o.y) + (o.z + o.w), (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w));
+                        if ((t & 31) == 0 && m < p.M) *reinterpret_cast<float2*>(p.st_part + ((size_t)m * p.st_np + tile_n) * 2) = st2;
+                    }
                 }
                 return;
             }

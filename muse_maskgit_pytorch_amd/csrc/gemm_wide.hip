@@ -17,6 +17,7 @@ namespace {
 
 constexpr int TM = 256, TN = 256, BKB = 128;      // tile (TN: the 256-row weight tile; the dense kernel also has a 192-row form); bytes per k-step row (64 bf16)
 constexpr int X_B = TM * BKB, W_B = TN * BKB, STG = X_B + W_B, SMEM = 2 * STG;
+constexpr int WIDE_MAX_NP = 8;      // LayerNorm(dim) fold: up to 8 partials per row (dim <= 1024) fit behind the stages (160 KiB of LDS)
 
 __device__ __forceinline__ int sw128(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
@@ -89,6 +90,13 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs p) {
             const int st = kt & 1;
             if (kt == 0) wait_vmcnt_w(pending); else __builtin_amdgcn_s_waitcnt(0x0F70);      // this step's DMA has landed (only younger stores may still be in flight)
             __builtin_amdgcn_s_barrier();            // ... for everybody, and everybody is done reading the other stage
+            if (kt == 1 && p.in_c1 && wid < 4) {
+                // LayerNorm(dim) fold: the partials of this tile's 256 rows landed with step 1's wait; ONE thread per row turns them into (rstd, mean * rstd) in
+                // the shadow of this step's MFMAs (read again only in the epilogue, many barriers from here)
+                const int np_ = p.in_np;
+                const float2 stv = ln_stats_seq(reinterpret_cast<const float2*>(smem + 2 * STG) + t * np_, np_, p.in_F);
+                reinterpret_cast<float2*>(smem + 2 * STG + TM * np_ * 8 + 2048)[t] = make_float2(stv.y, stv.x * stv.y);
+            }
             const unsigned char* xs = smem + st * STG + (wm * 128) * BKB;
             const unsigned char* ws = smem + st * STG + X_B + (wn * 16 * NFW) * BKB;
 #pragma unroll
@@ -111,6 +119,21 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs p) {
                         TILE_SETUP(vb + G);
                         ISSUE(0, 0);
                     }
+                    if (kt == 0 && p.in_c1) {
+                        // LayerNorm(dim) fold (GemmArgs::in_c1): this tile's row statistics partials (256 rows x np x 8 bytes) and its 64 NFW entries of c1 / c2
+                        // arrive by LDS-DMA too, behind the stages (retired by the vmcnt(0) of step 1: K >= 128)
+                        const int np_ = p.in_np;
+                        const int left_ = p.M - m0;
+                        const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in_part + (size_t)m0 * np_ * 2), 0,
+                                                                                             (unsigned)(left_ < TM ? left_ : TM) * (unsigned)np_ * 8u, 0x00020000);
+                        for (int pc = wid; pc < 2 * np_; pc += 8)
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_ptr_t)(smem + 2 * STG + pc * 1024), 16, lane * 16, pc * 1024, 0, 0);
+                        if (wid == 7 || (wid == 6 && p.in_c2)) {
+                            const float* src_ = (wid == 7 ? p.in_c1 : p.in_c2) + n0;
+                            const __amdgpu_buffer_rsrc_t rc_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src_), 0, (unsigned)TN * 4u, 0x00020000);
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rc_, (lds_ptr_t)(smem + 2 * STG + TM * np_ * 8 + (wid == 7 ? 0 : 1024)), 16, lane * 16, 0, 0, 0);
+                        }
+                    }
                 }
             }
         }
@@ -118,6 +141,33 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs p) {
         __builtin_amdgcn_s_barrier();                // everybody is done with stage 1: it becomes the output staging tile
         const bool full = m0 + TM <= p.M;            // ragged tiles skip stores: their count is not wave-uniform, the next wait then takes everything
         int nstore = 0;
+        if (p.in_c1) {
+            // LayerNorm(dim) fold, consumer side: X held the raw residual rows, W the gains -> out = rstd * acc - rstd * mean * c1[n] + c2[n] (before GEGLU);
+            // one canonical evaluation order with the 128 x 128 kernel (ln_stats_seq == ln_stats_from_partials, the same three-term expression)
+            const int np_ = p.in_np;
+            const float2* rsm = reinterpret_cast<const float2*>(smem + 2 * STG + TM * np_ * 8 + 2048);      // per row (rstd, mean * rstd), written at k-step 1
+            const float* lc1 = reinterpret_cast<const float*>(smem + 2 * STG + TM * np_ * 8);
+            const bool has_c2 = p.in_c2 != nullptr;
+            float4 c1v[NFW], c2v[NFW];
+#pragma unroll
+            for (int a = 0; a < NFW; ++a) {
+                const int ci = wn * 16 * NFW + a * 16 + 4 * fg;
+                c1v[a] = *reinterpret_cast<const float4*>(lc1 + ci);
+                c2v[a] = has_c2 ? *reinterpret_cast<const float4*>(lc1 + 256 + ci) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const float2 stv = rsm[wm * 128 + b * 16 + fr];
+                const float rs = stv.x, rm = stv.y;
+#pragma unroll
+                for (int a = 0; a < NFW; ++a) {
+                    acc[a][b][0] = rs * acc[a][b][0] - rm * c1v[a].x + c2v[a].x;
+                    acc[a][b][1] = rs * acc[a][b][1] - rm * c1v[a].y + c2v[a].y;
+                    acc[a][b][2] = rs * acc[a][b][2] - rm * c1v[a].z + c2v[a].z;
+                    acc[a][b][3] = rs * acc[a][b][3] - rm * c1v[a].w + c2v[a].w;
+                }
+            }
+        }
         if constexpr (GEGLU && NFW == 4) {
             // interleaved w1 packing: within a wave's 64 weight rows the first 32 are values, the next 32 their gates -> 128 output columns per tile
             constexpr int ROWB = 256;                // staging row bytes (128 bf16): 256 rows = 64 KiB = stage 1
@@ -400,7 +450,7 @@ __global__ __launch_bounds__(512) void gemm_wide_fused_kernel(const GemmArgs p) 
 
 template <bool GEGLU, int NFW>
 int launch_wide(GemmArgs a, hipStream_t stream) {
-    constexpr int SM = 2 * (TM + 64 * NFW) * BKB;
+    constexpr int SM = 2 * (TM + 64 * NFW) * BKB + TM * WIDE_MAX_NP * 8 + 2048 + TM * 8;      // two stages + the LayerNorm-fold data (row statistics partials, c1, c2, per-row rstd / mean * rstd)
     static bool attr_set = false;
     if (!attr_set) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<GEGLU, NFW>), hipFuncAttributeMaxDynamicSharedMemorySize, SM);
@@ -438,6 +488,7 @@ bool mm_gemm_wide_eligible(const GemmArgs& a) {
     if (a.epi != EPI_NONE && a.epi != EPI_GEGLU) return false;
     if ((a.K % 64) || a.K < 128 || (a.ldx % 8) || (a.ldw % 8) || (a.ldc % 8) || (((uintptr_t)a.out) & 15)) return false;
     if (a.ln_part && a.epi != EPI_GEGLU) return false;
+    if (a.in_c1 && (a.in_np < 1 || a.in_np > WIDE_MAX_NP || !a.in_part || (a.N % 4))) return false;
     return wide_nfw(a) != 0;
 }
 

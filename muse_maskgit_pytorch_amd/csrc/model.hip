@@ -194,6 +194,8 @@ struct Bufs {       // activation scratch for `rows` token rows
     bf16_t* h;      // [rows][2Fp]
     bf16_t* a;      // [rows][Fp]
     float* lnp;     // [rows][Fp / 32][2]: LayerNorm(inner) partial sums of the folded feed-forward
+    bf16_t* xb;     // [rows][D]: the residual stream as bf16, written by the residual-adding epilogues (LayerNorm(dim) fold, bf16 engine)
+    float* stp;     // [rows][ceil(D / 128)][2]: ... with the rows' (sum, sum of squares) per 128-column tile
     unsigned char* q8;   // fp8 engine: the e4m3 rows of the activation that feeds the next Linear, [rows][max(D, I, Fp)]
     float* q8s;          // ... and their per-row scales [rows]
 };
@@ -209,6 +211,8 @@ void carve_bufs(Carver& c, const mm_transformer* t, size_t rows, Bufs& b) {
     b.h = c.take<bf16_t>(rows * 2 * Fp * f32);
     b.a = c.take<bf16_t>(rows * Fp * seg);
     b.lnp = c.take<float>(rows * (Fp / 32) * 2);
+    b.xb = c.take<bf16_t>((t->P || t->F8) ? 0 : rows * D);
+    b.stp = c.take<float>((t->P || t->F8) ? 0 : rows * ((D + 127) / 128) * 2);
     b.q8 = nullptr; b.q8s = nullptr;
     if (t->F8) {
         const size_t w = (size_t)(D > I ? (D > Fp ? D : Fp) : (I > Fp ? I : Fp));
@@ -233,10 +237,39 @@ int f8_linear_bf16(hipStream_t s, Bufs& b, const bf16_t* act, long lda, int K, c
     return f8_linear(s, b, K, w, w_scale, M, N, out, ldc, epi, resid);
 }
 
+// LayerNorm(dim) folded into the GEMMs around it (round 4, bf16 engine; GemmArgs::xb_out / in_c1): the residual-adding epilogues (attention output
+// projections, FF w2) also write the new residual row as bf16 + its (sum, sum of squares) per 128-column tile, and the projection behind the next
+// LayerNorm (q|k|v, cross-attention q, FF w1) multiplies those RAW rows by gain-folded weights and applies rstd * (acc - mean * c1) + c2 in its
+// epilogue: the LayerNorm's own pass over the stream (468 launches, 4.5 ms per generate at the base config) disappears.  Layer 0 keeps the unfolded
+// self-attention / feed-forward LayerNorms (its inputs come from the embedding kernel and, in the decode loop, from a row copy); debug bit 1 << 29 turns
+// the fold off (A/B and the closeness test).
+bool ln_fold_on(const mm_transformer* t) {
+    return !t->P && !t->F8 && !(g_mm_debug & (1 << 29)) && (t->d.dim % 4) == 0 && (t->d.dim + 127) / 128 <= 8;
+}
+void fold_consume(GemmArgs& a, const mm_transformer* t, const Bufs& b, const void* w_ln, const float* c1, const float* c2) {
+    a.X = b.xb; a.ldx = t->d.dim; a.W = (const bf16_t*)w_ln;
+    a.in_part = b.stp; a.in_np = (t->d.dim + 127) / 128; a.in_F = t->d.dim; a.in_c1 = c1; a.in_c2 = c2;
+}
+void fold_produce(GemmArgs& a, const mm_transformer* t, const Bufs& b, const float* add_row, int add_row_from) {
+    a.xb_out = b.xb; a.ldxb = t->d.dim; a.st_part = b.stp; a.add_row = add_row; a.add_row_from = add_row_from;
+}
+// out (fp32, in place over resid) = resid + X . W^T, optionally producing the fold data of the new rows
+int gemm_resid(const mm_transformer* t, hipStream_t s, const bf16_t* X, int ldx, const bf16_t* W, int ldw, int M, int N, int K, float* out, const Bufs& b,
+               bool fold_out, const float* add_row = nullptr, int add_row_from = 0) {
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mode = MODE_DENSE;
+    a.W = W; a.N = N; a.ldw = ldw; a.K = K; a.M = M; a.X = X; a.ldx = ldx;
+    a.out = out; a.ldc = N; a.out_kind = OUT_F32; a.resid_f32 = out; a.ldr = N;
+    if (fold_out) fold_produce(a, t, b, add_row, add_row_from);
+    return mm_gemm_launch(a, s);
+}
+
 // dst += FF(src)   (mmp.py:79-89 with the residual of :193 / the self-cond add of :328)
 // addvec != NULL (src == dst): rows [add_from, rows) first get the row vector added in place, inside the first LayerNorm's pass
+// fold_in: the rows' bf16 copy + statistics are in b.xb / b.stp (src == dst, no addvec: the producer added it); fold_out: the w2 epilogue produces them
 int ff_block(const mm_transformer* t, hipStream_t s, const mm_ff_weights& w, const float* src, float* dst, int rows, Bufs& b,
-             const float* addvec = nullptr, int add_from = 0) {
+             const float* addvec = nullptr, int add_from = 0, bool fold_in = false, bool fold_out = false) {
     const int D = t->d.dim, F = t->d.ff_inner, Fp = t->Fp;
     if (t->P) {      // precision tier: LN -> P segments -> w1 (fp32 out, plain [x | gate] halves) -> GEGLU + LN(inner) -> P segments -> w2 + residual
         const int P = t->P;
@@ -257,13 +290,17 @@ int ff_block(const mm_transformer* t, hipStream_t s, const mm_ff_weights& w, con
         TR(dst, (size_t)rows * D * 4);
         return MM_OK;
     }
-    if (addvec) RC(k_layernorm_addvec(s, dst, D, rows, D, w.ln1_gamma, w.ln1_beta, addvec, add_from, b.xn, D));
+    fold_in = fold_in && w.w1_ln && w.ln1_c1 && !addvec && src == dst;
+    fold_out = fold_out && src == dst;
+    if (fold_in) {}      // LayerNorm(dim) rides in w1's epilogue
+    else if (addvec) RC(k_layernorm_addvec(s, dst, D, rows, D, w.ln1_gamma, w.ln1_beta, addvec, add_from, b.xn, D));
     else RC(k_layernorm(s, src, D, rows, D, w.ln1_gamma, w.ln1_beta, nullptr, b.xn, D));
     GemmArgs a1;      // Linear(D, 2F) with the GEGLU fused into the epilogue: w1 is packed GEGLU-interleaved, the GEMM emits gate*gelu(x)
     memset(&a1, 0, sizeof(a1));
     a1.mode = MODE_DENSE; a1.epi = EPI_GEGLU;
     a1.W = (const bf16_t*)w.w1; a1.N = 2 * Fp; a1.ldw = D; a1.K = D; a1.M = rows; a1.X = b.xn; a1.ldx = D;
     a1.out = b.h; a1.ldc = Fp; a1.out_kind = OUT_BF16;
+    if (fold_in) fold_consume(a1, t, b, w.w1_ln, w.ln1_c1, w.ln1_c2);
     GemmArgs a2;      // Linear(F, D) + residual
     memset(&a2, 0, sizeof(a2));
     a2.mode = MODE_DENSE;
@@ -274,7 +311,8 @@ int ff_block(const mm_transformer* t, hipStream_t s, const mm_ff_weights& w, con
     // own pass over the [rows][Fp] activation (read + write, 2.8 ms per generate at the base config) disappears.  Every kernel of the
     // GEMM family implements both halves identically, so the result does not depend on which kernel a shape is dispatched to.
     const bool fold = w.w2_folded && w.ln2_c1 && w.ln2_c2 && !(g_mm_debug & (1 << 24)) && (D % 4) == 0;
-    TR(b.xn, (size_t)rows * D * 2);
+    TR(fold_in ? b.xb : b.xn, (size_t)rows * D * 2);      // (fold: the raw bf16 rows the producer's epilogue left; their statistics show in w1's output)
+    if (fold_out) fold_produce(a2, t, b, nullptr, 0);
     if (fold) {
         a1.ln_part = b.lnp;
         RC(mm_gemm_launch(a1, s));
@@ -296,7 +334,8 @@ int ff_block(const mm_transformer* t, hipStream_t s, const mm_ff_weights& w, con
 }
 
 // b.att = heads of SelfAttention(LN(x)) over `seqs` sequences of n tokens, before the output projection  (mmp.py:126-159, context = None)
-int self_attn_core(const mm_transformer* t, hipStream_t s, const mm_attn_weights& w, int seqs, int n, Bufs& b) {
+// fold_in: the rows' bf16 copy + statistics are in b.xb / b.stp (LayerNorm(dim) fold): q|k|v runs on them with the gain-folded weights, no LayerNorm pass
+int self_attn_core(const mm_transformer* t, hipStream_t s, const mm_attn_weights& w, int seqs, int n, Bufs& b, bool fold_in = false) {
     const int D = t->d.dim, I = t->I, H = t->d.heads, dh = t->d.dim_head;
     const int rows = seqs * n;
     if (t->P) {      // precision tier: q|k|v stay fp32, the attention runs on the fp32 MFMA and writes its output as P segments
@@ -334,6 +373,15 @@ int self_attn_core(const mm_transformer* t, hipStream_t s, const mm_attn_weights
             RC(f8_linear(s, b, D, w.w_kv, w.w_kv_scale, rows, 2 * I, b.qkv + I, 3 * I, 0, nullptr));
         }
     } else {
+    if (fold_in && w.w_q_ln && w.ln_c1 && wkv == wq + (size_t)I * D) {
+        GemmArgs a;
+        memset(&a, 0, sizeof(a));
+        a.mode = MODE_DENSE; a.N = 3 * I; a.ldw = D; a.K = D; a.M = rows;
+        a.out = b.qkv; a.ldc = 3 * I; a.out_kind = OUT_BF16;
+        fold_consume(a, t, b, w.w_q_ln, w.ln_c1, w.ln_c2);
+        TR(b.xb, (size_t)rows * D * 2);
+        RC(mm_gemm_launch(a, s));
+    } else {
     RC(k_layernorm(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, b.xn, D));
     TR(b.xn, (size_t)rows * D * 2);
     if (wkv == wq + (size_t)I * D) {
@@ -341,6 +389,7 @@ int self_attn_core(const mm_transformer* t, hipStream_t s, const mm_attn_weights
     } else {
         RC(gemm_dense(t, s, b.xn, D, wq, D, rows, I, D, b.qkv, 3 * I, OUT_BF16, nullptr));
         RC(gemm_dense(t, s, b.xn, D, wkv, D, rows, 2 * I, D, b.qkv + I, 3 * I, OUT_BF16, nullptr));
+    }
     }
     }
     AttnArgs a;
@@ -359,10 +408,14 @@ int self_attn_core(const mm_transformer* t, hipStream_t s, const mm_attn_weights
 }
 
 // x += SelfAttention(x) over `seqs` sequences of n tokens  (mmp.py:126-162 with context = None, :189)
-int self_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weights& w, int seqs, int n, Bufs& b) {
-    RC(self_attn_core(t, s, w, seqs, n, b));
+// fold_out: the output projection's epilogue also writes the new rows as bf16 + statistics (b.xb / b.stp); add_row (fold_out only): a row vector added to
+// rows >= add_row_from behind the residual (the null half's constant cross-attention, which otherwise rides in the feed-forward's LayerNorm pass)
+int self_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weights& w, int seqs, int n, Bufs& b, bool fold_in = false, bool fold_out = false,
+                    const float* add_row = nullptr, int add_row_from = 0) {
+    RC(self_attn_core(t, s, w, seqs, n, b, fold_in));
     const int KI = (t->P ? t->P : 1) * t->I;      // precision tier: P segments per operand row
     if (t->F8) RC(f8_linear_bf16(s, b, b.att, t->I, t->I, w.w_out, w.w_out_scale, seqs * n, t->d.dim, b.x, t->d.dim, 2, b.x));
+    else if (fold_out) RC(gemm_resid(t, s, b.att, KI, (const bf16_t*)w.w_out, KI, seqs * n, t->d.dim, KI, b.x, b, true, add_row, add_row_from));
     else RC(gemm_dense(t, s, b.att, KI, (const bf16_t*)w.w_out, KI, seqs * n, t->d.dim, KI, b.x, t->d.dim, OUT_F32, b.x));
     TR(b.x, (size_t)seqs * n * t->d.dim * 4);
     return MM_OK;
@@ -370,7 +423,7 @@ int self_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weight
 
 // x += CrossAttention(x, ctx) for `seqs` sequences; ckv = ctx @ to_kv^T given as [kv_seqs*m][2I]  (mmp.py:191)
 int cross_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weights& w, int seqs, int n, const bf16_t* ckv,
-                     int m, int kv_batch_mod, const uint8_t* key_mask, Bufs& b) {
+                     int m, int kv_batch_mod, const uint8_t* key_mask, Bufs& b, bool fold_in = false, bool fold_out = false) {
     const int D = t->d.dim, I = t->I, H = t->d.heads, dh = t->d.dim_head;
     const int rows = seqs * n;
     if (t->P) {      // precision tier: ckv is fp32 [kv_seqs*m][2I]
@@ -397,6 +450,14 @@ int cross_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weigh
     if (t->F8) {      // fp8 engine: LN -> e4m3, q projection on the fp8 MFMA (the context's k | v projection stays bf16: once per generate)
         RC(k_layernorm_q8(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, 0, b.q8, D, b.q8s));
         RC(f8_linear(s, b, D, w.w_q, w.w_q_scale, rows, I, b.qkv, I, 0, nullptr));
+    } else if (fold_in && w.w_q_ln && w.ln_c1) {      // LayerNorm(dim) fold: q from the raw bf16 rows + statistics the self-attention's output projection left
+        GemmArgs a;
+        memset(&a, 0, sizeof(a));
+        a.mode = MODE_DENSE; a.N = I; a.ldw = D; a.K = D; a.M = rows;
+        a.out = b.qkv; a.ldc = I; a.out_kind = OUT_BF16;
+        fold_consume(a, t, b, w.w_q_ln, w.ln_c1, w.ln_c2);
+        TR(b.xb, (size_t)rows * D * 2);
+        RC(mm_gemm_launch(a, s));
     } else {
         RC(k_layernorm(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, b.xn, D));
         TR(b.xn, (size_t)rows * D * 2);
@@ -416,6 +477,7 @@ int cross_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weigh
     RC(k_attention(s, a));
     TR(b.att, (size_t)rows * I * 2);
     if (t->F8) RC(f8_linear_bf16(s, b, b.att, I, I, w.w_out, w.w_out_scale, rows, D, b.x, D, 2, b.x));
+    else if (fold_out) RC(gemm_resid(t, s, b.att, I, (const bf16_t*)w.w_out, I, rows, D, I, b.x, b, true));
     else RC(gemm_dense(t, s, b.att, I, (const bf16_t*)w.w_out, I, rows, D, I, b.x, D, OUT_F32, b.x));
     TR(b.x, (size_t)rows * D * 4);
     return MM_OK;
@@ -577,13 +639,14 @@ int mm_transformer_forward(const mm_transformer_t* t, mm_stream_t stream, const 
     TR(b.x, (size_t)rows * D * 4);
     if (t->d.self_cond && self_cond_embed)       // mmp.py:325-328 (zeros when absent: FF(0) still adds LN-beta terms = 0)
         RC(ff_block(t, s, t->d.self_cond_ff, self_cond_embed, b.x, rows, b));
+    const bool fold = ln_fold_on(t);      // LayerNorm(dim) fold: layer 0's self-attention / feed-forward keep their own LayerNorm pass (the same rule as mm_generate)
     for (int l = 0; l < t->d.depth; ++l) {
         const mm_layer_weights& w = t->layers[l];
-        RC(self_attn_block(t, s, w.self_attn, B, n, b));
+        RC(self_attn_block(t, s, w.self_attn, B, n, b, fold && l > 0, fold));
         RC(gemm_dense(t, s, (const bf16_t*)ctx, KD, (const bf16_t*)w.cross_attn.w_kv, KD, B * m, 2 * I, KD, ckv, 2 * I, P ? OUT_F32 : OUT_BF16, nullptr));
         TR(ckv, (size_t)B * m * 2 * I * 2);
-        RC(cross_attn_block(t, s, w.cross_attn, B, n, ckv, m, 0, key_mask, b));
-        RC(ff_block(t, s, w.ff, b.x, b.x, rows, b));
+        RC(cross_attn_block(t, s, w.cross_attn, B, n, ckv, m, 0, key_mask, b, fold, fold && l > 0));
+        RC(ff_block(t, s, w.ff, b.x, b.x, rows, b, nullptr, 0, fold && l > 0, fold && l + 1 < t->d.depth));
     }
     if (P) RC(k_layernorm_split(s, b.x, D, rows, D, t->d.final_gamma, t->d.final_beta, nullptr, t->PC, emb, nullptr, nullptr, 0, nullptr));
     else RC(k_layernorm(s, b.x, D, rows, D, t->d.final_gamma, t->d.final_beta, nullptr, emb, D));
@@ -866,6 +929,7 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
         // sample's queries stay contiguous).  Identical values for the rows that matter; (1 - k/n) of that work is skipped.
         // (Self-conditioning needs the embed of every position for the next step, re-masking samples every position: no compaction.)
         const bool compact_last = k < n && !(g_mm_debug & 16384) && !self_cond && !can_remask;
+        const bool fold = ln_fold_on(t);
         for (int l = 0; l < t->d.depth; ++l) {
             const mm_layer_weights& w = t->layers[l];
             const bf16_t* ckv_l = g.ckv + (size_t)l * B * m * 2 * I * (PT ? 2 : 1);
@@ -873,28 +937,41 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
             const int nq = last_compact ? k : n;             // queries per sequence from here on
             const int Mq = B * nq;
             Bufs bc = b;
+            // LayerNorm(dim) fold (see ln_fold_on): from layer 1 on every LayerNorm of the blocks rides in the GEMMs around it; layer 0 keeps the self-attention's
+            // and the feed-forward's (its rows come from the embedding kernel and from the row copy below).  The null half's constant cross-attention row is then
+            // added by the self-attention's output projection ((acc + x) + c: the same two roundings as the feed-forward LayerNorm's in-place add).
+            const bool fold_l = fold && l > 0;
+            const bool null_const = P == 2 && nc == 0;
+            const float* cvec_l = g.cvec + (size_t)l * D;
             if (last_compact) {
-                RC(self_attn_core(t, s, w.self_attn, seqs, n, b));
+                RC(self_attn_core(t, s, w.self_attn, seqs, n, b, fold_l));
                 for (int h = 0; h < P; ++h) {
                     RC(k_gather_rows16(s, b.x, (long)D * 4, g.rows, R, h * M, D * 4, g.xc + (size_t)h * R * D));
                     RC(k_gather_rows16(s, b.att, (long)KI * 2, g.rows, R, h * M, KI * 2, g.attc + (size_t)h * R * KI));
                 }
-                if (t->F8) RC(f8_linear_bf16(s, b, g.attc, I, I, w.self_attn.w_out, w.self_attn.w_out_scale, P * R, D, g.xc, D, 2, g.xc));
-                else RC(gemm_dense(t, s, g.attc, KI, (const bf16_t*)w.self_attn.w_out, KI, P * R, D, KI, g.xc, D, OUT_F32, g.xc));
                 bc.x = g.xc; bc.att = g.attc;
+                if (t->F8) RC(f8_linear_bf16(s, b, g.attc, I, I, w.self_attn.w_out, w.self_attn.w_out_scale, P * R, D, g.xc, D, 2, g.xc));
+                else if (fold) RC(gemm_resid(t, s, g.attc, KI, (const bf16_t*)w.self_attn.w_out, KI, P * R, D, KI, g.xc, bc, true, (fold_l && null_const) ? cvec_l : nullptr, R));
+                else RC(gemm_dense(t, s, g.attc, KI, (const bf16_t*)w.self_attn.w_out, KI, P * R, D, KI, g.xc, D, OUT_F32, g.xc));
             } else if (l == 0 && share0) {
-                RC(self_attn_block(t, s, w.self_attn, B, n, b));
-                const hipError_t e = hipMemcpyAsync(b.x + (size_t)M * D, b.x, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s);
+                RC(self_attn_block(t, s, w.self_attn, B, n, b, false, fold));
+                hipError_t e = hipMemcpyAsync(b.x + (size_t)M * D, b.x, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s);
+                if (e == hipSuccess && fold && !null_const) {      // the null half's cross-attention runs (condition ids stay attended): it reads the fold data of its rows too
+                    const size_t np_ = (size_t)(D + 127) / 128;
+                    e = hipMemcpyAsync(b.xb + (size_t)M * D, b.xb, (size_t)M * D * 2, hipMemcpyDeviceToDevice, s);
+                    if (e == hipSuccess) e = hipMemcpyAsync(b.stp + (size_t)M * np_ * 2, b.stp, (size_t)M * np_ * 8, hipMemcpyDeviceToDevice, s);
+                }
                 if (e != hipSuccess) return mm_set_hip_error(e, "generate: x copy");
             } else {
-                RC(self_attn_block(t, s, w.self_attn, seqs, n, b));
+                RC(self_attn_block(t, s, w.self_attn, seqs, n, b, fold_l, fold, (fold_l && null_const) ? cvec_l : nullptr, M));
             }
-            if (P == 2 && nc == 0) {
-                RC(cross_attn_block(t, s, w.cross_attn, B, nq, ckv_l, m, 0, g.masks, bc));
-                RC(ff_block(t, s, w.ff, bc.x, bc.x, 2 * Mq, bc, g.cvec + (size_t)l * D, Mq));      // null rows += to_out(null_v) (the constant cross-attention)
+            if (null_const) {
+                RC(cross_attn_block(t, s, w.cross_attn, B, nq, ckv_l, m, 0, g.masks, bc, fold, fold_l));
+                if (fold_l) RC(ff_block(t, s, w.ff, bc.x, bc.x, 2 * Mq, bc, nullptr, 0, true, l + 1 < t->d.depth));      // (the constant row went in with the output projection above)
+                else RC(ff_block(t, s, w.ff, bc.x, bc.x, 2 * Mq, bc, cvec_l, Mq, false, fold && l + 1 < t->d.depth));      // null rows += to_out(null_v) (the constant cross-attention)
             } else {
-                RC(cross_attn_block(t, s, w.cross_attn, seqs, nq, ckv_l, m, P == 2 ? B : 0, g.masks, bc));
-                RC(ff_block(t, s, w.ff, bc.x, bc.x, P * Mq, bc));
+                RC(cross_attn_block(t, s, w.cross_attn, seqs, nq, ckv_l, m, P == 2 ? B : 0, g.masks, bc, fold, fold_l));
+                RC(ff_block(t, s, w.ff, bc.x, bc.x, P * Mq, bc, nullptr, 0, fold_l, fold && l + 1 < t->d.depth));
             }
         }
         // final norm + to_logits + CFG only at the rows that are sampled this step

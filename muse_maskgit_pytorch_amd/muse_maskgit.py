@@ -207,9 +207,15 @@ class Transformer(nn.Module):
         t['w2f'] = w2f
         t['c1'] = w2f.float().sum(dim=1).contiguous()
         t['c2'] = (w2p.float() * t['b2']).sum(dim=1).contiguous()
+        # LayerNorm(dim) in front of w1 folded into w1 (mm_ff_weights.w1_ln): gains into the (GEGLU-interleaved) weight rows, mean / bias terms per packed row
+        g1, b1 = t['g1'], t['b1']
+        w1l = ops.pack_w1_geglu((w1.float() * g1[None, :]).to(bf16), Fp)
+        t['w1l'] = w1l
+        t['l1c1'] = w1l.float().sum(dim=1).contiguous()
+        t['l1c2'] = ops.pack_w1_geglu((w1.float() @ b1)[:, None], Fp, dtype=torch.float32)[:, 0].contiguous() if bool((b1 != 0).any()) else None
         keep.append(t)
         fw = L.FFWeights(L.ptr(t['g1']), L.ptr(t['b1']), L.ptr(t['w1']), L.ptr(t['g2']), L.ptr(t['b2']), L.ptr(t['w2']),
-                         L.ptr(t['w2f']), L.ptr(t['c1']), L.ptr(t['c2']))
+                         L.ptr(t['w2f']), L.ptr(t['c1']), L.ptr(t['c2']), None, None, L.ptr(t['w1l']), L.ptr(t['l1c1']), L.ptr(t['l1c2']))
         return fw, F, Fp
 
     def _pack_attn(self, a, keep, fused):
@@ -227,9 +233,15 @@ class Transformer(nn.Module):
             wq_ptr, wkv_ptr, wkeep = wq.data_ptr(), wkv.data_ptr(), (wq, wkv)
         t = dict(g=f32c(a.norm.gamma), b=f32c(a.norm.beta), w=wkeep, wo=a.to_out.weight.detach().to(bf16).contiguous(),
                  nk=f32c(a.null_kv[0, :, 0, :]), nv=f32c(a.null_kv[1, :, 0, :]), qs=f32c(a.q_scale), ks=f32c(a.k_scale))
+        # the block's LayerNorm folded into its first projection (mm_attn_weights.w_q_ln): self-attention q|k|v (normalises the kv input too,
+        # mmp.py:137-141), cross-attention q only (its k|v read the context, which is not normalised)
+        wf = (torch.cat([a.to_q.weight.detach(), a.to_kv.weight.detach()], dim=0) if fused else a.to_q.weight.detach()).float()
+        t['wl'] = (wf * t['g'][None, :]).to(bf16).contiguous()
+        t['lc1'] = t['wl'].float().sum(dim=1).contiguous()
+        t['lc2'] = (wf @ t['b']).contiguous() if bool((t['b'] != 0).any()) else None
         keep.append(t)
         return L.AttnWeights(L.ptr(t['g']), L.ptr(t['b']), C.c_void_p(wq_ptr), C.c_void_p(wkv_ptr), L.ptr(t['wo']),
-                             L.ptr(t['nk']), L.ptr(t['nv']), L.ptr(t['qs']), L.ptr(t['ks']))
+                             L.ptr(t['nk']), L.ptr(t['nv']), L.ptr(t['qs']), L.ptr(t['ks']), None, None, None, L.ptr(t['wl']), L.ptr(t['lc1']), L.ptr(t['lc2']))
 
     def _model(self):
         L.require_device()

@@ -700,6 +700,36 @@ def test_ff_inner_layernorm_fold_matches_the_unfolded_path(golden):
     assert e.max() < 0.03 * ref.abs().max()
 
 
+def test_layernorm_dim_fold_matches_the_unfolded_path(golden):
+    """mmp.py:63-70, 137, 187-195 (round 4): from layer 1 on, the LayerNorm in front of q|k|v, of the cross-attention's q and of FF w1 rides in the GEMMs
+    around it -- the residual-adding epilogues write the new rows as bf16 + per-row (sum, sum of squares), the projection multiplies the raw rows by
+    gain-folded weights and applies rstd * (acc - mean * c1) + c2.  Debug bit 1 << 29 runs the LayerNorm kernels instead: the two agree to bf16 noise, both
+    stay within the oracle tolerance, and the decode loop's folded engine equals the general (folded) forward path + oracle tail (bit-exact ids)."""
+    from muse_maskgit_pytorch_amd import _lib
+    g, t = _tiny_transformer(golden)
+    te = g['text_embeds']
+    ids = g['ids'].to(DEV)
+    lib = _lib.lib()
+    folded = t(ids, text_embeds=te.to(DEV))
+    folded_null = t(ids, text_embeds=te.to(DEV), cond_drop_prob=1.)
+    lib.mm_debug_set(1 << 29)
+    try:
+        unfolded = t(ids, text_embeds=te.to(DEV))
+        unfolded_null = t(ids, text_embeds=te.to(DEV), cond_drop_prob=1.)
+    finally:
+        lib.mm_debug_set(0)
+    sd = {k: (v.float().cpu() if v.is_floating_point() else v.cpu()) for k, v in t.state_dict().items()}
+    cfg = dict(depth=g['cfg']['depth'], heads=g['cfg']['heads'])
+    for name, a, b, drop in (('cond', folded, unfolded, 0.), ('null', folded_null, unfolded_null, 1.)):
+        scale = b.abs().max()
+        d = (a - b).abs()
+        assert d.max() > 0, 'the debug bit did not change the path'
+        assert d.max() < 0.02 * scale and d.mean() < 2e-3 * scale, (name, d.max().item(), d.mean().item(), scale.item())
+        ref = O.transformer_forward(sd, cfg, g['ids'], te, drop, rp=O.bf16_round)
+        e_f, e_u = _report(f'LayerNorm(dim) fold, {name} logits vs oracle', a, ref), _report(f'... unfolded, {name}', b, ref)
+        assert e_f.max() < 0.03 * ref.abs().max() and e_f.mean() < 1.5 * e_u.mean() + 1e-4
+
+
 def test_full_size_c2_properties():
     """BASELINE configs[1] at FULL size (dim 512, depth 8, seq_len 256, codebook 65536; B = 8 to keep the fp32 oracle out of it):
     size-independent properties instead of an oracle comparison --

@@ -182,6 +182,19 @@ def test_oracle_matches_reference_on_general_fp32_weights(golden):
     close(O.vae_decode_from_ids(v['sd'], gen['final_ids']), gen['images'])
 
 
+def test_fp32_fixtures_discriminate_bf16_rounded_weights(golden):
+    """what the *_fp32.pt fixtures are for: an engine that packed its weights through bf16 is far outside the 1e-3 bound on them (so a 'parity' /
+    'f16x2' / 'bf16x3' engine that did so silently could not pass tests/test_gpu_parity_mode.py::test_general_fp32_checkpoint_vs_reference_golden)"""
+    g = golden('tiny_fp32.pt')
+    cfg = dict(depth=g['cfg']['depth'], heads=g['cfg']['heads'])
+    sd_r = {k: (v.to(torch.bfloat16).float() if v.is_floating_point() else v) for k, v in g['sd'].items()}
+    lc = O.transformer_forward(sd_r, cfg, g['ids'], g['text_embeds'], 0.)
+    scale = g['logits_cond'].abs().max().item()
+    bound = 1e-3 * max(1., scale / 8)                    # the bound of the GPU test on this fixture (logits are x8)
+    err = (lc - g['logits_cond']).abs().max().item()
+    assert err > 10 * bound, f'bf16-rounded weights are only {err:.3g} from the fp32-weight reference logits (bound {bound:.3g})'
+
+
 # ------------------------------------------------------------------------------------------------ base size (BASELINE configs[1])
 @pytest.fixture(scope='module', params=['base_c2.pt', 'base_c2_fp32.pt'])
 def base_setup(golden, request):
