@@ -136,18 +136,33 @@ __device__ __forceinline__ float2 ln_stats_seq(const float2* pp, int np, int F) 
     return make_float2(mean, 1.f / sqrtf(var + 1e-5f));
 }
 
+// LayerNorm(dim) fold: per-row (rstd, -mean) from the np (sum, sum of squares) partials the producer epilogues left, by ONE lane -- summed in index
+// order, then multiplications by 1 / F and the hardware reciprocal square root instead of three IEEE divisions and a square root (a dependent chain the
+// consumer GEMM waits for once per tile; rsq is within 1 ulp: far inside what the bf16 operands resolve).  One definition for every consumer kernel.
+__device__ __forceinline__ float2 ln_rstd_negmean(const float2* pp, int np, float inv_F) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < np; ++i) { const float2 v = pp[i]; s1 += v.x; s2 += v.y; }
+    const float mean = s1 * inv_F;
+    const float var = fmaxf(__builtin_fmaf(-mean, mean, s2 * inv_F), 0.f);
+    return make_float2(__builtin_amdgcn_rsqf(var + 1e-5f), -mean);
+}
+
+// LayerNorm(dim) fold, CONSUMER side: LayerNorm(x) . W^T for one output = rstd * (acc - mean * c1) + c2 with acc = x . Wg^T -- two explicit fused
+// multiply-adds (the build runs with -ffp-contract=off; these are written as FMAs so that the 128-value accumulator sweep costs 2 instructions per value)
+__device__ __forceinline__ float ln_fold_apply(float acc, float rstd, float neg_mean, float c1, float c2) {
+    return __builtin_fmaf(rstd, __builtin_fmaf(neg_mean, c1, acc), c2);
+}
+
 // LayerNorm(dim) folded into the GEMMs around it (round 4; GemmArgs::st_part / in_c1).  PRODUCER side: the fp32-residual epilogues (out = x + ...) hand 4
-// consecutive columns of one row to 32 adjacent lanes (one 128-column tile row): the row's (sum, sum of squares) over those 128 fp32 values, identical in
-// all 32 lanes.  DPP inside each 16-lane row (fixed pairing), one cross-row exchange.
-__device__ __forceinline__ float2 row_stats32(float s1, float s2) {
+// consecutive columns of one row to 32 adjacent lanes (one 128-column tile row): the row's (sum, sum of squares) over the 64 fp32 values of each 16-lane
+// DPP row, identical in its 16 lanes (fixed pairing).
+__device__ __forceinline__ float2 row_stats16(float s1, float s2) {      // ... per 16 lanes = 64 columns: two partials per row and 128-column tile, no cross-row exchange
 #define MM_DPP_ADD(x_, ctrl_) x_ += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x_), ctrl_, 0xF, 0xF, true))
     MM_DPP_ADD(s1, 0xB1); MM_DPP_ADD(s2, 0xB1);      // quad_perm [1,0,3,2]
     MM_DPP_ADD(s1, 0x4E); MM_DPP_ADD(s2, 0x4E);      // quad_perm [2,3,0,1]
     MM_DPP_ADD(s1, 0x141); MM_DPP_ADD(s2, 0x141);    // row_half_mirror
     MM_DPP_ADD(s1, 0x140); MM_DPP_ADD(s2, 0x140);    // row_mirror
 #undef MM_DPP_ADD
-    s1 += __shfl_xor(s1, 16, 64);
-    s2 += __shfl_xor(s2, 16, 64);
     return make_float2(s1, s2);
 }
 

@@ -32,7 +32,7 @@ namespace {
 constexpr int BT = 128;   // tile edge (both n and m)
 constexpr int BK = 64;    // k per stage
 constexpr int STAGE_BYTES = 2 * BT * BK * 2;   // W tile + X tile
-constexpr int SMEM_BYTES = BT * (BT + 4) * 4 + BT * 8;  // max(2 stages = 64 KiB, fp32 output tile with padded rows = 66 KiB) + 1 KiB of per-row LayerNorm (mean, rstd)
+constexpr int SMEM_BYTES = BT * (BT + 4) * 4 + BT * 8 + BT * 8;  // max(2 stages = 64 KiB, fp32 output tile with padded rows = 66 KiB) + 1 KiB of per-row LayerNorm (mean, rstd) + 1 KiB of the LayerNorm(dim) fold's c1 | c2 tile entries
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
@@ -157,9 +157,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
             const float2 st = ln_stats_from_partials(p.ln_part, p.ln_np, m_ < p.M ? m_ : 0, p.ln_F, t & 1, m_ < p.M);
             if (!(t & 1)) ln_stat[r_] = st;
         } else if (p.in_c1) {           // LayerNorm(dim) fold, consumer side (GemmArgs::in_c1): the operand rows are raw residual rows, their statistics come with them
-            const int r_ = t >> 1, m_ = m0 + r_;
-            const float2 st = ln_stats_from_partials(p.in_part, p.in_np, m_ < p.M ? m_ : 0, p.in_F, t & 1, m_ < p.M);
-            if (!(t & 1)) ln_stat[r_] = st;
+            if (t >= 128) {             // one thread per tile row: (rstd, -mean) by the shared routine (common.h ln_rstd_negmean)
+                const int r_ = t - 128, m_ = m0 + r_;
+                ln_stat[r_] = ln_rstd_negmean(reinterpret_cast<const float2*>(p.in_part) + (size_t)(m_ < p.M ? m_ : 0) * p.in_np, m_ < p.M ? p.in_np : 0, 1.f / (float)p.in_F);
+            }
+            if (t < 64) {               // this tile's 128 entries of c1 | c2 go to LDS now: a global load in the epilogue would be pure exposed latency
+                const int n_ = n0 + (t & 31) * 4;
+                const float* src_ = (t < 32) ? p.in_c1 : p.in_c2;
+                float4 v_ = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (src_ && n_ + 3 < p.N) v_ = *reinterpret_cast<const float4*>(src_ + n_);
+                reinterpret_cast<float4*>(smem + BT * (BT + 4) * 4 + BT * 8)[t] = v_;
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA of the first k-tile has landed (explicit: a barrier alone does not drain VMEM)
@@ -204,26 +212,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 
     if constexpr (MODE == MODE_DENSE) {
         if (p.in_c1) {
-            // LayerNorm(dim) fold, consumer side: X held the raw residual rows, W the gains -> acc = rstd * acc - rstd * mean * c1[n] + c2[n], applied on the
+            // LayerNorm(dim) fold, consumer side: X held the raw residual rows, W the gains -> acc = rstd * (acc - mean * c1[n]) + c2[n], applied on the
             // accumulators (before GEGLU when there is one), the same expression in the same order as gemm_wide.hip's
-            const bool has_c2 = p.in_c2 != nullptr;
+            const float4* lc = reinterpret_cast<const float4*>(smem + BT * (BT + 4) * 4 + BT * 8);      // [32] c1 then [32] c2 of this tile's 128 columns
             float4 c1v[4], c2v[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                const int n = n0 + wave_n * 64 + a * 16 + fg * 4;
-                c1v[a] = (n + 3 < p.N) ? *reinterpret_cast<const float4*>(p.in_c1 + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-                c2v[a] = (has_c2 && n + 3 < p.N) ? *reinterpret_cast<const float4*>(p.in_c2 + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int q4 = wave_n * 16 + a * 4 + fg;
+                c1v[a] = lc[q4];
+                c2v[a] = lc[32 + q4];
             }
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const float2 stv = ln_stat[wave_m * 64 + b * 16 + fr];
-                const float rs = stv.y, rm = stv.x * stv.y;
+                const float rs = stv.x, nm = stv.y;
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
-                    acc[a][b][0] = rs * acc[a][b][0] - rm * c1v[a].x + c2v[a].x;
-                    acc[a][b][1] = rs * acc[a][b][1] - rm * c1v[a].y + c2v[a].y;
-                    acc[a][b][2] = rs * acc[a][b][2] - rm * c1v[a].z + c2v[a].z;
-                    acc[a][b][3] = rs * acc[a][b][3] - rm * c1v[a].w + c2v[a].w;
+                    acc[a][b][0] = ln_fold_apply(acc[a][b][0], rs, nm, c1v[a].x, c2v[a].x);
+                    acc[a][b][1] = ln_fold_apply(acc[a][b][1], rs, nm, c1v[a].y, c2v[a].y);
+                    acc[a][b][2] = ln_fold_apply(acc[a][b][2], rs, nm, c1v[a].z, c2v[a].z);
+                    acc[a][b][3] = ln_fold_apply(acc[a][b][3], rs, nm, c1v[a].w, c2v[a].w);
                 }
             }
         }
@@ -380,11 +388,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                     if (ok_) *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + (size_t)m * p.ldc + n) = o;
                     if (fold_out) {
                         // the new residual row also leaves as bf16 (the operand of the GEMM behind the next LayerNorm, which then needs no pass of its own)
-                        // together with this 128-column tile's share of the row's (sum, sum of squares), taken from the fp32 values
+                        // together with this tile's two 64-column shares of the row's (sum, sum of squares), taken from the fp32 values
                         if (!ok_) o = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (ok_) *reinterpret_cast<uint2*>(p.xb_out + (size_t)m * p.ldxb + n) = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
-                        const float2 st2 = row_stats32((o.x + o.y) + (o.z + o.w), (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w));
-                        if ((t & 31) == 0 && m < p.M) *reinterpret_cast<float2*>(p.st_part + ((size_t)m * p.st_np + tile_n) * 2) = st2;
+                        float2 st2 = row_stats16((o.x + o.y) + (o.z + o.w), (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w));
+                        if (p.st_gran == 64) {      // two partials per 128-column tile (N <= 512: no cross-row exchange)
+                            const int pi_ = tile_n * 2 + ((t >> 4) & 1);      // (a width of an odd number of 64-column blocks has no second half in its last tile)
+                            if ((t & 15) == 0 && m < p.M && pi_ < p.st_np) *reinterpret_cast<float2*>(p.st_part + ((size_t)m * p.st_np + pi_) * 2) = st2;
+                        } else {                    // one per tile: wide rows keep the consumers' partial count small (it rides in their LDS)
+                            st2.x += __shfl_xor(st2.x, 16, 64);
+                            st2.y += __shfl_xor(st2.y, 16, 64);
+                            if ((t & 31) == 0 && m < p.M) *reinterpret_cast<float2*>(p.st_part + ((size_t)m * p.st_np + tile_n) * 2) = st2;
+                        }
                     }
                 }
                 TSTAMP(43)
@@ -532,7 +547,8 @@ int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
     if (a.xb_out) {     // ... producer side: the fp32-residual epilogue of the 256x128 / 128x128 kernels
         if (a.mode != MODE_DENSE || a.out_kind != OUT_F32 || !a.resid_f32 || (a.N % 4) || !a.st_part || a.splits > 1 || a.m_dev || a.epi != EPI_NONE)
             return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: the LayerNorm(dim) fold is produced by the dense fp32-residual epilogue");
-        a.st_np = (a.N + 127) / 128;
+        a.st_gran = a.N <= 512 ? 64 : 128;      // (model.hip ln_fold_np computes the same count for the consumers)
+        a.st_np = (a.N + a.st_gran - 1) / a.st_gran;
         if (!(a.debug & 8) && mm_gemm_big_eligible(a)) return mm_gemm_big_launch(a, stream);
         a.tiles_n = (a.N + BT - 1) / BT;
         a.tiles_m = (a.M + BT - 1) / BT;

@@ -291,11 +291,18 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
                     if (ok_) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = o;
                     if (fold_out) {
                         // the new residual row also leaves as bf16 (the operand of the GEMM behind the next LayerNorm, which then needs no pass of its own)
-                        // together with this 128-column tile's share of the row's (sum, sum of squares), taken from the fp32 values
+                        // together with this tile's two 64-column shares of the row's (sum, sum of squares), taken from the fp32 values
                         if (!ok_) o = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (ok_) *reinterpret_cast<uint2*>(p.xb_out + (size_t)m * p.ldxb + n) = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
-                        const float2 st2 = row_stats32((o.x + o.y) + (o.z + o.w), (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w));
-                        if ((t & 31) == 0 && m < p.M) *reinterpret_cast<float2*>(p.st_part + ((size_t)m * p.st_np + tile_n) * 2) = st2;
+                        float2 st2 = row_stats16((o.x + o.y) + (o.z + o.w), (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w));
+                        if (p.st_gran == 64) {      // two partials per 128-column tile (N <= 512: no cross-row exchange)
+                            const int pi_ = tile_n * 2 + ((t >> 4) & 1);      // (a width of an odd number of 64-column blocks has no second half in its last tile)
+                            if ((t & 15) == 0 && m < p.M && pi_ < p.st_np) *reinterpret_cast<float2*>(p.st_part + ((size_t)m * p.st_np + pi_) * 2) = st2;
+                        } else {                    // one per tile: wide rows keep the consumers' partial count small (it rides in their LDS)
+                            st2.x += __shfl_xor(st2.x, 16, 64);
+                            st2.y += __shfl_xor(st2.y, 16, 64);
+                            if ((t & 31) == 0 && m < p.M) *reinterpret_cast<float2*>(p.st_part + ((size_t)m * p.st_np + tile_n) * 2) = st2;
+                        }
                     }
                 }
                 return;

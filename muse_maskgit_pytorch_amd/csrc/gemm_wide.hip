@@ -13,11 +13,16 @@
 #include "common.h"
 #include "muse_hip_internal.h"
 
+#ifndef MM_WIDE_SPREAD
+#define MM_WIDE_SPREAD 0      // 1: one LDS-DMA piece behind every second block of a k-step instead of a burst (round-4 experiment, measured SLOWER on the same box:
+                              // w1 63.1 vs 60.7 us, logits 590-610 vs 550-560 us, bit-identical results -- where the pieces are issued is not what bounds the loop)
+#endif
+
 namespace {
 
 constexpr int TM = 256, TN = 256, BKB = 128;      // tile (TN: the 256-row weight tile; the dense kernel also has a 192-row form); bytes per k-step row (64 bf16)
 constexpr int X_B = TM * BKB, W_B = TN * BKB, STG = X_B + W_B, SMEM = 2 * STG;
-constexpr int WIDE_MAX_NP = 8;      // LayerNorm(dim) fold: up to 8 partials per row (dim <= 1024) fit behind the stages (160 KiB of LDS)
+constexpr int WIDE_MAX_NP = 8;      // LayerNorm(dim) fold: up to 8 partials per row (two per 128 columns: dim <= 512) fit behind the stages (160 KiB of LDS)
 
 __device__ __forceinline__ int sw128(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
@@ -72,6 +77,11 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs p) {
         _Pragma("unroll") for (int i = 0; i < NFW; ++i)                                                                                \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(ws_ + i * 1024), 16, voff_w[i], (kt_) * BKB, 0, 0);              \
     }
+#define ISSUE_PIECE(kt_, st_, j_)                                                                                                      \
+    {                                                                                                                                  \
+        if ((j_) < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(smem + (st_) * STG + wid * 4096 + (j_) * 1024), 16, voff_x[(j_) & 3], (kt_) * BKB, 0, 0); \
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(smem + (st_) * STG + X_B + wid * (NFW * 1024) + ((j_) - 4) * 1024), 16, voff_w[((j_) - 4) & 3], (kt_) * BKB, 0, 0); \
+    }
     // Persistent when the step count is even (the launcher then starts one workgroup per CU): the NEXT tile's first k-step is requested during the last step of
     // the current one, into stage 0, which that step (odd index: stage 1) does not read; the epilogue stages its output through stage 1 and its global stores
     // are still retiring while the next tile's first steps run (the wait of that tile's step 0 counts them: VMEM retires in order).
@@ -90,35 +100,60 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs p) {
             const int st = kt & 1;
             if (kt == 0) wait_vmcnt_w(pending); else __builtin_amdgcn_s_waitcnt(0x0F70);      // this step's DMA has landed (only younger stores may still be in flight)
             __builtin_amdgcn_s_barrier();            // ... for everybody, and everybody is done reading the other stage
+#if MM_WIDE_SPREAD
+            // where this step's LDS-DMA pieces go: the next k-step's stage, or -- last step, persistent launch (even KT) -- the NEXT tile's first step into stage 0
+            int nk = kt + 1, ns = st ^ 1;
+            bool do_issue = true;
+            if (kt + 1 == KT) {
+                nk = 0; ns = 0;
+                do_issue = vb + G < total;
+                if (do_issue) TILE_SETUP(vb + G);
+            }
+#endif
             if (kt == 1 && p.in_c1 && wid < 4) {
-                // LayerNorm(dim) fold: the partials of this tile's 256 rows landed with step 1's wait; ONE thread per row turns them into (rstd, mean * rstd) in
+                // LayerNorm(dim) fold: the partials of this tile's 256 rows landed with step 1's wait; ONE thread per row turns them into (rstd, -mean) in
                 // the shadow of this step's MFMAs (read again only in the epilogue, many barriers from here)
                 const int np_ = p.in_np;
-                const float2 stv = ln_stats_seq(reinterpret_cast<const float2*>(smem + 2 * STG) + t * np_, np_, p.in_F);
-                reinterpret_cast<float2*>(smem + 2 * STG + TM * np_ * 8 + 2048)[t] = make_float2(stv.y, stv.x * stv.y);
+                reinterpret_cast<float2*>(smem + 2 * STG + TM * np_ * 8 + 2048)[t] =
+                    ln_rstd_negmean(reinterpret_cast<const float2*>(smem + 2 * STG) + t * np_, np_, 1.f / (float)p.in_F);
             }
             const unsigned char* xs = smem + st * STG + (wm * 128) * BKB;
             const unsigned char* ws = smem + st * STG + X_B + (wn * 16 * NFW) * BKB;
+            // Software pipeline of the fragment reads (round 4): hipcc schedules "read the token fragment, wait for it, four MFMAs" strictly in that order, so
+            // every 64 cycles of MFMA work waited for a full LDS round trip (ISA: ds_read_b128, s_waitcnt lgkmcnt(0), 4 x v_mfma, repeated).  Here the token
+            // fragment of block b + 1 is requested BEFORE the MFMAs of block b, and the second sub-step's weight fragments before the last block of the first
+            // (same MFMA order per accumulator: bit-identical results).
+            u32x4_t wf[NFW], wf2[NFW], xr[3];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {         // two 32-deep MFMA sub-steps, k ascending
-                u32x4_t wf[NFW];
+            for (int a = 0; a < NFW; ++a) wf[a] = *reinterpret_cast<const u32x4_t*>(ws + sw128(a * 16 + fr, fg));
+            xr[0] = *reinterpret_cast<const u32x4_t*>(xs + sw128(fr, fg));
+            xr[1] = *reinterpret_cast<const u32x4_t*>(xs + sw128(16 + fr, fg));
 #pragma unroll
-                for (int a = 0; a < NFW; ++a) wf[a] = *reinterpret_cast<const u32x4_t*>(ws + sw128(a * 16 + fr, ks * 4 + fg));
+            for (int it = 0; it < 16; ++it) {        // 16 blocks of 16 tokens x 32 k: sub-step ks = it >> 3 (k ascending), token block b = it & 7
+                const int b = it & 7;
+                if (it + 2 < 16) xr[(it + 2) % 3] = *reinterpret_cast<const u32x4_t*>(xs + sw128(((it + 2) & 7) * 16 + fr, ((it + 2) >> 3) * 4 + fg));
+                if (it == 6) {
 #pragma unroll
-                for (int b = 0; b < 8; ++b) {
-                    const u32x4_t xf = *reinterpret_cast<const u32x4_t*>(xs + sw128(b * 16 + fr, ks * 4 + fg));
-#pragma unroll
-                    for (int a = 0; a < NFW; ++a) acc[a][b] = mfma16(wf[a], xf, acc[a][b]);
+                    for (int a = 0; a < NFW; ++a) wf2[a] = *reinterpret_cast<const u32x4_t*>(ws + sw128(a * 16 + fr, 4 + fg));
                 }
+                __builtin_amdgcn_sched_barrier(0);      // the prefetches stay in FRONT of this block's MFMAs (the scheduler otherwise sinks them behind)
+#pragma unroll
+                for (int a = 0; a < NFW; ++a) acc[a][b] = mfma16(it < 8 ? wf[a] : wf2[a], xr[it % 3], acc[a][b]);
                 // The next step's DMA goes out BEHIND the first sub-step: right behind the barrier it delays the first MFMAs of both waves of a SIMD, behind
                 // the second sub-step it lands too late (FF w1 of the base config, tools/gemm_harness: 62.0 / 58.6 / 67.7 us for the three placements)
-                if (ks == 0) {
+#if MM_WIDE_SPREAD
+                // (round-4 experiment, off by default: one LDS-DMA piece behind every second block instead of a burst of 4 + NFW -- see MM_WIDE_SPREAD above)
+                if ((it & 1) == 0 && (it >> 1) < 4 + NFW && do_issue) ISSUE_PIECE(nk, ns, it >> 1);
+#endif
+                if (it == 7) {
+#if !MM_WIDE_SPREAD
                     if (kt + 1 < KT) {
                         ISSUE(kt + 1, st ^ 1);
                     } else if (vb + G < total) {     // (only with an even KT: see the launcher)
                         TILE_SETUP(vb + G);
                         ISSUE(0, 0);
                     }
+#endif
                     if (kt == 0 && p.in_c1) {
                         // LayerNorm(dim) fold (GemmArgs::in_c1): this tile's row statistics partials (256 rows x np x 8 bytes) and its 64 NFW entries of c1 / c2
                         // arrive by LDS-DMA too, behind the stages (retired by the vmcnt(0) of step 1: K >= 128)
@@ -142,10 +177,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs p) {
         const bool full = m0 + TM <= p.M;            // ragged tiles skip stores: their count is not wave-uniform, the next wait then takes everything
         int nstore = 0;
         if (p.in_c1) {
-            // LayerNorm(dim) fold, consumer side: X held the raw residual rows, W the gains -> out = rstd * acc - rstd * mean * c1[n] + c2[n] (before GEGLU);
-            // one canonical evaluation order with the 128 x 128 kernel (ln_stats_seq == ln_stats_from_partials, the same three-term expression)
+            // LayerNorm(dim) fold, consumer side: X held the raw residual rows, W the gains -> out = rstd * (acc - mean * c1[n]) + c2[n] (before GEGLU);
+            // one canonical evaluation with the 128 x 128 kernel (ln_rstd_negmean, ln_fold_apply)
             const int np_ = p.in_np;
-            const float2* rsm = reinterpret_cast<const float2*>(smem + 2 * STG + TM * np_ * 8 + 2048);      // per row (rstd, mean * rstd), written at k-step 1
+            const float2* rsm = reinterpret_cast<const float2*>(smem + 2 * STG + TM * np_ * 8 + 2048);      // per row (rstd, -mean), written at k-step 1
             const float* lc1 = reinterpret_cast<const float*>(smem + 2 * STG + TM * np_ * 8);
             const bool has_c2 = p.in_c2 != nullptr;
             float4 c1v[NFW], c2v[NFW];
@@ -158,13 +193,13 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs p) {
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
                 const float2 stv = rsm[wm * 128 + b * 16 + fr];
-                const float rs = stv.x, rm = stv.y;
+                const float rs = stv.x, nm = stv.y;      // rstd, -mean
 #pragma unroll
-                for (int a = 0; a < NFW; ++a) {
-                    acc[a][b][0] = rs * acc[a][b][0] - rm * c1v[a].x + c2v[a].x;
-                    acc[a][b][1] = rs * acc[a][b][1] - rm * c1v[a].y + c2v[a].y;
-                    acc[a][b][2] = rs * acc[a][b][2] - rm * c1v[a].z + c2v[a].z;
-                    acc[a][b][3] = rs * acc[a][b][3] - rm * c1v[a].w + c2v[a].w;
+                for (int a = 0; a < NFW; ++a) {          // ln_fold_apply (common.h): two fused multiply-adds per value, one definition for both consumer kernels
+                    acc[a][b][0] = ln_fold_apply(acc[a][b][0], rs, nm, c1v[a].x, c2v[a].x);
+                    acc[a][b][1] = ln_fold_apply(acc[a][b][1], rs, nm, c1v[a].y, c2v[a].y);
+                    acc[a][b][2] = ln_fold_apply(acc[a][b][2], rs, nm, c1v[a].z, c2v[a].z);
+                    acc[a][b][3] = ln_fold_apply(acc[a][b][3], rs, nm, c1v[a].w, c2v[a].w);
                 }
             }
         }
@@ -236,6 +271,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs p) {
         // (no barrier here: a wave reaches the next tile's first barrier only behind its own staging reads, and the DMA into stage 1 is issued behind that barrier)
     }
 #undef ISSUE
+#undef ISSUE_PIECE
 #undef TILE_SETUP
 }
 
@@ -299,6 +335,11 @@ __global__ __launch_bounds__(512) void gemm_wide_fused_kernel(const GemmArgs p) 
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                                  \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(ws_ + i * 1024), 16, voff_w[i], (kt_) * BKB, 0, 0);              \
     }
+#define ISSUE_PIECE_F(kt_, st_, j_)                                                                                                    \
+    {                                                                                                                                  \
+        if ((j_) < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(smem + (st_) * STG + wid * 4096 + (j_) * 1024), 16, voff_x[(j_) & 3], (kt_) * BKB, 0, 0); \
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(smem + (st_) * STG + X_B + wid * 4096 + ((j_) - 4) * 1024), 16, voff_w[((j_) - 4) & 3], (kt_) * BKB, 0, 0); \
+    }
     TILE_SETUP(vb);
     ISSUE(0, 0);
     int pending = 0;                 // VMEM stores this wave issued BEHIND the DMA of the coming tile's first step (the previous tile's emission)
@@ -313,28 +354,47 @@ __global__ __launch_bounds__(512) void gemm_wide_fused_kernel(const GemmArgs p) 
             const int st = kt & 1;
             if (kt == 0) wait_vmcnt_w(pending); else __builtin_amdgcn_s_waitcnt(0x0F70);      // this step's DMA has landed (in-order retirement: only younger stores may be in flight)
             __builtin_amdgcn_s_barrier();
-            // (here the DMA issue stays right behind the barrier: behind the first sub-step -- what the non-persistent kernel above does -- measured 2 %
+#if MM_WIDE_SPREAD
+            int nk = kt + 1, ns = st ^ 1;      // see gemm_wide_kernel
+            bool do_issue = true;
+            if (kt + 1 == KT) {
+                nk = 0; ns = 0;
+                do_issue = vb + G < total;
+                if (do_issue) TILE_SETUP(vb + G);
+            }
+#endif
+            // (round 3, burst issue: right behind the barrier; behind the first sub-step -- what the non-persistent kernel above did -- measured 2 %
             //  slower in this kernel, same box, 583-586 vs 594-597 us per launch at R = 5140)
+#if !MM_WIDE_SPREAD
             if (kt + 1 < KT) {
                 ISSUE(kt + 1, st ^ 1);
             } else if (vb + G < total) {      // last step (stage 1, KT even): the next tile's first step goes into stage 0
                 TILE_SETUP(vb + G);
                 ISSUE(0, 0);
             }
+#endif
             if (kt == 0 && wid == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(thr_rs, (lds_ptr_t)(lthr), 16, lane * 16, cur_m * TM * 4, 0, 0);
             const unsigned char* xs = smem + st * STG + (wm * 128) * BKB;
             const unsigned char* ws = smem + st * STG + X_B + (wn * 64) * BKB;
+            u32x4_t wf[4], wf2[4], xr[3];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                u32x4_t wf[4];
+            for (int a = 0; a < 4; ++a) wf[a] = *reinterpret_cast<const u32x4_t*>(ws + sw128(a * 16 + fr, fg));
+            xr[0] = *reinterpret_cast<const u32x4_t*>(xs + sw128(fr, fg));
+            xr[1] = *reinterpret_cast<const u32x4_t*>(xs + sw128(16 + fr, fg));
 #pragma unroll
-                for (int a = 0; a < 4; ++a) wf[a] = *reinterpret_cast<const u32x4_t*>(ws + sw128(a * 16 + fr, ks * 4 + fg));
+            for (int it = 0; it < 16; ++it) {        // 16 blocks of 16 tokens x 32 k: sub-step ks = it >> 3 (k ascending), token block b = it & 7
+                const int b = it & 7;
+                if (it + 2 < 16) xr[(it + 2) % 3] = *reinterpret_cast<const u32x4_t*>(xs + sw128(((it + 2) & 7) * 16 + fr, ((it + 2) >> 3) * 4 + fg));
+                if (it == 6) {
 #pragma unroll
-                for (int b = 0; b < 8; ++b) {
-                    const u32x4_t xf = *reinterpret_cast<const u32x4_t*>(xs + sw128(b * 16 + fr, ks * 4 + fg));
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) acc[a][b] = mfma16t<F16>(wf[a], xf, acc[a][b]);
+                    for (int a = 0; a < 4; ++a) wf2[a] = *reinterpret_cast<const u32x4_t*>(ws + sw128(a * 16 + fr, 4 + fg));
                 }
+                __builtin_amdgcn_sched_barrier(0);      // the prefetches stay in FRONT of this block's MFMAs (the scheduler otherwise sinks them behind)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a][b] = mfma16t<F16>(it < 8 ? wf[a] : wf2[a], xr[it % 3], acc[a][b]);
+#if MM_WIDE_SPREAD
+                if ((it & 1) == 0 && do_issue) ISSUE_PIECE_F(nk, ns, it >> 1);      // one LDS-DMA piece behind every second block: see gemm_wide_kernel
+#endif
             }
         }
         if constexpr (F16) {      // undo the power-of-two scale of the packed weight terms (exact) before statistics and candidates

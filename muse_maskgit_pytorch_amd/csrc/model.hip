@@ -195,7 +195,7 @@ struct Bufs {       // activation scratch for `rows` token rows
     bf16_t* a;      // [rows][Fp]
     float* lnp;     // [rows][Fp / 32][2]: LayerNorm(inner) partial sums of the folded feed-forward
     bf16_t* xb;     // [rows][D]: the residual stream as bf16, written by the residual-adding epilogues (LayerNorm(dim) fold, bf16 engine)
-    float* stp;     // [rows][ceil(D / 128)][2]: ... with the rows' (sum, sum of squares) per 128-column tile
+    float* stp;     // [rows][2 ceil(D / 128)][2]: ... with the rows' (sum, sum of squares) per 64 columns
     unsigned char* q8;   // fp8 engine: the e4m3 rows of the activation that feeds the next Linear, [rows][max(D, I, Fp)]
     float* q8s;          // ... and their per-row scales [rows]
 };
@@ -212,7 +212,7 @@ void carve_bufs(Carver& c, const mm_transformer* t, size_t rows, Bufs& b) {
     b.a = c.take<bf16_t>(rows * Fp * seg);
     b.lnp = c.take<float>(rows * (Fp / 32) * 2);
     b.xb = c.take<bf16_t>((t->P || t->F8) ? 0 : rows * D);
-    b.stp = c.take<float>((t->P || t->F8) ? 0 : rows * ((D + 127) / 128) * 2);
+    b.stp = c.take<float>((t->P || t->F8) ? 0 : rows * 2 * ((D + 127) / 128) * 2);      // (>= rows * ln_fold_np(D) * 2)
     b.q8 = nullptr; b.q8s = nullptr;
     if (t->F8) {
         const size_t w = (size_t)(D > I ? (D > Fp ? D : Fp) : (I > Fp ? I : Fp));
@@ -243,12 +243,13 @@ int f8_linear_bf16(hipStream_t s, Bufs& b, const bf16_t* act, long lda, int K, c
 // epilogue: the LayerNorm's own pass over the stream (468 launches, 4.5 ms per generate at the base config) disappears.  Layer 0 keeps the unfolded
 // self-attention / feed-forward LayerNorms (its inputs come from the embedding kernel and, in the decode loop, from a row copy); debug bit 1 << 29 turns
 // the fold off (A/B and the closeness test).
+int ln_fold_np(int D) { return D <= 512 ? (D + 63) / 64 : (D + 127) / 128; }      // statistics partials per row: per 64 columns up to dim 512, per 128 beyond (== mm_gemm_launch's st_np)
 bool ln_fold_on(const mm_transformer* t) {
-    return !t->P && !t->F8 && !(g_mm_debug & (1 << 29)) && (t->d.dim % 4) == 0 && (t->d.dim + 127) / 128 <= 8;
+    return !t->P && !t->F8 && !(g_mm_debug & (1 << 29)) && (t->d.dim % 4) == 0;
 }
 void fold_consume(GemmArgs& a, const mm_transformer* t, const Bufs& b, const void* w_ln, const float* c1, const float* c2) {
     a.X = b.xb; a.ldx = t->d.dim; a.W = (const bf16_t*)w_ln;
-    a.in_part = b.stp; a.in_np = (t->d.dim + 127) / 128; a.in_F = t->d.dim; a.in_c1 = c1; a.in_c2 = c2;
+    a.in_part = b.stp; a.in_np = ln_fold_np(t->d.dim); a.in_F = t->d.dim; a.in_c1 = c1; a.in_c2 = c2;
 }
 void fold_produce(GemmArgs& a, const mm_transformer* t, const Bufs& b, const float* add_row, int add_row_from) {
     a.xb_out = b.xb; a.ldxb = t->d.dim; a.st_part = b.stp; a.add_row = add_row; a.add_row_from = add_row_from;
@@ -957,7 +958,7 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
                 RC(self_attn_block(t, s, w.self_attn, B, n, b, false, fold));
                 hipError_t e = hipMemcpyAsync(b.x + (size_t)M * D, b.x, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s);
                 if (e == hipSuccess && fold && !null_const) {      // the null half's cross-attention runs (condition ids stay attended): it reads the fold data of its rows too
-                    const size_t np_ = (size_t)(D + 127) / 128;
+                    const size_t np_ = (size_t)ln_fold_np(D);
                     e = hipMemcpyAsync(b.xb + (size_t)M * D, b.xb, (size_t)M * D * 2, hipMemcpyDeviceToDevice, s);
                     if (e == hipSuccess) e = hipMemcpyAsync(b.stp + (size_t)M * np_ * 2, b.stp, (size_t)M * np_ * 8, hipMemcpyDeviceToDevice, s);
                 }

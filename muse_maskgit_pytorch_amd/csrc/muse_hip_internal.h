@@ -48,12 +48,12 @@ struct GemmArgs {
     int f16; float alpha;
     // LayerNorm(dim) folded into the GEMMs around it (round 4, bf16 engine; model.hip):
     //   PRODUCER -- the fp32-residual epilogue of the 128x128 / 256x128 kernels (out = resid + acc): with xb_out != NULL it also writes the new residual
-    //     row as bf16 (xb_out [M][ldxb]) and, per row and 128-column tile, the (sum, sum of squares) of the fp32 values to st_part[(row * st_np + tile) * 2 ..],
-    //     st_np = ceil(N / 128).  add_row (optional, fp32 [N]) is added to rows >= add_row_from after the residual: (acc + resid) + add_row.
+    //     row as bf16 (xb_out [M][ldxb]) and, per row and 64 columns, the (sum, sum of squares) of the fp32 values to st_part[(row * st_np + i) * 2 ..],
+    //     st_np = 2 ceil(N / 128).  add_row (optional, fp32 [N]) is added to rows >= add_row_from after the residual: (acc + resid) + add_row.
     //   CONSUMER -- bf16-output dense GEMMs (gemm_wide plain / GEGLU, the 128x128 kernel): with in_c1 != NULL the operand rows X are the RAW bf16 residual
     //     rows and W carries the gains (bf16(W . diag gamma)); the epilogue applies out = rstd * acc - rstd * mean * in_c1[n] + in_c2[n] (in_c2 optional)
     //     with the row's mean / rstd from the in_np partials in_part[(row * in_np + i) * 2 ..] over in_F features -- before GEGLU when there is one.
-    bf16_t* xb_out; long ldxb; float* st_part; int st_np; const float* add_row; int add_row_from;
+    bf16_t* xb_out; long ldxb; float* st_part; int st_np; int st_gran; const float* add_row; int add_row_from;      // st_gran: columns per partial (64 for N <= 512, else 128; set by mm_gemm_launch)
     const float* in_part; int in_np; int in_F; const float* in_c1; const float* in_c2;
 };
 extern int g_mm_debug;

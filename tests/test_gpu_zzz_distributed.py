@@ -78,13 +78,18 @@ def _rccl_worker(q, port):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     torch.cuda.set_device(0)
-    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
-    ids = torch.randint(0, 65536, (5, 16, 16), device='cuda')
-    out = parallel.allgather_ids(ids, dist)                      # backend nccl -> the library's own communicator + mm_allgather_ids
-    gather = parallel._GATHERS[0]
-    ok = torch.equal(out, ids) and out.dtype == torch.long and gather.world == 1 and isinstance(gather, parallel.IdsGather)
-    out2 = parallel.allgather_ids(ids + 1 - 1, dist)             # a second call reuses the communicator
-    q.put(bool(ok and torch.equal(out2, ids)))
+    result = False
+    try:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+        ids = torch.randint(0, 65536, (5, 16, 16), device='cuda')
+        out = parallel.allgather_ids(ids, dist)                      # backend nccl -> the library's own communicator + mm_allgather_ids
+        gather = parallel._GATHERS[parallel._gather_key(dist, None)]
+        ok = torch.equal(out, ids) and out.dtype == torch.long and gather.world == 1 and isinstance(gather, parallel.IdsGather)
+        out2 = parallel.allgather_ids(ids + 1 - 1, dist)             # a second call reuses the communicator
+        assert len(parallel._GATHERS) == 1
+        result = bool(ok and torch.equal(out2, ids))
+    finally:
+        q.put(result)                                                # (a worker that dies must not leave the parent waiting for its timeout)
     dist.destroy_process_group()
 
 
