@@ -39,8 +39,14 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + 
 // source of the implicit-GEMM loader for taps that fall into the zero padding
 __device__ __attribute__((aligned(16))) const unsigned int g_zero_page[64] = {0};
 
-template <int MODE, bool F16 = false>
+// BM: token rows per tile.  128 everywhere, except dense launches whose 128 x 128 tiles would leave a CU with fewer than two workgroups (the cross-attention's
+// projections: 8192 rows x 512 columns = 256 tiles, ONE four-wave workgroup per CU, i.e. one wave per SIMD with every latency exposed -- 16.9 us for 4.3 GFLOP):
+// there BM = 64 gives each CU two or three independent workgroups whose barrier phases drift apart and cover one another (round 4).  Same MFMA order per
+// output element: bit-identical results.
+template <int MODE, bool F16 = false, int BM = 128>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
+    static_assert(BM == 128 || (BM == 64 && MODE == MODE_DENSE), "64-token tiles: dense mode only");
+    constexpr int MB = BM / 32;      // token fragments per wave (a wave: 64 weight rows x BM / 2 tokens)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TSTAMP(0)
     const int t = threadIdx.x;
@@ -49,7 +55,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     int tile_m, tile_n;
     xcd_grouped_tile(blockIdx.x, p.tiles_m, p.tiles_n, 16, tile_m, tile_n);
     const int n0 = tile_n * BT;
-    const int m0 = tile_m * (MODE == MODE_CFG ? 64 : BT);   // CFG: 64 tokens x {cond, null} per tile
+    const int m0 = tile_m * (MODE == MODE_CFG ? 64 : BM);   // CFG: 64 tokens x {cond, null} per tile
     // device-side row count (the per-row fallback of the fused sampler: the number of rows to redo is only known on the device): tiles
     // beyond it leave at once, so a launch sized for the capacity costs a launch and nothing else when no row failed
     if (p.m_dev && m0 >= *p.m_dev) return;
@@ -58,6 +64,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     //      instruction lane l lands on (row l>>3, physical chunk l&7), which must hold logical chunk (l&7) ^ (row & 7).
     const int chunk = (lane & 7) ^ (lane >> 3);
     const int row0 = 32 * wid + (lane >> 3);          // rows row0 + 8*i
+    constexpr int XI = BM / 32;                       // X tile: this wave's BM / 4 rows = XI instructions (rows xrow0 + 8*i)
+    const int xrow0 = (BM / 4) * wid + (lane >> 3);
     const bf16_t* wptr[4];
     const bf16_t* xptr[4];
     bool xok[4];
@@ -69,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         // out-of-range rows are clamped to row 0: they only feed outputs the epilogue never stores
         wptr[i] = p.W + (size_t)(n < p.N ? n : 0) * p.ldw + chunk * 8;
         if constexpr (MODE == MODE_DENSE) {
-            const int m = m0 + r;
+            const int m = m0 + xrow0 + 8 * (i < XI ? i : 0);
             xok[i] = m < p.M;
             xptr[i] = p.X + (size_t)(xok[i] ? m : 0) * p.ldx + chunk * 8;
         } else if constexpr (MODE == MODE_CFG) {
@@ -95,11 +103,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     {                                                                                                              \
         const int k0_ = (kt_) * BK;                                                                                \
         unsigned char* ws_ = smem + (stage_) * STAGE_BYTES + wid * 4096;   /* this wave's 32 rows of the W tile */ \
-        unsigned char* xs_ = ws_ + BT * BK * 2;                                                                    \
+        unsigned char* xs_ = smem + (stage_) * STAGE_BYTES + BT * BK * 2 + wid * (BM * 32);   /* ... its BM / 4 rows of the X tile */ \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
             __builtin_amdgcn_global_load_lds(wptr[i] + k0_, (lds_ptr_t)(ws_ + i * 1024), 16, 0, 0);                \
         if constexpr (MODE != MODE_CONV) {                                                                         \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+            _Pragma("unroll") for (int i = 0; i < XI; ++i)                                                         \
                 __builtin_amdgcn_global_load_lds(xptr[i] + k0_, (lds_ptr_t)(xs_ + i * 1024), 16, 0, 0);            \
         } else {                                                                                                   \
             /* im2col on the fly: this lane's 8 channels of K-index k belong to tap k / Cin; taps that fall in the */ \
@@ -120,11 +128,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         }                                                                                                          \
     }
 
-    f32x4_t acc[4][4];
+    f32x4_t acc[4][MB];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < MB; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // split-K: this workgroup covers k-tiles [kt0, kt0 + KT) and writes its partial sums to slab blockIdx.y of `out`
     const int nsplit = p.splits > 1 ? p.splits : 1;
@@ -137,13 +145,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     // the first k-tile's DMA -- in the epilogue the read-modify-write of all workgroups at once was a pure latency / bandwidth tail
     // (cycle stamps, 8192 x 512 x 512: write-out 16.1 k cycles with the residual read there, 2.3 k without)
     constexpr bool RESID_PF = (MODE == MODE_DENSE);
-    float4 rres[RESID_PF ? BT / 8 : 1];
+    float4 rres[RESID_PF ? BM / 8 : 1];
     const bool resid_pf = RESID_PF && p.resid_f32 && p.out_kind == OUT_F32 && p.splits <= 1 && (p.N % 4) == 0;
     if constexpr (RESID_PF) {
         if (resid_pf) {
             const int n_ = n0 + (t & 31) * 4;
 #pragma unroll
-            for (int pass = 0; pass < BT / 8; ++pass) {
+            for (int pass = 0; pass < BM / 8; ++pass) {
                 const int m_ = m0 + pass * 8 + (t >> 5);
                 rres[pass] = (m_ < p.M && n_ < p.N) ? *reinterpret_cast<const float4*>(p.resid_f32 + (size_t)m_ * p.ldr + n_) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -154,12 +162,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     if constexpr (RESID_PF) {
         if (resid_pf && p.ln_c1) {      // 256 threads = 2 per tile row
             const int r_ = t >> 1, m_ = m0 + r_;
-            const float2 st = ln_stats_from_partials(p.ln_part, p.ln_np, m_ < p.M ? m_ : 0, p.ln_F, t & 1, m_ < p.M);
+            const float2 st = ln_stats_from_partials(p.ln_part, p.ln_np, m_ < p.M ? m_ : 0, p.ln_F, t & 1, m_ < p.M && r_ < BM);
             if (!(t & 1)) ln_stat[r_] = st;
         } else if (p.in_c1) {           // LayerNorm(dim) fold, consumer side (GemmArgs::in_c1): the operand rows are raw residual rows, their statistics come with them
             if (t >= 128) {             // one thread per tile row: (rstd, -mean) by the shared routine (common.h ln_rstd_negmean)
                 const int r_ = t - 128, m_ = m0 + r_;
-                ln_stat[r_] = ln_rstd_negmean(reinterpret_cast<const float2*>(p.in_part) + (size_t)(m_ < p.M ? m_ : 0) * p.in_np, m_ < p.M ? p.in_np : 0, 1.f / (float)p.in_F);
+                const bool ok_ = m_ < p.M && r_ < BM;
+                ln_stat[r_] = ln_rstd_negmean(reinterpret_cast<const float2*>(p.in_part) + (size_t)(ok_ ? m_ : 0) * p.in_np, ok_ ? p.in_np : 0, 1.f / (float)p.in_F);
             }
             if (t < 64) {               // this tile's 128 entries of c1 | c2 go to LDS now: a global load in the epilogue would be pure exposed latency
                 const int n_ = n0 + (t & 31) * 4;
@@ -180,14 +189,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         const unsigned char* ws_ = smem + (stage_) * STAGE_BYTES;                                                  \
         const unsigned char* xs_ = ws_ + BT * BK * 2;                                                              \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                         \
-            u32x4_t af[4], bfm[4];                                                                                 \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                        \
+            u32x4_t af[4], bfm[MB];                                                                                \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
                 af[i] = *reinterpret_cast<const u32x4_t*>(ws_ + lds_off(wave_n * 64 + i * 16 + fr, ks * 4 + fg)); \
-                bfm[i] = *reinterpret_cast<const u32x4_t*>(xs_ + lds_off(wave_m * 64 + i * 16 + fr, ks * 4 + fg)); \
-            }                                                                                                      \
+            _Pragma("unroll") for (int i = 0; i < MB; ++i)                                                         \
+                bfm[i] = *reinterpret_cast<const u32x4_t*>(xs_ + lds_off(wave_m * (BM / 2) + i * 16 + fr, ks * 4 + fg)); \
             if (!(p.debug & 4)) {                                                                                  \
             _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                          \
-                _Pragma("unroll") for (int b = 0; b < 4; ++b) acc[a][b] = mfma16t<F16>(af[a], bfm[b], acc[a][b]);   \
+                _Pragma("unroll") for (int b = 0; b < MB; ++b) acc[a][b] = mfma16t<F16>(af[a], bfm[b], acc[a][b]);  \
             } else { _Pragma("unroll") for (int a = 0; a < 4; ++a) { acc[a][0][0] += __uint_as_float(af[a][0] ^ bfm[a][1]); } } \
         }                                                                                                          \
     }
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] *= al;
+            for (int b = 0; b < MB; ++b) acc[a][b] *= al;
     }
 
     if constexpr (MODE == MODE_DENSE) {
@@ -223,8 +232,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                 c2v[a] = lc[32 + q4];
             }
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const float2 stv = ln_stat[wave_m * 64 + b * 16 + fr];
+            for (int b = 0; b < MB; ++b) {
+                const float2 stv = ln_stat[wave_m * (BM / 2) + b * 16 + fr];
                 const float rs = stv.x, nm = stv.y;
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
@@ -241,8 +250,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     //      through LDS (fp32, row stride 132 floats: conflict-free ds_write_b128) and is written out row-contiguously,
     //      16 B per lane, 512 B (fp32) / 256 B (bf16) of one row per quarter wave; the residual is read the same way.
     if ((p.debug & 1) && acc[0][0][0] != 12345.678f) return;
-    constexpr int MT = (MODE == MODE_CFG) ? 2 : 4;
-    constexpr int TROWS = (MODE == MODE_CFG) ? 64 : BT;
+    constexpr int MT = (MODE == MODE_CFG) ? 2 : MB;
+    constexpr int TROWS = (MODE == MODE_CFG) ? 64 : BM;
 
     if (p.out_kind == OUT_NCHW_F32) {
         // narrow conv head (Cout = image channels): direct scalar stores, out[b][n][y][x]
@@ -277,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     const bool geglu = (MODE == MODE_DENSE) && p.epi == EPI_GEGLU;
 #pragma unroll
     for (int b = 0; b < MT; ++b) {
-        const int ml = (MODE == MODE_CFG) ? (wave_m * 32 + b * 16 + fr) : (wave_m * 64 + b * 16 + fr);
+        const int ml = (MODE == MODE_CFG) ? (wave_m * 32 + b * 16 + fr) : (wave_m * (BM / 2) + b * 16 + fr);
         if (geglu) {
             // W rows are interleaved per wave: fragments a = 0,1 hold the gelu half, a = 2,3 the gate half of the SAME
             // 32 output columns -> gate * gelu(x) is lane-local; the tile emits 64 columns
@@ -324,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         const int c8 = (t & 7) * 8;
         const int no = tile_n * 64 + c8;           // output column; the output has N/2 columns
 #pragma unroll 4
-        for (int pass = 0; pass < BT / 32; ++pass) {
+        for (int pass = 0; pass < BM / 32; ++pass) {
             const int ml = pass * 32 + (t >> 3);
             const int m = m0 + ml;
             const float4 lo = *reinterpret_cast<const float4*>(ct + ml * CT_LD + c8);
@@ -365,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                 if (p.add_row && n < p.N) arow = *reinterpret_cast<const float4*>(p.add_row + n);
                 const bool fold_out = p.xb_out != nullptr;         // (wave-uniform)
 #pragma unroll
-                for (int pass = 0; pass < BT / 8; ++pass) {
+                for (int pass = 0; pass < BM / 8; ++pass) {
                     const int ml = pass * 8 + (t >> 5);
                     const int m = m0 + ml;
                     const bool ok_ = m < p.M && n < p.N;
@@ -469,24 +478,35 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     TSTAMP(43)
 }
 
-template <int MODE, bool F16 = false>
+template <int MODE, bool F16 = false, int BM = 128>
 int launch(const GemmArgs& a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_kernel<MODE, F16>)),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_kernel<MODE, F16, BM>)),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
         if (e != hipSuccess) return mm_set_hip_error(e, "gemm hipFuncSetAttribute");
         attr_set = true;
     }
     const int blocks = a.tiles_m * a.tiles_n;
     if (blocks <= 0) return MM_OK;
-    hipLaunchKernelGGL((gemm_kernel<MODE, F16>), dim3(blocks, a.splits > 1 ? a.splits : 1), dim3(256), SMEM_BYTES, stream, a);
+    hipLaunchKernelGGL((gemm_kernel<MODE, F16, BM>), dim3(blocks, a.splits > 1 ? a.splits : 1), dim3(256), SMEM_BYTES, stream, a);
     return mm_check_launch("gemm_kernel");
 }
 
 }  // namespace
 
 int g_mm_debug = 0;
+
+// dense launch on the 128 x 128 kernel: 64-token tiles when the 128-token grid would give a CU fewer than two workgroups (see gemm_kernel)
+static int launch_dense_small(GemmArgs a, hipStream_t stream) {
+    a.tiles_n = (a.N + BT - 1) / BT;
+    a.tiles_m = (a.M + BT - 1) / BT;
+    if ((long)a.tiles_m * a.tiles_n < 512 && a.M > 64 && a.splits <= 1 && !a.m_dev) {
+        a.tiles_m = (a.M + 63) / 64;
+        return launch<MODE_DENSE, false, 64>(a, stream);
+    }
+    return launch<MODE_DENSE>(a, stream);
+}
 
 int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
     a.debug = g_mm_debug;
@@ -540,9 +560,7 @@ int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
         if (a.mode != MODE_DENSE || a.out_kind != OUT_BF16 || !a.in_part || a.in_np <= 0 || a.in_F <= 0 || a.resid_bf16 || a.bias || a.splits > 1 || a.m_dev || (a.N % 4))
             return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: the LayerNorm(dim) fold needs a plain dense bf16-output GEMM");
         if (!(a.debug & (8 | 4096 | 8192 | (1 << 30))) && mm_gemm_wide_eligible(a)) return mm_gemm_wide_launch(a, stream);
-        a.tiles_n = (a.N + BT - 1) / BT;
-        a.tiles_m = (a.M + BT - 1) / BT;
-        return launch<MODE_DENSE>(a, stream);
+        return launch_dense_small(a, stream);
     }
     if (a.xb_out) {     // ... producer side: the fp32-residual epilogue of the 256x128 / 128x128 kernels
         if (a.mode != MODE_DENSE || a.out_kind != OUT_F32 || !a.resid_f32 || (a.N % 4) || !a.st_part || a.splits > 1 || a.m_dev || a.epi != EPI_NONE)
@@ -550,9 +568,7 @@ int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
         a.st_gran = a.N <= 512 ? 64 : 128;      // (model.hip ln_fold_np computes the same count for the consumers)
         a.st_np = (a.N + a.st_gran - 1) / a.st_gran;
         if (!(a.debug & 8) && mm_gemm_big_eligible(a)) return mm_gemm_big_launch(a, stream);
-        a.tiles_n = (a.N + BT - 1) / BT;
-        a.tiles_m = (a.M + BT - 1) / BT;
-        return launch<MODE_DENSE>(a, stream);
+        return launch_dense_small(a, stream);
     }
     if (a.m_dev) a.debug |= 8;      // only the 128x128 kernel reads the device-side row count
     if (!(a.debug & (8 | 4096 | 8192 | (1 << 30))) && mm_gemm_wide_eligible(a)) return mm_gemm_wide_launch(a, stream);      // (bit 1 << 30: A/B against the older kernels)
@@ -563,7 +579,7 @@ int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
     const int tm = a.mode == MODE_CFG ? 64 : BT;
     a.tiles_m = (a.M + tm - 1) / tm;
     switch (a.mode) {
-        case MODE_DENSE: return launch<MODE_DENSE>(a, stream);
+        case MODE_DENSE: return launch_dense_small(a, stream);
         case MODE_CFG: return launch<MODE_CFG>(a, stream);
         case MODE_CONV: return launch<MODE_CONV>(a, stream);
     }

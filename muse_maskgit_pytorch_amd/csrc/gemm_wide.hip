@@ -335,11 +335,6 @@ __global__ __launch_bounds__(512) void gemm_wide_fused_kernel(const GemmArgs p) 
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                                  \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(ws_ + i * 1024), 16, voff_w[i], (kt_) * BKB, 0, 0);              \
     }
-#define ISSUE_PIECE_F(kt_, st_, j_)                                                                                                    \
-    {                                                                                                                                  \
-        if ((j_) < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(smem + (st_) * STG + wid * 4096 + (j_) * 1024), 16, voff_x[(j_) & 3], (kt_) * BKB, 0, 0); \
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(smem + (st_) * STG + X_B + wid * 4096 + ((j_) - 4) * 1024), 16, voff_w[((j_) - 4) & 3], (kt_) * BKB, 0, 0); \
-    }
     TILE_SETUP(vb);
     ISSUE(0, 0);
     int pending = 0;                 // VMEM stores this wave issued BEHIND the DMA of the coming tile's first step (the previous tile's emission)
@@ -354,47 +349,30 @@ __global__ __launch_bounds__(512) void gemm_wide_fused_kernel(const GemmArgs p) 
             const int st = kt & 1;
             if (kt == 0) wait_vmcnt_w(pending); else __builtin_amdgcn_s_waitcnt(0x0F70);      // this step's DMA has landed (in-order retirement: only younger stores may be in flight)
             __builtin_amdgcn_s_barrier();
-#if MM_WIDE_SPREAD
-            int nk = kt + 1, ns = st ^ 1;      // see gemm_wide_kernel
-            bool do_issue = true;
-            if (kt + 1 == KT) {
-                nk = 0; ns = 0;
-                do_issue = vb + G < total;
-                if (do_issue) TILE_SETUP(vb + G);
-            }
-#endif
-            // (round 3, burst issue: right behind the barrier; behind the first sub-step -- what the non-persistent kernel above did -- measured 2 %
+            // (the DMA issue stays right behind the barrier; behind the first sub-step -- what the non-persistent kernel above did -- measured 2 %
             //  slower in this kernel, same box, 583-586 vs 594-597 us per launch at R = 5140)
-#if !MM_WIDE_SPREAD
             if (kt + 1 < KT) {
                 ISSUE(kt + 1, st ^ 1);
             } else if (vb + G < total) {      // last step (stage 1, KT even): the next tile's first step goes into stage 0
                 TILE_SETUP(vb + G);
                 ISSUE(0, 0);
             }
-#endif
             if (kt == 0 && wid == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(thr_rs, (lds_ptr_t)(lthr), 16, lane * 16, cur_m * TM * 4, 0, 0);
             const unsigned char* xs = smem + st * STG + (wm * 128) * BKB;
             const unsigned char* ws = smem + st * STG + X_B + (wn * 64) * BKB;
-            u32x4_t wf[4], wf2[4], xr[3];
+            // (the two-block-ahead prefetch of gemm_wide_kernel was measured here as well: 546 vs 568 us stand-alone, but 565 vs 535 us inside the decode loop --
+            //  this kernel keeps hipcc's own order of the fragment reads)
 #pragma unroll
-            for (int a = 0; a < 4; ++a) wf[a] = *reinterpret_cast<const u32x4_t*>(ws + sw128(a * 16 + fr, fg));
-            xr[0] = *reinterpret_cast<const u32x4_t*>(xs + sw128(fr, fg));
-            xr[1] = *reinterpret_cast<const u32x4_t*>(xs + sw128(16 + fr, fg));
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4_t wf[4];
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {        // 16 blocks of 16 tokens x 32 k: sub-step ks = it >> 3 (k ascending), token block b = it & 7
-                const int b = it & 7;
-                if (it + 2 < 16) xr[(it + 2) % 3] = *reinterpret_cast<const u32x4_t*>(xs + sw128(((it + 2) & 7) * 16 + fr, ((it + 2) >> 3) * 4 + fg));
-                if (it == 6) {
+                for (int a = 0; a < 4; ++a) wf[a] = *reinterpret_cast<const u32x4_t*>(ws + sw128(a * 16 + fr, ks * 4 + fg));
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) wf2[a] = *reinterpret_cast<const u32x4_t*>(ws + sw128(a * 16 + fr, 4 + fg));
+                for (int b = 0; b < 8; ++b) {
+                    const u32x4_t xf = *reinterpret_cast<const u32x4_t*>(xs + sw128(b * 16 + fr, ks * 4 + fg));
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) acc[a][b] = mfma16t<F16>(wf[a], xf, acc[a][b]);
                 }
-                __builtin_amdgcn_sched_barrier(0);      // the prefetches stay in FRONT of this block's MFMAs (the scheduler otherwise sinks them behind)
-#pragma unroll
-                for (int a = 0; a < 4; ++a) acc[a][b] = mfma16t<F16>(it < 8 ? wf[a] : wf2[a], xr[it % 3], acc[a][b]);
-#if MM_WIDE_SPREAD
-                if ((it & 1) == 0 && do_issue) ISSUE_PIECE_F(nk, ns, it >> 1);      // one LDS-DMA piece behind every second block: see gemm_wide_kernel
-#endif
             }
         }
         if constexpr (F16) {      // undo the power-of-two scale of the packed weight terms (exact) before statistics and candidates
