@@ -295,6 +295,8 @@ def train_bench(args, dev, rank, world, dist):
     te = synth_text(world * B, args.text_len, tr.text_embed_dim)[rank * B:(rank + 1) * B].to(dev)
     opt = torch.optim.AdamW(tr.parameters(), lr=1e-4)
     losses = []
+    from muse_maskgit_pytorch_amd import training as _training
+    c_step = _training._c_step_eligible(tr, ids, te, None, False, None, None, tr.grad_sync)
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -319,14 +321,24 @@ def train_bench(args, dev, rank, world, dist):
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     if rank == 0:
         sec = dt.item() / args.steps
+        # executed MFMA flops of one step: the Linear layers three times (forward, dX, dW), the attention products once forward and 3.5x backward
+        # (7 block products against 2), the head on the labelled rows only (their count of the last step)
+        cfgb = tr.transformer_blocks.cfg
+        D, H, I, F, V, M, Mc = tr.dim, cfgb['heads'], cfgb['heads'] * 64, int(tr.dim * 4 * 2 / 3), tr.dim_out, B * n, B * args.text_len
+        R = int(getattr(tr, '_last_train_rows', M // 2))
+        lin = cfgb['depth'] * (2.0 * M * D * 3 * I + 2.0 * M * I * D + 2.0 * M * D * I + 2.0 * M * I * D + 2.0 * Mc * D * 2 * I + 2.0 * M * D * 2 * F + 2.0 * M * F * D) + 2.0 * R * D * V
+        att = cfgb['depth'] * (4.0 * B * H * n * (n + 1) * 64 + 4.0 * B * H * n * (args.text_len + 1) * 64)
+        ex = 3.0 * lin + 4.5 * att
         _RECORD_OUT.write(json.dumps({
+            'executed_tflops': ex / sec / 1e12, 'executed_mfma_frac': ex / sec / 1e12 / PEAK_BF16_TFLOPS, 'labelled_rows_last_step': R,
+            'driver': 'mm_train_step (one C call per step: forward + loss + backward, csrc/train_step.hip)' if c_step else 'training.py (operator by operator over the C ABI)',
             'metric': 'training tokens/sec (C2 base transformer: MaskGit.forward + backward + AdamW)', 'value': world * B * n / sec, 'unit': 'tokens/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': sec * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16 (fp32 master weights, fp32 gradients)', 'data': 'synthetic',
             'config': {'workload': 'training step of the BASELINE configs[1] transformer (dim 512, depth 8, 256 tokens, codebook 65536), token ids in, '
                                    'cosine-schedule random masking, cond_drop_prob 0.5, AdamW', 'sequences_per_gpu_per_step': B, 'global_batch': world * B,
                        'seq_len': n, 'parallelism': f'dp{world} (bucketed gradient all-reduce overlapped with the backward)'},
-            'note': 'secondary line: BASELINE.json names no training metric; orchestrated from Python over the C-ABI operators (training.py)',
+            'note': 'secondary line: BASELINE.json names no training metric',
             'loss_first': float(losses[0]), 'loss_last': float(losses[-1])}) + '\n')
         _RECORD_OUT.flush()
     if dist is not None:

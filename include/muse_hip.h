@@ -548,6 +548,39 @@ size_t mm_generate_critic_workspace_bytes(const mm_transformer_t* critic, int B,
 int mm_generate(const mm_transformer_t* model, mm_stream_t stream, const mm_generate_params* params,
                 void* workspace, size_t workspace_bytes);
 
+/* ------------------------------------------------------------------------------------------------ training step (round 4)
+ * MaskGit.forward's differentiable core (muse_maskgit_pytorch.py:623-741 through Transformer.forward :279-348) as ONE call: forward with saved
+ * activations, mean cross-entropy over the R labelled rows, and the hand-written backward, ~1150 launches on one stream with no allocation and no
+ * host synchronisation in between (capturable).  Parameters are the caller's fp32 tensors (nn.Parameter layouts), bf16 operand copies are made per
+ * step inside the workspace; every gradient is WRITTEN (not accumulated) as fp32 in the parameter's own shape.  The operators and their order are
+ * those of the operator-by-operator driver (training.py): the loss and every gradient are bit-identical to it.  Scope: dim_head 64, n in {64, 128,
+ * 256}, batch * n / dim / dim_out / text_dim multiples of 64, no self-conditioning, no conditioning ids, cross-entropy head (the other variants run on
+ * the operator-by-operator driver).  null_kv: [2][heads][1][64] (k then v), q_scale / k_scale [64]; beta pointers: the LayerNorms' zero buffers (may be
+ * NULL only for ff.b2); text_proj NULL = nn.Identity (text_dim == dim; d_text_proj unused). */
+typedef struct mm_train_attn {
+    const float *gamma, *beta, *to_q, *to_kv, *q_scale, *k_scale, *null_kv, *to_out;
+    float *d_gamma, *d_to_q, *d_to_kv, *d_q_scale, *d_k_scale, *d_null_kv, *d_to_out;
+} mm_train_attn;
+typedef struct mm_train_ff {
+    const float *g1, *b1, *w1, *g2, *b2, *w2;      /* w1 [2F][D] (rows [0, F) gelu half, [F, 2F) gate half), w2 [D][F] */
+    float *d_g1, *d_w1, *d_g2, *d_w2;
+} mm_train_ff;
+typedef struct mm_train_layer {
+    mm_train_attn sa, ca;
+    mm_train_ff ff;
+} mm_train_layer;
+typedef struct mm_train_desc {
+    int32_t dim, depth, heads, ff_inner, seq_len, vocab_rows, dim_out, text_dim;
+    const float *token_emb, *pos_emb, *text_proj, *final_gamma, *final_beta, *to_logits;
+    float *d_token_emb, *d_pos_emb, *d_text_proj, *d_final_gamma, *d_to_logits;
+    const mm_train_layer* layers;      /* host array [depth] */
+} mm_train_desc;
+size_t mm_train_step_workspace_bytes(const mm_train_desc* desc, int B, int n, int L, int R);
+/* ids int64 [B][n]; text_embeds fp32 [B][L][text_dim]; ctx_mask uint8 [B][L] (1 = attend); row_index int32 [R] flat positions b * n + pos that carry a
+ * label, labels_rows int64 [R]; loss_out fp32 [1]; logits_rows_out (optional) fp32 [R][dim_out]. */
+int mm_train_step(const mm_train_desc* desc, mm_stream_t stream, const int64_t* ids, int B, int n, const float* text_embeds, int L, const uint8_t* ctx_mask,
+                  const int32_t* row_index, const int64_t* labels_rows, int R, float* loss_out, float* logits_rows_out, void* workspace, size_t workspace_bytes);
+
 /* ------------------------------------------------------------------------------------------------ multi-GPU: the one collective of the path
  * Inference shards by sample (one process per GPU); mm_generate needs no communication (every reduction of MaskGit.generate is per sample,
  * mmp.py:561,576,580,603).  What remains is ONE all-gather of the generated token grids: ids int64 [count] per rank (all < codebook size) travel as

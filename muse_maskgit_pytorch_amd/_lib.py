@@ -43,6 +43,25 @@ class TransformerDesc(C.Structure):
                 ('split_products', C.c_int32), ('fp8', C.c_int32), ('split_alpha', c_f32)]
 
 
+class TrainAttn(C.Structure):
+    _fields_ = [(n, c_vp) for n in ('gamma', 'beta', 'to_q', 'to_kv', 'q_scale', 'k_scale', 'null_kv', 'to_out',
+                                    'd_gamma', 'd_to_q', 'd_to_kv', 'd_q_scale', 'd_k_scale', 'd_null_kv', 'd_to_out')]
+
+
+class TrainFF(C.Structure):
+    _fields_ = [(n, c_vp) for n in ('g1', 'b1', 'w1', 'g2', 'b2', 'w2', 'd_g1', 'd_w1', 'd_g2', 'd_w2')]
+
+
+class TrainLayer(C.Structure):
+    _fields_ = [('sa', TrainAttn), ('ca', TrainAttn), ('ff', TrainFF)]
+
+
+class TrainDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('dim', 'depth', 'heads', 'ff_inner', 'seq_len', 'vocab_rows', 'dim_out', 'text_dim')] + \
+               [(n, c_vp) for n in ('token_emb', 'pos_emb', 'text_proj', 'final_gamma', 'final_beta', 'to_logits',
+                                    'd_token_emb', 'd_pos_emb', 'd_text_proj', 'd_final_gamma', 'd_to_logits')] + [('layers', C.POINTER(TrainLayer))]
+
+
 class VaeLayer(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('kind', 'cout', 'k', 'groups')] + [('w', c_vp * 4), ('b', c_vp * 3), ('gn_g', c_vp * 2), ('gn_b', c_vp * 2)]
 
@@ -109,6 +128,8 @@ SIGNATURES = {
     'mm_attention_bwd': (c_int, [c_vp] + [c_vp, c_i64, c_i64, c_i64] * 8 + [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32]),
     'mm_qk_norm_bwd_blocks': (c_i64, [c_i64]),
     'mm_qk_norm_bwd': (c_int, [c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_vp]),
+    'mm_train_step_workspace_bytes': (c_sz, [C.POINTER(TrainDesc), c_int, c_int, c_int, c_int]),
+    'mm_train_step': (c_int, [C.POINTER(TrainDesc), c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_sz]),
     'mm_philox_uniform': (c_int, [c_vp, c_u64, c_u64, c_u32, c_int, c_int, c_vp]),
     'mm_conv2d_nhwc': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int] + [c_int] * 12 + [c_vp, c_int, c_vp, c_vp, c_int]),
     'mm_conv2d_nhwc_f16': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int] + [c_int] * 12 + [c_vp, c_int, c_vp, c_vp, c_int, c_f32]),

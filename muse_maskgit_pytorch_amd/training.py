@@ -321,6 +321,87 @@ class TransformerTrainFn(torch.autograd.Function):
         return (None, None, None, None, None, None, None, None, *grads)
 
 
+class TrainStepFn(torch.autograd.Function):
+    """The same step as TransformerTrainFn through ONE C call (mm_train_step, csrc/train_step.hip): forward, loss and the whole backward run
+    on the stream without returning to Python; the gradients are kept and handed to autograd in backward() (scaled by the incoming gradient of
+    the loss).  Bit-identical to the operator-by-operator driver above (tests/test_gpu_train_step.py)."""
+
+    @staticmethod
+    def forward(ctx, cfg, ids, te, ctx_mask, labels_rows, row_index, *params):
+        from . import _lib as L
+        import ctypes as C
+        tr = cfg['tr']
+        P = dict(zip(cfg['names'], params))
+        dev = ids.device
+        b, n = ids.shape
+        tb = tr.transformer_blocks
+        depth, D, H = cfg['depth'], cfg['dim'], cfg['heads']
+        R = row_index.numel()
+        V = P['to_logits'].shape[0]
+        G = {k: torch.empty(v.shape, dtype=torch.float32, device=dev) for k, v in P.items()}
+        keep = [v.detach().float().contiguous() for v in params]      # (fp32 contiguous parameters: no copies in the usual case)
+        Pc = dict(zip(cfg['names'], keep))
+        layers = (L.TrainLayer * depth)()
+        betas = cfg['betas']
+        for i in range(depth):
+            for tag, fld in (('sa', layers[i].sa), ('ca', layers[i].ca)):
+                a = f'{i}.{tag}.'
+                fld.gamma, fld.beta = L.ptr(Pc[a + 'norm.gamma']), L.ptr(betas[a])
+                fld.to_q, fld.to_kv, fld.to_out = L.ptr(Pc[a + 'to_q.weight']), L.ptr(Pc[a + 'to_kv.weight']), L.ptr(Pc[a + 'to_out.weight'])
+                fld.q_scale, fld.k_scale, fld.null_kv = L.ptr(Pc[a + 'q_scale']), L.ptr(Pc[a + 'k_scale']), L.ptr(Pc[a + 'null_kv'])
+                fld.d_gamma, fld.d_to_q, fld.d_to_kv, fld.d_to_out = L.ptr(G[a + 'norm.gamma']), L.ptr(G[a + 'to_q.weight']), L.ptr(G[a + 'to_kv.weight']), L.ptr(G[a + 'to_out.weight'])
+                fld.d_q_scale, fld.d_k_scale, fld.d_null_kv = L.ptr(G[a + 'q_scale']), L.ptr(G[a + 'k_scale']), L.ptr(G[a + 'null_kv'])
+            f = f'{i}.ff.'
+            ff = layers[i].ff
+            ff.g1, ff.b1, ff.w1 = L.ptr(Pc[f + 'g1']), L.ptr(betas[f + 'b1']), L.ptr(Pc[f + 'w1'])
+            ff.g2, ff.b2, ff.w2 = L.ptr(Pc[f + 'g2']), L.ptr(betas[f + 'b2']), L.ptr(Pc[f + 'w2'])
+            ff.d_g1, ff.d_w1, ff.d_g2, ff.d_w2 = L.ptr(G[f + 'g1']), L.ptr(G[f + 'w1']), L.ptr(G[f + 'g2']), L.ptr(G[f + 'w2'])
+        d = L.TrainDesc()
+        d.dim, d.depth, d.heads, d.ff_inner = D, depth, H, P['0.ff.w2'].shape[1]
+        d.seq_len, d.vocab_rows, d.dim_out, d.text_dim = P['pos_emb'].shape[0], P['token_emb'].shape[0], V, te.shape[-1]
+        d.token_emb, d.pos_emb, d.to_logits = L.ptr(Pc['token_emb']), L.ptr(Pc['pos_emb']), L.ptr(Pc['to_logits'])
+        d.final_gamma, d.final_beta = L.ptr(Pc['final.gamma']), L.ptr(betas['final'])
+        d.d_token_emb, d.d_pos_emb, d.d_final_gamma, d.d_to_logits = L.ptr(G['token_emb']), L.ptr(G['pos_emb']), L.ptr(G['final.gamma']), L.ptr(G['to_logits'])
+        if cfg['has_proj']:
+            d.text_proj, d.d_text_proj = L.ptr(Pc['text_proj']), L.ptr(G['text_proj'])
+        d.layers = C.cast(layers, C.POINTER(L.TrainLayer))
+        Lt = te.shape[1]
+        lib = L.lib()
+        wsb = lib.mm_train_step_workspace_bytes(C.byref(d), b, n, Lt, R)
+        if wsb == 0:
+            raise L.MuseHipError('mm_train_step: ' + (lib.mm_last_error() or b'').decode())
+        ws = getattr(tr, '_train_ws', None)
+        if ws is None or ws.numel() < wsb or ws.device != dev:
+            ws = tr._train_ws = torch.empty(int(wsb), dtype=torch.uint8, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        logits = torch.empty(R, V, dtype=torch.float32, device=dev) if cfg['want_logits'] else None
+        L.check(lib.mm_train_step(C.byref(d), L.stream(), L.ptr(ids), b, n, L.ptr(te), Lt, L.ptr(ctx_mask), L.ptr(row_index), L.ptr(labels_rows), R,
+                                  L.ptr(loss), L.ptr(logits), L.ptr(ws), ws.numel()), 'mm_train_step')
+        ctx.grads = [G[k] for k in cfg['names']]
+        ctx.dtypes = [p.dtype for p in params]
+        if logits is None:
+            logits = torch.empty(0, device=dev)
+        ctx.mark_non_differentiable(logits)
+        return loss[0].clone(), logits
+
+    @staticmethod
+    def backward(ctx, gloss, _glogits=None):
+        scale = gloss if (gloss.numel() == 1 and float(gloss) != 1.0) else None
+        grads = [(g * scale if scale is not None else g).to(dt) for g, dt in zip(ctx.grads, ctx.dtypes)]
+        ctx.grads = None
+        return (None, None, None, None, None, None, *grads)
+
+
+def _c_step_eligible(tr, ids, te, head, bce, sce, cond_ids, grad_sync):
+    """shapes / variants mm_train_step covers (include/muse_hip.h); everything else runs on the operator-by-operator driver above"""
+    import os
+    if os.environ.get('MM_TRAIN_PY'):      # A/B and the bit-identity test
+        return False
+    b, n = ids.shape
+    return (head is None and not bce and sce is None and cond_ids is None and grad_sync is None and not tr.self_cond and n in (64, 128, 256)
+            and (b * n) % 64 == 0 and tr.dim % 64 == 0 and tr.dim_out % 64 == 0 and te.shape[-1] % 64 == 0 and te.shape[1] > 0)
+
+
 def transformer_loss(tr, ids, text_embeds, labels, ignore_index, cond_drop_prob, grad_sync=None, return_logits=False,
                      self_cond_embed=None, conditioning_token_ids=None, head=None):
     """Differentiable CE loss of Transformer.forward(labels=...) (mmp.py:337-346) on the MI355X training path.
@@ -346,6 +427,7 @@ def transformer_loss(tr, ids, text_embeds, labels, ignore_index, cond_drop_prob,
         row_index = torch.nonzero(labels != ignore_index).reshape(-1).to(torch.int32).contiguous()
         assert row_index.numel() > 0, 'no position carries a label'
         labels_rows = labels[row_index.long()].contiguous()
+    tr._last_train_rows = int(row_index.numel()) if not bce else b * n      # (bench.py: executed flops of the step)
     pr = _Params(tr, head)
     tb = tr.transformer_blocks
     betas = {'final': tb.norm.beta.float().contiguous()}
@@ -364,6 +446,10 @@ def transformer_loss(tr, ids, text_embeds, labels, ignore_index, cond_drop_prob,
         cond_ids = conditioning_token_ids.reshape(b, -1).to(device=dev, dtype=torch.long).contiguous()
     cfg = dict(depth=tb.cfg['depth'], heads=tb.cfg['heads'], dim=tr.dim, names=pr.names, has_proj=pr.has_proj, betas=betas,
                sync=grad_sync, bce=bce, self_cond=bool(tr.self_cond), ext_head=head is not None)
+    if _c_step_eligible(tr, ids, te, head, bce, sce, cond_ids, grad_sync):      # the whole step as one C call (mm_train_step)
+        cfg.update(tr=tr, want_logits=return_logits)
+        loss, logits = TrainStepFn.apply(cfg, ids, te, ctx_mask.to(torch.uint8).contiguous(), labels_rows, row_index, *pr.tensors)
+        return (loss, logits, row_index) if return_logits else loss
     loss, logits = TransformerTrainFn.apply(cfg, ids, te, ctx_mask.to(torch.uint8).contiguous(), labels_rows, row_index, sce, cond_ids, *pr.tensors)
     if return_logits:
         return loss, logits, row_index          # logits of the labelled rows only (CE) / of every position (BCE)
