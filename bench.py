@@ -293,7 +293,10 @@ def train_bench(args, dev, rank, world, dist):
     g = torch.Generator().manual_seed(100 + rank)
     ids = torch.randint(0, 65536, (B, n), generator=g).to(dev)
     te = synth_text(world * B, args.text_len, tr.text_embed_dim)[rank * B:(rank + 1) * B].to(dev)
-    opt = torch.optim.AdamW(tr.parameters(), lr=1e-4)
+    try:
+        opt = torch.optim.AdamW(tr.parameters(), lr=1e-4, fused=True)      # torch's single-kernel-per-group AdamW (the optimizer is torch's on every path)
+    except (RuntimeError, TypeError):
+        opt = torch.optim.AdamW(tr.parameters(), lr=1e-4)
     losses = []
     from muse_maskgit_pytorch_amd import training as _training
     c_step = _training._c_step_eligible(tr, ids, te, None, False, None, None, tr.grad_sync)
@@ -430,12 +433,12 @@ def main():
     nc = (cond_size // 16) ** 2 if cond_size else 0
 
     def step(i):
-        ids = mg.generate([''] * B, timesteps=T, cond_scale=3, text_embeds=te, cond_images=cond, seed=1000 + i, row_offset=rank * B, return_ids=True,
-                          fused_sampling=not args.no_fused_sampling)
+        # ids + images from the one call: the VAE decode is enqueued before generate() reads its 8-byte status (the step's one host synchronisation);
+        # e_mid marks the end of the decode loop on the stream
         e_mid = torch.cuda.Event(enable_timing=True)
-        e_mid.record()
+        ids, images = mg.generate([''] * B, timesteps=T, cond_scale=3, text_embeds=te, cond_images=cond, seed=1000 + i, row_offset=rank * B, return_ids='both',
+                                  fused_sampling=not args.no_fused_sampling, loop_end_event=e_mid)
         all_ids = allgather_ids(ids, dist) if dist is not None else ids      # one RCCL all-gather of token grids
-        images = mg.vae.decode_from_ids(ids)
         return all_ids, images, e_mid
 
     for i in range(args.warmup):

@@ -435,7 +435,7 @@ int k_attention_bwd(hipStream_t s, const bf16_t* q, long q_sb, long q_sh, long q
 
 long k_qk_norm_bwd_blocks(long nvec) {
     long b = (nvec + 15) / 16;
-    return b > 128 ? 128 : (b < 1 ? 1 : b);
+    return b > 1024 ? 1024 : (b < 1 ? 1 : b);      // (round 4: was 128 -- half the CUs idle and 32 serial vectors per 16-lane group at the base size: 22.8 us per call)
 }
 
 int k_qk_norm_bwd(hipStream_t s, const bf16_t* x, long ldx, const float* x_f32, int H, const bf16_t* dy, long lddy, const float* dy_f32,

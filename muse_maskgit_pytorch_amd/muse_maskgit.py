@@ -835,7 +835,7 @@ class MaskGit(nn.Module):
                  *, text_embeds: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None, noise_kind: str = 'philox',
                  seed: Optional[int] = None, row_offset: int = 0, return_ids: bool = False, trace: Optional[dict] = None,
                  critic_noise: Optional[torch.Tensor] = None, neg_text_embeds: Optional[torch.Tensor] = None, fused_sampling: bool = True,
-                 stepwise: bool = False):
+                 stepwise: bool = False, loop_end_event=None):
         """mmp.py:491-621.  Keyword-only extras (not in the reference): `text_embeds` bypasses the T5 call,
         `noise` (+ `noise_kind` 'gumbel' | 'uniform') injects the per-step noise tensor [T,B,n,V] for parity runs,
         `seed` / `row_offset` key the on-device Philox stream (row_offset = global index of this shard's first
@@ -968,21 +968,29 @@ class MaskGit(nn.Module):
         else:
             p.flags |= L.MM_GEN_NO_FUSED_SAMPLING
         L.check(L.lib().mm_generate(h.ptr, L.stream(), C.byref(p), L.ptr(self._gen_ws), self._gen_ws.numel()), 'mm_generate')
+        want_images = exists(self.vae) and (return_ids is False or return_ids == 'both')      # return_ids='both': (ids, images)
+        if exists(loop_end_event):
+            loop_end_event.record()                                            # (bench.py: the decode loop's end on the stream, before the VAE decode is enqueued)
+        images = None
         if deferred:
             self.fused_status = status
             # a captured graph replays reads of every tensor this call handed to the library: they stay alive with the module, not with this frame
             self._deferred_keep = (keep, te, cond_ids, noise, ids, scores, trace, self._gen_ws, getattr(self, '_critic_ws', None))
         elif status is not None:
+            if want_images:      # the VAE decode is LAUNCHED before the flag is read: the one host synchronisation of generate() then waits behind it, not in front
+                images = self.vae.decode_from_ids(ids.reshape(B, fmap, fmap))
             st = status.tolist()
             self.fused_row_fallbacks += st[1]
         if not deferred and status is not None and st[0] != 0:
             self.fused_sampling_fallbacks += 1
+            images = None                                                      # (decoded from ids that are being replaced)
             p.flags, p.status = p.flags | L.MM_GEN_NO_FUSED_SAMPLING, None
             L.check(L.lib().mm_generate(h.ptr, L.stream(), C.byref(p), L.ptr(self._gen_ws), self._gen_ws.numel()), 'mm_generate')
         ids = ids.reshape(B, fmap, fmap)                                       # mmp.py:615
-        if return_ids or not exists(self.vae):
+        if not want_images:
             return ids
-        return self.vae.decode_from_ids(ids)                                   # mmp.py:620
+        images = images if images is not None else self.vae.decode_from_ids(ids)  # mmp.py:620
+        return (ids, images) if return_ids == 'both' else images
 
     def _generate_stepwise(self, texts, cond_images, fmap_size, temperature, thres, can_remask, use_critic, timesteps, cond_scale,
                            critic_noise_scale, text_embeds, noise, noise_kind, seed, row_offset, return_ids, trace, critic_noise=None,
@@ -1055,6 +1063,8 @@ class MaskGit(nn.Module):
                 trace.setdefault('ids', []).append(ids.clone())
                 trace.setdefault('scores', []).append(scores.clone())
         ids = ids.reshape(B, fmap, fmap)
+        if return_ids == 'both' and exists(self.vae):
+            return ids, self.vae.decode_from_ids(ids)
         if return_ids or not exists(self.vae):
             return ids
         return self.vae.decode_from_ids(ids)
