@@ -1,20 +1,33 @@
 #!/bin/bash
 # Collects the round's committed measurements on a GPU box (run from the repo root through gpurun):
-#   kernel trace + stats, two PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs, no other trace domains), their summary, then the
-#   plain bench line (which reads the fresh summary for roofline.traffic).  Outputs land in gpurun_out/final/.
+#   kernel trace + stats, two HBM PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs, no other trace domains), two SQ passes
+#   (matrix pipe + LDS conflicts; wait / issue cycles), their summaries, then the plain bench lines (which read the fresh PMC summary
+#   for roofline.traffic).  Outputs land in gpurun_out/final/ under the names they are committed with in profiles/.
+#   usage: [ROUND=r04] [FULL=1] tools/collect_profiles.sh        FULL=1 adds the c4 / c5 / c5 --fp8 / --train lines
 set -u
 ROOT=$PWD
+R=${ROUND:-r04}
 OUT=$ROOT/gpurun_out/final
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/p_k -o bench --output-format csv -- python $ROOT/bench.py --steps 2 --warmup 1 --no-parity-tier --no-cpu-baseline > $OUT/prof_k.log 2>&1
-timeout 400 rocprofv3 --pmc FETCH_SIZE -d $OUT/p_f -o bench --output-format csv -- python $ROOT/bench.py --steps 2 --warmup 1 --no-parity-tier --no-cpu-baseline > $OUT/prof_f.log 2>&1
-timeout 400 rocprofv3 --pmc WRITE_SIZE -d $OUT/p_w -o bench --output-format csv -- python $ROOT/bench.py --steps 2 --warmup 1 --no-parity-tier --no-cpu-baseline > $OUT/prof_w.log 2>&1
+BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-parity-tier --no-cpu-baseline"
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/p_k -o bench --output-format csv -- $BENCH > $OUT/prof_k.log 2>&1
+timeout 400 rocprofv3 --pmc FETCH_SIZE -d $OUT/p_f -o bench --output-format csv -- $BENCH > $OUT/prof_f.log 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE -d $OUT/p_w -o bench --output-format csv -- $BENCH > $OUT/prof_w.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/p_s1 -o bench --output-format csv -- $BENCH > $OUT/prof_s1.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM -d $OUT/p_s2 -o bench --output-format csv -- $BENCH > $OUT/prof_s2.log 2>&1
 cd $ROOT
-python tools/summarize_profile.py $OUT/p_k $OUT/p_f $OUT/p_w $OUT/r03_bench_b32 3 > $OUT/summary.txt 2>&1
-cp $OUT/r03_bench_b32_pmc_summary.json profiles/ 2>/dev/null
-rm -f $OUT/p_k/bench_kernel_trace.csv $OUT/p_f/bench_counter_collection.csv $OUT/p_w/bench_counter_collection.csv      # large raw files
-timeout 300 python bench.py --steps 10 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
-MM_BENCH_FORCE_DIST=1 timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 2 --warmup 1 > $OUT/bench_dist.json 2> $OUT/bench_dist.err
-tail -n 20 $OUT/summary.txt
-tail -c 600 $OUT/bench.json; echo; tail -c 300 $OUT/bench_dist.json
+python tools/summarize_profile.py $OUT/p_k $OUT/p_f $OUT/p_w $OUT/${R}_bench_b32 3 > $OUT/${R}_bench_b32_summary.txt 2>&1
+python tools/summarize_profile.py --sq $OUT/p_s1 $OUT/p_s2 $OUT/${R}_bench_b32_sq_counters.json >> $OUT/${R}_bench_b32_summary.txt 2>&1
+cp $OUT/${R}_bench_b32_pmc_summary.json profiles/ 2>/dev/null
+rm -f $OUT/p_k/bench_kernel_trace.csv $OUT/p_*/bench_counter_collection.csv      # large raw files
+timeout 400 python bench.py --steps 10 --warmup 2 > $OUT/${R}_bench_b32.json 2> $OUT/bench.err
+MM_BENCH_FORCE_DIST=1 timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 2 --warmup 1 --no-parity-tier --no-cpu-baseline > $OUT/${R}_bench_b32_rccl_world1.json 2> $OUT/bench_dist.err
+if [ "${FULL:-0}" = 1 ]; then
+  timeout 200 python bench.py --config c4 --batch 8 --steps 3 --warmup 1 --no-parity-tier --no-cpu-baseline > $OUT/${R}_bench_c4_b8.json 2> $OUT/bench_c4.err
+  timeout 200 python bench.py --config c5 --steps 5 --warmup 2 --no-parity-tier --no-cpu-baseline > $OUT/${R}_bench_c5_b32.json 2> $OUT/bench_c5.err
+  timeout 200 python bench.py --config c5 --fp8 --steps 5 --warmup 2 --no-parity-tier --no-cpu-baseline > $OUT/${R}_bench_c5_b32_fp8.json 2> $OUT/bench_c5f.err
+  timeout 200 python bench.py --train --steps 10 --warmup 3 > $OUT/${R}_bench_train_b32.json 2> $OUT/bench_train.err
+fi
+tail -n 45 $OUT/${R}_bench_b32_summary.txt
+for f in $OUT/${R}_bench_*.json; do echo "== $f"; tail -c 500 $f; echo; done
