@@ -334,7 +334,7 @@ def train_bench(args, dev, rank, world, dist):
         ex = 3.0 * lin + 4.5 * att
         _RECORD_OUT.write(json.dumps({
             'executed_tflops': ex / sec / 1e12, 'executed_mfma_frac': ex / sec / 1e12 / PEAK_BF16_TFLOPS, 'labelled_rows_last_step': R,
-            'driver': 'mm_train_step (one C call per step: forward + loss + backward, csrc/train_step.hip)' if c_step else 'training.py (operator by operator over the C ABI)',
+            'driver': 'mm_train_step (one C call per step: forward + loss + backward; dependent chain on the caller\'s stream, parameter preparation and the leaves of the backward -- dW GEMMs, reductions -- on a second stream; csrc/train_step.hip)' if c_step else 'training.py (operator by operator over the C ABI)',
             'metric': 'training tokens/sec (C2 base transformer: MaskGit.forward + backward + AdamW)', 'value': world * B * n / sec, 'unit': 'tokens/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': sec * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16 (fp32 master weights, fp32 gradients)', 'data': 'synthetic',

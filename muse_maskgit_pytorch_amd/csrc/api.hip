@@ -1,5 +1,6 @@
 // C-ABI layer: argument validation + error plumbing around the kernel launchers.  See include/muse_hip.h.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -302,7 +303,8 @@ int mm_gemm_wgrad_splits(int M, int N, int K) {
     const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
     const int kt = K / 64;
     int s = 1;
-    while (tiles * s < 384 && (kt % (s * 2)) == 0 && kt / (s * 2) >= 8) s *= 2;      // fill the 256 CUs, keep >= 512 of K per workgroup
+    static const long fill = getenv("MM_WGRAD_FILL") ? atol(getenv("MM_WGRAD_FILL")) : 256;      // (384: 15.0-15.5 ms per C2 training step, 256: 14.3-15.1, 192: 15.0-15.6; same box)
+    while (tiles * s < fill && (kt % (s * 2)) == 0 && kt / (s * 2) >= 8) s *= 2;      // fill the 256 CUs, keep >= 512 of K per workgroup
     return s;
 }
 

@@ -138,10 +138,12 @@ int k_transpose_bf16(hipStream_t s, const bf16_t* in, long rows, long cols, long
 int k_colsum(hipStream_t s, const float* part, int nparts, long D, float* out);
 long k_ln_bwd_workspace_floats(int rows, int D);
 int k_layernorm_bwd(hipStream_t s, const float* x, long ldx, const bf16_t* dy, long lddy, const float* gamma, const int32_t* row_index,
-                    int rows, int D, float* dx, long lddx, int accumulate, float* dgamma, float* ws);
+                    int rows, int D, float* dx, long lddx, int accumulate, float* dgamma, float* ws, bf16_t* dxb = nullptr);
+int k_ln_bwd_blocks(int rows);
 int k_geglu_ln_bwd(hipStream_t s, const bf16_t* h, long ldh, const bf16_t* dz, long lddz, const float* gamma, int rows, int F, int Fp,
                    bf16_t* dh, long lddh, float* dgamma, float* ws);
-int k_ce_bwd(hipStream_t s, const float* logits, long ld, int R, int V, const int64_t* labels, float scale, bf16_t* dl, long ldd);
+int k_ce_bwd(hipStream_t s, const float* logits, long ld, int R, int V, const int64_t* labels, float scale, bf16_t* dl, long ldd, float* row_loss = nullptr);
+int k_ce_finish(hipStream_t s, const float* row_loss, int R, float* out);      // sampling.hip: mean of the row losses >= 0
 int k_bce_head_bwd(hipStream_t s, const bf16_t* e, long lde, const float* x, const float* y, const float* w, int rows, int D, bf16_t* de,
                    long ldde, float* dw, float* ws);
 int k_embed_bwd(hipStream_t s, const int64_t* ids, int B, int n, int D, const float* dx, float* dtoken, float* dpos);

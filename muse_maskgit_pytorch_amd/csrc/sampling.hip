@@ -628,6 +628,11 @@ int k_ce_loss(hipStream_t s, const float* logits, long ld, int R, int V, const i
     return mm_check_launch("ce_finish_kernel");
 }
 
+int k_ce_finish(hipStream_t s, const float* row_loss, int R, float* out) {
+    hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, s, row_loss, R, out);
+    return mm_check_launch("ce_finish_kernel");
+}
+
 int k_bce_loss(hipStream_t s, const float* x, const float* y, int n, float* out) {
     if (n <= 0) return mm_set_error(MM_ERR_SHAPE, "bce_loss: no elements");
     hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(256), 0, s, x, y, n, out);

@@ -62,7 +62,7 @@ template <int NIT>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, long ldx, const bf16_t* __restrict__ dy, long lddy,
                                                             const float* __restrict__ gamma, const int32_t* __restrict__ row_index,
                                                             int rows, int D, float* __restrict__ dx, long lddx, int accumulate,
-                                                            float* __restrict__ dgamma_part) {
+                                                            float* __restrict__ dgamma_part, bf16_t* __restrict__ dxb) {
     __shared__ float red[4][64 * 4 * NIT];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int nvec = D >> 2;
@@ -138,6 +138,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                     o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
                 }
                 *reinterpret_cast<float4*>(dxr + c * 4) = o;
+                // (mm_train_step) the bf16 image of the updated gradient row -- the operand of the GEMMs that follow -- in the same pass: the values
+                // f32_to_bf16_kernel would produce from dx
+                if (dxb) *reinterpret_cast<uint2*>(dxb + src * (long)D + c * 4) = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
             }
         }
     }
@@ -175,6 +178,36 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
     red[rg][threadIdx.x & 63] = s0 + s1;
     __syncthreads();
     if (rg == 0 && c < D) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// The same sums in the same association for WIDE inputs (the split-K slabs of a weight gradient: D = N x K, a handful of parts): one thread owns 4 adjacent
+// columns and all 8 accumulators of colsum_kernel's tree -- stream rg = p mod 4, accumulator (p / 4) mod 2 -- so every load of a column quad is in flight
+// at once, 16 bytes per lane; out = ((s00 + s01) + (s10 + s11)) + ((s20 + s21) + (s30 + s31)) exactly as above.
+__global__ __launch_bounds__(256) void colsum_wide_kernel(const float* __restrict__ part, int nparts, long D, float* __restrict__ out) {
+    const long c = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= D) return;
+    float4 acc[4][2];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) acc[rg][0] = acc[rg][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p0 = 0; p0 < nparts; p0 += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p0 + j < nparts ? *reinterpret_cast<const float4*>(part + (long)(p0 + j) * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (p0 + j < nparts) {      // (a missing part adds nothing, as in colsum_kernel: no "+ 0" that could turn -0 into +0)
+                float4& a = acc[j & 3][j >> 2];
+                a.x += v[j].x; a.y += v[j].y; a.z += v[j].z; a.w += v[j].w;
+            }
+        }
+    }
+    float4 r[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) r[rg] = make_float4(acc[rg][0].x + acc[rg][1].x, acc[rg][0].y + acc[rg][1].y, acc[rg][0].z + acc[rg][1].z, acc[rg][0].w + acc[rg][1].w);
+    float4 o;
+    o.x = (r[0].x + r[1].x) + (r[2].x + r[3].x); o.y = (r[0].y + r[1].y) + (r[2].y + r[3].y);
+    o.z = (r[0].z + r[1].z) + (r[2].z + r[3].z); o.w = (r[0].w + r[1].w) + (r[2].w + r[3].w);
+    *reinterpret_cast<float4*>(out + c) = o;
 }
 
 // ------------------------------------------------------------------------------------------------ GEGLU + inner LayerNorm backward
@@ -307,7 +340,7 @@ __global__ __launch_bounds__(256) void geglu_ln_bwd_kernel(const bf16_t* __restr
 // ------------------------------------------------------------------------------------------------ cross-entropy backward
 // loss = mean over R rows of (logsumexp(l_r) - l_r[label_r]);  dl[r][v] = (softmax(l_r)[v] - [v == label_r]) / R, written in bf16.
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, long ld, int V, const int64_t* __restrict__ labels,
-                                                     float scale, bf16_t* __restrict__ dl, long ldd) {
+                                                     float scale, bf16_t* __restrict__ dl, long ldd, float* __restrict__ row_loss) {
     __shared__ float sm[4], ss[4];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const float* lr = logits + (size_t)row * ld;
@@ -335,6 +368,9 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
     }
     const float inv = scale / S;
     const int lab = (int)labels[row];
+    // (mm_train_step) the row's loss from the same (M, S): what ce_rows_kernel (sampling.hip) computes with the same operations, so the forward pass over
+    // the logits is not needed; -1 marks a row without a valid label for ce_finish_kernel
+    if (row_loss && tid == 0) row_loss[row] = (lab >= 0 && lab < V) ? (M + logf(S)) - lr[lab] : -1.f;
     bf16_t* dr = dl + (size_t)row * ldd;
     for (int i = tid * 4; i < V; i += 256 * 4) {      // second sweep: the row (<= 256 KiB) is L2-resident
         const float4 x = *reinterpret_cast<const float4*>(lr + i);
@@ -358,13 +394,16 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(int B, int n, int D,
 }
 // one workgroup per token row r: if r is the FIRST row with its id, it sums the gradient rows of every row with that id in ascending order and
 // is the only writer of dtoken[id]; any other workgroup leaves after the look-back.  Matches are found 256 rows at a time (one ballot per wave).
-template <int NC>      // columns per thread: D <= 256 * NC
+// blockIdx.y selects a slab of 256 * NC columns: the chain of additions per column is serial (the mask id owns about half of all rows), so the columns are
+// spread over as many workgroups as there are 256-column slabs (NC = 1: 32 rows' loads in flight per lane) -- the same sums in the same order.
+template <int NC>      // columns per thread: a workgroup covers 256 * NC columns
 __global__ __launch_bounds__(256) void embed_token_bwd_kernel(const int64_t* __restrict__ ids, int R, int D, const float* __restrict__ dx,
                                                               float* __restrict__ dtoken) {
     constexpr int U = 32 / NC;      // matching rows per trip: U * NC loads in flight per lane
     __shared__ unsigned long long masks[4];
     __shared__ int seen;
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int c0 = blockIdx.y * 256 * NC;
     const int64_t id = ids[r];
     if (tid == 0) seen = 0;
     __syncthreads();
@@ -396,7 +435,7 @@ __global__ __launch_bounds__(256) void embed_token_bwd_kernel(const int64_t* __r
                 for (int u = 0; u < U; ++u)
 #pragma unroll
                     for (int i = 0; i < NC; ++i)
-                        v[u][i] = (jj[u] >= 0 && tid + i * 256 < D) ? dx[(long)jj[u] * D + tid + i * 256] : 0.f;
+                        v[u][i] = (jj[u] >= 0 && c0 + tid + i * 256 < D) ? dx[(long)jj[u] * D + c0 + tid + i * 256] : 0.f;
 #pragma unroll
                 for (int u = 0; u < U; ++u)
                     if (jj[u] >= 0) {
@@ -409,7 +448,7 @@ __global__ __launch_bounds__(256) void embed_token_bwd_kernel(const int64_t* __r
     }
 #pragma unroll
     for (int i = 0; i < NC; ++i)
-        if (tid + i * 256 < D) dtoken[id * D + tid + i * 256] += acc[i];
+        if (c0 + tid + i * 256 < D) dtoken[id * D + c0 + tid + i * 256] += acc[i];
 }
 
 // ------------------------------------------------------------------------------------------------ BCE head backward (TokenCritic)
@@ -502,23 +541,31 @@ int k_transpose_bf16(hipStream_t s, const bf16_t* in, long rows, long cols, long
 
 int k_colsum(hipStream_t s, const float* part, int nparts, long D, float* out) {
     if (D <= 0) return MM_OK;
+    if (D >= 65536 && D % 4 == 0 && (((uintptr_t)part | (uintptr_t)out) & 15) == 0) {
+        hipLaunchKernelGGL(colsum_wide_kernel, dim3((unsigned)((D / 4 + 255) / 256)), dim3(256), 0, s, part, nparts, D, out);
+        return mm_check_launch("colsum_wide_kernel");
+    }
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((D + 63) / 64)), dim3(256), 0, s, part, nparts, D, out);
     return mm_check_launch("colsum_kernel");
 }
 
 long k_ln_bwd_workspace_floats(int rows, int D) { return (long)((rows + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS)) * D; }
 
+// dgamma == nullptr: only the per-workgroup partials are left in ws ([k_ln_bwd_blocks(rows)][D]) -- the caller reduces them (k_colsum) where and when it likes;
+// dxb: optional bf16 image [rows of x][D] of the updated dx rows
+int k_ln_bwd_blocks(int rows) { return (rows + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS); }
+
 int k_layernorm_bwd(hipStream_t s, const float* x, long ldx, const bf16_t* dy, long lddy, const float* gamma, const int32_t* row_index,
-                    int rows, int D, float* dx, long lddx, int accumulate, float* dgamma, float* ws) {
+                    int rows, int D, float* dx, long lddx, int accumulate, float* dgamma, float* ws, bf16_t* dxb) {
     if (rows <= 0) return MM_OK;
     if (D % 4 || D > 2048 || (ldx % 4) || (lddy % 4) || (lddx % 4)) return mm_set_error(MM_ERR_SHAPE, "layernorm_bwd: dim multiple of 4, <= 2048; strides multiples of 4");
     const int blocks = (rows + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS);
     const int nit = (D / 4 + 63) / 64;
-    if (nit <= 2) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(256), 0, s, x, ldx, dy, lddy, gamma, row_index, rows, D, dx, lddx, accumulate, ws);
-    else if (nit <= 4) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(blocks), dim3(256), 0, s, x, ldx, dy, lddy, gamma, row_index, rows, D, dx, lddx, accumulate, ws);
-    else hipLaunchKernelGGL(layernorm_bwd_kernel<8>, dim3(blocks), dim3(256), 0, s, x, ldx, dy, lddy, gamma, row_index, rows, D, dx, lddx, accumulate, ws);
+    if (nit <= 2) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(256), 0, s, x, ldx, dy, lddy, gamma, row_index, rows, D, dx, lddx, accumulate, ws, dxb);
+    else if (nit <= 4) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(blocks), dim3(256), 0, s, x, ldx, dy, lddy, gamma, row_index, rows, D, dx, lddx, accumulate, ws, dxb);
+    else hipLaunchKernelGGL(layernorm_bwd_kernel<8>, dim3(blocks), dim3(256), 0, s, x, ldx, dy, lddy, gamma, row_index, rows, D, dx, lddx, accumulate, ws, dxb);
     int rc = mm_check_launch("layernorm_bwd_kernel");
-    if (rc) return rc;
+    if (rc || !dgamma) return rc;
     hipLaunchKernelGGL(colsum_kernel, dim3((D + 63) / 64), dim3(256), 0, s, ws, blocks, (long)D, dgamma);
     return mm_check_launch("colsum_kernel");
 }
@@ -533,15 +580,15 @@ int k_geglu_ln_bwd(hipStream_t s, const bf16_t* h, long ldh, const bf16_t* dz, l
     else if (nit <= 6) hipLaunchKernelGGL(geglu_ln_bwd_kernel<6>, dim3(blocks), dim3(256), 0, s, h, ldh, dz, lddz, gamma, rows, F, Fp, dh, lddh, ws);
     else return mm_set_error(MM_ERR_SHAPE, "geglu_ln_bwd: padded inner width above 3072 is not built");
     int rc = mm_check_launch("geglu_ln_bwd_kernel");
-    if (rc) return rc;
+    if (rc || !dgamma) return rc;      // (dgamma == nullptr: partials only, as k_layernorm_bwd)
     hipLaunchKernelGGL(colsum_kernel, dim3((Fp + 63) / 64), dim3(256), 0, s, ws, blocks, (long)Fp, dgamma);
     return mm_check_launch("colsum_kernel");
 }
 
-int k_ce_bwd(hipStream_t s, const float* logits, long ld, int R, int V, const int64_t* labels, float scale, bf16_t* dl, long ldd) {
+int k_ce_bwd(hipStream_t s, const float* logits, long ld, int R, int V, const int64_t* labels, float scale, bf16_t* dl, long ldd, float* row_loss) {
     if (R <= 0) return MM_OK;
     if (V % 4 || (ld % 4) || (ldd % 4)) return mm_set_error(MM_ERR_SHAPE, "ce_bwd: V and strides must be multiples of 4");
-    hipLaunchKernelGGL(ce_bwd_kernel, dim3(R), dim3(256), 0, s, logits, ld, V, labels, scale, dl, ldd);
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3(R), dim3(256), 0, s, logits, ld, V, labels, scale, dl, ldd, row_loss);
     return mm_check_launch("ce_bwd_kernel");
 }
 
@@ -576,10 +623,7 @@ int k_embed_bwd(hipStream_t s, const int64_t* ids, int B, int n, int D, const fl
     hipLaunchKernelGGL(embed_pos_bwd_kernel, dim3(n), dim3(256), 0, s, B, n, D, dx, dpos);
     int rc = mm_check_launch("embed_pos_bwd_kernel");
     if (rc) return rc;
-    if (D <= 256) hipLaunchKernelGGL(embed_token_bwd_kernel<1>, dim3(B * n), dim3(256), 0, s, ids, B * n, D, dx, dtoken);
-    else if (D <= 512) hipLaunchKernelGGL(embed_token_bwd_kernel<2>, dim3(B * n), dim3(256), 0, s, ids, B * n, D, dx, dtoken);
-    else if (D <= 1024) hipLaunchKernelGGL(embed_token_bwd_kernel<4>, dim3(B * n), dim3(256), 0, s, ids, B * n, D, dx, dtoken);
-    else hipLaunchKernelGGL(embed_token_bwd_kernel<8>, dim3(B * n), dim3(256), 0, s, ids, B * n, D, dx, dtoken);
+    hipLaunchKernelGGL(embed_token_bwd_kernel<1>, dim3(B * n, (D + 255) / 256), dim3(256), 0, s, ids, B * n, D, dx, dtoken);
     return mm_check_launch("embed_token_bwd_kernel");
 }
 

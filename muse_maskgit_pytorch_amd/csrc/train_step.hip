@@ -1,11 +1,25 @@
 // mm_train_step: the training step of the transformer -- forward with saved activations, cross-entropy on the labelled rows, and the whole hand-written
-// backward -- as ONE C call on one stream: no allocation, no host synchronisation, no Python between the ~1150 launches (the same operators, in the same
-// order, as the operator-by-operator driver in training.py, so the loss and every gradient are bit-identical to it: tests/test_gpu_train_step.py).
+// backward -- as ONE C call: no allocation, no host synchronisation, no Python between the ~1100 launches.  The operators and their arithmetic are those of
+// the operator-by-operator driver in training.py, so the loss and every gradient are bit-identical to it (tests/test_gpu_train_step.py).
 // Reference: MaskGit.forward (muse_maskgit_pytorch.py:623-741) differentiating Transformer.forward (:279-348) with autograd.
 // Scope of the C entry: the generator's cross-entropy path (token ids in, labels at the masked rows), optional text projection; dim_head 64 and
 // n in {64, 128, 256} (the attention backward's query blocks).  Self-conditioning, conditioning ids, the critics' BCE heads and longer sequences stay on
 // training.py's driver (muse_maskgit.py picks).  Linear layers: dX = dY W and dW = dY^T X are NT GEMMs on transposed bf16 copies, as there.
+//
+// Two streams.  The caller's stream carries the dependent chain only: forward, loss, and of the backward what the next operator needs (dX GEMMs, attention /
+// LayerNorm / GEGLU backward).  Everything else is enqueued on a second stream of the library, forked from and joined to the caller's stream with events
+// inside this call: (1) what depends on the parameters alone -- their bf16 operand copies and the transposes the dX GEMMs read -- runs ahead of the forward;
+// (2) the transposes of a layer's saved activations follow that layer's forward; (3) the LEAVES of the backward -- every dW GEMM with its gradient-row
+// transpose, split-K reduction and copies, and the reductions of the dgamma / scale / null key-value partials: nothing reads them before the call returns --
+// follow the operator that produced their input.  Buffers a leaf reads are per layer (the chain moves on while the leaf is pending).  Same kernels, same
+// inputs, same values; MM_TRAIN_SIDE=0 keeps everything on the caller's stream (A/B: 14.7-15.1 vs 15.7-16.3 ms per C2 step, same box).
+// Three launches of the driver are fused away here with identical results: the bf16 image of the residual-stream gradient is written by the LayerNorm backward
+// that produced it (no f32->bf16 pass), the cross-entropy value comes out of its backward kernel (no forward pass over the logits), and the head's
+// dX = dlogits . W contracts over the vocabulary with split-K (training.py does the same: _dgrad_long_k).
+#include <stdlib.h>
 #include <string.h>
+
+#include <vector>
 
 #include "common.h"
 #include "muse_hip_internal.h"
@@ -42,6 +56,11 @@ struct LayerBufs {
     bf16_t *u, *qkv, *o, *u2, *q2, *kv2, *o2, *u3, *h, *z; // saved activations
     bf16_t *wqkv, *wo, *wq2, *wkv2, *wo2, *w1p, *w2p;      // bf16 operand copies of this step's parameters
     float *g2p, *b2p;                                      // LayerNorm(inner) gain / bias padded to Fp
+    bf16_t *twqkv, *two, *twq2, *twkv2, *two2, *tw1p, *tw2p;  // transposed weights  [K][pad64(N)]  (B operand of dX = dY W)
+    bf16_t *tu, *to, *tu2, *to2, *tu3, *tz;                // transposed saved activations [K][M]  (B operand of dW = dY^T X)
+    float *part[2][3], *pair[2], *dnull[2], *dnv[2];       // leaf-reduction inputs of the cross- (0) / self- (1) attention backward, read by the side stream
+    float *lnw[3], *glw;                                   // dgamma partials of the three LayerNorm(dim) backwards / of the GEGLU + LayerNorm(inner) backward
+    bf16_t *dy[3], *dh, *dq2, *dkv2, *dqkv;                // this layer's gradient rows (A operand of its dW GEMMs, which run on the side stream while the chain moves on)
 };
 
 struct Bufs {
@@ -50,8 +69,12 @@ struct Bufs {
     bf16_t *tok_b, *pos_b, *te_b, *wtp, *cx, *wl, *e;
     float *logits, *rowloss;
     // backward scratch
-    float *dres, *gtmp, *wg_ws, *ln_ws, *part, *dnk, *dnv, *dnull, *pair, *dcx[2];
-    bf16_t *dl, *de, *dy, *dz, *dh, *du, *dob, *dqn, *dkn, *dq2, *dkv2, *dqkv, *dcxb, *tA, *tB, *tW;
+    float *dres, *gtmp, *wg_ws, *ln_ws, *dnk, *dcx[2];
+    bf16_t *dl, *de, *dz, *du, *dob, *dqn, *dkn, *dcxb, *tA, *tB, *tW;
+    float *hd_ws, *de32;                                   // the head's split-K dX: slabs, fp32 sum
+    int hd_splits;
+    float* gtmp2;                                          // LayerNorm(inner) gain gradient padded to Fp (caller's stream; gtmp belongs to the dW GEMMs)
+    bf16_t *twl, *tcx, *w2tmp;                             // transposed to_logits weight [D][V], transposed context [D][Mcp], dense bf16 w2 before its padding
 };
 
 struct Dims { int B, n, L, R, M, D, H, I, F, Fp, V, td, Mc, depth; };
@@ -68,6 +91,19 @@ void carve(Arena& A, const mm_train_desc& d, const Dims& q, Bufs& b, LayerBufs* 
         y.wqkv = A.take<bf16_t>(3 * I * D); y.wo = A.take<bf16_t>(D * I); y.wq2 = A.take<bf16_t>(I * D); y.wkv2 = A.take<bf16_t>(2 * I * D);
         y.wo2 = A.take<bf16_t>(D * I); y.w1p = A.take<bf16_t>(2 * Fp * D); y.w2p = A.take<bf16_t>(D * Fp);
         y.g2p = A.take<float>(Fp); y.b2p = A.take<float>(Fp);
+        y.twqkv = A.take<bf16_t>(D * (size_t)pad64((int)(3 * I))); y.two = A.take<bf16_t>(I * (size_t)pad64((int)D)); y.twq2 = A.take<bf16_t>(D * (size_t)pad64((int)I));
+        y.twkv2 = A.take<bf16_t>(D * (size_t)pad64((int)(2 * I))); y.two2 = A.take<bf16_t>(I * (size_t)pad64((int)D));
+        y.tw1p = A.take<bf16_t>(D * (size_t)pad64((int)(2 * Fp))); y.tw2p = A.take<bf16_t>(Fp * (size_t)pad64((int)D));
+        y.tu = A.take<bf16_t>(D * M); y.to = A.take<bf16_t>(I * M); y.tu2 = A.take<bf16_t>(D * M); y.to2 = A.take<bf16_t>(I * M); y.tu3 = A.take<bf16_t>(D * M); y.tz = A.take<bf16_t>(Fp * M);
+        for (int i = 0; i < 3; ++i) y.dy[i] = A.take<bf16_t>(M * D);
+        for (int i = 0; i < 3; ++i) y.lnw[i] = A.take<float>((size_t)mm_ln_bwd_workspace_floats((int)M, (int)D));
+        y.glw = A.take<float>((size_t)mm_ln_bwd_workspace_floats((int)M, (int)Fp));
+        y.dh = A.take<bf16_t>(M * 2 * Fp); y.dq2 = A.take<bf16_t>(M * I); y.dkv2 = A.take<bf16_t>(Mc * 2 * I); y.dqkv = A.take<bf16_t>(M * 3 * I);
+        const size_t nvec_l = (M > Mc ? M : Mc) * q.H;
+        for (int a = 0; a < 2; ++a) {
+            for (int i = 0; i < 3; ++i) y.part[a][i] = A.take<float>((size_t)mm_qk_norm_bwd_blocks((int64_t)nvec_l) * 64 + 128);
+            y.pair[a] = A.take<float>(128); y.dnull[a] = A.take<float>((size_t)q.B * q.H * 64); y.dnv[a] = A.take<float>((size_t)q.B * q.H * 64);
+        }
     }
     b.xL = A.take<float>(M * D);
     b.tok_b = A.take<bf16_t>((size_t)d.vocab_rows * D); b.pos_b = A.take<bf16_t>((size_t)d.seq_len * D);
@@ -78,22 +114,31 @@ void carve(Arena& A, const mm_train_desc& d, const Dims& q, Bufs& b, LayerBufs* 
     b.dres = A.take<float>(M * D);
     size_t gmax = D * Fp; if (2 * Fp * D > gmax) gmax = 2 * Fp * D; if (3 * I * D > gmax) gmax = 3 * I * D;
     b.gtmp = A.take<float>(gmax);
-    b.wg_ws = A.take<float>((size_t)384 * 128 * 128);                       // split-K slabs: mm_gemm_wgrad_splits keeps tiles x splits < 384
+    // split-K slabs of the dW GEMMs: splits x N_ x K_ floats, the largest over the shapes wgrad() is called with below
+    auto slabs = [](long N_, long K_, long rows) -> size_t {
+        const int s_ = (K_ % 4 == 0) ? mm_gemm_wgrad_splits((int)N_, (int)K_, pad64((int)rows)) : 1;
+        return s_ > 1 ? (size_t)s_ * N_ * K_ : 0;
+    };
+    size_t wmax = slabs(V, D, R);
+    for (size_t c : {slabs(D, Fp, M), slabs(2 * Fp, D, M), slabs(D, I, M), slabs(I, D, M), slabs(2 * I, D, Mc), slabs(3 * I, D, M), slabs(D, q.td, Mc)}) wmax = c > wmax ? c : wmax;
+    b.wg_ws = A.take<float>(wmax + 64);
+    // the head's dX = dl W_logits contracts over the vocabulary into only R/128 x D/128 tiles: split-K as well (slabs + fp32 sum on the caller's stream)
+    b.hd_splits = mm_gemm_wgrad_splits((int)R, (int)D, (int)V);
+    b.hd_ws = A.take<float>(b.hd_splits > 1 ? (size_t)b.hd_splits * R * D : 0);
+    b.de32 = A.take<float>(b.hd_splits > 1 ? R * D : 0);
     size_t lnw = (size_t)mm_ln_bwd_workspace_floats((int)M, (int)D), lnw2 = (size_t)mm_ln_bwd_workspace_floats((int)M, (int)Fp);
     b.ln_ws = A.take<float>(lnw > lnw2 ? lnw : lnw2);
-    const size_t nvec = (M > Mc ? M : Mc) * q.H;
-    b.part = A.take<float>((size_t)mm_qk_norm_bwd_blocks((int64_t)nvec) * 64 + 128);
-    b.dnk = A.take<float>((size_t)q.B * q.H * 64); b.dnv = A.take<float>((size_t)q.B * q.H * 64); b.dnull = A.take<float>((size_t)q.B * q.H * 64);
-    b.pair = A.take<float>(128);
+    b.dnk = A.take<float>((size_t)q.B * q.H * 64);
     b.dcx[0] = A.take<float>(d.text_proj ? Mc * D : 0); b.dcx[1] = A.take<float>(d.text_proj ? Mc * D : 0); b.dcxb = A.take<bf16_t>(d.text_proj ? Mc * D : 0);
-    b.dl = A.take<bf16_t>(R * V); b.de = A.take<bf16_t>(R * D); b.dy = A.take<bf16_t>(M * D); b.dz = A.take<bf16_t>(M * Fp); b.dh = A.take<bf16_t>(M * 2 * Fp);
+    b.dl = A.take<bf16_t>(R * V); b.de = A.take<bf16_t>(R * D); b.dz = A.take<bf16_t>(M * Fp);
     b.du = A.take<bf16_t>(M * D); b.dob = A.take<bf16_t>(M * I); b.dqn = A.take<bf16_t>(M * I); b.dkn = A.take<bf16_t>((M > Mc ? M : Mc) * I);
-    b.dq2 = A.take<bf16_t>(M * I); b.dkv2 = A.take<bf16_t>(Mc * 2 * I); b.dqkv = A.take<bf16_t>(M * 3 * I);
     // transposed copies: tA = T(gradient rows), tB = T(saved activation rows), tW = T(weight)
     size_t ta = wide * (size_t)M; if (V * Rp > ta) ta = V * Rp; if (2 * I * Mcp > ta) ta = 2 * I * Mcp;
     size_t tb = (Fp > D ? Fp : D) * (size_t)M; if (I * (size_t)M > tb) tb = I * (size_t)M; if (D * Rp > tb) tb = D * Rp; if ((size_t)(q.td > (int)D ? q.td : (int)D) * Mcp > tb) tb = (size_t)(q.td > (int)D ? q.td : (int)D) * Mcp;
     size_t tw = D * V; if (D * wide > tw) tw = D * wide; if (Fp * (size_t)pad64((int)D) > tw) tw = Fp * (size_t)pad64((int)D);
     b.tA = A.take<bf16_t>(ta); b.tB = A.take<bf16_t>(tb); b.tW = A.take<bf16_t>(tw);
+    b.gtmp2 = A.take<float>(Fp);
+    b.twl = A.take<bf16_t>(D * V); b.tcx = A.take<bf16_t>(D * Mcp); b.w2tmp = A.take<bf16_t>(D * (size_t)q.F);
 }
 
 // out [cols][Rp] = x [rows][cols]^T, Rp = rows rounded up to 64, padding columns zero   (training.py _t)
@@ -103,18 +148,60 @@ int tr64(mm_stream_t st, hipStream_t s, const bf16_t* x, long rows, long cols, l
     return mm_transpose_bf16(st, x, rows, cols, ld, out, Rp);
 }
 // dW fp32 [N_][K_] = dY^T X for dY bf16 [rows][N_] (ld ldy), X bf16 [rows][K_] (ld ldx)   (training.py _wgrad)
-int wgrad(mm_stream_t st, hipStream_t s, const Bufs& b, const bf16_t* dy, long ldy, int N_, const bf16_t* x, long ldx, int K_, long rows, float* out) {
+// xt: the transposed activation [K_][Rp] when the side stream has already made it (else nullptr: made here into tB)
+bool g_skip_leaves = false;
+int wgrad(mm_stream_t st, hipStream_t s, const Bufs& b, const bf16_t* dy, long ldy, int N_, const bf16_t* x, long ldx, int K_, long rows, float* out, const bf16_t* xt = nullptr) {
+    if (g_skip_leaves) return MM_OK;
     RC(tr64(st, s, dy, rows, N_, ldy, b.tA));
-    RC(tr64(st, s, x, rows, K_, ldx, b.tB));
+    if (!xt) RC(tr64(st, s, x, rows, K_, ldx, b.tB));
+    const bf16_t* tB = xt ? xt : b.tB;
     const int Rp = pad64((int)rows);
     const int splits = (K_ % 4 == 0) ? mm_gemm_wgrad_splits(N_, K_, Rp) : 1;
-    if (splits <= 1) return mm_gemm_bf16(st, b.tA, Rp, b.tB, Rp, N_, K_, Rp, out, K_, 1, nullptr);      // (every K_ here is a multiple of 64: rows of the gradient are dense)
-    return mm_gemm_wgrad(st, b.tA, Rp, b.tB, Rp, N_, K_, Rp, splits, b.wg_ws, out);
+    if (splits <= 1) return mm_gemm_bf16(st, b.tA, Rp, tB, Rp, N_, K_, Rp, out, K_, 1, nullptr);      // (every K_ here is a multiple of 64: rows of the gradient are dense)
+    return mm_gemm_wgrad(st, b.tA, Rp, tB, Rp, N_, K_, Rp, splits, b.wg_ws, out);
 }
 // dX bf16 [rows][K_] = dY W for dY bf16 [rows][N_], W bf16 [N_][K_]   (training.py _dgrad)
-int dgrad(mm_stream_t st, hipStream_t s, const Bufs& b, const bf16_t* dy, long ldy, int N_, const bf16_t* w, int K_, long rows, bf16_t* out, long ldo) {
-    RC(tr64(st, s, w, N_, K_, K_, b.tW));                 // [K_][Np]
-    return mm_gemm_bf16(st, dy, ldy, b.tW, pad64(N_), (int)rows, K_, pad64(N_), out, ldo, 0, nullptr);
+// wt: the transposed weight [K_][Np] when the side stream has already made it (else nullptr: made here into tW)
+int dgrad(mm_stream_t st, hipStream_t s, const Bufs& b, const bf16_t* dy, long ldy, int N_, const bf16_t* w, int K_, long rows, bf16_t* out, long ldo, const bf16_t* wt = nullptr) {
+    if (!wt) RC(tr64(st, s, w, N_, K_, K_, b.tW));       // [K_][Np]
+    return mm_gemm_bf16(st, dy, ldy, wt ? wt : b.tW, pad64(N_), (int)rows, K_, pad64(N_), out, ldo, 0, nullptr);
+}
+
+// The second stream and its events: one per device, created on first use, reused by every step (a step joins the side stream before it returns, so an event is
+// never re-recorded while a wait on its previous record is still pending).
+struct Side {
+    hipStream_t s2 = nullptr;
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+};
+Side g_side[16];
+
+int side_get(Side** out) {
+    int dev = 0;
+    HC(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) return mm_set_error(MM_ERR_UNSUPPORTED, "train_step: device ordinal >= 16");
+    Side& sd = g_side[dev];
+    if (!sd.s2) HC(hipStreamCreateWithFlags(&sd.s2, hipStreamNonBlocking));
+    sd.used = 0;
+    *out = &sd;
+    return MM_OK;
+}
+// mark(): an event recorded at the current tail of `from`; await(): `to` continues only after that point.  Both are no-ops when the step runs on one stream.
+int mark(Side* sd, hipStream_t from, hipEvent_t* out) {
+    *out = nullptr;
+    if (!sd) return MM_OK;
+    if (sd->used == sd->ev.size()) {
+        hipEvent_t e;
+        HC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        sd->ev.push_back(e);
+    }
+    *out = sd->ev[sd->used++];
+    HC(hipEventRecord(*out, from));
+    return MM_OK;
+}
+int await(hipStream_t to, hipEvent_t e) {
+    if (e) HC(hipStreamWaitEvent(to, e, 0));
+    return MM_OK;
 }
 
 }  // namespace
@@ -156,6 +243,70 @@ int mm_train_step(const mm_train_desc* desc, mm_stream_t stream, const int64_t* 
     carve(A, d, q, b, layers);
     const int M = q.M, D = q.D, H = q.H, I = q.I, F = q.F, Fp = q.Fp, V = q.V, td = q.td, Mc = q.Mc;
 
+    // ---- the side stream (see the head of this file); sd == nullptr: one stream, mark / await are no-ops, s2 == s
+    // MM_TRAIN_SIDE=0 (A/B): everything on the caller's stream
+    Side* sd = nullptr;
+    const char* env = getenv("MM_TRAIN_SIDE");
+    if (!(env && env[0] == '0')) RC(side_get(&sd));
+    g_skip_leaves = env && env[0] == 'x';         // TIMING EXPERIMENT ONLY (wrong gradients): how long is the caller's chain alone?
+    hipStream_t s2 = sd ? sd->s2 : s;
+    mm_stream_t stream2 = (mm_stream_t)s2;
+    hipEvent_t e_f;
+    const int lnb = k_ln_bwd_blocks(M);
+    // FORK(): the side stream may read what the caller's stream has produced so far.  What follows a FORK on the side stream are leaves of the step -- the dW
+    // GEMMs (nothing reads a weight gradient before the call returns) and the reductions of dgamma / scale / null key-value partials.
+#define FORK()                      \
+    do {                            \
+        RC(mark(sd, s, &e_f));      \
+        RC(await(s2, e_f));         \
+    } while (0)
+    hipEvent_t e_in, e_w[256], e_wl, e_tw[256], e_twl, e_a[256], e_ta[256], e_tcx = nullptr, e_out;
+    RC(mark(sd, s, &e_in));
+    RC(await(s2, e_in));                                   // the parameters (and this workspace) as the caller's stream leaves them
+
+    // ================================================================ side stream, part 1: bf16 operand copies of the parameters, then their transposes
+    for (int l = 0; l < q.depth; ++l) {
+        const mm_train_layer& w = d.layers[l];
+        LayerBufs& y = layers[l];
+        RC(mm_f32_to_bf16(stream2, w.sa.to_q, y.wqkv, (int64_t)I * D));
+        RC(mm_f32_to_bf16(stream2, w.sa.to_kv, y.wqkv + (size_t)I * D, (int64_t)2 * I * D));
+        RC(mm_f32_to_bf16(stream2, w.sa.to_out, y.wo, (int64_t)D * I));
+        RC(mm_f32_to_bf16(stream2, w.ca.to_q, y.wq2, (int64_t)I * D));
+        RC(mm_f32_to_bf16(stream2, w.ca.to_kv, y.wkv2, (int64_t)2 * I * D));
+        RC(mm_f32_to_bf16(stream2, w.ca.to_out, y.wo2, (int64_t)D * I));
+        // feed forward (mmp.py:79-89): plain [x | gate] halves padded to Fp (the backward recomputes GEGLU from the saved pre-activation)
+        HC(hipMemsetAsync(y.w1p, 0, (size_t)2 * Fp * D * 2, s2));
+        RC(mm_f32_to_bf16(stream2, w.ff.w1, y.w1p, (int64_t)F * D));
+        RC(mm_f32_to_bf16(stream2, w.ff.w1 + (size_t)F * D, y.w1p + (size_t)Fp * D, (int64_t)F * D));
+        if (Fp != F) {      // w2 [D][F] -> bf16 [D][Fp], zero columns: row by row through a dense bf16 copy
+            HC(hipMemsetAsync(y.w2p, 0, (size_t)D * Fp * 2, s2));
+            RC(mm_f32_to_bf16(stream2, w.ff.w2, b.w2tmp, (int64_t)D * F));
+            HC(hipMemcpy2DAsync(y.w2p, (size_t)Fp * 2, b.w2tmp, (size_t)F * 2, (size_t)F * 2, D, hipMemcpyDeviceToDevice, s2));
+        } else {
+            RC(mm_f32_to_bf16(stream2, w.ff.w2, y.w2p, (int64_t)D * F));
+        }
+        HC(hipMemsetAsync(y.g2p, 0, (size_t)Fp * 4, s2));
+        HC(hipMemsetAsync(y.b2p, 0, (size_t)Fp * 4, s2));
+        HC(hipMemcpyAsync(y.g2p, w.ff.g2, (size_t)F * 4, hipMemcpyDeviceToDevice, s2));
+        if (w.ff.b2) HC(hipMemcpyAsync(y.b2p, w.ff.b2, (size_t)F * 4, hipMemcpyDeviceToDevice, s2));
+        RC(mark(sd, s2, &e_w[l]));
+    }
+    RC(mm_f32_to_bf16(stream2, d.to_logits, b.wl, (int64_t)V * D));
+    RC(mark(sd, s2, &e_wl));
+    RC(tr64(stream2, s2, b.wl, V, D, D, b.twl));           // the backward starts at the head and walks the layers downwards
+    RC(mark(sd, s2, &e_twl));
+    for (int l = q.depth - 1; l >= 0; --l) {
+        LayerBufs& y = layers[l];
+        RC(tr64(stream2, s2, y.w2p, D, Fp, Fp, y.tw2p));
+        RC(tr64(stream2, s2, y.w1p, 2 * Fp, D, D, y.tw1p));
+        RC(tr64(stream2, s2, y.wo2, D, I, I, y.two2));
+        RC(tr64(stream2, s2, y.wq2, I, D, D, y.twq2));
+        if (d.text_proj) RC(tr64(stream2, s2, y.wkv2, 2 * I, D, D, y.twkv2));
+        RC(tr64(stream2, s2, y.wo, D, I, I, y.two));
+        RC(tr64(stream2, s2, y.wqkv, 3 * I, D, D, y.twqkv));
+        RC(mark(sd, s2, &e_tw[l]));
+    }
+
     // ================================================================ forward (training.py TransformerTrainFn.forward)
     RC(mm_f32_to_bf16(stream, d.token_emb, b.tok_b, (int64_t)d.vocab_rows * D));
     RC(mm_f32_to_bf16(stream, d.pos_emb, b.pos_b, (int64_t)d.seq_len * D));
@@ -169,125 +320,143 @@ int mm_train_step(const mm_train_desc* desc, mm_stream_t stream, const int64_t* 
         const mm_train_layer& w = d.layers[l];
         LayerBufs& y = layers[l];
         float* xn = l + 1 < q.depth ? layers[l + 1].x0 : b.xL;
+        RC(await(s, e_w[l]));
         // ---- self attention (mmp.py:137-162, 186)
-        RC(mm_f32_to_bf16(stream, w.sa.to_q, y.wqkv, (int64_t)I * D));
-        RC(mm_f32_to_bf16(stream, w.sa.to_kv, y.wqkv + (size_t)I * D, (int64_t)2 * I * D));
-        RC(mm_f32_to_bf16(stream, w.sa.to_out, y.wo, (int64_t)D * I));
         RC(mm_layernorm(stream, y.x0, D, M, D, w.sa.gamma, w.sa.beta, nullptr, y.u, D));
         RC(mm_gemm_bf16(stream, y.u, D, y.wqkv, D, M, 3 * I, D, y.qkv, 3 * I, 0, nullptr));
         RC(mm_attend(stream, y.qkv, (int64_t)n * 3 * I, 64, 3 * I, y.qkv + I, (int64_t)n * 3 * I, 64, 3 * I, y.qkv + 2 * I, (int64_t)n * 3 * I, 64, 3 * I,
                      y.o, (int64_t)n * I, 64, I, B, H, n, n, nullptr, 0, 1, w.sa.q_scale, w.sa.k_scale, w.sa.null_kv, w.sa.null_kv + (size_t)H * 64, 8.f, 64));
         RC(mm_gemm_bf16(stream, y.o, I, y.wo, I, M, D, I, y.x1, D, 1, y.x0));
         // ---- cross attention (mmp.py:139-141, 155-157, 187)
-        RC(mm_f32_to_bf16(stream, w.ca.to_q, y.wq2, (int64_t)I * D));
-        RC(mm_f32_to_bf16(stream, w.ca.to_kv, y.wkv2, (int64_t)2 * I * D));
-        RC(mm_f32_to_bf16(stream, w.ca.to_out, y.wo2, (int64_t)D * I));
         RC(mm_layernorm(stream, y.x1, D, M, D, w.ca.gamma, w.ca.beta, nullptr, y.u2, D));
         RC(mm_gemm_bf16(stream, y.u2, D, y.wq2, D, M, I, D, y.q2, I, 0, nullptr));
         RC(mm_gemm_bf16(stream, b.cx, D, y.wkv2, D, Mc, 2 * I, D, y.kv2, 2 * I, 0, nullptr));
         RC(mm_attend(stream, y.q2, (int64_t)n * I, 64, I, y.kv2, (int64_t)L * 2 * I, 64, 2 * I, y.kv2 + I, (int64_t)L * 2 * I, 64, 2 * I,
                      y.o2, (int64_t)n * I, 64, I, B, H, n, L, ctx_mask, L, 1, w.ca.q_scale, w.ca.k_scale, w.ca.null_kv, w.ca.null_kv + (size_t)H * 64, 8.f, 64));
         RC(mm_gemm_bf16(stream, y.o2, I, y.wo2, I, M, D, I, y.x2, D, 1, y.x1));
-        // ---- feed forward (mmp.py:79-89, 188): plain [x | gate] halves padded to Fp (the backward recomputes GEGLU from the saved pre-activation)
-        HC(hipMemsetAsync(y.w1p, 0, (size_t)2 * Fp * D * 2, s));
-        RC(mm_f32_to_bf16(stream, w.ff.w1, y.w1p, (int64_t)F * D));
-        RC(mm_f32_to_bf16(stream, w.ff.w1 + (size_t)F * D, y.w1p + (size_t)Fp * D, (int64_t)F * D));
-        if (Fp != F) {      // w2 [D][F] -> bf16 [D][Fp], zero columns: row by row through a dense bf16 copy in tW
-            HC(hipMemsetAsync(y.w2p, 0, (size_t)D * Fp * 2, s));
-            RC(mm_f32_to_bf16(stream, w.ff.w2, b.tW, (int64_t)D * F));
-            HC(hipMemcpy2DAsync(y.w2p, (size_t)Fp * 2, b.tW, (size_t)F * 2, (size_t)F * 2, D, hipMemcpyDeviceToDevice, s));
-        } else {
-            RC(mm_f32_to_bf16(stream, w.ff.w2, y.w2p, (int64_t)D * F));
-        }
-        HC(hipMemsetAsync(y.g2p, 0, (size_t)Fp * 4, s));
-        HC(hipMemsetAsync(y.b2p, 0, (size_t)Fp * 4, s));
-        HC(hipMemcpyAsync(y.g2p, w.ff.g2, (size_t)F * 4, hipMemcpyDeviceToDevice, s));
-        if (w.ff.b2) HC(hipMemcpyAsync(y.b2p, w.ff.b2, (size_t)F * 4, hipMemcpyDeviceToDevice, s));
+        // ---- feed forward (mmp.py:79-89, 188)
         RC(mm_layernorm(stream, y.x2, D, M, D, w.ff.g1, w.ff.b1, nullptr, y.u3, D));
         RC(mm_gemm_bf16(stream, y.u3, D, y.w1p, D, M, 2 * Fp, D, y.h, 2 * Fp, 0, nullptr));
         RC(mm_geglu_ln(stream, y.h, 2 * Fp, M, F, Fp, y.g2p, w.ff.b2 ? y.b2p : nullptr, y.z, Fp));
         RC(mm_gemm_bf16(stream, y.z, Fp, y.w2p, Fp, M, D, Fp, xn, D, 1, y.x2));
+        // ---- side stream, part 2: this layer's saved activations transposed for the dW GEMMs of the backward
+        RC(mark(sd, s, &e_a[l]));
+        RC(await(s2, e_a[l]));
+        if (l == 0) {
+            RC(tr64(stream2, s2, b.cx, Mc, D, D, b.tcx));
+            RC(mark(sd, s2, &e_tcx));
+        }
+        RC(tr64(stream2, s2, y.z, M, Fp, Fp, y.tz));
+        RC(tr64(stream2, s2, y.u3, M, D, D, y.tu3));
+        RC(tr64(stream2, s2, y.o2, M, I, I, y.to2));
+        RC(tr64(stream2, s2, y.u2, M, D, D, y.tu2));
+        RC(tr64(stream2, s2, y.o, M, I, I, y.to));
+        RC(tr64(stream2, s2, y.u, M, D, D, y.tu));
+        RC(mark(sd, s2, &e_ta[l]));
     }
     // ---- head on the rows that carry a label (mmp.py:330-343)
-    RC(mm_f32_to_bf16(stream, d.to_logits, b.wl, (int64_t)V * D));
+    RC(await(s, e_wl));
     RC(mm_layernorm(stream, b.xL, D, R, D, d.final_gamma, d.final_beta, row_index, b.e, D));
     RC(mm_gemm_bf16(stream, b.e, D, b.wl, D, R, V, D, b.logits, V, 1, nullptr));
-    RC(mm_ce_loss(stream, b.logits, V, R, V, labels_rows, -100, b.rowloss, loss_out));
+    // (the cross-entropy itself comes out of the backward kernel below: it recomputes the row's max and denominator anyway)
     if (logits_rows_out) HC(hipMemcpyAsync(logits_rows_out, b.logits, (size_t)R * V * 4, hipMemcpyDeviceToDevice, s));
 
     // ================================================================ backward (training.py TransformerTrainFn.backward, gloss == 1: the caller scales)
     HC(hipMemsetAsync(b.dres, 0, (size_t)M * D * 4, s));
-    RC(mm_ce_bwd(stream, b.logits, V, R, V, labels_rows, 1.0f / (float)R, b.dl, V));
-    RC(wgrad(stream, s, b, b.dl, V, V, b.e, D, D, R, d.d_to_logits));
-    RC(dgrad(stream, s, b, b.dl, V, V, b.wl, D, R, b.de, D));
+    RC(k_ce_bwd(s, b.logits, V, R, V, labels_rows, 1.0f / (float)R, b.dl, V, b.rowloss));                               // mmp.py:343 and its gradient
+    RC(k_ce_finish(s, b.rowloss, R, loss_out));
+    FORK();
+    RC(wgrad(stream2, s2, b, b.dl, V, V, b.e, D, D, R, d.d_to_logits));
+    RC(await(s, e_twl));
+    if (b.hd_splits > 1) {                                 // (training.py _dgrad_long_k)
+        RC(mm_gemm_wgrad(stream, b.dl, V, b.twl, V, R, D, V, b.hd_splits, b.hd_ws, b.de32));
+        RC(mm_f32_to_bf16(stream, b.de32, b.de, (int64_t)R * D));
+    } else {
+        RC(dgrad(stream, s, b, b.dl, V, V, b.wl, D, R, b.de, D, b.twl));
+    }
     RC(mm_layernorm_bwd(stream, b.xL, D, b.de, D, d.final_gamma, row_index, R, D, b.dres, D, 0, d.d_final_gamma, b.ln_ws));
+    RC(await(s, e_tcx));
     int dcx_i = -1;      // ping-pong buffer holding the context gradient so far (text projection only)
     for (int l = q.depth - 1; l >= 0; --l) {
         const mm_train_layer& w = d.layers[l];
         LayerBufs& y = layers[l];
+        RC(await(s, e_tw[l]));
+        RC(await(s, e_ta[l]));
         // ---- feed forward (training.py _ff_backward)
-        RC(mm_f32_to_bf16(stream, b.dres, b.dy, (int64_t)M * D));
-        RC(dgrad(stream, s, b, b.dy, D, D, y.w2p, Fp, M, b.dz, Fp));
-        RC(wgrad(stream, s, b, b.dy, D, D, y.z, Fp, Fp, M, b.gtmp));
-        HC(hipMemcpy2DAsync(w.ff.d_w2, (size_t)F * 4, b.gtmp, (size_t)Fp * 4, (size_t)F * 4, D, hipMemcpyDeviceToDevice, s));
-        RC(mm_geglu_ln_bwd(stream, y.h, 2 * Fp, b.dz, Fp, y.g2p, M, F, Fp, b.dh, 2 * Fp, b.gtmp, b.ln_ws));
-        HC(hipMemcpyAsync(w.ff.d_g2, b.gtmp, (size_t)F * 4, hipMemcpyDeviceToDevice, s));
-        RC(wgrad(stream, s, b, b.dh, 2 * Fp, 2 * Fp, y.u3, D, D, M, b.gtmp));
-        HC(hipMemcpyAsync(w.ff.d_w1, b.gtmp, (size_t)F * D * 4, hipMemcpyDeviceToDevice, s));
-        HC(hipMemcpyAsync(w.ff.d_w1 + (size_t)F * D, b.gtmp + (size_t)Fp * D, (size_t)F * D * 4, hipMemcpyDeviceToDevice, s));
-        RC(dgrad(stream, s, b, b.dh, 2 * Fp, 2 * Fp, y.w1p, D, M, b.du, D));
-        RC(mm_layernorm_bwd(stream, y.x2, D, b.du, D, w.ff.g1, nullptr, M, D, b.dres, D, 1, w.ff.d_g1, b.ln_ws));
+        // dy[0] = bf16(dres): written by the LayerNorm backward that produced dres (the layer above's), except under the head (its backward touches labelled rows only)
+        if (l == q.depth - 1) {
+            RC(mm_f32_to_bf16(stream, b.dres, y.dy[0], (int64_t)M * D));
+            FORK();
+        }
+        RC(wgrad(stream2, s2, b, y.dy[0], D, D, y.z, Fp, Fp, M, b.gtmp, y.tz));
+        HC(hipMemcpy2DAsync(w.ff.d_w2, (size_t)F * 4, b.gtmp, (size_t)Fp * 4, (size_t)F * 4, D, hipMemcpyDeviceToDevice, s2));
+        RC(dgrad(stream, s, b, y.dy[0], D, D, y.w2p, Fp, M, b.dz, Fp, y.tw2p));
+        RC(k_geglu_ln_bwd(s, y.h, 2 * Fp, b.dz, Fp, y.g2p, M, F, Fp, y.dh, 2 * Fp, nullptr, y.glw));
+        FORK();
+        RC(k_colsum(s2, y.glw, lnb, Fp, b.gtmp2));
+        HC(hipMemcpyAsync(w.ff.d_g2, b.gtmp2, (size_t)F * 4, hipMemcpyDeviceToDevice, s2));
+        RC(wgrad(stream2, s2, b, y.dh, 2 * Fp, 2 * Fp, y.u3, D, D, M, b.gtmp, y.tu3));
+        HC(hipMemcpyAsync(w.ff.d_w1, b.gtmp, (size_t)F * D * 4, hipMemcpyDeviceToDevice, s2));
+        HC(hipMemcpyAsync(w.ff.d_w1 + (size_t)F * D, b.gtmp + (size_t)Fp * D, (size_t)F * D * 4, hipMemcpyDeviceToDevice, s2));
+        RC(dgrad(stream, s, b, y.dh, 2 * Fp, 2 * Fp, y.w1p, D, M, b.du, D, y.tw1p));
+        RC(k_layernorm_bwd(s, y.x2, D, b.du, D, w.ff.g1, nullptr, M, D, b.dres, D, 1, nullptr, y.lnw[0], y.dy[1]));
+        FORK();
+        RC(k_colsum(s2, y.lnw[0], lnb, D, w.ff.d_g1));
         // ---- cross attention
-        RC(mm_f32_to_bf16(stream, b.dres, b.dy, (int64_t)M * D));
-        RC(dgrad(stream, s, b, b.dy, D, D, y.wo2, I, M, b.dob, I));
-        RC(wgrad(stream, s, b, b.dy, D, D, y.o2, I, I, M, w.ca.d_to_out));
+        RC(wgrad(stream2, s2, b, y.dy[1], D, D, y.o2, I, I, M, w.ca.d_to_out, y.to2));
+        RC(dgrad(stream, s, b, y.dy[1], D, D, y.wo2, I, M, b.dob, I, y.two2));
         const float* nk = w.ca.null_kv;
         const float* nv = w.ca.null_kv + (size_t)H * 64;
         RC(mm_attention_bwd(stream, y.q2, (int64_t)n * I, 64, I, y.kv2, (int64_t)L * 2 * I, 64, 2 * I, y.kv2 + I, (int64_t)L * 2 * I, 64, 2 * I,
                             y.o2, (int64_t)n * I, 64, I, b.dob, (int64_t)n * I, 64, I, b.dqn, (int64_t)n * I, 64, I, b.dkn, (int64_t)L * I, 64, I,
-                            b.dkv2 + I, (int64_t)L * 2 * I, 64, 2 * I, b.dnk, b.dnv, B, H, n, L, ctx_mask, L, w.ca.q_scale, w.ca.k_scale, nk, nv, 8.f));
-        RC(mm_qk_norm_bwd(stream, y.q2, I, nullptr, H, b.dqn, I, nullptr, w.ca.q_scale, M, H, b.dq2, I, nullptr, b.part));
-        RC(mm_colsum_f32(stream, b.part, (int)mm_qk_norm_bwd_blocks((int64_t)M * H), 64, w.ca.d_q_scale));
-        RC(mm_qk_norm_bwd(stream, y.kv2, 2 * I, nullptr, H, b.dkn, I, nullptr, w.ca.k_scale, Mc, H, b.dkv2, 2 * I, nullptr, b.part));
-        RC(mm_colsum_f32(stream, b.part, (int)mm_qk_norm_bwd_blocks((int64_t)Mc * H), 64, b.pair));
-        RC(mm_qk_norm_bwd(stream, nullptr, 0, nk, H, nullptr, 0, b.dnk, w.ca.k_scale, (int64_t)B * H, 1, nullptr, 0, b.dnull, b.part));
-        RC(mm_colsum_f32(stream, b.part, (int)mm_qk_norm_bwd_blocks((int64_t)B * H), 64, b.pair + 64));
-        RC(mm_colsum_f32(stream, b.pair, 2, 64, w.ca.d_k_scale));                                                        // dks + dks_n
-        RC(mm_colsum_f32(stream, b.dnull, B, H * 64, w.ca.d_null_kv));
-        RC(mm_colsum_f32(stream, b.dnv, B, H * 64, w.ca.d_null_kv + (size_t)H * 64));
-        RC(dgrad(stream, s, b, b.dq2, I, I, y.wq2, D, M, b.du, D));
-        RC(wgrad(stream, s, b, b.dq2, I, I, y.u2, D, D, M, w.ca.d_to_q));
-        RC(wgrad(stream, s, b, b.dkv2, 2 * I, 2 * I, b.cx, D, D, Mc, w.ca.d_to_kv));
+                            y.dkv2 + I, (int64_t)L * 2 * I, 64, 2 * I, b.dnk, y.dnv[0], B, H, n, L, ctx_mask, L, w.ca.q_scale, w.ca.k_scale, nk, nv, 8.f));
+        RC(mm_qk_norm_bwd(stream, y.q2, I, nullptr, H, b.dqn, I, nullptr, w.ca.q_scale, M, H, y.dq2, I, nullptr, y.part[0][0]));
+        RC(mm_qk_norm_bwd(stream, y.kv2, 2 * I, nullptr, H, b.dkn, I, nullptr, w.ca.k_scale, Mc, H, y.dkv2, 2 * I, nullptr, y.part[0][1]));
+        RC(mm_qk_norm_bwd(stream, nullptr, 0, nk, H, nullptr, 0, b.dnk, w.ca.k_scale, (int64_t)B * H, 1, nullptr, 0, y.dnull[0], y.part[0][2]));
+        // the leaf reductions (scale and null key / value gradients) leave the chain: side stream, same kernels in the same order
+        FORK();
+        RC(mm_colsum_f32(stream2, y.part[0][0], (int)mm_qk_norm_bwd_blocks((int64_t)M * H), 64, w.ca.d_q_scale));
+        RC(mm_colsum_f32(stream2, y.part[0][1], (int)mm_qk_norm_bwd_blocks((int64_t)Mc * H), 64, y.pair[0]));
+        RC(mm_colsum_f32(stream2, y.part[0][2], (int)mm_qk_norm_bwd_blocks((int64_t)B * H), 64, y.pair[0] + 64));
+        RC(mm_colsum_f32(stream2, y.pair[0], 2, 64, w.ca.d_k_scale));                                                     // dks + dks_n
+        RC(mm_colsum_f32(stream2, y.dnull[0], B, H * 64, w.ca.d_null_kv));
+        RC(mm_colsum_f32(stream2, y.dnv[0], B, H * 64, w.ca.d_null_kv + (size_t)H * 64));
+        RC(wgrad(stream2, s2, b, y.dq2, I, I, y.u2, D, D, M, w.ca.d_to_q, y.tu2));
+        RC(wgrad(stream2, s2, b, y.dkv2, 2 * I, 2 * I, b.cx, D, D, Mc, w.ca.d_to_kv, b.tcx));
+        RC(dgrad(stream, s, b, y.dq2, I, I, y.wq2, D, M, b.du, D, y.twq2));
         if (d.text_proj) {      // the context's gradient (only the projection needs it): dcx = dkv2 W_kv (+ what the layers above left)
-            RC(tr64(stream, s, y.wkv2, 2 * I, D, D, b.tW));
             const int nxt = dcx_i < 0 ? 0 : 1 - dcx_i;
-            RC(mm_gemm_bf16(stream, b.dkv2, 2 * I, b.tW, pad64(2 * I), Mc, D, pad64(2 * I), b.dcx[nxt], D, 1, dcx_i < 0 ? nullptr : b.dcx[dcx_i]));
+            RC(mm_gemm_bf16(stream, y.dkv2, 2 * I, y.twkv2, pad64(2 * I), Mc, D, pad64(2 * I), b.dcx[nxt], D, 1, dcx_i < 0 ? nullptr : b.dcx[dcx_i]));
             dcx_i = nxt;
         }
-        RC(mm_layernorm_bwd(stream, y.x1, D, b.du, D, w.ca.gamma, nullptr, M, D, b.dres, D, 1, w.ca.d_gamma, b.ln_ws));
+        RC(k_layernorm_bwd(s, y.x1, D, b.du, D, w.ca.gamma, nullptr, M, D, b.dres, D, 1, nullptr, y.lnw[1], y.dy[2]));
+        FORK();
+        RC(k_colsum(s2, y.lnw[1], lnb, D, w.ca.d_gamma));
         // ---- self attention
-        RC(mm_f32_to_bf16(stream, b.dres, b.dy, (int64_t)M * D));
-        RC(dgrad(stream, s, b, b.dy, D, D, y.wo, I, M, b.dob, I));
-        RC(wgrad(stream, s, b, b.dy, D, D, y.o, I, I, M, w.sa.d_to_out));
+        RC(wgrad(stream2, s2, b, y.dy[2], D, D, y.o, I, I, M, w.sa.d_to_out, y.to));
+        RC(dgrad(stream, s, b, y.dy[2], D, D, y.wo, I, M, b.dob, I, y.two));
         nk = w.sa.null_kv;
         nv = w.sa.null_kv + (size_t)H * 64;
         RC(mm_attention_bwd(stream, y.qkv, (int64_t)n * 3 * I, 64, 3 * I, y.qkv + I, (int64_t)n * 3 * I, 64, 3 * I, y.qkv + 2 * I, (int64_t)n * 3 * I, 64, 3 * I,
                             y.o, (int64_t)n * I, 64, I, b.dob, (int64_t)n * I, 64, I, b.dqn, (int64_t)n * I, 64, I, b.dkn, (int64_t)n * I, 64, I,
-                            b.dqkv + 2 * I, (int64_t)n * 3 * I, 64, 3 * I, b.dnk, b.dnv, B, H, n, n, nullptr, 0, w.sa.q_scale, w.sa.k_scale, nk, nv, 8.f));
-        RC(mm_qk_norm_bwd(stream, y.qkv, 3 * I, nullptr, H, b.dqn, I, nullptr, w.sa.q_scale, M, H, b.dqkv, 3 * I, nullptr, b.part));
-        RC(mm_colsum_f32(stream, b.part, (int)mm_qk_norm_bwd_blocks((int64_t)M * H), 64, w.sa.d_q_scale));
-        RC(mm_qk_norm_bwd(stream, y.qkv + I, 3 * I, nullptr, H, b.dkn, I, nullptr, w.sa.k_scale, M, H, b.dqkv + I, 3 * I, nullptr, b.part));
-        RC(mm_colsum_f32(stream, b.part, (int)mm_qk_norm_bwd_blocks((int64_t)M * H), 64, b.pair));
-        RC(mm_qk_norm_bwd(stream, nullptr, 0, nk, H, nullptr, 0, b.dnk, w.sa.k_scale, (int64_t)B * H, 1, nullptr, 0, b.dnull, b.part));
-        RC(mm_colsum_f32(stream, b.part, (int)mm_qk_norm_bwd_blocks((int64_t)B * H), 64, b.pair + 64));
-        RC(mm_colsum_f32(stream, b.pair, 2, 64, w.sa.d_k_scale));
-        RC(mm_colsum_f32(stream, b.dnull, B, H * 64, w.sa.d_null_kv));
-        RC(mm_colsum_f32(stream, b.dnv, B, H * 64, w.sa.d_null_kv + (size_t)H * 64));
-        RC(dgrad(stream, s, b, b.dqkv, 3 * I, 3 * I, y.wqkv, D, M, b.du, D));
-        RC(wgrad(stream, s, b, b.dqkv, 3 * I, 3 * I, y.u, D, D, M, b.gtmp));
-        HC(hipMemcpyAsync(w.sa.d_to_q, b.gtmp, (size_t)I * D * 4, hipMemcpyDeviceToDevice, s));
-        HC(hipMemcpyAsync(w.sa.d_to_kv, b.gtmp + (size_t)I * D, (size_t)2 * I * D * 4, hipMemcpyDeviceToDevice, s));
-        RC(mm_layernorm_bwd(stream, y.x0, D, b.du, D, w.sa.gamma, nullptr, M, D, b.dres, D, 1, w.sa.d_gamma, b.ln_ws));
+                            y.dqkv + 2 * I, (int64_t)n * 3 * I, 64, 3 * I, b.dnk, y.dnv[1], B, H, n, n, nullptr, 0, w.sa.q_scale, w.sa.k_scale, nk, nv, 8.f));
+        RC(mm_qk_norm_bwd(stream, y.qkv, 3 * I, nullptr, H, b.dqn, I, nullptr, w.sa.q_scale, M, H, y.dqkv, 3 * I, nullptr, y.part[1][0]));
+        RC(mm_qk_norm_bwd(stream, y.qkv + I, 3 * I, nullptr, H, b.dkn, I, nullptr, w.sa.k_scale, M, H, y.dqkv + I, 3 * I, nullptr, y.part[1][1]));
+        RC(mm_qk_norm_bwd(stream, nullptr, 0, nk, H, nullptr, 0, b.dnk, w.sa.k_scale, (int64_t)B * H, 1, nullptr, 0, y.dnull[1], y.part[1][2]));
+        FORK();
+        RC(mm_colsum_f32(stream2, y.part[1][0], (int)mm_qk_norm_bwd_blocks((int64_t)M * H), 64, w.sa.d_q_scale));
+        RC(mm_colsum_f32(stream2, y.part[1][1], (int)mm_qk_norm_bwd_blocks((int64_t)M * H), 64, y.pair[1]));
+        RC(mm_colsum_f32(stream2, y.part[1][2], (int)mm_qk_norm_bwd_blocks((int64_t)B * H), 64, y.pair[1] + 64));
+        RC(mm_colsum_f32(stream2, y.pair[1], 2, 64, w.sa.d_k_scale));
+        RC(mm_colsum_f32(stream2, y.dnull[1], B, H * 64, w.sa.d_null_kv));
+        RC(mm_colsum_f32(stream2, y.dnv[1], B, H * 64, w.sa.d_null_kv + (size_t)H * 64));
+        RC(wgrad(stream2, s2, b, y.dqkv, 3 * I, 3 * I, y.u, D, D, M, b.gtmp, y.tu));
+        HC(hipMemcpyAsync(w.sa.d_to_q, b.gtmp, (size_t)I * D * 4, hipMemcpyDeviceToDevice, s2));
+        HC(hipMemcpyAsync(w.sa.d_to_kv, b.gtmp + (size_t)I * D, (size_t)2 * I * D * 4, hipMemcpyDeviceToDevice, s2));
+        RC(dgrad(stream, s, b, y.dqkv, 3 * I, 3 * I, y.wqkv, D, M, b.du, D, y.twqkv));
+        RC(k_layernorm_bwd(s, y.x0, D, b.du, D, w.sa.gamma, nullptr, M, D, b.dres, D, 1, nullptr, y.lnw[2], l > 0 ? layers[l - 1].dy[0] : nullptr));
+        FORK();                                            // (also hands layers[l - 1].dy[0] to the dW GEMM that opens the next iteration)
+        RC(k_colsum(s2, y.lnw[2], lnb, D, w.sa.d_gamma));
     }
     // ---- embeddings / text projection
     HC(hipMemsetAsync(d.d_token_emb, 0, (size_t)d.vocab_rows * D * 4, s));
@@ -295,8 +464,12 @@ int mm_train_step(const mm_train_desc* desc, mm_stream_t stream, const int64_t* 
     RC(mm_embed_bwd(stream, ids, B, n, D, b.dres, d.d_token_emb, d.d_pos_emb));
     if (d.text_proj) {
         RC(mm_f32_to_bf16(stream, b.dcx[dcx_i], b.dcxb, (int64_t)Mc * D));
-        RC(wgrad(stream, s, b, b.dcxb, D, D, b.te_b, td, td, Mc, d.d_text_proj));
+        FORK();
+        RC(wgrad(stream2, s2, b, b.dcxb, D, D, b.te_b, td, td, Mc, d.d_text_proj));
     }
+#undef FORK
+    RC(mark(sd, s2, &e_out));                              // join: the caller's stream owns every gradient when this call's work on it has run
+    RC(await(s, e_out));
     return MM_OK;
 }
 

@@ -34,6 +34,15 @@ def _dgrad(dy, w):
     return ops.gemm(dy, _t(w))
 
 
+def _dgrad_long_k(dy, w):
+    """dX = dY W where the contraction is LONG and the output small (the head: N = the vocabulary, dX = [labelled rows, dim] is a few dozen tiles that
+    cannot fill 256 CUs): split-K like a weight gradient -- fp32 slabs summed in a fixed order -- then bf16.  Falls back to _dgrad when one split is chosen."""
+    wt = _t(w)
+    if dy.shape[1] % 4 == 0 and ops.L.lib().mm_gemm_wgrad_splits(dy.shape[0], wt.shape[0], dy.shape[1]) > 1:
+        return ops.to_bf16(ops.gemm_wgrad(dy, wt))
+    return ops.gemm(dy, wt)
+
+
 def _heads(t, b, n, h, col0=0):
     """[b*n, >= col0 + h*64] row tensor -> (b, h, n, 64) strided view."""
     return t[:, col0:col0 + h * 64].unflatten(0, (b, n)).unflatten(2, (h, 64)).permute(0, 2, 1, 3)
@@ -240,7 +249,7 @@ class TransformerTrainFn(torch.autograd.Function):
             R = ctx.row_index.numel()
             dl = ops.ce_bwd(sv['logits'], ctx.labels_rows, 1.0 / R, pad_to=64)
             G['to_logits'] = _wgrad(dl, sv['e'])[:sv['logits'].shape[1]]
-            de = _dgrad(dl, sv['W']['wl'])
+            de = _dgrad_long_k(dl, sv['W']['wl'])
             G['final.gamma'] = ops.layernorm_bwd(sv['xL'], de, f32(P['final.gamma']), dres, accumulate=False, row_index=ctx.row_index)
         dcx = None
         sync = cfg.get('sync')

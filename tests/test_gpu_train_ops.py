@@ -187,3 +187,16 @@ def test_attention_bwd_and_qk_norm_bwd(ops, n, j, masked):
         assert rel_err(dks + dks_null, ks.grad) < tol
     else:
         assert rel_err(dks_null, ks.grad) < tol
+
+
+@pytest.mark.parametrize('nparts', [1, 2, 5, 8, 13, 16, 32])
+def test_wide_colsum_is_the_narrow_colsum_bit_for_bit(ops, nparts):
+    """split-K slabs of a weight gradient (D = N x K >= 65536) take the 16-byte-per-lane kernel: the same 4-stream x 2-accumulator association as the
+    64-column kernel, so the two agree bit for bit (the narrow kernel runs on each half, which is below the switch)."""
+    g = torch.Generator().manual_seed(nparts)
+    part = (torch.randn(nparts, 131072, generator=g) * torch.logspace(-3, 3, 131072)[None]).to(DEV)
+    wide = ops.colsum(part)
+    narrow = torch.cat([ops.colsum(part[:, :32768].contiguous()), ops.colsum(part[:, 32768:65536].contiguous()),
+                        ops.colsum(part[:, 65536:98304].contiguous()), ops.colsum(part[:, 98304:].contiguous())])
+    assert torch.equal(wide, narrow)
+    assert (wide.double().cpu() - part.double().sum(0).cpu()).abs().max() <= 1e-5 * part.abs().sum(0).max().item()

@@ -66,3 +66,44 @@ def test_train_step_lowers_the_loss_through_a_torch_optimizer():
         opt.step()
         losses.append(loss.item())
     assert losses[-1] < losses[0] - 0.5, losses
+
+
+def test_train_step_side_stream_keeps_pace_with_parameter_updates():
+    """The bf16 operand copies / transposes of the parameters, the dW GEMMs and the leaf reductions run on the library's second stream (csrc/train_step.hip): over several optimizer steps --
+    parameters change between the calls, the workspace is reused -- the C step with the side stream, the C step on one stream (MM_TRAIN_SIDE=0) and the
+    operator-by-operator driver must walk the same trajectory bit for bit."""
+    import copy
+    torch.manual_seed(5)
+    tr0 = mm.MaskGitTransformer(num_tokens=1024, seq_len=64, dim=256, depth=3, dim_head=64, heads=4, t5_name='t5-small').to(DEV).train()
+    g = torch.Generator().manual_seed(2)
+    batches = [(torch.randint(0, 1025, (4, 64), generator=g).to(DEV), torch.randint(0, 1024, (4, 64), generator=g).to(DEV), torch.randn(4, 6, 512, generator=g).to(DEV))
+               for _ in range(4)]
+
+    def run(mode):
+        tr = copy.deepcopy(tr0)
+        opt = torch.optim.SGD(tr.parameters(), lr=0.05)
+        os.environ.pop('MM_TRAIN_PY', None)
+        os.environ.pop('MM_TRAIN_SIDE', None)
+        if mode == 'py':
+            os.environ['MM_TRAIN_PY'] = '1'
+        if mode == 'one_stream':
+            os.environ['MM_TRAIN_SIDE'] = '0'
+        try:
+            losses = []
+            for ids, labels, te in batches:
+                opt.zero_grad(set_to_none=True)
+                loss = tr(ids, text_embeds=te, labels=labels, ignore_index=-1)
+                loss.backward()
+                opt.step()
+                losses.append(loss.detach().clone())
+        finally:
+            os.environ.pop('MM_TRAIN_PY', None)
+            os.environ.pop('MM_TRAIN_SIDE', None)
+        torch.cuda.synchronize()
+        return torch.stack(losses), {n: p.detach().clone() for n, p in tr.named_parameters()}
+
+    l_side, p_side = run('side')
+    l_one, p_one = run('one_stream')
+    l_py, p_py = run('py')
+    assert torch.equal(l_side, l_py) and torch.equal(l_one, l_py), (l_side.tolist(), l_one.tolist(), l_py.tolist())
+    assert all(torch.equal(p_side[k], p_py[k]) and torch.equal(p_one[k], p_py[k]) for k in p_py)
