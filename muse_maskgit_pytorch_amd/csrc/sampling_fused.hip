@@ -108,7 +108,11 @@ constexpr int FT = 512, FW = FT / 64;
 constexpr int WSL = 1408;                       // per-wave slice of the candidate list; a wave gathers 1/8 of the tiles: ~1150 +- 35 values at V = 65536
 constexpr int LIST_CAP = FW * WSL;              // 11264 candidates of one row held in LDS as (fp32 value, u16 index): 66 KiB
 constexpr int NBF = 1024;                       // value-linear histogram bins over [thr_lo, row max]
+#if MM_EXP == 10
+constexpr int GU = 8;
+#else
 constexpr int GU = 16;                          // tiles per wave whose candidate loads are in flight together (2 rounds per row at V = 65536)
+#endif
 constexpr int CANDF = 1024;                     // exact-select capacity (members of the bin that holds the k-th largest)
 
 struct FusedShared {
@@ -125,20 +129,65 @@ struct FusedShared {
 };
 __device__ __forceinline__ int hslotf(int b) { return ((b & 15) << 6) | (b >> 4); }
 
-__global__ __launch_bounds__(FT, 2) void sample_fused_kernel(const FusedSampleArgs p) {
+// both values of one list entry per lane (columns col, col + 1): those >= lo are appended to the wave's slice in lane order (ballot prefix, no atomics; a
+// dead lane carries NaN, which passes no comparison).  A slice that would overflow is not written at all: its count still grows, so the row fails the
+// `fits` check below and goes to the fallback.
+__device__ __forceinline__ void fs_append2(const float2 x, int col, float lo, float* myx, uint16_t* myc, int& wcount) {
+    const bool k0 = x.x >= lo, k1 = x.y >= lo;
+    const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1);
+    const int nw = __popcll(b0) + __popcll(b1);
+    if (wcount + nw <= WSL) {                                     // wave-uniform
+        int idx = wcount + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
+                  (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
+        if (k0) { myx[idx] = x.x; myc[idx] = (uint16_t)col; }
+        idx += k0 ? 1 : 0;
+        if (k1) { myx[idx] = x.y; myc[idx] = (uint16_t)(col + 1); }
+    }
+    wcount += nw;
+}
+// per-lane select by a wave-uniform 64-bit lane mask held in scalar registers: bit `lane` of mask ? if_set : if_clear (one v_cndmask)
+__device__ __forceinline__ int fs_sel_mask(int if_clear, int if_set, unsigned long long mask) {
+    int r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask));
+    return r;
+}
+
+__global__ __launch_bounds__(FT, 4) void sample_fused_kernel(const FusedSampleArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fs_raw[];
     FusedShared& S = *reinterpret_cast<FusedShared*>(fs_raw);
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the gather's piece walk, its addresses and its branches are wave-uniform
     const int NT = p.V / 256;
+#if MM_EXP != 9
+    // lane u < 32 of wave w holds the keep mask of piece w + 8 u (the wave's u-th piece) of the current row: read once per row straight from the
+    // records, one row ahead, and handed to the gather through v_readlane (scalar registers, no LDS round trip)
+    auto load_masks = [&](int r) -> uint4 {
+        uint4 m = make_uint4(0u, 0u, 0u, 0u);
+        const int tp = wid + lane * FW;
+        if (r < p.R && lane < 32 && tp < NT) {
+            const float4 mk = p.stats[((size_t)r * NT + tp) * FS_REC + 1];
+            m = make_uint4(__float_as_uint(mk.x), __float_as_uint(mk.y), __float_as_uint(mk.z), __float_as_uint(mk.w));
+        }
+        return m;
+    };
+    uint4 mkv = load_masks(blockIdx.x);
+#endif
     for (int row = blockIdx.x; row < p.R; row += gridDim.x) {
         const long pos_flat = p.rows ? (long)p.rows[row] : (long)row;
         // ---- tile statistics -> row max, softmax denominator; the kept-lane masks are parked in LDS for the gather
         float tmax = -INFINITY, tsum = 0.f;
+#if MM_EXP != 9
+        if (tid < NT) {
+            const float4 st = p.stats[((size_t)row * NT + tid) * FS_REC];
+            tmax = st.x; tsum = st.y;
+        }
+#else
         if (tid < NT) {
             const float4 st = p.stats[((size_t)row * NT + tid) * FS_REC], mk = p.stats[((size_t)row * NT + tid) * FS_REC + 1];
             tmax = st.x; tsum = st.y;
             S.masks[tid] = make_uint4(__float_as_uint(mk.x), __float_as_uint(mk.y), __float_as_uint(mk.z), __float_as_uint(mk.w));
         }
+#endif
         const float wm = wave_max(tmax);
         if (lane == 0) S.redf[wid] = wm;
         if (tid == 0) S.ncand = 0;
@@ -159,6 +208,58 @@ __global__ __launch_bounds__(FT, 2) void sample_fused_kernel(const FusedSampleAr
         float* myx = S.xs + wid * WSL;
         uint16_t* myc = S.cols + wid * WSL;
         int wcount = 0;                                           // wave-uniform
+#if MM_EXP != 9
+        // Dense gather: a piece's slot IS a compacted list (cnt = popcount of its keep mask granules, in column order), so lane e reads granule e -- one
+        // coalesced 8-byte load per lane, no per-lane position arithmetic -- and only the granule NUMBER of entry e (the position of the e-th set bit of
+        // the 128-bit mask) has to be found.  The mask is wave-uniform (scalar registers): the lane that owns bit J knows its rank (v_mbcnt), and one
+        // ds_permute per mask half sends J to the lane of that rank (the lanes that own a cleared bit are routed behind the list, so each permute is a
+        // bijection: no destination is written twice).  ~45 VALU instructions per piece against ~100 of the per-column walk it replaces (round 4: this
+        // loop is VALU-issue-bound).
+        for (int t0 = wid, pl0 = 0; t0 < NT; t0 += FW * GU, pl0 += GU) {      // pl0 + u: the lane of mkv that holds piece t0 + u FW
+            float2 v[GU];
+            uint32_t gr[GU / 2];                                  // 16 bits per piece: granule number of list entry `lane` | (pass-2 sender) << 8 for the tail round
+            uint32_t big = 0;                                     // wave-uniform: pieces with more than 64 kept granules
+            const float dead = __uint_as_float(0x7FC00000u);
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int t_ = t0 + u * FW;
+                v[u] = make_float2(dead, dead);
+                if ((u & 1) == 0) gr[u / 2] = 0;
+                if (t_ < NT) {                                    // wave-uniform
+                    const uint32_t m0 = __builtin_amdgcn_readlane(mkv.x, pl0 + u), m1 = __builtin_amdgcn_readlane(mkv.y, pl0 + u);
+                    const uint32_t m2 = __builtin_amdgcn_readlane(mkv.z, pl0 + u), m3 = __builtin_amdgcn_readlane(mkv.w, pl0 + u);
+                    const int c01 = __popc(m0) + __popc(m1), cnt = c01 + __popc(m2) + __popc(m3);
+                    if (lane < cnt) v[u] = reinterpret_cast<const float2*>(p.cand + ((size_t)row * NT + t_) * FS_SLOT)[lane];
+                    // pass 1: lane l owns granule l (bit l of m1:m0), list position = its rank; pass 2: granule 64 + l (bit l of m3:m2), list position c01 + rank
+                    // taken mod 64 -- a position >= 64 (more than 64 kept granules in the piece) wraps to lane position - 64 < c01, where the tail round
+                    // of the second loop picks it up.  Owners of a cleared bit are routed behind the owners: each permute is a bijection of the lanes.
+                    const int ra = (int)__builtin_amdgcn_mbcnt_hi(m1, __builtin_amdgcn_mbcnt_lo(m0, 0u));
+                    const int rb = (int)__builtin_amdgcn_mbcnt_hi(m3, __builtin_amdgcn_mbcnt_lo(m2, 0u));
+                    const int da = fs_sel_mask(c01 + lane - ra, ra, ((unsigned long long)m1 << 32) | m0);
+                    const int db = fs_sel_mask(cnt + lane - rb, c01 + rb, ((unsigned long long)m3 << 32) | m2) & 63;
+                    const int ja = __builtin_amdgcn_ds_permute(da << 2, lane), jb = __builtin_amdgcn_ds_permute(db << 2, lane);
+                    gr[u / 2] |= (uint32_t)((lane < c01 ? ja : 64 + jb) | (jb << 8)) << (16 * (u & 1));
+                    big |= (cnt > 64 ? 1u : 0u) << u;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int t_ = t0 + u * FW;
+                if (t_ < NT) {                                    // wave-uniform
+                    const uint32_t g16 = (gr[u / 2] >> (16 * (u & 1))) & 0xFFFFu;
+                    fs_append2(v[u], t_ * 256 + 2 * (int)(g16 & 255u), lo, myx, myc, wcount);
+                    if ((big >> u) & 1u) {                        // wave-uniform, rare (more than half of the piece kept): entries 64 .. cnt - 1
+                        const int cnt = __popc(__builtin_amdgcn_readlane(mkv.x, pl0 + u)) + __popc(__builtin_amdgcn_readlane(mkv.y, pl0 + u)) +
+                                        __popc(__builtin_amdgcn_readlane(mkv.z, pl0 + u)) + __popc(__builtin_amdgcn_readlane(mkv.w, pl0 + u));
+                        float2 w = make_float2(dead, dead);
+                        if (64 + lane < cnt) w = reinterpret_cast<const float2*>(p.cand + ((size_t)row * NT + t_) * FS_SLOT)[64 + lane];
+                        fs_append2(w, t_ * 256 + 2 * (int)(64u + (g16 >> 8)), lo, myx, myc, wcount);
+                    }
+                }
+            }
+        }
+        mkv = load_masks(row + (int)gridDim.x);                  // the next row's masks arrive under the rest of this row
+#else
         for (int t0 = wid; t0 < NT; t0 += FW * GU) {
             float4 v[GU];
             uint32_t mine_bits = 0;                               // bits 2 u + h: granule 2 lane + h (columns 4 lane + 2 h, + 1) of tile u was kept (packed: VGPR budget of 128 for two workgroups per CU)
@@ -205,6 +306,7 @@ __global__ __launch_bounds__(FT, 2) void sample_fused_kernel(const FusedSampleAr
                 wcount += (r0 + r1) + (r2 + r3);
             }
         }
+#endif
         // the histogram over THIS wave's slice, in a dense sweep (all 64 lanes busy: ~18 LDS atomic instructions per wave instead of the 128 sparse ones
         // an atomic per appended value inside the gather costs -- the LDS instruction slots, not the bytes, bound this kernel)
         if (fast) {

@@ -67,6 +67,43 @@ def test_fused_sample_hot_tile_and_failure_paths():
     assert int(fb['fail'].item()) == 1
 
 
+@pytest.mark.parametrize('pattern', ['two_of_three', 'upper_half', 'three_of_four', 'all_but_first_quarter'])
+def test_fused_sample_crowded_pieces_keep_their_columns(pattern):
+    """pieces with 65 .. 128 kept granules (the finisher reads a slot densely, 64 entries per round, and recovers every entry's granule number
+    from the piece's keep mask: the second round takes its granule numbers from the wrapped half of the second lane permutation).  With
+    T -> 0 the predicted id IS the row's largest logit, which is planted in the crowded piece behind its 64th kept granule; with T = 1 / 0.5
+    the Gumbel winner lies in the crowded piece for most rows"""
+    g = torch.Generator().manual_seed(21)
+    R, V = 9, 65536
+    base = torch.randn(R, V, generator=g)
+    cols = torch.arange(256)
+    hot = {'two_of_three': cols % 3 != 0, 'upper_half': cols >= 100, 'three_of_four': cols % 4 != 1, 'all_but_first_quarter': cols >= 64}[pattern]
+    hot_cols = cols[hot]
+    planted_logits = None
+    planted = []
+    for r in range(R):
+        piece = 3 + 7 * r
+        base[r, piece * 256:(piece + 1) * 256][hot] += 7.0
+    planted_logits = base.clone()
+    for r in range(R):
+        piece = 3 + 7 * r
+        c = int(hot_cols[len(hot_cols) - 1 - 3 * r]) + piece * 256      # behind the 64th kept granule of the piece
+        planted_logits[r, c] = 40.0 + r
+        planted.append(c)
+    k_keep = math.ceil(0.1 * V)
+    ref_pred, ref_score, pred, score, fb = _both(planted_logits.to(DEV), k_keep, 1e-10)
+    assert int(fb['fail'].item()) == 0
+    assert torch.equal(pred, ref_pred) and torch.equal(score, ref_score)
+    assert pred.flatten().tolist() == planted
+    in_piece = 0
+    for T, kw in ((1.0, dict(noise_kind=_lib.MM_NOISE_PHILOX, seed=11, step=2)), (0.5, dict(noise_kind=_lib.MM_NOISE_PHILOX, seed=12, row_offset=5))):
+        ref_pred, ref_score, pred, score, fb = _both(base.to(DEV), k_keep, T, **kw)
+        assert int(fb['fail'].item()) == 0
+        assert torch.equal(pred, ref_pred) and torch.equal(score, ref_score)
+        in_piece += sum(int(pc) // 256 == 3 + 7 * r for r, pc in enumerate(pred.flatten().tolist()))
+    assert in_piece >= R            # the crowded pieces do carry the winners (otherwise this test shows nothing)
+
+
 def _valid_slots(stats):
     """which of the 128 float2 entries of every (row, piece) slot hold a candidate, as a mask over the slot viewed as [.., 64, 4] floats: the slot is one
     compacted list, as long as the record's 128-bit mask has bits set (common.h fs_pos)"""
