@@ -200,6 +200,54 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 }
 #undef MM_DPP_F
 
+// ------------------------------------------------------------------------------------------------ Philox2x32-10 and the Gumbel transform
+// ONE definition for the logits-path sampler (sampling.hip) and the fused finisher (sampling_fused.hip): the two paths must draw bit-identical
+// noise.  Counter-based: the uniform for (seed, global token row, decode step, vocabulary index v) is output (v & 1) of Philox2x32-10 with the
+// 64-bit counter  row << 24 | (step & 0xFF) << 16 | (v >> 1)  and a 32-bit key mixed from the seed.  One call serves two adjacent vocabulary
+// entries; the samplers only evaluate it for the kept entries.
+__device__ __forceinline__ void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t k, uint32_t (&out)[2]) {
+    // the key schedule lives in vector registers: as scalar values the ten round keys were hoisted out of the samplers' loops, spilled (both kernels
+    // are short of scalar registers) and read back with v_readlane + wait states inside every round
+    asm volatile("" : "+v"(k));
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p = (uint64_t)0xD256D193u * c0;
+        const uint32_t n0 = (uint32_t)(p >> 32) ^ k ^ c1;
+        c1 = (uint32_t)p;
+        c0 = n0;
+        k += 0x9E3779B9u;
+    }
+    out[0] = c0; out[1] = c1;
+}
+__device__ __forceinline__ void philox_uniform2(uint64_t seed, uint64_t row_global, uint32_t step, uint32_t col2, float (&u)[2]) {
+    const uint64_t ctr = (row_global << 24) | ((uint64_t)(step & 0xFFu) << 16) | (uint64_t)(col2 & 0xFFFFu);
+    const uint32_t key = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x85EBCA6Bu) ^ ((step >> 8) * 0xC2B2AE35u);
+    uint32_t o[2];
+    philox2x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), key, o);
+    u[0] = (float)(o[0] >> 8) * (1.0f / 16777216.0f);   // 24-bit, [0, 1)
+    u[1] = (float)(o[1] >> 8) * (1.0f / 16777216.0f);
+}
+// -log(-log(u)) with the reference's clamps (muse_maskgit_pytorch.py:403-408)
+__device__ __forceinline__ float gumbel_of(float u) {
+    const float a = logf(fmaxf(u, 1e-20f));
+    return -logf(fmaxf(-a, 1e-20f));
+}
+// log(x) for NORMAL, finite, positive x: the operation sequence of the device library's logf on that domain -- v_log_f32, then the product with ln 2
+// as a compensated two-term multiply -- without its denormal pre-scaling and infinity pass-through (8 of its 13 instructions).
+__device__ __forceinline__ float log_normal_pos(float x) {
+    const float r = __builtin_amdgcn_logf(x);
+    const float ch = __uint_as_float(0x3F317217u), cl = __uint_as_float(0x3377D1CFu);      // ln 2 = ch + cl
+    const float y = r * ch;
+    float t = __builtin_fmaf(r, ch, -y);
+    t = __builtin_fmaf(r, cl, t);
+    return y + t;
+}
+// gumbel_of for a Philox uniform (0 or k 2^-24, k < 2^24): both logarithms see normal arguments (>= 1e-20 resp. >= 5.9e-8), same values as gumbel_of
+__device__ __forceinline__ float gumbel_of_unit(float u) {
+    const float a = log_normal_pos(fmaxf(u, 1e-20f));
+    return -log_normal_pos(fmaxf(-a, 1e-20f));
+}
+
 // Fused sampling (sampling_fused.hip): what leaves the guidance-logits GEMM instead of the logits.  One 256-column piece of a logits row is 128 GRANULES of
 // two adjacent columns; a granule whose larger value reaches thr is kept: the kept granules (float2) are stored compacted, in column order, into the
 // piece's slot (at most 128 x 8 B: the slot cannot overflow), and the piece's record is two float4s: {max, sum exp(x - max), -, -} and the 128-bit mask of
@@ -239,6 +287,17 @@ __device__ __forceinline__ uint32_t fs_interleave16(uint32_t even, uint32_t odd)
 // exp(x - ml) as v_exp_f32((x - ml) * log2 e): the subtraction first -- exact near the maximum, so the largest value contributes exactly 1 (an FMA
 // form x * log2 e - ml * log2 e rounds the product of the MAGNITUDES: 2e-6 off at |ml| ~ 40, enough to push a dominant token's 1 - p below 0)
 __device__ __forceinline__ float fs_exp(float x, float ml) { return __builtin_amdgcn_exp2f((x - ml) * 1.4426950408889634f); }
+// g(a) = (e0 + e1) + (e2 + e3) of one accumulator fragment with the subtraction and the scaling as PACKED fp32 operations (v_pk_add_f32 / v_pk_mul_f32: two
+// values per instruction at the full VALU rate) -- the same IEEE operations on the same operands in the same order as four fs_exp calls, bit-identical
+typedef float fs_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float fs_exp_sum4(float x0, float x1, float x2, float x3, float ml) {
+    const fs_f32x2_t m2 = {ml, ml}, l2 = {1.4426950408889634f, 1.4426950408889634f};
+    const fs_f32x2_t a = {x0, x1}, b = {x2, x3};
+    const fs_f32x2_t da = (a - m2) * l2, db = (b - m2) * l2;
+    const fs_f32x2_t e02 = {__builtin_amdgcn_exp2f(da.x), __builtin_amdgcn_exp2f(db.x)}, e13 = {__builtin_amdgcn_exp2f(da.y), __builtin_amdgcn_exp2f(db.y)};
+    const fs_f32x2_t s = e02 + e13;                   // (e0 + e1, e2 + e3)
+    return s.x + s.y;
+}
 __device__ __forceinline__ void tile_combine16(const float (&ml)[16], const float (&pl)[16], float& M, float& E) {
     float m = ml[0];
 #pragma unroll

@@ -410,7 +410,7 @@ __global__ __launch_bounds__(512) void gemm_wide_fused_kernel(const GemmArgs p) 
             float gs[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
-                gs[a] = (fs_exp(acc[a][b][0], ml) + fs_exp(acc[a][b][1], ml)) + (fs_exp(acc[a][b][2], ml) + fs_exp(acc[a][b][3], ml));
+                gs[a] = fs_exp_sum4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3], ml);
             const float pl = (gs[0] + gs[1]) + (gs[2] + gs[3]);
             // keep bits: this lane's 8 granules sit at bits 8 a + 2 f + h of the quarter's word; the token's four lane groups (lanes FR_, 16 + FR_, 32 + FR_,
             // 48 + FR_) OR their shares together with two lane exchanges

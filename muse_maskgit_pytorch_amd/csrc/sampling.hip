@@ -54,36 +54,7 @@ __global__ __launch_bounds__(256) void mask_step_kernel(float* __restrict__ scor
     }
 }
 
-// ------------------------------------------------------------------------------------------------ Philox2x32-10
-// Counter-based: the uniform for (seed, global token row, decode step, vocabulary index v) is output (v & 1) of
-// Philox2x32-10 with the 64-bit counter  row << 24 | (step & 0xFF) << 16 | (v >> 1)  and a 32-bit key mixed from the seed.
-// One call serves two adjacent vocabulary entries; the kernel only evaluates it for the ~10 % kept entries.
-__device__ __forceinline__ void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t k, uint32_t (&out)[2]) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p = (uint64_t)0xD256D193u * c0;
-        const uint32_t n0 = (uint32_t)(p >> 32) ^ k ^ c1;
-        c1 = (uint32_t)p;
-        c0 = n0;
-        k += 0x9E3779B9u;
-    }
-    out[0] = c0; out[1] = c1;
-}
-
-__device__ __forceinline__ void philox_uniform2(uint64_t seed, uint64_t row_global, uint32_t step, uint32_t col2, float (&u)[2]) {
-    const uint64_t ctr = (row_global << 24) | ((uint64_t)(step & 0xFFu) << 16) | (uint64_t)(col2 & 0xFFFFu);
-    const uint32_t key = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x85EBCA6Bu) ^ ((step >> 8) * 0xC2B2AE35u);
-    uint32_t o[2];
-    philox2x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), key, o);
-    u[0] = (float)(o[0] >> 8) * (1.0f / 16777216.0f);   // 24-bit, [0, 1)
-    u[1] = (float)(o[1] >> 8) * (1.0f / 16777216.0f);
-}
-
-__device__ __forceinline__ float gumbel_of(float u) {
-    // -log(-log(u)) with the reference's clamps (mmp.py:403-408)
-    const float a = logf(fmaxf(u, 1e-20f));
-    return -logf(fmaxf(-a, 1e-20f));
-}
+// Philox2x32-10, philox_uniform2, gumbel_of / gumbel_of_unit: common.h (one definition for both sampling paths)
 
 __global__ __launch_bounds__(256) void philox_fill_kernel(uint64_t seed, uint64_t row_offset, uint32_t step, int rows, int V, float* out) {
     const int nv = V >> 2;
@@ -191,7 +162,7 @@ __device__ __forceinline__ float noise_gumbel(const SampleArgs& p, long pos_flat
     if (p.noise_kind == MM_NOISE_PHILOX) {
         float u[2];
         philox_uniform2(p.seed, p.row_offset + (uint64_t)pos_flat, p.step, (uint32_t)(idx >> 1), u);
-        return gumbel_of((idx & 1) ? u[1] : u[0]);
+        return gumbel_of_unit((idx & 1) ? u[1] : u[0]);
     }
     return 0.f;
 }

@@ -29,36 +29,14 @@ __device__ __forceinline__ uint32_t fkey(float f) {      // order-preserving flo
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-__device__ __forceinline__ void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t k, uint32_t (&out)[2]) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p = (uint64_t)0xD256D193u * c0;
-        const uint32_t n0 = (uint32_t)(p >> 32) ^ k ^ c1;
-        c1 = (uint32_t)p;
-        c0 = n0;
-        k += 0x9E3779B9u;
-    }
-    out[0] = c0; out[1] = c1;
-}
-__device__ __forceinline__ void philox_uniform2(uint64_t seed, uint64_t row_global, uint32_t step, uint32_t col2, float (&u)[2]) {      // == sampling.hip
-    const uint64_t ctr = (row_global << 24) | ((uint64_t)(step & 0xFFu) << 16) | (uint64_t)(col2 & 0xFFFFu);
-    const uint32_t key = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x85EBCA6Bu) ^ ((step >> 8) * 0xC2B2AE35u);
-    uint32_t o[2];
-    philox2x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), key, o);
-    u[0] = (float)(o[0] >> 8) * (1.0f / 16777216.0f);
-    u[1] = (float)(o[1] >> 8) * (1.0f / 16777216.0f);
-}
-__device__ __forceinline__ float gumbel_of(float u) {
-    const float a = logf(fmaxf(u, 1e-20f));
-    return -logf(fmaxf(-a, 1e-20f));
-}
+// Philox2x32-10, philox_uniform2, gumbel_of / gumbel_of_unit: common.h (one definition for both sampling paths)
 __device__ __forceinline__ float noise_gumbel(const FusedSampleArgs& p, long pos_flat, int idx) {
     if (p.noise_kind == MM_NOISE_GUMBEL) return p.noise[(size_t)pos_flat * p.noise_ld + idx];
     if (p.noise_kind == MM_NOISE_UNIFORM) return gumbel_of(p.noise[(size_t)pos_flat * p.noise_ld + idx]);
     if (p.noise_kind == MM_NOISE_PHILOX) {
         float u[2];
         philox_uniform2(p.seed, p.row_offset + (uint64_t)pos_flat, p.step, (uint32_t)(idx >> 1), u);
-        return gumbel_of((idx & 1) ? u[1] : u[0]);
+        return gumbel_of_unit((idx & 1) ? u[1] : u[0]);
     }
     return 0.f;
 }
@@ -108,21 +86,17 @@ constexpr int FT = 512, FW = FT / 64;
 constexpr int WSL = 1408;                       // per-wave slice of the candidate list; a wave gathers 1/8 of the tiles: ~1150 +- 35 values at V = 65536
 constexpr int LIST_CAP = FW * WSL;              // 11264 candidates of one row held in LDS as (fp32 value, u16 index): 66 KiB
 constexpr int NBF = 1024;                       // value-linear histogram bins over [thr_lo, row max]
-#if MM_EXP == 10
-constexpr int GU = 8;
-#else
-constexpr int GU = 16;                          // tiles per wave whose candidate loads are in flight together (2 rounds per row at V = 65536)
-#endif
+constexpr int GU = 16;                          // tiles per wave whose candidate loads are in flight together (2 rounds per row at V = 65536; 8: same time)
 constexpr int CANDF = 1024;                     // exact-select capacity (members of the bin that holds the k-th largest)
 
 struct FusedShared {
     float xs[LIST_CAP];
     uint16_t cols[LIST_CAP];
     uint32_t hist[NBF];                         // TRANSPOSED (hslotf): lane l's 16 consecutive bins form a conflict-free column
-    uint32_t cand[CANDF];
+    uint32_t cand[CANDF];                       // members of the bin that holds the k-th largest value: order-preserving keys ...
+    uint16_t candc[CANDF];                      // ... and their columns (the members >= the k-th largest belong to the kept set)
     float redf[FW], redx[FW];
     int redi[FW];
-    uint4 masks[256];                           // per piece: the 128-bit mask of its kept granules (common.h fs_pos)
     int wcnt[FW];
     int ncand;
     uint32_t thr_key;
@@ -158,7 +132,6 @@ __global__ __launch_bounds__(FT, 4) void sample_fused_kernel(const FusedSampleAr
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the gather's piece walk, its addresses and its branches are wave-uniform
     const int NT = p.V / 256;
-#if MM_EXP != 9
     // lane u < 32 of wave w holds the keep mask of piece w + 8 u (the wave's u-th piece) of the current row: read once per row straight from the
     // records, one row ahead, and handed to the gather through v_readlane (scalar registers, no LDS round trip)
     auto load_masks = [&](int r) -> uint4 {
@@ -171,23 +144,17 @@ __global__ __launch_bounds__(FT, 4) void sample_fused_kernel(const FusedSampleAr
         return m;
     };
     uint4 mkv = load_masks(blockIdx.x);
-#endif
+    // thread t < V / 256 holds piece t's softmax statistics {max, sum exp(x - max)} of the current row, read one row ahead as well
+    auto load_stats = [&](int r) -> float2 {
+        float2 st = make_float2(-INFINITY, 0.f);
+        if (r < p.R && tid < NT) { const float4 q = p.stats[((size_t)r * NT + tid) * FS_REC]; st = make_float2(q.x, q.y); }
+        return st;
+    };
+    float2 stv = load_stats(blockIdx.x);
     for (int row = blockIdx.x; row < p.R; row += gridDim.x) {
         const long pos_flat = p.rows ? (long)p.rows[row] : (long)row;
-        // ---- tile statistics -> row max, softmax denominator; the kept-lane masks are parked in LDS for the gather
-        float tmax = -INFINITY, tsum = 0.f;
-#if MM_EXP != 9
-        if (tid < NT) {
-            const float4 st = p.stats[((size_t)row * NT + tid) * FS_REC];
-            tmax = st.x; tsum = st.y;
-        }
-#else
-        if (tid < NT) {
-            const float4 st = p.stats[((size_t)row * NT + tid) * FS_REC], mk = p.stats[((size_t)row * NT + tid) * FS_REC + 1];
-            tmax = st.x; tsum = st.y;
-            S.masks[tid] = make_uint4(__float_as_uint(mk.x), __float_as_uint(mk.y), __float_as_uint(mk.z), __float_as_uint(mk.w));
-        }
-#endif
+        // ---- tile statistics -> row max, softmax denominator
+        const float tmax = stv.x, tsum = stv.y;
         const float wm = wave_max(tmax);
         if (lane == 0) S.redf[wid] = wm;
         if (tid == 0) S.ncand = 0;
@@ -208,7 +175,6 @@ __global__ __launch_bounds__(FT, 4) void sample_fused_kernel(const FusedSampleAr
         float* myx = S.xs + wid * WSL;
         uint16_t* myc = S.cols + wid * WSL;
         int wcount = 0;                                           // wave-uniform
-#if MM_EXP != 9
         // Dense gather: a piece's slot IS a compacted list (cnt = popcount of its keep mask granules, in column order), so lane e reads granule e -- one
         // coalesced 8-byte load per lane, no per-lane position arithmetic -- and only the granule NUMBER of entry e (the position of the e-th set bit of
         // the 128-bit mask) has to be found.  The mask is wave-uniform (scalar registers): the lane that owns bit J knows its rank (v_mbcnt), and one
@@ -258,55 +224,8 @@ __global__ __launch_bounds__(FT, 4) void sample_fused_kernel(const FusedSampleAr
                 }
             }
         }
-        mkv = load_masks(row + (int)gridDim.x);                  // the next row's masks arrive under the rest of this row
-#else
-        for (int t0 = wid; t0 < NT; t0 += FW * GU) {
-            float4 v[GU];
-            uint32_t mine_bits = 0;                               // bits 2 u + h: granule 2 lane + h (columns 4 lane + 2 h, + 1) of tile u was kept (packed: VGPR budget of 128 for two workgroups per CU)
-#pragma unroll
-            for (int u = 0; u < GU; ++u) {
-                const int t_ = t0 + u * FW;
-                v[u] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-                if (t_ < NT) {
-                    const uint4 mask = S.masks[t_];                // word q = lane >> 4, bits 2 (lane & 15) + h; position in the slot: common.h fs_pos
-                    const int q = lane >> 4, gq = 2 * (lane & 15);
-                    const uint32_t mq = q == 0 ? mask.x : (q == 1 ? mask.y : (q == 2 ? mask.z : mask.w));
-                    const uint32_t mu = (mq >> gq) & 3u;
-                    mine_bits |= mu << (2 * u);
-                    if (mu) {
-                        const float2* slot = reinterpret_cast<const float2*>(p.cand + ((size_t)row * NT + t_) * FS_SLOT) + fs_pos(mask, q, gq);
-                        if (mu & 1u) { const float2 a = slot[0]; v[u].x = a.x; v[u].y = a.y; }
-                        if (mu & 2u) { const float2 a = slot[mu & 1u]; v[u].z = a.x; v[u].w = a.y; }
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < GU; ++u) {
-                const int t_ = t0 + u * FW;
-                const float xv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-                // Every value >= the bound is appended to this wave's slice.  One wave-wide prefix sum of the per-lane counts (DPP row scan + three row
-                // totals) instead of a ballot / mbcnt pair per value: the gather is VALU-issue-bound.  The order of the entries
-                // changes with it (lane-major); nothing downstream depends on it (rank counting, ties by column).
-                bool kp[4];
-                int c = 0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { kp[i] = ((mine_bits >> (2 * u + (i >> 1))) & 1u) && xv[i] >= lo; c += kp[i] ? 1 : 0; }
-                int x = c;
-#define MM_SHR(x_, n_) __builtin_amdgcn_update_dpp(0, x_, 0x110 + (n_), 0xF, 0xF, true)
-                x += MM_SHR(x, 1); x += MM_SHR(x, 2); x += MM_SHR(x, 4); x += MM_SHR(x, 8);      // inclusive scan inside each row of 16 lanes
-#undef MM_SHR
-                const int r0 = __builtin_amdgcn_readlane(x, 15), r1 = __builtin_amdgcn_readlane(x, 31), r2 = __builtin_amdgcn_readlane(x, 47), r3 = __builtin_amdgcn_readlane(x, 63);
-                const int row16 = lane >> 4;
-                int idx = wcount + x - c + (row16 > 0 ? r0 : 0) + (row16 > 1 ? r1 : 0) + (row16 > 2 ? r2 : 0);      // exclusive prefix over the wave
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {      // (one write pass per lane's j-th passing value -- fewer, fuller LDS stores -- measured slower: 531 vs 470 us)
-                    if (kp[i] && idx < WSL) { myx[idx] = xv[i]; myc[idx] = (uint16_t)(t_ * 256 + lane * 4 + i); }
-                    idx += kp[i] ? 1 : 0;
-                }
-                wcount += (r0 + r1) + (r2 + r3);
-            }
-        }
-#endif
+        mkv = load_masks(row + (int)gridDim.x);                  // the next row's masks and statistics arrive under the rest of this row
+        stv = load_stats(row + (int)gridDim.x);
         // the histogram over THIS wave's slice, in a dense sweep (all 64 lanes busy: ~18 LDS atomic instructions per wave instead of the 128 sparse ones
         // an atomic per appended value inside the gather costs -- the LDS instruction slots, not the bytes, bound this kernel)
         if (fast) {
@@ -361,30 +280,47 @@ __global__ __launch_bounds__(FT, 4) void sample_fused_kernel(const FusedSampleAr
         }
         const bool slow = !fast || bcnt > CANDF;
         uint32_t thr;
+        int kept_w = 0;                                           // wave-uniform: this wave's kept entries, squeezed to the front of its slice
+        int n_side = 0;                                           // fast path: members of the threshold bin parked in S.cand / S.candc
+        const int cw = min(wcount, WSL);                          // (== wcount: the row passed `fits`)
         if (!slow) {
-            for (int i = tid; i < FW * WSL; i += FT) {
-                if (i % WSL >= S.wcnt[i / WSL]) continue;
-                const float x = S.xs[i];
-                if (min(NBF - 1, max(0, (int)((x - lo) * inv_w))) == tbin) { const int sl = atomicAdd(&S.ncand, 1); if (sl < CANDF) S.cand[sl] = fkey(x); }
+            // ONE sweep over the wave's slice: an entry above the threshold bin is kept whatever the exact threshold turns out to be -> squeezed to the front of
+            // the slice, in place (the write position never passes the read position; same wave: LDS accesses complete in program order); a member of the
+            // threshold bin is parked (key + column) for the exact select, and joins the Gumbel loop below if it reaches the k-th largest value
+            int wpos = 0;
+            for (int b0 = 0; b0 < cw; b0 += 64) {
+                const int i = b0 + lane;
+                const bool live = i < cw;
+                const float x = live ? myx[i] : 0.f;
+                const uint16_t c = live ? myc[i] : (uint16_t)0;
+                const int bn = min(NBF - 1, max(0, (int)((x - lo) * inv_w)));
+                const bool kp = live && bn > tbin;
+                const unsigned long long bal = __ballot(kp);
+                const int idx = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, (uint32_t)wpos));
+                if (kp) { myx[idx] = x; myc[idx] = c; }
+                wpos += __popcll(bal);
+                if (live && bn == tbin) { const int sl = atomicAdd(&S.ncand, 1); if (sl < CANDF) { S.cand[sl] = fkey(x); S.candc[sl] = c; } }
             }
+            kept_w = wpos;
             __syncthreads();
-            const int need_in = need - above, n_c = min(S.ncand, CANDF);
-            for (int i = tid; i < n_c; i += FT) {
+            const int need_in = need - above;
+            n_side = min(S.ncand, CANDF);                         // == bcnt <= CANDF
+            for (int i = tid; i < n_side; i += FT) {
                 const uint32_t ki = S.cand[i];
                 int gt = 0, ge = 0;
 #pragma unroll 4
-                for (int j = 0; j < n_c; ++j) { const uint32_t kj = S.cand[j]; gt += kj > ki; ge += kj >= ki; }
+                for (int j = 0; j < n_side; ++j) { const uint32_t kj = S.cand[j]; gt += kj > ki; ge += kj >= ki; }
                 if (gt < need_in && need_in <= ge) S.thr_key = ki;      // every thread that satisfies this holds the same key
             }
             __syncthreads();
             thr = S.thr_key;
         } else {
-            // massive ties / degenerate span: bisection over the 32 key bits on the LDS list
+            // massive ties / degenerate span: bisection over the 32 key bits on the LDS list, then the slice is squeezed down to the entries >= the k-th largest
             uint32_t prefix = 0;
             for (int bit = 31; bit >= 0; --bit) {
                 const uint32_t trial = prefix | (1u << bit);
                 int c = 0;
-                for (int i = tid; i < FW * WSL; i += FT) c += (i % WSL < S.wcnt[i / WSL]) && fkey(S.xs[i]) >= trial;
+                for (int i = lane; i < cw; i += 64) c += fkey(myx[i]) >= trial;
                 c = wave_sum_i(c);
                 __syncthreads();
                 if (lane == 0) S.redi[wid] = c;
@@ -395,43 +331,50 @@ __global__ __launch_bounds__(FT, 4) void sample_fused_kernel(const FusedSampleAr
             }
             __syncthreads();
             thr = prefix;
-        }
-        if (MM_EXP == 2) { __syncthreads(); continue; }      /* tools: + threshold */
-        // ---- every wave squeezes its slice down to the kept entries (value >= the k-th largest), in place: the write position never passes the
-        //      read position, so the Gumbel loop below runs on dense lanes (71 % of the candidates are kept, interleaved at random)
-        {
-            const int cw = S.wcnt[wid];
-            float* myx2 = S.xs + wid * WSL;
-            uint16_t* myc2 = S.cols + wid * WSL;
-            int wpos = 0;                                         // wave-uniform
+            int wpos = 0;
             for (int b0 = 0; b0 < cw; b0 += 64) {
                 const int i = b0 + lane;
-                const float x = i < cw ? myx2[i] : 0.f;
-                const uint16_t c = i < cw ? myc2[i] : (uint16_t)0;
+                const float x = i < cw ? myx[i] : 0.f;
+                const uint16_t c = i < cw ? myc[i] : (uint16_t)0;
                 const bool kp = i < cw && fkey(x) >= thr;
                 const unsigned long long bal = __ballot(kp);
                 const int idx = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, (uint32_t)wpos));
-                if (kp) { myx2[idx] = x; myc2[idx] = c; }        // (same wave: LDS accesses complete in program order)
+                if (kp) { myx[idx] = x; myc[idx] = c; }
                 wpos += __popcll(bal);
             }
-            __syncthreads();
-            if (lane == 0) S.wcnt[wid] = wpos;
-            __syncthreads();
+            kept_w = wpos;
         }
-        if (MM_EXP == 3) { __syncthreads(); continue; }      /* tools: + compaction */
-        // ---- Gumbel argmax over the kept entries (mmp.py:410-411); ties -> lower index
+        if (MM_EXP == 2) { __syncthreads(); continue; }      /* tools: up to the kept list */
+        // ---- Gumbel argmax over the kept entries (mmp.py:410-411); ties -> lower index.  Every wave scans its own dense slice (its own LDS writes: no barrier
+        //      needed), then the parked members of the threshold bin, 512 per round over the workgroup, those below the k-th largest masked out.  The result does
+        //      not depend on which lane sees which entry (ties go by column index).
         const float T = p.temperature;
         float best = -INFINITY, best_x = 0.f;
         int best_i = 0x7FFFFFFF;
-        {      // every wave scans its own (dense) slice: the result does not depend on which lane sees which entry (ties go by column index)
-            const int cw = S.wcnt[wid];
-            const float* myx3 = S.xs + wid * WSL;
-            const uint16_t* myc3 = S.cols + wid * WSL;
-            for (int i = lane; i < cw; i += 64) {
-                const float x = myx3[i];
-                const int idx = (int)myc3[i];
-                const float y = x / T + noise_gumbel(p, pos_flat, idx);
-                if (y > best || (y == best && idx < best_i)) { best = y; best_i = idx; best_x = x; }
+        {
+            const int nit = (kept_w + 63) >> 6;
+            const int nsd = (n_side > wid * 64 ? 1 : 0) + (n_side > FT + wid * 64 ? 1 : 0);      // rounds of parked members this wave takes part in (CANDF = 2 FT)
+            for (int it = 0; it < nit + nsd; ++it) {
+                const bool side = it >= nit;
+                const int i = side ? (it - nit) * FT + tid : it * 64 + lane;
+                bool live = side ? i < n_side : i < kept_w;
+                float x = 0.f;
+                int idx = 0;
+                if (live) {
+                    if (side) {
+                        const uint32_t k = S.cand[i];
+                        x = __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);      // inverse of fkey
+                        idx = (int)S.candc[i];
+                        live = k >= thr;
+                    } else {
+                        x = myx[i];
+                        idx = (int)myc[i];
+                    }
+                }
+                if (live) {
+                    const float y = x / T + noise_gumbel(p, pos_flat, idx);
+                    if (y > best || (y == best && idx < best_i)) { best = y; best_i = idx; best_x = x; }
+                }
             }
         }
 #pragma unroll
