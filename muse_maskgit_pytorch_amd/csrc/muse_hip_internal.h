@@ -129,6 +129,27 @@ struct AttnArgs {
 };
 int k_attention(hipStream_t s, const AttnArgs& a);
 
+// cross_fold.hip: cross-attention with the output projection folded into the (step-invariant) values, residual add and LayerNorm(dim)-fold producer epilogue
+struct CrossFoldArgs {
+    const bf16_t* q; long q_ld;                  // [seqs * nq][q_ld] bf16: the q projection's output (heads x 64 contiguous)
+    const bf16_t* khat;                          // k_cross_fold_pack: K^ fragments [kv_seqs][8][3][2][64][8]
+    const bf16_t* vwt;                           // k_cross_fold_pack: (V W_o^T)^T fragments [kv_seqs][32][9][64][8]
+    const uint8_t* key_mask; long km_sb;         // optional [seqs][m], 1 = keep
+    const float* q_scale;                        // [64]
+    float* x; long ldx;                          // fp32 residual stream [seqs * nq][ldx], updated in place
+    bf16_t* xb; long ldxb;                       // optional: bf16 image of the new rows ...
+    float* stp; int st_np;                       // ... and their (sum, sum of squares) per 64 columns [rows][st_np][2]
+    int seqs, nq, m, kv_batch_mod;
+    float scale;                                 // 8
+};
+bool k_cross_fold_eligible(int D, int I, int H, int dh, int m);
+size_t k_cross_fold_khat_elems(int kv_seqs);
+size_t k_cross_fold_vwt_elems(int kv_seqs);
+int k_cross_fold_pack(hipStream_t s, const bf16_t* ckv, int kv_seqs, int m, int I, const float* null_k, const float* null_v, const float* k_scale,
+                      const bf16_t* w_out, int ldw, bf16_t* khat, bf16_t* vwt);
+int k_cross_fold(hipStream_t s, const CrossFoldArgs& a);
+int k_cross_fold_null_row(hipStream_t s, const bf16_t* vwt, float* out);      // [512] fp32: what the kernel adds to a row whose text keys are all masked
+
 // vq.hip
 int k_vq_nearest(hipStream_t s, const float* x, long ldx, int N, int C, const float* cb, int K, int cosine, float* aux, int64_t* ids);
 int k_vq_gather(hipStream_t s, const int64_t* ids, long N, int C, const float* cb, float* out);

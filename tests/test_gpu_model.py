@@ -730,6 +730,52 @@ def test_layernorm_dim_fold_matches_the_unfolded_path(golden):
         assert e_f.max() < 0.03 * ref.abs().max() and e_f.mean() < 1.5 * e_u.mean() + 1e-4
 
 
+@pytest.mark.parametrize('n,L', [(80, 13), (256, 33), (7, 1)])
+def test_cross_attention_with_the_folded_output_projection_matches_the_two_kernel_path(n, L):
+    """mmp.py:139-162 on the headline shape class (dim = inner = 512, 8 heads x 64, <= 35 context tokens): the text context is the same at every
+    decode step, so the cross-attention's output projection is folded into its values once per context -- (P_h V_h) W_o,h^T = P_h (V_h W_o,h^T) -- and the
+    block behind the q projection is one kernel (csrc/cross_fold.hip: scores + softmax per head, one MFMA contraction over the 288 (head, key) pairs, residual
+    add, LayerNorm(dim)-fold producer outputs).  Debug bit 1 << 31 runs the two-kernel path (33-key attention, then the 512 x 512 projection): the two agree
+    to bf16 noise, both stay within the oracle tolerance; ragged text rows (key mask), the null pass (every text key masked: only
+    the null key is attended) and query counts that are no multiple of the 32-query workgroup.  (The decode loop, whose last layer runs this kernel on compacted
+    rows, is held to the reference goldens at full size by tests/test_gpu_base_size.py.)"""
+    torch.manual_seed(n * 100 + L)
+    V, depth, B = 1000, 2, 3
+    OFF = -(1 << 31)                                                   # debug bit 31 as a C int
+    t = mm.MaskGitTransformer(num_tokens=V, seq_len=n, dim=512, depth=depth, dim_head=64, heads=8, t5_name='t5-small')
+    with torch.no_grad():
+        for p in t.parameters():                                       # de-trivialise the gains / scales / null key and value
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    sd = {k: v.detach().float().clone() for k, v in t.state_dict().items()}
+    cfg = dict(depth=depth, heads=8)
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, V + 1, (B, n), generator=g)
+    te = torch.randn(B, L, 512, generator=g)
+    if L > 2:
+        te[1, L // 2:] = 0.                                            # zero-padded rows -> masked keys
+        te[2, L - 1:] = 0.
+    t = t.to(DEV)
+    lib = _lib.lib()
+    outs = {}
+    for bit in (0, OFF):
+        lib.mm_debug_set(bit)
+        try:
+            outs[bit] = [t(ids.to(DEV), text_embeds=te.to(DEV), cond_drop_prob=drop).float().cpu() for drop in (0., 1.)]
+        finally:
+            lib.mm_debug_set(0)
+    for i, drop in enumerate((0., 1.)):
+        a, b = outs[0][i], outs[OFF][i]
+        scale = b.abs().max()
+        d = (a - b).abs()
+        if drop == 0.:
+            assert d.max() > 0, 'the debug bit did not change the path'
+        assert d.max() < 0.02 * scale and d.mean() < 2e-3 * scale, (drop, d.max().item(), d.mean().item(), scale.item())
+        ref = O.transformer_forward(sd, cfg, ids, te, drop, rp=O.bf16_round)
+        e_f, e_u = _report(f'folded cross-attention n={n} L={L} drop={drop} vs oracle', a, ref), _report('... two-kernel path', b, ref)
+        assert e_f.max() < 0.03 * ref.abs().max() and e_f.mean() < 1.5 * e_u.mean() + 1e-4
+
+
 def test_full_size_c2_properties():
     """BASELINE configs[1] at FULL size (dim 512, depth 8, seq_len 256, codebook 65536; B = 8 to keep the fp32 oracle out of it):
     size-independent properties instead of an oracle comparison --
