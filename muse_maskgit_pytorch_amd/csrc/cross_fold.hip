@@ -1,24 +1,28 @@
-// Cross-attention of the decode loop with the output projection folded into the values (round 4):
-//     x += ( softmax(8 q^ . k^ + key mask) @ V ) W_o^T      (muse_maskgit_pytorch.py:139-162, context = the text encoding)
-// The text context is the same at every decode step, so K, V and everything linear behind V are step-invariant:
+// Cross-attention block of the decode loop as ONE kernel (round 4):
+//     x += ( softmax(8 q^ . k^ + key mask) @ V ) W_o^T,   q = LayerNorm(x) W_q^T      (muse_maskgit_pytorch.py:139-162, context = the text encoding)
+// Two observations.  (1) The text context is the same at every decode step, so K, V and everything linear behind V are step-invariant:
 //     (P_h V_h) W_o,h^T = P_h (V_h W_o,h^T) =: P_h VW_h          per head h, VW_h [keys][dim]
-// Packed once per generate and layer (k_cross_fold_pack): K^ (l2-normalised, scaled, bf16, null key first) and VW (bf16, null value first) -- then a layer's
-// cross-attention behind its q projection is ONE kernel instead of two (33-key attention + a 512 x 512 output projection with the fp32 residual, each of them
-// pure launch latency at 8192 rows: 13 + 17 us): scores and softmax per head, then out[query][:] = P_flat[query][(head, key)] . VW_flat -- one MFMA contraction
-// over the 8 x 36 = 288 (head, key) pairs -- the residual add, and the LayerNorm(dim)-fold producer outputs (bf16 row image + per-64-column statistics).
-// Fewer flops too: 2 x 288 x 512 per query instead of 2 x 512 x 512 + the P V products.
+// K^ (l2-normalised, scaled, bf16, null key first) and VW (bf16, null value first) are packed once per generate and layer (k_cross_fold_pack), and the
+// attention's P V product + the 512 x 512 output projection become one MFMA contraction over the 8 x 36 = 288 (head, key) pairs: fewer flops (2 x 288 x 512
+// per query instead of 2 x 512 x 512 + P V) and no second kernel.  (2) At 8192 rows the q projection, the 33-key attention and the output projection were
+// three launches of pure latency (17 + 13 + 17 us, matrix pipe 0.12 / 0.04); a workgroup that owns 32 complete rows can run all of it: q for its rows (the
+// LayerNorm(dim) fold's consumer side: raw bf16 rows x gain-folded weight, rstd * (acc - mean * c1) + c2), scores, softmax, P . VW, the residual add, and the
+// fold's producer outputs for the feed-forward behind it.
 //
-// Shape class (the headline config): dim = inner = 512, 8 heads x 64, <= 35 context tokens (+ the null key = 36 keys per head).  Everything else takes
-// the two-kernel path (model.hip cross_attn_block).
+// Shape class (the headline config): dim = inner = 512, 8 heads x 64, <= 35 context tokens (+ the null key = 36 keys per head), LayerNorm(dim) fold on.
+// Everything else takes the three-kernel path (model.hip cross_attn_block).
 //
-// One 512-thread workgroup = 32 queries of one sequence; grid = (ceil(nq / 32), sequences) = 256 workgroups at the base config.
-//   phase 0  every wave requests ITS 64 output features of VW_flat^T as MFMA A fragments straight into registers (36 x 16 B per lane; the pack kernel stores
-//            them fragment-major: one contiguous KiB per wave load).  They do not depend on the scores, so their L2 latency hides behind phases 1 and 2.
-//   phase 1  wave h = head h: q^ fragments (l2norm * q_scale while loading, as attention.hip), S^T = K^ Q^T on the MFMA (3 key blocks x 2 query blocks),
-//            mask, softmax over the head's <= 36 keys in registers (a lane owns 12 keys of ONE query), P -> bf16 -> LDS [32 queries][288] (592-byte rows:
-//            conflict-free for the 8-byte writes and the 16-byte fragment reads).
-//   phase 2  wave w = output features 64 w .. 64 w + 63: 9 k-blocks x (2 B-fragment reads + 8 MFMAs).
-//   phase 3  accumulator fragment = 4 consecutive features of one query: residual add in place, bf16 image, and the wave's 64 columns ARE one statistics partial.
+// One 512-thread workgroup = 32 queries of one sequence; all query blocks of a sequence sit on ONE XCD (they read the same 295 KB of VW fragments: out of HBM /
+// MALL once per sequence instead of once per query block: 22.7 -> 17.8 us when this was measured on the two-kernel form).
+//   phase A  the 32 raw rows (bf16 image of the residual stream) -> LDS (1040-byte rows: conflict-free fragment reads)
+//   phase B  wave h = head h: q_h = rows . Wq_h^T, 16 k-blocks x (2 B-fragment reads + 8 MFMAs); the weight fragments stream from L2 straight into registers
+//            (fragment-major pack: one contiguous KiB per wave load), two k-blocks ahead
+//   phase C  fold epilogue on the accumulators, l2norm * q_scale over the head's 64 features (16 per lane + two lane exchanges), q^ -> bf16.  An accumulator
+//            fragment (4 consecutive features of one query per lane) IS the B operand of v_mfma_f32_16x16x16_bf16: S^T = K^ Q^T needs no transposition.
+//            Mask, softmax over the head's <= 36 keys in registers, P -> bf16 -> LDS [32 queries][288] (592-byte rows).  The wave's 36 VW^T fragments
+//            (phase D's A operands) are requested at the start of this phase.
+//   phase D  wave w = output features 64 w .. 64 w + 63: 9 k-blocks x (2 B-fragment reads + 8 MFMAs)
+//   phase E  accumulator fragment = 4 consecutive features of one query: residual add in place, bf16 image, and the wave's 64 columns ARE one statistics partial
 #include <string.h>
 
 #include "common.h"
@@ -33,131 +37,208 @@ constexpr int XKF = XH * XKS;     // 288 = 9 MFMA k-blocks of 32
 constexpr int XKB = XKF / 32;
 constexpr int XD = 512;           // model dim = 8 waves x 64 output features
 constexpr int P_LD = 592;         // bytes per P row in LDS (288 bf16 + 16: rows start 20 banks apart -> 16 rows x 16 B cover the 64 banks exactly once)
+constexpr int X_LD = 1040;        // bytes per raw row in LDS (512 bf16 + 16: rows start 4 banks apart)
 constexpr float NEG_BIG = -3.0e38f;
 
+typedef __attribute__((ext_vector_type(4))) short bf16x4s_t;
+__device__ __forceinline__ f32x4_t mfma16k16(const uint2& a, const uint2& b, f32x4_t c) {      // 16 x 16 x 16: 4 consecutive k per lane
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf16x4s_t, a), __builtin_bit_cast(bf16x4s_t, b), c, 0, 0, 0);
+}
+
 __global__ __launch_bounds__(512, 2) void cross_fold_kernel(const CrossFoldArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char Xs[XQ * X_LD];
     __shared__ __attribute__((aligned(16))) unsigned char Ps[XQ * P_LD];
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int fr = lane & 15, fg = lane >> 4;
     // workgroup -> (sequence, query block): consecutive workgroup ids go round-robin to the 8 XCDs, each with its own L2.  All query blocks of one
-    // sequence read the same 295 KB of VW fragments, so they are placed on ONE XCD (sequence b lives on XCD b % 8): the fragments come out of HBM / MALL
-    // once per sequence instead of once per query block (round 4: 22.7 us -> see DESIGN.md, the kernel was bound by exactly that traffic)
+    // sequence read the same 295 KB of VW fragments, so they are placed on ONE XCD (sequence b lives on XCD b % 8)
     const int nqb = (p.nq + XQ - 1) / XQ;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int b = (slot / nqb) * 8 + xcd;
     if (b >= p.seqs) return;
     const int q0 = (slot % nqb) * XQ;
     const int kvb = p.kv_batch_mod > 0 ? b % p.kv_batch_mod : b;
+    const size_t row0 = (size_t)b * p.nq;
 
-    // key validity (the same for every query of the sequence): bit 0 = the null key (always attended, mmp.py:145-155), bit j = context token j - 1.  One byte per
-    // lane and a ballot -> a wave-uniform 64-bit mask (twelve dependent byte loads per lane would each cost a memory round trip)
-    unsigned long long valid64;
-    {
-        bool keep = lane < p.m;
-        if (keep && p.key_mask) keep = p.key_mask[(size_t)b * p.km_sb + lane] != 0;
-        valid64 = (__ballot(keep) << 1) | 1ull;
-    }
-    bool kvalid[3][4];
-#pragma unroll
-    for (int kb = 0; kb < 3; ++kb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) kvalid[kb][r] = (valid64 >> (kb * 16 + 4 * fg + r)) & 1ull;
-    // ---- loads of phase 1 first (vector memory returns in order: waiting for them must not wait for the 36 fragment loads behind them).
-    //      K^ fragments [kv sequence][head][3 key blocks][2 d-halves][64 lanes][8 bf16]; head = wave
-    uint4 kf[3][2];
-    {
-        const uint4* kp = reinterpret_cast<const uint4*>(p.khat) + ((size_t)kvb * XH + w) * 6 * 64 + lane;
-#pragma unroll
-        for (int kb = 0; kb < 3; ++kb)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) kf[kb][ks] = kp[(kb * 2 + ks) * 64];
-    }
-    float qs0[8], qs1[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { qs0[j] = p.q_scale[8 * fg + j]; qs1[j] = p.q_scale[32 + 8 * fg + j]; }
-    uint4 qraw[2][2];
+    // ---- requests, oldest first (vector memory returns in order): the key-mask byte and the rows' statistics partials, the raw rows, then the first five
+    //      k-blocks of this wave's q-weight fragments.  [head][4 feature blocks][16 k-blocks][64 lanes][8 bf16]: a wave load = one contiguous KiB
+    int kmb = 1;
+    if (p.key_mask && lane < p.m) kmb = p.key_mask[(size_t)b * p.km_sb + lane];
+    float4 part[2][4];      // 8 partials (sum, sum of squares) per row: dim 512 = 8 x 64 columns
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const int qi = q0 + qb * 16 + fr;
-        const bf16_t* qp = p.q + ((size_t)b * p.nq + (size_t)(qi < p.nq ? qi : 0)) * p.q_ld + w * 64;
-        qraw[qb][0] = *reinterpret_cast<const uint4*>(qp + 8 * fg);
-        qraw[qb][1] = *reinterpret_cast<const uint4*>(qp + 32 + 8 * fg);
+        const float4* pp = reinterpret_cast<const float4*>(p.stp_in + (row0 + (size_t)(qi < p.nq ? qi : 0)) * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part[qb][i] = pp[i];
     }
-    // ---- phase 0: this wave's VW^T fragments (A operands of phase 2): [kv sequence][32 feature blocks][9 k-blocks][64 lanes][8 bf16]
-    uint4 av[4][XKB];
+    // K^ fragments of head w for the 16 x 16 x 16 MFMA [kv sequence][head][3 key blocks][4 d-blocks][64 lanes][4 bf16], and the fold / scale constants of
+    // this lane's 16 features (64 w + 16 ob + 4 fg + r)
+    uint2 kf[3][4];
     {
-        const uint4* vp = reinterpret_cast<const uint4*>(p.vwt) + ((size_t)kvb * (XD / 16) + (size_t)w * 4) * XKB * 64 + lane;
+        const uint2* kp = reinterpret_cast<const uint2*>(p.khat) + ((size_t)kvb * XH + w) * 12 * 64 + lane;
 #pragma unroll
-        for (int kb = 0; kb < XKB; ++kb)      // (requested in the order phase 2 consumes them)
+        for (int kb = 0; kb < 3; ++kb)
 #pragma unroll
-            for (int ob = 0; ob < 4; ++ob) av[ob][kb] = vp[(ob * XKB + kb) * 64];
+            for (int ob = 0; ob < 4; ++ob) kf[kb][ob] = kp[(kb * 4 + ob) * 64];
     }
-    __builtin_amdgcn_sched_barrier(0);      // (keep the request order: phase-1 operands, then the fragments)
-
-    // ---- phase 1: head w
+    float4 c1[4], c2[4], qs[4];
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+        c1[ob] = *reinterpret_cast<const float4*>(p.c1 + w * 64 + ob * 16 + 4 * fg);
+        c2[ob] = p.c2 ? *reinterpret_cast<const float4*>(p.c2 + w * 64 + ob * 16 + 4 * fg) : make_float4(0.f, 0.f, 0.f, 0.f);      // (NULL: beta = 0)
+        qs[ob] = *reinterpret_cast<const float4*>(p.q_scale + ob * 16 + 4 * fg);
+    }
+    uint4 xr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = t + 512 * i, r = c >> 6, ch = c & 63;
+        const int qi = q0 + r;
+        xr[i] = *reinterpret_cast<const uint4*>(p.xb_in + (row0 + (size_t)(qi < p.nq ? qi : 0)) * p.ldxb_in + ch * 8);
+    }
+    constexpr int RING = 5;      // k-blocks of weight fragments in flight per wave (20 KiB: latency x L2 -> CU bandwidth at 8 waves)
+    const uint4* wp = reinterpret_cast<const uint4*>(p.wqf) + (size_t)w * 4 * 16 * 64 + lane;
+    uint4 wa[RING][4];
+#pragma unroll
+    for (int kb = 0; kb < RING; ++kb)
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) wa[kb][ob] = wp[(ob * 16 + kb) * 64];
+    // ---- phase A: raw rows -> LDS (rows past nq: the sequence's first row, never stored)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = t + 512 * i, r = c >> 6, ch = c & 63;
+        *reinterpret_cast<uint4*>(Xs + r * X_LD + ch * 16) = xr[i];
+    }
+    // key validity (the same for every query of the sequence): bit 0 = the null key (always attended, mmp.py:145-155), bit j = context token j - 1: a
+    // wave-uniform 64-bit mask from one byte per lane
+    asm volatile("" : "+v"(kmb));      // (the byte is consumed HERE, behind the row loads it was requested in front of -- not right behind its own request)
+    const unsigned long long valid64 = (__ballot(lane < p.m && kmb != 0) << 1) | 1ull;
+    // this lane's two queries: LayerNorm statistics of their raw rows (fold, consumer side; common.h ln_rstd_negmean on the partials read above)
+    float2 lnst[2];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
-        float v0[8], v1[8];
-        unpack8(qraw[qb][0], v0);
-        unpack8(qraw[qb][1], v1);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s1 += part[qb][i].x; s2 += part[qb][i].y; s1 += part[qb][i].z; s2 += part[qb][i].w; }      // (partials in index order, as ln_rstd_negmean)
+        const float mean = s1 * (1.f / (float)XD);
+        const float var = fmaxf(__builtin_fmaf(-mean, mean, s2 * (1.f / (float)XD)), 0.f);
+        lnst[qb] = make_float2(__builtin_amdgcn_rsqf(var + 1e-5f), -mean);
+    }
+    __syncthreads();      // the rows are in LDS
+    // ---- phase B: q_h = rows . Wq_h^T (head = wave), the weight fragments RING k-blocks ahead
+    f32x4_t accq[4][2];
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) accq[ob][qb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) {
+        uint4 bx[2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) bx[qb] = *reinterpret_cast<const uint4*>(Xs + (qb * 16 + fr) * X_LD + kb * 64 + fg * 16);
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) accq[ob][qb] = mfma16(wa[kb % RING][ob], bx[qb], accq[ob][qb]);
+        if (kb + RING < 16) {
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) wa[kb % RING][ob] = wp[(ob * 16 + kb + RING) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);      // (the refill is requested HERE: the scheduler otherwise sinks it to its use five k-blocks later and waits for it there)
+    }
+    // ---- phase C: fold epilogue + l2norm * q_scale: lane holds features 64 w + 16 ob + 4 fg + r of query fr (per query block)
+    uint2 qh[4][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const float rstd = lnst[qb].x, nmean = lnst[qb].y;
+        float qv[4][4];
         float ss = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ss += v0[j] * v0[j] + v1[j] * v1[j];
+        for (int ob = 0; ob < 4; ++ob) {
+            qv[ob][0] = ln_fold_apply(accq[ob][qb][0], rstd, nmean, c1[ob].x, c2[ob].x);
+            qv[ob][1] = ln_fold_apply(accq[ob][qb][1], rstd, nmean, c1[ob].y, c2[ob].y);
+            qv[ob][2] = ln_fold_apply(accq[ob][qb][2], rstd, nmean, c1[ob].z, c2[ob].z);
+            qv[ob][3] = ln_fold_apply(accq[ob][qb][3], rstd, nmean, c1[ob].w, c2[ob].w);
+            ss += (qv[ob][0] * qv[ob][0] + qv[ob][1] * qv[ob][1]) + (qv[ob][2] * qv[ob][2] + qv[ob][3] * qv[ob][3]);
+        }
         ss += __shfl_xor(ss, 16, 64);
         ss += __shfl_xor(ss, 32, 64);
         const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);      // F.normalize eps (mmp.py:41-42)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { v0[j] = v0[j] * inv * qs0[j]; v1[j] = v1[j] * inv * qs1[j]; }
-        const uint4 qf0 = pack8(v0), qf1 = pack8(v1);
-        // S^T = K^ Q^T: a[r] = score(key 16 kb + 4 fg + r, query fr of this block)
-        float s[3][4];
-        float mx = NEG_BIG;
+        for (int ob = 0; ob < 4; ++ob)
+            qh[ob][qb] = make_uint2(pack_bf16x2(qv[ob][0] * inv * qs[ob].x, qv[ob][1] * inv * qs[ob].y),
+                                    pack_bf16x2(qv[ob][2] * inv * qs[ob].z, qv[ob][3] * inv * qs[ob].w));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // this wave's VW^T fragments (A operands of phase D) are requested now, behind the q accumulators' registers: [kv sequence][32 feature blocks][9 k-blocks]
+    // [64 lanes][8 bf16]; they arrive under the scores and the softmax
+    uint4 av[4][XKB];
+    {
+        const uint4* vp = reinterpret_cast<const uint4*>(p.vwt) + ((size_t)kvb * (XD / 16) + (size_t)w * 4) * XKB * 64 + lane;
 #pragma unroll
-        for (int kb = 0; kb < 3; ++kb) {
-            f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            a = mfma16(kf[kb][0], qf0, a);
-            a = mfma16(kf[kb][1], qf1, a);
+        for (int kb = 0; kb < XKB; ++kb)      // (requested in the order phase D consumes them)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s[kb][r] = kvalid[kb][r] ? a[r] * p.scale : NEG_BIG;
-                mx = fmaxf(mx, s[kb][r]);
-            }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
+            for (int ob = 0; ob < 4; ++ob) av[ob][kb] = vp[(ob * XKB + kb) * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        bool kvalid[3][4];
 #pragma unroll
         for (int kb = 0; kb < 3; ++kb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s[kb][r] = kvalid[kb][r] ? __expf(s[kb][r] - mx) : 0.f;      // (the null key is always valid: mx is a real score, sum >= 1)
-                sum += s[kb][r];
-            }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        const float linv = 1.f / sum;
-        // P[query][36 w + key], keys 0 .. 35 of this head (the third key block only holds keys 32 .. 35: its lanes fg = 0)
-        unsigned char* prow = Ps + (qb * 16 + fr) * P_LD + w * (XKS * 2);
+            for (int r = 0; r < 4; ++r) kvalid[kb][r] = (valid64 >> (kb * 16 + 4 * fg + r)) & 1ull;
 #pragma unroll
-        for (int kb = 0; kb < 3; ++kb) {
-            if (kb == 2 && fg != 0) continue;
-            *reinterpret_cast<uint2*>(prow + (kb * 16 + 4 * fg) * 2) =
-                make_uint2(pack_bf16x2(s[kb][0] * linv, s[kb][1] * linv), pack_bf16x2(s[kb][2] * linv, s[kb][3] * linv));
+        for (int qb = 0; qb < 2; ++qb) {
+            // S^T = K^ Q^T: a[r] = score(key 16 kb + 4 fg + r, query fr of this block)
+            float s[3][4];
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb) {
+                f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ob = 0; ob < 4; ++ob) a = mfma16k16(kf[kb][ob], qh[ob][qb], a);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s[kb][r] = kvalid[kb][r] ? a[r] * p.scale : NEG_BIG;
+                    mx = fmaxf(mx, s[kb][r]);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s[kb][r] = kvalid[kb][r] ? __expf(s[kb][r] - mx) : 0.f;      // (the null key is always valid: mx is a real score, sum >= 1)
+                    sum += s[kb][r];
+                }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float linv = 1.f / sum;
+            // P[query][36 w + key], keys 0 .. 35 of this head (the third key block only holds keys 32 .. 35: its lanes fg = 0)
+            unsigned char* prow = Ps + (qb * 16 + fr) * P_LD + w * (XKS * 2);
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb) {
+                if (kb == 2 && fg != 0) continue;
+                *reinterpret_cast<uint2*>(prow + (kb * 16 + 4 * fg) * 2) =
+                    make_uint2(pack_bf16x2(s[kb][0] * linv, s[kb][1] * linv), pack_bf16x2(s[kb][2] * linv, s[kb][3] * linv));
+            }
         }
     }
-    // the residual rows of this wave's features (phase 3) are requested now: they arrive under phase 2
+    // the residual rows of this wave's features (phase E) are requested now: they arrive under phase D
     float4 res[2][4];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const int qi = q0 + qb * 16 + fr;
-        const float* xr = p.x + ((size_t)b * p.nq + (size_t)(qi < p.nq ? qi : 0)) * p.ldx + w * 64 + 4 * fg;
+        const float* xr = p.x + (row0 + (size_t)(qi < p.nq ? qi : 0)) * p.ldx + w * 64 + 4 * fg;
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob) res[qb][ob] = *reinterpret_cast<const float4*>(xr + ob * 16);
     }
     __syncthreads();
 
-    // ---- phase 2: out^T[feature][query] = VW^T . P^T over the 288 (head, key) pairs
+    // ---- phase D: out^T[feature][query] = VW^T . P^T over the 288 (head, key) pairs
     f32x4_t acc[4][2];
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob)
@@ -174,12 +255,12 @@ __global__ __launch_bounds__(512, 2) void cross_fold_kernel(const CrossFoldArgs 
             for (int qb = 0; qb < 2; ++qb) acc[ob][qb] = mfma16(av[ob][kb], pf[qb], acc[ob][qb]);
     }
 
-    // ---- phase 3: x += out (fp32, in place), bf16 image + this wave's 64-column statistics partial of the new row (LayerNorm(dim) fold, producer side)
+    // ---- phase E: x += out (fp32, in place), bf16 image + this wave's 64-column statistics partial of the new row (LayerNorm(dim) fold, producer side)
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const int qi = q0 + qb * 16 + fr;
         const bool ok = qi < p.nq;
-        const size_t row = (size_t)b * p.nq + (size_t)(ok ? qi : 0);
+        const size_t row = row0 + (size_t)(ok ? qi : 0);
         // statistics in the canonical order of every fold producer (common.h row_stats16: a balanced tree over the 64 columns in natural order, so the
         // decode loop's null half -- whose rows get the constant null-pass row in the self-attention's output projection -- and the general path -- which
         // runs this kernel on the null pass too -- hand bit-identical (sum, sum of squares) to the next LayerNorm fold): columns 16 ob + 4 fg + r
@@ -212,8 +293,8 @@ __global__ __launch_bounds__(512, 2) void cross_fold_kernel(const CrossFoldArgs 
 }
 
 // ---- pack, once per generate and layer.  grid (kv sequences, heads, 2 halves of the features), 256 threads.
-//   khat  [s][h][3 key blocks][2 d-halves][64 lanes][8]: K^ = bf16(k / max(|k|, eps) * k_scale) of key (16 kb + lane % 16), d = 32 ks + 8 (lane / 16) .. + 7; key 0 = the
-//         null key (fp32 parameter, mmp.py:145-149), key j = context token j - 1 (the K half of ckv, bf16), keys > m zero
+//   khat  [s][h][3 key blocks][4 d-blocks][64 lanes][4]: K^ = bf16(k / max(|k|, eps) * k_scale) of key (16 kb + lane % 16), d = 16 ob + 4 (lane / 16) .. + 3 (the A operand
+//         of the 16 x 16 x 16 MFMA); key 0 = the null key (fp32 parameter, mmp.py:145-149), key j = context token j - 1 (the K half of ckv, bf16), keys > m zero
 //   vwt   [s][32 feature blocks][9 k-blocks][64 lanes][8]: VW^T[feature 16 ob + lane % 16][flat k = 32 kb + 8 (lane / 16) .. + 7], flat k = 36 head + key,
 //         VW[key][feature] = bf16( sum_d v[key][64 head + d] * W_o[feature][64 head + d] ), v[0] = bf16(null_v) like attention.hip, keys > m zero
 __global__ __launch_bounds__(256) void cross_fold_pack_kernel(const bf16_t* __restrict__ ckv, int m, int I, const float* __restrict__ null_k, const float* __restrict__ null_v,
@@ -242,11 +323,11 @@ __global__ __launch_bounds__(256) void cross_fold_pack_kernel(const bf16_t* __re
             ss += v * v;
         }
         const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
-        bf16_t* kb_ = khat + ((size_t)s * XH + h) * 6 * 64 * 8;
+        bf16_t* kb_ = khat + ((size_t)s * XH + h) * 12 * 64 * 4;
 #pragma unroll
         for (int d = 0; d < 64; ++d) {
-            const int kb = key >> 4, frk = key & 15, ks = d >> 5, fgk = (d & 31) >> 3, j = d & 7;
-            kb_[(((kb * 2 + ks) * 64) + fgk * 16 + frk) * 8 + j] = f32_to_bf16(k[d] * inv * k_scale[d]);
+            const int kb = key >> 4, frk = key & 15, ob = d >> 4, fgk = (d & 15) >> 2, j = d & 3;
+            kb_[(((kb * 4 + ob) * 64) + fgk * 16 + frk) * 4 + j] = f32_to_bf16(k[d] * inv * k_scale[d]);
         }
     }
     __syncthreads();
@@ -293,16 +374,33 @@ __global__ __launch_bounds__(256) void cross_fold_null_row_kernel(const bf16_t* 
     out[o] = a;
 }
 
+// the gain-folded q weight [512 features][512] as MFMA A fragments: [head][4 feature blocks][16 k-blocks][64 lanes][8] (a wave load = one contiguous KiB).  Once per
+// generate and layer (0.5 MB; the weight itself is step-invariant, the packed copy lives in the workspace)
+__global__ __launch_bounds__(256) void cross_fold_wq_pack_kernel(const bf16_t* __restrict__ wq, int ldw, bf16_t* __restrict__ wqf) {
+    const int c = blockIdx.x * 256 + threadIdx.x;      // one 16-byte chunk per thread: (feature o, k-chunk kc of 8)
+    if (c >= XD * (XD / 8)) return;
+    const int o = c >> 6, kc = c & 63;
+    const int h = o >> 6, ob = (o & 63) >> 4, fro = o & 15, kb = kc >> 2, fgk = kc & 3;
+    reinterpret_cast<uint4*>(wqf)[(((size_t)(h * 4 + ob) * 16 + kb) * 64) + fgk * 16 + fro] = *reinterpret_cast<const uint4*>(wq + (size_t)o * ldw + kc * 8);
+}
+
 }  // namespace
 
 bool k_cross_fold_eligible(int D, int I, int H, int dh, int m) { return D == XD && I == XD && H == XH && dh == 64 && m >= 1 && m + 1 <= XKS; }
-size_t k_cross_fold_khat_elems(int kv_seqs) { return (size_t)kv_seqs * XH * 6 * 64 * 8; }
+size_t k_cross_fold_khat_elems(int kv_seqs) { return (size_t)kv_seqs * XH * 12 * 64 * 4; }
+size_t k_cross_fold_wqf_elems() { return (size_t)XD * XD; }
 size_t k_cross_fold_vwt_elems(int kv_seqs) { return (size_t)kv_seqs * XD * XKF; }
 
 int k_cross_fold_pack(hipStream_t s, const bf16_t* ckv, int kv_seqs, int m, int I, const float* null_k, const float* null_v, const float* k_scale,
-                      const bf16_t* w_out, int ldw, bf16_t* khat, bf16_t* vwt) {
+                      const bf16_t* w_out, int ldw, const bf16_t* w_q_ln, int ldwq, bf16_t* khat, bf16_t* vwt, bf16_t* wqf) {
     if (kv_seqs <= 0) return MM_OK;
-    if (!null_k || !null_v || !k_scale) return mm_set_error(MM_ERR_SHAPE, "cross_fold_pack: null key / value and k_scale required");
+    if (!null_k || !null_v || !k_scale || !w_q_ln) return mm_set_error(MM_ERR_SHAPE, "cross_fold_pack: null key / value, k_scale and the gain-folded q weight required");
+    if (ldwq % 8) return mm_set_error(MM_ERR_SHAPE, "cross_fold_pack: unaligned q weight rows");
+    hipLaunchKernelGGL(cross_fold_wq_pack_kernel, dim3(XD * (XD / 8) / 256), dim3(256), 0, s, w_q_ln, ldwq, wqf);
+    {
+        const int rc = mm_check_launch("cross_fold_wq_pack_kernel");
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(cross_fold_pack_kernel, dim3(kv_seqs, XH, 2), dim3(256), 0, s, ckv, m, I, null_k, null_v, k_scale, w_out, ldw, khat, vwt);
     return mm_check_launch("cross_fold_pack_kernel");
 }
@@ -315,7 +413,8 @@ int k_cross_fold_null_row(hipStream_t s, const bf16_t* vwt, float* out) {
 int k_cross_fold(hipStream_t s, const CrossFoldArgs& a) {
     if (a.seqs <= 0 || a.nq <= 0) return MM_OK;
     if (a.m < 1 || a.m + 1 > XKS) return mm_set_error(MM_ERR_SHAPE, "cross_fold: 1 <= context tokens <= 35");
-    if ((a.ldx % 4) || (a.q_ld % 8) || (a.xb && (a.ldxb % 4))) return mm_set_error(MM_ERR_SHAPE, "cross_fold: unaligned rows");
+    if ((a.ldx % 4) || (a.ldxb_in % 8) || (a.xb && (a.ldxb % 4))) return mm_set_error(MM_ERR_SHAPE, "cross_fold: unaligned rows");
+    if (!a.xb_in || !a.stp_in || a.in_np != XD / 64 || !a.wqf || !a.c1 || !a.q_scale) return mm_set_error(MM_ERR_SHAPE, "cross_fold: fold inputs of the q projection required");
     const int nqb = (a.nq + XQ - 1) / XQ;
     hipLaunchKernelGGL(cross_fold_kernel, dim3(8 * ((a.seqs + 7) / 8) * nqb), dim3(512), 0, s, a);
     return mm_check_launch("cross_fold_kernel");

@@ -422,24 +422,40 @@ int self_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weight
     return MM_OK;
 }
 
-// Output projection folded into the (step-invariant) cross-attention values (cross_fold.hip): bf16 engine, the headline shape class (dim = inner = 512, 8 heads
-// x 64, <= 35 context tokens); debug bit 1 << 31 turns it off (A/B and the closeness test; bits 16 .. 23 are attention.hip's repetition count)
+// The cross-attention block as one kernel (cross_fold.hip: q projection on the LayerNorm(dim) fold's consumer side, attention with the output projection folded into
+// the step-invariant values, residual, fold producer outputs): bf16 engine with the LayerNorm(dim) fold on, the headline shape class (dim = inner = 512, 8 heads x 64,
+// <= 35 context tokens); debug bit 1 << 31 turns it off (A/B and the closeness test; bits 16 .. 23 are attention.hip's repetition count)
 bool cross_fold_on(const mm_transformer* t, const mm_attn_weights& w, int m) {
-    return !t->P && !t->F8 && !(g_mm_debug & (int)0x80000000) && k_cross_fold_eligible(t->d.dim, t->I, t->d.heads, t->d.dim_head, m) && w.null_k && w.null_v &&
-           w.q_scale && w.k_scale;
+    return ln_fold_on(t) && !(g_mm_debug & (int)0x80000000) && k_cross_fold_eligible(t->d.dim, t->I, t->d.heads, t->d.dim_head, m) && w.null_k && w.null_v &&
+           w.q_scale && w.k_scale && w.w_q_ln && w.ln_c1;      // (ln_c2 is NULL for the reference's LayerNorm: its beta is a zeros buffer)
 }
-// the packed operands of one layer: K^ and (V W_o^T)^T of every kv sequence, from ckv = ctx @ to_kv^T
-int cross_fold_pack(const mm_transformer* t, hipStream_t s, const mm_attn_weights& w, const bf16_t* ckv, int kv_seqs, int m, bf16_t* khat, bf16_t* vwt) {
-    return k_cross_fold_pack(s, ckv, kv_seqs, m, t->I, w.null_k, w.null_v, w.k_scale, (const bf16_t*)w.w_out, t->I, khat, vwt);
+// the packed operands of one layer: K^ and (V W_o^T)^T of every kv sequence (from ckv = ctx @ to_kv^T) and the gain-folded q weight as MFMA fragments
+struct CrossFoldPack { bf16_t* khat; bf16_t* vwt; bf16_t* wqf; };
+int cross_fold_pack(const mm_transformer* t, hipStream_t s, const mm_attn_weights& w, const bf16_t* ckv, int kv_seqs, int m, const CrossFoldPack& pk) {
+    return k_cross_fold_pack(s, ckv, kv_seqs, m, t->I, w.null_k, w.null_v, w.k_scale, (const bf16_t*)w.w_out, t->I, (const bf16_t*)w.w_q_ln, t->d.dim, pk.khat, pk.vwt, pk.wqf);
 }
 
 // x += CrossAttention(x, ctx) for `seqs` sequences; ckv = ctx @ to_kv^T given as [kv_seqs*m][2I]  (mmp.py:191)
-// khat / vwt (cross_fold_pack of this layer, or NULL): behind the q projection the block is then ONE kernel (cross_fold.hip)
+// pk (cross_fold_pack of this layer, or NULL) with fold_in: the whole block is ONE kernel (cross_fold.hip)
 int cross_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weights& w, int seqs, int n, const bf16_t* ckv,
                      int m, int kv_batch_mod, const uint8_t* key_mask, Bufs& b, bool fold_in = false, bool fold_out = false,
-                     const bf16_t* khat = nullptr, const bf16_t* vwt = nullptr) {
+                     const CrossFoldPack* pk = nullptr) {
     const int D = t->d.dim, I = t->I, H = t->d.heads, dh = t->d.dim_head;
     const int rows = seqs * n;
+    if (pk && fold_in && !t->P && !t->F8 && w.w_q_ln && w.ln_c1) {
+        CrossFoldArgs f;
+        memset(&f, 0, sizeof(f));
+        f.xb_in = b.xb; f.ldxb_in = D; f.stp_in = b.stp; f.in_np = ln_fold_np(D);
+        f.wqf = pk->wqf; f.c1 = w.ln_c1; f.c2 = w.ln_c2; f.khat = pk->khat; f.vwt = pk->vwt;
+        f.key_mask = key_mask; f.km_sb = m; f.q_scale = w.q_scale;
+        f.x = b.x; f.ldx = D;
+        if (fold_out) { f.xb = b.xb; f.ldxb = D; f.stp = b.stp; f.st_np = ln_fold_np(D); }
+        f.seqs = seqs; f.nq = n; f.m = m; f.kv_batch_mod = kv_batch_mod; f.scale = 8.f;
+        TR(b.xb, (size_t)rows * D * 2);
+        RC(k_cross_fold(s, f));
+        TR(b.x, (size_t)rows * D * 4);
+        return MM_OK;
+    }
     if (t->P) {      // precision tier: ckv is fp32 [kv_seqs*m][2I]
         const int P = t->P;
         RC(k_layernorm_split(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, t->PC, b.xn, nullptr, nullptr, 0, nullptr));
@@ -478,18 +494,6 @@ int cross_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weigh
         RC(gemm_dense(t, s, b.xn, D, (const bf16_t*)w.w_q, D, rows, I, D, b.qkv, I, OUT_BF16, nullptr));
     }
     TR(b.qkv, (size_t)rows * I * 2);
-    if (khat && vwt && !t->F8) {      // attention + output projection + residual (+ the fold data of the new rows) in one kernel on the packed operands
-        CrossFoldArgs f;
-        memset(&f, 0, sizeof(f));
-        f.q = b.qkv; f.q_ld = I; f.khat = khat; f.vwt = vwt;
-        f.key_mask = key_mask; f.km_sb = m; f.q_scale = w.q_scale;
-        f.x = b.x; f.ldx = D;
-        if (fold_out) { f.xb = b.xb; f.ldxb = D; f.stp = b.stp; f.st_np = ln_fold_np(D); }
-        f.seqs = seqs; f.nq = n; f.m = m; f.kv_batch_mod = kv_batch_mod; f.scale = 8.f;
-        RC(k_cross_fold(s, f));
-        TR(b.x, (size_t)rows * D * 4);
-        return MM_OK;
-    }
     AttnArgs a;
     memset(&a, 0, sizeof(a));
     a.q = b.qkv; a.q_sb = (long)n * I; a.q_sh = dh; a.q_sn = I;
@@ -640,6 +644,7 @@ size_t mm_transformer_workspace_bytes(const mm_transformer_t* t, int B, int n, i
     c.take<bf16_t>((size_t)B * n * t->d.dim * (t->P ? t->P : 1));  // embed when the caller does not want it
     c.take<bf16_t>(k_cross_fold_khat_elems(B));                    // packed cross-attention operands of one layer (cross_fold.hip; reserved whatever the shape)
     c.take<bf16_t>(k_cross_fold_vwt_elems(B));
+    c.take<bf16_t>(k_cross_fold_wqf_elems());
     return c.used() + 256;
 }
 
@@ -659,8 +664,10 @@ int mm_transformer_forward(const mm_transformer_t* t, mm_stream_t stream, const 
     const int P = t->P, KD = (P ? P : 1) * D;      // operand row width of the GEMMs that read [.][D] activations
     bf16_t* ckv = c.take<bf16_t>((size_t)B * m * 2 * I * (P ? 2 : 1));
     bf16_t* emb = c.take<bf16_t>((size_t)rows * KD);
-    bf16_t* khat = c.take<bf16_t>(k_cross_fold_khat_elems(B));
-    bf16_t* vwt = c.take<bf16_t>(k_cross_fold_vwt_elems(B));
+    CrossFoldPack pk;
+    pk.khat = c.take<bf16_t>(k_cross_fold_khat_elems(B));
+    pk.vwt = c.take<bf16_t>(k_cross_fold_vwt_elems(B));
+    pk.wqf = c.take<bf16_t>(k_cross_fold_wqf_elems());
     if (embed_out) emb = (bf16_t*)embed_out;
 
     trace::idx = 0;
@@ -676,8 +683,8 @@ int mm_transformer_forward(const mm_transformer_t* t, mm_stream_t stream, const 
         RC(gemm_dense(t, s, (const bf16_t*)ctx, KD, (const bf16_t*)w.cross_attn.w_kv, KD, B * m, 2 * I, KD, ckv, 2 * I, P ? OUT_F32 : OUT_BF16, nullptr));
         TR(ckv, (size_t)B * m * 2 * I * 2);
         const bool xf = cross_fold_on(t, w.cross_attn, m);
-        if (xf) RC(cross_fold_pack(t, s, w.cross_attn, ckv, B, m, khat, vwt));
-        RC(cross_attn_block(t, s, w.cross_attn, B, n, ckv, m, 0, key_mask, b, fold, fold && l > 0, xf ? khat : nullptr, xf ? vwt : nullptr));
+        if (xf) RC(cross_fold_pack(t, s, w.cross_attn, ckv, B, m, pk));
+        RC(cross_attn_block(t, s, w.cross_attn, B, n, ckv, m, 0, key_mask, b, fold, fold && l > 0, xf ? &pk : nullptr));
         RC(ff_block(t, s, w.ff, b.x, b.x, rows, b, nullptr, 0, fold && l > 0, fold && l + 1 < t->d.depth));
     }
     if (P) RC(k_layernorm_split(s, b.x, D, rows, D, t->d.final_gamma, t->d.final_beta, nullptr, t->PC, emb, nullptr, nullptr, 0, nullptr));
@@ -702,7 +709,8 @@ struct GenBufs {
     uint8_t* masks;         // [2B][m]: cond masks then null masks
     bf16_t* ckv;            // [depth][B*m][2I]
     bf16_t* khat;           // [depth][...] packed cross-attention operands (cross_fold.hip): K^ fragments ...
-    bf16_t* vwt;            // ... and (V W_o^T)^T fragments of every layer, or NULL (shape class not covered)
+    bf16_t* vwt;            // ... (V W_o^T)^T fragments ...
+    bf16_t* wqf;            // ... and gain-folded q weight fragments of every layer, or NULL (shape class not covered)
     float* cvec;            // [depth][D]: to_out(null_v) of each cross-attention (base model null pass)
     bf16_t* nullv;          // [I] scratch
     int32_t* rows;          // [B*n]
@@ -760,7 +768,8 @@ void carve_gen(Carver& c, const mm_transformer* t, int B, int n, int L, int nc, 
     const bool xf = !t->P && !t->F8 && k_cross_fold_eligible(D, I, t->d.heads, t->d.dim_head, m);      // (sized by shape only: the debug switch must not change the workspace)
     g.khat = c.take<bf16_t>(xf ? (size_t)t->d.depth * k_cross_fold_khat_elems(B) : 0);
     g.vwt = c.take<bf16_t>(xf ? (size_t)t->d.depth * k_cross_fold_vwt_elems(B) : 0);
-    if (!xf) { g.khat = nullptr; g.vwt = nullptr; }
+    g.wqf = c.take<bf16_t>(xf ? (size_t)t->d.depth * k_cross_fold_wqf_elems() : 0);
+    if (!xf) { g.khat = nullptr; g.vwt = nullptr; g.wqf = nullptr; }
     g.cvec = c.take<float>((size_t)t->d.depth * D);
     g.nullv = c.take<bf16_t>((size_t)I * seg + 64);
     g.rows = c.take<int32_t>((size_t)B * n);
@@ -902,8 +911,10 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
         const mm_attn_weights& w = t->layers[l].cross_attn;
         bf16_t* ckv_l = g.ckv + (size_t)l * B * m * 2 * I * (PT ? 2 : 1);
         RC(gemm_dense(t, s, g.ctx, KD, (const bf16_t*)w.w_kv, KD, B * m, 2 * I, KD, ckv_l, 2 * I, PT ? OUT_F32 : OUT_BF16, nullptr));
-        if (g.khat && cross_fold_on(t, w, m))
-            RC(cross_fold_pack(t, s, w, ckv_l, B, m, g.khat + (size_t)l * k_cross_fold_khat_elems(B), g.vwt + (size_t)l * k_cross_fold_vwt_elems(B)));
+        if (g.khat && cross_fold_on(t, w, m)) {
+            const CrossFoldPack pk = {g.khat + (size_t)l * k_cross_fold_khat_elems(B), g.vwt + (size_t)l * k_cross_fold_vwt_elems(B), g.wqf + (size_t)l * k_cross_fold_wqf_elems()};
+            RC(cross_fold_pack(t, s, w, ckv_l, B, m, pk));
+        }
         if (nc == 0 && P == 2) {
             // softmax over the single unmasked (null) key is exactly 1 -> attention out = bf16(null_v) for every
             // query, so the null pass's cross-attention is the constant row to_out(null_v)
@@ -986,8 +997,8 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
             const bool null_const = P == 2 && nc == 0;
             const float* cvec_l = g.cvec + (size_t)l * D;
             const bool xf = g.khat && cross_fold_on(t, w.cross_attn, m);
-            const bf16_t* khat_l = xf ? g.khat + (size_t)l * k_cross_fold_khat_elems(B) : nullptr;
-            const bf16_t* vwt_l = xf ? g.vwt + (size_t)l * k_cross_fold_vwt_elems(B) : nullptr;
+            const CrossFoldPack pk_l = {g.khat + (size_t)l * k_cross_fold_khat_elems(B), g.vwt + (size_t)l * k_cross_fold_vwt_elems(B), g.wqf + (size_t)l * k_cross_fold_wqf_elems()};
+            const CrossFoldPack* pkp = xf ? &pk_l : nullptr;
             if (last_compact) {
                 RC(self_attn_core(t, s, w.self_attn, seqs, n, b, fold_l));
                 for (int h = 0; h < P; ++h) {
@@ -1011,11 +1022,11 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
                 RC(self_attn_block(t, s, w.self_attn, seqs, n, b, fold_l, fold, (fold_l && null_const) ? cvec_l : nullptr, M));
             }
             if (null_const) {
-                RC(cross_attn_block(t, s, w.cross_attn, B, nq, ckv_l, m, 0, g.masks, bc, fold, fold_l, khat_l, vwt_l));
+                RC(cross_attn_block(t, s, w.cross_attn, B, nq, ckv_l, m, 0, g.masks, bc, fold, fold_l, pkp));
                 if (fold_l) RC(ff_block(t, s, w.ff, bc.x, bc.x, 2 * Mq, bc, nullptr, 0, true, l + 1 < t->d.depth));      // (the constant row went in with the output projection above)
                 else RC(ff_block(t, s, w.ff, bc.x, bc.x, 2 * Mq, bc, cvec_l, Mq, false, fold && l + 1 < t->d.depth));      // null rows += to_out(null_v) (the constant cross-attention)
             } else {
-                RC(cross_attn_block(t, s, w.cross_attn, seqs, nq, ckv_l, m, P == 2 ? B : 0, g.masks, bc, fold, fold_l, khat_l, vwt_l));
+                RC(cross_attn_block(t, s, w.cross_attn, seqs, nq, ckv_l, m, P == 2 ? B : 0, g.masks, bc, fold, fold_l, pkp));
                 RC(ff_block(t, s, w.ff, bc.x, bc.x, P * Mq, bc, nullptr, 0, fold_l, fold && l + 1 < t->d.depth));
             }
         }

@@ -129,10 +129,14 @@ struct AttnArgs {
 };
 int k_attention(hipStream_t s, const AttnArgs& a);
 
-// cross_fold.hip: cross-attention with the output projection folded into the (step-invariant) values, residual add and LayerNorm(dim)-fold producer epilogue
+// cross_fold.hip: the cross-attention block as one kernel -- q projection (LayerNorm(dim) fold, consumer side), attention with the output projection folded into
+// the (step-invariant) values, residual add, fold producer epilogue
 struct CrossFoldArgs {
-    const bf16_t* q; long q_ld;                  // [seqs * nq][q_ld] bf16: the q projection's output (heads x 64 contiguous)
-    const bf16_t* khat;                          // k_cross_fold_pack: K^ fragments [kv_seqs][8][3][2][64][8]
+    const bf16_t* xb_in; long ldxb_in;           // [seqs * nq][ldxb_in] bf16: raw rows of the residual stream (may alias xb: a workgroup reads its rows before it writes them)
+    const float* stp_in; int in_np;              // their (sum, sum of squares) partials [rows][in_np][2] (may alias stp)
+    const bf16_t* wqf;                           // k_cross_fold_pack: gain-folded q weight as fragments [8][4][16][64][8]
+    const float* c1; const float* c2;            // [512] fold constants of the q projection (mm_attn_weights::ln_c1 / ln_c2; c2 may be NULL = zeros)
+    const bf16_t* khat;                          // k_cross_fold_pack: K^ fragments [kv_seqs][8][3][4][64][4]
     const bf16_t* vwt;                           // k_cross_fold_pack: (V W_o^T)^T fragments [kv_seqs][32][9][64][8]
     const uint8_t* key_mask; long km_sb;         // optional [seqs][m], 1 = keep
     const float* q_scale;                        // [64]
@@ -145,8 +149,9 @@ struct CrossFoldArgs {
 bool k_cross_fold_eligible(int D, int I, int H, int dh, int m);
 size_t k_cross_fold_khat_elems(int kv_seqs);
 size_t k_cross_fold_vwt_elems(int kv_seqs);
+size_t k_cross_fold_wqf_elems();
 int k_cross_fold_pack(hipStream_t s, const bf16_t* ckv, int kv_seqs, int m, int I, const float* null_k, const float* null_v, const float* k_scale,
-                      const bf16_t* w_out, int ldw, bf16_t* khat, bf16_t* vwt);
+                      const bf16_t* w_out, int ldw, const bf16_t* w_q_ln, int ldwq, bf16_t* khat, bf16_t* vwt, bf16_t* wqf);
 int k_cross_fold(hipStream_t s, const CrossFoldArgs& a);
 int k_cross_fold_null_row(hipStream_t s, const bf16_t* vwt, float* out);      // [512] fp32: what the kernel adds to a row whose text keys are all masked
 
