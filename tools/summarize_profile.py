@@ -25,7 +25,7 @@ def sq_main(dirs, out_json):
             a[1] += float(r['Counter_Value'])
     keep = {}
     for k, cs in acc.items():
-        if not any(w in k for w in ('gemm', 'attention', 'sample', 'conv', 'layernorm')):
+        if not any(w in k for w in ('gemm', 'attention', 'sample', 'conv', 'layernorm', 'cross_fold')):
             continue
         v = {c: t / n for c, (n, t) in cs.items()}
         v['launches'] = max(n for n, _ in cs.values())
