@@ -212,9 +212,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
                     const int col = wn * 32 + a * 16 + 4 * fg;
+                    const mm_f32x2_t g01 = geglu_f2((mm_f32x2_t){acc[a][b][0], acc[a][b][1]}, (mm_f32x2_t){acc[a + 2][b][0], acc[a + 2][b][1]});      // (packed fp32: same values as geglu_f)
+                    const mm_f32x2_t g23 = geglu_f2((mm_f32x2_t){acc[a][b][2], acc[a][b][3]}, (mm_f32x2_t){acc[a + 2][b][2], acc[a + 2][b][3]});
                     *reinterpret_cast<uint2*>(stg + row * ROWB + (((col >> 3) ^ (row & 7)) << 4) + (col & 4) * 2) =
-                        make_uint2(pack_bf16x2(geglu_f(acc[a][b][0], acc[a + 2][b][0]), geglu_f(acc[a][b][1], acc[a + 2][b][1])),
-                                   pack_bf16x2(geglu_f(acc[a][b][2], acc[a + 2][b][2]), geglu_f(acc[a][b][3], acc[a + 2][b][3])));
+                        make_uint2(pack_bf16x2(g01.x, g01.y), pack_bf16x2(g23.x, g23.y));
                 }
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);

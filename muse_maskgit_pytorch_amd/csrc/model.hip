@@ -1001,9 +1001,14 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
             const CrossFoldPack* pkp = xf ? &pk_l : nullptr;
             if (last_compact) {
                 RC(self_attn_core(t, s, w.self_attn, seqs, n, b, fold_l));
-                for (int h = 0; h < P; ++h) {
-                    RC(k_gather_rows16(s, b.x, (long)D * 4, g.rows, R, h * M, D * 4, g.xc + (size_t)h * R * D));
-                    RC(k_gather_rows16(s, b.att, (long)KI * 2, g.rows, R, h * M, KI * 2, g.attc + (size_t)h * R * KI));
+                {      // residual stream and attention output of both guidance halves: one launch
+                    const void* gsrc[4]; void* gdst[4]; long gpitch[4]; int gadd[4], gbytes[4];
+                    int nj = 0;
+                    for (int h = 0; h < P; ++h) {
+                        gsrc[nj] = b.x; gpitch[nj] = (long)D * 4; gadd[nj] = h * M; gbytes[nj] = D * 4; gdst[nj] = g.xc + (size_t)h * R * D; ++nj;
+                        gsrc[nj] = b.att; gpitch[nj] = (long)KI * 2; gadd[nj] = h * M; gbytes[nj] = KI * 2; gdst[nj] = g.attc + (size_t)h * R * KI; ++nj;
+                    }
+                    RC(k_gather_rows16_multi(s, nj, gsrc, gpitch, gadd, gbytes, gdst, g.rows, R));
                 }
                 bc.x = g.xc; bc.att = g.attc;
                 if (t->F8) RC(f8_linear_bf16(s, b, g.attc, I, I, w.self_attn.w_out, w.self_attn.w_out_scale, P * R, D, g.xc, D, 2, g.xc));
@@ -1030,48 +1035,15 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
                 RC(ff_block(t, s, w.ff, bc.x, bc.x, P * Mq, bc, nullptr, 0, fold_l, fold && l + 1 < t->d.depth));
             }
         }
-        // final norm + to_logits + CFG only at the rows that are sampled this step
-        if (PT) {
-            const float* fg = t->d.final_gamma;
-            const float* fb = t->d.final_beta;
-            if (compact_last) {
-                RC(k_layernorm_split(s, g.xc, D, R, D, fg, fb, nullptr, t->PC, g.embc, nullptr, nullptr, 0, nullptr));
-                if (P == 2) RC(k_layernorm_split(s, g.xc + (size_t)R * D, D, R, D, fg, fb, nullptr, t->PC, g.embn, nullptr, nullptr, 0, nullptr));
-            } else {
-                if (self_cond)      // the cond pass's fp32 embed at every position is the next step's self-conditioning input (mmp.py:574)
-                    RC(k_layernorm_split(s, b.x, D, M, D, fg, fb, nullptr, t->PC, nullptr, g.sce, nullptr, 0, nullptr));
-                RC(k_layernorm_split(s, b.x, D, R, D, fg, fb, rows, t->PC, g.embc, nullptr, nullptr, 0, nullptr));
-                if (P == 2) RC(k_layernorm_split(s, b.x + (size_t)M * D, D, R, D, fg, fb, rows, t->PC, g.embn, nullptr, nullptr, 0, nullptr));
-            }
-        } else if (compact_last) {
-            RC(k_layernorm(s, g.xc, D, R, D, t->d.final_gamma, t->d.final_beta, nullptr, g.embc, D));
-            if (P == 2) RC(k_layernorm(s, g.xc + (size_t)R * D, D, R, D, t->d.final_gamma, t->d.final_beta, nullptr, g.embn, D));
-        } else {
-            if (self_cond) {      // the cond pass's embed at EVERY position is the next step's self-conditioning input (mmp.py:574)
-                RC(k_layernorm(s, b.x, D, M, D, t->d.final_gamma, t->d.final_beta, nullptr, g.emb_all, D));
-                hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(1024), dim3(256), 0, s, g.emb_all, g.sce, (long)M * D);
-                RC(mm_check_launch("bf16_to_f32_kernel"));
-            }
-            RC(k_layernorm(s, b.x, D, R, D, t->d.final_gamma, t->d.final_beta, rows, g.embc, D));
-            if (P == 2) RC(k_layernorm(s, b.x + (size_t)M * D, D, R, D, t->d.final_gamma, t->d.final_beta, rows, g.embn, D));
-        }
         int64_t* ids_out = can_remask ? nullptr : p->ids;
         float* scores_out = can_remask ? nullptr : p->scores;
         int64_t* pred_out = can_remask ? g.pred : nullptr;
         float* conf_out = can_remask ? g.conf : nullptr;
-        // Guidance in the embedding (round 3): to_logits is linear (mmp.py:332), so null + (cond - null) * s of the logits (mmp.py:254) is to_logits of
-        // e = e_null + (e_cond - e_null) * s.  The two passes' final embeddings are mixed first (k_cfg_mix) and multiplied ONCE: half the flops of the
-        // loop's dominant GEMM; the general path (Transformer.forward_with_cond_scale) does the same, so the two stay bit-identical.
-        const bf16_t* emb_in = g.embc;
-        if (!single) {
-            RC(k_cfg_mix(s, g.embc, g.embn, KD, R, D, t->PC, p->cond_scale, g.embm));
-            emb_in = g.embm;
-        }
         GemmArgs a;
         memset(&a, 0, sizeof(a));
         a.mode = MODE_DENSE; a.wide_tok = 1;
         a.W = (const bf16_t*)t->d.to_logits; a.N = V; a.ldw = KD; a.K = KD;
-        a.M = R; a.X = emb_in; a.ldx = KD;
+        a.M = R; a.X = nullptr; a.ldx = KD;      // (X: the mixed rows, set below)
         a.out = g.logits; a.ldc = V; a.out_kind = OUT_F32;
         a.debug = g_mm_debug;
         a.f16 = t->F16; a.alpha = t->alpha;
@@ -1084,6 +1056,51 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
             probe.fs_thr = g.fs_thr; probe.fs_stats = g.fs_stats; probe.fs_cand = g.fs_cand;
             fused = mm_gemm_wide_fused_eligible(probe) && !(g_mm_debug & ((1 << 26) | (1 << 28) | (1 << 30)));
         }
+        // The step tail of the plain decode (bf16 engine, two guidance passes, fused sampling): final LayerNorm of both passes' sampled rows, the guidance mix
+        // and the bound estimate's row means in ONE pass (k_final_mix) -- the same values as the separate LayerNorm / k_cfg_mix / fused_combine kernels below
+        const bool fmix = fused && !PT && !t->F16 && !t->F8 && !single && !self_cond && P == 2 && t->d.logits_wmean && KD == D;
+        const bf16_t* emb_in = g.embc;
+        if (fmix) {
+            const float* xc_ = compact_last ? g.xc : b.x;
+            const float* xn_ = compact_last ? g.xc + (size_t)R * D : b.x + (size_t)M * D;
+            RC(k_final_mix(s, xc_, xn_, D, R, D, t->d.final_gamma, t->d.final_beta, compact_last ? nullptr : rows, p->cond_scale, g.embm, t->d.logits_wmean,
+                           k_fused_threshold_mu(g.fs_ws, R, D)));
+            emb_in = g.embm;
+        } else {
+            // final norm + to_logits + CFG only at the rows that are sampled this step
+            if (PT) {
+                const float* fg = t->d.final_gamma;
+                const float* fb = t->d.final_beta;
+                if (compact_last) {
+                    RC(k_layernorm_split(s, g.xc, D, R, D, fg, fb, nullptr, t->PC, g.embc, nullptr, nullptr, 0, nullptr));
+                    if (P == 2) RC(k_layernorm_split(s, g.xc + (size_t)R * D, D, R, D, fg, fb, nullptr, t->PC, g.embn, nullptr, nullptr, 0, nullptr));
+                } else {
+                    if (self_cond)      // the cond pass's fp32 embed at every position is the next step's self-conditioning input (mmp.py:574)
+                        RC(k_layernorm_split(s, b.x, D, M, D, fg, fb, nullptr, t->PC, nullptr, g.sce, nullptr, 0, nullptr));
+                    RC(k_layernorm_split(s, b.x, D, R, D, fg, fb, rows, t->PC, g.embc, nullptr, nullptr, 0, nullptr));
+                    if (P == 2) RC(k_layernorm_split(s, b.x + (size_t)M * D, D, R, D, fg, fb, rows, t->PC, g.embn, nullptr, nullptr, 0, nullptr));
+                }
+            } else if (compact_last) {
+                RC(k_layernorm(s, g.xc, D, R, D, t->d.final_gamma, t->d.final_beta, nullptr, g.embc, D));
+                if (P == 2) RC(k_layernorm(s, g.xc + (size_t)R * D, D, R, D, t->d.final_gamma, t->d.final_beta, nullptr, g.embn, D));
+            } else {
+                if (self_cond) {      // the cond pass's embed at EVERY position is the next step's self-conditioning input (mmp.py:574)
+                    RC(k_layernorm(s, b.x, D, M, D, t->d.final_gamma, t->d.final_beta, nullptr, g.emb_all, D));
+                    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(1024), dim3(256), 0, s, g.emb_all, g.sce, (long)M * D);
+                    RC(mm_check_launch("bf16_to_f32_kernel"));
+                }
+                RC(k_layernorm(s, b.x, D, R, D, t->d.final_gamma, t->d.final_beta, rows, g.embc, D));
+                if (P == 2) RC(k_layernorm(s, b.x + (size_t)M * D, D, R, D, t->d.final_gamma, t->d.final_beta, rows, g.embn, D));
+            }
+            // Guidance in the embedding (round 3): to_logits is linear (mmp.py:332), so null + (cond - null) * s of the logits (mmp.py:254) is to_logits of
+            // e = e_null + (e_cond - e_null) * s.  The two passes' final embeddings are mixed first (k_cfg_mix) and multiplied ONCE: half the flops of the
+            // loop's dominant GEMM; the general path (Transformer.forward_with_cond_scale) does the same, so the two stay bit-identical.
+            if (!single) {
+                RC(k_cfg_mix(s, g.embc, g.embn, KD, R, D, t->PC, p->cond_scale, g.embm));
+                emb_in = g.embm;
+            }
+        }
+        a.X = emb_in;
         const double gemm_flops = 2.0 * (double)R * (double)V * (double)KD;      // EXECUTED bf16 MFMA flops: one pass over the mixed rows (x the term products in the precision tier)
         if (fused) {
             const bf16_t* emb_est = emb_in;      // the rows the bound is estimated from: bf16 (the leading bf16 term in the 'bf16x3' tier)
@@ -1093,8 +1110,9 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
                 RC(mm_check_launch("f16_rows_to_bf16_kernel"));
                 emb_est = g.embb; ld_est = D;
             }
-            RC(k_fused_threshold(s, emb_est, emb_est, ld_est, R, D, 1.f, t->d.logits_wmean, (const bf16_t*)t->d.logits_wcov, k_fused_z(p->k_keep, V, FS_MARGIN),
-                                 g.fs_ws, g.fs_thr));
+            if (fmix) RC(k_fused_threshold_mixed(s, emb_in, D, R, D, (const bf16_t*)t->d.logits_wcov, k_fused_z(p->k_keep, V, FS_MARGIN), g.fs_ws, g.fs_thr));
+            else RC(k_fused_threshold(s, emb_est, emb_est, ld_est, R, D, 1.f, t->d.logits_wmean, (const bf16_t*)t->d.logits_wcov, k_fused_z(p->k_keep, V, FS_MARGIN),
+                                      g.fs_ws, g.fs_thr));
             a.out = nullptr;
             a.fs_thr = g.fs_thr; a.fs_stats = g.fs_stats; a.fs_cand = g.fs_cand;
             prof::Rec pr;

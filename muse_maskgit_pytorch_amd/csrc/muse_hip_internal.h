@@ -86,6 +86,11 @@ int k_geglu_ln(hipStream_t s, const bf16_t* h, long ldh, int rows, int F, int Fp
 int k_layernorm_addvec(hipStream_t s, float* x, long ldx, int rows, int D, const float* gamma, const float* beta, const float* addvec,
                        int add_from, bf16_t* out, long ldo);
 int k_gather_rows16(hipStream_t s, const void* src, long src_pitch_bytes, const int32_t* rows, int R, int row_add, int row_bytes, void* dst);
+int k_gather_rows16_multi(hipStream_t s, int njobs, const void* const* src, const long* src_pitch_bytes, const int* row_add, const int* row_bytes, void* const* dst,
+                          const int32_t* rows, int R);
+// final LayerNorm of both guidance passes + guidance mix in the embedding (+ <e, wmean> per row) over the (optionally gathered) rows, in one pass
+int k_final_mix(hipStream_t s, const float* xc, const float* xn, long ldx, int rows, int D, const float* gamma, const float* beta, const int32_t* row_index,
+                float cond_scale, bf16_t* out, const float* wmean, float* mu);
 int k_gather_rows16_counted(hipStream_t s, const void* src, long src_pitch_bytes, const int32_t* rows, const int32_t* count, int cap, int row_bytes, void* dst,
                             int32_t* total);
 int k_ln_bf16(hipStream_t s, const bf16_t* a, long lda, int rows, int F, int Fp, const float* gamma, const float* beta,
@@ -252,6 +257,8 @@ struct FusedSampleArgs {
 float k_fused_z(int k_keep, int V, float margin);
 // thr[r] = mean_r + z sigma_r of row r's logits over the vocabulary; ws: k_fused_threshold_ws_bytes(R, D) bytes of scratch; wcov bf16 [D][D]
 size_t k_fused_threshold_ws_bytes(int R, int D);
+float* k_fused_threshold_mu(void* ws, int R, int D);      // where the rows' means live in that scratch (k_final_mix writes them; then k_fused_threshold_mixed)
+int k_fused_threshold_mixed(hipStream_t s, const bf16_t* e, long ld, int R, int D, const bf16_t* wcov, float z, void* ws, float* thr);      // e = the mixed rows, means already in ws
 int k_fused_threshold(hipStream_t s, const bf16_t* ec, const bf16_t* en, long ld, int R, int D, float cond_scale, const float* wmean, const bf16_t* wcov,
                       float z, void* ws, float* thr);
 int k_fused_emit(hipStream_t s, const float* logits, long ld, int R, int V, const float* thr, float4* stats, float4* cand);

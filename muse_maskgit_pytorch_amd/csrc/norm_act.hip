@@ -1,5 +1,7 @@
 // HBM-bound row kernels of the transformer (gfx950): token+position embedding, LayerNorm, GEGLU+LayerNorm,
 // row-vector add.  One 64-lane wave per row, 16-byte vector accesses, fp32 statistics via wave butterflies.
+#include <string.h>
+
 #include "common.h"
 #include "muse_hip_internal.h"
 
@@ -81,6 +83,91 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             const float o2 = (v[it].z - mean) * rstd * g.z + bt.z, o3 = (v[it].w - mean) * rstd * g.w + bt.w;
             *reinterpret_cast<uint2*>(orow + c * 4) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
         }
+    }
+}
+
+// The decode loop's step tail in one pass over the sampled rows (round 4): final LayerNorm of the conditional and of the null pass (the arithmetic of
+// layernorm_kernel, each result rounded to bf16 as that kernel stores it), the guidance mix in the embedding e = e_null + (e_cond - e_null) * s rounded to
+// bf16 once (the arithmetic of cfg_mix_kernel), and the row's mean of the logits <e, mean_w> for the fused sampler's bound -- the values the three kernels
+// (+ fused_combine_kernel) produced with four launches and three round trips of the rows through HBM.
+template <int NIT>
+__global__ __launch_bounds__(256) void final_mix_kernel(const float* __restrict__ xc, const float* __restrict__ xn, long ldx, int rows, int D,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, const int32_t* __restrict__ row_index,
+                                                        float s, bf16_t* __restrict__ out, const float* __restrict__ wmean, float* __restrict__ mu) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long src = row_index ? (long)row_index[row] : (long)row;
+    const int nvec = D >> 2;
+    float4 e[2][NIT];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float* xr = (h == 0 ? xc : xn) + src * ldx;
+        float4 v[NIT];
+        float sum = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = it * 64 + lane;
+            if (c < nvec) {
+                v[it] = *reinterpret_cast<const float4*>(xr + c * 4);
+                sum += (v[it].x + v[it].y) + (v[it].z + v[it].w);
+            }
+        }
+        const float mean = wave_sum(sum) / (float)D;
+        float sq = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = it * 64 + lane;
+            if (c < nvec) {
+                const float a = v[it].x - mean, b = v[it].y - mean, cc = v[it].z - mean, d = v[it].w - mean;
+                sq += (a * a + b * b) + (cc * cc + d * d);
+            }
+        }
+        const float rstd = 1.f / sqrtf(wave_sum(sq) / (float)D + 1e-5f);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = it * 64 + lane;
+            if (c < nvec) {
+                const float4 g = *reinterpret_cast<const float4*>(gamma + c * 4);
+                float4 bt = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (beta) bt = *reinterpret_cast<const float4*>(beta + c * 4);
+                const float o0 = (v[it].x - mean) * rstd * g.x + bt.x, o1 = (v[it].y - mean) * rstd * g.y + bt.y;
+                const float o2 = (v[it].z - mean) * rstd * g.z + bt.z, o3 = (v[it].w - mean) * rstd * g.w + bt.w;
+                const uint32_t w0 = pack_bf16x2(o0, o1), w1 = pack_bf16x2(o2, o3);      // the bf16 values layernorm_kernel stores
+                e[h][it] = make_float4(bf16lo(w0), bf16hi(w0), bf16lo(w1), bf16hi(w1));
+            }
+        }
+    }
+    float m = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int c = it * 64 + lane;
+        if (c < nvec) {
+            const float4 cv = e[0][it], nv = e[1][it];
+            const uint32_t w0 = pack_bf16x2(nv.x + (cv.x - nv.x) * s, nv.y + (cv.y - nv.y) * s), w1 = pack_bf16x2(nv.z + (cv.z - nv.z) * s, nv.w + (cv.w - nv.w) * s);
+            *reinterpret_cast<uint2*>(out + (long)row * D + c * 4) = make_uint2(w0, w1);
+            if (wmean) {
+                const float4 wm = *reinterpret_cast<const float4*>(wmean + c * 4);
+                m += (bf16lo(w0) * wm.x + bf16hi(w0) * wm.y) + (bf16lo(w1) * wm.z + bf16hi(w1) * wm.w);
+            }
+        }
+    }
+    if (mu) {
+        m = wave_sum(m);
+        if (lane == 0) mu[row] = m;
+    }
+}
+
+// several row gathers with one row list in one launch (the last layer's compaction: residual stream and attention output of both guidance halves)
+struct GatherJobs { const unsigned char* src[4]; unsigned char* dst[4]; long pitch[4]; int row_add[4]; int chunks[4]; int n; };
+__global__ __launch_bounds__(256) void gather_rows16_multi_kernel(const GatherJobs j, const int32_t* __restrict__ rows, int R) {
+    const int job = blockIdx.y;
+    const int chunks = j.chunks[job];
+    const long total = (long)R * chunks;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / chunks), c = (int)(i - (long)r * chunks);
+        *reinterpret_cast<uint4*>(j.dst[job] + ((long)r * chunks + c) * 16) =
+            *reinterpret_cast<const uint4*>(j.src[job] + (long)(rows[r] + j.row_add[job]) * j.pitch[job] + (long)c * 16);
     }
 }
 
@@ -254,6 +341,37 @@ int k_gather_rows16(hipStream_t s, const void* src, long src_pitch_bytes, const 
     hipLaunchKernelGGL(gather_rows16_kernel, dim3(grid_for((long)R * (row_bytes / 16))), dim3(256), 0, s, (const unsigned char*)src,
                        src_pitch_bytes, rows, R, row_add, row_bytes / 16, (unsigned char*)dst);
     return mm_check_launch("gather_rows16_kernel");
+}
+
+int k_final_mix(hipStream_t s, const float* xc, const float* xn, long ldx, int rows, int D, const float* gamma, const float* beta, const int32_t* row_index,
+                float cond_scale, bf16_t* out, const float* wmean, float* mu) {
+    if (rows <= 0) return MM_OK;
+    if (D % 4 || D > 64 * 4 * LN_MAX_IT || (ldx % 4)) return mm_set_error(MM_ERR_SHAPE, "final_mix: dim must be a multiple of 4 and <= 2048");
+    const int nit = (D / 4 + 63) / 64;
+    const dim3 grid((rows + 3) / 4), block(256);
+    if (nit <= 2) hipLaunchKernelGGL((final_mix_kernel<2>), grid, block, 0, s, xc, xn, ldx, rows, D, gamma, beta, row_index, cond_scale, out, wmean, mu);
+    else if (nit <= 4) hipLaunchKernelGGL((final_mix_kernel<4>), grid, block, 0, s, xc, xn, ldx, rows, D, gamma, beta, row_index, cond_scale, out, wmean, mu);
+    else hipLaunchKernelGGL((final_mix_kernel<8>), grid, block, 0, s, xc, xn, ldx, rows, D, gamma, beta, row_index, cond_scale, out, wmean, mu);
+    return mm_check_launch("final_mix_kernel");
+}
+
+// up to four gathers with the same row list in one launch: dst_j[r] = src_j[rows[r] + row_add_j] (16-byte aligned rows)
+int k_gather_rows16_multi(hipStream_t s, int njobs, const void* const* src, const long* src_pitch_bytes, const int* row_add, const int* row_bytes, void* const* dst,
+                          const int32_t* rows, int R) {
+    if (R <= 0 || njobs <= 0) return MM_OK;
+    if (njobs > 4) return mm_set_error(MM_ERR_SHAPE, "gather_rows_multi: at most 4 jobs");
+    GatherJobs j;
+    memset(&j, 0, sizeof(j));
+    int maxc = 0;
+    for (int i = 0; i < njobs; ++i) {
+        if ((row_bytes[i] % 16) || (src_pitch_bytes[i] % 16)) return mm_set_error(MM_ERR_ALIGN, "gather_rows: rows must be multiples of 16 bytes");
+        j.src[i] = (const unsigned char*)src[i]; j.dst[i] = (unsigned char*)dst[i]; j.pitch[i] = src_pitch_bytes[i]; j.row_add[i] = row_add[i];
+        j.chunks[i] = row_bytes[i] / 16;
+        if (j.chunks[i] > maxc) maxc = j.chunks[i];
+    }
+    j.n = njobs;
+    hipLaunchKernelGGL(gather_rows16_multi_kernel, dim3(grid_for((long)R * maxc), njobs), dim3(256), 0, s, j, rows, R);
+    return mm_check_launch("gather_rows16_multi_kernel");
 }
 
 int k_gather_rows16_counted(hipStream_t s, const void* src, long src_pitch_bytes, const int32_t* rows, const int32_t* count, int cap, int row_bytes, void* dst,

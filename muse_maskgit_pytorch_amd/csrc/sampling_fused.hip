@@ -440,6 +440,30 @@ int k_fused_threshold(hipStream_t s, const bf16_t* ec, const bf16_t* en, long ld
     return mm_check_launch("fused_sigma_kernel");
 }
 
+float* k_fused_threshold_mu(void* ws, int R, int D) {
+    unsigned char* w8 = (unsigned char*)ws;
+    float* tq = (float*)(w8 + ((size_t)R * D * 2 + 255) / 256 * 256);
+    return tq + (size_t)R * D;
+}
+
+// the same bound from rows that ARE the operand of the logits GEMM already (k_final_mix: mixed, bf16) with their means in place: T = E Cov on those rows, sigma
+int k_fused_threshold_mixed(hipStream_t s, const bf16_t* e, long ld, int R, int D, const bf16_t* wcov, float z, void* ws, float* thr) {
+    if (R <= 0) return MM_OK;
+    if (D <= 0 || (D % 64) || ld != D) return mm_set_error(MM_ERR_SHAPE, "fused_threshold: D must be a positive multiple of 64, rows dense");
+    unsigned char* w8 = (unsigned char*)ws;
+    float* tq = (float*)(w8 + ((size_t)R * D * 2 + 255) / 256 * 256);
+    float* mu = tq + (size_t)R * D;
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mode = MODE_DENSE;
+    a.W = wcov; a.N = D; a.ldw = D; a.K = D; a.M = R; a.X = e; a.ldx = (int)ld;
+    a.out = tq; a.ldc = D; a.out_kind = OUT_F32;
+    const int rc = mm_gemm_launch(a, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fused_sigma_kernel, dim3((R + 3) / 4), dim3(256), 0, s, e, tq, mu, R, D, z, thr);
+    return mm_check_launch("fused_sigma_kernel");
+}
+
 int k_fused_emit(hipStream_t s, const float* logits, long ld, int R, int V, const float* thr, float4* stats, float4* cand) {
     if (R <= 0) return MM_OK;
     if (V <= 0 || (V % 256)) return mm_set_error(MM_ERR_SHAPE, "fused_emit: V must be a multiple of 256");
