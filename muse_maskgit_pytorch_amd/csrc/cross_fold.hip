@@ -16,7 +16,7 @@
 // MALL once per sequence instead of once per query block: 22.7 -> 17.8 us when this was measured on the two-kernel form).
 //   phase A  the 32 raw rows (bf16 image of the residual stream) -> LDS (1040-byte rows: conflict-free fragment reads)
 //   phase B  wave h = head h: q_h = rows . Wq_h^T, 16 k-blocks x (2 B-fragment reads + 8 MFMAs); the weight fragments stream from L2 straight into registers
-//            (fragment-major pack: one contiguous KiB per wave load), two k-blocks ahead
+//            (fragment-major pack: one contiguous KiB per wave load), a ring of five k-blocks in flight per wave
 //   phase C  fold epilogue on the accumulators, l2norm * q_scale over the head's 64 features (16 per lane + two lane exchanges), q^ -> bf16.  An accumulator
 //            fragment (4 consecutive features of one query per lane) IS the B operand of v_mfma_f32_16x16x16_bf16: S^T = K^ Q^T needs no transposition.
 //            Mask, softmax over the head's <= 36 keys in registers, P -> bf16 -> LDS [32 queries][288] (592-byte rows).  The wave's 36 VW^T fragments
