@@ -22,8 +22,10 @@ import bench  # noqa: E402
 from muse_maskgit_pytorch_amd import _lib  # noqa: E402
 
 # operator outputs per transformer pass, in launch order (model.hip TR points)
-LAYER_POINTS = ['self.ln', 'self.qkv', 'self.attn', 'self.out+res', 'cross.kv', 'cross.ln', 'cross.q', 'cross.attn', 'cross.out+res',
-                'ff.ln', 'ff.w1+geglu', 'ff.ln_partials', 'ff.w2+res']
+# (round 4: the cross-attention block is one kernel, csrc/cross_fold.hip -- 11 points per layer; with debug bit 1 << 31 the three-kernel path leaves 13 and the
+#  names below are off by the two extra cross-attention points)
+LAYER_POINTS = ['self.rows', 'self.qkv', 'self.attn', 'self.out+res', 'cross.kv', 'cross.rows', 'cross.block+res',
+                'ff.rows', 'ff.w1+geglu', 'ff.ln_partials', 'ff.w2+res']
 
 
 def point_name(i, depth):
