@@ -93,6 +93,32 @@ def _cpu_model():
     return 'unknown'
 
 
+def graph_replay_leg(mg, B, T, te, steps, eager_s):
+    """The same generate + VAE decode captured ONCE in a hipGraph (generate(fused_sampling='deferred'): mm_generate and the VAE decode are capturable -- no host
+    synchronisation inside, the fused-sampling status words stay on the device) and replayed `steps` times: what the launch sequence costs without the host's
+    launch calls and the gaps between dependent launches.  Reported BESIDE the headline (which times the eager call sequence, a fresh Philox seed per step);
+    a replay re-executes all of the work with the captured seed."""
+    try:
+        torch.cuda.synchronize()
+        graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                images = mg.generate([''] * B, timesteps=T, cond_scale=3, text_embeds=te, seed=4242, fused_sampling='deferred')
+        graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            graph.replay()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        status = [int(v) for v in mg.fused_status.tolist()]
+        return {'value': B / dt, 'unit': 'images/sec', 'ms_per_step': dt * 1e3, 'steps': steps, 'x_eager_time': dt / eager_s,
+                'fused_sampling_status_words': status, 'finite_images': bool(torch.isfinite(images).all().item()),
+                'note': 'one captured generate + VAE decode replayed; status word 0 must be 0 (no step had more than 128 unverifiable rows)'}
+    except Exception as e:      # never lets the extra leg cost the line
+        return {'error': f'{type(e).__name__}: {e}'[:300]}
+
+
 def cpu_baseline(mg, te_two, timesteps, cond_scale, max_threads=32):
     """The reference algorithm on the host cores, beside the GPU number (never the thing measured as `value`).  kind = "port": the oracle
     (oracle/muse_oracle.py, a functional fp32 torch restatement pinned bit-exactly to goldens of the unmodified reference) -- the reference
@@ -379,6 +405,7 @@ def main():
     ap.add_argument('--no-fused-sampling', action='store_true', help='materialise the logits (round-1 path) for A/B timing')
     ap.add_argument('--fp8', action='store_true', help="secondary line: run the transformer on the fp8 engine (precision 'fp8', BASELINE configs[4] \"fp8 MFMA weights\"; "
                     "use with --config c5).  Never the headline: the metric configuration is quoted in bf16")
+    ap.add_argument('--no-graph-leg', action='store_true', help='skip the extra leg that replays one captured generate (hipGraph) -- reported beside, never as, the value')
     ap.add_argument('--no-parity-tier', action='store_true', help="skip the second timed leg (precision 'f16x2', the tolerance-meeting tier)")
     ap.add_argument('--train', action='store_true', help='time the TRAINING step of the C2 base transformer (MaskGit.forward + backward + AdamW) instead of '
                     'generation: a second, separately labelled line -- not the BASELINE metric')
@@ -549,6 +576,8 @@ def main():
                            'per_rank_images_per_s': [B * args.steps / t_ for t_ in rank_times]} if dist is not None else None),
             'fused_sampling': {'enabled': fused_on, 'fallbacks_to_logits_path': mg.fused_sampling_fallbacks, 'rows_finished_by_on_device_fallback': mg.fused_row_fallbacks},
         }
+        if world == 1 and not args.tiny and args.config == 'c2' and fused_on and not args.no_graph_leg and not args.fp8:
+            out['hip_graph_replay'] = graph_replay_leg(mg, B, T, te, args.steps, elapsed / args.steps)
         if world == 1 and not args.no_parity_tier and not args.tiny:
             out['parity_tier'] = parity_tier_leg(mg, tr, step, args, B, T, n, nc, image_size, counts, lib, elapsed / args.steps)
         if world == 1 and not args.no_cpu_baseline and not args.tiny and args.config == 'c2':
