@@ -26,6 +26,9 @@ DEV = 'cuda'
 FULL_ROWS = [0, 77, 255, 256, 300, 301, 448, 511]
 PRECISIONS = ['parity', 'bf16x3', 'f16x2', 'bf16']
 EXACT = ('parity', 'bf16x3', 'f16x2')      # the engines held to the north star's bar
+# the bf16 engine on a GENERAL fp32 checkpoint (weights rounded to bf16 at pack time on top of the bf16 activations): bounds from the measured figures
+# of round 5 (printed by the tests), ~2x head-room
+BF16_FP32W_LOGITS, BF16_FP32W_EMBED, BF16_FP32W_IDS = 5e-2, 8e-2, 0.85
 
 
 @pytest.fixture(scope='module', params=['base_c2.pt', 'base_c2_fp32.pt'], ids=['bf16w', 'fp32w'])
@@ -49,9 +52,11 @@ def base(golden, request):
     torch.cuda.empty_cache()
 
 
-def _skip_bf16_engine_on_fp32_weights(g, precision):
-    if precision == 'bf16' and not g['recipe'].get('bf16_weights', True):
-        pytest.skip('the bf16 engine rounds the weights to bf16 by definition: its bounds are stated on the bf16-representable fixture')
+def _fp32w(g):
+    """the fixture's checkpoint holds general fp32 parameters (what the reference's constructors / training produce): the bf16 engine then ALSO rounds
+    every weight to bf16 at pack time -- the case a drop-in user hits with `maskgit.load('maskgit.pt')`.  Its bounds on that fixture are stated
+    separately below (round 5; rounds 1-4 skipped the combination)."""
+    return not g['recipe'].get('bf16_weights', True)
 
 
 @pytest.fixture(scope='module')
@@ -82,7 +87,6 @@ def test_transformer_forward_logits_at_base_size(base, precision):
     all 512 rows, and the final-LayerNorm embed, against the reference's fp32 run.  Random-init logits are unit scale (std 0.59, |max| 3.2),
     so the absolute bound IS the north star's 1e-3 for the parity engine; the bf16 engine's bound is what 8 layers of bf16 operands give."""
     g, mg, inp = base
-    _skip_bf16_engine_on_fp32_weights(g, precision)
     tr = mg.transformer.set_precision(precision)
     if precision in ('bf16x3', 'f16x2'):      # term products per GEMM: bf16 terms 3 / 6, fp16 terms 2 / 3 (bf16-representable / general fp32 checkpoint)
         assert tr.split_products() == dict(bf16x3=(6, 3), f16x2=(3, 2))[precision][int(g['recipe'].get('bf16_weights', True))]
@@ -94,7 +98,8 @@ def test_transformer_forward_logits_at_base_size(base, precision):
     finally:
         tr.set_precision('bf16')
     fw = g['forward']
-    tol = 1e-3 if precision in EXACT else 2.5e-2
+    # bf16 engine: 2.5e-2 on the bf16-representable checkpoint (activation rounding only), BF16_FP32W_LOGITS on the general fp32 one (+ weight rounding)
+    tol = 1e-3 if precision in EXACT else (BF16_FP32W_LOGITS if _fp32w(g) else 2.5e-2)
     for name, got, rec in (('logits(cond)', lc, fw['logits_cond']), ('logits(null)', ln, fw['logits_null'])):
         rows, cols = _samples(got)
         _err(f'{precision} {name} full rows', rows, rec['rows'], tol)
@@ -102,7 +107,7 @@ def test_transformer_forward_logits_at_base_size(base, precision):
     rows, cols = _samples(sc)
     _err(f'{precision} logits(guidance 3.0) full rows', rows, fw['logits_scaled']['rows'], tol * 5)      # null + 3 (cond - null): errors add up to 5x
     _err(f'{precision} logits(guidance 3.0) strided columns', cols, fw['logits_scaled']['cols'], tol * 5)
-    _err(f'{precision} embed', emb.reshape(R.B, R.N, -1), fw['embed'], 1e-3 if precision in EXACT else 4e-2)
+    _err(f'{precision} embed', emb.reshape(R.B, R.N, -1), fw['embed'], 1e-3 if precision in EXACT else (BF16_FP32W_EMBED if _fp32w(g) else 4e-2))
 
 
 @pytest.mark.parametrize('precision', PRECISIONS)
@@ -112,7 +117,6 @@ def test_generate_at_base_size_against_the_reference_run(base, noise, precision)
     checked bit-exactly at V = 65536 through the oracle tail fed with the GENERAL path's logits on the engine's own states (three steps),
     and its agreement with the fp32 reference trajectory is reported (bf16 operands may flip a near-tie; the run then follows another path)."""
     g, mg, inp = base
-    _skip_bf16_engine_on_fp32_weights(g, precision)
     gen = g['generate']
     tr = mg.transformer
     te = inp['text_embeds'].to(DEV)
@@ -136,7 +140,7 @@ def test_generate_at_base_size_against_the_reference_run(base, noise, precision)
         if precision in EXACT:
             assert min(agree_steps) == 1.0 and final_agree == 1.0
         else:
-            assert final_agree >= 0.90
+            assert final_agree >= (BF16_FP32W_IDS if _fp32w(g) else 0.90)
             # the fused engine against the general path + oracle tail at full vocabulary, on its own states
             counts, temps = O.mask_counts(R.T, R.N), O.step_temperatures(R.T, 1.)
             st_ids = trace['ids'].cpu()
@@ -163,7 +167,6 @@ def test_vqgan_vae_dim_256_against_the_reference(base, precision):
     (|max| 0.063 at random init) for the parity engine.  LFQ ids: a bit is the SIGN of a projection, so ids are compared where the reference's
     own pre-sign value clears the engine's error band (all 16 bits of the position), and the fraction of positions covered is reported."""
     g, mg, inp = base
-    _skip_bf16_engine_on_fp32_weights(g, precision)
     v = g['vae']
     vae = mg.vae.set_precision(precision)
     if precision in ('bf16x3', 'f16x2'):
@@ -188,6 +191,66 @@ def test_vqgan_vae_dim_256_against_the_reference(base, precision):
         assert safe.float().mean().item() > 0.95 and same.float().mean().item() > 0.99
     d = (fmap[:, ::16].float().cpu() - v['enc_fmap_strided']).abs().amax(dim=1)          # (B, 16, 16): project_out(+-1 codes) of equal ids is the same sum
     assert d[same.reshape(R.B, 16, 16)].max().item() <= (1e-5 if precision in EXACT else 2e-2)
+
+
+# ------------------------------------------------------------------------------------------------ the un-scanned fp32 fixture, tie-aware
+TIE_EPS = 5e-4      # logit units (tests/tie_aware.py): 12x the fp32-grade engines' largest logit error at the fixtures' x8 logit scale
+
+
+@pytest.fixture(scope='module')
+def base_s77(golden):
+    """tests/golden/base_c2_fp32_s77.pt (round 5): the general-fp32 checkpoint on the ORIGINAL input seed 77 -- NOT chosen by tools/find_golden_input_seed.py.
+    The reference's own run has two confidences 2.3e-6 apart at the re-masking boundary entering step 8; no implementation that is not bit-identical to
+    the reference's BLAS can be expected to order them, so the run is held to "equal outside eps-ties" instead of plain equality."""
+    import muse_maskgit_pytorch_amd as mm
+    g = golden('base_c2_fp32_s77.pt')
+    assert g['recipe']['input_seed'] == R.INPUT_SEED and not g['recipe']['bf16_weights']
+    tr = R.build_transformer(mm.MaskGitTransformer, peaky=True, bf16_weights=False)
+    assert R.state_checksum(tr) == g['weight_checksum_peaky'], 'the seeded recipe did not reproduce the reference checkpoint'
+    mg = mm.MaskGit(vae=None, transformer=tr, image_size=256).to(DEV).eval()
+    inp = R.inputs(R.INPUT_SEED)
+    assert {k: R.checksum(v.float()) for k, v in inp.items()} == g['input_checksum']
+    yield g, mg, inp
+    del mg, tr
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('precision', ['parity', 'bf16x3', 'f16x2'])
+def test_generate_on_the_unscanned_fp32_fixture_tie_aware(base_s77, noise, precision):
+    """free run: every sample equals the reference's trajectory step by step, or its FIRST difference lies inside a tie band of the reference's own
+    scores (then the trajectories legitimately part).  Teacher-forced on the reference's states (every step, so also what lies behind the tie):
+    sampled ids equal, re-masked sets equal outside the band."""
+    import tie_aware as TA
+    g, mg, inp = base_s77
+    gen = g['generate']
+    assert gen['noise_checksum'] == [R.checksum(u) for u in noise]
+    tr = mg.transformer
+    te = inp['text_embeds'].to(DEV)
+    counts, temps = O.mask_counts(R.T, R.N), O.step_temperatures(R.T, 1.)
+    mg.set_precision(precision)
+    try:
+        trace = {}
+        ids = mg.generate(['a', 'b'], fmap_size=16, timesteps=R.T, cond_scale=3., text_embeds=te, noise=noise.to(DEV), noise_kind='uniform', return_ids=True, trace=trace)
+        masked = torch.stack(list(trace['masked_ids'])).cpu() if isinstance(trace['masked_ids'], list) else trace['masked_ids'].cpu()
+        rep = TA.compare_free_run(gen, masked, ids.cpu(), counts, 65536, TIE_EPS)
+        print(f'[base-size parity] {precision} un-scanned fp32 fixture, free run vs the reference (tie-aware, eps {TIE_EPS:g}): '
+              + '; '.join(f"sample {b}: {r['status']}" + (f" at step {r['step']} ({r['kind']}, positions {r['positions']})" if r['status'] == 'tie' else '') for b, r in enumerate(rep)))
+        assert rep[1]['status'] == 'equal'                                    # sample 1 has no tie anywhere: plain equality
+        assert rep[0]['status'] == 'equal' or rep[0]['step'] in (7, 8)       # sample 0: the known pairs of steps 7 / 8
+        skipped = [0, 0]
+        steps = range(R.T) if precision != 'parity' else (0, 7, 8, R.T - 1)   # (the fp32-MFMA engine is the slow yardstick)
+        for s in steps:
+            ids_in = gen['step_in_ids'][s].long()
+            logits = tr.forward_with_cond_scale(ids_in.to(DEV), text_embeds=te, cond_scale=3.).cpu()
+            new_ids, scores, _ = O.sample_step(logits, O.gumbel_from_uniform(noise[s]), ids_in, 65536, temps[s])
+            near, band = TA.compare_forced_step(gen, s, new_ids, scores, counts, 65536, TIE_EPS, O.select_topk_stable)
+            skipped[0] += near
+            skipped[1] += band
+        print(f'[base-size parity] {precision} un-scanned fp32 fixture, teacher-forced over {len(list(steps))} steps: all sampled ids and re-masked sets equal the '
+              f"reference's outside {skipped[0]} sampling near-ties and {skipped[1]} boundary-band positions")
+    finally:
+        mg.set_precision('bf16')
+        torch.cuda.empty_cache()
 
 
 # ------------------------------------------------------------------------------------------------ BASELINE configs[3]: super-resolution at full size
