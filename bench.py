@@ -407,6 +407,9 @@ def main():
                     "use with --config c5).  Never the headline: the metric configuration is quoted in bf16")
     ap.add_argument('--no-graph-leg', action='store_true', help='skip the extra leg that replays one captured generate (hipGraph) -- reported beside, never as, the value')
     ap.add_argument('--no-parity-tier', action='store_true', help="skip the second timed leg (precision 'f16x2', the tolerance-meeting tier)")
+    ap.add_argument('--precision', choices=['bf16', 'f16x2', 'bf16x3'], default='bf16', help="secondary line: run the timed region on a precision tier instead of the bf16 engine "
+                    "(profiling the tier: tools/r5_kstats.sh); never the headline")
+    ap.add_argument('--bf16-round-weights', action='store_true', help='secondary line: round the random-init parameters to bf16 first (the bf16-representable checkpoint of the tier figures)')
     ap.add_argument('--train', action='store_true', help='time the TRAINING step of the C2 base transformer (MaskGit.forward + backward + AdamW) instead of '
                     'generation: a second, separately labelled line -- not the BASELINE metric')
     args = ap.parse_args()
@@ -449,6 +452,13 @@ def main():
     if args.fp8:
         mg.set_precision('fp8')
         args.no_parity_tier = True
+    if args.bf16_round_weights:
+        with torch.no_grad():
+            for p_ in list(mg.transformer.parameters()) + list(mg.vae.parameters()):
+                p_.copy_(p_.to(torch.bfloat16).float())
+    if args.precision != 'bf16':
+        mg.set_precision(args.precision)
+        args.no_parity_tier = args.no_graph_leg = True
     B = args.batch or (32 if args.tiny else CONFIGS[args.config][4])
     T = args.timesteps
     n = (image_size // 16) ** 2
@@ -525,7 +535,7 @@ def main():
                 if substr in name:
                     return v['hbm_bytes_per_launch']
             return None
-        metric_cfg = (not args.tiny) and args.config == 'c2' and B == 32 and not args.fp8
+        metric_cfg = (not args.tiny) and args.config == 'c2' and B == 32 and not args.fp8 and args.precision == 'bf16' and args.text_len == 32
         fused_on = tr._model().packed.get('wcov') is not None and not args.no_fused_sampling
         total_images = world * B * args.steps
         value = total_images / elapsed
@@ -541,7 +551,8 @@ def main():
             'value': value, 'unit': 'images/sec', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'fp8 (e4m3 weights and activations on the fp8 MFMA for the blocks\' Linear layers; attention / to_logits / sampling / VAE bf16)' if args.fp8 else 'bf16',
+            'dtype': ('fp8 (e4m3 weights and activations on the fp8 MFMA for the blocks\' Linear layers; attention / to_logits / sampling / VAE bf16)' if args.fp8
+                      else ('bf16' if args.precision == 'bf16' else f'{args.precision} (precision tier: fp16 / bf16 term products with fp32 accumulation; secondary line)')),
             'data': 'synthetic',
             'config': {'workload': desc + (' [fp8 engine]' if args.fp8 else ''), 'images_per_gpu_per_step': B, 'global_batch': world * B, 'seq_len': n, 'timesteps': T,
                        'text_len': args.text_len, 'cond_ids': nc, 'parallelism': f'dp{world} (batch-sharded, 1 all-gather of ids per step)',

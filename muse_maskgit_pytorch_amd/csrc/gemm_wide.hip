@@ -18,6 +18,13 @@
                               // w1 63.1 vs 60.7 us, logits 590-610 vs 550-560 us, bit-identical results -- where the pieces are issued is not what bounds the loop)
 #endif
 
+#ifdef MM_GEMM_TIMING      // tools (gemm_harness `stamps`): s_memtime stamps of workgroup 0, waves 0 and 4 of gemm_wide_fused_kernel along their tiles
+__device__ unsigned long long g_wide_stamps[2][2048];
+#define WD_STAMP() { if (ts_on && ts_i < 2048) g_wide_stamps[ts_g][ts_i++] = __builtin_readcyclecounter(); }
+#else
+#define WD_STAMP()
+#endif
+
 namespace {
 
 constexpr int TM = 256, TN = 256, BKB = 128;      // tile (TN: the 256-row weight tile; the dense kernel also has a 192-row form); bytes per k-step row (64 bf16)
@@ -317,6 +324,11 @@ __global__ __launch_bounds__(512) void gemm_wide_fused_kernel(const GemmArgs p) 
     }
     int vb = blockIdx.x;
     if (vb >= total) return;
+#ifdef MM_GEMM_TIMING
+    const bool ts_on = blockIdx.x == 0 && (t == 0 || t == 256);
+    const int ts_g = t >> 8;
+    int ts_i = 0;
+#endif
     __amdgpu_buffer_rsrc_t rx, rw;
     int tile_m, tile_n;
 #define TILE_SETUP(vb_)                                                                                                                \
@@ -346,8 +358,12 @@ __global__ __launch_bounds__(512) void gemm_wide_fused_kernel(const GemmArgs p) 
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = 0; b < 8; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        WD_STAMP();      // tile start
         for (int kt = 0; kt < KT; ++kt) {
             const int st = kt & 1;
+#ifdef MM_GEMM_TIMING
+            if (kt > 0 && vb == (int)blockIdx.x + 3 * G) WD_STAMP();      // the fourth tile: one stamp per k-step
+#endif
             if (kt == 0) wait_vmcnt_w(pending); else __builtin_amdgcn_s_waitcnt(0x0F70);      // this step's DMA has landed (in-order retirement: only younger stores may be in flight)
             __builtin_amdgcn_s_barrier();
             // (the DMA issue stays right behind the barrier; behind the first sub-step -- what the non-persistent kernel above did -- measured 2 %
@@ -383,6 +399,7 @@ __global__ __launch_bounds__(512) void gemm_wide_fused_kernel(const GemmArgs p) 
 #pragma unroll
                 for (int b = 0; b < 8; ++b) acc[a][b] *= al;
         }
+        WD_STAMP();      // k-loop end
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();            // everybody is done with stage 1: it becomes the exchange area
         // ---- emission from the accumulators (gemm_cfg.hip, tile end of WIDE_MIX2; token of fragment block b: 128 wm + 16 b + fr)
@@ -430,6 +447,7 @@ __global__ __launch_bounds__(512) void gemm_wide_fused_kernel(const GemmArgs p) 
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();      // all 16 lane groups of every token have published their masks and (ml, pl)
+        WD_STAMP();      // statistics + masks published, exchange barrier passed
         // ---- the kept granules go out compacted in column order: a quarter starts behind the kept granules of the quarters in front of it
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -477,6 +495,7 @@ __global__ __launch_bounds__(512) void gemm_wide_fused_kernel(const GemmArgs p) 
                 nstore += 2;
             }
         }
+        WD_STAMP();      // candidate stores + records issued
         pending = nstore;
         vb += G;
         if (vb >= total) break;
@@ -538,6 +557,7 @@ bool mm_gemm_wide_fused_eligible(const GemmArgs& a) {
 }
 
 int mm_gemm_wide_fused_launch(GemmArgs a, hipStream_t stream) {
+    if (mm_gemm_pp_fused_selected(a)) return mm_gemm_pp_fused_launch(a, stream);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_F);
@@ -561,3 +581,10 @@ int mm_gemm_wide_launch(GemmArgs a, hipStream_t stream) {
     if (a.epi == EPI_GEGLU) return launch_wide<true, 4>(a, stream);
     return wide_nfw(a) == 4 ? launch_wide<false, 4>(a, stream) : launch_wide<false, 3>(a, stream);
 }
+
+#ifdef MM_GEMM_TIMING
+extern "C" int mm_debug_wide_stamps(unsigned long long* host_dst, int n) {      // [2][2048]
+    (void)n;
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_wide_stamps), sizeof(unsigned long long) * 2 * 2048);
+}
+#endif

@@ -68,6 +68,8 @@ int mm_gemm_wide_launch(GemmArgs a, hipStream_t stream);
 bool mm_gemm_wide_fused_eligible(const GemmArgs& a);      // the fused-sampling logits GEMM on the same k-loop (persistent)
 int mm_gemm_wide_fused_launch(GemmArgs a, hipStream_t stream);     // gemm_cfg.hip: persistent 128 tokens x 256 columns, guidance logits
 int mm_gemm_cfg2_launch(GemmArgs a, hipStream_t stream);
+bool mm_gemm_pp_fused_selected(const GemmArgs& a);      // gemm_pp.hip (round 5): the logits GEMM with its wave groups out of lock-step
+int mm_gemm_pp_fused_launch(GemmArgs a, hipStream_t stream);
 // gemm_pers.hip: persistent 256x128, stores overlapped with the next tile
 int mm_gemm_pers_launch(GemmArgs a, hipStream_t stream);
 

@@ -5,6 +5,7 @@
 //                 -Wl,-rpath,'$ORIGIN/../../muse_maskgit_pytorch_amd'
 //   run:    tools/build/gemm_harness [debug_bits] [case ...]      cases: qkv w1 out w2 xq logits sample fp8check fp8 (default: all)
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -188,7 +189,7 @@ int main(int argc, char** argv) {
             CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(o)); CK(hipFree(dsx)); CK(hipFree(dsw)); if (dr) CK(hipFree(dr));
         }
     }
-    if (want("logits") || want("sample")) {
+    if (want("logits") || want("sample") || want("stamps") || want("pairs")) {
         void* x = dev_bf16((size_t)R * D, 1.f); void* w = dev_bf16((size_t)V * D, 0.02f);
         // logits ~ N(0, sigma^2), sigma = sqrt(D) * 0.02; thr_lo at the 12 % quantile + margin as in the decode loop
         const float sigma = sqrtf((float)D) * 0.02f;
@@ -198,8 +199,94 @@ int main(int argc, char** argv) {
         void *stats, *cand;
         CK(hipMalloc(&stats, (size_t)R * (V / 256) * 32)); CK(hipMalloc(&cand, (size_t)R * (V / 256) * MM_FUSED_SLOT * 16));
         if (want("logits")) {
-            const double us = time_us([&] { MK(mm_gemm_cfg_logits_fused(nullptr, x, nullptr, D, w, D, R, V, D, 3.f, thr, stats, cand)); });
-            report("logits", us, 2.0 * R * (double)V * D, checksum(stats, (size_t)R * (V / 256) * 32));
+            // one run on zeroed buffers first: the candidate slots are only partly written, so their checksum needs a defined background
+            CK(hipMemset(stats, 0, (size_t)R * (V / 256) * 32)); CK(hipMemset(cand, 0, (size_t)R * (V / 256) * MM_FUSED_SLOT * 16));
+            MK(mm_gemm_cfg_logits_fused(nullptr, x, nullptr, D, w, D, R, V, D, 3.f, thr, stats, cand));
+            CK(hipDeviceSynchronize());
+            const uint64_t cs_stats = checksum(stats, (size_t)R * (V / 256) * 32), cs_cand = checksum(cand, (size_t)R * (V / 256) * MM_FUSED_SLOT * 16);
+            const double us = time_us([&] { MK(mm_gemm_cfg_logits_fused(nullptr, x, nullptr, D, w, D, R, V, D, 3.f, thr, stats, cand)); }, getenv("MM_ITERS") ? atoi(getenv("MM_ITERS")) : 20);
+            report("logits", us, 2.0 * R * (double)V * D, cs_stats);
+            printf("         candidates checksum %016llx  (MM_PP=%s)\n", (unsigned long long)cs_cand, getenv("MM_PP") ? getenv("MM_PP") : "0");
+        }
+        if (want("stamps")) {
+            // in-kernel s_memtime stamps of workgroup 0 (a library built with -DMM_GEMM_TIMING: tools/build_timing.sh): per tile {start, [k-steps of the 4th tile], k-loop end,
+            // exchange barrier passed, stores issued}, for wave 0 (group 0) and wave 4 (group 1)
+            typedef int (*stamps_fn)(unsigned long long*, int);
+            const bool pp = getenv("MM_PP") && atoi(getenv("MM_PP")) != 0;
+            stamps_fn fn = (stamps_fn)dlsym(RTLD_DEFAULT, pp ? "mm_debug_pp_stamps" : "mm_debug_wide_stamps");
+            if (!fn) { printf("stamps: the library was not built with MM_GEMM_TIMING\n"); return 1; }
+            for (int i = 0; i < 3; ++i) MK(mm_gemm_cfg_logits_fused(nullptr, x, nullptr, D, w, D, R, V, D, 3.f, thr, stats, cand));
+            CK(hipDeviceSynchronize());
+            const double us = time_us([&] { MK(mm_gemm_cfg_logits_fused(nullptr, x, nullptr, D, w, D, R, V, D, 3.f, thr, stats, cand)); }, 5);
+            std::vector<unsigned long long> st(2 * 2048);
+            if (fn(st.data(), 2048)) { printf("stamps: copy failed\n"); return 1; }
+            const int extra = getenv("MM_STAMP_EXTRA") ? atoi(getenv("MM_STAMP_EXTRA")) : (pp ? D / 32 : D / 64 - 1);      // stamps inside the 4th tile's k-loop
+            printf("stamps (MM_PP=%s, %.1f us per launch, %d in-loop stamps in tile 3)\n", getenv("MM_PP") ? getenv("MM_PP") : "0", us, extra);
+            for (int g = 0; g < 2; ++g) {
+                const unsigned long long* t = st.data() + g * 2048;
+                int i = 0, tile = 0;
+                double sk = 0, s1 = 0, s2 = 0, sg = 0; int cnt = 0;
+                unsigned long long prev_end = 0;
+                while (i + 4 <= 2048 && t[i] && tile < 40) {
+                    const unsigned long long t0 = t[i];
+                    const int ex = tile == 3 ? extra : 0;
+                    if (i + 4 + ex > 2048 || !t[i + 3 + ex]) break;
+                    const unsigned long long te = t[i + 1 + ex], tb = t[i + 2 + ex], ts_ = t[i + 3 + ex];
+                    if (tile == 3) {
+                        printf("  group %d tile 3 in-loop deltas:", g);
+                        unsigned long long p0 = t0;
+                        for (int j = 0; j < ex; ++j) { printf(" %llu", t[i + 1 + j] - p0); p0 = t[i + 1 + j]; }
+                        printf(" | last -> loop end %llu\n", te - p0);
+                    }
+                    if (tile >= 1 && tile != 3) { sk += (double)(te - t0); s1 += (double)(tb - te); s2 += (double)(ts_ - tb); if (prev_end) sg += (double)(t0 - prev_end); ++cnt; }
+                    if (tile < 3 || tile == 3) printf("  group %d tile %d: k-loop %llu  stats+exchange %llu  stores+records %llu  (gap before %lld)\n", g, tile, te - t0, tb - te, ts_ - tb, prev_end ? (long long)(t0 - prev_end) : 0ll);
+                    prev_end = ts_;
+                    i += 4 + ex; ++tile;
+                }
+                if (cnt) printf("  group %d mean over %d tiles: k-loop %.0f  stats+exchange %.0f  stores+records %.0f  gap %.0f  -> tile %.0f cycles; %d tiles seen, first->last %.0f cycles\n", g, cnt, sk / cnt, s1 / cnt, s2 / cnt, sg / cnt,
+                                (sk + s1 + s2 + sg) / cnt, tile, (double)(prev_end - t[0]));
+            }
+        }
+        if (want("pairs")) {
+            // which workgroups share a CU, and how their k-loops / emissions interleave (timing build, MM_PP=13x): per workgroup {hw id, start, per tile: k-loop end, emission end}
+            typedef int (*tfn)(unsigned long long*);
+            tfn fn = (tfn)dlsym(RTLD_DEFAULT, "mm_debug_pp_tile_stamps");
+            if (!fn) { printf("pairs: the library was not built with MM_GEMM_TIMING\n"); return 1; }
+            for (int i = 0; i < 2; ++i) MK(mm_gemm_cfg_logits_fused(nullptr, x, nullptr, D, w, D, R, V, D, 3.f, thr, stats, cand));
+            CK(hipDeviceSynchronize());
+            std::vector<unsigned long long> ts(512 * 128);
+            if (fn(ts.data())) { printf("pairs: copy failed\n"); return 1; }
+            auto cu_key = [&](int b) { const unsigned long long h = ts[(size_t)b * 128]; return (unsigned)(((h >> 32) & 15) << 12) | (unsigned)((h >> 8) & 0xFF); };      // xcc | se, sh, cu
+            int shown = 0, odd_second_half = 0, pairs_half = 0, npairs = 0;
+            double both_k = 0, total = 0;
+            for (int b = 0; b < 512; ++b) {
+                for (int c = b + 1; c < 512; ++c) {
+                    if (cu_key(b) != cu_key(c)) continue;
+                    ++npairs;
+                    if ((b < 256) != (c < 256)) ++pairs_half;
+                    const unsigned long long* A = &ts[(size_t)b * 128]; const unsigned long long* B = &ts[(size_t)c * 128];
+                    if (shown < 3) {
+                        printf("  CU %05x: workgroups %d (wave slot %llu) and %d (slot %llu); start %lld apart\n", cu_key(b), b, A[0] & 15, c, B[0] & 15, (long long)(B[1] - A[1]));
+                        for (int i = 0; i < 6; ++i) printf("    tile %d: wg %d k-loop [%lld, %lld) emission -> %lld | wg %d k-loop [%lld, %lld) emission -> %lld\n", i,
+                                                           b, (long long)((i ? A[1 + 2 * i] : A[1]) - A[1]), (long long)(A[2 + 2 * i] - A[1]), (long long)(A[3 + 2 * i] - A[1]),
+                                                           c, (long long)((i ? B[1 + 2 * i] : B[1]) - A[1]), (long long)(B[2 + 2 * i] - A[1]), (long long)(B[3 + 2 * i] - A[1]));
+                        ++shown;
+                    }
+                    // overlap of the two k-loops over tiles 1 .. 15
+                    for (int i = 1; i < 16; ++i) {
+                        const long long a0 = A[1 + 2 * i], a1 = A[2 + 2 * i];
+                        for (int j = 0; j < 18; ++j) {
+                            const long long b0 = j ? B[1 + 2 * j] : B[1], b1 = B[2 + 2 * j];
+                            const long long lo = a0 > b0 ? a0 : b0, hi = a1 < b1 ? a1 : b1;
+                            if (hi > lo) both_k += (double)(hi - lo);
+                        }
+                        total += (double)(a1 - a0);
+                    }
+                }
+                if ((ts[(size_t)b * 128] & 1) && b >= 256) ++odd_second_half;
+            }
+            printf("pairs: %d co-resident pairs found, %d of them (first half, second half); odd-slot workgroups in the second half: %d; k-loop time of a workgroup spent beside its partner's k-loop: %.2f\n",
+                   npairs, pairs_half, odd_second_half, total > 0 ? both_k / total : 0.);
         }
         if (want("sample")) {
             MK(mm_gemm_cfg_logits_fused(nullptr, x, nullptr, D, w, D, R, V, D, 3.f, thr, stats, cand));
