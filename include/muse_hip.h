@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 5
+#define MM_ABI_VERSION 6
 
 #define MM_OK 0
 #define MM_ERR_SHAPE (-1)
@@ -474,7 +474,15 @@ typedef struct mm_transformer_desc {
      * Self-defined numerics: the oracle is the fp32 restatement with the same per-row fake quantisation at every Linear of the layers. */
     int32_t fp8;
     float split_alpha;              /* fp16 terms only: the power of two every GEMM accumulator is multiplied by (0 = 1); the weight terms were packed x 1 / split_alpha */
+    /* bf16 engine, LayerNorm(dim) folded into the GEMMs around it (default).  The fold multiplies the bf16 image of the RAW residual row, so its rounding error in
+     * normalised units grows with |row mean| / (row standard deviation): negligible for random-init-like statistics, visible for a checkpoint whose residual
+     * stream carries a large DC offset.  ln_fold_off != 0 runs every LayerNorm as its own kernel (the round-3 engine; same arithmetic otherwise).  ln_probe
+     * (optional, device float[1], zeroed by the caller): every fold consumer first records max(|mean| * rstd) of the rows it reads (atomicMax) -- the host side
+     * probes once per packed model and falls back to ln_fold_off above MM_LN_FOLD_MAX_RATIO (muse_maskgit.py, Transformer.set_layernorm_fold). */
+    int32_t ln_fold_off;
+    float* ln_probe;
 } mm_transformer_desc;
+#define MM_LN_FOLD_MAX_RATIO 1.0f
 
 typedef struct mm_transformer mm_transformer_t;
 
@@ -496,6 +504,14 @@ size_t mm_transformer_workspace_bytes(const mm_transformer_t* model, int B, int 
 int mm_transformer_forward(const mm_transformer_t* model, mm_stream_t stream, const int64_t* ids, int B, int n,
                            const void* ctx, const uint8_t* key_mask, int m, const float* self_cond_embed,
                            void* embed_out, float* logits_out, void* workspace, size_t workspace_bytes);
+
+/* The cross-attention block of ONE layer as an operator (round 5): x (fp32 [seqs * n][dim], updated in place) += CrossAttention(LayerNorm(x), ctx) -- mmp.py:139-162,
+ * 191 -- exactly as mm_transformer_forward runs it for this model: on the bf16 engine's headline shape class (dim = inner = 512, 8 heads x 64, <= 35 context tokens,
+ * LayerNorm(dim) fold on) the one-kernel form of csrc/cross_fold.hip, otherwise (or with mm_debug_set bit 1 << 31) q projection + attention + output projection.
+ * ctx bf16 [seqs][m][dim], key_mask uint8 [seqs][m] or NULL.  bf16 engine only.  Test surface of the block (tests/test_gpu_ops.py). */
+size_t mm_cross_attention_block_workspace_bytes(const mm_transformer_t* model, int seqs, int n, int m);
+int mm_cross_attention_block(const mm_transformer_t* model, mm_stream_t stream, int layer, float* x, int seqs, int n, const void* ctx, const uint8_t* key_mask, int m,
+                             void* workspace, size_t workspace_bytes);
 
 /* MaskGit.generate's decode loop (mmp.py:519-615), whole loop on `stream` with no host synchronisation:
  * CFG double pass batched as 2B sequences, cross-attention K/V of the context computed once, logits and
@@ -540,6 +556,10 @@ typedef struct mm_generate_params {
     float pad1;
     void* critic_workspace;         /* device, >= mm_generate_critic_workspace_bytes(critic or model, ...) */
     size_t critic_workspace_bytes;
+    /* optional device uint64[2] = {seed, row_offset}: with MM_NOISE_PHILOX the sampling kernels read their keys from here AT EXECUTION TIME instead of the
+     * `seed` / `row_offset` fields above -- a hipGraph captured once around mm_generate then replays with whatever the host wrote into the buffer before
+     * the replay (MaskGit.generate(graph=True)): fresh noise per replay, bit-identical to an eager call with the same keys. */
+    const uint64_t* seed_dev;
 } mm_generate_params;
 
 size_t mm_generate_workspace_bytes(const mm_transformer_t* model, int B, int n, int L, int nc);

@@ -35,12 +35,15 @@ class LayerWeights(C.Structure):
     _fields_ = [('self_attn', AttnWeights), ('cross_attn', AttnWeights), ('ff', FFWeights)]
 
 
+MM_LN_FOLD_MAX_RATIO = 1.0      # include/muse_hip.h
+
+
 class TransformerDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('dim', 'depth', 'heads', 'dim_head', 'ff_inner', 'ff_inner_padded', 'seq_len',
                                          'num_tokens', 'vocab_rows', 'dim_out', 'text_dim', 'self_cond')] + \
                [('token_emb', c_vp), ('pos_emb', c_vp), ('text_proj', c_vp), ('layers', C.POINTER(LayerWeights)),
                 ('final_gamma', c_vp), ('final_beta', c_vp), ('to_logits', c_vp), ('self_cond_ff', FFWeights), ('logits_wmean', c_vp), ('logits_wcov', c_vp),
-                ('split_products', C.c_int32), ('fp8', C.c_int32), ('split_alpha', c_f32)]
+                ('split_products', C.c_int32), ('fp8', C.c_int32), ('split_alpha', c_f32), ('ln_fold_off', C.c_int32), ('ln_probe', c_vp)]
 
 
 class TrainAttn(C.Structure):
@@ -78,7 +81,7 @@ class GenerateParams(C.Structure):
                 ('text_embeds', c_vp), ('cond_ids', c_vp), ('noise', c_vp), ('ids', c_vp), ('scores', c_vp),
                 ('trace_masked_ids', c_vp), ('trace_ids', c_vp), ('trace_scores', c_vp), ('status', c_vp),
                 ('critic', c_vp), ('critic_head_w', c_vp), ('critic_head_b', c_vp), ('critic_noise', c_vp), ('critic_noise_scale', c_f32),
-                ('pad1', c_f32), ('critic_workspace', c_vp), ('critic_workspace_bytes', c_sz)]
+                ('pad1', c_f32), ('critic_workspace', c_vp), ('critic_workspace_bytes', c_sz), ('seed_dev', c_vp)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/muse_hip.h must appear here (tests check both ways)
@@ -167,6 +170,8 @@ SIGNATURES = {
     'mm_transformer_context': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_sz]),
     'mm_transformer_workspace_bytes': (c_sz, [c_vp, c_int, c_int, c_int]),
     'mm_transformer_forward': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_sz]),
+    'mm_cross_attention_block_workspace_bytes': (c_sz, [c_vp, c_int, c_int, c_int]),
+    'mm_cross_attention_block': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_sz]),
     'mm_generate_critic_workspace_bytes': (c_sz, [c_vp, c_int, c_int, c_int, c_int]),
     'mm_generate_workspace_bytes': (c_sz, [c_vp, c_int, c_int, c_int, c_int]),
     'mm_generate': (c_int, [c_vp, c_vp, C.POINTER(GenerateParams), c_vp, c_sz]),
@@ -207,7 +212,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.mm_abi_version() != 5:
+        if l.mm_abi_version() != 6:
             raise MuseHipError('libmuse_hip ABI version mismatch')
         if os.environ.get('MM_DEBUG'):      # tools / A-B runs only: kernel-selection bits (see muse_hip_internal.h)
             l.mm_debug_set(int(os.environ['MM_DEBUG'], 0))

@@ -44,10 +44,11 @@ __device__ __forceinline__ f32x4_t mfma16k16(const uint2& a, const uint2& b, f32
     return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf16x4s_t, a), __builtin_bit_cast(bf16x4s_t, b), c, 0, 0, 0);
 }
 
-template <int NQB>      // 16-query blocks per workgroup: 2 (32 queries) or 4 (64 queries: the packed operands -- 840 KB -- are streamed once for twice the rows)
+constexpr int NQB = 2;            // 16-query blocks per workgroup (32 queries).  A 64-query form -- the packed operands streamed once for twice the rows, half as many
+                                  // workgroups -- measured 31.5 vs 24.3 us per launch in round 4 (the operand feed is bound per CU: idling half of the CUs loses) and was removed
 __global__ __launch_bounds__(512, 2) void cross_fold_kernel(const CrossFoldArgs p) {
     constexpr int XQ = 16 * NQB;
-    constexpr int RING = NQB == 2 ? 5 : 4;      // k-blocks of q-weight fragments in flight per wave (register budget: 256; a k-block of the 64-query form computes twice as long)
+    constexpr int RING = 5;       // k-blocks of q-weight fragments in flight per wave (register budget: 256)
     __shared__ __attribute__((aligned(16))) unsigned char Xs[XQ * X_LD];
     __shared__ __attribute__((aligned(16))) unsigned char Ps[XQ * P_LD];
     const int t = threadIdx.x, lane = t & 63;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(512, 2) void cross_fold_kernel(const CrossFoldArgs 
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob) kf[kb][ob] = kp[(kb * 4 + ob) * 64];
     };
-    if constexpr (NQB == 2) load_kf();      // (the 64-query form has no registers for them during phase B: it requests them at the start of phase C)
+    load_kf();
     float4 c1[4], c2[4], qs[4];
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) {
@@ -150,7 +151,6 @@ __global__ __launch_bounds__(512, 2) void cross_fold_kernel(const CrossFoldArgs 
         __builtin_amdgcn_sched_barrier(0);      // (the refill is requested HERE: the scheduler otherwise sinks it to its use five k-blocks later and waits for it there)
     }
     // ---- phase C: fold epilogue + l2norm * q_scale: lane holds features 64 w + 16 ob + 4 fg + r of query fr (per query block)
-    if constexpr (NQB != 2) load_kf();
     uint2 qh[4][NQB];
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
@@ -176,12 +176,12 @@ __global__ __launch_bounds__(512, 2) void cross_fold_kernel(const CrossFoldArgs 
     __builtin_amdgcn_sched_barrier(0);
     // this wave's VW^T fragments (A operands of phase D) are requested now, behind the q accumulators' registers: [kv sequence][32 feature blocks][9 k-blocks]
     // [64 lanes][8 bf16]; they arrive under the scores and the softmax.  (64-query form: in two batches, one in front of each pair of query blocks -- all 36
-    // fragments + the four blocks' q^ + K^ do not fit the register file at once)
+    // fragments + the four blocks' q^ + K^ do not fit the register file at once -- NQB == 2: one batch)
     uint4 av[4][XKB];
     const uint4* vp = reinterpret_cast<const uint4*>(p.vwt) + ((size_t)kvb * (XD / 16) + (size_t)w * 4) * XKB * 64 + lane;
 #pragma unroll
     for (int qp = 0; qp < NQB / 2; ++qp) {
-        constexpr int KSPLIT = NQB == 2 ? XKB : 5;
+        constexpr int KSPLIT = XKB;
 #pragma unroll
         for (int kb = (qp == 0 ? 0 : KSPLIT); kb < (qp == 0 ? KSPLIT : XKB); ++kb)      // (requested in the order phase D consumes them)
 #pragma unroll
@@ -425,9 +425,7 @@ int k_cross_fold(hipStream_t s, const CrossFoldArgs& a) {
     if (a.m < 1 || a.m + 1 > XKS) return mm_set_error(MM_ERR_SHAPE, "cross_fold: 1 <= context tokens <= 35");
     if ((a.ldx % 4) || (a.ldxb_in % 8) || (a.xb && (a.ldxb % 4))) return mm_set_error(MM_ERR_SHAPE, "cross_fold: unaligned rows");
     if (!a.xb_in || !a.stp_in || a.in_np != XD / 64 || !a.wqf || !a.c1 || !a.q_scale) return mm_set_error(MM_ERR_SHAPE, "cross_fold: fold inputs of the q projection required");
-    // 32 queries per workgroup.  (The 64-query instantiation -- the packed operands streamed once for twice the rows, half as many workgroups -- measured 31.5 vs
-    // 24.3 us per launch, 539.0 vs 546.9 images/s on the same box: the operand feed is bound per CU, so idling half of the CUs loses.  The template keeps the form.)
-    const int nqb = (a.nq + 31) / 32;
-    hipLaunchKernelGGL(cross_fold_kernel<2>, dim3(8 * ((a.seqs + 7) / 8) * nqb), dim3(512), 0, s, a);
+    const int nqb = (a.nq + 31) / 32;      // 32 queries per workgroup
+    hipLaunchKernelGGL(cross_fold_kernel, dim3(8 * ((a.seqs + 7) / 8) * nqb), dim3(512), 0, s, a);
     return mm_check_launch("cross_fold_kernel");
 }

@@ -13,11 +13,6 @@
 #include "common.h"
 #include "muse_hip_internal.h"
 
-#ifndef MM_WIDE_SPREAD
-#define MM_WIDE_SPREAD 0      // 1: one LDS-DMA piece behind every second block of a k-step instead of a burst (round-4 experiment, measured SLOWER on the same box:
-                              // w1 63.1 vs 60.7 us, logits 590-610 vs 550-560 us, bit-identical results -- where the pieces are issued is not what bounds the loop)
-#endif
-
 #ifdef MM_GEMM_TIMING      // tools (gemm_harness `stamps`): s_memtime stamps of workgroup 0, waves 0 and 4 of gemm_wide_fused_kernel along their tiles
 __device__ unsigned long long g_wide_stamps[2][2048];
 #define WD_STAMP() { if (ts_on && ts_i < 2048) g_wide_stamps[ts_g][ts_i++] = __builtin_readcyclecounter(); }
@@ -84,11 +79,6 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs p) {
         _Pragma("unroll") for (int i = 0; i < NFW; ++i)                                                                                \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(ws_ + i * 1024), 16, voff_w[i], (kt_) * BKB, 0, 0);              \
     }
-#define ISSUE_PIECE(kt_, st_, j_)                                                                                                      \
-    {                                                                                                                                  \
-        if ((j_) < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(smem + (st_) * STG + wid * 4096 + (j_) * 1024), 16, voff_x[(j_) & 3], (kt_) * BKB, 0, 0); \
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(smem + (st_) * STG + X_B + wid * (NFW * 1024) + ((j_) - 4) * 1024), 16, voff_w[((j_) - 4) & 3], (kt_) * BKB, 0, 0); \
-    }
     // Persistent when the step count is even (the launcher then starts one workgroup per CU): the NEXT tile's first k-step is requested during the last step of
     // the current one, into stage 0, which that step (odd index: stage 1) does not read; the epilogue stages its output through stage 1 and its global stores
     // are still retiring while the next tile's first steps run (the wait of that tile's step 0 counts them: VMEM retires in order).
@@ -107,16 +97,6 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs p) {
             const int st = kt & 1;
             if (kt == 0) wait_vmcnt_w(pending); else __builtin_amdgcn_s_waitcnt(0x0F70);      // this step's DMA has landed (only younger stores may still be in flight)
             __builtin_amdgcn_s_barrier();            // ... for everybody, and everybody is done reading the other stage
-#if MM_WIDE_SPREAD
-            // where this step's LDS-DMA pieces go: the next k-step's stage, or -- last step, persistent launch (even KT) -- the NEXT tile's first step into stage 0
-            int nk = kt + 1, ns = st ^ 1;
-            bool do_issue = true;
-            if (kt + 1 == KT) {
-                nk = 0; ns = 0;
-                do_issue = vb + G < total;
-                if (do_issue) TILE_SETUP(vb + G);
-            }
-#endif
             if (kt == 1 && p.in_c1 && wid < 4) {
                 // LayerNorm(dim) fold: the partials of this tile's 256 rows landed with step 1's wait; ONE thread per row turns them into (rstd, -mean) in
                 // the shadow of this step's MFMAs (read again only in the epilogue, many barriers from here)
@@ -148,19 +128,13 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs p) {
                 for (int a = 0; a < NFW; ++a) acc[a][b] = mfma16(it < 8 ? wf[a] : wf2[a], xr[it % 3], acc[a][b]);
                 // The next step's DMA goes out BEHIND the first sub-step: right behind the barrier it delays the first MFMAs of both waves of a SIMD, behind
                 // the second sub-step it lands too late (FF w1 of the base config, tools/gemm_harness: 62.0 / 58.6 / 67.7 us for the three placements)
-#if MM_WIDE_SPREAD
-                // (round-4 experiment, off by default: one LDS-DMA piece behind every second block instead of a burst of 4 + NFW -- see MM_WIDE_SPREAD above)
-                if ((it & 1) == 0 && (it >> 1) < 4 + NFW && do_issue) ISSUE_PIECE(nk, ns, it >> 1);
-#endif
                 if (it == 7) {
-#if !MM_WIDE_SPREAD
                     if (kt + 1 < KT) {
                         ISSUE(kt + 1, st ^ 1);
                     } else if (vb + G < total) {     // (only with an even KT: see the launcher)
                         TILE_SETUP(vb + G);
                         ISSUE(0, 0);
                     }
-#endif
                     if (kt == 0 && p.in_c1) {
                         // LayerNorm(dim) fold (GemmArgs::in_c1): this tile's row statistics partials (256 rows x np x 8 bytes) and its 64 NFW entries of c1 / c2
                         // arrive by LDS-DMA too, behind the stages (retired by the vmcnt(0) of step 1: K >= 128)
@@ -279,7 +253,6 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs p) {
         // (no barrier here: a wave reaches the next tile's first barrier only behind its own staging reads, and the DMA into stage 1 is issued behind that barrier)
     }
 #undef ISSUE
-#undef ISSUE_PIECE
 #undef TILE_SETUP
 }
 

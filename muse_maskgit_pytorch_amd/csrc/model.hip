@@ -245,7 +245,12 @@ int f8_linear_bf16(hipStream_t s, Bufs& b, const bf16_t* act, long lda, int K, c
 // the fold off (A/B and the closeness test).
 int ln_fold_np(int D) { return D <= 512 ? (D + 63) / 64 : (D + 127) / 128; }      // statistics partials per row: per 64 columns up to dim 512, per 128 beyond (== mm_gemm_launch's st_np)
 bool ln_fold_on(const mm_transformer* t) {
-    return !t->P && !t->F8 && !(g_mm_debug & (1 << 29)) && (t->d.dim % 4) == 0;
+    return !t->P && !t->F8 && !t->d.ln_fold_off && !(g_mm_debug & (1 << 29)) && (t->d.dim % 4) == 0;
+}
+// safety probe of the fold (mm_transformer_desc.ln_probe): called in front of every fold consumer's launch
+int fold_probe(const mm_transformer* t, hipStream_t s, const Bufs& b, int rows) {
+    if (!t->d.ln_probe) return MM_OK;
+    return k_ln_fold_ratio(s, b.stp, rows, ln_fold_np(t->d.dim), t->d.dim, t->d.ln_probe);
 }
 void fold_consume(GemmArgs& a, const mm_transformer* t, const Bufs& b, const void* w_ln, const float* c1, const float* c2) {
     a.X = b.xb; a.ldx = t->d.dim; a.W = (const bf16_t*)w_ln;
@@ -301,7 +306,7 @@ int ff_block(const mm_transformer* t, hipStream_t s, const mm_ff_weights& w, con
     a1.mode = MODE_DENSE; a1.epi = EPI_GEGLU;
     a1.W = (const bf16_t*)w.w1; a1.N = 2 * Fp; a1.ldw = D; a1.K = D; a1.M = rows; a1.X = b.xn; a1.ldx = D;
     a1.out = b.h; a1.ldc = Fp; a1.out_kind = OUT_BF16;
-    if (fold_in) fold_consume(a1, t, b, w.w1_ln, w.ln1_c1, w.ln1_c2);
+    if (fold_in) { fold_consume(a1, t, b, w.w1_ln, w.ln1_c1, w.ln1_c2); RC(fold_probe(t, s, b, rows)); }
     GemmArgs a2;      // Linear(F, D) + residual
     memset(&a2, 0, sizeof(a2));
     a2.mode = MODE_DENSE;
@@ -380,6 +385,7 @@ int self_attn_core(const mm_transformer* t, hipStream_t s, const mm_attn_weights
         a.mode = MODE_DENSE; a.N = 3 * I; a.ldw = D; a.K = D; a.M = rows;
         a.out = b.qkv; a.ldc = 3 * I; a.out_kind = OUT_BF16;
         fold_consume(a, t, b, w.w_q_ln, w.ln_c1, w.ln_c2);
+        RC(fold_probe(t, s, b, rows));
         TR(b.xb, (size_t)rows * D * 2);
         RC(mm_gemm_launch(a, s));
     } else {
@@ -451,6 +457,7 @@ int cross_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weigh
         f.x = b.x; f.ldx = D;
         if (fold_out) { f.xb = b.xb; f.ldxb = D; f.stp = b.stp; f.st_np = ln_fold_np(D); }
         f.seqs = seqs; f.nq = n; f.m = m; f.kv_batch_mod = kv_batch_mod; f.scale = 8.f;
+        RC(fold_probe(t, s, b, rows));
         TR(b.xb, (size_t)rows * D * 2);
         RC(k_cross_fold(s, f));
         TR(b.x, (size_t)rows * D * 4);
@@ -486,6 +493,7 @@ int cross_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weigh
         a.mode = MODE_DENSE; a.N = I; a.ldw = D; a.K = D; a.M = rows;
         a.out = b.qkv; a.ldc = I; a.out_kind = OUT_BF16;
         fold_consume(a, t, b, w.w_q_ln, w.ln_c1, w.ln_c2);
+        RC(fold_probe(t, s, b, rows));
         TR(b.xb, (size_t)rows * D * 2);
         RC(mm_gemm_launch(a, s));
     } else {
@@ -693,6 +701,45 @@ int mm_transformer_forward(const mm_transformer_t* t, mm_stream_t stream, const 
     if (logits_out)
         RC(gemm_dense(t, s, emb, KD, (const bf16_t*)t->d.to_logits, KD, rows, t->d.dim_out, KD, logits_out, t->d.dim_out, OUT_F32, nullptr));
     return MM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ the cross-attention block as an operator
+// x += CrossAttention(LayerNorm(x), context) of one layer (mmp.py:139-162, 191) on a caller-given residual stream, exactly as mm_transformer_forward runs it for this
+// model -- on the bf16 engine's headline shape class the one-kernel form (csrc/cross_fold.hip), otherwise (or with mm_debug_set bit 1 << 31) q projection +
+// attention + output projection.  Exists so that the block can be tested against the oracle as an OPERATOR (tests/test_gpu_ops.py), not only through a model.
+size_t mm_cross_attention_block_workspace_bytes(const mm_transformer_t* t, int seqs, int n, int m) {
+    if (!t || seqs <= 0 || n <= 0 || m <= 0) return 0;
+    Carver c(nullptr);
+    Bufs b;
+    carve_bufs(c, t, (size_t)seqs * n, b);
+    const size_t f32 = t->P ? 2 : 1;
+    c.take<bf16_t>((size_t)seqs * m * 2 * t->I * f32);
+    c.take<bf16_t>(k_cross_fold_khat_elems(seqs)); c.take<bf16_t>(k_cross_fold_vwt_elems(seqs)); c.take<bf16_t>(k_cross_fold_wqf_elems());
+    return c.used() + 256;
+}
+int mm_cross_attention_block(const mm_transformer_t* t, mm_stream_t stream, int layer, float* x, int seqs, int n, const void* ctx, const uint8_t* key_mask, int m,
+                             void* workspace, size_t workspace_bytes) {
+    if (!t || !x || !ctx || !workspace) return mm_set_error(MM_ERR_SHAPE, "cross_attention_block: null argument");
+    if (layer < 0 || layer >= t->d.depth || seqs <= 0 || n <= 0 || m <= 0) return mm_set_error(MM_ERR_SHAPE, "cross_attention_block: bad layer / shape");
+    if (t->P || t->F8) return mm_set_error(MM_ERR_UNSUPPORTED, "cross_attention_block: bf16 engine only");
+    if (workspace_bytes < mm_cross_attention_block_workspace_bytes(t, seqs, n, m)) return mm_set_error(MM_ERR_WORKSPACE, "cross_attention_block: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int D = t->d.dim, I = t->I;
+    const size_t rows = (size_t)seqs * n;
+    Carver c(workspace);
+    Bufs b;
+    carve_bufs(c, t, rows, b);
+    b.x = x;      // the caller's residual stream, updated in place
+    bf16_t* ckv = c.take<bf16_t>((size_t)seqs * m * 2 * I);
+    CrossFoldPack pk;
+    pk.khat = c.take<bf16_t>(k_cross_fold_khat_elems(seqs)); pk.vwt = c.take<bf16_t>(k_cross_fold_vwt_elems(seqs)); pk.wqf = c.take<bf16_t>(k_cross_fold_wqf_elems());
+    const mm_attn_weights& w = t->layers[layer].cross_attn;
+    const bool fold = ln_fold_on(t);
+    if (fold) RC(k_fold_image(s, x, D, (int)rows, D, b.xb, D, b.stp, ln_fold_np(D)));      // what the self-attention's output projection leaves in the model
+    RC(gemm_dense(t, s, (const bf16_t*)ctx, D, (const bf16_t*)w.w_kv, D, seqs * m, 2 * I, D, ckv, 2 * I, OUT_BF16, nullptr));
+    const bool xf = cross_fold_on(t, w, m);
+    if (xf) RC(cross_fold_pack(t, s, w, ckv, seqs, m, pk));
+    return cross_attn_block(t, s, w, seqs, n, ckv, m, 0, key_mask, b, fold, false, xf ? &pk : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------ generate
@@ -1125,7 +1172,7 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
             fa.R = R; fa.V = V; fa.k_keep = p->k_keep; fa.rows = rows;
             fa.temperature = p->temperatures[step]; fa.noise_kind = p->noise_kind;
             fa.noise = p->noise ? p->noise + (size_t)step * M * V : nullptr; fa.noise_ld = V;
-            fa.seed = p->seed; fa.row_offset = p->row_offset * (uint64_t)n; fa.step = (uint32_t)step;
+            fa.seed = p->seed; fa.row_offset = p->row_offset * (uint64_t)n; fa.step = (uint32_t)step; fa.seed_dev = p->seed_dev; fa.row_mul = n;
             fa.ids = ids_out; fa.scores = scores_out; fa.pred_out = pred_out; fa.score_out = conf_out; fa.fail_flag = p->status;
             const bool row_fallback = step < FB_STEPS;
             if (row_fallback) { fa.fail_rows = g.fb_rows; fa.fail_count = g.fb_cnt + step; fa.fail_cap = FB_CAP; }
@@ -1150,7 +1197,7 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
                 fs_.logits = g.fb_logits; fs_.ld = V; fs_.R = FB_CAP; fs_.V = V; fs_.k_keep = p->k_keep; fs_.rows = rows;
                 fs_.temperature = p->temperatures[step]; fs_.noise_kind = p->noise_kind;
                 fs_.noise = p->noise ? p->noise + (size_t)step * M * V : nullptr; fs_.noise_ld = V;
-                fs_.seed = p->seed; fs_.row_offset = p->row_offset * (uint64_t)n; fs_.step = (uint32_t)step;
+                fs_.seed = p->seed; fs_.row_offset = p->row_offset * (uint64_t)n; fs_.step = (uint32_t)step; fs_.seed_dev = p->seed_dev; fs_.row_mul = n;
                 fs_.ids = ids_out; fs_.scores = scores_out; fs_.pred_out = pred_out; fs_.score_out = conf_out;
                 fs_.src_rows = g.fb_rows; fs_.count_dev = g.fb_cnt + step;
                 RC(k_sample_rows(s, fs_));
@@ -1167,7 +1214,7 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
             sa.logits = g.logits; sa.ld = V; sa.R = R; sa.V = V; sa.k_keep = p->k_keep; sa.rows = rows;
             sa.temperature = p->temperatures[step]; sa.noise_kind = p->noise_kind;
             sa.noise = p->noise ? p->noise + (size_t)step * M * V : nullptr; sa.noise_ld = V;
-            sa.seed = p->seed; sa.row_offset = p->row_offset * (uint64_t)n; sa.step = (uint32_t)step;
+            sa.seed = p->seed; sa.row_offset = p->row_offset * (uint64_t)n; sa.step = (uint32_t)step; sa.seed_dev = p->seed_dev; sa.row_mul = n;
             sa.ids = ids_out; sa.scores = scores_out; sa.pred_out = pred_out; sa.score_out = conf_out;
             prof::Rec pr;
             if (prof::enabled) pr = prof::begin(s, 4.0 * (double)R * (double)V);      // one fp32 read of each row

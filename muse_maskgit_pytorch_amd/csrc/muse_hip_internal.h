@@ -87,6 +87,8 @@ int k_geglu_ln(hipStream_t s, const bf16_t* h, long ldh, int rows, int F, int Fp
                bf16_t* out, long ldo);
 int k_layernorm_addvec(hipStream_t s, float* x, long ldx, int rows, int D, const float* gamma, const float* beta, const float* addvec,
                        int add_from, bf16_t* out, long ldo);
+int k_fold_image(hipStream_t s, const float* x, long ldx, int rows, int D, bf16_t* xb, long ldxb, float* stp, int np);      // fold producer outputs of a stream no GEMM just wrote
+int k_ln_fold_ratio(hipStream_t s, const float* stp, int rows, int np, int F, float* out);      // max |mean| * rstd of the rows a LayerNorm(dim)-fold consumer reads -> atomicMax(*out)
 int k_gather_rows16(hipStream_t s, const void* src, long src_pitch_bytes, const int32_t* rows, int R, int row_add, int row_bytes, void* dst);
 int k_gather_rows16_multi(hipStream_t s, int njobs, const void* const* src, const long* src_pitch_bytes, const int* row_add, const int* row_bytes, void* const* dst,
                           const int32_t* rows, int R);
@@ -238,6 +240,9 @@ struct SampleArgs {
     // per-row fallback of the fused sampler: logits row i belongs to original row src_rows[i] (whose position / compact output slot / noise
     // stream it samples for), and only the first min(R, *count_dev) rows exist
     const int32_t* src_rows; const int32_t* count_dev;
+    // optional device-side Philox keys (mm_generate_params.seed_dev): {seed, row offset in SAMPLES}; when set they replace seed / row_offset (= seed_dev[1] * row_mul)
+    // at execution time, so a captured launch replays with fresh noise
+    const uint64_t* seed_dev; int row_mul;
 };
 int k_sample_rows(hipStream_t s, const SampleArgs& a);
 // sampling_fused.hip: sampling from what the guidance-logits GEMM emits instead of the logits (tile statistics + candidates)
@@ -255,6 +260,7 @@ struct FusedSampleArgs {
     // flag; the flag is raised only when the list overflows.  The caller finishes the listed rows on the logits path (model.hip).
     int32_t* fail_rows; int32_t* fail_count; int fail_cap;
     int debug;                                   // set by k_sample_fused from mm_debug_set (bit 1 << 27: test hook of the fallback)
+    const uint64_t* seed_dev; int row_mul;       // optional device-side Philox keys, see SampleArgs
 };
 float k_fused_z(int k_keep, int V, float margin);
 // thr[r] = mean_r + z sigma_r of row r's logits over the vocabulary; ws: k_fused_threshold_ws_bytes(R, D) bytes of scratch; wcov bf16 [D][D]

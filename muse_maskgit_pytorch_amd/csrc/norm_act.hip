@@ -296,6 +296,56 @@ int k_layernorm(hipStream_t s, const float* x, long ldx, int rows, int D, const 
     return mm_check_launch("layernorm_kernel");
 }
 
+// LayerNorm(dim) fold, producer outputs of a residual stream that no GEMM epilogue has just written (operator-level entry mm_cross_attention_block): the bf16 image
+// of every row and its (sum, sum of squares) per `gran` columns in the canonical order of common.h row_stats16 (16 adjacent lanes x 4 columns = 64 columns; two such
+// groups combined as (first + second) for 128-column partials) -- the bits a fp32-residual GEMM epilogue would have left.
+__global__ __launch_bounds__(256) void fold_image_kernel(const float* __restrict__ x, long ldx, int rows, int D, int gran, bf16_t* __restrict__ xb, long ldxb, float* __restrict__ stp, int np) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    for (int c0 = 0; c0 < D; c0 += 256) {      // a wave covers 256 columns per sweep: 4 groups of 16 lanes x 4 columns
+        const int col = c0 + lane * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col < D) v = *reinterpret_cast<const float4*>(x + (size_t)row * ldx + col);
+        if (col < D) *reinterpret_cast<uint2*>(xb + (size_t)row * ldxb + col) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+        float2 st = row_stats16((v.x + v.y) + (v.z + v.w), (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+        if (gran == 128) {      // (first 64 columns + second 64 columns)
+            st.x += __shfl_xor(st.x, 16, 64); st.y += __shfl_xor(st.y, 16, 64);
+            if ((lane & 31) == 0 && col < D) *reinterpret_cast<float2*>(stp + ((size_t)row * np + col / 128) * 2) = st;
+        } else if ((lane & 15) == 0 && col < D) {
+            *reinterpret_cast<float2*>(stp + ((size_t)row * np + col / 64) * 2) = st;
+        }
+    }
+}
+int k_fold_image(hipStream_t s, const float* x, long ldx, int rows, int D, bf16_t* xb, long ldxb, float* stp, int np) {
+    if (rows <= 0) return MM_OK;
+    if ((D % 64) || (ldx % 4) || (ldxb % 4)) return mm_set_error(MM_ERR_SHAPE, "fold_image: dim must be a multiple of 64, rows 16-byte aligned");
+    const int gran = D <= 512 ? 64 : 128;
+    if (np != (D + gran - 1) / gran) return mm_set_error(MM_ERR_SHAPE, "fold_image: partial count");
+    hipLaunchKernelGGL(fold_image_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, D, gran, xb, ldxb, stp, np);
+    return mm_check_launch("fold_image_kernel");
+}
+
+// LayerNorm(dim) fold, safety probe (mm_transformer_desc.ln_probe): max over rows of |mean| * rstd of the rows a fold consumer is about to read, from the
+// statistics partials their producer left (common.h ln_rstd_negmean: the value the consumer itself computes).  The fold multiplies the bf16 image of the RAW
+// row, whose rounding error in normalised units grows like |x^ + mean / sigma| instead of |x^|: harmless while the row mean is small against its spread
+// (random init: ~0.05), degrading for a checkpoint whose residual stream carries a DC offset.  One thread per row, atomicMax on the float's bits (>= 0).
+__global__ __launch_bounds__(256) void ln_fold_ratio_kernel(const float* __restrict__ stp, int rows, int np, float inv_F, float* __restrict__ out) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    float r = 0.f;
+    if (row < rows) {
+        const float2 st = ln_rstd_negmean(reinterpret_cast<const float2*>(stp) + (size_t)row * np, np, inv_F);
+        r = fabsf(st.y) * st.x;
+    }
+    r = wave_max(r);
+    if ((threadIdx.x & 63) == 0 && r > 0.f) atomicMax(reinterpret_cast<int*>(out), __float_as_int(r));
+}
+int k_ln_fold_ratio(hipStream_t s, const float* stp, int rows, int np, int F, float* out) {
+    if (rows <= 0) return MM_OK;
+    hipLaunchKernelGGL(ln_fold_ratio_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, stp, rows, np, 1.f / (float)F, out);
+    return mm_check_launch("ln_fold_ratio_kernel");
+}
+
 // x[add_from..rows) += addvec (in place), then out = LayerNorm(x) for all rows
 int k_layernorm_addvec(hipStream_t s, float* x, long ldx, int rows, int D, const float* gamma, const float* beta, const float* addvec,
                        int add_from, bf16_t* out, long ldo) {

@@ -168,7 +168,9 @@ __device__ __forceinline__ float noise_gumbel(const SampleArgs& p, long pos_flat
 }
 
 template <int VEC_IT, bool FULL>
-__global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p) {
+__global__ __launch_bounds__(ST) void sample_kernel(const SampleArgs p_in) {
+    SampleArgs p = p_in;
+    if (p.seed_dev) { p.seed = p.seed_dev[0]; p.row_offset = p.seed_dev[1] * (uint64_t)p.row_mul; }      // (wave-uniform scalar loads: the keys of a replayed graph)
     __shared__ SampleShared S;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int V = p.V;

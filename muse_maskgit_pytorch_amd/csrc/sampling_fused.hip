@@ -126,7 +126,9 @@ __device__ __forceinline__ int fs_sel_mask(int if_clear, int if_set, unsigned lo
     return r;
 }
 
-__global__ __launch_bounds__(FT, 4) void sample_fused_kernel(const FusedSampleArgs p) {
+__global__ __launch_bounds__(FT, 4) void sample_fused_kernel(const FusedSampleArgs p_in) {
+    FusedSampleArgs p = p_in;
+    if (p.seed_dev) { p.seed = p.seed_dev[0]; p.row_offset = p.seed_dev[1] * (uint64_t)p.row_mul; }      // (wave-uniform scalar loads: the keys of a replayed graph)
     extern __shared__ __attribute__((aligned(16))) unsigned char fs_raw[];
     FusedShared& S = *reinterpret_cast<FusedShared*>(fs_raw);
     const int tid = threadIdx.x, lane = tid & 63;

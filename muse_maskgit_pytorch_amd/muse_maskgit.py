@@ -128,6 +128,8 @@ class _Handle:
         self.desc = None           # the mm_transformer_desc the handle was created from (re-used by ensure_logits_stats)
         self.packed = None
         self.stats_src = None      # callable -> fp32 [V][D] to_logits weights for the vocabulary statistics, or None when they do not apply
+        self.ln_probe = None       # device float[1] while the LayerNorm(dim) fold of this handle is being probed (Transformer.set_layernorm_fold('auto'))
+        self.ln_ratio = None       # the probe's result: max |row mean| / (row standard deviation) over every folded LayerNorm input of the first call
 
     def create(self, d, packed):
         self.desc, self.packed = d, packed
@@ -146,10 +148,30 @@ class _Handle:
         self.packed['wcov'] = (P32.gemm(wt, wt) / float(V) - torch.outer(self.packed['wmean'], self.packed['wmean'])).to(bf16).contiguous()
         del wt
         self.desc.logits_wmean, self.desc.logits_wcov = L.ptr(self.packed['wmean']), L.ptr(self.packed['wcov'])
+        self._recreate()
+        return self
+
+    def _recreate(self):
         L.lib().mm_transformer_destroy(self.ptr)
         self.ptr = C.c_void_p()
         L.check(L.lib().mm_transformer_create(C.byref(self.desc), C.byref(self.ptr)), 'mm_transformer_create')
-        return self
+
+    def begin_ln_probe(self, dev):
+        self.ln_probe = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.desc.ln_probe = L.ptr(self.ln_probe)
+
+    def finish_ln_probe(self):
+        """Reads what the first call through this handle recorded (one host synchronisation, once per packed model) and re-creates the C handle without
+        the probe -- with the LayerNorm(dim) fold OFF when some folded LayerNorm input had |mean| > MM_LN_FOLD_MAX_RATIO x its standard deviation
+        (include/muse_hip.h, mm_transformer_desc.ln_fold_off).  Returns True in that case: the caller recomputes what it just computed."""
+        if self.ln_probe is None:
+            return False
+        self.ln_ratio = float(self.ln_probe.item())
+        off = self.ln_ratio > L.MM_LN_FOLD_MAX_RATIO
+        self.desc.ln_probe, self.desc.ln_fold_off = None, int(off)
+        self.ln_probe = None
+        self._recreate()
+        return off
 
     def __del__(self):
         try:
@@ -190,6 +212,7 @@ class Transformer(nn.Module):
         self._handle_f8 = None         # packed weights + C handle of the fp8 engine (precision 'fp8', built on first use)
         self._handle_f8_key = None
         self.precision = 'bf16'        # 'bf16x3': fp32-grade tier on the bf16 matrix pipe inside the same C loop; 'parity': fp32 MFMA, operator by operator (set_precision)
+        self.layernorm_fold = 'auto'   # bf16 engine: LayerNorm(dim) folded into the GEMMs around it -- 'auto' (probed on the first call per packed model) | True | False (set_layernorm_fold)
 
     # ---- packing (once per parameter version / device)
     def _pack_ff(self, ff, keep):
@@ -289,9 +312,32 @@ class Transformer(nn.Module):
         d.final_gamma, d.final_beta, d.to_logits = L.ptr(t['fg']), L.ptr(t['fb']), L.ptr(t['wl'])
         d.self_cond_ff = sc_ff
         d.logits_wmean, d.logits_wcov = L.ptr(t['wmean']), L.ptr(t['wcov'])
+        d.ln_fold_off = int(self.layernorm_fold is False)
+        h.desc = d
+        if self.layernorm_fold == 'auto':
+            h.begin_ln_probe(dev)
         h.create(d, t)
         self._handle, self._handle_key = h, key
         return h
+
+    def set_layernorm_fold(self, mode='auto'):
+        """bf16 engine.  The three LayerNorm(dim)s of a block ride in the GEMMs around them (csrc/model.hip ln_fold_on): the projections multiply the bf16 image of
+        the RAW residual row and apply rstd * (acc - mean * c1) + c2 on their accumulators.  The bf16 rounding then acts on x instead of LayerNorm(x): its error in
+        normalised units grows like |x^ + mean / sigma|, i.e. with the row's DC offset -- invisible for random-init-like statistics (|mean| / sigma ~ 0.05), a
+        silent loss of accuracy for a checkpoint whose residual stream carries massive-activation channels or a large mean.
+        'auto' (default): the first call through a freshly packed model records max |mean| / sigma over every folded LayerNorm input (one extra host
+        synchronisation, once per packed model); above MM_LN_FOLD_MAX_RATIO the model falls back to the LayerNorm kernels and that call is recomputed.
+        True / False force the choice.  `layernorm_fold_ratio` holds the probe's result."""
+        if mode not in ('auto', True, False):
+            raise ValueError("layernorm fold mode must be 'auto', True or False")
+        if mode != self.layernorm_fold:
+            self.layernorm_fold = mode
+            self._handle, self._handle_key = None, None
+        return self
+
+    @property
+    def layernorm_fold_ratio(self):
+        return self._handle.ln_ratio if self._handle is not None else None
 
     def linear_weights(self):
         """every nn.Linear weight of the hot path (what the precision tier packs as bf16 term segments)"""
@@ -493,7 +539,28 @@ class Transformer(nn.Module):
         ws = self._workspace(wsb, dev)
         L.check(L.lib().mm_transformer_forward(h.ptr, L.stream(), L.ptr(ids), b, n, L.ptr(ctx), L.ptr(mask), m, L.ptr(sce),
                                                L.ptr(embed), L.ptr(logits), L.ptr(ws), ws.numel()), 'mm_transformer_forward')
+        if h.ln_probe is not None and not torch.cuda.is_current_stream_capturing() and h.finish_ln_probe():
+            # the LayerNorm(dim) fold was probed on this call and found unsafe for this checkpoint: once more on the LayerNorm kernels
+            L.check(L.lib().mm_transformer_forward(h.ptr, L.stream(), L.ptr(ids), b, n, L.ptr(ctx), L.ptr(mask), m, L.ptr(sce),
+                                                   L.ptr(embed), L.ptr(logits), L.ptr(ws), ws.numel()), 'mm_transformer_forward')
         return embed, logits
+
+    def cross_attention_block(self, layer, x, context, context_mask=None):
+        """The cross-attention block of `layer` as an operator (mmp.py:139-162, 191): returns x + CrossAttention(LayerNorm(x), context) for x fp32 [b, n, dim],
+        context [b, m, dim] (rounded to bf16, what the engine's context is), context_mask bool [b, m] or None -- computed exactly as the model's forward computes
+        the block (one-kernel form on the headline shape class).  bf16 engine only; a test surface (tests/test_gpu_ops.py)."""
+        assert self.precision == 'bf16'
+        h = self._model()
+        dev = self.token_emb.weight.device
+        xs = x.to(device=dev, dtype=torch.float32).contiguous().clone()
+        b, n, _ = xs.shape
+        ctx = context.to(device=dev, dtype=bf16).contiguous()
+        m = ctx.shape[1]
+        km = context_mask.to(device=dev, dtype=torch.uint8).contiguous() if exists(context_mask) else None
+        wsb = L.lib().mm_cross_attention_block_workspace_bytes(h.ptr, b, n, m)
+        ws = torch.zeros(int(wsb), dtype=torch.uint8, device=dev)
+        L.check(L.lib().mm_cross_attention_block(h.ptr, L.stream(), int(layer), L.ptr(xs), b, n, L.ptr(ctx), L.ptr(km), m, L.ptr(ws), ws.numel()), 'mm_cross_attention_block')
+        return xs
 
     def _embed_f32(self, embed):
         """fp32 [rows, dim] view of what `_run` / `forward(_embed_only=True)` returned: the bf16 embed, or -- precision tier -- the exact sum of
@@ -797,6 +864,7 @@ class MaskGit(nn.Module):
         self.self_cond_prob = self_cond_prob
         self.no_mask_token_prob = no_mask_token_prob
         self._gen_ws = None
+        self._graphs = {}                      # generate(graph=True): one captured hipGraph per call signature (see _generate_graphed)
         self.fused_sampling_fallbacks = 0      # generate() calls repeated on the logits path (more than 128 rows of one step failed the candidate bound)
         self.fused_row_fallbacks = 0           # rows whose bound could not be verified and that the on-device per-row fallback finished
 
@@ -835,7 +903,7 @@ class MaskGit(nn.Module):
                  *, text_embeds: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None, noise_kind: str = 'philox',
                  seed: Optional[int] = None, row_offset: int = 0, return_ids: bool = False, trace: Optional[dict] = None,
                  critic_noise: Optional[torch.Tensor] = None, neg_text_embeds: Optional[torch.Tensor] = None, fused_sampling: bool = True,
-                 stepwise: bool = False, loop_end_event=None):
+                 stepwise: bool = False, loop_end_event=None, graph: bool = False, _seed_dev: Optional[torch.Tensor] = None):
         """mmp.py:491-621.  Keyword-only extras (not in the reference): `text_embeds` bypasses the T5 call,
         `noise` (+ `noise_kind` 'gumbel' | 'uniform') injects the per-step noise tensor [T,B,n,V] for parity runs,
         `seed` / `row_offset` key the on-device Philox stream (row_offset = global index of this shard's first
@@ -845,7 +913,17 @@ class MaskGit(nn.Module):
         the decode loop to materialise the logits (same ids; tests / A-B timing); `fused_sampling='deferred'` leaves the device status flag in
         `self.fused_status` instead of reading it (hipGraph capture of the fused path: check it after every replay).  Every decode variant of the reference -- token critic / self critic
         scores, self-conditioning, can_remask_prev_masked, cond_scale == 1 -- runs inside the one mm_generate call; `stepwise=True` runs the same
-        loop one operator call at a time from Python instead (tests: the two must agree bit for bit)."""
+        loop one operator call at a time from Python instead (tests: the two must agree bit for bit).
+        `graph=True` (round 5): the whole call -- decode loop and VAE decode, ~1190 launches -- is captured ONCE per call signature in a hipGraph and replayed
+        on later calls; the Philox keys are read from a small device buffer at execution time, so every replay draws fresh noise and its ids / images are
+        bit-identical to the eager call with the same `seed` (tests/test_gpu_model.py).  Signatures the graph path does not take (injected noise, critics,
+        negative prompts, traces, the stepwise / parity engines) run eagerly."""
+        if graph and not torch.cuda.is_current_stream_capturing():
+            if (not exists(noise) and not exists(trace) and not exists(negative_texts) and not exists(neg_text_embeds) and not stepwise and not exists(loop_end_event)
+                    and not exists(critic_noise) and self.transformer.precision != 'parity' and fused_sampling is True
+                    and not (exists(self.token_critic) and not force_not_use_token_critic)):
+                return self._generate_graphed(texts, cond_images, fmap_size, temperature, topk_filter_thres, can_remask_prev_masked, timesteps, cond_scale,
+                                              text_embeds, seed, row_offset, return_ids)
         tr = self.transformer
         use_token_critic = exists(self.token_critic) and not force_not_use_token_critic
         if exists(negative_texts) or exists(neg_text_embeds):
@@ -914,6 +992,8 @@ class MaskGit(nn.Module):
         if not exists(seed):
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())                # follows torch.manual_seed
         p.seed, p.row_offset = seed, row_offset
+        if exists(_seed_dev):                                                  # (graph capture: the sampling kernels read {seed, row_offset} from this buffer at execution time)
+            p.seed_dev = L.ptr(_seed_dev)
         cnt_arr = (C.c_int32 * timesteps)(*counts)
         tmp_arr = (C.c_float * timesteps)(*temps)
         p.mask_counts, p.temperatures = cnt_arr, tmp_arr
@@ -975,12 +1055,24 @@ class MaskGit(nn.Module):
         if deferred:
             self.fused_status = status
             # a captured graph replays reads of every tensor this call handed to the library: they stay alive with the module, not with this frame
-            self._deferred_keep = (keep, te, cond_ids, noise, ids, scores, trace, self._gen_ws, getattr(self, '_critic_ws', None))
+            self._deferred_keep = (keep, te, cond_ids, noise, ids, scores, trace, self._gen_ws, getattr(self, '_critic_ws', None), _seed_dev)
         elif status is not None:
             if want_images:      # the VAE decode is LAUNCHED before the flag is read: the one host synchronisation of generate() then waits behind it, not in front
                 images = self.vae.decode_from_ids(ids.reshape(B, fmap, fmap))
             st = status.tolist()
             self.fused_row_fallbacks += st[1]
+        probed = [x for x in (h, (ch if exists(critic) else None)) if x is not None and x.ln_probe is not None] if not capturing else []
+        if sum(int(x.finish_ln_probe()) for x in probed):
+            # first generate through a freshly packed model, LayerNorm(dim) fold probed and found unsafe for this checkpoint (Transformer.set_layernorm_fold):
+            # the whole call once more on the LayerNorm kernels (the handles were re-created: same packed weights)
+            images = None
+            if isinstance(critic, Transformer):
+                p.critic = ch.ptr
+            if status is not None:
+                status.zero_()
+            L.check(L.lib().mm_generate(h.ptr, L.stream(), C.byref(p), L.ptr(self._gen_ws), self._gen_ws.numel()), 'mm_generate')
+            if not deferred and status is not None:
+                st = status.tolist()
         if not deferred and status is not None and st[0] != 0:
             self.fused_sampling_fallbacks += 1
             images = None                                                      # (decoded from ids that are being replaced)
@@ -991,6 +1083,57 @@ class MaskGit(nn.Module):
             return ids
         images = images if images is not None else self.vae.decode_from_ids(ids)  # mmp.py:620
         return (ids, images) if return_ids == 'both' else images
+
+    def _generate_graphed(self, texts, cond_images, fmap_size, temperature, thres, can_remask, timesteps, cond_scale, text_embeds, seed, row_offset, return_ids):
+        """generate(graph=True).  Per call signature: the first call runs eagerly (it packs the weights, computes the vocabulary statistics, probes the
+        LayerNorm fold, sizes the workspaces -- none of which may happen under capture), the second captures generate(fused_sampling='deferred') + the VAE
+        decode on static input / output buffers, every later one copies its text embeddings (and condition images) into the static inputs, writes
+        {seed, row_offset} into the key buffer and replays.  The fused-sampling status words are read after the replay exactly like the eager path reads
+        them after its launches (the one host synchronisation); a replay whose status asks for the logits path is repeated eagerly with it."""
+        tr = self.transformer
+        dev = tr.token_emb.weight.device
+        if not exists(text_embeds):
+            text_embeds = tr.encode_text(texts)
+        te = text_embeds.to(device=dev, dtype=torch.float32)
+        if not exists(seed):
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())                # follows torch.manual_seed
+        vkey = self.vae._pack_key() if exists(self.vae) else None
+        ckey = self.cond_vae._pack_key() if (exists(cond_images) and self.cond_vae is not self.vae) else None
+        key = (tuple(te.shape), None if not exists(cond_images) else tuple(cond_images.shape), fmap_size, float(temperature), float(thres), bool(can_remask), int(timesteps),
+               float(cond_scale), return_ids, tr.precision, tr._pack_key(), vkey, ckey)
+        eager = dict(cond_images=cond_images, fmap_size=fmap_size, temperature=temperature, topk_filter_thres=thres, can_remask_prev_masked=can_remask, timesteps=timesteps,
+                     cond_scale=cond_scale, row_offset=row_offset, return_ids=return_ids)
+        entry = self._graphs.get(key)
+        if entry is None:
+            if len(self._graphs) >= 8:                                          # (weights changed / many shapes: drop the oldest captures)
+                self._graphs.pop(next(iter(self._graphs)))
+            self._graphs[key] = 'warm'
+            return self.generate(texts, text_embeds=te, seed=seed, **eager)
+        if entry == 'warm':
+            st = dict(te=te.clone(), cond=cond_images.to(dev).clone() if exists(cond_images) else None,
+                      keys=torch.zeros(2, dtype=torch.int64, device=dev), keys_host=torch.zeros(2, dtype=torch.int64).pin_memory())
+            torch.cuda.synchronize()
+            g, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side):
+                    out = self.generate(texts, text_embeds=st['te'], seed=0, _seed_dev=st['keys'], fused_sampling='deferred',
+                                        **dict(eager, cond_images=st['cond'], row_offset=0))
+            st.update(graph=g, out=out, status=self.fused_status, keep=self._deferred_keep)
+            entry = self._graphs[key] = st
+        st = entry
+        st['te'].copy_(te, non_blocking=True)
+        if exists(cond_images):
+            st['cond'].copy_(cond_images, non_blocking=True)
+        st['keys_host'][0], st['keys_host'][1] = seed, row_offset
+        st['keys'].copy_(st['keys_host'], non_blocking=True)
+        st['graph'].replay()
+        stw = st['status'].tolist()                                            # the one host synchronisation, behind the VAE decode
+        self.fused_row_fallbacks += stw[1]
+        if stw[0] != 0:                                                        # more than 128 unverifiable rows in one step: this call on the logits path
+            self.fused_sampling_fallbacks += 1
+            return self.generate(texts, text_embeds=te, seed=seed, fused_sampling=False, **eager)
+        out = st['out']
+        return tuple(o.clone() for o in out) if isinstance(out, tuple) else out.clone()
 
     def _generate_stepwise(self, texts, cond_images, fmap_size, temperature, thres, can_remask, use_critic, timesteps, cond_scale,
                            critic_noise_scale, text_embeds, noise, noise_kind, seed, row_offset, return_ids, trace, critic_noise=None,

@@ -26,9 +26,10 @@ DEV = 'cuda'
 FULL_ROWS = [0, 77, 255, 256, 300, 301, 448, 511]
 PRECISIONS = ['parity', 'bf16x3', 'f16x2', 'bf16']
 EXACT = ('parity', 'bf16x3', 'f16x2')      # the engines held to the north star's bar
-# the bf16 engine on a GENERAL fp32 checkpoint (weights rounded to bf16 at pack time on top of the bf16 activations): bounds from the measured figures
-# of round 5 (printed by the tests), ~2x head-room
-BF16_FP32W_LOGITS, BF16_FP32W_EMBED, BF16_FP32W_IDS = 5e-2, 8e-2, 0.85
+# the bf16 engine on a GENERAL fp32 checkpoint (weights rounded to bf16 at pack time on top of the bf16 activations).  Measured in round 5 (printed by the
+# tests): logits 1.95e-2 max / 2.9e-3 mean (1.33e-2 / 2.2e-3 on the bf16-representable checkpoint), guidance-combined 6.5e-2, embed 3.7e-2,
+# final ids 95.9 % / worst step 94.3 % equal to the reference run -- the weight rounding costs about half again of the activation rounding's error
+BF16_FP32W_LOGITS, BF16_FP32W_EMBED, BF16_FP32W_IDS = 3.5e-2, 6e-2, 0.90
 
 
 @pytest.fixture(scope='module', params=['base_c2.pt', 'base_c2_fp32.pt'], ids=['bf16w', 'fp32w'])

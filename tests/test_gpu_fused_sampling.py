@@ -276,6 +276,37 @@ def test_fused_sampling_inside_a_hip_graph_with_the_deferred_status_flag():
         assert int(mg.fused_status[0].item()) == 0 and torch.equal(captured, eager)
 
 
+def test_generate_graph_mode_replays_with_fresh_seeds_bit_equal_to_eager():
+    """generate(graph=True) (round 5; mmp.py:556-559 has a host synchronisation per step, this path has one per generate): the first call per signature runs
+    eagerly, the second captures decode loop + VAE decode in a hipGraph, later ones replay.  The Philox keys are read from a device buffer at execution
+    time (mm_generate_params.seed_dev), so a replay with seed s and row offset r is bit-identical -- ids and pixels -- to the eager call with the same keys,
+    for keys the capture never saw; new text embeddings go through the static input; a different signature gets its own graph."""
+    torch.manual_seed(4)
+    t = mm.MaskGitTransformer(num_tokens=8192, seq_len=64, dim=256, depth=2, dim_head=64, heads=4, t5_name='t5-small')
+    with torch.no_grad():
+        t.to_logits.weight.mul_(6.)
+    vae = mm.VQGanVAE(dim=32, codebook_size=8192)
+    mg = mm.MaskGit(image_size=128, transformer=t, vae=vae).to(DEV)
+    B, T = 4, 6
+    tes = [torch.randn(B, 7, 512, device=DEV) for _ in range(2)]
+    tes[1][2, 4:] = 0.
+    calls = [(11, 0, 0), (12, 0, 0), (13, 4, 1), (14, 0, 0), (11, 0, 1)]      # (seed, row_offset, which text embeddings): call 0 warms, call 1 captures + replays, the rest replay
+    for i, (seed, roff, k) in enumerate(calls):
+        ids_g, img_g = mg.generate([''] * B, timesteps=T, text_embeds=tes[k], seed=seed, row_offset=roff, return_ids='both', graph=True)
+        ids_e, img_e = mg.generate([''] * B, timesteps=T, text_embeds=tes[k], seed=seed, row_offset=roff, return_ids='both')
+        assert torch.equal(ids_g, ids_e), f'call {i}: graph-mode ids differ from the eager call with the same keys'
+        assert torch.equal(img_g, img_e), f'call {i}: pixels differ'
+    assert len(mg._graphs) == 1 and isinstance(next(iter(mg._graphs.values())), dict) and mg.fused_sampling_fallbacks == 0
+    a = mg.generate([''] * B, timesteps=T, text_embeds=tes[0], seed=11, graph=True)
+    b = mg.generate([''] * B, timesteps=T, text_embeds=tes[0], seed=12, graph=True)
+    assert not torch.equal(a, b), 'two replays with different seeds produced the same images'
+    # another signature (timesteps): its own warm-up / capture, same equality
+    for seed in (21, 22, 23):
+        x = mg.generate([''] * B, timesteps=4, text_embeds=tes[0], seed=seed, return_ids=True, graph=True)
+        assert torch.equal(x, mg.generate([''] * B, timesteps=4, text_embeds=tes[0], seed=seed, return_ids=True))
+    assert len(mg._graphs) == 2
+
+
 @pytest.mark.parametrize('family', ['zipf_bias', 'hot_tokens', 'row_temperature', 'student_t', 'bimodal'])
 def test_non_gaussian_logits_are_finished_row_by_row(family):
     """Trained checkpoints do not have Gaussian logits.  Families that defeat the Gaussian bound for SOME rows: the finishing kernel must list

@@ -730,6 +730,51 @@ def test_layernorm_dim_fold_matches_the_unfolded_path(golden):
         assert e_f.max() < 0.03 * ref.abs().max() and e_f.mean() < 1.5 * e_u.mean() + 1e-4
 
 
+def test_layernorm_dim_fold_probe_falls_back_on_a_dc_offset():
+    """the LayerNorm(dim) fold multiplies the bf16 image of the RAW residual row, so its rounding error in normalised units grows like
+    |x^ + mean / sigma| -- every closeness test so far used random-init weights, whose rows have mean ~ 0.  Here the residual stream carries a DC offset of
+    several sigma (a constant added to the position embedding: every row of every layer keeps it).  Forced on, the fold is measurably worse than the LayerNorm
+    kernels against the fp64-grade oracle; the default 'auto' mode probes max |mean| / sigma on the first call through a freshly packed model, finds it above
+    MM_LN_FOLD_MAX_RATIO, re-creates the handle with the fold off and recomputes: bit-identical to the forced-off engine.  On the same model WITHOUT the
+    offset the probe stays below the limit and 'auto' == forced on, bit for bit."""
+    from muse_maskgit_pytorch_amd import _lib
+    torch.manual_seed(11)
+    V, n, depth, B, L = 1000, 64, 3, 2, 9
+    t = mm.MaskGitTransformer(num_tokens=V, seq_len=n, dim=256, depth=depth, dim_head=64, heads=4, t5_name='t5-small')
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, V + 1, (B, n), generator=g)
+    te = torch.randn(B, L, 512, generator=g)
+    cfg = dict(depth=depth, heads=4)
+    for offset, expect_off in ((0., False), (8., True)):
+        with torch.no_grad():
+            t.pos_emb.weight.add_(offset)
+        sd = {k: v.detach().float().cpu().clone() for k, v in t.state_dict().items()}
+        ref = O.transformer_forward(sd, cfg, ids, te, 0., rp=O.bf16_round)
+        t = t.to(DEV)
+        outs = {}
+        for mode in (True, False, 'auto'):
+            t.set_layernorm_fold(mode)
+            outs[mode] = t(ids.to(DEV), text_embeds=te.to(DEV)).float().cpu()
+            if mode == 'auto':
+                ratio = t.layernorm_fold_ratio
+                assert t._handle.ln_probe is None and bool(t._handle.desc.ln_fold_off) == expect_off
+                again = t(ids.to(DEV), text_embeds=te.to(DEV)).float().cpu()      # the probed handle: no more probing, same result
+                assert torch.equal(again, outs['auto'])
+        t.set_layernorm_fold('auto')
+        e_on, e_off = (outs[True] - ref).abs(), (outs[False] - ref).abs()
+        print(f'[ln-fold probe] position-embedding offset {offset}: max |mean| / sigma over the folded LayerNorm inputs = {ratio:.3f} (limit {_lib.MM_LN_FOLD_MAX_RATIO}); '
+              f'logits error vs oracle: fold on max {e_on.max().item():.3g} mean {e_on.mean().item():.3g}, fold off max {e_off.max().item():.3g} mean {e_off.mean().item():.3g} '
+              f'(scale {ref.abs().max().item():.3g})')
+        assert torch.equal(outs['auto'], outs[False] if expect_off else outs[True])
+        assert (ratio > _lib.MM_LN_FOLD_MAX_RATIO) == expect_off
+        if expect_off:
+            assert e_on.mean() > 1.5 * e_off.mean(), 'the DC offset was expected to degrade the folded engine (the hazard this test documents)'
+            assert e_off.max() < 0.03 * ref.abs().max()
+        else:
+            assert e_on.max() < 0.03 * ref.abs().max() and ratio < 0.5
+        t = t.cpu()
+
+
 @pytest.mark.parametrize('n,L', [(80, 13), (256, 33), (7, 1), (64, 35)])      # 35 = the most context tokens the folded form takes (36 key slots per head with the null key)
 def test_cross_attention_with_the_folded_output_projection_matches_the_two_kernel_path(n, L):
     """mmp.py:139-162 on the headline shape class (dim = inner = 512, 8 heads x 64, <= 35 context tokens): the text context is the same at every

@@ -374,6 +374,55 @@ def test_attention_fused_norm_null(n, j, masked):
         check_close(got[1:2], exp, atol=0, what='null-only attention')
 
 
+@pytest.mark.parametrize('n,L', [(80, 13), (256, 33), (7, 1), (64, 35), (96, 36), (40, 77)])
+def test_cross_attention_block_as_an_operator(n, L):
+    """mmp.py:139-162, 191 at OPERATOR level: x + CrossAttention(LayerNorm(x), context) of one layer against the oracle's attention() on the
+    same rounding points, for the one-kernel form (csrc/cross_fold.hip; L <= 35 here) AND the q-projection + attention + output-projection form (L = 36, 77 and
+    the debug bit), with ragged contexts (key masks), a fully masked context (the classifier-free null pass: only the null key), and query counts that are no
+    multiple of the 32-query workgroup.  A wrong key slot or head offset shows up here at full size instead of hiding in a model's logits.  Bound: the bf16
+    operator bound of this file (2e-3 absolute + relative ULPs) on the block's OUTPUT CONTRIBUTION (out - x: the fp32 residual add itself is exact)."""
+    import muse_maskgit_pytorch_amd as mm
+    from muse_maskgit_pytorch_amd import _lib
+    torch.manual_seed(n * 131 + L)
+    t = mm.MaskGitTransformer(num_tokens=512, seq_len=max(n, 8), dim=512, depth=2, dim_head=64, heads=8, t5_name='t5-small')
+    with torch.no_grad():
+        for p in t.parameters():                                       # de-trivialise gains / scales / null key and value
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+        for p in t.parameters():                                       # bf16-representable parameters: the engine's weight packing is exact, the oracle sees the same values
+            p.copy_(p.to(torch.bfloat16).float())
+    layer = 1
+    sd = {k: v.detach().float().clone() for k, v in t.state_dict().items()}
+    B = 3
+    g = torch.Generator().manual_seed(L)
+    x = torch.randn(B, n, 512, generator=g) * 1.5 + 0.1
+    ctx = r16(torch.randn(B, L, 512, generator=g))
+    mask = torch.ones(B, L, dtype=torch.bool)
+    if L > 2:
+        mask[1, L // 2:] = False                                       # ragged
+    mask[2, :] = False                                                 # the null pass: every context key masked
+    prefix = f'transformer_blocks.layers.{layer}.1.'
+    ref = O.attention(x, sd, prefix, 8, context=ctx, context_mask=mask, rp=O.bf16_round)      # the block's contribution (no residual)
+    t = t.to(DEV)
+    lib = _lib.lib()
+    outs = {}
+    for bit in (0, -(1 << 31)):
+        lib.mm_debug_set(bit)
+        try:
+            outs[bit] = (t.cross_attention_block(layer, x, ctx, mask).cpu() - x)
+        finally:
+            lib.mm_debug_set(0)
+    one_kernel = L <= 35
+    if one_kernel:
+        assert not torch.equal(outs[0], outs[-(1 << 31)]), 'the debug bit did not change the path'
+    for name, got in (('default path' + (' (one kernel)' if one_kernel else ''), outs[0]), ('three-kernel path', outs[-(1 << 31)])):
+        check_close(got, ref, atol=3e-3 * max(1.0, ref.abs().max().item()), rtol=2 * ULP, what=f'cross-attention block n={n} L={L} {name}')
+        print(f'[cross-attention operator] n={n} L={L} {name}: max abs err {(got - ref).abs().max().item():.3g} on scale {ref.abs().max().item():.3g}')
+    # per head: the contribution of head h lives in all 512 output features, but a swapped key slot changes P: compare per sequence as well (a fully masked one = a constant row)
+    d = (outs[0][2] - outs[0][2][0:1]).abs().max().item()
+    assert d <= 1e-6 * max(1.0, ref.abs().max().item()), 'null pass: every query must receive the same row'
+
+
 # ------------------------------------------------------------------------------------------------ sampling tail
 def test_mask_step_matches_stable_topk():
     g = torch.Generator().manual_seed(9)

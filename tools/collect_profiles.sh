@@ -10,7 +10,7 @@ R=${ROUND:-r04}
 OUT=$ROOT/gpurun_out/final
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-parity-tier --no-cpu-baseline --no-graph-leg"
+BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-parity-tier --no-cpu-baseline --no-graph-leg --no-off-ideal"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/p_k -o bench --output-format csv -- $BENCH > $OUT/prof_k.log 2>&1
 timeout 400 rocprofv3 --pmc FETCH_SIZE -d $OUT/p_f -o bench --output-format csv -- $BENCH > $OUT/prof_f.log 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE -d $OUT/p_w -o bench --output-format csv -- $BENCH > $OUT/prof_w.log 2>&1
@@ -22,11 +22,11 @@ python tools/summarize_profile.py --sq $OUT/p_s1 $OUT/p_s2 $OUT/${R}_bench_b32_s
 cp $OUT/${R}_bench_b32_pmc_summary.json profiles/ 2>/dev/null
 rm -f $OUT/p_k/bench_kernel_trace.csv $OUT/p_*/bench_counter_collection.csv      # large raw files
 timeout 400 python bench.py --steps 10 --warmup 2 > $OUT/${R}_bench_b32.json 2> $OUT/bench.err
-MM_BENCH_FORCE_DIST=1 timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 2 --warmup 1 --no-parity-tier --no-cpu-baseline --no-graph-leg > $OUT/${R}_bench_b32_rccl_world1.json 2> $OUT/bench_dist.err
+MM_BENCH_FORCE_DIST=1 timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 2 --warmup 1 --no-parity-tier --no-cpu-baseline --no-graph-leg --no-off-ideal > $OUT/${R}_bench_b32_rccl_world1.json 2> $OUT/bench_dist.err
 if [ "${FULL:-0}" = 1 ]; then
-  timeout 200 python bench.py --config c4 --batch 8 --steps 3 --warmup 1 --no-parity-tier --no-cpu-baseline --no-graph-leg > $OUT/${R}_bench_c4_b8.json 2> $OUT/bench_c4.err
-  timeout 200 python bench.py --config c5 --steps 5 --warmup 2 --no-parity-tier --no-cpu-baseline --no-graph-leg > $OUT/${R}_bench_c5_b32.json 2> $OUT/bench_c5.err
-  timeout 200 python bench.py --config c5 --fp8 --steps 5 --warmup 2 --no-parity-tier --no-cpu-baseline --no-graph-leg > $OUT/${R}_bench_c5_b32_fp8.json 2> $OUT/bench_c5f.err
+  timeout 200 python bench.py --config c4 --batch 8 --steps 3 --warmup 1 --no-parity-tier --no-cpu-baseline --no-graph-leg --no-off-ideal > $OUT/${R}_bench_c4_b8.json 2> $OUT/bench_c4.err
+  timeout 200 python bench.py --config c5 --steps 5 --warmup 2 --no-parity-tier --no-cpu-baseline --no-graph-leg --no-off-ideal > $OUT/${R}_bench_c5_b32.json 2> $OUT/bench_c5.err
+  timeout 200 python bench.py --config c5 --fp8 --steps 5 --warmup 2 --no-parity-tier --no-cpu-baseline --no-graph-leg --no-off-ideal > $OUT/${R}_bench_c5_b32_fp8.json 2> $OUT/bench_c5f.err
   timeout 200 python bench.py --train --steps 10 --warmup 3 > $OUT/${R}_bench_train_b32.json 2> $OUT/bench_train.err
 fi
 tail -n 45 $OUT/${R}_bench_b32_summary.txt

@@ -2,7 +2,7 @@
 TAG=$1; DBG=${2:-0}
 ROOT=$PWD; OUT=$ROOT/gpurun_out/$TAG; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-MM_DEBUG=$DBG timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/p_k -o bench --output-format csv -- python $ROOT/bench.py --steps 2 --warmup 1 --no-parity-tier --no-cpu-baseline --no-graph-leg > $OUT/prof_k.log 2>&1
+MM_DEBUG=$DBG timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/p_k -o bench --output-format csv -- python $ROOT/bench.py --steps 2 --warmup 1 --no-parity-tier --no-cpu-baseline --no-graph-leg --no-off-ideal > $OUT/prof_k.log 2>&1
 cd $ROOT
 python - <<PY
 import csv, glob

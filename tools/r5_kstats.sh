@@ -3,7 +3,7 @@
 TAG=$1; shift
 ROOT=$PWD; OUT=$ROOT/gpurun_out/$TAG; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/p_k -o bench --output-format csv -- python $ROOT/bench.py --steps 2 --warmup 1 --no-parity-tier --no-cpu-baseline --no-graph-leg "$@" > $OUT/prof_k.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/p_k -o bench --output-format csv -- python $ROOT/bench.py --steps 2 --warmup 1 --no-parity-tier --no-cpu-baseline --no-graph-leg --no-off-ideal "$@" > $OUT/prof_k.log 2>&1
 cd $ROOT
 python - <<PY
 import csv, glob
@@ -12,7 +12,7 @@ rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: -float(r['TotalDurationNs']))
 tot = 0
 with open('gpurun_out/${TAG}_kstats.txt', 'w') as o:
-    o.write('# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-parity-tier --no-cpu-baseline --no-graph-leg $*\n# ms per generate = total / 3 traced generates\n')
+    o.write('# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-parity-tier --no-cpu-baseline --no-graph-leg --no-off-ideal $*\n# ms per generate = total / 3 traced generates\n')
     for r in rows[:45]:
         ms = float(r['TotalDurationNs']) / 1e6 / 3
         tot += ms

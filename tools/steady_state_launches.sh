@@ -4,7 +4,7 @@
 ROOT=$PWD; OUT=$ROOT/gpurun_out/steady; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for n in 2 5; do
-  timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/p$n -o bench --output-format csv -- python $ROOT/bench.py --steps $n --warmup 1 --no-parity-tier --no-cpu-baseline --no-graph-leg > $OUT/prof$n.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/p$n -o bench --output-format csv -- python $ROOT/bench.py --steps $n --warmup 1 --no-parity-tier --no-cpu-baseline --no-graph-leg --no-off-ideal > $OUT/prof$n.log 2>&1
 done
 cd $ROOT
 python - <<'PY'
