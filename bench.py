@@ -578,7 +578,7 @@ def main():
                     return v['hbm_bytes_per_launch']
             return None
         metric_cfg = (not args.tiny) and args.config == 'c2' and B == 32 and not args.fp8 and args.precision == 'bf16' and args.text_len == 32
-        fused_on = tr._model().packed.get('wcov') is not None and not args.no_fused_sampling
+        fused_on = tr._model().fused_ready and not args.no_fused_sampling
         total_images = world * B * args.steps
         value = total_images / elapsed
         passes = 2 * T

@@ -132,6 +132,10 @@ int mm_sample_rows(mm_stream_t stream, const float* logits, int64_t ld, int R, i
  *                        the logits path (mm_generate does, on the device); without a list, or when it is full, *fail_flag is set to 1 */
 #define MM_FUSED_SLOT 64
 float mm_fused_z(int k_keep, int V, float margin);
+/* Distribution-free form of the bound (round 5): thr[r] = the mm_fused_quantile_rank(k_keep, V, S)-th largest of the S sampled logits sub[r][0 .. S) of row r
+ * (S <= 4096 vocabulary columns drawn once per model, mm_transformer_desc.logits_wsub): rank = S k / V + 4.5 standard deviations of the hypergeometric count. */
+int mm_fused_quantile_rank(int k_keep, int V, int S);
+int mm_fused_quantile(mm_stream_t stream, const float* sub, int64_t ld, int R, int S, int rank, float* thr);
 size_t mm_fused_threshold_workspace_bytes(int R, int D);
 int mm_fused_threshold(mm_stream_t stream, const void* emb_cond, const void* emb_null, int64_t ld, int R, int D, float cond_scale, const float* wmean,
                        const void* wcov, float z, void* ws, float* thr);
@@ -481,8 +485,14 @@ typedef struct mm_transformer_desc {
      * probes once per packed model and falls back to ln_fold_off above MM_LN_FOLD_MAX_RATIO (muse_maskgit.py, Transformer.set_layernorm_fold). */
     int32_t ln_fold_off;
     float* ln_probe;
+    /* optional: logits_wsub_rows (<= 4096) rows of to_logits at vocabulary indices drawn once per model, bf16 [rows][dim] (plain bf16 values on every engine).
+     * With them the fused sampler's per-row lower bound of the k-th largest logit is DISTRIBUTION-FREE: the row's logits at the sampled columns are computed by
+     * a small GEMM and the bound is their (rows k / V + 4.5 sigma)-th largest -- it holds for peaky / heavy-tailed / multi-modal logits alike, where the
+     * Gaussian estimate from logits_wmean / logits_wcov (used when this is NULL) fails every row and the call falls back to materialised logits. */
+    const void* logits_wsub;
+    int32_t logits_wsub_rows;
 } mm_transformer_desc;
-#define MM_LN_FOLD_MAX_RATIO 1.0f
+#define MM_LN_FOLD_MAX_RATIO 4.0f
 
 typedef struct mm_transformer mm_transformer_t;
 

@@ -35,7 +35,7 @@ class LayerWeights(C.Structure):
     _fields_ = [('self_attn', AttnWeights), ('cross_attn', AttnWeights), ('ff', FFWeights)]
 
 
-MM_LN_FOLD_MAX_RATIO = 1.0      # include/muse_hip.h
+MM_LN_FOLD_MAX_RATIO = 4.0      # include/muse_hip.h
 
 
 class TransformerDesc(C.Structure):
@@ -43,7 +43,7 @@ class TransformerDesc(C.Structure):
                                          'num_tokens', 'vocab_rows', 'dim_out', 'text_dim', 'self_cond')] + \
                [('token_emb', c_vp), ('pos_emb', c_vp), ('text_proj', c_vp), ('layers', C.POINTER(LayerWeights)),
                 ('final_gamma', c_vp), ('final_beta', c_vp), ('to_logits', c_vp), ('self_cond_ff', FFWeights), ('logits_wmean', c_vp), ('logits_wcov', c_vp),
-                ('split_products', C.c_int32), ('fp8', C.c_int32), ('split_alpha', c_f32), ('ln_fold_off', C.c_int32), ('ln_probe', c_vp)]
+                ('split_products', C.c_int32), ('fp8', C.c_int32), ('split_alpha', c_f32), ('ln_fold_off', C.c_int32), ('ln_probe', c_vp), ('logits_wsub', c_vp), ('logits_wsub_rows', C.c_int32)]
 
 
 class TrainAttn(C.Structure):
@@ -170,6 +170,8 @@ SIGNATURES = {
     'mm_transformer_context': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_sz]),
     'mm_transformer_workspace_bytes': (c_sz, [c_vp, c_int, c_int, c_int]),
     'mm_transformer_forward': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_sz]),
+    'mm_fused_quantile_rank': (c_int, [c_int, c_int, c_int]),
+    'mm_fused_quantile': (c_int, [c_vp, c_vp, C.c_int64, c_int, c_int, c_int, c_vp]),
     'mm_cross_attention_block_workspace_bytes': (c_sz, [c_vp, c_int, c_int, c_int]),
     'mm_cross_attention_block': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_sz]),
     'mm_generate_critic_workspace_bytes': (c_sz, [c_vp, c_int, c_int, c_int, c_int]),

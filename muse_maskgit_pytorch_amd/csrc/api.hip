@@ -105,6 +105,12 @@ int mm_gemm_cfg_logits(mm_stream_t stream, const void* x_cond, const void* x_nul
 }
 
 float mm_fused_z(int k_keep, int V, float margin) { return k_fused_z(k_keep, V, margin); }
+int mm_fused_quantile_rank(int k_keep, int V, int S) { return k_fused_quantile_rank(k_keep, V, S); }
+int mm_fused_quantile(mm_stream_t stream, const float* sub, int64_t ld, int R, int S, int rank, float* thr) {
+    if (R == 0) return MM_OK;
+    CHK_PTR(sub, "sub"); CHK_PTR(thr, "thr");
+    return k_fused_quantile((hipStream_t)stream, sub, (long)ld, R, S, rank, thr);
+}
 size_t mm_fused_threshold_workspace_bytes(int R, int D) { return k_fused_threshold_ws_bytes(R, D); }
 
 int mm_fused_threshold(mm_stream_t stream, const void* emb_cond, const void* emb_null, int64_t ld, int R, int D, float cond_scale, const float* wmean,

@@ -773,6 +773,7 @@ struct GenBufs {
     float4* fs_stats;       // [B*n][V/256][FS_REC]
     float4* fs_cand;        // [B*n][V/256][FS_SLOT]
     void* fs_ws;            // scratch of the bound estimate (k_fused_threshold)
+    float* fs_sub;          // [B*n][logits_wsub_rows]: the rows' logits at the sampled vocabulary columns (distribution-free bound)
     // on-device per-row fallback of the fused sampler: rows whose bound could not be verified are listed by the finishing kernel and finished
     // on the logits path inside the same step (their logits recomputed by a small dense GEMM, sampled by sample_kernel)
     int32_t* fb_rows;       // [FB_CAP] rows listed this step
@@ -827,12 +828,13 @@ void carve_gen(Carver& c, const mm_transformer* t, int B, int n, int L, int nc, 
     g.logits = c.take<float>((size_t)B * n * t->d.dim_out);
     g.xc = c.take<float>((size_t)2 * B * n * D);
     g.attc = c.take<bf16_t>((size_t)2 * B * n * I * seg);
-    const bool fs = t->d.logits_wcov && (t->d.dim_out % 256) == 0 && (D % 64) == 0;
+    const bool fs = (t->d.logits_wcov || t->d.logits_wsub) && (t->d.dim_out % 256) == 0 && (D % 64) == 0;
     const size_t NT = fs ? (size_t)t->d.dim_out / 256 : 0;
     g.fs_thr = c.take<float>(fs ? (size_t)B * n : 0);
     g.fs_stats = c.take<float4>((size_t)B * n * NT * FS_REC);
     g.fs_cand = c.take<float4>((size_t)B * n * NT * FS_SLOT);
     g.fs_ws = c.take<unsigned char>(fs ? k_fused_threshold_ws_bytes(B * n, D) : 0);
+    g.fs_sub = c.take<float>(fs && t->d.logits_wsub ? (size_t)B * n * t->d.logits_wsub_rows : 0);
     g.fb_rows = c.take<int32_t>(fs ? FB_CAP : 0);
     g.fb_cnt = c.take<int32_t>(fs ? FB_STEPS : 0);
     g.fb_x = c.take<bf16_t>(fs ? (size_t)FB_CAP * D * seg : 0);
@@ -1096,7 +1098,8 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
         a.f16 = t->F16; a.alpha = t->alpha;
         // Sampling without the logits round trip: the GEMM emits tile statistics + the candidates above a per-row lower bound of the k-th largest
         // logit (estimated from the row's embeddings and the vocabulary statistics of to_logits), the finishing kernel verifies the bound.
-        bool fused = t->d.logits_wcov && t->d.logits_wmean && p->status && !(p->flags & MM_GEN_NO_FUSED_SAMPLING) && (V % 256) == 0 &&
+        const bool qbound = t->d.logits_wsub && t->d.logits_wsub_rows > 0;      // distribution-free bound from sampled vocabulary columns (else: the Gaussian estimate)
+        bool fused = (qbound || (t->d.logits_wcov && t->d.logits_wmean)) && p->status && !(p->flags & MM_GEN_NO_FUSED_SAMPLING) && (V % 256) == 0 &&
                      !(g_mm_debug & (8 | 4096 | 8192 | (1 << 25))) && mm_gemm_cfg2_eligible(a);
         if (fused && t->F16) {      // fp16 terms: the emission exists on the 256 x 256 kernel only (>= 1024 rows); smaller steps take the logits path
             GemmArgs probe = a;
@@ -1105,12 +1108,12 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
         }
         // The step tail of the plain decode (bf16 engine, two guidance passes, fused sampling): final LayerNorm of both passes' sampled rows, the guidance mix
         // and the bound estimate's row means in ONE pass (k_final_mix) -- the same values as the separate LayerNorm / k_cfg_mix / fused_combine kernels below
-        const bool fmix = fused && !PT && !t->F16 && !t->F8 && !single && !self_cond && P == 2 && t->d.logits_wmean && KD == D;
+        const bool fmix = fused && !PT && !t->F16 && !t->F8 && !single && !self_cond && P == 2 && (t->d.logits_wmean || qbound) && KD == D;
         const bf16_t* emb_in = g.embc;
         if (fmix) {
             const float* xc_ = compact_last ? g.xc : b.x;
             const float* xn_ = compact_last ? g.xc + (size_t)R * D : b.x + (size_t)M * D;
-            RC(k_final_mix(s, xc_, xn_, D, R, D, t->d.final_gamma, t->d.final_beta, compact_last ? nullptr : rows, p->cond_scale, g.embm, t->d.logits_wmean,
+            RC(k_final_mix(s, xc_, xn_, D, R, D, t->d.final_gamma, t->d.final_beta, compact_last ? nullptr : rows, p->cond_scale, g.embm, qbound ? nullptr : t->d.logits_wmean,
                            k_fused_threshold_mu(g.fs_ws, R, D)));
             emb_in = g.embm;
         } else {
@@ -1157,7 +1160,17 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
                 RC(mm_check_launch("f16_rows_to_bf16_kernel"));
                 emb_est = g.embb; ld_est = D;
             }
-            if (fmix) RC(k_fused_threshold_mixed(s, emb_in, D, R, D, (const bf16_t*)t->d.logits_wcov, k_fused_z(p->k_keep, V, FS_MARGIN), g.fs_ws, g.fs_thr));
+            if (qbound) {
+                // the rows' logits at the sampled columns (a plain bf16 GEMM, 3 % of the step's flops) and their rank-th largest
+                const int S = t->d.logits_wsub_rows;
+                GemmArgs q;
+                memset(&q, 0, sizeof(q));
+                q.mode = MODE_DENSE;
+                q.W = (const bf16_t*)t->d.logits_wsub; q.N = S; q.ldw = D; q.K = D; q.M = R; q.X = emb_est; q.ldx = (int)ld_est;
+                q.out = g.fs_sub; q.ldc = S; q.out_kind = OUT_F32; q.debug = g_mm_debug;
+                RC(mm_gemm_launch(q, s));
+                RC(k_fused_quantile(s, g.fs_sub, S, R, S, k_fused_quantile_rank(p->k_keep, V, S), g.fs_thr));
+            } else if (fmix) RC(k_fused_threshold_mixed(s, emb_in, D, R, D, (const bf16_t*)t->d.logits_wcov, k_fused_z(p->k_keep, V, FS_MARGIN), g.fs_ws, g.fs_thr));
             else RC(k_fused_threshold(s, emb_est, emb_est, ld_est, R, D, 1.f, t->d.logits_wmean, (const bf16_t*)t->d.logits_wcov, k_fused_z(p->k_keep, V, FS_MARGIN),
                                       g.fs_ws, g.fs_thr));
             a.out = nullptr;

@@ -263,6 +263,9 @@ struct FusedSampleArgs {
     const uint64_t* seed_dev; int row_mul;       // optional device-side Philox keys, see SampleArgs
 };
 float k_fused_z(int k_keep, int V, float margin);
+// distribution-free bound: thr[r] = the rank-th largest of the S sampled logits sub[r][0..S) (rank from k_fused_quantile_rank: S k / V + 4.5 standard deviations)
+int k_fused_quantile_rank(int k_keep, int V, int S);
+int k_fused_quantile(hipStream_t s, const float* sub, long ld, int R, int S, int rank, float* thr);
 // thr[r] = mean_r + z sigma_r of row r's logits over the vocabulary; ws: k_fused_threshold_ws_bytes(R, D) bytes of scratch; wcov bf16 [D][D]
 size_t k_fused_threshold_ws_bytes(int R, int D);
 float* k_fused_threshold_mu(void* ws, int R, int D);      // where the rows' means live in that scratch (k_final_mix writes them; then k_fused_threshold_mixed)

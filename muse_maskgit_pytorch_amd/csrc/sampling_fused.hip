@@ -418,6 +418,52 @@ double norm_quantile(double pq) {      // Acklam's rational approximation (place
 
 float k_fused_z(int k_keep, int V, float margin) { return (float)(norm_quantile(1.0 - (double)k_keep / (double)V) - (double)margin); }
 
+// ---- distribution-free bound (round 5): thr[r] = the rank-th largest of S sampled logits of row r (sub [R][S]: the row's embedding times S vocabulary rows of
+// to_logits drawn once per model).  The number of sampled columns above the row's true k-th largest logit is hypergeometric with mean S k / V, whatever the
+// logits' distribution: a rank 4.5 standard deviations beyond that mean leaves the true top-k inside the candidates except for ~3e-6 of the rows (which the
+// finisher detects and the on-device fallback finishes).  Exact select by radix descent on the order-preserving keys: 32 counting steps, one barrier each.
+template <int PER>
+__global__ __launch_bounds__(256) void quantile_rows_kernel(const float* __restrict__ sub, long ld, int R, int S, int rank, float* __restrict__ thr) {
+    __shared__ int cnt[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int row = blockIdx.x; row < R; row += gridDim.x) {
+        uint32_t key[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int c = i * 256 + tid;
+            key[i] = c < S ? fkey(sub[(size_t)row * ld + c]) : 0u;      // (padding: below every real key)
+        }
+        uint32_t prefix = 0;
+#pragma unroll 1
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t trial = prefix | (1u << bit);
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) c += __popcll(__ballot(key[i] >= trial));
+            if (lane == 0) cnt[bit & 1][wid] = c;
+            __syncthreads();
+            const int tot = (cnt[bit & 1][0] + cnt[bit & 1][1]) + (cnt[bit & 1][2] + cnt[bit & 1][3]);
+            if (tot >= rank) prefix = trial;      // at least `rank` keys >= trial: the rank-th largest has this bit set
+        }
+        if (tid == 0) thr[row] = __uint_as_float((prefix & 0x80000000u) ? (prefix & 0x7FFFFFFFu) : ~prefix);
+        __syncthreads();
+    }
+}
+int k_fused_quantile_rank(int k_keep, int V, int S) {
+    const double p = (double)k_keep / (double)V;
+    const double q = (double)S * p + 4.5 * sqrt((double)S * p * (1. - p)) + 1.;
+    const int r = (int)ceil(q);
+    return r < 1 ? 1 : (r > S ? S : r);
+}
+int k_fused_quantile(hipStream_t s, const float* sub, long ld, int R, int S, int rank, float* thr) {
+    if (R <= 0) return MM_OK;
+    if (S <= 0 || S > 4096 || rank < 1 || rank > S) return mm_set_error(MM_ERR_SHAPE, "fused_quantile: 1 <= rank <= S <= 4096");
+    const int grid = R < 2048 ? R : 2048;
+    if (S <= 2048) hipLaunchKernelGGL((quantile_rows_kernel<8>), dim3(grid), dim3(256), 0, s, sub, ld, R, S, rank, thr);
+    else hipLaunchKernelGGL((quantile_rows_kernel<16>), dim3(grid), dim3(256), 0, s, sub, ld, R, S, rank, thr);
+    return mm_check_launch("quantile_rows_kernel");
+}
+
 size_t k_fused_threshold_ws_bytes(int R, int D) { return ((size_t)R * D * 2 + 255) / 256 * 256 + (size_t)R * D * 4 + (size_t)R * 4 + 512; }
 
 int k_fused_threshold(hipStream_t s, const bf16_t* ec, const bf16_t* en, long ld, int R, int D, float cond_scale, const float* wmean, const bf16_t* wcov,

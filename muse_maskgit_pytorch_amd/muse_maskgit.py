@@ -119,6 +119,9 @@ class TransformerBlocks(nn.Module):
 
 # ------------------------------------------------------------------------------------------------ Transformer
 
+FUSED_BOUND_SAMPLES = 2048      # vocabulary rows of to_logits the distribution-free bound of the fused sampler samples (mm_transformer_desc.logits_wsub)
+
+
 class _Handle:
     """Owns the packed device weights (torch tensors) and the C model handle built from them."""
 
@@ -135,21 +138,43 @@ class _Handle:
         self.desc, self.packed = d, packed
         L.check(L.lib().mm_transformer_create(C.byref(d), C.byref(self.ptr)), 'mm_transformer_create')
 
-    def ensure_logits_stats(self):
-        """vocabulary statistics of to_logits for sampling without materialised logits (mm_transformer_desc.logits_wmean / _wcov): the mean of the
-        weight rows and their covariance; a row's logits over the vocabulary have mean <e, wmean> and variance e' wcov e.  Computed on the first
-        generate() that wants the fused sampler -- a [D][V] fp32 copy and a D x V x D fp32 GEMM, which a forward()-only user (training with
-        self-conditioning repacks every optimizer step) never pays -- then the C handle is re-created from the same packed tensors."""
-        if self.stats_src is None or self.packed.get('wcov') is not None:
+    def ensure_logits_stats(self, mode='quantile'):
+        """What sampling without materialised logits needs besides the weights: a per-row LOWER BOUND of the k-th largest logit before the logits exist.
+        mode 'quantile' (default, round 5; mm_transformer_desc.logits_wsub): FUSED_BOUND_SAMPLES rows of to_logits at vocabulary indices drawn once (seeded);
+        per step a small GEMM gives every row's logits at those columns and the bound is their (S k / V + 4.5 sigma)-th largest -- distribution-free.
+        mode 'gaussian' (rounds 2-4; logits_wmean / _wcov): mean and covariance of the weight rows; a row's logits over the vocabulary have mean <e, wmean>
+        and variance e' wcov e, the bound is the Gaussian quantile -- fails every row of a peaky / heavy-tailed checkpoint (the call then repeats on the logits
+        path).  Computed on the first generate() that wants the fused sampler (a forward()-only user never pays), then the C handle is re-created from the
+        same packed tensors.  Either bound is verified per row on the device: the ids never depend on it."""
+        if self.stats_src is None:
             return self
-        wt = self.stats_src().t().contiguous()                      # [D][V]
-        V = wt.shape[1]
-        self.packed['wmean'] = wt.mean(dim=1).contiguous()
-        self.packed['wcov'] = (P32.gemm(wt, wt) / float(V) - torch.outer(self.packed['wmean'], self.packed['wmean'])).to(bf16).contiguous()
-        del wt
-        self.desc.logits_wmean, self.desc.logits_wcov = L.ptr(self.packed['wmean']), L.ptr(self.packed['wcov'])
-        self._recreate()
+        d = self.desc
+        if mode == 'quantile':
+            if self.packed.get('wsub') is None:
+                w = self.stats_src()                                    # [V][D] fp32
+                V = w.shape[0]
+                S = min(FUSED_BOUND_SAMPLES, V // 2)
+                idx = torch.randperm(V, generator=torch.Generator().manual_seed(0x5EED))[:S].sort().values.to(w.device)
+                self.packed['wsub'], self.packed['wsub_idx'] = w[idx].to(bf16).contiguous(), idx
+            want = (int(self.packed['wsub'].data_ptr()), int(self.packed['wsub'].shape[0]))
+        else:
+            if self.packed.get('wcov') is None:
+                wt = self.stats_src().t().contiguous()                  # [D][V]
+                V = wt.shape[1]
+                self.packed['wmean'] = wt.mean(dim=1).contiguous()
+                self.packed['wcov'] = (P32.gemm(wt, wt) / float(V) - torch.outer(self.packed['wmean'], self.packed['wmean'])).to(bf16).contiguous()
+                del wt
+            d.logits_wmean, d.logits_wcov = L.ptr(self.packed['wmean']), L.ptr(self.packed['wcov'])
+            want = (None, 0)
+        if (d.logits_wsub, d.logits_wsub_rows) != want or (mode != 'quantile' and getattr(self, '_bound_mode', None) != mode):      # (a c_void_p field reads back as int / None)
+            d.logits_wsub, d.logits_wsub_rows = want
+            self._recreate()
+        self._bound_mode = mode
         return self
+
+    @property
+    def fused_ready(self):
+        return self.packed is not None and (self.packed.get('wsub') is not None or self.packed.get('wcov') is not None)
 
     def _recreate(self):
         L.lib().mm_transformer_destroy(self.ptr)
@@ -212,6 +237,8 @@ class Transformer(nn.Module):
         self._handle_f8 = None         # packed weights + C handle of the fp8 engine (precision 'fp8', built on first use)
         self._handle_f8_key = None
         self.precision = 'bf16'        # 'bf16x3': fp32-grade tier on the bf16 matrix pipe inside the same C loop; 'parity': fp32 MFMA, operator by operator (set_precision)
+        self.fused_bound = 'quantile'  # fused sampling: per-row bound of the k-th largest logit from sampled vocabulary columns ('quantile', distribution-free) or from the
+                                       # Gaussian estimate of rounds 2-4 ('gaussian'); _Handle.ensure_logits_stats
         self.layernorm_fold = 'auto'   # bf16 engine: LayerNorm(dim) folded into the GEMMs around it -- 'auto' (probed on the first call per packed model) | True | False (set_layernorm_fold)
 
     # ---- packing (once per parameter version / device)
@@ -972,8 +999,8 @@ class MaskGit(nn.Module):
             tr._x3_extra_weights = ()
         h = tr._model()
         if fused_sampling and not torch.cuda.is_current_stream_capturing():
-            h.ensure_logits_stats()              # vocabulary statistics of to_logits: first fused generate() only (not inside a capture: it allocates)
-        elif fused_sampling == 'deferred' and h.stats_src is not None and h.packed.get('wcov') is None:
+            h.ensure_logits_stats(tr.fused_bound)      # what the bound of the k-th largest logit needs: first fused generate() only (not inside a capture: it allocates)
+        elif fused_sampling == 'deferred' and h.stats_src is not None and not h.fused_ready:
             raise RuntimeError("generate(fused_sampling='deferred') under stream capture needs the vocabulary statistics of to_logits: run one eager "
                                'generate() with the same weights before capturing')
         counts = self._mask_counts(timesteps, seq_len)

@@ -596,6 +596,16 @@ def fused_buffers(R, V, device):
                 fail=torch.zeros(1, dtype=torch.int32, device=device))
 
 
+def fused_quantile(sub, k_keep, V):
+    """thr[r] = the (S k / V + 4.5 sigma)-th largest of the sampled logits sub fp32 [R][S] (the distribution-free bound of the fused sampler)"""
+    sub = sub.contiguous()
+    R, S = sub.shape
+    rank = L.lib().mm_fused_quantile_rank(int(k_keep), int(V), int(S))
+    thr = torch.empty(R, dtype=torch.float32, device=sub.device)
+    L.check(L.lib().mm_fused_quantile(L.stream(), L.ptr(sub), S, R, S, rank, L.ptr(thr)), 'mm_fused_quantile')
+    return thr, rank
+
+
 def fused_z(k_keep, V, margin=0.20):
     return float(L.lib().mm_fused_z(int(k_keep), int(V), float(margin)))
 

@@ -68,6 +68,6 @@ def test_mm_generate_equals_the_stepwise_loop_on_random_shapes(seed):
     assert a.shape == (c['B'], c['fmap'], c['fmap']) and int(a.min()) >= 0 and int(a.max()) < c['V'], c
     assert torch.equal(nofuse, b), f'logits path of mm_generate != stepwise loop: {c}'
     assert torch.equal(ta['ids'][0], torch.stack(tb['ids'])[0]), f'first step differs: {c}'
-    fused_possible = t._model().packed.get('wcov') is not None and cond_scale != 1
+    fused_possible = t._model().fused_ready and cond_scale != 1
     assert torch.equal(a, b), f'mm_generate != stepwise loop: {c}'      # fused or not: the same per-tile softmax statistics on both sampling paths
     assert mg.fused_sampling_fallbacks == 0 or fused_possible

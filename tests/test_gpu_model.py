@@ -733,7 +733,8 @@ def test_layernorm_dim_fold_matches_the_unfolded_path(golden):
 def test_layernorm_dim_fold_probe_falls_back_on_a_dc_offset():
     """the LayerNorm(dim) fold multiplies the bf16 image of the RAW residual row, so its rounding error in normalised units grows like
     |x^ + mean / sigma| -- every closeness test so far used random-init weights, whose rows have mean ~ 0.  Here the residual stream carries a DC offset of
-    several sigma (a constant added to the position embedding: every row of every layer keeps it).  Forced on, the fold is measurably worse than the LayerNorm
+    several (then: many) sigma (a constant added to the position embedding: every row of every layer keeps it; +2 stays below the limit and costs
+    nothing measurable, +64 is a caricature of a massive-activation checkpoint).  Forced on, the fold is measurably worse than the LayerNorm
     kernels against the fp64-grade oracle; the default 'auto' mode probes max |mean| / sigma on the first call through a freshly packed model, finds it above
     MM_LN_FOLD_MAX_RATIO, re-creates the handle with the fold off and recomputes: bit-identical to the forced-off engine.  On the same model WITHOUT the
     offset the probe stays below the limit and 'auto' == forced on, bit for bit."""
@@ -745,7 +746,7 @@ def test_layernorm_dim_fold_probe_falls_back_on_a_dc_offset():
     ids = torch.randint(0, V + 1, (B, n), generator=g)
     te = torch.randn(B, L, 512, generator=g)
     cfg = dict(depth=depth, heads=4)
-    for offset, expect_off in ((0., False), (8., True)):
+    for offset, expect_off in ((0., False), (2., False), (62., True)):      # cumulative: the position embedding carries +0, +2, +64
         with torch.no_grad():
             t.pos_emb.weight.add_(offset)
         sd = {k: v.detach().float().cpu().clone() for k, v in t.state_dict().items()}
@@ -767,10 +768,12 @@ def test_layernorm_dim_fold_probe_falls_back_on_a_dc_offset():
               f'(scale {ref.abs().max().item():.3g})')
         assert torch.equal(outs['auto'], outs[False] if expect_off else outs[True])
         assert (ratio > _lib.MM_LN_FOLD_MAX_RATIO) == expect_off
-        if expect_off:
-            assert e_on.mean() > 1.5 * e_off.mean(), 'the DC offset was expected to degrade the folded engine (the hazard this test documents)'
-            assert e_off.max() < 0.03 * ref.abs().max()
-        else:
+        # measured (round 5, this construction): ratio 0.2 -> fold on / off mean error 1.01x, ratio 1.7 -> 1.03x, ratio 6.5 -> 1.12x, ratio 52 -> 1.13x (there the
+        # bf16 embedding tables themselves -- resolution 0.5 at 64 -- dominate both engines' error): the hazard exists and stays modest; the limit is 4
+        assert e_on.mean() >= 0.97 * e_off.mean()
+        if not expect_off:
+            assert e_on.mean() < 1.10 * e_off.mean() + 1e-4, 'below the limit the fold must cost (almost) nothing'
+        if offset == 0.:
             assert e_on.max() < 0.03 * ref.abs().max() and ratio < 0.5
         t = t.cpu()
 
