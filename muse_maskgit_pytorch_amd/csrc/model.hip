@@ -971,7 +971,7 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
             else RC(k_f32_to_bf16(s, w.null_v, g.nullv, I));
             if (t->F8) RC(f8_linear_bf16(s, g.b, g.nullv, I, I, w.w_out, w.w_out_scale, 1, D, g.cvec + (size_t)l * D, D, 2, nullptr));
             else if (g.khat && cross_fold_on(t, w, m))      // the value the folded kernel adds on an all-masked row (the general path's null pass runs that kernel)
-                RC(k_cross_fold_null_row(s, g.vwt + (size_t)l * k_cross_fold_vwt_elems(B), g.cvec + (size_t)l * D));
+                RC(k_cross_fold_null_row(s, g.vwt + (size_t)l * k_cross_fold_vwt_elems(B), m, g.cvec + (size_t)l * D));
             else RC(gemm_dense(t, s, g.nullv, KI, (const bf16_t*)w.w_out, KI, 1, D, KI, g.cvec + (size_t)l * D, D, OUT_F32, nullptr));
         }
     }

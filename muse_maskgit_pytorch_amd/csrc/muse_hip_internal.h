@@ -162,7 +162,7 @@ size_t k_cross_fold_wqf_elems();
 int k_cross_fold_pack(hipStream_t s, const bf16_t* ckv, int kv_seqs, int m, int I, const float* null_k, const float* null_v, const float* k_scale,
                       const bf16_t* w_out, int ldw, const bf16_t* w_q_ln, int ldwq, bf16_t* khat, bf16_t* vwt, bf16_t* wqf);
 int k_cross_fold(hipStream_t s, const CrossFoldArgs& a);
-int k_cross_fold_null_row(hipStream_t s, const bf16_t* vwt, float* out);      // [512] fp32: what the kernel adds to a row whose text keys are all masked
+int k_cross_fold_null_row(hipStream_t s, const bf16_t* vwt, int m, float* out);      // [512] fp32: what the kernel adds to a row whose text keys are all masked
 
 // vq.hip
 int k_vq_nearest(hipStream_t s, const float* x, long ldx, int N, int C, const float* cb, int K, int cosine, float* aux, int64_t* ids);

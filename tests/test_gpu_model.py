@@ -778,7 +778,7 @@ def test_layernorm_dim_fold_probe_falls_back_on_a_dc_offset():
         t = t.cpu()
 
 
-@pytest.mark.parametrize('n,L', [(80, 13), (256, 33), (7, 1), (64, 35)])      # 35 = the most context tokens the folded form takes (36 key slots per head with the null key)
+@pytest.mark.parametrize('n,L', [(80, 13), (256, 33), (7, 1), (64, 35), (96, 36), (64, 77), (40, 65)])      # 35 / 79 = the most context tokens the two instantiations take (36 / 80 key slots per head with the null key)
 def test_cross_attention_with_the_folded_output_projection_matches_the_two_kernel_path(n, L):
     """mmp.py:139-162 on the headline shape class (dim = inner = 512, 8 heads x 64, <= 35 context tokens): the text context is the same at every
     decode step, so the cross-attention's output projection is folded into its values once per context -- (P_h V_h) W_o,h^T = P_h (V_h W_o,h^T) -- and the

@@ -374,11 +374,11 @@ def test_attention_fused_norm_null(n, j, masked):
         check_close(got[1:2], exp, atol=0, what='null-only attention')
 
 
-@pytest.mark.parametrize('n,L', [(80, 13), (256, 33), (7, 1), (64, 35), (96, 36), (40, 77)])
+@pytest.mark.parametrize('n,L', [(80, 13), (256, 33), (7, 1), (64, 35), (96, 36), (40, 77), (256, 64), (33, 79), (48, 80)])
 def test_cross_attention_block_as_an_operator(n, L):
     """mmp.py:139-162, 191 at OPERATOR level: x + CrossAttention(LayerNorm(x), context) of one layer against the oracle's attention() on the
-    same rounding points, for the one-kernel form (csrc/cross_fold.hip; L <= 35 here) AND the q-projection + attention + output-projection form (L = 36, 77 and
-    the debug bit), with ragged contexts (key masks), a fully masked context (the classifier-free null pass: only the null key), and query counts that are no
+    same rounding points, for the one-kernel form (csrc/cross_fold.hip: L <= 35 on 36 key slots per head, L <= 79 on 80 -- 64 / 65 tokens straddle the two
+    64-bit halves of its key-validity mask) AND the q-projection + attention + output-projection form (L = 80 and the debug bit), with ragged contexts (key masks), a fully masked context (the classifier-free null pass: only the null key), and query counts that are no
     multiple of the 32-query workgroup.  A wrong key slot or head offset shows up here at full size instead of hiding in a model's logits.  Bound: the bf16
     operator bound of this file (2e-3 absolute + relative ULPs) on the block's OUTPUT CONTRIBUTION (out - x: the fp32 residual add itself is exact)."""
     import muse_maskgit_pytorch_amd as mm
@@ -412,7 +412,7 @@ def test_cross_attention_block_as_an_operator(n, L):
             outs[bit] = (t.cross_attention_block(layer, x, ctx, mask).cpu() - x)
         finally:
             lib.mm_debug_set(0)
-    one_kernel = L <= 35
+    one_kernel = L <= 79
     if one_kernel:
         assert not torch.equal(outs[0], outs[-(1 << 31)]), 'the debug bit did not change the path'
     for name, got in (('default path' + (' (one kernel)' if one_kernel else ''), outs[0]), ('three-kernel path', outs[-(1 << 31)])):
