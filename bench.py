@@ -151,7 +151,8 @@ def off_ideal_legs(mg, tr, args, B, T, rank, world, dev, eager_s):
             out['non_gaussian_logits'] = {'value': B / sec, 'unit': 'images/sec', 'ms_per_step': sec * 1e3, 'steps': nsteps, 'x_headline_time': sec / eager_s,
                                           'to_logits': 'x 8 (peaky), vocabulary rows 1024 .. 5119 x 4 on top (heavy-tailed block)',
                                           'rows_finished_by_on_device_fallback_per_generate': rows, 'sampled_rows_per_generate': sampled_rows,
-                                          'fallback_row_fraction': rows / sampled_rows, 'whole_call_fallbacks_to_logits_path': falls}
+                                          'fallback_row_fraction': rows / sampled_rows, 'whole_call_fallbacks_to_logits_path': falls,
+                                          'bound_in_use': getattr(tr._model(), 'auto_bound', None) if tr.fused_bound == 'auto' else tr.fused_bound, 'bound_switches': mg.fused_bound_switches}
         finally:
             with torch.no_grad():
                 w.copy_(saved)
@@ -451,6 +452,7 @@ def main():
     ap.add_argument('--no-parity-tier', action='store_true', help="skip the second timed leg (precision 'f16x2', the tolerance-meeting tier)")
     ap.add_argument('--precision', choices=['bf16', 'f16x2', 'bf16x3'], default='bf16', help="secondary line: run the timed region on a precision tier instead of the bf16 engine "
                     "(profiling the tier: tools/r5_kstats.sh); never the headline")
+    ap.add_argument('--fused-bound', choices=['auto', 'quantile', 'gaussian'], default='auto', help="A/B: the fused sampler's bound of the k-th largest logit (Transformer.fused_bound); 'gaussian' = rounds 2-4")
     ap.add_argument('--bf16-round-weights', action='store_true', help='secondary line: round the random-init parameters to bf16 first (the bf16-representable checkpoint of the tier figures)')
     ap.add_argument('--train', action='store_true', help='time the TRAINING step of the C2 base transformer (MaskGit.forward + backward + AdamW) instead of '
                     'generation: a second, separately labelled line -- not the BASELINE metric')
@@ -498,6 +500,7 @@ def main():
         with torch.no_grad():
             for p_ in list(mg.transformer.parameters()) + list(mg.vae.parameters()):
                 p_.copy_(p_.to(torch.bfloat16).float())
+    tr.fused_bound = args.fused_bound
     if args.precision != 'bf16':
         mg.set_precision(args.precision)
         args.no_parity_tier = args.no_graph_leg = True
@@ -627,7 +630,8 @@ def main():
             'multi_gpu': ({'ranks_in_process_group': dist.get_world_size(), 'backend': dist.get_backend(), 'ids_gather': allgather_ids.last_transport, 'ids_gather_error': allgather_ids.last_error,
                            'devices_visible_to_rank0': torch.cuda.device_count(), 'per_rank_elapsed_s': {'min': min(rank_times), 'max': max(rank_times)},
                            'per_rank_images_per_s': [B * args.steps / t_ for t_ in rank_times]} if dist is not None else None),
-            'fused_sampling': {'enabled': fused_on, 'fallbacks_to_logits_path': mg.fused_sampling_fallbacks, 'rows_finished_by_on_device_fallback': mg.fused_row_fallbacks},
+            'fused_sampling': {'enabled': fused_on, 'bound': tr.fused_bound, 'bound_in_use': getattr(tr._model(), 'auto_bound', None) if tr.fused_bound == 'auto' else tr.fused_bound,
+                               'fallbacks_to_logits_path': mg.fused_sampling_fallbacks, 'rows_finished_by_on_device_fallback': mg.fused_row_fallbacks},
         }
         if world == 1 and not args.tiny and args.config == 'c2' and fused_on and not args.no_graph_leg and not args.fp8:
             out['hip_graph_replay'] = graph_replay_leg(mg, B, T, te, args.steps, elapsed / args.steps)

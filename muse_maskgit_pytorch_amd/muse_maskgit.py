@@ -131,6 +131,7 @@ class _Handle:
         self.desc = None           # the mm_transformer_desc the handle was created from (re-used by ensure_logits_stats)
         self.packed = None
         self.stats_src = None      # callable -> fp32 [V][D] to_logits weights for the vocabulary statistics, or None when they do not apply
+        self.auto_bound = 'gaussian'   # Transformer.fused_bound == 'auto': the bound this packed model currently uses (switched to 'quantile' by the first generate the Gaussian one fails)
         self.ln_probe = None       # device float[1] while the LayerNorm(dim) fold of this handle is being probed (Transformer.set_layernorm_fold('auto'))
         self.ln_ratio = None       # the probe's result: max |row mean| / (row standard deviation) over every folded LayerNorm input of the first call
 
@@ -237,8 +238,9 @@ class Transformer(nn.Module):
         self._handle_f8 = None         # packed weights + C handle of the fp8 engine (precision 'fp8', built on first use)
         self._handle_f8_key = None
         self.precision = 'bf16'        # 'bf16x3': fp32-grade tier on the bf16 matrix pipe inside the same C loop; 'parity': fp32 MFMA, operator by operator (set_precision)
-        self.fused_bound = 'quantile'  # fused sampling: per-row bound of the k-th largest logit from sampled vocabulary columns ('quantile', distribution-free) or from the
-                                       # Gaussian estimate of rounds 2-4 ('gaussian'); _Handle.ensure_logits_stats
+        self.fused_bound = 'auto'      # fused sampling, per-row bound of the k-th largest logit: 'gaussian' (rounds 2-4: from the vocabulary statistics of to_logits; ~1 ms per
+                                       # generate cheaper), 'quantile' (round 5: from sampled vocabulary columns, distribution-free), or 'auto' (default): Gaussian until a
+                                       # generate shows it failing on this checkpoint, then the sampled bound for good (_Handle.ensure_logits_stats, MaskGit.generate)
         self.layernorm_fold = 'auto'   # bf16 engine: LayerNorm(dim) folded into the GEMMs around it -- 'auto' (probed on the first call per packed model) | True | False (set_layernorm_fold)
 
     # ---- packing (once per parameter version / device)
@@ -893,6 +895,7 @@ class MaskGit(nn.Module):
         self._gen_ws = None
         self._graphs = {}                      # generate(graph=True): one captured hipGraph per call signature (see _generate_graphed)
         self.fused_sampling_fallbacks = 0      # generate() calls repeated on the logits path (more than 128 rows of one step failed the candidate bound)
+        self.fused_bound_switches = 0          # Transformer.fused_bound == 'auto': times a packed model was moved from the Gaussian to the sampled bound
         self.fused_row_fallbacks = 0           # rows whose bound could not be verified and that the on-device per-row fallback finished
 
     def save(self, path):
@@ -999,7 +1002,7 @@ class MaskGit(nn.Module):
             tr._x3_extra_weights = ()
         h = tr._model()
         if fused_sampling and not torch.cuda.is_current_stream_capturing():
-            h.ensure_logits_stats(tr.fused_bound)      # what the bound of the k-th largest logit needs: first fused generate() only (not inside a capture: it allocates)
+            h.ensure_logits_stats(h.auto_bound if tr.fused_bound == 'auto' else tr.fused_bound)      # what the bound of the k-th largest logit needs: first fused generate() only (not inside a capture: it allocates)
         elif fused_sampling == 'deferred' and h.stats_src is not None and not h.fused_ready:
             raise RuntimeError("generate(fused_sampling='deferred') under stream capture needs the vocabulary statistics of to_logits: run one eager "
                                'generate() with the same weights before capturing')
@@ -1100,6 +1103,22 @@ class MaskGit(nn.Module):
             L.check(L.lib().mm_generate(h.ptr, L.stream(), C.byref(p), L.ptr(self._gen_ws), self._gen_ws.numel()), 'mm_generate')
             if not deferred and status is not None:
                 st = status.tolist()
+        if (not deferred and status is not None and not capturing and tr.fused_bound == 'auto' and h.auto_bound == 'gaussian'
+                and (st[0] != 0 or st[1] * 200 > B * sum(counts))):
+            # 'auto': the Gaussian bound fails on this checkpoint (the whole call, or more than 0.5 % of its sampled rows needed the on-device fallback): this packed
+            # model uses the sampled (distribution-free) bound from now on; a failed call is repeated with it before the logits path is considered
+            h.auto_bound = 'quantile'
+            h.ensure_logits_stats('quantile')
+            self.fused_bound_switches += 1
+            wsb = L.lib().mm_generate_workspace_bytes(h.ptr, B, seq_len, Lt, nc)      # (the sampled bound carves the rows' logits at the sampled columns)
+            if self._gen_ws.numel() < wsb:
+                self._gen_ws = torch.zeros(int(wsb), dtype=torch.uint8, device=dev)
+            if st[0] != 0:
+                images = None
+                status.zero_()
+                L.check(L.lib().mm_generate(h.ptr, L.stream(), C.byref(p), L.ptr(self._gen_ws), self._gen_ws.numel()), 'mm_generate')
+                st = status.tolist()
+                self.fused_row_fallbacks += st[1]
         if not deferred and status is not None and st[0] != 0:
             self.fused_sampling_fallbacks += 1
             images = None                                                      # (decoded from ids that are being replaced)
@@ -1126,8 +1145,9 @@ class MaskGit(nn.Module):
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())                # follows torch.manual_seed
         vkey = self.vae._pack_key() if exists(self.vae) else None
         ckey = self.cond_vae._pack_key() if (exists(cond_images) and self.cond_vae is not self.vae) else None
+        hb = tr._handle if tr.precision == 'bf16' else None
         key = (tuple(te.shape), None if not exists(cond_images) else tuple(cond_images.shape), fmap_size, float(temperature), float(thres), bool(can_remask), int(timesteps),
-               float(cond_scale), return_ids, tr.precision, tr._pack_key(), vkey, ckey)
+               float(cond_scale), return_ids, tr.precision, tr.fused_bound, hb.auto_bound if hb is not None else None, tr._pack_key(), vkey, ckey)
         eager = dict(cond_images=cond_images, fmap_size=fmap_size, temperature=temperature, topk_filter_thres=thres, can_remask_prev_masked=can_remask, timesteps=timesteps,
                      cond_scale=cond_scale, row_offset=row_offset, return_ids=return_ids)
         entry = self._graphs.get(key)

@@ -209,13 +209,21 @@ def test_generate_with_fused_sampling_at_bench_size_and_its_fallback():
         assert torch.equal(ta['scores'][s_], tb['scores'][s_]), f'step {s_}: confidences differ by {(ta["scores"][s_] - tb["scores"][s_]).abs().max().item():.3g}'
     assert torch.equal(a, b)
     assert torch.equal(a, mg.generate([''] * 32, timesteps=18, cond_scale=3, text_embeds=te, seed=7, return_ids=True))
-    # heavy-tailed vocabulary: 30 huge rows inflate sigma, the Gaussian bound keeps fewer than k entries -> flag -> logits path
+    # heavy-tailed vocabulary: 30 huge rows inflate sigma, the Gaussian bound keeps fewer than k entries -> flag.  fused_bound 'gaussian' (rounds 2-4): the call
+    # is repeated on the logits path.  'auto' (default): the packed model moves to the sampled bound and the call is repeated with THAT -- no logits path, and the
+    # next calls start there.  The ids are the logits path's either way.
     with torch.no_grad():
         tr.to_logits.weight[:30].mul_(400.)
-    c = mg.generate([''] * 32, timesteps=6, cond_scale=3, text_embeds=te, seed=7, return_ids=True)
-    assert mg.fused_sampling_fallbacks == 1
     d = mg.generate([''] * 32, timesteps=6, cond_scale=3, text_embeds=te, seed=7, return_ids=True, fused_sampling=False)
-    assert torch.equal(c, d)
+    tr.fused_bound = 'gaussian'
+    c = mg.generate([''] * 32, timesteps=6, cond_scale=3, text_embeds=te, seed=7, return_ids=True)
+    assert mg.fused_sampling_fallbacks == 1 and torch.equal(c, d)
+    tr.fused_bound = 'auto'
+    assert tr._model().auto_bound == 'gaussian' and mg.fused_bound_switches == 0
+    c = mg.generate([''] * 32, timesteps=6, cond_scale=3, text_embeds=te, seed=7, return_ids=True)
+    assert mg.fused_sampling_fallbacks == 1 and mg.fused_bound_switches == 1 and tr._model().auto_bound == 'quantile' and torch.equal(c, d)
+    c = mg.generate([''] * 32, timesteps=6, cond_scale=3, text_embeds=te, seed=7, return_ids=True)
+    assert mg.fused_sampling_fallbacks == 1 and mg.fused_bound_switches == 1 and torch.equal(c, d)
 
 
 @pytest.mark.parametrize('name', ['self_critic', 'token_critic', 'self_cond', 'can_remask'])
@@ -320,7 +328,7 @@ def test_quantile_bound_keeps_the_fused_path_on_non_gaussian_checkpoints(shape):
         out = mg.generate([''] * B, timesteps=T, text_embeds=te, seed=3, fmap_size=8)
         assert torch.equal(out, ref), f'{mode}: ids differ from the logits path'
         res[mode] = (mg.fused_sampling_fallbacks - f0, mg.fused_row_fallbacks - r0)
-    t.fused_bound = 'quantile'
+    t.fused_bound = 'auto'
     rows = B * sum(mg._mask_counts(T, 64))
     print(f'[fused bound] {shape}: whole-call fallbacks / rows finished by the on-device fallback (of {rows} sampled rows): quantile {res["quantile"]}, gaussian {res["gaussian"]}')
     assert res['quantile'][0] == 0 and res['quantile'][1] <= max(2, rows // 200)
