@@ -345,6 +345,12 @@ int mm_f32_embed(mm_stream_t stream, const int64_t* ids, int64_t rows, int n, co
                  float* x, int64_t ldx);
 /* mask[row] = any(text_embeds[row] != 0)  (mmp.py:304) */
 int mm_f32_text_mask(mm_stream_t stream, const float* text_embeds, int64_t rows, int D, uint8_t* mask);
+/* The same attention as fp16 TERM PRODUCTS on the fp16 matrix pipe (csrc/attention_x2.hip, the 'f16x2' tier's self-attention kernel: q, k, v split into two fp16
+ * terms in registers, three products per block, fp32 softmax), fp32 result.  Shape class: dim_head 64, nk in {128, 192, 256}, nq >= 128, no key mask
+ * (MM_ERR_UNSUPPORTED otherwise).  Element strides (batch, head, token), d contiguous, 16-byte aligned rows. */
+int mm_attend_terms(mm_stream_t stream, const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const float* k, int64_t k_sb, int64_t k_sh, int64_t k_sn,
+                    const float* v, int64_t v_sb, int64_t v_sh, int64_t v_sn, float* out, int64_t o_sb, int64_t o_sh, int64_t o_sn, int B, int H, int nq, int nk,
+                    int normalize, const float* q_scale, const float* k_scale, const float* null_k, const float* null_v, float scale);
 /* mm_attend semantics (attend.py:109-140 + mmp.py:145-157) on fp32 operands, dim_head 32 / 64 / 128 */
 int mm_f32_attend(mm_stream_t stream, const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const float* k, int64_t k_sb, int64_t k_sh, int64_t k_sn,
                   const float* v, int64_t v_sb, int64_t v_sh, int64_t v_sn, float* out, int64_t o_sb, int64_t o_sh, int64_t o_sn, int B, int H, int nq, int nk,

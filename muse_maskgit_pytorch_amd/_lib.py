@@ -155,6 +155,7 @@ SIGNATURES = {
     'mm_f32_cfg_combine': (c_int, [c_vp, c_vp, c_vp, c_f32, c_i64, c_vp]),
     'mm_f32_embed': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_i64]),
     'mm_f32_text_mask': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp]),
+    'mm_attend_terms': (c_int, [c_vp] + [c_vp, c_i64, c_i64, c_i64] * 4 + [c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_f32]),
     'mm_f32_attend': (c_int, [c_vp] + [c_vp, c_i64, c_i64, c_i64] * 4 + [c_int, c_int, c_int, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_f32, c_int]),
     'mm_f32_glu_nhwc': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp]),
     'mm_f32_groupnorm_nhwc': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp]),

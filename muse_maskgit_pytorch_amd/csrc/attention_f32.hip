@@ -230,6 +230,9 @@ int k_attention_f32(hipStream_t s, const AttnF32Args& a) {
         return mm_set_error(MM_ERR_SHAPE, "attention_f32: products must be 3, 5, 6 or MM_SPLIT_F16 | 2, 3");
     if (a.normalize && (!a.q_scale || !a.k_scale)) return mm_set_error(MM_ERR_SHAPE, "attention_f32: q_scale / k_scale required with normalize");
     if ((a.null_k == nullptr) != (a.null_v == nullptr)) return mm_set_error(MM_ERR_SHAPE, "attention_f32: null_k and null_v go together");
+    // 'f16x2' tier, self-attention of the 256-token configs: fp16 term products on the fp16 matrix pipe (attention_x2.hip) instead of the 1/16-rate fp32 MFMA;
+    // debug bit 32768 ("no resident-key attention kernel") keeps this kernel for A/B
+    if (a.out_split && !a.out && split_is_f16(a.P) && !(g_mm_debug & 32768) && k_attention_x2_eligible(a)) return k_attention_x2(s, a);
     const dim3 grid((a.nq + AQ - 1) / AQ, a.H, a.B), block(256);
 #define MM_AF(D_, B_) hipLaunchKernelGGL((attention_f32_mfma_kernel<D_, B_>), grid, block, 0, s, a)
     if (a.io_bf16) { if (dh == 32) MM_AF(32, true); else if (dh == 64) MM_AF(64, true); else MM_AF(128, true); }

@@ -222,6 +222,10 @@ struct AttnF32Args {
     int io_bf16;                                 // q / k / v / out are bf16 (the bf16 engine's route for dim_head != 64)
 };
 int k_attention_f32(hipStream_t s, const AttnF32Args& a);
+// attention_x2.hip (round 5): the same attention as fp16 TERM PRODUCTS on the fp16 matrix pipe (fp32 q / k / v split in registers, all keys resident): dim_head 64,
+// nk in {128, 192, 256}, no key mask; fp16-term segments out (the 'f16x2' tier) or fp32 out (operator entry mm_attend_terms)
+bool k_attention_x2_eligible(const AttnF32Args& a);
+int k_attention_x2(hipStream_t s, const AttnF32Args& a);
 
 int k_mask_step(hipStream_t s, float* scores, int64_t* ids, int B, int n, int k, int64_t mask_id, int32_t* rows_out);
 struct SampleArgs {

@@ -515,6 +515,31 @@ int mm_f32_text_mask(mm_stream_t stream, const float* text_embeds, int64_t rows,
     return mm_check_launch("text_mask_kernel");
 }
 
+// The same attention as fp16 TERM PRODUCTS on the fp16 matrix pipe (attention_x2.hip: the 'f16x2' tier's self-attention kernel), fp32 result -- operator-level
+// entry for tests; MM_ERR_UNSUPPORTED outside its shape class (dim_head 64, nk in {128, 192, 256}, nq >= 128, no key mask).
+int mm_attend_terms(mm_stream_t stream, const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const float* k, int64_t k_sb, int64_t k_sh, int64_t k_sn,
+                    const float* v, int64_t v_sb, int64_t v_sh, int64_t v_sn, float* out, int64_t o_sb, int64_t o_sh, int64_t o_sn, int B, int H, int nq, int nk,
+                    int normalize, const float* q_scale, const float* k_scale, const float* null_k, const float* null_v, float scale) {
+    if (B == 0 || H == 0 || nq == 0) return MM_OK;
+    CHKP(q, "q"); CHKP(k, "k"); CHKP(v, "v"); CHKP(out, "out");
+    if (normalize && (!q_scale || !k_scale)) return mm_set_error(MM_ERR_SHAPE, "attend_terms: normalize needs q_scale / k_scale");
+    if ((null_k == nullptr) != (null_v == nullptr)) return mm_set_error(MM_ERR_SHAPE, "attend_terms: null_k and null_v come together");
+    const int64_t st[] = {q_sb, q_sh, q_sn, k_sb, k_sh, k_sn, v_sb, v_sh, v_sn, o_sb, o_sh, o_sn};
+    bool aligned = ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)out)) & 15) == 0;
+    for (int64_t x : st) aligned = aligned && (x % 4) == 0;
+    if (!aligned) return mm_set_error(MM_ERR_ALIGN, "attend_terms: 16-byte aligned rows required");
+    AttnF32Args m;
+    memset(&m, 0, sizeof(m));
+    m.q = q; m.q_sb = q_sb; m.q_sh = q_sh; m.q_sn = q_sn;
+    m.k = k; m.k_sb = k_sb; m.k_sh = k_sh; m.k_sn = k_sn;
+    m.v = v; m.v_sb = v_sb; m.v_sh = v_sh; m.v_sn = v_sn;
+    m.out = out; m.o_sb = o_sb; m.o_sh = o_sh; m.o_sn = o_sn;
+    m.B = B; m.H = H; m.nq = nq; m.nk = nk; m.normalize = normalize;
+    m.q_scale = q_scale; m.k_scale = k_scale; m.null_k = null_k; m.null_v = null_v; m.scale = scale; m.dh = 64;
+    if (!k_attention_x2_eligible(m)) return mm_set_error(MM_ERR_UNSUPPORTED, "attend_terms: dim_head 64, nk in {128, 192, 256}, nq >= 128");
+    return k_attention_x2((hipStream_t)stream, m);
+}
+
 int mm_f32_attend(mm_stream_t stream, const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const float* k, int64_t k_sb, int64_t k_sh, int64_t k_sn,
                   const float* v, int64_t v_sb, int64_t v_sh, int64_t v_sn, float* out, int64_t o_sb, int64_t o_sh, int64_t o_sn, int B, int H, int nq, int nk,
                   const uint8_t* key_mask, int64_t km_sb, int normalize, const float* q_scale, const float* k_scale, const float* null_k,

@@ -81,6 +81,15 @@ def attend(q, k, v, b, heads, nq, nk, q_strides, k_strides, v_strides, key_mask=
     return out
 
 
+def attend_terms(q, k, v, b, heads, nq, nk, q_strides, k_strides, v_strides, q_scale=None, k_scale=None, null_k=None, null_v=None, scale=8.0):
+    """the same attention as fp16 term products on the fp16 matrix pipe (csrc/attention_x2.hip, the 'f16x2' tier's self-attention kernel); dim_head 64"""
+    I = heads * 64
+    out = torch.empty(b * nq, I, dtype=f32, device=q.device)
+    L.check(L.lib().mm_attend_terms(L.stream(), L.ptr(q), *q_strides, L.ptr(k), *k_strides, L.ptr(v), *v_strides, L.ptr(out), nq * I, 64, I, b, heads, nq, nk,
+                                    int(q_scale is not None), L.ptr(q_scale), L.ptr(k_scale), L.ptr(null_k), L.ptr(null_v), float(scale)), 'mm_attend_terms')
+    return out
+
+
 class _View:
     """a data_ptr() at an element offset inside a tensor (k / v halves of a fused projection)"""
 

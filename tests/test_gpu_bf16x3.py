@@ -115,6 +115,42 @@ def test_f16_term_product_gemm_has_fp32_accuracy(M, N, K, wkind):
     assert e <= 4e-6 * max(scale, 2.0 ** -12) and e <= 16 * e32 + 1e-6 * scale
 
 
+@pytest.mark.parametrize('nk,masked_tail', [(256, 0), (192, 0), (128, 0), (256, 37)])
+def test_term_product_attention_has_fp32_accuracy(nk, masked_tail):
+    """csrc/attention_x2.hip (round 5): the 'f16x2' tier's self-attention as fp16 term products on the fp16 matrix pipe -- q^ / k^ / P / V each split into two fp16
+    terms in registers, three v_mfma_f32_16x16x32_f16 per block, fp32 softmax, null key / value (mmp.py:137-162, attend.py:109-140) -- against fp64 torch, beside
+    the fp32-MFMA kernel it replaces (attention_f32.hip): the same 1e-6-grade error.  `masked_tail`: queries beyond nq in the last block (nq no multiple of 32)."""
+    from muse_maskgit_pytorch_amd import parity as P32
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(nk + masked_tail)
+    b, h, nq = 2, 8, 256 - masked_tail
+    I = h * 64
+    qm = torch.randn(b, nq, I, generator=g) * 1.3
+    kvm = torch.randn(b, nk, 2 * I, generator=g) * 1.3
+    kvm[0, 3, :64] *= 30.                                     # a key row with a large norm (normalisation) ...
+    kvm[1, 5, I: I + 64] *= 8.                                # ... and a large value row
+    qs, ks = 1 + 0.2 * torch.randn(64, generator=g), 1 + 0.2 * torch.randn(64, generator=g)
+    nkv, nvv = torch.randn(h, 64, generator=g), torch.randn(h, 64, generator=g)
+    q = qm.double().reshape(b, nq, h, 64).permute(0, 2, 1, 3)
+    k = kvm.double()[:, :, :I].reshape(b, nk, h, 64).permute(0, 2, 1, 3)
+    v = kvm.double()[:, :, I:].reshape(b, nk, h, 64).permute(0, 2, 1, 3)
+    k = torch.cat((nkv.double()[None, :, None, :].expand(b, -1, -1, -1), k), dim=2)
+    v = torch.cat((nvv.double()[None, :, None, :].expand(b, -1, -1, -1), v), dim=2)
+    qn, kn = F.normalize(q, dim=-1) * qs.double(), F.normalize(k, dim=-1) * ks.double()
+    ref = (torch.softmax(qn @ kn.transpose(-1, -2) * 8., dim=-1) @ v).permute(0, 2, 1, 3).reshape(b * nq, I)
+    qd, kvd = qm.to(DEV), kvm.to(DEV)
+    args = (b, h, nq, nk, (nq * I, 64, I), (nk * 2 * I, 64, 2 * I), (nk * 2 * I, 64, 2 * I))
+    kw = dict(q_scale=qs.to(DEV), k_scale=ks.to(DEV), null_k=nkv.to(DEV).contiguous(), null_v=nvv.to(DEV).contiguous())
+    vview = P32._View(kvd, I)
+    got = P32.attend_terms(qd, kvd, vview, *args, **kw).double().cpu()
+    base = P32.attend(qd, kvd, vview, *args, **kw).double().cpu()
+    scale = ref.abs().max().item()
+    e_t, e_b = (got - ref).abs().max().item(), (base - ref).abs().max().item()
+    print(f'[term-product attention] nk={nk} nq={nq}: max abs err vs fp64 {e_t:.3g} (fp32-MFMA kernel {e_b:.3g}) on scale {scale:.3g}')
+    assert e_t <= 4e-6 * max(1.0, scale) and e_t <= 8 * e_b + 1e-6
+
+
+
 @pytest.mark.parametrize('tier', ['bf16x3', 'f16x2'])
 @pytest.mark.parametrize('seed', list(range(12)))
 def test_tier_mm_generate_equals_its_stepwise_loop_and_tracks_the_fp32_engine(seed, tier):
