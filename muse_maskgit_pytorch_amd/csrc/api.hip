@@ -309,7 +309,7 @@ int mm_gemm_wgrad_splits(int M, int N, int K) {
     const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
     const int kt = K / 64;
     int s = 1;
-    static const long fill = getenv("MM_WGRAD_FILL") ? atol(getenv("MM_WGRAD_FILL")) : 256;      // (384: 15.0-15.5 ms per C2 training step, 256: 14.3-15.1, 192: 15.0-15.6; same box)
+    const long fill = 256;      // (384: 15.0-15.5 ms per C2 training step, 256: 14.3-15.1, 192: 15.0-15.6; same box -- measured through an environment override that no longer exists)
     while (tiles * s < fill && (kt % (s * 2)) == 0 && kt / (s * 2) >= 8) s *= 2;      // fill the 256 CUs, keep >= 512 of K per workgroup
     return s;
 }

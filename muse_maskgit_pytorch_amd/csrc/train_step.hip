@@ -149,9 +149,7 @@ int tr64(mm_stream_t st, hipStream_t s, const bf16_t* x, long rows, long cols, l
 }
 // dW fp32 [N_][K_] = dY^T X for dY bf16 [rows][N_] (ld ldy), X bf16 [rows][K_] (ld ldx)   (training.py _wgrad)
 // xt: the transposed activation [K_][Rp] when the side stream has already made it (else nullptr: made here into tB)
-bool g_skip_leaves = false;
 int wgrad(mm_stream_t st, hipStream_t s, const Bufs& b, const bf16_t* dy, long ldy, int N_, const bf16_t* x, long ldx, int K_, long rows, float* out, const bf16_t* xt = nullptr) {
-    if (g_skip_leaves) return MM_OK;
     RC(tr64(st, s, dy, rows, N_, ldy, b.tA));
     if (!xt) RC(tr64(st, s, x, rows, K_, ldx, b.tB));
     const bf16_t* tB = xt ? xt : b.tB;
@@ -248,7 +246,7 @@ int mm_train_step(const mm_train_desc* desc, mm_stream_t stream, const int64_t* 
     Side* sd = nullptr;
     const char* env = getenv("MM_TRAIN_SIDE");
     if (!(env && env[0] == '0')) RC(side_get(&sd));
-    g_skip_leaves = env && env[0] == 'x';         // TIMING EXPERIMENT ONLY (wrong gradients): how long is the caller's chain alone?
+    // (round 4's MM_TRAIN_SIDE=x timing experiment -- skip every dW GEMM, wrong gradients -- is gone from the shipped library: ADVICE r4)
     hipStream_t s2 = sd ? sd->s2 : s;
     mm_stream_t stream2 = (mm_stream_t)s2;
     hipEvent_t e_f;

@@ -391,7 +391,7 @@ class Transformer(nn.Module):
         checkpoint trained / stored in bf16), 5 for two-term weights, 6 for general fp32 weights.  'f16x2': 2 when one fp16 term holds every
         weight (any bf16-representable checkpoint), 3 for general fp32 weights (csrc/split.hip, common.h split2_f16)"""
         f16 = self.precision == 'f16x2'
-        key = self._pack_key() + (f16,)
+        key = self._pack_key() + (f16,) + tuple((w.data_ptr(), w._version) for w in self._x3_extra_weights)      # (the extra weights move the fp16 term scale: ADVICE r4)
         if getattr(self, '_x3_terms', None) is None or self._x3_terms[0] != key:      # one pass over the weights per parameter version
             if f16:
                 sc = self.split_scale()

@@ -395,10 +395,10 @@ class TrainStepFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gloss, _glogits=None):
-        scale = gloss if (gloss.numel() == 1 and float(gloss) != 1.0) else None
-        grads = [(g * scale if scale is not None else g).to(dt) for g, dt in zip(ctx.grads, ctx.dtypes)]
-        ctx.grads = None
-        return (None, None, None, None, None, None, *grads)
+        # the gradients were computed by the C step with d loss = 1; the incoming scale is applied ON THE DEVICE (one fused multi-tensor multiply) -- reading it on the
+        # host, as round 4 did, is a synchronisation per step.  ctx.grads stays alive with the ctx: a second backward (retain_graph) sees the same gradients.
+        grads = torch._foreach_mul(ctx.grads, gloss.reshape(()).to(ctx.grads[0].dtype))
+        return (None, None, None, None, None, None, *[g.to(dt) for g, dt in zip(grads, ctx.dtypes)])
 
 
 def _c_step_eligible(tr, ids, te, head, bce, sce, cond_ids, grad_sync):
@@ -406,6 +406,8 @@ def _c_step_eligible(tr, ids, te, head, bce, sce, cond_ids, grad_sync):
     import os
     if os.environ.get('MM_TRAIN_PY'):      # A/B and the bit-identity test
         return False
+    if not torch.is_grad_enabled() or not any(p.requires_grad for p in tr.parameters()):
+        return False                        # (evaluation / validation loss: the C entry computes the whole backward -- the operator driver runs the forward only)
     b, n = ids.shape
     return (head is None and not bce and sce is None and cond_ids is None and grad_sync is None and not tr.self_cond and n in (64, 128, 256)
             and (b * n) % 64 == 0 and tr.dim % 64 == 0 and tr.dim_out % 64 == 0 and te.shape[-1] % 64 == 0 and te.shape[1] > 0)
