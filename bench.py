@@ -567,7 +567,7 @@ def main():
         # HBM traffic per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
         # (separate runs: counters cannot be collected inside the timed region); null when no summary is committed
         pmc, pmc_file = {}, None
-        for cand in ('r04_bench_b32_pmc_summary.json', 'r03_bench_b32_pmc_summary.json', 'r02_bench_b32_pmc_summary.json', 'r01_bench_b32_pmc_summary.json'):
+        for cand in ('r05_bench_b32_pmc_summary.json', 'r04_bench_b32_pmc_summary.json', 'r03_bench_b32_pmc_summary.json', 'r02_bench_b32_pmc_summary.json', 'r01_bench_b32_pmc_summary.json'):
             try:
                 with open(os.path.join(ROOT, 'profiles', cand)) as f:
                     pmc, pmc_file = json.load(f), cand

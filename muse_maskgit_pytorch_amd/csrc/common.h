@@ -397,9 +397,12 @@ __device__ __forceinline__ int seg_term(int s) { return s < 3 ? s : (s < 5 ? s -
 #define MM_SPLIT_F16_BIT 0x100
 __device__ __forceinline__ uint16_t f32_to_f16_bits(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }      // round-to-nearest-even
 __device__ __forceinline__ float f16_bits_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+// Range guard: both terms saturate at the largest finite fp16 (65504) instead of overflowing to infinity -- the pair then still represents |x| up to
+// 131008 exactly-ish (h = 65504, l = the rest) and stays FINITE beyond (the value is clipped: an activation of that size is outside what the tier can multiply
+// accurately, but one such element no longer turns a whole logits row into NaN through h = inf, l = x - inf = -inf).  One v_med3_f32 per term.
 __device__ __forceinline__ void split2_f16(float x, uint16_t& h, uint16_t& l) {
-    h = f32_to_f16_bits(x);
-    l = f32_to_f16_bits(x - f16_bits_to_f32(h));      // (the difference is exact in fp32)
+    h = f32_to_f16_bits(__builtin_amdgcn_fmed3f(x, -65504.f, 65504.f));
+    l = f32_to_f16_bits(__builtin_amdgcn_fmed3f(x - f16_bits_to_f32(h), -65504.f, 65504.f));      // (the difference is exact in fp32)
 }
 __host__ __device__ __forceinline__ int split_count(int code) { return code & 0xff; }            // segments per operand row
 __host__ __device__ __forceinline__ bool split_is_f16(int code) { return (code & MM_SPLIT_F16_BIT) != 0; }

@@ -74,6 +74,13 @@ def test_split_rows_f16_terms(products):
         assert torch.equal(xs[:, s].view(torch.int16), order[s].view(torch.int16)), f'segment {s}'
     back = ops.unsplit_rows(ops.split_rows(x.to(DEV), code), code, 192).cpu()
     assert bool(((back - x).abs() <= x.abs() * 2.0 ** -21 + 2.0 ** -24).all())          # 22 bits, absolute floor of the subnormal low term
+    # range guard: values beyond the fp16 range saturate term by term instead of becoming (inf, -inf) -> NaN products: exact-ish up to 2 x 65504,
+    # clipped (finite) beyond; tiny values keep their relative accuracy down to the subnormal floor
+    big = torch.tensor([[1.0e5, -1.2e5, 7.0e4, 3.0e5, -1.0e9, 65504., 1.0e-4, -3.1e-5] + [0.] * 184])
+    bb = ops.unsplit_rows(ops.split_rows(big.to(DEV), code), code, 192).cpu()
+    assert bool(torch.isfinite(bb).all())
+    assert bool(((bb - big)[0, :3].abs() <= 16.).all()) and bb[0, 3].item() == 131008. and bb[0, 4].item() == -131008. and bb[0, 5].item() == 65504.
+    assert bool(((bb - big)[0, 6:8].abs() <= big[0, 6:8].abs() * 2.0 ** -21 + 2.0 ** -24).all())
 
 
 def test_f16_mfma_takes_subnormal_terms_unflushed():

@@ -6,7 +6,7 @@
 #   usage: [ROUND=r04] [FULL=1] tools/collect_profiles.sh        FULL=1 adds the c4 / c5 / c5 --fp8 / --train lines
 set -u
 ROOT=$PWD
-R=${ROUND:-r04}
+R=${ROUND:-r05}
 OUT=$ROOT/gpurun_out/final
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -16,9 +16,10 @@ timeout 400 rocprofv3 --pmc FETCH_SIZE -d $OUT/p_f -o bench --output-format csv 
 timeout 400 rocprofv3 --pmc WRITE_SIZE -d $OUT/p_w -o bench --output-format csv -- $BENCH > $OUT/prof_w.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/p_s1 -o bench --output-format csv -- $BENCH > $OUT/prof_s1.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM -d $OUT/p_s2 -o bench --output-format csv -- $BENCH > $OUT/prof_s2.log 2>&1
+timeout 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum -d $OUT/p_s3 -o bench --output-format csv -- $BENCH > $OUT/prof_s3.log 2>&1
 cd $ROOT
 python tools/summarize_profile.py $OUT/p_k $OUT/p_f $OUT/p_w $OUT/${R}_bench_b32 3 > $OUT/${R}_bench_b32_summary.txt 2>&1
-python tools/summarize_profile.py --sq $OUT/p_s1 $OUT/p_s2 $OUT/${R}_bench_b32_sq_counters.json >> $OUT/${R}_bench_b32_summary.txt 2>&1
+python tools/summarize_profile.py --sq $OUT/p_s1 $OUT/p_s2 $OUT/p_s3 $OUT/${R}_bench_b32_sq_counters.json >> $OUT/${R}_bench_b32_summary.txt 2>&1
 cp $OUT/${R}_bench_b32_pmc_summary.json profiles/ 2>/dev/null
 rm -f $OUT/p_k/bench_kernel_trace.csv $OUT/p_*/bench_counter_collection.csv      # large raw files
 timeout 400 python bench.py --steps 10 --warmup 2 > $OUT/${R}_bench_b32.json 2> $OUT/bench.err
@@ -28,6 +29,8 @@ if [ "${FULL:-0}" = 1 ]; then
   timeout 200 python bench.py --config c5 --steps 5 --warmup 2 --no-parity-tier --no-cpu-baseline --no-graph-leg --no-off-ideal > $OUT/${R}_bench_c5_b32.json 2> $OUT/bench_c5.err
   timeout 200 python bench.py --config c5 --fp8 --steps 5 --warmup 2 --no-parity-tier --no-cpu-baseline --no-graph-leg --no-off-ideal > $OUT/${R}_bench_c5_b32_fp8.json 2> $OUT/bench_c5f.err
   timeout 200 python bench.py --train --steps 10 --warmup 3 > $OUT/${R}_bench_train_b32.json 2> $OUT/bench_train.err
+  bash tools/r5_kstats.sh ${R}_f16x2_fp32w_final --precision f16x2 > $OUT/k_tier1.log 2>&1
+  bash tools/r5_kstats.sh ${R}_f16x2_bf16w_final --precision f16x2 --bf16-round-weights > $OUT/k_tier2.log 2>&1
 fi
 tail -n 45 $OUT/${R}_bench_b32_summary.txt
 for f in $OUT/${R}_bench_*.json; do echo "== $f"; tail -c 500 $f; echo; done

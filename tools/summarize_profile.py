@@ -33,6 +33,9 @@ def sq_main(dirs, out_json):
             v['mfma_pipe_utilisation'] = v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / v['SQ_BUSY_CU_CYCLES'] / 4.0
         if v.get('SQ_LDS_IDX_ACTIVE'):
             v['lds_conflict_share'] = v.get('SQ_LDS_BANK_CONFLICT', 0.0) / v['SQ_LDS_IDX_ACTIVE']
+        if v.get('TCC_HIT_sum') is not None and v.get('TCC_MISS_sum') is not None and v['TCC_HIT_sum'] + v['TCC_MISS_sum'] > 0:
+            # L2: hit rate over all its requests; what goes out on the fabric (TCC_EA0_RDREQ: to Infinity Cache / HBM -- the counters cannot tell the two apart) per launch
+            v['l2_hit_rate'] = v['TCC_HIT_sum'] / (v['TCC_HIT_sum'] + v['TCC_MISS_sum'])
         if v.get('SQ_WAVE_CYCLES'):
             for c, name in (('SQ_WAIT_ANY', 'wait_any_share'), ('SQ_WAIT_INST_ANY', 'wait_inst_share'), ('SQ_WAIT_INST_LDS', 'wait_inst_lds_share'),
                             ('SQ_ACTIVE_INST_ANY', 'issue_share'), ('SQ_ACTIVE_INST_LDS', 'issue_lds_share'), ('SQ_ACTIVE_INST_VMEM', 'issue_vmem_share')):
@@ -44,7 +47,8 @@ def sq_main(dirs, out_json):
     print('SQ counters per launch (top kernels by busy cycles):')
     for k, v in order:
         print(f"{k[:62]:62s} n {v['launches']:5d}  mfma {v.get('mfma_pipe_utilisation', 0):.3f}  lds-conflict {v.get('lds_conflict_share', 0):.3f}  "
-              f"wait {v.get('wait_any_share', 0):.3f}  wait-inst {v.get('wait_inst_share', 0):.3f}  wait-lds {v.get('wait_inst_lds_share', 0):.3f}  issue {v.get('issue_share', 0):.3f}")
+              f"wait {v.get('wait_any_share', 0):.3f}  wait-inst {v.get('wait_inst_share', 0):.3f}  wait-lds {v.get('wait_inst_lds_share', 0):.3f}  issue {v.get('issue_share', 0):.3f}"
+              + (f"  L2-hit {v['l2_hit_rate']:.3f}  EA-rd-req/launch {v.get('TCC_EA0_RDREQ_sum', 0):.3g} (DRAM-space {v.get('TCC_EA0_RDREQ_DRAM_sum', 0):.3g})" if 'l2_hit_rate' in v else ''))
 
 
 def main():
