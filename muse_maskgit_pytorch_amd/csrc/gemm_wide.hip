@@ -433,36 +433,41 @@ __global__ __launch_bounds__(512) void gemm_wide_fused_kernel(const GemmArgs p) 
             if (wn > 2) base += __popc(xmask[2 * TM + tokl]);
             float2* slot = reinterpret_cast<float2*>(p.fs_cand + ((size_t)(m0t + tokl) * p.tiles_n + cur_n) * FS_SLOT) + base;
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const bool kp = (mine >> (8 * a + h)) & 1u;
-                    if (__ballot(kp) != 0ull) {                         // wave-uniform: the store below is ISSUED (exact VMEM count for the waits)
-                        if (kp) slot[__popc(mq[b] & ((1u << (8 * a + 2 * FG_ + h)) - 1u))] = make_float2(acc[a][b][2 * h], acc[a][b][2 * h + 1]);
-                        ++nstore;
-                    }
+            for (int a = 0; a < 4; ++a) {
+                // one rank per granule PAIR (round 5): granule (a, 1) sits right behind (a, 0) when that one is kept
+                const int pa = __popc(mq[b] & ((1u << (8 * a + 2 * FG_)) - 1u));
+                const bool kp0 = (mine >> (8 * a)) & 1u, kp1 = (mine >> (8 * a + 1)) & 1u;
+                if (__ballot(kp0) != 0ull) {                            // wave-uniform: the store below is ISSUED (exact VMEM count for the waits)
+                    if (kp0) slot[pa] = make_float2(acc[a][b][0], acc[a][b][1]);
+                    ++nstore;
                 }
+                if (__ballot(kp1) != 0ull) {
+                    if (kp1) slot[pa + (kp0 ? 1 : 0)] = make_float2(acc[a][b][2], acc[a][b][3]);
+                    ++nstore;
+                }
+            }
         }
+        // ---- one record per (token, piece): this wave combines the tokens of its half's blocks wn and wn + 4 (common.h tile_combine16).  Round 5: ALL four lane
+        // groups of a token take part -- lane group FG_ owns quarter FG_ of the 16 (ml, pl) pairs: its max, its w(q) = (t0 + t1) + (t2 + t3) with four exponentials,
+        // then the maximum and the sum travel across the four lane groups by two lane exchanges each, in the canonical order (w0 + w1) + (w2 + w3) (a + b == b + a
+        // exactly, so the pairing is what matters).  Rounds 3-4: lane group 0 alone, 16 exponentials in a row, three quarters of the lanes idle.
 #pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {   // one record per (token, piece): this wave combines the tokens of its half's blocks wn and wn + 4
+        for (int hb = 0; hb < 2; ++hb) {
             const int tokl = wm * 128 + (hb * 4 + wn) * 16 + FR_;
             const int tok = m0t + tokl;
+            const float2* gq = xml + (4 * FG_) * TM + tokl;      // this lane group's quarter: pairs 4 FG_ .. 4 FG_ + 3 of the token
+            const float2 u0 = gq[0], u1 = gq[TM], u2 = gq[2 * TM], u3 = gq[3 * TM];
+            float M_ = fmaxf(fmaxf(u0.x, u1.x), fmaxf(u2.x, u3.x));
+            M_ = fmaxf(M_, __shfl_xor(M_, 16, 64));
+            M_ = fmaxf(M_, __shfl_xor(M_, 32, 64));
+            float wq = (u0.y * __expf(u0.x - M_) + u1.y * __expf(u1.x - M_)) + (u2.y * __expf(u2.x - M_) + u3.y * __expf(u3.x - M_));
+            wq += __shfl_xor(wq, 16, 64);      // w(0) + w(1) | w(2) + w(3)
+            wq += __shfl_xor(wq, 32, 64);      // (w(0) + w(1)) + (w(2) + w(3))
             const bool w_ = FG_ == 0 && tok < p.M;
             if (__ballot(w_) != 0ull) {
                 if (w_) {
-                    const float2* gq = xml + tokl;              // tile_combine16 (common.h), streamed from LDS in two sweeps
-                    float M_ = -INFINITY;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) M_ = fmaxf(M_, gq[i * TM].x);
-                    float wq[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float2 u0 = gq[(4 * q) * TM], u1 = gq[(4 * q + 1) * TM], u2 = gq[(4 * q + 2) * TM], u3 = gq[(4 * q + 3) * TM];
-                        wq[q] = (u0.y * __expf(u0.x - M_) + u1.y * __expf(u1.x - M_)) + (u2.y * __expf(u2.x - M_) + u3.y * __expf(u3.x - M_));
-                    }
-                    const float E_ = (wq[0] + wq[1]) + (wq[2] + wq[3]);
                     float4* rec = p.fs_stats + ((size_t)tok * p.tiles_n + cur_n) * FS_REC;
-                    rec[0] = make_float4(M_, E_, 0.f, 0.f);
+                    rec[0] = make_float4(M_, wq, 0.f, 0.f);
                     rec[1] = make_float4(__uint_as_float(xmask[tokl]), __uint_as_float(xmask[TM + tokl]), __uint_as_float(xmask[2 * TM + tokl]), __uint_as_float(xmask[3 * TM + tokl]));
                 }
                 nstore += 2;

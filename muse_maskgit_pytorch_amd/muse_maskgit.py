@@ -1145,7 +1145,7 @@ class MaskGit(nn.Module):
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())                # follows torch.manual_seed
         vkey = self.vae._pack_key() if exists(self.vae) else None
         ckey = self.cond_vae._pack_key() if (exists(cond_images) and self.cond_vae is not self.vae) else None
-        hb = tr._handle if tr.precision == 'bf16' else None
+        hb = tr._model() if tr.precision == 'bf16' else None      # (packed here if need be: the key below names the bound this packed model currently uses)
         key = (tuple(te.shape), None if not exists(cond_images) else tuple(cond_images.shape), fmap_size, float(temperature), float(thres), bool(can_remask), int(timesteps),
                float(cond_scale), return_ids, tr.precision, tr.fused_bound, hb.auto_bound if hb is not None else None, tr._pack_key(), vkey, ckey)
         eager = dict(cond_images=cond_images, fmap_size=fmap_size, temperature=temperature, topk_filter_thres=thres, can_remask_prev_masked=can_remask, timesteps=timesteps,
