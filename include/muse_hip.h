@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 6
+#define MM_ABI_VERSION 7
 
 #define MM_OK 0
 #define MM_ERR_SHAPE (-1)
@@ -385,6 +385,15 @@ int mm_split_rows(mm_stream_t stream, const float* x, int64_t ldx, int64_t rows,
 int mm_gemm_split(mm_stream_t stream, const void* x, int64_t ldx, const void* w, int64_t ldw, int M, int N, int K, int products, float alpha,
                   float* out, int64_t ldc, const float* resid_f32);
 
+/* FF w1 of the 'f16x2' tier (round 5, csrc/gemm_terms.hip): out_split = the term-segment pack [hh | hl | hh][:P] (16-bit container, ldo elements per row,
+ * segment length Fp = N / 2) of gate * gelu(x) (exact erf, fp32; mmp.py:72-77) with [x | gate] = alpha X' . W'^T, W' the term segments of the GEGLU-INTERLEAVED
+ * w1 rows (mm_ff_weights.w1); ln_part (optional) fp32 [M][N / 64][2] = (sum, sum of squares) of the row's fp32 products per 32 output columns -- what
+ * mm_ff_weights.w2_folded's LayerNorm(inner) fold consumes.  products = MM_SPLIT_F16 | 2 / 3; the kernel's shape class only (segment length % 64 (3) / 128 (2),
+ * N % 256 == 0, >= 256 tiles of 256 rows x 256 weight rows unless mm_debug_set2(1)): MM_ERR_UNSUPPORTED otherwise (the caller then runs mm_gemm_split + the
+ * GEGLU / LayerNorm / split pass). */
+int mm_gemm_split_geglu(mm_stream_t stream, const void* x, int64_t ldx, const void* w, int64_t ldw, int M, int N, int K, int products, float alpha,
+                        void* out_split, int64_t ldo, float* ln_part);
+
 /* mm_conv2d_nhwc on fp16 term operands: `in` holds MM_SPLIT_F16 | P segments per pixel (Cin = P x channels), w the matching per-tap pack (x 1 / alpha);
  * fp32 output only: out_nchw_f32 = 1 (NCHW) or 2 (NHWC, optional fp32 NHWC residual). */
 int mm_conv2d_nhwc_f16(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
@@ -444,6 +453,10 @@ typedef struct mm_ff_weights {
     const void* w1_ln;       /* bf16 [2*Fp][D], w1's GEGLU-interleaved row order = bf16(w1[n][k] * ln1_gamma[k])                    */
     const float* ln1_c1;     /* [2*Fp] in the same row order: sum_k float(w1_ln[n][k])                                   */
     const float* ln1_c2;     /* [2*Fp]: sum_k ln1_beta[k] * w1[n][k]  (NULL when ln1_beta is NULL / zero)                */
+    /* optional, 'f16x2' tier (round 5, ABI 7): w1 as term segments [wh | wh | wl][:P] of its GEGLU-INTERLEAVED rows (the row order of `w1` above; in the
+     * tier `w1` itself stays plain [x half | gate half]).  With it AND w2_folded (term segments of w2[o][f] * ln2_gamma[f]) / ln2_c1 / ln2_c2 the feed-forward
+     * runs as two kernels: w1 + GEGLU + term split + LayerNorm(inner) partial sums (csrc/gemm_terms.hip), w2 with the LayerNorm folded in               */
+    const void* w1_terms_geglu;
 } mm_ff_weights;
 
 typedef struct mm_layer_weights {
@@ -639,6 +652,9 @@ int mm_allgather_ids(mm_comm_t* comm, mm_stream_t stream, const int64_t* ids, in
 #define MM_PROF_SLOTS 2
 /* kernel ablation switches for tools/ (0 = product behaviour) */
 int mm_debug_set(int flags);
+/* second word (round 5): 1 = the term-sharing GEMM of the 'f16x2' tier (csrc/gemm_terms.hip) whatever the tile count (tests run small batches through the
+ * production kernels with it), 2 = that kernel off (A/B) */
+int mm_debug_set2(int flags);
 /* Race / determinism screen (tools/determinism_stress.py, tests): with a device buffer registered (NULL = off) every
  * mm_transformer_forward writes one 64-bit position-sensitive checksum per operator output, in launch order, to device_buf[0..];
  * mm_debug_trace_count() = entries of the last pass.  Two passes over the same inputs must produce identical traces. */

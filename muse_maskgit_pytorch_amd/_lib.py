@@ -28,7 +28,7 @@ class AttnWeights(C.Structure):
 
 
 class FFWeights(C.Structure):
-    _fields_ = [(n, c_vp) for n in ('ln1_gamma', 'ln1_beta', 'w1', 'ln2_gamma', 'ln2_beta', 'w2', 'w2_folded', 'ln2_c1', 'ln2_c2', 'w1_scale', 'w2_scale', 'w1_ln', 'ln1_c1', 'ln1_c2')]
+    _fields_ = [(n, c_vp) for n in ('ln1_gamma', 'ln1_beta', 'w1', 'ln2_gamma', 'ln2_beta', 'w2', 'w2_folded', 'ln2_c1', 'ln2_c2', 'w1_scale', 'w2_scale', 'w1_ln', 'ln1_c1', 'ln1_c2', 'w1_terms_geglu')]
 
 
 class LayerWeights(C.Structure):
@@ -91,6 +91,7 @@ SIGNATURES = {
     'mm_device_check': (c_int, []),
     'mm_gemm_bf16': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_int, c_vp]),
     'mm_gemm_split': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_int, c_f32, c_vp, c_i64, c_vp]),
+    'mm_gemm_split_geglu': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_int, c_f32, c_vp, c_i64, c_vp]),
     'mm_gemm_cfg_logits': (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_f32]),
     'mm_embed': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp]),
     'mm_layernorm': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_i64]),
@@ -186,6 +187,7 @@ SIGNATURES = {
     'mm_allgather_ids_workspace_bytes': (c_sz, [c_vp, c_i64]),
     'mm_allgather_ids': (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_sz]),
     'mm_debug_set': (c_int, [c_int]),
+    'mm_debug_set2': (c_int, [c_int]),
     'mm_debug_trace': (c_int, [c_vp, c_int]),
     'mm_debug_trace_count': (c_int, []),
     'mm_debug_capture': (c_int, [c_vp, c_sz, c_int, c_int]),
@@ -215,10 +217,12 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.mm_abi_version() != 6:
+        if l.mm_abi_version() != 7:
             raise MuseHipError('libmuse_hip ABI version mismatch')
         if os.environ.get('MM_DEBUG'):      # tools / A-B runs only: kernel-selection bits (see muse_hip_internal.h)
             l.mm_debug_set(int(os.environ['MM_DEBUG'], 0))
+        if os.environ.get('MM_DEBUG2'):
+            l.mm_debug_set2(int(os.environ['MM_DEBUG2'], 0))
         _lib = l
     return _lib
 

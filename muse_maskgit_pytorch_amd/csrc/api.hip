@@ -35,6 +35,7 @@ extern "C" {
 
 int mm_abi_version(void) { return MM_ABI_VERSION; }
 int mm_debug_set(int flags) { g_mm_debug = flags; return MM_OK; }
+int mm_debug_set2(int flags) { g_mm_debug2 = flags; return MM_OK; }
 const char* mm_last_error(void) { return g_err; }
 
 int mm_device_check(void) {
@@ -87,6 +88,27 @@ int mm_gemm_split(mm_stream_t stream, const void* x, int64_t ldx, const void* w,
     a.out = out; a.ldc = ldc; a.out_kind = OUT_F32;
     a.resid_f32 = resid_f32; a.ldr = ldc;
     a.f16 = f16 ? 1 : 0; a.alpha = alpha;
+    a.terms = f16 ? cnt : 0;      // equal-length term segments: the term-sharing kernel may take it (gemm_terms.hip)
+    return mm_gemm_launch(a, (hipStream_t)stream);
+}
+
+int mm_gemm_split_geglu(mm_stream_t stream, const void* x, int64_t ldx, const void* w, int64_t ldw, int M, int N, int K, int products, float alpha,
+                        void* out_split, int64_t ldo, float* ln_part) {
+    if (M == 0 || N == 0) return MM_OK;
+    CHK_PTR(x, "x"); CHK_PTR(w, "w"); CHK_PTR(out_split, "out_split");
+    CHK_ALIGN16(x, "x"); CHK_ALIGN16(w, "w"); CHK_ALIGN16(out_split, "out_split");
+    if (M < 0 || N < 0) return mm_set_error(MM_ERR_SHAPE, "gemm: negative size");
+    const int cnt = split_count(products);
+    if (!split_is_f16(products) || (cnt != 2 && cnt != 3)) return mm_set_error(MM_ERR_SHAPE, "gemm_split_geglu: fp16 term operands only (MM_SPLIT_F16 | 2 / 3)");
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mode = MODE_DENSE; a.epi = EPI_GEGLU;
+    a.W = (const bf16_t*)w; a.N = N; a.ldw = (int)ldw; a.K = K;
+    a.M = M; a.X = (const bf16_t*)x; a.ldx = (int)ldx;
+    a.out = out_split; a.ldc = ldo; a.out_kind = OUT_BF16;
+    a.ln_part = ln_part; a.ln_np = N / 64;
+    a.f16 = 1; a.alpha = alpha; a.terms = cnt;
+    if (!mm_gemm_terms_eligible(a)) return mm_set_error(MM_ERR_UNSUPPORTED, "gemm_split_geglu: outside the term-sharing kernel's shape class");
     return mm_gemm_launch(a, (hipStream_t)stream);
 }
 

@@ -496,6 +496,7 @@ int launch(const GemmArgs& a, hipStream_t stream) {
 }  // namespace
 
 int g_mm_debug = 0;
+int g_mm_debug2 = 0;
 
 // dense launch on the 128 x 128 kernel: 64-token tiles when the 128-token grid would give a CU fewer than two workgroups (see gemm_kernel)
 static int launch_dense_small(GemmArgs a, hipStream_t stream) {
@@ -530,7 +531,7 @@ int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
     if (a.ln_part && !a.ln_c1) {
         // FF w1 that also emits the LayerNorm(inner) partial sums (every GEGLU epilogue of the family does, identically)
         if (a.epi != EPI_GEGLU) return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: LayerNorm partial sums ride on the GEGLU epilogue");
-        a.ln_np = a.N / 128;
+        a.ln_np = a.f16 ? a.N / 64 : a.N / 128;      // (the tier's w1 on gemm_terms.hip: one partial per 32 output columns)
     }
     if (a.ln_c1) {
         // FF w2 with the LayerNorm(inner) folded in: the fp32-residual epilogue of the 128x128 / 256x128 kernels
@@ -548,12 +549,21 @@ int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
         return mm_gemm_cfg2_launch(a, stream);
     }
     if (a.f16) {      // fp16 term operands ('f16x2' tier): fp32 output, dense / convolution; the 256x128 kernel when it fills the chip, else the 128x128 one
-        if (a.out_kind == OUT_BF16 || a.mode == MODE_CFG || a.epi != EPI_NONE || a.ln_c1 || a.ln_part || a.splits > 1 || a.resid_bf16)
-            return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: fp16 term operands take the plain fp32-output dense / convolution forms only");
         if (a.alpha == 0.f) a.alpha = 1.f;
+        if (a.epi == EPI_GEGLU) {      // the tier's FF w1 with GEGLU + term-split output: gemm_terms.hip only (model.hip checks eligibility first)
+            if (!mm_gemm_terms_eligible(a)) return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: the GEGLU epilogue on fp16 term operands needs the term-sharing kernel's shape class");
+            return mm_gemm_terms_launch(a, stream);
+        }
+        if (a.out_kind == OUT_BF16 || a.mode == MODE_CFG || a.epi != EPI_NONE || (a.ln_part && !a.ln_c1) || a.splits > 1 || a.resid_bf16)
+            return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: fp16 term operands take the fp32-output dense / convolution forms only");
+        if (!(a.debug & (8 | (1 << 30))) && mm_gemm_terms_eligible(a)) return mm_gemm_terms_launch(a, stream);
         if (!a.m_dev && !(a.debug & 8) && mm_gemm_big_eligible(a)) return mm_gemm_big_launch(a, stream);
         a.tiles_n = (a.N + BT - 1) / BT;
         a.tiles_m = (a.M + BT - 1) / BT;
+        if (a.mode == MODE_DENSE && (long)a.tiles_m * a.tiles_n < 512 && a.M > 64 && !a.m_dev) {      // 64-token tiles, as launch_dense_small (the tier's cross-attention projections)
+            a.tiles_m = (a.M + 63) / 64;
+            return launch<MODE_DENSE, true, 64>(a, stream);
+        }
         return a.mode == MODE_CONV ? launch<MODE_CONV, true>(a, stream) : launch<MODE_DENSE, true>(a, stream);
     }
     if (a.in_c1) {      // LayerNorm(dim) fold, consumer side: the wide kernels or the 128x128 kernel (bf16 output, dense)

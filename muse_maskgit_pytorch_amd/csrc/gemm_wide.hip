@@ -275,7 +275,11 @@ __device__ __forceinline__ float max4_w(float a, float b, float c, float d) {   
 
 constexpr int SMEM_F = SMEM + 1024;      // + the tile's per-token bounds
 
-template <bool F16>      // F16: the operands are fp16 terms ('f16x2' tier) -> the fp16 MFMA, accumulators scaled by p.alpha before the emission
+// F16: the operands are fp16 terms ('f16x2' tier) -> the fp16 MFMA, accumulators scaled by p.alpha before the emission.  NP (F16 only; round 5): 0 = the segment
+// packs as one contraction of depth K (rounds 4-5); 2 / 3 = term sharing as in gemm_terms.hip -- 32-deep steps on [xh | xl] token rows and [wh | wl] weight rows
+// (NP 3; NP 2: [wh(64)] weight rows staged every other step), every product of a k-block from one staging of its term planes: 96 (64) MFMAs per wave and step on
+// the 64 (48) KiB that carried 64 before.  Same stage layout (stage s = token tile s | weight tile s), so the emission is untouched.
+template <bool F16, int NP = 0>
 __global__ __launch_bounds__(512) void gemm_wide_fused_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x, lane = t & 63;
@@ -283,17 +287,21 @@ __global__ __launch_bounds__(512) void gemm_wide_fused_kernel(const GemmArgs p) 
     const int wm = wid >> 2, wn = wid & 3;
     const int fr = lane & 15, fg = lane >> 4;
     const int total = p.tiles_m * p.tiles_n, G = gridDim.x;
-    const int KT = p.K / 64;
+    const int KS = NP ? p.K / NP : p.K;      // term sharing: the contraction length proper (one segment of the packs)
+    const int KT = NP ? KS / 32 : p.K / 64;
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     unsigned char* xch = smem + STG;                                           // exchange arrays of the emission: stage 1 (free at a tile's end)
     float* lthr = reinterpret_cast<float*>(smem + SMEM);                       // this tile's per-token bounds (LDS-DMA at its first k-step)
     const __amdgpu_buffer_rsrc_t thr_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.fs_thr), 0, (unsigned)p.M * 4u, 0x00020000);
-    const int dchunk = ((lane & 7) ^ (lane >> 3)) * 16;
+    const int lchunk = (lane & 7) ^ (lane >> 3);
+    // term sharing: logical chunks 0-3 of a staged row are 32 k-values of the h plane, 4-7 the same 32 of the l plane (tokens: segment 1; weights, NP 3: segment 2)
+    const int dchunk = NP ? (lchunk & 3) * 16 + (lchunk >> 2) * KS * 2 : lchunk * 16;
+    const int dchunk_w = NP == 3 ? (lchunk & 3) * 16 + (lchunk >> 2) * KS * 4 : lchunk * 16;
     int voff_x[4], voff_w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         voff_x[i] = (32 * wid + 8 * i + (lane >> 3)) * p.ldx * 2 + dchunk;
-        voff_w[i] = (32 * wid + 8 * i + (lane >> 3)) * p.ldw * 2 + dchunk;
+        voff_w[i] = (32 * wid + 8 * i + (lane >> 3)) * p.ldw * 2 + dchunk_w;
     }
     int vb = blockIdx.x;
     if (vb >= total) return;
@@ -321,8 +329,25 @@ __global__ __launch_bounds__(512) void gemm_wide_fused_kernel(const GemmArgs p) 
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                                  \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(ws_ + i * 1024), 16, voff_w[i], (kt_) * BKB, 0, 0);              \
     }
+#define ISSUE_TX(kt_, st_)      /* term sharing: the token rows of 32-deep step kt_ */                                               \
+    {                                                                                                                                  \
+        unsigned char* xs_ = smem + (st_) * STG + wid * 4096;                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                                  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(xs_ + i * 1024), 16, voff_x[i], (kt_) * 64, 0, 0);               \
+    }
+#define ISSUE_TW(byte_, st_)    /* ... the weight rows: byte_ = 64 kt (NP 3, per step) or 128 j (NP 2, per step pair j) */             \
+    {                                                                                                                                  \
+        unsigned char* ws_ = smem + (st_) * STG + X_B + wid * 4096;                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                                  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(ws_ + i * 1024), 16, voff_w[i], (byte_), 0, 0);                   \
+    }
     TILE_SETUP(vb);
-    ISSUE(0, 0);
+    if constexpr (NP != 0) {
+        ISSUE_TX(0, 0);
+        ISSUE_TW(0, 0);
+    } else {
+        ISSUE(0, 0);
+    }
     int pending = 0;                 // VMEM stores this wave issued BEHIND the DMA of the coming tile's first step (the previous tile's emission)
     f32x4_t acc[4][8];
     while (true) {
@@ -332,6 +357,57 @@ __global__ __launch_bounds__(512) void gemm_wide_fused_kernel(const GemmArgs p) 
 #pragma unroll
             for (int b = 0; b < 8; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         WD_STAMP();      // tile start
+        if constexpr (NP != 0) {
+        // term sharing (gemm_terms.hip's loop; requests right behind the barrier as in this kernel's plain loop).  NP 2: the weights of step pair j + 1 go out at
+        // the even step 2 j BEHIND the tokens of step 2 j + 1, so the top of an odd step waits for everything but those 4 instructions.
+        for (int kt = 0; kt < KT; ++kt) {
+            const int st = kt & 1;
+            if (kt == 0) wait_vmcnt_w(pending);
+            else if (NP == 2 && st == 1 && kt + 1 < KT) __builtin_amdgcn_s_waitcnt(MM_VMCNT_IMM(4));
+            else __builtin_amdgcn_s_waitcnt(0x0F70);
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < KT) {
+                ISSUE_TX(kt + 1, st ^ 1);
+                if constexpr (NP == 3) {
+                    ISSUE_TW((kt + 1) * 64, st ^ 1);
+                } else {
+                    if (st == 0 && kt + 2 < KT) ISSUE_TW(((kt >> 1) + 1) * 128, ((kt >> 1) + 1) & 1);
+                }
+            } else if (vb + G < total) {      // last step (odd): the next tile's first step goes into stage 0 (NP 2: K / NP % 128 == 0, so the last pair sits in stage 1)
+                TILE_SETUP(vb + G);
+                ISSUE_TX(0, 0);
+                ISSUE_TW(0, 0);
+            }
+            if (kt == 0 && wid == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(thr_rs, (lds_ptr_t)(lthr), 16, lane * 16, cur_m * TM * 4, 0, 0);
+            const unsigned char* xs = smem + st * STG + (wm * 128) * BKB;
+            const unsigned char* ws = smem + (NP == 3 ? st : ((kt >> 1) & 1)) * STG + X_B + (wn * 64) * BKB;
+            const int wc = NP == 3 ? 0 : st * 4;
+            u32x4_t wh[4], wl[4], xh[2], xl[2];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                wh[a] = *reinterpret_cast<const u32x4_t*>(ws + sw128(a * 16 + fr, wc + fg));
+                if constexpr (NP == 3) wl[a] = *reinterpret_cast<const u32x4_t*>(ws + sw128(a * 16 + fr, 4 + fg));
+            }
+            xh[0] = *reinterpret_cast<const u32x4_t*>(xs + sw128(fr, fg));
+            xl[0] = *reinterpret_cast<const u32x4_t*>(xs + sw128(fr, 4 + fg));
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                if (b + 1 < 8) {
+                    xh[(b + 1) & 1] = *reinterpret_cast<const u32x4_t*>(xs + sw128((b + 1) * 16 + fr, fg));
+                    xl[(b + 1) & 1] = *reinterpret_cast<const u32x4_t*>(xs + sw128((b + 1) * 16 + fr, 4 + fg));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a][b] = mfma16t<F16>(wh[a], xh[b & 1], acc[a][b]);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a][b] = mfma16t<F16>(wh[a], xl[b & 1], acc[a][b]);
+                if constexpr (NP == 3) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) acc[a][b] = mfma16t<F16>(wl[a], xh[b & 1], acc[a][b]);
+                }
+            }
+        }
+        } else {
         for (int kt = 0; kt < KT; ++kt) {
             const int st = kt & 1;
 #ifdef MM_GEMM_TIMING
@@ -364,6 +440,7 @@ __global__ __launch_bounds__(512) void gemm_wide_fused_kernel(const GemmArgs p) 
                     for (int a = 0; a < 4; ++a) acc[a][b] = mfma16t<F16>(wf[a], xf, acc[a][b]);
                 }
             }
+        }
         }
         if constexpr (F16) {      // undo the power-of-two scale of the packed weight terms (exact) before statistics and candidates
             const float al = p.alpha;
@@ -480,6 +557,8 @@ __global__ __launch_bounds__(512) void gemm_wide_fused_kernel(const GemmArgs p) 
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();      // the exchange area (stage 1) is read out before the next tile's second step lands in it
     }
+#undef ISSUE_TX
+#undef ISSUE_TW
 #undef ISSUE
 #undef TILE_SETUP
 }
@@ -540,6 +619,8 @@ int mm_gemm_wide_fused_launch(GemmArgs a, hipStream_t stream) {
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_F);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_F);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_fused_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_F);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_fused_kernel<true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_F);
         if (e != hipSuccess) return mm_set_hip_error(e, "gemm_wide_fused hipFuncSetAttribute");
         attr_set = true;
     }
@@ -548,7 +629,12 @@ int mm_gemm_wide_fused_launch(GemmArgs a, hipStream_t stream) {
     const int total = a.tiles_m * a.tiles_n;
     if (a.f16) {
         if (a.alpha == 0.f) a.alpha = 1.f;
-        hipLaunchKernelGGL(gemm_wide_fused_kernel<true>, dim3(total < 256 ? total : 256), dim3(512), SMEM_F, stream, a);
+        // term sharing (round 5) when the caller states the term count and the segment length fits the step structure (mm_debug_set2 bit 2: off, A/B)
+        const int ks = (a.terms == 2 || a.terms == 3) && (a.K % a.terms) == 0 ? a.K / a.terms : 0;
+        const bool share = ks && !(g_mm_debug2 & 2) && (ks % (a.terms == 3 ? 64 : 128)) == 0 && a.ldx >= a.K && a.ldw >= a.K;
+        if (share && a.terms == 3) hipLaunchKernelGGL((gemm_wide_fused_kernel<true, 3>), dim3(total < 256 ? total : 256), dim3(512), SMEM_F, stream, a);
+        else if (share) hipLaunchKernelGGL((gemm_wide_fused_kernel<true, 2>), dim3(total < 256 ? total : 256), dim3(512), SMEM_F, stream, a);
+        else hipLaunchKernelGGL(gemm_wide_fused_kernel<true>, dim3(total < 256 ? total : 256), dim3(512), SMEM_F, stream, a);
     } else {
         hipLaunchKernelGGL(gemm_wide_fused_kernel<false>, dim3(total < 256 ? total : 256), dim3(512), SMEM_F, stream, a);
     }

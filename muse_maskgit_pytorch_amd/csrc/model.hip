@@ -181,6 +181,7 @@ int gemm_dense(const mm_transformer* t, hipStream_t s, const bf16_t* X, int ldx,
     memset(&a, 0, sizeof(a));
     a.mode = MODE_DENSE;
     a.f16 = t->F16; a.alpha = t->alpha;      // 'f16x2' tier: fp16 term operands (every GEMM of such a model)
+    a.terms = t->F16 ? t->P : 0;             // ... as equal-length term segments: gemm_terms.hip stages every term plane once where its shape class applies
     a.W = W; a.N = N; a.ldw = ldw; a.K = K; a.M = M; a.X = X; a.ldx = ldx;
     a.out = out; a.ldc = ldc; a.out_kind = out_kind; a.resid_f32 = resid; a.ldr = ldc;
     return mm_gemm_launch(a, s);
@@ -280,6 +281,28 @@ int ff_block(const mm_transformer* t, hipStream_t s, const mm_ff_weights& w, con
     if (t->P) {      // precision tier: LN -> P segments -> w1 (fp32 out, plain [x | gate] halves) -> GEGLU + LN(inner) -> P segments -> w2 + residual
         const int P = t->P;
         RC(k_layernorm_split(s, addvec ? dst : src, D, rows, D, w.ln1_gamma, w.ln1_beta, nullptr, t->PC, b.xn, nullptr, addvec, add_from, addvec ? dst : nullptr));
+        if (t->F16 && w.w1_terms_geglu && w.w2_folded && w.ln2_c1 && w.ln2_c2 && !(g_mm_debug & (1 << 24))) {
+            // round 5: w1 on the term-sharing kernel with GEGLU + the term split of its output + the LayerNorm(inner) partial sums in the epilogue
+            // (gemm_terms.hip), LayerNorm(inner) folded into w2 as in the bf16 engine (mmp.py:85-88): the fp32 [rows][2 Fp] intermediate and the
+            // GEGLU / LayerNorm / split pass over it disappear.  Shapes outside the kernel's class (small batches) take the three-kernel form below.
+            GemmArgs a1;
+            memset(&a1, 0, sizeof(a1));
+            a1.mode = MODE_DENSE; a1.epi = EPI_GEGLU; a1.f16 = 1; a1.alpha = t->alpha; a1.terms = P;
+            a1.W = (const bf16_t*)w.w1_terms_geglu; a1.N = 2 * Fp; a1.ldw = P * D; a1.K = P * D; a1.M = rows; a1.X = b.xn; a1.ldx = P * D;
+            a1.out = b.a; a1.ldc = (long)P * Fp; a1.out_kind = OUT_BF16; a1.ln_part = b.lnp; a1.ln_np = 2 * Fp / 64;
+            if (mm_gemm_terms_eligible(a1)) {
+                RC(mm_gemm_launch(a1, s));
+                GemmArgs a2;
+                memset(&a2, 0, sizeof(a2));
+                a2.mode = MODE_DENSE; a2.f16 = 1; a2.alpha = t->alpha; a2.terms = P;
+                a2.W = (const bf16_t*)w.w2_folded; a2.N = D; a2.ldw = P * Fp; a2.K = P * Fp; a2.M = rows; a2.X = b.a; a2.ldx = P * Fp;
+                a2.out = dst; a2.ldc = D; a2.out_kind = OUT_F32; a2.resid_f32 = dst; a2.ldr = D;
+                a2.ln_part = b.lnp; a2.ln_np = Fp / 32; a2.ln_F = F; a2.ln_c1 = w.ln2_c1; a2.ln_c2 = w.ln2_c2;
+                RC(mm_gemm_launch(a2, s));
+                TR(dst, (size_t)rows * D * 4);
+                return MM_OK;
+            }
+        }
         float* hf = reinterpret_cast<float*>(b.h);
         RC(gemm_dense(t, s, b.xn, P * D, (const bf16_t*)w.w1, P * D, rows, 2 * Fp, P * D, hf, 2 * Fp, OUT_F32, nullptr));
         RC(k_geglu_ln_split(s, hf, 2 * Fp, rows, F, Fp, w.ln2_gamma, w.ln2_beta, t->PC, b.a));
@@ -1095,7 +1118,7 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
         a.M = R; a.X = nullptr; a.ldx = KD;      // (X: the mixed rows, set below)
         a.out = g.logits; a.ldc = V; a.out_kind = OUT_F32;
         a.debug = g_mm_debug;
-        a.f16 = t->F16; a.alpha = t->alpha;
+        a.f16 = t->F16; a.alpha = t->alpha; a.terms = t->F16 ? t->P : 0;
         // Sampling without the logits round trip: the GEMM emits tile statistics + the candidates above a per-row lower bound of the k-th largest
         // logit (estimated from the row's embeddings and the vocabulary statistics of to_logits), the finishing kernel verifies the bound.
         const bool qbound = t->d.logits_wsub && t->d.logits_wsub_rows > 0;      // distribution-free bound from sampled vocabulary columns (else: the Gaussian estimate)

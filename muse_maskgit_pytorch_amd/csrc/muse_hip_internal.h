@@ -46,6 +46,11 @@ struct GemmArgs {
     // `alpha` (the inverse of the power-of-two scale the weight terms were packed with; 0 = 1) before anything else in the epilogue.  fp32 output only,
     // dense and convolution modes, on the 128x128 / 256x128 kernels and the fused-sampling logits kernel.
     int f16; float alpha;
+    // ... with `terms` = 2 / 3 the caller also states that X' / W' are equal-length term segments [xh | xl | xh][:terms] / [wh | wh | wl][:terms] (K = terms x the
+    // segment length): gemm_terms.hip then stages every term plane once and runs the products of a k-block from that one staging (0: unknown -- plain fp16 GEMM
+    // of depth K).  With EPI_GEGLU (terms != 0 only): W rows GEGLU-interleaved, `out` = the term-segment pack [hh | hl | hh][:terms] of gate * gelu(x)
+    // (16-bit container, ldc elements per row, segment length N / 2), ln_part = (sum, sum of squares) per row and 32 output columns (ln_np = N / 64).
+    int terms;
     // LayerNorm(dim) folded into the GEMMs around it (round 4, bf16 engine; model.hip):
     //   PRODUCER -- the fp32-residual epilogue of the 128x128 / 256x128 kernels (out = resid + acc): with xb_out != NULL it also writes the new residual
     //     row as bf16 (xb_out [M][ldxb]) and, per row and 64 columns, the (sum, sum of squares) of the fp32 values to st_part[(row * st_np + i) * 2 ..],
@@ -57,6 +62,7 @@ struct GemmArgs {
     const float* in_part; int in_np; int in_F; const float* in_c1; const float* in_c2;
 };
 extern int g_mm_debug;
+extern int g_mm_debug2;      // mm_debug_set2 (round 5): 1 = gemm_terms.hip whatever the tile count (tests: small batches through the production kernels), 2 = gemm_terms.hip off (A/B)
 
 int mm_gemm_launch(GemmArgs a, hipStream_t stream);
 bool mm_gemm_big_eligible(const GemmArgs& a);      // gemm_big.hip: 256x128 tile, 3-stage counted-vmcnt pipeline
@@ -68,6 +74,8 @@ int mm_gemm_wide_launch(GemmArgs a, hipStream_t stream);
 bool mm_gemm_wide_fused_eligible(const GemmArgs& a);      // the fused-sampling logits GEMM on the same k-loop (persistent)
 int mm_gemm_wide_fused_launch(GemmArgs a, hipStream_t stream);     // gemm_cfg.hip: persistent 128 tokens x 256 columns, guidance logits
 int mm_gemm_cfg2_launch(GemmArgs a, hipStream_t stream);
+bool mm_gemm_terms_eligible(const GemmArgs& a);      // gemm_terms.hip (round 5): fp16 term-segment operands, every term plane staged once
+int mm_gemm_terms_launch(GemmArgs a, hipStream_t stream);
 bool mm_gemm_pp_fused_selected(const GemmArgs& a);      // gemm_pp.hip (round 5): the logits GEMM with its wave groups out of lock-step
 int mm_gemm_pp_fused_launch(GemmArgs a, hipStream_t stream);
 // gemm_pers.hip: persistent 256x128, stores overlapped with the next tile

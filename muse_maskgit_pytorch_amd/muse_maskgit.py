@@ -426,8 +426,22 @@ class Transformer(nn.Module):
             w1p[Fp:Fp + F] = w1[F:]
             t = dict(g1=f32c(ff[0].gamma), b1=ff[0].beta.float().contiguous(), w1=pack(w1p), g2=ops.pad_cols(f32c(ff[3].gamma), Fp),
                      b2=ops.pad_cols(ff[3].beta.float(), Fp), w2=pack(w2, 64))
+            t['w1g'] = t['w2f'] = t['c1'] = t['c2'] = None
+            if ops.split_is_f16(PC):
+                # round 5 (csrc/gemm_terms.hip, model.hip ff_block): w1 as term segments of its GEGLU-interleaved rows (GEGLU + the term split + the LayerNorm(inner)
+                # partial sums ride in its epilogue) and LayerNorm(inner) folded into w2 -- gains into the weight terms, mean / bias terms as two [D] vectors
+                # taken from the terms the GEMM really multiplies.  Only when the gain-folded weight fits the model's term count and fp16 range.
+                w2g = ops.pad_cols(w2, 64) * t['g2'][None, :]
+                if float(w2g.abs().max()) * scale <= 65504. and ops.weight_terms_f16(w2g, scale) <= P - 1:
+                    hh, ll = ops.split_terms_f16(w2g, scale)
+                    rep = hh.double() + (ll.double() if P > 2 else 0.)
+                    t['w2f'] = ops.split_pack_weight(w2g, PC, 64, scale)
+                    t['c1'] = (rep.sum(dim=1) / scale).float().contiguous()
+                    t['c2'] = (ops.pad_cols(w2, 64).double() * t['b2'].double()[None, :]).sum(dim=1).float().contiguous()
+                    t['w1g'] = pack(ops.pack_w1_geglu(ff[1].weight.detach().float(), Fp, dtype=torch.float32))
             h.keep.append(t)
-            return L.FFWeights(L.ptr(t['g1']), L.ptr(t['b1']), L.ptr(t['w1']), L.ptr(t['g2']), L.ptr(t['b2']), L.ptr(t['w2']), None, None, None), F, Fp
+            return L.FFWeights(ln1_gamma=L.ptr(t['g1']), ln1_beta=L.ptr(t['b1']), w1=L.ptr(t['w1']), ln2_gamma=L.ptr(t['g2']), ln2_beta=L.ptr(t['b2']), w2=L.ptr(t['w2']),
+                               w2_folded=L.ptr(t['w2f']), ln2_c1=L.ptr(t['c1']), ln2_c2=L.ptr(t['c2']), w1_terms_geglu=L.ptr(t['w1g'])), F, Fp
 
         def pack_attn(a, fused):
             I, D = a.to_q.weight.shape

@@ -753,6 +753,21 @@ def gemm_split(xs, ws, products, alpha=1.0, resid=None):
     return out[:, :N]
 
 
+def gemm_split_geglu(xs, w1s, products, alpha=1.0, stats=True):
+    """FF w1 of the 'f16x2' tier (mm_gemm_split_geglu, csrc/gemm_terms.hip): xs term-segment rows [M][P*K], w1s = split_pack_weight of the GEGLU-interleaved
+    w1 (pack_w1_geglu(..., dtype=float32)) [2Fp][P*K] -> (term-segment pack [M][P*Fp] of gate * gelu(x), fp32 [M][Fp/32][2] LayerNorm(inner) partial sums or None)"""
+    _chk_cuda(xs, w1s)
+    M, K = xs.shape
+    N = w1s.shape[0]
+    P = split_count(products)
+    assert w1s.shape[1] == K and xs.stride(1) == 1 and w1s.stride(1) == 1 and split_is_f16(products)
+    out = torch.empty(M, P * (N // 2), dtype=bf16, device=xs.device)
+    part = torch.empty(M, N // 64, 2, dtype=torch.float32, device=xs.device) if stats else None
+    L.check(L.lib().mm_gemm_split_geglu(L.stream(), L.ptr(xs), xs.stride(0), L.ptr(w1s), w1s.stride(0), M, N, K, int(products), float(alpha), L.ptr(out),
+                                        out.stride(0), L.ptr(part)), 'mm_gemm_split_geglu')
+    return out, part
+
+
 def split_rows(x, products):
     """fp32 [rows][K] -> bf16 [rows][products * K] (mm_split_rows): the GEMM operand form of the precision tier"""
     _chk_cuda(x)
