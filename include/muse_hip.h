@@ -379,6 +379,11 @@ int mm_split_rows(mm_stream_t stream, const float* x, int64_t ldx, int64_t rows,
  * (mm_split_rows, mm_cfg_mix, mm_gemm_split, mm_transformer_desc.split_products).  Measured on the reference's own fp32 checkpoint at
  * BASELINE configs[1] size: logits within 4e-6 of the reference, ids 100 % at every decode step. */
 #define MM_SPLIT_F16 0x100
+/* mm_gemm_split only, with MM_SPLIT_F16 (round 5): the caller states that X' / W' are GENUINE term-segment packs of mm_split_rows / the weight packing -- segment 2
+ * of X' repeats segment 0, segment 1 of W' repeats segment 0 -- so the kernels may stage every term plane ONCE and run the products of a k-block from that one
+ * staging (csrc/gemm_terms.hip; same terms, summation order per 32-deep k-block hh, lh, hl instead of all hh, all lh, all hl).  Without the bit the operator is
+ * the plain matrix product of the two packs.  mm_transformer_* / mm_generate on an 'f16x2' model always state it (they own their packs). */
+#define MM_SPLIT_SHARED 0x200
 
 /* out fp32 [M][ldc] (+ resid_f32) = X' . W'^T over term-segment packs: products = 3 / 5 / 6 -> bf16 terms (== mm_gemm_bf16 with out_f32), alpha unused;
  * MM_SPLIT_F16 | 2 / 3 -> fp16 terms on the fp16 MFMA, accumulators x alpha.  K = segments x inner width, a multiple of 64. */
@@ -399,6 +404,11 @@ int mm_gemm_split_geglu(mm_stream_t stream, const void* x, int64_t ldx, const vo
 int mm_conv2d_nhwc_f16(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
                        int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
                        int Hout, int Wout, const float* bias, int act, const float* resid_f32, float* out, int out_nchw_f32, float alpha);
+/* ... with the operand code stated (round 5): products = MM_SPLIT_F16 | 2 / 3 segments per pixel (Cin = P x channels) and per tap of the weight rows; with
+ * MM_SPLIT_SHARED (genuine packs: [xh | xl | xh] per pixel, [wh | wh | wl] per tap) the 256 x 128 kernel stages every term plane once (channels % 32 == 0). */
+int mm_conv2d_nhwc_terms(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
+                         int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
+                         int Hout, int Wout, const float* bias, int act, const float* resid_f32, float* out, int out_nchw_f32, float alpha, int products);
 
 /* Classifier-free guidance applied to the EMBEDDINGS (round 3): to_logits is linear (mmp.py:332), so null + (cond - null) * s of the two passes'
  * logits (mmp.py:254) equals to_logits(e) with e = e_null + (e_cond - e_null) * s -- ONE [R x V x D] product instead of two.  mm_generate and

@@ -88,7 +88,7 @@ int mm_gemm_split(mm_stream_t stream, const void* x, int64_t ldx, const void* w,
     a.out = out; a.ldc = ldc; a.out_kind = OUT_F32;
     a.resid_f32 = resid_f32; a.ldr = ldc;
     a.f16 = f16 ? 1 : 0; a.alpha = alpha;
-    a.terms = f16 ? cnt : 0;      // equal-length term segments: the term-sharing kernel may take it (gemm_terms.hip)
+    a.terms = (f16 && (products & 0x200)) ? cnt : 0;      // MM_SPLIT_SHARED: genuine term-segment packs -- the term-sharing kernels may take it (gemm_terms.hip)
     return mm_gemm_launch(a, (hipStream_t)stream);
 }
 
@@ -461,13 +461,13 @@ int mm_philox_uniform(mm_stream_t stream, uint64_t seed, uint64_t row_offset, ui
 
 static int conv2d_nhwc_impl(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
                             int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
-                            int Hout, int Wout, const float* bias, int act, const void* resid, void* out, int out_nchw_f32, int f16, float alpha);
+                            int Hout, int Wout, const float* bias, int act, const void* resid, void* out, int out_nchw_f32, int f16, float alpha, int terms);
 
 int mm_conv2d_nhwc(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
                    int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
                    int Hout, int Wout, const float* bias, int act, const void* resid, void* out, int out_nchw_f32) {
     return conv2d_nhwc_impl(stream, in, B, Hin, Win, Cin, w, Cout, TH, TW, stride, off_y, off_x, Hv, Wv, os, py, px, Hout, Wout, bias, act, resid, out,
-                            out_nchw_f32, 0, 1.f);
+                            out_nchw_f32, 0, 1.f, 0);
 }
 
 // the same convolution on fp16 TERM operands ('f16x2' tier: `in` holds MM_SPLIT_F16 | P segments per pixel, w the matching per-tap pack scaled by a power
@@ -477,12 +477,22 @@ int mm_conv2d_nhwc_f16(mm_stream_t stream, const void* in, int B, int Hin, int W
                        int Hout, int Wout, const float* bias, int act, const float* resid_f32, float* out, int out_nchw_f32, float alpha) {
     if (out_nchw_f32 != 1 && out_nchw_f32 != 2) return mm_set_error(MM_ERR_SHAPE, "conv_f16: fp32 output only (out_nchw_f32 = 1 or 2)");
     return conv2d_nhwc_impl(stream, in, B, Hin, Win, Cin, w, Cout, TH, TW, stride, off_y, off_x, Hv, Wv, os, py, px, Hout, Wout, bias, act, resid_f32, out,
-                            out_nchw_f32, 1, alpha);
+                            out_nchw_f32, 1, alpha, 0);
+}
+
+int mm_conv2d_nhwc_terms(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
+                         int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
+                         int Hout, int Wout, const float* bias, int act, const float* resid_f32, float* out, int out_nchw_f32, float alpha, int products) {
+    if (out_nchw_f32 != 1 && out_nchw_f32 != 2) return mm_set_error(MM_ERR_SHAPE, "conv_terms: fp32 output only (out_nchw_f32 = 1 or 2)");
+    const int cnt = split_count(products);
+    if (!split_is_f16(products) || (cnt != 2 && cnt != 3) || (Cin % cnt)) return mm_set_error(MM_ERR_SHAPE, "conv_terms: products = MM_SPLIT_F16 | 2 / 3 segments per pixel");
+    return conv2d_nhwc_impl(stream, in, B, Hin, Win, Cin, w, Cout, TH, TW, stride, off_y, off_x, Hv, Wv, os, py, px, Hout, Wout, bias, act, resid_f32, out,
+                            out_nchw_f32, 1, alpha, (products & 0x200) ? cnt : 0);
 }
 
 static int conv2d_nhwc_impl(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
                             int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
-                            int Hout, int Wout, const float* bias, int act, const void* resid, void* out, int out_nchw_f32, int f16, float alpha) {
+                            int Hout, int Wout, const float* bias, int act, const void* resid, void* out, int out_nchw_f32, int f16, float alpha, int terms) {
     if (B == 0) return MM_OK;
     CHK_PTR(in, "in"); CHK_PTR(w, "w"); CHK_PTR(out, "out");
     CHK_ALIGN16(in, "in"); CHK_ALIGN16(w, "w"); CHK_ALIGN16(out, "out");
@@ -503,7 +513,7 @@ static int conv2d_nhwc_impl(mm_stream_t stream, const void* in, int B, int Hin, 
     if (out_nchw_f32 == 2) a.resid_f32 = (const float*)resid;      // fp32 NHWC in and out (the precision tier's convolutions: bf16 term segments in, fp32 out)
     else a.resid_bf16 = (const bf16_t*)resid;
     a.ldr = Cout;
-    a.f16 = f16; a.alpha = alpha;
+    a.f16 = f16; a.alpha = alpha; a.terms = terms;
     return mm_gemm_launch(a, (hipStream_t)stream);
 }
 

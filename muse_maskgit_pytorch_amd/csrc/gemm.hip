@@ -43,9 +43,12 @@ __device__ __attribute__((aligned(16))) const unsigned int g_zero_page[64] = {0}
 // projections: 8192 rows x 512 columns = 256 tiles, ONE four-wave workgroup per CU, i.e. one wave per SIMD with every latency exposed -- 16.9 us for 4.3 GFLOP):
 // there BM = 64 gives each CU two or three independent workgroups whose barrier phases drift apart and cover one another (round 4).  Same MFMA order per
 // output element: bit-identical results.
-template <int MODE, bool F16 = false, int BM = 128>
+// NP (F16, MODE_DENSE; round 5): 0 = segment packs as one contraction of depth K; 2 / 3 = term sharing as in gemm_terms.hip / gemm_big.hip -- 32-deep steps on
+// [xh(32) | xl(32)] token rows and [wh(32) | wl(32)] weight rows (NP 2: 64-byte rows [wh(32)], lane-linear), every product of the k-block from one staging.
+template <int MODE, bool F16 = false, int BM = 128, int NP = 0>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     static_assert(BM == 128 || (BM == 64 && MODE == MODE_DENSE), "64-token tiles: dense mode only");
+    static_assert(NP == 0 || (F16 && MODE == MODE_DENSE), "term sharing: dense fp16 term operands only");
     constexpr int MB = BM / 32;      // token fragments per wave (a wave: 64 weight rows x BM / 2 tokens)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TSTAMP(0)
@@ -63,6 +66,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     // ---- per-lane DMA geometry.  Wave w stages tile rows [32w, 32w+32) with 4 instructions of 8 rows each; within an
     //      instruction lane l lands on (row l>>3, physical chunk l&7), which must hold logical chunk (l&7) ^ (row & 7).
     const int chunk = (lane & 7) ^ (lane >> 3);
+    const int KS = NP ? p.K / NP : p.K;      // term sharing: the contraction length proper; logical chunks 0-3 = 32 k-values of the h plane, 4-7 = of the l plane
+    const int xce = NP ? (chunk & 3) * 8 + (chunk >> 2) * KS : chunk * 8;
+    const int wce = NP == 3 ? (chunk & 3) * 8 + (chunk >> 2) * 2 * KS : chunk * 8;
     const int row0 = 32 * wid + (lane >> 3);          // rows row0 + 8*i
     constexpr int XI = BM / 32;                       // X tile: this wave's BM / 4 rows = XI instructions (rows xrow0 + 8*i)
     const int xrow0 = (BM / 4) * wid + (lane >> 3);
@@ -75,11 +81,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         const int r = row0 + 8 * i;
         const int n = n0 + r;
         // out-of-range rows are clamped to row 0: they only feed outputs the epilogue never stores
-        wptr[i] = p.W + (size_t)(n < p.N ? n : 0) * p.ldw + chunk * 8;
+        if constexpr (NP == 2) {      // one instruction = 16 rows of 64 bytes: lane l -> row l >> 2, chunk l & 3 (two instructions per wave)
+            const int n2 = n0 + 32 * wid + 16 * (i & 1) + (lane >> 2);
+            wptr[i] = p.W + (size_t)(n2 < p.N ? n2 : 0) * p.ldw + (lane & 3) * 8;
+        } else {
+            wptr[i] = p.W + (size_t)(n < p.N ? n : 0) * p.ldw + wce;
+        }
         if constexpr (MODE == MODE_DENSE) {
             const int m = m0 + xrow0 + 8 * (i < XI ? i : 0);
             xok[i] = m < p.M;
-            xptr[i] = p.X + (size_t)(xok[i] ? m : 0) * p.ldx + chunk * 8;
+            xptr[i] = p.X + (size_t)(xok[i] ? m : 0) * p.ldx + xce;
         } else if constexpr (MODE == MODE_CFG) {
             const int wm = r >> 6, jj = r & 63;
             const int tok = m0 + wm * 32 + (jj & 31);
@@ -101,10 +112,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define ISSUE_TILE(kt_, stage_)                                                                                    \
     {                                                                                                              \
-        const int k0_ = (kt_) * BK;                                                                                \
-        unsigned char* ws_ = smem + (stage_) * STAGE_BYTES + wid * 4096;   /* this wave's 32 rows of the W tile */ \
+        const int k0_ = (kt_) * (NP ? 32 : BK);                                                                    \
+        unsigned char* ws_ = smem + (stage_) * STAGE_BYTES + wid * (NP == 2 ? 2048 : 4096);   /* this wave's 32 rows of the W tile */ \
         unsigned char* xs_ = smem + (stage_) * STAGE_BYTES + BT * BK * 2 + wid * (BM * 32);   /* ... its BM / 4 rows of the X tile */ \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
+        _Pragma("unroll") for (int i = 0; i < (NP == 2 ? 2 : 4); ++i)                                              \
             __builtin_amdgcn_global_load_lds(wptr[i] + k0_, (lds_ptr_t)(ws_ + i * 1024), 16, 0, 0);                \
         if constexpr (MODE != MODE_CONV) {                                                                         \
             _Pragma("unroll") for (int i = 0; i < XI; ++i)                                                         \
@@ -136,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 
     // split-K: this workgroup covers k-tiles [kt0, kt0 + KT) and writes its partial sums to slab blockIdx.y of `out`
     const int nsplit = p.splits > 1 ? p.splits : 1;
-    const int KT = p.K / BK / nsplit;
+    const int KT = NP ? KS / 32 : p.K / BK / nsplit;
     const int kt0 = (int)blockIdx.y * KT;
     void* const outp = p.splits > 1 ? static_cast<void*>(reinterpret_cast<float*>(p.out) + (size_t)blockIdx.y * p.split_stride) : p.out;
     TSTAMP(1)
@@ -200,16 +211,43 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
             } else { _Pragma("unroll") for (int a = 0; a < 4; ++a) { acc[a][0][0] += __uint_as_float(af[a][0] ^ bfm[a][1]); } } \
         }                                                                                                          \
     }
+#define COMPUTE_TERMS(stage_)      /* term sharing: xh.wh, xl.wh (, xh.wl) of this 32-deep k-block from one staging of its term planes */ \
+    {                                                                                                              \
+        const unsigned char* ws_ = smem + (stage_) * STAGE_BYTES;                                                  \
+        const unsigned char* xs_ = ws_ + BT * BK * 2;                                                              \
+        u32x4_t wh[4], wl[4], xh[MB], xl[MB];                                                                      \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
+            if constexpr (NP == 3) {                                                                               \
+                wh[i] = *reinterpret_cast<const u32x4_t*>(ws_ + lds_off(wave_n * 64 + i * 16 + fr, fg));           \
+                wl[i] = *reinterpret_cast<const u32x4_t*>(ws_ + lds_off(wave_n * 64 + i * 16 + fr, 4 + fg));       \
+            } else {                                                                                               \
+                wh[i] = *reinterpret_cast<const u32x4_t*>(ws_ + (wave_n * 64 + i * 16 + fr) * 64 + fg * 16);       \
+            }                                                                                                      \
+        }                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < MB; ++i) {                                                           \
+            xh[i] = *reinterpret_cast<const u32x4_t*>(xs_ + lds_off(wave_m * (BM / 2) + i * 16 + fr, fg));         \
+            xl[i] = *reinterpret_cast<const u32x4_t*>(xs_ + lds_off(wave_m * (BM / 2) + i * 16 + fr, 4 + fg));     \
+        }                                                                                                          \
+        _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                              \
+            _Pragma("unroll") for (int b = 0; b < MB; ++b) acc[a][b] = mfma16t<F16>(wh[a], xh[b], acc[a][b]);      \
+        _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                              \
+            _Pragma("unroll") for (int b = 0; b < MB; ++b) acc[a][b] = mfma16t<F16>(wh[a], xl[b], acc[a][b]);      \
+        if constexpr (NP == 3) {                                                                                   \
+            _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                          \
+                _Pragma("unroll") for (int b = 0; b < MB; ++b) acc[a][b] = mfma16t<F16>(wl[a], xh[b], acc[a][b]);  \
+        }                                                                                                          \
+    }
+#define COMPUTE_STEP(stage_) { if constexpr (NP != 0) COMPUTE_TERMS(stage_) else COMPUTE_TILE(stage_) }
     // steady state: the next tile's DMA is in flight while this tile's MFMAs run; one barrier per tile
     for (int kt = 0; kt < KT - 1; ++kt) {
         if (!(p.debug & 2)) ISSUE_TILE(kt0 + kt + 1, (kt + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);   // keep the DMA issue ahead of the MFMA block
-        COMPUTE_TILE(kt & 1);
+        COMPUTE_STEP(kt & 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's DMA (issued above by this wave) has landed before the barrier publishes it
         __syncthreads();
         TSTAMP(3 + kt)
     }
-    COMPUTE_TILE((KT - 1) & 1);
+    COMPUTE_STEP((KT - 1) & 1);
     TSTAMP(40)
     if constexpr (F16) {      // fp16 term products: undo the power-of-two scale of the packed weight terms (exact)
         const float al = p.alpha;
@@ -478,18 +516,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     TSTAMP(43)
 }
 
-template <int MODE, bool F16 = false, int BM = 128>
+template <int MODE, bool F16 = false, int BM = 128, int NP = 0>
 int launch(const GemmArgs& a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_kernel<MODE, F16, BM>)),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_kernel<MODE, F16, BM, NP>)),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
         if (e != hipSuccess) return mm_set_hip_error(e, "gemm hipFuncSetAttribute");
         attr_set = true;
     }
     const int blocks = a.tiles_m * a.tiles_n;
     if (blocks <= 0) return MM_OK;
-    hipLaunchKernelGGL((gemm_kernel<MODE, F16, BM>), dim3(blocks, a.splits > 1 ? a.splits : 1), dim3(256), SMEM_BYTES, stream, a);
+    hipLaunchKernelGGL((gemm_kernel<MODE, F16, BM, NP>), dim3(blocks, a.splits > 1 ? a.splits : 1), dim3(256), SMEM_BYTES, stream, a);
     return mm_check_launch("gemm_kernel");
 }
 
@@ -560,10 +598,15 @@ int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
         if (!a.m_dev && !(a.debug & 8) && mm_gemm_big_eligible(a)) return mm_gemm_big_launch(a, stream);
         a.tiles_n = (a.N + BT - 1) / BT;
         a.tiles_m = (a.M + BT - 1) / BT;
+        // term sharing (round 5; equal-length term segments stated by the caller): every term plane staged once, the products of a k-block from that staging
+        const int np = (a.mode == MODE_DENSE && (a.terms == 2 || a.terms == 3) && !(g_mm_debug2 & 2) && !(a.debug & (1 | 2 | 4)) && (a.K % a.terms) == 0 &&
+                        ((a.K / a.terms) % 32) == 0 && a.ldx >= a.K && a.ldw >= a.K) ? a.terms : 0;
         if (a.mode == MODE_DENSE && (long)a.tiles_m * a.tiles_n < 512 && a.M > 64 && !a.m_dev) {      // 64-token tiles, as launch_dense_small (the tier's cross-attention projections)
             a.tiles_m = (a.M + 63) / 64;
-            return launch<MODE_DENSE, true, 64>(a, stream);
+            return np == 3 ? launch<MODE_DENSE, true, 64, 3>(a, stream) : np == 2 ? launch<MODE_DENSE, true, 64, 2>(a, stream) : launch<MODE_DENSE, true, 64>(a, stream);
         }
+        if (np == 3) return launch<MODE_DENSE, true, 128, 3>(a, stream);
+        if (np == 2) return launch<MODE_DENSE, true, 128, 2>(a, stream);
         return a.mode == MODE_CONV ? launch<MODE_CONV, true>(a, stream) : launch<MODE_DENSE, true>(a, stream);
     }
     if (a.in_c1) {      // LayerNorm(dim) fold, consumer side: the wide kernels or the 128x128 kernel (bf16 output, dense)

@@ -33,7 +33,10 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + 
 // source of the implicit-GEMM loader for taps that fall into the zero padding
 __device__ __attribute__((aligned(16))) const unsigned int g_zero_page_big[64] = {0};
 
-template <int MODE, bool F16 = false>
+// NP (F16, MODE_DENSE only; round 5): 0 = segment packs as one contraction of depth K; 2 / 3 = term sharing as in gemm_terms.hip -- a 32-deep step stages the token
+// rows as [xh(32) | xl(32)] and the weight rows as [wh(32) | wl(32)] (NP 3; NP 2: 64-byte rows [wh(32)], lane-linear -- conflict-free without a swizzle) and runs
+// the products xh.wh, xl.wh (, xh.wl) of the k-block from that one staging: 48 (32) MFMAs per wave on the 48 (40) KiB that carried 32.
+template <int MODE, bool F16 = false, int NP = 0>
 __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
@@ -48,12 +51,23 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
     // ---- per-lane DMA geometry: one instruction = 8 tile rows; lane l -> (row l>>3, physical chunk l&7) holding logical
     //      chunk (l&7) ^ (row&7).  Wave w stages W rows [16w, 16w+16) (2 instr) and X rows [32w, 32w+32) (4 instr).
     const int chunk = (lane & 7) ^ (lane >> 3);
+    const int KS = NP ? p.K / NP : p.K;      // term sharing: the contraction length proper (one segment of the packs)
+    // ... logical chunks 0-3 of a staged row are 32 k-values of the h plane, 4-7 the same 32 of the l plane (tokens: segment 1; weights, NP 3: segment 2).
+    // Convolutions: the segments are per PIXEL (Cin = NP x channels) and per TAP of the weight row, so the plane stride is the channel count
+    const int PS = (MODE == MODE_CONV && NP) ? p.Cin / NP : KS;
+    const int xce = NP ? (chunk & 3) * 8 + (chunk >> 2) * PS : chunk * 8;
+    const int wce = NP == 3 ? (chunk & 3) * 8 + (chunk >> 2) * 2 * PS : chunk * 8;
     const bf16_t* wptr[2];
     const bf16_t* xptr[4];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int n = n0 + 16 * wid + 8 * i + (lane >> 3);
-        wptr[i] = p.W + (size_t)(n < p.N ? n : 0) * p.ldw + chunk * 8;      // clamped rows feed only unstored outputs
+        if constexpr (NP == 2) {      // one instruction = 16 rows of 64 bytes: lane l -> row l >> 2, chunk l & 3
+            const int n = n0 + 16 * wid + (lane >> 2);
+            wptr[i] = p.W + (size_t)(n < p.N ? n : 0) * p.ldw + (lane & 3) * 8;
+        } else {
+            const int n = n0 + 16 * wid + 8 * i + (lane >> 3);
+            wptr[i] = p.W + (size_t)(n < p.N ? n : 0) * p.ldw + wce;      // clamped rows feed only unstored outputs
+        }
     }
     int ciy[4], cix[4], cpix[4];      // conv: input y / x of tap (0,0) and the flat pixel index of that position, per staged row
 #pragma unroll
@@ -73,21 +87,22 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
             ciy[i] = cy * p.stride + p.off_y;
             cix[i] = cx * p.stride + p.off_x;
             cpix[i] = (cb * p.Hin + ciy[i]) * p.Win + cix[i];
-            xptr[i] = p.X + chunk * 8;
+            xptr[i] = p.X + xce;
         } else {
             const int m = m0 + r;
-            xptr[i] = p.X + (size_t)(m < p.M ? m : 0) * p.ldx + chunk * 8;
+            xptr[i] = p.X + (size_t)(m < p.M ? m : 0) * p.ldx + xce;
         }
     }
     int tap_y = 0, tap_x = 0, tap_c = 0;      // conv: filter tap and channel offset of the NEXT k-tile to issue (wave-uniform)
+    int tap_k = 0;                            // conv with term sharing: first weight column of that tap (taps x Cin: the walk skips the l / repeated segments)
 
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define ISSUE_TILE(kt_, stage_)                                                                              \
     {                                                                                                        \
-        const int k0_ = (kt_) * BK;                                                                          \
-        unsigned char* ws_ = smem + (stage_) * STAGE_B + wid * 2048;                                         \
+        const int k0_ = (MODE == MODE_CONV && NP) ? tap_k + tap_c : (kt_) * (NP ? 32 : BK);                  \
+        unsigned char* ws_ = smem + (stage_) * STAGE_B + wid * (NP == 2 ? 1024 : 2048);                      \
         unsigned char* xs_ = smem + (stage_) * STAGE_B + W_BYTES + wid * 4096;                               \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                        \
+        _Pragma("unroll") for (int i = 0; i < (NP == 2 ? 1 : 2); ++i)                                        \
             __builtin_amdgcn_global_load_lds(wptr[i] + k0_, (lds_ptr_t)(ws_ + i * 1024), 16, 0, 0);          \
         if constexpr (MODE != MODE_CONV) {                                                                   \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                    \
@@ -100,8 +115,8 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
                 if (!ok_) src_ = reinterpret_cast<const bf16_t*>(g_zero_page_big);                           \
                 __builtin_amdgcn_global_load_lds(src_, (lds_ptr_t)(xs_ + i * 1024), 16, 0, 0);               \
             }                                                                                                \
-            tap_c += BK;                                                                                     \
-            if (tap_c >= p.Cin) { tap_c = 0; if (++tap_x == p.TW) { tap_x = 0; ++tap_y; } }                  \
+            tap_c += NP ? 32 : BK;                                                                           \
+            if (tap_c >= (NP ? PS : p.Cin)) { tap_c = 0; tap_k += p.Cin; if (++tap_x == p.TW) { tap_x = 0; ++tap_y; } } \
         }                                                                                                    \
     }
 
@@ -112,7 +127,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fg = lane >> 4;
-    const int KT = p.K / BK;
+    const int KT = NP ? KS / 32 : p.K / BK;
     // fp32 residual (out = x + ...: attention out-projection, FF w2): this lane's 16 x 16 B of the tile's 128 KiB are fetched FIRST, ahead
     // of the DMA (VMEM returns in order, so the counted waits below see them retire before k-tile 0).  Read in the epilogue, the
     // residual made the write-out a read-modify-write latency tail of every workgroup at once (gemm.hip: 16 k vs 2.3 k cycles).
@@ -143,8 +158,10 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
 
     for (int kt = 0; kt < KT; ++kt) {
         // tile kt has landed once at most the NEXT tile's 6 DMA instructions of this wave are still outstanding
-        if (kt + 1 < KT && !(p.debug & 2)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kt + 1 < KT && !(p.debug & 2)) {
+            if constexpr (NP == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");      // (one weight instruction per wave and step)
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my ds_reads of the previous tile are complete
         __builtin_amdgcn_s_barrier();                          // everybody's DMA of tile kt landed; stage (kt+2)%3 is free
         __builtin_amdgcn_sched_barrier(0);
@@ -152,6 +169,35 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char* ws = smem + (kt % NSTAGE) * STAGE_B;
         const unsigned char* xs = ws + W_BYTES;
+        if constexpr (NP != 0) {      // term sharing: every product of this 32-deep k-block from one staging of its term planes
+            u32x4_t wh[4], wl[4], xh[4], xl[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (NP == 3) {
+                    wh[i] = *reinterpret_cast<const u32x4_t*>(ws + lds_off(wave_n * 64 + i * 16 + fr, fg));
+                    wl[i] = *reinterpret_cast<const u32x4_t*>(ws + lds_off(wave_n * 64 + i * 16 + fr, 4 + fg));
+                } else {
+                    wh[i] = *reinterpret_cast<const u32x4_t*>(ws + (wave_n * 64 + i * 16 + fr) * 64 + fg * 16);
+                }
+                xh[i] = *reinterpret_cast<const u32x4_t*>(xs + lds_off(wave_m * 64 + i * 16 + fr, fg));
+                xl[i] = *reinterpret_cast<const u32x4_t*>(xs + lds_off(wave_m * 64 + i * 16 + fr, 4 + fg));
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = mfma16t<F16>(wh[a], xh[b], acc[a][b]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = mfma16t<F16>(wh[a], xl[b], acc[a][b]);
+            if constexpr (NP == 3) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = mfma16t<F16>(wl[a], xh[b], acc[a][b]);
+            }
+            continue;
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             u32x4_t af[4], bfm[4];
@@ -368,17 +414,17 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
     }
 }
 
-template <int MODE, bool F16 = false>
+template <int MODE, bool F16 = false, int NP = 0>
 int launch_big(const GemmArgs& a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_big_kernel<MODE, F16>)),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_big_kernel<MODE, F16, NP>)),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
         if (e != hipSuccess) return mm_set_hip_error(e, "gemm_big hipFuncSetAttribute");
         attr_set = true;
     }
     const int blocks = a.tiles_m * a.tiles_n;
-    hipLaunchKernelGGL((gemm_big_kernel<MODE, F16>), dim3(blocks), dim3(512), SMEM_B, stream, a);
+    hipLaunchKernelGGL((gemm_big_kernel<MODE, F16, NP>), dim3(blocks), dim3(512), SMEM_B, stream, a);
     return mm_check_launch("gemm_big_kernel");
 }
 
@@ -397,6 +443,12 @@ int mm_gemm_big_launch(GemmArgs a, hipStream_t stream) {
     a.tiles_n = (a.N + BNB - 1) / BNB;
     const int tm = a.mode == MODE_CFG ? 128 : BMB;
     a.tiles_m = (a.M + tm - 1) / tm;
+    if (a.f16 && a.mode == MODE_DENSE && (a.terms == 2 || a.terms == 3) && !(g_mm_debug2 & 2) && !(a.debug & (1 | 2 | 4)) && (a.K % a.terms) == 0 &&
+        ((a.K / a.terms) % 32) == 0 && a.ldx >= a.K && a.ldw >= a.K)      // term sharing (round 5): equal-length term segments, every term plane staged once
+        return a.terms == 3 ? launch_big<MODE_DENSE, true, 3>(a, stream) : launch_big<MODE_DENSE, true, 2>(a, stream);
+    if (a.f16 && a.mode == MODE_CONV && (a.terms == 2 || a.terms == 3) && !(g_mm_debug2 & 2) && !(a.debug & (1 | 2 | 4)) && (a.Cin % a.terms) == 0 &&
+        ((a.Cin / a.terms) % 32) == 0 && a.K == a.Ktrue)      // ... convolutions: segments per pixel / per tap, a 32-channel step inside one tap
+        return a.terms == 3 ? launch_big<MODE_CONV, true, 3>(a, stream) : launch_big<MODE_CONV, true, 2>(a, stream);
     if (a.f16) return a.mode == MODE_CONV ? launch_big<MODE_CONV, true>(a, stream) : launch_big<MODE_DENSE, true>(a, stream);      // (mm_gemm_launch admits dense / conv only)
     if (a.mode == MODE_CFG) return launch_big<MODE_CFG>(a, stream);
     if (a.mode == MODE_CONV) return launch_big<MODE_CONV>(a, stream);

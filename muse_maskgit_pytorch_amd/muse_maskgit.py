@@ -715,7 +715,7 @@ class Transformer(nn.Module):
         # (what mm_generate does; every GEMM kernel of the family accumulates in the same order, so the two agree bit for bit)
         if self.precision in SPLIT_TIERS:
             pk = self._model().packed
-            return ops.gemm_split(ops.cfg_mix(emb_a, emb_b, cond_scale, self.dim, pk['PC']), pk['wl'], pk['PC'], pk['alpha'])
+            return ops.gemm_split(ops.cfg_mix(emb_a, emb_b, cond_scale, self.dim, pk['PC']), pk['wl'], pk['PC'], pk['alpha'], shared=True)
         return ops.gemm(ops.cfg_mix(emb_a, emb_b, cond_scale, self.dim), self._model().packed['wl'], out_f32=True)
 
     # ---- reference surface
@@ -825,7 +825,7 @@ class SelfCritic(nn.Module):
         if self.net.precision == 'f16x2':       # ... as fp16 term products (all three: the head is tiny), with its own power-of-two scale
             PC, sc = ops.MM_SPLIT_F16 | 3, ops.f16_weight_scale([self.to_pred.weight])
             x = ops.split_rows(embeds.reshape(b * n, d).float().contiguous(), PC)
-            out = ops.gemm_split(x, ops.split_pack_weight(self.to_pred.weight, PC, 1, sc), PC, 1.0 / sc)
+            out = ops.gemm_split(x, ops.split_pack_weight(self.to_pred.weight, PC, 1, sc), PC, 1.0 / sc, shared=True)
             return (out + self.to_pred.bias.detach().float()).reshape(b, n, 1)
         w = ops.pad_cols(self.to_pred.weight.detach().to(bf16), 64)                    # [1, D] as a 1x1 conv weight
         x = embeds.reshape(b * n, 1, 1, d).to(bf16).contiguous()

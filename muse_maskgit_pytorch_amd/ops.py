@@ -680,6 +680,7 @@ def products_for_terms(terms):
 # ---- precision tier 'f16x2' (round 4): the same engine on fp16 terms.  x ~ h + l (11 + 11 significand bits), products h.h + l.h (+ h.l): X' = [xh|xl|xh][:P]
 #      against W' = [wh|wh|wl][:P] -- P = 3 for general fp32 weights, 2 when one fp16 term holds every weight.  Operand code: MM_SPLIT_F16 | P.
 MM_SPLIT_F16 = 0x100
+MM_SPLIT_SHARED = 0x200      # mm_gemm_split: the operands are genuine term-segment packs -> every term plane may be staged once (csrc/gemm_terms.hip)
 SPLIT_W_SEGMENTS_F16 = (0, 0, 1)
 
 
@@ -740,15 +741,17 @@ def split_pack_weight(w, products, pad_k=1, scale=1.0):
     return out.reshape(N, products * Kp).contiguous()
 
 
-def gemm_split(xs, ws, products, alpha=1.0, resid=None):
-    """fp32 [M][N] = X' . W'^T over term-segment packs (mm_gemm_split): xs / ws from split_rows / split_pack_weight with the same operand code"""
+def gemm_split(xs, ws, products, alpha=1.0, resid=None, shared=False):
+    """fp32 [M][N] = X' . W'^T over term-segment packs (mm_gemm_split): xs / ws from split_rows / split_pack_weight with the same operand code.
+    shared=True (fp16 terms): the packs are genuine ([xh|xl|xh] / [wh|wh|wl]) -- the term-sharing kernels may read every term plane once (MM_SPLIT_SHARED)"""
     _chk_cuda(xs, ws)
     M, K = xs.shape
     N = ws.shape[0]
     assert ws.shape[1] == K and xs.stride(1) == 1 and ws.stride(1) == 1
     ldc = (N + 3) // 4 * 4 if resid is None else N      # (fp32 rows are written 16 bytes at a time)
     out = torch.empty(M, ldc, dtype=torch.float32, device=xs.device)
-    L.check(L.lib().mm_gemm_split(L.stream(), L.ptr(xs), xs.stride(0), L.ptr(ws), ws.stride(0), M, N, K, int(products), float(alpha), L.ptr(out), ldc,
+    code = int(products) | (MM_SPLIT_SHARED if shared and split_is_f16(products) else 0)
+    L.check(L.lib().mm_gemm_split(L.stream(), L.ptr(xs), xs.stride(0), L.ptr(ws), ws.stride(0), M, N, K, code, float(alpha), L.ptr(out), ldc,
                                   L.ptr(resid)), 'mm_gemm_split')
     return out[:, :N]
 

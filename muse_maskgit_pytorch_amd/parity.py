@@ -230,9 +230,10 @@ def conv_x3(x, w_taps, cout, th, tw, stride=1, off=(0, 0), out_hw=None, os_=1, p
     if out_nchw:
         assert resid is None
     if ops.split_is_f16(code):
-        L.check(L.lib().mm_conv2d_nhwc_f16(L.stream(), L.ptr(xs), B, H, W, P * Cin, L.ptr(wp), cout, th, tw, stride, off[0], off[1], Hv, Wv, os_,
-                                           parity[0], parity[1], Hout, Wout, L.ptr(bias), int(act), L.ptr(resid), L.ptr(out), 1 if out_nchw else 2,
-                                           1.0 / _X3['scale']), 'mm_conv2d_nhwc_f16')
+        # (round 5) the packs are genuine term segments per pixel / per tap: the 256 x 128 kernel may stage every term plane once (MM_SPLIT_SHARED)
+        L.check(L.lib().mm_conv2d_nhwc_terms(L.stream(), L.ptr(xs), B, H, W, P * Cin, L.ptr(wp), cout, th, tw, stride, off[0], off[1], Hv, Wv, os_,
+                                             parity[0], parity[1], Hout, Wout, L.ptr(bias), int(act), L.ptr(resid), L.ptr(out), 1 if out_nchw else 2,
+                                             1.0 / _X3['scale'], int(code) | ops.MM_SPLIT_SHARED), 'mm_conv2d_nhwc_terms')
         return out
     L.check(L.lib().mm_conv2d_nhwc(L.stream(), L.ptr(xs), B, H, W, P * Cin, L.ptr(wp), cout, th, tw, stride, off[0], off[1], Hv, Wv, os_,
                                    parity[0], parity[1], Hout, Wout, L.ptr(bias), int(act), L.ptr(resid), L.ptr(out), 1 if out_nchw else 2), 'mm_conv2d_nhwc')

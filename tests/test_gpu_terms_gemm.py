@@ -40,10 +40,10 @@ def test_term_sharing_gemm_against_fp64_and_the_concatenated_kernel(M, N, K, wki
     x, w, sc, code = _operands(M, N, K, wkind, M + N + K)
     xs, ws = ops.split_rows(x.to(DEV), code), ops.split_pack_weight(w.to(DEV), code, 64, sc)
     ref = (x.double().to(DEV) @ w.double().to(DEV).t())
-    got = ops.gemm_split(xs, ws, code, 1.0 / sc).double()
+    got = ops.gemm_split(xs, ws, code, 1.0 / sc, shared=True).double()
     L.lib().mm_debug_set2(2)
     try:
-        old = ops.gemm_split(xs, ws, code, 1.0 / sc).double()
+        old = ops.gemm_split(xs, ws, code, 1.0 / sc, shared=True).double()
     finally:
         L.lib().mm_debug_set2(0)
     scale = ref.abs().max().item()
@@ -59,7 +59,7 @@ def test_term_sharing_gemm_small_and_ragged_shapes(force_terms, M, N, K, wkind):
     bf16-representable ones multiples of 128: others fall back to the concatenated kernel and still have to be right)"""
     x, w, sc, code = _operands(M, N, K, wkind, 7 * M + N + K)
     ref = x.double() @ w.double().t()
-    got = ops.gemm_split(ops.split_rows(x.to(DEV), code), ops.split_pack_weight(w.to(DEV), code, 64, sc), code, 1.0 / sc).double().cpu()
+    got = ops.gemm_split(ops.split_rows(x.to(DEV), code), ops.split_pack_weight(w.to(DEV), code, 64, sc), code, 1.0 / sc, shared=True).double().cpu()
     scale = ref.abs().max().item()
     e = (got - ref).abs().max().item()
     print(f'[terms] forced gemm {M}x{N}x{K} {wkind}: max err {e:.3g}; |ref| {scale:.3g}')
@@ -94,3 +94,94 @@ def test_w1_geglu_term_split_epilogue(M, F, D, wkind):
     assert P == 2 or torch.equal(seg[:, 0], seg[:, 2]), 'segment 2 repeats the high term'
     print(f'[terms] w1 + GEGLU {M}x{2 * Fp}x{D} {wkind} ({P} products): max err {e:.3g} on |ref| {scale:.3g}; row sums {e1:.3g}, sums of squares {e2:.3g} (relative)')
     assert e <= 4e-6 * scale and e1 <= 1e-5 and e2 <= 1e-5
+
+
+@pytest.mark.parametrize('M,N,K', [(16384, 512, 512), (16384, 512, 1408), (8192, 512, 512), (8200, 512, 512), (300, 200, 64)])
+@pytest.mark.parametrize('wkind', ['fp32', 'bf16'])
+def test_term_sharing_in_the_residual_and_narrow_kernels(M, N, K, wkind):
+    """the fp32-residual projections (attention out, FF w2: 256 x 128 kernel) and the narrow ones (cross-attention q / out: 128 x 128 and 64-token tiles) with the
+    same term sharing in their k-loops (gemm_big.hip / gemm.hip NP = 2, 3), against fp64 and the concatenated-depth form (mm_debug_set2(2))"""
+    x, w, sc, code = _operands(M, N, K, wkind, 3 * M + N + K)
+    g = torch.Generator().manual_seed(M + 1)
+    resid = torch.randn(M, N, generator=g).to(DEV)
+    xs, ws = ops.split_rows(x.to(DEV), code), ops.split_pack_weight(w.to(DEV), code, 64, sc)
+    ref = x.double().to(DEV) @ w.double().to(DEV).t() + resid.double()
+    got = ops.gemm_split(xs, ws, code, 1.0 / sc, resid=resid, shared=True).double()
+    L.lib().mm_debug_set2(2)
+    try:
+        old = ops.gemm_split(xs, ws, code, 1.0 / sc, resid=resid, shared=True).double()
+    finally:
+        L.lib().mm_debug_set2(0)
+    scale = ref.abs().max().item()
+    e, eo, d = (got - ref).abs().max().item(), (old - ref).abs().max().item(), (got - old).abs().max().item()
+    print(f'[terms] gemm + residual {M}x{N}x{K} {wkind}: max err {e:.3g} (concatenated {eo:.3g}), between the two {d:.3g}; |ref| {scale:.3g}')
+    assert d > 0., 'term sharing was not dispatched'
+    assert e <= 4e-6 * scale and e <= 2 * eo + 1e-7 * scale
+
+
+@pytest.mark.parametrize('bf16_weights', [False, True], ids=['fp32w', 'bf16w'])
+def test_tier_generate_at_bench_size_fused_logits_kernel_against_the_logits_path(bf16_weights):
+    """'f16x2' mm_generate at B = 32 (the rows of the bench: every GEMM of the loop on its term-sharing form by itself).  The fused logits kernel
+    (gemm_wide_fused_kernel<F16, NP>: emission from the accumulators) and the logits path (gemm_terms_kernel + sample_kernel) run the same MFMA sequence per
+    logit and combine the same tile statistics in the same order: ids AND confidences bit for bit at every step -- which ties the B = 32 fused path to the
+    path tests/test_gpu_base_size.py holds to the reference at B = 2."""
+    import bench
+    mg, _ = bench.build_models(DEV)
+    tr = mg.transformer
+    with torch.no_grad():
+        if bf16_weights:
+            for q in mg.parameters():
+                q.copy_(q.bfloat16().float())
+        tr.to_logits.weight.mul_(8.)
+    mg.set_precision('f16x2')
+    try:
+        assert tr.split_products() == (2 if bf16_weights else 3)
+        te = bench.synth_text(32, 32, 512).to(DEV)
+        ta, tb = {}, {}
+        a = mg.generate([''] * 32, timesteps=18, cond_scale=3, text_embeds=te, seed=11, return_ids=True, trace=ta)
+        assert mg.fused_sampling_fallbacks == 0 and tr._model().fused_ready
+        b = mg.generate([''] * 32, timesteps=18, cond_scale=3, text_embeds=te, seed=11, return_ids=True, fused_sampling=False, trace=tb)
+        for s_ in range(18):
+            assert torch.equal(ta['masked_ids'][s_], tb['masked_ids'][s_]) and torch.equal(ta['ids'][s_], tb['ids'][s_]), f'step {s_}'
+            assert torch.equal(ta['scores'][s_], tb['scores'][s_]), f'step {s_}: confidences differ by {(ta["scores"][s_] - tb["scores"][s_]).abs().max().item():.3g}'
+        assert torch.equal(a, b)
+        L.lib().mm_debug_set2(2)      # the concatenated-depth kernels of rounds 4-5: same terms, another summation order -> the same ids on these well-separated logits
+        try:
+            c = mg.generate([''] * 32, timesteps=18, cond_scale=3, text_embeds=te, seed=11, return_ids=True)
+        finally:
+            L.lib().mm_debug_set2(0)
+        agree = (a == c).float().mean().item()
+        print(f'[terms] f16x2 generate B = 32 ({tr.split_products()} products): term-sharing vs concatenated kernels: {100 * agree:.3f} % of the final ids equal')
+        assert agree >= 0.95      # (a near-tie flipped by the last-bit difference sends one image down another trajectory)
+    finally:
+        mg.set_precision('bf16')
+
+
+@pytest.mark.parametrize('B,H,C,Cout,wkind', [(2, 128, 256, 256, 'fp32'), (2, 128, 256, 256, 'bf16'), (1, 256, 128, 128, 'fp32'), (8, 64, 512, 256, 'bf16')])
+def test_term_sharing_convolution(B, H, C, Cout, wkind):
+    """3 x 3 convolution on fp16 term segments per pixel (the tier's VAE decoder, parity.conv_x3): the 256 x 128 implicit-GEMM kernel with every term plane of a
+    32-channel step staged once (mm_conv2d_nhwc_terms + MM_SPLIT_SHARED) against the concatenated-depth form and torch's fp64 convolution"""
+    from muse_maskgit_pytorch_amd import parity as P32
+    g = torch.Generator().manual_seed(B + H + C)
+    x = torch.randn(B, H, H, C, generator=g).to(DEV)
+    w = (torch.randn(Cout, C, 3, 3, generator=g) / (9 * C) ** 0.5)
+    if wkind == 'bf16':
+        w = w.bfloat16().float()
+    w = w.to(DEV)
+    sc = ops.f16_weight_scale([w])
+    code = ops.MM_SPLIT_F16 | (1 + ops.weight_terms_f16(w, sc))
+    P = ops.split_count(code)
+    xs = ops.split_rows(x.reshape(-1, C), code).reshape(B, H, H, P * C)
+    wp = P32._pack_x3(P32._taps_conv(w), code, sc)
+    outs = []
+    for shared in (ops.MM_SPLIT_SHARED, 0):
+        out = torch.empty(B, H, H, Cout, dtype=torch.float32, device=DEV)
+        L.check(L.lib().mm_conv2d_nhwc_terms(L.stream(), L.ptr(xs), B, H, H, P * C, L.ptr(wp), Cout, 3, 3, 1, -1, -1, H, H, 1, 0, 0, H, H, None, 0, None, L.ptr(out), 2,
+                                             1.0 / sc, code | shared), 'mm_conv2d_nhwc_terms')
+        outs.append(out.double())
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)
+    scale = ref.abs().max().item()
+    e, eo, d = (outs[0] - ref).abs().max().item(), (outs[1] - ref).abs().max().item(), (outs[0] - outs[1]).abs().max().item()
+    print(f'[terms] conv 3x3 {B}x{H}x{H}x{C} -> {Cout} {wkind} ({P} products): max err {e:.3g} (concatenated {eo:.3g}), between the two {d:.3g}; |ref| {scale:.3g}')
+    assert d > 0., 'term sharing was not dispatched'
+    assert e <= 4e-6 * scale and e <= 2 * eo + 1e-7 * scale
