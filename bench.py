@@ -271,8 +271,10 @@ def reference_flops_per_generate(tr, B, n, m_text, nc, timesteps):
 def parity_tier_leg(mg, tr, step, args, B, T, n, nc, image_size, counts, lib, bf16_s_per_step):
     """The same step through precision 'f16x2' (round 4; csrc/split.hip, common.h split2_f16): every GEMM / convolution operand as TWO fp16 terms of
     its fp32 value (22 significand bits), multiplied as term products on the fp16 MFMA (same rate as the bf16 one) with fp32 accumulation -- THREE
-    products for general fp32 weights, TWO for a bf16-representable checkpoint --, fp32 everywhere else, attention on the fp32 MFMA, the VAE decode's
-    convolutions the same way.  The tier that holds logits within 1e-3 of the reference's fp32 run and reproduces its ids bit for bit on BOTH kinds of
+    products for general fp32 weights, TWO for a bf16-representable checkpoint --, fp32 everywhere else, self-attention as fp16 term products too, the VAE
+    decode's convolutions the same way.  Round 5: the products of a k-block SHARE operands (xh.wh, xl.wh, xh.wl), so every GEMM of the tier stages each term plane
+    once and runs all products from that staging (csrc/gemm_terms.hip and the NP forms of the other kernels) instead of one GEMM of depth 3 K over duplicated
+    segments; FF w1 carries GEGLU + the term split + the LayerNorm(inner) statistics in its epilogue.  The tier that holds logits within 1e-3 of the reference's fp32 run and reproduces its ids bit for bit on BOTH kinds of
     checkpoint (tests/test_gpu_base_size.py, fixtures base_c2.pt and base_c2_fp32.pt).  Timed first on the raw fp32 initialisation of the main line
     (`fp32_checkpoint`: what the reference's own constructors produce), then on the same parameters rounded to bf16 -- the checkpoint the bf16
     engine effectively multiplies by.  `bf16x3` is round 3's tier (three bf16 terms per value, 6 / 3 products) on the same two checkpoints."""
@@ -328,7 +330,7 @@ def parity_tier_leg(mg, tr, step, args, B, T, n, nc, image_size, counts, lib, bf
             'tolerance': 'logits <= 1e-3 absolute (measured 4e-6) and ids bit-exact at every decode step against the reference fp32 run at this size, on a '
                          'bf16-representable AND on a general fp32 checkpoint (tests/test_gpu_base_size.py, precision f16x2, fixtures base_c2.pt / base_c2_fp32.pt); '
                          'VAE decode with its convolutions as fp16 term products on the fp16 MFMA',
-            'roofline': {'kernel': 'gemm_wide_fused_kernel<F16> on K = products x dim (term products of to_logits on the guidance-mixed embeddings)', 'bound': 'mfma',
+            'roofline': {'kernel': 'gemm_wide_fused_kernel<F16, NP> (term products of to_logits on the guidance-mixed embeddings, every term plane staged once per 32-deep k-block)', 'bound': 'mfma',
                          'achieved': g_flops / (g_ms * 1e-3) / 1e12 if g_ms else None, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': (g_flops / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if g_ms else None,
                          'flops_kind': 'executed fp16 MFMA flops (term products x 2 R V D of the one mixed pass; same peak as bf16)',

@@ -226,7 +226,7 @@ int k_attention_f32(hipStream_t s, const AttnF32Args& a) {
         (((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v) & (a.io_bf16 ? 7 : 15)))
         return mm_set_error(MM_ERR_ALIGN, "attention_f32: q / k / v rows must be aligned to 4 elements");
     if (a.out && ((a.o_sn % 4) || (a.o_sh % 4) || (a.o_sb % 4) || (((uintptr_t)a.out) & (a.io_bf16 ? 7 : 15)))) return mm_set_error(MM_ERR_ALIGN, "attention_f32: output rows must be aligned to 4 elements");
-    if (a.out_split && (a.P != 3 && a.P != 5 && a.P != 6 && a.P != (MM_SPLIT_F16_BIT | 2) && a.P != (MM_SPLIT_F16_BIT | 3)))
+    if (a.out_split && (a.P != 3 && a.P != 5 && a.P != 6 && a.P != (MM_SPLIT_F16_BIT | 2) && a.P != (MM_SPLIT_F16_BIT | 3) && a.P != (MM_SPLIT_NODUP_BIT | MM_SPLIT_F16_BIT | 3)))
         return mm_set_error(MM_ERR_SHAPE, "attention_f32: products must be 3, 5, 6 or MM_SPLIT_F16 | 2, 3");
     if (a.normalize && (!a.q_scale || !a.k_scale)) return mm_set_error(MM_ERR_SHAPE, "attention_f32: q_scale / k_scale required with normalize");
     if ((a.null_k == nullptr) != (a.null_v == nullptr)) return mm_set_error(MM_ERR_SHAPE, "attention_f32: null_k and null_v go together");

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         // ---- O / l -> fp16 terms, transposed through LDS per wave (4 queries = one accumulator register index r per pass) so that a lane stores 16 B of one output
         //      row per segment: segments [h | l | h][:P] of the output projection's operand (common.h store_split4)
-        const int nseg = split_count(p.P);
+        const int nseg = (p.P & MM_SPLIT_NODUP_BIT) ? 2 : split_count(p.P);      // (NODUP: the repeated h segment is not written -- its readers stage the h plane once)
         if (p.out) {      // (operator-level entry mm_attend_terms: the fp32 result itself, same staging area: 4 queries x 256 B)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

@@ -395,6 +395,9 @@ __device__ __forceinline__ int seg_term(int s) { return s < 3 ? s : (s < 5 ? s -
 // against W' = [wh | wh | wl] -- THREE products for general fp32 weights where the bf16 split needs six, TWO ([xh | xl] . [wh | wh]) when every
 // weight is a single fp16 term (any bf16-representable checkpoint).  Operand codes: products | MM_SPLIT_F16 (muse_hip.h).
 #define MM_SPLIT_F16_BIT 0x100
+// Producer-side flag on an operand code (round 5, internal): the repeated segment ([h | l | h]: segment 2) is NOT written -- every consumer of the buffer runs a
+// term-sharing k-loop (gemm_terms.hip and the NP forms), which stages the h plane once and never reads the repeat.  Row stride and segment offsets unchanged.
+#define MM_SPLIT_NODUP_BIT 0x400
 __device__ __forceinline__ uint16_t f32_to_f16_bits(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }      // round-to-nearest-even
 __device__ __forceinline__ float f16_bits_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
 // Range guard: both terms saturate at the largest finite fp16 (65504) instead of overflowing to infinity -- the pair then still represents |x| up to
@@ -416,7 +419,7 @@ __device__ __forceinline__ void store_split4(bf16_t* orow, int K, int P, int col
         const uint2 hv = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
         *reinterpret_cast<uint2*>(orow + col) = hv;
         *reinterpret_cast<uint2*>(orow + (long)K + col) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
-        if (split_count(P) > 2) *reinterpret_cast<uint2*>(orow + 2l * K + col) = hv;
+        if (split_count(P) > 2 && !(P & MM_SPLIT_NODUP_BIT)) *reinterpret_cast<uint2*>(orow + 2l * K + col) = hv;
         return;
     }
     float t[3][4];

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(512) void gemm_terms_kernel(const GemmArgs p) {
             static_assert(EPI == 0 || NFW == 4, "the GEGLU epilogue pairs weight fragments (a, a + 2)");
             bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
             const int Fp = p.N >> 1;
-            const int code = MM_SPLIT_F16_BIT | NP;
+            const int code = MM_SPLIT_F16_BIT | NP | (p.terms_nodup ? MM_SPLIT_NODUP_BIT : 0);
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
                 const int m = m0 + wm * 128 + b * 16 + fr;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(512) void gemm_terms_kernel(const GemmArgs p) {
                     if (fg == 0 && ok) *reinterpret_cast<float2*>(p.ln_part + ((size_t)m * p.ln_np + cur_n * 4 + wn) * 2) = make_float2(s1, s2);
                 }
             }
-            nstore = 8 * 2 * NP + (p.ln_part ? 8 : 0);
+            nstore = 8 * 2 * (p.terms_nodup ? 2 : NP) + (p.ln_part ? 8 : 0);
         }
         pending = full ? nstore : 0;
         vb += G;

@@ -187,6 +187,13 @@ int gemm_dense(const mm_transformer* t, hipStream_t s, const bf16_t* X, int ldx,
     return mm_gemm_launch(a, s);
 }
 
+// operand code of the block-internal term-segment buffers (b.xn, b.att, b.a) of an 'f16x2' model with three products: their only readers are GEMMs that state the
+// term count (gemm_dense: GemmArgs::terms), i.e. term-sharing k-loops that stage the h plane once -- so the producers skip the repeated h segment (a third of
+// their writes; common.h MM_SPLIT_NODUP_BIT).  Off with the term-sharing kernels (mm_debug_set2 bit 2) or a k-loop ablation bit.
+int pc_scratch(const mm_transformer* t) {
+    return (t->F16 && t->P == 3 && !(g_mm_debug2 & 2) && !(g_mm_debug & 7)) ? (t->PC | MM_SPLIT_NODUP_BIT) : t->PC;
+}
+
 struct Bufs {       // activation scratch for `rows` token rows
     float* x;       // [rows][D] residual stream fp32
     bf16_t* xn;     // [rows][D]
@@ -280,7 +287,7 @@ int ff_block(const mm_transformer* t, hipStream_t s, const mm_ff_weights& w, con
     const int D = t->d.dim, F = t->d.ff_inner, Fp = t->Fp;
     if (t->P) {      // precision tier: LN -> P segments -> w1 (fp32 out, plain [x | gate] halves) -> GEGLU + LN(inner) -> P segments -> w2 + residual
         const int P = t->P;
-        RC(k_layernorm_split(s, addvec ? dst : src, D, rows, D, w.ln1_gamma, w.ln1_beta, nullptr, t->PC, b.xn, nullptr, addvec, add_from, addvec ? dst : nullptr));
+        RC(k_layernorm_split(s, addvec ? dst : src, D, rows, D, w.ln1_gamma, w.ln1_beta, nullptr, pc_scratch(t), b.xn, nullptr, addvec, add_from, addvec ? dst : nullptr));
         if (t->F16 && w.w1_terms_geglu && w.w2_folded && w.ln2_c1 && w.ln2_c2 && !(g_mm_debug & (1 << 24))) {
             // round 5: w1 on the term-sharing kernel with GEGLU + the term split of its output + the LayerNorm(inner) partial sums in the epilogue
             // (gemm_terms.hip), LayerNorm(inner) folded into w2 as in the bf16 engine (mmp.py:85-88): the fp32 [rows][2 Fp] intermediate and the
@@ -290,6 +297,7 @@ int ff_block(const mm_transformer* t, hipStream_t s, const mm_ff_weights& w, con
             a1.mode = MODE_DENSE; a1.epi = EPI_GEGLU; a1.f16 = 1; a1.alpha = t->alpha; a1.terms = P;
             a1.W = (const bf16_t*)w.w1_terms_geglu; a1.N = 2 * Fp; a1.ldw = P * D; a1.K = P * D; a1.M = rows; a1.X = b.xn; a1.ldx = P * D;
             a1.out = b.a; a1.ldc = (long)P * Fp; a1.out_kind = OUT_BF16; a1.ln_part = b.lnp; a1.ln_np = 2 * Fp / 64;
+            a1.terms_nodup = (pc_scratch(t) & MM_SPLIT_NODUP_BIT) ? 1 : 0;
             if (mm_gemm_terms_eligible(a1)) {
                 RC(mm_gemm_launch(a1, s));
                 GemmArgs a2;
@@ -305,7 +313,7 @@ int ff_block(const mm_transformer* t, hipStream_t s, const mm_ff_weights& w, con
         }
         float* hf = reinterpret_cast<float*>(b.h);
         RC(gemm_dense(t, s, b.xn, P * D, (const bf16_t*)w.w1, P * D, rows, 2 * Fp, P * D, hf, 2 * Fp, OUT_F32, nullptr));
-        RC(k_geglu_ln_split(s, hf, 2 * Fp, rows, F, Fp, w.ln2_gamma, w.ln2_beta, t->PC, b.a));
+        RC(k_geglu_ln_split(s, hf, 2 * Fp, rows, F, Fp, w.ln2_gamma, w.ln2_beta, pc_scratch(t), b.a));
         RC(gemm_dense(t, s, b.a, P * Fp, (const bf16_t*)w.w2, P * Fp, rows, D, P * Fp, dst, D, OUT_F32, dst));
         TR(dst, (size_t)rows * D * 4);
         return MM_OK;
@@ -369,7 +377,7 @@ int self_attn_core(const mm_transformer* t, hipStream_t s, const mm_attn_weights
     const int rows = seqs * n;
     if (t->P) {      // precision tier: q|k|v stay fp32, the attention runs on the fp32 MFMA and writes its output as P segments
         const int P = t->P;
-        RC(k_layernorm_split(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, t->PC, b.xn, nullptr, nullptr, 0, nullptr));
+        RC(k_layernorm_split(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, pc_scratch(t), b.xn, nullptr, nullptr, 0, nullptr));
         const bf16_t* wq = (const bf16_t*)w.w_q;
         const bf16_t* wkv = (const bf16_t*)w.w_kv;
         float* qkv = reinterpret_cast<float*>(b.qkv);
@@ -384,7 +392,7 @@ int self_attn_core(const mm_transformer* t, hipStream_t s, const mm_attn_weights
         a.q = qkv; a.q_sb = (long)n * 3 * I; a.q_sh = dh; a.q_sn = 3 * I;
         a.k = qkv + I; a.k_sb = a.q_sb; a.k_sh = dh; a.k_sn = 3 * I;
         a.v = qkv + 2 * I; a.v_sb = a.q_sb; a.v_sh = dh; a.v_sn = 3 * I;
-        a.out_split = b.att; a.os_sb = (long)n * P * I; a.os_sn = (long)P * I; a.os_seg = I; a.P = t->PC;
+        a.out_split = b.att; a.os_sb = (long)n * P * I; a.os_sn = (long)P * I; a.os_seg = I; a.P = pc_scratch(t);
         a.B = seqs; a.H = H; a.nq = n; a.nk = n;
         a.normalize = 1; a.q_scale = w.q_scale; a.k_scale = w.k_scale; a.null_k = w.null_k; a.null_v = w.null_v;
         a.scale = 8.f; a.dh = dh;
@@ -488,7 +496,7 @@ int cross_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weigh
     }
     if (t->P) {      // precision tier: ckv is fp32 [kv_seqs*m][2I]
         const int P = t->P;
-        RC(k_layernorm_split(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, t->PC, b.xn, nullptr, nullptr, 0, nullptr));
+        RC(k_layernorm_split(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, pc_scratch(t), b.xn, nullptr, nullptr, 0, nullptr));
         float* q = reinterpret_cast<float*>(b.qkv);
         RC(gemm_dense(t, s, b.xn, P * D, (const bf16_t*)w.w_q, P * D, rows, I, P * D, q, I, OUT_F32, nullptr));
         const float* kv = reinterpret_cast<const float*>(ckv);
@@ -497,7 +505,7 @@ int cross_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weigh
         a.q = q; a.q_sb = (long)n * I; a.q_sh = dh; a.q_sn = I;
         a.k = kv; a.k_sb = (long)m * 2 * I; a.k_sh = dh; a.k_sn = 2 * I;
         a.v = kv + I; a.v_sb = a.k_sb; a.v_sh = dh; a.v_sn = 2 * I;
-        a.out_split = b.att; a.os_sb = (long)n * P * I; a.os_sn = (long)P * I; a.os_seg = I; a.P = t->PC;
+        a.out_split = b.att; a.os_sb = (long)n * P * I; a.os_sn = (long)P * I; a.os_seg = I; a.P = pc_scratch(t);
         a.B = seqs; a.H = H; a.nq = n; a.nk = m;
         a.key_mask = key_mask; a.km_sb = m;
         a.normalize = 1; a.q_scale = w.q_scale; a.k_scale = w.k_scale; a.null_k = w.null_k; a.null_v = w.null_v;

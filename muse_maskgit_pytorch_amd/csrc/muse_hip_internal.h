@@ -51,6 +51,7 @@ struct GemmArgs {
     // of depth K).  With EPI_GEGLU (terms != 0 only): W rows GEGLU-interleaved, `out` = the term-segment pack [hh | hl | hh][:terms] of gate * gelu(x)
     // (16-bit container, ldc elements per row, segment length N / 2), ln_part = (sum, sum of squares) per row and 32 output columns (ln_np = N / 64).
     int terms;
+    int terms_nodup;      // EPI_GEGLU on term operands: do not write the repeated h segment of the output pack (its only reader, FF w2, runs a term-sharing k-loop)
     // LayerNorm(dim) folded into the GEMMs around it (round 4, bf16 engine; model.hip):
     //   PRODUCER -- the fp32-residual epilogue of the 128x128 / 256x128 kernels (out = resid + acc): with xb_out != NULL it also writes the new residual
     //     row as bf16 (xb_out [M][ldxb]) and, per row and 64 columns, the (sum, sum of squares) of the fp32 values to st_part[(row * st_np + i) * 2 ..],

@@ -230,7 +230,10 @@ __global__ __launch_bounds__(256) void cfg_mix_kernel(const bf16_t* __restrict__
     }
 }
 
-inline bool bad_p(int P) { return P != 3 && P != 5 && P != 6 && P != (MM_SPLIT_F16_BIT | 2) && P != (MM_SPLIT_F16_BIT | 3); }      // bf16 terms: 3 / 5 / 6; fp16 terms: MM_SPLIT_F16 | 2 / 3
+inline bool bad_p(int P) {      // (fp16 terms: the producer-side MM_SPLIT_NODUP_BIT may ride on the code)
+    if (P & MM_SPLIT_NODUP_BIT) return P != (MM_SPLIT_NODUP_BIT | MM_SPLIT_F16_BIT | 3);
+    return P != 3 && P != 5 && P != 6 && P != (MM_SPLIT_F16_BIT | 2) && P != (MM_SPLIT_F16_BIT | 3);
+}      // bf16 terms: 3 / 5 / 6; fp16 terms: MM_SPLIT_F16 | 2 / 3
 
 }  // namespace
 
