@@ -63,7 +63,7 @@ struct GemmArgs {
     const float* in_part; int in_np; int in_F; const float* in_c1; const float* in_c2;
 };
 extern int g_mm_debug;
-extern int g_mm_debug2;      // mm_debug_set2 (round 5): 1 = gemm_terms.hip whatever the tile count (tests: small batches through the production kernels), 2 = gemm_terms.hip off (A/B)
+extern int g_mm_debug2;      // mm_debug_set2 (round 5): 1 = gemm_terms.hip whatever the tile count (tests: small batches through the production kernels), 2 = gemm_terms.hip and every term-sharing k-loop off (A/B)
 
 int mm_gemm_launch(GemmArgs a, hipStream_t stream);
 bool mm_gemm_big_eligible(const GemmArgs& a);      // gemm_big.hip: 256x128 tile, 3-stage counted-vmcnt pipeline

@@ -45,11 +45,15 @@ def main():
     ap.add_argument('--alloc-churn', action='store_true', help='allocate / free other tensors and run a second model between passes')
     ap.add_argument('--capture', action='store_true', help='keep x after every ff.w2 and report exactly which values differ at the first bad operator')
     ap.add_argument('--configs', default='0,8,4096,32768,0x1000000,0x1000008')
+    ap.add_argument('--precision', default='bf16', help="'f16x2': the screen on the precision tier (round 5: term-sharing kernels, csrc/gemm_terms.hip; use --configs 0)")
     args = ap.parse_args()
     dev = 'cuda'
     lib = _lib.lib()
     mg, _ = bench.build_models(dev)
     tr = mg.transformer
+    if args.precision != 'bf16':
+        mg.set_precision(args.precision)
+        print(f'[stress] precision {args.precision}: {tr.split_products()} term products')
     depth = tr.transformer_blocks.cfg['depth']
     B, n = args.batch, 256
     te = bench.synth_text(B, 32, 512).to(dev)
