@@ -38,7 +38,7 @@ __device__ __forceinline__ void wait_vmcnt_t(int n) {      // wave-uniform n; ab
     }
 }
 
-template <int NP, int NFW, int EPI>
+template <int NP, int NFW, int EPI, int DPOS = 1>      // DPOS: token block behind which the next step's requests go out (-1: right behind the barrier)
 __global__ __launch_bounds__(512) void gemm_terms_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TN = 64 * NFW, W_B = TN * ROWB;
@@ -112,6 +112,22 @@ __global__ __launch_bounds__(512) void gemm_terms_kernel(const GemmArgs p) {
             const unsigned char* ws = smem + 2 * X_B + (NP == 3 ? st : ((kt >> 1) & 1)) * W_B + (wn * 16 * NFW) * ROWB;
             const int wc = NP == 3 ? 0 : st * 4;      // first chunk of this step's wh fragment in the weight row
             u32x4_t wh[NFW], wl[NFW], xh[2], xl[2];
+#define TERMS_ISSUE_NEXT()                                                                                                             \
+            {                                                                                                                          \
+                if (kt + 1 < KT) {                                                                                                     \
+                    ISSUE_X(kt + 1, st ^ 1);                                                                                           \
+                    if constexpr (NP == 3) {                                                                                           \
+                        ISSUE_W((kt + 1) * 64, st ^ 1);                                                                                \
+                    } else {                                                                                                           \
+                        if (st == 0 && kt + 2 < KT) ISSUE_W(((kt >> 1) + 1) * 128, ((kt >> 1) + 1) & 1);                               \
+                    }                                                                                                                  \
+                } else if (vb + G < total) {                                                                                           \
+                    TILE_SETUP(vb + G);                                                                                                \
+                    ISSUE_X(0, 0);                                                                                                     \
+                    ISSUE_W(0, 0);                                                                                                     \
+                }                                                                                                                      \
+            }
+            if constexpr (DPOS < 0) TERMS_ISSUE_NEXT();
 #pragma unroll
             for (int a = 0; a < NFW; ++a) {
                 wh[a] = *reinterpret_cast<const u32x4_t*>(ws + sw128(a * 16 + fr, wc + fg));
@@ -134,20 +150,7 @@ __global__ __launch_bounds__(512) void gemm_terms_kernel(const GemmArgs p) {
 #pragma unroll
                     for (int a = 0; a < NFW; ++a) acc[a][b] = mfma16t<true>(wl[a], xh[b & 1], acc[a][b]);
                 }
-                if (b == 1) {      // the requests go out behind the first blocks (gemm_wide.hip: right behind the barrier they delay both waves' first MFMAs)
-                    if (kt + 1 < KT) {
-                        ISSUE_X(kt + 1, st ^ 1);
-                        if constexpr (NP == 3) {
-                            ISSUE_W((kt + 1) * 64, st ^ 1);
-                        } else {
-                            if (st == 0 && kt + 2 < KT) ISSUE_W(((kt >> 1) + 1) * 128, ((kt >> 1) + 1) & 1);
-                        }
-                    } else if (vb + G < total) {
-                        TILE_SETUP(vb + G);
-                        ISSUE_X(0, 0);
-                        ISSUE_W(0, 0);
-                    }
-                }
+                if (b == DPOS) TERMS_ISSUE_NEXT();      // the requests go out behind the first blocks (gemm_wide.hip: right behind the barrier they delay both waves' first MFMAs)
             }
         }
         const float al = p.alpha;
@@ -205,25 +208,30 @@ __global__ __launch_bounds__(512) void gemm_terms_kernel(const GemmArgs p) {
         if (vb >= total) break;
         // (no barrier here: the epilogue touches no LDS, and the next request into a stage is issued behind the next barrier)
     }
+#undef TERMS_ISSUE_NEXT
 #undef ISSUE_X
 #undef ISSUE_W
 #undef TILE_SETUP
 }
 
-template <int NP, int NFW, int EPI>
-int launch_terms(GemmArgs a, hipStream_t stream) {
+template <int NP, int NFW, int EPI, int DPOS>
+int launch_terms_at(GemmArgs a, hipStream_t stream) {
     constexpr int SM = 2 * X_B + 2 * 64 * NFW * ROWB;
     static bool attr_set = false;
     if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_terms_kernel<NP, NFW, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, SM);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_terms_kernel<NP, NFW, EPI, DPOS>), hipFuncAttributeMaxDynamicSharedMemorySize, SM);
         if (e != hipSuccess) return mm_set_hip_error(e, "gemm_terms hipFuncSetAttribute");
         attr_set = true;
     }
     a.tiles_m = (a.M + TM - 1) / TM;
     a.tiles_n = a.N / (64 * NFW);
     const int total = a.tiles_m * a.tiles_n;
-    hipLaunchKernelGGL((gemm_terms_kernel<NP, NFW, EPI>), dim3(total < 256 ? total : 256), dim3(512), SM, stream, a);
+    hipLaunchKernelGGL((gemm_terms_kernel<NP, NFW, EPI, DPOS>), dim3(total < 256 ? total : 256), dim3(512), SM, stream, a);
     return mm_check_launch("gemm_terms_kernel");
+}
+template <int NP, int NFW, int EPI>
+int launch_terms(GemmArgs a, hipStream_t stream) {
+    return launch_terms_at<NP, NFW, EPI, 1>(a, stream);
 }
 
 // weight-tile height (in 64-row units) whose tile count fills the last round of CUs best: 4 (256 rows), or 3 (192 rows, plain epilogue only) when N is no
