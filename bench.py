@@ -309,6 +309,11 @@ def parity_tier_leg(mg, tr, step, args, B, T, n, nc, image_size, counts, lib, bf
         mg.set_precision('f16x2')
         sec3, loop3, _ = timed(nsteps)
         p3 = tr._model().packed['P']
+        lib.mm_debug_set2(2)          # A/B in the same process: rounds 4-5's concatenated-depth kernels (no term sharing, three-kernel feed-forward)
+        try:
+            sec3_old, loop3_old, _ = timed(3)
+        finally:
+            lib.mm_debug_set2(0)
         mg.set_precision('bf16x3')
         sec6, loop6, _ = timed(2)
         p6 = tr._model().packed['P']
@@ -321,6 +326,11 @@ def parity_tier_leg(mg, tr, step, args, B, T, n, nc, image_size, counts, lib, bf
         mg.set_precision('f16x2')
         sec, loop_ms, prof = timed(nsteps)
         P = tr._model().packed['P']
+        lib.mm_debug_set2(2)
+        try:
+            sec_old, loop_old, _ = timed(3)
+        finally:
+            lib.mm_debug_set2(0)
         g_cnt, g_ms, g_flops = prof[0]
         ex = executed_flops_per_generate(tr, B, n, args.text_len, nc, counts)
         return {
@@ -337,8 +347,12 @@ def parity_tier_leg(mg, tr, step, args, B, T, n, nc, image_size, counts, lib, bf
                          'algorithmic_frac': (g_flops / P / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if g_ms else None,
                          'launches': g_cnt, 'avg_launch_ms': g_ms / g_cnt if g_cnt else None, 'traffic': None},
             'executed_f16_tflops_decode_loop_gemms_x_products': P * ex / (loop_ms * 1e-3) / 1e12,
+            'without_term_sharing': {'value': B / sec_old, 'ms_per_step': sec_old * 1e3, 'decode_loop_ms_per_step': loop_old, 'steps': 3, 'x_time': sec_old / sec,
+                                     'note': 'same process, mm_debug_set2(2): the depth-P*K GEMMs over duplicated term segments of rounds 4-5 (DESIGN 3.10)'},
             'fp32_checkpoint': {'term_products': p3, 'value': B / sec3, 'ms_per_step': sec3 * 1e3, 'decode_loop_ms_per_step': loop3, 'steps': nsteps,
                                 'x_bf16_engine_time': sec3 / bf16_s_per_step,
+                                'without_term_sharing': {'value': B / sec3_old, 'ms_per_step': sec3_old * 1e3, 'decode_loop_ms_per_step': loop3_old, 'steps': 3,
+                                                         'x_time': sec3_old / sec3},
                                 'note': 'same tier on the raw fp32 initialisation (general fp32 weights, what the reference\'s constructors / training produce): three term pairs'},
             'bf16x3': {'note': 'round 3\'s tier (bf16 terms) on the same two checkpoints, 2 timed steps each',
                        'fp32_checkpoint': {'term_products': p6, 'value': B / sec6, 'ms_per_step': sec6 * 1e3, 'decode_loop_ms_per_step': loop6},
