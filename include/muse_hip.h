@@ -405,7 +405,7 @@ int mm_conv2d_nhwc_f16(mm_stream_t stream, const void* in, int B, int Hin, int W
                        int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
                        int Hout, int Wout, const float* bias, int act, const float* resid_f32, float* out, int out_nchw_f32, float alpha);
 /* ... with the operand code stated (round 5): products = MM_SPLIT_F16 | 2 / 3 segments per pixel (Cin = P x channels) and per tap of the weight rows; with
- * MM_SPLIT_SHARED (genuine packs: [xh | xl | xh] per pixel, [wh | wh | wl] per tap) the 256 x 128 kernel stages every term plane once (channels % 32 == 0). */
+ * MM_SPLIT_SHARED (genuine packs: [xh | xl | xh] per pixel, [wh | wh | wl] per tap) the 256 x 128 kernel stages every term plane once (three products, channels % 32 == 0). */
 int mm_conv2d_nhwc_terms(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
                          int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
                          int Hout, int Wout, const float* bias, int act, const float* resid_f32, float* out, int out_nchw_f32, float alpha, int products);

@@ -446,9 +446,10 @@ int mm_gemm_big_launch(GemmArgs a, hipStream_t stream) {
     if (a.f16 && a.mode == MODE_DENSE && (a.terms == 2 || a.terms == 3) && !(g_mm_debug2 & 2) && !(a.debug & (1 | 2 | 4)) && (a.K % a.terms) == 0 &&
         ((a.K / a.terms) % 32) == 0 && a.ldx >= a.K && a.ldw >= a.K)      // term sharing (round 5): equal-length term segments, every term plane staged once
         return a.terms == 3 ? launch_big<MODE_DENSE, true, 3>(a, stream) : launch_big<MODE_DENSE, true, 2>(a, stream);
-    if (a.f16 && a.mode == MODE_CONV && (a.terms == 2 || a.terms == 3) && !(g_mm_debug2 & 2) && !(a.debug & (1 | 2 | 4)) && (a.Cin % a.terms) == 0 &&
-        ((a.Cin / a.terms) % 32) == 0 && a.K == a.Ktrue)      // ... convolutions: segments per pixel / per tap, a 32-channel step inside one tap
-        return a.terms == 3 ? launch_big<MODE_CONV, true, 3>(a, stream) : launch_big<MODE_CONV, true, 2>(a, stream);
+    // ... convolutions: segments per pixel / per tap, a 32-channel step inside one tap.  Three products only: with two the step count and the MFMAs per step equal the
+    // concatenated form's and the loader's per-instruction address arithmetic doubles per flop -- measured 0.45 ms per generate SLOWER (VAE part 15.99 vs 15.54 ms, same box)
+    if (a.f16 && a.mode == MODE_CONV && a.terms == 3 && !(g_mm_debug2 & 2) && !(a.debug & (1 | 2 | 4)) && (a.Cin % 3) == 0 && ((a.Cin / 3) % 32) == 0 && a.K == a.Ktrue)
+        return launch_big<MODE_CONV, true, 3>(a, stream);
     if (a.f16) return a.mode == MODE_CONV ? launch_big<MODE_CONV, true>(a, stream) : launch_big<MODE_DENSE, true>(a, stream);      // (mm_gemm_launch admits dense / conv only)
     if (a.mode == MODE_CFG) return launch_big<MODE_CFG>(a, stream);
     if (a.mode == MODE_CONV) return launch_big<MODE_CONV>(a, stream);

@@ -183,5 +183,5 @@ def test_term_sharing_convolution(B, H, C, Cout, wkind):
     scale = ref.abs().max().item()
     e, eo, d = (outs[0] - ref).abs().max().item(), (outs[1] - ref).abs().max().item(), (outs[0] - outs[1]).abs().max().item()
     print(f'[terms] conv 3x3 {B}x{H}x{H}x{C} -> {Cout} {wkind} ({P} products): max err {e:.3g} (concatenated {eo:.3g}), between the two {d:.3g}; |ref| {scale:.3g}')
-    assert d > 0., 'term sharing was not dispatched'
+    assert (d > 0.) == (P == 3), 'three products: term sharing; two: the concatenated form stays (measured faster, gemm_big.hip mm_gemm_big_launch)'
     assert e <= 4e-6 * scale and e <= 2 * eo + 1e-7 * scale
