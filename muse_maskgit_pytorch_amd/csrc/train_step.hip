@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -172,12 +173,17 @@ struct Side {
     std::vector<hipEvent_t> ev;
     size_t used = 0;
 };
-Side g_side[16];
+constexpr int SIDE_DEVS = 16;
+Side g_side[SIDE_DEVS];
+std::mutex g_side_mu[SIDE_DEVS];      // a device's side stream and event pool serve ONE step at a time: two host threads training on one device take turns
 
-int side_get(Side** out) {
+// *out = the device's side state with `lock` held until the caller drops it, or nullptr (one-stream step) for a device ordinal beyond the table
+int side_get(Side** out, std::unique_lock<std::mutex>& lock) {
     int dev = 0;
+    *out = nullptr;
     HC(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 16) return mm_set_error(MM_ERR_UNSUPPORTED, "train_step: device ordinal >= 16");
+    if (dev < 0 || dev >= SIDE_DEVS) return MM_OK;
+    lock = std::unique_lock<std::mutex>(g_side_mu[dev]);
     Side& sd = g_side[dev];
     if (!sd.s2) HC(hipStreamCreateWithFlags(&sd.s2, hipStreamNonBlocking));
     sd.used = 0;
@@ -244,8 +250,9 @@ int mm_train_step(const mm_train_desc* desc, mm_stream_t stream, const int64_t* 
     // ---- the side stream (see the head of this file); sd == nullptr: one stream, mark / await are no-ops, s2 == s
     // MM_TRAIN_SIDE=0 (A/B): everything on the caller's stream
     Side* sd = nullptr;
+    std::unique_lock<std::mutex> side_lock;      // (released when the call returns: the step joins the side stream before that)
     const char* env = getenv("MM_TRAIN_SIDE");
-    if (!(env && env[0] == '0')) RC(side_get(&sd));
+    if (!(env && env[0] == '0')) RC(side_get(&sd, side_lock));
     // (round 4's MM_TRAIN_SIDE=x timing experiment -- skip every dW GEMM, wrong gradients -- is gone from the shipped library: ADVICE r4)
     hipStream_t s2 = sd ? sd->s2 : s;
     mm_stream_t stream2 = (mm_stream_t)s2;

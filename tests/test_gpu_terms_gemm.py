@@ -185,3 +185,34 @@ def test_term_sharing_convolution(B, H, C, Cout, wkind):
     print(f'[terms] conv 3x3 {B}x{H}x{H}x{C} -> {Cout} {wkind} ({P} products): max err {e:.3g} (concatenated {eo:.3g}), between the two {d:.3g}; |ref| {scale:.3g}')
     assert (d > 0.) == (P == 3), 'three products: term sharing; two: the concatenated form stays (measured faster, gemm_big.hip mm_gemm_big_launch)'
     assert e <= 4e-6 * scale and e <= 2 * eo + 1e-7 * scale
+
+
+def test_tier_feed_forward_fused_form_and_its_refusal(force_terms):
+    """model.hip ff_block of the tier: w1 + GEGLU + term split + LayerNorm(inner) partials (gemm_terms.hip EPI 1) -> w2 with the LayerNorm folded in, against the fp32
+    engine ('parity': fp32 MFMA, operator by operator).  Then a checkpoint whose LayerNorm(inner) gains push the gain-folded w2 out of fp16 range at the model's
+    term scale: the pack refuses the fold for those layers (mm_ff_weights.w1_terms_geglu = NULL) and the three-kernel form must give the same accuracy."""
+    import muse_maskgit_pytorch_amd as mm
+    torch.manual_seed(3)
+    tr = mm.MaskGitTransformer(num_tokens=512, seq_len=64, dim=128, depth=2, dim_head=64, heads=2, t5_name='t5-small').to(DEV).eval()
+    g = torch.Generator().manual_seed(4)
+    ids = torch.randint(0, 513, (3, 64), generator=g).to(DEV)
+    te = torch.randn(3, 6, 512, generator=g).to(DEV)
+
+    def both():
+        with torch.no_grad():
+            ref = tr.set_precision('parity')(ids, text_embeds=te, cond_drop_prob=0.).float()
+            got = tr.set_precision('f16x2')(ids, text_embeds=te, cond_drop_prob=0.).float()
+        fused = [t_.get('w1g') is not None for t_ in tr._model().keep if isinstance(t_, dict) and 'w1g' in t_]
+        tr.set_precision('bf16')
+        return (got - ref).abs().max().item(), ref.abs().max().item(), fused
+
+    e, sc, fused = both()
+    print(f'[terms] tier feed-forward, fused form on {sum(fused)} of {len(fused)} blocks: logits max err {e:.3g} on |ref| {sc:.3g}')
+    assert all(fused) and e <= 2e-5 * max(1., sc)
+    with torch.no_grad():
+        for _, _, ff in tr.transformer_blocks.layers:
+            ff[3].gamma.mul_(20.)            # |w2 . gamma| x the model's term scale (the largest |w| at 2^13 .. 2^14) leaves the fp16 range: no fold for these blocks
+    tr.invalidate_packed_weights()
+    e2, sc2, fused2 = both()
+    print(f'[terms] ... with the fold refused on {len(fused2) - sum(fused2)} of {len(fused2)} blocks: logits max err {e2:.3g} on |ref| {sc2:.3g}')
+    assert not any(fused2[:2]) and e2 <= 2e-5 * max(1., sc2)

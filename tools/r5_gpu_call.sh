@@ -1,5 +1,3 @@
-mkdir -p gpurun_out/r5v
-for d in 0 0x10 0x20 0x30; do echo "== MM_DEBUG2=$d"; MM_DEBUG2=$d python tools/terms_gemm_timing.py 2>&1 | grep -E "q\|k\|v|FF w1" ; done | tee gpurun_out/r5v/dpos_timing.txt
-for d in 0 0x10 0x20 0x30 0 0x10; do
-  echo "== MM_DEBUG2=$d"; MM_DEBUG2=$d timeout 300 python bench.py --steps 5 --warmup 2 --no-parity-tier --no-cpu-baseline --no-graph-leg --no-off-ideal --precision f16x2 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('decode_loop_ms_per_step'))"
-done 2>&1 | tee gpurun_out/r5v/dpos_ab.log
+mkdir -p gpurun_out/r5w
+timeout 900 python -m pytest tests/test_gpu_terms_gemm.py tests/test_gpu_train_step.py -q -x -s > gpurun_out/r5w/t1.log 2>&1; echo "pytest 1 rc $?"; grep -E "feed-forward|fold refused|conv 3x3|passed|failed|Error" gpurun_out/r5w/t1.log | tail -12
+timeout 900 python -m pytest tests/test_gpu_base_size.py tests/test_gpu_parity_mode.py -q -x -k "vae or vqgan" > gpurun_out/r5w/t2.log 2>&1; echo "pytest 2 rc $?"; tail -2 gpurun_out/r5w/t2.log
