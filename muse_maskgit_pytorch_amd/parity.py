@@ -216,12 +216,21 @@ def _cached_pack(key, make_taps):
     return cache[key]
 
 
+def split_nhwc(x):
+    """the term-segment form of an fp32 NHWC activation for the current tier (what conv_x3 multiplies): [B, H, W, P * C]"""
+    from . import ops
+    B, H, W, Cin = x.shape
+    return ops.split_rows(x.reshape(-1, Cin), _X3['code']).reshape(B, H, W, _X3['P'] * Cin)
+
+
 def conv_x3(x, w_taps, cout, th, tw, stride=1, off=(0, 0), out_hw=None, os_=1, parity=(0, 0), full_hw=None, bias=None, act=False, resid=None, out=None,
-            out_nchw=False):
+            out_nchw=False, xs=None):
+    """xs (optional): split_nhwc(x) made by the caller -- the four output parities of a ConvTranspose2d read the SAME input (round 5: split once, not four times)"""
     from . import ops
     P, code = _X3['P'], _X3['code']
     B, H, W, Cin = x.shape
-    xs = ops.split_rows(x.reshape(-1, Cin), code).reshape(B, H, W, P * Cin)
+    if xs is None:
+        xs = split_nhwc(x)
     wp = w_taps if torch.is_tensor(w_taps) else _pack_x3(w_taps, code, _X3['scale'])      # (already packed: _cached_pack)
     Hv, Wv = out_hw if out_hw is not None else (H, W)
     Hout, Wout = full_hw if full_hw is not None else (Hv * os_, Wv * os_)
@@ -307,11 +316,12 @@ def _vae_layer(x, m, first=False, last=False):
         B, H, W, _ = x.shape
         out = torch.empty(B, 2 * H, 2 * W, ct.out_channels, dtype=f32, device=x.device)
         if _X3['P']:
+            xs = split_nhwc(x)          # one split of the input for the four output parities
             for py in range(2):
                 for px in range(2):
                     wp = _cached_pack((ct.weight, 'convT', py, px), lambda: _taps_convT(ct.weight)[(py, px)])
                     conv_x3(x, wp, ct.out_channels, 2, 2, 1, (py - 1, px - 1), out_hw=(H, W), os_=2, parity=(py, px), full_hw=(2 * H, 2 * W), bias=_w(ct.bias),
-                            act=True, out=out)
+                            act=True, out=out, xs=xs)
             return out
         for (py, px), wp in pack_convT(ct.weight).items():
             conv(x, wp, ct.out_channels, 2, 2, 1, (py - 1, px - 1), out_hw=(H, W), os_=2, parity=(py, px), full_hw=(2 * H, 2 * W), bias=_w(ct.bias), act=True,
