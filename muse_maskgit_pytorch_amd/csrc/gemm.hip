@@ -50,6 +50,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     static_assert(BM == 128 || (BM == 64 && MODE == MODE_DENSE), "64-token tiles: dense mode only");
     static_assert(NP == 0 || (F16 && MODE == MODE_DENSE), "term sharing: dense fp16 term operands only");
     constexpr int MB = BM / 32;      // token fragments per wave (a wave: 64 weight rows x BM / 2 tokens)
+    // Term sharing on 64-token tiles (the tier's cross-attention projections): a 32-deep step carries only 24 MFMAs per wave, far less than one L2 round trip, so
+    // the two-stage loop below (request step kt + 1, compute step kt, wait) exposed the DMA latency at every step (28 us for 19 GFLOP, matrix pipe 0.25).  These
+    // instantiations run THREE stages of 24 KiB (weights 16 + tokens 8) with the requests two steps ahead and a counted vmcnt, as gemm_big.hip; still two workgroups per CU.
+    constexpr bool P3 = NP != 0 && BM == 64;
+    constexpr int STG = P3 ? BT * BK * 2 + BM * BK * 2 : STAGE_BYTES;
+    constexpr int TAIL = (P3 && 3 * STG > BT * (BT + 4) * 4) ? 3 * STG : BT * (BT + 4) * 4;      // LayerNorm statistics / c1 | c2 entries live behind the stages and the output tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TSTAMP(0)
     const int t = threadIdx.x;
@@ -113,8 +119,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 #define ISSUE_TILE(kt_, stage_)                                                                                    \
     {                                                                                                              \
         const int k0_ = (kt_) * (NP ? 32 : BK);                                                                    \
-        unsigned char* ws_ = smem + (stage_) * STAGE_BYTES + wid * (NP == 2 ? 2048 : 4096);   /* this wave's 32 rows of the W tile */ \
-        unsigned char* xs_ = smem + (stage_) * STAGE_BYTES + BT * BK * 2 + wid * (BM * 32);   /* ... its BM / 4 rows of the X tile */ \
+        unsigned char* ws_ = smem + (stage_) * STG + wid * (NP == 2 ? 2048 : 4096);   /* this wave's 32 rows of the W tile */ \
+        unsigned char* xs_ = smem + (stage_) * STG + BT * BK * 2 + wid * (BM * 32);   /* ... its BM / 4 rows of the X tile */ \
         _Pragma("unroll") for (int i = 0; i < (NP == 2 ? 2 : 4); ++i)                                              \
             __builtin_amdgcn_global_load_lds(wptr[i] + k0_, (lds_ptr_t)(ws_ + i * 1024), 16, 0, 0);                \
         if constexpr (MODE != MODE_CONV) {                                                                         \
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         }
     }
     // LayerNorm(inner) folded into this GEMM (GemmArgs::ln_c1): per-row mean / rstd from the w1 kernel's partial sums, parked behind the tile
-    float2* ln_stat = reinterpret_cast<float2*>(smem + BT * (BT + 4) * 4);
+    float2* ln_stat = reinterpret_cast<float2*>(smem + TAIL);
     if constexpr (RESID_PF) {
         if (resid_pf && p.ln_c1) {      // 256 threads = 2 per tile row
             const int r_ = t >> 1, m_ = m0 + r_;
@@ -186,18 +192,30 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                 const float* src_ = (t < 32) ? p.in_c1 : p.in_c2;
                 float4 v_ = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (src_ && n_ + 3 < p.N) v_ = *reinterpret_cast<const float4*>(src_ + n_);
-                reinterpret_cast<float4*>(smem + BT * (BT + 4) * 4 + BT * 8)[t] = v_;
+                reinterpret_cast<float4*>(smem + TAIL + BT * 8)[t] = v_;
             }
         }
     }
+    if constexpr (P3) {      // three stages: the second step goes out now (behind the residual / statistics loads: VMEM retires in order); step 0 has landed once at most
+                             // that step's requests are outstanding
+        constexpr int NREQ = (NP == 2 ? 2 : 4) + BM / 32;      // DMA instructions per wave and step
+        if (KT > 1) {
+            ISSUE_TILE(kt0 + 1, 1);
+            if constexpr (NREQ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+    } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA of the first k-tile has landed (explicit: a barrier alone does not drain VMEM)
     __syncthreads();
+    }
     TSTAMP(2)
 
     const int fr = lane & 15, fg = lane >> 4;
 #define COMPUTE_TILE(stage_)                                                                                       \
     {                                                                                                              \
-        const unsigned char* ws_ = smem + (stage_) * STAGE_BYTES;                                                  \
+        const unsigned char* ws_ = smem + (stage_) * STG;                                                          \
         const unsigned char* xs_ = ws_ + BT * BK * 2;                                                              \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                         \
             u32x4_t af[4], bfm[MB];                                                                                \
@@ -213,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     }
 #define COMPUTE_TERMS(stage_)      /* term sharing: xh.wh, xl.wh (, xh.wl) of this 32-deep k-block from one staging of its term planes */ \
     {                                                                                                              \
-        const unsigned char* ws_ = smem + (stage_) * STAGE_BYTES;                                                  \
+        const unsigned char* ws_ = smem + (stage_) * STG;                                                          \
         const unsigned char* xs_ = ws_ + BT * BK * 2;                                                              \
         u32x4_t wh[4], wl[4], xh[MB], xl[MB];                                                                      \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
@@ -238,6 +256,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         }                                                                                                          \
     }
 #define COMPUTE_STEP(stage_) { if constexpr (NP != 0) COMPUTE_TERMS(stage_) else COMPUTE_TILE(stage_) }
+    if constexpr (P3) {
+        constexpr int NREQ = (NP == 2 ? 2 : 4) + BM / 32;
+        for (int kt = 0; kt < KT; ++kt) {
+            if (kt > 0) {
+                // step kt has landed once at most step kt + 1's requests of this wave are outstanding; the barrier publishes it and frees stage (kt + 2) % 3
+                if (kt + 1 < KT) { if constexpr (NREQ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 2 < KT) ISSUE_TILE(kt0 + kt + 2, (kt + 2) % 3);
+            __builtin_amdgcn_sched_barrier(0);
+            COMPUTE_TERMS(kt % 3);
+        }
+    } else {
     // steady state: the next tile's DMA is in flight while this tile's MFMAs run; one barrier per tile
     for (int kt = 0; kt < KT - 1; ++kt) {
         if (!(p.debug & 2)) ISSUE_TILE(kt0 + kt + 1, (kt + 1) & 1);
@@ -248,6 +282,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         TSTAMP(3 + kt)
     }
     COMPUTE_STEP((KT - 1) & 1);
+    }
     TSTAMP(40)
     if constexpr (F16) {      // fp16 term products: undo the power-of-two scale of the packed weight terms (exact)
         const float al = p.alpha;
@@ -261,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         if (p.in_c1) {
             // LayerNorm(dim) fold, consumer side: X held the raw residual rows, W the gains -> acc = rstd * (acc - mean * c1[n]) + c2[n], applied on the
             // accumulators (before GEGLU when there is one), the same expression in the same order as gemm_wide.hip's
-            const float4* lc = reinterpret_cast<const float4*>(smem + BT * (BT + 4) * 4 + BT * 8);      // [32] c1 then [32] c2 of this tile's 128 columns
+            const float4* lc = reinterpret_cast<const float4*>(smem + TAIL + BT * 8);      // [32] c1 then [32] c2 of this tile's 128 columns
             float4 c1v[4], c2v[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
@@ -518,16 +553,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 
 template <int MODE, bool F16 = false, int BM = 128, int NP = 0>
 int launch(const GemmArgs& a, hipStream_t stream) {
+    // (three-stage term-sharing instantiations: 3 x 24 KiB of stages + the 2 KiB tail; gemm_kernel's P3)
+    constexpr int SM = (NP != 0 && BM == 64) ? 3 * (BT * BK * 2 + BM * BK * 2) + BT * 8 + BT * 8 : SMEM_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_kernel<MODE, F16, BM, NP>)),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SM);
         if (e != hipSuccess) return mm_set_hip_error(e, "gemm hipFuncSetAttribute");
         attr_set = true;
     }
     const int blocks = a.tiles_m * a.tiles_n;
     if (blocks <= 0) return MM_OK;
-    hipLaunchKernelGGL((gemm_kernel<MODE, F16, BM, NP>), dim3(blocks, a.splits > 1 ? a.splits : 1), dim3(256), SMEM_BYTES, stream, a);
+    hipLaunchKernelGGL((gemm_kernel<MODE, F16, BM, NP>), dim3(blocks, a.splits > 1 ? a.splits : 1), dim3(256), SM, stream, a);
     return mm_check_launch("gemm_kernel");
 }
 
