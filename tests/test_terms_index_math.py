@@ -145,3 +145,37 @@ def test_request_and_wait_schedule_of_the_persistent_term_sharing_loop():
         pass
     else:
         raise AssertionError('the schedule model does not see the buffer conflict of a two-product loop with KT % 4 == 2')
+
+
+def _three_stage(KT, nreq):
+    """gemm_big.hip / gemm.hip (64-token term-sharing tiles): three stages, step kt + 2 requested while step kt computes, counted wait at the top of a step.
+    Asserts that a step's operands have landed when it starts and that a request never targets the stage of a step some wave may still be reading."""
+    inflight, landed = [], set()
+
+    def wait(allow):
+        total = sum(n for _, n in inflight)
+        while total > allow:
+            tag, n = inflight.pop(0)
+            landed.add(tag)
+            total -= n
+
+    inflight.append((0, nreq))
+    inflight.append(('resid', 8))           # the fp32 residual prefetch goes out between the first two requests (VMEM retires in order)
+    if KT > 1:
+        inflight.append((1, nreq))
+    wait(nreq if KT > 1 else 0)             # prologue: step 0 (and the residual) landed, step 1 may still be in flight
+    assert 0 in landed and 'resid' in landed
+    for kt in range(KT):
+        if kt > 0:
+            wait(nreq if kt + 1 < KT else 0)
+        assert kt in landed, f'step {kt} not landed at its barrier'
+        # barrier passed: every wave has finished step kt - 1, whose stage (kt - 1) % 3 == (kt + 2) % 3 is now free
+        if kt + 2 < KT:
+            assert (kt + 2) % 3 not in {kt % 3, (kt + 1) % 3}
+            inflight.append((kt + 2, nreq))
+
+
+def test_three_stage_counted_waits_of_the_256x128_and_64_token_kernels():
+    for KT in (1, 2, 3, 4, 16, 44):
+        for nreq in (4, 5, 6):              # requests per wave and step: 64-token tiles NP 2 / 256 x 128 NP 2 / both NP 3
+            _three_stage(KT, nreq)
