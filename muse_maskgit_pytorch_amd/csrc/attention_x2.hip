@@ -215,18 +215,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         psum += __shfl_xor(psum, 16, 64);
         psum += __shfl_xor(psum, 32, 64);
         const float p_null = p.null_k ? __builtin_amdgcn_exp2f((s_null - m) * c1) : 0.f;
-        const float linv = 1.f / (psum + p_null);
+        // Round 6: the probabilities enter the P V product multiplied by 2^12 (exact), the inverse rides in linv.  Unscaled, the LOW fp16 term of a
+        // probability below ~2^-3 is subnormal (absolute floor 2^-25 per key): diffuse attention over 256 keys kept ~17 bits.  With P in (0, 4096] the low term
+        // is normal down to p ~ 2^-15 and the floor is 2^-37 -- the weight side of the tier scales by a power of two for the same reason (ops.f16_weight_scale).
+        constexpr float PSC = 4096.f;
+        const float linv = (1.f / PSC) / (psum + p_null);
         // ---- O = p_null * v_null + P V as three term products: acc_o[dt][r] -> query 4 fg + r, d = dt * 16 + fr
         f32x4_t acc_o[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float pn = __shfl(p_null, 4 * fg + r, 64);
+            const float pn = __shfl(p_null, 4 * fg + r, 64) * PSC;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) acc_o[dt][r] = pn * nvv[dt];
         }
 #pragma unroll
         for (int ks = 0; ks < NKB / 2; ++ks) {
-            const float pe[8] = {acc_s[2 * ks][0], acc_s[2 * ks][1], acc_s[2 * ks][2], acc_s[2 * ks][3], acc_s[2 * ks + 1][0], acc_s[2 * ks + 1][1], acc_s[2 * ks + 1][2], acc_s[2 * ks + 1][3]};
+            const float pe[8] = {acc_s[2 * ks][0] * PSC, acc_s[2 * ks][1] * PSC, acc_s[2 * ks][2] * PSC, acc_s[2 * ks][3] * PSC,
+                                 acc_s[2 * ks + 1][0] * PSC, acc_s[2 * ks + 1][1] * PSC, acc_s[2 * ks + 1][2] * PSC, acc_s[2 * ks + 1][3] * PSC};
             uint4 ph, pl;
             x2_split8(pe, ph, pl);
 #pragma unroll

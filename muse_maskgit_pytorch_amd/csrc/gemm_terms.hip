@@ -104,7 +104,14 @@ __global__ __launch_bounds__(512) void gemm_terms_kernel(const GemmArgs p) {
             for (int b = 0; b < 8; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         for (int kt = 0; kt < KT; ++kt) {
             const int st = kt & 1;
+#if defined(MM_EXP) && MM_EXP == 61      // tools A/B only (tools/build_exp.sh 61 gemm_terms): round 5's hand-counted wait across the tile boundary
             if (kt == 0) wait_vmcnt_t(pending);
+#else
+            // Round 6: the first wait of a tile takes EVERYTHING.  Round 5 waited vmcnt(number of epilogue stores issued behind this step's
+            // LDS-DMA), which is only right if hipcc emits exactly the counted stores -- it may merge the GEGLU epilogue's 8-byte segment stores, and then the
+            // wait would return before step 0's operands have landed: silent wrong results.  One drained wait per tile costs < 1 % (profiles/r06_*).
+            if (kt == 0) { (void)pending; __builtin_amdgcn_s_waitcnt(MT_VMCNT_IMM(0)); }
+#endif
             else if (NP == 2 && st == 1 && kt + 1 < KT) __builtin_amdgcn_s_waitcnt(MT_VMCNT_IMM(NFW));
             else __builtin_amdgcn_s_waitcnt(MT_VMCNT_IMM(0));
             __builtin_amdgcn_s_barrier();            // this step's operands have landed for everybody, and everybody is done reading what the next request overwrites

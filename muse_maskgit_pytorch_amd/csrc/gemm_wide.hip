@@ -614,7 +614,9 @@ bool mm_gemm_wide_fused_eligible(const GemmArgs& a) {
 }
 
 int mm_gemm_wide_fused_launch(GemmArgs a, hipStream_t stream) {
+#ifdef MM_TOOLS_PP      // tools/build_timing.sh only: the rejected out-of-lock-step forms (tools/experiments/gemm_pp.hip); never compiled into libmuse_hip.so
     if (mm_gemm_pp_fused_selected(a)) return mm_gemm_pp_fused_launch(a, stream);
+#endif
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_F);

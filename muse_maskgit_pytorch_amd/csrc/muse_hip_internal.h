@@ -63,7 +63,7 @@ struct GemmArgs {
     const float* in_part; int in_np; int in_F; const float* in_c1; const float* in_c2;
 };
 extern int g_mm_debug;
-extern int g_mm_debug2;      // mm_debug_set2 (round 5): 1 = gemm_terms.hip whatever the tile count (tests: small batches through the production kernels), 2 = gemm_terms.hip and every term-sharing k-loop off (A/B)
+extern int g_mm_debug2;      // mm_debug_set2 (round 5): 1 = gemm_terms.hip whatever the tile count (tests: small batches through the production kernels), 2 = gemm_terms.hip and every term-sharing k-loop off (A/B), 4 = mm_train_step on the caller's stream only (A/B)
 
 int mm_gemm_launch(GemmArgs a, hipStream_t stream);
 bool mm_gemm_big_eligible(const GemmArgs& a);      // gemm_big.hip: 256x128 tile, 3-stage counted-vmcnt pipeline
@@ -77,8 +77,10 @@ int mm_gemm_wide_fused_launch(GemmArgs a, hipStream_t stream);     // gemm_cfg.h
 int mm_gemm_cfg2_launch(GemmArgs a, hipStream_t stream);
 bool mm_gemm_terms_eligible(const GemmArgs& a);      // gemm_terms.hip (round 5): fp16 term-segment operands, every term plane staged once
 int mm_gemm_terms_launch(GemmArgs a, hipStream_t stream);
-bool mm_gemm_pp_fused_selected(const GemmArgs& a);      // gemm_pp.hip (round 5): the logits GEMM with its wave groups out of lock-step
+#ifdef MM_TOOLS_PP      // tools/experiments/gemm_pp.hip (round 5's measured-and-rejected forms; tools build only, see tools/build_timing.sh)
+bool mm_gemm_pp_fused_selected(const GemmArgs& a);
 int mm_gemm_pp_fused_launch(GemmArgs a, hipStream_t stream);
+#endif
 // gemm_pers.hip: persistent 256x128, stores overlapped with the next tile
 int mm_gemm_pers_launch(GemmArgs a, hipStream_t stream);
 

@@ -12,7 +12,7 @@
 // (2) the transposes of a layer's saved activations follow that layer's forward; (3) the LEAVES of the backward -- every dW GEMM with its gradient-row
 // transpose, split-K reduction and copies, and the reductions of the dgamma / scale / null key-value partials: nothing reads them before the call returns --
 // follow the operator that produced their input.  Buffers a leaf reads are per layer (the chain moves on while the leaf is pending).  Same kernels, same
-// inputs, same values; MM_TRAIN_SIDE=0 keeps everything on the caller's stream (A/B: 14.7-15.1 vs 15.7-16.3 ms per C2 step, same box).
+// inputs, same values; mm_debug_set2(4) keeps everything on the caller's stream (A/B: 14.7-15.1 vs 15.7-16.3 ms per C2 step, same box).
 // Three launches of the driver are fused away here with identical results: the bf16 image of the residual-stream gradient is written by the LayerNorm backward
 // that produced it (no f32->bf16 pass), the cross-entropy value comes out of its backward kernel (no forward pass over the logits), and the head's
 // dX = dlogits . W contracts over the vocabulary with split-K (training.py does the same: _dgrad_long_k).
@@ -248,12 +248,11 @@ int mm_train_step(const mm_train_desc* desc, mm_stream_t stream, const int64_t* 
     const int M = q.M, D = q.D, H = q.H, I = q.I, F = q.F, Fp = q.Fp, V = q.V, td = q.td, Mc = q.Mc;
 
     // ---- the side stream (see the head of this file); sd == nullptr: one stream, mark / await are no-ops, s2 == s
-    // MM_TRAIN_SIDE=0 (A/B): everything on the caller's stream
+    // mm_debug_set2 bit 4 (A/B and the bit-identity test): everything on the caller's stream.  (Round 6: an explicit call instead of the MM_TRAIN_SIDE
+    // environment variable -- the library reads no environment variable any more; tests/test_host_logic.py checks that it does not even import getenv.)
     Side* sd = nullptr;
     std::unique_lock<std::mutex> side_lock;      // (released when the call returns: the step joins the side stream before that)
-    const char* env = getenv("MM_TRAIN_SIDE");
-    if (!(env && env[0] == '0')) RC(side_get(&sd, side_lock));
-    // (round 4's MM_TRAIN_SIDE=x timing experiment -- skip every dW GEMM, wrong gradients -- is gone from the shipped library: ADVICE r4)
+    if (!(g_mm_debug2 & 4)) RC(side_get(&sd, side_lock));
     hipStream_t s2 = sd ? sd->s2 : s;
     mm_stream_t stream2 = (mm_stream_t)s2;
     hipEvent_t e_f;

@@ -7,6 +7,7 @@ libmuse_hip.so (bf16 MFMA kernels, fp32 residual stream / logits / sampling) thr
 include/muse_hip.h.  There is no eager fallback: without the library or without a gfx950 device these raise.
 """
 import ctypes as C
+import weakref
 import math
 from functools import partial
 from pathlib import Path
@@ -132,6 +133,7 @@ class _Handle:
         self.packed = None
         self.stats_src = None      # callable -> fp32 [V][D] to_logits weights for the vocabulary statistics, or None when they do not apply
         self.auto_bound = 'gaussian'   # Transformer.fused_bound == 'auto': the bound this packed model currently uses (switched to 'quantile' by the first generate the Gaussian one fails)
+        self.owner = None          # the Transformer this handle was packed for (keeps the LayerNorm-fold probe's verdict)
         self.ln_probe = None       # device float[1] while the LayerNorm(dim) fold of this handle is being probed (Transformer.set_layernorm_fold('auto'))
         self.ln_ratio = None       # the probe's result: max |row mean| / (row standard deviation) over every folded LayerNorm input of the first call
 
@@ -178,6 +180,7 @@ class _Handle:
         return self.packed is not None and (self.packed.get('wsub') is not None or self.packed.get('wcov') is not None)
 
     def _recreate(self):
+        self.gen = getattr(self, 'gen', 0) + 1      # (a captured hipGraph names the buffers of the C handle it was captured with: MaskGit._generate_graphed keys on this)
         L.lib().mm_transformer_destroy(self.ptr)
         self.ptr = C.c_void_p()
         L.check(L.lib().mm_transformer_create(C.byref(self.desc), C.byref(self.ptr)), 'mm_transformer_create')
@@ -194,6 +197,9 @@ class _Handle:
             return False
         self.ln_ratio = float(self.ln_probe.item())
         off = self.ln_ratio > L.MM_LN_FOLD_MAX_RATIO
+        owner = self.owner() if self.owner is not None else None
+        if owner is not None:
+            owner._ln_fold_auto = not off           # the verdict outlives this packed copy (Transformer._model)
         self.desc.ln_probe, self.desc.ln_fold_off = None, int(off)
         self.ln_probe = None
         self._recreate()
@@ -341,9 +347,14 @@ class Transformer(nn.Module):
         d.final_gamma, d.final_beta, d.to_logits = L.ptr(t['fg']), L.ptr(t['fb']), L.ptr(t['wl'])
         d.self_cond_ff = sc_ff
         d.logits_wmean, d.logits_wcov = L.ptr(t['wmean']), L.ptr(t['wcov'])
-        d.ln_fold_off = int(self.layernorm_fold is False)
+        # 'auto' (ADVICE r5): the probe's verdict is kept PER MODEL OBJECT (`_ln_fold_auto`), not per packed copy -- an optimizer step repacks the weights every
+        # iteration, and re-probing each time cost a host synchronisation + a handle re-creation per step and could flip the engine between steps.  It is
+        # forgotten only where the VALUES can change wholesale: load_state_dict / invalidate_packed_weights / .to().
+        decided = getattr(self, '_ln_fold_auto', None)
+        d.ln_fold_off = int(self.layernorm_fold is False or (self.layernorm_fold == 'auto' and decided is False))
         h.desc = d
-        if self.layernorm_fold == 'auto':
+        if self.layernorm_fold == 'auto' and decided is None:
+            h.owner = weakref.ref(self)
             h.begin_ln_probe(dev)
         h.create(d, t)
         self._handle, self._handle_key = h, key
@@ -354,14 +365,17 @@ class Transformer(nn.Module):
         the RAW residual row and apply rstd * (acc - mean * c1) + c2 on their accumulators.  The bf16 rounding then acts on x instead of LayerNorm(x): its error in
         normalised units grows like |x^ + mean / sigma|, i.e. with the row's DC offset -- invisible for random-init-like statistics (|mean| / sigma ~ 0.05), a
         silent loss of accuracy for a checkpoint whose residual stream carries massive-activation channels or a large mean.
-        'auto' (default): the first call through a freshly packed model records max |mean| / sigma over every folded LayerNorm input (one extra host
-        synchronisation, once per packed model); above MM_LN_FOLD_MAX_RATIO the model falls back to the LayerNorm kernels and that call is recomputed.
+        'auto' (default): the first call through the model records max |mean| / sigma over every folded LayerNorm input (one extra host
+        synchronisation); above MM_LN_FOLD_MAX_RATIO the model falls back to the LayerNorm kernels and that call is recomputed.  The verdict is kept for the
+        model object until its values are replaced (load_state_dict / invalidate_packed_weights / .to()); repacks after optimizer steps reuse it.  It depends
+        on the FIRST inputs the model sees: two processes that must produce identical ids should pin the engine with True / False.
         True / False force the choice.  `layernorm_fold_ratio` holds the probe's result."""
         if mode not in ('auto', True, False):
             raise ValueError("layernorm fold mode must be 'auto', True or False")
         if mode != self.layernorm_fold:
             self.layernorm_fold = mode
             self._handle, self._handle_key = None, None
+            self._pack_gen = getattr(self, '_pack_gen', 0) + 1
         return self
 
     @property
@@ -506,6 +520,8 @@ class Transformer(nn.Module):
         self._handle_f8, self._handle_f8_key = None, None
         self._handle_x3, self._handle_x3_key = None, None
         self._x3_terms = None
+        self._ln_fold_auto = None      # (the 'auto' LayerNorm-fold verdict belongs to the values that were just replaced)
+        self._pack_gen = getattr(self, '_pack_gen', 0) + 1      # (part of the hipGraph cache key -- `_pack_key()` cannot see `.data` surgery)
 
     def _apply(self, fn, *args, **kwargs):
         self._drop_packed()
@@ -967,7 +983,7 @@ class MaskGit(nn.Module):
                     and not exists(critic_noise) and self.transformer.precision != 'parity' and fused_sampling is True
                     and not (exists(self.token_critic) and not force_not_use_token_critic)):
                 return self._generate_graphed(texts, cond_images, fmap_size, temperature, topk_filter_thres, can_remask_prev_masked, timesteps, cond_scale,
-                                              text_embeds, seed, row_offset, return_ids)
+                                              text_embeds, seed, row_offset, return_ids, force_not_use_token_critic, critic_noise_scale)
         tr = self.transformer
         use_token_critic = exists(self.token_critic) and not force_not_use_token_critic
         if exists(negative_texts) or exists(neg_text_embeds):
@@ -1144,12 +1160,16 @@ class MaskGit(nn.Module):
         images = images if images is not None else self.vae.decode_from_ids(ids)  # mmp.py:620
         return (ids, images) if return_ids == 'both' else images
 
-    def _generate_graphed(self, texts, cond_images, fmap_size, temperature, thres, can_remask, timesteps, cond_scale, text_embeds, seed, row_offset, return_ids):
+    def _generate_graphed(self, texts, cond_images, fmap_size, temperature, thres, can_remask, timesteps, cond_scale, text_embeds, seed, row_offset, return_ids,
+                          force_not_use_token_critic=False, critic_noise_scale=1):
         """generate(graph=True).  Per call signature: the first call runs eagerly (it packs the weights, computes the vocabulary statistics, probes the
         LayerNorm fold, sizes the workspaces -- none of which may happen under capture), the second captures generate(fused_sampling='deferred') + the VAE
         decode on static input / output buffers, every later one copies its text embeddings (and condition images) into the static inputs, writes
         {seed, row_offset} into the key buffer and replays.  The fused-sampling status words are read after the replay exactly like the eager path reads
-        them after its launches (the one host synchronisation); a replay whose status asks for the logits path is repeated eagerly with it."""
+        them after its launches (the one host synchronisation); a replay whose status asks for the logits path is repeated eagerly with it.
+        What a capture names: the packed weights of the transformer handle and of the VAE(s), the workspaces and the static inputs -- the entry holds
+        references to all of them, and the key carries the pack GENERATION of every module (bumped by `invalidate_packed_weights()`, `set_layernorm_fold()`,
+        `.to()`, `load_state_dict()`) and of the C handle (bumped whenever it is re-created), so surgery the version counters cannot see never replays a stale capture."""
         tr = self.transformer
         dev = tr.token_emb.weight.device
         if not exists(text_embeds):
@@ -1160,10 +1180,15 @@ class MaskGit(nn.Module):
         vkey = self.vae._pack_key() if exists(self.vae) else None
         ckey = self.cond_vae._pack_key() if (exists(cond_images) and self.cond_vae is not self.vae) else None
         hb = tr._model() if tr.precision == 'bf16' else None      # (packed here if need be: the key below names the bound this packed model currently uses)
+        hm = tr._model()
+        gens = (getattr(tr, '_pack_gen', 0), id(hm), getattr(hm, 'gen', 0), getattr(self.vae, '_pack_gen', 0) if exists(self.vae) else None,
+                getattr(self.cond_vae, '_pack_gen', 0) if exists(self.cond_vae) else None)
         key = (tuple(te.shape), None if not exists(cond_images) else tuple(cond_images.shape), fmap_size, float(temperature), float(thres), bool(can_remask), int(timesteps),
-               float(cond_scale), return_ids, tr.precision, tr.fused_bound, hb.auto_bound if hb is not None else None, tr._pack_key(), vkey, ckey)
+               float(cond_scale), return_ids, tr.precision, tr.fused_bound, hb.auto_bound if hb is not None else None, tr._pack_key(), vkey, ckey, gens,
+               bool(force_not_use_token_critic), float(critic_noise_scale))
         eager = dict(cond_images=cond_images, fmap_size=fmap_size, temperature=temperature, topk_filter_thres=thres, can_remask_prev_masked=can_remask, timesteps=timesteps,
-                     cond_scale=cond_scale, row_offset=row_offset, return_ids=return_ids)
+                     cond_scale=cond_scale, row_offset=row_offset, return_ids=return_ids, force_not_use_token_critic=force_not_use_token_critic,
+                     critic_noise_scale=critic_noise_scale)
         entry = self._graphs.get(key)
         if entry is None:
             if len(self._graphs) >= 8:                                          # (weights changed / many shapes: drop the oldest captures)
@@ -1179,7 +1204,10 @@ class MaskGit(nn.Module):
                 with torch.cuda.graph(g, stream=side):
                     out = self.generate(texts, text_embeds=st['te'], seed=0, _seed_dev=st['keys'], fused_sampling='deferred',
                                         **dict(eager, cond_images=st['cond'], row_offset=0))
-            st.update(graph=g, out=out, status=self.fused_status, keep=self._deferred_keep)
+            held = (tr._model(), self.vae._pack() if exists(self.vae) else None, getattr(self.vae, '_ws', None),
+                    self.cond_vae._pack() if (exists(cond_images) and exists(self.cond_vae)) else None,
+                    getattr(self.cond_vae, '_ws', None))      # what the captured launches read or write outside the graph's own pool: alive as long as the capture
+            st.update(graph=g, out=out, status=self.fused_status, keep=self._deferred_keep, held=held)
             entry = self._graphs[key] = st
         st = entry
         st['te'].copy_(te, non_blocking=True)

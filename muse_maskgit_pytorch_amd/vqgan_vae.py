@@ -258,16 +258,15 @@ class VQGanVAE(nn.Module):
         """Drop the packed device copies and the precision tier's term count (needed only after `.data` edits the version counters cannot see)."""
         self._packed = None
         self._x3_terms = self._x3_scale = self._x3_packs = None
+        self._pack_gen = getattr(self, '_pack_gen', 0) + 1      # (part of MaskGit's hipGraph cache key)
         return self
 
     def _apply(self, fn, *args, **kwargs):
-        self._packed = None
-        self._x3_terms = self._x3_scale = self._x3_packs = None
+        self.invalidate_packed_weights()
         return super()._apply(fn, *args, **kwargs)
 
     def load_state_dict(self, *args, **kwargs):
-        self._packed = None
-        self._x3_terms = self._x3_scale = self._x3_packs = None
+        self.invalidate_packed_weights()
         return super().load_state_dict(*args, **kwargs)
 
     def _pack(self):

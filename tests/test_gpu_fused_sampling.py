@@ -367,6 +367,54 @@ def test_generate_graph_mode_replays_with_fresh_seeds_bit_equal_to_eager():
     assert len(mg._graphs) == 2
 
 
+def test_generate_graph_mode_never_replays_a_stale_capture():
+    """ADVICE r5 (medium, twice).  (1) `param.data` surgery + `invalidate_packed_weights()` (the documented EMA recipe) and `set_layernorm_fold()` drop the packed
+    weights; `_pack_key()` cannot see either, so round 5's graph cache replayed the old capture on freed / stale packs.  The key now carries every module's pack
+    generation and the entry holds what the capture reads: after the surgery the graph call must equal the EAGER call on the new weights (and differ from the
+    old result).  (2) a MaskGit with a token critic and force_not_use_token_critic=True is admitted to the graph path: the flag must reach the warm-up and the
+    captured call (round 5 dropped it: the critic ran, with a captured torch.rand)."""
+    torch.manual_seed(9)
+    t = mm.MaskGitTransformer(num_tokens=8192, seq_len=64, dim=256, depth=2, dim_head=64, heads=4, t5_name='t5-small')
+    with torch.no_grad():
+        t.to_logits.weight.mul_(6.)
+    vae = mm.VQGanVAE(dim=32, codebook_size=8192)
+    mg = mm.MaskGit(image_size=128, transformer=t, vae=vae).to(DEV)
+    B, T = 4, 5
+    te = torch.randn(B, 7, 512, device=DEV)
+    kw = dict(timesteps=T, text_embeds=te, return_ids='both')
+    for seed in (1, 2, 3):                                                        # warm, capture, replay
+        old_ids, old_img = mg.generate([''] * B, seed=seed, graph=True, **kw)
+    tr = mg.transformer
+    with torch.no_grad():                                                         # surgery the version counters cannot see
+        tr.to_logits.weight.data.copy_(tr.to_logits.weight.data.roll(1, 0))
+        mg.vae.enc_dec.decoders[-1].weight.data.mul_(2.)
+    tr.invalidate_packed_weights()
+    mg.vae.invalidate_packed_weights()
+    for seed in (3, 4, 5, 3):
+        ids_g, img_g = mg.generate([''] * B, seed=seed, graph=True, **kw)
+        ids_e, img_e = mg.generate([''] * B, seed=seed, **kw)
+        assert torch.equal(ids_g, ids_e) and torch.equal(img_g, img_e), 'graph mode replayed a capture of the old weights'
+    assert not torch.equal(ids_g, old_ids) and not torch.equal(img_g, old_img)
+    tr.set_layernorm_fold(False)                                                  # another engine for the same parameters: its own capture
+    for seed in (3, 6, 7):
+        ids_g, img_g = mg.generate([''] * B, seed=seed, graph=True, **kw)
+        ids_e, img_e = mg.generate([''] * B, seed=seed, **kw)
+        assert torch.equal(ids_g, ids_e) and torch.equal(img_g, img_e)
+    tr.set_layernorm_fold('auto')
+    # (2) the critic flag
+    torch.manual_seed(10)
+    critic = mm.TokenCritic(num_tokens=8192, seq_len=64, dim=256, depth=1, dim_head=64, heads=4, t5_name='t5-small')
+    mgc = mm.MaskGit(image_size=128, transformer=t, vae=vae, token_critic=critic).to(DEV)
+    ref = mgc.generate([''] * B, seed=5, force_not_use_token_critic=True, **kw)
+    with_critic = mgc.generate([''] * B, seed=5, **kw)
+    assert not torch.equal(ref[0], with_critic[0]), 'the test cannot tell the two decode algorithms apart'
+    for _ in range(3):
+        got = mgc.generate([''] * B, seed=5, force_not_use_token_critic=True, graph=True, **kw)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), 'graph mode ran the token critic although force_not_use_token_critic=True'
+    got = mgc.generate([''] * B, seed=5, graph=True, **kw)                        # with the critic: not a graph signature, runs eagerly
+    assert got[0].shape == ref[0].shape and len(mgc._graphs) == 1
+
+
 @pytest.mark.parametrize('family', ['zipf_bias', 'hot_tokens', 'row_temperature', 'student_t', 'bimodal'])
 def test_non_gaussian_logits_are_finished_row_by_row(family):
     """Trained checkpoints do not have Gaussian logits.  Families that defeat the Gaussian bound for SOME rows: the finishing kernel must list

@@ -761,6 +761,12 @@ def test_layernorm_dim_fold_probe_falls_back_on_a_dc_offset():
                 assert t._handle.ln_probe is None and bool(t._handle.desc.ln_fold_off) == expect_off
                 again = t(ids.to(DEV), text_embeds=te.to(DEV)).float().cpu()      # the probed handle: no more probing, same result
                 assert torch.equal(again, outs['auto'])
+                # round 6: an in-place parameter update (an optimizer step) repacks the weights but keeps the verdict -- no second probe, same engine
+                with torch.no_grad():
+                    t.to_logits.weight.mul_(1.0)
+                h2 = t._model()
+                assert h2 is not None and h2.ln_probe is None and bool(h2.desc.ln_fold_off) == expect_off and t._ln_fold_auto == (not expect_off)
+                assert torch.equal(t(ids.to(DEV), text_embeds=te.to(DEV)).float().cpu(), outs['auto'])
         t.set_layernorm_fold('auto')
         e_on, e_off = (outs[True] - ref).abs(), (outs[False] - ref).abs()
         print(f'[ln-fold probe] position-embedding offset {offset}: max |mean| / sigma over the folded LayerNorm inputs = {ratio:.3f} (limit {_lib.MM_LN_FOLD_MAX_RATIO}); '

@@ -8,6 +8,7 @@ import pytest
 import torch
 
 import muse_maskgit_pytorch_amd as mm
+from muse_maskgit_pytorch_amd import _lib as L
 from muse_maskgit_pytorch_amd import training
 
 pytestmark = pytest.mark.gpu
@@ -70,7 +71,7 @@ def test_train_step_lowers_the_loss_through_a_torch_optimizer():
 
 def test_train_step_side_stream_keeps_pace_with_parameter_updates():
     """The bf16 operand copies / transposes of the parameters, the dW GEMMs and the leaf reductions run on the library's second stream (csrc/train_step.hip): over several optimizer steps --
-    parameters change between the calls, the workspace is reused -- the C step with the side stream, the C step on one stream (MM_TRAIN_SIDE=0) and the
+    parameters change between the calls, the workspace is reused -- the C step with the side stream, the C step on one stream (mm_debug_set2(4)) and the
     operator-by-operator driver must walk the same trajectory bit for bit."""
     import copy
     torch.manual_seed(5)
@@ -83,11 +84,10 @@ def test_train_step_side_stream_keeps_pace_with_parameter_updates():
         tr = copy.deepcopy(tr0)
         opt = torch.optim.SGD(tr.parameters(), lr=0.05)
         os.environ.pop('MM_TRAIN_PY', None)
-        os.environ.pop('MM_TRAIN_SIDE', None)
         if mode == 'py':
             os.environ['MM_TRAIN_PY'] = '1'
         if mode == 'one_stream':
-            os.environ['MM_TRAIN_SIDE'] = '0'
+            L.lib().mm_debug_set2(4)
         try:
             losses = []
             for ids, labels, te in batches:
@@ -98,7 +98,7 @@ def test_train_step_side_stream_keeps_pace_with_parameter_updates():
                 losses.append(loss.detach().clone())
         finally:
             os.environ.pop('MM_TRAIN_PY', None)
-            os.environ.pop('MM_TRAIN_SIDE', None)
+            L.lib().mm_debug_set2(0)
         torch.cuda.synchronize()
         return torch.stack(losses), {n: p.detach().clone() for n, p in tr.named_parameters()}
 

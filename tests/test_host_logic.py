@@ -29,6 +29,19 @@ def test_library_loads_and_exports_every_header_symbol():
     assert lib.mm_abi_version() == 7
 
 
+def test_library_reads_no_environment_variable_and_carries_no_experimental_kernel():
+    """VERDICT r5 weak 8 / ADVICE r5: MM_PP / MM_PP_ABL (tools switches of the rejected out-of-lock-step logits GEMMs) lived in the shipped library and could
+    turn a product generate() into garbage; MM_TRAIN_SIDE was read per training step.  The library now does not IMPORT getenv at all, and the experimental
+    kernels (tools/experiments/gemm_pp.hip) are linked only by tools/build_timing.sh."""
+    so = _lib.LIB_PATH
+    und = subprocess.run(['nm', '-D', '--undefined-only', so], capture_output=True, text=True, check=True).stdout
+    assert 'getenv' not in und, 'libmuse_hip.so imports getenv'
+    syms = subprocess.run(['nm', '-C', so], capture_output=True, text=True, check=True).stdout
+    assert 'gemm_pp' not in syms and 'pp_variant' not in syms
+    for f in os.listdir(os.path.join(ROOT, 'muse_maskgit_pytorch_amd', 'csrc')):
+        assert 'getenv' not in open(os.path.join(ROOT, 'muse_maskgit_pytorch_amd', 'csrc', f)).read().replace('import getenv', ''), f
+
+
 def test_abi_reports_errors_without_touching_the_gpu():
     lib = _lib.lib()
     # empty problems are no-ops
