@@ -180,7 +180,6 @@ class _Handle:
         return self.packed is not None and (self.packed.get('wsub') is not None or self.packed.get('wcov') is not None)
 
     def _recreate(self):
-        self.gen = getattr(self, 'gen', 0) + 1      # (a captured hipGraph names the buffers of the C handle it was captured with: MaskGit._generate_graphed keys on this)
         L.lib().mm_transformer_destroy(self.ptr)
         self.ptr = C.c_void_p()
         L.check(L.lib().mm_transformer_create(C.byref(self.desc), C.byref(self.ptr)), 'mm_transformer_create')
@@ -200,6 +199,7 @@ class _Handle:
         owner = self.owner() if self.owner is not None else None
         if owner is not None:
             owner._ln_fold_auto = not off           # the verdict outlives this packed copy (Transformer._model)
+            owner._ln_fold_ratio = self.ln_ratio
         self.desc.ln_probe, self.desc.ln_fold_off = None, int(off)
         self.ln_probe = None
         self._recreate()
@@ -380,7 +380,8 @@ class Transformer(nn.Module):
 
     @property
     def layernorm_fold_ratio(self):
-        return self._handle.ln_ratio if self._handle is not None else None
+        r = self._handle.ln_ratio if self._handle is not None else None
+        return r if r is not None else getattr(self, '_ln_fold_ratio', None)
 
     def linear_weights(self):
         """every nn.Linear weight of the hot path (what the precision tier packs as bf16 term segments)"""
@@ -1169,7 +1170,7 @@ class MaskGit(nn.Module):
         them after its launches (the one host synchronisation); a replay whose status asks for the logits path is repeated eagerly with it.
         What a capture names: the packed weights of the transformer handle and of the VAE(s), the workspaces and the static inputs -- the entry holds
         references to all of them, and the key carries the pack GENERATION of every module (bumped by `invalidate_packed_weights()`, `set_layernorm_fold()`,
-        `.to()`, `load_state_dict()`) and of the C handle (bumped whenever it is re-created), so surgery the version counters cannot see never replays a stale capture."""
+        `.to()`, `load_state_dict()`), so surgery the version counters cannot see never replays a stale capture."""
         tr = self.transformer
         dev = tr.token_emb.weight.device
         if not exists(text_embeds):
@@ -1180,8 +1181,9 @@ class MaskGit(nn.Module):
         vkey = self.vae._pack_key() if exists(self.vae) else None
         ckey = self.cond_vae._pack_key() if (exists(cond_images) and self.cond_vae is not self.vae) else None
         hb = tr._model() if tr.precision == 'bf16' else None      # (packed here if need be: the key below names the bound this packed model currently uses)
-        hm = tr._model()
-        gens = (getattr(tr, '_pack_gen', 0), id(hm), getattr(hm, 'gen', 0), getattr(self.vae, '_pack_gen', 0) if exists(self.vae) else None,
+        # (the C handle owns no device memory -- nothing in csrc/ allocates -- so re-creating it, as the LayerNorm-fold probe of the warm-up call does, leaves a
+        #  capture's pointers valid; what a capture depends on are the packed tensors (held below) and the engine choices named in this key)
+        gens = (getattr(tr, '_pack_gen', 0), getattr(self.vae, '_pack_gen', 0) if exists(self.vae) else None,
                 getattr(self.cond_vae, '_pack_gen', 0) if exists(self.cond_vae) else None)
         key = (tuple(te.shape), None if not exists(cond_images) else tuple(cond_images.shape), fmap_size, float(temperature), float(thres), bool(can_remask), int(timesteps),
                float(cond_scale), return_ids, tr.precision, tr.fused_bound, hb.auto_bound if hb is not None else None, tr._pack_key(), vkey, ckey, gens,

@@ -12,7 +12,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import golden_recipe as R  # noqa: E402
-from reference_harness import reference_modules  # noqa: E402
+from reference_harness import DecisionRecorder, reference_modules  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden', 'superres_c4.pt')
 FULL_ROWS = [0, 77, 255, 256, 511, 700, 1000, 1023]
@@ -55,15 +55,7 @@ def main():
         return orig_fw(ids_, *a, **kw)
 
     tr.forward_with_cond_scale = fw
-    log = mmp.log
-
-    def gumbel_noise(t):
-        noise = torch.zeros_like(t).uniform_(0, 1)
-        rec['noise_checksum'].append(R.checksum(noise))
-        return -log(-log(noise))
-
-    orig_gn = mmp.gumbel_noise
-    mmp.gumbel_noise = gumbel_noise
+    dec = DecisionRecorder(mmp, (1, 1024), on_noise=lambda u: rec['noise_checksum'].append(R.checksum(u)))      # round 6: + what tests/tie_aware.py needs
     final = {}
     orig_dec = mg.vae.decode_from_ids
 
@@ -73,13 +65,12 @@ def main():
 
     mg.vae.decode_from_ids = dec_rec
     torch.manual_seed(R.C4_NOISE_SEED)
-    with torch.no_grad():
+    with torch.no_grad(), dec:
         images = mg.generate(['a'], cond_images=inp['cond_image'], timesteps=R.C4_T, cond_scale=3.)
-    mmp.gumbel_noise = orig_gn
     tr.forward_with_cond_scale = orig_fw
     for s, u in enumerate(R.noise_stream(R.C4_T, R.C4_NOISE_SEED, (1, 1024, 65536))):
         assert R.checksum(u) == rec['noise_checksum'][s], f'noise recipe does not reproduce step {s}'
-    out['generate'] = dict(step_in_ids=torch.stack(rec['step_in_ids']), final_ids=final['ids'].clone(), noise_checksum=rec['noise_checksum'],
+    out['generate'] = dict(step_in_ids=torch.stack(rec['step_in_ids']), final_ids=final['ids'].clone(), noise_checksum=rec['noise_checksum'], **dec.stacked(),
                            images_strided=images[:, :, ::8, ::8].clone(), images_absmax=images.abs().max().item())
     torch.save(out, OUT)
     print(f'wrote {OUT} ({os.path.getsize(OUT) / 1e6:.1f} MB) in {time.time() - t0:.0f}s')

@@ -12,7 +12,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import golden_recipe as R  # noqa: E402
-from reference_harness import reference_modules  # noqa: E402
+from reference_harness import DecisionRecorder, reference_modules  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden', 'paper_c5.pt')
 FULL_ROWS = [0, 77, 255, 256, 300, 411, 500, 511]
@@ -59,23 +59,14 @@ def main():
         return orig_fw(ids_, *a, **kw)
 
     tr.forward_with_cond_scale = fw
-    log = mmp.log
-
-    def gumbel_noise(t):
-        noise = torch.zeros_like(t).uniform_(0, 1)
-        rec['noise_checksum'].append(R.checksum(noise))
-        return -log(-log(noise))
-
-    orig_gn = mmp.gumbel_noise
-    mmp.gumbel_noise = gumbel_noise
+    dec = DecisionRecorder(mmp, (2, 256), on_noise=lambda u: rec['noise_checksum'].append(R.checksum(u)))      # round 6: + what tests/tie_aware.py needs
     torch.manual_seed(R.C5_NOISE_SEED)
-    with torch.no_grad():
+    with torch.no_grad(), dec:
         mg.generate(['a', 'b'], fmap_size=16, timesteps=R.C5_T, cond_scale=3.)
-    mmp.gumbel_noise = orig_gn
     tr.forward_with_cond_scale = orig_fw
     for s, u in enumerate(R.noise_stream(R.C5_T, R.C5_NOISE_SEED, (2, 256, 8192))):
         assert R.checksum(u) == rec['noise_checksum'][s], f'noise recipe does not reproduce step {s}'
-    out['generate'] = dict(step_in_ids=torch.stack(rec['step_in_ids']), final_ids=final['ids'].clone(), noise_checksum=rec['noise_checksum'])
+    out['generate'] = dict(step_in_ids=torch.stack(rec['step_in_ids']), final_ids=final['ids'].clone(), noise_checksum=rec['noise_checksum'], **dec.stacked())
     torch.save(out, OUT)
     print(f'wrote {OUT} ({os.path.getsize(OUT) / 1e6:.1f} MB) in {time.time() - t0:.0f}s')
 

@@ -117,3 +117,61 @@ class NoiseTape:
     def __exit__(self, *exc):
         self.mmp.gumbel_noise, = self._orig
         return False
+
+
+class DecisionRecorder:
+    """What tests/tie_aware.py needs from the reference's OWN run of MaskGit.generate, recorded without changing a value it computes
+    (the recipe of oracle/make_golden_base.py, shared by make_golden_c4.py / make_golden_c5.py since round 6):
+      scores_in      the tensor entering every step's `scores.topk(num_token_masked)` (muse_maskgit_pytorch.py:561),
+      pred_ids       what `gumbel_sample` returned (:580; the reference's own function runs),
+      argmax_margin  top-1 / top-2 gap of its perturbed logits in LOGIT units (an error d of a logit moves logits / T + gumbel by d / T),
+      noise          `on_noise(uniforms)` is called with every uniform draw of gumbel_noise (:406-408: identical draw).
+    Use:  with DecisionRecorder(mmp, (B, n), on_noise) as rec: mg.generate(...)   ->  rec.stacked()"""
+
+    def __init__(self, mmp, scores_shape, on_noise=None):
+        self.mmp, self.shape, self.on_noise = mmp, tuple(scores_shape), on_noise
+        self.scores_in, self.pred_ids, self.argmax_margin = [], [], []
+        self._last_gumbel = None
+
+    def __enter__(self):
+        import torch
+        mmp, rec = self.mmp, self
+        self._orig = (mmp.gumbel_noise, mmp.gumbel_sample, torch.Tensor.topk)
+        orig_gs, orig_topk, log = mmp.gumbel_sample, torch.Tensor.topk, mmp.log
+
+        def gumbel_noise(t):
+            noise = torch.zeros_like(t).uniform_(0, 1)
+            if rec.on_noise is not None:
+                rec.on_noise(noise)
+            rec._last_gumbel = -log(-log(noise))
+            return rec._last_gumbel
+
+        def gumbel_sample(t, temperature=1., dim=-1):
+            pred = orig_gs(t, temperature=temperature, dim=dim)
+            rec.pred_ids.append(pred.clone().to(torch.int32))
+            g, rec._last_gumbel = rec._last_gumbel, None
+            if temperature > 0:
+                top2 = orig_topk(t / max(temperature, 1e-10) + g, 2, dim=-1).values
+                rec.argmax_margin.append(((top2[..., 0] - top2[..., 1]) * temperature).clone())
+            else:      # last step (temperature 0 -> 1e-10): a pure arg-max of the kept logits
+                top2 = orig_topk(t, 2, dim=-1).values
+                rec.argmax_margin.append((top2[..., 0] - top2[..., 1]).clone())
+            return pred
+
+        def topk_rec(self_, *a, **kw):      # `scores.topk(num_token_masked, dim=-1)` is the only 2-D float top-k of that shape in the loop
+            if self_.dim() == 2 and tuple(self_.shape) == rec.shape and self_.is_floating_point():
+                rec.scores_in.append(self_.clone())
+            return orig_topk(self_, *a, **kw)
+
+        mmp.gumbel_noise, mmp.gumbel_sample, torch.Tensor.topk = gumbel_noise, gumbel_sample, topk_rec
+        return self
+
+    def __exit__(self, *exc):
+        import torch
+        self.mmp.gumbel_noise, self.mmp.gumbel_sample, torch.Tensor.topk = self._orig
+        return False
+
+    def stacked(self):
+        import torch
+        assert len(self.scores_in) == len(self.pred_ids) == len(self.argmax_margin)
+        return dict(scores_in=torch.stack(self.scores_in), pred_ids=torch.stack(self.pred_ids), argmax_margin=torch.stack(self.argmax_margin))

@@ -106,3 +106,44 @@ def compare_forced_step(ref, s, new_ids, new_scores, counts, mask_id, eps, selec
             # outside the excused positions the two sets have the same size on both sides
             skipped_band += int(band.sum())
     return int(near.sum()), skipped_band
+
+
+# ------------------------------------------------------------------------------------------------ the smallest eps that explains a run (round 6)
+def _passes(fn, eps):
+    try:
+        fn(eps)
+        return True
+    except AssertionError:
+        return False
+
+
+def min_eps(fn, lo=1e-7, hi=64., rel=0.02):
+    """`fn(eps)` raises AssertionError when eps does not explain the run; bands only grow with eps, so the set of passing eps is an interval [eps*, inf).
+    Returns eps* to `rel` relative accuracy by geometric bisection (0. when even `lo` passes, None when `hi` does not)."""
+    if _passes(fn, lo):
+        return 0.
+    if not _passes(fn, hi):
+        return None
+    while hi / lo > 1. + rel:
+        mid = (lo * hi) ** 0.5
+        if _passes(fn, mid):
+            hi = mid
+        else:
+            lo = mid
+    return hi
+
+
+def band_population(ref, counts, mask_id, eps):
+    """how much of the reference's run lies inside a tie band at `eps` -- what a contract at that eps EXCUSES: (sampling near-ties / sampled positions,
+    boundary-band positions / live positions at the re-masking steps)"""
+    T, B, n = ref['step_in_ids'].shape
+    near = sampled = band = live = 0
+    for s in range(T):
+        masked = ref['step_in_ids'][s].long() == mask_id
+        near += int(((ref['argmax_margin'][s] < eps) & masked).sum())
+        sampled += int(masked.sum())
+        if s + 1 < T:
+            for b in range(B):
+                band += int(boundary_band(ref['scores_in'][s + 1, b], counts[s + 1], eps).sum())
+                live += int((ref['scores_in'][s + 1, b] > MASK_FILL / 2).sum())
+    return near / max(sampled, 1), band / max(live, 1)
