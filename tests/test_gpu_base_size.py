@@ -2,13 +2,17 @@
 18 decode steps.  tests/golden/base_c2.pt was recorded from the UNMODIFIED reference (oracle/make_golden_base.py); checkpoint and noise are
 rebuilt from the seeded recipe (oracle/golden_recipe.py) and their checksums asserted first.
 
-Three engines are compared with the same fixture:
-  precision 'bf16x3' -- the tolerance-meeting tier INSIDE mm_generate / mm_transformer_forward (csrc/split.hip: exact three-term bf16 splits
-                        of every GEMM activation on the bf16 matrix pipe, 3 products for these bf16-representable checkpoints; fp32 MFMA
-                        attention): the north star's bar, logits within 1e-3 absolute, every step's ids 100 %, through the C loop.
-  precision 'parity' -- fp32 storage + fp32 MFMA (csrc/parity.hip), operator by operator from Python: same bar, the tier's verification baseline.
-  precision 'bf16'   -- the production engine: bounds are what bf16 operands achieve at this size (stated per assert), ids compared
-                        through the oracle tail on the engine's own logits (bit-exact) and, informationally, with the reference run.
+Engines compared with the same fixtures (bf16-representable AND general fp32 checkpoints):
+  precision 'f16x2'  -- THE tolerance-meeting tier (rounds 4-5; bench.py's `parity_tier`) INSIDE mm_generate / mm_transformer_forward: every GEMM operand as two
+                        fp16 terms, products xh wh + xl wh (+ xh wl) on the fp16 matrix pipe with term sharing (csrc/gemm_terms.hip; the 'f16x2-terms' entries
+                        force those kernels onto the fixtures' B = 2), self-attention as fp16 term products: the north star's bar -- logits within 1e-3
+                        absolute, every step's ids 100 % -- through the C loop.
+  precision 'bf16x3' -- round 3's tier (three bf16 terms, 3 / 6 products): same bar, kept as a second independent implementation of it.
+  precision 'parity' -- fp32 storage + fp32 MFMA (csrc/parity.hip), operator by operator from Python: same bar, the tiers' verification baseline.
+  precision 'bf16'   -- the production engine (the bench line's `value`): logit bounds are what bf16 operands achieve at this size (stated per assert); ids are
+                        compared through the oracle tail on the engine's own logits (bit-exact) and -- round 6 -- held to a TIE-AWARE CONTRACT against the
+                        reference's run on all five full-size fixtures: every id / re-masked position that differs must lie inside a tie band of the REFERENCE's
+                        own margins whose width is the engine's stated logit bound (test_bf16_engine_differs_from_the_reference_only_inside_tie_bands_*).
 """
 import os
 import sys
@@ -47,6 +51,11 @@ def _term_sharing_kernel(request):
 # tests): logits 1.95e-2 max / 2.9e-3 mean (1.33e-2 / 2.2e-3 on the bf16-representable checkpoint), guidance-combined 6.5e-2, embed 3.7e-2,
 # final ids 95.9 % / worst step 94.3 % equal to the reference run -- the weight rounding costs about half again of the activation rounding's error
 BF16_FP32W_LOGITS, BF16_FP32W_EMBED, BF16_FP32W_IDS = 3.5e-2, 6e-2, 0.90
+# Round 6: the bf16 engine's stated bound G on the GUIDANCE-COMBINED logits null + 3 (cond - null) (what the sampler consumes), per fixture, at the fixtures' unit logit
+# scale: measured 0.045 (base, bf16-representable weights) / 0.065 (base, general fp32 weights) / 0.040 (super-res) / 0.070 (paper scale), stated 1.3 x that
+# (rounds 1-5 asserted 5 x the per-pass bound = 0.125 / 0.175: no contract at all).  The SAME number is the width of the tie band the engine's ids are held to:
+# a decision of the reference run may differ only where the reference's own margin is below PEAK x G logit units (_bf16_tie_contract).
+BF16_GUIDANCE = dict(base_bf16w=0.06, base_fp32w=0.085, c4=0.055, c5=0.09)
 
 
 @pytest.fixture(scope='module', params=['base_c2.pt', 'base_c2_fp32.pt'], ids=['bf16w', 'fp32w'])
@@ -123,8 +132,9 @@ def test_transformer_forward_logits_at_base_size(base, precision):
         _err(f'{precision} {name} full rows', rows, rec['rows'], tol)
         _err(f'{precision} {name} strided columns', cols, rec['cols'], tol)
     rows, cols = _samples(sc)
-    _err(f'{precision} logits(guidance 3.0) full rows', rows, fw['logits_scaled']['rows'], tol * 5)      # null + 3 (cond - null): errors add up to 5x
-    _err(f'{precision} logits(guidance 3.0) strided columns', cols, fw['logits_scaled']['cols'], tol * 5)
+    gtol = tol * 5 if precision in EXACT else BF16_GUIDANCE['base_fp32w' if _fp32w(g) else 'base_bf16w']      # null + 3 (cond - null): errors add up to 5x
+    _err(f'{precision} logits(guidance 3.0) full rows', rows, fw['logits_scaled']['rows'], gtol)
+    _err(f'{precision} logits(guidance 3.0) strided columns', cols, fw['logits_scaled']['cols'], gtol)
     _err(f'{precision} embed', emb.reshape(R.B, R.N, -1), fw['embed'], 1e-3 if precision in EXACT else (BF16_FP32W_EMBED if _fp32w(g) else 4e-2))
 
 
@@ -271,6 +281,87 @@ def test_generate_on_the_unscanned_fp32_fixture_tie_aware(base_s77, noise, preci
         torch.cuda.empty_cache()
 
 
+
+# ------------------------------------------------------------------------------------------------ the bf16 engine's id contract (round 6, VERDICT r5 missing 2)
+def _bf16_tie_contract(name, gen, mg, te, noise, V, E, fwd_kw=None, gen_kw=None, texts=('a', 'b'), free=True):
+    """The headline engine cannot be bit-equal to an fp32 run: its logits are off by up to its stated bound.  What CAN be demanded of it -- and falsified -- is
+    that it never takes a decision the reference's own numbers call clear: with eps* = the smallest eps (logit units) at which tests/tie_aware.py explains
+    every difference by a tie band of the REFERENCE's recorded margins,
+      * teacher-forced on the reference's states with the reference's noise, every one of the T steps (so also what lies behind a divergence): every
+        sampled id equals the reference's outside its arg-max near-ties, every re-masked set outside the boundary band;
+      * free-running through mm_generate: each sample equals the reference's trajectory or first parts from it inside a band;
+    eps* must not exceed E = PEAK x G, G = the engine's asserted bound on the guidance-combined logits (BF16_GUIDANCE; the forward tests hold the engine to the same
+    number).  Printed beside it: the share of the reference's decisions a band of that width covers, i.e. how much the contract excuses.
+    Measured (round 6, gpurun_out/r6b): eps* = 0.21 - 0.30 logit units on logits of std 4.7 (x 8 peaky): a band that covers 7 - 20 % of the reference's decisions;
+    the rounds 1-5 floor "ids >= 0.90 equal" said nothing about WHERE the other 4 - 9 % may lie."""
+    import tie_aware as TA
+    tr = mg.transformer
+    T, B, n = gen['step_in_ids'].shape
+    counts, temps = O.mask_counts(T, n), O.step_temperatures(T, 1.)
+    forced, agree = [], []
+    for s in range(T):
+        ids_in = gen['step_in_ids'][s].long()
+        logits = tr.forward_with_cond_scale(ids_in.to(DEV), text_embeds=te, cond_scale=3., **(fwd_kw or {})).cpu()
+        new_ids, scores, _ = O.sample_step(logits, O.gumbel_from_uniform(noise[s].cpu()), ids_in, V, temps[s])
+        del logits
+        masked = ids_in == V
+        agree.append(((new_ids == gen['pred_ids'][s].long()) | ~masked).float().mean().item())
+        forced.append((new_ids, scores))
+
+    def check_forced(eps):
+        for s, (ni, sc) in enumerate(forced):
+            TA.compare_forced_step(gen, s, ni, sc, counts, V, eps, O.select_topk_stable)
+
+    eps_forced = TA.min_eps(check_forced)
+    if not free:      # (super-resolution when the engine's own condition ids differ from the reference's: a free run then starts from another condition)
+        assert eps_forced is not None and eps_forced <= E, (name, eps_forced, E)
+        near, band = TA.band_population(gen, counts, V, max(eps_forced, 1e-9))
+        print(f'[bf16 id contract] {name}: teacher-forced over {T} steps sampled ids equal to the reference {100 * min(agree):.2f} % (worst step); smallest eps that explains every '
+              f'difference: {eps_forced:.3g} logit units (contract E = PEAK x G = {E:.3g}); a band of that width covers {100 * near:.2f} % of the sampling decisions and '
+              f'{100 * band:.2f} % of the re-masking candidates; free run not compared (the condition ids differ)')
+        return eps_forced, None
+    trace = {}
+    ids = mg.generate(list(texts[:B]), timesteps=T, cond_scale=3., text_embeds=te, noise=noise.to(DEV), noise_kind='uniform', return_ids=True, trace=trace, **(gen_kw or {}))
+    masked_ids = torch.stack(list(trace['masked_ids'])).cpu() if isinstance(trace['masked_ids'], list) else trace['masked_ids'].cpu()
+    eps_free = TA.min_eps(lambda e: TA.compare_free_run(gen, masked_ids, ids.cpu(), counts, V, e))
+    assert eps_forced is not None and eps_free is not None, f'{name}: a difference from the reference run lies outside every tie band'
+    eps_star = max(eps_forced, eps_free)
+    near, band = TA.band_population(gen, counts, V, max(eps_star, 1e-9))
+    near_b, band_b = TA.band_population(gen, counts, V, E)
+    rep = TA.compare_free_run(gen, masked_ids, ids.cpu(), counts, V, max(eps_free, 1e-9))
+    print(f'[bf16 id contract] {name}: teacher-forced over {T} steps sampled ids equal to the reference {100 * min(agree):.2f} % (worst step); smallest eps that explains EVERY '
+          f'difference by a tie band of the reference: teacher-forced {eps_forced:.3g}, free run {eps_free:.3g} logit units (contract E = PEAK x G = {E:.3g}); a band of eps* covers '
+          f'{100 * near:.2f} % of the sampling decisions and {100 * band:.2f} % of the re-masking candidates (at E: {100 * near_b:.2f} % / {100 * band_b:.2f} %); free run: '
+          + '; '.join(f"sample {b}: {r['status']}" + (f" at step {r['step']} ({r['kind']})" if r['status'] == 'tie' else '') for b, r in enumerate(rep)))
+    assert eps_star <= E, f'{name}: eps* = {eps_star:.3g} > E = {E:.3g}: the bf16 engine took a decision the reference calls clear at its stated logit bound'
+    return eps_forced, eps_free
+
+
+def test_bf16_engine_differs_from_the_reference_only_inside_tie_bands_base(base, noise):
+    """configs[1], both checkpoints (scanned input seeds).  E = PEAK x the asserted bound on the guidance-combined logits (test_transformer_forward_logits_at_base_size
+    holds the engine to exactly that number)."""
+    g, mg, inp = base
+    tr = mg.transformer
+    G = BF16_GUIDANCE['base_fp32w' if _fp32w(g) else 'base_bf16w']
+    with torch.no_grad():
+        tr.to_logits.weight.mul_(R.PEAK)
+    try:
+        assert R.state_checksum(tr) == g['weight_checksum_peaky']
+        _bf16_tie_contract('base_c2_fp32' if _fp32w(g) else 'base_c2', g['generate'], mg, inp['text_embeds'].to(DEV), noise, 65536, R.PEAK * G)
+    finally:
+        with torch.no_grad():
+            tr.to_logits.weight.div_(R.PEAK)
+        torch.cuda.empty_cache()
+
+
+def test_bf16_engine_differs_from_the_reference_only_inside_tie_bands_unscanned(base_s77, noise):
+    """the general fp32 checkpoint on the UN-SCANNED input seed (the reference's own run has a 2.3e-6 near-tie there)"""
+    g, mg, inp = base_s77
+    try:
+        _bf16_tie_contract('base_c2_fp32_s77', g['generate'], mg, inp['text_embeds'].to(DEV), noise, 65536, R.PEAK * BF16_GUIDANCE['base_fp32w'], gen_kw=dict(fmap_size=16))
+    finally:
+        torch.cuda.empty_cache()
+
 # ------------------------------------------------------------------------------------------------ BASELINE configs[3]: super-resolution at full size
 C4_ROWS = [0, 77, 255, 256, 511, 700, 1000, 1023]
 
@@ -312,8 +403,9 @@ def test_superres_forward_and_generate_at_full_size(superres, precision):
         tol = 1e-3 if precision in EXACT else 2.5e-2
         for name, got, rec, k in (('logits(cond)', lc, fw['logits_cond'], 1), ('logits(null)', ln, fw['logits_null'], 1), ('logits(guidance)', sc, fw['logits_scaled'], 5)):
             f = got.reshape(1024, -1)
-            _err(f'{precision} super-res {name} full rows', f[C4_ROWS], rec['rows'], tol * k)
-            _err(f'{precision} super-res {name} strided columns', f[:, ::128], rec['cols'], tol * k)
+            bound = BF16_GUIDANCE['c4'] if (k == 5 and precision not in EXACT) else tol * k
+            _err(f'{precision} super-res {name} full rows', f[C4_ROWS], rec['rows'], bound)
+            _err(f'{precision} super-res {name} strided columns', f[:, ::128], rec['cols'], bound)
         _err(f'{precision} super-res embed', emb.reshape(1, 1024, -1), fw['embed'], 1e-3 if precision in EXACT else 4e-2)
         # ---- generate, peaky logits, the reference's noise
         gen = g['generate']
@@ -343,6 +435,10 @@ def test_superres_forward_and_generate_at_full_size(superres, precision):
                 out2 = mg.generate(['a'], cond_images=inp['cond_image'].to(DEV), timesteps=R.C4_T, cond_scale=3., text_embeds=te, noise=noise, noise_kind='uniform',
                                    return_ids=True, fused_sampling=False)
                 assert torch.equal(out, out2)      # both sampling paths give bit-identical confidences (common.h tile_softmax_stats)
+                # round 6: the tie-aware id contract (the engine's own condition ids differ from the reference's in a few LFQ sign near-ties: the free run uses them,
+                # the teacher-forced steps the reference's)
+                _bf16_tie_contract('superres_c4', gen, mg, te, noise, 65536, R.PEAK * BF16_GUIDANCE['c4'], fwd_kw=dict(conditioning_token_ids=g['cond_ids'].to(DEV)),
+                                   gen_kw=dict(cond_images=inp['cond_image'].to(DEV)), texts=('a',), free=(agree == 1.0))
         finally:
             with torch.no_grad():
                 tr.to_logits.weight.div_(R.PEAK)
@@ -384,8 +480,9 @@ def test_paper_scale_forward_and_generate_at_full_size(paper, precision):
         tol = 1e-3 if precision in EXACT else 3.5e-2
         for name, got, rec, k in (('logits(cond)', lc, fw['logits_cond'], 1), ('logits(null)', ln, fw['logits_null'], 1), ('logits(guidance)', sc, fw['logits_scaled'], 3)):
             f = got.reshape(512, -1)
-            _err(f'{precision} paper-scale {name} full rows', f[C5_ROWS], rec['rows'], tol * k)
-            _err(f'{precision} paper-scale {name} strided columns', f[:, ::16], rec['cols'], tol * k)
+            bound = BF16_GUIDANCE['c5'] if (k == 3 and precision not in EXACT) else tol * k
+            _err(f'{precision} paper-scale {name} full rows', f[C5_ROWS], rec['rows'], bound)
+            _err(f'{precision} paper-scale {name} strided columns', f[:, ::16], rec['cols'], bound)
         _err(f'{precision} paper-scale embed', emb[:, ::4], fw['embed'], 1e-3 if precision in EXACT else 0.06)
         gen = g['generate']
         us = []
@@ -413,6 +510,7 @@ def test_paper_scale_forward_and_generate_at_full_size(paper, precision):
                 out2 = mg.generate(['a', 'b'], fmap_size=16, timesteps=R.C5_T, cond_scale=3., text_embeds=te, noise=noise, noise_kind='uniform', return_ids=True,
                                    fused_sampling=False)
                 assert torch.equal(out, out2)      # both sampling paths give bit-identical confidences (common.h tile_softmax_stats)
+                _bf16_tie_contract('paper_c5', gen, mg, te, noise, 8192, R.PEAK * BF16_GUIDANCE['c5'], gen_kw=dict(fmap_size=16))
         finally:
             with torch.no_grad():
                 tr.to_logits.weight.div_(R.PEAK)
