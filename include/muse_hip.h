@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 7
+#define MM_ABI_VERSION 8
 
 #define MM_OK 0
 #define MM_ERR_SHAPE (-1)
@@ -302,11 +302,15 @@ typedef struct mm_vae_layer {
     const float* gn_b[2];
 } mm_vae_layer;
 typedef struct mm_vae_desc {
-    int32_t channels, encoded_dim, bits, n_enc, n_dec, reserved;
+    int32_t channels, encoded_dim, bits, n_enc, n_dec;
+    int32_t half;                   /* round 6 (ABI 8): 1 = DECODE-ONLY handle on fp16 storage -- the decoder's conv weights packed as fp16 x 1 / alpha, activations
+                                       NHWC fp16, single fp16 terms on the fp16 MFMA (mm_conv2d_nhwc_half); n_enc must be 0                                        */
     const mm_vae_layer* enc;        /* host array [n_enc]: stem, then down-sampling convolutions / residual blocks in list order */
     const mm_vae_layer* dec;        /* host array [n_dec]: GLU blocks / up-sampling convolutions in list order, head last       */
     const float* lfq_wi; const float* lfq_bi;      /* project_in  [bits][encoded_dim], [bits]  (NULL when encoded_dim == bits) */
     const float* lfq_wo; const float* lfq_bo;      /* project_out [encoded_dim][bits], [encoded_dim]                            */
+    float alpha;                    /* half != 0: the inverse of the power-of-two scale the fp16 conv weights were packed with (0 = 1) */
+    int32_t reserved;
 } mm_vae_desc;
 typedef struct mm_vae mm_vae_t;
 int mm_vae_create(const mm_vae_desc* desc, mm_vae_t** out);
@@ -404,6 +408,12 @@ int mm_gemm_split_geglu(mm_stream_t stream, const void* x, int64_t ldx, const vo
 int mm_conv2d_nhwc_f16(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
                        int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
                        int Hout, int Wout, const float* bias, int act, const float* resid_f32, float* out, int out_nchw_f32, float alpha);
+/* Round 6 -- the half-precision VAE decode: the same convolution on SINGLE fp16 terms with fp16 activation storage.  `in` NHWC fp16, w fp16 [Cout][Kp] packed
+ * x 1 / alpha (a power of two: ops.f16_weight_scale), fp32 accumulation; out NHWC fp16 (out_nchw_f32 = 0; optional resid NHWC fp16) or NCHW fp32 (= 1).  Same MFMA
+ * rate as bf16, 11 significand bits instead of 8: decoded pixels 2e-4 of the image scale instead of 1.6e-3 (values saturate at +-65504). */
+int mm_conv2d_nhwc_half(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
+                        int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
+                        int Hout, int Wout, const float* bias, int act, const void* resid, void* out, int out_nchw_f32, float alpha);
 /* ... with the operand code stated (round 5): products = MM_SPLIT_F16 | 2 / 3 segments per pixel (Cin = P x channels) and per tap of the weight rows; with
  * MM_SPLIT_SHARED (genuine packs: [xh | xl | xh] per pixel, [wh | wh | wl] per tap) the 256 x 128 kernel stages every term plane once (three products, channels % 32 == 0). */
 int mm_conv2d_nhwc_terms(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,

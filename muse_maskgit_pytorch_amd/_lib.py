@@ -70,8 +70,9 @@ class VaeLayer(C.Structure):
 
 
 class VaeDesc(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ('channels', 'encoded_dim', 'bits', 'n_enc', 'n_dec', 'reserved')] + \
-               [('enc', C.POINTER(VaeLayer)), ('dec', C.POINTER(VaeLayer)), ('lfq_wi', c_vp), ('lfq_bi', c_vp), ('lfq_wo', c_vp), ('lfq_bo', c_vp)]
+    _fields_ = [(n, C.c_int32) for n in ('channels', 'encoded_dim', 'bits', 'n_enc', 'n_dec', 'half')] + \
+               [('enc', C.POINTER(VaeLayer)), ('dec', C.POINTER(VaeLayer)), ('lfq_wi', c_vp), ('lfq_bi', c_vp), ('lfq_wo', c_vp), ('lfq_bo', c_vp),
+                ('alpha', c_f32), ('reserved', C.c_int32)]
 
 
 class GenerateParams(C.Structure):
@@ -137,6 +138,7 @@ SIGNATURES = {
     'mm_philox_uniform': (c_int, [c_vp, c_u64, c_u64, c_u32, c_int, c_int, c_vp]),
     'mm_conv2d_nhwc': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int] + [c_int] * 12 + [c_vp, c_int, c_vp, c_vp, c_int]),
     'mm_conv2d_nhwc_f16': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int] + [c_int] * 12 + [c_vp, c_int, c_vp, c_vp, c_int, c_f32]),
+    'mm_conv2d_nhwc_half': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int] + [c_int] * 12 + [c_vp, c_int, c_vp, c_vp, c_int, c_f32]),
     'mm_conv2d_nhwc_terms': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int] + [c_int] * 12 + [c_vp, c_int, c_vp, c_vp, c_int, c_f32, c_int]),
     'mm_glu_nhwc': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp]),
     'mm_groupnorm_nhwc': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
@@ -218,7 +220,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.mm_abi_version() != 7:
+        if l.mm_abi_version() != 8:
             raise MuseHipError('libmuse_hip ABI version mismatch')
         if os.environ.get('MM_DEBUG'):      # tools / A-B runs only: kernel-selection bits (see muse_hip_internal.h)
             l.mm_debug_set(int(os.environ['MM_DEBUG'], 0))

@@ -461,7 +461,7 @@ int mm_philox_uniform(mm_stream_t stream, uint64_t seed, uint64_t row_offset, ui
 
 static int conv2d_nhwc_impl(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
                             int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
-                            int Hout, int Wout, const float* bias, int act, const void* resid, void* out, int out_nchw_f32, int f16, float alpha, int terms);
+                            int Hout, int Wout, const float* bias, int act, const void* resid, void* out, int out_nchw_f32, int f16, float alpha, int terms, int half_io = 0);
 
 int mm_conv2d_nhwc(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
                    int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
@@ -480,6 +480,16 @@ int mm_conv2d_nhwc_f16(mm_stream_t stream, const void* in, int B, int Hin, int W
                             out_nchw_f32, 1, alpha, 0);
 }
 
+// the same convolution with SINGLE fp16 terms as operands and fp16 activation storage (round 6: the half-precision VAE decode): `in` NHWC fp16, w fp16 [Cout][Kp]
+// scaled by 1 / alpha, out NHWC fp16 (out_nchw_f32 = 0; resid NHWC fp16) or NCHW fp32 (= 1)
+int mm_conv2d_nhwc_half(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
+                        int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
+                        int Hout, int Wout, const float* bias, int act, const void* resid, void* out, int out_nchw_f32, float alpha) {
+    if (out_nchw_f32 != 0 && out_nchw_f32 != 1) return mm_set_error(MM_ERR_SHAPE, "conv_half: out_nchw_f32 = 0 (NHWC fp16) or 1 (NCHW fp32)");
+    return conv2d_nhwc_impl(stream, in, B, Hin, Win, Cin, w, Cout, TH, TW, stride, off_y, off_x, Hv, Wv, os, py, px, Hout, Wout, bias, act, resid, out,
+                            out_nchw_f32, 1, alpha, 0, 1);
+}
+
 int mm_conv2d_nhwc_terms(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
                          int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
                          int Hout, int Wout, const float* bias, int act, const float* resid_f32, float* out, int out_nchw_f32, float alpha, int products) {
@@ -492,7 +502,7 @@ int mm_conv2d_nhwc_terms(mm_stream_t stream, const void* in, int B, int Hin, int
 
 static int conv2d_nhwc_impl(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
                             int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
-                            int Hout, int Wout, const float* bias, int act, const void* resid, void* out, int out_nchw_f32, int f16, float alpha, int terms) {
+                            int Hout, int Wout, const float* bias, int act, const void* resid, void* out, int out_nchw_f32, int f16, float alpha, int terms, int half_io) {
     if (B == 0) return MM_OK;
     CHK_PTR(in, "in"); CHK_PTR(w, "w"); CHK_PTR(out, "out");
     CHK_ALIGN16(in, "in"); CHK_ALIGN16(w, "w"); CHK_ALIGN16(out, "out");
@@ -513,7 +523,7 @@ static int conv2d_nhwc_impl(mm_stream_t stream, const void* in, int B, int Hin, 
     if (out_nchw_f32 == 2) a.resid_f32 = (const float*)resid;      // fp32 NHWC in and out (the precision tier's convolutions: bf16 term segments in, fp32 out)
     else a.resid_bf16 = (const bf16_t*)resid;
     a.ldr = Cout;
-    a.f16 = f16; a.alpha = alpha; a.terms = terms;
+    a.f16 = f16; a.alpha = alpha; a.terms = terms; a.half_io = half_io;
     return mm_gemm_launch(a, (hipStream_t)stream);
 }
 

@@ -403,6 +403,29 @@ __device__ __forceinline__ float f16_bits_to_f32(uint16_t h) { return (float)__b
 // Range guard: both terms saturate at the largest finite fp16 (65504) instead of overflowing to infinity -- the pair then still represents |x| up to
 // 131008 exactly-ish (h = 65504, l = the rest) and stays FINITE beyond (the value is clipped: an activation of that size is outside what the tier can multiply
 // accurately, but one such element no longer turns a whole logits row into NaN through h = inf, l = x - inf = -inf).  One v_med3_f32 per term.
+// 16-bit activation storage chosen at compile time (round 6): bf16 (the default engine) or fp16 -- the single-term fp16 VAE decode (vae_model.hip `half`): the
+// same MFMA rate, 11 instead of 8 significand bits (decoded pixels 2e-4 instead of 1.6e-3 of the image scale), values saturated at the largest finite fp16.
+__device__ __forceinline__ uint32_t pack_f16x2_sat(float a, float b) {
+    return (uint32_t)f32_to_f16_bits(__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f)) | ((uint32_t)f32_to_f16_bits(__builtin_amdgcn_fmed3f(b, -65504.f, 65504.f)) << 16);
+}
+template <bool H> __device__ __forceinline__ uint4 pack8s(const float (&f)[8]) {
+    if constexpr (H) return make_uint4(pack_f16x2_sat(f[0], f[1]), pack_f16x2_sat(f[2], f[3]), pack_f16x2_sat(f[4], f[5]), pack_f16x2_sat(f[6], f[7]));
+    else return pack8(f);
+}
+template <bool H> __device__ __forceinline__ void unpack8s(const uint4& v, float (&f)[8]) {
+    if constexpr (H) {
+        f[0] = f16_bits_to_f32((uint16_t)v.x); f[1] = f16_bits_to_f32((uint16_t)(v.x >> 16)); f[2] = f16_bits_to_f32((uint16_t)v.y); f[3] = f16_bits_to_f32((uint16_t)(v.y >> 16));
+        f[4] = f16_bits_to_f32((uint16_t)v.z); f[5] = f16_bits_to_f32((uint16_t)(v.z >> 16)); f[6] = f16_bits_to_f32((uint16_t)v.w); f[7] = f16_bits_to_f32((uint16_t)(v.w >> 16));
+    } else {
+        unpack8(v, f);
+    }
+}
+template <bool H> __device__ __forceinline__ float ld16s(bf16_t h) {
+    if constexpr (H) return f16_bits_to_f32(__builtin_bit_cast(uint16_t, h)); else return bf16_to_f32(h);
+}
+template <bool H> __device__ __forceinline__ bf16_t st16s(float f) {
+    if constexpr (H) return __builtin_bit_cast(bf16_t, f32_to_f16_bits(__builtin_amdgcn_fmed3f(f, -65504.f, 65504.f))); else return f32_to_bf16(f);
+}
 __device__ __forceinline__ void split2_f16(float x, uint16_t& h, uint16_t& l) {
     h = f32_to_f16_bits(__builtin_amdgcn_fmed3f(x, -65504.f, 65504.f));
     l = f32_to_f16_bits(__builtin_amdgcn_fmed3f(x - f16_bits_to_f32(h), -65504.f, 65504.f));      // (the difference is exact in fp32)

@@ -532,19 +532,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                 const bf16_t* rp = p.resid_bf16 + orow * p.ldr + n;
                 if (full) {
                     float rv[8];
-                    unpack8(*reinterpret_cast<const uint4*>(rp), rv);
+                    if (F16 && p.half_io) unpack8s<true>(*reinterpret_cast<const uint4*>(rp), rv); else unpack8(*reinterpret_cast<const uint4*>(rp), rv);
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] += rv[r];
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) if (n + r < p.N) v[r] += bf16_to_f32(rp[r]);
+                    for (int r = 0; r < 8; ++r) if (n + r < p.N) v[r] += (F16 && p.half_io) ? ld16s<true>(rp[r]) : bf16_to_f32(rp[r]);
                 }
             }
             bf16_t* op = reinterpret_cast<bf16_t*>(outp) + orow * p.ldc + n;
-            if (full) *reinterpret_cast<uint4*>(op) = pack8(v);
+            if (full) *reinterpret_cast<uint4*>(op) = (F16 && p.half_io) ? pack8s<true>(v) : pack8(v);      // (round 6: fp16 storage of the single-term fp16 VAE decode)
             else {
 #pragma unroll
-                for (int r = 0; r < 8; ++r) if (n + r < p.N) op[r] = f32_to_bf16(v[r]);
+                for (int r = 0; r < 8; ++r) if (n + r < p.N) op[r] = (F16 && p.half_io) ? st16s<true>(v[r]) : f32_to_bf16(v[r]);
             }
         }
     }
@@ -629,8 +629,9 @@ int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
             if (!mm_gemm_terms_eligible(a)) return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: the GEGLU epilogue on fp16 term operands needs the term-sharing kernel's shape class");
             return mm_gemm_terms_launch(a, stream);
         }
-        if (a.out_kind == OUT_BF16 || a.mode == MODE_CFG || a.epi != EPI_NONE || (a.ln_part && !a.ln_c1) || a.splits > 1 || a.resid_bf16)
-            return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: fp16 term operands take the fp32-output dense / convolution forms only");
+        if (((a.out_kind == OUT_BF16 || a.resid_bf16) && !a.half_io) || a.mode == MODE_CFG || a.epi != EPI_NONE || (a.ln_part && !a.ln_c1) || a.splits > 1)
+            return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: fp16 term operands take the fp32-output dense / convolution forms only (16-bit fp16 outputs: half_io)");
+        if (a.half_io && (a.terms || a.xb_out || a.in_c1 || a.ln_c1)) return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: half_io is the plain single-term fp16 form");
         if (!(a.debug & (8 | (1 << 30))) && mm_gemm_terms_eligible(a)) return mm_gemm_terms_launch(a, stream);
         if (!a.m_dev && !(a.debug & 8) && mm_gemm_big_eligible(a)) return mm_gemm_big_launch(a, stream);
         a.tiles_n = (a.N + BT - 1) / BT;

@@ -396,19 +396,19 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
                 const bf16_t* rp = p.resid_bf16 + orow * p.ldr + n;
                 if (n + 7 < p.N) {
                     float rv[8];
-                    unpack8(*reinterpret_cast<const uint4*>(rp), rv);
+                    if (F16 && p.half_io) unpack8s<true>(*reinterpret_cast<const uint4*>(rp), rv); else unpack8(*reinterpret_cast<const uint4*>(rp), rv);
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] += rv[r];
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) if (n + r < p.N) v[r] += bf16_to_f32(rp[r]);
+                    for (int r = 0; r < 8; ++r) if (n + r < p.N) v[r] += (F16 && p.half_io) ? ld16s<true>(rp[r]) : bf16_to_f32(rp[r]);
                 }
             }
             bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + orow * p.ldc + n;
-            if (n + 7 < p.N) *reinterpret_cast<uint4*>(op) = pack8(v);
+            if (n + 7 < p.N) *reinterpret_cast<uint4*>(op) = (F16 && p.half_io) ? pack8s<true>(v) : pack8(v);
             else {
 #pragma unroll
-                for (int r = 0; r < 8; ++r) if (n + r < p.N) op[r] = f32_to_bf16(v[r]);
+                for (int r = 0; r < 8; ++r) if (n + r < p.N) op[r] = (F16 && p.half_io) ? st16s<true>(v[r]) : f32_to_bf16(v[r]);
             }
         }
     }

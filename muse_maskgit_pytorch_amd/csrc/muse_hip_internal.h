@@ -46,6 +46,9 @@ struct GemmArgs {
     // `alpha` (the inverse of the power-of-two scale the weight terms were packed with; 0 = 1) before anything else in the epilogue.  fp32 output only,
     // dense and convolution modes, on the 128x128 / 256x128 kernels and the fused-sampling logits kernel.
     int f16; float alpha;
+    // round 6 (f16 only): 16-bit outputs / residuals of this launch are fp16, not bf16 (out_kind OUT_BF16 / resid_bf16 name the 16-bit container): the single-term
+    // fp16 VAE decode -- NHWC fp16 activations in and out, the head convolution to NCHW fp32
+    int half_io;
     // ... with `terms` = 2 / 3 the caller also states that X' / W' are equal-length term segments [xh | xl | xh][:terms] / [wh | wh | wl][:terms] (K = terms x the
     // segment length): gemm_terms.hip then stages every term plane once and runs the products of a k-block from that one staging (0: unknown -- plain fp16 GEMM
     // of depth K).  With EPI_GEGLU (terms != 0 only): W rows GEGLU-interleaved, `out` = the term-segment pack [hh | hl | hh][:terms] of gate * gelu(x)
@@ -300,11 +303,11 @@ int k_ce_loss(hipStream_t s, const float* logits, long ld, int R, int V, const i
 int k_bce_loss(hipStream_t s, const float* x, const float* y, int n, float* out);
 
 // vae kernels
-int k_lfq_decode(hipStream_t s, const int64_t* ids, long count, int bits, int C, const float* w, const float* b, bf16_t* out);
+int k_lfq_decode(hipStream_t s, const int64_t* ids, long count, int bits, int C, const float* w, const float* b, bf16_t* out, int half = 0);      // half: fp16 storage (round 6)
 int k_lfq_encode(hipStream_t s, const bf16_t* x, long count, int C, int bits, const float* w, const float* b,
                  const float* wo, const float* bo, int64_t* ids, bf16_t* out);
-int k_glu(hipStream_t s, const bf16_t* x, long rows, int C, bf16_t* out);
+int k_glu(hipStream_t s, const bf16_t* x, long rows, int C, bf16_t* out, int half = 0);
 int k_groupnorm(hipStream_t s, const bf16_t* x, int B, int HW, int C, int groups, const float* gamma, const float* beta,
-                int act, float* stats_ws, bf16_t* out);
+                int act, float* stats_ws, bf16_t* out, int half = 0);
 int k_nchw_to_nhwc8(hipStream_t s, const float* img, int B, int C, int H, int W, bf16_t* out);
 int k_nhwc_to_nchw_f32(hipStream_t s, const bf16_t* x, int B, int C, int H, int W, float* out);

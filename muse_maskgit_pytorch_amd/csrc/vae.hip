@@ -18,7 +18,7 @@ inline int grid_for(long items, int per_block = 256, int cap = 256 * 16) {
 // out[p][c] = bias[c] + sum_j (bit_j(id_p) ? +1 : -1) * w[c][j],  bit_j = (id >> (bits-1-j)) & 1  (MSB = code dim 0).
 // A thread owns 8 consecutive channels: their bits x 8 projection weights stay in registers while it walks a strip of pixels
 // (one 16-byte store per pixel); the sum runs j = 0..bits-1 from the bias like the reference's Linear.
-template <int BITS>
+template <int BITS, bool H>
 __global__ __launch_bounds__(256) void lfq_decode_proj_kernel(const int64_t* __restrict__ ids, long count, int C, int strip,
                                                               const float* __restrict__ w, const float* __restrict__ bias,
                                                               bf16_t* __restrict__ out) {
@@ -48,11 +48,12 @@ __global__ __launch_bounds__(256) void lfq_decode_proj_kernel(const int64_t* __r
             for (int j = 0; j < BITS; ++j) a += sg[j] * wr[k][j];      // exact product: same bits as a +/- w
             acc[k] = a;
         }
-        *reinterpret_cast<uint4*>(out + pix * C + c0) = pack8(acc);
+        *reinterpret_cast<uint4*>(out + pix * C + c0) = pack8s<H>(acc);
     }
 }
 
 // general / projection-free form: one thread produces 8 consecutive channels of one pixel
+template <bool H>
 __global__ __launch_bounds__(256) void lfq_decode_kernel(const int64_t* __restrict__ ids, long count, int bits, int C,
                                                          const float* __restrict__ w, const float* __restrict__ bias,
                                                          bf16_t* __restrict__ out) {
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void lfq_decode_kernel(const int64_t* __restri
                 acc[k] = ((id >> (bits - 1 - c)) & 1) ? 1.f : -1.f;
             }
         }
-        *reinterpret_cast<uint4*>(out + pix * C + c0) = pack8(acc);
+        *reinterpret_cast<uint4*>(out + pix * C + c0) = pack8s<H>(acc);
     }
 }
 
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(256) void lfq_encode_kernel(const bf16_t* __restric
 }
 
 // F.glu(x, dim=channel): x[:, :C] * sigmoid(x[:, C:])
+template <bool H>
 __global__ __launch_bounds__(256) void glu_kernel(const bf16_t* __restrict__ x, long rows, int C, bf16_t* __restrict__ out) {
     const int nch = C >> 3;
     const long total = rows * nch;
@@ -127,15 +129,17 @@ __global__ __launch_bounds__(256) void glu_kernel(const bf16_t* __restrict__ x, 
         const long row = i / nch;
         const int c = (int)(i - row * nch);
         float a[8], g[8], o[8];
-        unpack8(*reinterpret_cast<const uint4*>(x + row * 2 * C + c * 8), a);
-        unpack8(*reinterpret_cast<const uint4*>(x + row * 2 * C + C + c * 8), g);
+        unpack8s<H>(*reinterpret_cast<const uint4*>(x + row * 2 * C + c * 8), a);
+        unpack8s<H>(*reinterpret_cast<const uint4*>(x + row * 2 * C + C + c * 8), g);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = a[j] / (1.f + expf(-g[j]));
-        *reinterpret_cast<uint4*>(out + row * C + c * 8) = pack8(o);
+        *reinterpret_cast<uint4*>(out + row * C + c * 8) = pack8s<H>(o);
     }
 }
 
-// GroupNorm statistics: one workgroup per (group, batch); two passes (mean, then centred variance)
+// GroupNorm statistics: one workgroup per (group, batch); two passes (mean, then centred variance).  Round 6: 16-byte loads (8 channels of one pixel per lane;
+// channels-per-group % 8 == 0 -- every VQGanVAE width -- else the element-wise walk): 86 -> ~20 us per launch at the decoder's 256 x 2048 maps.
+template <bool H>
 __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16_t* __restrict__ x, int HW, int C, int groups,
                                                               float* __restrict__ stats) {
     __shared__ float red[4];
@@ -145,11 +149,24 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16_t* __re
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const bf16_t* xb = x + (size_t)b * HW * C + g * cpg;
     const long cnt = (long)HW * cpg;
+    const bool vec = (cpg % 8) == 0 && (C % 8) == 0;
+    const int c8n = cpg >> 3;
+    const long cnt8 = (long)HW * c8n;
     float s = 0.f;
-    for (long i = tid; i < cnt; i += 256) {
-        const long r = i / cpg;
-        const int c = (int)(i - r * cpg);
-        s += bf16_to_f32(xb[r * C + c]);
+    if (vec) {
+        for (long i = tid; i < cnt8; i += 256) {
+            const long r = i / c8n;
+            const int c = (int)(i - r * c8n) * 8;
+            float v[8];
+            unpack8s<H>(*reinterpret_cast<const uint4*>(xb + r * C + c), v);
+            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+    } else {
+        for (long i = tid; i < cnt; i += 256) {
+            const long r = i / cpg;
+            const int c = (int)(i - r * cpg);
+            s += ld16s<H>(xb[r * C + c]);
+        }
     }
     s = wave_sum(s);
     if (lane == 0) red[wid] = s;
@@ -158,11 +175,22 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16_t* __re
     __syncthreads();
     const float mean = bcast;
     float q = 0.f;
-    for (long i = tid; i < cnt; i += 256) {
-        const long r = i / cpg;
-        const int c = (int)(i - r * cpg);
-        const float d = bf16_to_f32(xb[r * C + c]) - mean;
-        q += d * d;
+    if (vec) {
+        for (long i = tid; i < cnt8; i += 256) {
+            const long r = i / c8n;
+            const int c = (int)(i - r * c8n) * 8;
+            float v[8];
+            unpack8s<H>(*reinterpret_cast<const uint4*>(xb + r * C + c), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[j] - mean; q += d * d; }
+        }
+    } else {
+        for (long i = tid; i < cnt; i += 256) {
+            const long r = i / cpg;
+            const int c = (int)(i - r * cpg);
+            const float d = ld16s<H>(xb[r * C + c]) - mean;
+            q += d * d;
+        }
     }
     q = wave_sum(q);
     __syncthreads();
@@ -175,6 +203,7 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16_t* __re
     }
 }
 
+template <bool H>
 __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __restrict__ x, int HW, int C, int groups,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ stats, int act, long total_chunks,
@@ -186,7 +215,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
         const int c8 = (int)(i - row * nch) * 8;
         const int b = (int)(row / HW);
         float a[8], o[8];
-        unpack8(*reinterpret_cast<const uint4*>(x + row * C + c8), a);
+        unpack8s<H>(*reinterpret_cast<const uint4*>(x + row * C + c8), a);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = c8 + j;
@@ -196,7 +225,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
             if (act == ACT_LEAKY) y = y > 0.f ? y : 0.1f * y;
             o[j] = y;
         }
-        *reinterpret_cast<uint4*>(out + row * C + c8) = pack8(o);
+        *reinterpret_cast<uint4*>(out + row * C + c8) = pack8s<H>(o);
     }
 }
 
@@ -227,7 +256,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_f32_kernel(const bf16_t* __r
 
 }  // namespace
 
-int k_lfq_decode(hipStream_t s, const int64_t* ids, long count, int bits, int C, const float* w, const float* b, bf16_t* out) {
+int k_lfq_decode(hipStream_t s, const int64_t* ids, long count, int bits, int C, const float* w, const float* b, bf16_t* out, int half) {
     if (count <= 0) return MM_OK;
     if (!w && C != bits) return mm_set_error(MM_ERR_SHAPE, "lfq_decode: no projection requires C == bits");
     if (C % 8) return mm_set_error(MM_ERR_SHAPE, "lfq_decode: C must be a multiple of 8");
@@ -239,11 +268,14 @@ int k_lfq_decode(hipStream_t s, const int64_t* ids, long count, int bits, int C,
         if (strips > count) strips = count;
         const int strip = (int)((count + strips - 1) / strips);
         const dim3 grid(bx, (unsigned)((count + strip - 1) / strip));
-        if (bits == 16) hipLaunchKernelGGL((lfq_decode_proj_kernel<16>), grid, dim3(256), 0, s, ids, count, C, strip, w, b, out);
-        else hipLaunchKernelGGL((lfq_decode_proj_kernel<13>), grid, dim3(256), 0, s, ids, count, C, strip, w, b, out);
+        if (bits == 16 && half) hipLaunchKernelGGL((lfq_decode_proj_kernel<16, true>), grid, dim3(256), 0, s, ids, count, C, strip, w, b, out);
+        else if (bits == 16) hipLaunchKernelGGL((lfq_decode_proj_kernel<16, false>), grid, dim3(256), 0, s, ids, count, C, strip, w, b, out);
+        else if (half) hipLaunchKernelGGL((lfq_decode_proj_kernel<13, true>), grid, dim3(256), 0, s, ids, count, C, strip, w, b, out);
+        else hipLaunchKernelGGL((lfq_decode_proj_kernel<13, false>), grid, dim3(256), 0, s, ids, count, C, strip, w, b, out);
         return mm_check_launch("lfq_decode_proj_kernel");
     }
-    hipLaunchKernelGGL(lfq_decode_kernel, dim3(grid_for(count * (C / 8))), dim3(256), 0, s, ids, count, bits, C, w, b, out);
+    if (half) hipLaunchKernelGGL(lfq_decode_kernel<true>, dim3(grid_for(count * (C / 8))), dim3(256), 0, s, ids, count, bits, C, w, b, out);
+    else hipLaunchKernelGGL(lfq_decode_kernel<false>, dim3(grid_for(count * (C / 8))), dim3(256), 0, s, ids, count, bits, C, w, b, out);
     return mm_check_launch("lfq_decode_kernel");
 }
 
@@ -255,23 +287,25 @@ int k_lfq_encode(hipStream_t s, const bf16_t* x, long count, int C, int bits, co
     return mm_check_launch("lfq_encode_kernel");
 }
 
-int k_glu(hipStream_t s, const bf16_t* x, long rows, int C, bf16_t* out) {
+int k_glu(hipStream_t s, const bf16_t* x, long rows, int C, bf16_t* out, int half) {
     if (rows <= 0) return MM_OK;
     if (C % 8) return mm_set_error(MM_ERR_SHAPE, "glu: C must be a multiple of 8");
-    hipLaunchKernelGGL(glu_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, s, x, rows, C, out);
+    if (half) hipLaunchKernelGGL(glu_kernel<true>, dim3(grid_for(rows * (C / 8))), dim3(256), 0, s, x, rows, C, out);
+    else hipLaunchKernelGGL(glu_kernel<false>, dim3(grid_for(rows * (C / 8))), dim3(256), 0, s, x, rows, C, out);
     return mm_check_launch("glu_kernel");
 }
 
 int k_groupnorm(hipStream_t s, const bf16_t* x, int B, int HW, int C, int groups, const float* gamma, const float* beta,
-                int act, float* stats_ws, bf16_t* out) {
+                int act, float* stats_ws, bf16_t* out, int half) {
     if (B <= 0) return MM_OK;
     if (C % 8 || C % groups) return mm_set_error(MM_ERR_SHAPE, "groupnorm: C must be a multiple of 8 and of groups");
-    hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(groups, B), dim3(256), 0, s, x, HW, C, groups, stats_ws);
+    if (half) hipLaunchKernelGGL(groupnorm_stats_kernel<true>, dim3(groups, B), dim3(256), 0, s, x, HW, C, groups, stats_ws);
+    else hipLaunchKernelGGL(groupnorm_stats_kernel<false>, dim3(groups, B), dim3(256), 0, s, x, HW, C, groups, stats_ws);
     int rc = mm_check_launch("groupnorm_stats_kernel");
     if (rc) return rc;
     const long chunks = (long)B * HW * (C / 8);
-    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(grid_for(chunks)), dim3(256), 0, s, x, HW, C, groups, gamma, beta,
-                       stats_ws, act, chunks, out);
+    if (half) hipLaunchKernelGGL(groupnorm_apply_kernel<true>, dim3(grid_for(chunks)), dim3(256), 0, s, x, HW, C, groups, gamma, beta, stats_ws, act, chunks, out);
+    else hipLaunchKernelGGL(groupnorm_apply_kernel<false>, dim3(grid_for(chunks)), dim3(256), 0, s, x, HW, C, groups, gamma, beta, stats_ws, act, chunks, out);
     return mm_check_launch("groupnorm_apply_kernel");
 }
 

@@ -56,47 +56,51 @@ Plan plan(const std::vector<mm_vae_layer>& layers, int B, int H, int W, int C) {
     return p;
 }
 
+// (hf: the handle's storage -- 0 bf16, 1 fp16 with the weights' inverse scale al)
 int conv(hipStream_t s, const bf16_t* in, int B, int H, int W, int Cin, const void* w, int Cout, int k, int stride, int off, int Hv, int Wv, int os, int py,
-         int px, int Hout, int Wout, const float* bias, int act, const bf16_t* resid, void* out, int nchw) {
+         int px, int Hout, int Wout, const float* bias, int act, const bf16_t* resid, void* out, int nchw, int hf, float al) {
+    if (hf) return mm_conv2d_nhwc_half((mm_stream_t)s, in, B, H, W, Cin, w, Cout, k, k, stride, off, off, Hv, Wv, os, py, px, Hout, Wout, bias, act, resid, out, nchw, al);
     return mm_conv2d_nhwc((mm_stream_t)s, in, B, H, W, Cin, w, Cout, k, k, stride, off, off, Hv, Wv, os, py, px, Hout, Wout, bias, act, resid, out, nchw);
 }
 
 // runs `layers` on x (NHWC bf16, B x H x W x C); the result is left in *out_buf (one of the two ping-pong buffers) or, for the head, in image_out
 int run_layers(const std::vector<mm_vae_layer>& layers, hipStream_t s, int B, int& H, int& W, int& C, bf16_t* cur, bf16_t* other, bf16_t* tw, bf16_t* tc,
-               float* stats, float* image_out, bf16_t** result) {
+               float* stats, float* image_out, bf16_t** result, int hf = 0, float al = 1.f) {
     for (const mm_vae_layer& l : layers) {
         switch (l.kind) {
             case MM_VAE_STEM:      // Conv2d(channels, dim, k, padding k // 2) on the 8-channel padded image
-                RC(conv(s, cur, B, H, W, 8, l.w[0], l.cout, l.k, 1, -(l.k / 2), H, W, 1, 0, 0, H, W, l.b[0], 0, nullptr, other, 0));
+                RC(conv(s, cur, B, H, W, 8, l.w[0], l.cout, l.k, 1, -(l.k / 2), H, W, 1, 0, 0, H, W, l.b[0], 0, nullptr, other, 0, hf, al));
                 break;
             case MM_VAE_DOWN:      // Conv2d(4, stride 2, pad 1) + LeakyReLU(0.1)
-                RC(conv(s, cur, B, H, W, C, l.w[0], l.cout, 4, 2, -1, H / 2, W / 2, 1, 0, 0, H / 2, W / 2, l.b[0], 1, nullptr, other, 0));
+                RC(conv(s, cur, B, H, W, C, l.w[0], l.cout, 4, 2, -1, H / 2, W / 2, 1, 0, 0, H / 2, W / 2, l.b[0], 1, nullptr, other, 0, hf, al));
                 break;
             case MM_VAE_RES:       // ResBlock (vqgan_vae.py:267-281): conv3 -> GN + LeakyReLU -> conv3 -> GN + LeakyReLU -> conv1 + x
-                RC(conv(s, cur, B, H, W, C, l.w[0], C, 3, 1, -1, H, W, 1, 0, 0, H, W, l.b[0], 0, nullptr, tw, 0));
-                RC(k_groupnorm(s, tw, B, H * W, C, l.groups, l.gn_g[0], l.gn_b[0], ACT_LEAKY, stats, tc));
-                RC(conv(s, tc, B, H, W, C, l.w[1], C, 3, 1, -1, H, W, 1, 0, 0, H, W, l.b[1], 0, nullptr, tw, 0));
-                RC(k_groupnorm(s, tw, B, H * W, C, l.groups, l.gn_g[1], l.gn_b[1], ACT_LEAKY, stats, tc));
-                RC(conv(s, tc, B, H, W, C, l.w[2], C, 1, 1, 0, H, W, 1, 0, 0, H, W, l.b[2], 0, cur, other, 0));
+                RC(conv(s, cur, B, H, W, C, l.w[0], C, 3, 1, -1, H, W, 1, 0, 0, H, W, l.b[0], 0, nullptr, tw, 0, hf, al));
+                RC(k_groupnorm(s, tw, B, H * W, C, l.groups, l.gn_g[0], l.gn_b[0], ACT_LEAKY, stats, tc, hf));
+                RC(conv(s, tc, B, H, W, C, l.w[1], C, 3, 1, -1, H, W, 1, 0, 0, H, W, l.b[1], 0, nullptr, tw, 0, hf, al));
+                RC(k_groupnorm(s, tw, B, H * W, C, l.groups, l.gn_g[1], l.gn_b[1], ACT_LEAKY, stats, tc, hf));
+                RC(conv(s, tc, B, H, W, C, l.w[2], C, 1, 1, 0, H, W, 1, 0, 0, H, W, l.b[2], 0, cur, other, 0, hf, al));
                 break;
             case MM_VAE_GLU:       // GLUResBlock (vqgan_vae.py:251-265): conv3 (C -> 2C) -> GLU -> GN -> conv3 -> GLU -> GN -> conv1 + x
-                RC(conv(s, cur, B, H, W, C, l.w[0], 2 * C, 3, 1, -1, H, W, 1, 0, 0, H, W, l.b[0], 0, nullptr, tw, 0));
-                RC(k_glu(s, tw, (long)B * H * W, C, tc));
-                RC(k_groupnorm(s, tc, B, H * W, C, l.groups, l.gn_g[0], l.gn_b[0], ACT_NONE, stats, tc));
-                RC(conv(s, tc, B, H, W, C, l.w[1], 2 * C, 3, 1, -1, H, W, 1, 0, 0, H, W, l.b[1], 0, nullptr, tw, 0));
-                RC(k_glu(s, tw, (long)B * H * W, C, tc));
-                RC(k_groupnorm(s, tc, B, H * W, C, l.groups, l.gn_g[1], l.gn_b[1], ACT_NONE, stats, tc));
-                RC(conv(s, tc, B, H, W, C, l.w[2], C, 1, 1, 0, H, W, 1, 0, 0, H, W, l.b[2], 0, cur, other, 0));
+                RC(conv(s, cur, B, H, W, C, l.w[0], 2 * C, 3, 1, -1, H, W, 1, 0, 0, H, W, l.b[0], 0, nullptr, tw, 0, hf, al));
+                RC(k_glu(s, tw, (long)B * H * W, C, tc, hf));
+                RC(k_groupnorm(s, tc, B, H * W, C, l.groups, l.gn_g[0], l.gn_b[0], ACT_NONE, stats, tc, hf));
+                RC(conv(s, tc, B, H, W, C, l.w[1], 2 * C, 3, 1, -1, H, W, 1, 0, 0, H, W, l.b[1], 0, nullptr, tw, 0, hf, al));
+                RC(k_glu(s, tw, (long)B * H * W, C, tc, hf));
+                RC(k_groupnorm(s, tc, B, H * W, C, l.groups, l.gn_g[1], l.gn_b[1], ACT_NONE, stats, tc, hf));
+                RC(conv(s, tc, B, H, W, C, l.w[2], C, 1, 1, 0, H, W, 1, 0, 0, H, W, l.b[2], 0, cur, other, 0, hf, al));
                 break;
             case MM_VAE_UP:        // ConvTranspose2d(4, 2, 1) + LeakyReLU(0.1) as four parity 2x2 convolutions
                 for (int py = 0; py < 2; ++py)
                     for (int px = 0; px < 2; ++px)
-                        RC(mm_conv2d_nhwc((mm_stream_t)s, cur, B, H, W, C, l.w[py * 2 + px], l.cout, 2, 2, 1, py - 1, px - 1, H, W, 2, py, px, 2 * H, 2 * W, l.b[0], 1,
-                                          nullptr, other, 0));
+                        RC(hf ? mm_conv2d_nhwc_half((mm_stream_t)s, cur, B, H, W, C, l.w[py * 2 + px], l.cout, 2, 2, 1, py - 1, px - 1, H, W, 2, py, px, 2 * H, 2 * W, l.b[0], 1,
+                                                     nullptr, other, 0, al)
+                              : mm_conv2d_nhwc((mm_stream_t)s, cur, B, H, W, C, l.w[py * 2 + px], l.cout, 2, 2, 1, py - 1, px - 1, H, W, 2, py, px, 2 * H, 2 * W, l.b[0], 1,
+                                               nullptr, other, 0));
                 break;
             case MM_VAE_HEAD:      // Conv2d(dim, channels, 1) -> NCHW fp32 image
                 if (!image_out) return mm_set_error(MM_ERR_SHAPE, "vae: head layer without an image output");
-                RC(conv(s, cur, B, H, W, C, l.w[0], l.cout, 1, 1, 0, H, W, 1, 0, 0, H, W, l.b[0], 0, nullptr, image_out, 1));
+                RC(conv(s, cur, B, H, W, C, l.w[0], l.cout, 1, 1, 0, H, W, 1, 0, 0, H, W, l.b[0], 0, nullptr, image_out, 1, hf, al));
                 next_shape(l, H, W, C);
                 *result = nullptr;
                 return MM_OK;
@@ -121,6 +125,7 @@ int mm_vae_create(const mm_vae_desc* desc, mm_vae_t** out) {
     if (desc->n_enc < 0 || desc->n_dec < 0 || (desc->n_enc && !desc->enc) || (desc->n_dec && !desc->dec)) return mm_set_error(MM_ERR_SHAPE, "vae_create: layer lists");
     if (desc->channels <= 0 || desc->channels > 8) return mm_set_error(MM_ERR_UNSUPPORTED, "vae_create: 1..8 image channels");
     if (desc->bits <= 0 || desc->bits > 62 || desc->encoded_dim % 8) return mm_set_error(MM_ERR_SHAPE, "vae_create: bits / encoded_dim");
+    if (desc->half && desc->n_enc) return mm_set_error(MM_ERR_UNSUPPORTED, "vae_create: an fp16-storage handle is decode-only (n_enc = 0)");
     mm_vae* v = new (std::nothrow) mm_vae();
     if (!v) return mm_set_error(MM_ERR_HIP, "out of host memory");
     v->d = *desc;
@@ -157,10 +162,11 @@ int mm_vae_decode_from_ids(const mm_vae_t* v, mm_stream_t stream, const int64_t*
     bf16_t* tw = (bf16_t*)(base + 2 * al(p.act)); bf16_t* tc = (bf16_t*)(base + 2 * al(p.act) + al(p.tmp_wide));
     float* stats = (float*)(base + 2 * al(p.act) + al(p.tmp_wide) + al(p.tmp_c));
     // LFQ.indices_to_codes + project_out (vqgan_vae.py:430-432) straight into NHWC
-    RC(k_lfq_decode(s, ids, (long)B * h * w, v->d.bits, v->d.encoded_dim, v->d.lfq_wo, v->d.lfq_bo, a0));
+    const int hf = v->d.half ? 1 : 0;
+    RC(k_lfq_decode(s, ids, (long)B * h * w, v->d.bits, v->d.encoded_dim, v->d.lfq_wo, v->d.lfq_bo, a0, hf));
     int H = h, W = w, C = v->d.encoded_dim;
     bf16_t* res = nullptr;
-    return run_layers(v->dec, s, B, H, W, C, a0, a1, tw, tc, stats, image, &res);
+    return run_layers(v->dec, s, B, H, W, C, a0, a1, tw, tc, stats, image, &res, hf, v->d.alpha != 0.f ? v->d.alpha : 1.f);
 }
 
 int mm_vae_encode(const mm_vae_t* v, mm_stream_t stream, const float* image, int B, int H, int W, float* fmap_out, int64_t* ids_out, void* workspace,
@@ -168,6 +174,7 @@ int mm_vae_encode(const mm_vae_t* v, mm_stream_t stream, const float* image, int
     if (!v) return mm_set_error(MM_ERR_SHAPE, "vae handle is NULL");
     if (!image || !ids_out || !workspace) return mm_set_error(MM_ERR_SHAPE, "vae_encode: NULL argument");
     if (B <= 0 || H <= 0 || W <= 0) return mm_set_error(MM_ERR_SHAPE, "vae_encode: bad sizes");
+    if (v->d.half) return mm_set_error(MM_ERR_UNSUPPORTED, "vae_encode: this handle is the fp16-storage decoder");
     if (workspace_bytes < mm_vae_encode_workspace_bytes(v, B, H, W)) return mm_set_error(MM_ERR_WORKSPACE, "vae_encode: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     const Plan p = plan(v->enc, B, H, W, 8);

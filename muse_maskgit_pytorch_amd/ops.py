@@ -227,6 +227,25 @@ def conv2d_nhwc(x, w_packed, cout, th, tw, stride=1, off=(0, 0), out_hw=None, os
     return out
 
 
+def conv2d_nhwc_half(x, w_packed, cout, th, tw, stride=1, off=(0, 0), out_hw=None, os_=1, parity=(0, 0), full_hw=None, bias=None,
+                     act=False, resid=None, out=None, out_nchw_f32=False, alpha=1.0):
+    """mm_conv2d_nhwc_half (round 6): x fp16 [B,H,W,Cin]; w_packed fp16 [Cout, Kp] = pack_conv_weight(w, torch.float16, 1 / alpha); single fp16 terms on the
+    fp16 MFMA, fp32 accumulation.  Returns NHWC fp16 (resid NHWC fp16) or NCHW fp32."""
+    _chk_cuda(x, w_packed, bias, resid, out)
+    f16 = torch.float16
+    assert x.dtype == f16 and w_packed.dtype == f16 and (resid is None or resid.dtype == f16)
+    B, H, W, Cin = x.shape
+    Hv, Wv = out_hw if out_hw is not None else (H, W)
+    Hout, Wout = full_hw if full_hw is not None else (Hv * os_, Wv * os_)
+    if out is None:
+        out = (torch.empty(B, cout, Hout, Wout, dtype=torch.float32, device=x.device) if out_nchw_f32
+               else torch.empty(B, Hout, Wout, cout, dtype=f16, device=x.device))
+    L.check(L.lib().mm_conv2d_nhwc_half(L.stream(), L.ptr(x), B, H, W, Cin, L.ptr(w_packed), cout, th, tw, stride, off[0], off[1],
+                                        Hv, Wv, os_, parity[0], parity[1], Hout, Wout, L.ptr(bias), int(act), L.ptr(resid),
+                                        L.ptr(out), int(out_nchw_f32), float(alpha)), 'mm_conv2d_nhwc_half')
+    return out
+
+
 def glu_nhwc(x):
     _chk_cuda(x)
     C2 = x.shape[-1]
@@ -284,10 +303,11 @@ def nhwc_to_nchw_f32(x):
 
 # ------------------------------------------------------------------------------------------------ weight packing (host side, once)
 
-def pack_conv_weight(w):
-    """Conv2d weight [Cout, Cin, TH, TW] -> bf16 [Cout, Kp], k = (ty*TW + tx)*Cin + ci, Kp = ceil64(TH*TW*Cin)."""
+def pack_conv_weight(w, dtype=bf16, scale=1.0):
+    """Conv2d weight [Cout, Cin, TH, TW] -> bf16 [Cout, Kp], k = (ty*TW + tx)*Cin + ci, Kp = ceil64(TH*TW*Cin).
+    dtype=torch.float16, scale=2^j (round 6): the single-term fp16 pack of the half-precision VAE decode (the kernels multiply their accumulators by 1 / scale)."""
     cout = w.shape[0]
-    return pad_cols(w.permute(0, 2, 3, 1).reshape(cout, -1).to(bf16), 64)
+    return pad_cols((w.permute(0, 2, 3, 1).reshape(cout, -1).float() * float(scale)).to(dtype), 64)
 
 
 def pack_conv_weight_cin8(w):
@@ -298,7 +318,7 @@ def pack_conv_weight_cin8(w):
     return pack_conv_weight(wp)
 
 
-def pack_convT_weight(w):
+def pack_convT_weight(w, dtype=bf16, scale=1.0):
     """ConvTranspose2d(4,2,1) weight [Cin, Cout, 4, 4] -> four bf16 [Cout, Kp] matrices, one per output parity (py,px):
     out[2y+py, 2x+px] = sum_{ty,tx in 0..1} in[y+ty-1+py, x+tx-1+px] . w[:, :, 3-py-2ty, 3-px-2tx]."""
     packs = {}
@@ -308,7 +328,7 @@ def pack_convT_weight(w):
             for ty in range(2):
                 for tx in range(2):
                     taps.append(w[:, :, 3 - py - 2 * ty, 3 - px - 2 * tx].t())      # [Cout, Cin]
-            packs[(py, px)] = pad_cols(torch.cat(taps, dim=1).to(bf16), 64)
+            packs[(py, px)] = pad_cols((torch.cat(taps, dim=1).float() * float(scale)).to(dtype), 64)
     return packs
 
 

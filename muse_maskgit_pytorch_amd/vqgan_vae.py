@@ -170,6 +170,11 @@ class VQGanVAE(nn.Module):
             self.discr = Discriminator(dims=dims, channels=channels)
         self._packed = None
         self.precision = 'bf16'        # 'parity': fp32 storage + fp32 MFMA (set_precision)
+        # round 6: 16-bit storage of the DECODER on the fast engines ('bf16' and 'f16x2'): 'f16' (default) = single fp16 terms -- fp16 weights x a power of two, NHWC fp16
+        # activations, fp16 MFMA at the bf16 rate, fp32 accumulation; decoded pixels 2e-4 of the image scale against the reference instead of bf16's 1.6e-3 -- or 'bf16'
+        # (rounds 1-5; the one to choose for a checkpoint whose decoder activations exceed fp16's 65504: values saturate there).  'terms' keeps the 'f16x2' tier's decode
+        # on the three-product term split of rounds 4-5 (A/B, tests).
+        self.decode_storage = 'f16'
 
     # ---- reference surface
     @property
@@ -211,6 +216,23 @@ class VQGanVAE(nn.Module):
             raise ValueError(f"precision must be 'bf16', 'parity', 'bf16x3' or 'f16x2', got {precision!r}")
         self.precision = precision
         return self
+
+    def set_decode_storage(self, storage):
+        """'f16' (default) | 'bf16' | 'terms' -- see __init__.  Applies to decode / decode_from_ids of the 'bf16' and 'f16x2' precisions; encode is unaffected."""
+        if storage not in ('f16', 'bf16', 'terms'):
+            raise ValueError("decode storage must be 'f16', 'bf16' or 'terms'")
+        self.decode_storage = storage
+        return self
+
+    def _half_decode(self):
+        """does decode_from_ids take the fp16-storage composite decoder?"""
+        if not (self.lookup_free_quantization and self.composite):
+            return False
+        if self.precision == 'bf16':
+            return self.decode_storage == 'f16'
+        if self.precision == 'f16x2':
+            return self.decode_storage != 'terms'
+        return False
 
     def _decoder_conv_weights(self):
         return [m.weight for m in self.enc_dec.decoders.modules() if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d))]
@@ -318,10 +340,36 @@ class VQGanVAE(nn.Module):
         self._packed = P
         return P
 
+    def _pack_half(self):
+        """the decoder packed for the fp16-storage engine (round 6): every convolution weight as ONE fp16 term of scale * w, scale = the power of two that puts the
+        decoder's largest |w| into [2^13, 2^14) (ops.f16_weight_scale: small weights stay normal fp16 numbers); biases / GroupNorm parameters fp32 as before."""
+        P = self._pack()
+        if P.get('half') is not None:
+            return P['half']
+        f16 = torch.float16
+        scale = ops.f16_weight_scale(self._decoder_conv_weights())
+        ed = self.enc_dec
+        mods = list(ed.decoders)
+        dec = []
+        for e, m in zip(P['dec'], mods):
+            if e['kind'] in ('res', 'glu'):
+                idx = (0, 3, 6)
+                convs = [dict(c, w=ops.pack_conv_weight(m.net[i].weight.detach(), f16, scale)) for c, i in zip(e['convs'], idx)]
+                dec.append(dict(e, convs=convs))
+            elif e['kind'] == 'up':
+                dec.append(dict(e, w=ops.pack_convT_weight(m[0].weight.detach(), f16, scale)))
+            else:      # head
+                dec.append(dict(e, w=ops.pack_conv_weight(m.weight.detach(), f16, scale)))
+        H = dict(dec=dec, enc=[], lfq=P['lfq'], bits=P['bits'], scale=scale)
+        H['handle'] = self._make_handle(H, half=True, alpha=1.0 / scale)
+        P['half'] = H
+        return H
+
     composite = True    # False: run encode / decode_from_ids operator by operator (mm_conv2d_nhwc, ...) instead of the one-call C entry points
 
-    def _make_handle(self, P):
-        """mm_vae_create over the packed layer list: encode / decode_from_ids then run as ONE C call each (csrc/vae_model.hip)."""
+    def _make_handle(self, P, half=False, alpha=1.0):
+        """mm_vae_create over the packed layer list: encode / decode_from_ids then run as ONE C call each (csrc/vae_model.hip).  half: the decode-only
+        handle on fp16 storage (P['dec'] then holds fp16 packs scaled by 1 / alpha; no encoder list)."""
         import ctypes as C
         import weakref
         kinds = dict(stem=0, down=1, res=2, glu=3, up=4, head=5)
@@ -346,11 +394,12 @@ class VQGanVAE(nn.Module):
                 l.cout, l.w[0], l.b[0] = e['cout'], L.ptr(e['w']), L.ptr(e['b'])
             return l
 
-        enc = (L.VaeLayer * len(P['enc']))(*[layer(e) for e in P['enc']])
+        enc_list = [] if half else P['enc']
+        enc = (L.VaeLayer * max(len(enc_list), 1))(*[layer(e) for e in enc_list])
         dec = (L.VaeLayer * len(P['dec']))(*[layer(e) for e in P['dec']])
         lf = P['lfq']
-        d = L.VaeDesc(channels=self.channels, encoded_dim=self.enc_dec.encoded_dim, bits=P['bits'], n_enc=len(P['enc']), n_dec=len(P['dec']),
-                      enc=enc, dec=dec, lfq_wi=L.ptr(lf['wi']), lfq_bi=L.ptr(lf['bi']), lfq_wo=L.ptr(lf['wo']), lfq_bo=L.ptr(lf['bo']))
+        d = L.VaeDesc(channels=self.channels, encoded_dim=self.enc_dec.encoded_dim, bits=P['bits'], n_enc=len(enc_list), n_dec=len(P['dec']), half=int(half),
+                      enc=enc, dec=dec, lfq_wi=L.ptr(lf['wi']), lfq_bi=L.ptr(lf['bi']), lfq_wo=L.ptr(lf['wo']), lfq_bo=L.ptr(lf['bo']), alpha=float(alpha), reserved=0)
         h = C.c_void_p()
         L.check(L.lib().mm_vae_create(C.byref(d), C.byref(h)), 'mm_vae_create')
         holder = type('VaeHandle', (), {})()
@@ -439,10 +488,22 @@ class VQGanVAE(nn.Module):
     @torch.no_grad()
     def decode_from_ids(self, ids):
         """vqgan_vae.py:427-438: ids (B,h,w) int64 -> image (B,C,H,W) fp32 (unclamped)."""
-        if self.precision in ('parity', 'bf16x3', 'f16x2') and self.lookup_free_quantization:
+        half = self._half_decode()
+        if self.precision in ('parity', 'bf16x3', 'f16x2') and self.lookup_free_quantization and not half:
             from . import parity
             return parity.vae_decode_from_ids(self, ids)
         P = self._pack()
+        if half:      # round 6: LFQ + the whole decoder in one C call on fp16 storage (single fp16 terms: pixels ~2e-4 of the image scale)
+            Hh = self._pack_half()
+            ops._chk_cuda(ids)
+            ids = ids.long().contiguous()
+            B, h_, w_ = ids.shape
+            f = 2 ** self.enc_dec.layers
+            lib, h = L.lib(), Hh['handle'].h
+            ws = self._workspace(lib.mm_vae_decode_workspace_bytes(h, B, h_, w_), ids.device)
+            img = torch.empty(B, self.channels, h_ * f, w_ * f, dtype=torch.float32, device=ids.device)
+            L.check(lib.mm_vae_decode_from_ids(h, L.stream(), L.ptr(ids), B, h_, w_, L.ptr(img), L.ptr(ws), ws.numel()), 'mm_vae_decode_from_ids')
+            return img
         if not self.lookup_free_quantization:
             return self._decode_nhwc(self.quantizer.codes_nhwc(ids.to(self.device)))
         if not (self.composite and P['handle'] is not None):

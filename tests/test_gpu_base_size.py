@@ -189,30 +189,40 @@ def test_generate_at_base_size_against_the_reference_run(base, noise, precision)
         torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize('precision', ['parity', 'bf16x3', 'f16x2', 'bf16'])
-def test_vqgan_vae_dim_256_against_the_reference(base, precision):
+@pytest.mark.parametrize('precision', ['parity', 'bf16x3', 'f16x2', pytest.param('f16x2', id='f16x2-terms-decode'), 'bf16', pytest.param('bf16', id='bf16-bf16-decode')])
+def test_vqgan_vae_dim_256_against_the_reference(base, precision, request):
     """VQGanVAE(dim=256) decode_from_ids / encode (vqgan_vae.py:422-441), the VAE the bench decodes with.  Pixels: 1e-3 of the image scale
     (|max| 0.063 at random init) for the parity engine.  LFQ ids: a bit is the SIGN of a projection, so ids are compared where the reference's
-    own pre-sign value clears the engine's error band (all 16 bits of the position), and the fraction of positions covered is reported."""
+    own pre-sign value clears the engine's error band (all 16 bits of the position), and the fraction of positions covered is reported.
+    Round 6: the fast engines ('bf16' -- the bench line -- and 'f16x2') decode on fp16 STORAGE with single fp16 terms (VQGanVAE.decode_storage = 'f16': fp16 MFMA
+    at the bf16 rate, 11 significand bits): the decoded pixels of BOTH now meet the north star's 1e-3 (measured ~2e-4 of the scale; rounds 1-5: the bf16 engine
+    1.6e-3 with a bound of 8e-3, the tier 6e-8 at three times the time).  The earlier forms stay selectable and tested: 'bf16' storage, and the tier's three-product
+    term split ('terms')."""
     g, mg, inp = base
     v = g['vae']
     vae = mg.vae.set_precision(precision)
+    cid = request.node.callspec.id
+    storage = 'terms' if 'terms-decode' in cid else ('bf16' if 'bf16-decode' in cid else 'f16')
+    vae.set_decode_storage(storage)
     if precision in ('bf16x3', 'f16x2'):
         assert vae.x3_products() == dict(bf16x3=(6, 3), f16x2=(3, 2))[precision][int(g['recipe'].get('bf16_weights', True))]
     try:
+        assert vae._half_decode() == (precision in ('bf16', 'f16x2') and storage == 'f16')
         dec = vae.decode_from_ids(inp['vae_ids'].to(DEV))
         fmap, ids, _ = vae.encode(inp['image'].to(DEV))
     finally:
         vae.set_precision('bf16')
+        vae.set_decode_storage('f16')
     scale = v['decoded_absmax']
-    tol = (1e-3 if precision in EXACT else 8e-3) * scale      # 'bf16x3': the convolutions as exact bf16 term products on the bf16 MFMA (decode); encode = the fp32 engine
-    _err(f'{precision} decoded pixels (strided)', dec[:, :, ::4, ::4], v['decoded_strided'], tol)
-    _err(f'{precision} decoded pixels (64x64 crop)', dec[:, :, 96:160, 96:160], v['decoded_crop'], tol)
+    exact_decode = precision in EXACT or storage == 'f16'      # (fp16 storage: single fp16 terms meet the pixel bar)
+    tol = (1e-3 if exact_decode else 8e-3) * scale      # 'bf16x3': the convolutions as exact bf16 term products on the bf16 MFMA (decode); encode = the fp32 engine
+    _err(f'{cid} decoded pixels (strided)', dec[:, :, ::4, ::4], v['decoded_strided'], tol)
+    _err(f'{cid} decoded pixels (64x64 crop)', dec[:, :, 96:160, 96:160], v['decoded_crop'], tol)
     pre = v['enc_pre_sign']                                   # (B, 256, 16): the reference's values whose signs are the id bits
     band = (2e-5 if precision in EXACT else 2e-2) * pre.abs().max().item()
     safe = (pre.abs() > band).all(dim=-1)                     # positions whose 16 bits are all outside the band
     same = ids.cpu().reshape(R.B, -1) == v['enc_ids'].reshape(R.B, -1)
-    print(f'[base-size parity] {precision} LFQ encode: {100 * same.float().mean().item():.2f} % of ids equal the reference; '
+    print(f'[base-size parity] {cid} LFQ encode: {100 * same.float().mean().item():.2f} % of ids equal the reference; '
           f'{100 * safe.float().mean().item():.1f} % of positions have every pre-sign value outside +-{band:.3g}')
     assert bool(same[safe].all()), f'{(~same[safe]).sum().item()} ids differ at positions whose bits are all outside the error band'
     if precision in EXACT:

@@ -183,7 +183,16 @@ def test_vae_composite_entry_points_equal_the_operator_sequence():
         f = 2 ** v.enc_dec.layers
         ids = torch.randint(0, kw['codebook_size'], (3, 4, 6), device=DEV)
         img = torch.randn(3, 3, 4 * f, 6 * f, device=DEV)
+        h_dec = v.decode_from_ids(ids)                      # round 6 default: the decoder on fp16 storage (composite only)
+        assert v._half_decode()
+        v.set_decode_storage('bf16')                        # the operator sequence below runs the bf16 operators
         a_dec, (a_q, a_ids, _) = v.decode_from_ids(ids), v.encode(img)
+        sd = {k: (t.detach().float().cpu() if t.is_floating_point() else t.detach().cpu()) for k, t in v.state_dict().items()}
+        ref = O.vae_decode_from_ids(sd, ids.cpu(), layers=v.enc_dec.layers) if kw.get('encdec_num_resnet_blocks') is None else None
+        if ref is not None:                                 # fp16 storage is the closer of the two to the fp32 oracle, by about the 3 extra significand bits
+            e_h, e_b = (h_dec.cpu() - ref).abs().max().item(), (a_dec.cpu() - ref).abs().max().item()
+            print(f'[vae storage] decode vs fp32 oracle: fp16 storage {e_h:.3g}, bf16 storage {e_b:.3g} (image scale {ref.abs().max().item():.3g})')
+            assert e_h < 0.5 * e_b and e_h < 1e-3 * ref.abs().max().item()
         v.composite = False
         b_dec, (b_q, b_ids, _) = v.decode_from_ids(ids), v.encode(img)
         assert a_dec.shape == (3, 3, 4 * f, 6 * f) and torch.equal(a_dec, b_dec)

@@ -548,6 +548,37 @@ def test_conv_variants_match_emulation(cin, cout, hw, kind):
     check_close(got, ref, atol=2e-3, rtol=ULP, what=f'conv {kind}')
 
 
+@pytest.mark.parametrize('shape', [(2, 16, 64, 128, 3), (2, 16, 72, 40, 1), (8, 64, 64, 256, 3), (2, 12, 256, 3, 1)])
+def test_conv_half_storage_against_fp64(shape):
+    """mm_conv2d_nhwc_half (round 6; vqgan_vae.py:224-232 on the fp16-storage decoder): fp16 NHWC activations x fp16 weights (packed x 2^j, undone by alpha) on
+    the fp16 MFMA with fp32 accumulation, + bias, LeakyReLU, fp16 residual -> fp16 NHWC or NCHW fp32, against torch's fp64 convolution of the SAME fp16 values:
+    what is left is fp32 accumulation order and the final fp16 rounding.  Shapes cover the 128x128 kernel, ragged channel counts, the 256x128 kernel (>= 256
+    tiles, Cin % 64 == 0) and the narrow NCHW head."""
+    B, hw, cin, cout, k = shape
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    f16 = torch.float16
+    x = rnd(B, hw, hw, cin, gen=g).to(f16)
+    w = rnd(cout, cin, k, k, gen=g, scale=0.05)
+    scale = ops.f16_weight_scale([w])
+    wp = ops.pack_conv_weight(w, f16, scale)
+    wq = (w * scale).to(f16).double() / scale               # the weights the kernel multiplies by
+    bias = 0.1 * rnd(cout, gen=g)
+    head = cout < 8
+    resid = None if (k == 3 or head) else rnd(B, hw, hw, cout, gen=g).to(f16)
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), wq, bias.double(), padding=k // 2)
+    if k == 3:
+        ref = torch.nn.functional.leaky_relu(ref, 0.1)
+    if resid is not None:
+        ref = ref + resid.double().permute(0, 3, 1, 2)
+    got = ops.conv2d_nhwc_half(x.to(DEV), wp.to(DEV), cout, k, k, 1, (-(k // 2), -(k // 2)), bias=bias.to(DEV), act=(k == 3),
+                               resid=resid.to(DEV) if resid is not None else None, out_nchw_f32=head, alpha=1.0 / scale)
+    got = got.double().cpu() if head else got.double().cpu().permute(0, 3, 1, 2)
+    err = (got - ref).abs().max().item()
+    sc = ref.abs().max().item()
+    print(f'[conv half] {shape}: max abs err {err:.3g} on scale {sc:.3g}')
+    assert err <= (2e-5 if head else 6e-4) * sc               # fp16 output rounding: 2^-11 relative
+
+
 @pytest.mark.parametrize('kind', ['c3', 'c1', 'c4s2', 'ct'])
 def test_conv_large_tile_kernel_is_bit_identical_to_small(kind):
     """Cin % 64 == 0 convolutions with >= 256 tiles run on the 256x128 three-stage kernel (gemm_big.hip: wave-uniform tap walk);
