@@ -339,7 +339,7 @@ def parity_tier_leg(mg, tr, step, args, B, T, n, nc, image_size, counts, lib, bf
             'checkpoint': 'the main line\'s parameters rounded to bf16 (what the bf16 engine multiplies by): one fp16 term per weight, 2 term products',
             'tolerance': 'logits <= 1e-3 absolute (measured 4e-6) and ids bit-exact at every decode step against the reference fp32 run at this size, on a '
                          'bf16-representable AND on a general fp32 checkpoint (tests/test_gpu_base_size.py, precision f16x2, fixtures base_c2.pt / base_c2_fp32.pt); '
-                         'VAE decode with its convolutions as fp16 term products on the fp16 MFMA',
+                         'VAE decode: single fp16 terms on fp16 storage (round 6; decoded pixels 1.7e-4 of the image scale against the reference, bound 1e-3 -- the three-product term split of rounds 4-5 stays selectable: VQGanVAE.set_decode_storage(\'terms\'))',
             'roofline': {'kernel': 'gemm_wide_fused_kernel<F16, NP> (term products of to_logits on the guidance-mixed embeddings, every term plane staged once per 32-deep k-block)', 'bound': 'mfma',
                          'achieved': g_flops / (g_ms * 1e-3) / 1e12 if g_ms else None, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': (g_flops / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if g_ms else None,
@@ -470,6 +470,7 @@ def main():
                     "(profiling the tier: tools/r5_kstats.sh); never the headline")
     ap.add_argument('--fused-bound', choices=['auto', 'quantile', 'gaussian'], default='auto', help="A/B: the fused sampler's bound of the k-th largest logit (Transformer.fused_bound); 'gaussian' = rounds 2-4")
     ap.add_argument('--bf16-round-weights', action='store_true', help='secondary line: round the random-init parameters to bf16 first (the bf16-representable checkpoint of the tier figures)')
+    ap.add_argument('--vae-storage', choices=['f16', 'bf16'], default='f16', help="A/B: 16-bit storage of the VAE decoder (VQGanVAE.decode_storage; 'bf16' = rounds 1-5)")
     ap.add_argument('--train', action='store_true', help='time the TRAINING step of the C2 base transformer (MaskGit.forward + backward + AdamW) instead of '
                     'generation: a second, separately labelled line -- not the BASELINE metric')
     args = ap.parse_args()
@@ -517,6 +518,8 @@ def main():
             for p_ in list(mg.transformer.parameters()) + list(mg.vae.parameters()):
                 p_.copy_(p_.to(torch.bfloat16).float())
     tr.fused_bound = args.fused_bound
+    if mg.vae is not None:
+        mg.vae.set_decode_storage(args.vae_storage)
     if args.precision != 'bf16':
         mg.set_precision(args.precision)
         args.no_parity_tier = args.no_graph_leg = True
@@ -617,7 +620,8 @@ def main():
             'data': 'synthetic',
             'config': {'workload': desc + (' [fp8 engine]' if args.fp8 else ''), 'images_per_gpu_per_step': B, 'global_batch': world * B, 'seq_len': n, 'timesteps': T,
                        'text_len': args.text_len, 'cond_ids': nc, 'parallelism': f'dp{world} (batch-sharded, 1 all-gather of ids per step)',
-                       'weights': 'random init (module defaults, torch.manual_seed(0))'},
+                       'weights': 'random init (module defaults, torch.manual_seed(0))',
+                       'vae_decode_storage': getattr(mg.vae, 'decode_storage', None) and {'f16': 'fp16 (single fp16 terms on the fp16 MFMA, fp32 accumulation: same rate as bf16, pixels 1.7e-4 of the image scale vs the reference)', 'bf16': 'bf16', 'terms': 'bf16'}[mg.vae.decode_storage]},
             # reference-equivalent: the reference's 2 * timesteps full passes over all n positions / the decode-loop time (comparable across
             # implementations); executed: token rows that actually pass through the transformer blocks here (2B sequences per step)
             'transformer_tok_per_s_per_gpu': B * n * passes / loop_s,

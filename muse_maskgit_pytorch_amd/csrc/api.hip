@@ -461,7 +461,8 @@ int mm_philox_uniform(mm_stream_t stream, uint64_t seed, uint64_t row_offset, ui
 
 static int conv2d_nhwc_impl(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
                             int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
-                            int Hout, int Wout, const float* bias, int act, const void* resid, void* out, int out_nchw_f32, int f16, float alpha, int terms, int half_io = 0);
+                            int Hout, int Wout, const float* bias, int act, const void* resid, void* out, int out_nchw_f32, int f16, float alpha, int terms, int half_io = 0,
+                            const void* head_w = nullptr, int head_ldw = 0, const float* head_b = nullptr, int head_c = 0);
 
 int mm_conv2d_nhwc(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
                    int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
@@ -502,7 +503,8 @@ int mm_conv2d_nhwc_terms(mm_stream_t stream, const void* in, int B, int Hin, int
 
 static int conv2d_nhwc_impl(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
                             int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
-                            int Hout, int Wout, const float* bias, int act, const void* resid, void* out, int out_nchw_f32, int f16, float alpha, int terms, int half_io) {
+                            int Hout, int Wout, const float* bias, int act, const void* resid, void* out, int out_nchw_f32, int f16, float alpha, int terms, int half_io,
+                            const void* head_w, int head_ldw, const float* head_b, int head_c) {
     if (B == 0) return MM_OK;
     CHK_PTR(in, "in"); CHK_PTR(w, "w"); CHK_PTR(out, "out");
     CHK_ALIGN16(in, "in"); CHK_ALIGN16(w, "w"); CHK_ALIGN16(out, "out");
@@ -524,6 +526,7 @@ static int conv2d_nhwc_impl(mm_stream_t stream, const void* in, int B, int Hin, 
     else a.resid_bf16 = (const bf16_t*)resid;
     a.ldr = Cout;
     a.f16 = f16; a.alpha = alpha; a.terms = terms; a.half_io = half_io;
+    a.head_w = (const bf16_t*)head_w; a.head_ldw = head_ldw; a.head_b = head_b; a.head_c = head_c;
     return mm_gemm_launch(a, (hipStream_t)stream);
 }
 
@@ -567,3 +570,14 @@ int mm_nhwc_bf16_to_nchw_f32(mm_stream_t stream, const void* x, int B, int C, in
 }
 
 }  // extern "C"
+
+// internal (vae_model.hip): a 256-channel convolution with the 1 x 1 head Conv2d(256, head_c, 1) in its epilogue (gemm_wide_conv.hip): `image` = NCHW fp32
+// [B][head_c][Hout][Wout]; head_w = the head's own 16-bit pack [head_c][head_ldw]; half = the fp16-storage form.  MM_ERR_UNSUPPORTED when the shape is outside
+// the 256 x 256 convolution kernel's class (the caller then runs the two convolutions separately).
+int mm_conv2d_nhwc_head(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout, int TH, int TW, int stride, int off_y, int off_x,
+                        int Hv, int Wv, int os, int py, int px, int Hout, int Wout, const float* bias, int act, const void* head_w, int head_ldw, const float* head_b,
+                        int head_c, float* image, int half, float alpha) {
+    if (!head_w || !head_b || !image) return mm_set_error(MM_ERR_SHAPE, "conv_head: NULL argument");
+    return conv2d_nhwc_impl(stream, in, B, Hin, Win, Cin, w, Cout, TH, TW, stride, off_y, off_x, Hv, Wv, os, py, px, Hout, Wout, bias, act, nullptr, image, 1,
+                            half ? 1 : 0, half ? alpha : 1.f, 0, half ? 1 : 0, head_w, head_ldw, head_b, head_c);
+}

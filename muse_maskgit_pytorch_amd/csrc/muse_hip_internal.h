@@ -49,6 +49,9 @@ struct GemmArgs {
     // round 6 (f16 only): 16-bit outputs / residuals of this launch are fp16, not bf16 (out_kind OUT_BF16 / resid_bf16 name the 16-bit container): the single-term
     // fp16 VAE decode -- NHWC fp16 activations in and out, the head convolution to NCHW fp32
     int half_io;
+    // round 6, gemm_wide_conv.hip: the 1 x 1 head convolution (Conv2d(dim, channels, 1), vqgan_vae.py:232) in the epilogue of the last up-sampling convolution
+    // (N == 256): head_w = the head's packed 16-bit weights [head_c][head_ldw] (same storage type and scale as W), head_b fp32 [head_c]; `out` = NCHW fp32 image
+    const bf16_t* head_w; const float* head_b; int head_c; int head_ldw;
     // ... with `terms` = 2 / 3 the caller also states that X' / W' are equal-length term segments [xh | xl | xh][:terms] / [wh | wh | wl][:terms] (K = terms x the
     // segment length): gemm_terms.hip then stages every term plane once and runs the products of a k-block from that one staging (0: unknown -- plain fp16 GEMM
     // of depth K).  With EPI_GEGLU (terms != 0 only): W rows GEGLU-interleaved, `out` = the term-segment pack [hh | hl | hh][:terms] of gate * gelu(x)
@@ -66,7 +69,7 @@ struct GemmArgs {
     const float* in_part; int in_np; int in_F; const float* in_c1; const float* in_c2;
 };
 extern int g_mm_debug;
-extern int g_mm_debug2;      // mm_debug_set2 (round 5): 1 = gemm_terms.hip whatever the tile count (tests: small batches through the production kernels), 2 = gemm_terms.hip and every term-sharing k-loop off (A/B), 4 = mm_train_step on the caller's stream only (A/B)
+extern int g_mm_debug2;      // mm_debug_set2 (round 5): 1 = gemm_terms.hip whatever the tile count (tests: small batches through the production kernels), 2 = gemm_terms.hip and every term-sharing k-loop off (A/B), 4 = mm_train_step on the caller's stream only (A/B), 8 = gemm_wide_conv.hip off (A/B: convolutions on the 256 x 128 kernel), 16 = the VAE head not fused into the last up-sampling convolution (A/B)
 
 int mm_gemm_launch(GemmArgs a, hipStream_t stream);
 bool mm_gemm_big_eligible(const GemmArgs& a);      // gemm_big.hip: 256x128 tile, 3-stage counted-vmcnt pipeline
@@ -78,6 +81,8 @@ int mm_gemm_wide_launch(GemmArgs a, hipStream_t stream);
 bool mm_gemm_wide_fused_eligible(const GemmArgs& a);      // the fused-sampling logits GEMM on the same k-loop (persistent)
 int mm_gemm_wide_fused_launch(GemmArgs a, hipStream_t stream);     // gemm_cfg.hip: persistent 128 tokens x 256 columns, guidance logits
 int mm_gemm_cfg2_launch(GemmArgs a, hipStream_t stream);
+bool mm_gemm_wide_conv_eligible(const GemmArgs& a);      // gemm_wide_conv.hip (round 6): NHWC convolutions on the persistent 256 x 256 x 64 tile (+ the fused 1 x 1 head)
+int mm_gemm_wide_conv_launch(GemmArgs a, hipStream_t stream);
 bool mm_gemm_terms_eligible(const GemmArgs& a);      // gemm_terms.hip (round 5): fp16 term-segment operands, every term plane staged once
 int mm_gemm_terms_launch(GemmArgs a, hipStream_t stream);
 #ifdef MM_TOOLS_PP      // tools/experiments/gemm_pp.hip (round 5's measured-and-rejected forms; tools build only, see tools/build_timing.sh)
@@ -302,6 +307,9 @@ int k_ce_loss(hipStream_t s, const float* logits, long ld, int R, int V, const i
               float* row_loss_ws, float* out);
 int k_bce_loss(hipStream_t s, const float* x, const float* y, int n, float* out);
 
+int mm_conv2d_nhwc_head(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout, int TH, int TW, int stride, int off_y, int off_x,
+                        int Hv, int Wv, int os, int py, int px, int Hout, int Wout, const float* bias, int act, const void* head_w, int head_ldw, const float* head_b,
+                        int head_c, float* image, int half, float alpha);      // api.hip (round 6): convolution + the fused 1 x 1 head
 // vae kernels
 int k_lfq_decode(hipStream_t s, const int64_t* ids, long count, int bits, int C, const float* w, const float* b, bf16_t* out, int half = 0);      // half: fp16 storage (round 6)
 int k_lfq_encode(hipStream_t s, const bf16_t* x, long count, int C, int bits, const float* w, const float* b,

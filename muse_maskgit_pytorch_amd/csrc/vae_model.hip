@@ -66,7 +66,8 @@ int conv(hipStream_t s, const bf16_t* in, int B, int H, int W, int Cin, const vo
 // runs `layers` on x (NHWC bf16, B x H x W x C); the result is left in *out_buf (one of the two ping-pong buffers) or, for the head, in image_out
 int run_layers(const std::vector<mm_vae_layer>& layers, hipStream_t s, int B, int& H, int& W, int& C, bf16_t* cur, bf16_t* other, bf16_t* tw, bf16_t* tc,
                float* stats, float* image_out, bf16_t** result, int hf = 0, float al = 1.f) {
-    for (const mm_vae_layer& l : layers) {
+    for (size_t li = 0; li < layers.size(); ++li) {
+        const mm_vae_layer& l = layers[li];
         switch (l.kind) {
             case MM_VAE_STEM:      // Conv2d(channels, dim, k, padding k // 2) on the 8-channel padded image
                 RC(conv(s, cur, B, H, W, 8, l.w[0], l.cout, l.k, 1, -(l.k / 2), H, W, 1, 0, 0, H, W, l.b[0], 0, nullptr, other, 0, hf, al));
@@ -90,7 +91,30 @@ int run_layers(const std::vector<mm_vae_layer>& layers, hipStream_t s, int B, in
                 RC(k_groupnorm(s, tc, B, H * W, C, l.groups, l.gn_g[1], l.gn_b[1], ACT_NONE, stats, tc, hf));
                 RC(conv(s, tc, B, H, W, C, l.w[2], C, 1, 1, 0, H, W, 1, 0, 0, H, W, l.b[2], 0, cur, other, 0, hf, al));
                 break;
-            case MM_VAE_UP:        // ConvTranspose2d(4, 2, 1) + LeakyReLU(0.1) as four parity 2x2 convolutions
+            case MM_VAE_UP: {      // ConvTranspose2d(4, 2, 1) + LeakyReLU(0.1) as four parity 2x2 convolutions
+                // Round 6: when the head Conv2d(dim, channels, 1) follows a 256-channel up-sampling layer, it rides in that layer's epilogue (gemm_wide_conv.hip:
+                // a 256 x 256 tile holds every channel of its pixels) -- the largest activation of the decoder is neither written nor read back.  The first parity
+                // decides: MM_ERR_UNSUPPORTED (shape outside that kernel's class) before anything ran -> the separate sequence below.
+                const bool head_next = li + 1 < layers.size() && layers[li + 1].kind == MM_VAE_HEAD && image_out && l.cout == 256 && layers[li + 1].cout <= 8 &&
+                                       !(g_mm_debug2 & 16);
+                if (head_next) {
+                    const mm_vae_layer& hd = layers[li + 1];
+                    int rc = MM_OK;
+                    bool fused = true;
+                    for (int py = 0; py < 2 && fused; ++py)
+                        for (int px = 0; px < 2; ++px) {
+                            rc = mm_conv2d_nhwc_head((mm_stream_t)s, cur, B, H, W, C, l.w[py * 2 + px], l.cout, 2, 2, 1, py - 1, px - 1, H, W, 2, py, px, 2 * H, 2 * W, l.b[0], 1,
+                                                     hd.w[0], (l.cout + 63) / 64 * 64, hd.b[0], hd.cout, image_out, hf, al);
+                            if (rc == MM_ERR_UNSUPPORTED && py == 0 && px == 0) { fused = false; break; }
+                            if (rc) return rc;
+                        }
+                    if (fused) {
+                        next_shape(l, H, W, C);
+                        next_shape(hd, H, W, C);
+                        *result = nullptr;
+                        return MM_OK;
+                    }
+                }
                 for (int py = 0; py < 2; ++py)
                     for (int px = 0; px < 2; ++px)
                         RC(hf ? mm_conv2d_nhwc_half((mm_stream_t)s, cur, B, H, W, C, l.w[py * 2 + px], l.cout, 2, 2, 1, py - 1, px - 1, H, W, 2, py, px, 2 * H, 2 * W, l.b[0], 1,
@@ -98,6 +122,7 @@ int run_layers(const std::vector<mm_vae_layer>& layers, hipStream_t s, int B, in
                               : mm_conv2d_nhwc((mm_stream_t)s, cur, B, H, W, C, l.w[py * 2 + px], l.cout, 2, 2, 1, py - 1, px - 1, H, W, 2, py, px, 2 * H, 2 * W, l.b[0], 1,
                                                nullptr, other, 0));
                 break;
+            }
             case MM_VAE_HEAD:      // Conv2d(dim, channels, 1) -> NCHW fp32 image
                 if (!image_out) return mm_set_error(MM_ERR_SHAPE, "vae: head layer without an image output");
                 RC(conv(s, cur, B, H, W, C, l.w[0], l.cout, 1, 1, 0, H, W, 1, 0, 0, H, W, l.b[0], 0, nullptr, image_out, 1, hf, al));

@@ -231,6 +231,31 @@ def test_vqgan_vae_dim_256_against_the_reference(base, precision, request):
     assert d[same.reshape(R.B, 16, 16)].max().item() <= (1e-5 if precision in EXACT else 2e-2)
 
 
+@pytest.mark.parametrize('storage', ['f16', 'bf16'])
+def test_vae_head_fused_into_the_last_upsampling_convolution(base, storage):
+    """Round 6 (vqgan_vae.py:230-232, 246-249): at dim = 256 the decoder's last ConvTranspose2d has 256 output channels = one 256 x 256 tile of gemm_wide_conv.hip,
+    so the 1 x 1 head rides in its epilogue and the (B, 256, 256, 256) activation (1 GiB at B = 32) is never written.  Same rounding points as the separate sequence
+    (the activation is rounded to its 16-bit storage type before the head multiplies it, the head's weights are its own 16-bit pack); what differs is the fp32
+    summation order of the 256-term head product: the images agree to ~1e-7 of the scale.  mm_debug_set2(16) keeps the two convolutions apart."""
+    from muse_maskgit_pytorch_amd import _lib as L
+    g, mg, inp = base
+    vae = mg.vae.set_decode_storage(storage)
+    ids = torch.randint(0, 65536, (4, 16, 16), generator=torch.Generator().manual_seed(5)).to(DEV)
+    try:
+        fused = vae.decode_from_ids(ids)
+        L.lib().mm_debug_set2(16)
+        try:
+            apart = vae.decode_from_ids(ids)
+        finally:
+            L.lib().mm_debug_set2(0)
+    finally:
+        vae.set_decode_storage('f16')
+    scale = apart.abs().max().item()
+    d = (fused - apart).abs().max().item()
+    print(f'[vae head fusion] {storage}: fused vs separate head, max abs diff {d:.3g} on image scale {scale:.3g}')
+    assert scale > 1e-3 and d <= 2e-6 * scale and not torch.equal(fused, torch.zeros_like(fused))
+
+
 # ------------------------------------------------------------------------------------------------ the un-scanned fp32 fixture, tie-aware (SURVEY 8c(4))
 TIE_EPS = 5e-4      # logit units (tests/tie_aware.py): 12x the fp32-grade engines' largest logit error at the fixtures' x8 logit scale
 

@@ -579,6 +579,59 @@ def test_conv_half_storage_against_fp64(shape):
     assert err <= (2e-5 if head else 6e-4) * sc               # fp16 output rounding: 2^-11 relative
 
 
+@pytest.mark.parametrize('half', [False, True], ids=['bf16', 'f16'])
+@pytest.mark.parametrize('kind', ['c3', 'c1', 'c4s2', 'ct'])
+def test_conv_wide_tile_kernel_is_bit_identical_to_the_256x128_kernel(kind, half):
+    """Round 6: NHWC convolutions with Cin % 64 == 0, Cout % 256 == 0, an even number of 64-deep k-steps and >= 256 tiles of 256 pixels x 256 channels run on
+    gemm_wide_conv.hip (the persistent 256 x 256 x 64 tile of gemm_wide.hip with an implicit-GEMM loader: taps in the zero padding are requested beyond the buffer
+    extent and arrive as zeros).  Same MFMA order per output element as gemm_big_kernel<MODE_CONV>, which test_conv_variants_match_emulation pins through the
+    128 x 128 kernel -> bit-identical outputs, for bf16 and for the fp16-storage form; mm_debug_set2(8) selects the older kernel."""
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(23)
+    B, hw, cin, cout = 8, 64, 128, 512
+    dt = torch.float16 if half else bf16
+    scale = 64.0 if half else 1.0
+    conv = (lambda *a, **k: ops.conv2d_nhwc_half(*a, alpha=1.0 / scale, **k)) if half else ops.conv2d_nhwc
+    pk = (lambda w: ops.pack_conv_weight(w, torch.float16, scale)) if half else ops.pack_conv_weight
+    pkT = (lambda w: ops.pack_convT_weight(w, torch.float16, scale)) if half else ops.pack_convT_weight
+    x = rnd(B, hw, hw, cin, gen=g).to(DEV, dt)
+    bias = (0.1 * rnd(cout, gen=g)).to(DEV)
+    if kind in ('c3', 'c1'):
+        k = 3 if kind == 'c3' else 1
+        w = pk(rnd(cout, cin, k, k, gen=g, scale=0.05)).to(DEV)
+        run = lambda: conv(x, w, cout, k, k, 1, (-(k // 2), -(k // 2)), bias=bias, act=(k == 3))
+    elif kind == 'c4s2':
+        x = rnd(B, 2 * hw, 2 * hw, cin, gen=g).to(DEV, dt)
+        w = pk(rnd(cout, cin, 4, 4, gen=g, scale=0.05)).to(DEV)
+        run = lambda: conv(x, w, cout, 4, 4, 2, (-1, -1), out_hw=(hw, hw), bias=bias, act=True)
+    else:
+        packs = {k_: v.to(DEV) for k_, v in pkT(rnd(cin, cout, 4, 4, gen=g, scale=0.05)).items()}
+
+        def run():
+            out = torch.zeros(B, 2 * hw, 2 * hw, cout, dtype=dt, device=DEV)
+            for (py, px), wp in packs.items():
+                conv(x, wp, cout, 2, 2, 1, (py - 1, px - 1), out_hw=(hw, hw), os_=2, parity=(py, px), full_hw=(2 * hw, 2 * hw), bias=bias, act=True, out=out)
+            return out
+    wide = run()
+    lib.mm_debug_set2(8)
+    try:
+        big = run()
+    finally:
+        lib.mm_debug_set2(0)
+    assert torch.isfinite(wide.float()).all() and wide.float().abs().max() > 0.1
+    assert torch.equal(wide, big), f'{(wide != big).sum().item()} of {wide.numel()} outputs differ (max {(wide.float() - big.float()).abs().max().item():.3g})'
+    # a ragged pixel count (the last tile's rows beyond M are requested out of bounds and never stored)
+    if kind == 'c3':
+        xr = x[:, :61].contiguous()
+        a_ = conv(xr, w, cout, 3, 3, 1, (-1, -1), bias=bias, act=True)
+        lib.mm_debug_set2(8)
+        try:
+            b_ = conv(xr, w, cout, 3, 3, 1, (-1, -1), bias=bias, act=True)
+        finally:
+            lib.mm_debug_set2(0)
+        assert torch.equal(a_, b_)
+
+
 @pytest.mark.parametrize('kind', ['c3', 'c1', 'c4s2', 'ct'])
 def test_conv_large_tile_kernel_is_bit_identical_to_small(kind):
     """Cin % 64 == 0 convolutions with >= 256 tiles run on the 256x128 three-stage kernel (gemm_big.hip: wave-uniform tap walk);
