@@ -462,7 +462,7 @@ int mm_philox_uniform(mm_stream_t stream, uint64_t seed, uint64_t row_offset, ui
 static int conv2d_nhwc_impl(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
                             int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
                             int Hout, int Wout, const float* bias, int act, const void* resid, void* out, int out_nchw_f32, int f16, float alpha, int terms, int half_io = 0,
-                            const void* head_w = nullptr, int head_ldw = 0, const float* head_b = nullptr, int head_c = 0);
+                            const void* head_w = nullptr, int head_ldw = 0, const float* head_b = nullptr, int head_c = 0, const void* const* par_w = nullptr);
 
 int mm_conv2d_nhwc(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
                    int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
@@ -504,7 +504,7 @@ int mm_conv2d_nhwc_terms(mm_stream_t stream, const void* in, int B, int Hin, int
 static int conv2d_nhwc_impl(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout,
                             int TH, int TW, int stride, int off_y, int off_x, int Hv, int Wv, int os, int py, int px,
                             int Hout, int Wout, const float* bias, int act, const void* resid, void* out, int out_nchw_f32, int f16, float alpha, int terms, int half_io,
-                            const void* head_w, int head_ldw, const float* head_b, int head_c) {
+                            const void* head_w, int head_ldw, const float* head_b, int head_c, const void* const* par_w) {
     if (B == 0) return MM_OK;
     CHK_PTR(in, "in"); CHK_PTR(w, "w"); CHK_PTR(out, "out");
     CHK_ALIGN16(in, "in"); CHK_ALIGN16(w, "w"); CHK_ALIGN16(out, "out");
@@ -527,6 +527,7 @@ static int conv2d_nhwc_impl(mm_stream_t stream, const void* in, int B, int Hin, 
     a.ldr = Cout;
     a.f16 = f16; a.alpha = alpha; a.terms = terms; a.half_io = half_io;
     a.head_w = (const bf16_t*)head_w; a.head_ldw = head_ldw; a.head_b = head_b; a.head_c = head_c;
+    if (par_w) for (int i = 0; i < 4; ++i) a.par_w[i] = (const bf16_t*)par_w[i];
     return mm_gemm_launch(a, (hipStream_t)stream);
 }
 
@@ -580,4 +581,14 @@ int mm_conv2d_nhwc_head(mm_stream_t stream, const void* in, int B, int Hin, int 
     if (!head_w || !head_b || !image) return mm_set_error(MM_ERR_SHAPE, "conv_head: NULL argument");
     return conv2d_nhwc_impl(stream, in, B, Hin, Win, Cin, w, Cout, TH, TW, stride, off_y, off_x, Hv, Wv, os, py, px, Hout, Wout, bias, act, nullptr, image, 1,
                             half ? 1 : 0, half ? alpha : 1.f, 0, half ? 1 : 0, head_w, head_ldw, head_b, head_c);
+}
+
+// internal (vae_model.hip): ConvTranspose2d(4, 2, 1) + bias (+ LeakyReLU) as ONE launch over its four parity classes (gemm_wide_conv.hip; w4[py * 2 + px] = the
+// packed 2 x 2 weights of class (py, px)), optionally with the fused head (head_w != NULL -> image NCHW fp32, else out NHWC 16-bit [B][2 Hin][2 Win][Cout]).
+// MM_ERR_UNSUPPORTED outside the 256 x 256 convolution kernel's shape class: the caller runs the four classes separately.
+int mm_convT2d_nhwc_4(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* const* w4, int Cout, const float* bias, int act, void* out,
+                      const void* head_w, int head_ldw, const float* head_b, int head_c, int half, float alpha) {
+    if (!w4 || !w4[0] || !w4[1] || !w4[2] || !w4[3]) return mm_set_error(MM_ERR_SHAPE, "convT2d_4: NULL weights");
+    return conv2d_nhwc_impl(stream, in, B, Hin, Win, Cin, w4[0], Cout, 2, 2, 1, -1, -1, Hin, Win, 2, 0, 0, 2 * Hin, 2 * Win, bias, act, nullptr, out, head_w ? 1 : 0,
+                            half ? 1 : 0, half ? alpha : 1.f, 0, half ? 1 : 0, head_w, head_ldw, head_b, head_c, w4);
 }

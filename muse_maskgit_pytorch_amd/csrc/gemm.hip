@@ -633,7 +633,7 @@ int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
             return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: fp16 term operands take the fp32-output dense / convolution forms only (16-bit fp16 outputs: half_io)");
         if (a.half_io && (a.terms || a.xb_out || a.in_c1 || a.ln_c1)) return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: half_io is the plain single-term fp16 form");
         if (a.half_io && mm_gemm_wide_conv_eligible(a)) return mm_gemm_wide_conv_launch(a, stream);      // round 6: convolutions on the persistent 256 x 256 x 64 tile
-        if (a.head_w) return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: the fused head needs the 256 x 256 convolution kernel's shape class");
+        if (a.head_w || a.par_w[1]) return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: the fused head / the parity-batched form need the 256 x 256 convolution kernel's shape class");
         if (!(a.debug & (8 | (1 << 30))) && mm_gemm_terms_eligible(a)) return mm_gemm_terms_launch(a, stream);
         if (!a.m_dev && !(a.debug & 8) && mm_gemm_big_eligible(a)) return mm_gemm_big_launch(a, stream);
         a.tiles_n = (a.N + BT - 1) / BT;
@@ -664,7 +664,7 @@ int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
         return launch_dense_small(a, stream);
     }
     if (a.mode == MODE_CONV && mm_gemm_wide_conv_eligible(a)) return mm_gemm_wide_conv_launch(a, stream);      // round 6: convolutions on the persistent 256 x 256 x 64 tile
-    if (a.head_w) return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: the fused head needs the 256 x 256 convolution kernel's shape class");
+    if (a.head_w || a.par_w[1]) return mm_set_error(MM_ERR_UNSUPPORTED, "gemm: the fused head / the parity-batched form need the 256 x 256 convolution kernel's shape class");
     if (a.m_dev) a.debug |= 8;      // only the 128x128 kernel reads the device-side row count
     if (!(a.debug & (8 | 4096 | 8192 | (1 << 30))) && mm_gemm_wide_eligible(a)) return mm_gemm_wide_launch(a, stream);      // (bit 1 << 30: A/B against the older kernels)
     if (!(a.debug & (8 | 4096 | 8192)) && mm_gemm_cfg2_eligible(a)) return mm_gemm_cfg2_launch(a, stream);

@@ -10,7 +10,8 @@
 //
 // Loader: Cin % 64 == 0, so a 64-deep k-step lies inside ONE filter tap: the tap walk (ty, tx, channel offset) is wave-uniform running state, a staged row's
 // source is pixel (y * stride + off_y + ty, x * stride + off_x + tx) of its image, and rows whose tap falls into the zero padding (or beyond M) are requested
-// at an offset beyond the buffer's extent -- the LDS-DMA then writes zeros, no branch and no zero page.  Same XOR-swizzled 128-byte LDS rows, same fragment
+// at an offset beyond the buffer's extent -- the LDS-DMA then writes zeros, no branch and no zero page.  A ConvTranspose2d(4, 2, 1) -- four parity classes, each a
+// 2 x 2 convolution with its own weight matrix, tap offset and output phase -- runs as ONE launch (GemmArgs::par_w): the parity is the slowest tile coordinate.  Same XOR-swizzled 128-byte LDS rows, same fragment
 // reads and MFMA order per output element (k ascending in chunks of 32, one MFMA each) as every other kernel of the family: results are BIT-IDENTICAL to
 // gemm_big_kernel<MODE_CONV> (tests/test_gpu_ops.py).
 #include "common.h"
@@ -45,7 +46,8 @@ __global__ __launch_bounds__(512) void gemm_wide_conv_kernel(const GemmArgs p) {
     const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wid >> 2, wn = wid & 3;
     const int fr = lane & 15, fg = lane >> 4;
-    const int total = p.tiles_m * p.tiles_n, G = gridDim.x;
+    const int per_par = p.tiles_m * p.tiles_n;
+    const int total = per_par * (p.par_w[1] ? 4 : 1), G = gridDim.x;
     const int KT = p.K / 64;
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     const int dchunk = ((lane & 7) ^ (lane >> 3)) * 16;
@@ -60,22 +62,28 @@ __global__ __launch_bounds__(512) void gemm_wide_conv_kernel(const GemmArgs p) {
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.X), 0, x_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rw;
     int tile_m, tile_n;
-    int ciy[4], cix[4], cpix[4];      // input y / x of tap (0, 0) and the flat pixel index of that position, per staged row of this lane
+    int cur_py = 0, cur_px = 0, cur_offy = 0, cur_offx = 0;      // output parity / tap offset of the tile being SET UP (wave-uniform)
+    int cyx[4], cpix[4];      // per staged row of this lane: input (y + 8) << 16 | (x + 8) of tap (0, 0) (packed: the kernel sits at the 256-register limit) and that position's flat pixel index
     int is_ty = 0, is_tx = 0, is_c = 0, is_k = 0;      // the NEXT k-step to issue: its tap, channel offset and weight column (wave-uniform)
 #define TILE_SETUP(vb_)                                                                                                                \
     {                                                                                                                                  \
-        xcd_grouped_tile(vb_, p.tiles_m, p.tiles_n, 8, tile_m, tile_n);                                                                \
-        rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W + (size_t)tile_n * TN * p.ldw), 0, (unsigned)TN * (unsigned)p.ldw * 2u, 0x00020000); \
+        int par_ = 0, vt_ = (vb_);                                                                                                     \
+        if (p.par_w[1]) { par_ = vt_ / per_par; vt_ -= par_ * per_par; }      /* the four parity classes of a ConvTranspose2d(4, 2, 1) in ONE launch */ \
+        xcd_grouped_tile(vt_, p.tiles_m, p.tiles_n, 8, tile_m, tile_n);                                                                \
+        cur_py = p.par_w[1] ? (par_ >> 1) : p.py; cur_px = p.par_w[1] ? (par_ & 1) : p.px;                                             \
+        cur_offy = p.par_w[1] ? cur_py - 1 : p.off_y; cur_offx = p.par_w[1] ? cur_px - 1 : p.off_x;                                    \
+        const bf16_t* wb_ = p.par_w[1] ? p.par_w[par_] : p.W;                                                                          \
+        rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(wb_ + (size_t)tile_n * TN * p.ldw), 0, (unsigned)TN * (unsigned)p.ldw * 2u, 0x00020000); \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                                \
             const int m_ = tile_m * TM + 32 * wid + 8 * i + (lane >> 3);                                                               \
             if (m_ < p.M) {                                                                                                            \
                 const int cb_ = m_ / hw, rem_ = m_ - cb_ * hw;                                                                         \
                 const int cy_ = rem_ / p.Wv, cx_ = rem_ - cy_ * p.Wv;                                                                  \
-                ciy[i] = cy_ * p.stride + p.off_y;                                                                                     \
-                cix[i] = cx_ * p.stride + p.off_x;                                                                                     \
-                cpix[i] = (cb_ * p.Hin + ciy[i]) * p.Win + cix[i];                                                                     \
+                const int iy_ = cy_ * p.stride + cur_offy, ix_ = cx_ * p.stride + cur_offx;                                            \
+                cyx[i] = ((iy_ + 8) << 16) | (ix_ + 8);                                                                                \
+                cpix[i] = (cb_ * p.Hin + iy_) * p.Win + ix_;                                                                           \
             } else {                                                                                                                   \
-                ciy[i] = -(1 << 20); cix[i] = 0; cpix[i] = 0;      /* rows beyond M: every tap out of bounds -> zeros */               \
+                cyx[i] = 0x7FFF0000; cpix[i] = 0;      /* rows beyond M: every tap out of bounds -> zeros */                            \
             }                                                                                                                          \
         }                                                                                                                              \
         is_ty = is_tx = is_c = is_k = 0;                                                                                               \
@@ -86,7 +94,7 @@ __global__ __launch_bounds__(512) void gemm_wide_conv_kernel(const GemmArgs p) {
         unsigned char* ws_ = smem + (st_) * STG + X_B + wid * 4096;                                                                    \
         const int dpix_ = is_ty * p.Win + is_tx;                                                                                       \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                                \
-            const bool ok_ = (unsigned)(ciy[i] + is_ty) < (unsigned)p.Hin && (unsigned)(cix[i] + is_tx) < (unsigned)p.Win;             \
+            const bool ok_ = (unsigned)((cyx[i] >> 16) - 8 + is_ty) < (unsigned)p.Hin && (unsigned)((cyx[i] & 0xFFFF) - 8 + is_tx) < (unsigned)p.Win; \
             const int vo_ = ok_ ? ((cpix[i] + dpix_) * p.Cin + is_c) * 2 + dchunk : OOB;                                               \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(xs_ + i * 1024), 16, vo_, 0, 0, 0);                               \
         }                                                                                                                              \
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(512) void gemm_wide_conv_kernel(const GemmArgs p) {
     unsigned char* stg = smem + STG; // output staging: stage 1
     f32x4_t acc[4][8];               // [channel fragment a][pixel fragment b]: lane (fr, fg) holds channels 64 wn + 16 a + 4 fg .. + 3 of pixel 128 wm + 16 b + fr
     while (true) {
-        const int m0 = tile_m * TM, n0 = tile_n * TN;
+        const int m0 = tile_m * TM, n0 = tile_n * TN, opy = cur_py, opx = cur_px;      // (the next tile's setup overwrites the running values during the last k-step)
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(512) void gemm_wide_conv_kernel(const GemmArgs p) {
                     const int m = m0 + half * 128 + row;
                     if (m < p.M) {
                         const int ob = m / hw, rem = m - ob * hw;
-                        const int oy = (rem / p.Wv) * p.os + p.py, ox = (rem % p.Wv) * p.os + p.px;
+                        const int oy = (rem / p.Wv) * p.os + opy, ox = (rem % p.Wv) * p.os + opx;
                         const size_t orow = ((size_t)ob * p.Hout + oy) * p.Wout + ox;
                         const uint4 v = *reinterpret_cast<const uint4*>(stg + row * ROWB + ((c ^ (row & 7)) << 4));
                         *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + orow * p.ldc + n0 + c * 8) = v;
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(512) void gemm_wide_conv_kernel(const GemmArgs p) {
                 const int m = m0 + half * 128 + row;
                 if (q == 0 && m < p.M) {
                     const int ob = m / hw, rem = m - ob * hw;
-                    const int oy = (rem / p.Wv) * p.os + p.py, ox = (rem % p.Wv) * p.os + p.px;
+                    const int oy = (rem / p.Wv) * p.os + opy, ox = (rem % p.Wv) * p.os + opx;
                     float* op = reinterpret_cast<float*>(p.out) + ((size_t)ob * p.head_c * p.Hout + oy) * p.Wout + ox;
 #pragma unroll
                     for (int c = 0; c < HEAD_MAX; ++c)
@@ -256,7 +264,7 @@ int launch_wide_conv(GemmArgs a, hipStream_t stream) {
     }
     a.tiles_m = (a.M + TM - 1) / TM;
     a.tiles_n = a.N / TN;
-    const int total = a.tiles_m * a.tiles_n;
+    const int total = a.tiles_m * a.tiles_n * (a.par_w[1] ? 4 : 1);
     hipLaunchKernelGGL((gemm_wide_conv_kernel<F16, HEAD>), dim3(total < 256 ? total : 256), dim3(512), SMEM, stream, a);
     return mm_check_launch("gemm_wide_conv_kernel");
 }
@@ -279,7 +287,8 @@ bool mm_gemm_wide_conv_eligible(const GemmArgs& a) {
     const long hw = (long)a.Hv * a.Wv;
     if (hw <= 0 || (a.M % hw)) return false;
     if ((double)(a.M / hw) * a.Hin * a.Win * a.Cin * 2.0 >= 2147418112.0) return false;      // the input addressed by 32-bit byte offsets below the out-of-bounds marker
-    const long tiles = (long)((a.M + TM - 1) / TM) * (a.N / TN);
+    if (a.par_w[1] && (!a.par_w[0] || !a.par_w[2] || !a.par_w[3] || a.TW != 2 || a.K != 4 * a.Cin || a.stride != 1 || a.os != 2)) return false;
+    const long tiles = (long)((a.M + TM - 1) / TM) * (a.N / TN) * (a.par_w[1] ? 4 : 1);
     return tiles >= 256;
 }
 

@@ -52,6 +52,9 @@ struct GemmArgs {
     // round 6, gemm_wide_conv.hip: the 1 x 1 head convolution (Conv2d(dim, channels, 1), vqgan_vae.py:232) in the epilogue of the last up-sampling convolution
     // (N == 256): head_w = the head's packed 16-bit weights [head_c][head_ldw] (same storage type and scale as W), head_b fp32 [head_c]; `out` = NCHW fp32 image
     const bf16_t* head_w; const float* head_b; int head_c; int head_ldw;
+    // ... and all four parity classes of a ConvTranspose2d(4, 2, 1) in one launch: par_w[py * 2 + px] = that class's packed 2 x 2 weights (par_w[1] != NULL selects
+    // the form; W / off_y / off_x / py / px are then ignored: tap offset (py - 1, px - 1), output phase (py, px), os = 2)
+    const bf16_t* par_w[4];
     // ... with `terms` = 2 / 3 the caller also states that X' / W' are equal-length term segments [xh | xl | xh][:terms] / [wh | wh | wl][:terms] (K = terms x the
     // segment length): gemm_terms.hip then stages every term plane once and runs the products of a k-block from that one staging (0: unknown -- plain fp16 GEMM
     // of depth K).  With EPI_GEGLU (terms != 0 only): W rows GEGLU-interleaved, `out` = the term-segment pack [hh | hl | hh][:terms] of gate * gelu(x)
@@ -69,7 +72,7 @@ struct GemmArgs {
     const float* in_part; int in_np; int in_F; const float* in_c1; const float* in_c2;
 };
 extern int g_mm_debug;
-extern int g_mm_debug2;      // mm_debug_set2 (round 5): 1 = gemm_terms.hip whatever the tile count (tests: small batches through the production kernels), 2 = gemm_terms.hip and every term-sharing k-loop off (A/B), 4 = mm_train_step on the caller's stream only (A/B), 8 = gemm_wide_conv.hip off (A/B: convolutions on the 256 x 128 kernel), 16 = the VAE head not fused into the last up-sampling convolution (A/B)
+extern int g_mm_debug2;      // mm_debug_set2 (round 5): 1 = gemm_terms.hip whatever the tile count (tests: small batches through the production kernels), 2 = gemm_terms.hip and every term-sharing k-loop off (A/B), 4 = mm_train_step on the caller's stream only (A/B), 8 = gemm_wide_conv.hip off (A/B: convolutions on the 256 x 128 kernel), 16 = the VAE head not fused into the last up-sampling convolution (A/B), 32 = a ConvTranspose2d's parity classes as four launches (A/B)
 
 int mm_gemm_launch(GemmArgs a, hipStream_t stream);
 bool mm_gemm_big_eligible(const GemmArgs& a);      // gemm_big.hip: 256x128 tile, 3-stage counted-vmcnt pipeline
@@ -310,6 +313,8 @@ int k_bce_loss(hipStream_t s, const float* x, const float* y, int n, float* out)
 int mm_conv2d_nhwc_head(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* w, int Cout, int TH, int TW, int stride, int off_y, int off_x,
                         int Hv, int Wv, int os, int py, int px, int Hout, int Wout, const float* bias, int act, const void* head_w, int head_ldw, const float* head_b,
                         int head_c, float* image, int half, float alpha);      // api.hip (round 6): convolution + the fused 1 x 1 head
+int mm_convT2d_nhwc_4(mm_stream_t stream, const void* in, int B, int Hin, int Win, int Cin, const void* const* w4, int Cout, const float* bias, int act, void* out,
+                      const void* head_w, int head_ldw, const float* head_b, int head_c, int half, float alpha);      // api.hip (round 6): the four parity classes in one launch
 // vae kernels
 int k_lfq_decode(hipStream_t s, const int64_t* ids, long count, int bits, int C, const float* w, const float* b, bf16_t* out, int half = 0);      // half: fp16 storage (round 6)
 int k_lfq_encode(hipStream_t s, const bf16_t* x, long count, int C, int bits, const float* w, const float* b,

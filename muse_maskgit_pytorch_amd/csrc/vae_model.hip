@@ -97,6 +97,24 @@ int run_layers(const std::vector<mm_vae_layer>& layers, hipStream_t s, int B, in
                 // decides: MM_ERR_UNSUPPORTED (shape outside that kernel's class) before anything ran -> the separate sequence below.
                 const bool head_next = li + 1 < layers.size() && layers[li + 1].kind == MM_VAE_HEAD && image_out && l.cout == 256 && layers[li + 1].cout <= 8 &&
                                        !(g_mm_debug2 & 16);
+                // ... and the four parity classes run as ONE launch of that kernel (the parity is its slowest tile coordinate): MM_ERR_UNSUPPORTED before anything ran
+                // (shape outside the kernel's class, or mm_debug_set2(8)) -> the sequences below
+                if (!(g_mm_debug2 & 32)) {
+                    const mm_vae_layer* hd = head_next ? &layers[li + 1] : nullptr;
+                    const int rc4 = mm_convT2d_nhwc_4((mm_stream_t)s, cur, B, H, W, C, l.w, l.cout, l.b[0], 1, hd ? (void*)image_out : (void*)other,
+                                                      hd ? hd->w[0] : nullptr, (l.cout + 63) / 64 * 64, hd ? hd->b[0] : nullptr, hd ? hd->cout : 0, hf, al);
+                    if (rc4 == MM_OK) {
+                        next_shape(l, H, W, C);
+                        if (hd) {
+                            next_shape(*hd, H, W, C);
+                            *result = nullptr;
+                            return MM_OK;
+                        }
+                        bf16_t* t4_ = cur; cur = other; other = t4_;
+                        continue;
+                    }
+                    if (rc4 != MM_ERR_UNSUPPORTED) return rc4;
+                }
                 if (head_next) {
                     const mm_vae_layer& hd = layers[li + 1];
                     int rc = MM_OK;
