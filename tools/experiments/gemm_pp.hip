@@ -75,7 +75,8 @@ struct PPGeo {
 
 template <int GROUPS, int NS, bool F16>
 __global__ __launch_bounds__(256 * GROUPS, 2) void gemm_pp_fused_kernel(const GemmArgs p, const int prio, const int delay_cycles, const int abl) {
-    // abl (tools only, MM_PP_ABL): 1 = no emission, 2 = no LDS-DMA after the prologue, 4 = no MFMAs, 8 = no fragment reads
+    // abl (tools only, MM_PP_ABL): 1 = no emission, 2 = no LDS-DMA after the prologue, 4 = no MFMAs, 8 = no fragment reads, 16 = no workgroup barriers inside the k-loop
+    // (round 6: only meaningful with 2 | 8 -- nothing is shared then), 32 = no counted waits inside the k-loop (with 2: nothing is in flight)
     using G = PPGeo<GROUPS, NS>;
     constexpr int NW = G::NW, TM = G::TM, XS_B = G::XS_B, SLOT = G::SLOT, NPW = G::NPW, NXW = G::NXW, DIST = G::DIST;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -187,9 +188,9 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void gemm_pp_fused_kernel(const Ge
 #define PP_WAIT_NEXT() { if (plain_wait) __builtin_amdgcn_s_waitcnt(PP_VMCNT_IMM((DIST - 1) * NPW)); else pp_wait_vmcnt(ahead * NPW + (ph < DIST - 1 ? pending : 0)); }
             if constexpr (GROUPS == 2) {
                 // group 1's share is read by group 0 in the very next interval: it waits here; group 0's own next LOAD comes behind its COMPUTE segment: it waits there
-                if (grp == 1) PP_WAIT_NEXT();
-                PP_LGKM0();                              // this group is done with the slot once the barrier is passed
-                __builtin_amdgcn_s_barrier();
+                if (grp == 1 && !(abl & 32)) PP_WAIT_NEXT();
+                if (!(abl & 32)) PP_LGKM0();             // this group is done with the slot once the barrier is passed
+                if (!(abl & 16)) __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 if (prio == 1) __builtin_amdgcn_s_setprio(1);
             }
@@ -206,13 +207,12 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void gemm_pp_fused_kernel(const Ge
             if constexpr (GROUPS == 2) {
                 if (prio == 1) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (grp == 0) PP_WAIT_NEXT();
+                if (grp == 0 && !(abl & 32)) PP_WAIT_NEXT();
             } else {
-                PP_WAIT_NEXT();
-                PP_LGKM0();
+                if (!(abl & 32)) { PP_WAIT_NEXT(); PP_LGKM0(); }
             }
 #undef PP_WAIT_NEXT
-            __builtin_amdgcn_s_barrier();
+            if (!(abl & 16)) __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             rs = rs + 1 == NS ? 0 : rs + 1;
 #ifdef MM_GEMM_TIMING
