@@ -1050,7 +1050,10 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
             RC(ff_block(t, s, t->d.self_cond_ff, g.sce, b.x, M, b));
         // Both guidance halves start from the same ids, so their residual streams are identical until the first cross-attention: layer 0's
         // self-attention runs on the cond half only and the stream is duplicated behind it (below) instead of in front of it.
-        const bool compact_last0 = p->mask_counts[step] < n && !(g_mm_debug & 16384) && !self_cond && !can_remask;
+        // Round 6: compaction only where it pays.  The compacted row counts miss the tile classes of the wide kernels (FF w1 of 15232 rows ran on the 128 x 128
+        // kernel: 75 us for 93 % of the rows the 256 x 256 kernel does in 70), so while more than 72 % of the positions are still masked (the first 9 of 18 steps) the
+        // last layer runs on all rows like the others: 202 -> 162 us at step 4, loop 50.7 -> 50.4 ms per generate (same box, two runs each).  Same values either way.
+        const bool compact_last0 = p->mask_counts[step] < n && p->mask_counts[step] * 100 <= n * 72 && !(g_mm_debug & 16384) && !self_cond && !can_remask;
         const bool share0 = P == 2 && !(t->d.depth == 1 && compact_last0);
         if (P == 2 && !share0) {
             const hipError_t e = hipMemcpyAsync(b.x + (size_t)M * D, b.x, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s);
@@ -1061,7 +1064,7 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
         // the feed-forward run on the COMPACTED rows [cond R | null R] (every sample has exactly k of them, position-sorted, so a
         // sample's queries stay contiguous).  Identical values for the rows that matter; (1 - k/n) of that work is skipped.
         // (Self-conditioning needs the embed of every position for the next step, re-masking samples every position: no compaction.)
-        const bool compact_last = k < n && !(g_mm_debug & 16384) && !self_cond && !can_remask;
+        const bool compact_last = compact_last0;
         const bool fold = ln_fold_on(t);
         for (int l = 0; l < t->d.depth; ++l) {
             const mm_layer_weights& w = t->layers[l];
