@@ -354,6 +354,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 
     __syncthreads();                       // every wave is done reading the last stage
     TSTAMP(41)
+    // Round 6 -- an unsynchronised overlay found by inspection while looking for the root cause of the round-1 LDS hazard: the fp32 staging
+    // tile below OVERLAYS the k-loop's stages (rows 64 .. 127 of `ct` = bytes 33.8 .. 67.6 KiB = all of stage 1), and rounds 1-5 had NO workgroup barrier between
+    // a wave's last fragment reads (its final COMPUTE_STEP, which follows the loop's last barrier) and another wave's first staging write.  The four waves leave
+    // that barrier together and run the same ~600 cycles of work, so the window is a wave lagging by more than half a step (LDS arbitration against the co-resident
+    // workgroup) -- rare, timing-dependent, and exactly the kind of failure the determinism stress can only screen for.  gemm_big.hip / gemm_wide.hip / gemm_fp8.hip
+    // always had this barrier; this kernel now has it too: every wave's fragment reads have returned (lgkmcnt) before anybody overwrites a stage.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     float* ct = reinterpret_cast<float*>(smem);
     constexpr int CT_LD = BT + 4;          // floats per tile row (528 B)
     const bool geglu = (MODE == MODE_DENSE) && p.epi == EPI_GEGLU;
