@@ -115,6 +115,19 @@ def graph_replay_leg(mg, B, T, te, steps, eager_s):
         return {'error': f'{type(e).__name__}: {e}'[:300]}
 
 
+def _tier_traffic(substr):
+    """HBM bytes per launch of a kernel of the f16x2 tier from the committed PMC passes of `bench.py --precision f16x2` (general fp32 checkpoint), or None"""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r06_f16x2_pmc_summary.json')) as f:
+            pmc = json.load(f)
+    except OSError:
+        return None
+    for name, v in pmc.items():
+        if substr in name:
+            return v['hbm_bytes_per_launch']
+    return None
+
+
 def off_ideal_legs(mg, tr, args, B, T, rank, world, dev, eager_s):
     """What the headline is worth off its ideal case, each timed like the main region (eager, fresh seeds), reported BESIDE the value:
     text_len 77 / 256 -- the reference pads to the longest prompt up to MAX_LENGTH = 256 (t5.py:16,78-79), the headline runs L = 32 --, and a to_logits whose
@@ -345,7 +358,8 @@ def parity_tier_leg(mg, tr, step, args, B, T, n, nc, image_size, counts, lib, bf
                          'frac': (g_flops / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if g_ms else None,
                          'flops_kind': 'executed fp16 MFMA flops (term products x 2 R V D of the one mixed pass; same peak as bf16)',
                          'algorithmic_frac': (g_flops / P / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if g_ms else None,
-                         'launches': g_cnt, 'avg_launch_ms': g_ms / g_cnt if g_cnt else None, 'traffic': None},
+                         'launches': g_cnt, 'avg_launch_ms': g_ms / g_cnt if g_cnt else None, 'traffic': _tier_traffic('gemm_wide_fused_kernel'),
+                         'traffic_source': 'profiles/r06_f16x2_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of `bench.py --precision f16x2`, bytes per launch, FETCH x2 gfx950 correction)'},
             'executed_f16_tflops_decode_loop_gemms_x_products': P * ex / (loop_ms * 1e-3) / 1e12,
             'without_term_sharing': {'value': B / sec_old, 'ms_per_step': sec_old * 1e3, 'decode_loop_ms_per_step': loop_old, 'steps': 3, 'x_time': sec_old / sec,
                                      'note': 'same process, mm_debug_set2(2): the depth-P*K GEMMs over duplicated term segments of rounds 4-5 (DESIGN 3.10)'},
@@ -586,7 +600,7 @@ def main():
         # HBM traffic per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
         # (separate runs: counters cannot be collected inside the timed region); null when no summary is committed
         pmc, pmc_file = {}, None
-        for cand in ('r05_bench_b32_pmc_summary.json', 'r04_bench_b32_pmc_summary.json', 'r03_bench_b32_pmc_summary.json', 'r02_bench_b32_pmc_summary.json', 'r01_bench_b32_pmc_summary.json'):
+        for cand in ('r06_bench_b32_pmc_summary.json', 'r05_bench_b32_pmc_summary.json', 'r04_bench_b32_pmc_summary.json', 'r03_bench_b32_pmc_summary.json', 'r02_bench_b32_pmc_summary.json', 'r01_bench_b32_pmc_summary.json'):
             try:
                 with open(os.path.join(ROOT, 'profiles', cand)) as f:
                     pmc, pmc_file = json.load(f), cand

@@ -6,9 +6,12 @@
 #   usage: [ROUND=r04] [FULL=1] tools/collect_profiles.sh        FULL=1 adds the c4 / c5 / c5 --fp8 / --train lines
 set -u
 ROOT=$PWD
-R=${ROUND:-r05}
+R=${ROUND:-r06}
 OUT=$ROOT/gpurun_out/final
 rm -rf $OUT; mkdir -p $OUT
+# which box (the pool's boxes differ by up to 9 % on the headline): every file of this collection comes from the ONE box recorded here
+{ echo "collected $(date -u +%Y-%m-%dT%H:%M:%SZ) on host $(hostname)"; cat /sys/class/drm/card*/device/unique_id 2>/dev/null | head -1 | sed 's/^/gpu unique_id /';
+  rocm-smi --showuniqueid --showproductname --showpower --showclocks --showmaxpower 2>/dev/null | grep -v "^=\|^$" | head -24; } > $OUT/${R}_box.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-parity-tier --no-cpu-baseline --no-graph-leg --no-off-ideal"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/p_k -o bench --output-format csv -- $BENCH > $OUT/prof_k.log 2>&1
@@ -31,6 +34,15 @@ if [ "${FULL:-0}" = 1 ]; then
   timeout 200 python bench.py --train --steps 10 --warmup 3 > $OUT/${R}_bench_train_b32.json 2> $OUT/bench_train.err
   bash tools/r5_kstats.sh ${R}_f16x2_fp32w_final --precision f16x2 > $OUT/k_tier1.log 2>&1
   bash tools/r5_kstats.sh ${R}_f16x2_bf16w_final --precision f16x2 --bf16-round-weights > $OUT/k_tier2.log 2>&1
+  # round 6: the tier's HBM counters (parity_tier.roofline.traffic): kernel trace + FETCH_SIZE + WRITE_SIZE passes of the general-fp32-checkpoint tier
+  TB="python $ROOT/bench.py --steps 2 --warmup 1 --no-parity-tier --no-cpu-baseline --no-graph-leg --no-off-ideal --precision f16x2"
+  ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/t_k -o bench --output-format csv -- $TB > $OUT/prof_tk.log 2>&1
+    timeout 500 rocprofv3 --pmc FETCH_SIZE -d $OUT/t_f -o bench --output-format csv -- $TB > $OUT/prof_tf.log 2>&1
+    timeout 500 rocprofv3 --pmc WRITE_SIZE -d $OUT/t_w -o bench --output-format csv -- $TB > $OUT/prof_tw.log 2>&1 )
+  python tools/summarize_profile.py $OUT/t_k $OUT/t_f $OUT/t_w $OUT/${R}_f16x2 3 > $OUT/${R}_f16x2_summary.txt 2>&1
+  cp $OUT/${R}_f16x2_pmc_summary.json profiles/ 2>/dev/null
+  rm -f $OUT/t_k/bench_kernel_trace.csv $OUT/t_*/bench_counter_collection.csv
 fi
+{ echo "# box: $(head -2 $OUT/${R}_box.txt | tr '\n' ' ')"; cat $OUT/${R}_bench_b32_summary.txt; } > $OUT/tmp_sum && mv $OUT/tmp_sum $OUT/${R}_bench_b32_summary.txt
 tail -n 45 $OUT/${R}_bench_b32_summary.txt
 for f in $OUT/${R}_bench_*.json; do echo "== $f"; tail -c 500 $f; echo; done
