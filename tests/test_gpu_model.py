@@ -25,7 +25,12 @@ from muse_maskgit_pytorch_amd import _lib, ops
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
-ENGINE_MODEL_TOL = 1.0      # (placeholder: set from the measured values)
+# engine vs oracle/engine_model.py (its own rounding points), fraction of the logits' scale.  Measured (round 6, tiny config, logits scale 20.5): max 3.1e-3 / 2.8e-3
+# (fold on / off), mean 4.2e-4 -- NOT better than against the round-1 oracle (3.4e-3 / 3.2e-3), and the same with the fold off, where that oracle has exactly the engine's
+# rounding points: what separates two bf16 evaluations with identical rounding points is the bf16 roundings that a different fp32 accumulation order flips (one flip =
+# 2^-8 of that activation, carried through the remaining layers), not a mis-modelled rounding point.  SURVEY 8c's "L1: <= 1e-3 against a bf16-cast oracle" is therefore
+# not attainable in the maximum norm for a multi-layer bf16 network unless the accumulation order is reproduced as well; the mean is.
+ENGINE_MODEL_TOL = 5e-3
 
 
 def _tiny_transformer(golden):
