@@ -426,7 +426,7 @@ def test_cross_attention_block_as_an_operator(n, L):
 # ------------------------------------------------------------------------------------------------ sampling tail
 def test_mask_step_matches_stable_topk():
     g = torch.Generator().manual_seed(9)
-    for n, k in [(64, 64), (64, 55), (256, 23), (256, 1), (1024, 617)]:
+    for n, k in [(64, 64), (64, 55), (256, 23), (256, 1), (1024, 617), (1024, 1024), (1023, 300), (450, 0), (2500, 1999), (4096, 5)]:      # (round 6: up to 1024 threads, chunked beyond; lengths that are no multiple of 4 / 64)
         scores = torch.rand(3, n, generator=g)
         scores[0, ::3] = 0.5                      # ties, including across the k boundary
         scores[1, :] = 0.0                        # the all-zero first step (mmp.py:520)
