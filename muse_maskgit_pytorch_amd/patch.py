@@ -128,7 +128,9 @@ def _maskgit_shadow(ref):
               'critic_loss_weight', 'self_cond_prob', 'no_mask_token_prob'):
         setattr(sh, k, getattr(ref, k))
     sh._gen_ws = None
+    sh._graphs = {}                   # (generate(graph=True) through a patched reference object: the attributes MaskGit.__init__ would have set)
     sh.fused_sampling_fallbacks = 0
+    sh.fused_bound_switches = 0
     sh.fused_row_fallbacks = 0
     ref.__dict__[_SHADOW] = sh
     return sh
