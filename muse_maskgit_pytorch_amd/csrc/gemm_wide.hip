@@ -64,7 +64,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs p) {
     int tile_m, tile_n;
 #define TILE_SETUP(vb_)                                                                                                                \
     {                                                                                                                                  \
-        xcd_grouped_tile(vb_, p.tiles_m, p.tiles_n, 8, tile_m, tile_n);                                                                \
+        xcd_grouped_tile(vb_, p.tiles_m, p.tiles_n, p.group_m, tile_m, tile_n);                                                                \
         const int left_ = p.M - tile_m * TM;                                                                                           \
         rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.X + (size_t)tile_m * TM * p.ldx), 0,                              \
                                                (unsigned)(left_ < TM ? left_ : TM) * (unsigned)p.ldx * 2u, 0x00020000);      /* rows beyond M read as zero */ \
@@ -574,6 +574,7 @@ int launch_wide(GemmArgs a, hipStream_t stream) {
     }
     a.tiles_m = (a.M + TM - 1) / TM;
     a.tiles_n = a.N / (64 * NFW);
+    a.group_m = 8;      // row-tiles per group of the XCD-grouped tile order (round 6 sweep 1 .. 12 on w1 / q|k|v: 59.0-60.4 / 34.2-34.7 us -- the order does not matter)
     const int total = a.tiles_m * a.tiles_n;
     // persistent (one workgroup per CU) when the k-step count is even -- the prefetch across tiles relies on the stage parity --, one tile per workgroup otherwise
     const int grid = ((a.K / 64) % 2 == 0 && !(g_mm_debug & (1 << 22))) ? (total < 256 ? total : 256) : total;

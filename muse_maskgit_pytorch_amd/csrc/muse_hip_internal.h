@@ -28,6 +28,7 @@ struct GemmArgs {
     int act; float cfg_scale;
     int epi;                      // EPI_GEGLU: W rows are GEGLU-interleaved, the tile emits N/2 columns of gate*gelu(x)
     int tiles_m, tiles_n;         // filled by mm_gemm_launch
+    int group_m;                  // gemm_wide.hip: row-tiles per group of the XCD-grouped tile order (filled by its launcher)
     int splits; long split_stride; // split-K (weight gradients): gridDim.y = splits, split s sums k-tiles [s*K/splits, (s+1)*K/splits) into out + s*split_stride floats
     // LayerNorm(inner) folded into the FF GEMM pair (model.hip ff_block):
     //   w1 + GEGLU (any kernel of the family): ln_part != NULL -> per output row and 64 output columns the sum and sum of squares of

@@ -75,6 +75,7 @@ int main(int argc, char** argv) {
     auto want = [&](const char* c) { if (cases.empty()) return true; for (auto& s : cases) if (s == c) return true; return false; };
     MK(mm_device_check());
     mm_debug_set(debug);
+    if (getenv("MM_DEBUG2")) mm_debug_set2((int)strtoul(getenv("MM_DEBUG2"), nullptr, 0));      // (tools: the second debug word)
     const int M = 16384, D = 512, I = 512, F = 1365, Fp = 1408, V = 65536, R = 5140;
     if (want("qkv")) {
         void* x = dev_bf16((size_t)M * D, 1.f); void* w = dev_bf16((size_t)3 * I * D, 0.04f);
