@@ -247,6 +247,8 @@ class Transformer(nn.Module):
         self.fused_bound = 'auto'      # fused sampling, per-row bound of the k-th largest logit: 'gaussian' (rounds 2-4: from the vocabulary statistics of to_logits; ~1 ms per
                                        # generate cheaper), 'quantile' (round 5: from sampled vocabulary columns, distribution-free), or 'auto' (default): Gaussian until a
                                        # generate shows it failing on this checkpoint, then the sampled bound for good (_Handle.ensure_logits_stats, MaskGit.generate)
+        self._pack_gen = 0             # bumped whenever the packed weights are dropped or the engine choice changes (part of MaskGit's hipGraph cache key)
+        self._ln_fold_auto = None      # the 'auto' LayerNorm-fold verdict for the current parameter values (None: not probed yet)
         self.layernorm_fold = 'auto'   # bf16 engine: LayerNorm(dim) folded into the GEMMs around it -- 'auto' (probed on the first call per packed model) | True | False (set_layernorm_fold)
 
     # ---- packing (once per parameter version / device)

@@ -169,6 +169,7 @@ class VQGanVAE(nn.Module):
             dims = (dim, *[dim * 2 ** t for t in range(discr_layers)])
             self.discr = Discriminator(dims=dims, channels=channels)
         self._packed = None
+        self._pack_gen = 0             # bumped whenever the packed copies are dropped (part of MaskGit's hipGraph cache key)
         self.precision = 'bf16'        # 'parity': fp32 storage + fp32 MFMA (set_precision)
         # round 6: 16-bit storage of the DECODER on the fast engines ('bf16' and 'f16x2'): 'f16' (default) = single fp16 terms -- fp16 weights x a power of two, NHWC fp16
         # activations, fp16 MFMA at the bf16 rate, fp32 accumulation; decoded pixels 2e-4 of the image scale against the reference instead of bf16's 1.6e-3 -- or 'bf16'

@@ -290,6 +290,45 @@ def test_vae_composite_handle_and_workspace_queries():
     assert lib.mm_vae_create(None, C.byref(out)) == -1
 
 
+def test_vae_half_decode_handle_packing_and_policy():
+    """Round 6: the decoder on fp16 storage (VQGanVAE.decode_storage; csrc/vae_model.hip `half`).  Host side only: the policy (which precision / storage pairs take it),
+    the fp16 packs (one fp16 term of scale * w, scale a power of two that puts the decoder's largest |w| into [2^13, 2^14); the value the kernels multiply, pack / scale,
+    within 2^-11 of w), the decode-only C handle (encode on it is refused, its workspace query answers), and that invalidating the weights drops it."""
+    import ctypes as C
+    from muse_maskgit_pytorch_amd import _lib as L
+    torch.manual_seed(2)
+    v = mm.VQGanVAE(dim=16, codebook_size=512)
+    assert v.decode_storage == 'f16' and v._half_decode()
+    for prec, storage, want in (('bf16', 'f16', True), ('bf16', 'bf16', False), ('f16x2', 'f16', True), ('f16x2', 'terms', False), ('f16x2', 'bf16', True),
+                                ('parity', 'f16', False), ('bf16x3', 'f16', False)):
+        v.set_precision(prec).set_decode_storage(storage)
+        assert v._half_decode() == want, (prec, storage)
+    v.set_precision('bf16').set_decode_storage('f16')
+    with pytest.raises(ValueError):
+        v.set_decode_storage('fp8')
+    H = v._pack_half()
+    scale = H['scale']
+    wmax = max(float(w.detach().abs().max()) for w in v._decoder_conv_weights())
+    assert math.log2(scale) == round(math.log2(scale)) and 2 ** 13 <= wmax * scale < 2 ** 14
+    assert [e['kind'] for e in H['dec']] == [e['kind'] for e in v._pack()['dec']] and H['enc'] == []
+    head = v.enc_dec.decoders[-1]
+    wp = H['dec'][-1]['w']
+    assert wp.dtype == torch.float16 and wp.shape == (3, 64)                     # [Cout][Kp]: K = 16 padded to 64
+    ref = head.weight.detach().reshape(3, 16)
+    got = wp[:, :16].float() / scale
+    assert (got - ref).abs().max() <= ref.abs().max() * 2.0 ** -11 and bool((wp[:, 16:] == 0).all())
+    up = H['dec'][1]
+    assert up['kind'] == 'up' and set(up['w']) == {(0, 0), (0, 1), (1, 0), (1, 1)} and all(t.dtype == torch.float16 for t in up['w'].values())
+    lib, h = L.lib(), H['handle'].h
+    assert lib.mm_vae_decode_workspace_bytes(h, 2, 8, 8) > 0
+    buf = C.create_string_buffer(64)
+    assert lib.mm_vae_encode(h, None, buf, 1, 64, 64, None, buf, buf, 1 << 30) == -7      # MM_ERR_UNSUPPORTED: the fp16-storage handle is decode-only
+    assert v._pack_half() is H                                                    # cached beside the bf16 packs ...
+    gen0 = v._pack_gen
+    v.invalidate_packed_weights()
+    assert v._packed is None and v._pack_gen == gen0 + 1 and v._pack_half() is not H      # ... and dropped with them
+
+
 def test_seeded_construction_matches_the_base_golden_recipe(golden):
     """The base-size golden stores no checkpoint: both sides rebuild it from seeds (oracle/golden_recipe.py).  This package's classes must
     reproduce the reference's parameters exactly -- checked against the checksums the reference run stored."""

@@ -102,3 +102,39 @@ def test_forced_step_comparator_with_the_oracle_at_the_tie(golden):
         near, band = TA.compare_forced_step(gen, s, new_ids, scores, counts, MASK_ID, EPS, O.select_topk_stable)
         assert near == 0 and band == 2
         break
+
+
+def test_min_eps_finds_the_smallest_explaining_band(golden):
+    """tie_aware.min_eps (round 6: the bf16 engine's id contract): bands only grow with eps, so the smallest eps that explains a run is found by bisection.
+    On the un-scanned fixture: swapping the two boundary positions of (step 8, sample 0) is explained from eps ~ 2.3e-6 / (s (1 - s)) on -- far below 5e-4 --
+    the reference against itself needs eps 0, and a wrong id at a position whose reference margin is m needs eps just above m (never less)."""
+    gen = _gen(golden)
+    counts = O.mask_counts(R.T, R.N)
+    ref_in, final = gen['step_in_ids'].long(), gen['final_ids'].reshape(R.B, R.N).long()
+    assert TA.min_eps(lambda e: TA.compare_free_run(gen, ref_in, final, counts, MASK_ID, e)) == 0.
+    band = TA.boundary_band(gen['scores_in'][8, 0], counts[8], EPS).nonzero().flatten().tolist()
+    alt = ref_in.clone()
+    i, j = band
+    if alt[8, 0, i] != MASK_ID:
+        i, j = j, i
+    prev = torch.where(ref_in[7, 0] == MASK_ID, gen['pred_ids'][7, 0].long(), ref_in[7, 0])
+    alt[8, 0, i], alt[8, 0, j] = prev[i], MASK_ID
+    e_swap = TA.min_eps(lambda e: TA.compare_free_run(gen, alt, final, counts, MASK_ID, e))
+    assert 0. < e_swap < EPS, e_swap
+    # a wrong sampled id at a masked position of step 3: explained only by a band at least as wide as that position's own arg-max margin
+    s = 3
+    masked = (ref_in[s, 1] == MASK_ID).nonzero().flatten()
+    pos = int(masked[gen['argmax_margin'][s, 1][masked].argmin()])
+    m = float(gen['argmax_margin'][s, 1, pos])
+    new_ids = torch.where(ref_in[s] == MASK_ID, gen['pred_ids'][s].long(), ref_in[s])
+    new_ids[1, pos] = (new_ids[1, pos] + 1) % 65536
+    scores = gen['scores_in'][s + 1].clone()
+
+    def forced(e):
+        TA.compare_forced_step(gen, s, new_ids, scores, counts, MASK_ID, e, O.select_topk_stable)
+
+    e_id = TA.min_eps(forced)
+    assert e_id is not None and m < e_id <= m * 1.03 + 1e-7, (m, e_id)
+    near, bandfrac = TA.band_population(gen, counts, MASK_ID, e_id)
+    assert 0. < near <= 1. and 0. <= bandfrac <= 1.
+    assert TA.band_population(gen, counts, MASK_ID, 1e-9)[0] == 0.      # no sampling decision of this fixture is an exact tie
