@@ -191,8 +191,30 @@ int k_cross_fold_null_row(hipStream_t s, const bf16_t* vwt, int m, float* out); 
 int k_vq_nearest(hipStream_t s, const float* x, long ldx, int N, int C, const float* cb, int K, int cosine, float* aux, int64_t* ids);
 int k_vq_gather(hipStream_t s, const int64_t* ids, long N, int C, const float* cb, float* out);
 
+// train_prep.hip: the fp32 master weights of a training step -> their bf16 operand copies (optionally padded / placed inside a concatenated operand) and the
+// transposed copies, one 64 x 64 tile per workgroup, a table of jobs per launch
+struct PrepJob {
+    const float* src;      // fp32 [rows][cols], dense
+    void* dst;             // bf16 [rows_p][ld_d] (first cols_p columns written; zeros outside the source) or nullptr;  kind 1: fp32 [cols_p]
+    bf16_t* dst_t;         // bf16 [cols_p][ld_t] (first rows_p columns written) or nullptr
+    int rows, cols, rows_p, cols_p, ld_d, ld_t, tile0, kind;
+};
+constexpr int PREP_MAX_JOBS = 64;
+struct PrepArgs {
+    PrepJob job[PREP_MAX_JOBS];
+    int njobs;
+};
+struct PrepList {
+    PrepArgs a;
+    hipStream_t s;
+    int tiles = 0, rc = 0;
+    explicit PrepList(hipStream_t stream) : s(stream) { a.njobs = 0; }
+    void add(const float* src, void* dst, bf16_t* dst_t, int rows, int cols, int rows_p, int cols_p, int ld_d, int ld_t, int kind = 0);
+    int flush();           // launches what has been added (a full table is launched by add()); returns the first error of the list
+};
+
 // train.hip / attention_bwd.hip: backward operators
-int k_transpose_bf16(hipStream_t s, const bf16_t* in, long rows, long cols, long ldi, bf16_t* out, long ldo);
+int k_transpose_bf16(hipStream_t s, const bf16_t* in, long rows, long cols, long ldi, bf16_t* out, long ldo, int zero_pad64 = 0);   // zero_pad64: also write zeros up to rows rounded to 64 (needs ldo >= that)
 int k_colsum(hipStream_t s, const float* part, int nparts, long D, float* out);
 long k_ln_bwd_workspace_floats(int rows, int D);
 int k_layernorm_bwd(hipStream_t s, const float* x, long ldx, const bf16_t* dy, long lddy, const float* gamma, const int32_t* row_index,

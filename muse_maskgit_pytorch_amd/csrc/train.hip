@@ -17,8 +17,10 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------ transpose
+// wrows: output columns written per output row -- `rows`, or (mm_train_step's operands) rows rounded up to 64 with the padding written as zeros HERE (the tile rows
+// past `rows` are zero-filled on the way in) instead of by a memset of the whole output in front of the launch
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, long rows, long cols, long ldi,
-                                                             bf16_t* __restrict__ out, long ldo) {
+                                                             bf16_t* __restrict__ out, long ldo, long wrows) {
     __shared__ bf16_t tile[64][72];          // row pitch 144 B
     const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
     const int t = threadIdx.x;
@@ -47,10 +49,10 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
 #pragma unroll
         for (int j = 0; j < 8; ++j) tmp[j] = tile[r + j][c];
         bf16_t* op = out + (c0 + c) * ldo + r0 + r;
-        if (r0 + r + 8 <= rows) *reinterpret_cast<uint4*>(op) = *reinterpret_cast<const uint4*>(tmp);
+        if (r0 + r + 8 <= wrows) *reinterpret_cast<uint4*>(op) = *reinterpret_cast<const uint4*>(tmp);
         else
             for (int j = 0; j < 8; ++j)
-                if (r0 + r + j < rows) op[j] = tmp[j];
+                if (r0 + r + j < wrows) op[j] = tmp[j];
     }
 }
 
@@ -164,20 +166,31 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
-// out[c] = sum over p of part[p][c] in a fixed order (deterministic): 64 columns per workgroup, 4 interleaved partial streams
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int nparts, long D, float* __restrict__ out) {
-    __shared__ float red[4][64];
-    const long c = (long)blockIdx.x * 64 + (threadIdx.x & 63);
-    const int rg = threadIdx.x >> 6;
-    float s0 = 0.f, s1 = 0.f;
+// out[c] = sum over p of part[p][c] in a fixed order (deterministic): 64 columns per workgroup.  The association is that of rounds 1-5 -- eight serial chains per
+// column, chain (rg, a) = the parts p with p mod 4 == rg and (p / 4) mod 2 == a in ascending order, out = ((s00 + s01) + (s10 + s11)) + ((s20 + s21) + (s30 + s31)) --
+// so every sum is bit-identical to what the 256-thread kernel produced.  Round 6: one WAVE per chain (512 threads) and sixteen loads of a chain in flight per lane:
+// the 1024 x 64 partials of a q / k scale gradient took 62 us on one workgroup with two dependent loads per trip (a training step reduces 128 such tables: 2.5 ms
+// of its side stream), now 8 trips of latency.
+__global__ __launch_bounds__(512) void colsum_kernel(const float* __restrict__ part, int nparts, long D, float* __restrict__ out) {
+    __shared__ float red[8][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;      // chain rg = w & 3, a = w >> 2: parts (w & 3) + 4 * (w >> 2) + 8 i
+    const long c = (long)blockIdx.x * 64 + lane;
+    float s = 0.f;
     if (c < D) {
-        int p = rg;
-        for (; p + 4 < nparts; p += 8) { s0 += part[(long)p * D + c]; s1 += part[(long)(p + 4) * D + c]; }
-        if (p < nparts) s0 += part[(long)p * D + c];
+        int p = (w & 3) + 4 * (w >> 2);
+        constexpr int U = 16;
+        for (; p + 8 * (U - 1) < nparts; p += 8 * U) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = part[(long)(p + 8 * u) * D + c];
+#pragma unroll
+            for (int u = 0; u < U; ++u) s += v[u];
+        }
+        for (; p < nparts; p += 8) s += part[(long)p * D + c];
     }
-    red[rg][threadIdx.x & 63] = s0 + s1;
+    red[w][lane] = s;
     __syncthreads();
-    if (rg == 0 && c < D) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (w == 0 && c < D) out[c] = ((red[0][lane] + red[4][lane]) + (red[1][lane] + red[5][lane])) + ((red[2][lane] + red[6][lane]) + (red[3][lane] + red[7][lane]));
 }
 
 // The same sums in the same association for WIDE inputs (the split-K slabs of a weight gradient: D = N x K, a handful of parts): one thread owns 4 adjacent
@@ -532,10 +545,11 @@ __global__ __launch_bounds__(256) void scatter_rows_bf16_kernel(const bf16_t* __
 
 }  // namespace
 
-int k_transpose_bf16(hipStream_t s, const bf16_t* in, long rows, long cols, long ldi, bf16_t* out, long ldo) {
+int k_transpose_bf16(hipStream_t s, const bf16_t* in, long rows, long cols, long ldi, bf16_t* out, long ldo, int zero_pad64) {
     if (rows <= 0 || cols <= 0) return MM_OK;
     if ((ldi % 8) || (ldo % 8)) return mm_set_error(MM_ERR_ALIGN, "transpose: strides must be multiples of 8 elements");
-    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64)), dim3(256), 0, s, in, rows, cols, ldi, out, ldo);
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64)), dim3(256), 0, s, in, rows, cols, ldi, out, ldo,
+                       zero_pad64 ? (rows + 63) / 64 * 64 : rows);
     return mm_check_launch("transpose_bf16_kernel");
 }
 
@@ -545,7 +559,7 @@ int k_colsum(hipStream_t s, const float* part, int nparts, long D, float* out) {
         hipLaunchKernelGGL(colsum_wide_kernel, dim3((unsigned)((D / 4 + 255) / 256)), dim3(256), 0, s, part, nparts, D, out);
         return mm_check_launch("colsum_wide_kernel");
     }
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((D + 63) / 64)), dim3(256), 0, s, part, nparts, D, out);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((D + 63) / 64)), dim3(512), 0, s, part, nparts, D, out);
     return mm_check_launch("colsum_kernel");
 }
 
@@ -566,7 +580,7 @@ int k_layernorm_bwd(hipStream_t s, const float* x, long ldx, const bf16_t* dy, l
     else hipLaunchKernelGGL(layernorm_bwd_kernel<8>, dim3(blocks), dim3(256), 0, s, x, ldx, dy, lddy, gamma, row_index, rows, D, dx, lddx, accumulate, ws, dxb);
     int rc = mm_check_launch("layernorm_bwd_kernel");
     if (rc || !dgamma) return rc;
-    hipLaunchKernelGGL(colsum_kernel, dim3((D + 63) / 64), dim3(256), 0, s, ws, blocks, (long)D, dgamma);
+    hipLaunchKernelGGL(colsum_kernel, dim3((D + 63) / 64), dim3(512), 0, s, ws, blocks, (long)D, dgamma);
     return mm_check_launch("colsum_kernel");
 }
 
@@ -581,7 +595,7 @@ int k_geglu_ln_bwd(hipStream_t s, const bf16_t* h, long ldh, const bf16_t* dz, l
     else return mm_set_error(MM_ERR_SHAPE, "geglu_ln_bwd: padded inner width above 3072 is not built");
     int rc = mm_check_launch("geglu_ln_bwd_kernel");
     if (rc || !dgamma) return rc;      // (dgamma == nullptr: partials only, as k_layernorm_bwd)
-    hipLaunchKernelGGL(colsum_kernel, dim3((Fp + 63) / 64), dim3(256), 0, s, ws, blocks, (long)Fp, dgamma);
+    hipLaunchKernelGGL(colsum_kernel, dim3((Fp + 63) / 64), dim3(512), 0, s, ws, blocks, (long)Fp, dgamma);
     return mm_check_launch("colsum_kernel");
 }
 
@@ -604,7 +618,7 @@ int k_bce_head_bwd(hipStream_t s, const bf16_t* e, long lde, const float* x, con
     else hipLaunchKernelGGL(bce_head_bwd_kernel<4>, dim3(blocks), dim3(256), 0, s, e, lde, x, y, w, rows, D, inv, de, ldde, ws);
     int rc = mm_check_launch("bce_head_bwd_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(colsum_kernel, dim3((D + 63) / 64), dim3(256), 0, s, ws, blocks, (long)D, dw);
+    hipLaunchKernelGGL(colsum_kernel, dim3((D + 63) / 64), dim3(512), 0, s, ws, blocks, (long)D, dw);
     return mm_check_launch("colsum_kernel");
 }
 

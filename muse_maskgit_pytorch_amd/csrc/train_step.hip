@@ -75,7 +75,7 @@ struct Bufs {
     float *hd_ws, *de32;                                   // the head's split-K dX: slabs, fp32 sum
     int hd_splits;
     float* gtmp2;                                          // LayerNorm(inner) gain gradient padded to Fp (caller's stream; gtmp belongs to the dW GEMMs)
-    bf16_t *twl, *tcx, *w2tmp;                             // transposed to_logits weight [D][V], transposed context [D][Mcp], dense bf16 w2 before its padding
+    bf16_t *twl, *tcx;                                     // transposed to_logits weight [D][V], transposed context [D][Mcp]
 };
 
 struct Dims { int B, n, L, R, M, D, H, I, F, Fp, V, td, Mc, depth; };
@@ -139,14 +139,15 @@ void carve(Arena& A, const mm_train_desc& d, const Dims& q, Bufs& b, LayerBufs* 
     size_t tw = D * V; if (D * wide > tw) tw = D * wide; if (Fp * (size_t)pad64((int)D) > tw) tw = Fp * (size_t)pad64((int)D);
     b.tA = A.take<bf16_t>(ta); b.tB = A.take<bf16_t>(tb); b.tW = A.take<bf16_t>(tw);
     b.gtmp2 = A.take<float>(Fp);
-    b.twl = A.take<bf16_t>(D * V); b.tcx = A.take<bf16_t>(D * Mcp); b.w2tmp = A.take<bf16_t>(D * (size_t)q.F);
+    b.twl = A.take<bf16_t>(D * V); b.tcx = A.take<bf16_t>(D * Mcp);
 }
 
 // out [cols][Rp] = x [rows][cols]^T, Rp = rows rounded up to 64, padding columns zero   (training.py _t)
 int tr64(mm_stream_t st, hipStream_t s, const bf16_t* x, long rows, long cols, long ld, bf16_t* out) {
-    const long Rp = pad64((int)rows);
-    if (Rp != rows) HC(hipMemsetAsync(out, 0, (size_t)cols * Rp * 2, s));
-    return mm_transpose_bf16(st, x, rows, cols, ld, out, Rp);
+    // (round 6: the zero padding of the last 64-row block is written by the transpose itself -- in front of the head's dW GEMM the memset this replaces cleared
+    //  vocabulary x Rp x 2 bytes = 730 MB per step)
+    (void)st;
+    return k_transpose_bf16(s, x, rows, cols, ld, out, pad64((int)rows), 1);
 }
 // dW fp32 [N_][K_] = dY^T X for dY bf16 [rows][N_] (ld ldy), X bf16 [rows][K_] (ld ldx)   (training.py _wgrad)
 // xt: the transposed activation [K_][Rp] when the side stream has already made it (else nullptr: made here into tB)
@@ -268,47 +269,38 @@ int mm_train_step(const mm_train_desc* desc, mm_stream_t stream, const int64_t* 
     RC(mark(sd, s, &e_in));
     RC(await(s2, e_in));                                   // the parameters (and this workspace) as the caller's stream leaves them
 
-    // ================================================================ side stream, part 1: bf16 operand copies of the parameters, then their transposes
-    for (int l = 0; l < q.depth; ++l) {
-        const mm_train_layer& w = d.layers[l];
-        LayerBufs& y = layers[l];
-        RC(mm_f32_to_bf16(stream2, w.sa.to_q, y.wqkv, (int64_t)I * D));
-        RC(mm_f32_to_bf16(stream2, w.sa.to_kv, y.wqkv + (size_t)I * D, (int64_t)2 * I * D));
-        RC(mm_f32_to_bf16(stream2, w.sa.to_out, y.wo, (int64_t)D * I));
-        RC(mm_f32_to_bf16(stream2, w.ca.to_q, y.wq2, (int64_t)I * D));
-        RC(mm_f32_to_bf16(stream2, w.ca.to_kv, y.wkv2, (int64_t)2 * I * D));
-        RC(mm_f32_to_bf16(stream2, w.ca.to_out, y.wo2, (int64_t)D * I));
-        // feed forward (mmp.py:79-89): plain [x | gate] halves padded to Fp (the backward recomputes GEGLU from the saved pre-activation)
-        HC(hipMemsetAsync(y.w1p, 0, (size_t)2 * Fp * D * 2, s2));
-        RC(mm_f32_to_bf16(stream2, w.ff.w1, y.w1p, (int64_t)F * D));
-        RC(mm_f32_to_bf16(stream2, w.ff.w1 + (size_t)F * D, y.w1p + (size_t)Fp * D, (int64_t)F * D));
-        if (Fp != F) {      // w2 [D][F] -> bf16 [D][Fp], zero columns: row by row through a dense bf16 copy
-            HC(hipMemsetAsync(y.w2p, 0, (size_t)D * Fp * 2, s2));
-            RC(mm_f32_to_bf16(stream2, w.ff.w2, b.w2tmp, (int64_t)D * F));
-            HC(hipMemcpy2DAsync(y.w2p, (size_t)Fp * 2, b.w2tmp, (size_t)F * 2, (size_t)F * 2, D, hipMemcpyDeviceToDevice, s2));
-        } else {
-            RC(mm_f32_to_bf16(stream2, w.ff.w2, y.w2p, (int64_t)D * F));
+    // ================================================================ side stream, part 1: bf16 operand copies of the parameters and their transposes
+    // (round 6: a job table per launch -- train_prep.hip -- instead of ~190 conversions, memsets, strided copies and transposes: layer 0 first, so that the forward
+    //  starts behind ONE small launch; the other layers and the head follow while it runs)
+    {
+        PrepList P(s2);
+        int marked = 0;
+        for (int l = 0; l < q.depth; ++l) {
+            const mm_train_layer& w = d.layers[l];
+            LayerBufs& y = layers[l];
+            P.add(w.sa.to_q, y.wqkv, y.twqkv, I, D, I, D, D, pad64(3 * I));                                      // [to_q ; to_kv] -> wqkv [3I][D], twqkv [D][3I]
+            P.add(w.sa.to_kv, y.wqkv + (size_t)I * D, y.twqkv + I, 2 * I, D, 2 * I, D, D, pad64(3 * I));
+            P.add(w.sa.to_out, y.wo, y.two, D, I, D, I, I, pad64(D));
+            P.add(w.ca.to_q, y.wq2, y.twq2, I, D, I, D, D, pad64(I));
+            P.add(w.ca.to_kv, y.wkv2, d.text_proj ? y.twkv2 : nullptr, 2 * I, D, 2 * I, D, D, pad64(2 * I));
+            P.add(w.ca.to_out, y.wo2, y.two2, D, I, D, I, I, pad64(D));
+            // feed forward (mmp.py:79-89): plain [x | gate] halves padded to Fp (the backward recomputes GEGLU from the saved pre-activation)
+            P.add(w.ff.w1, y.w1p, y.tw1p, F, D, Fp, D, D, pad64(2 * Fp));
+            P.add(w.ff.w1 + (size_t)F * D, y.w1p + (size_t)Fp * D, y.tw1p + Fp, F, D, Fp, D, D, pad64(2 * Fp));
+            P.add(w.ff.w2, y.w2p, y.tw2p, D, F, D, Fp, Fp, pad64(D));                                            // w2 [D][F] -> [D][Fp], zero columns
+            P.add(w.ff.g2, y.g2p, nullptr, 1, F, 1, Fp, 0, 0, 1);
+            if (w.ff.b2) P.add(w.ff.b2, y.b2p, nullptr, 1, F, 1, Fp, 0, 0, 1);
+            if (l == 0 || l == q.depth - 1) {
+                RC(P.flush());
+                hipEvent_t e;
+                RC(mark(sd, s2, &e));
+                for (; marked <= l; ++marked) e_w[marked] = e_tw[marked] = e;
+            }
         }
-        HC(hipMemsetAsync(y.g2p, 0, (size_t)Fp * 4, s2));
-        HC(hipMemsetAsync(y.b2p, 0, (size_t)Fp * 4, s2));
-        HC(hipMemcpyAsync(y.g2p, w.ff.g2, (size_t)F * 4, hipMemcpyDeviceToDevice, s2));
-        if (w.ff.b2) HC(hipMemcpyAsync(y.b2p, w.ff.b2, (size_t)F * 4, hipMemcpyDeviceToDevice, s2));
-        RC(mark(sd, s2, &e_w[l]));
-    }
-    RC(mm_f32_to_bf16(stream2, d.to_logits, b.wl, (int64_t)V * D));
-    RC(mark(sd, s2, &e_wl));
-    RC(tr64(stream2, s2, b.wl, V, D, D, b.twl));           // the backward starts at the head and walks the layers downwards
-    RC(mark(sd, s2, &e_twl));
-    for (int l = q.depth - 1; l >= 0; --l) {
-        LayerBufs& y = layers[l];
-        RC(tr64(stream2, s2, y.w2p, D, Fp, Fp, y.tw2p));
-        RC(tr64(stream2, s2, y.w1p, 2 * Fp, D, D, y.tw1p));
-        RC(tr64(stream2, s2, y.wo2, D, I, I, y.two2));
-        RC(tr64(stream2, s2, y.wq2, I, D, D, y.twq2));
-        if (d.text_proj) RC(tr64(stream2, s2, y.wkv2, 2 * I, D, D, y.twkv2));
-        RC(tr64(stream2, s2, y.wo, D, I, I, y.two));
-        RC(tr64(stream2, s2, y.wqkv, 3 * I, D, D, y.twqkv));
-        RC(mark(sd, s2, &e_tw[l]));
+        P.add(d.to_logits, b.wl, b.twl, V, D, V, D, D, pad64(V));
+        RC(P.flush());
+        RC(mark(sd, s2, &e_wl));
+        e_twl = e_wl;
     }
 
     // ================================================================ forward (training.py TransformerTrainFn.forward)
