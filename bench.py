@@ -409,6 +409,25 @@ def train_bench(args, dev, rank, world, dist):
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    if args.train_phases:      # tools: device-side duration of the phases of a step (events on the stream) and the host's time in each, printed to stderr -- not the timed run
+        evs, host = [], []
+        for _ in range(8):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            h = [time.perf_counter()]
+            opt.zero_grad(set_to_none=True)
+            e[0].record()
+            loss = mg(ids, text_embeds=te); e[1].record(); h.append(time.perf_counter())
+            loss.backward(); e[2].record(); h.append(time.perf_counter())
+            opt.step(); e[3].record(); h.append(time.perf_counter())
+            evs.append(e); host.append(h)
+        torch.cuda.synchronize()
+        for i in range(2, 8):
+            e, h = evs[i], host[i]
+            sys.stderr.write('[train phases] device: MaskGit.forward (masking + C step) %.3f ms, backward() %.3f ms, AdamW %.3f ms, to the next step\'s first event %s ms | '
+                             'host: forward %.3f, backward %.3f, optimizer %.3f ms\n' % (
+                                 e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]), e[2].elapsed_time(e[3]),
+                                 ('%.3f' % e[3].elapsed_time(evs[i + 1][0])) if i + 1 < 8 else '-',
+                                 (h[1] - h[0]) * 1e3, (h[2] - h[1]) * 1e3, (h[3] - h[2]) * 1e3))
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
@@ -485,6 +504,7 @@ def main():
     ap.add_argument('--fused-bound', choices=['auto', 'quantile', 'gaussian'], default='auto', help="A/B: the fused sampler's bound of the k-th largest logit (Transformer.fused_bound); 'gaussian' = rounds 2-4")
     ap.add_argument('--bf16-round-weights', action='store_true', help='secondary line: round the random-init parameters to bf16 first (the bf16-representable checkpoint of the tier figures)')
     ap.add_argument('--vae-storage', choices=['f16', 'bf16'], default='f16', help="A/B: 16-bit storage of the VAE decoder (VQGanVAE.decode_storage; 'bf16' = rounds 1-5)")
+    ap.add_argument('--train-phases', action='store_true', help='with --train: print device- and host-side durations of the phases of a step to stderr (tools)')
     ap.add_argument('--train', action='store_true', help='time the TRAINING step of the C2 base transformer (MaskGit.forward + backward + AdamW) instead of '
                     'generation: a second, separately labelled line -- not the BASELINE metric')
     args = ap.parse_args()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 8
+#define MM_ABI_VERSION 9
 
 #define MM_OK 0
 #define MM_ERR_SHAPE (-1)
@@ -223,9 +223,12 @@ int mm_ce_bwd(mm_stream_t stream, const float* logits, int64_t ld, int R, int V,
 int mm_bce_head_bwd(mm_stream_t stream, const void* e, int64_t lde, const float* x, const float* y, const float* w, int rows, int D,
                     void* de, int64_t ldde, float* dw, float* ws);
 
-/* Embedding backward (mmp.py:322-323): dx fp32 [B*n][D]; dpos fp32 [n][D] is overwritten, dtoken fp32 [rows of the table][D]
- * must be zeroed by the caller and is accumulated with fp32 atomics (the one non-deterministic sum of the backward pass). */
-int mm_embed_bwd(mm_stream_t stream, const int64_t* ids, int B, int n, int D, const float* dx, float* dtoken, float* dpos);
+/* Embedding backward (mmp.py:322-323): dx fp32 [B*n][D]; dpos fp32 [n][D] is overwritten; dtoken fp32 [rows of the table][D] must be zeroed by the
+ * caller and receives, per id, the sum of the gradient rows carrying that id -- deterministic (one writer per id, a fixed order of additions).
+ * ws == NULL: one serial chain per id and column (slow when one id owns most rows: the mask id of a training batch).  ws of
+ * mm_embed_bwd_workspace_bytes(B, n, D) bytes: two levels -- per 256-row block, then over the blocks (ABI 9; a different association of the same sum). */
+size_t mm_embed_bwd_workspace_bytes(int B, int n, int D);
+int mm_embed_bwd(mm_stream_t stream, const int64_t* ids, int B, int n, int D, const float* dx, float* dtoken, float* dpos, void* ws, size_t ws_bytes);
 /* dst[row_index[r]][:] = src[r][:] for r < R; bf16, D % 8 == 0 (gradient of a row gather; dst zeroed by the caller). */
 int mm_scatter_rows_bf16(mm_stream_t stream, const void* src, const int32_t* row_index, int R, int D, void* dst);
 

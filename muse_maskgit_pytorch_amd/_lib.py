@@ -127,7 +127,8 @@ SIGNATURES = {
     'mm_geglu_ln_bwd': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp]),
     'mm_ce_bwd': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_f32, c_vp, c_i64]),
     'mm_bce_head_bwd': (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_i64, c_vp, c_vp]),
-    'mm_embed_bwd': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    'mm_embed_bwd_workspace_bytes': (c_sz, [c_int, c_int, c_int]),
+    'mm_embed_bwd': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_sz]),
     'mm_scatter_rows_bf16': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
     'mm_sum_parts_bf16': (c_int, [c_vp, c_vp, c_int, c_i64, c_vp]),
     'mm_attention_bwd': (c_int, [c_vp] + [c_vp, c_i64, c_i64, c_i64] * 8 + [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32]),
@@ -220,7 +221,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.mm_abi_version() != 8:
+        if l.mm_abi_version() != 9:
             raise MuseHipError('libmuse_hip ABI version mismatch')
         if os.environ.get('MM_DEBUG'):      # tools / A-B runs only: kernel-selection bits (see muse_hip_internal.h)
             l.mm_debug_set(int(os.environ['MM_DEBUG'], 0))

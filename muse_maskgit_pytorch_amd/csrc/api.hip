@@ -331,6 +331,14 @@ int mm_gemm_wgrad_splits(int M, int N, int K) {
     const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
     const int kt = K / 64;
     int s = 1;
+    if (K >= 32768 && M >= 512 && N >= 128 && (N % 4) == 0) {
+        // a LONG contraction into few tiles (round 6: the training head's dX over the vocabulary): 256 x 128 tiles (gemm_big.hip, twice the flops per staged byte),
+        // enough splits for >= 2 workgroups per CU, >= 4096 of K per split.  (The 128 x 128 choice below gave 344 workgroups = 1.34 rounds on 256 CUs: 0.88 ms for
+        // 369 GFLOP.)
+        const long tb = (long)((M + 255) / 256) * ((N + 127) / 128);
+        while (tb * s < 512 && (kt % (s * 2)) == 0 && kt / (s * 2) >= 64) s *= 2;
+        return s;
+    }
     const long fill = 256;      // (384: 15.0-15.5 ms per C2 training step, 256: 14.3-15.1, 192: 15.0-15.6; same box -- measured through an environment override that no longer exists)
     while (tiles * s < fill && (kt % (s * 2)) == 0 && kt / (s * 2) >= 8) s *= 2;      // fill the 256 CUs, keep >= 512 of K per workgroup
     return s;
@@ -405,10 +413,14 @@ int mm_bce_head_bwd(mm_stream_t stream, const void* e, int64_t lde, const float*
     return k_bce_head_bwd((hipStream_t)stream, (const bf16_t*)e, lde, x, y, w, rows, D, (bf16_t*)de, ldde, dw, ws);
 }
 
-int mm_embed_bwd(mm_stream_t stream, const int64_t* ids, int B, int n, int D, const float* dx, float* dtoken, float* dpos) {
+size_t mm_embed_bwd_workspace_bytes(int B, int n, int D) { return (B <= 0 || n <= 0 || D <= 0) ? 0 : k_embed_bwd_workspace_bytes(B, n, D); }
+
+int mm_embed_bwd(mm_stream_t stream, const int64_t* ids, int B, int n, int D, const float* dx, float* dtoken, float* dpos, void* ws, size_t ws_bytes) {
     if (B == 0) return MM_OK;
     CHK_PTR(ids, "ids"); CHK_PTR(dx, "dx"); CHK_PTR(dtoken, "dtoken"); CHK_PTR(dpos, "dpos");
-    return k_embed_bwd((hipStream_t)stream, ids, B, n, D, dx, dtoken, dpos);
+    if (ws && ws_bytes < k_embed_bwd_workspace_bytes(B, n, D)) return mm_set_error(MM_ERR_WORKSPACE, "embed_bwd: workspace too small");
+    if (ws) CHK_ALIGN16(ws, "ws");
+    return k_embed_bwd((hipStream_t)stream, ids, B, n, D, dx, dtoken, dpos, ws);
 }
 
 int mm_scatter_rows_bf16(mm_stream_t stream, const void* src, const int32_t* row_index, int R, int D, void* dst) {

@@ -607,6 +607,7 @@ int mm_gemm_launch(GemmArgs a, hipStream_t stream) {
     if (a.splits > 1) {
         if (a.mode != MODE_DENSE || a.out_kind != OUT_F32 || a.resid_f32 || a.bias || a.epi != EPI_NONE || (a.K / BK) % a.splits)
             return mm_set_error(MM_ERR_SHAPE, "gemm: split-K needs a plain dense fp32-output GEMM with K/64 divisible by the split count");
+        if (mm_gemm_big_split_eligible(a)) return mm_gemm_big_launch(a, stream);      // (round 6: long contractions, see gemm_big.hip)
         a.tiles_n = (a.N + BT - 1) / BT;
         a.tiles_m = (a.M + BT - 1) / BT;
         return launch<MODE_DENSE>(a, stream);

@@ -44,7 +44,9 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
     const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wave_m = wid >> 1, wave_n = wid & 1;
     int tile_m, tile_n;
-    xcd_grouped_tile(blockIdx.x, p.tiles_m, p.tiles_n, 8, tile_m, tile_n);
+    // (split-K: column tiles fastest inside an XCD's run -- the few column tiles of a row tile then stream the SAME long activation panel through one L2 together;
+    //  with groups of 8 row tiles they sat on different XCDs and the head's dX read its 720 MB operand four times: 0.82 ms)
+    xcd_grouped_tile(blockIdx.x, p.tiles_m, p.tiles_n, p.splits > 1 ? 1 : 8, tile_m, tile_n);
     const int n0 = tile_n * BNB;
     const int m0 = tile_m * (MODE == MODE_CFG ? 128 : BMB);
 
@@ -126,8 +128,20 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    // split-K (round 6; plain dense fp32-output products with a LONG contraction and few tiles -- the training head's dX = dlogits . W over the vocabulary):
+    // blockIdx.y contracts its K / splits share into its own fp32 slab, the caller sums the slabs in a fixed order (k_colsum)
+    const int nsplit = (MODE == MODE_DENSE && !NP && !F16 && p.splits > 1) ? p.splits : 1;
+    if constexpr (MODE == MODE_DENSE && !NP && !F16) {
+        if (nsplit > 1) {
+            const int kbase = (int)blockIdx.y * (p.K / nsplit);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) wptr[i] += kbase;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xptr[i] += kbase;
+        }
+    }
     const int fr = lane & 15, fg = lane >> 4;
-    const int KT = NP ? KS / 32 : p.K / BK;
+    const int KT = NP ? KS / 32 : p.K / nsplit / BK;
     // fp32 residual (out = x + ...: attention out-projection, FF w2): this lane's 16 x 16 B of the tile's 128 KiB are fetched FIRST, ahead
     // of the DMA (VMEM returns in order, so the counted waits below see them retire before k-tile 0).  Read in the epilogue, the
     // residual made the write-out a read-modify-write latency tail of every workgroup at once (gemm.hip: 16 k vs 2.3 k cycles).
@@ -373,7 +387,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
                     for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += rp[r];
                 }
             }
-            float* op = reinterpret_cast<float*>(p.out) + orow * p.ldc + n;
+            float* op = reinterpret_cast<float*>(p.out) + (nsplit > 1 ? (size_t)blockIdx.y * p.split_stride : (size_t)0) + orow * p.ldc + n;
             if (full) *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
             else {
 #pragma unroll
@@ -424,7 +438,7 @@ int launch_big(const GemmArgs& a, hipStream_t stream) {
         attr_set = true;
     }
     const int blocks = a.tiles_m * a.tiles_n;
-    hipLaunchKernelGGL((gemm_big_kernel<MODE, F16, NP>), dim3(blocks), dim3(512), SMEM_B, stream, a);
+    hipLaunchKernelGGL((gemm_big_kernel<MODE, F16, NP>), dim3(blocks, (MODE == MODE_DENSE && !NP && !F16 && a.splits > 1) ? a.splits : 1), dim3(512), SMEM_B, stream, a);
     return mm_check_launch("gemm_big_kernel");
 }
 
@@ -439,7 +453,14 @@ bool mm_gemm_big_eligible(const GemmArgs& a) {
     return a.M >= 2 * tok && a.N >= BNB && tiles >= 256;      // one workgroup per CU: fewer tiles than CUs idles the chip
 }
 
+// split-K on the 256 x 128 tile: a long contraction whose 128 x 128 tiling is bound by operand traffic (64 flop per staged byte) -- each split keeps >= 4096 of K
+bool mm_gemm_big_split_eligible(const GemmArgs& a) {
+    return a.mode == MODE_DENSE && !a.f16 && a.splits > 1 && a.out_kind == OUT_F32 && !a.resid_f32 && !a.bias && a.epi == EPI_NONE && !a.m_dev && !a.ln_c1 && !a.xb_out &&
+           a.M >= 2 * BMB && a.N >= BNB && (a.N % 4) == 0 && ((a.K / BK) % a.splits) == 0 && a.K / a.splits >= 4096;
+}
+
 int mm_gemm_big_launch(GemmArgs a, hipStream_t stream) {
+    if (a.splits > 1 && !mm_gemm_big_split_eligible(a)) return mm_set_error(MM_ERR_UNSUPPORTED, "gemm_big: split-K needs a plain dense bf16 product with >= 4096 of K per split");
     a.tiles_n = (a.N + BNB - 1) / BNB;
     const int tm = a.mode == MODE_CFG ? 128 : BMB;
     a.tiles_m = (a.M + tm - 1) / tm;

@@ -76,7 +76,8 @@ extern int g_mm_debug;
 extern int g_mm_debug2;      // mm_debug_set2 (round 5): 1 = gemm_terms.hip whatever the tile count (tests: small batches through the production kernels), 2 = gemm_terms.hip and every term-sharing k-loop off (A/B), 4 = mm_train_step on the caller's stream only (A/B), 8 = gemm_wide_conv.hip off (A/B: convolutions on the 256 x 128 kernel), 16 = the VAE head not fused into the last up-sampling convolution (A/B), 32 = a ConvTranspose2d's parity classes as four launches (A/B)
 
 int mm_gemm_launch(GemmArgs a, hipStream_t stream);
-bool mm_gemm_big_eligible(const GemmArgs& a);      // gemm_big.hip: 256x128 tile, 3-stage counted-vmcnt pipeline
+bool mm_gemm_big_eligible(const GemmArgs& a);
+bool mm_gemm_big_split_eligible(const GemmArgs& a);      // split-K (a.splits > 1) on the 256 x 128 tile: >= 4096 of K per split      // gemm_big.hip: 256x128 tile, 3-stage counted-vmcnt pipeline
 int mm_gemm_big_launch(GemmArgs a, hipStream_t stream);
 bool mm_gemm_pers_eligible(const GemmArgs& a);
 bool mm_gemm_cfg2_eligible(const GemmArgs& a);
@@ -226,7 +227,8 @@ int k_ce_bwd(hipStream_t s, const float* logits, long ld, int R, int V, const in
 int k_ce_finish(hipStream_t s, const float* row_loss, int R, float* out);      // sampling.hip: mean of the row losses >= 0
 int k_bce_head_bwd(hipStream_t s, const bf16_t* e, long lde, const float* x, const float* y, const float* w, int rows, int D, bf16_t* de,
                    long ldde, float* dw, float* ws);
-int k_embed_bwd(hipStream_t s, const int64_t* ids, int B, int n, int D, const float* dx, float* dtoken, float* dpos);
+int k_embed_bwd(hipStream_t s, const int64_t* ids, int B, int n, int D, const float* dx, float* dtoken, float* dpos, void* ws = nullptr);   // ws: k_embed_bwd_workspace_bytes -> the two-level sum
+size_t k_embed_bwd_workspace_bytes(int B, int n, int D);
 int k_sum_parts_bf16(hipStream_t s, const bf16_t* parts, int P, long n, bf16_t* out);
 int k_scatter_rows_bf16(hipStream_t s, const bf16_t* src, const int32_t* row_index, int R, int D, bf16_t* dst);
 int k_attention_bwd(hipStream_t s, const bf16_t* q, long q_sb, long q_sh, long q_sn, const bf16_t* k, long k_sb, long k_sh, long k_sn,

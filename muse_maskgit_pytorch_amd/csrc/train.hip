@@ -464,6 +464,65 @@ __global__ __launch_bounds__(256) void embed_token_bwd_kernel(const int64_t* __r
         if (c0 + tid + i * 256 < D) dtoken[id * D + c0 + tid + i * 256] += acc[i];
 }
 
+// The same sum in TWO levels (round 6, used when the caller brings a workspace): the mask id owns about two thirds of a training batch's rows, and its serial
+// chain -- 5500 additions per column at the base size -- made the single-level kernel above 0.41 ms at the very end of the backward's dependent chain.
+//   LOCAL = true  : row r acts when it is the first row WITH ITS ID INSIDE ITS BLOCK of 256 rows; it sums the block's rows with that id (ascending) into
+//                   part[r] and sets first[r] (every other row clears its flag);
+//   LOCAL = false : row r acts when first[r] is set and no earlier flagged row carries its id; it adds part[j] of the flagged rows j >= r with that id
+//                   (ascending) to dtoken[id].
+// dtoken[id] = sum over blocks (ascending) of (sum over the block's rows, ascending): deterministic, a different association from the single-level kernel.
+template <bool LOCAL>
+__global__ __launch_bounds__(256) void embed_token_bwd2_kernel(const int64_t* __restrict__ ids, int R, int D, const float* __restrict__ src,
+                                                               float* __restrict__ dst, uint8_t* __restrict__ first) {
+    constexpr int U = 32;
+    __shared__ unsigned long long masks[4];
+    __shared__ int seen;
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int c = blockIdx.y * 256 + tid;
+    if (!LOCAL && !first[r]) return;
+    const int lo = LOCAL ? (r & ~255) : 0;
+    const int hi = LOCAL ? (lo + 256 < R ? lo + 256 : R) : R;
+    const int64_t id = ids[r];
+    if (tid == 0) seen = 0;
+    __syncthreads();
+    bool hit = false;
+    for (int j = lo + tid; j < r; j += 256) hit |= ids[j] == id && (LOCAL || first[j]);
+    if (__ballot(hit) != 0ull && lane == 0) seen = 1;
+    __syncthreads();
+    if (LOCAL && blockIdx.y == 0 && tid == 0) first[r] = seen ? 0 : 1;
+    if (seen) return;
+    float acc = 0.f;
+    for (int base = r & ~255; base < hi; base += 256) {
+        const int j = base + tid;
+        const unsigned long long m = __ballot(j >= r && j < hi && ids[j] == id && (LOCAL || first[j]));
+        if (lane == 0) masks[wid] = m;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            unsigned long long mm = masks[w];
+            while (mm) {
+                int jj[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    jj[u] = mm ? base + w * 64 + __builtin_ctzll(mm) : -1;
+                    mm &= mm - 1;
+                }
+                float v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) v[u] = (jj[u] >= 0 && c < D) ? src[(long)jj[u] * D + c] : 0.f;
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (jj[u] >= 0) acc += v[u];
+            }
+        }
+        __syncthreads();
+    }
+    if (c < D) {
+        if (LOCAL) dst[(long)r * D + c] = acc;
+        else dst[id * D + c] += acc;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ BCE head backward (TokenCritic)
 // logits x_m = e_m . w (Linear(dim, 1), mmp.py:383-386), loss = mean_m BCEWithLogits(x_m, y_m) (mmp.py:345-346):
 //   g_m = (sigmoid(x_m) - y_m) / M,   de_m = g_m * w (bf16),   dw = sum_m g_m * e_m  (per-workgroup partials, reduced by colsum)
@@ -631,12 +690,22 @@ int k_sum_parts_bf16(hipStream_t s, const bf16_t* parts, int P, long n, bf16_t* 
     return mm_check_launch("sum_parts_bf16_kernel");
 }
 
-int k_embed_bwd(hipStream_t s, const int64_t* ids, int B, int n, int D, const float* dx, float* dtoken, float* dpos) {
+size_t k_embed_bwd_workspace_bytes(int B, int n, int D) { return ((size_t)B * n * D * 4 + 255) / 256 * 256 + (size_t)B * n + 256; }
+
+int k_embed_bwd(hipStream_t s, const int64_t* ids, int B, int n, int D, const float* dx, float* dtoken, float* dpos, void* ws) {
     if (B <= 0) return MM_OK;
     if (D > 2048) return mm_set_error(MM_ERR_SHAPE, "embed_bwd: D <= 2048");
     hipLaunchKernelGGL(embed_pos_bwd_kernel, dim3(n), dim3(256), 0, s, B, n, D, dx, dpos);
     int rc = mm_check_launch("embed_pos_bwd_kernel");
     if (rc) return rc;
+    if (ws) {      // two levels: per-block partial rows, then the blocks' partials (see embed_token_bwd2_kernel)
+        float* part = reinterpret_cast<float*>(ws);
+        uint8_t* first = reinterpret_cast<uint8_t*>(ws) + ((size_t)B * n * D * 4 + 255) / 256 * 256;
+        const dim3 grid(B * n, (D + 255) / 256);
+        hipLaunchKernelGGL(embed_token_bwd2_kernel<true>, grid, dim3(256), 0, s, ids, B * n, D, dx, part, first);
+        hipLaunchKernelGGL(embed_token_bwd2_kernel<false>, grid, dim3(256), 0, s, ids, B * n, D, (const float*)part, dtoken, first);
+        return mm_check_launch("embed_token_bwd2_kernel");
+    }
     hipLaunchKernelGGL(embed_token_bwd_kernel<1>, dim3(B * n, (D + 255) / 256), dim3(256), 0, s, ids, B * n, D, dx, dtoken);
     return mm_check_launch("embed_token_bwd_kernel");
 }

@@ -75,6 +75,7 @@ struct Bufs {
     float *hd_ws, *de32;                                   // the head's split-K dX: slabs, fp32 sum
     int hd_splits;
     float* gtmp2;                                          // LayerNorm(inner) gain gradient padded to Fp (caller's stream; gtmp belongs to the dW GEMMs)
+    unsigned char* emb_ws;                                 // workspace of the embedding backward's two-level sum
     bf16_t *twl, *tcx;                                     // transposed to_logits weight [D][V], transposed context [D][Mcp]
 };
 
@@ -140,6 +141,7 @@ void carve(Arena& A, const mm_train_desc& d, const Dims& q, Bufs& b, LayerBufs* 
     b.tA = A.take<bf16_t>(ta); b.tB = A.take<bf16_t>(tb); b.tW = A.take<bf16_t>(tw);
     b.gtmp2 = A.take<float>(Fp);
     b.twl = A.take<bf16_t>(D * V); b.tcx = A.take<bf16_t>(D * Mcp);
+    b.emb_ws = A.take<unsigned char>(k_embed_bwd_workspace_bytes(q.B, q.n, q.D));
 }
 
 // out [cols][Rp] = x [rows][cols]^T, Rp = rows rounded up to 64, padding columns zero   (training.py _t)
@@ -457,7 +459,7 @@ int mm_train_step(const mm_train_desc* desc, mm_stream_t stream, const int64_t* 
     // ---- embeddings / text projection
     HC(hipMemsetAsync(d.d_token_emb, 0, (size_t)d.vocab_rows * D * 4, s));
     if (n < d.seq_len) HC(hipMemsetAsync(d.d_pos_emb, 0, (size_t)d.seq_len * D * 4, s));
-    RC(mm_embed_bwd(stream, ids, B, n, D, b.dres, d.d_token_emb, d.d_pos_emb));
+    RC(k_embed_bwd(s, ids, B, n, D, b.dres, d.d_token_emb, d.d_pos_emb, b.emb_ws));      // (two levels: train.hip embed_token_bwd2_kernel)
     if (d.text_proj) {
         RC(mm_f32_to_bf16(stream, b.dcx[dcx_i], b.dcxb, (int64_t)Mc * D));
         FORK();

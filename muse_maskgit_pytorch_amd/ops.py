@@ -445,15 +445,19 @@ def bce_head_bwd(e, x, y, w):
     return de, dw
 
 
-def embed_bwd(ids, dx, table_rows, dtoken=None):
-    """ids int64 [B,n], dx fp32 [B*n, D] -> (dtoken fp32 [table_rows, D], dpos fp32 [n, D]); dtoken: accumulate into this table."""
+def embed_bwd(ids, dx, table_rows, dtoken=None, two_level=True):
+    """ids int64 [B,n], dx fp32 [B*n, D] -> (dtoken fp32 [table_rows, D], dpos fp32 [n, D]); dtoken: accumulate into this table.
+    two_level=False: the workspace-free single chain per id (same sum, another association)."""
     _chk_cuda(ids, dx, dtoken)
     B, n = ids.shape
     D = dx.shape[1]
     assert dx.is_contiguous() and dx.dtype == torch.float32
     dtok = dtoken if dtoken is not None else torch.zeros(table_rows, D, dtype=torch.float32, device=dx.device)
     dpos = torch.empty(n, D, dtype=torch.float32, device=dx.device)
-    L.check(L.lib().mm_embed_bwd(L.stream(), L.ptr(ids.contiguous()), B, n, D, L.ptr(dx), L.ptr(dtok), L.ptr(dpos)), 'mm_embed_bwd')
+    # (round 6) the two-level sum: per 256-row block, then over the blocks -- the mask id of a training batch owns most rows, one serial chain was 0.4 ms
+    wsb = L.lib().mm_embed_bwd_workspace_bytes(B, n, D) if two_level else 0
+    ws = torch.empty(int(wsb), dtype=torch.uint8, device=dx.device) if two_level else None
+    L.check(L.lib().mm_embed_bwd(L.stream(), L.ptr(ids.contiguous()), B, n, D, L.ptr(dx), L.ptr(dtok), L.ptr(dpos), L.ptr(ws), wsb), 'mm_embed_bwd')
     return dtok, dpos
 
 

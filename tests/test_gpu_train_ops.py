@@ -118,14 +118,29 @@ def test_ce_bwd_and_embed_bwd(ops):
     ids = torch.randint(0, T, (B, n), generator=g)
     ids[ids % 3 == 0] = 39
     dx = torch.randn(B * n, D, generator=g)
-    a_tok, a_pos = ops.embed_bwd(ids.to(DEV), dx.to(DEV), T)
-    b_tok, b_pos = ops.embed_bwd(ids.to(DEV), dx.to(DEV), T)
+    a_tok, a_pos = ops.embed_bwd(ids.to(DEV), dx.to(DEV), T, two_level=False)
+    b_tok, b_pos = ops.embed_bwd(ids.to(DEV), dx.to(DEV), T, two_level=False)
     assert torch.equal(a_tok, b_tok) and torch.equal(a_pos, b_pos)
     seq = torch.zeros(T, D)
     flat = ids.reshape(-1)
     for j in range(B * n):
         seq[flat[j]] += dx[j]
     assert torch.equal(a_tok.cpu(), seq)
+    # the two-level form (round 6, what the training step uses): per 256-row block in ascending row order, then the blocks in ascending order
+    c_tok, c_pos = ops.embed_bwd(ids.to(DEV), dx.to(DEV), T)
+    d_tok, _ = ops.embed_bwd(ids.to(DEV), dx.to(DEV), T)
+    assert torch.equal(c_tok, d_tok) and torch.equal(c_pos, a_pos)
+    seq2 = torch.zeros(T, D)
+    for b0 in range(0, B * n, 256):
+        part = torch.zeros(T, D)
+        seen = set()
+        for j in range(b0, min(b0 + 256, B * n)):
+            part[flat[j]] += dx[j]
+            seen.add(int(flat[j]))
+        for t in sorted(seen):
+            seq2[t] += part[t]
+    assert torch.equal(c_tok.cpu(), seq2)
+    assert rel_err(c_tok, a_tok.cpu()) < 1e-6
 
 
 def _attn_ref(q, k, v, qs, ks, nk, nv, mask):
@@ -200,3 +215,20 @@ def test_wide_colsum_is_the_narrow_colsum_bit_for_bit(ops, nparts):
                         ops.colsum(part[:, 65536:98304].contiguous()), ops.colsum(part[:, 98304:].contiguous())])
     assert torch.equal(wide, narrow)
     assert (wide.double().cpu() - part.double().sum(0).cpu()).abs().max() <= 1e-5 * part.abs().sum(0).max().item()
+
+
+@pytest.mark.parametrize('M,N,K', [(600, 256, 32768), (1100, 512, 65536), (512, 132, 32768)])
+def test_split_k_on_the_256x128_tile_for_long_contractions(ops, M, N, K):
+    """round 6: dX of the training head (rows x dim over the vocabulary) -- mm_gemm_wgrad_splits picks 256 x 128 tiles and enough splits for two workgroups per
+    CU; the slabs are summed in a fixed order.  Against the fp64 product of the same bf16 operands; twice the same bits."""
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.5).to(torch.bfloat16)
+    lib = ops.L.lib()
+    s = lib.mm_gemm_wgrad_splits(M, N, K)
+    assert s >= 4 and (K // 64) % s == 0 and K // s >= 4096
+    a = ops.gemm_wgrad(x.to(DEV), w.to(DEV))
+    b = ops.gemm_wgrad(x.to(DEV), w.to(DEV))
+    assert torch.equal(a, b)
+    ref = x.double() @ w.double().t()
+    assert (a.cpu().double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()

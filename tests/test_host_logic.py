@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_header_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in include/muse_hip.h but not exported'
     assert set(declared) == set(_lib.SIGNATURES), 'ctypes signature table out of sync with the header'
-    assert lib.mm_abi_version() == 8
+    assert lib.mm_abi_version() == 9
 
 
 def test_library_reads_no_environment_variable_and_carries_no_experimental_kernel():
