@@ -1,0 +1,302 @@
+// The 'f16x2' tier's cross-attention behind its q projection as ONE kernel (round 6):
+//     x += ( softmax(8 q^ . k^ + key mask) @ V ) W_o^T        (muse_maskgit_pytorch.py:139-162, context = the text encoding)
+// with the output projection folded into the step-invariant values, as cross_fold.hip does for the bf16 engine:
+//     (P_h V_h) W_o,h^T = P_h (V_h W_o,h^T) =: P_h VW_h       per head h, VW_h [keys][dim] -- packed once per generate and layer from the fp32 values.
+// Rounds 4-5 ran the tier's block as LayerNorm-split + q projection (term GEMM) + attention on the fp32 MFMA (attention_f32.hip: 2048 workgroups, each
+// normalising the same 33 keys again, P . V at 1/16 of the fp16 rate) + output projection (term GEMM, fp32 residual in / out): 17 + 26 + 28.8 + 26 us per
+// layer and step at the headline size against 25 us of the bf16 engine's single kernel.  Here the last two become one launch:
+//   phase C  wave h = head h, 32 queries: q^ = l2norm(q_h) * q_scale in fp32 registers, S^T = K^ Q^T on v_mfma_f32_16x16x4_f32 (exact fp32 products; K^ is the
+//            fp32 pack, normalised ONCE per generate), mask, softmax in registers (expf), P x 2^10 -> its two fp16 terms -> LDS [32 queries][288 (head, key)] x 2 planes
+//   phase D  wave w = output features 64 w .. + 63: out^T = VW^T . P^T over the 288 (head, key) pairs as THREE fp16 products per k-block
+//            (VWh.Ph + VWh.Pl + VWl.Ph, fp32 accumulation; VW x 2^8 split into two fp16 terms at pack time: 22 significand bits each side), the VW^T fragments
+//            streamed from L2 through a register ring
+//   phase E  x += out * 2^-18 (fp32, in place)
+// Precision: every product is exact in fp32 or carries 2^-22 relative operand error -- the level of the tier's term GEMMs; the association differs from the
+// reference's (P V) W_o^T (tests: against the fp64 block, and the tier's goldens).
+// Shape class: dim = inner = 512, 8 heads x 64, <= 35 context tokens (+ the null key): KS = 36 key slots per head.  Everything else keeps the four-launch path.
+#include <float.h>
+#include <string.h>
+
+#include "common.h"
+#include "muse_hip_internal.h"
+
+namespace {
+
+constexpr int VH = 8, VD = 512, KS = 36;
+constexpr int XKF = VH * KS;            // 288 flat (head, key) pairs
+constexpr int XKB = XKF / 32;           // 9 MFMA k-blocks
+constexpr int NKB = 3;                  // key blocks of 16 per head
+constexpr int P_LD = XKF * 2 + 32;      // bytes per P row in LDS (608 = 64 k + 32: conflict-free fragment reads, cross_fold.hip X_LD)
+constexpr int VQ = 32;                  // queries per workgroup
+constexpr int RD = 4;                   // VW^T k-blocks in flight per wave (two planes: 32 x 16 bytes per lane)
+constexpr float P_SCALE = 1024.f, VW_SCALE = 256.f, OUT_SCALE = 1.f / (1024.f * 256.f);
+constexpr float NEG_BIG = -3.0e38f;
+
+__device__ __forceinline__ f32x4_t mfma4(float a, float b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+__global__ __launch_bounds__(512, 1) void cross_vw_x2_kernel(const CrossVwArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char Ps[2 * VQ * P_LD];      // plane 0: leading terms of P, plane 1: the remainders
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    // workgroup -> (sequence, query block): all query blocks of a sequence on ONE XCD (they stream the same VW fragments), as cross_fold.hip
+    const int nqb = (p.nq + VQ - 1) / VQ;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int b = (slot / nqb) * 8 + xcd;
+    if (b >= p.seqs) return;
+    const int q0 = (slot % nqb) * VQ;
+    const int kvb = p.kv_batch_mod > 0 ? b % p.kv_batch_mod : b;
+    const size_t row0 = (size_t)b * p.nq;
+
+    int kmb = 1;
+    if (p.key_mask && lane < p.m) kmb = p.key_mask[(size_t)b * p.km_sb + lane];
+    // q rows of head w: lane (fr, fg) holds dims 16 j + 4 fg + i of query fr (per query block) in qf[qb][4 j + i]
+    float qf[2][16];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qi = q0 + qb * 16 + fr;
+        const float* qp = p.q + (row0 + (size_t)(qi < p.nq ? qi : 0)) * p.ldq + w * 64 + 4 * fg;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(qp + 16 * j);
+            qf[qb][4 * j] = v.x; qf[qb][4 * j + 1] = v.y; qf[qb][4 * j + 2] = v.z; qf[qb][4 * j + 3] = v.w;
+        }
+    }
+    // K^ of head w: [kv sequence][head][3 key blocks][4 dim blocks][64 lanes][4]: lane (fr, fg) gets key 16 kb + fr, dims 16 j + 4 fg .. + 3
+    float4 kf[NKB][4];
+    {
+        const float4* kp = reinterpret_cast<const float4*>(p.khat) + ((size_t)kvb * VH + w) * (NKB * 4) * 64 + lane;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) kf[kb][j] = kp[(kb * 4 + j) * 64];
+    }
+    float4 qs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qs[j] = *reinterpret_cast<const float4*>(p.q_scale + 16 * j + 4 * fg);
+    // this wave's first VW^T fragments (phase D) are requested now: they arrive under the scores and the softmax.  [kv sequence][plane][32 feature blocks][9 k-blocks][64 lanes][8]
+    uint4 avh[4][RD], avl[4][RD];
+    const uint4* vph = reinterpret_cast<const uint4*>(p.vwt) + (((size_t)kvb * 2) * (VD / 16) + (size_t)w * 4) * XKB * 64 + lane;
+    const uint4* vpl = vph + (size_t)(VD / 16) * XKB * 64;
+#pragma unroll
+    for (int kb = 0; kb < RD; ++kb)
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) { avh[ob][kb] = vph[(ob * XKB + kb) * 64]; avl[ob][kb] = vpl[(ob * XKB + kb) * 64]; }
+    __builtin_amdgcn_sched_barrier(0);
+
+    const unsigned long long tok_lo = __ballot(lane < p.m && kmb != 0);
+    const unsigned long long valid64 = (tok_lo << 1) | 1ull;      // bit 0 = the null key (always attended, mmp.py:145-155), bit j = context token j - 1
+    bool kvalid[NKB][4];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) kvalid[kb][r] = (valid64 >> (kb * 16 + 4 * fg + r)) & 1ull;
+
+    // ---- phase C
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ss += qf[qb][e] * qf[qb][e];
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        const float den = fmaxf(sqrtf(ss), 1e-12f);      // F.normalize eps (mmp.py:41-42)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            qf[qb][4 * j] = qf[qb][4 * j] / den * qs[j].x; qf[qb][4 * j + 1] = qf[qb][4 * j + 1] / den * qs[j].y;
+            qf[qb][4 * j + 2] = qf[qb][4 * j + 2] / den * qs[j].z; qf[qb][4 * j + 3] = qf[qb][4 * j + 3] / den * qs[j].w;
+        }
+        float s[NKB][4];
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a = mfma4(kf[kb][j].x, qf[qb][4 * j], a);
+                a = mfma4(kf[kb][j].y, qf[qb][4 * j + 1], a);
+                a = mfma4(kf[kb][j].z, qf[qb][4 * j + 2], a);
+                a = mfma4(kf[kb][j].w, qf[qb][4 * j + 3], a);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {      // a[r] = score(key 16 kb + 4 fg + r, query fr)
+                s[kb][r] = kvalid[kb][r] ? a[r] * p.scale : NEG_BIG;
+                mx = fmaxf(mx, s[kb][r]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[kb][r] = kvalid[kb][r] ? expf(s[kb][r] - mx) : 0.f;      // (the null key is always valid: mx is a real score, sum >= 1)
+                sum += s[kb][r];
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float linv = P_SCALE / sum;
+        unsigned char* prow = Ps + (qb * 16 + fr) * P_LD + w * (KS * 2);
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            if (kb * 16 + 4 * fg >= KS) continue;      // (the third key block only holds keys 32 .. 35: its lanes fg = 0)
+            uint16_t h[4], l[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) split2_f16(s[kb][r] * linv, h[r], l[r]);
+            *reinterpret_cast<uint2*>(prow + (kb * 16 + 4 * fg) * 2) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+            *reinterpret_cast<uint2*>(prow + VQ * P_LD + (kb * 16 + 4 * fg) * 2) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+        }
+    }
+    // the residual rows of this wave's features: requested before the barrier, consumed in phase E
+    float4 res[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qi = q0 + qb * 16 + fr;
+        const float* xr = p.x + (row0 + (size_t)(qi < p.nq ? qi : 0)) * p.ldx + w * 64 + 4 * fg;
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) res[qb][ob] = *reinterpret_cast<const float4*>(xr + ob * 16);
+    }
+    __syncthreads();      // P of every head is in LDS
+
+    // ---- phase D: out^T[feature][query] = VW^T . P^T over the 288 (head, key) pairs, three term products per k-block
+    f32x4_t acc[4][2];
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) acc[ob][qb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < XKB; ++kb) {
+        u32x4_t ph[2], pl[2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            ph[qb] = *reinterpret_cast<const u32x4_t*>(Ps + (qb * 16 + fr) * P_LD + kb * 64 + fg * 16);
+            pl[qb] = *reinterpret_cast<const u32x4_t*>(Ps + VQ * P_LD + (qb * 16 + fr) * P_LD + kb * 64 + fg * 16);
+        }
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            const u32x4_t ah = __builtin_bit_cast(u32x4_t, avh[ob][kb % RD]), al = __builtin_bit_cast(u32x4_t, avl[ob][kb % RD]);
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                acc[ob][qb] = mfma16t<true>(ah, ph[qb], acc[ob][qb]);
+                acc[ob][qb] = mfma16t<true>(ah, pl[qb], acc[ob][qb]);
+                acc[ob][qb] = mfma16t<true>(al, ph[qb], acc[ob][qb]);
+            }
+        }
+        if (kb + RD < XKB) {      // the slot just consumed takes k-block kb + RD (requested HERE: the scheduler otherwise sinks the load to its use)
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) { avh[ob][kb % RD] = vph[(ob * XKB + kb + RD) * 64]; avl[ob][kb % RD] = vpl[(ob * XKB + kb + RD) * 64]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- phase E: accumulator fragment = 4 consecutive features of one query: x += out (fp32, in place)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qi = q0 + qb * 16 + fr;
+        if (qi >= p.nq) continue;
+        float* xr = p.x + (row0 + (size_t)qi) * p.ldx + w * 64 + 4 * fg;
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            float4 o;
+            o.x = acc[ob][qb][0] * OUT_SCALE + res[qb][ob].x; o.y = acc[ob][qb][1] * OUT_SCALE + res[qb][ob].y;
+            o.z = acc[ob][qb][2] * OUT_SCALE + res[qb][ob].z; o.w = acc[ob][qb][3] * OUT_SCALE + res[qb][ob].w;
+            *reinterpret_cast<float4*>(xr + ob * 16) = o;
+        }
+    }
+}
+
+// ---- pack, once per generate and layer.  grid (kv sequences, heads, 2 halves of the features), 256 threads.
+//   khat  [s][h][3 key blocks][4 dim blocks][64 lanes][4] fp32: K^ = k / max(|k|, eps) * k_scale of key (16 kb + lane % 16), dims 16 j + 4 (lane / 16) .. + 3; key 0 = the
+//         null key (mmp.py:145-149), key j = context token j - 1 (the K half of the fp32 ckv), keys > m zero
+//   vwt   [s][2 planes][32 feature blocks][9 k-blocks][64 lanes][8] fp16: the two terms of 2^8 VW^T[feature 16 ob + lane % 16][flat k = 32 kb + 8 (lane / 16) .. + 7],
+//         flat k = 36 head + key, VW[key][feature] = sum_d v[key][64 head + d] * W_o[feature][64 head + d] in fp32, W_o = (wh + wl) * alpha from the term pack
+__global__ __launch_bounds__(256) void cross_vw_x2_pack_kernel(const float* __restrict__ ckv, int m, int I, const float* __restrict__ null_k, const float* __restrict__ null_v,
+                                                                const float* __restrict__ k_scale, const uint16_t* __restrict__ w_out, int ldw, int terms, float alpha,
+                                                                float* __restrict__ khat, uint16_t* __restrict__ vwt) {
+    __shared__ __attribute__((aligned(16))) float vs[KS][64];
+    const int s = blockIdx.x, h = blockIdx.y, half = blockIdx.z, t = threadIdx.x;
+    for (int i = t; i < KS * 64; i += 256) {
+        const int key = i >> 6, d = i & 63;
+        float v = 0.f;
+        if (key == 0) v = null_v[h * 64 + d];
+        else if (key <= m) v = ckv[((size_t)s * m + key - 1) * 2 * I + I + h * 64 + d];
+        vs[key][d] = v;
+    }
+    if (half == 0 && t < NKB * 16) {
+        const int key = t;
+        float k[64];
+        float ss = 0.f;
+#pragma unroll
+        for (int d = 0; d < 64; ++d) {
+            float v = 0.f;
+            if (key == 0) v = null_k[h * 64 + d];
+            else if (key <= m) v = ckv[((size_t)s * m + key - 1) * 2 * I + h * 64 + d];
+            k[d] = v;
+            ss += v * v;
+        }
+        const float den = fmaxf(sqrtf(ss), 1e-12f);
+        float* kb_ = khat + ((size_t)s * VH + h) * (NKB * 4) * 64 * 4;
+#pragma unroll
+        for (int d = 0; d < 64; ++d) {
+            const int kb = key >> 4, frk = key & 15, j = d >> 4, fgk = (d & 15) >> 2, i = d & 3;
+            kb_[(((kb * 4 + j) * 64) + fgk * 16 + frk) * 4 + i] = k[d] / den * k_scale[d];      // (the operations of attention_f32.hip's staging, in its order)
+        }
+    }
+    __syncthreads();
+    {
+        const int o = half * 256 + t;      // one output feature per thread: its 64 weights of head h in registers
+        float wr[64];
+        const uint16_t* wp = w_out + (size_t)o * ldw + h * 64;
+#pragma unroll
+        for (int d = 0; d < 64; ++d) {
+            float v = f16_bits_to_f32(wp[d]);
+            if (terms == 3) v += f16_bits_to_f32(wp[2 * I + d]);      // segments [wh | wh | wl]
+            wr[d] = v * alpha;
+        }
+        const int ob = o >> 4, fro = o & 15;
+        uint16_t* vh = vwt + ((size_t)s * 2) * VD * XKF;
+        uint16_t* vl = vh + (size_t)VD * XKF;
+        for (int key = 0; key < KS; ++key) {
+            float a = 0.f;
+#pragma unroll
+            for (int d4 = 0; d4 < 16; ++d4) {
+                const float4 v = *reinterpret_cast<const float4*>(&vs[key][d4 * 4]);
+                a = __builtin_fmaf(v.x, wr[d4 * 4], a); a = __builtin_fmaf(v.y, wr[d4 * 4 + 1], a);
+                a = __builtin_fmaf(v.z, wr[d4 * 4 + 2], a); a = __builtin_fmaf(v.w, wr[d4 * 4 + 3], a);
+            }
+            const int kfl = h * KS + key;
+            const int kb = kfl >> 5, fgk = (kfl & 31) >> 3, j = kfl & 7;
+            const size_t at = ((((size_t)ob) * XKB + kb) * 64 + fgk * 16 + fro) * 8 + j;
+            uint16_t th, tl;
+            split2_f16(a * VW_SCALE, th, tl);
+            vh[at] = th;
+            vl[at] = tl;
+        }
+    }
+}
+
+}  // namespace
+
+bool k_cross_vw_x2_eligible(int D, int I, int H, int dh, int m) { return D == VD && I == VD && H == VH && dh == 64 && m >= 1 && m + 1 <= KS; }
+size_t k_cross_vw_x2_khat_floats(int kv_seqs) { return (size_t)kv_seqs * VH * (NKB * 4) * 64 * 4; }
+size_t k_cross_vw_x2_vwt_halves(int kv_seqs) { return (size_t)kv_seqs * 2 * VD * XKF; }
+
+int k_cross_vw_x2_pack(hipStream_t s, const float* ckv, int kv_seqs, int m, int I, const float* null_k, const float* null_v, const float* k_scale,
+                       const bf16_t* w_out, int ldw, int terms, float alpha, float* khat, bf16_t* vwt) {
+    if (kv_seqs <= 0) return MM_OK;
+    if (!null_k || !null_v || !k_scale || !w_out) return mm_set_error(MM_ERR_SHAPE, "cross_vw_x2_pack: null key / value, k_scale and the output projection's term pack required");
+    if (m < 1 || m + 1 > KS || I != VD || (terms != 2 && terms != 3) || ldw < terms * I) return mm_set_error(MM_ERR_SHAPE, "cross_vw_x2_pack: 1 <= context tokens <= 35, inner 512, 2 or 3 term segments");
+    hipLaunchKernelGGL(cross_vw_x2_pack_kernel, dim3(kv_seqs, VH, 2), dim3(256), 0, s, ckv, m, I, null_k, null_v, k_scale, (const uint16_t*)w_out, ldw, terms,
+                       alpha == 0.f ? 1.f : alpha, khat, (uint16_t*)vwt);
+    return mm_check_launch("cross_vw_x2_pack_kernel");
+}
+
+int k_cross_vw_x2(hipStream_t s, const CrossVwArgs& a) {
+    if (a.seqs <= 0 || a.nq <= 0) return MM_OK;
+    if (a.m < 1 || a.m + 1 > KS) return mm_set_error(MM_ERR_SHAPE, "cross_vw_x2: 1 <= context tokens <= 35");
+    if ((a.ldx % 4) || (a.ldq % 4) || !a.q || !a.khat || !a.vwt || !a.q_scale || !a.x) return mm_set_error(MM_ERR_SHAPE, "cross_vw_x2: operands / alignment");
+    const int nqb = (a.nq + VQ - 1) / VQ;
+    hipLaunchKernelGGL(cross_vw_x2_kernel, dim3(8 * ((a.seqs + 7) / 8) * nqb), dim3(512), 0, s, a);
+    return mm_check_launch("cross_vw_x2_kernel");
+}

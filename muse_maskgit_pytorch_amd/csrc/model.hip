@@ -467,9 +467,20 @@ bool cross_fold_on(const mm_transformer* t, const mm_attn_weights& w, int m) {
            w.q_scale && w.k_scale && w.w_q_ln && w.ln_c1;      // (ln_c2 is NULL for the reference's LayerNorm: its beta is a zeros buffer)
 }
 // the packed operands of one layer: K^ and (V W_o^T)^T of every kv sequence (from ckv = ctx @ to_kv^T) and the gain-folded q weight as MFMA fragments
-struct CrossFoldPack { bf16_t* khat; bf16_t* vwt; bf16_t* wqf; };
+struct CrossFoldPack { bf16_t* khat; bf16_t* vwt; bf16_t* wqf; bool x2 = false; };      // x2: the 'f16x2' tier's pack (cross_vw_x2.hip: khat = fp32 K^, vwt = two fp16 term planes, no wqf)
+// the tier's cross-attention behind its q projection as one kernel (cross_vw_x2.hip); mm_debug_set2 bit 64 keeps the attention + output projection launches (A/B, tests)
+bool cross_vw_on(const mm_transformer* t, const mm_attn_weights& w, int m) {
+    return t->F16 && (t->P == 2 || t->P == 3) && !(g_mm_debug2 & 64) && !(g_mm_debug & 7) && k_cross_vw_x2_eligible(t->d.dim, t->I, t->d.heads, t->d.dim_head, m) &&
+           w.null_k && w.null_v && w.q_scale && w.k_scale;
+}
 int cross_fold_pack(const mm_transformer* t, hipStream_t s, const mm_attn_weights& w, const bf16_t* ckv, int kv_seqs, int m, const CrossFoldPack& pk) {
     return k_cross_fold_pack(s, ckv, kv_seqs, m, t->I, w.null_k, w.null_v, w.k_scale, (const bf16_t*)w.w_out, t->I, (const bf16_t*)w.w_q_ln, t->d.dim, pk.khat, pk.vwt, pk.wqf);
+}
+
+// bf16_t elements of one layer's K^ pack, whichever of the two one-kernel forms a model takes (the tier's is fp32: 12288 floats per sequence)
+size_t xpack_khat_elems(const mm_transformer* t, int seqs) {
+    const size_t a = k_cross_fold_khat_elems(seqs), b = t->F16 ? k_cross_vw_x2_khat_floats(seqs) * 2 : 0;
+    return a > b ? a : b;
 }
 
 // x += CrossAttention(x, ctx) for `seqs` sequences; ckv = ctx @ to_kv^T given as [kv_seqs*m][2I]  (mmp.py:191)
@@ -499,6 +510,16 @@ int cross_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weigh
         RC(k_layernorm_split(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, pc_scratch(t), b.xn, nullptr, nullptr, 0, nullptr));
         float* q = reinterpret_cast<float*>(b.qkv);
         RC(gemm_dense(t, s, b.xn, P * D, (const bf16_t*)w.w_q, P * D, rows, I, P * D, q, I, OUT_F32, nullptr));
+        if (pk && pk->x2) {      // round 6: scores, softmax, P . (V W_o^T) on fp16 terms and the residual add in ONE kernel (the pack: once per generate and layer)
+            CrossVwArgs v;
+            memset(&v, 0, sizeof(v));
+            v.q = q; v.ldq = I; v.khat = reinterpret_cast<const float*>(pk->khat); v.vwt = pk->vwt;
+            v.key_mask = key_mask; v.km_sb = m; v.q_scale = w.q_scale;
+            v.x = b.x; v.ldx = D; v.seqs = seqs; v.nq = n; v.m = m; v.kv_batch_mod = kv_batch_mod; v.scale = 8.f;
+            RC(k_cross_vw_x2(s, v));
+            TR(b.x, (size_t)rows * D * 4);
+            return MM_OK;
+        }
         const float* kv = reinterpret_cast<const float*>(ckv);
         AttnF32Args a;
         memset(&a, 0, sizeof(a));
@@ -681,7 +702,7 @@ size_t mm_transformer_workspace_bytes(const mm_transformer_t* t, int B, int n, i
     carve_bufs(c, t, (size_t)B * n, b);
     c.take<bf16_t>((size_t)B * m * 2 * t->I * (t->P ? 2 : 1));    // cross K/V of one layer (fp32 in the precision tier)
     c.take<bf16_t>((size_t)B * n * t->d.dim * (t->P ? t->P : 1));  // embed when the caller does not want it
-    c.take<bf16_t>(k_cross_fold_khat_elems(B));                    // packed cross-attention operands of one layer (cross_fold.hip; reserved whatever the shape)
+    c.take<bf16_t>(xpack_khat_elems(t, B));                        // packed cross-attention operands of one layer (cross_fold.hip / the tier's cross_vw_x2.hip; reserved whatever the shape)
     c.take<bf16_t>(k_cross_fold_vwt_elems(B));
     c.take<bf16_t>(k_cross_fold_wqf_elems());
     return c.used() + 256;
@@ -704,7 +725,7 @@ int mm_transformer_forward(const mm_transformer_t* t, mm_stream_t stream, const 
     bf16_t* ckv = c.take<bf16_t>((size_t)B * m * 2 * I * (P ? 2 : 1));
     bf16_t* emb = c.take<bf16_t>((size_t)rows * KD);
     CrossFoldPack pk;
-    pk.khat = c.take<bf16_t>(k_cross_fold_khat_elems(B));
+    pk.khat = c.take<bf16_t>(xpack_khat_elems(t, B));
     pk.vwt = c.take<bf16_t>(k_cross_fold_vwt_elems(B));
     pk.wqf = c.take<bf16_t>(k_cross_fold_wqf_elems());
     if (embed_out) emb = (bf16_t*)embed_out;
@@ -722,8 +743,12 @@ int mm_transformer_forward(const mm_transformer_t* t, mm_stream_t stream, const 
         RC(gemm_dense(t, s, (const bf16_t*)ctx, KD, (const bf16_t*)w.cross_attn.w_kv, KD, B * m, 2 * I, KD, ckv, 2 * I, P ? OUT_F32 : OUT_BF16, nullptr));
         TR(ckv, (size_t)B * m * 2 * I * 2);
         const bool xf = cross_fold_on(t, w.cross_attn, m);
+        const bool xv = !xf && cross_vw_on(t, w.cross_attn, m);      // the tier's one-kernel form behind its q projection (cross_vw_x2.hip)
+        pk.x2 = xv;
         if (xf) RC(cross_fold_pack(t, s, w.cross_attn, ckv, B, m, pk));
-        RC(cross_attn_block(t, s, w.cross_attn, B, n, ckv, m, 0, key_mask, b, fold, fold && l > 0, xf ? &pk : nullptr));
+        else if (xv) RC(k_cross_vw_x2_pack(s, reinterpret_cast<const float*>(ckv), B, m, I, w.cross_attn.null_k, w.cross_attn.null_v, w.cross_attn.k_scale,
+                                           (const bf16_t*)w.cross_attn.w_out, P * I, P, t->alpha, reinterpret_cast<float*>(pk.khat), pk.vwt));
+        RC(cross_attn_block(t, s, w.cross_attn, B, n, ckv, m, 0, key_mask, b, fold, fold && l > 0, (xf || xv) ? &pk : nullptr));
         RC(ff_block(t, s, w.ff, b.x, b.x, rows, b, nullptr, 0, fold && l > 0, fold && l + 1 < t->d.depth));
     }
     if (P) RC(k_layernorm_split(s, b.x, D, rows, D, t->d.final_gamma, t->d.final_beta, nullptr, t->PC, emb, nullptr, nullptr, 0, nullptr));
@@ -845,10 +870,12 @@ void carve_gen(Carver& c, const mm_transformer* t, int B, int n, int L, int nc, 
     g.masks = c.take<uint8_t>((size_t)2 * B * m);
     g.ckv = c.take<bf16_t>((size_t)t->d.depth * B * m * 2 * I * f32);
     const bool xf = !t->P && !t->F8 && k_cross_fold_eligible(D, I, t->d.heads, t->d.dim_head, m);      // (sized by shape only: the debug switch must not change the workspace)
-    g.khat = c.take<bf16_t>(xf ? (size_t)t->d.depth * k_cross_fold_khat_elems(B) : 0);
-    g.vwt = c.take<bf16_t>(xf ? (size_t)t->d.depth * k_cross_fold_vwt_elems(B) : 0);
+    const bool xv = t->F16 && k_cross_vw_x2_eligible(D, I, t->d.heads, t->d.dim_head, m);              // the tier's pack (cross_vw_x2.hip): fp32 K^, two fp16 planes of V W_o^T
+    g.khat = c.take<bf16_t>(xf ? (size_t)t->d.depth * k_cross_fold_khat_elems(B) : xv ? (size_t)t->d.depth * k_cross_vw_x2_khat_floats(B) * 2 : 0);
+    g.vwt = c.take<bf16_t>(xf ? (size_t)t->d.depth * k_cross_fold_vwt_elems(B) : xv ? (size_t)t->d.depth * k_cross_vw_x2_vwt_halves(B) : 0);
     g.wqf = c.take<bf16_t>(xf ? (size_t)t->d.depth * k_cross_fold_wqf_elems() : 0);
-    if (!xf) { g.khat = nullptr; g.vwt = nullptr; g.wqf = nullptr; }
+    if (!xf && !xv) { g.khat = nullptr; g.vwt = nullptr; }
+    if (!xf) g.wqf = nullptr;
     g.cvec = c.take<float>((size_t)t->d.depth * D);
     g.nullv = c.take<bf16_t>((size_t)I * seg + 64);
     g.rows = c.take<int32_t>((size_t)B * n);
@@ -994,6 +1021,9 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
         if (g.khat && cross_fold_on(t, w, m)) {
             const CrossFoldPack pk = {g.khat + (size_t)l * k_cross_fold_khat_elems(B), g.vwt + (size_t)l * k_cross_fold_vwt_elems(B), g.wqf + (size_t)l * k_cross_fold_wqf_elems()};
             RC(cross_fold_pack(t, s, w, ckv_l, B, m, pk));
+        } else if (g.khat && cross_vw_on(t, w, m)) {
+            RC(k_cross_vw_x2_pack(s, reinterpret_cast<const float*>(ckv_l), B, m, I, w.null_k, w.null_v, w.k_scale, (const bf16_t*)w.w_out, KI, PT, t->alpha,
+                                  reinterpret_cast<float*>(g.khat) + (size_t)l * k_cross_vw_x2_khat_floats(B), g.vwt + (size_t)l * k_cross_vw_x2_vwt_halves(B)));
         }
         if (nc == 0 && P == 2) {
             // softmax over the single unmasked (null) key is exactly 1 -> attention out = bf16(null_v) for every
@@ -1080,8 +1110,12 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
             const bool null_const = P == 2 && nc == 0;
             const float* cvec_l = g.cvec + (size_t)l * D;
             const bool xf = g.khat && cross_fold_on(t, w.cross_attn, m);
-            const CrossFoldPack pk_l = {g.khat + (size_t)l * k_cross_fold_khat_elems(B), g.vwt + (size_t)l * k_cross_fold_vwt_elems(B), g.wqf + (size_t)l * k_cross_fold_wqf_elems()};
-            const CrossFoldPack* pkp = xf ? &pk_l : nullptr;
+            const bool xv = !xf && g.khat && cross_vw_on(t, w.cross_attn, m);
+            const CrossFoldPack pk_l = xv ? CrossFoldPack{reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(g.khat) + (size_t)l * k_cross_vw_x2_khat_floats(B)),
+                                                          g.vwt + (size_t)l * k_cross_vw_x2_vwt_halves(B), nullptr, true}
+                                          : CrossFoldPack{g.khat + (size_t)l * k_cross_fold_khat_elems(B), g.vwt + (size_t)l * k_cross_fold_vwt_elems(B),
+                                                          g.wqf + (size_t)l * k_cross_fold_wqf_elems()};
+            const CrossFoldPack* pkp = (xf || xv) ? &pk_l : nullptr;
             if (last_compact) {
                 RC(self_attn_core(t, s, w.self_attn, seqs, n, b, fold_l));
                 {      // residual stream and attention output of both guidance halves: one launch

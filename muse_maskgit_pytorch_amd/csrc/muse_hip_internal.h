@@ -73,7 +73,7 @@ struct GemmArgs {
     const float* in_part; int in_np; int in_F; const float* in_c1; const float* in_c2;
 };
 extern int g_mm_debug;
-extern int g_mm_debug2;      // mm_debug_set2 (round 5): 1 = gemm_terms.hip whatever the tile count (tests: small batches through the production kernels), 2 = gemm_terms.hip and every term-sharing k-loop off (A/B), 4 = mm_train_step on the caller's stream only (A/B), 8 = gemm_wide_conv.hip off (A/B: convolutions on the 256 x 128 kernel), 16 = the VAE head not fused into the last up-sampling convolution (A/B), 32 = a ConvTranspose2d's parity classes as four launches (A/B)
+extern int g_mm_debug2;      // mm_debug_set2 (round 5): 1 = gemm_terms.hip whatever the tile count (tests: small batches through the production kernels), 2 = gemm_terms.hip and every term-sharing k-loop off (A/B), 4 = mm_train_step on the caller's stream only (A/B), 8 = gemm_wide_conv.hip off (A/B: convolutions on the 256 x 128 kernel), 16 = the VAE head not fused into the last up-sampling convolution (A/B), 32 = a ConvTranspose2d's parity classes as four launches (A/B), 64 = the 'f16x2' tier's cross-attention as attention + output projection launches instead of cross_vw_x2.hip (A/B, tests)
 
 int mm_gemm_launch(GemmArgs a, hipStream_t stream);
 bool mm_gemm_big_eligible(const GemmArgs& a);
@@ -187,6 +187,24 @@ int k_cross_fold_pack(hipStream_t s, const bf16_t* ckv, int kv_seqs, int m, int 
                       const bf16_t* w_out, int ldw, const bf16_t* w_q_ln, int ldwq, bf16_t* khat, bf16_t* vwt, bf16_t* wqf);
 int k_cross_fold(hipStream_t s, const CrossFoldArgs& a);
 int k_cross_fold_null_row(hipStream_t s, const bf16_t* vwt, int m, float* out);      // [512] fp32: what the kernel adds to a row whose text keys are all masked
+
+// cross_vw_x2.hip: the 'f16x2' tier's cross-attention behind its q projection (scores on the fp32 MFMA, P . (V W_o^T) as fp16 term products, residual add) as one kernel
+struct CrossVwArgs {
+    const float* q; long ldq;                    // [seqs * nq][ldq] fp32: the q projection's output (un-normalised)
+    const float* khat;                           // k_cross_vw_x2_pack: K^ [kv_seqs][8][3][4][64][4] fp32
+    const bf16_t* vwt;                           // k_cross_vw_x2_pack: the two fp16 terms of 2^8 (V W_o^T)^T as fragments [kv_seqs][2][32][9][64][8]
+    const uint8_t* key_mask; long km_sb;         // optional [seqs][m], 1 = keep
+    const float* q_scale;                        // [64]
+    float* x; long ldx;                          // fp32 residual stream [seqs * nq][ldx], updated in place
+    int seqs, nq, m, kv_batch_mod;
+    float scale;                                 // 8
+};
+bool k_cross_vw_x2_eligible(int D, int I, int H, int dh, int m);
+size_t k_cross_vw_x2_khat_floats(int kv_seqs);
+size_t k_cross_vw_x2_vwt_halves(int kv_seqs);
+int k_cross_vw_x2_pack(hipStream_t s, const float* ckv, int kv_seqs, int m, int I, const float* null_k, const float* null_v, const float* k_scale,
+                       const bf16_t* w_out, int ldw, int terms, float alpha, float* khat, bf16_t* vwt);
+int k_cross_vw_x2(hipStream_t s, const CrossVwArgs& a);
 
 // vq.hip
 int k_vq_nearest(hipStream_t s, const float* x, long ldx, int N, int C, const float* cb, int K, int cosine, float* aux, int64_t* ids);

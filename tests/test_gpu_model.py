@@ -874,6 +874,53 @@ def test_cross_attention_with_the_folded_output_projection_matches_the_two_kerne
         assert e_f.max() < 0.03 * ref.abs().max() and e_f.mean() < 1.5 * e_u.mean() + 1e-4
 
 
+@pytest.mark.parametrize('n,L,fp32w', [(80, 13, False), (256, 33, True), (7, 1, True), (64, 35, False), (96, 35, True)])
+def test_tier_cross_attention_behind_the_q_projection_as_one_kernel(n, L, fp32w):
+    """'f16x2' tier, round 6 (csrc/cross_vw_x2.hip): on the headline shape class (dim = inner = 512, 8 heads x 64, <= 35 context tokens) the tier's cross-attention
+    behind its q projection is ONE kernel -- scores on the fp32 MFMA against K^ normalised once per context, softmax, P . (V W_o^T) as fp16 term products with the
+    output projection folded into the step-invariant values, residual add -- instead of attention_f32 + a term GEMM.  mm_debug_set2(64) keeps the two launches:
+    the forms agree to ~1e-6 of the logits' scale (another association of fp32-grade arithmetic), both hold the tier's 1e-3 against the fp32 oracle;
+    bf16-representable and general fp32 weights (two / three weight terms), ragged text rows (key mask), the null pass, query counts that are no multiple of 32."""
+    torch.manual_seed(n * 100 + L)
+    V, depth, B = 1000, 2, 3
+    t = mm.MaskGitTransformer(num_tokens=V, seq_len=n, dim=512, depth=depth, dim_head=64, heads=8, t5_name='t5-small')
+    with torch.no_grad():
+        for p in t.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+            elif not fp32w:
+                p.copy_(p.to(torch.bfloat16).float())                  # a bf16-representable checkpoint: single fp16 weight terms
+    sd = {k: v.detach().float().clone() for k, v in t.state_dict().items()}
+    cfg = dict(depth=depth, heads=8)
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, V + 1, (B, n), generator=g)
+    te = torch.randn(B, L, 512, generator=g)
+    if L > 2:
+        te[1, L // 2:] = 0.
+        te[2, L - 1:] = 0.
+    t = t.to(DEV)
+    t.set_precision('f16x2')
+    lib = _lib.lib()
+    outs = {}
+    for bit in (0, 64):
+        lib.mm_debug_set2(bit)
+        try:
+            outs[bit] = [t(ids.to(DEV), text_embeds=te.to(DEV), cond_drop_prob=drop).float().cpu() for drop in (0., 1.)]
+        finally:
+            lib.mm_debug_set2(0)
+    for i, drop in enumerate((0., 1.)):
+        a, b = outs[0][i], outs[64][i]
+        ref = O.transformer_forward(sd, cfg, ids, te, drop)
+        scale = ref.abs().max()
+        d = (a - b).abs()
+        if drop == 0.:
+            assert d.max() > 0, 'the debug bit did not change the path'
+        assert d.max() < 2e-5 * scale, (drop, d.max().item(), scale.item())
+        e_new, e_old = (a - ref).abs().max() / scale, (b - ref).abs().max() / scale
+        print(f'tier cross-attention one kernel n={n} L={L} fp32w={fp32w} drop={drop}: |new - old| {d.max().item() / scale.item():.2e}, vs oracle new {e_new.item():.2e} old {e_old.item():.2e}')
+        assert e_new < 1e-3 and e_old < 1e-3
+
+
 def test_full_size_c2_properties():
     """BASELINE configs[1] at FULL size (dim 512, depth 8, seq_len 256, codebook 65536; B = 8 to keep the fp32 oracle out of it):
     size-independent properties instead of an oracle comparison --
