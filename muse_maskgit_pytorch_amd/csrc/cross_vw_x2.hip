@@ -14,6 +14,10 @@
 // Precision: every product is exact in fp32 or carries 2^-22 relative operand error -- the level of the tier's term GEMMs; the association differs from the
 // reference's (P V) W_o^T (tests: against the fp64 block, and the tier's goldens).
 // Shape class: dim = inner = 512, 8 heads x 64, <= 35 context tokens (+ the null key): KS = 36 key slots per head.  Everything else keeps the four-launch path.
+// Measured and NOT kept (round 6): a phase F taking the feed-forward's LayerNorm + term split for the workgroup's 32 complete rows (and, in the same workgroup, for
+// the matching rows of the null half with their constant row added) -- it removes the 17 us LayerNorm-split launch and lengthens this kernel by as much: a single
+// round of one-workgroup-per-CU latency chains pays every added barrier and 32-byte store segment in full, the stand-alone pass streams at 6 TB/s
+// (97.4 / 97.6 ms per tier step with it, 97.5 / 97.0 without, same box).
 #include <float.h>
 #include <string.h>
 
@@ -249,10 +253,12 @@ __global__ __launch_bounds__(256) void cross_vw_x2_pack_kernel(const float* __re
         float wr[64];
         const uint16_t* wp = w_out + (size_t)o * ldw + h * 64;
 #pragma unroll
-        for (int d = 0; d < 64; ++d) {
-            float v = f16_bits_to_f32(wp[d]);
-            if (terms == 3) v += f16_bits_to_f32(wp[2 * I + d]);      // segments [wh | wh | wl]
-            wr[d] = v * alpha;
+        for (int d8 = 0; d8 < 8; ++d8) {      // 16-byte loads: 8 fp16 terms each (rows and segments are multiples of 64 elements)
+            float fh[8], fl[8];
+            unpack8s<true>(*reinterpret_cast<const uint4*>(wp + d8 * 8), fh);
+            if (terms == 3) unpack8s<true>(*reinterpret_cast<const uint4*>(wp + 2 * I + d8 * 8), fl);      // segments [wh | wh | wl]
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wr[d8 * 8 + j] = (terms == 3 ? fh[j] + fl[j] : fh[j]) * alpha;
         }
         const int ob = o >> 4, fro = o & 15;
         uint16_t* vh = vwt + ((size_t)s * 2) * VD * XKF;
