@@ -483,6 +483,11 @@ size_t xpack_khat_elems(const mm_transformer* t, int seqs) {
     return a > b ? a : b;
 }
 
+size_t xpack_wqf_elems(const mm_transformer* t) {
+    const size_t a = k_cross_fold_wqf_elems(), b = t->F16 ? k_cross_vw_x2_wqf_halves() : 0;
+    return a > b ? a : b;
+}
+
 // x += CrossAttention(x, ctx) for `seqs` sequences; ckv = ctx @ to_kv^T given as [kv_seqs*m][2I]  (mmp.py:191)
 // pk (cross_fold_pack of this layer, or NULL) with fold_in: the whole block is ONE kernel (cross_fold.hip)
 int cross_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weights& w, int seqs, int n, const bf16_t* ckv,
@@ -507,12 +512,16 @@ int cross_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weigh
     }
     if (t->P) {      // precision tier: ckv is fp32 [kv_seqs*m][2I]
         const int P = t->P;
-        RC(k_layernorm_split(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, pc_scratch(t), b.xn, nullptr, nullptr, 0, nullptr));
+        const bool qp = pk && pk->x2 && pk->wqf && !(g_mm_debug2 & 128);      // the LayerNorm and the q projection inside the kernel as well (bit 128, A/B: as launches in front of it)
         float* q = reinterpret_cast<float*>(b.qkv);
-        RC(gemm_dense(t, s, b.xn, P * D, (const bf16_t*)w.w_q, P * D, rows, I, P * D, q, I, OUT_F32, nullptr));
+        if (!qp) {
+            RC(k_layernorm_split(s, b.x, D, rows, D, w.ln_gamma, w.ln_beta, nullptr, pc_scratch(t), b.xn, nullptr, nullptr, 0, nullptr));
+            RC(gemm_dense(t, s, b.xn, P * D, (const bf16_t*)w.w_q, P * D, rows, I, P * D, q, I, OUT_F32, nullptr));
+        }
         if (pk && pk->x2) {      // round 6: scores, softmax, P . (V W_o^T) on fp16 terms and the residual add in ONE kernel (the pack: once per generate and layer)
             CrossVwArgs v;
             memset(&v, 0, sizeof(v));
+            if (qp) { v.wqf = pk->wqf; v.wq_terms = P; v.alpha = t->alpha; v.ln_gamma = w.ln_gamma; v.ln_beta = w.ln_beta; }
             v.q = q; v.ldq = I; v.khat = reinterpret_cast<const float*>(pk->khat); v.vwt = pk->vwt;
             v.key_mask = key_mask; v.km_sb = m; v.q_scale = w.q_scale;
             v.x = b.x; v.ldx = D; v.seqs = seqs; v.nq = n; v.m = m; v.kv_batch_mod = kv_batch_mod; v.scale = 8.f;
@@ -704,7 +713,7 @@ size_t mm_transformer_workspace_bytes(const mm_transformer_t* t, int B, int n, i
     c.take<bf16_t>((size_t)B * n * t->d.dim * (t->P ? t->P : 1));  // embed when the caller does not want it
     c.take<bf16_t>(xpack_khat_elems(t, B));                        // packed cross-attention operands of one layer (cross_fold.hip / the tier's cross_vw_x2.hip; reserved whatever the shape)
     c.take<bf16_t>(k_cross_fold_vwt_elems(B));
-    c.take<bf16_t>(k_cross_fold_wqf_elems());
+    c.take<bf16_t>(xpack_wqf_elems(t));
     return c.used() + 256;
 }
 
@@ -727,7 +736,7 @@ int mm_transformer_forward(const mm_transformer_t* t, mm_stream_t stream, const 
     CrossFoldPack pk;
     pk.khat = c.take<bf16_t>(xpack_khat_elems(t, B));
     pk.vwt = c.take<bf16_t>(k_cross_fold_vwt_elems(B));
-    pk.wqf = c.take<bf16_t>(k_cross_fold_wqf_elems());
+    pk.wqf = c.take<bf16_t>(xpack_wqf_elems(t));
     if (embed_out) emb = (bf16_t*)embed_out;
 
     trace::idx = 0;
@@ -746,8 +755,11 @@ int mm_transformer_forward(const mm_transformer_t* t, mm_stream_t stream, const 
         const bool xv = !xf && cross_vw_on(t, w.cross_attn, m);      // the tier's one-kernel form behind its q projection (cross_vw_x2.hip)
         pk.x2 = xv;
         if (xf) RC(cross_fold_pack(t, s, w.cross_attn, ckv, B, m, pk));
-        else if (xv) RC(k_cross_vw_x2_pack(s, reinterpret_cast<const float*>(ckv), B, m, I, w.cross_attn.null_k, w.cross_attn.null_v, w.cross_attn.k_scale,
-                                           (const bf16_t*)w.cross_attn.w_out, P * I, P, t->alpha, reinterpret_cast<float*>(pk.khat), pk.vwt));
+        else if (xv) {
+            RC(k_cross_vw_x2_pack(s, reinterpret_cast<const float*>(ckv), B, m, I, w.cross_attn.null_k, w.cross_attn.null_v, w.cross_attn.k_scale,
+                                  (const bf16_t*)w.cross_attn.w_out, P * I, P, t->alpha, reinterpret_cast<float*>(pk.khat), pk.vwt));
+            RC(k_cross_vw_x2_wq_pack(s, (const bf16_t*)w.cross_attn.w_q, P * D, P, pk.wqf));
+        }
         RC(cross_attn_block(t, s, w.cross_attn, B, n, ckv, m, 0, key_mask, b, fold, fold && l > 0, (xf || xv) ? &pk : nullptr));
         RC(ff_block(t, s, w.ff, b.x, b.x, rows, b, nullptr, 0, fold && l > 0, fold && l + 1 < t->d.depth));
     }
@@ -873,9 +885,8 @@ void carve_gen(Carver& c, const mm_transformer* t, int B, int n, int L, int nc, 
     const bool xv = t->F16 && k_cross_vw_x2_eligible(D, I, t->d.heads, t->d.dim_head, m);              // the tier's pack (cross_vw_x2.hip): fp32 K^, two fp16 planes of V W_o^T
     g.khat = c.take<bf16_t>(xf ? (size_t)t->d.depth * k_cross_fold_khat_elems(B) : xv ? (size_t)t->d.depth * k_cross_vw_x2_khat_floats(B) * 2 : 0);
     g.vwt = c.take<bf16_t>(xf ? (size_t)t->d.depth * k_cross_fold_vwt_elems(B) : xv ? (size_t)t->d.depth * k_cross_vw_x2_vwt_halves(B) : 0);
-    g.wqf = c.take<bf16_t>(xf ? (size_t)t->d.depth * k_cross_fold_wqf_elems() : 0);
-    if (!xf && !xv) { g.khat = nullptr; g.vwt = nullptr; }
-    if (!xf) g.wqf = nullptr;
+    g.wqf = c.take<bf16_t>(xf ? (size_t)t->d.depth * k_cross_fold_wqf_elems() : xv ? (size_t)t->d.depth * k_cross_vw_x2_wqf_halves() : 0);
+    if (!xf && !xv) { g.khat = nullptr; g.vwt = nullptr; g.wqf = nullptr; }
     g.cvec = c.take<float>((size_t)t->d.depth * D);
     g.nullv = c.take<bf16_t>((size_t)I * seg + 64);
     g.rows = c.take<int32_t>((size_t)B * n);
@@ -1024,6 +1035,7 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
         } else if (g.khat && cross_vw_on(t, w, m)) {
             RC(k_cross_vw_x2_pack(s, reinterpret_cast<const float*>(ckv_l), B, m, I, w.null_k, w.null_v, w.k_scale, (const bf16_t*)w.w_out, KI, PT, t->alpha,
                                   reinterpret_cast<float*>(g.khat) + (size_t)l * k_cross_vw_x2_khat_floats(B), g.vwt + (size_t)l * k_cross_vw_x2_vwt_halves(B)));
+            RC(k_cross_vw_x2_wq_pack(s, (const bf16_t*)w.w_q, KD, PT, g.wqf + (size_t)l * k_cross_vw_x2_wqf_halves()));
         }
         if (nc == 0 && P == 2) {
             // softmax over the single unmasked (null) key is exactly 1 -> attention out = bf16(null_v) for every
@@ -1112,7 +1124,7 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
             const bool xf = g.khat && cross_fold_on(t, w.cross_attn, m);
             const bool xv = !xf && g.khat && cross_vw_on(t, w.cross_attn, m);
             const CrossFoldPack pk_l = xv ? CrossFoldPack{reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(g.khat) + (size_t)l * k_cross_vw_x2_khat_floats(B)),
-                                                          g.vwt + (size_t)l * k_cross_vw_x2_vwt_halves(B), nullptr, true}
+                                                          g.vwt + (size_t)l * k_cross_vw_x2_vwt_halves(B), g.wqf + (size_t)l * k_cross_vw_x2_wqf_halves(), true}
                                           : CrossFoldPack{g.khat + (size_t)l * k_cross_fold_khat_elems(B), g.vwt + (size_t)l * k_cross_fold_vwt_elems(B),
                                                           g.wqf + (size_t)l * k_cross_fold_wqf_elems()};
             const CrossFoldPack* pkp = (xf || xv) ? &pk_l : nullptr;

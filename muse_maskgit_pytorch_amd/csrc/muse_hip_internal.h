@@ -198,7 +198,14 @@ struct CrossVwArgs {
     float* x; long ldx;                          // fp32 residual stream [seqs * nq][ldx], updated in place
     int seqs, nq, m, kv_batch_mod;
     float scale;                                 // 8
+    // QP form (wqf != NULL): the block's LayerNorm and q projection run inside the kernel, q / ldq unused
+    const bf16_t* wqf;                           // k_cross_vw_x2_wq_pack: the q weight's term planes as fragments [2][8 heads][4][16][64][8] fp16 (plane 1 read iff wq_terms == 3)
+    int wq_terms;                                // 2: single fp16 weight terms (a bf16-representable checkpoint), 3: [wh | wh | wl]
+    float alpha;                                 // inverse of the weight terms' power-of-two scale (mm_transformer::alpha)
+    const float* ln_gamma; const float* ln_beta; // [512] the cross-attention's LayerNorm (beta may be NULL)
 };
+size_t k_cross_vw_x2_wqf_halves();
+int k_cross_vw_x2_wq_pack(hipStream_t s, const bf16_t* w_q, int ldw, int terms, bf16_t* wqf);
 bool k_cross_vw_x2_eligible(int D, int I, int H, int dh, int m);
 size_t k_cross_vw_x2_khat_floats(int kv_seqs);
 size_t k_cross_vw_x2_vwt_halves(int kv_seqs);
