@@ -175,10 +175,14 @@ struct Carver {
         if (_rc) return _rc; \
     } while (0)
 
+// add_row (with resid, fp32 out): a row vector added to rows >= add_row_from behind the residual, (acc + resid) + add_row -- the precision tier's null half takes its
+// constant cross-attention row here (round 6), as the bf16 engine's fold producer does
 int gemm_dense(const mm_transformer* t, hipStream_t s, const bf16_t* X, int ldx, const bf16_t* W, int ldw, int M, int N, int K, void* out, long ldc,
-               int out_kind, const float* resid) {
+               int out_kind, const float* resid, const float* add_row = nullptr, int add_row_from = 0) {
     GemmArgs a;
     memset(&a, 0, sizeof(a));
+    if (add_row && resid && out_kind == OUT_F32 && (N % 4) == 0) { a.add_row = add_row; a.add_row_from = add_row_from; }
+    else if (add_row) return mm_set_error(MM_ERR_UNSUPPORTED, "gemm_dense: add_row rides on the fp32-residual epilogue");
     a.mode = MODE_DENSE;
     a.f16 = t->F16; a.alpha = t->alpha;      // 'f16x2' tier: fp16 term operands (every GEMM of such a model)
     a.terms = t->F16 ? t->P : 0;             // ... as equal-length term segments: gemm_terms.hip stages every term plane once where its shape class applies
@@ -454,7 +458,7 @@ int self_attn_block(const mm_transformer* t, hipStream_t s, const mm_attn_weight
     const int KI = (t->P ? t->P : 1) * t->I;      // precision tier: P segments per operand row
     if (t->F8) RC(f8_linear_bf16(s, b, b.att, t->I, t->I, w.w_out, w.w_out_scale, seqs * n, t->d.dim, b.x, t->d.dim, 2, b.x));
     else if (fold_out) RC(gemm_resid(t, s, b.att, KI, (const bf16_t*)w.w_out, KI, seqs * n, t->d.dim, KI, b.x, b, true, add_row, add_row_from));
-    else RC(gemm_dense(t, s, b.att, KI, (const bf16_t*)w.w_out, KI, seqs * n, t->d.dim, KI, b.x, t->d.dim, OUT_F32, b.x));
+    else RC(gemm_dense(t, s, b.att, KI, (const bf16_t*)w.w_out, KI, seqs * n, t->d.dim, KI, b.x, t->d.dim, OUT_F32, b.x, add_row, add_row_from));
     TR(b.x, (size_t)seqs * n * t->d.dim * 4);
     return MM_OK;
 }
@@ -1121,6 +1125,9 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
             const bool fold_l = fold && l > 0;
             const bool null_const = P == 2 && nc == 0;
             const float* cvec_l = g.cvec + (size_t)l * D;
+            // precision tier (round 6): the null half's constant cross-attention row goes in with the self-attention's output projection as well ((acc + x) + c: the same two
+            // roundings as the feed-forward LayerNorm's in-place add it replaces -- that pass then neither adds nor writes x back); layer 0 of a shared first layer keeps the add
+            const bool early_c = (fold_l || (PT && !(g_mm_debug2 & 256) && !(l == 0 && share0))) && null_const;
             const bool xf = g.khat && cross_fold_on(t, w.cross_attn, m);
             const bool xv = !xf && g.khat && cross_vw_on(t, w.cross_attn, m);
             const CrossFoldPack pk_l = xv ? CrossFoldPack{reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(g.khat) + (size_t)l * k_cross_vw_x2_khat_floats(B)),
@@ -1142,7 +1149,7 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
                 bc.x = g.xc; bc.att = g.attc;
                 if (t->F8) RC(f8_linear_bf16(s, b, g.attc, I, I, w.self_attn.w_out, w.self_attn.w_out_scale, P * R, D, g.xc, D, 2, g.xc));
                 else if (fold) RC(gemm_resid(t, s, g.attc, KI, (const bf16_t*)w.self_attn.w_out, KI, P * R, D, KI, g.xc, bc, true, (fold_l && null_const) ? cvec_l : nullptr, R));
-                else RC(gemm_dense(t, s, g.attc, KI, (const bf16_t*)w.self_attn.w_out, KI, P * R, D, KI, g.xc, D, OUT_F32, g.xc));
+                else RC(gemm_dense(t, s, g.attc, KI, (const bf16_t*)w.self_attn.w_out, KI, P * R, D, KI, g.xc, D, OUT_F32, g.xc, (PT && early_c) ? cvec_l : nullptr, R));
             } else if (l == 0 && share0) {
                 RC(self_attn_block(t, s, w.self_attn, B, n, b, false, fold));
                 hipError_t e = hipMemcpyAsync(b.x + (size_t)M * D, b.x, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s);
@@ -1153,11 +1160,12 @@ int mm_generate(const mm_transformer_t* t, mm_stream_t stream, const mm_generate
                 }
                 if (e != hipSuccess) return mm_set_hip_error(e, "generate: x copy");
             } else {
-                RC(self_attn_block(t, s, w.self_attn, seqs, n, b, fold_l, fold, (fold_l && null_const) ? cvec_l : nullptr, M));
+                RC(self_attn_block(t, s, w.self_attn, seqs, n, b, fold_l, fold, early_c ? cvec_l : nullptr, M));
             }
             if (null_const) {
                 RC(cross_attn_block(t, s, w.cross_attn, B, nq, ckv_l, m, 0, g.masks, bc, fold, fold_l, pkp));
                 if (fold_l) RC(ff_block(t, s, w.ff, bc.x, bc.x, 2 * Mq, bc, nullptr, 0, true, l + 1 < t->d.depth));      // (the constant row went in with the output projection above)
+                else if (early_c) RC(ff_block(t, s, w.ff, bc.x, bc.x, 2 * Mq, bc, nullptr, 0, false, false));             // (tier: likewise)
                 else RC(ff_block(t, s, w.ff, bc.x, bc.x, 2 * Mq, bc, cvec_l, Mq, false, fold && l + 1 < t->d.depth));      // null rows += to_out(null_v) (the constant cross-attention)
             } else {
                 RC(cross_attn_block(t, s, w.cross_attn, seqs, nq, ckv_l, m, P == 2 ? B : 0, g.masks, bc, fold, fold_l, pkp));
