@@ -339,10 +339,12 @@ def test_attend_seam_against_reference_golden(golden):
 
 
 @pytest.mark.parametrize('n,j,masked', [(64, 64, False), (256, 256, False), (256, 37, True), (100, 300, True), (16, 1, False),
-                                        (256, 192, False), (200, 128, False), (512, 256, False), (130, 129, False)])
+                                        (256, 192, False), (200, 128, False), (512, 256, False), (130, 129, False),
+                                        (1024, 1024, False), (300, 384, False), (256, 512, False), (700, 640, False), (1024, 384, True)])
 def test_attention_fused_norm_null(n, j, masked):
     """mmp.py:143-159 fused: l2norm + scales + null kv + key mask, strided q/k/v straight from projection buffers.
-    j in {128, 192, 256} without a key mask and n >= 128 take the all-keys-resident kernel (attention_full_kernel)."""
+    j in {128, 192, 256} without a key mask and n >= 128 take the all-keys-resident kernel (attention_full_kernel); everything else -- the 1024-token
+    self-attention of the super-resolution config included (round 6 added the long cases) -- the 64-key tile kernel with its online softmax."""
     g = torch.Generator().manual_seed(n * 3 + j)
     b, h = 2, 8
     q = r16(rnd(b, n, h * 64, gen=g))
