@@ -191,6 +191,15 @@ int mm_vq_gather(mm_stream_t stream, const int64_t* ids, int64_t N, int C, const
 int mm_gemm_wgrad_splits(int M, int N, int K);
 int mm_gemm_wgrad(mm_stream_t stream, const void* x, int64_t ldx, const void* w, int64_t ldw, int M, int N, int K, int splits,
                   float* ws, float* out);
+/* The same weight gradient WITHOUT transposed copies (round 6, csrc/gemm_tn.hip): dW fp32 [N][K] = dY^T X for row-major bf16 dY [rows][ldy] (first N columns) and
+ * X [rows][ldx] (first K columns) -- the operands are read as they are (LDS-DMA + transposing LDS reads), rows need not be a multiple of anything.  N and K
+ * multiples of 128 (MM_ERR_UNSUPPORTED otherwise: transpose and use mm_gemm_wgrad).  ws: mm_gemm_wgrad_tn_splits(rows, N, K) x N x K floats when that is > 1
+ * (split over the rows, slabs summed in a fixed order).  Deterministic; a different summation order from mm_gemm_wgrad. */
+int mm_gemm_wgrad_tn_splits(int rows, int N, int K);
+/* 1 where mm_train_step takes this form instead of transposed copies + mm_gemm_wgrad (the small projections and the head: measured, csrc/gemm_tn.hip); a driver that
+ * wants the step's bits follows it (training.py does). */
+int mm_gemm_wgrad_tn_prefer(int rows, int N, int K, int64_t ldy, int64_t ldx);
+int mm_gemm_wgrad_tn(mm_stream_t stream, const void* dy, int64_t ldy, const void* x, int64_t ldx, int rows, int N, int K, float* ws, float* out);
 /* out[c][r] = in[r][c]; bf16, strides in elements (multiples of 8). */
 int mm_transpose_bf16(mm_stream_t stream, const void* in, int64_t rows, int64_t cols, int64_t ld_in, void* out, int64_t ld_out);
 /* out[i] = bf16(x[i]). */
@@ -678,7 +687,7 @@ int mm_debug_set(int flags);
 /* second word (round 5): 1 = the term-sharing GEMM of the 'f16x2' tier (csrc/gemm_terms.hip) whatever the tile count (tests run small batches through the
  * production kernels with it), 2 = term sharing off (A/B), 4 (round 6; was the environment variable MM_TRAIN_SIDE=0) = mm_train_step without its side stream (A/B),
  * 8 / 16 / 32 = the VAE decode's 256 x 256 convolution tile / fused head / parity-batched ConvTranspose off (A/B), 64 = the 'f16x2' tier's cross-attention as
- * separate attention + output projection launches instead of csrc/cross_vw_x2.hip, 128 = that kernel without its in-kernel LayerNorm + q projection, 256 = the tier's null-half constant row in the feed-forward's LayerNorm pass (A/B, tests).
+ * separate attention + output projection launches instead of csrc/cross_vw_x2.hip, 128 = that kernel without its in-kernel LayerNorm + q projection, 256 = the tier's null-half constant row in the feed-forward's LayerNorm pass, 1024 = csrc/gemm_tn.hip off in mm_train_step (A/B, tests).
  * The library reads NO environment variable: every switch is an explicit call. */
 int mm_debug_set2(int flags);
 /* Race / determinism screen (tools/determinism_stress.py, tests): with a device buffer registered (NULL = off) every

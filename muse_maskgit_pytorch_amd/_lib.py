@@ -119,6 +119,9 @@ SIGNATURES = {
     'mm_vq_gather': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp]),
     'mm_gemm_wgrad_splits': (c_int, [c_int, c_int, c_int]),
     'mm_gemm_wgrad': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    'mm_gemm_wgrad_tn_splits': (c_int, [c_int, c_int, c_int]),
+    'mm_gemm_wgrad_tn_prefer': (c_int, [c_int, c_int, c_int, c_i64, c_i64]),
+    'mm_gemm_wgrad_tn': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp]),
     'mm_transpose_bf16': (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64]),
     'mm_f32_to_bf16': (c_int, [c_vp, c_vp, c_vp, c_i64]),
     'mm_colsum_f32': (c_int, [c_vp, c_vp, c_int, c_int, c_vp]),

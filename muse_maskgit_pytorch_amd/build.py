@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libmuse_hip.so')
-SOURCES = ['gemm.hip', 'gemm_big.hip', 'gemm_pers.hip', 'gemm_cfg.hip', 'gemm_wide.hip', 'gemm_wide_conv.hip', 'gemm_terms.hip', 'gemm_fp8.hip', 'fp8_act.hip', 'attention.hip', 'cross_fold.hip', 'cross_vw_x2.hip', 'attention_bwd.hip', 'train.hip', 'train_step.hip', 'train_prep.hip', 'norm_act.hip', 'sampling.hip', 'sampling_fused.hip', 'vae.hip', 'vq.hip', 'parity.hip', 'split.hip', 'attention_f32.hip', 'attention_x2.hip', 'vae_model.hip', 'model.hip', 'comm.hip', 'api.hip']
+SOURCES = ['gemm.hip', 'gemm_big.hip', 'gemm_pers.hip', 'gemm_cfg.hip', 'gemm_wide.hip', 'gemm_wide_conv.hip', 'gemm_terms.hip', 'gemm_fp8.hip', 'gemm_tn.hip', 'fp8_act.hip', 'attention.hip', 'cross_fold.hip', 'cross_vw_x2.hip', 'attention_bwd.hip', 'train.hip', 'train_step.hip', 'train_prep.hip', 'norm_act.hip', 'sampling.hip', 'sampling_fused.hip', 'vae.hip', 'vq.hip', 'parity.hip', 'split.hip', 'attention_f32.hip', 'attention_x2.hip', 'vae_model.hip', 'model.hip', 'comm.hip', 'api.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
          '-fno-fast-math', '-ffp-contract=off']
 

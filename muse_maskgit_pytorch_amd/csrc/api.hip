@@ -363,6 +363,21 @@ int mm_gemm_wgrad(mm_stream_t stream, const void* x, int64_t ldx, const void* w,
     return k_colsum((hipStream_t)stream, ws, splits, (long)M * N, out);
 }
 
+int mm_gemm_wgrad_tn_splits(int rows, int N, int K) { return k_gemm_tn_splits(rows, N, K); }
+int mm_gemm_wgrad_tn_prefer(int rows, int N, int K, int64_t ldy, int64_t ldx) { return k_gemm_tn_prefer(rows, N, K, ldy, ldx) ? 1 : 0; }
+
+int mm_gemm_wgrad_tn(mm_stream_t stream, const void* dy, int64_t ldy, const void* x, int64_t ldx, int rows, int N, int K, float* ws, float* out) {
+    if (rows == 0 || N == 0 || K == 0) return MM_OK;
+    CHK_PTR(dy, "dy"); CHK_PTR(x, "x"); CHK_PTR(out, "out"); CHK_ALIGN16(dy, "dy"); CHK_ALIGN16(x, "x"); CHK_ALIGN16(out, "out");
+    if (!k_gemm_tn_eligible(rows, N, K, ldy, ldx)) return mm_set_error(MM_ERR_UNSUPPORTED, "gemm_wgrad_tn: N and K must be multiples of 128 (use the transposed-copy form)");
+    const int splits = k_gemm_tn_splits(rows, N, K);
+    if (splits <= 1) return k_gemm_tn((hipStream_t)stream, (const bf16_t*)dy, ldy, (const bf16_t*)x, ldx, rows, N, K, 1, out);
+    CHK_PTR(ws, "ws"); CHK_ALIGN16(ws, "ws");
+    const int rc = k_gemm_tn((hipStream_t)stream, (const bf16_t*)dy, ldy, (const bf16_t*)x, ldx, rows, N, K, splits, ws);
+    if (rc) return rc;
+    return k_colsum((hipStream_t)stream, ws, splits, (long)N * K, out);
+}
+
 int mm_transpose_bf16(mm_stream_t stream, const void* in, int64_t rows, int64_t cols, int64_t ld_in, void* out, int64_t ld_out) {
     if (rows == 0 || cols == 0) return MM_OK;
     CHK_PTR(in, "in"); CHK_PTR(out, "out"); CHK_ALIGN16(in, "in"); CHK_ALIGN16(out, "out");

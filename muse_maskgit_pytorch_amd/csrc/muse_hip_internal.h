@@ -73,7 +73,7 @@ struct GemmArgs {
     const float* in_part; int in_np; int in_F; const float* in_c1; const float* in_c2;
 };
 extern int g_mm_debug;
-extern int g_mm_debug2;      // mm_debug_set2 (round 5): 1 = gemm_terms.hip whatever the tile count (tests: small batches through the production kernels), 2 = gemm_terms.hip and every term-sharing k-loop off (A/B), 4 = mm_train_step on the caller's stream only (A/B), 8 = gemm_wide_conv.hip off (A/B: convolutions on the 256 x 128 kernel), 16 = the VAE head not fused into the last up-sampling convolution (A/B), 32 = a ConvTranspose2d's parity classes as four launches (A/B), 64 = the 'f16x2' tier's cross-attention as attention + output projection launches instead of cross_vw_x2.hip (A/B, tests), 128 = cross_vw_x2.hip behind LayerNorm-split + q GEMM launches (A/B, tests), 256 = the tier's null-half constant cross-attention row added by the feed-forward's LayerNorm-split pass instead of the self-attention's output projection (A/B)
+extern int g_mm_debug2;      // mm_debug_set2 (round 5): 1 = gemm_terms.hip whatever the tile count (tests: small batches through the production kernels), 2 = gemm_terms.hip and every term-sharing k-loop off (A/B), 4 = mm_train_step on the caller's stream only (A/B), 8 = gemm_wide_conv.hip off (A/B: convolutions on the 256 x 128 kernel), 16 = the VAE head not fused into the last up-sampling convolution (A/B), 32 = a ConvTranspose2d's parity classes as four launches (A/B), 64 = the 'f16x2' tier's cross-attention as attention + output projection launches instead of cross_vw_x2.hip (A/B, tests), 128 = cross_vw_x2.hip behind LayerNorm-split + q GEMM launches (A/B, tests), 256 = the tier's null-half constant cross-attention row added by the feed-forward's LayerNorm-split pass instead of the self-attention's output projection (A/B), 1024 = the training step's weight gradients all through transposed copies (gemm_tn.hip off; A/B)
 
 int mm_gemm_launch(GemmArgs a, hipStream_t stream);
 bool mm_gemm_big_eligible(const GemmArgs& a);
@@ -238,6 +238,12 @@ struct PrepList {
     void add(const float* src, void* dst, bf16_t* dst_t, int rows, int cols, int rows_p, int cols_p, int ld_d, int ld_t, int kind = 0);
     int flush();           // launches what has been added (a full table is launched by add()); returns the first error of the list
 };
+
+// gemm_tn.hip: dW [N][K] fp32 = dY^T X for row-major dY [rows][lda], X [rows][ldb] (no transposed copies: transposing LDS reads); splits > 1: one slab per split
+bool k_gemm_tn_eligible(int rows, int N, int K, long lda, long ldb);
+int k_gemm_tn_splits(int rows, int N, int K);
+bool k_gemm_tn_prefer(int rows, int N, int K, long lda, long ldb);      // the training step's rule: this kernel instead of transposed copies + the NT GEMM
+int k_gemm_tn(hipStream_t s, const bf16_t* A, long lda, const bf16_t* B, long ldb, int rows, int N, int K, int splits, float* out_or_slabs);
 
 // train.hip / attention_bwd.hip: backward operators
 int k_transpose_bf16(hipStream_t s, const bf16_t* in, long rows, long cols, long ldi, bf16_t* out, long ldo, int zero_pad64 = 0);   // zero_pad64: also write zeros up to rows rounded to 64 (needs ldo >= that)

@@ -118,6 +118,10 @@ void carve(Arena& A, const mm_train_desc& d, const Dims& q, Bufs& b, LayerBufs* 
     b.gtmp = A.take<float>(gmax);
     // split-K slabs of the dW GEMMs: splits x N_ x K_ floats, the largest over the shapes wgrad() is called with below
     auto slabs = [](long N_, long K_, long rows) -> size_t {
+        if (k_gemm_tn_prefer((int)rows, (int)N_, (int)K_, N_, K_)) {      // (the rule looks at sizes only for dense rows; strides of the step's operands are multiples of 8)
+            const int st_ = k_gemm_tn_splits((int)rows, (int)N_, (int)K_);
+            return st_ > 1 ? (size_t)st_ * N_ * K_ : 0;
+        }
         const int s_ = (K_ % 4 == 0) ? mm_gemm_wgrad_splits((int)N_, (int)K_, pad64((int)rows)) : 1;
         return s_ > 1 ? (size_t)s_ * N_ * K_ : 0;
     };
@@ -154,6 +158,12 @@ int tr64(mm_stream_t st, hipStream_t s, const bf16_t* x, long rows, long cols, l
 // dW fp32 [N_][K_] = dY^T X for dY bf16 [rows][N_] (ld ldy), X bf16 [rows][K_] (ld ldx)   (training.py _wgrad)
 // xt: the transposed activation [K_][Rp] when the side stream has already made it (else nullptr: made here into tB)
 int wgrad(mm_stream_t st, hipStream_t s, const Bufs& b, const bf16_t* dy, long ldy, int N_, const bf16_t* x, long ldx, int K_, long rows, float* out, const bf16_t* xt = nullptr) {
+    if (k_gemm_tn_prefer((int)rows, N_, K_, ldy, ldx)) {      // round 6: the operands as they are (gemm_tn.hip) -- no transposed copy of dy (nor of x: the caller skipped it)
+        const int sp = k_gemm_tn_splits((int)rows, N_, K_);
+        if (sp <= 1) return k_gemm_tn(s, dy, ldy, x, ldx, (int)rows, N_, K_, 1, out);
+        RC(k_gemm_tn(s, dy, ldy, x, ldx, (int)rows, N_, K_, sp, b.wg_ws));
+        return k_colsum(s, b.wg_ws, sp, (long)N_ * K_, out);
+    }
     RC(tr64(st, s, dy, rows, N_, ldy, b.tA));
     if (!xt) RC(tr64(st, s, x, rows, K_, ldx, b.tB));
     const bf16_t* tB = xt ? xt : b.tB;
@@ -340,16 +350,17 @@ int mm_train_step(const mm_train_desc* desc, mm_stream_t stream, const int64_t* 
         // ---- side stream, part 2: this layer's saved activations transposed for the dW GEMMs of the backward
         RC(mark(sd, s, &e_a[l]));
         RC(await(s2, e_a[l]));
+        // (round 6: a dW that reads its operands as they are -- gemm_tn.hip, wgrad() asks the same rule -- needs no transposed activation)
         if (l == 0) {
-            RC(tr64(stream2, s2, b.cx, Mc, D, D, b.tcx));
+            if (!k_gemm_tn_prefer(Mc, 2 * I, D, 2 * I, D)) RC(tr64(stream2, s2, b.cx, Mc, D, D, b.tcx));
             RC(mark(sd, s2, &e_tcx));
         }
-        RC(tr64(stream2, s2, y.z, M, Fp, Fp, y.tz));
-        RC(tr64(stream2, s2, y.u3, M, D, D, y.tu3));
-        RC(tr64(stream2, s2, y.o2, M, I, I, y.to2));
-        RC(tr64(stream2, s2, y.u2, M, D, D, y.tu2));
-        RC(tr64(stream2, s2, y.o, M, I, I, y.to));
-        RC(tr64(stream2, s2, y.u, M, D, D, y.tu));
+        if (!k_gemm_tn_prefer(M, D, Fp, D, Fp)) RC(tr64(stream2, s2, y.z, M, Fp, Fp, y.tz));
+        if (!k_gemm_tn_prefer(M, 2 * Fp, D, 2 * Fp, D)) RC(tr64(stream2, s2, y.u3, M, D, D, y.tu3));
+        if (!k_gemm_tn_prefer(M, D, I, D, I)) RC(tr64(stream2, s2, y.o2, M, I, I, y.to2));
+        if (!k_gemm_tn_prefer(M, I, D, I, D)) RC(tr64(stream2, s2, y.u2, M, D, D, y.tu2));
+        if (!k_gemm_tn_prefer(M, D, I, D, I)) RC(tr64(stream2, s2, y.o, M, I, I, y.to));
+        if (!k_gemm_tn_prefer(M, 3 * I, D, 3 * I, D)) RC(tr64(stream2, s2, y.u, M, D, D, y.tu));
         RC(mark(sd, s2, &e_ta[l]));
     }
     // ---- head on the rows that carry a label (mmp.py:330-343)

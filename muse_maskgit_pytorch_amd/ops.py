@@ -378,6 +378,20 @@ def gemm_wgrad(xt, wt):
     return out
 
 
+def gemm_wgrad_tn(dy, x):
+    """fp32 [N, K] = dy^T @ x for row-major bf16 dy [rows, N], x [rows, K] (strided rows allowed): no transposed copies (csrc/gemm_tn.hip).  N, K multiples of 128."""
+    _chk_cuda(dy, x)
+    rows, N = dy.shape
+    K = x.shape[1]
+    assert x.shape[0] == rows and dy.dtype == bf16 and x.dtype == bf16 and dy.stride(1) == 1 and x.stride(1) == 1
+    lib = L.lib()
+    splits = lib.mm_gemm_wgrad_tn_splits(rows, N, K)
+    ws = torch.empty(splits, N, K, dtype=torch.float32, device=dy.device) if splits > 1 else None
+    out = torch.empty(N, K, dtype=torch.float32, device=dy.device)
+    L.check(lib.mm_gemm_wgrad_tn(L.stream(), L.ptr(dy), dy.stride(0), L.ptr(x), x.stride(0), rows, N, K, L.ptr(ws), L.ptr(out)), 'mm_gemm_wgrad_tn')
+    return out
+
+
 def to_bf16(x):
     _chk_cuda(x)
     assert x.dtype == torch.float32 and x.is_contiguous()

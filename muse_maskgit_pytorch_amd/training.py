@@ -25,7 +25,10 @@ def _t(x):
 
 
 def _wgrad(dy, x):
-    """dW [N, K] = dY^T X for dY [M, N], X [M, K] (bf16) -> fp32."""
+    """dW [N, K] = dY^T X for dY [M, N], X [M, K] (bf16) -> fp32.  Where mm_train_step reads the operands as they are (csrc/gemm_tn.hip: the small projections, the
+    head) this driver does too -- same kernel, same split count, same bits."""
+    if dy.stride(1) == 1 and x.stride(1) == 1 and ops.L.lib().mm_gemm_wgrad_tn_prefer(dy.shape[0], dy.shape[1], x.shape[1], dy.stride(0), x.stride(0)):
+        return ops.gemm_wgrad_tn(dy, x)
     return ops.gemm_wgrad(_t(dy), _t(x))
 
 

@@ -232,3 +232,20 @@ def test_split_k_on_the_256x128_tile_for_long_contractions(ops, M, N, K):
     assert torch.equal(a, b)
     ref = x.double() @ w.double().t()
     assert (a.cpu().double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize('rows,N,K', [(8192, 512, 512), (8192, 2816, 512), (8192, 512, 1408), (1024, 1024, 512), (5457, 1024, 512), (100, 128, 128), (8192, 1536, 512)])
+def test_weight_gradient_without_transposed_copies(ops, rows, N, K):
+    """round 6 (csrc/gemm_tn.hip): dW = dY^T X read straight from the row-major operands (LDS-DMA blocks + ds_read_b64_tr_b16), against the fp64 product and
+    the transposed-copy form; row counts that are no multiple of the 64-row stage, strided operand rows; twice the same bits."""
+    g = torch.Generator().manual_seed(rows + N + K)
+    dy_full = (torch.randn(rows, N + 64, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    x_full = (torch.randn(rows, K + 128, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    dy, x = dy_full[:, :N], x_full[:, 64:64 + K]                      # strided rows, the second operand at a column offset
+    a = ops.gemm_wgrad_tn(dy, x)
+    b = ops.gemm_wgrad_tn(dy, x)
+    assert torch.equal(a, b)
+    ref = dy.double().cpu().t() @ x.double().cpu()
+    assert (a.cpu().double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item() + 1e-4
+    old = ops.gemm_wgrad(ops.transpose(dy.contiguous(), pad_to=64), ops.transpose(x.contiguous(), pad_to=64))
+    assert (a - old).abs().max().item() < 2e-5 * ref.abs().max().item() + 1e-4
