@@ -121,17 +121,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
 bool k_gemm_tn_eligible(int rows, int N, int K, long lda, long ldb) {
     return rows > 0 && N > 0 && K > 0 && (N % TT) == 0 && (K % TT) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 && (size_t)rows * (size_t)(lda > ldb ? lda : ldb) * 2 < ((size_t)1 << 32);
 }
-// where the step prefers this kernel to transposed copies + the NT GEMM (measured, tools/tn_gemm_timing.py: per launch it runs at 0.2-0.6 PFLOP/s against the NT kernels'
-// 0.45-0.55 -- 32-byte row segments per DMA lane pair -- so it wins where the transposes it removes cost more than that): the small projections (22 vs 28.5 us at
-// 512 x 512 over 8192 rows, 19 vs 25 for the context's k | v) and the head (617 vs 877 us: the vocabulary-wide dl no longer crosses HBM twice more)
+// where the step prefers this kernel to transposed copies + the NT GEMM (measured, tools/tn_gemm_timing.py, us per launch incl. the slab sum; NT + the dY transpose
+// the step pays): 512 x 512 over 8192 rows 21.5 vs 28.5, the context's k | v 15-17 vs 25, q|k|v 36 vs 41.5, w1 59 vs 62, the head 617 vs 877 (the vocabulary-wide dl
+// no longer crosses HBM twice more) -- and w2 (K = 1408) 38 vs 37.6: a tie that keeps its transposes.  Per launch this kernel runs at 0.2-0.6 PFLOP/s against the NT
+// kernels' 0.45-0.9: ablations (plain instead of transposing LDS reads: no change; no stores: -3 %; no loads after the first stage: -50 %) put the difference on the
+// global -> LDS feed (every n-tile streams the whole second operand again, and a dY row is a 256-byte segment at a stride of the full row), not on the tr reads.
 bool k_gemm_tn_prefer(int rows, int N, int K, long lda, long ldb) {
+    // (taking q|k|v and w1 as well -- every shape with K <= 512 -- measured 11.49 vs 11.50 ms per step: their launches win in isolation but load the memory system
+    //  beside the dependent chain; the small projections + the head alone: 11.32 vs 11.47)
     return !(g_mm_debug2 & 1024) && k_gemm_tn_eligible(rows, N, K, lda, ldb) && ((N <= 1024 && K <= 512 && (long)N * K <= 512 * 1024) || N >= 8192);      // (bit 1024: A/B)
 }
-// split count: enough workgroups for two per CU, at least 512 rows per split, splits of whole 64-row stages
+// split count: one workgroup per CU at least, at least 512 rows per split, splits of whole 64-row stages
 int k_gemm_tn_splits(int rows, int N, int K) {
     const long tiles = (long)(N / TT) * (K / TT);
     int s = 1;
-    while (tiles * s < 512 && rows / (s * 2) >= 512) s *= 2;
+    while (tiles * s < 256 && rows / (s * 2) >= 512) s *= 2;      // (512: twice the slabs for the column sum to read -- 62 / 44 / 43 us instead of 59 / 38 / 36 at the w1 / w2 / q|k|v shapes)
     return s;
 }
 int k_gemm_tn(hipStream_t s, const bf16_t* A, long lda, const bf16_t* B, long ldb, int rows, int N, int K, int splits, float* out_or_slabs) {
