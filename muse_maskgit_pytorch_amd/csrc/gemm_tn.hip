@@ -125,7 +125,9 @@ bool k_gemm_tn_eligible(int rows, int N, int K, long lda, long ldb) {
 // the step pays): 512 x 512 over 8192 rows 21.5 vs 28.5, the context's k | v 15-17 vs 25, q|k|v 36 vs 41.5, w1 59 vs 62, the head 617 vs 877 (the vocabulary-wide dl
 // no longer crosses HBM twice more) -- and w2 (K = 1408) 38 vs 37.6: a tie that keeps its transposes.  Per launch this kernel runs at 0.2-0.6 PFLOP/s against the NT
 // kernels' 0.45-0.9: ablations (plain instead of transposing LDS reads: no change; no stores: -3 %; no loads after the first stage: -50 %) put the difference on the
-// global -> LDS feed (every n-tile streams the whole second operand again, and a dY row is a 256-byte segment at a stride of the full row), not on the tr reads.
+// global -> LDS feed, not on the tr reads: at the head's shape the 2048 workgroups of 128 x 128 tiles pull 5.7 GB through L2 -> LDS in 616 us = 9.3 TB/s, the same
+// rate the 256 x 128 NT kernel reaches on 4.3 GB (406 us) -- the tile's 64 flop per staged byte is the limit.  A 256 x 128 tile (512 threads, three stages: 681 us) and a
+// four-deep ring of 32-row stages (702 us) measured no better: with one workgroup per CU / half the MFMAs per barrier the waits are exposed instead.
 bool k_gemm_tn_prefer(int rows, int N, int K, long lda, long ldb) {
     // (taking q|k|v and w1 as well -- every shape with K <= 512 -- measured 11.49 vs 11.50 ms per step: their launches win in isolation but load the memory system
     //  beside the dependent chain; the small projections + the head alone: 11.32 vs 11.47)
