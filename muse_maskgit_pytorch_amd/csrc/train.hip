@@ -393,6 +393,62 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
     }
 }
 
+// The same gradient with the row held in REGISTERS between the two sweeps (round 6): 1024 threads x 16 float4 = a whole row of up to 65536 logits.  The kernel above reads
+// every row twice -- "L2-resident" was wrong at the training head's size: 512 rows of 256 KiB are in flight at once, so the second sweep came from HBM again (2.9 GB read
+// + 0.72 GB written per step, 0.72-0.75 ms on the backward's dependent chain).  One read: 2.2 GB.  Per-thread online (max, sum) over its own 64 values, then a fixed-order
+// combine over the 16 waves -- a different association of the softmax denominator from the kernel above (both deterministic; the driver and mm_train_step share this one).
+// The 131072 exponentials of a row are the hardware exp2 of x log2 e (~1e-6 relative: the gradient leaves as bf16, the loss as M + log S): with libm's expf the kernel
+// was bound by them (584 us against 723 for two sweeps), not by its 2.2 GB.
+__global__ __launch_bounds__(1024) void ce_bwd_row_kernel(const float* __restrict__ logits, long ld, int V, const int64_t* __restrict__ labels,
+                                                          float scale, bf16_t* __restrict__ dl, long ldd, float* __restrict__ row_loss) {
+    __shared__ float sm[16], ss[16];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float* lr = logits + (size_t)row * ld;
+    const int nv = V >> 2;                      // float4 chunks of the row (<= 16384)
+    float4 x[16];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int c = tid + j * 1024;
+        x[j] = c < nv ? *reinterpret_cast<const float4*>(lr + (size_t)c * 4) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        m = fmaxf(m, fmaxf(fmaxf(x[j].x, x[j].y), fmaxf(x[j].z, x[j].w)));
+    }
+    float s = 0.f;
+    if (m > -INFINITY) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += (__expf(x[j].x - m) + __expf(x[j].y - m)) + (__expf(x[j].z - m) + __expf(x[j].w - m));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o, 64), os = __shfl_xor(s, o, 64);
+        const float nm = fmaxf(m, om);
+        s = (nm == -INFINITY) ? 0.f : s * expf(m - nm) + os * expf(om - nm);
+        m = nm;
+    }
+    if (lane == 0) { sm[wid] = m; ss[wid] = s; }
+    __syncthreads();
+    float M = sm[0], S = ss[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) {
+        const float nm = fmaxf(M, sm[w]);
+        S = (nm == -INFINITY) ? 0.f : S * expf(M - nm) + ss[w] * expf(sm[w] - nm);
+        M = nm;
+    }
+    const float inv = scale / S;
+    const int lab = (int)labels[row];
+    if (row_loss && tid == 0) row_loss[row] = (lab >= 0 && lab < V) ? (M + logf(S)) - lr[lab] : -1.f;      // (-1: no valid label, ce_finish_kernel skips the row)
+    bf16_t* dr = dl + (size_t)row * ldd;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int c = tid + j * 1024;
+        if (c >= nv) continue;
+        const int i = c * 4;
+        float p0 = __expf(x[j].x - M) * inv, p1 = __expf(x[j].y - M) * inv, p2 = __expf(x[j].z - M) * inv, p3 = __expf(x[j].w - M) * inv;
+        if (lab == i) p0 -= scale; else if (lab == i + 1) p1 -= scale; else if (lab == i + 2) p2 -= scale; else if (lab == i + 3) p3 -= scale;
+        *reinterpret_cast<uint2*>(dr + i) = make_uint2(pack_bf16x2(p0, p1), pack_bf16x2(p2, p3));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ embedding backward
 // x[b*n + p] = token_emb[ids] + pos_emb[p]  ->  dpos[p] = sum_b dx[b*n + p], dtoken[id] += sum over the rows that carry id.  Both sums run in
 // a FIXED order (ascending row index), so the whole backward pass is bit-reproducible: many rows share an id (the mask id covers half the
@@ -661,6 +717,10 @@ int k_geglu_ln_bwd(hipStream_t s, const bf16_t* h, long ldh, const bf16_t* dz, l
 int k_ce_bwd(hipStream_t s, const float* logits, long ld, int R, int V, const int64_t* labels, float scale, bf16_t* dl, long ldd, float* row_loss) {
     if (R <= 0) return MM_OK;
     if (V % 4 || (ld % 4) || (ldd % 4)) return mm_set_error(MM_ERR_SHAPE, "ce_bwd: V and strides must be multiples of 4");
+    if (V > 16384 && V <= 65536 && !(g_mm_debug2 & 4096)) {      // a long row: held in registers, read once (bit 4096: the two-sweep kernel, A/B)
+        hipLaunchKernelGGL(ce_bwd_row_kernel, dim3(R), dim3(1024), 0, s, logits, ld, V, labels, scale, dl, ldd, row_loss);
+        return mm_check_launch("ce_bwd_row_kernel");
+    }
     hipLaunchKernelGGL(ce_bwd_kernel, dim3(R), dim3(256), 0, s, logits, ld, V, labels, scale, dl, ldd, row_loss);
     return mm_check_launch("ce_bwd_kernel");
 }

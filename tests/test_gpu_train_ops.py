@@ -249,3 +249,19 @@ def test_weight_gradient_without_transposed_copies(ops, rows, N, K):
     assert (a.cpu().double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item() + 1e-4
     old = ops.gemm_wgrad(ops.transpose(dy.contiguous(), pad_to=64), ops.transpose(x.contiguous(), pad_to=64))
     assert (a - old).abs().max().item() < 2e-5 * ref.abs().max().item() + 1e-4
+
+
+@pytest.mark.parametrize('R,V', [(37, 65536), (5, 40000), (3, 16388)])
+def test_ce_bwd_on_long_rows_reads_every_row_once(ops, R, V):
+    """round 6: rows of 16388 .. 65536 logits are held in registers between the statistics and the gradient sweep (train.hip ce_bwd_row_kernel: 1024 threads x 16
+    float4) instead of being read twice; against torch's cross-entropy gradient, with labels at the row's first / last column, twice the same bits."""
+    g = torch.Generator().manual_seed(R + V)
+    logits = (torch.randn(R, V, generator=g) * 3).requires_grad_(True)
+    labels = torch.randint(0, V, (R,), generator=g)
+    labels[0], labels[-1] = 0, V - 1
+    torch.nn.functional.cross_entropy(logits, labels).backward()
+    a = ops.ce_bwd(logits.detach().to(DEV), labels.to(DEV), 1.0 / R)
+    b = ops.ce_bwd(logits.detach().to(DEV), labels.to(DEV), 1.0 / R)
+    assert torch.equal(a, b)
+    assert (a.float().cpu() - logits.grad).abs().max() < 2 ** -8 * logits.grad.abs().max()      # (bf16 output: half an ulp of the label's (p - 1) / R entry)
+    assert abs(a.float().sum(dim=1).cpu()).max() < 2 ** -7 / R          # rows of softmax - onehot sum to ~0 (bf16 rounding of 65536 entries)
