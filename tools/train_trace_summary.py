@@ -21,7 +21,7 @@ def main():
     step = ev[a:b]
     T0 = step[0][0]
     span = (ev[b][0] - T0) / 1e6
-    ce = next(s for s, d, st, n in step if 'ce_bwd_kernel' in n)
+    ce = next(s for s, d, st, n in step if 'ce_bwd' in n)
     eb = next(s + d for s, d, st, n in step if 'embed_token_bwd' in n or 'embed_bwd_token' in n)
     print(f'one training step (embed_kernel to embed_kernel): {span:.3f} ms, {len(step)} launches / copies')
     print(f'  forward 0 - {(ce - T0) / 1e6:.3f} ms, backward - {(eb - T0) / 1e6:.3f} ms, tail (gradient scale, AdamW, next step\'s masking + host + parameter preparation) - {span:.3f} ms')
