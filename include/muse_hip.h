@@ -687,7 +687,7 @@ int mm_debug_set(int flags);
 /* second word (round 5): 1 = the term-sharing GEMM of the 'f16x2' tier (csrc/gemm_terms.hip) whatever the tile count (tests run small batches through the
  * production kernels with it), 2 = term sharing off (A/B), 4 (round 6; was the environment variable MM_TRAIN_SIDE=0) = mm_train_step without its side stream (A/B),
  * 8 / 16 / 32 = the VAE decode's 256 x 256 convolution tile / fused head / parity-batched ConvTranspose off (A/B), 64 = the 'f16x2' tier's cross-attention as
- * separate attention + output projection launches instead of csrc/cross_vw_x2.hip, 128 = that kernel without its in-kernel LayerNorm + q projection, 256 = the tier's null-half constant row in the feed-forward's LayerNorm pass, 1024 = csrc/gemm_tn.hip off in mm_train_step, 4096 = the two-sweep cross-entropy backward on long rows (A/B, tests).
+ * separate attention + output projection launches instead of csrc/cross_vw_x2.hip, 128 = that kernel without its in-kernel LayerNorm + q projection, 256 = the tier's null-half constant row in the feed-forward's LayerNorm pass, 1024 = csrc/gemm_tn.hip off in mm_train_step, 4096 = the two-sweep cross-entropy backward on long rows, 8192 = the head's dW beside (not behind) its dX in mm_train_step (A/B, tests).
  * The library reads NO environment variable: every switch is an explicit call. */
 int mm_debug_set2(int flags);
 /* Race / determinism screen (tools/determinism_stress.py, tests): with a device buffer registered (NULL = off) every

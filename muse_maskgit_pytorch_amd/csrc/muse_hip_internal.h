@@ -73,7 +73,7 @@ struct GemmArgs {
     const float* in_part; int in_np; int in_F; const float* in_c1; const float* in_c2;
 };
 extern int g_mm_debug;
-extern int g_mm_debug2;      // mm_debug_set2 (round 5): 1 = gemm_terms.hip whatever the tile count (tests: small batches through the production kernels), 2 = gemm_terms.hip and every term-sharing k-loop off (A/B), 4 = mm_train_step on the caller's stream only (A/B), 8 = gemm_wide_conv.hip off (A/B: convolutions on the 256 x 128 kernel), 16 = the VAE head not fused into the last up-sampling convolution (A/B), 32 = a ConvTranspose2d's parity classes as four launches (A/B), 64 = the 'f16x2' tier's cross-attention as attention + output projection launches instead of cross_vw_x2.hip (A/B, tests), 128 = cross_vw_x2.hip behind LayerNorm-split + q GEMM launches (A/B, tests), 256 = the tier's null-half constant cross-attention row added by the feed-forward's LayerNorm-split pass instead of the self-attention's output projection (A/B), 1024 = the training step's weight gradients all through transposed copies (gemm_tn.hip off; A/B), 4096 = ce_bwd on long rows as two sweeps (A/B)
+extern int g_mm_debug2;      // mm_debug_set2 (round 5): 1 = gemm_terms.hip whatever the tile count (tests: small batches through the production kernels), 2 = gemm_terms.hip and every term-sharing k-loop off (A/B), 4 = mm_train_step on the caller's stream only (A/B), 8 = gemm_wide_conv.hip off (A/B: convolutions on the 256 x 128 kernel), 16 = the VAE head not fused into the last up-sampling convolution (A/B), 32 = a ConvTranspose2d's parity classes as four launches (A/B), 64 = the 'f16x2' tier's cross-attention as attention + output projection launches instead of cross_vw_x2.hip (A/B, tests), 128 = cross_vw_x2.hip behind LayerNorm-split + q GEMM launches (A/B, tests), 256 = the tier's null-half constant cross-attention row added by the feed-forward's LayerNorm-split pass instead of the self-attention's output projection (A/B), 1024 = the training step's weight gradients all through transposed copies (gemm_tn.hip off; A/B), 4096 = ce_bwd on long rows as two sweeps (A/B), 8192 = mm_train_step's head dW launched beside the head's dX instead of behind it (A/B)
 
 int mm_gemm_launch(GemmArgs a, hipStream_t stream);
 bool mm_gemm_big_eligible(const GemmArgs& a);

@@ -374,14 +374,23 @@ int mm_train_step(const mm_train_desc* desc, mm_stream_t stream, const int64_t* 
     HC(hipMemsetAsync(b.dres, 0, (size_t)M * D * 4, s));
     RC(k_ce_bwd(s, b.logits, V, R, V, labels_rows, 1.0f / (float)R, b.dl, V, b.rowloss));                               // mmp.py:343 and its gradient
     RC(k_ce_finish(s, b.rowloss, R, loss_out));
-    FORK();
-    RC(wgrad(stream2, s2, b, b.dl, V, V, b.e, D, D, R, d.d_to_logits));
+    // the head's dW is a leaf, but it streams the same vocabulary-wide dl as the head's dX on the caller's stream: side by side each slowed the other (dX 0.80 -> 1.12 ms once
+    // the dW no longer waited behind its transposes).  It goes out BEHIND the dX (bit 8192: at once, A/B)
+    const bool head_dw_late = !(g_mm_debug2 & 8192);
+    if (!head_dw_late) {
+        FORK();
+        RC(wgrad(stream2, s2, b, b.dl, V, V, b.e, D, D, R, d.d_to_logits));
+    }
     RC(await(s, e_twl));
     if (b.hd_splits > 1) {                                 // (training.py _dgrad_long_k)
         RC(mm_gemm_wgrad(stream, b.dl, V, b.twl, V, R, D, V, b.hd_splits, b.hd_ws, b.de32));
         RC(mm_f32_to_bf16(stream, b.de32, b.de, (int64_t)R * D));
     } else {
         RC(dgrad(stream, s, b, b.dl, V, V, b.wl, D, R, b.de, D, b.twl));
+    }
+    if (head_dw_late) {
+        FORK();
+        RC(wgrad(stream2, s2, b, b.dl, V, V, b.e, D, D, R, d.d_to_logits));
     }
     RC(mm_layernorm_bwd(stream, b.xL, D, b.de, D, d.final_gamma, row_index, R, D, b.dres, D, 0, d.d_final_gamma, b.ln_ws));
     RC(await(s, e_tcx));
