@@ -285,6 +285,10 @@ int mm_train_step(const mm_train_desc* desc, mm_stream_t stream, const int64_t* 
     // (round 6: a job table per launch -- train_prep.hip -- instead of ~190 conversions, memsets, strided copies and transposes: layer 0 first, so that the forward
     //  starts behind ONE small launch; the other layers and the head follow while it runs)
     {
+        // the zero-initialised gradient tables of the embeddings (the embedding backward at the very end accumulates into them): cleared here, ahead of everything --
+        // the caller's stream waits for e_w[0] (recorded behind this) in front of layer 0, long before it reaches the embedding backward
+        HC(hipMemsetAsync(d.d_token_emb, 0, (size_t)d.vocab_rows * D * 4, s2));
+        if (n < d.seq_len) HC(hipMemsetAsync(d.d_pos_emb, 0, (size_t)d.seq_len * D * 4, s2));
         PrepList P(s2);
         int marked = 0;
         for (int l = 0; l < q.depth; ++l) {
@@ -477,8 +481,7 @@ int mm_train_step(const mm_train_desc* desc, mm_stream_t stream, const int64_t* 
         RC(k_colsum(s2, y.lnw[2], lnb, D, w.sa.d_gamma));
     }
     // ---- embeddings / text projection
-    HC(hipMemsetAsync(d.d_token_emb, 0, (size_t)d.vocab_rows * D * 4, s));
-    if (n < d.seq_len) HC(hipMemsetAsync(d.d_pos_emb, 0, (size_t)d.seq_len * D * 4, s));
+    // (the embedding gradients' tables were zeroed on the side stream at the start of the call: 134 MB at the base size, off the dependent chain)
     RC(k_embed_bwd(s, ids, B, n, D, b.dres, d.d_token_emb, d.d_pos_emb, b.emb_ws));      // (two levels: train.hip embed_token_bwd2_kernel)
     if (d.text_proj) {
         RC(mm_f32_to_bf16(stream, b.dcx[dcx_i], b.dcxb, (int64_t)Mc * D));
